@@ -1,0 +1,170 @@
+"""Pin the CPU oracle against every known-answer / invariant test the reference holds for the hot path
+(SURVEY.md 8c).  CPU only.  Each test names the reference test it restates."""
+import math
+
+import numpy as np
+import pytest
+
+import tnqs_oracle as o
+import statevector as sv
+
+Z = np.diag([1.0, -1.0]).astype(complex)
+TIGHT = dict(maxiter=300, tolerance=1e-14)
+
+
+def tfim_layer(g, dt=0.25, hx=1.0, hz=0.8, J=0.5):
+    """layer of test/test_apply.jl:30-47"""
+    layer = [("Rx", [v], 2 * hx * dt) for v in g.vertices]
+    layer += [("Rz", [v], 2 * hz * dt) for v in g.vertices]
+    for grp in o.edge_color(g):
+        layer += [("Rzz", [a, b], 2 * J * dt) for (a, b) in grp]
+    return layer
+
+
+def test_custom_circuit_norm_and_bondcap():
+    """test/test_apply.jl:11-20: Rx,Rx,CPHASE from "down-down", maxdim=2, cutoff=1e-10, no normalisation."""
+    circuit = [("Rx", [(1, 1)], 0.5), ("Rx", [(2, 1)], 0.2), ("CPHASE", [(1, 1), (2, 1)], -0.3)]
+    g = o.Graph([(1, 1), (2, 1)], [((1, 1), (2, 1))])
+    psi0 = o.product_state(np.complex64, lambda v: "↓", g)
+    bpc = o.update(o.BeliefPropagationCache(psi0))
+    bpc, errs = o.apply_gates(circuit, bpc, apply_kwargs=dict(maxdim=2, cutoff=1e-10, normalize_tensors=False))
+    assert bpc.tns.dtype == np.complex64
+    assert bpc.tns.maxvirtualdim() <= 2
+    vec = sv.tns_to_statevector(bpc.tns)
+    assert abs(np.vdot(vec, vec).real - 1) < 1e-5
+    ref = sv.run_circuit_statevector(g, {v: [0, 1] for v in g.vertices}, circuit)
+    assert sv.fidelity(vec, ref) > 1 - 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.complex64, 2e-5), (np.complex128, 1e-12)])
+def test_tfim_layer_3x3_exact_without_truncation(dtype, tol):
+    """test/test_apply.jl:23-53 + simple_update.jl:4 ("exact if no truncation is performed")."""
+    g = o.named_grid((3, 3))
+    psi0 = o.random_state(dtype, g, chi=1, seed=123)
+    bpc = o.rescale(o.update(o.BeliefPropagationCache(psi0)))            # normalize(psi0; alg="bp")
+    layer = tfim_layer(g)
+    vecs = {v: np.asarray(bpc.tns.tensors[v]).reshape(2) for v in g.vertices}
+    bpc, errs = o.apply_gates(layer, bpc, apply_kwargs=dict(cutoff=1e-10 if dtype == np.complex64 else 1e-20,
+                                                            normalize_tensors=False))
+    assert bpc.tns.dtype == dtype
+    assert bpc.tns.maxvirtualdim() <= 2
+    vec = sv.tns_to_statevector(bpc.tns)
+    assert abs(np.vdot(vec, vec).real - 1) < tol
+    ref = sv.run_circuit_statevector(g, vecs, layer)
+    assert np.max(np.abs(vec - ref * np.vdot(ref, vec) / abs(np.vdot(ref, vec)))) < 10 * tol
+    assert np.all(errs < 1e-6)
+
+
+def test_two_layers_exact_complex128():
+    g = o.named_grid((3, 3))
+    psi0 = o.product_state(np.complex128, lambda v: "↑", g)
+    bpc = o.update(o.BeliefPropagationCache(psi0))
+    layer = tfim_layer(g)
+    for _ in range(2):
+        bpc, errs = o.apply_gates(layer, bpc, apply_kwargs=dict(cutoff=1e-24, normalize_tensors=False),
+                                  bp_update_kwargs=TIGHT)
+    vec = sv.tns_to_statevector(bpc.tns)
+    ref = sv.run_circuit_statevector(g, {v: [1, 0] for v in g.vertices}, layer + layer)
+    assert abs(np.vdot(vec, vec).real - 1) < 1e-11
+    assert sv.fidelity(vec, ref) > 1 - 1e-11
+    # the two bond messages written by apply_gate! are diag(S) (apply_gates.jl:126-135)
+    for (a, b) in g.edges[:3]:
+        m = bpc.message((a, b))
+        assert m.shape[0] == m.shape[1]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex64, np.complex128])
+def test_bp_exact_on_trees(dtype):
+    """test/test_beliefpropagation.jl:9-56: comb tree (3,3): partition function == exact norm, RDM bp == exact."""
+    g = o.comb_tree((3, 3))
+    psi = o.random_state(dtype, g, chi=2, seed=7)
+    bpc = o.update(o.BeliefPropagationCache(psi))                          # trees: maxiter=1, no tolerance
+    assert len(bpc.messages) == 2 * len(g.edges)                           # :54
+    vec = sv.tns_to_statevector(psi)
+    z_exact = np.vdot(vec, vec).real
+    z_bp = o.partitionfunction(bpc)
+    eps = np.finfo(np.zeros(1, dtype=dtype).real.dtype).eps
+    assert abs(z_bp - z_exact) / z_exact < 200 * eps
+    for v in g.vertices[:4]:
+        rho = o.rdm_1site(bpc, v)
+        rho = rho / np.trace(rho)
+        assert np.max(np.abs(rho - sv.rdm_statevector(vec, g, v))) < 200 * eps
+
+
+def test_expect_bp_exact_on_line_and_not_on_loop():
+    """test/test_expect.jl:19-44"""
+    g = o.named_grid((6,))
+    psi = o.random_state(np.complex128, g, chi=3, seed=11)
+    bpc = o.update(o.BeliefPropagationCache(psi))
+    vec = sv.tns_to_statevector(psi)
+    for v in g.vertices:
+        assert abs(o.expect_1site(bpc, Z, v) - sv.expect_statevector(vec, g, Z, v)) < 1e-12
+    g2 = o.named_grid((3, 3))
+    psi2 = o.random_state(np.complex128, g2, chi=2, seed=5)
+    bpc2 = o.update(o.BeliefPropagationCache(psi2), **TIGHT)
+    vec2 = sv.tns_to_statevector(psi2)
+    d = abs(o.expect_1site(bpc2, Z, (2, 2)) - sv.expect_statevector(vec2, g2, Z, (2, 2)))
+    assert d > 1e-6
+
+
+def test_ghz_bond_entropy_is_log2():
+    """test/test_constructors.jl:69-74"""
+    g = o.named_grid((3, 3))
+    tensors = {}
+    for v in g.vertices:
+        t = np.zeros((2,) + (2,) * g.degree(v), dtype=np.complex128)
+        t[(0,) * t.ndim] = 1
+        t[(1,) * t.ndim] = 1
+        tensors[v] = t
+    bpc = o.update(o.BeliefPropagationCache(o.TensorNetworkState(g, tensors)), **TIGHT)
+    for e in g.edges[:4]:
+        assert abs(o.bond_entropy(bpc, e) - math.log(2)) < 1e-9
+
+
+def test_truncate_respects_maxdim_and_fidelity():
+    """test/test_truncate.jl:12-35 (BP branch)"""
+    g = o.named_hexagonal_lattice_graph(2, 2)
+    psi = o.random_state(np.complex128, g, chi=3, seed=3)
+    bpc = o.rescale(o.update(o.BeliefPropagationCache(psi), **TIGHT))
+    t = o.truncate(bpc, maxdim=2, cutoff=1e-10, bp_update_kwargs=TIGHT)
+    assert t.tns.maxvirtualdim() <= 2
+    a, b = sv.tns_to_statevector(bpc.tns), sv.tns_to_statevector(t.tns)
+    f = sv.fidelity(a, b)
+    assert 0 <= f <= 1 + 1e-12
+
+
+def test_truncation_rule_edge_cases():
+    """NDTensors truncate! restatement"""
+    p = np.array([0.5, 0.3, 0.15, 0.05])
+    assert o.truncate_spectrum(p, None, None) == (4, 0.0)
+    n, e = o.truncate_spectrum(p, 2, None)
+    assert n == 2 and abs(e - 0.2) < 1e-15
+    n, e = o.truncate_spectrum(p, None, 0.06)
+    assert n == 3 and abs(e - 0.05) < 1e-15
+    n, e = o.truncate_spectrum(p, 3, 0.25)
+    assert n == 2 and abs(e - 0.2) < 1e-15
+    assert o.truncate_spectrum(np.array([1.0]), 1, 0.5) == (1, 0.0)
+    n, e = o.truncate_spectrum(np.array([1.0, 0.0, 0.0]), None, None)
+    assert n == 1 and e == 0.0
+    n, e = o.truncate_spectrum(np.array([1.0, 1e-3]), None, 1.0)      # mindim = 1
+    assert n == 1
+
+
+def test_unitary_gate_leaves_messages_at_fixed_point():
+    """without truncation the post-gate update converges in one sweep."""
+    g = o.named_grid((3, 3))
+    bpc = o.update(o.BeliefPropagationCache(o.product_state(np.complex128, lambda v: "↑", g)))
+    info = {}
+    bpc, _ = o.apply_gates(tfim_layer(g), bpc, apply_kwargs=dict(cutoff=1e-24, normalize_tensors=False), info=info)
+    assert info["n_updates"] == len(o.edge_color(g)) + 1
+    assert all(s == 1 for s in info["sweeps"])
+
+
+def test_apply_gate_errors():
+    """apply_gates.jl:109-120"""
+    g = o.named_grid((3, 3))
+    bpc = o.BeliefPropagationCache(o.product_state(np.complex128, lambda v: "↑", g))
+    with pytest.raises(RuntimeError):
+        o.apply_gate(bpc, np.eye(4), [(1, 1), (3, 3)])
+    with pytest.raises(RuntimeError):
+        o.apply_gate(bpc, np.eye(8), [(1, 1), (2, 1), (3, 1)])
