@@ -1,0 +1,153 @@
+/*
+ * tnqs.h -- C ABI of libtnqs_hip.so: MI355X (gfx950) implementation of the BP-gauged
+ * gate-application hot path of TensorNetworkQuantumSimulator.jl.
+ *
+ * The reference has no FFI seam (it is pure Julia); these entry points are what a
+ * Julia shim type `HipBeliefPropagationCache <: AbstractBeliefPropagationCache` would `ccall`
+ * (INTEGRATION.md shows the shim).  Each entry cites the reference function it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every function returns an int status (0 = TNQS_OK, <0 = error); the message is available from
+ *     tnqs_last_error() (thread-local).  No C++ exception crosses the ABI.
+ *   - vertices are 0..nv-1, undirected edges are 0..ne-1 in the order given to tnqs_create; a directed
+ *     edge is named by (src vertex, dst vertex).
+ *   - host pointers are borrowed for the duration of the call only.
+ *   - complex numbers are interleaved (re, im); matrices/tensors are column-major (Julia order).
+ *   - canonical device layout of the site tensor of v:  [site d][leg to nbr_0]...[leg to nbr_{z-1}]
+ *     column-major, neighbours in ascending vertex id.  Messages are chi x chi, index order (ket, bra).
+ *   - one handle must not be used from two threads at once; every call is synchronous on return.
+ */
+#ifndef TNQS_H
+#define TNQS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tnqs_state_s* tnqs_handle;
+
+enum { TNQS_C64 = 0, TNQS_C128 = 1, TNQS_F32 = 2, TNQS_F64 = 3 }; /* F32/F64: TNQS_ERR_UNSUPPORTED for now */
+
+enum {
+    TNQS_OK = 0,
+    TNQS_ERR_INVALID = -1,     /* bad argument; mirrors `error(...)` / ArgumentError in the reference */
+    TNQS_ERR_UNSUPPORTED = -2,
+    TNQS_ERR_HIP = -3,         /* HIP runtime failure (includes "no GPU") */
+    TNQS_ERR_NUMERIC = -4,     /* e.g. sqrt of a negative message eigenvalue (Julia DomainError, src/utils.jl:21) */
+    TNQS_ERR_COMM = -5
+};
+
+/* BP update options: kwargs of `update(bpc; maxiter, tolerance, edge_sequence, ...)`
+ * (src/MessagePassing/abstractbeliefpropagationcache.jl:223-259, beliefpropagationcache.jl:51-72,103-117). */
+typedef struct {
+    int maxiter;          /* <= 0: reference default (25 on loopy graphs, 1 on trees) */
+    double tolerance;     /* < 0: none (no convergence check);  NaN: reference default (1e-5 c64 / 1e-8 c128, none on trees) */
+    int normalize;        /* message_update_alg "contract" kwarg `normalize` (default true): m <- m / sum(m) */
+    int n_sequence;       /* 0: library default edge sequence (edge-colour grouped Gauss-Seidel) */
+    const int32_t* seq_src; /* explicit `edge_sequence` kwarg: directed edges, swept sequentially (Gauss-Seidel) */
+    const int32_t* seq_dst;
+} tnqs_bp_opts;
+
+/* apply_kwargs of apply_gates / simple_update (src/Apply/simple_update.jl:21-24, forwarded to factorize_svd :58). */
+typedef struct {
+    int maxdim;             /* <= 0: no cap (`maxdim = nothing`) */
+    double cutoff;          /* < 0: `cutoff = nothing` (behaves as 0: only exactly-zero weight is cut) */
+    int normalize_tensors;  /* default true */
+    double sqrt_cutoff;     /* < 0: default 10*eps(real(eltype)) (src/Apply/simple_update.jl:32-33) */
+    int update_cache;       /* apply_gates kwarg `update_cache` (default true) */
+} tnqs_apply_opts;
+
+/* run statistics of the last tnqs_apply_gates / tnqs_truncate call (the reference only prints these when verbose) */
+typedef struct {
+    int n_bp_updates;       /* number of `update` calls triggered (c+1 for a TFIM layer) */
+    int n_bp_sweeps;        /* total sweeps over all of them */
+    int n_batches;          /* batched launches of pairwise-disjoint gates */
+    int n_two_site;         /* two-site gates applied */
+    int bp_not_converged;   /* updates that hit maxiter (reference: @warn, abstract...:245-252) */
+    double last_bp_diff;
+} tnqs_apply_stats;
+
+/* ---- library ---------------------------------------------------------------------------------------- */
+int tnqs_version(void);
+const char* tnqs_last_error(void);
+int tnqs_device_count(int* count);
+
+/* ---- state handle: TensorNetworkState + BeliefPropagationCache(psi)
+ *      (src/TensorNetworks/tensornetworkstate.jl:12-15, src/MessagePassing/beliefpropagationcache.jl:9-15,27-31).
+ *      Created as the all-"up" product state with bond dimension 1 and unset (= identity) messages
+ *      (tensornetworkstate.jl:72-75,141-161). */
+int tnqs_create(int nv, int ne, const int32_t* edge_src, const int32_t* edge_dst, const int32_t* site_dim,
+                int dtype, int device, tnqs_handle* out);
+int tnqs_destroy(tnqs_handle h);
+/* Base.copy(::BeliefPropagationCache) (beliefpropagationcache.jl:35-37): shallow, buffers are shared and
+ * never mutated in place, so the copy is O(nv + ne). */
+int tnqs_copy(tnqs_handle h, tnqs_handle* out);
+/* use an existing HIP stream (e.g. torch's current stream) instead of the handle's own */
+int tnqs_set_stream(tnqs_handle h, void* hip_stream);
+
+/* ---- tensors / messages  (setindex_preserve! abstracttensornetwork.jl:40-43; psi[v]; setmessage!/message
+ *      abstractbeliefpropagationcache.jl:93-102) ------------------------------------------------------------ */
+/* leg_role[k] = -1 for the site leg, otherwise the neighbour vertex that leg k connects to.  The library
+ * permutes into the canonical layout bit-exactly.  Bond dimensions of the incident edges are updated; messages
+ * on an edge whose dimension changes are reset to the identity. */
+int tnqs_set_site_tensor(tnqs_handle h, int v, const void* host, int ndim, const int64_t* dims, const int32_t* leg_role);
+int tnqs_get_site_tensor(tnqs_handle h, int v, void* host, int ndim, const int32_t* leg_role);
+int tnqs_site_tensor_size(tnqs_handle h, int v, int64_t* nelem);
+int tnqs_set_message(tnqs_handle h, int src, int dst, const void* host, int chi);
+int tnqs_get_message(tnqs_handle h, int src, int dst, void* host, int chi);
+int tnqs_bond_dim(tnqs_handle h, int u, int v, int* chi);           /* dim(virtualinds) */
+int tnqs_maxvirtualdim(tnqs_handle h, int* chi);                     /* abstracttensornetwork.jl:27-29 */
+
+/* ---- BP update (abstractbeliefpropagationcache.jl:223-259) -------------------------------------------------
+ * Non-convergence is not an error (the reference only warns): status OK, *niter == maxiter, diff returned. */
+int tnqs_bp_update(tnqs_handle h, const tnqs_bp_opts* opts, int* niter, double* final_diff);
+
+/* ---- apply_gates (src/Apply/apply_gates.jl:46-98 incl. the update scheduling rule :68-90 and apply_gate!
+ *      :101-143, simple_update src/Apply/simple_update.jl:21-77).  Mutates h (callers wanting the reference's
+ *      value semantics call tnqs_copy first).
+ *      gate_nverts[g] in {1,2}; gate_verts is the concatenation of the vertex lists; gate_mats is the
+ *      concatenation of the d^k x d^k complex128 matrices, column-major, first listed vertex = most significant
+ *      index.  out_truncerr is caller-allocated double[ngates] (apply_gates.jl:61). */
+int tnqs_apply_gates(tnqs_handle h, int ngates, const int32_t* gate_nverts, const int32_t* gate_verts,
+                     const double* gate_mats, const tnqs_apply_opts* opts, const tnqs_bp_opts* bp_opts,
+                     double* out_truncerr, tnqs_apply_stats* stats);
+
+/* ---- truncate (src/truncate.jl:12-38, edge_color = true branch).  Edge colour groups are supplied by the
+ *      caller (the reference gets them from SimpleGraphAlgorithms.edge_color); n_groups = 0 selects the
+ *      non-coloured branch (:31-35): one update after every edge in edge order. */
+int tnqs_truncate(tnqs_handle h, int maxdim, double cutoff, int normalize_tensors, int n_groups,
+                  const int32_t* group_offsets, const int32_t* edge_u, const int32_t* edge_v,
+                  const tnqs_bp_opts* bp_opts, tnqs_apply_stats* stats);
+
+/* ---- parity probes (src/expect.jl:59-82) ------------------------------------------------------------------
+ * rho[s,s'] = sum psi[s,l..] conj psi[s',l'..] prod m[l,l'] (un-normalised, d x d complex128 col-major);
+ * expect = tr(op rho)/tr(rho), op[s',s] column-major complex128. */
+int tnqs_rdm_1site(tnqs_handle h, int v, double* out_rho);
+int tnqs_expect_1site(tnqs_handle h, int v, const double* op, double* out_re_im);
+/* all-vertex <op_v>: ops is nv consecutive d x d matrices; out is nv complex128 */
+int tnqs_expect_all(tnqs_handle h, const double* ops, double* out_re_im);
+
+/* ---- multi-GPU sharding (no reference analogue).  A rank owns a vertex subset: it holds only
+ *      those site tensors and does all per-vertex work for them; messages are replicated.  The library calls
+ *      the host-supplied all-gather at the exchange points (host side: torch.distributed over RCCL). --------- */
+typedef int (*tnqs_allgatherv_fn)(void* ctx, const void* d_send, void* d_recv, const int64_t* byte_counts,
+                                  const int64_t* byte_displs, int nranks, void* hip_stream);
+int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* vertex_owner,
+                      tnqs_allgatherv_fn fn, void* ctx);
+
+/* ---- profiling: HIP-event timing of the kernel classes on the handle's stream ---------------------------- */
+enum { TNQS_PROF_BP_MODEPROD = 0, TNQS_PROF_BP_GRAM = 1, TNQS_PROF_GATE_MODEPROD = 2, TNQS_PROF_GATE_GRAM = 3,
+       TNQS_PROF_GATE_APPLY = 4, TNQS_PROF_JACOBI = 5, TNQS_PROF_SMALL = 6, TNQS_PROF_BP_FUSED = 7, TNQS_PROF_NCLASSES = 8 };
+int tnqs_profile_enable(tnqs_handle h, int on);
+/* launches, total ms, algorithmic bytes (min traffic: operands read once + result written once) and flops */
+int tnqs_profile_get(tnqs_handle h, int cls, int64_t* launches, double* total_ms, double* alg_bytes, double* alg_flops);
+int tnqs_profile_reset(tnqs_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TNQS_H */

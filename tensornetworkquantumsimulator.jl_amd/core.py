@@ -1,0 +1,424 @@
+"""Host-side mirror of the reference's operator interface for the BP-gauged gate-application path.
+
+Same names, argument meaning and error behaviour as TensorNetworkQuantumSimulator.jl (paths relative to the
+reference repo):
+  TensorNetworkState / tensornetworkstate / random_tensornetworkstate   src/TensorNetworks/tensornetworkstate.jl:12-15,93-103,141-161
+  BeliefPropagationCache, copy, message, network                         src/MessagePassing/beliefpropagationcache.jl:9-37
+  update(bpc; maxiter, tolerance, edge_sequence, ...)                     src/MessagePassing/abstractbeliefpropagationcache.jl:223-259
+  apply_gates / apply_circuit                                            src/Apply/apply_gates.jl:17-98,145
+  truncate(bpc; maxdim, cutoff, edge_color, normalize_tensors)           src/truncate.jl:12-38
+  expect(bpc, (op, [v]))                                                  src/expect.jl:54-82,114-121
+  maxvirtualdim                                                           src/TensorNetworks/abstracttensornetwork.jl:27-29
+Every flop runs in libtnqs_hip.so; this file only marshals arguments through the C ABI (include/tnqs.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import warnings
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from .gates import gate_matrix, resolve_gate
+from .graphs import NamedGraph, edge_color as _edge_color
+
+_DT = {np.dtype(np.complex64): L.TNQS_C64, np.dtype(np.complex128): L.TNQS_C128}
+_STATES = {"↑": (1, 0), "Up": (1, 0), "0": (1, 0), "Z+": (1, 0), "↓": (0, 1), "Dn": (0, 1), "1": (0, 1), "Z-": (0, 1),
+           "+": (1 / math.sqrt(2), 1 / math.sqrt(2)), "X+": (1 / math.sqrt(2), 1 / math.sqrt(2)),
+           "-": (1 / math.sqrt(2), -1 / math.sqrt(2)), "X-": (1 / math.sqrt(2), -1 / math.sqrt(2))}
+
+
+class TensorNetworkState:
+    """graph + one host tensor per vertex; axes (site, leg to each neighbour in ascending vertex position)"""
+
+    def __init__(self, graph: NamedGraph, tensors: Dict):
+        self.graph = graph
+        self.tensors = {v: np.asarray(tensors[v]) for v in graph.vertices}
+        dts = {t.dtype for t in self.tensors.values()}
+        if len(dts) != 1:
+            raise ValueError("all site tensors must share one dtype")
+        for v in graph.vertices:
+            if self.tensors[v].ndim != 1 + graph.degree(v):
+                raise ValueError(f"tensor at {v} must have 1 + degree axes")
+        for (a, b) in graph.edges:
+            if self.bond_dim(a, b) != self.tensors[b].shape[1 + graph.neighbors(b).index(a)]:
+                raise ValueError(f"bond dimension mismatch on edge {(a, b)}")
+
+    @property
+    def dtype(self):
+        return next(iter(self.tensors.values())).dtype
+
+    def bond_dim(self, a, b) -> int:
+        return self.tensors[a].shape[1 + self.graph.neighbors(a).index(b)]
+
+    def __getitem__(self, v):
+        return self.tensors[v]
+
+    def copy(self):
+        return TensorNetworkState(self.graph, dict(self.tensors))
+
+
+def scalartype(x):
+    return x.dtype
+
+
+def tensornetworkstate(eltype, f: Callable, g: NamedGraph, sitetype: str = "S=1/2", d: int = 2) -> TensorNetworkState:
+    tensors = {}
+    for v in g.vertices:
+        s = f(v)
+        if isinstance(s, str):
+            if s not in _STATES:
+                raise ValueError(f"unknown local state {s!r}")
+            vec = np.zeros(d, dtype=eltype)
+            vec[:2] = _STATES[s]
+        elif isinstance(s, (list, tuple, np.ndarray)):
+            vec = np.asarray(s, dtype=eltype)
+        else:
+            raise RuntimeError("Unrecognized local state constructor. Currently supported: Strings and Vectors.")
+        tensors[v] = vec.reshape((len(vec),) + (1,) * g.degree(v))
+    return TensorNetworkState(g, tensors)
+
+
+def random_tensornetworkstate(eltype, g: NamedGraph, bond_dimension: int = 1, d: int = 2, seed: Optional[int] = None) -> TensorNetworkState:
+    rng = np.random.default_rng(seed)
+    tensors = {}
+    for v in g.vertices:
+        shp = (d,) + (bond_dimension,) * g.degree(v)
+        t = rng.standard_normal(shp)
+        if np.issubdtype(np.dtype(eltype), np.complexfloating):
+            t = (t + 1j * rng.standard_normal(shp)) / math.sqrt(2)
+        tensors[v] = t.astype(eltype)
+    return TensorNetworkState(g, tensors)
+
+
+def default_tolerance(dtype) -> Optional[float]:
+    dt = np.dtype(dtype)
+    if dt in (np.dtype(np.float32), np.dtype(np.complex64)):
+        return 1.0e-5
+    if dt in (np.dtype(np.float64), np.dtype(np.complex128)):
+        return 1.0e-8
+    return None
+
+
+class BeliefPropagationCache:
+    """Device-resident {network, messages} (beliefpropagationcache.jl:9-15) behind an opaque C handle."""
+
+    def __init__(self, network, device: int = 0, _handle=None):
+        if _handle is not None:
+            self.graph, self.dtype, self._h, self.device = network, device[0], _handle, device[1]
+            return
+        if not isinstance(network, TensorNetworkState):
+            raise TypeError("BeliefPropagationCache(network): expected a TensorNetworkState")
+        g = network.graph
+        if network.dtype not in _DT:
+            raise TypeError(f"unsupported element type {network.dtype}; supported: complex64, complex128")
+        self.graph, self.dtype, self.device = g, network.dtype, device
+        es, esp = L.i32([g.index[a] for (a, b) in g.edges])
+        ed, edp = L.i32([g.index[b] for (a, b) in g.edges])
+        sd, sdp = L.i32([network.tensors[v].shape[0] for v in g.vertices])
+        h = L.H()
+        L.check(L.lib.tnqs_create(g.nv(), g.ne(), esp, edp, sdp, _DT[network.dtype], device, C.byref(h)))
+        self._h = h
+        for v in g.vertices:
+            self._set_tensor(v, network.tensors[v])
+
+    # -- marshalling ---------------------------------------------------------------------------------------
+    def _roles(self, v):
+        # numpy C-order axes (s, n0, n1, ...) == column-major axes (..., n1, n0, s)
+        nb = [self.graph.index[w] for w in self.graph.neighbors(v)]
+        return list(reversed([-1] + nb))
+
+    def _set_tensor(self, v, t):
+        t = np.ascontiguousarray(t, dtype=self.dtype)
+        dims = np.array(list(reversed(t.shape)), dtype=np.int64)
+        roles, rp = L.i32(self._roles(v))
+        L.check(L.lib.tnqs_set_site_tensor(self._h, self.graph.index[v], t.ctypes.data_as(C.c_void_p), t.ndim,
+                                           dims.ctypes.data_as(C.POINTER(C.c_int64)), rp))
+
+    def tensor(self, v) -> np.ndarray:
+        g = self.graph
+        shape = [self._site_dim(v)] + [self.bond_dim(v, w) for w in g.neighbors(v)]
+        out = np.empty(shape, dtype=self.dtype)
+        roles, rp = L.i32(self._roles(v))
+        L.check(L.lib.tnqs_get_site_tensor(self._h, g.index[v], out.ctypes.data_as(C.c_void_p), out.ndim, rp))
+        return out
+
+    def _site_dim(self, v) -> int:
+        n = C.c_int64()
+        L.check(L.lib.tnqs_site_tensor_size(self._h, self.graph.index[v], C.byref(n)))
+        p = 1
+        for w in self.graph.neighbors(v):
+            p *= self.bond_dim(v, w)
+        return int(n.value // p)
+
+    def bond_dim(self, a, b) -> int:
+        c = C.c_int()
+        L.check(L.lib.tnqs_bond_dim(self._h, self.graph.index[a], self.graph.index[b], C.byref(c)))
+        return c.value
+
+    def message(self, e) -> np.ndarray:
+        """message(bpc, src => dst): chi x chi, axes (ket, bra); identity when unset"""
+        a, b = e
+        chi = self.bond_dim(a, b)
+        out = np.empty((chi, chi), dtype=self.dtype, order="F")
+        L.check(L.lib.tnqs_get_message(self._h, self.graph.index[a], self.graph.index[b], out.ctypes.data_as(C.c_void_p), chi))
+        return np.ascontiguousarray(out)
+
+    def setmessage(self, e, m):
+        a, b = e
+        m = np.asfortranarray(m, dtype=self.dtype)
+        L.check(L.lib.tnqs_set_message(self._h, self.graph.index[a], self.graph.index[b], m.ctypes.data_as(C.c_void_p), m.shape[0]))
+        return self
+
+    def network(self) -> TensorNetworkState:
+        return TensorNetworkState(self.graph, {v: self.tensor(v) for v in self.graph.vertices})
+
+    def copy(self) -> "BeliefPropagationCache":
+        h = L.H()
+        L.check(L.lib.tnqs_copy(self._h, C.byref(h)))
+        return BeliefPropagationCache(self.graph, (self.dtype, self.device), _handle=h)
+
+    def maxvirtualdim(self) -> int:
+        c = C.c_int()
+        L.check(L.lib.tnqs_maxvirtualdim(self._h, C.byref(c)))
+        return c.value
+
+    def default_bp_update_kwargs(self) -> dict:
+        if self.graph.is_tree():
+            return dict(maxiter=1, tolerance=None)
+        return dict(maxiter=25, tolerance=default_tolerance(self.dtype))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and L is not None:
+            try:
+                L.lib.tnqs_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+
+def network(bpc: BeliefPropagationCache) -> TensorNetworkState:
+    return bpc.network()
+
+
+def maxvirtualdim(x) -> int:
+    if isinstance(x, BeliefPropagationCache):
+        return x.maxvirtualdim()
+    return max([x.bond_dim(a, b) for (a, b) in x.graph.edges], default=1)
+
+
+def default_bp_update_kwargs(x) -> dict:
+    if isinstance(x, BeliefPropagationCache):
+        return x.default_bp_update_kwargs()
+    if x.graph.is_tree():
+        return dict(maxiter=1, tolerance=None)
+    return dict(maxiter=25, tolerance=default_tolerance(x.dtype))
+
+
+def _bp_opts(g: NamedGraph, kw: Optional[dict]):
+    """kwargs of `update` -> tnqs_bp_opts (+ the arrays that must stay alive during the call)"""
+    kw = dict(kw or {})
+    o = L.BpOpts()
+    keep = []
+    unknown = set(kw) - {"maxiter", "tolerance", "edge_sequence", "normalize", "verbose"}
+    if unknown:
+        raise TypeError(f"update: unknown keyword(s) {sorted(unknown)}")
+    mi = kw.get("maxiter")
+    o.maxiter = int(mi) if mi is not None else 0
+    if "tolerance" not in kw:
+        o.tolerance = float("nan")                 # reference default for the dtype / graph
+    else:
+        o.tolerance = -1.0 if kw["tolerance"] is None else float(kw["tolerance"])
+    o.normalize = 1 if kw.get("normalize", True) else 0
+    seq = kw.get("edge_sequence")
+    if seq is not None:
+        for (a, b) in seq:
+            if a not in g.index or b not in g.index or not g.has_edge(a, b):
+                raise RuntimeError(f"update: edge_sequence entry {(a, b)} is not an edge of the graph")
+        s, sp = L.i32([g.index[a] for (a, b) in seq])
+        d, dp = L.i32([g.index[b] for (a, b) in seq])
+        keep += [s, d]
+        o.n_sequence, o.seq_src, o.seq_dst = len(seq), sp, dp
+    else:
+        o.n_sequence = 0
+    return o, keep
+
+
+def update(bpc: BeliefPropagationCache, info: Optional[dict] = None, **kwargs) -> BeliefPropagationCache:
+    """update(bpc; maxiter, tolerance, edge_sequence, normalize, verbose): returns a NEW cache (:228)."""
+    verbose = kwargs.get("verbose", False)
+    o, keep = _bp_opts(bpc.graph, kwargs)
+    out = bpc.copy()
+    niter, diff = C.c_int(), C.c_double()
+    L.check(L.lib.tnqs_bp_update(out._h, C.byref(o), C.byref(niter), C.byref(diff)))
+    tol = o.tolerance
+    if math.isnan(tol):
+        dk = bpc.default_bp_update_kwargs()
+        tol = -1.0 if dk["tolerance"] is None else dk["tolerance"]
+    if tol >= 0:
+        if diff.value <= tol:
+            if verbose:
+                print(f"BP converged to desired precision after {niter.value} iterations.")
+        else:
+            msg = (f"BP did not converge to tolerance {tol} after {niter.value} iterations "
+                   f"(final average message change: {diff.value}).")
+            print(msg) if verbose else warnings.warn(msg)
+    if info is not None:
+        info.update(niter=niter.value, diff=diff.value if diff.value >= 0 else None)
+    return out
+
+
+def _apply_opts(kw: Optional[dict], update_cache: bool) -> L.ApplyOpts:
+    kw = dict(kw or {})
+    unknown = set(kw) - {"maxdim", "cutoff", "normalize_tensors", "sqrt_cutoff"}
+    if unknown:
+        raise TypeError(f"apply_kwargs: unknown keyword(s) {sorted(unknown)}")
+    a = L.ApplyOpts()
+    md = kw.get("maxdim")
+    a.maxdim = int(md) if md is not None else 0
+    co = kw.get("cutoff")
+    a.cutoff = float(co) if co is not None else -1.0
+    a.normalize_tensors = 1 if kw.get("normalize_tensors", True) else 0
+    sc = kw.get("sqrt_cutoff")
+    a.sqrt_cutoff = float(sc) if sc is not None else -1.0
+    a.update_cache = 1 if update_cache else 0
+    return a
+
+
+def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_update_kwargs: Optional[dict] = None,
+                update_cache: bool = True, verbose: bool = False, info: Optional[dict] = None):
+    """apply_gates(circuit, psi; apply_kwargs, bp_update_kwargs, update_cache) -> (psi', truncation_errors).
+    psi may be a TensorNetworkState (wrapped, BP-updated first, network returned; apply_gates.jl:17-27) or a
+    BeliefPropagationCache (returned as a new cache; the input is untouched, :55)."""
+    if isinstance(psi, TensorNetworkState):
+        bpc = update(BeliefPropagationCache(psi), **(bp_update_kwargs or {}))
+        out, errs = apply_gates(circuit, bpc, apply_kwargs=apply_kwargs, bp_update_kwargs=bp_update_kwargs,
+                                update_cache=update_cache, verbose=verbose, info=info)
+        return out.network(), errs
+    if not isinstance(psi, BeliefPropagationCache):
+        raise TypeError("apply_gates: expected a TensorNetworkState or a BeliefPropagationCache")
+    g = psi.graph
+    nverts, verts, mats = [], [], []
+    for gate in circuit:
+        m, vs = resolve_gate(gate, g)
+        nverts.append(len(vs))
+        verts += [g.index[v] for v in vs]
+        mats.append(np.asarray(m, dtype=np.complex128).ravel(order="F"))
+    ng = len(nverts)
+    nv_a, nv_p = L.i32(nverts if ng else [0])
+    vs_a, vs_p = L.i32(verts if verts else [0])
+    mat_a = np.ascontiguousarray(np.concatenate(mats) if mats else np.zeros(1, dtype=np.complex128))
+    errs = np.zeros(max(ng, 1), dtype=np.float64)
+    ao = _apply_opts(apply_kwargs, update_cache)
+    bo, keep = _bp_opts(g, bp_update_kwargs)
+    st = L.ApplyStats()
+    out = psi.copy()
+    L.check(L.lib.tnqs_apply_gates(out._h, ng, nv_p, vs_p, mat_a.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ao),
+                                   C.byref(bo), errs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
+    if st.bp_not_converged and not verbose:
+        warnings.warn(f"BP did not converge in {st.bp_not_converged} of {st.n_bp_updates} cache updates "
+                      f"(final average message change: {st.last_bp_diff}).")
+    if info is not None:
+        info.update(n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
+                    n_two_site=st.n_two_site, bp_not_converged=st.bp_not_converged)
+    return out, errs[:ng]
+
+
+apply_circuit = apply_gates
+
+
+def truncate(bpc: BeliefPropagationCache, maxdim: int, cutoff: Optional[float] = None, edge_color=True,
+             normalize_tensors: bool = True, bp_update_kwargs: Optional[dict] = None, info: Optional[dict] = None):
+    """truncate(bpc; maxdim, cutoff, edge_color, normalize_tensors) (src/truncate.jl:12-38).  `edge_color` may be
+    True (compute a colouring), False (update after every edge) or an explicit list of edge groups."""
+    g = bpc.graph
+    if edge_color is True:
+        groups = _edge_color(g)
+    elif edge_color is False:
+        groups = []
+    else:
+        groups = [list(grp) for grp in edge_color]
+    offs, eu, ev = [0], [], []
+    for grp in groups:
+        for (a, b) in grp:
+            eu.append(g.index[a]); ev.append(g.index[b])
+        offs.append(len(eu))
+    o_a, o_p = L.i32(offs)
+    u_a, u_p = L.i32(eu if eu else [0])
+    v_a, v_p = L.i32(ev if ev else [0])
+    bo, keep = _bp_opts(g, bp_update_kwargs)
+    st = L.ApplyStats()
+    out = bpc.copy()
+    L.check(L.lib.tnqs_truncate(out._h, int(maxdim), -1.0 if cutoff is None else float(cutoff), 1 if normalize_tensors else 0,
+                                len(groups), o_p, u_p, v_p, C.byref(bo), C.byref(st)))
+    if info is not None:
+        info.update(n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_two_site=st.n_two_site)
+    return out
+
+
+def rdm(bpc: BeliefPropagationCache, v) -> np.ndarray:
+    """normalised single-site reduced density matrix rho[s, s'] from the BP environment"""
+    d = bpc._site_dim(v)
+    out = np.zeros((d, d), dtype=np.complex128, order="F")
+    L.check(L.lib.tnqs_rdm_1site(bpc._h, bpc.graph.index[v], out.ctypes.data_as(C.POINTER(C.c_double))))
+    out = np.ascontiguousarray(out)
+    return out / np.trace(out)
+
+
+def _collect_observable(obs, g):
+    """collectobservable (src/expect.jl:159-175): ("Z", [v]) / ("Z", v) / ("Z", [v], coeff)"""
+    op = obs[0]
+    verts = obs[1] if isinstance(obs[1], list) else ([obs[1]] if obs[1] in g.index else list(obs[1]))
+    coeff = obs[2] if len(obs) > 2 else 1.0
+    return op, verts, coeff
+
+
+def expect(bpc: BeliefPropagationCache, observable):
+    """expect(alg"bp", cache, obs) for single-site observables (src/expect.jl:59-82); a list of observables returns
+    a list (:114-121)."""
+    if isinstance(observable, list):
+        return [expect(bpc, o) for o in observable]
+    op, verts, coeff = _collect_observable(observable, bpc.graph)
+    if coeff == 0:
+        return 0.0 * coeff
+    if len(verts) != 1:
+        raise NotImplementedError("expect: only single-site observables are on the HIP path (multi-site: SURVEY.md 8f N1)")
+    m = np.asfortranarray(gate_matrix(op) if isinstance(op, str) else np.asarray(op), dtype=np.complex128)
+    out = (C.c_double * 2)()
+    L.check(L.lib.tnqs_expect_1site(bpc._h, bpc.graph.index[verts[0]], m.ctypes.data_as(C.POINTER(C.c_double)), out))
+    return coeff * complex(out[0], out[1])
+
+
+def expect_all(bpc: BeliefPropagationCache, op) -> np.ndarray:
+    """<op_v> for every vertex in one batched launch (the per-layer probe of examples/2dIsing_dynamics.jl:60)"""
+    g = bpc.graph
+    mats = []
+    for v in g.vertices:
+        m = gate_matrix(op) if isinstance(op, str) else np.asarray(op)
+        mats.append(np.asarray(m, dtype=np.complex128).ravel(order="F"))
+    ops = np.ascontiguousarray(np.concatenate(mats))
+    out = np.zeros(g.nv(), dtype=np.complex128)
+    L.check(L.lib.tnqs_expect_all(bpc._h, ops.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def profile_enable(bpc: BeliefPropagationCache, on: bool = True):
+    L.check(L.lib.tnqs_profile_enable(bpc._h, 1 if on else 0))
+
+
+PROF_CLASSES = ("bp_modeprod", "bp_gram", "gate_modeprod", "gate_gram", "gate_apply", "jacobi", "small", "bp_fused")
+
+
+def profile_get(bpc: BeliefPropagationCache) -> dict:
+    out = {}
+    for i, name in enumerate(PROF_CLASSES):
+        n, ms, by, fl = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        L.check(L.lib.tnqs_profile_get(bpc._h, i, C.byref(n), C.byref(ms), C.byref(by), C.byref(fl)))
+        out[name] = dict(launches=n.value, ms=ms.value, bytes=by.value, flops=fl.value)
+    return out
+
+
+def profile_reset(bpc: BeliefPropagationCache):
+    L.check(L.lib.tnqs_profile_reset(bpc._h))

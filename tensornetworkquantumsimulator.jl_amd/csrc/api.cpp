@@ -1,0 +1,142 @@
+// api.cpp -- extern "C" boundary of libtnqs_hip.so (include/tnqs.h).  No C++ exception crosses the ABI.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include "engine.hpp"
+
+using namespace tnqs;
+
+struct tnqs_state_s { State* s; };
+
+static thread_local std::string g_err;
+
+template <class F> static int guard(F&& f) {
+    try { f(); return TNQS_OK; }
+    catch (const Err& e) { g_err = e.what(); return e.code; }
+    catch (const std::bad_alloc&) { g_err = "out of host memory"; return TNQS_ERR_HIP; }
+    catch (const std::exception& e) { g_err = e.what(); return TNQS_ERR_INVALID; }
+    catch (...) { g_err = "unknown error"; return TNQS_ERR_INVALID; }
+}
+static State* S(tnqs_handle h) { if (!h || !h->s) throw Err(TNQS_ERR_INVALID, "null handle"); return h->s; }
+
+extern "C" {
+
+int tnqs_version(void) { return 100; }
+const char* tnqs_last_error(void) { return g_err.c_str(); }
+int tnqs_device_count(int* count) {
+    return guard([&] { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) n = 0; if (count) *count = n; });
+}
+
+int tnqs_create(int nv, int ne, const int32_t* es, const int32_t* ed, const int32_t* sd, int dtype, int device, tnqs_handle* out) {
+    return guard([&] {
+        if (!out) throw Err(TNQS_ERR_INVALID, "tnqs_create: out is null");
+        if (ne > 0 && (!es || !ed)) throw Err(TNQS_ERR_INVALID, "tnqs_create: edge arrays are null");
+        State* s = state_create(nv, ne, es, ed, sd, dtype, device);
+        *out = new tnqs_state_s{s};
+    });
+}
+int tnqs_destroy(tnqs_handle h) {
+    return guard([&] { if (!h) return; if (h->s) { (void)hipSetDevice(h->s->device); if (h->s->stream) (void)hipStreamSynchronize(h->s->stream); delete h->s; } delete h; });
+}
+int tnqs_copy(tnqs_handle h, tnqs_handle* out) {
+    return guard([&] { if (!out) throw Err(TNQS_ERR_INVALID, "tnqs_copy: out is null"); *out = new tnqs_state_s{state_copy(S(h))}; });
+}
+int tnqs_set_stream(tnqs_handle h, void* stream) {
+    return guard([&] {
+        State* s = S(h);
+        if (s->own_stream && s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+        s->stream = reinterpret_cast<hipStream_t>(stream); s->own_stream = false;
+    });
+}
+
+int tnqs_set_site_tensor(tnqs_handle h, int v, const void* host, int ndim, const int64_t* dims, const int32_t* role) {
+    return guard([&] { if (!host || !dims || !role) throw Err(TNQS_ERR_INVALID, "set_site_tensor: null argument"); state_set_site(S(h), v, host, ndim, dims, role); });
+}
+int tnqs_get_site_tensor(tnqs_handle h, int v, void* host, int ndim, const int32_t* role) {
+    return guard([&] { if (!host || !role) throw Err(TNQS_ERR_INVALID, "get_site_tensor: null argument"); state_get_site(S(h), v, host, ndim, role); });
+}
+int tnqs_site_tensor_size(tnqs_handle h, int v, int64_t* n) {
+    return guard([&] { State* s = S(h); if (v < 0 || v >= s->g->nv) throw Err(TNQS_ERR_INVALID, "bad vertex"); *n = state_site_size(s, v); });
+}
+int tnqs_set_message(tnqs_handle h, int src, int dst, const void* host, int chi) {
+    return guard([&] { if (!host) throw Err(TNQS_ERR_INVALID, "set_message: null"); state_set_message(S(h), src, dst, host, chi); });
+}
+int tnqs_get_message(tnqs_handle h, int src, int dst, void* host, int chi) {
+    return guard([&] { if (!host) throw Err(TNQS_ERR_INVALID, "get_message: null"); state_get_message(S(h), src, dst, host, chi); });
+}
+int tnqs_bond_dim(tnqs_handle h, int u, int v, int* chi) {
+    return guard([&] { State* s = S(h); int e = s->g->edge(u, v); if (e < 0) throw Err(TNQS_ERR_INVALID, "bond_dim: not an edge"); *chi = s->chi[e]; });
+}
+int tnqs_maxvirtualdim(tnqs_handle h, int* chi) {
+    return guard([&] { State* s = S(h); int m = 1; for (int c : s->chi) m = c > m ? c : m; *chi = m; });
+}
+
+int tnqs_bp_update(tnqs_handle h, const tnqs_bp_opts* o, int* niter, double* diff) {
+    return guard([&] { State* s = S(h); s->stats = tnqs_apply_stats{}; bp_update(s, o, niter, diff); });
+}
+int tnqs_apply_gates(tnqs_handle h, int ngates, const int32_t* nverts, const int32_t* verts, const double* mats,
+                     const tnqs_apply_opts* opts, const tnqs_bp_opts* bp, double* errs, tnqs_apply_stats* stats) {
+    return guard([&] {
+        State* s = S(h);
+        if (ngates < 0 || (ngates > 0 && (!nverts || !verts || !mats))) throw Err(TNQS_ERR_INVALID, "apply_gates: null argument");
+        apply_gates(s, ngates, nverts, verts, mats, opts, bp, errs);
+        if (stats) *stats = s->stats;
+    });
+}
+int tnqs_truncate(tnqs_handle h, int maxdim, double cutoff, int normalize, int ngroups, const int32_t* offs,
+                  const int32_t* eu, const int32_t* ev, const tnqs_bp_opts* bp, tnqs_apply_stats* stats) {
+    return guard([&] { State* s = S(h); truncate_bp(s, maxdim, cutoff, normalize, ngroups, offs, eu, ev, bp); if (stats) *stats = s->stats; });
+}
+int tnqs_rdm_1site(tnqs_handle h, int v, double* out) {
+    return guard([&] { if (!out) throw Err(TNQS_ERR_INVALID, "rdm_1site: null"); rdm_1site(S(h), v, out); });
+}
+int tnqs_expect_1site(tnqs_handle h, int v, const double* op, double* out) {
+    return guard([&] {
+        State* s = S(h);
+        if (!op || !out) throw Err(TNQS_ERR_INVALID, "expect_1site: null");
+        if (v < 0 || v >= s->g->nv) throw Err(TNQS_ERR_INVALID, "expect_1site: bad vertex");
+        int d = s->d[v];
+        std::vector<double> r(2 * (size_t)d * d);
+        rdm_1site(s, v, r.data());
+        double nre = 0, nim = 0, tre = 0, tim = 0;
+        for (int sp = 0; sp < d; ++sp) for (int si = 0; si < d; ++si) {
+            double ore = op[2 * (sp + d * si)], oim = op[2 * (sp + d * si) + 1];
+            double rre = r[2 * (si + d * sp)], rim = r[2 * (si + d * sp) + 1];
+            nre += ore * rre - oim * rim; nim += ore * rim + oim * rre;
+        }
+        for (int si = 0; si < d; ++si) { tre += r[2 * (si + d * si)]; tim += r[2 * (si + d * si) + 1]; }
+        double den = tre * tre + tim * tim;
+        out[0] = (nre * tre + nim * tim) / den; out[1] = (nim * tre - nre * tim) / den;
+    });
+}
+int tnqs_expect_all(tnqs_handle h, const double* ops, double* out) {
+    return guard([&] { if (!ops || !out) throw Err(TNQS_ERR_INVALID, "expect_all: null"); expect_all(S(h), ops, out); });
+}
+
+int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* owner, tnqs_allgatherv_fn fn, void* ctx) {
+    return guard([&] {
+        State* s = S(h);
+        if (nranks < 1 || rank < 0 || rank >= nranks) throw Err(TNQS_ERR_INVALID, "set_sharding: bad rank");
+        if (nranks > 1) throw Err(TNQS_ERR_UNSUPPORTED, "set_sharding: nranks > 1 is not implemented in this build");
+        (void)owner; (void)fn; (void)ctx;
+        s->rank = rank; s->nranks = nranks;
+    });
+}
+
+int tnqs_profile_enable(tnqs_handle h, int on) { return guard([&] { S(h)->prof_on = on != 0; }); }
+int tnqs_profile_get(tnqs_handle h, int cls, int64_t* launches, double* ms, double* bytes, double* flops) {
+    return guard([&] {
+        State* s = S(h);
+        if (cls < 0 || cls >= TNQS_PROF_NCLASSES) throw Err(TNQS_ERR_INVALID, "profile_get: bad class");
+        prof_collect(s);
+        if (launches) *launches = s->prof[cls].launches;
+        if (ms) *ms = s->prof[cls].ms;
+        if (bytes) *bytes = s->prof[cls].bytes;
+        if (flops) *flops = s->prof[cls].flops;
+    });
+}
+int tnqs_profile_reset(tnqs_handle h) {
+    return guard([&] { State* s = S(h); prof_collect(s); for (auto& p : s->prof) p = ProfClass{}; });
+}
+
+}  // extern "C"

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libtnqs_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+OUT=../libtnqs_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
+mkdir -p build
+pids=()
+for f in kernels.hip kernels_mfma.hip engine.cpp api.cpp; do
+  [ -f "$f" ] || continue
+  o=build/${f%.*}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ kernels.hpp -nt "$o" ] || [ engine.hpp -nt "$o" ] || [ ../../include/tnqs.h -nt "$o" ]; then
+    if [[ "$f" == *.hip ]]; then hipcc $FLAGS -c "$f" -o "$o" & else hipcc $FLAGS -x hip -c "$f" -o "$o" & fi
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+echo "built $OUT"

@@ -1,0 +1,961 @@
+// engine.cpp -- see engine.hpp.  Host orchestration only; every flop runs in the HIP kernels of kernels*.hip.
+#include "engine.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <set>
+#include "kernels.hpp"
+
+namespace tnqs {
+
+void hipchk(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw Err(TNQS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(x) hipchk((x), #x)
+
+// ---------------------------------------------------------------------------------------------------------------
+// pool
+// ---------------------------------------------------------------------------------------------------------------
+static size_t round_size(size_t b) {
+    if (b < 256) return 256;
+    if (b <= (1u << 20)) return (b + 255) & ~size_t(255);
+    // above 1 MiB: 8 size classes per power of two, so buffers of nearby sizes are reusable
+    size_t p = size_t(1) << (63 - __builtin_clzll(b));
+    size_t step = p >> 3;
+    return (b + step - 1) / step * step;
+}
+Pool::~Pool() { trim(); }
+void Pool::trim() {
+    for (auto& kv : free_) for (void* p : kv.second) (void)hipFree(p);
+    free_.clear(); cached_ = 0;
+}
+void* Pool::alloc(size_t bytes, size_t* rounded) {
+    size_t r = round_size(bytes);
+    *rounded = r;
+    auto it = free_.find(r);
+    if (it != free_.end() && !it->second.empty()) {
+        void* p = it->second.back(); it->second.pop_back(); cached_ -= r; live_ += r; return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, r);
+    if (e != hipSuccess) { trim(); e = hipMalloc(&p, r); }
+    hipchk(e, "hipMalloc");
+    live_ += r;
+    return p;
+}
+void Pool::release(void* p, size_t rounded) {
+    live_ -= rounded; cached_ += rounded;
+    free_[rounded].push_back(p);
+}
+static Buf dalloc(State* s, size_t bytes) {
+    auto b = std::make_shared<DevBuf>();
+    b->pool = s->pool; b->bytes = bytes;
+    b->p = s->pool->alloc(bytes ? bytes : 1, &b->rounded);
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// graph
+// ---------------------------------------------------------------------------------------------------------------
+static uint64_t ekey(int a, int b) { if (a > b) std::swap(a, b); return (uint64_t(uint32_t(a)) << 32) | uint32_t(b); }
+int Graph::edge(int u, int v) const { auto it = emap.find(ekey(u, v)); return it == emap.end() ? -1 : it->second; }
+int Graph::leg(int v, int w) const {
+    const auto& n = nbr[v];
+    auto it = std::lower_bound(n.begin(), n.end(), w);
+    return (it != n.end() && *it == w) ? int(it - n.begin()) : -1;
+}
+int Graph::dedge(int src, int dst) const { int e = edge(src, dst); if (e < 0) return -1; return 2 * e + (src == edst[e] ? 1 : 0); }
+
+static std::shared_ptr<Graph> make_graph(int nv, int ne, const int32_t* es, const int32_t* ed) {
+    auto g = std::make_shared<Graph>();
+    g->nv = nv; g->ne = ne; g->esrc.assign(es, es + ne); g->edst.assign(ed, ed + ne);
+    g->nbr.resize(nv); g->nbr_e.resize(nv);
+    for (int e = 0; e < ne; ++e) {
+        int a = es[e], b = ed[e];
+        if (a < 0 || a >= nv || b < 0 || b >= nv || a == b) throw Err(TNQS_ERR_INVALID, "tnqs_create: bad edge endpoints");
+        if (g->emap.count(ekey(a, b))) throw Err(TNQS_ERR_INVALID, "tnqs_create: duplicate edge");
+        g->emap[ekey(a, b)] = e;
+    }
+    for (int v = 0; v < nv; ++v) {
+        std::vector<std::pair<int, int>> tmp;
+        for (int e = 0; e < ne; ++e) { if (es[e] == v) tmp.push_back({ed[e], e}); else if (ed[e] == v) tmp.push_back({es[e], e}); }
+        std::sort(tmp.begin(), tmp.end());
+        for (auto& p : tmp) { g->nbr[v].push_back(p.first); g->nbr_e[v].push_back(p.second); }
+    }
+    // forest test (union-find)
+    std::vector<int> par(nv); std::iota(par.begin(), par.end(), 0);
+    auto find = [&](int x) { while (par[x] != x) { par[x] = par[par[x]]; x = par[x]; } return x; };
+    g->is_tree = true;
+    for (int e = 0; e < ne; ++e) { int a = find(es[e]), b = find(ed[e]); if (a == b) { g->is_tree = false; break; } par[a] = b; }
+    // greedy proper edge colouring in edge order
+    g->ecolor.assign(ne, -1);
+    std::vector<std::vector<char>> used(nv);
+    for (int e = 0; e < ne; ++e) {
+        int a = es[e], b = ed[e], c = 0;
+        for (;; ++c) {
+            bool ua = c < (int)used[a].size() && used[a][c], ub = c < (int)used[b].size() && used[b][c];
+            if (!ua && !ub) break;
+        }
+        if ((int)used[a].size() <= c) used[a].resize(c + 1, 0);
+        if ((int)used[b].size() <= c) used[b].resize(c + 1, 0);
+        used[a][c] = used[b][c] = 1; g->ecolor[e] = c; g->ncolors = std::max(g->ncolors, c + 1);
+    }
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// state plumbing
+// ---------------------------------------------------------------------------------------------------------------
+struct HostArena {   // pinned staging for descriptor uploads, reset at host sync points
+    char* base = nullptr; size_t cap = 0, off = 0;
+};
+static thread_local std::unordered_map<State*, HostArena> g_arenas;
+
+State::~State() {
+    auto it = g_arenas.find(this);
+    if (it != g_arenas.end()) { if (it->second.base) (void)hipHostFree(it->second.base); g_arenas.erase(it); }
+    for (auto& p : prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : ev_free) (void)hipEventDestroy(e);
+    keepalive.clear(); site.clear(); msg.clear();
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+static void sync(State* s) {
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->keepalive.clear();
+    auto it = g_arenas.find(s);
+    if (it != g_arenas.end()) it->second.off = 0;
+}
+
+template <class Item> static const Item* upload(State* s, const std::vector<Item>& v) {
+    if (v.empty()) return nullptr;
+    size_t bytes = v.size() * sizeof(Item);
+    HostArena& ar = g_arenas[s];
+    if (!ar.base) { ar.cap = size_t(32) << 20; HIPCHK(hipHostMalloc((void**)&ar.base, ar.cap, hipHostMallocDefault)); }
+    size_t aligned = (bytes + 255) & ~size_t(255);
+    if (aligned > ar.cap) throw Err(TNQS_ERR_UNSUPPORTED, "descriptor batch too large");
+    if (ar.off + aligned > ar.cap) sync(s);
+    char* h = ar.base + ar.off; ar.off += aligned;
+    std::memcpy(h, v.data(), bytes);
+    Buf b = dalloc(s, bytes);
+    HIPCHK(hipMemcpyAsync(b->p, h, bytes, hipMemcpyHostToDevice, s->stream));
+    s->keepalive.push_back(b);
+    return reinterpret_cast<const Item*>(b->p);
+}
+
+struct ProfScope {
+    State* s; int cls; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(State* st, int c, double bytes, double flops) : s(st), cls(c) {
+        if (!s->prof_on) return;
+        s->prof[c].bytes += bytes; s->prof[c].flops += flops; s->prof[c].launches += 1;
+        auto get = [&]() { hipEvent_t e; if (!s->ev_free.empty()) { e = s->ev_free.back(); s->ev_free.pop_back(); } else HIPCHK(hipEventCreate(&e)); return e; };
+        a = get(); b = get();
+        HIPCHK(hipEventRecord(a, s->stream));
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, s->stream);
+        s->prof_pending.push_back({cls, a, b});
+    }
+};
+void prof_collect(State* s) {
+    if (s->prof_pending.empty()) return;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (auto& p : s->prof_pending) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b);
+        s->prof[p.cls].ms += ms;
+        s->ev_free.push_back(p.a); s->ev_free.push_back(p.b);
+    }
+    s->prof_pending.clear();
+}
+
+struct SD {       // dims of a site tensor in canonical layout
+    int z = 0, d = 1; std::vector<int> chi; size_t n = 1;
+    size_t pre(int j) const { size_t p = d; for (int i = 0; i < j; ++i) p *= chi[i]; return p; }
+    size_t post(int j) const { size_t p = 1; for (int i = j + 1; i < z; ++i) p *= chi[i]; return p; }
+};
+static SD site_dims(const State* s, int v) {
+    SD r; const Graph& g = *s->g;
+    r.z = (int)g.nbr[v].size(); r.d = s->d[v]; r.n = r.d;
+    for (int j = 0; j < r.z; ++j) { int c = s->chi[g.nbr_e[v][j]]; r.chi.push_back(c); r.n *= c; }
+    return r;
+}
+int64_t state_site_size(const State* s, int v) { return (int64_t)site_dims(s, v).n; }
+
+template <class T> static void fill_product_up(State* s, int v) {
+    // |up> = (1, 0, ...) with all bonds of dimension 1 (tensornetworkstate.jl:141-161)
+    std::vector<T> h(2 * s->d[v], T(0)); h[0] = T(1);
+    Buf b = dalloc(s, s->d[v] * s->esz());
+    HIPCHK(hipMemcpyAsync(b->p, h.data(), s->d[v] * s->esz(), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->site[v] = b;
+}
+
+State* state_create(int nv, int ne, const int32_t* es, const int32_t* ed, const int32_t* sd, int dtype, int device) {
+    if (nv <= 0 || ne < 0) throw Err(TNQS_ERR_INVALID, "tnqs_create: nv must be > 0 and ne >= 0");
+    if (dtype != TNQS_C64 && dtype != TNQS_C128) throw Err(TNQS_ERR_UNSUPPORTED, "tnqs_create: only TNQS_C64 / TNQS_C128 are implemented");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw Err(TNQS_ERR_HIP, "tnqs_create: no HIP device available (the HIP path has no CPU fallback)");
+    if (device < 0 || device >= ndev) throw Err(TNQS_ERR_INVALID, "tnqs_create: bad device index");
+    HIPCHK(hipSetDevice(device));
+    auto s = std::make_unique<State>();
+    s->g = make_graph(nv, ne, es, ed);
+    s->dtype = dtype; s->device = device;
+    s->d.assign(nv, 2);
+    if (sd) for (int v = 0; v < nv; ++v) { if (sd[v] < 1 || sd[v] > 16) throw Err(TNQS_ERR_INVALID, "tnqs_create: site dimension out of range"); s->d[v] = sd[v]; }
+    s->chi.assign(ne, 1);
+    s->site.resize(nv); s->msg.assign(2 * (size_t)ne, nullptr);
+    s->pool = std::make_shared<Pool>(device);
+    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true;
+    for (int v = 0; v < nv; ++v) { if (dtype == TNQS_C64) fill_product_up<float>(s.get(), v); else fill_product_up<double>(s.get(), v); }
+    return s.release();
+}
+
+State* state_copy(const State* o) {
+    auto s = std::make_unique<State>();
+    s->g = o->g; s->dtype = o->dtype; s->device = o->device; s->d = o->d; s->chi = o->chi;
+    s->site = o->site; s->msg = o->msg; s->pool = o->pool;
+    s->rank = o->rank; s->nranks = o->nranks; s->owner = o->owner; s->ag_fn = o->ag_fn; s->ag_ctx = o->ag_ctx;
+    HIPCHK(hipSetDevice(o->device));
+    if (o->own_stream) { HIPCHK(hipStreamSynchronize(o->stream)); HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
+    else { s->stream = o->stream; s->own_stream = false; }
+    return s.release();
+}
+
+template <class T> static void permute_dispatch(State* s, const PermItem& it) { launch_permute<T>(s->stream, it); }
+
+void state_set_site(State* s, int v, const void* host, int ndim, const int64_t* dims, const int32_t* role) {
+    const Graph& g = *s->g;
+    if (v < 0 || v >= g.nv) throw Err(TNQS_ERR_INVALID, "set_site_tensor: bad vertex");
+    const int z = (int)g.nbr[v].size();
+    if (ndim != z + 1 || ndim > 8) throw Err(TNQS_ERR_INVALID, "set_site_tensor: tensor must have one site leg and one leg per neighbour (<= 7 neighbours)");
+    // caller axis k -> canonical axis
+    std::vector<int> canon_of(ndim, -1); std::vector<int> src_of(ndim, -1);
+    for (int k = 0; k < ndim; ++k) {
+        int c;
+        if (role[k] < 0) c = 0;
+        else { int j = g.leg(v, role[k]); if (j < 0) throw Err(TNQS_ERR_INVALID, "set_site_tensor: leg_role names a non-neighbour"); c = 1 + j; }
+        if (src_of[c] >= 0) throw Err(TNQS_ERR_INVALID, "set_site_tensor: duplicate leg role");
+        canon_of[k] = c; src_of[c] = k;
+    }
+    if (dims[src_of[0]] != s->d[v]) throw Err(TNQS_ERR_INVALID, "set_site_tensor: site dimension mismatch");
+    size_t n = 1; std::vector<long long> stride_caller(ndim);
+    for (int k = 0; k < ndim; ++k) { stride_caller[k] = (long long)n; if (dims[k] < 1) throw Err(TNQS_ERR_INVALID, "set_site_tensor: bad dim"); n *= (size_t)dims[k]; }
+    HIPCHK(hipSetDevice(s->device));
+    Buf raw = dalloc(s, n * s->esz());
+    HIPCHK(hipMemcpyAsync(raw->p, host, n * s->esz(), hipMemcpyHostToDevice, s->stream));
+    Buf out = dalloc(s, n * s->esz());
+    PermItem it{}; it.in = raw->p; it.out = out->p; it.ndim = ndim; it.n = n;
+    for (int c = 0; c < ndim; ++c) { it.dims_out[c] = (int)dims[src_of[c]]; it.stride_in[c] = stride_caller[src_of[c]]; }
+    if (s->dtype == TNQS_C64) permute_dispatch<float>(s, it); else permute_dispatch<double>(s, it);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->site[v] = out;
+    for (int j = 0; j < z; ++j) {
+        int e = g.nbr_e[v][j]; int c = it.dims_out[1 + j];
+        if (s->chi[e] != c) { s->chi[e] = c; s->msg[2 * e] = nullptr; s->msg[2 * e + 1] = nullptr; }
+    }
+}
+
+void state_get_site(State* s, int v, void* host, int ndim, const int32_t* role) {
+    const Graph& g = *s->g;
+    if (v < 0 || v >= g.nv) throw Err(TNQS_ERR_INVALID, "get_site_tensor: bad vertex");
+    if (!s->site[v]) throw Err(TNQS_ERR_INVALID, "get_site_tensor: vertex not owned by this rank");
+    SD sd = site_dims(s, v);
+    if (ndim != sd.z + 1 || ndim > 8) throw Err(TNQS_ERR_INVALID, "get_site_tensor: ndim mismatch");
+    // consistency: the neighbour tensors must agree on bond dims; verify buffer size
+    if (s->site[v]->bytes != sd.n * s->esz()) throw Err(TNQS_ERR_INVALID, "get_site_tensor: bond dimensions are inconsistent with the stored tensor (set all neighbours first)");
+    std::vector<int> cdims(ndim); std::vector<long long> cstride(ndim);
+    cdims[0] = sd.d; for (int j = 0; j < sd.z; ++j) cdims[1 + j] = sd.chi[j];
+    { long long st = 1; for (int c = 0; c < ndim; ++c) { cstride[c] = st; st *= cdims[c]; } }
+    PermItem it{}; it.in = s->site[v]->p; it.ndim = ndim; it.n = sd.n;
+    std::vector<char> seen(ndim, 0);
+    for (int k = 0; k < ndim; ++k) {
+        int c;
+        if (role[k] < 0) c = 0; else { int j = g.leg(v, role[k]); if (j < 0) throw Err(TNQS_ERR_INVALID, "get_site_tensor: leg_role names a non-neighbour"); c = 1 + j; }
+        if (seen[c]) throw Err(TNQS_ERR_INVALID, "get_site_tensor: duplicate leg role"); seen[c] = 1;
+        it.dims_out[k] = cdims[c]; it.stride_in[k] = cstride[c];
+    }
+    HIPCHK(hipSetDevice(s->device));
+    Buf out = dalloc(s, sd.n * s->esz()); it.out = out->p;
+    if (s->dtype == TNQS_C64) permute_dispatch<float>(s, it); else permute_dispatch<double>(s, it);
+    HIPCHK(hipMemcpyAsync(host, out->p, sd.n * s->esz(), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+}
+
+void state_set_message(State* s, int src, int dst, const void* host, int chi) {
+    int de = s->g->dedge(src, dst);
+    if (de < 0) throw Err(TNQS_ERR_INVALID, "set_message: not an edge");
+    if (chi != s->chi[de / 2]) throw Err(TNQS_ERR_INVALID, "set_message: dimension does not match the bond");
+    HIPCHK(hipSetDevice(s->device));
+    Buf b = dalloc(s, (size_t)chi * chi * s->esz());
+    HIPCHK(hipMemcpyAsync(b->p, host, (size_t)chi * chi * s->esz(), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->msg[de] = b;
+}
+void state_get_message(State* s, int src, int dst, void* host, int chi) {
+    int de = s->g->dedge(src, dst);
+    if (de < 0) throw Err(TNQS_ERR_INVALID, "get_message: not an edge");
+    if (chi != s->chi[de / 2]) throw Err(TNQS_ERR_INVALID, "get_message: dimension does not match the bond");
+    HIPCHK(hipSetDevice(s->device));
+    size_t bytes = (size_t)chi * chi * s->esz();
+    if (!s->msg[de]) {      // default_message: identity
+        std::memset(host, 0, bytes);
+        for (int i = 0; i < chi; ++i) {
+            if (s->dtype == TNQS_C64) reinterpret_cast<float*>(host)[2 * (size_t)(i + (size_t)chi * i)] = 1.f;
+            else reinterpret_cast<double*>(host)[2 * (size_t)(i + (size_t)chi * i)] = 1.0;
+        }
+        return;
+    }
+    HIPCHK(hipMemcpyAsync(host, s->msg[de]->p, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// batched building blocks
+// ---------------------------------------------------------------------------------------------------------------
+static int pick_TR(size_t KK, size_t esz, int copies) {
+    for (int tr : {64, 32, 16}) if (KK * tr * esz * copies <= 64 * 1024) return tr;
+    throw Err(TNQS_ERR_UNSUPPORTED, "bond dimension too large for the fiber-tile kernels (d*chi*16*elemsize must fit 64 KiB of LDS)");
+}
+static void tile_params(size_t PA, size_t PB, int TR, int& TA, int& TB, int& nta, int& ntb) {
+    TA = (int)std::min<size_t>(PA, TR); TB = std::max(1, TR / TA); TB = (int)std::min<size_t>(TB, PB);
+    nta = (int)((PA + TA - 1) / TA); ntb = (int)((PB + TB - 1) / TB);
+}
+
+// a chain = one site tensor pushed through several mode products (leg j with matrix X_j, chi_j x chi_j)
+struct Chain {
+    int v = -1; const void* src = nullptr; SD sd;
+    std::vector<std::pair<int, const void*>> steps;
+    const void* result = nullptr; Buf tmp[2];
+};
+
+template <class T> static void run_chains(State* s, std::vector<Chain>& chains, int cls) {
+    size_t maxsteps = 0;
+    for (auto& c : chains) { maxsteps = std::max(maxsteps, c.steps.size()); c.result = c.src; }
+    const size_t esz = s->esz();
+    for (size_t o = 0; o < maxsteps; ++o) {
+        std::vector<FiberItem> items; int tiles = 0; size_t KKmax = 1; double bytes = 0, flops = 0;
+        for (auto& c : chains) if (c.steps.size() > o) KKmax = std::max<size_t>(KKmax, c.sd.chi[c.steps[o].first]);
+        const int TR = pick_TR(KKmax, esz, 1);
+        for (auto& c : chains) {
+            if (c.steps.size() <= o) continue;
+            int j = c.steps[o].first;
+            FiberItem it{};
+            Buf& dst = c.tmp[o & 1];
+            if (!dst) dst = dalloc(s, c.sd.n * esz);
+            it.in = c.result; it.out = dst->p; it.X = c.steps[o].second;
+            it.D = 1; it.PA = (int)c.sd.pre(j); it.K = c.sd.chi[j]; it.PB = (int)c.sd.post(j); it.Do = 1; it.No = it.K;
+            tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
+            it.tile_begin = tiles; tiles += it.nta * it.ntb; it.want_norm = 0;
+            items.push_back(it);
+            c.result = dst->p;
+            bytes += 2.0 * c.sd.n * esz; flops += 8.0 * c.sd.n * it.K;
+        }
+        const FiberItem* d = upload(s, items);
+        ProfScope ps(s, cls, bytes, flops);
+        launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, nullptr);
+    }
+}
+
+struct GramJob {      // out[i,j] = sum X[i,.] conj(Y[j,.]) over everything but the kept index (s and/or leg)
+    const void* X; const void* Y; SD sd; int leg;  /* -1: keep the site index only */ bool keep_site;
+    Buf partial; int nchunks = 0; int KK = 0;
+};
+template <class T, class Acc> static void run_grams(State* s, std::vector<GramJob>& jobs, int cls) {
+    if (jobs.empty()) return;
+    const size_t esz = s->esz();
+    size_t KKmax = 1;
+    for (auto& j : jobs) { j.KK = (j.keep_site ? j.sd.d : 1) * (j.leg >= 0 ? j.sd.chi[j.leg] : 1); KKmax = std::max<size_t>(KKmax, j.KK); }
+    const int TR = pick_TR(KKmax + 1, esz, 2);
+    const int target = 2048;
+    int per_item = std::max(1, target / (int)jobs.size());
+    std::vector<GramItem> items; int chunks = 0; double bytes = 0, flops = 0;
+    for (auto& j : jobs) {
+        GramItem it{};
+        it.X = j.X; it.Y = j.Y;
+        if (j.leg >= 0) {
+            size_t pre = j.sd.pre(j.leg);
+            if (j.keep_site) { it.D = j.sd.d; it.PA = (int)(pre / j.sd.d); } else { it.D = 1; it.PA = (int)pre; }
+            it.K = j.sd.chi[j.leg]; it.PB = (int)j.sd.post(j.leg);
+        } else { it.D = j.sd.d; it.PA = (int)(j.sd.n / j.sd.d); it.K = 1; it.PB = 1; }
+        tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
+        int ntiles = it.nta * it.ntb;
+        int nch = std::min(per_item, ntiles);
+        it.tiles_per_chunk = (ntiles + nch - 1) / nch;
+        it.nchunks = (ntiles + it.tiles_per_chunk - 1) / it.tiles_per_chunk;
+        j.nchunks = it.nchunks;
+        j.partial = dalloc(s, (size_t)it.nchunks * j.KK * j.KK * 2 * sizeof(Acc));
+        it.partial = j.partial->p; it.chunk_begin = chunks; chunks += it.nchunks;
+        items.push_back(it);
+        bytes += (j.X == j.Y ? 1.0 : 2.0) * j.sd.n * esz; flops += 8.0 * j.sd.n * j.KK;
+    }
+    const GramItem* d = upload(s, items);
+    ProfScope ps(s, cls, bytes, flops);
+    launch_gram<T, Acc>(s->stream, d, (int)items.size(), chunks, TR, (int)KKmax);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BP update  (abstractbeliefpropagationcache.jl:223-259; Gauss-Seidel over edge_sequence, executed level by level)
+// ---------------------------------------------------------------------------------------------------------------
+struct BPPlan {
+    std::vector<int> seq;                       // directed edge ids in sequence order
+    std::vector<std::vector<int>> levels;       // positions in seq grouped by dependency level
+    std::vector<int> pos_of;                    // de -> position in seq or -1
+    bool in_place = false;                      // duplicates in the sequence: strictly sequential, single buffer
+};
+
+static std::vector<int> default_sequence(const Graph& g) {
+    // edge-colour grouped order: within one colour no message depends on another, so each colour is one level
+    std::vector<int> seq;
+    for (int c = 0; c < g.ncolors; ++c) {
+        for (int e = 0; e < g.ne; ++e) if (g.ecolor[e] == c) seq.push_back(2 * e);
+        for (int e = 0; e < g.ne; ++e) if (g.ecolor[e] == c) seq.push_back(2 * e + 1);
+    }
+    return seq;
+}
+
+static BPPlan make_plan(const State* s, const tnqs_bp_opts* o) {
+    const Graph& g = *s->g;
+    BPPlan p;
+    if (o && o->n_sequence > 0) {
+        for (int i = 0; i < o->n_sequence; ++i) {
+            int de = g.dedge(o->seq_src[i], o->seq_dst[i]);
+            if (de < 0) throw Err(TNQS_ERR_INVALID, "bp_update: edge_sequence contains a pair of non-adjacent vertices");
+            p.seq.push_back(de);
+        }
+    } else p.seq = default_sequence(g);
+    p.pos_of.assign(2 * (size_t)g.ne, -1);
+    for (size_t t = 0; t < p.seq.size(); ++t) { if (p.pos_of[p.seq[t]] >= 0) p.in_place = true; p.pos_of[p.seq[t]] = (int)t; }
+    if (p.in_place) { for (size_t t = 0; t < p.seq.size(); ++t) p.levels.push_back({(int)t}); return p; }
+    std::vector<int> level(p.seq.size(), 0); int nlev = 0;
+    for (size_t t = 0; t < p.seq.size(); ++t) {
+        int de = p.seq[t]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
+        int lv = 0;
+        for (size_t j = 0; j < g.nbr[src].size(); ++j) {
+            int k = g.nbr[src][j]; if (k == dst) continue;
+            int din = g.dedge(k, src); int pp = p.pos_of[din];
+            if (pp >= 0 && pp < (int)t) lv = std::max(lv, level[pp] + 1);
+        }
+        level[t] = lv; nlev = std::max(nlev, lv + 1);
+    }
+    p.levels.resize(nlev);
+    for (size_t t = 0; t < p.seq.size(); ++t) p.levels[level[t]].push_back((int)t);
+    return p;
+}
+
+static double default_tol(const State* s) { return s->dtype == TNQS_C64 ? 1e-5 : 1e-8; }   // beliefpropagationcache.jl:104-108
+
+template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out) {
+    const Graph& g = *s->g;
+    HIPCHK(hipSetDevice(s->device));
+    BPPlan plan = make_plan(s, o);
+    int maxiter = (o && o->maxiter > 0) ? o->maxiter : (g.is_tree ? 1 : 25);                  // :39,:103
+    double tol;
+    if (!o || std::isnan(o->tolerance)) tol = g.is_tree ? -1.0 : default_tol(s); else tol = o->tolerance;
+    const bool compute_error = tol >= 0;
+    const int normalize = o ? o->normalize : 1;
+    const size_t esz = s->esz();
+    const size_t nseq = plan.seq.size();
+    if (nseq == 0) { if (niter_out) *niter_out = 0; if (diff_out) *diff_out = 0; return; }
+    Buf d_diffs = dalloc(s, nseq * sizeof(double));
+    Buf d_sum = dalloc(s, sizeof(double));
+    std::vector<Buf> cur = s->msg;
+    int niter = maxiter; double avg = 0; bool converged = false;
+    for (int iter = 1; iter <= maxiter; ++iter) {
+        std::vector<Buf> fresh(2 * (size_t)g.ne);
+        for (auto& lev : plan.levels) {
+            // sub-batches bounded by workspace bytes
+            size_t start = 0;
+            while (start < lev.size()) {
+                size_t budget = size_t(24) << 30, used = 0, end = start;
+                while (end < lev.size()) {
+                    int de = plan.seq[lev[end]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
+                    size_t need = 2 * site_dims(s, src).n * esz;
+                    if (end > start && used + need > budget) break;
+                    used += need; ++end;
+                }
+                std::vector<Chain> chains; std::vector<int> tpos;
+                for (size_t q = start; q < end; ++q) {
+                    int t = lev[q]; int de = plan.seq[t]; int e = de / 2;
+                    int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
+                    if (!s->owns(src)) continue;
+                    Chain c; c.v = src; c.src = s->site[src]->p; c.sd = site_dims(s, src);
+                    for (int j = 0; j < c.sd.z; ++j) {
+                        int k = g.nbr[src][j]; if (k == dst) continue;
+                        int din = g.dedge(k, src); int pp = plan.pos_of[din];
+                        const Buf& mb = (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
+                        if (mb) c.steps.push_back({j, mb->p});        // unset message = identity: nothing to absorb
+                    }
+                    chains.push_back(std::move(c)); tpos.push_back(t);
+                }
+                run_chains<T>(s, chains, TNQS_PROF_BP_MODEPROD);
+                std::vector<GramJob> jobs;
+                for (size_t i = 0; i < chains.size(); ++i) {
+                    int de = plan.seq[tpos[i]]; int e = de / 2; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
+                    GramJob j{}; j.X = chains[i].result; j.Y = chains[i].src; j.sd = chains[i].sd; j.leg = g.leg(chains[i].v, dst); j.keep_site = false;
+                    jobs.push_back(j);
+                }
+                run_grams<T, T>(s, jobs, TNQS_PROF_BP_GRAM);
+                std::vector<MsgFinalItem> fin;
+                for (size_t i = 0; i < jobs.size(); ++i) {
+                    int t = tpos[i]; int de = plan.seq[t]; int c = s->chi[de / 2];
+                    Buf nb = dalloc(s, (size_t)c * c * esz);
+                    MsgFinalItem f{}; f.partial = jobs[i].partial->p; f.nchunks = jobs[i].nchunks; f.chi = c;
+                    const Buf& oldb = plan.in_place && fresh[de] ? fresh[de] : cur[de];
+                    f.old_msg = oldb ? oldb->p : nullptr; f.new_msg = nb->p;
+                    f.diff_out = reinterpret_cast<double*>(d_diffs->p) + t; f.normalize = normalize;
+                    fin.push_back(f);
+                    fresh[de] = nb;
+                }
+                {
+                    const MsgFinalItem* d = upload(s, fin);
+                    ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
+                    launch_msg_finalize<T>(s->stream, d, (int)fin.size());
+                }
+                start = end;
+            }
+        }
+        for (size_t t = 0; t < nseq; ++t) if (fresh[plan.seq[t]]) cur[plan.seq[t]] = fresh[plan.seq[t]];
+        s->stats.n_bp_sweeps += 1;
+        if (compute_error) {
+            launch_sum_doubles(s->stream, reinterpret_cast<const double*>(d_diffs->p), (int)nseq, reinterpret_cast<double*>(d_sum->p));
+            double tot = 0;
+            HIPCHK(hipMemcpyAsync(&tot, d_sum->p, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            sync(s);
+            avg = tot / (double)nseq;
+            if (avg <= tol) { converged = true; niter = iter; break; }
+        }
+    }
+    sync(s);
+    s->msg = cur;
+    s->stats.n_bp_updates += 1;
+    if (compute_error && !converged) s->stats.bp_not_converged += 1;
+    s->stats.last_bp_diff = avg;
+    if (niter_out) *niter_out = niter;
+    if (diff_out) *diff_out = compute_error ? avg : -1.0;
+}
+
+void bp_update(State* s, const tnqs_bp_opts* o, int* niter, double* diff) {
+    if (s->dtype == TNQS_C64) bp_update_t<float>(s, o, niter, diff); else bp_update_t<double>(s, o, niter, diff);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gates
+// ---------------------------------------------------------------------------------------------------------------
+struct Gate1 { int v; const double* mat; };
+struct Gate2 { int v1, v2; const double* mat; int index; };
+
+template <class T> static void norm_and_replace(State* s, std::vector<int>& verts, std::vector<Buf>& outs,
+                                                std::vector<size_t>& nelem, Buf norm_partials,
+                                                std::vector<int>& tile_begin, std::vector<int>& ntiles, bool normalize) {
+    if (normalize) {
+        std::vector<ScaleItem> sc;
+        for (size_t i = 0; i < verts.size(); ++i) {
+            ScaleItem it{}; it.t = outs[i]->p; it.n = nelem[i];
+            it.norm_partials = reinterpret_cast<const double*>(norm_partials->p) + tile_begin[i]; it.npart = ntiles[i];
+            sc.push_back(it);
+        }
+        const ScaleItem* d = upload(s, sc);
+        ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
+        launch_scale<T>(s->stream, d, (int)sc.size());
+    }
+    for (size_t i = 0; i < verts.size(); ++i) s->site[verts[i]] = outs[i];
+}
+
+template <class T> static void apply_one_site_batch(State* s, const std::vector<Gate1>& gates, bool normalize) {
+    if (gates.empty()) return;
+    const size_t esz = s->esz();
+    std::vector<FiberItem> items; std::vector<int> verts, tb, nt; std::vector<Buf> outs; std::vector<size_t> ne;
+    int tiles = 0; size_t KKmax = 1; double bytes = 0, flops = 0;
+    for (auto& g1 : gates) KKmax = std::max<size_t>(KKmax, s->d[g1.v]);
+    const int TR = pick_TR(KKmax, esz, 1);
+    std::vector<T> hx;       // X[kk + d*nn] = G[nn, kk]  (out[s'] = sum_s G[s', s] psi[s], simple_update.jl:27)
+    std::vector<size_t> xoff;
+    for (auto& g1 : gates) {
+        int d = s->d[g1.v]; xoff.push_back(hx.size());
+        for (int nn = 0; nn < d; ++nn) for (int kk = 0; kk < d; ++kk) { hx.push_back((T)g1.mat[2 * (nn + d * kk)]); hx.push_back((T)g1.mat[2 * (nn + d * kk) + 1]); }
+    }
+    // note: column-major X means index kk + d*nn; the loop above emits nn-major order, i.e. X[kk + d*nn] at position nn*d + kk
+    const char* dxp;
+    {
+        std::vector<char> raw(reinterpret_cast<char*>(hx.data()), reinterpret_cast<char*>(hx.data()) + hx.size() * sizeof(T));
+        dxp = upload(s, raw);
+    }
+    size_t gi = 0;
+    for (auto& g1 : gates) {
+        if (!s->owns(g1.v)) { ++gi; continue; }
+        SD sd = site_dims(s, g1.v);
+        FiberItem it{}; Buf out = dalloc(s, sd.n * esz);
+        it.in = s->site[g1.v]->p; it.out = out->p; it.X = dxp + xoff[gi] * sizeof(T);
+        it.D = sd.d; it.PA = (int)(sd.n / sd.d); it.K = 1; it.PB = 1; it.Do = sd.d; it.No = 1;
+        tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
+        it.tile_begin = tiles; it.want_norm = normalize ? 1 : 0;
+        verts.push_back(g1.v); outs.push_back(out); ne.push_back(sd.n); tb.push_back(tiles); nt.push_back(it.nta * it.ntb);
+        tiles += it.nta * it.ntb; items.push_back(it);
+        bytes += 2.0 * sd.n * esz; flops += 8.0 * sd.n * sd.d;
+        ++gi;
+    }
+    if (items.empty()) return;
+    Buf np = dalloc(s, std::max(1, tiles) * sizeof(double));
+    const FiberItem* d = upload(s, items);
+    { ProfScope ps(s, TNQS_PROF_GATE_APPLY, bytes, flops);
+      launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
+    norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, normalize);
+}
+
+template <class T> static void apply_two_site_batch(State* s, const std::vector<Gate2>& gates, const tnqs_apply_opts& ao, double* errs) {
+    if (gates.empty()) return;
+    const Graph& g = *s->g;
+    const size_t esz = s->esz();
+    const double sqrt_cutoff = ao.sqrt_cutoff >= 0 ? ao.sqrt_cutoff : 10.0 * (s->dtype == TNQS_C64 ? 1.1920928955078125e-07 : 2.220446049250313e-16);
+    const int ng = (int)gates.size();
+    struct SiteJob { int v, other, bleg; SD sd; std::vector<int> env_idx; std::vector<int> env_leg; };
+    std::vector<SiteJob> sj(2 * (size_t)ng);
+    // ---- 1. environments: sqrt(M) and projector for every incoming message (utils.jl:18-27) ---------------------
+    struct EnvRec { int de; int n; Buf H, V, msq, prj, flags; };
+    std::vector<EnvRec> envs;
+    for (int gi = 0; gi < ng; ++gi) {
+        for (int side = 0; side < 2; ++side) {
+            SiteJob& j = sj[2 * gi + side];
+            j.v = side == 0 ? gates[gi].v1 : gates[gi].v2; j.other = side == 0 ? gates[gi].v2 : gates[gi].v1;
+            j.sd = site_dims(s, j.v); j.bleg = g.leg(j.v, j.other);
+            for (int l = 0; l < j.sd.z; ++l) {
+                if (l == j.bleg) continue;
+                int de = g.dedge(g.nbr[j.v][l], j.v);
+                if (!s->msg[de]) continue;                  // identity message: sqrt = I, nothing to absorb
+                EnvRec r; r.de = de; r.n = j.sd.chi[l];
+                j.env_idx.push_back((int)envs.size()); j.env_leg.push_back(l);
+                envs.push_back(r);
+            }
+        }
+    }
+    std::vector<int> h_flags(2 * envs.size() + 2, 0);
+    Buf d_flags = dalloc(s, h_flags.size() * sizeof(int));
+    {
+        std::vector<EnvItem> ei; std::vector<JacobiItem> ji; std::vector<EnvFinishItem> fi;
+        for (size_t i = 0; i < envs.size(); ++i) {
+            EnvRec& r = envs[i]; size_t nn = (size_t)r.n * r.n;
+            r.H = dalloc(s, nn * 16); r.V = dalloc(s, nn * 16); r.msq = dalloc(s, nn * esz); r.prj = dalloc(s, nn * esz);
+            ei.push_back(EnvItem{s->msg[r.de]->p, r.H->p, r.V->p, r.n});
+            ji.push_back(JacobiItem{r.H->p, r.V->p, r.n, r.n, nullptr});
+            fi.push_back(EnvFinishItem{r.H->p, r.V->p, r.msq->p, r.prj->p, r.n, sqrt_cutoff, reinterpret_cast<int*>(d_flags->p) + 2 * i});
+        }
+        if (!envs.empty()) {
+            const EnvItem* de = upload(s, ei); const JacobiItem* dj = upload(s, ji); const EnvFinishItem* df = upload(s, fi);
+            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, de, (int)ei.size()); }
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60); }
+            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_finish<T>(s->stream, df, (int)fi.size()); }
+        }
+    }
+    // ---- 2. gauge: psi~ = psi x_outer M^{1/2}  (simple_update.jl:43-44) ----------------------------------------------
+    std::vector<Chain> chains(2 * (size_t)ng);
+    for (size_t i = 0; i < sj.size(); ++i) {
+        Chain& c = chains[i]; c.v = sj[i].v; c.src = s->site[sj[i].v]->p; c.sd = sj[i].sd;
+        for (size_t q = 0; q < sj[i].env_idx.size(); ++q) c.steps.push_back({sj[i].env_leg[q], envs[sj[i].env_idx[q]].msq->p});
+    }
+    run_chains<T>(s, chains, TNQS_PROF_GATE_MODEPROD);
+    // ---- 3. G = psi~^dagger psi~ over the outer legs, f64 accumulation (replaces the thin QR, simple_update.jl:45-48) --
+    std::vector<GramJob> jobs;
+    for (size_t i = 0; i < sj.size(); ++i) {
+        GramJob j{}; j.X = chains[i].result; j.Y = chains[i].result; j.sd = sj[i].sd; j.leg = sj[i].bleg; j.keep_site = true;
+        jobs.push_back(j);
+    }
+    run_grams<T, double>(s, jobs, TNQS_PROF_GATE_GRAM);
+    std::vector<Buf> GA(sj.size()), GV(sj.size());
+    {
+        std::vector<ReduceItem> ri; std::vector<EnvItem> idn; std::vector<JacobiItem> ji; int elems = 0;
+        for (size_t i = 0; i < sj.size(); ++i) {
+            int n = jobs[i].KK; size_t nn = (size_t)n * n;
+            GA[i] = dalloc(s, nn * 16); GV[i] = dalloc(s, nn * 16);
+            ri.push_back(ReduceItem{jobs[i].partial->p, GA[i]->p, (int)nn, jobs[i].nchunks, 1, elems}); elems += (int)nn;
+            ji.push_back(JacobiItem{GA[i]->p, GV[i]->p, n, n, nullptr});
+        }
+        const ReduceItem* dr = upload(s, ri);
+        { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, dr, (int)ri.size(), elems); }
+        for (size_t i = 0; i < sj.size(); ++i) launch_identity<double>(s->stream, GV[i]->p, jobs[i].KK);
+        const JacobiItem* dj = upload(s, ji);
+        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60); }
+    }
+    // ---- 4. theta = gate . (R1 R2), SVD, truncation, X1 / X2  (simple_update.jl:51-59) -----------------------------
+    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, X1, X2, S, info, terr, gate; int n1, n2, chi, cap; };
+    std::vector<GateWS> ws(ng);
+    std::vector<GateItem> gitems(ng);
+    {
+        std::vector<char> raw;
+        std::vector<size_t> off(ng);
+        for (int gi = 0; gi < ng; ++gi) {
+            int dd = s->d[gates[gi].v1] * s->d[gates[gi].v2];
+            off[gi] = raw.size();
+            const char* p = reinterpret_cast<const char*>(gates[gi].mat);
+            raw.insert(raw.end(), p, p + (size_t)dd * dd * 16);
+        }
+        const char* d_gm = upload(s, raw);
+        for (int gi = 0; gi < ng; ++gi) {
+            GateWS& w = ws[gi]; GateItem& it = gitems[gi];
+            const SiteJob& a = sj[2 * gi]; const SiteJob& b = sj[2 * gi + 1];
+            int chi = a.sd.chi[a.bleg];
+            w.n1 = a.sd.d * chi; w.n2 = b.sd.d * chi; w.chi = chi;
+            int Mr = w.n1 * a.sd.d, Nc = w.n2 * b.sd.d;
+            if (Mr > 256 || Nc > 256) throw Err(TNQS_ERR_UNSUPPORTED, "two-site gate: d^2*chi > 256 is not supported by the Jacobi SVD kernel yet");
+            int cap = std::min(Mr, Nc); if (ao.maxdim > 0) cap = std::min(cap, ao.maxdim);
+            w.cap = cap;
+            w.lam1 = dalloc(s, w.n1 * 8); w.lam2 = dalloc(s, w.n2 * 8); w.idx1 = dalloc(s, w.n1 * 4); w.idx2 = dalloc(s, w.n2 * 4);
+            w.theta = dalloc(s, (size_t)Mr * Nc * esz); w.thetaV = dalloc(s, (size_t)Nc * Nc * esz);
+            w.X1 = dalloc(s, (size_t)w.n1 * a.sd.d * cap * esz); w.X2 = dalloc(s, (size_t)w.n2 * b.sd.d * cap * esz);
+            w.S = dalloc(s, cap * 8); w.info = dalloc(s, 8 * 4); w.terr = dalloc(s, 8);
+            it.GA1 = GA[2 * gi]->p; it.GV1 = GV[2 * gi]->p; it.GA2 = GA[2 * gi + 1]->p; it.GV2 = GV[2 * gi + 1]->p;
+            it.n1 = w.n1; it.n2 = w.n2; it.d1 = a.sd.d; it.d2 = b.sd.d; it.chi = chi;
+            it.gate = reinterpret_cast<const double*>(d_gm + off[gi]);
+            it.lam1 = (double*)w.lam1->p; it.lam2 = (double*)w.lam2->p; it.idx1 = (int*)w.idx1->p; it.idx2 = (int*)w.idx2->p;
+            it.theta = w.theta->p; it.thetaV = w.thetaV->p; it.X1 = w.X1->p; it.X2 = w.X2->p; it.S = (double*)w.S->p;
+            it.info = (int*)w.info->p; it.truncerr = (double*)w.terr->p;
+            it.maxdim = ao.maxdim; it.cutoff = ao.cutoff; it.normalize = ao.normalize_tensors; it.chi_cap = cap;
+        }
+    }
+    const GateItem* d_gitems = upload(s, gitems);
+    { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_theta<T>(s->stream, d_gitems, ng); }
+    {
+        // theta dims depend on the ranks found on the device; Jacobi reads m, n from the item, so ranks must be known:
+        // read them back (small) -- this is also where message-eigenvalue errors surface.
+        std::vector<int> info(8 * (size_t)ng);
+        for (int gi = 0; gi < ng; ++gi) HIPCHK(hipMemcpyAsync(&info[8 * gi], ws[gi].info->p, 8 * 4, hipMemcpyDeviceToHost, s->stream));
+        if (!envs.empty()) HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags->p, 2 * envs.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        for (size_t i = 0; i < envs.size(); ++i)
+            if (h_flags[2 * i + 1]) throw Err(TNQS_ERR_NUMERIC, "simple_update: incoming message has a negative eigenvalue above sqrt_cutoff (DomainError in the reference, src/utils.jl:21)");
+        std::vector<JacobiItem> ji;
+        for (int gi = 0; gi < ng; ++gi) {
+            int r1 = info[8 * gi], r2 = info[8 * gi + 1];
+            int Mr = r1 * gitems[gi].d1, Nc = r2 * gitems[gi].d2;
+            ji.push_back(JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, reinterpret_cast<int*>(ws[gi].info->p) + 4});
+        }
+        const JacobiItem* dj = upload(s, ji);
+        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<T>(s->stream, dj, ng, 60); }
+    }
+    { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, ng); }
+    std::vector<int> info(8 * (size_t)ng); std::vector<double> terr(ng);
+    for (int gi = 0; gi < ng; ++gi) {
+        HIPCHK(hipMemcpyAsync(&info[8 * gi], ws[gi].info->p, 8 * 4, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(&terr[gi], ws[gi].terr->p, 8, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    // ---- 5. psi' = (psi x_outer P) x_(s,b) X  (simple_update.jl:62-64, net effect of gauge + ungauge) ----------------
+    std::vector<Chain> pch(2 * (size_t)ng);
+    for (size_t i = 0; i < sj.size(); ++i) {
+        Chain& c = pch[i]; c.v = sj[i].v; c.src = s->site[sj[i].v]->p; c.sd = sj[i].sd;
+        for (size_t q = 0; q < sj[i].env_idx.size(); ++q)
+            if (!h_flags[2 * sj[i].env_idx[q]]) c.steps.push_back({sj[i].env_leg[q], envs[sj[i].env_idx[q]].prj->p});  // rank-deficient message only
+    }
+    run_chains<T>(s, pch, TNQS_PROF_GATE_MODEPROD);
+    {
+        std::vector<FiberItem> items; std::vector<int> verts, tb, nt; std::vector<Buf> outs; std::vector<size_t> ne;
+        int tiles = 0; size_t KKmax = 1; double bytes = 0, flops = 0;
+        for (size_t i = 0; i < sj.size(); ++i) KKmax = std::max<size_t>(KKmax, (size_t)sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]);
+        const int TR = pick_TR(KKmax, esz, 1);
+        for (size_t i = 0; i < sj.size(); ++i) {
+            int gi = (int)i / 2; int chin = info[8 * gi + 2];
+            const SiteJob& j = sj[i];
+            size_t pre = j.sd.pre(j.bleg), post = j.sd.post(j.bleg);
+            int chi = j.sd.chi[j.bleg];
+            size_t nout = j.sd.n / chi * chin;
+            FiberItem it{}; Buf out = dalloc(s, nout * esz);
+            it.in = pch[i].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
+            it.D = j.sd.d; it.PA = (int)(pre / j.sd.d); it.K = chi; it.PB = (int)post; it.Do = j.sd.d; it.No = chin;
+            tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
+            it.tile_begin = tiles; it.want_norm = ao.normalize_tensors ? 1 : 0;
+            verts.push_back(j.v); outs.push_back(out); ne.push_back(nout); tb.push_back(tiles); nt.push_back(it.nta * it.ntb);
+            tiles += it.nta * it.ntb; items.push_back(it);
+            bytes += (double)(j.sd.n + nout) * esz; flops += 8.0 * j.sd.n * j.sd.d * chin;
+        }
+        Buf np = dalloc(s, std::max(1, tiles) * sizeof(double));
+        const FiberItem* d = upload(s, items);
+        { ProfScope ps(s, TNQS_PROF_GATE_APPLY, bytes, flops);
+          launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
+        norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, ao.normalize_tensors != 0);
+        }
+    // ---- 6. both bond messages := diag(S)  (apply_gates.jl:126-135), new bond dimension ---------------------------
+    {
+        std::vector<DiagItem> di;
+        for (int gi = 0; gi < ng; ++gi) {
+            int e = g.edge(gates[gi].v1, gates[gi].v2); int chin = info[8 * gi + 2];
+            if (info[8 * gi + 3] != 0) throw Err(TNQS_ERR_NUMERIC, "simple_update: internal bond capacity exceeded");
+            s->chi[e] = chin;
+            for (int dir = 0; dir < 2; ++dir) {
+                Buf m = dalloc(s, (size_t)chin * chin * esz);
+                di.push_back(DiagItem{m->p, (const double*)ws[gi].S->p, chin});
+                s->msg[2 * e + dir] = m;
+            }
+            if (errs) errs[gates[gi].index] = terr[gi];
+        }
+        const DiagItem* d = upload(s, di);
+        { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_diag<T>(s->stream, d, (int)di.size()); }
+    }
+    s->stats.n_two_site += ng;
+    sync(s);   // workspace of this batch is released to the pool after the stream drained
+}
+
+template <class T> static void flush_batch(State* s, std::vector<Gate1>& b1, std::vector<Gate2>& b2, const tnqs_apply_opts& ao, double* errs) {
+    if (b1.empty() && b2.empty()) return;
+    apply_one_site_batch<T>(s, b1, ao.normalize_tensors != 0);
+    apply_two_site_batch<T>(s, b2, ao, errs);
+    s->stats.n_batches += 1;
+    b1.clear(); b2.clear();
+    sync(s);
+}
+
+template <class T> static void apply_gates_t(State* s, int ngates, const int32_t* nverts, const int32_t* verts, const double* mats,
+                                             const tnqs_apply_opts* opts, const tnqs_bp_opts* bp, double* errs) {
+    const Graph& g = *s->g;
+    HIPCHK(hipSetDevice(s->device));
+    tnqs_apply_opts ao; ao.maxdim = 0; ao.cutoff = -1; ao.normalize_tensors = 1; ao.sqrt_cutoff = -1; ao.update_cache = 1;
+    if (opts) ao = *opts;
+    // validation first (apply_gates.jl:109-120): nothing is mutated when an argument is bad
+    std::vector<int> voff(ngates + 1, 0); std::vector<size_t> moff(ngates + 1, 0);
+    for (int i = 0; i < ngates; ++i) {
+        int nv = nverts[i];
+        if (nv < 1 || nv > 2) throw Err(TNQS_ERR_INVALID, "apply_gate!: only one- and two-site gates are supported; received a gate acting on " + std::to_string(nv) + " vertices.");
+        voff[i + 1] = voff[i] + nv;
+        size_t dd = 1;
+        for (int k = 0; k < nv; ++k) { int v = verts[voff[i] + k]; if (v < 0 || v >= g.nv) throw Err(TNQS_ERR_INVALID, "apply_gates: vertex out of range"); dd *= s->d[v]; }
+        moff[i + 1] = moff[i] + 2 * dd * dd;
+        if (nv == 2) {
+            int a = verts[voff[i]], b = verts[voff[i] + 1];
+            if (a == b || g.edge(a, b) < 0)
+                throw Err(TNQS_ERR_INVALID, "apply_gate!: cannot apply a two-site gate on the non-adjacent vertices " + std::to_string(a) + " and " + std::to_string(b) +
+                                                ". Simple update requires the two sites to share an edge of the tensor-network graph.");
+        }
+    }
+    if (errs) std::fill(errs, errs + ngates, 0.0);
+    std::set<int> affected, batch_verts;
+    std::vector<Gate1> b1; std::vector<Gate2> b2;
+    for (int i = 0; i < ngates; ++i) {
+        const int nv = nverts[i]; const int32_t* vs = verts + voff[i];
+        bool need = false;
+        if (nv >= 2) for (int k = 0; k < nv; ++k) need = need || affected.count(vs[k]);            // apply_gates.jl:68
+        if (ao.update_cache && need) {
+            flush_batch<T>(s, b1, b2, ao, errs); batch_verts.clear();
+            bp_update_t<T>(s, bp, nullptr, nullptr);                                               // :76
+            affected.clear();                                                                      // :78
+        }
+        bool overlap = false;
+        for (int k = 0; k < nv; ++k) overlap = overlap || batch_verts.count(vs[k]);
+        if (overlap) { flush_batch<T>(s, b1, b2, ao, errs); batch_verts.clear(); }
+        if (nv == 1) b1.push_back(Gate1{vs[0], mats + moff[i]}); else b2.push_back(Gate2{vs[0], vs[1], mats + moff[i], i});
+        for (int k = 0; k < nv; ++k) { batch_verts.insert(vs[k]); affected.insert(vs[k]); }         // :88-90
+    }
+    flush_batch<T>(s, b1, b2, ao, errs);
+    if (ao.update_cache) bp_update_t<T>(s, bp, nullptr, nullptr);                                   // :93-95
+}
+
+void apply_gates(State* s, int ngates, const int32_t* nverts, const int32_t* verts, const double* mats,
+                 const tnqs_apply_opts* opts, const tnqs_bp_opts* bp, double* errs) {
+    s->stats = tnqs_apply_stats{};
+    if (s->dtype == TNQS_C64) apply_gates_t<float>(s, ngates, nverts, verts, mats, opts, bp, errs);
+    else apply_gates_t<double>(s, ngates, nverts, verts, mats, opts, bp, errs);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// truncate (src/truncate.jl:12-38)
+// ---------------------------------------------------------------------------------------------------------------
+template <class T> static void truncate_t(State* s, int maxdim, double cutoff, int normalize, int ngroups, const int32_t* offs,
+                                          const int32_t* eu, const int32_t* ev, const tnqs_bp_opts* bp) {
+    const Graph& g = *s->g;
+    HIPCHK(hipSetDevice(s->device));
+    if (maxdim <= 0) throw Err(TNQS_ERR_INVALID, "truncate: maxdim must be a positive integer");
+    tnqs_apply_opts ao; ao.maxdim = maxdim; ao.cutoff = cutoff; ao.normalize_tensors = normalize; ao.sqrt_cutoff = -1; ao.update_cache = 1;
+    std::vector<std::vector<double>> idmats;
+    auto ident = [&](int dd) { std::vector<double> m(2 * (size_t)dd * dd, 0.0); for (int i = 0; i < dd; ++i) m[2 * (size_t)(i + (size_t)dd * i)] = 1.0; return m; };
+    auto run_group = [&](const std::vector<std::pair<int, int>>& edges) {
+        std::vector<Gate2> b2; std::set<int> seen; idmats.clear(); idmats.reserve(edges.size());
+        for (auto& pr : edges) {
+            int e = g.edge(pr.first, pr.second);
+            if (e < 0) throw Err(TNQS_ERR_INVALID, "truncate: colour group contains a non-edge");
+            if (s->chi[e] == 1) continue;                                   // truncatable_edge (:5-10)
+            if (seen.count(pr.first) || seen.count(pr.second)) throw Err(TNQS_ERR_INVALID, "truncate: edges of one colour group must be vertex-disjoint");
+            seen.insert(pr.first); seen.insert(pr.second);
+            idmats.push_back(ident(s->d[pr.first] * s->d[pr.second]));
+            b2.push_back(Gate2{pr.first, pr.second, idmats.back().data(), 0});
+        }
+        apply_two_site_batch<T>(s, b2, ao, nullptr);
+        if (!b2.empty()) s->stats.n_batches += 1;
+        bp_update_t<T>(s, bp, nullptr, nullptr);                               // :28 / :34
+    };
+    if (ngroups > 0) {
+        for (int c = 0; c < ngroups; ++c) {
+            std::vector<std::pair<int, int>> edges;
+            for (int i = offs[c]; i < offs[c + 1]; ++i) edges.push_back({eu[i], ev[i]});
+            run_group(edges);
+        }
+    } else {
+        for (int e = 0; e < g.ne; ++e) run_group({{g.esrc[e], g.edst[e]}});
+    }
+}
+void truncate_bp(State* s, int maxdim, double cutoff, int normalize, int ngroups, const int32_t* offs,
+                 const int32_t* eu, const int32_t* ev, const tnqs_bp_opts* bp) {
+    s->stats = tnqs_apply_stats{};
+    if (s->dtype == TNQS_C64) truncate_t<float>(s, maxdim, cutoff, normalize, ngroups, offs, eu, ev, bp);
+    else truncate_t<double>(s, maxdim, cutoff, normalize, ngroups, offs, eu, ev, bp);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// parity probes (src/expect.jl:59-82)
+// ---------------------------------------------------------------------------------------------------------------
+template <class T> static void rdm_batch(State* s, const std::vector<int>& vs, double* out /* per vertex d*d complex128, packed */) {
+    const Graph& g = *s->g;
+    HIPCHK(hipSetDevice(s->device));
+    std::vector<Chain> chains(vs.size());
+    for (size_t i = 0; i < vs.size(); ++i) {
+        int v = vs[i];
+        if (!s->site[v]) throw Err(TNQS_ERR_INVALID, "rdm: vertex not owned by this rank");
+        Chain& c = chains[i]; c.v = v; c.src = s->site[v]->p; c.sd = site_dims(s, v);
+        for (int j = 0; j < c.sd.z; ++j) { int de = g.dedge(g.nbr[v][j], v); if (s->msg[de]) c.steps.push_back({j, s->msg[de]->p}); }
+    }
+    run_chains<T>(s, chains, TNQS_PROF_SMALL);
+    std::vector<GramJob> jobs;
+    for (size_t i = 0; i < vs.size(); ++i) { GramJob j{}; j.X = chains[i].result; j.Y = chains[i].src; j.sd = chains[i].sd; j.leg = -1; j.keep_site = true; jobs.push_back(j); }
+    run_grams<T, double>(s, jobs, TNQS_PROF_SMALL);
+    std::vector<ReduceItem> ri; int elems = 0; std::vector<int> off;
+    for (size_t i = 0; i < vs.size(); ++i) { int n2 = jobs[i].KK * jobs[i].KK; off.push_back(elems); elems += n2; }
+    Buf d_out = dalloc(s, (size_t)elems * 16);
+    for (size_t i = 0; i < vs.size(); ++i) {
+        int n2 = jobs[i].KK * jobs[i].KK;
+        ri.push_back(ReduceItem{jobs[i].partial->p, reinterpret_cast<char*>(d_out->p) + (size_t)off[i] * 16, n2, jobs[i].nchunks, 0, off[i]});
+    }
+    const ReduceItem* dr = upload(s, ri);
+    launch_reduce<double, double>(s->stream, dr, (int)ri.size(), elems);
+    HIPCHK(hipMemcpyAsync(out, d_out->p, (size_t)elems * 16, hipMemcpyDeviceToHost, s->stream));
+    sync(s);
+}
+void rdm_1site(State* s, int v, double* out) {
+    if (v < 0 || v >= s->g->nv) throw Err(TNQS_ERR_INVALID, "rdm_1site: bad vertex");
+    std::vector<int> vs{v};
+    if (s->dtype == TNQS_C64) rdm_batch<float>(s, vs, out); else rdm_batch<double>(s, vs, out);
+}
+void expect_all(State* s, const double* ops, double* out) {
+    const Graph& g = *s->g;
+    std::vector<int> vs; std::vector<size_t> off; size_t tot = 0;
+    for (int v = 0; v < g.nv; ++v) if (s->owns(v)) { vs.push_back(v); off.push_back(tot); tot += 2 * (size_t)s->d[v] * s->d[v]; }
+    std::vector<double> rho(tot);
+    if (!vs.empty()) { if (s->dtype == TNQS_C64) rdm_batch<float>(s, vs, rho.data()); else rdm_batch<double>(s, vs, rho.data()); }
+    size_t opoff = 0; size_t q = 0;
+    for (int v = 0; v < g.nv; ++v) {
+        int d = s->d[v];
+        if (q < vs.size() && vs[q] == v) {
+            const double* r = rho.data() + off[q]; const double* o = ops + opoff;
+            double nre = 0, nim = 0, tre = 0, tim = 0;
+            for (int sp = 0; sp < d; ++sp) for (int si = 0; si < d; ++si) {       // sum op[s',s] rho[s,s']
+                double ore = o[2 * (sp + d * si)], oim = o[2 * (sp + d * si) + 1];
+                double rre = r[2 * (si + d * sp)], rim = r[2 * (si + d * sp) + 1];
+                nre += ore * rre - oim * rim; nim += ore * rim + oim * rre;
+            }
+            for (int si = 0; si < d; ++si) { tre += r[2 * (si + d * si)]; tim += r[2 * (si + d * si) + 1]; }
+            double den = tre * tre + tim * tim;
+            out[2 * v] = (nre * tre + nim * tim) / den; out[2 * v + 1] = (nim * tre - nre * tim) / den;
+            ++q;
+        } else { out[2 * v] = std::nan(""); out[2 * v + 1] = std::nan(""); }
+        opoff += 2 * (size_t)d * d;
+    }
+}
+
+}  // namespace tnqs

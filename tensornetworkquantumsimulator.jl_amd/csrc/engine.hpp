@@ -1,0 +1,102 @@
+// engine.hpp -- host-side engine behind the C ABI: state container (TensorNetworkState + BeliefPropagationCache),
+// BP update driver, apply_gates scheduler, truncate, parity probes.  Mirrors (paths relative to the reference):
+//   src/MessagePassing/beliefpropagationcache.jl:9-15   struct BeliefPropagationCache {network, messages, edge_sequence}
+//   src/TensorNetworks/tensornetworkstate.jl:12-15       TensorNetworkState
+//   src/Apply/apply_gates.jl:46-143                      apply_gates / apply_gate!
+//   src/MessagePassing/abstractbeliefpropagationcache.jl:223-259   update
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/tnqs.h"
+
+namespace tnqs {
+
+struct Err : std::runtime_error {
+    int code;
+    Err(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+void hipchk(hipError_t e, const char* what);
+
+// ---- caching device allocator (stream-ordered reuse on the handle's single stream) ----------------------------
+class Pool {
+public:
+    explicit Pool(int device) : device_(device) {}
+    ~Pool();
+    void* alloc(size_t bytes, size_t* rounded);
+    void release(void* p, size_t rounded);
+    size_t bytes_live() const { return live_; }
+    size_t bytes_cached() const { return cached_; }
+    void trim();
+private:
+    int device_ [[maybe_unused]];
+    std::map<size_t, std::vector<void*>> free_;
+    size_t live_ = 0, cached_ = 0;
+};
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0; size_t rounded = 0; std::shared_ptr<Pool> pool;
+    ~DevBuf() { if (p && pool) pool->release(p, rounded); }
+};
+using Buf = std::shared_ptr<DevBuf>;
+
+struct Graph {
+    int nv = 0, ne = 0;
+    std::vector<int> esrc, edst;
+    std::vector<std::vector<int>> nbr, nbr_e;     // neighbours of v in ascending id, and the edge to each
+    std::unordered_map<uint64_t, int> emap;
+    bool is_tree = false;
+    std::vector<int> ecolor; int ncolors = 0;     // deterministic greedy proper edge colouring
+    int edge(int u, int v) const;                 // -1 if absent
+    int leg(int v, int w) const;                  // position of neighbour w in nbr[v], -1 if absent
+    int dedge(int src, int dst) const;            // directed edge id 2*e + (src == edst[e]), -1 if absent
+};
+
+struct ProfClass { int64_t launches = 0; double ms = 0, bytes = 0, flops = 0; };
+
+struct State {
+    std::shared_ptr<Graph> g;
+    int dtype = TNQS_C64;
+    int device = 0;
+    std::vector<int> d;            // site dims
+    std::vector<int> chi;          // bond dim per edge
+    std::vector<Buf> site;         // canonical layout; null when not owned (sharding)
+    std::vector<Buf> msg;          // 2*ne, null = unset = identity (tensornetworkstate.jl:72-75)
+    std::shared_ptr<Pool> pool;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    // sharding
+    int rank = 0, nranks = 1; std::vector<int> owner; tnqs_allgatherv_fn ag_fn = nullptr; void* ag_ctx = nullptr;
+    // profiling
+    bool prof_on = false; ProfClass prof[TNQS_PROF_NCLASSES];
+    struct Pending { int cls; hipEvent_t a, b; };
+    std::vector<Pending> prof_pending; std::vector<hipEvent_t> ev_free;
+    std::vector<Buf> keepalive;    // descriptor buffers kept until the next host sync
+    tnqs_apply_stats stats{};
+
+    size_t esz() const { return dtype == TNQS_C64 ? 8 : 16; }
+    bool owns(int v) const { return nranks == 1 || owner[v] == rank; }
+    ~State();
+};
+
+// ---- operations (implemented in engine.cpp, templated internally on the real type) ---------------------------
+State* state_create(int nv, int ne, const int32_t* es, const int32_t* ed, const int32_t* sd, int dtype, int device);
+State* state_copy(const State* s);
+void state_set_site(State* s, int v, const void* host, int ndim, const int64_t* dims, const int32_t* role);
+void state_get_site(State* s, int v, void* host, int ndim, const int32_t* role);
+int64_t state_site_size(const State* s, int v);
+void state_set_message(State* s, int src, int dst, const void* host, int chi);
+void state_get_message(State* s, int src, int dst, void* host, int chi);
+void bp_update(State* s, const tnqs_bp_opts* opts, int* niter, double* diff);
+void apply_gates(State* s, int ngates, const int32_t* nverts, const int32_t* verts, const double* mats,
+                 const tnqs_apply_opts* opts, const tnqs_bp_opts* bp, double* errs);
+void truncate_bp(State* s, int maxdim, double cutoff, int normalize, int ngroups, const int32_t* offs,
+                 const int32_t* eu, const int32_t* ev, const tnqs_bp_opts* bp);
+void rdm_1site(State* s, int v, double* out);
+void expect_all(State* s, const double* ops, double* out);
+void prof_collect(State* s);
+
+}  // namespace tnqs

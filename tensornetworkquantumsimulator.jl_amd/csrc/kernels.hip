@@ -1,0 +1,713 @@
+// kernels.hip -- generic (any dims, c64/c128) HIP kernels of the BP-gauged gate-application path, gfx950.
+// These are the always-correct fiber-tile kernels; the MFMA fast paths for the hot shapes live in
+// kernels_mfma.hip and are validated against these.
+//
+// Reference call sites replaced (paths relative to the reference repo):
+//   fiber_gemm  : ITensors `contract`/`apply` in src/Apply/simple_update.jl:27,43-44,62-64 and the message
+//                 absorptions of src/MessagePassing/abstractbeliefpropagationcache.jl:180
+//   gram        : final contraction with dag(prime(psi)) (abstract...:180) and the R-factor Gram of the QR
+//                 step (simple_update.jl:47-48, replaced by an f64 Gram + eigen factorisation)
+//   msg_finalize: abstract...:182-187 (m / sum(m)) + message_diff beliefpropagationcache.jl:17-21
+//   jacobi      : `eigen` (src/utils.jl:29-35,94-108) and `factorize_svd` (simple_update.jl:53-59)
+//   gate_theta / gate_finish : simple_update.jl:51-59 + NDTensors truncate! rule, apply_gates.jl:126-135
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+#include "kernels.hpp"
+
+namespace tnqs {
+
+template <class T> struct alignas(2 * sizeof(T)) cx { T re, im; };
+
+template <class T> __device__ __forceinline__ cx<T> cmake(T a, T b) { cx<T> r; r.re = a; r.im = b; return r; }
+template <class T> __device__ __forceinline__ void cfma(cx<T>& acc, const cx<T>& a, const cx<T>& b) {
+    acc.re = fma(a.re, b.re, acc.re); acc.re = fma(-a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im); acc.im = fma(a.im, b.re, acc.im);
+}
+// acc += a * conj(b)
+template <class T> __device__ __forceinline__ void cfma_conj(cx<T>& acc, const cx<T>& a, const cx<T>& b) {
+    acc.re = fma(a.re, b.re, acc.re); acc.re = fma(a.im, b.im, acc.re);
+    acc.im = fma(a.im, b.re, acc.im); acc.im = fma(-a.re, b.im, acc.im);
+}
+template <class T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <class T> __device__ __forceinline__ T eps_of();
+template <> __device__ __forceinline__ float eps_of<float>() { return FLT_EPSILON; }
+template <> __device__ __forceinline__ double eps_of<double>() { return DBL_EPSILON; }
+
+// block-wide sum of a double (blockDim.x <= 1024); result valid in every thread
+__device__ __forceinline__ double block_sum(double v, double* sh /* >= 17 doubles */) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0; for (int i = 0; i < nw; ++i) t += sh[i]; sh[16] = t; }
+    __syncthreads();
+    return sh[16];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fiber_gemm
+// ------------------------------------------------------------------------------------------------------------
+template <class T, int NB>
+__global__ __launch_bounds__(256) void fiber_gemm_kernel(const FiberItem* __restrict__ items, int nitems, int TR,
+                                                         double* __restrict__ norm_partials) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<T>* tile = reinterpret_cast<cx<T>*>(smem);
+    __shared__ double sh_red[17];
+    const int tid = threadIdx.x;
+    int lo = 0, hi = nitems - 1;
+    const int gt = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].tile_begin <= gt) lo = mid; else hi = mid - 1; }
+    const FiberItem it = items[lo];
+    const int lt = gt - it.tile_begin;
+    const int ta = lt % it.nta, tb = lt / it.nta;
+    const int a0 = ta * it.TA, b0 = tb * it.TB;
+    const int na = min(it.TA, it.PA - a0), nb = min(it.TB, it.PB - b0);
+    const int D = it.D, K = it.K, TA = it.TA, TB = it.TB, KK = D * K;
+    const size_t PA = it.PA;
+    const cx<T>* __restrict__ in = reinterpret_cast<const cx<T>*>(it.in);
+    const int ntile_el = D * TA * K * TB;
+    for (int e = tid; e < ntile_el; e += 256) {
+        int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
+        cx<T> v = cmake<T>(0, 0);
+        if (al < na && bl < nb) v = in[s + D * ((size_t)(a0 + al) + PA * ((size_t)k + (size_t)K * (b0 + bl)))];
+        tile[(s + D * k) * TR + (al + TA * bl)] = v;
+    }
+    __syncthreads();
+    const int Do = it.Do, No = it.No, NN = Do * No;
+    const int r = tid % TR, g = tid / TR, G = 256 / TR;
+    const int al = r % TA, bl = r / TA;
+    const bool valid = (r < TA * TB) && al < na && bl < nb;
+    const cx<T>* __restrict__ X = reinterpret_cast<const cx<T>*>(it.X);
+    cx<T>* __restrict__ out = reinterpret_cast<cx<T>*>(it.out);
+    double nrm = 0;
+    for (int nn0 = g * NB; nn0 < NN; nn0 += G * NB) {
+        cx<T> acc[NB];
+        int col[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { acc[j] = cmake<T>(0, 0); col[j] = min(nn0 + j, NN - 1) * KK; }
+        for (int kk = 0; kk < KK; ++kk) {
+            const cx<T> a = tile[kk * TR + r];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) cfma(acc[j], a, X[col[j] + kk]);
+        }
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                int nn = nn0 + j;
+                if (nn < NN) {
+                    int sp = nn % Do, n = nn / Do;
+                    out[sp + Do * ((size_t)(a0 + al) + PA * ((size_t)n + (size_t)No * (b0 + bl)))] = acc[j];
+                    nrm += (double)acc[j].re * acc[j].re + (double)acc[j].im * acc[j].im;
+                }
+            }
+        }
+    }
+    if (it.want_norm) {   // uniform per block
+        double t = block_sum(nrm, sh_red);
+        if (tid == 0) norm_partials[gt] = t;
+    }
+}
+
+template <class T>
+void launch_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_tiles, int TR, int KKmax,
+                       double* d_norm_partials) {
+    if (total_tiles <= 0) return;
+    size_t lds = (size_t)KKmax * TR * sizeof(cx<T>);
+    hipLaunchKernelGGL((fiber_gemm_kernel<T, 8>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, TR, d_norm_partials);
+}
+template void launch_fiber_gemm<float>(hipStream_t, const FiberItem*, int, int, int, int, double*);
+template void launch_fiber_gemm<double>(hipStream_t, const FiberItem*, int, int, int, int, double*);
+
+// ------------------------------------------------------------------------------------------------------------
+// gram
+// ------------------------------------------------------------------------------------------------------------
+template <class T, class Acc, int MAXB>
+__global__ __launch_bounds__(256) void gram_kernel(const GramItem* __restrict__ items, int nitems, int TR) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    int lo = 0, hi = nitems - 1;
+    const int gc = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].chunk_begin <= gc) lo = mid; else hi = mid - 1; }
+    const GramItem it = items[lo];
+    const int lc = gc - it.chunk_begin;
+    const int D = it.D, K = it.K, TA = it.TA, TB = it.TB, KK = D * K;
+    const int KKp = KK + 1;                      // row pitch of the LDS tiles [row][kk]
+    const size_t PA = it.PA;
+    const bool same = (it.X == it.Y);
+    cx<T>* Xt = reinterpret_cast<cx<T>*>(smem);
+    cx<T>* Yt = same ? Xt : Xt + (size_t)TR * KKp;
+    const cx<T>* __restrict__ Xg = reinterpret_cast<const cx<T>*>(it.X);
+    const cx<T>* __restrict__ Yg = reinterpret_cast<const cx<T>*>(it.Y);
+    const int KB = (KK + 1) >> 1;                // 2x2 output blocks per dimension
+    const int nblk = KB * KB;
+    const int ntiles = it.nta * it.ntb;
+    const int t_begin = lc * it.tiles_per_chunk;
+    const int t_end = min(ntiles, t_begin + it.tiles_per_chunk);
+    cx<Acc>* __restrict__ part = reinterpret_cast<cx<Acc>*>(it.partial) + (size_t)lc * KK * KK;
+    const int ntile_el = D * TA * K * TB;
+    for (int pass0 = 0; pass0 < nblk; pass0 += 256 * MAXB) {
+        cx<Acc> acc[MAXB][4];
+        int bi[MAXB], bj[MAXB];
+#pragma unroll
+        for (int j = 0; j < MAXB; ++j) {
+            int q = pass0 + tid + 256 * j;
+            int qq = min(q, nblk - 1);
+            bi[j] = qq % KB; bj[j] = qq / KB;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[j][c] = cmake<Acc>(0, 0);
+        }
+        for (int t = t_begin; t < t_end; ++t) {
+            const int ta = t % it.nta, tb = t / it.nta;
+            const int a0 = ta * TA, b0 = tb * TB;
+            const int na = min(TA, it.PA - a0), nb = min(TB, it.PB - b0);
+            __syncthreads();
+            for (int e = tid; e < ntile_el; e += 256) {
+                int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
+                cx<T> vx = cmake<T>(0, 0), vy = cmake<T>(0, 0);
+                if (al < na && bl < nb) {
+                    size_t off = s + D * ((size_t)(a0 + al) + PA * ((size_t)k + (size_t)K * (b0 + bl)));
+                    vx = Xg[off];
+                    if (!same) vy = Yg[off];
+                }
+                int li = (al + TA * bl) * KKp + (s + D * k);
+                Xt[li] = vx;
+                if (!same) Yt[li] = vy;
+            }
+            // zero the pad column so clamped reads of index KK (odd KK) are harmless
+            for (int e = tid; e < TA * TB; e += 256) { Xt[e * KKp + KK] = cmake<T>(0, 0); if (!same) Yt[e * KKp + KK] = cmake<T>(0, 0); }
+            __syncthreads();
+            const int nrow = TA * TB;
+            for (int rr = 0; rr < nrow; ++rr) {
+                const cx<T>* xr = Xt + rr * KKp;
+                const cx<T>* yr = Yt + rr * KKp;
+#pragma unroll
+                for (int j = 0; j < MAXB; ++j) {
+                    cx<T> x0 = xr[2 * bi[j]], x1 = xr[2 * bi[j] + 1];
+                    cx<T> y0 = yr[2 * bj[j]], y1 = yr[2 * bj[j] + 1];
+                    cx<Acc> X0 = cmake<Acc>(x0.re, x0.im), X1 = cmake<Acc>(x1.re, x1.im);
+                    cx<Acc> Y0 = cmake<Acc>(y0.re, y0.im), Y1 = cmake<Acc>(y1.re, y1.im);
+                    cfma_conj(acc[j][0], X0, Y0); cfma_conj(acc[j][1], X1, Y0);
+                    cfma_conj(acc[j][2], X0, Y1); cfma_conj(acc[j][3], X1, Y1);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXB; ++j) {
+            int q = pass0 + tid + 256 * j;
+            if (q < nblk) {
+                int i0 = 2 * bi[j], j0 = 2 * bj[j];
+                part[i0 + (size_t)KK * j0] = acc[j][0];
+                if (i0 + 1 < KK) part[i0 + 1 + (size_t)KK * j0] = acc[j][1];
+                if (j0 + 1 < KK) {
+                    part[i0 + (size_t)KK * (j0 + 1)] = acc[j][2];
+                    if (i0 + 1 < KK) part[i0 + 1 + (size_t)KK * (j0 + 1)] = acc[j][3];
+                }
+            }
+        }
+    }
+}
+
+template <class T, class Acc>
+void launch_gram(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int TR, int KKmax) {
+    if (total_chunks <= 0) return;
+    size_t lds = 2 * (size_t)TR * (KKmax + 1) * sizeof(cx<T>);
+    hipLaunchKernelGGL((gram_kernel<T, Acc, 4>), dim3(total_chunks), dim3(256), lds, s, d_items, nitems, TR);
+}
+template void launch_gram<float, float>(hipStream_t, const GramItem*, int, int, int, int);
+template void launch_gram<float, double>(hipStream_t, const GramItem*, int, int, int, int);
+template void launch_gram<double, double>(hipStream_t, const GramItem*, int, int, int, int);
+
+// ------------------------------------------------------------------------------------------------------------
+// reduce partials
+// ------------------------------------------------------------------------------------------------------------
+template <class Acc, class Out>
+__global__ __launch_bounds__(256) void reduce_kernel(const ReduceItem* __restrict__ items, int nitems, int total) {
+    int ge = blockIdx.x * 256 + threadIdx.x;
+    if (ge >= total) return;
+    int lo = 0, hi = nitems - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].elem_begin <= ge) lo = mid; else hi = mid - 1; }
+    const ReduceItem it = items[lo];
+    int e = ge - it.elem_begin;
+    const cx<Acc>* p = reinterpret_cast<const cx<Acc>*>(it.partial);
+    Acc re = 0, im = 0;
+    for (int c = 0; c < it.nchunks; ++c) { cx<Acc> v = p[(size_t)c * it.n2 + e]; re += v.re; im += v.im; }
+    if (it.conj) im = -im;
+    reinterpret_cast<cx<Out>*>(it.out)[e] = cmake<Out>((Out)re, (Out)im);
+}
+template <class Acc, class Out>
+void launch_reduce(hipStream_t s, const ReduceItem* d_items, int nitems, int total_elems) {
+    if (total_elems <= 0) return;
+    hipLaunchKernelGGL((reduce_kernel<Acc, Out>), dim3((total_elems + 255) / 256), dim3(256), 0, s, d_items, nitems, total_elems);
+}
+template void launch_reduce<double, double>(hipStream_t, const ReduceItem*, int, int);
+template void launch_reduce<float, float>(hipStream_t, const ReduceItem*, int, int);
+template void launch_reduce<double, float>(hipStream_t, const ReduceItem*, int, int);
+
+// ------------------------------------------------------------------------------------------------------------
+// BP message epilogue: reduce partials, normalise by the sum of all elements, message_diff
+// ------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void msg_finalize_kernel(const MsgFinalItem* __restrict__ items) {
+    __shared__ double sh[17];
+    const MsgFinalItem it = items[blockIdx.x];
+    const int n2 = it.chi * it.chi;
+    const cx<T>* p = reinterpret_cast<const cx<T>*>(it.partial);
+    cx<T>* out = reinterpret_cast<cx<T>*>(it.new_msg);
+    const cx<T>* old = reinterpret_cast<const cx<T>*>(it.old_msg);
+    // pass 1: reduce chunks (fixed order) into new_msg, accumulate the element sum
+    double sre = 0, sim = 0;
+    for (int e = threadIdx.x; e < n2; e += 256) {
+        T re = 0, im = 0;
+        for (int c = 0; c < it.nchunks; ++c) { cx<T> v = p[(size_t)c * n2 + e]; re += v.re; im += v.im; }
+        out[e] = cmake<T>(re, im);
+        sre += re; sim += im;
+    }
+    sre = block_sum(sre, sh); sim = block_sum(sim, sh);
+    // m / sum(m)   (abstractbeliefpropagationcache.jl:182-187; skipped when the sum is exactly zero)
+    double ire = 1, iim = 0;
+    if (it.normalize && (sre != 0 || sim != 0)) { double d = sre * sre + sim * sim; ire = sre / d; iim = -sim / d; }
+    double dre = 0, dim_ = 0, na = 0, nb = 0;
+    for (int e = threadIdx.x; e < n2; e += 256) {
+        cx<T> v = out[e];
+        double re = v.re * ire - v.im * iim, im = v.re * iim + v.im * ire;
+        cx<T> w = cmake<T>((T)re, (T)im);
+        out[e] = w;
+        double ore, oim;
+        if (old) { ore = old[e].re; oim = old[e].im; } else { ore = (e % it.chi == e / it.chi) ? 1.0 : 0.0; oim = 0; }
+        // dot(a, b) = sum conj(a) b with a = new, b = old  (beliefpropagationcache.jl:17-21)
+        dre += (double)w.re * ore + (double)w.im * oim;
+        dim_ += (double)w.re * oim - (double)w.im * ore;
+        na += (double)w.re * w.re + (double)w.im * w.im;
+        nb += ore * ore + oim * oim;
+    }
+    dre = block_sum(dre, sh); dim_ = block_sum(dim_, sh); na = block_sum(na, sh); nb = block_sum(nb, sh);
+    if (threadIdx.x == 0 && it.diff_out) {
+        double f = (dre * dre + dim_ * dim_) / (na * nb);
+        *it.diff_out = 1.0 - f;
+    }
+}
+template <class T> void launch_msg_finalize(hipStream_t s, const MsgFinalItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((msg_finalize_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+}
+template void launch_msg_finalize<float>(hipStream_t, const MsgFinalItem*, int);
+template void launch_msg_finalize<double>(hipStream_t, const MsgFinalItem*, int);
+
+// ------------------------------------------------------------------------------------------------------------
+// one-sided (Hestenes) Jacobi: A <- A J_1 J_2 ..., V <- V J_1 J_2 ...  until the columns of A are orthogonal.
+// One workgroup per matrix, one wave per column pair, round-robin pair ordering.  m, n <= 256.
+// ------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restrict__ items, int max_sweeps) {
+    constexpr int R = 4;
+    __shared__ int s_rot;
+    const JacobiItem it = items[blockIdx.x];
+    cx<T>* A = reinterpret_cast<cx<T>*>(it.A);
+    cx<T>* V = reinterpret_cast<cx<T>*>(it.V);
+    const int m = it.m, n = it.n;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int ne = n + (n & 1);
+    const T tol = eps_of<T>() * sqrt((T)(m > 4 ? m : 4));
+    int sweep = 0;
+    for (; sweep < max_sweeps && n > 1; ++sweep) {
+        if (threadIdx.x == 0) s_rot = 0;
+        __syncthreads();
+        for (int round = 0; round < ne - 1; ++round) {
+            for (int pi = w; pi < ne / 2; pi += nw) {
+                int p, q;
+                if (pi == 0) { p = ne - 1; q = round; }
+                else { p = (round + pi) % (ne - 1); q = (round - pi + (ne - 1)) % (ne - 1); }
+                if (p > q) { int t = p; p = q; q = t; }
+                if (q >= n) continue;
+                cx<T> ap[R], aq[R];
+                T alpha = 0, beta = 0, gre = 0, gim = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    int i = lane + 64 * r;
+                    if (i < m) {
+                        ap[r] = A[i + (size_t)m * p]; aq[r] = A[i + (size_t)m * q];
+                        alpha += ap[r].re * ap[r].re + ap[r].im * ap[r].im;
+                        beta += aq[r].re * aq[r].re + aq[r].im * aq[r].im;
+                        gre += ap[r].re * aq[r].re + ap[r].im * aq[r].im;     // conj(ap) * aq
+                        gim += ap[r].re * aq[r].im - ap[r].im * aq[r].re;
+                    }
+                }
+                alpha = wave_sum(alpha); beta = wave_sum(beta); gre = wave_sum(gre); gim = wave_sum(gim);
+                const T g2 = gre * gre + gim * gim;
+                if (g2 > 0 && g2 > tol * tol * alpha * beta) {
+                    const T ga = sqrt(g2);
+                    const T pre = gre / ga, pim = -gim / ga;           // e^{-i phi}
+                    const T zeta = (beta - alpha) / (2 * ga);
+                    const T t = (zeta >= 0 ? (T)1 : (T)-1) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+                    const T c = 1 / sqrt(1 + t * t), sn = c * t;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        int i = lane + 64 * r;
+                        if (i < m) {
+                            T qre = aq[r].re * pre - aq[r].im * pim, qim = aq[r].re * pim + aq[r].im * pre;
+                            A[i + (size_t)m * p] = cmake<T>(c * ap[r].re - sn * qre, c * ap[r].im - sn * qim);
+                            A[i + (size_t)m * q] = cmake<T>(sn * ap[r].re + c * qre, sn * ap[r].im + c * qim);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        int i = lane + 64 * r;
+                        if (i < n) {
+                            cx<T> vp = V[i + (size_t)n * p], vq = V[i + (size_t)n * q];
+                            T qre = vq.re * pre - vq.im * pim, qim = vq.re * pim + vq.im * pre;
+                            V[i + (size_t)n * p] = cmake<T>(c * vp.re - sn * qre, c * vp.im - sn * qim);
+                            V[i + (size_t)n * q] = cmake<T>(sn * vp.re + c * qre, sn * vp.im + c * qim);
+                        }
+                    }
+                    if (lane == 0) s_rot = 1;
+                }
+            }
+            __syncthreads();
+        }
+        const int rot = s_rot;
+        __syncthreads();
+        if (!rot) { ++sweep; break; }
+    }
+    if (threadIdx.x == 0 && it.sweeps_out) *it.sweeps_out = sweep;
+}
+template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((jacobi_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items, max_sweeps);
+}
+template void launch_jacobi<float>(hipStream_t, const JacobiItem*, int, int);
+template void launch_jacobi<double>(hipStream_t, const JacobiItem*, int, int);
+
+// ------------------------------------------------------------------------------------------------------------
+// environment square roots  (src/utils.jl:18-27 with safe_eigen :94-108: always f64)
+// ------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void env_prepare_kernel(const EnvItem* __restrict__ items) {
+    const EnvItem it = items[blockIdx.x];
+    const int n = it.n;
+    const cx<T>* M = reinterpret_cast<const cx<T>*>(it.msg);
+    cx<double>* H = reinterpret_cast<cx<double>*>(it.H);
+    cx<double>* V = reinterpret_cast<cx<double>*>(it.V);
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        int i = e % n, j = e / n;
+        double re, im;
+        if (M) {
+            cx<T> a = M[i + n * j], b = M[j + n * i];
+            re = 0.5 * ((double)a.re + (double)b.re); im = 0.5 * ((double)a.im - (double)b.im);
+        } else { re = (i == j) ? 1.0 : 0.0; im = 0; }
+        H[e] = cmake<double>(re, im);
+        V[e] = cmake<double>(i == j ? 1.0 : 0.0, 0.0);
+    }
+}
+template <class T> void launch_env_prepare(hipStream_t s, const EnvItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((env_prepare_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+}
+template void launch_env_prepare<float>(hipStream_t, const EnvItem*, int);
+template void launch_env_prepare<double>(hipStream_t, const EnvItem*, int);
+
+template <class T>
+__global__ __launch_bounds__(256) void env_finish_kernel(const EnvFinishItem* __restrict__ items) {
+    __shared__ double lam[256];
+    __shared__ int s_full, s_err;
+    const EnvFinishItem it = items[blockIdx.x];
+    const int n = it.n;
+    const cx<double>* A = reinterpret_cast<const cx<double>*>(it.A);
+    const cx<double>* V = reinterpret_cast<const cx<double>*>(it.V);
+    if (threadIdx.x == 0) { s_full = 1; s_err = 0; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += 256) {
+        double l = 0;       // Rayleigh quotient v_j^dagger H v_j = Re(v_j^dagger a_j)
+        for (int i = 0; i < n; ++i) { cx<double> v = V[i + n * j], a = A[i + n * j]; l += v.re * a.re + v.im * a.im; }
+        lam[j] = l;
+        const bool zero = (l == 0) || (fabs(l) < it.cutoff);
+        if (zero) s_full = 0;
+        else if (l < 0) s_err = 1;        // Julia: sqrt(negative) -> DomainError (src/utils.jl:21)
+    }
+    __syncthreads();
+    cx<T>* ms = reinterpret_cast<cx<T>*>(it.msqrt);
+    cx<T>* pr = reinterpret_cast<cx<T>*>(it.proj);
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        int i = e % n, l = e / n;
+        cx<double> s1 = cmake<double>(0, 0), s2 = cmake<double>(0, 0);
+        for (int j = 0; j < n; ++j) {
+            double lj = lam[j];
+            if ((lj == 0) || (fabs(lj) < it.cutoff) || lj < 0) continue;
+            cx<double> vi = V[i + n * j], vl = V[l + n * j];
+            cx<double> o = cmake<double>(vi.re * vl.re + vi.im * vl.im, vi.im * vl.re - vi.re * vl.im);  // vi conj(vl)
+            double sq = sqrt(lj);
+            s1.re += sq * o.re; s1.im += sq * o.im;
+            s2.re += o.re; s2.im += o.im;
+        }
+        ms[e] = cmake<T>((T)s1.re, (T)s1.im);
+        pr[e] = cmake<T>((T)s2.re, (T)s2.im);
+    }
+    if (threadIdx.x == 0) { it.flags[0] = s_full; it.flags[1] = s_err; }
+}
+template <class T> void launch_env_finish(hipStream_t s, const EnvFinishItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((env_finish_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+}
+template void launch_env_finish<float>(hipStream_t, const EnvFinishItem*, int);
+template void launch_env_finish<double>(hipStream_t, const EnvFinishItem*, int);
+
+// ------------------------------------------------------------------------------------------------------------
+// per-gate small algebra.  With G_i = psi~_i^dagger psi~_i = W L W^dagger:  R_i = L^{1/2} W^dagger (any
+// orthogonal factorisation psi~ = Q R gives the same gauge-invariant result as the reference's QR).
+// ------------------------------------------------------------------------------------------------------------
+#define TNQS_RANK_TAU 1e-12
+
+__device__ void gate_eigs(const cx<double>* A, const cx<double>* V, int n, double* lam_tmp /*LDS n*/, double* lam_out,
+                          int* idx_out, int* r_out, int* s_r /*LDS*/) {
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        double l = 0;
+        for (int i = 0; i < n; ++i) { cx<double> v = V[i + n * j], a = A[i + n * j]; l += v.re * a.re + v.im * a.im; }
+        lam_tmp[j] = l;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double lmax = 0;
+        for (int j = 0; j < n; ++j) lmax = fmax(lmax, lam_tmp[j]);
+        int r = 0;
+        for (int j = 0; j < n; ++j)
+            if (lam_tmp[j] > TNQS_RANK_TAU * lmax && lam_tmp[j] > 0) { lam_out[r] = lam_tmp[j]; idx_out[r] = j; ++r; }
+        *r_out = r; *s_r = r;
+    }
+    __syncthreads();
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void gate_theta_kernel(const GateItem* __restrict__ items) {
+    __shared__ double lam_tmp[256];
+    __shared__ int s_r1, s_r2;
+    const GateItem it = items[blockIdx.x];
+    const cx<double>* A1 = reinterpret_cast<const cx<double>*>(it.GA1);
+    const cx<double>* V1 = reinterpret_cast<const cx<double>*>(it.GV1);
+    const cx<double>* A2 = reinterpret_cast<const cx<double>*>(it.GA2);
+    const cx<double>* V2 = reinterpret_cast<const cx<double>*>(it.GV2);
+    gate_eigs(A1, V1, it.n1, lam_tmp, it.lam1, it.idx1, &it.info[0], &s_r1);
+    gate_eigs(A2, V2, it.n2, lam_tmp, it.lam2, it.idx2, &it.info[1], &s_r2);
+    const int r1 = s_r1, r2 = s_r2, d1 = it.d1, d2 = it.d2, chi = it.chi;
+    const int Mr = r1 * d1, Nc = r2 * d2;
+    cx<T>* th = reinterpret_cast<cx<T>*>(it.theta);
+    cx<T>* tv = reinterpret_cast<cx<T>*>(it.thetaV);
+    const cx<double>* g = reinterpret_cast<const cx<double>*>(it.gate);
+    const int dd = d1 * d2;
+    // theta[(a,s1'),(c,s2')] = sum_{s1,s2} g[(s1' s2'),(s1 s2)] sum_b R1[a,(s1,b)] R2[c,(s2,b)],  R_i[a,(s,b)] = sqrt(l_a) conj(W_i[(s,b),a])
+    for (int e = threadIdx.x; e < Mr * Nc; e += 256) {
+        int row = e % Mr, col = e / Mr;
+        int a = row % r1, s1p = row / r1, c = col % r2, s2p = col / r2;
+        const cx<double>* w1 = V1 + (size_t)it.n1 * it.idx1[a];
+        const cx<double>* w2 = V2 + (size_t)it.n2 * it.idx2[c];
+        cx<double> acc = cmake<double>(0, 0);
+        for (int s1 = 0; s1 < d1; ++s1)
+            for (int s2 = 0; s2 < d2; ++s2) {
+                cx<double> gg = g[(s1p * d2 + s2p) + dd * (s1 * d2 + s2)];
+                if (gg.re == 0 && gg.im == 0) continue;
+                cx<double> cc = cmake<double>(0, 0);
+                for (int b = 0; b < chi; ++b) {
+                    cx<double> x = w1[s1 + d1 * b], y = w2[s2 + d2 * b];
+                    // conj(x) * conj(y)
+                    cc.re += x.re * y.re - x.im * y.im;
+                    cc.im -= x.re * y.im + x.im * y.re;
+                }
+                cfma(acc, gg, cc);
+            }
+        double sc = sqrt(it.lam1[a] * it.lam2[c]);
+        th[e] = cmake<T>((T)(acc.re * sc), (T)(acc.im * sc));
+    }
+    for (int e = threadIdx.x; e < Nc * Nc; e += 256) tv[e] = cmake<T>((e % Nc) == (e / Nc) ? (T)1 : (T)0, (T)0);
+}
+template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((gate_theta_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+}
+template void launch_gate_theta<float>(hipStream_t, const GateItem*, int);
+template void launch_gate_theta<double>(hipStream_t, const GateItem*, int);
+
+template <class T>
+__global__ __launch_bounds__(256) void gate_finish_kernel(const GateItem* __restrict__ items) {
+    __shared__ double sig[256];
+    __shared__ int perm[256];
+    __shared__ int s_keep;
+    const GateItem it = items[blockIdx.x];
+    const int r1 = it.info[0], r2 = it.info[1], d1 = it.d1, d2 = it.d2, chi = it.chi;
+    const int Mr = r1 * d1, Nc = r2 * d2;
+    const cx<T>* th = reinterpret_cast<const cx<T>*>(it.theta);      // = U Sigma (columns)
+    const cx<T>* tv = reinterpret_cast<const cx<T>*>(it.thetaV);
+    for (int u = threadIdx.x; u < Nc; u += 256) {
+        double s2 = 0;
+        for (int i = 0; i < Mr; ++i) { cx<T> v = th[i + (size_t)Mr * u]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
+        sig[u] = sqrt(s2);
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < Nc; u += 256) {      // rank by counting (descending, stable)
+        int rk = 0; double su = sig[u];
+        for (int v = 0; v < Nc; ++v) rk += (sig[v] > su) || (sig[v] == su && v < u);
+        perm[rk] = u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // NDTensors truncate! on P = S^2 (computed in the data's real precision), relative cutoff, mindim = 1
+        const int nsv = min(Mr, Nc);     // number of singular values of theta
+        int n = nsv;
+        int status = 0;
+        T truncerr = 0;
+        T p0 = (T)sig[perm[0]]; p0 = p0 * p0;
+        if (p0 <= 0) { n = 1; }
+        else if (nsv > 1) {
+            const int md = it.maxdim > 0 ? it.maxdim : nsv;
+            while (n > md) { T s = (T)sig[perm[n - 1]]; truncerr += s * s; --n; }
+            T scale = 0;
+            for (int i = 0; i < nsv; ++i) { T s = (T)sig[perm[i]]; scale += s * s; }
+            if (scale == 0) scale = 1;
+            const T cut = (T)(it.cutoff < 0 ? 0.0 : it.cutoff);
+            while (n > 1) { T s = (T)sig[perm[n - 1]]; T p = s * s; if (truncerr + p <= cut * scale) { truncerr += p; --n; } else break; }
+            truncerr = truncerr / scale;
+        }
+        if (n > it.chi_cap) { status = 1; n = it.chi_cap; }
+        double nrm = 0;
+        for (int i = 0; i < n; ++i) nrm += sig[perm[i]] * sig[perm[i]];
+        nrm = sqrt(nrm);
+        for (int i = 0; i < n; ++i) {
+            double s = sig[perm[i]];
+            it.S[i] = (it.normalize && nrm > 0) ? (double)((T)s / (T)nrm) : (double)(T)s;
+        }
+        it.info[2] = n; it.info[3] = status; *it.truncerr = (double)truncerr;
+        s_keep = n;
+    }
+    __syncthreads();
+    const int nk = s_keep;
+    const cx<double>* V1 = reinterpret_cast<const cx<double>*>(it.GV1);
+    const cx<double>* V2 = reinterpret_cast<const cx<double>*>(it.GV2);
+    cx<T>* X1 = reinterpret_cast<cx<T>*>(it.X1);
+    cx<T>* X2 = reinterpret_cast<cx<T>*>(it.X2);
+    const int n1 = it.n1, n2 = it.n2;
+    // X1[(s,b),(s1',u)] = sum_a W1[(s,b),a] / sqrt(l1_a) * (U Sigma)[(a,s1'),pi(u)] / sqrt(sigma_u)
+    for (int e = threadIdx.x; e < n1 * d1 * nk; e += 256) {
+        int kk = e % n1, nn = e / n1;
+        int s1p = nn % d1, u = nn / d1;
+        int pu = perm[u];
+        double su = sig[pu];
+        cx<double> acc = cmake<double>(0, 0);
+        if (su > 0) {
+            for (int a = 0; a < r1; ++a) {
+                cx<double> w = V1[kk + (size_t)n1 * it.idx1[a]];
+                cx<T> l = th[(a + r1 * s1p) + (size_t)Mr * pu];
+                double f = 1.0 / sqrt(it.lam1[a]);
+                cx<double> ld = cmake<double>(l.re * f, l.im * f);
+                cfma(acc, w, ld);
+            }
+            double f = 1.0 / sqrt(su);
+            acc.re *= f; acc.im *= f;
+        }
+        X1[e] = cmake<T>((T)acc.re, (T)acc.im);
+    }
+    // X2[(s,b),(s2',u)] = sum_c W2[(s,b),c] / sqrt(l2_c) * sqrt(sigma_u) conj(Vtheta[(c,s2'),pi(u)])
+    for (int e = threadIdx.x; e < n2 * d2 * nk; e += 256) {
+        int kk = e % n2, nn = e / n2;
+        int s2p = nn % d2, u = nn / d2;
+        int pu = perm[u];
+        double su = sig[pu];
+        cx<double> acc = cmake<double>(0, 0);
+        for (int c = 0; c < r2; ++c) {
+            cx<double> w = V2[kk + (size_t)n2 * it.idx2[c]];
+            cx<T> v = tv[(c + r2 * s2p) + (size_t)Nc * pu];
+            double f = 1.0 / sqrt(it.lam2[c]);
+            cx<double> vd = cmake<double>(v.re * f, -v.im * f);
+            cfma(acc, w, vd);
+        }
+        double f = sqrt(su);
+        X2[e] = cmake<T>((T)(acc.re * f), (T)(acc.im * f));
+    }
+}
+template <class T> void launch_gate_finish(hipStream_t s, const GateItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((gate_finish_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+}
+template void launch_gate_finish<float>(hipStream_t, const GateItem*, int);
+template void launch_gate_finish<double>(hipStream_t, const GateItem*, int);
+
+// ------------------------------------------------------------------------------------------------------------
+// small utilities
+// ------------------------------------------------------------------------------------------------------------
+template <class T> __global__ void diag_kernel(const DiagItem* __restrict__ items) {
+    const DiagItem it = items[blockIdx.x];
+    cx<T>* out = reinterpret_cast<cx<T>*>(it.out);
+    for (int e = threadIdx.x; e < it.chi * it.chi; e += blockDim.x) {
+        int i = e % it.chi, j = e / it.chi;
+        out[e] = cmake<T>(i == j ? (T)it.S[i] : (T)0, (T)0);
+    }
+}
+template <class T> void launch_diag(hipStream_t s, const DiagItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((diag_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+}
+template void launch_diag<float>(hipStream_t, const DiagItem*, int);
+template void launch_diag<double>(hipStream_t, const DiagItem*, int);
+
+template <class T> __global__ __launch_bounds__(256) void scale_kernel(const ScaleItem* __restrict__ items) {
+    __shared__ double sh[17];
+    const ScaleItem it = items[blockIdx.y];
+    double t = 0;
+    for (int i = threadIdx.x; i < it.npart; i += 256) t += it.norm_partials[i];
+    // fixed-order reduction would need a second pass; the block_sum order is deterministic for a given launch shape
+    t = block_sum(t, sh);
+    if (!(t > 0)) return;
+    const T f = (T)(1.0 / sqrt(t));
+    cx<T>* p = reinterpret_cast<cx<T>*>(it.t);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < it.n; i += (size_t)gridDim.x * 256) {
+        cx<T> v = p[i]; p[i] = cmake<T>(v.re * f, v.im * f);
+    }
+}
+template <class T> void launch_scale(hipStream_t s, const ScaleItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((scale_kernel<T>), dim3(64, nitems), dim3(256), 0, s, d_items);
+}
+template void launch_scale<float>(hipStream_t, const ScaleItem*, int);
+template void launch_scale<double>(hipStream_t, const ScaleItem*, int);
+
+template <class T> __global__ __launch_bounds__(256) void permute_kernel(PermItem it) {
+    const cx<T>* in = reinterpret_cast<const cx<T>*>(it.in);
+    cx<T>* out = reinterpret_cast<cx<T>*>(it.out);
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < it.n; e += (size_t)gridDim.x * 256) {
+        size_t rem = e; long long off = 0;
+        for (int k = 0; k < it.ndim; ++k) { int idx = (int)(rem % it.dims_out[k]); rem /= it.dims_out[k]; off += idx * it.stride_in[k]; }
+        out[e] = in[off];     // pure data movement: bit-exact
+    }
+}
+template <class T> void launch_permute(hipStream_t s, const PermItem& item) {
+    if (item.n == 0) return;
+    int blocks = (int)((item.n + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((permute_kernel<T>), dim3(blocks), dim3(256), 0, s, item);
+}
+template void launch_permute<float>(hipStream_t, const PermItem&);
+template void launch_permute<double>(hipStream_t, const PermItem&);
+
+template <class T> __global__ void identity_kernel(cx<T>* out, int n) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x)
+        out[e] = cmake<T>((e % n) == (e / n) ? (T)1 : (T)0, (T)0);
+}
+template <class T> void launch_identity(hipStream_t s, void* out, int n) {
+    hipLaunchKernelGGL((identity_kernel<T>), dim3((n * n + 255) / 256), dim3(256), 0, s, reinterpret_cast<cx<T>*>(out), n);
+}
+template void launch_identity<float>(hipStream_t, void*, int);
+template void launch_identity<double>(hipStream_t, void*, int);
+
+__global__ void sum_doubles_kernel(const double* in, int n, double* out) {
+    __shared__ double sh[17];
+    double t = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) t += in[i];
+    t = block_sum(t, sh);
+    if (threadIdx.x == 0) *out = t;
+}
+void launch_sum_doubles(hipStream_t s, const double* in, int n, double* out) {
+    hipLaunchKernelGGL(sum_doubles_kernel, dim3(1), dim3(256), 0, s, in, n, out);
+}
+
+}  // namespace tnqs

@@ -1,0 +1,92 @@
+// kernels.hpp -- host-side interface of the HIP kernels (gfx950).  All tensors live in the canonical layout
+// [site d][leg_0]...[leg_{z-1}] (column-major, interleaved complex).  Every heavy kernel works on "fiber tiles":
+// the tensor is viewed as  element(s, a, k, b) at  s + D*(a + PA*(k + K*b)),  where k is the leg being
+// contracted / kept, (s) the site index when it takes part (D = d) or folded into a (D = 1), and (a, b) the
+// remaining indices before / after leg k.  No explicit transposes are ever materialised.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace tnqs {
+
+// ---- batched item descriptors (POD, uploaded to the device per launch) -------------------------------------
+struct FiberItem {        // out[(s',n),(a,b)] = sum_{(s,k)} in[(s,k),(a,b)] * X[(s,k),(s',n)]
+    const void* in; void* out; const void* X;   // X: (D*K) x (Do*No) column-major complex
+    int D, PA, K, PB;     // input addressing
+    int Do, No;           // output addressing: s' + Do*(a + PA*(n + No*b))
+    int TA, TB, nta, ntb; // tile = TA x TB fibers, nta x ntb tiles
+    int tile_begin;       // first global tile id of this item
+    int want_norm;        // 1: write sum |out|^2 of each tile to norm_partials[global tile id]
+};
+
+struct GramItem {         // partial[c][i + KK*j] = sum_{(a,b) in chunk c} X[i,(a,b)] * conj(Y[j,(a,b)]),  i,j = (s,k)
+    const void* X; const void* Y; void* partial;
+    int D, PA, K, PB;
+    int TA, TB, nta, ntb;
+    int chunk_begin, nchunks, tiles_per_chunk;
+};
+
+struct ReduceItem {       // out[i + n*j] = sum_c partial[c][..] (optionally conjugated)
+    const void* partial; void* out; int n2; int nchunks; int conj; int elem_begin;
+};
+
+struct MsgFinalItem {     // BP epilogue: reduce partials, m /= sum(m), message_diff against the previous message
+    const void* partial; int nchunks; int chi;
+    const void* old_msg;  // may be null => identity
+    void* new_msg;
+    double* diff_out;     // one double
+    int normalize;
+};
+
+struct JacobiItem {       // one-sided Jacobi on A (m x n, col-major, ld = m); V (n x n) accumulates the rotations
+    void* A; void* V; int m; int n; int* sweeps_out;
+};
+
+struct EnvItem {          // env message -> Hermitian f64 matrix H (= (M + M^dagger)/2), V = I
+    const void* msg; void* H; void* V; int n;
+};
+struct EnvFinishItem {    // (H rotated, V) -> M^{1/2} and P = M^{1/2} M^{-1/2} in data precision
+    const void* A; const void* V; void* msqrt; void* proj; int n; double cutoff; int* flags; // flags[0]: full rank, flags[1]: error
+};
+
+struct GateItem {         // everything the per-gate small-algebra kernels need (pointers into the workspace)
+    // Gram factors: Jacobi output for G1, G2 (f64): A = G V, V
+    const void* GA1; const void* GV1; const void* GA2; const void* GV2;
+    int n1, n2;           // d1*chi, d2*chi
+    int d1, d2, chi;      // bond dim before the gate
+    const double* gate;   // (d1 d2) x (d1 d2) complex128 column-major, first vertex most significant
+    // outputs / scratch
+    double* lam1; double* lam2;     // kept eigenvalues (n1 / n2 doubles)
+    int* idx1; int* idx2;           // kept eigen-column indices
+    void* theta; void* thetaV;      // (r1 d1) x (r2 d2) in data precision (+ V of its SVD), ld = r1*d1
+    void* X1; void* X2;             // n1 x (d1 chi') , n2 x (d2 chi') in data precision (allocated for chi' <= chi_cap)
+    double* S;                      // chi_cap reals
+    int* info;                      // [0]=r1 [1]=r2 [2]=chi' [3]=status [4]=svd sweeps
+    double* truncerr;               // one double
+    int maxdim; double cutoff; int normalize; int chi_cap;
+};
+
+struct DiagItem { void* out; const double* S; int chi; };          // dense diag(S) message
+struct ScaleItem { void* t; size_t n; const double* norm_partials; int npart; }; // t *= 1/sqrt(sum partials)
+struct PermItem { const void* in; void* out; int ndim; int dims_out[8]; long long stride_in[8]; size_t n; };
+
+// ---- launchers (T = float or double; data are complex<T>) ------------------------------------------------------
+template <class T> void launch_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_tiles,
+                                          int TR, int KKmax, double* d_norm_partials);
+template <class T, class Acc> void launch_gram(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks,
+                                               int TR, int KKmax);
+template <class Acc, class Out> void launch_reduce(hipStream_t s, const ReduceItem* d_items, int nitems, int total_elems);
+template <class T> void launch_msg_finalize(hipStream_t s, const MsgFinalItem* d_items, int nitems);
+template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps);
+template <class T> void launch_env_prepare(hipStream_t s, const EnvItem* d_items, int nitems);
+template <class T> void launch_env_finish(hipStream_t s, const EnvFinishItem* d_items, int nitems);
+template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems);
+template <class T> void launch_gate_finish(hipStream_t s, const GateItem* d_items, int nitems);
+template <class T> void launch_diag(hipStream_t s, const DiagItem* d_items, int nitems);
+template <class T> void launch_scale(hipStream_t s, const ScaleItem* d_items, int nitems);
+template <class T> void launch_permute(hipStream_t s, const PermItem& item);
+template <class T> void launch_identity(hipStream_t s, void* out, int n);
+void launch_sum_doubles(hipStream_t s, const double* in, int n, double* out);
+
+}  // namespace tnqs

@@ -1,0 +1,176 @@
+"""Gate registry: circuit tuples ("Rzz", [v1, v2], theta) -> d^k x d^k matrices, qiskit convention.
+Mirrors src/Apply/gate_definitions.jl (GateSpec :12-17, GATES :21-64, ALIASES :74-83, toitensor :110-153,
+register_gate!/register_alias!/unregister_gate! :189-239, in-house gates :248-281, Levenshtein suggestions
+:97-105 and src/utils.jl:115-135).  Matrices are built in complex128 and cast to the state's precision by the
+library (adapt_gate, src/Apply/apply_gates.jl:41-44).  First listed vertex = most significant index."""
+from __future__ import annotations
+
+import cmath
+import math
+from typing import Callable, Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+class GateSpec:
+    def __init__(self, fn: Callable[..., np.ndarray], nparams: int = 0, rescale: Callable = lambda *p: p):
+        self.fn, self.nparams, self.rescale = fn, nparams, rescale
+
+
+_PX = np.array([[0, 1], [1, 0]], dtype=complex)
+_PY = np.array([[0, -1j], [1j, 0]], dtype=complex)
+_PZ = np.array([[1, 0], [0, -1]], dtype=complex)
+_PAULI = {"X": _PX, "Y": _PY, "Z": _PZ}
+
+
+def _rot(p: np.ndarray, phi: float) -> np.ndarray:
+    """exp(-i phi P) for an involutory P (P^2 = 1)"""
+    return math.cos(phi) * np.eye(p.shape[0], dtype=complex) - 1j * math.sin(phi) * p
+
+
+def _exp_herm(h: np.ndarray, t: float) -> np.ndarray:
+    w, v = np.linalg.eigh(h)
+    return (v * np.exp(-1j * t * w)) @ v.conj().T
+
+
+def _controlled(u: np.ndarray) -> np.ndarray:
+    m = np.eye(4, dtype=complex)
+    m[2:, 2:] = u
+    return m
+
+
+def _half(t):
+    return (t / 2,)
+
+
+GATES: Dict[str, GateSpec] = {
+    "X": GateSpec(lambda: _PX.copy()), "Y": GateSpec(lambda: _PY.copy()), "Z": GateSpec(lambda: _PZ.copy()),
+    "H": GateSpec(lambda: np.array([[1, 1], [1, -1]], dtype=complex) / math.sqrt(2)),
+    "Rx": GateSpec(lambda t: _rot(_PX, t / 2), 1), "Ry": GateSpec(lambda t: _rot(_PY, t / 2), 1),
+    "Rz": GateSpec(lambda t: _rot(_PZ, t / 2), 1),
+    "P": GateSpec(lambda p: np.diag([1.0, cmath.exp(1j * p)]), 1),
+    "CNOT": GateSpec(lambda: _controlled(_PX)), "CX": GateSpec(lambda: _controlled(_PX)),
+    "CY": GateSpec(lambda: _controlled(_PY)), "CZ": GateSpec(lambda: _controlled(_PZ)),
+    "SWAP": GateSpec(lambda: np.eye(4, dtype=complex)[[0, 2, 1, 3]]),
+    "iSWAP": GateSpec(lambda: np.array([[1, 0, 0, 0], [0, 0, 1j, 0], [0, 1j, 0, 0], [0, 0, 0, 1]], dtype=complex)),
+    "√SWAP": GateSpec(lambda: np.array([[1, 0, 0, 0], [0, (1 + 1j) / 2, (1 - 1j) / 2, 0],
+                                         [0, (1 - 1j) / 2, (1 + 1j) / 2, 0], [0, 0, 0, 1]], dtype=complex)),
+    "√iSWAP": GateSpec(lambda: np.array([[1, 0, 0, 0], [0, 1 / math.sqrt(2), 1j / math.sqrt(2), 0],
+                                          [0, 1j / math.sqrt(2), 1 / math.sqrt(2), 0], [0, 0, 0, 1]], dtype=complex)),
+    # qiskit Rxx(theta) = exp(-i theta XX / 2); the reference forwards phi = theta/2 to ITensors (:46-51)
+    "Rxx": GateSpec(lambda p: _rot(np.kron(_PX, _PX), p), 1, _half),
+    "Ryy": GateSpec(lambda p: _rot(np.kron(_PY, _PY), p), 1, _half),
+    "Rzz": GateSpec(lambda p: _rot(np.kron(_PZ, _PZ), p), 1, _half),
+    "CRx": GateSpec(lambda t: _controlled(_rot(_PX, t / 2)), 1), "CRy": GateSpec(lambda t: _controlled(_rot(_PY, t / 2)), 1),
+    "CRz": GateSpec(lambda t: _controlled(_rot(_PZ, t / 2)), 1),
+    "CPHASE": GateSpec(lambda p: np.diag([1, 1, 1, cmath.exp(1j * p)]), 1),
+    "Rxxyy": GateSpec(lambda t: _exp_herm(0.5 * (np.kron(_PX, _PX) + np.kron(_PY, _PY)), t), 1),
+    "Rxxyyzz": GateSpec(lambda t: _exp_herm(0.5 * (np.kron(_PX, _PX) + np.kron(_PY, _PY) + np.kron(_PZ, _PZ)), t), 1),
+    "xx_plus_yy": GateSpec(lambda t, b: np.array(
+        [[1, 0, 0, 0], [0, math.cos(t / 2), -1j * math.sin(t / 2) * cmath.exp(-1j * b), 0],
+         [0, -1j * math.sin(t / 2) * cmath.exp(1j * b), math.cos(t / 2), 0], [0, 0, 0, 1]], dtype=complex), 2),
+}
+BUILTIN_GATES = frozenset(GATES)
+
+
+def _default_aliases() -> Dict[str, str]:
+    m = {}
+    for canon in GATES:
+        low = canon.lower()
+        if low != canon:
+            m[low] = canon
+    m["cp"] = "CPHASE"
+    return m
+
+
+ALIASES: Dict[str, str] = _default_aliases()
+
+
+def levenshtein(a: str, b: str) -> int:
+    if not a:
+        return len(b)
+    if not b:
+        return len(a)
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i] + [0] * len(b)
+        for j, cb in enumerate(b, 1):
+            cur[j] = min(cur[j - 1] + 1, prev[j] + 1, prev[j - 1] + (ca != cb))
+        prev = cur
+    return prev[-1]
+
+
+def _suggestions(name: str, topk: int = 3, maxdist: int = 2):
+    scored = sorted(((levenshtein(name.lower(), k.lower()), k) for k in GATES))
+    return [k for (dist, k) in scored if dist <= maxdist][:topk]
+
+
+def _resolve(name: str) -> Optional[GateSpec]:
+    if name in GATES:
+        return GATES[name]
+    canon = ALIASES.get(name)
+    return GATES[canon] if canon is not None else None
+
+
+def register_gate(name: str, fn: Callable[..., np.ndarray], nparams: int = 0, rescale: Optional[Callable] = None):
+    """register_gate! (:189-203).  `fn(*params)` returns the matrix; built-in names are locked."""
+    if name in BUILTIN_GATES:
+        raise ValueError(f'"{name}" is a built-in gate and cannot be overwritten. Choose a different name for your custom gate.')
+    GATES[name] = GateSpec(fn, nparams, rescale if rescale is not None else (lambda *p: p))
+    return name
+
+
+def register_alias(alias: str, canonical: str):
+    if canonical not in GATES:
+        raise ValueError(f'Cannot register alias "{alias}" → "{canonical}": canonical gate is not registered.')
+    ALIASES[alias] = canonical
+    return alias
+
+
+def unregister_gate(name: str):
+    if name in BUILTIN_GATES:
+        raise ValueError(f'"{name}" is a built-in gate and cannot be unregistered.')
+    GATES.pop(name, None)
+    for a, c in list(ALIASES.items()):
+        if c == name:
+            del ALIASES[a]
+    return name
+
+
+def gate_matrix(name, *params) -> np.ndarray:
+    """name -> complex128 matrix (toitensor :118-153)"""
+    if isinstance(name, np.ndarray):
+        return np.asarray(name, dtype=complex)
+    if len(name) > 1 and all(c in "XYZxyz" for c in name):          # Pauli-string sugar (:123-128)
+        m = np.ones((1, 1), dtype=complex)
+        for c in name:
+            m = np.kron(m, _PAULI[c.upper()])
+        return m
+    spec = _resolve(name)
+    if spec is None:
+        sug = _suggestions(name)
+        msg = f'Unknown gate "{name}".'
+        msg += (" Did you mean: " + ", ".join(f'"{s}"' for s in sug) + "?") if sug else f" Registered gates: {sorted(GATES)}."
+        raise ValueError(msg)
+    if spec.nparams == 0:
+        return np.asarray(spec.fn(), dtype=complex)
+    if len(params) == 1 and isinstance(params[0], (tuple, list)):
+        params = tuple(params[0])
+    if len(params) != spec.nparams:
+        raise ValueError(f'Gate "{name}" expects {spec.nparams} parameter(s), got {len(params)}.')
+    scaled = spec.rescale(*params)
+    return np.asarray(spec.fn(*scaled), dtype=complex)
+
+
+def resolve_gate(gate, graph) -> Tuple[np.ndarray, list]:
+    """circuit tuple -> (matrix, [vertices]) with collect_vertices semantics (src/utils.jl:137-160)"""
+    name, verts = gate[0], gate[1]
+    if not isinstance(verts, (list,)):
+        verts = [verts] if verts in graph.index else list(verts)
+    verts = list(verts)
+    for v in verts:
+        if v not in graph.index:
+            raise RuntimeError("Vertex does not match the vertex type of the tensor network")
+    if len(set(verts)) != len(verts):
+        raise RuntimeError("Repeated vertex in collection")
+    return gate_matrix(name, *gate[2:]), verts

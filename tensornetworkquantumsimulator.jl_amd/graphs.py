@@ -1,0 +1,280 @@
+"""Host-side graph helpers: the NamedGraphs / graph_ops.jl subset the hot path needs
+(reference: src/graph_ops.jl:6-18,50-64; NamedGraphs.named_grid; SimpleGraphAlgorithms.edge_color via src/imports.jl:9)."""
+from __future__ import annotations
+
+import itertools
+from collections import deque
+from typing import Dict, Hashable, Iterable, List, Sequence, Tuple
+
+Vertex = Hashable
+
+
+class NamedGraph:
+    """Undirected simple graph with ordered, arbitrarily-named vertices.  Vertex ids handed to the C ABI are the
+    positions in `vertices`; edge ids are positions in `edges`."""
+
+    def __init__(self, vertices: Sequence[Vertex], edges: Iterable[Tuple[Vertex, Vertex]] = ()):
+        self.vertices: List[Vertex] = list(vertices)
+        if len(set(self.vertices)) != len(self.vertices):
+            raise ValueError("repeated vertex")
+        self.index: Dict[Vertex, int] = {v: i for i, v in enumerate(self.vertices)}
+        self.edges: List[Tuple[Vertex, Vertex]] = []
+        self._adj: Dict[Vertex, List[Vertex]] = {v: [] for v in self.vertices}
+        self._eset = set()
+        for (a, b) in edges:
+            self.add_edge(a, b)
+
+    def add_edge(self, a: Vertex, b: Vertex):
+        if a == b:
+            raise ValueError("self loops are not supported")
+        if a not in self.index or b not in self.index:
+            raise KeyError(f"edge ({a}, {b}) names an unknown vertex")
+        key = frozenset((a, b))
+        if key in self._eset:
+            return
+        self._eset.add(key)
+        self.edges.append((a, b))
+        self._adj[a].append(b)
+        self._adj[b].append(a)
+
+    def has_edge(self, a, b) -> bool:
+        return frozenset((a, b)) in self._eset
+
+    def neighbors(self, v) -> List[Vertex]:
+        """neighbours in ascending vertex position (= leg order of the canonical device layout)"""
+        return sorted(self._adj[v], key=self.index.__getitem__)
+
+    def degree(self, v) -> int:
+        return len(self._adj[v])
+
+    def nv(self) -> int:
+        return len(self.vertices)
+
+    def ne(self) -> int:
+        return len(self.edges)
+
+    def is_tree(self) -> bool:
+        """no cycles (forest): BP defaults use maxiter = 1, no tolerance (beliefpropagationcache.jl:39,110-117)"""
+        parent = list(range(len(self.vertices)))
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        for (a, b) in self.edges:
+            ra, rb = find(self.index[a]), find(self.index[b])
+            if ra == rb:
+                return False
+            parent[ra] = rb
+        return True
+
+    def is_connected(self) -> bool:
+        if not self.vertices:
+            return True
+        seen = {self.vertices[0]}
+        dq = deque(seen)
+        while dq:
+            x = dq.popleft()
+            for y in self._adj[x]:
+                if y not in seen:
+                    seen.add(y)
+                    dq.append(y)
+        return len(seen) == len(self.vertices)
+
+
+def named_grid(dims, periodic: bool = False) -> NamedGraph:
+    """NamedGraphs.named_grid: 1-based tuple vertices, first coordinate fastest.  Periodic dimensions of length
+    <= 2 do not wrap (they would collapse onto existing edges)."""
+    if isinstance(dims, int):
+        dims = (dims,)
+    dims = tuple(int(n) for n in dims)
+    verts = [tuple(reversed(t)) for t in itertools.product(*[range(1, n + 1) for n in reversed(dims)])]
+    g = NamedGraph(verts)
+    for v in verts:
+        for ax, n in enumerate(dims):
+            if v[ax] < n:
+                w = v[:ax] + (v[ax] + 1,) + v[ax + 1:]
+                g.add_edge(v, w)
+            elif periodic and n > 2:
+                w = v[:ax] + (1,) + v[ax + 1:]
+                g.add_edge(v, w)
+    return g
+
+
+def named_hexagonal_lattice_graph(nx: int, ny: int) -> NamedGraph:
+    """honeycomb lattice of nx x ny hexagons (brick-wall construction)"""
+    rows, cols = 2 * nx + 2, ny
+    dropped = {(0, rows - 1), (cols, (rows - 1) * (cols % 2))}
+    nodes = [(i, j) for i in range(cols + 1) for j in range(rows) if (i, j) not in dropped]
+    name = {v: (v[0] + 1, v[1] + 1) for v in nodes}
+    g = NamedGraph([name[v] for v in nodes])
+    present = set(nodes)
+    for (i, j) in nodes:
+        if (i, j + 1) in present:
+            g.add_edge(name[(i, j)], name[(i, j + 1)])
+    for (i, j) in nodes:
+        if i < cols and i % 2 == j % 2 and (i + 1, j) in present:
+            g.add_edge(name[(i, j)], name[(i + 1, j)])
+    # keep the edge order of the generator: all column edges, then all row edges
+    return g
+
+
+def heavy_hexagonal_lattice(nx: int, ny: int) -> NamedGraph:
+    """src/graph_ops.jl:6-18 -- every edge of the honeycomb lattice gets a decorating vertex"""
+    h = named_hexagonal_lattice_graph(nx, ny)
+    ren = {v: (2 * v[0] - 1, 2 * v[1] - 1) for v in h.vertices}
+    verts = [ren[v] for v in h.vertices]
+    edges = []
+    for (a, b) in h.edges:
+        a2, b2 = ren[a], ren[b]
+        mid = ((a2[0] + b2[0]) / 2, (a2[1] + b2[1]) / 2)
+        verts.append(mid)
+        edges += [(a2, mid), (mid, b2)]
+    return NamedGraph(verts, edges)
+
+
+def named_comb_tree(dims) -> NamedGraph:
+    nx, ny = dims
+    verts = [(i, j) for j in range(1, ny + 1) for i in range(1, nx + 1)]
+    g = NamedGraph(verts)
+    for i in range(1, nx):
+        g.add_edge((i, 1), (i + 1, 1))
+    for i in range(1, nx + 1):
+        for j in range(1, ny):
+            g.add_edge((i, j), (i, j + 1))
+    return g
+
+
+def build_graph_from_gates(circuit) -> NamedGraph:
+    """src/graph_ops.jl:50-64"""
+    verts = []
+    for gate in circuit:
+        vs = gate[1] if isinstance(gate[1], list) else [gate[1]]
+        for v in vs:
+            if v not in verts:
+                verts.append(v)
+    g = NamedGraph(verts)
+    for gate in circuit:
+        vs = gate[1] if isinstance(gate[1], list) else [gate[1]]
+        if len(vs) == 2:
+            g.add_edge(vs[0], vs[1])
+    if not g.is_connected():
+        raise RuntimeError("The circuit graph is not connected, meaning the resulting tensor network will be "
+                           "disconnected which we do not support.")
+    return g
+
+
+build_graph_from_circuit = build_graph_from_gates
+
+
+def _bipartition(g: NamedGraph):
+    side = {}
+    for root in g.vertices:
+        if root in side:
+            continue
+        side[root] = 0
+        dq = deque([root])
+        while dq:
+            x = dq.popleft()
+            for y in g._adj[x]:
+                if y not in side:
+                    side[y] = 1 - side[x]
+                    dq.append(y)
+                elif side[y] == side[x]:
+                    return None
+    return side
+
+
+def edge_color(g: NamedGraph, k: int | None = None) -> List[List[Tuple[Vertex, Vertex]]]:
+    """Proper edge colouring into groups of vertex-disjoint edges (role of SimpleGraphAlgorithms.edge_color(g, k),
+    src/truncate.jl:20, examples/2dIsing_dynamics.jl:25).  Bipartite graphs get an optimal max-degree colouring
+    (Koenig, alternating-path recolouring); other graphs a greedy one.  Raises if more than k colours are needed."""
+    maxdeg = max((g.degree(v) for v in g.vertices), default=0)
+    color_at: Dict[Vertex, Dict[int, Vertex]] = {v: {} for v in g.vertices}    # vertex -> colour -> neighbour
+    ecol: Dict[frozenset, int] = {}
+
+    def free(v, limit):
+        for c in range(limit):
+            if c not in color_at[v]:
+                return c
+        return None
+
+    if _bipartition(g) is not None:
+        for (u, v) in g.edges:
+            a, b = free(u, maxdeg), free(v, maxdeg)
+            if a != b and a in color_at[v]:
+                # flip the a/b alternating path that starts at v with colour a (it cannot reach u in a bipartite graph)
+                path = []
+                x, c, d = v, a, b
+                while c in color_at[x]:
+                    y = color_at[x][c]
+                    path.append((x, y, c))
+                    x, c, d = y, d, c
+                for (x, y, c) in path:
+                    del color_at[x][c]
+                    del color_at[y][c]
+                for (x, y, c) in path:
+                    nc = b if c == a else a
+                    color_at[x][nc] = y
+                    color_at[y][nc] = x
+                    ecol[frozenset((x, y))] = nc
+            color_at[u][a] = v
+            color_at[v][a] = u
+            ecol[frozenset((u, v))] = a
+    else:
+        for (u, v) in g.edges:
+            c = 0
+            while c in color_at[u] or c in color_at[v]:
+                c += 1
+            color_at[u][c] = v
+            color_at[v][c] = u
+            ecol[frozenset((u, v))] = c
+    ncol = max(ecol.values(), default=-1) + 1
+    if k is not None and ncol > k:
+        raise ValueError(f"edge_color: needs {ncol} colours, {k} requested")
+    groups: List[List[Tuple[Vertex, Vertex]]] = [[] for _ in range(ncol)]
+    for (u, v) in g.edges:
+        groups[ecol[frozenset((u, v))]].append((u, v))
+    return groups
+
+
+def forest_cover_edge_sequence(g: NamedGraph) -> List[Tuple[Vertex, Vertex]]:
+    """The reference's default BP edge order (beliefpropagationcache.jl:28, NamedGraphs forest_cover_edge_sequence):
+    for each spanning forest of a greedy cover, DFS post-order edges towards the root, then their reverses in
+    reverse order.  Pass it as `edge_sequence=` to `update` to sweep in the reference's order."""
+    remaining = {frozenset(e) for e in g.edges}
+    seq: List[Tuple[Vertex, Vertex]] = []
+    while remaining:
+        visited = set()
+        used = set()
+        for root in g.vertices:
+            if root in visited or not any(frozenset((root, y)) in remaining for y in g._adj[root]):
+                continue
+            children: Dict[Vertex, List[Vertex]] = {root: []}
+            visited.add(root)
+            dq = deque([root])
+            while dq:
+                x = dq.popleft()
+                for y in g.neighbors(x):
+                    if y not in visited and frozenset((x, y)) in remaining:
+                        visited.add(y)
+                        children.setdefault(x, []).append(y)
+                        children.setdefault(y, [])
+                        used.add(frozenset((x, y)))
+                        dq.append(y)
+            post: List[Tuple[Vertex, Vertex]] = []
+            stack = [(root, iter(children[root]))]
+            while stack:
+                x, it = stack[-1]
+                nxt = next(it, None)
+                if nxt is None:
+                    stack.pop()
+                    if stack:
+                        post.append((x, stack[-1][0]))
+                else:
+                    stack.append((nxt, iter(children[nxt])))
+            seq.extend(post)
+            seq.extend((b, a) for (a, b) in reversed(post))
+        remaining -= used
+    return seq

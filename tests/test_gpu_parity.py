@@ -1,0 +1,270 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+Tolerances: complex128 -> 1e-9 relative on gauge-invariant quantities (messages, S, truncerr, <Z>, state vector);
+complex64 -> 2e-4 on messages / S / <Z>, 1e-5 absolute on truncation errors.  Index work (leg permutations,
+bond dimensions, scheduling counts) is exact."""
+import itertools
+import math
+
+import numpy as np
+import pytest
+
+import tnqs_amd as tn
+import tnqs_oracle as o
+import statevector as sv
+from helpers import (to_oracle_graph, to_oracle_state, oracle_cache_from_device, colour_sequence, tfim_layer)
+
+pytestmark = pytest.mark.gpu
+
+Z = np.diag([1.0, -1.0]).astype(complex)
+TOL = {np.dtype(np.complex128): 1e-9, np.dtype(np.complex64): 2e-4}
+
+
+def tight(dtype):
+    return dict(maxiter=200, tolerance=1e-13 if np.dtype(dtype) == np.complex128 else 1e-9)
+
+
+def compare_messages(bpc, oc, tol, edges=None):
+    worst = 0.0
+    for (a, b) in (edges or bpc.graph.edges):
+        for e in ((a, b), (b, a)):
+            m, mo = bpc.message(e), oc.message(e)
+            assert m.shape == mo.shape, (e, m.shape, mo.shape)
+            worst = max(worst, np.max(np.abs(m - mo)) / max(1e-30, np.max(np.abs(mo))))
+    assert worst <= tol, f"message mismatch {worst:.3e} > {tol}"
+    return worst
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_site_tensor_roundtrip_is_bit_exact(dtype):
+    """K13: leg permutation import/export (bit-exact)"""
+    g = tn.named_grid((3, 3))
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=3, seed=1)
+    # odd dims so that a wrong permutation cannot pass
+    rng = np.random.default_rng(2)
+    dims = {frozenset(e): int(rng.integers(2, 5)) for e in g.edges}
+    tensors = {}
+    for v in g.vertices:
+        shp = (2,) + tuple(dims[frozenset((v, w))] for w in g.neighbors(v))
+        tensors[v] = (rng.standard_normal(shp) + 1j * rng.standard_normal(shp)).astype(dtype)
+    psi = tn.TensorNetworkState(g, tensors)
+    bpc = tn.BeliefPropagationCache(psi)
+    for v in g.vertices:
+        assert np.array_equal(bpc.tensor(v), tensors[v]), v
+    for (a, b) in g.edges:
+        assert bpc.bond_dim(a, b) == dims[frozenset((a, b))]
+    m = bpc.message(g.edges[0])
+    assert np.array_equal(m, np.eye(m.shape[0], dtype=dtype))           # unset message = identity
+    c = bpc.copy()
+    assert np.array_equal(c.tensor(g.vertices[4]), tensors[g.vertices[4]])
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_rdm_and_expect_with_default_messages(dtype):
+    """fiber_gemm chain (skipped: identity messages) + gram(keep site) + reduce"""
+    g = tn.named_grid((2, 3))
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=3, seed=3)
+    bpc = tn.BeliefPropagationCache(psi)
+    oc = o.BeliefPropagationCache(to_oracle_state(psi))
+    for v in g.vertices:
+        e1, e2 = tn.expect(bpc, ("Z", [v])), o.expect_1site(oc, Z, v)
+        assert abs(e1 - e2) < TOL[np.dtype(dtype)], (v, e1, e2)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+@pytest.mark.parametrize("lattice", ["grid3x3", "hh11", "grid2x2x3"])
+def test_bp_update_matches_oracle(dtype, lattice):
+    """K1-K3: message update + normalisation + diff, Gauss-Seidel over an explicit edge sequence"""
+    g = {"grid3x3": lambda: tn.named_grid((3, 3)), "hh11": lambda: tn.heavy_hexagonal_lattice(1, 1),
+         "grid2x2x3": lambda: tn.named_grid((2, 2, 3))}[lattice]()
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=3, seed=5)
+    tol = TOL[np.dtype(dtype)]
+    bpc = tn.BeliefPropagationCache(psi)
+    for seq_name in ("forest", "colour"):
+        seq = tn.forest_cover_edge_sequence(g) if seq_name == "forest" else colour_sequence(g, tn.edge_color(g))
+        # one sweep, then a fixed number of sweeps: trajectories must agree, not only fixed points
+        for nsweep in (1, 3):
+            info = {}
+            out = tn.update(bpc, maxiter=nsweep, tolerance=None, edge_sequence=seq, info=info)
+            oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), maxiter=nsweep, tolerance=None, edge_sequence=seq)
+            compare_messages(out, oc, tol)
+    # convergence loop with the default (library) sequence against the oracle at its fixed point
+    info = {}
+    out = tn.update(bpc, info=info, **tight(dtype))
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **tight(dtype))
+    compare_messages(out, oc, 50 * tol)
+    assert info["niter"] < 200
+    for v in g.vertices[:4]:
+        assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oc, Z, v)) < 50 * tol
+    # the input cache is untouched (value semantics, abstract...:228)
+    assert np.array_equal(bpc.message(g.edges[0]), np.eye(3, dtype=dtype))
+
+
+def test_bp_diff_and_iteration_count_match_oracle():
+    g = tn.named_grid((3, 3))
+    psi = tn.random_tensornetworkstate(np.complex128, g, bond_dimension=2, seed=8)
+    seq = tn.forest_cover_edge_sequence(g)
+    info, oinfo = {}, {}
+    tn.update(tn.BeliefPropagationCache(psi), maxiter=50, tolerance=1e-10, edge_sequence=seq, info=info)
+    o.update(o.BeliefPropagationCache(to_oracle_state(psi)), maxiter=50, tolerance=1e-10, edge_sequence=seq, info=oinfo)
+    assert info["niter"] == oinfo["niter"]
+    assert abs(info["diff"] - oinfo["diff"]) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_one_site_gates(dtype):
+    """K11 (+ normalisation K10)"""
+    g = tn.named_grid((2, 2))
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=3, seed=9)
+    circuit = [("Rx", [v], 0.3 + 0.1 * i) for i, v in enumerate(g.vertices)] + [("H", [g.vertices[0]])]
+    for norm in (False, True):
+        out, errs = tn.apply_gates(circuit, tn.BeliefPropagationCache(psi), apply_kwargs=dict(normalize_tensors=norm),
+                                   update_cache=False)
+        oc, oerrs = o.apply_gates(circuit, o.BeliefPropagationCache(to_oracle_state(psi)),
+                                  apply_kwargs=dict(normalize_tensors=norm), update_cache=False)
+        assert np.all(errs == 0)
+        for v in g.vertices:
+            assert np.max(np.abs(out.tensor(v) - oc.tns.tensors[v])) < TOL[np.dtype(dtype)], v
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_two_site_gate_on_a_dimer(dtype):
+    """K6-K9, K12 with no environments: exact against the state vector, S against the oracle"""
+    g = tn.NamedGraph([(1, 1), (2, 1)], [((1, 1), (2, 1))])
+    circuit = [("Rx", [(1, 1)], 0.5), ("Rx", [(2, 1)], 0.2), ("CPHASE", [(1, 1), (2, 1)], -0.3), ("Rxx", [(1, 1), (2, 1)], 0.7)]
+    psi0 = tn.tensornetworkstate(dtype, lambda v: "↓", g)
+    kw = dict(maxdim=2, cutoff=1e-10, normalize_tensors=False)
+    out, errs = tn.apply_gates(circuit, tn.BeliefPropagationCache(psi0), apply_kwargs=kw)
+    oc, oerrs = o.apply_gates(circuit, o.update(o.BeliefPropagationCache(to_oracle_state(psi0))), apply_kwargs=kw)
+    tol = TOL[np.dtype(dtype)]
+    assert out.maxvirtualdim() == oc.tns.maxvirtualdim() <= 2
+    vec = sv.tns_to_statevector(to_oracle_state(out.network()))
+    ref = sv.run_circuit_statevector(to_oracle_graph(g), {v: [0, 1] for v in g.vertices}, circuit)
+    assert abs(np.vdot(vec, vec).real - 1) < 10 * tol               # test/test_apply.jl:20
+    assert sv.fidelity(vec, ref) > 1 - 10 * tol
+    assert np.allclose(errs, oerrs, atol=1e-5 if dtype == np.complex64 else 1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_tfim_layers_3x3_exact_without_truncation(dtype):
+    """test/test_apply.jl:23-53 + simple_update.jl:4: un-truncated simple update is exact"""
+    g = tn.named_grid((3, 3))
+    groups = tn.edge_color(g, 4)
+    layer = tfim_layer(g, groups)
+    psi0 = tn.tensornetworkstate(dtype, lambda v: "↑", g)
+    bpc = tn.update(tn.BeliefPropagationCache(psi0))
+    nl = 2
+    kw = dict(cutoff=1e-10 if dtype == np.complex64 else 1e-24, normalize_tensors=False)
+    for _ in range(nl):
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=tight(dtype))
+        assert np.all(errs < 1e-6)
+    tol = TOL[np.dtype(dtype)]
+    vec = sv.tns_to_statevector(to_oracle_state(bpc.network()))
+    ref = sv.run_circuit_statevector(to_oracle_graph(g), {v: [1, 0] for v in g.vertices}, layer * nl)
+    assert abs(np.vdot(vec, vec).real - 1) < 20 * tol
+    assert sv.fidelity(vec, ref) > 1 - 20 * tol
+    assert bpc.network().dtype == dtype
+
+
+@pytest.mark.parametrize("dtype,maxdim", [(np.complex128, 2), (np.complex128, 4), (np.complex64, 3)])
+def test_tfim_layers_truncated_match_oracle(dtype, maxdim):
+    """full apply_gates schedule with truncation: S spectra (bond messages), truncation errors, bond dims, <Z>,
+    number of BP updates -- against the oracle run with the same explicit edge sequence"""
+    g = tn.named_grid((3, 3))
+    groups = tn.edge_color(g, 4)
+    layer = tfim_layer(g, groups)
+    seq = colour_sequence(g, groups)
+    bpkw = dict(edge_sequence=seq, **tight(dtype))
+    kw = dict(maxdim=maxdim, cutoff=1e-10, normalize_tensors=True)
+    psi0 = tn.tensornetworkstate(dtype, lambda v: "↑", g)
+    bpc = tn.update(tn.BeliefPropagationCache(psi0), **bpkw)
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi0)), **bpkw)
+    tol = TOL[np.dtype(dtype)]
+    for layer_no in range(3):
+        info, oinfo = {}, {}
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=bpkw, info=info)
+        oc, oerrs = o.apply_gates(layer, oc, apply_kwargs=kw, bp_update_kwargs=bpkw, info=oinfo)
+        assert info["n_updates"] == oinfo["n_updates"] == len(groups) + 1       # c+1 updates per layer
+        assert info["n_two_site"] == g.ne()
+        for (a, b) in g.edges:
+            assert bpc.bond_dim(a, b) == oc.tns.bond_dim(a, b), (layer_no, a, b)
+        assert np.max(np.abs(errs - oerrs)) < (1e-5 if dtype == np.complex64 else 1e-9), (layer_no, errs, oerrs)
+        scale = 30 * (layer_no + 1)
+        compare_messages(bpc, oc, scale * tol)
+        for v in g.vertices:
+            assert abs(tn.expect(bpc, ("Z", [v])) - o.expect_1site(oc, Z, v)) < scale * tol, (layer_no, v)
+    ez = tn.expect_all(bpc, "Z")
+    for i, v in enumerate(g.vertices):
+        assert abs(ez[i] - tn.expect(bpc, ("Z", [v]))) < 1e-12
+
+
+def test_heavy_hex_layer_matches_oracle():
+    """irregular degrees (2 and 3): examples/heavyhexIsing_dynamics.jl circuit on heavy-hex(1,1)"""
+    g = tn.heavy_hexagonal_lattice(1, 1)
+    groups = tn.edge_color(g, 3)
+    layer = [("Rx", [v], 0.4) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rzz", [a, b], math.pi / 2) for (a, b) in grp]
+    seq = colour_sequence(g, groups)
+    bpkw = dict(edge_sequence=seq, **tight(np.complex128))
+    kw = dict(maxdim=4, cutoff=1e-12, normalize_tensors=True)
+    psi0 = tn.tensornetworkstate(np.complex128, lambda v: "↑", g)
+    bpc = tn.update(tn.BeliefPropagationCache(psi0), **bpkw)
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi0)), **bpkw)
+    for _ in range(3):
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=bpkw)
+        oc, oerrs = o.apply_gates(layer, oc, apply_kwargs=kw, bp_update_kwargs=bpkw)
+        assert np.max(np.abs(errs - oerrs)) < 1e-9
+    compare_messages(bpc, oc, 1e-7)
+    for v in g.vertices:
+        assert abs(tn.expect(bpc, ("Z", [v])) - o.expect_1site(oc, Z, v)) < 1e-7
+
+
+def test_truncate_matches_oracle():
+    """src/truncate.jl:12-38 + test/test_truncate.jl:29-33"""
+    g = tn.named_hexagonal_lattice_graph(2, 2)
+    groups = tn.edge_color(g, 3)
+    seq = colour_sequence(g, groups)
+    bpkw = dict(edge_sequence=seq, **tight(np.complex128))
+    psi = tn.random_tensornetworkstate(np.complex128, g, bond_dimension=3, seed=3)
+    bpc = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)
+    t = tn.truncate(bpc, maxdim=2, cutoff=1e-10, edge_color=groups, bp_update_kwargs=bpkw)
+    ot = o.truncate(oc, maxdim=2, cutoff=1e-10, edge_groups=groups, bp_update_kwargs=bpkw)
+    assert t.maxvirtualdim() <= 2
+    compare_messages(t, ot, 1e-7)
+    a = sv.tns_to_statevector(to_oracle_state(t.network()))
+    b = sv.tns_to_statevector(ot.tns)
+    assert sv.fidelity(a, b) > 1 - 1e-8
+    assert bpc.maxvirtualdim() == 3                                   # input untouched
+
+
+def test_errors_mirror_the_reference():
+    """apply_gates.jl:109-120, gate_definitions.jl:130-140"""
+    g = tn.named_grid((3, 3))
+    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex64, lambda v: "↑", g))
+    with pytest.raises(tn.TnqsError, match="non-adjacent"):
+        tn.apply_gates([("Rzz", [(1, 1), (3, 3)], 0.1)], bpc)
+    with pytest.raises(tn.TnqsError, match="only one- and two-site"):
+        tn.apply_gates([(np.eye(8), [(1, 1), (2, 1), (3, 1)])], bpc)
+    with pytest.raises(ValueError, match="Unknown gate"):
+        tn.apply_gates([("Rzx", [(1, 1), (2, 1)], 0.1)], bpc)
+    assert bpc.maxvirtualdim() == 1
+
+
+def test_scheduling_rule_counts():
+    """apply_gates.jl:68-90: only two-site gates touching affected vertices trigger an update"""
+    g = tn.named_grid((3, 3))
+    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex128, lambda v: "↑", g))
+    info = {}
+    # disjoint two-site gates on fresh vertices: no update before any of them, one final update
+    tn.apply_gates([("Rzz", [(1, 1), (2, 1)], 0.3), ("Rzz", [(1, 2), (2, 2)], 0.3)], bpc, info=info)
+    assert info["n_updates"] == 1 and info["n_batches"] == 1
+    # second gate shares a vertex: one update in between + final
+    tn.apply_gates([("Rzz", [(1, 1), (2, 1)], 0.3), ("Rzz", [(2, 1), (3, 1)], 0.3)], bpc, info=info)
+    assert info["n_updates"] == 2 and info["n_batches"] == 2
+    # one-site gates poison the set (:88-90) but never trigger by themselves
+    tn.apply_gates([("Rx", [(1, 1)], 0.3), ("Rz", [(1, 1)], 0.3), ("Rzz", [(1, 1), (2, 1)], 0.3)], bpc, info=info)
+    assert info["n_updates"] == 2 and info["n_batches"] == 3
+    tn.apply_gates([("Rx", [(1, 1)], 0.3)], bpc, update_cache=False, info=info)
+    assert info["n_updates"] == 0

@@ -1,0 +1,70 @@
+"""Host-side logic (no GPU): graphs, edge colouring, gate registry -- checked against the oracle's independent
+restatement where both exist."""
+import numpy as np
+import pytest
+
+import tnqs_amd as tn
+import tnqs_oracle as o
+
+
+@pytest.mark.parametrize("g,k", [(tn.named_grid((20, 20)), 4), (tn.heavy_hexagonal_lattice(5, 5), 3),
+                                 (tn.named_grid((10, 10, 10), periodic=True), 6), (tn.named_grid((5, 5)), 4),
+                                 (tn.named_grid((3, 3, 3), periodic=True), None)])
+def test_edge_color_is_proper(g, k):
+    groups = tn.edge_color(g, k)
+    assert sum(len(x) for x in groups) == g.ne()
+    for grp in groups:
+        vs = [v for e in grp for v in e]
+        assert len(vs) == len(set(vs))
+        assert all(g.has_edge(a, b) for (a, b) in grp)
+
+
+def test_lattice_sizes_match_baseline_configs():
+    g = tn.named_grid((20, 20)); assert (g.nv(), g.ne()) == (400, 760)
+    g = tn.heavy_hexagonal_lattice(5, 5); assert (g.nv(), g.ne()) == (164, 188)
+    assert sorted(set(g.degree(v) for v in g.vertices)) == [2, 3]
+    g = tn.named_grid((10, 10, 10), periodic=True); assert (g.nv(), g.ne()) == (1000, 3000)
+    g = tn.named_grid((32, 32)); assert (g.nv(), g.ne()) == (1024, 1984)
+    g = tn.named_grid((5, 5)); assert (g.nv(), g.ne()) == (25, 40)
+    og = o.named_grid((5, 5))
+    assert og.vertices == g.vertices and set(map(frozenset, og.edges)) == set(map(frozenset, g.edges))
+
+
+def test_forest_cover_sequence_covers_every_directed_edge_once():
+    for g in (tn.named_grid((4, 4)), tn.heavy_hexagonal_lattice(1, 1), tn.named_comb_tree((3, 3))):
+        seq = tn.forest_cover_edge_sequence(g)
+        assert len(seq) == 2 * g.ne() and len(set(seq)) == len(seq)
+        assert all(g.has_edge(a, b) for (a, b) in seq)
+
+
+def test_gate_matrices_match_oracle_and_are_unitary():
+    cases = [("Rx", (0.3,)), ("Ry", (0.7,)), ("Rz", (1.1,)), ("P", (0.4,)), ("H", ()), ("CNOT", ()), ("CY", ()),
+             ("CZ", ()), ("SWAP", ()), ("iSWAP", ()), ("Rxx", (0.5,)), ("Ryy", (0.5,)), ("Rzz", (0.9,)),
+             ("CRx", (0.2,)), ("CRz", (0.2,)), ("CPHASE", (-0.3,)), ("Rxxyy", (0.3,)), ("Rxxyyzz", (0.6,)),
+             ("xx_plus_yy", (0.3, 0.8))]
+    for n, p in cases:
+        m = tn.gate_matrix(n, *p)
+        assert np.allclose(m, o.gate_matrix(n, *p)), n
+        assert np.allclose(m @ m.conj().T, np.eye(m.shape[0])), n
+    assert np.allclose(tn.gate_matrix("√SWAP") @ tn.gate_matrix("√SWAP"), tn.gate_matrix("SWAP"))
+    assert np.allclose(tn.gate_matrix("√iSWAP") @ tn.gate_matrix("√iSWAP"), tn.gate_matrix("iSWAP"))
+
+
+def test_gate_registry_behaviour():
+    """test/test_apply.jl:56-106: custom registration, aliases, locked built-ins, unknown-gate suggestions"""
+    tn.register_gate("MyZRot", lambda t: tn.gate_matrix("Rz", t), nparams=1)
+    assert np.allclose(tn.gate_matrix("MyZRot", 0.37), tn.gate_matrix("Rz", 0.37))
+    tn.register_alias("myz", "MyZRot")
+    assert np.allclose(tn.gate_matrix("myz", 0.1), tn.gate_matrix("Rz", 0.1))
+    tn.unregister_gate("MyZRot")
+    with pytest.raises(ValueError):
+        tn.gate_matrix("myz", 0.1)
+    with pytest.raises(ValueError, match="built-in"):
+        tn.register_gate("Rz", lambda t: np.eye(2), nparams=1)
+    with pytest.raises(ValueError, match="built-in"):
+        tn.unregister_gate("CNOT")
+    with pytest.raises(ValueError, match="Did you mean"):
+        tn.gate_matrix("Rzx", 0.1)
+    assert np.allclose(tn.gate_matrix("rzz", 0.3), tn.gate_matrix("Rzz", 0.3))
+    assert np.allclose(tn.gate_matrix("cp", 0.3), tn.gate_matrix("CPHASE", 0.3))
+    assert np.allclose(tn.gate_matrix("XZ"), np.kron(tn.gate_matrix("X"), tn.gate_matrix("Z")))
