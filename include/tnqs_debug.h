@@ -1,0 +1,19 @@
+/* tnqs_debug.h -- kernel-level test entry points of libtnqs_hip.so (used by tests/ only; not part of the drop-in
+ * boundary).  Host pointers, column-major interleaved complex, synchronous. */
+#ifndef TNQS_DEBUG_H
+#define TNQS_DEBUG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* one-sided Jacobi on A (m x n): on return A = U*Sigma (columns), V (n x n) with A_in = (U Sigma) V^dagger. dtype: 0 c64, 1 c128 */
+int tnqs_dbg_jacobi(int dtype, int m, int n, void* A_inout, void* V_out, int* sweeps_out);
+/* out[(s',n),(a,b)] = sum_{(s,k)} in[(s,k),(a,b)] X[(s,k),(s',n)] with in element (s,a,k,b) at s + D*(a + PA*(k + K*b)) */
+int tnqs_dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, const void* in, const void* X, void* out,
+                        double* norm2_out, int use_mfma);
+/* out[i + KK*j] = sum_{(a,b)} X[i,(a,b)] conj(Y[j,(a,b)]), i,j = (s,k), KK = D*K; acc64: accumulate in double (out complex128) */
+int tnqs_dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma);
+#ifdef __cplusplus
+}
+#endif
+#endif

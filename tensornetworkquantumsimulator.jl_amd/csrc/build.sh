@@ -6,7 +6,7 @@ OUT=../libtnqs_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in kernels.hip kernels_mfma.hip engine.cpp api.cpp; do
+for f in kernels.hip kernels_mfma.hip engine.cpp api.cpp debug.cpp; do
   [ -f "$f" ] || continue
   o=build/${f%.*}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ kernels.hpp -nt "$o" ] || [ engine.hpp -nt "$o" ] || [ ../../include/tnqs.h -nt "$o" ]; then

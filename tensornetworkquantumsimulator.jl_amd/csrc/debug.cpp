@@ -1,0 +1,83 @@
+// debug.cpp -- kernel-level test entry points (include/tnqs_debug.h): host arrays in, host arrays out.
+#include <cstring>
+#include <vector>
+#include "engine.hpp"
+#include "kernels.hpp"
+
+namespace tnqs {
+#define HIPCHK(x) hipchk((x), #x)
+struct DBuf { void* p = nullptr; explicit DBuf(size_t n) { HIPCHK(hipMalloc(&p, n ? n : 1)); } ~DBuf() { (void)hipFree(p); }
+              void up(const void* h, size_t n) { HIPCHK(hipMemcpy(p, h, n, hipMemcpyHostToDevice)); } void down(void* h, size_t n) { HIPCHK(hipMemcpy(h, p, n, hipMemcpyDeviceToHost)); } };
+static void need_gpu() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Err(TNQS_ERR_HIP, "no HIP device available"); }
+
+void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
+    need_gpu();
+    if (m < 1 || n < 1 || m > 256 || n > 256) throw Err(TNQS_ERR_INVALID, "dbg_jacobi: 1 <= m, n <= 256");
+    size_t esz = dtype == TNQS_C64 ? 8 : 16;
+    DBuf dA((size_t)m * n * esz), dV((size_t)n * n * esz), dS(4), dI(sizeof(JacobiItem));
+    dA.up(A, (size_t)m * n * esz);
+    if (dtype == TNQS_C64) launch_identity<float>(nullptr, dV.p, n); else launch_identity<double>(nullptr, dV.p, n);
+    JacobiItem it{dA.p, dV.p, m, n, (int*)dS.p};
+    dI.up(&it, sizeof(it));
+    if (dtype == TNQS_C64) launch_jacobi<float>(nullptr, (const JacobiItem*)dI.p, 1, 60); else launch_jacobi<double>(nullptr, (const JacobiItem*)dI.p, 1, 60);
+    HIPCHK(hipDeviceSynchronize());
+    dA.down(A, (size_t)m * n * esz); dV.down(V, (size_t)n * n * esz);
+    if (sweeps) dS.down(sweeps, 4);
+}
+
+static void tile_params(size_t PA, size_t PB, int TR, int& TA, int& TB, int& nta, int& ntb) {
+    TA = (int)std::min<size_t>(PA, TR); TB = std::max(1, TR / TA); TB = (int)std::min<size_t>(TB, PB);
+    nta = (int)((PA + TA - 1) / TA); ntb = (int)((PB + TB - 1) / TB);
+}
+static int pick_TR(size_t KK, size_t esz, int copies) {
+    for (int tr : {64, 32, 16}) if (KK * tr * esz * copies <= 64 * 1024) return tr;
+    throw Err(TNQS_ERR_UNSUPPORTED, "too large");
+}
+
+void dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, const void* in, const void* X, void* out, double* norm2, int use_mfma) {
+    need_gpu();
+    size_t esz = dtype == TNQS_C64 ? 8 : 16;
+    size_t nin = (size_t)D * PA * K * PB, nout = (size_t)Do * PA * No * PB, nx = (size_t)D * K * Do * No;
+    DBuf dIn(nin * esz), dX(nx * esz), dOut(nout * esz), dI(sizeof(FiberItem));
+    dIn.up(in, nin * esz); dX.up(X, nx * esz);
+    HIPCHK(hipMemset(dOut.p, 0xff, nout * esz));
+    FiberItem it{}; it.in = dIn.p; it.out = dOut.p; it.X = dX.p; it.D = D; it.PA = PA; it.K = K; it.PB = PB; it.Do = Do; it.No = No;
+    int TR = pick_TR((size_t)D * K, esz, 1);
+    tile_params(PA, PB, TR, it.TA, it.TB, it.nta, it.ntb);
+    it.tile_begin = 0; it.want_norm = 1;
+    int tiles = it.nta * it.ntb;
+    DBuf dN((size_t)tiles * 8);
+    dI.up(&it, sizeof(it));
+    (void)use_mfma;
+    if (dtype == TNQS_C64) launch_fiber_gemm<float>(nullptr, (const FiberItem*)dI.p, 1, tiles, TR, D * K, (double*)dN.p);
+    else launch_fiber_gemm<double>(nullptr, (const FiberItem*)dI.p, 1, tiles, TR, D * K, (double*)dN.p);
+    HIPCHK(hipDeviceSynchronize());
+    dOut.down(out, nout * esz);
+    if (norm2) { std::vector<double> np(tiles); dN.down(np.data(), (size_t)tiles * 8); double t = 0; for (double v : np) t += v; *norm2 = t; }
+}
+
+void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma) {
+    need_gpu();
+    size_t esz = dtype == TNQS_C64 ? 8 : 16;
+    size_t nin = (size_t)D * PA * K * PB; int KK = D * K;
+    bool same = (X == Y);
+    DBuf dX(nin * esz), dY(same ? 1 : nin * esz), dI(sizeof(GramItem)), dR(sizeof(ReduceItem));
+    dX.up(X, nin * esz); if (!same) dY.up(Y, nin * esz);
+    GramItem it{}; it.X = dX.p; it.Y = same ? dX.p : dY.p; it.D = D; it.PA = PA; it.K = K; it.PB = PB;
+    int TR = pick_TR((size_t)KK + 1, esz, 2);
+    tile_params(PA, PB, TR, it.TA, it.TB, it.nta, it.ntb);
+    int ntiles = it.nta * it.ntb; int nch = std::min(7, ntiles);
+    it.tiles_per_chunk = (ntiles + nch - 1) / nch; it.nchunks = (ntiles + it.tiles_per_chunk - 1) / it.tiles_per_chunk; it.chunk_begin = 0;
+    bool a64 = acc64 || dtype == TNQS_C128;
+    size_t asz = a64 ? 16 : 8;
+    DBuf dP((size_t)it.nchunks * KK * KK * asz), dO((size_t)KK * KK * asz);
+    it.partial = dP.p; dI.up(&it, sizeof(it));
+    (void)use_mfma;
+    if (dtype == TNQS_C64) { if (a64) launch_gram<float, double>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); else launch_gram<float, float>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); }
+    else launch_gram<double, double>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK);
+    ReduceItem ri{dP.p, dO.p, KK * KK, it.nchunks, 0, 0}; dR.up(&ri, sizeof(ri));
+    if (a64) launch_reduce<double, double>(nullptr, (const ReduceItem*)dR.p, 1, KK * KK); else launch_reduce<float, float>(nullptr, (const ReduceItem*)dR.p, 1, KK * KK);
+    HIPCHK(hipDeviceSynchronize());
+    dO.down(out, (size_t)KK * KK * asz);
+}
+}  // namespace tnqs

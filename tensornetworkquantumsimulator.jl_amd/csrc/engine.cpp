@@ -728,6 +728,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         for (int gi = 0; gi < ng; ++gi) {
             int r1 = info[8 * gi], r2 = info[8 * gi + 1];
             int Mr = r1 * gitems[gi].d1, Nc = r2 * gitems[gi].d2;
+            if (Mr < Nc) std::swap(Mr, Nc);        // wide theta is stored as its adjoint (gate_theta_kernel)
             ji.push_back(JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, reinterpret_cast<int*>(ws[gi].info->p) + 4});
         }
         const JacobiItem* dj = upload(s, ji);

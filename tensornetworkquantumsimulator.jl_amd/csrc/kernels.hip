@@ -494,6 +494,7 @@ __global__ __launch_bounds__(256) void gate_theta_kernel(const GateItem* __restr
     gate_eigs(A2, V2, it.n2, lam_tmp, it.lam2, it.idx2, &it.info[1], &s_r2);
     const int r1 = s_r1, r2 = s_r2, d1 = it.d1, d2 = it.d2, chi = it.chi;
     const int Mr = r1 * d1, Nc = r2 * d2;
+    const bool wide = Mr < Nc;
     cx<T>* th = reinterpret_cast<cx<T>*>(it.theta);
     cx<T>* tv = reinterpret_cast<cx<T>*>(it.thetaV);
     const cx<double>* g = reinterpret_cast<const cx<double>*>(it.gate);
@@ -519,9 +520,13 @@ __global__ __launch_bounds__(256) void gate_theta_kernel(const GateItem* __restr
                 cfma(acc, gg, cc);
             }
         double sc = sqrt(it.lam1[a] * it.lam2[c]);
-        th[e] = cmake<T>((T)(acc.re * sc), (T)(acc.im * sc));
+        // one-sided Jacobi needs rows >= columns: a wide theta is stored as theta^dagger (Nc x Mr)
+        if (!wide) th[e] = cmake<T>((T)(acc.re * sc), (T)(acc.im * sc));
+        else th[col + (size_t)Nc * row] = cmake<T>((T)(acc.re * sc), (T)(-acc.im * sc));
     }
-    for (int e = threadIdx.x; e < Nc * Nc; e += 256) tv[e] = cmake<T>((e % Nc) == (e / Nc) ? (T)1 : (T)0, (T)0);
+    const int nI = wide ? Mr : Nc;
+    for (int e = threadIdx.x; e < nI * nI; e += 256) tv[e] = cmake<T>((e % nI) == (e / nI) ? (T)1 : (T)0, (T)0);
+    if (threadIdx.x == 0) it.info[5] = wide ? 1 : 0;
 }
 template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
@@ -538,17 +543,19 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const GateItem* __rest
     const GateItem it = items[blockIdx.x];
     const int r1 = it.info[0], r2 = it.info[1], d1 = it.d1, d2 = it.d2, chi = it.chi;
     const int Mr = r1 * d1, Nc = r2 * d2;
-    const cx<T>* th = reinterpret_cast<const cx<T>*>(it.theta);      // = U Sigma (columns)
-    const cx<T>* tv = reinterpret_cast<const cx<T>*>(it.thetaV);
-    for (int u = threadIdx.x; u < Nc; u += 256) {
+    const bool wide = it.info[5] != 0;                                // theta stored as theta^dagger (Nc x Mr)
+    const int ncol = wide ? Mr : Nc, ld = wide ? Nc : Mr;
+    const cx<T>* th = reinterpret_cast<const cx<T>*>(it.theta);      // rotated columns: U Sigma (or V Sigma when wide)
+    const cx<T>* tv = reinterpret_cast<const cx<T>*>(it.thetaV);     // accumulated rotations: V (or U when wide)
+    for (int u = threadIdx.x; u < ncol; u += 256) {
         double s2 = 0;
-        for (int i = 0; i < Mr; ++i) { cx<T> v = th[i + (size_t)Mr * u]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
+        for (int i = 0; i < ld; ++i) { cx<T> v = th[i + (size_t)ld * u]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
         sig[u] = sqrt(s2);
     }
     __syncthreads();
-    for (int u = threadIdx.x; u < Nc; u += 256) {      // rank by counting (descending, stable)
+    for (int u = threadIdx.x; u < ncol; u += 256) {    // rank by counting (descending, stable)
         int rk = 0; double su = sig[u];
-        for (int v = 0; v < Nc; ++v) rk += (sig[v] > su) || (sig[v] == su && v < u);
+        for (int v = 0; v < ncol; ++v) rk += (sig[v] > su) || (sig[v] == su && v < u);
         perm[rk] = u;
     }
     __syncthreads();
@@ -598,12 +605,12 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const GateItem* __rest
         if (su > 0) {
             for (int a = 0; a < r1; ++a) {
                 cx<double> w = V1[kk + (size_t)n1 * it.idx1[a]];
-                cx<T> l = th[(a + r1 * s1p) + (size_t)Mr * pu];
+                cx<T> l = wide ? tv[(a + r1 * s1p) + (size_t)Mr * pu] : th[(a + r1 * s1p) + (size_t)Mr * pu];
                 double f = 1.0 / sqrt(it.lam1[a]);
-                cx<double> ld = cmake<double>(l.re * f, l.im * f);
-                cfma(acc, w, ld);
+                cx<double> lv = cmake<double>(l.re * f, l.im * f);
+                cfma(acc, w, lv);
             }
-            double f = 1.0 / sqrt(su);
+            double f = wide ? sqrt(su) : 1.0 / sqrt(su);        // L = U sqrt(S)
             acc.re *= f; acc.im *= f;
         }
         X1[e] = cmake<T>((T)acc.re, (T)acc.im);
@@ -615,14 +622,16 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const GateItem* __rest
         int pu = perm[u];
         double su = sig[pu];
         cx<double> acc = cmake<double>(0, 0);
-        for (int c = 0; c < r2; ++c) {
-            cx<double> w = V2[kk + (size_t)n2 * it.idx2[c]];
-            cx<T> v = tv[(c + r2 * s2p) + (size_t)Nc * pu];
-            double f = 1.0 / sqrt(it.lam2[c]);
-            cx<double> vd = cmake<double>(v.re * f, -v.im * f);
-            cfma(acc, w, vd);
+        if (su > 0 || !wide) {
+            for (int c = 0; c < r2; ++c) {
+                cx<double> w = V2[kk + (size_t)n2 * it.idx2[c]];
+                cx<T> v = wide ? th[(c + r2 * s2p) + (size_t)Nc * pu] : tv[(c + r2 * s2p) + (size_t)Nc * pu];
+                double f = 1.0 / sqrt(it.lam2[c]);
+                cx<double> vd = cmake<double>(v.re * f, -v.im * f);
+                cfma(acc, w, vd);
+            }
         }
-        double f = sqrt(su);
+        double f = wide ? (su > 0 ? 1.0 / sqrt(su) : 0.0) : sqrt(su);    // R = sqrt(S) V^dagger
         X2[e] = cmake<T>((T)(acc.re * f), (T)(acc.im * f));
     }
 }

@@ -1,0 +1,110 @@
+"""Kernel-level GPU tests through include/tnqs_debug.h: each HIP kernel against a float64 numpy evaluation of the
+same contraction (transposition-detecting random inputs, odd dimensions, ragged tiles)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import tnqs_amd as tn
+
+pytestmark = pytest.mark.gpu
+lib = C.CDLL(tn.LIB_PATH)
+CDT = {0: np.complex64, 1: np.complex128}
+EPS = {0: 2e-6, 1: 1e-14}
+
+
+def rnd(rng, shape, dt):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dt)
+
+
+def jacobi(a, dtype):
+    m, n = a.shape
+    A = np.asfortranarray(a.astype(CDT[dtype]))
+    V = np.zeros((n, n), dtype=CDT[dtype], order="F")
+    sw = C.c_int()
+    rc = lib.tnqs_dbg_jacobi(dtype, m, n, A.ctypes.data_as(C.c_void_p), V.ctypes.data_as(C.c_void_p), C.byref(sw))
+    assert rc == 0, lib.tnqs_last_error()
+    return A, V, sw.value
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [(3, 3), (6, 6), (12, 12), (12, 6), (17, 9), (40, 40), (64, 64), (128, 128), (130, 70), (1, 1), (5, 2), (256, 256)])
+def test_jacobi_svd(dtype, shape):
+    rng = np.random.default_rng(sum(shape) + dtype)
+    a = rnd(rng, shape, np.complex128)
+    A, V, sw = jacobi(a, dtype)
+    eps = EPS[dtype] * max(shape)
+    s_ref = np.linalg.svd(a, compute_uv=False)
+    s = np.sort(np.linalg.norm(A, axis=0))[::-1]
+    assert sw < 60      # rows >= columns is required (wide matrices are handled through their adjoint)
+    assert np.max(np.abs(s[:len(s_ref)] - s_ref)) < eps * s_ref[0], (s[:5], s_ref[:5])
+    assert np.max(np.abs(V.conj().T @ V - np.eye(shape[1]))) < eps                      # V unitary
+    assert np.max(np.abs(A @ V.conj().T - a)) < eps * s_ref[0]                          # A_in = (U S) V^dagger
+    G = A.conj().T @ A
+    off = G - np.diag(np.diag(G))
+    assert np.max(np.abs(off)) < eps * s_ref[0] ** 2                                    # columns orthogonal
+
+
+@pytest.mark.parametrize("n,rank", [(6, 3), (12, 5), (64, 20), (8, 8)])
+def test_jacobi_hermitian_psd_rank_deficient(n, rank):
+    rng = np.random.default_rng(n)
+    b = rnd(rng, (rank, n), np.complex128)
+    g = b.conj().T @ b
+    A, V, sw = jacobi(g, 1)
+    lam = np.real(np.sum(V.conj() * A, axis=0))                                          # Rayleigh quotients
+    ref = np.linalg.eigvalsh(g)
+    assert np.max(np.abs(np.sort(lam) - ref)) < 1e-12 * ref[-1]
+    keep = lam > 1e-12 * lam.max()
+    assert keep.sum() == rank
+    rec = (V[:, keep] * lam[keep]) @ V[:, keep].conj().T
+    assert np.max(np.abs(rec - g)) < 1e-12 * ref[-1]
+
+
+def fiber_ref(x, X, D, PA, K, PB, Do, No):
+    t = x.reshape(PB, K, PA, D).transpose(3, 2, 1, 0)            # [s, a, k, b]
+    Xm = X.reshape(No, Do, K, D).transpose(3, 2, 1, 0)           # [s, k, s', n]
+    out = np.einsum("sakb,sktn->tanb", t.astype(np.complex128), Xm.astype(np.complex128))
+    return out.transpose(3, 2, 1, 0).reshape(-1)                 # memory order: s' fastest, then a, n, b
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("D,PA,K,PB,Do,No", [(1, 2, 3, 5, 1, 3), (1, 100, 10, 7, 1, 10), (1, 1, 7, 130, 1, 7), (2, 9, 5, 4, 2, 3),
+                                             (2, 1, 1, 1, 2, 1), (2, 300, 1, 1, 2, 1), (1, 64, 32, 33, 1, 32), (2, 16, 16, 16, 2, 16),
+                                             (3, 5, 4, 6, 3, 2), (2, 70, 8, 3, 2, 11)])
+def test_fiber_gemm(dtype, D, PA, K, PB, Do, No):
+    rng = np.random.default_rng(D + PA + K + PB)
+    dt = CDT[dtype]
+    x = rnd(rng, D * PA * K * PB, dt)
+    X = rnd(rng, D * K * Do * No, dt)
+    out = np.zeros(Do * PA * No * PB, dtype=dt)
+    n2 = C.c_double()
+    rc = lib.tnqs_dbg_fiber_gemm(dtype, D, PA, K, PB, Do, No, x.ctypes.data_as(C.c_void_p), X.ctypes.data_as(C.c_void_p),
+                                 out.ctypes.data_as(C.c_void_p), C.byref(n2), 0)
+    assert rc == 0, lib.tnqs_last_error()
+    ref = fiber_ref(x, X, D, PA, K, PB, Do, No)
+    scale = np.max(np.abs(ref))
+    assert np.max(np.abs(out - ref)) < EPS[dtype] * D * K * scale
+    assert abs(n2.value - np.sum(np.abs(ref) ** 2)) < 1e-5 * np.sum(np.abs(ref) ** 2)
+
+
+@pytest.mark.parametrize("dtype,acc64", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("D,PA,K,PB,same", [(1, 2, 3, 5, 0), (1, 100, 10, 7, 0), (1, 1, 7, 130, 1), (2, 9, 5, 40, 1), (2, 30, 1, 1, 0),
+                                           (1, 64, 32, 33, 0), (2, 16, 16, 16, 1), (2, 512, 32, 8, 1), (3, 5, 5, 6, 0)])
+def test_gram(dtype, acc64, D, PA, K, PB, same):
+    rng = np.random.default_rng(D + PA + K + PB)
+    dt = CDT[dtype]
+    x = rnd(rng, D * PA * K * PB, dt)
+    y = x if same else rnd(rng, D * PA * K * PB, dt)
+    KK = D * K
+    odt = np.complex128 if (acc64 or dtype == 1) else np.complex64
+    out = np.zeros(KK * KK, dtype=odt)
+    rc = lib.tnqs_dbg_gram(dtype, D, PA, K, PB, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+                           out.ctypes.data_as(C.c_void_p), acc64, 0)
+    assert rc == 0, lib.tnqs_last_error()
+    tx = x.reshape(PB, K, PA, D).transpose(3, 1, 2, 0).reshape(D, K, -1).astype(np.complex128)   # [s, k, (a,b)]
+    ty = y.reshape(PB, K, PA, D).transpose(3, 1, 2, 0).reshape(D, K, -1).astype(np.complex128)
+    mx = tx.transpose(1, 0, 2).reshape(KK, -1)        # row index s + D*k  -> reshape from [k, s]
+    my = ty.transpose(1, 0, 2).reshape(KK, -1)
+    ref = (mx @ my.conj().T).T.reshape(-1)            # out[i + KK*j]
+    tol = (1e-13 if odt == np.complex128 and dtype == 1 else (1e-6 if acc64 else 3e-5)) * np.max(np.abs(ref))
+    assert np.max(np.abs(out - ref)) < tol * max(1.0, np.sqrt(PA * PB / 64))

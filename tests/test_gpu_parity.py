@@ -23,13 +23,30 @@ def tight(dtype):
     return dict(maxiter=200, tolerance=1e-13 if np.dtype(dtype) == np.complex128 else 1e-9)
 
 
-def compare_messages(bpc, oc, tol, edges=None):
+def fixed(nsweeps=30):
+    """fixed number of sweeps: identical trajectories on both sides (a convergence threshold would make the sweep
+    count, hence the messages at ~sqrt(tolerance), depend on rounding)"""
+    return dict(maxiter=nsweeps, tolerance=None)
+
+
+def compare_messages(bpc, oc, tol, edges=None, spectra=False):
+    """elementwise when both sides hold the same site tensors; after gates the bond bases differ by the SVD's
+    phase / degenerate-subspace freedom (U, V are LAPACK- vs Jacobi-dependent), so only the message spectra --
+    invariant under a unitary change of the bond basis -- are comparable (hard parts)."""
     worst = 0.0
     for (a, b) in (edges or bpc.graph.edges):
         for e in ((a, b), (b, a)):
             m, mo = bpc.message(e), oc.message(e)
             assert m.shape == mo.shape, (e, m.shape, mo.shape)
-            worst = max(worst, np.max(np.abs(m - mo)) / max(1e-30, np.max(np.abs(mo))))
+            if spectra:
+                w = np.linalg.eigvalsh((m + m.conj().T).astype(np.complex128) / 2)
+                wo = np.linalg.eigvalsh((mo + mo.conj().T).astype(np.complex128) / 2)
+                # the reference normalises by sum(m) (abstract...:183), which is itself basis-dependent: compare
+                # trace-normalised spectra
+                w, wo = w / np.sum(w), wo / np.sum(wo)
+                worst = max(worst, np.max(np.abs(w - wo)) / max(1e-30, np.max(np.abs(wo))))
+            else:
+                worst = max(worst, np.max(np.abs(m - mo)) / max(1e-30, np.max(np.abs(mo))))
     assert worst <= tol, f"message mismatch {worst:.3e} > {tol}"
     return worst
 
@@ -92,10 +109,12 @@ def test_bp_update_matches_oracle(dtype, lattice):
     info = {}
     out = tn.update(bpc, info=info, **tight(dtype))
     oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **tight(dtype))
-    compare_messages(out, oc, 50 * tol)
+    # different sweep orders agree at the fixed point only to ~sqrt(tolerance) (the stopping rule is quadratic)
+    fp_tol = 3e-6 if np.dtype(dtype) == np.complex128 else 2e-3
+    compare_messages(out, oc, fp_tol)
     assert info["niter"] < 200
     for v in g.vertices[:4]:
-        assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oc, Z, v)) < 50 * tol
+        assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oc, Z, v)) < fp_tol
     # the input cache is untouched (value semantics, abstract...:228)
     assert np.array_equal(bpc.message(g.edges[0]), np.eye(3, dtype=dtype))
 
@@ -174,7 +193,7 @@ def test_tfim_layers_truncated_match_oracle(dtype, maxdim):
     groups = tn.edge_color(g, 4)
     layer = tfim_layer(g, groups)
     seq = colour_sequence(g, groups)
-    bpkw = dict(edge_sequence=seq, **tight(dtype))
+    bpkw = dict(edge_sequence=seq, **fixed())
     kw = dict(maxdim=maxdim, cutoff=1e-10, normalize_tensors=True)
     psi0 = tn.tensornetworkstate(dtype, lambda v: "↑", g)
     bpc = tn.update(tn.BeliefPropagationCache(psi0), **bpkw)
@@ -190,7 +209,7 @@ def test_tfim_layers_truncated_match_oracle(dtype, maxdim):
             assert bpc.bond_dim(a, b) == oc.tns.bond_dim(a, b), (layer_no, a, b)
         assert np.max(np.abs(errs - oerrs)) < (1e-5 if dtype == np.complex64 else 1e-9), (layer_no, errs, oerrs)
         scale = 30 * (layer_no + 1)
-        compare_messages(bpc, oc, scale * tol)
+        compare_messages(bpc, oc, scale * tol, spectra=True)
         for v in g.vertices:
             assert abs(tn.expect(bpc, ("Z", [v])) - o.expect_1site(oc, Z, v)) < scale * tol, (layer_no, v)
     ez = tn.expect_all(bpc, "Z")
@@ -206,7 +225,7 @@ def test_heavy_hex_layer_matches_oracle():
     for grp in groups:
         layer += [("Rzz", [a, b], math.pi / 2) for (a, b) in grp]
     seq = colour_sequence(g, groups)
-    bpkw = dict(edge_sequence=seq, **tight(np.complex128))
+    bpkw = dict(edge_sequence=seq, **fixed())
     kw = dict(maxdim=4, cutoff=1e-12, normalize_tensors=True)
     psi0 = tn.tensornetworkstate(np.complex128, lambda v: "↑", g)
     bpc = tn.update(tn.BeliefPropagationCache(psi0), **bpkw)
@@ -215,7 +234,7 @@ def test_heavy_hex_layer_matches_oracle():
         bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=bpkw)
         oc, oerrs = o.apply_gates(layer, oc, apply_kwargs=kw, bp_update_kwargs=bpkw)
         assert np.max(np.abs(errs - oerrs)) < 1e-9
-    compare_messages(bpc, oc, 1e-7)
+    compare_messages(bpc, oc, 1e-7, spectra=True)
     for v in g.vertices:
         assert abs(tn.expect(bpc, ("Z", [v])) - o.expect_1site(oc, Z, v)) < 1e-7
 
@@ -225,14 +244,14 @@ def test_truncate_matches_oracle():
     g = tn.named_hexagonal_lattice_graph(2, 2)
     groups = tn.edge_color(g, 3)
     seq = colour_sequence(g, groups)
-    bpkw = dict(edge_sequence=seq, **tight(np.complex128))
+    bpkw = dict(edge_sequence=seq, **fixed(40))
     psi = tn.random_tensornetworkstate(np.complex128, g, bond_dimension=3, seed=3)
     bpc = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
     oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)
     t = tn.truncate(bpc, maxdim=2, cutoff=1e-10, edge_color=groups, bp_update_kwargs=bpkw)
     ot = o.truncate(oc, maxdim=2, cutoff=1e-10, edge_groups=groups, bp_update_kwargs=bpkw)
     assert t.maxvirtualdim() <= 2
-    compare_messages(t, ot, 1e-7)
+    compare_messages(t, ot, 1e-7, spectra=True)
     a = sv.tns_to_statevector(to_oracle_state(t.network()))
     b = sv.tns_to_statevector(ot.tns)
     assert sv.fidelity(a, b) > 1 - 1e-8
