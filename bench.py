@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""bench.py -- two-site gates/sec at fixed chi on an L x L square-lattice TFIM Trotter layer (BASELINE.json metric).
+
+One "step" = one `apply_gates(layer, psi_bpc; apply_kwargs)` call on the named workload, INCLUDING the c+1 BP
+updates it triggers -- exactly what examples/2dIsing_dynamics.jl:56-57 times.  Workload at N=1: configs[1] of
+BASELINE.json (20x20 TFIM, chi=32, ComplexF32, batched edge-colour apply on one MI355X).  The state is synthetic
+(iid complex-normal site tensors at bond dimension chi) and resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel class (HIP-event timed inside the
+library on its own stream) and "cpu_baseline" (the numpy oracle timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+
+
+def tfim_layer(tn, g, groups, J=1.0, hx=2.5, dt=0.01):
+    """README.md:42-48 circuit: Rx(2 hx dt) on every vertex, Rzz(2 J dt) per edge colour"""
+    layer = [("Rx", [v], 2 * hx * dt) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rzz", [a, b], 2 * J * dt) for (a, b) in grp]
+    return layer
+
+
+def random_state_tensors(g, chi, d, seed, dtype):
+    rng = np.random.default_rng(seed)
+    for v in g.vertices:
+        shp = (d,) + (chi,) * g.degree(v)
+        n = int(np.prod(shp))
+        t = rng.standard_normal(2 * n, dtype=np.float32).view(np.complex64).reshape(shp)
+        t *= np.float32(1.0 / np.sqrt(n))                       # unit Frobenius norm (f32-friendly scale)
+        yield v, t.astype(dtype, copy=False)
+
+
+def cpu_baseline(chi, seed=1234, max_seconds=60.0):
+    """the CPU oracle (numpy restatement of the reference path, BLAS threads = host cores) on a bounded sample:
+    one TFIM layer on a 4x4 PERIODIC torus at the same chi / dtype (every site has the bulk degree 4 of the 20x20
+    lattice, so the per-gate work equals the bulk per-gate work of the benchmark workload)."""
+    import tnqs_oracle as o
+    L = 4
+    g = o.named_grid((L, L), periodic=True)
+    groups = o.edge_color(g)
+    layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+    rng = np.random.default_rng(seed)
+    tensors = {}
+    for v in g.vertices:
+        shp = (2,) + (chi,) * g.degree(v)
+        n = int(np.prod(shp))
+        tensors[v] = (rng.standard_normal(2 * n, dtype=np.float32).view(np.complex64).reshape(shp) / np.float32(np.sqrt(n)))
+    bpc = o.BeliefPropagationCache(o.TensorNetworkState(g, tensors))
+    kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+    # warm-up outside the timing: one BP update so that the timed layer starts from converged messages
+    bpc = o.update(bpc)
+    t0 = time.perf_counter()
+    info = {}
+    bpc, errs = o.apply_gates(layer, bpc, apply_kwargs=kw, info=info)
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    n2 = len(g.edges)
+    return {"value": n2 / dt, "unit": "two-site gates/s", "cores": int(cores), "kind": "port",
+            "sample": f"1 TFIM layer ({n2} two-site gates, {info.get('n_updates')} BP updates, sweeps {info.get('sweeps')}) on a "
+                      f"4x4 periodic torus (all sites degree 4), chi={chi}, complex64, numpy oracle; {dt:.1f} s"}
+
+
+PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix (= vector) peak
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--L", type=int, default=20)
+    ap.add_argument("--chi", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+    import tnqs_amd as tn
+
+    L, chi, d = args.L, args.chi, 2
+    dtype = np.complex64
+    g = tn.named_grid((L, L))
+    groups = tn.edge_color(g, 4)
+    layer = tfim_layer(tn, g, groups)
+    n2 = g.ne()
+    apply_kwargs = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+
+    # ---- state: bond dimension 1 handle, then upload the synthetic chi-saturated tensors ---------------------
+    psi0 = tn.tensornetworkstate(dtype, lambda v: "↑", g)
+    bpc = tn.BeliefPropagationCache(psi0, device=local if world > 1 else 0)
+    if world > 1:
+        from tnqs_amd import dist as tdist
+        tdist.shard(bpc, rank, world)
+    for v, t in random_state_tensors(g, chi, d, 1234, dtype):
+        if world == 1 or bpc.owns(v):
+            bpc._set_tensor(v, t)
+        else:
+            bpc._declare_dims(v, t.shape)
+    sweeps, updates = [], []
+    for _ in range(args.warmup):
+        info = {}
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=apply_kwargs, info=info)
+    tn.profile_enable(bpc, True)
+    tn.profile_reset(bpc)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = {}
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=apply_kwargs, info=info)
+        sweeps.append(info["n_sweeps"]); updates.append(info["n_updates"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    prof = tn.profile_get(bpc)
+    ms_per_step = 1e3 * elapsed / max(1, args.steps)
+    value = n2 * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel class ----------------------------------------------------------------
+    dom = max(prof, key=lambda k: prof[k]["ms"])
+    p = prof[dom]
+    roofline = None
+    if p["ms"] > 0:
+        tflops = p["flops"] / (p["ms"] * 1e-3) / 1e12
+        gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / PEAK_F32_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(p["ms"] / max(1, p["launches"]), 4), "launches": p["launches"],
+                    "alg_GBps": round(gbs, 1), "hbm_frac_of_8TBps": round(gbs / PEAK_HBM_GBS, 4)}
+    classes = {k: {"ms": round(v["ms"], 2), "launches": v["launches"],
+                   "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None}
+               for k, v in prof.items() if v["launches"]}
+
+    out = {"metric": "two-site gates/sec at fixed chi (LxL TFIM Trotter layer)", "value": round(value, 2),
+           "unit": "two-site gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "c64 (ComplexF32; Gram/eigen steps in f64)", "data": "synthetic",
+           "config": {"workload": f"{L}x{L} square-lattice TFIM Trotter layer (Rx + 4 edge colours of Rzz), chi={chi}, ComplexF32, "
+                                  f"apply_gates incl. BP updates; BASELINE.json configs[1]",
+                      "two_site_gates_per_step": n2, "bp_updates_per_step": updates, "bp_sweeps_per_step": sweeps,
+                      "apply_kwargs": {"maxdim": chi, "cutoff": 1e-10, "normalize_tensors": True},
+                      "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)", "parallelism": f"vertex-shard x{world}"},
+           "roofline": roofline, "kernel_classes": classes}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(chi)
+            except Exception as e:      # the baseline must never take the measured number down with it
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,20 +123,21 @@ int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* owner,
     });
 }
 
-int tnqs_profile_enable(tnqs_handle h, int on) { return guard([&] { S(h)->prof_on = on != 0; }); }
+int tnqs_profile_enable(tnqs_handle h, int on) { return guard([&] { S(h)->prof->on = on != 0; }); }
 int tnqs_profile_get(tnqs_handle h, int cls, int64_t* launches, double* ms, double* bytes, double* flops) {
     return guard([&] {
         State* s = S(h);
         if (cls < 0 || cls >= TNQS_PROF_NCLASSES) throw Err(TNQS_ERR_INVALID, "profile_get: bad class");
         prof_collect(s);
-        if (launches) *launches = s->prof[cls].launches;
-        if (ms) *ms = s->prof[cls].ms;
-        if (bytes) *bytes = s->prof[cls].bytes;
-        if (flops) *flops = s->prof[cls].flops;
+        const ProfClass& pc = s->prof->cls[cls];
+        if (launches) *launches = pc.launches;
+        if (ms) *ms = pc.ms;
+        if (bytes) *bytes = pc.bytes;
+        if (flops) *flops = pc.flops;
     });
 }
 int tnqs_profile_reset(tnqs_handle h) {
-    return guard([&] { State* s = S(h); prof_collect(s); for (auto& p : s->prof) p = ProfClass{}; });
+    return guard([&] { State* s = S(h); prof_collect(s); for (auto& p : s->prof->cls) p = ProfClass{}; });
 }
 
 }  // extern "C"

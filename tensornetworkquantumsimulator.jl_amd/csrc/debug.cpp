@@ -43,13 +43,15 @@ void dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, con
     HIPCHK(hipMemset(dOut.p, 0xff, nout * esz));
     FiberItem it{}; it.in = dIn.p; it.out = dOut.p; it.X = dX.p; it.D = D; it.PA = PA; it.K = K; it.PB = PB; it.Do = Do; it.No = No;
     int TR = pick_TR((size_t)D * K, esz, 1);
+    bool mf = use_mfma && dtype == TNQS_C64 && mfma_fiber_tile_rows(D * K, Do * No) > 0;
+    if (mf) TR = mfma_fiber_tile_rows(D * K, Do * No);
     tile_params(PA, PB, TR, it.TA, it.TB, it.nta, it.ntb);
     it.tile_begin = 0; it.want_norm = 1;
     int tiles = it.nta * it.ntb;
     DBuf dN((size_t)tiles * 8);
     dI.up(&it, sizeof(it));
-    (void)use_mfma;
-    if (dtype == TNQS_C64) launch_fiber_gemm<float>(nullptr, (const FiberItem*)dI.p, 1, tiles, TR, D * K, (double*)dN.p);
+    if (mf) launch_mfma_fiber_gemm(nullptr, (const FiberItem*)dI.p, 1, tiles, D * K, Do * No, (double*)dN.p);
+    else if (dtype == TNQS_C64) launch_fiber_gemm<float>(nullptr, (const FiberItem*)dI.p, 1, tiles, TR, D * K, (double*)dN.p);
     else launch_fiber_gemm<double>(nullptr, (const FiberItem*)dI.p, 1, tiles, TR, D * K, (double*)dN.p);
     HIPCHK(hipDeviceSynchronize());
     dOut.down(out, nout * esz);
@@ -65,17 +67,20 @@ void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void
     dX.up(X, nin * esz); if (!same) dY.up(Y, nin * esz);
     GramItem it{}; it.X = dX.p; it.Y = same ? dX.p : dY.p; it.D = D; it.PA = PA; it.K = K; it.PB = PB;
     int TR = pick_TR((size_t)KK + 1, esz, 2);
+    bool mf = use_mfma && dtype == TNQS_C64 && !acc64 && KK <= 32;
+    if (mf) TR = 64;
     tile_params(PA, PB, TR, it.TA, it.TB, it.nta, it.ntb);
     int ntiles = it.nta * it.ntb; int nch = std::min(7, ntiles);
     it.tiles_per_chunk = (ntiles + nch - 1) / nch; it.nchunks = (ntiles + it.tiles_per_chunk - 1) / it.tiles_per_chunk; it.chunk_begin = 0;
     bool a64 = acc64 || dtype == TNQS_C128;
     size_t asz = a64 ? 16 : 8;
-    DBuf dP((size_t)it.nchunks * KK * KK * asz), dO((size_t)KK * KK * asz);
+    int npart = mf ? 4 * it.nchunks : it.nchunks;
+    DBuf dP((size_t)npart * KK * KK * asz), dO((size_t)KK * KK * asz);
     it.partial = dP.p; dI.up(&it, sizeof(it));
-    (void)use_mfma;
-    if (dtype == TNQS_C64) { if (a64) launch_gram<float, double>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); else launch_gram<float, float>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); }
+    if (mf) launch_mfma_gram32(nullptr, (const GramItem*)dI.p, 1, it.nchunks, KK);
+    else if (dtype == TNQS_C64) { if (a64) launch_gram<float, double>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); else launch_gram<float, float>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); }
     else launch_gram<double, double>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK);
-    ReduceItem ri{dP.p, dO.p, KK * KK, it.nchunks, 0, 0}; dR.up(&ri, sizeof(ri));
+    ReduceItem ri{dP.p, dO.p, KK * KK, npart, 0, 0}; dR.up(&ri, sizeof(ri));
     if (a64) launch_reduce<double, double>(nullptr, (const ReduceItem*)dR.p, 1, KK * KK); else launch_reduce<float, float>(nullptr, (const ReduceItem*)dR.p, 1, KK * KK);
     HIPCHK(hipDeviceSynchronize());
     dO.down(out, (size_t)KK * KK * asz);

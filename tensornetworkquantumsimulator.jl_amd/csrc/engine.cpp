@@ -6,8 +6,12 @@
 #include <numeric>
 #include <set>
 #include "kernels.hpp"
+#include <cstdlib>
+#include <type_traits>
 
 namespace tnqs {
+
+static bool use_mfma() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_MFMA"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 
 void hipchk(hipError_t e, const char* what) {
     if (e != hipSuccess) throw Err(TNQS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -115,8 +119,6 @@ static thread_local std::unordered_map<State*, HostArena> g_arenas;
 State::~State() {
     auto it = g_arenas.find(this);
     if (it != g_arenas.end()) { if (it->second.base) (void)hipHostFree(it->second.base); g_arenas.erase(it); }
-    for (auto& p : prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    for (auto e : ev_free) (void)hipEventDestroy(e);
     keepalive.clear(); site.clear(); msg.clear();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
@@ -147,27 +149,29 @@ template <class Item> static const Item* upload(State* s, const std::vector<Item
 struct ProfScope {
     State* s; int cls; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(State* st, int c, double bytes, double flops) : s(st), cls(c) {
-        if (!s->prof_on) return;
-        s->prof[c].bytes += bytes; s->prof[c].flops += flops; s->prof[c].launches += 1;
-        auto get = [&]() { hipEvent_t e; if (!s->ev_free.empty()) { e = s->ev_free.back(); s->ev_free.pop_back(); } else HIPCHK(hipEventCreate(&e)); return e; };
+        Prof& P = *s->prof;
+        if (!P.on) return;
+        P.cls[c].bytes += bytes; P.cls[c].flops += flops; P.cls[c].launches += 1;
+        auto get = [&]() { hipEvent_t e; if (!P.ev_free.empty()) { e = P.ev_free.back(); P.ev_free.pop_back(); } else HIPCHK(hipEventCreate(&e)); return e; };
         a = get(); b = get();
         HIPCHK(hipEventRecord(a, s->stream));
     }
     ~ProfScope() {
         if (!a) return;
         (void)hipEventRecord(b, s->stream);
-        s->prof_pending.push_back({cls, a, b});
+        s->prof->pending.push_back({cls, a, b});
     }
 };
 void prof_collect(State* s) {
-    if (s->prof_pending.empty()) return;
+    Prof& P = *s->prof;
+    if (P.pending.empty()) return;
     HIPCHK(hipStreamSynchronize(s->stream));
-    for (auto& p : s->prof_pending) {
+    for (auto& p : P.pending) {
         float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b);
-        s->prof[p.cls].ms += ms;
-        s->ev_free.push_back(p.a); s->ev_free.push_back(p.b);
+        P.cls[p.cls].ms += ms;
+        P.ev_free.push_back(p.a); P.ev_free.push_back(p.b);
     }
-    s->prof_pending.clear();
+    P.pending.clear();
 }
 
 struct SD {       // dims of a site tensor in canonical layout
@@ -207,6 +211,7 @@ State* state_create(int nv, int ne, const int32_t* es, const int32_t* ed, const 
     s->chi.assign(ne, 1);
     s->site.resize(nv); s->msg.assign(2 * (size_t)ne, nullptr);
     s->pool = std::make_shared<Pool>(device);
+    s->prof = std::make_shared<Prof>();
     HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true;
     for (int v = 0; v < nv; ++v) { if (dtype == TNQS_C64) fill_product_up<float>(s.get(), v); else fill_product_up<double>(s.get(), v); }
     return s.release();
@@ -215,7 +220,7 @@ State* state_create(int nv, int ne, const int32_t* es, const int32_t* ed, const 
 State* state_copy(const State* o) {
     auto s = std::make_unique<State>();
     s->g = o->g; s->dtype = o->dtype; s->device = o->device; s->d = o->d; s->chi = o->chi;
-    s->site = o->site; s->msg = o->msg; s->pool = o->pool;
+    s->site = o->site; s->msg = o->msg; s->pool = o->pool; s->prof = o->prof;
     s->rank = o->rank; s->nranks = o->nranks; s->owner = o->owner; s->ag_fn = o->ag_fn; s->ag_ctx = o->ag_ctx;
     HIPCHK(hipSetDevice(o->device));
     if (o->own_stream) { HIPCHK(hipStreamSynchronize(o->stream)); HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
@@ -337,7 +342,9 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
     for (size_t o = 0; o < maxsteps; ++o) {
         std::vector<FiberItem> items; int tiles = 0; size_t KKmax = 1; double bytes = 0, flops = 0;
         for (auto& c : chains) if (c.steps.size() > o) KKmax = std::max<size_t>(KKmax, c.sd.chi[c.steps[o].first]);
-        const int TR = pick_TR(KKmax, esz, 1);
+        int TR = pick_TR(KKmax, esz, 1);
+        bool mf = false;
+        if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)KKmax); if (t > 0) { TR = t; mf = true; } }
         for (auto& c : chains) {
             if (c.steps.size() <= o) continue;
             int j = c.steps[o].first;
@@ -354,7 +361,8 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
         }
         const FiberItem* d = upload(s, items);
         ProfScope ps(s, cls, bytes, flops);
-        launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, nullptr);
+        if (mf) launch_mfma_fiber_gemm(s->stream, d, (int)items.size(), tiles, (int)KKmax, (int)KKmax, nullptr);
+        else launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, nullptr);
     }
 }
 
@@ -367,7 +375,9 @@ template <class T, class Acc> static void run_grams(State* s, std::vector<GramJo
     const size_t esz = s->esz();
     size_t KKmax = 1;
     for (auto& j : jobs) { j.KK = (j.keep_site ? j.sd.d : 1) * (j.leg >= 0 ? j.sd.chi[j.leg] : 1); KKmax = std::max<size_t>(KKmax, j.KK); }
-    const int TR = pick_TR(KKmax + 1, esz, 2);
+    int TR = pick_TR(KKmax + 1, esz, 2);
+    const bool mf = std::is_same<T, float>::value && std::is_same<Acc, float>::value && use_mfma() && KKmax <= 32 && KKmax >= 8;
+    if (mf) TR = 64;
     const int target = 2048;
     int per_item = std::max(1, target / (int)jobs.size());
     std::vector<GramItem> items; int chunks = 0; double bytes = 0, flops = 0;
@@ -384,15 +394,16 @@ template <class T, class Acc> static void run_grams(State* s, std::vector<GramJo
         int nch = std::min(per_item, ntiles);
         it.tiles_per_chunk = (ntiles + nch - 1) / nch;
         it.nchunks = (ntiles + it.tiles_per_chunk - 1) / it.tiles_per_chunk;
-        j.nchunks = it.nchunks;
-        j.partial = dalloc(s, (size_t)it.nchunks * j.KK * j.KK * 2 * sizeof(Acc));
+        j.nchunks = mf ? 4 * it.nchunks : it.nchunks;          // the MFMA kernel writes one partial per wave
+        j.partial = dalloc(s, (size_t)j.nchunks * j.KK * j.KK * 2 * sizeof(Acc));
         it.partial = j.partial->p; it.chunk_begin = chunks; chunks += it.nchunks;
         items.push_back(it);
         bytes += (j.X == j.Y ? 1.0 : 2.0) * j.sd.n * esz; flops += 8.0 * j.sd.n * j.KK;
     }
     const GramItem* d = upload(s, items);
     ProfScope ps(s, cls, bytes, flops);
-    launch_gram<T, Acc>(s->stream, d, (int)items.size(), chunks, TR, (int)KKmax);
+    if (mf) launch_mfma_gram32(s->stream, d, (int)items.size(), chunks, (int)KKmax);
+    else launch_gram<T, Acc>(s->stream, d, (int)items.size(), chunks, TR, (int)KKmax);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -752,8 +763,14 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     {
         std::vector<FiberItem> items; std::vector<int> verts, tb, nt; std::vector<Buf> outs; std::vector<size_t> ne;
         int tiles = 0; size_t KKmax = 1; double bytes = 0, flops = 0;
-        for (size_t i = 0; i < sj.size(); ++i) KKmax = std::max<size_t>(KKmax, (size_t)sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]);
-        const int TR = pick_TR(KKmax, esz, 1);
+        size_t NNmax = 1;
+        for (size_t i = 0; i < sj.size(); ++i) {
+            KKmax = std::max<size_t>(KKmax, (size_t)sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]);
+            NNmax = std::max<size_t>(NNmax, (size_t)sj[i].sd.d * info[8 * (i / 2) + 2]);
+        }
+        int TR = pick_TR(KKmax, esz, 1);
+        bool mf = false;
+        if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)NNmax); if (t > 0) { TR = t; mf = true; } }
         for (size_t i = 0; i < sj.size(); ++i) {
             int gi = (int)i / 2; int chin = info[8 * gi + 2];
             const SiteJob& j = sj[i];
@@ -772,7 +789,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         Buf np = dalloc(s, std::max(1, tiles) * sizeof(double));
         const FiberItem* d = upload(s, items);
         { ProfScope ps(s, TNQS_PROF_GATE_APPLY, bytes, flops);
-          launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
+          if (mf) launch_mfma_fiber_gemm(s->stream, d, (int)items.size(), tiles, (int)KKmax, (int)NNmax, reinterpret_cast<double*>(np->p));
+          else launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
         norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, ao.normalize_tensors != 0);
         }
     // ---- 6. both bond messages := diag(S)  (apply_gates.jl:126-135), new bond dimension ---------------------------

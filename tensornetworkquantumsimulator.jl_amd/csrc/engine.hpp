@@ -57,6 +57,12 @@ struct Graph {
 };
 
 struct ProfClass { int64_t launches = 0; double ms = 0, bytes = 0, flops = 0; };
+struct Prof {
+    bool on = false; ProfClass cls[TNQS_PROF_NCLASSES];
+    struct Pending { int cls; hipEvent_t a, b; };
+    std::vector<Pending> pending; std::vector<hipEvent_t> ev_free;
+    ~Prof() { for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); } for (auto e : ev_free) (void)hipEventDestroy(e); }
+};
 
 struct State {
     std::shared_ptr<Graph> g;
@@ -70,10 +76,8 @@ struct State {
     hipStream_t stream = nullptr; bool own_stream = false;
     // sharding
     int rank = 0, nranks = 1; std::vector<int> owner; tnqs_allgatherv_fn ag_fn = nullptr; void* ag_ctx = nullptr;
-    // profiling
-    bool prof_on = false; ProfClass prof[TNQS_PROF_NCLASSES];
-    struct Pending { int cls; hipEvent_t a, b; };
-    std::vector<Pending> prof_pending; std::vector<hipEvent_t> ev_free;
+    // profiling (shared by copies of a handle, so a loop `bpc = apply_gates(layer, bpc)` accumulates)
+    std::shared_ptr<Prof> prof;
     std::vector<Buf> keepalive;    // descriptor buffers kept until the next host sync
     tnqs_apply_stats stats{};
 

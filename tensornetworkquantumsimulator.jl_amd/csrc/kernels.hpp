@@ -89,4 +89,10 @@ template <class T> void launch_permute(hipStream_t s, const PermItem& item);
 template <class T> void launch_identity(hipStream_t s, void* out, int n);
 void launch_sum_doubles(hipStream_t s, const double* in, int n, double* out);
 
+// ---- MFMA fast paths (ComplexF32 only; kernels_mfma.hip) -----------------------------------------------------------
+int mfma_fiber_tile_rows(int KK, int NN);     // fibers per tile for the shape, 0 = not covered
+bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_tiles, int KKmax, int NNmax,
+                            double* d_norm_partials);
+bool launch_mfma_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);  // tiles of 64 fibers; writes 4 partials per chunk
+
 }  // namespace tnqs

@@ -67,11 +67,12 @@ def fiber_ref(x, X, D, PA, K, PB, Do, No):
     return out.transpose(3, 2, 1, 0).reshape(-1)                 # memory order: s' fastest, then a, n, b
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("D,PA,K,PB,Do,No", [(1, 2, 3, 5, 1, 3), (1, 100, 10, 7, 1, 10), (1, 1, 7, 130, 1, 7), (2, 9, 5, 4, 2, 3),
+@pytest.mark.parametrize("dtype,mfma", [(0, 0), (1, 0), (0, 1)])
+@pytest.mark.parametrize("D,PA,K,PB,Do,No", [(1, 64, 32, 64, 1, 32), (2, 32, 32, 32, 2, 32), (2, 128, 32, 4, 2, 17), (1, 2, 32, 200, 1, 32), (2, 16, 16, 70, 2, 5),
+                                             (1, 2, 3, 5, 1, 3), (1, 100, 10, 7, 1, 10), (1, 1, 7, 130, 1, 7), (2, 9, 5, 4, 2, 3),
                                              (2, 1, 1, 1, 2, 1), (2, 300, 1, 1, 2, 1), (1, 64, 32, 33, 1, 32), (2, 16, 16, 16, 2, 16),
                                              (3, 5, 4, 6, 3, 2), (2, 70, 8, 3, 2, 11)])
-def test_fiber_gemm(dtype, D, PA, K, PB, Do, No):
+def test_fiber_gemm(dtype, mfma, D, PA, K, PB, Do, No):
     rng = np.random.default_rng(D + PA + K + PB)
     dt = CDT[dtype]
     x = rnd(rng, D * PA * K * PB, dt)
@@ -79,7 +80,7 @@ def test_fiber_gemm(dtype, D, PA, K, PB, Do, No):
     out = np.zeros(Do * PA * No * PB, dtype=dt)
     n2 = C.c_double()
     rc = lib.tnqs_dbg_fiber_gemm(dtype, D, PA, K, PB, Do, No, x.ctypes.data_as(C.c_void_p), X.ctypes.data_as(C.c_void_p),
-                                 out.ctypes.data_as(C.c_void_p), C.byref(n2), 0)
+                                 out.ctypes.data_as(C.c_void_p), C.byref(n2), mfma)
     assert rc == 0, lib.tnqs_last_error()
     ref = fiber_ref(x, X, D, PA, K, PB, Do, No)
     scale = np.max(np.abs(ref))
@@ -87,10 +88,13 @@ def test_fiber_gemm(dtype, D, PA, K, PB, Do, No):
     assert abs(n2.value - np.sum(np.abs(ref) ** 2)) < 1e-5 * np.sum(np.abs(ref) ** 2)
 
 
-@pytest.mark.parametrize("dtype,acc64", [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("D,PA,K,PB,same", [(1, 2, 3, 5, 0), (1, 100, 10, 7, 0), (1, 1, 7, 130, 1), (2, 9, 5, 40, 1), (2, 30, 1, 1, 0),
+@pytest.mark.parametrize("dtype,acc64,mfma", [(0, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1)])
+@pytest.mark.parametrize("D,PA,K,PB,same", [(1, 64, 32, 1024, 0), (1, 2048, 32, 32, 0), (1, 2, 32, 700, 1), (1, 70, 17, 9, 0),
+                                           (1, 2, 3, 5, 0), (1, 100, 10, 7, 0), (1, 1, 7, 130, 1), (2, 9, 5, 40, 1), (2, 30, 1, 1, 0),
                                            (1, 64, 32, 33, 0), (2, 16, 16, 16, 1), (2, 512, 32, 8, 1), (3, 5, 5, 6, 0)])
-def test_gram(dtype, acc64, D, PA, K, PB, same):
+def test_gram(dtype, acc64, mfma, D, PA, K, PB, same):
+    if mfma and D * K > 32:
+        pytest.skip('f32 MFMA Gram covers D*K <= 32')
     rng = np.random.default_rng(D + PA + K + PB)
     dt = CDT[dtype]
     x = rnd(rng, D * PA * K * PB, dt)
@@ -99,7 +103,7 @@ def test_gram(dtype, acc64, D, PA, K, PB, same):
     odt = np.complex128 if (acc64 or dtype == 1) else np.complex64
     out = np.zeros(KK * KK, dtype=odt)
     rc = lib.tnqs_dbg_gram(dtype, D, PA, K, PB, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
-                           out.ctypes.data_as(C.c_void_p), acc64, 0)
+                           out.ctypes.data_as(C.c_void_p), acc64, mfma)
     assert rc == 0, lib.tnqs_last_error()
     tx = x.reshape(PB, K, PA, D).transpose(3, 1, 2, 0).reshape(D, K, -1).astype(np.complex128)   # [s, k, (a,b)]
     ty = y.reshape(PB, K, PA, D).transpose(3, 1, 2, 0).reshape(D, K, -1).astype(np.complex128)
