@@ -345,6 +345,8 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
         int TR = pick_TR(KKmax, esz, 1);
         bool mf = false;
         if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)KKmax); if (t > 0) { TR = t; mf = true; } }
+        int tpw = 1;
+        if (mf) { double tot = 0; for (auto& c : chains) if (c.steps.size() > o) tot += (double)c.sd.n / c.sd.chi[c.steps[o].first] / TR; tpw = (int)std::max(1.0, std::min(8.0, tot / 4096.0)); }
         for (auto& c : chains) {
             if (c.steps.size() <= o) continue;
             int j = c.steps[o].first;
@@ -354,7 +356,8 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
             it.in = c.result; it.out = dst->p; it.X = c.steps[o].second;
             it.D = 1; it.PA = (int)c.sd.pre(j); it.K = c.sd.chi[j]; it.PB = (int)c.sd.post(j); it.Do = 1; it.No = it.K;
             tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
-            it.tile_begin = tiles; tiles += it.nta * it.ntb; it.want_norm = 0;
+            it.tpw = mf ? tpw : 1;
+            it.tile_begin = tiles; tiles += (it.nta * it.ntb + it.tpw - 1) / it.tpw; it.want_norm = 0;
             items.push_back(it);
             c.result = dst->p;
             bytes += 2.0 * c.sd.n * esz; flops += 8.0 * c.sd.n * it.K;
@@ -601,7 +604,7 @@ template <class T> static void apply_one_site_batch(State* s, const std::vector<
         it.in = s->site[g1.v]->p; it.out = out->p; it.X = dxp + xoff[gi] * sizeof(T);
         it.D = sd.d; it.PA = (int)(sd.n / sd.d); it.K = 1; it.PB = 1; it.Do = sd.d; it.No = 1;
         tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
-        it.tile_begin = tiles; it.want_norm = normalize ? 1 : 0;
+        it.tpw = 1; it.tile_begin = tiles; it.want_norm = normalize ? 1 : 0;
         verts.push_back(g1.v); outs.push_back(out); ne.push_back(sd.n); tb.push_back(tiles); nt.push_back(it.nta * it.ntb);
         tiles += it.nta * it.ntb; items.push_back(it);
         bytes += 2.0 * sd.n * esz; flops += 8.0 * sd.n * sd.d;
@@ -781,9 +784,11 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             it.in = pch[i].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
             it.D = j.sd.d; it.PA = (int)(pre / j.sd.d); it.K = chi; it.PB = (int)post; it.Do = j.sd.d; it.No = chin;
             tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
+            it.tpw = mf ? 4 : 1;
+            const int nwg = (it.nta * it.ntb + it.tpw - 1) / it.tpw;
             it.tile_begin = tiles; it.want_norm = ao.normalize_tensors ? 1 : 0;
-            verts.push_back(j.v); outs.push_back(out); ne.push_back(nout); tb.push_back(tiles); nt.push_back(it.nta * it.ntb);
-            tiles += it.nta * it.ntb; items.push_back(it);
+            verts.push_back(j.v); outs.push_back(out); ne.push_back(nout); tb.push_back(tiles); nt.push_back(nwg);
+            tiles += nwg; items.push_back(it);
             bytes += (double)(j.sd.n + nout) * esz; flops += 8.0 * j.sd.n * j.sd.d * chin;
         }
         Buf np = dalloc(s, std::max(1, tiles) * sizeof(double));

@@ -16,7 +16,8 @@ struct FiberItem {        // out[(s',n),(a,b)] = sum_{(s,k)} in[(s,k),(a,b)] * X
     int D, PA, K, PB;     // input addressing
     int Do, No;           // output addressing: s' + Do*(a + PA*(n + No*b))
     int TA, TB, nta, ntb; // tile = TA x TB fibers, nta x ntb tiles
-    int tile_begin;       // first global tile id of this item
+    int tile_begin;       // first global tile id of this item (MFMA path: first workgroup id)
+    int tpw;              // MFMA path: consecutive tiles walked by one workgroup (generic kernel: 1)
     int want_norm;        // 1: write sum |out|^2 of each tile to norm_partials[global tile id]
 };
 

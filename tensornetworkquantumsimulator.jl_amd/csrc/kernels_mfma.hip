@@ -15,6 +15,10 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 struct alignas(8) cf { float re, im; };
 
+// LDS-only workgroup barrier: __syncthreads() also drains vmcnt (global loads AND stores in flight), which would
+// serialise the prefetch / store streams against the LDS hand-offs (cdna_hip_programming.md, "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -22,123 +26,213 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// fiber GEMM:  out[(s',n),(a,b)] = sum_{(s,k)} in[(s,k),(a,b)] X[(s,k),(s',n)]   with D*K <= 32*KB, Do*No <= 32*NB
-// one workgroup = one tile of TR fibers; zero padding in LDS makes any K, N legal.
+// tile <-> thread map (division-free inner loops).  A tile holds TA x TB fibers; one "unit" is VEC memory-adjacent
+// elements of one k-slice ((s=0,s=1) of a fiber when D == 2, fibers (a, a+1) when D == 1 and TA is even).  Thread t
+// owns unit u = t % U of the k-slices kp, kp+KP, ... .
+// ------------------------------------------------------------------------------------------------------------
+struct TileMap {
+    int U, KP, u, kp;          // units per k-slice, k phases, this thread's unit / first k
+    int row0, row1, c0, c1;    // LDS row and (s) column offset of the unit's two elements (row1 < 0: single)
+    int al, bl, al1;           // tile-local fiber coordinates (validity tests)
+    int vec;                   // elements per unit (1 or 2)
+    long long off;             // element offset of the unit inside the tile's origin (k = 0)
+    bool active;
+};
+__device__ __forceinline__ TileMap make_map(int tid, int D, int TA, int TB, long long PA, int K) {
+    TileMap m;
+    const int rows = TA * TB;
+    m.vec = (D == 2) ? 2 : ((D == 1 && (TA % 2 == 0) && (PA % 2 == 0)) ? 2 : 1);
+    m.U = D * rows / m.vec;
+    m.KP = m.U >= 256 ? 1 : 256 / m.U;
+    m.u = tid % m.U; m.kp = tid / m.U;
+    m.active = tid < m.U * m.KP;
+    int e0 = m.u * m.vec;                 // first element index in (s, al, bl) order
+    int s = e0 % D; int row = e0 / D;
+    m.al = row % TA; m.bl = row / TA;
+    m.row0 = row; m.c0 = s;
+    if (m.vec == 2) { if (D == 2) { m.row1 = row; m.c1 = 1; m.al1 = m.al; } else { m.row1 = row + 1; m.c1 = 0; m.al1 = m.al + 1; } }
+    else { m.row1 = -1; m.c1 = 0; m.al1 = m.al; }
+    m.off = s + (long long)D * (m.al + PA * (long long)K * m.bl);
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fiber GEMM:  out[(s',n),(a,b)] = sum_{(s,k)} in[(s,k),(a,b)] X[(s,k),(s',n)]   with D*K <= 32*KB, Do*No <= 32*NB.
+// One workgroup stages X^T once and walks `tpw` consecutive tiles of TR fibers; the next tile's global loads are
+// issued before the MFMA block of the current one.  Zero padding in LDS makes any K, N legal.
 // ------------------------------------------------------------------------------------------------------------
 template <int KB, int NB, int TR>
 __global__ __launch_bounds__(256) void mfma_fiber_gemm_kernel(const FiberItem* __restrict__ items, int nitems,
                                                               double* __restrict__ norm_partials) {
     constexpr int KKP = 32 * KB, NNP = 32 * NB;
     constexpr int CP = (KKP > NNP ? KKP : NNP);
-    constexpr int PA_ = CP + 4;        // pitch (floats) of a tile row: 16-B aligned, conflict-free b128 reads
-    constexpr int PX = KKP + 4;
-    constexpr int RB = TR / 32;        // row blocks per tile
+    constexpr int PT = CP + 1;         // odd pitch: conflict-free row-strided writes and ds_read_b32 operand reads
+    constexpr int PX = KKP + 1;
+    constexpr int RB = TR / 32;
+    constexpr int NU = 8;              // max units per thread per tile
     static_assert(RB * NB == 4, "one (row block, column block) unit per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* At_re = reinterpret_cast<float*>(smem);
-    float* At_im = At_re + TR * PA_;
-    float* Xt_re = At_im + TR * PA_;
+    float* At_im = At_re + TR * PT;
+    float* Xt_re = At_im + TR * PT;
     float* Xt_im = Xt_re + NNP * PX;
     __shared__ double sh_red[4];
     const int tid = threadIdx.x;
     int lo = 0, hi = nitems - 1;
-    const int gt = blockIdx.x;
-    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].tile_begin <= gt) lo = mid; else hi = mid - 1; }
+    const int gw = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].tile_begin <= gw) lo = mid; else hi = mid - 1; }
     const FiberItem it = items[lo];
-    const int lt = gt - it.tile_begin;
-    const int ta = lt % it.nta, tb = lt / it.nta;
-    const int a0 = ta * it.TA, b0 = tb * it.TB;
-    const int na = min(it.TA, it.PA - a0), nb = min(it.TB, it.PB - b0);
     const int D = it.D, K = it.K, TA = it.TA, TB = it.TB, KK = D * K;
     const int Do = it.Do, No = it.No, NN = Do * No;
-    const size_t PA = it.PA;
+    const long long PA = it.PA;
+    const int ntiles = it.nta * it.ntb;
+    const int t_begin = (gw - it.tile_begin) * it.tpw;
+    const int t_end = min(ntiles, t_begin + it.tpw);
     const cf* __restrict__ in = reinterpret_cast<const cf*>(it.in);
     const cf* __restrict__ X = reinterpret_cast<const cf*>(it.X);
-    // ---- stage X^T (zero padded) ---------------------------------------------------------------------------
+    cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
+    // ---- stage X^T (zero padded) once ---------------------------------------------------------------------------
     for (int e = tid; e < NNP * KKP; e += 256) {
-        int kk = e % KKP, nn = e / KKP;
+        int kk = e & (KKP - 1), nn = e / KKP;
         cf v; v.re = 0.f; v.im = 0.f;
         if (kk < KK && nn < NN) v = X[kk + (size_t)KK * nn];
         Xt_re[nn * PX + kk] = v.re; Xt_im[nn * PX + kk] = v.im;
     }
-    // ---- stage the input tile: rows = fibers, columns = (s,k) ---------------------------------------------------
-    const int ntile_el = D * TA * K * TB;
-    for (int e = tid; e < ntile_el; e += 256) {
-        int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
-        cf v; v.re = 0.f; v.im = 0.f;
-        if (al < na && bl < nb) v = in[s + D * ((size_t)(a0 + al) + PA * ((size_t)k + (size_t)K * (b0 + bl)))];
-        int row = al + TA * bl;
-        At_re[row * PA_ + s + D * k] = v.re; At_im[row * PA_ + s + D * k] = v.im;
-    }
-    if (KK < KKP) for (int e = tid; e < TR * (KKP - KK); e += 256) {
-        int row = e / (KKP - KK), c = KK + e % (KKP - KK);
-        At_re[row * PA_ + c] = 0.f; At_im[row * PA_ + c] = 0.f;
-    }
-    if (TA * TB < TR) for (int e = tid; e < (TR - TA * TB) * KKP; e += 256) {
-        int row = TA * TB + e / KKP, c = e % KKP;
-        At_re[row * PA_ + c] = 0.f; At_im[row * PA_ + c] = 0.f;
-    }
-    __syncthreads();
-    // ---- MFMA: wave w owns (row block rb, column block cb) ----------------------------------------------------
+    // zero the whole A tile once (padding columns / rows stay zero: tiles only overwrite valid cells)
+    for (int e = tid; e < TR * PT; e += 256) { At_re[e] = 0.f; At_im[e] = 0.f; }
+    const TileMap mi = make_map(tid, D, TA, TB, PA, K);
+    const TileMap mo = make_map(tid, Do, TA, TB, PA, No);
+    const long long kstride_in = (long long)D * PA, kstride_out = (long long)Do * PA;
+    const bool fast = mi.U <= 256 && mo.U <= 256 && (K + mi.KP - 1) / mi.KP <= NU;
     const int lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
     const int rb = w % RB, cb = w / RB;
-    v16f Cr, Ci;
+    v4f pre[NU];
+    auto tile_origin = [&](int t, int& a0, int& b0, int& na, int& nb) {
+        int ta = t % it.nta, tb = t / it.nta;
+        a0 = ta * TA; b0 = tb * TB; na = min(TA, it.PA - a0); nb = min(TB, it.PB - b0);
+    };
+    auto issue_loads = [&](int t) {
+        int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
+        const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        const bool v0 = mi.active && mi.al < na && mi.bl < nb, v1 = v0 && mi.al1 < na;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        float ar[16], ai[16], br[16], bi[16];
-        const float* pa_r = At_re + (32 * rb + ln) * PA_ + 32 * kb + 16 * h;
-        const float* pa_i = At_im + (32 * rb + ln) * PA_ + 32 * kb + 16 * h;
-        const float* pb_r = Xt_re + (32 * cb + ln) * PX + 32 * kb + 16 * h;
-        const float* pb_i = Xt_im + (32 * cb + ln) * PX + 32 * kb + 16 * h;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            v4f t0 = *reinterpret_cast<const v4f*>(pa_r + 4 * q), t1 = *reinterpret_cast<const v4f*>(pa_i + 4 * q);
-            v4f t2 = *reinterpret_cast<const v4f*>(pb_r + 4 * q), t3 = *reinterpret_cast<const v4f*>(pb_i + 4 * q);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { ar[4 * q + c] = t0[c]; ai[4 * q + c] = t1[c]; br[4 * q + c] = t2[c]; bi[4 * q + c] = t3[c]; }
+        for (int j = 0; j < NU; ++j) {
+            int k = mi.kp + mi.KP * j;
+            v4f v; v[0] = v[1] = v[2] = v[3] = 0.f;
+            if (k < K && v0) {
+                const cf* p = in + org + mi.off + kstride_in * k;
+                if (mi.vec == 2 && v1) v = *reinterpret_cast<const v4f*>(p);
+                else { cf x = *p; v[0] = x.re; v[1] = x.im; }
+            }
+            pre[j] = v;
         }
+    };
+    auto commit_loads = [&]() {
+        if (!mi.active) return;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[t], br[t], Cr, 0, 0, 0);
-            Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai[t], bi[t], Cr, 0, 0, 0);
-            Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[t], bi[t], Ci, 0, 0, 0);
-            Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[t], br[t], Ci, 0, 0, 0);
+        for (int j = 0; j < NU; ++j) {
+            int k = mi.kp + mi.KP * j;
+            if (k < K) {
+                int kk0 = mi.c0 + D * k;
+                At_re[mi.row0 * PT + kk0] = pre[j][0]; At_im[mi.row0 * PT + kk0] = pre[j][1];
+                if (mi.vec == 2) { int kk1 = mi.c1 + D * k; At_re[mi.row1 * PT + kk1] = pre[j][2]; At_im[mi.row1 * PT + kk1] = pre[j][3]; }
+            }
         }
-    }
-    __syncthreads();       // every wave has read its operands: the tile rows can now take the results
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int row = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * h;
-        At_re[row * PA_ + 32 * cb + ln] = Cr[r];
-        At_im[row * PA_ + 32 * cb + ln] = Ci[r];
-    }
-    __syncthreads();
-    // ---- coalesced store of the output tile -------------------------------------------------------------------
-    cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
+    };
     double nrm = 0;
-    const int nout_el = Do * TA * No * TB;
-    for (int e = tid; e < nout_el; e += 256) {
-        int sp = e % Do; int r1 = e / Do; int al = r1 % TA; int r2 = r1 / TA; int n = r2 % No; int bl = r2 / No;
-        if (al < na && bl < nb) {
-            int row = al + TA * bl, nn = sp + Do * n;
-            cf v; v.re = At_re[row * PA_ + nn]; v.im = At_im[row * PA_ + nn];
-            out[sp + Do * ((size_t)(a0 + al) + PA * ((size_t)n + (size_t)No * (b0 + bl)))] = v;
-            nrm += (double)v.re * v.re + (double)v.im * v.im;
+    if (fast && t_begin < t_end) issue_loads(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
+        lds_barrier();                       // previous tile's output has left the LDS tile
+        if (fast) commit_loads();
+        else {
+            const int ntile_el = D * TA * K * TB;
+            for (int e = tid; e < ntile_el; e += 256) {
+                int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
+                cf v; v.re = 0.f; v.im = 0.f;
+                if (al < na && bl < nb) v = in[s + D * ((long long)(a0 + al) + PA * ((long long)k + (long long)K * (b0 + bl)))];
+                int row = al + TA * bl;
+                At_re[row * PT + s + D * k] = v.re; At_im[row * PT + s + D * k] = v.im;
+            }
+        }
+        lds_barrier();
+        if (fast && t + 1 < t_end) issue_loads(t + 1);       // in flight while the matrix cores work
+        v16f Cr, Ci;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            float ar[16], ai[16], br[16], bi[16];
+            const float* pa_r = At_re + (32 * rb + ln) * PT + 32 * kb + 16 * h;
+            const float* pa_i = At_im + (32 * rb + ln) * PT + 32 * kb + 16 * h;
+            const float* pb_r = Xt_re + (32 * cb + ln) * PX + 32 * kb + 16 * h;
+            const float* pb_i = Xt_im + (32 * cb + ln) * PX + 32 * kb + 16 * h;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { ar[q] = pa_r[q]; ai[q] = pa_i[q]; br[q] = pb_r[q]; bi[q] = pb_i[q]; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], br[q], Cr, 0, 0, 0);
+                Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai[q], bi[q], Cr, 0, 0, 0);
+                Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], bi[q], Ci, 0, 0, 0);
+                Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[q], br[q], Ci, 0, 0, 0);
+            }
+        }
+        lds_barrier();       // every wave has read its operands: the tile rows can now take the results
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * h;
+            At_re[row * PT + 32 * cb + ln] = Cr[r];
+            At_im[row * PT + 32 * cb + ln] = Ci[r];
+        }
+        lds_barrier();
+        // ---- coalesced store of the output tile ---------------------------------------------------------------
+        if (fast) {
+            const long long org = (long long)Do * (a0 + PA * (long long)No * b0);
+            const bool v0 = mo.active && mo.al < na && mo.bl < nb, v1 = v0 && mo.al1 < na;
+            if (v0) {
+                for (int n = mo.kp; n < No; n += mo.KP) {
+                    int nn0 = mo.c0 + Do * n;
+                    v4f v;
+                    v[0] = At_re[mo.row0 * PT + nn0]; v[1] = At_im[mo.row0 * PT + nn0];
+                    cf* p = out + org + mo.off + kstride_out * n;
+                    nrm += (double)v[0] * v[0] + (double)v[1] * v[1];
+                    if (mo.vec == 2 && v1) {
+                        int nn1 = mo.c1 + Do * n;
+                        v[2] = At_re[mo.row1 * PT + nn1]; v[3] = At_im[mo.row1 * PT + nn1];
+                        nrm += (double)v[2] * v[2] + (double)v[3] * v[3];
+                        *reinterpret_cast<v4f*>(p) = v;
+                    } else { cf x; x.re = v[0]; x.im = v[1]; *p = x; }
+                }
+            }
+        } else {
+            const int nout_el = Do * TA * No * TB;
+            for (int e = tid; e < nout_el; e += 256) {
+                int sp = e % Do; int r1 = e / Do; int al = r1 % TA; int r2 = r1 / TA; int n = r2 % No; int bl = r2 / No;
+                if (al < na && bl < nb) {
+                    int row = al + TA * bl, nn = sp + Do * n;
+                    cf v; v.re = At_re[row * PT + nn]; v.im = At_im[row * PT + nn];
+                    out[sp + Do * ((long long)(a0 + al) + PA * ((long long)n + (long long)No * (b0 + bl)))] = v;
+                    nrm += (double)v.re * v.re + (double)v.im * v.im;
+                }
+            }
+        }
+        // the result cells written beyond the valid KK columns must be cleared again for the next tile's operands
+        if (NN > KK || KK < KKP) {
+            lds_barrier();
+            for (int e = tid; e < TR * (CP - KK); e += 256) { int row = e / (CP - KK), c = KK + e % (CP - KK); At_re[row * PT + c] = 0.f; At_im[row * PT + c] = 0.f; }
         }
     }
     if (it.want_norm) {
         nrm = wave_sum_d(nrm);
         if (lane == 0) sh_red[w] = nrm;
         __syncthreads();
-        if (tid == 0) norm_partials[gt] = sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3];
+        if (tid == 0) norm_partials[gw] = sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3];
     }
 }
 
 template <int KB, int NB, int TR> static size_t fiber_lds() {
     constexpr int KKP = 32 * KB, NNP = 32 * NB; constexpr int CP = (KKP > NNP ? KKP : NNP);
-    return (size_t)(2 * TR * (CP + 4) + 2 * NNP * (KKP + 4)) * sizeof(float);
+    return (size_t)(2 * TR * (CP + 1) + 2 * NNP * (KKP + 1)) * sizeof(float);
 }
 int mfma_fiber_tile_rows(int KK, int NN) {
     if (KK <= 32 && NN <= 32) return 128;
@@ -166,10 +260,11 @@ bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems,
 
 // ------------------------------------------------------------------------------------------------------------
 // Gram (f32 accumulate):  partial[4*c + w][i + KK*j] = sum_{rows of chunk c handled by wave w} X[i,row] conj(Y[j,row])
-// KK = D*K <= 32.  Tiles of 64 fibers; wave w takes 16 of them per tile.
+// KK = D*K <= 32.  Tiles of 64 fibers, LDS layout [kk][row] (rows contiguous = memory order); wave w takes 16 rows of
+// every tile; the next tile's loads are in flight during the MFMA block.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mfma_gram32_kernel(const GramItem* __restrict__ items, int nitems) {
-    constexpr int TR = 64, TRP = TR + 4;
+    constexpr int TR = 64, TRP = TR + 4, NU = 8;
     __shared__ __attribute__((aligned(16))) float Xr[32 * TRP];
     __shared__ __attribute__((aligned(16))) float Xi[32 * TRP];
     __shared__ __attribute__((aligned(16))) float Yr[32 * TRP];
@@ -181,7 +276,7 @@ __global__ __launch_bounds__(256) void mfma_gram32_kernel(const GramItem* __rest
     const GramItem it = items[lo];
     const int lc = gc - it.chunk_begin;
     const int D = it.D, K = it.K, TA = it.TA, TB = it.TB, KK = D * K;
-    const size_t PA = it.PA;
+    const long long PA = it.PA;
     const bool same = (it.X == it.Y);
     const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
     const cf* __restrict__ Yg = reinterpret_cast<const cf*>(it.Y);
@@ -192,31 +287,64 @@ __global__ __launch_bounds__(256) void mfma_gram32_kernel(const GramItem* __rest
     v16f Cr, Ci;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }
-    // zero the padding rows (kk >= KK) once
-    for (int e = tid; e < (32 - KK) * TRP; e += 256) { int o = KK * TRP + e; Xr[o] = 0.f; Xi[o] = 0.f; Yr[o] = 0.f; Yi[o] = 0.f; }
-    const int ntile_el = D * TA * K * TB;
-    for (int t = t_begin; t < t_end; ++t) {
-        const int ta = t % it.nta, tb = t / it.nta;
-        const int a0 = ta * TA, b0 = tb * TB;
-        const int na = min(TA, it.PA - a0), nb = min(TB, it.PB - b0);
-        __syncthreads();
-        for (int e = tid; e < ntile_el; e += 256) {
-            int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
-            cf vx, vy; vx.re = vx.im = vy.re = vy.im = 0.f;
-            if (al < na && bl < nb) {
-                size_t off = s + D * ((size_t)(a0 + al) + PA * ((size_t)k + (size_t)K * (b0 + bl)));
-                vx = Xg[off];
-                vy = same ? vx : Yg[off];
+    for (int e = tid; e < 32 * TRP; e += 256) { Xr[e] = 0.f; Xi[e] = 0.f; Yr[e] = 0.f; Yi[e] = 0.f; }
+    const TileMap m = make_map(tid, D, TA, TB, PA, K);
+    const long long kstride = (long long)D * PA;
+    const bool fast = m.U <= 256 && (K + m.KP - 1) / m.KP <= NU;
+    v4f px[NU], py[NU];
+    auto tile_origin = [&](int t, int& a0, int& b0, int& na, int& nb) {
+        int ta = t % it.nta, tb = t / it.nta;
+        a0 = ta * TA; b0 = tb * TB; na = min(TA, it.PA - a0); nb = min(TB, it.PB - b0);
+    };
+    auto issue_loads = [&](int t) {
+        int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
+        const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        const bool v0 = m.active && m.al < na && m.bl < nb, v1 = v0 && m.al1 < na;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = m.kp + m.KP * j;
+            v4f vx, vy; vx[0] = vx[1] = vx[2] = vx[3] = 0.f; vy = vx;
+            if (k < K && v0) {
+                const long long o = org + m.off + kstride * k;
+                if (m.vec == 2 && v1) { vx = *reinterpret_cast<const v4f*>(Xg + o); vy = same ? vx : *reinterpret_cast<const v4f*>(Yg + o); }
+                else { cf x = Xg[o]; vx[0] = x.re; vx[1] = x.im; if (same) vy = vx; else { cf y = Yg[o]; vy[0] = y.re; vy[1] = y.im; } }
             }
-            int o = (s + D * k) * TRP + (al + TA * bl);
-            Xr[o] = vx.re; Xi[o] = vx.im; Yr[o] = vy.re; Yi[o] = vy.im;
+            px[j] = vx; py[j] = vy;
         }
-        if (TA * TB < TR) for (int e = tid; e < 32 * (TR - TA * TB); e += 256) {
-            int kk = e / (TR - TA * TB), row = TA * TB + e % (TR - TA * TB); int o = kk * TRP + row;
-            Xr[o] = 0.f; Xi[o] = 0.f; Yr[o] = 0.f; Yi[o] = 0.f;
+    };
+    auto commit_loads = [&]() {
+        if (!m.active) return;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = m.kp + m.KP * j;
+            if (k < K) {
+                int o0 = (m.c0 + D * k) * TRP + m.row0;
+                Xr[o0] = px[j][0]; Xi[o0] = px[j][1]; Yr[o0] = py[j][0]; Yi[o0] = py[j][1];
+                if (m.vec == 2) { int o1 = (m.c1 + D * k) * TRP + m.row1; Xr[o1] = px[j][2]; Xi[o1] = px[j][3]; Yr[o1] = py[j][2]; Yi[o1] = py[j][3]; }
+            }
         }
-        __syncthreads();
-        // wave w: rows 16w .. 16w+15; lane half h takes rows 16w + 8h + t
+    };
+    if (fast && t_begin < t_end) issue_loads(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        lds_barrier();
+        if (fast) commit_loads();       // invalid cells were loaded as zeros, so edge tiles need no extra clearing
+        else {
+            int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
+            const int ntile_el = D * TA * K * TB;
+            for (int e = tid; e < ntile_el; e += 256) {
+                int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
+                cf vx, vy; vx.re = vx.im = vy.re = vy.im = 0.f;
+                if (al < na && bl < nb) {
+                    long long off = s + D * ((long long)(a0 + al) + PA * ((long long)k + (long long)K * (b0 + bl)));
+                    vx = Xg[off]; vy = same ? vx : Yg[off];
+                }
+                int o = (s + D * k) * TRP + (al + TA * bl);
+                Xr[o] = vx.re; Xi[o] = vx.im; Yr[o] = vy.re; Yi[o] = vy.im;
+            }
+        }
+        lds_barrier();
+        if (fast && t + 1 < t_end) issue_loads(t + 1);
+        // wave w: rows 16w .. 16w+15; lane half h takes rows 16w + 8h + q
         float xr[8], xi[8], yr[8], yi[8];
         const int ro = ln * TRP + 16 * w + 8 * h;
 #pragma unroll
