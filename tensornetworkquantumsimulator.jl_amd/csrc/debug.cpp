@@ -46,7 +46,7 @@ void dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, con
     bool mf = use_mfma && dtype == TNQS_C64 && mfma_fiber_tile_rows(D * K, Do * No) > 0;
     if (mf) TR = mfma_fiber_tile_rows(D * K, Do * No);
     tile_params(PA, PB, TR, it.TA, it.TB, it.nta, it.ntb);
-    it.tile_begin = 0; it.want_norm = 1; it.tpw = mf ? 3 : 1;
+    it.tile_begin = 0; it.want_norm = 1; it.tpw = mf ? 5 : 1;
     int tiles = (it.nta * it.ntb + it.tpw - 1) / it.tpw;
     DBuf dN((size_t)tiles * 8);
     dI.up(&it, sizeof(it));

@@ -11,6 +11,7 @@
 
 namespace tnqs {
 
+static size_t bp_ws_budget() { static size_t v = 0; if (!v) { const char* e = std::getenv("TNQS_BP_WS_MB"); v = (e ? (size_t)std::atoll(e) : (size_t)24576) << 20; } return v; }
 static bool use_mfma() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_MFMA"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 
 void hipchk(hipError_t e, const char* what) {
@@ -346,7 +347,7 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
         bool mf = false;
         if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)KKmax); if (t > 0) { TR = t; mf = true; } }
         int tpw = 1;
-        if (mf) { double tot = 0; for (auto& c : chains) if (c.steps.size() > o) tot += (double)c.sd.n / c.sd.chi[c.steps[o].first] / TR; tpw = (int)std::max(1.0, std::min(8.0, tot / 4096.0)); }
+        if (mf) { double tot = 0; for (auto& c : chains) if (c.steps.size() > o) tot += (double)c.sd.n / c.sd.chi[c.steps[o].first] / TR; tpw = (int)std::max(1.0, std::min(TR == 32 ? 32.0 : 8.0, tot / 4096.0)); if (TR == 32 && tpw >= 4) tpw &= ~3; }
         for (auto& c : chains) {
             if (c.steps.size() <= o) continue;
             int j = c.steps[o].first;
@@ -482,7 +483,7 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
             // sub-batches bounded by workspace bytes
             size_t start = 0;
             while (start < lev.size()) {
-                size_t budget = size_t(24) << 30, used = 0, end = start;
+                size_t budget = bp_ws_budget(), used = 0, end = start;
                 while (end < lev.size()) {
                     int de = plan.seq[lev[end]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
                     size_t need = 2 * site_dims(s, src).n * esz;
@@ -784,7 +785,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             it.in = pch[i].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
             it.D = j.sd.d; it.PA = (int)(pre / j.sd.d); it.K = chi; it.PB = (int)post; it.Do = j.sd.d; it.No = chin;
             tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
-            it.tpw = mf ? 4 : 1;
+            it.tpw = mf ? (TR == 32 ? 16 : 4) : 1;
             const int nwg = (it.nta * it.ntb + it.tpw - 1) / it.tpw;
             it.tile_begin = tiles; it.want_norm = ao.normalize_tensors ? 1 : 0;
             verts.push_back(j.v); outs.push_back(out); ne.push_back(nout); tb.push_back(tiles); nt.push_back(nwg);

@@ -7,6 +7,7 @@
 // Because the k index only has to be consistent between A and B, k-step t of a 32-deep block is mapped to
 // k = t + 16*h, so every lane reads 16 CONSECUTIVE floats of its operand row from LDS (4 x ds_read_b128).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kernels.hpp"
 
 namespace tnqs {
@@ -230,11 +231,208 @@ __global__ __launch_bounds__(256) void mfma_fiber_gemm_kernel(const FiberItem* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// wave-private variant: every wave owns tiles of 32 fibers and its own LDS slab, so there is NO workgroup barrier in
+// the tile loop -- the 3-4 waves resident on a SIMD drift apart and one wave's MFMA block overlaps the others'
+// global / LDS phases.  This is the production kernel; the workgroup-tile kernel above is kept for A/B.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ TileMap make_map_wave(int lane, int D, int TA, int TB, long long PA, int K) {
+    TileMap m;
+    const int rows = TA * TB;
+    m.vec = (D == 2) ? 2 : ((D == 1 && (TA % 2 == 0) && (PA % 2 == 0)) ? 2 : 1);
+    m.U = D * rows / m.vec;
+    m.KP = m.U >= 64 ? 1 : 64 / m.U;
+    m.u = lane % m.U; m.kp = lane / m.U;
+    m.active = lane < m.U * m.KP;
+    int e0 = m.u * m.vec;
+    int s = e0 % D; int row = e0 / D;
+    m.al = row % TA; m.bl = row / TA;
+    m.row0 = row; m.c0 = s;
+    if (m.vec == 2) { if (D == 2) { m.row1 = row; m.c1 = 1; m.al1 = m.al; } else { m.row1 = row + 1; m.c1 = 0; m.al1 = m.al + 1; } }
+    else { m.row1 = -1; m.c1 = 0; m.al1 = m.al; }
+    m.off = s + (long long)D * (m.al + PA * (long long)K * m.bl);
+    return m;
+}
+
+template <int KB, int NB, int NU>
+__global__ __launch_bounds__(256) void mfma_fiber_gemm_w_kernel(const FiberItem* __restrict__ items, int nitems,
+                                                                double* __restrict__ norm_partials) {
+    constexpr int KKP = 32 * KB, NNP = 32 * NB;
+    constexpr int CP = (KKP > NNP ? KKP : NNP);
+    constexpr int PT = CP + 1, PX = KKP + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Xt_re = reinterpret_cast<float*>(smem);
+    float* Xt_im = Xt_re + NNP * PX;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
+    float* At_re = Xt_im + NNP * PX + w * (2 * 32 * PT);
+    float* At_im = At_re + 32 * PT;
+    __shared__ double sh_red[4];
+    int lo = 0, hi = nitems - 1;
+    const int gw = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].tile_begin <= gw) lo = mid; else hi = mid - 1; }
+    const FiberItem it = items[lo];
+    const int D = it.D, K = it.K, TA = it.TA, TB = it.TB, KK = D * K;
+    const int Do = it.Do, No = it.No, NN = Do * No;
+    const long long PA = it.PA;
+    const int ntiles = it.nta * it.ntb;
+    const int t_begin = (gw - it.tile_begin) * it.tpw;
+    const int t_end = min(ntiles, t_begin + it.tpw);
+    const cf* __restrict__ in = reinterpret_cast<const cf*>(it.in);
+    const cf* __restrict__ X = reinterpret_cast<const cf*>(it.X);
+    cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
+    for (int e = tid; e < NNP * KKP; e += 256) {
+        int kk = e & (KKP - 1), nn = e / KKP;
+        cf v; v.re = 0.f; v.im = 0.f;
+        if (kk < KK && nn < NN) v = X[kk + (size_t)KK * nn];
+        Xt_re[nn * PX + kk] = v.re; Xt_im[nn * PX + kk] = v.im;
+    }
+    for (int e = lane; e < 32 * PT; e += 64) { At_re[e] = 0.f; At_im[e] = 0.f; }
+    __syncthreads();                                   // the only workgroup barrier: X^T is staged
+    const TileMap mi = make_map_wave(lane, D, TA, TB, PA, K);
+    const TileMap mo = make_map_wave(lane, Do, TA, TB, PA, No);
+    const long long kstride_in = (long long)D * PA, kstride_out = (long long)Do * PA;
+    const bool fast = mi.U <= 64 && mo.U <= 64 && (K + mi.KP - 1) / mi.KP <= NU;
+    v4f pre[NU];
+    auto tile_origin = [&](int t, int& a0, int& b0, int& na, int& nb) {
+        int ta = t % it.nta, tb = t / it.nta;
+        a0 = ta * TA; b0 = tb * TB; na = min(TA, it.PA - a0); nb = min(TB, it.PB - b0);
+    };
+    auto issue_loads = [&](int t) {
+        int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
+        const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        const bool v0 = mi.active && mi.al < na && mi.bl < nb, v1 = v0 && mi.al1 < na;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = mi.kp + mi.KP * j;
+            v4f v; v[0] = v[1] = v[2] = v[3] = 0.f;
+            if (k < K && v0) {
+                const cf* p = in + org + mi.off + kstride_in * k;
+                if (mi.vec == 2 && v1) v = *reinterpret_cast<const v4f*>(p);
+                else { cf x = *p; v[0] = x.re; v[1] = x.im; }
+            }
+            pre[j] = v;
+        }
+    };
+    auto commit_loads = [&]() {
+        if (!mi.active) return;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = mi.kp + mi.KP * j;
+            if (k < K) {
+                int kk0 = mi.c0 + D * k;
+                At_re[mi.row0 * PT + kk0] = pre[j][0]; At_im[mi.row0 * PT + kk0] = pre[j][1];
+                if (mi.vec == 2) { int kk1 = mi.c1 + D * k; At_re[mi.row1 * PT + kk1] = pre[j][2]; At_im[mi.row1 * PT + kk1] = pre[j][3]; }
+            }
+        }
+    };
+    double nrm = 0;
+    const int t_first = t_begin + w;
+    if (fast && t_first < t_end) issue_loads(t_first);
+    for (int t = t_first; t < t_end; t += 4) {
+        int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
+        if (fast) commit_loads();
+        else {
+            const int ntile_el = D * TA * K * TB;
+            for (int e = lane; e < ntile_el; e += 64) {
+                int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
+                cf v; v.re = 0.f; v.im = 0.f;
+                if (al < na && bl < nb) v = in[s + D * ((long long)(a0 + al) + PA * ((long long)k + (long long)K * (b0 + bl)))];
+                int row = al + TA * bl;
+                At_re[row * PT + s + D * k] = v.re; At_im[row * PT + s + D * k] = v.im;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                 // LDS is in-order per wave; only the compiler must not reorder
+        if (fast && t + 4 < t_end) issue_loads(t + 4);
+        v16f Cr[NB], Ci[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { Cr[c][r] = 0.f; Ci[c][r] = 0.f; }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            float ar[16], ai[16];
+            const float* pa_r = At_re + ln * PT + 32 * kb + 16 * h;
+            const float* pa_i = At_im + ln * PT + 32 * kb + 16 * h;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { ar[q] = pa_r[q]; ai[q] = pa_i[q]; }
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                float br[16], bi[16];
+                const float* pb_r = Xt_re + (32 * c + ln) * PX + 32 * kb + 16 * h;
+                const float* pb_i = Xt_im + (32 * c + ln) * PX + 32 * kb + 16 * h;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { br[q] = pb_r[q]; bi[q] = pb_i[q]; }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    Cr[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], br[q], Cr[c], 0, 0, 0);
+                    Cr[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai[q], bi[q], Cr[c], 0, 0, 0);
+                    Ci[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], bi[q], Ci[c], 0, 0, 0);
+                    Ci[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[q], br[q], Ci[c], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                At_re[row * PT + 32 * c + ln] = Cr[c][r];
+                At_im[row * PT + 32 * c + ln] = Ci[c][r];
+            }
+        __builtin_amdgcn_wave_barrier();
+        if (fast) {
+            const long long org = (long long)Do * (a0 + PA * (long long)No * b0);
+            const bool v0 = mo.active && mo.al < na && mo.bl < nb, v1 = v0 && mo.al1 < na;
+            if (v0) {
+                for (int n = mo.kp; n < No; n += mo.KP) {
+                    int nn0 = mo.c0 + Do * n;
+                    v4f v;
+                    v[0] = At_re[mo.row0 * PT + nn0]; v[1] = At_im[mo.row0 * PT + nn0];
+                    cf* p = out + org + mo.off + kstride_out * n;
+                    nrm += (double)v[0] * v[0] + (double)v[1] * v[1];
+                    if (mo.vec == 2 && v1) {
+                        int nn1 = mo.c1 + Do * n;
+                        v[2] = At_re[mo.row1 * PT + nn1]; v[3] = At_im[mo.row1 * PT + nn1];
+                        nrm += (double)v[2] * v[2] + (double)v[3] * v[3];
+                        *reinterpret_cast<v4f*>(p) = v;
+                    } else { cf x; x.re = v[0]; x.im = v[1]; *p = x; }
+                }
+            }
+        } else {
+            const int nout_el = Do * TA * No * TB;
+            for (int e = lane; e < nout_el; e += 64) {
+                int sp = e % Do; int r1 = e / Do; int al = r1 % TA; int r2 = r1 / TA; int n = r2 % No; int bl = r2 / No;
+                if (al < na && bl < nb) {
+                    int row = al + TA * bl, nn = sp + Do * n;
+                    cf v; v.re = At_re[row * PT + nn]; v.im = At_im[row * PT + nn];
+                    out[sp + Do * ((long long)(a0 + al) + PA * ((long long)n + (long long)No * (b0 + bl)))] = v;
+                    nrm += (double)v.re * v.re + (double)v.im * v.im;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (NN > KK || KK < KKP) {          // results spilled into the operand padding columns: clear them again
+            for (int e = lane; e < 32 * (CP - KK); e += 64) { int row = e / (CP - KK), c = KK + e % (CP - KK); At_re[row * PT + c] = 0.f; At_im[row * PT + c] = 0.f; }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (it.want_norm) {
+        nrm = wave_sum_d(nrm);
+        if (lane == 0) sh_red[w] = nrm;
+        __syncthreads();
+        if (tid == 0) norm_partials[gw] = sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3];
+    }
+}
+
 template <int KB, int NB, int TR> static size_t fiber_lds() {
     constexpr int KKP = 32 * KB, NNP = 32 * NB; constexpr int CP = (KKP > NNP ? KKP : NNP);
     return (size_t)(2 * TR * (CP + 1) + 2 * NNP * (KKP + 1)) * sizeof(float);
 }
+static int g_wave_private = -1;
+static bool wave_private() { if (g_wave_private < 0) { const char* e = getenv("TNQS_MFMA_WG_TILES"); g_wave_private = (e && e[0] == '1') ? 0 : 1; } return g_wave_private == 1; }
 int mfma_fiber_tile_rows(int KK, int NN) {
+    if (wave_private()) return (KK <= 64 && NN <= 64) ? 32 : 0;
     if (KK <= 32 && NN <= 32) return 128;
     if (KK <= 64 && NN <= 64) return 64;
     return 0;
@@ -243,6 +441,21 @@ int mfma_fiber_tile_rows(int KK, int NN) {
 bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_tiles, int KKmax, int NNmax,
                             double* d_norm_partials) {
     if (total_tiles <= 0) return true;
+    if (wave_private()) {
+        if (KKmax <= 32 && NNmax <= 32) {
+            const size_t lds = fiber_lds<1, 1, 128>();
+            hipLaunchKernelGGL((mfma_fiber_gemm_w_kernel<1, 1, 8>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials);
+            return true;
+        }
+        if (KKmax <= 64 && NNmax <= 64) {
+            const size_t lds = fiber_lds<2, 2, 128>();
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_fiber_gemm_w_kernel<2, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+            hipLaunchKernelGGL((mfma_fiber_gemm_w_kernel<2, 2, 16>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials);
+            return true;
+        }
+        return false;
+    }
     if (KKmax <= 32 && NNmax <= 32) {
         const size_t lds = fiber_lds<1, 1, 128>();
         hipLaunchKernelGGL((mfma_fiber_gemm_kernel<1, 1, 128>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials);
