@@ -134,10 +134,16 @@ int tnqs_expect_all(tnqs_handle h, const double* ops, double* out_re_im);
 /* ---- multi-GPU sharding (no reference analogue).  A rank owns a vertex subset: it holds only
  *      those site tensors and does all per-vertex work for them; messages are replicated.  The library calls
  *      the host-supplied all-gather at the exchange points (host side: torch.distributed over RCCL). --------- */
-typedef int (*tnqs_allgatherv_fn)(void* ctx, const void* d_send, void* d_recv, const int64_t* byte_counts,
-                                  const int64_t* byte_displs, int nranks, void* hip_stream);
-int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* vertex_owner,
-                      tnqs_allgatherv_fn fn, void* ctx);
+/* all-gather over the ranks of `bytes_per_rank` bytes: rank r's block sits at exch_base + r*bytes_per_rank of the
+ * exchange buffer handed to tnqs_set_sharding (in place).  Must be complete (device-visible) on return. */
+typedef int (*tnqs_allgather_fn)(void* ctx, void* exch_base, int64_t bytes_per_rank, int nranks);
+/* vertex_owner[v] in [0, nranks).  exch_dev/exch_bytes: a device buffer owned by the host side (e.g. a torch tensor)
+ * that the library packs its exchange payloads into.  Call right after tnqs_create on every rank; site tensors of
+ * vertices owned by other ranks are dropped, and tnqs_set_site_tensor on them only records the bond dimensions
+ * (host may be NULL).  Exchanges per apply_gates call: one per BP level (raw messages, <= 2|E| chi^2 elements per
+ * sweep in total) and two per gate batch (the d*chi x d*chi Gram matrices; chi', truncation error, S and X2). */
+int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* vertex_owner, tnqs_allgather_fn fn, void* ctx,
+                      void* exch_dev, int64_t exch_bytes);
 
 /* ---- profiling: HIP-event timing of the kernel classes on the handle's stream ---------------------------- */
 enum { TNQS_PROF_BP_MODEPROD = 0, TNQS_PROF_BP_GRAM = 1, TNQS_PROF_GATE_MODEPROD = 2, TNQS_PROF_GATE_GRAM = 3,

@@ -8,3 +8,5 @@ from .core import (TensorNetworkState, tensornetworkstate, random_tensornetworks
                    scalartype, maxvirtualdim, default_bp_update_kwargs, default_tolerance, update, apply_gates,
                    apply_circuit, truncate, expect, expect_all, rdm, profile_enable, profile_get, profile_reset,
                    PROF_CLASSES)
+from . import dist
+from .dist import partition_vertices, shard

@@ -34,8 +34,7 @@ class ApplyStats(C.Structure):
                 ("bp_not_converged", C.c_int), ("last_bp_diff", C.c_double)]
 
 
-ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
-                            C.c_int, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
 
 H = C.c_void_p
 _I32P = C.POINTER(C.c_int32)
@@ -65,7 +64,7 @@ _SIGS = {
     "tnqs_rdm_1site": ([H, C.c_int, _DP], C.c_int),
     "tnqs_expect_1site": ([H, C.c_int, _DP, _DP], C.c_int),
     "tnqs_expect_all": ([H, _DP, _DP], C.c_int),
-    "tnqs_set_sharding": ([H, C.c_int, C.c_int, _I32P, ALLGATHERV_FN, C.c_void_p], C.c_int),
+    "tnqs_set_sharding": ([H, C.c_int, C.c_int, _I32P, ALLGATHER_FN, C.c_void_p, C.c_void_p, C.c_int64], C.c_int),
     "tnqs_profile_enable": ([H, C.c_int], C.c_int),
     "tnqs_profile_get": ([H, C.c_int, _I64P, _DP, _DP, _DP], C.c_int),
     "tnqs_profile_reset": ([H], C.c_int),

@@ -105,6 +105,7 @@ class BeliefPropagationCache:
     """Device-resident {network, messages} (beliefpropagationcache.jl:9-15) behind an opaque C handle."""
 
     def __init__(self, network, device: int = 0, _handle=None):
+        self._shard = None
         if _handle is not None:
             self.graph, self.dtype, self._h, self.device = network, device[0], _handle, device[1]
             return
@@ -120,6 +121,7 @@ class BeliefPropagationCache:
         h = L.H()
         L.check(L.lib.tnqs_create(g.nv(), g.ne(), esp, edp, sdp, _DT[network.dtype], device, C.byref(h)))
         self._h = h
+        self._shard_pending = None
         for v in g.vertices:
             self._set_tensor(v, network.tensors[v])
 
@@ -177,7 +179,19 @@ class BeliefPropagationCache:
     def copy(self) -> "BeliefPropagationCache":
         h = L.H()
         L.check(L.lib.tnqs_copy(self._h, C.byref(h)))
-        return BeliefPropagationCache(self.graph, (self.dtype, self.device), _handle=h)
+        out = BeliefPropagationCache(self.graph, (self.dtype, self.device), _handle=h)
+        out._shard = self._shard          # copies share the sharding state (and keep its callback alive)
+        return out
+
+    def owns(self, v) -> bool:
+        return self._shard is None or self._shard.owner[self.graph.index[v]] == self._shard.rank
+
+    def _declare_dims(self, v, shape):
+        """sharded mode: record the bond dimensions of a vertex owned by another rank (no data is uploaded)"""
+        dims = np.array(list(reversed(shape)), dtype=np.int64)
+        roles, rp = L.i32(self._roles(v))
+        L.check(L.lib.tnqs_set_site_tensor(self._h, self.graph.index[v], None, len(shape),
+                                           dims.ctypes.data_as(C.POINTER(C.c_int64)), rp))
 
     def maxvirtualdim(self) -> int:
         c = C.c_int()

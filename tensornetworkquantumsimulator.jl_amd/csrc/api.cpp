@@ -50,7 +50,7 @@ int tnqs_set_stream(tnqs_handle h, void* stream) {
 }
 
 int tnqs_set_site_tensor(tnqs_handle h, int v, const void* host, int ndim, const int64_t* dims, const int32_t* role) {
-    return guard([&] { if (!host || !dims || !role) throw Err(TNQS_ERR_INVALID, "set_site_tensor: null argument"); state_set_site(S(h), v, host, ndim, dims, role); });
+    return guard([&] { if (!dims || !role) throw Err(TNQS_ERR_INVALID, "set_site_tensor: null argument"); state_set_site(S(h), v, host, ndim, dims, role); });
 }
 int tnqs_get_site_tensor(tnqs_handle h, int v, void* host, int ndim, const int32_t* role) {
     return guard([&] { if (!host || !role) throw Err(TNQS_ERR_INVALID, "get_site_tensor: null argument"); state_get_site(S(h), v, host, ndim, role); });
@@ -113,13 +113,18 @@ int tnqs_expect_all(tnqs_handle h, const double* ops, double* out) {
     return guard([&] { if (!ops || !out) throw Err(TNQS_ERR_INVALID, "expect_all: null"); expect_all(S(h), ops, out); });
 }
 
-int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* owner, tnqs_allgatherv_fn fn, void* ctx) {
+int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* owner, tnqs_allgather_fn fn, void* ctx,
+                      void* exch_dev, int64_t exch_bytes) {
     return guard([&] {
         State* s = S(h);
         if (nranks < 1 || rank < 0 || rank >= nranks) throw Err(TNQS_ERR_INVALID, "set_sharding: bad rank");
-        if (nranks > 1) throw Err(TNQS_ERR_UNSUPPORTED, "set_sharding: nranks > 1 is not implemented in this build");
-        (void)owner; (void)fn; (void)ctx;
-        s->rank = rank; s->nranks = nranks;
+        if (nranks > 1) {
+            if (!owner || !fn || !exch_dev || exch_bytes <= 0) throw Err(TNQS_ERR_INVALID, "set_sharding: owner, callback and exchange buffer are required for nranks > 1");
+            for (int v = 0; v < s->g->nv; ++v) if (owner[v] < 0 || owner[v] >= nranks) throw Err(TNQS_ERR_INVALID, "set_sharding: owner out of range");
+            s->owner.assign(owner, owner + s->g->nv);
+        } else s->owner.clear();
+        s->rank = rank; s->nranks = nranks; s->ag_fn = fn; s->ag_ctx = ctx; s->exch = exch_dev; s->exch_bytes = (size_t)exch_bytes;
+        if (nranks > 1) for (int v = 0; v < s->g->nv; ++v) if (!s->owns(v)) s->site[v] = nullptr;   // only owners hold site tensors
     });
 }
 

@@ -223,6 +223,7 @@ State* state_copy(const State* o) {
     s->g = o->g; s->dtype = o->dtype; s->device = o->device; s->d = o->d; s->chi = o->chi;
     s->site = o->site; s->msg = o->msg; s->pool = o->pool; s->prof = o->prof;
     s->rank = o->rank; s->nranks = o->nranks; s->owner = o->owner; s->ag_fn = o->ag_fn; s->ag_ctx = o->ag_ctx;
+    s->exch = o->exch; s->exch_bytes = o->exch_bytes;
     HIPCHK(hipSetDevice(o->device));
     if (o->own_stream) { HIPCHK(hipStreamSynchronize(o->stream)); HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
     else { s->stream = o->stream; s->own_stream = false; }
@@ -249,6 +250,15 @@ void state_set_site(State* s, int v, const void* host, int ndim, const int64_t* 
     size_t n = 1; std::vector<long long> stride_caller(ndim);
     for (int k = 0; k < ndim; ++k) { stride_caller[k] = (long long)n; if (dims[k] < 1) throw Err(TNQS_ERR_INVALID, "set_site_tensor: bad dim"); n *= (size_t)dims[k]; }
     HIPCHK(hipSetDevice(s->device));
+    if (!s->owns(v)) {          // sharded, not ours: only the bond dimensions are recorded (host may be null)
+        s->site[v] = nullptr;
+        for (int j = 0; j < z; ++j) {
+            int e = g.nbr_e[v][j]; int c = (int)dims[src_of[1 + j]];
+            if (s->chi[e] != c) { s->chi[e] = c; s->msg[2 * e] = nullptr; s->msg[2 * e + 1] = nullptr; }
+        }
+        return;
+    }
+    if (!host) throw Err(TNQS_ERR_INVALID, "set_site_tensor: null data for an owned vertex");
     Buf raw = dalloc(s, n * s->esz());
     HIPCHK(hipMemcpyAsync(raw->p, host, n * s->esz(), hipMemcpyHostToDevice, s->stream));
     Buf out = dalloc(s, n * s->esz());
@@ -328,6 +338,9 @@ static void tile_params(size_t PA, size_t PB, int TR, int& TA, int& TB, int& nta
     TA = (int)std::min<size_t>(PA, TR); TB = std::max(1, TR / TA); TB = (int)std::min<size_t>(TB, PB);
     nta = (int)((PA + TA - 1) / TA); ntb = (int)((PB + TB - 1) / TB);
 }
+
+static void exchange(State* s, size_t bytes_per_rank);
+static size_t round256(size_t b);
 
 // a chain = one site tensor pushed through several mode products (leg j with matrix X_j, chi_j x chi_j)
 struct Chain {
@@ -513,21 +526,56 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                 }
                 run_grams<T, T>(s, jobs, TNQS_PROF_BP_GRAM);
                 std::vector<MsgFinalItem> fin;
-                for (size_t i = 0; i < jobs.size(); ++i) {
-                    int t = tpos[i]; int de = plan.seq[t]; int c = s->chi[de / 2];
-                    Buf nb = dalloc(s, (size_t)c * c * esz);
-                    MsgFinalItem f{}; f.partial = jobs[i].partial->p; f.nchunks = jobs[i].nchunks; f.chi = c;
-                    const Buf& oldb = plan.in_place && fresh[de] ? fresh[de] : cur[de];
-                    f.old_msg = oldb ? oldb->p : nullptr; f.new_msg = nb->p;
-                    f.diff_out = reinterpret_cast<double*>(d_diffs->p) + t; f.normalize = normalize;
-                    fin.push_back(f);
-                    fresh[de] = nb;
+                if (s->nranks <= 1) {
+                    for (size_t i = 0; i < jobs.size(); ++i) {
+                        int t = tpos[i]; int de = plan.seq[t]; int c = s->chi[de / 2];
+                        Buf nb = dalloc(s, (size_t)c * c * esz);
+                        MsgFinalItem f{}; f.partial = jobs[i].partial->p; f.nchunks = jobs[i].nchunks; f.chi = c;
+                        const Buf& oldb = plan.in_place && fresh[de] ? fresh[de] : cur[de];
+                        f.old_msg = oldb ? oldb->p : nullptr; f.new_msg = nb->p;
+                        f.diff_out = reinterpret_cast<double*>(d_diffs->p) + t; f.normalize = normalize;
+                        fin.push_back(f);
+                        fresh[de] = nb;
+                    }
+                } else {
+                    // sharded: owners reduce their raw messages into the exchange buffer, all-gather, then EVERY rank
+                    // normalises / diffs every message of the sub-batch (messages are replicated)
+                    std::vector<size_t> slot(end - start, 0); std::vector<size_t> rank_bytes(s->nranks, 0);
+                    for (size_t q = start; q < end; ++q) {
+                        int de = plan.seq[lev[q]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
+                        int r = s->owner[src]; slot[q - start] = rank_bytes[r];
+                        rank_bytes[r] += round256((size_t)s->chi[e] * s->chi[e] * esz);
+                    }
+                    size_t stride = 0; for (size_t b : rank_bytes) stride = std::max(stride, b);
+                    char* base = reinterpret_cast<char*>(s->exch);
+                    std::vector<ReduceItem> ri; int elems = 0; size_t oi = 0;
+                    for (size_t q = start; q < end; ++q) {
+                        int de = plan.seq[lev[q]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
+                        if (!s->owns(src)) continue;
+                        int n2 = s->chi[e] * s->chi[e];
+                        ri.push_back(ReduceItem{jobs[oi].partial->p, base + (size_t)s->rank * stride + slot[q - start], n2, jobs[oi].nchunks, 0, elems});
+                        elems += n2; ++oi;
+                    }
+                    if (!ri.empty()) { const ReduceItem* dr = upload(s, ri); launch_reduce<T, T>(s->stream, dr, (int)ri.size(), elems); }
+                    exchange(s, stride);
+                    for (size_t q = start; q < end; ++q) {
+                        int t = lev[q]; int de = plan.seq[t]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
+                        int c = s->chi[e];
+                        Buf nb = dalloc(s, (size_t)c * c * esz);
+                        MsgFinalItem f{}; f.partial = base + (size_t)s->owner[src] * stride + slot[q - start]; f.nchunks = 1; f.chi = c;
+                        const Buf& oldb = plan.in_place && fresh[de] ? fresh[de] : cur[de];
+                        f.old_msg = oldb ? oldb->p : nullptr; f.new_msg = nb->p;
+                        f.diff_out = reinterpret_cast<double*>(d_diffs->p) + t; f.normalize = normalize;
+                        fin.push_back(f);
+                        fresh[de] = nb;
+                    }
                 }
                 {
                     const MsgFinalItem* d = upload(s, fin);
                     ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
                     launch_msg_finalize<T>(s->stream, d, (int)fin.size());
                 }
+                if (s->nranks > 1) HIPCHK(hipStreamSynchronize(s->stream));    // the exchange buffer is reused by the next sub-batch
                 start = end;
             }
         }
@@ -619,22 +667,37 @@ template <class T> static void apply_one_site_batch(State* s, const std::vector<
     norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, normalize);
 }
 
+// all-gather of equal-sized per-rank blocks laid out back to back in the host-provided exchange buffer
+void exchange(State* s, size_t bytes_per_rank) {
+    if (s->nranks <= 1) return;
+    if (!s->ag_fn) throw Err(TNQS_ERR_COMM, "sharded handle without an all-gather callback");
+    if (bytes_per_rank * (size_t)s->nranks > s->exch_bytes) throw Err(TNQS_ERR_COMM, "exchange buffer too small for this batch (raise the buffer size passed to tnqs_set_sharding)");
+    HIPCHK(hipStreamSynchronize(s->stream));
+    int rc = s->ag_fn(s->ag_ctx, s->exch, (int64_t)bytes_per_rank, s->nranks);
+    if (rc != 0) throw Err(TNQS_ERR_COMM, "all-gather callback failed");
+}
+size_t round256(size_t b) { return (b + 255) & ~size_t(255); }
+
 template <class T> static void apply_two_site_batch(State* s, const std::vector<Gate2>& gates, const tnqs_apply_opts& ao, double* errs) {
     if (gates.empty()) return;
     const Graph& g = *s->g;
     const size_t esz = s->esz();
+    const bool sharded = s->nranks > 1;
     const double sqrt_cutoff = ao.sqrt_cutoff >= 0 ? ao.sqrt_cutoff : 10.0 * (s->dtype == TNQS_C64 ? 1.1920928955078125e-07 : 2.220446049250313e-16);
     const int ng = (int)gates.size();
-    struct SiteJob { int v, other, bleg; SD sd; std::vector<int> env_idx; std::vector<int> env_leg; };
+    struct SiteJob { int v, other, bleg; bool owned; SD sd; std::vector<int> env_idx; std::vector<int> env_leg; };
     std::vector<SiteJob> sj(2 * (size_t)ng);
-    // ---- 1. environments: sqrt(M) and projector for every incoming message (utils.jl:18-27) ---------------------
-    struct EnvRec { int de; int n; Buf H, V, msq, prj, flags; };
+    std::vector<char> part(ng, 0);                  // this rank runs the small algebra of the gate
+    // ---- 1. environments: sqrt(M) and projector for every incoming message of an owned site (utils.jl:18-27) ------
+    struct EnvRec { int de; int n; Buf H, V, msq, prj; };
     std::vector<EnvRec> envs;
     for (int gi = 0; gi < ng; ++gi) {
         for (int side = 0; side < 2; ++side) {
             SiteJob& j = sj[2 * gi + side];
             j.v = side == 0 ? gates[gi].v1 : gates[gi].v2; j.other = side == 0 ? gates[gi].v2 : gates[gi].v1;
-            j.sd = site_dims(s, j.v); j.bleg = g.leg(j.v, j.other);
+            j.sd = site_dims(s, j.v); j.bleg = g.leg(j.v, j.other); j.owned = s->owns(j.v);
+            if (j.owned) part[gi] = 1;
+            if (!j.owned) continue;
             for (int l = 0; l < j.sd.z; ++l) {
                 if (l == j.bleg) continue;
                 int de = g.dedge(g.nbr[j.v][l], j.v);
@@ -663,126 +726,221 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_finish<T>(s->stream, df, (int)fi.size()); }
         }
     }
-    // ---- 2. gauge: psi~ = psi x_outer M^{1/2}  (simple_update.jl:43-44) ----------------------------------------------
-    std::vector<Chain> chains(2 * (size_t)ng);
-    for (size_t i = 0; i < sj.size(); ++i) {
-        Chain& c = chains[i]; c.v = sj[i].v; c.src = s->site[sj[i].v]->p; c.sd = sj[i].sd;
-        for (size_t q = 0; q < sj[i].env_idx.size(); ++q) c.steps.push_back({sj[i].env_leg[q], envs[sj[i].env_idx[q]].msq->p});
+    // ---- 2. gauge: psi~ = psi x_outer M^{1/2}  (simple_update.jl:43-44), owned sites only -----------------------------
+    std::vector<int> own_idx;                        // indices into sj of the owned sites
+    for (size_t i = 0; i < sj.size(); ++i) if (sj[i].owned) own_idx.push_back((int)i);
+    std::vector<Chain> chains(own_idx.size());
+    for (size_t q = 0; q < own_idx.size(); ++q) {
+        const SiteJob& j = sj[own_idx[q]];
+        Chain& c = chains[q]; c.v = j.v; c.src = s->site[j.v]->p; c.sd = j.sd;
+        for (size_t e = 0; e < j.env_idx.size(); ++e) c.steps.push_back({j.env_leg[e], envs[j.env_idx[e]].msq->p});
     }
     run_chains<T>(s, chains, TNQS_PROF_GATE_MODEPROD);
     // ---- 3. G = psi~^dagger psi~ over the outer legs, f64 accumulation (replaces the thin QR, simple_update.jl:45-48) --
     std::vector<GramJob> jobs;
-    for (size_t i = 0; i < sj.size(); ++i) {
-        GramJob j{}; j.X = chains[i].result; j.Y = chains[i].result; j.sd = sj[i].sd; j.leg = sj[i].bleg; j.keep_site = true;
+    for (size_t q = 0; q < own_idx.size(); ++q) {
+        const SiteJob& sjq = sj[own_idx[q]];
+        GramJob j{}; j.X = chains[q].result; j.Y = chains[q].result; j.sd = sjq.sd; j.leg = sjq.bleg; j.keep_site = true;
         jobs.push_back(j);
     }
     run_grams<T, double>(s, jobs, TNQS_PROF_GATE_GRAM);
     std::vector<Buf> GA(sj.size()), GV(sj.size());
+    auto nof = [&](size_t i) { return sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]; };
     {
-        std::vector<ReduceItem> ri; std::vector<EnvItem> idn; std::vector<JacobiItem> ji; int elems = 0;
-        for (size_t i = 0; i < sj.size(); ++i) {
-            int n = jobs[i].KK; size_t nn = (size_t)n * n;
-            GA[i] = dalloc(s, nn * 16); GV[i] = dalloc(s, nn * 16);
-            ri.push_back(ReduceItem{jobs[i].partial->p, GA[i]->p, (int)nn, jobs[i].nchunks, 1, elems}); elems += (int)nn;
-            ji.push_back(JacobiItem{GA[i]->p, GV[i]->p, n, n, nullptr});
+        // G slots: in the sharded case every rank needs G1 and G2 of the gates it takes part in -> all-gather all of them
+        std::vector<size_t> slot(sj.size(), 0); std::vector<size_t> rank_bytes(s->nranks, 0);
+        size_t stride = 0;
+        if (sharded) {
+            for (size_t i = 0; i < sj.size(); ++i) { int r = s->owner[sj[i].v]; slot[i] = rank_bytes[r]; rank_bytes[r] += round256((size_t)nof(i) * nof(i) * 16); }
+            for (size_t b : rank_bytes) stride = std::max(stride, b);
+        }
+        std::vector<ReduceItem> ri; int elems = 0;
+        for (size_t q = 0; q < own_idx.size(); ++q) {
+            size_t i = own_idx[q]; int n = jobs[q].KK; size_t nn = (size_t)n * n;
+            GA[i] = dalloc(s, nn * 16);
+            void* dst = sharded ? (void*)(reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride + slot[i]) : GA[i]->p;
+            ri.push_back(ReduceItem{jobs[q].partial->p, dst, (int)nn, jobs[q].nchunks, 1, elems}); elems += (int)nn;
         }
         const ReduceItem* dr = upload(s, ri);
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, dr, (int)ri.size(), elems); }
-        for (size_t i = 0; i < sj.size(); ++i) launch_identity<double>(s->stream, GV[i]->p, jobs[i].KK);
-        const JacobiItem* dj = upload(s, ji);
-        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60); }
+        if (sharded) {
+            exchange(s, stride);
+            for (size_t i = 0; i < sj.size(); ++i) {
+                if (!part[i / 2]) continue;
+                size_t nn = (size_t)nof(i) * nof(i);
+                if (!GA[i]) GA[i] = dalloc(s, nn * 16);
+                HIPCHK(hipMemcpyAsync(GA[i]->p, reinterpret_cast<char*>(s->exch) + (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16, hipMemcpyDeviceToDevice, s->stream));
+            }
+        }
+        std::vector<JacobiItem> ji; std::vector<EnvItem> idn;
+        for (size_t i = 0; i < sj.size(); ++i) {
+            if (!part[i / 2]) continue;
+            int n = nof(i);
+            GV[i] = dalloc(s, (size_t)n * n * 16);
+            idn.push_back(EnvItem{nullptr, GV[i]->p, GV[i]->p, n});      // msg == null: H := I, V := I (same buffer)
+            ji.push_back(JacobiItem{GA[i]->p, GV[i]->p, n, n, nullptr});
+        }
+        if (!ji.empty()) {
+            const EnvItem* di = upload(s, idn);
+            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)idn.size()); }
+            const JacobiItem* dj = upload(s, ji);
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60); }
+        }
     }
     // ---- 4. theta = gate . (R1 R2), SVD, truncation, X1 / X2  (simple_update.jl:51-59) -----------------------------
-    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, X1, X2, S, info, terr, gate; int n1, n2, chi, cap; };
+    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, X1, X2, S, info, terr; int n1, n2, chi, cap; };
     std::vector<GateWS> ws(ng);
-    std::vector<GateItem> gitems(ng);
+    std::vector<int> pg;                              // gates this rank takes part in
+    for (int gi = 0; gi < ng; ++gi) if (part[gi]) pg.push_back(gi);
+    std::vector<GateItem> gitems(pg.size());
+    int cap_max = 1; size_t x2_max = 0;
+    for (int gi = 0; gi < ng; ++gi) {
+        GateWS& w = ws[gi];
+        const SiteJob& a = sj[2 * gi]; const SiteJob& b = sj[2 * gi + 1];
+        int chi = a.sd.chi[a.bleg];
+        w.n1 = a.sd.d * chi; w.n2 = b.sd.d * chi; w.chi = chi;
+        int Mr = w.n1 * a.sd.d, Nc = w.n2 * b.sd.d;
+        if (Mr > 256 || Nc > 256) throw Err(TNQS_ERR_UNSUPPORTED, "two-site gate: d^2*chi > 256 is not supported by the Jacobi SVD kernel yet");
+        int cap = std::min(Mr, Nc); if (ao.maxdim > 0) cap = std::min(cap, ao.maxdim);
+        w.cap = cap; cap_max = std::max(cap_max, cap);
+        x2_max = std::max(x2_max, (size_t)w.n2 * b.sd.d * cap * esz);
+    }
     {
         std::vector<char> raw;
-        std::vector<size_t> off(ng);
-        for (int gi = 0; gi < ng; ++gi) {
+        std::vector<size_t> off(pg.size());
+        for (size_t q = 0; q < pg.size(); ++q) {
+            int gi = pg[q];
             int dd = s->d[gates[gi].v1] * s->d[gates[gi].v2];
-            off[gi] = raw.size();
+            off[q] = raw.size();
             const char* p = reinterpret_cast<const char*>(gates[gi].mat);
             raw.insert(raw.end(), p, p + (size_t)dd * dd * 16);
         }
-        const char* d_gm = upload(s, raw);
-        for (int gi = 0; gi < ng; ++gi) {
-            GateWS& w = ws[gi]; GateItem& it = gitems[gi];
+        const char* d_gm = pg.empty() ? nullptr : upload(s, raw);
+        for (size_t q = 0; q < pg.size(); ++q) {
+            int gi = pg[q];
+            GateWS& w = ws[gi]; GateItem& it = gitems[q];
             const SiteJob& a = sj[2 * gi]; const SiteJob& b = sj[2 * gi + 1];
-            int chi = a.sd.chi[a.bleg];
-            w.n1 = a.sd.d * chi; w.n2 = b.sd.d * chi; w.chi = chi;
-            int Mr = w.n1 * a.sd.d, Nc = w.n2 * b.sd.d;
-            if (Mr > 256 || Nc > 256) throw Err(TNQS_ERR_UNSUPPORTED, "two-site gate: d^2*chi > 256 is not supported by the Jacobi SVD kernel yet");
-            int cap = std::min(Mr, Nc); if (ao.maxdim > 0) cap = std::min(cap, ao.maxdim);
-            w.cap = cap;
+            int Mr = w.n1 * a.sd.d, Nc = w.n2 * b.sd.d, cap = w.cap;
             w.lam1 = dalloc(s, w.n1 * 8); w.lam2 = dalloc(s, w.n2 * 8); w.idx1 = dalloc(s, w.n1 * 4); w.idx2 = dalloc(s, w.n2 * 4);
-            w.theta = dalloc(s, (size_t)Mr * Nc * esz); w.thetaV = dalloc(s, (size_t)Nc * Nc * esz);
+            w.theta = dalloc(s, (size_t)Mr * Nc * esz); w.thetaV = dalloc(s, (size_t)std::max(Mr, Nc) * std::max(Mr, Nc) * esz);
             w.X1 = dalloc(s, (size_t)w.n1 * a.sd.d * cap * esz); w.X2 = dalloc(s, (size_t)w.n2 * b.sd.d * cap * esz);
             w.S = dalloc(s, cap * 8); w.info = dalloc(s, 8 * 4); w.terr = dalloc(s, 8);
             it.GA1 = GA[2 * gi]->p; it.GV1 = GV[2 * gi]->p; it.GA2 = GA[2 * gi + 1]->p; it.GV2 = GV[2 * gi + 1]->p;
-            it.n1 = w.n1; it.n2 = w.n2; it.d1 = a.sd.d; it.d2 = b.sd.d; it.chi = chi;
-            it.gate = reinterpret_cast<const double*>(d_gm + off[gi]);
+            it.n1 = w.n1; it.n2 = w.n2; it.d1 = a.sd.d; it.d2 = b.sd.d; it.chi = w.chi;
+            it.gate = reinterpret_cast<const double*>(d_gm + off[q]);
             it.lam1 = (double*)w.lam1->p; it.lam2 = (double*)w.lam2->p; it.idx1 = (int*)w.idx1->p; it.idx2 = (int*)w.idx2->p;
             it.theta = w.theta->p; it.thetaV = w.thetaV->p; it.X1 = w.X1->p; it.X2 = w.X2->p; it.S = (double*)w.S->p;
             it.info = (int*)w.info->p; it.truncerr = (double*)w.terr->p;
             it.maxdim = ao.maxdim; it.cutoff = ao.cutoff; it.normalize = ao.normalize_tensors; it.chi_cap = cap;
         }
     }
+    const int npg = (int)pg.size();
     const GateItem* d_gitems = upload(s, gitems);
-    { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_theta<T>(s->stream, d_gitems, ng); }
+    { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_theta<T>(s->stream, d_gitems, npg); }
+    std::vector<int> info(8 * (size_t)ng, 0); std::vector<double> terr(ng, 0.0);
     {
-        // theta dims depend on the ranks found on the device; Jacobi reads m, n from the item, so ranks must be known:
-        // read them back (small) -- this is also where message-eigenvalue errors surface.
-        std::vector<int> info(8 * (size_t)ng);
-        for (int gi = 0; gi < ng; ++gi) HIPCHK(hipMemcpyAsync(&info[8 * gi], ws[gi].info->p, 8 * 4, hipMemcpyDeviceToHost, s->stream));
+        // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
+        Buf d_info_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 32));
+        for (int q = 0; q < npg; ++q) HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d_info_all->p) + 32 * q, ws[pg[q]].info->p, 32, hipMemcpyDeviceToDevice, s->stream));
+        std::vector<int> hinfo(8 * (size_t)std::max(1, npg));
+        if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
         if (!envs.empty()) HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags->p, 2 * envs.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         for (size_t i = 0; i < envs.size(); ++i)
             if (h_flags[2 * i + 1]) throw Err(TNQS_ERR_NUMERIC, "simple_update: incoming message has a negative eigenvalue above sqrt_cutoff (DomainError in the reference, src/utils.jl:21)");
         std::vector<JacobiItem> ji;
-        for (int gi = 0; gi < ng; ++gi) {
-            int r1 = info[8 * gi], r2 = info[8 * gi + 1];
-            int Mr = r1 * gitems[gi].d1, Nc = r2 * gitems[gi].d2;
+        for (int q = 0; q < npg; ++q) {
+            int gi = pg[q];
+            int r1 = hinfo[8 * q], r2 = hinfo[8 * q + 1];
+            int Mr = r1 * gitems[q].d1, Nc = r2 * gitems[q].d2;
             if (Mr < Nc) std::swap(Mr, Nc);        // wide theta is stored as its adjoint (gate_theta_kernel)
             ji.push_back(JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, reinterpret_cast<int*>(ws[gi].info->p) + 4});
         }
         const JacobiItem* dj = upload(s, ji);
-        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<T>(s->stream, dj, ng, 60); }
+        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<T>(s->stream, dj, npg, 60); }
+        { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
+        Buf d_terr_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 8));
+        for (int q = 0; q < npg; ++q) {
+            HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d_info_all->p) + 32 * q, ws[pg[q]].info->p, 32, hipMemcpyDeviceToDevice, s->stream));
+            HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d_terr_all->p) + 8 * q, ws[pg[q]].terr->p, 8, hipMemcpyDeviceToDevice, s->stream));
+        }
+        std::vector<double> hterr(std::max(1, npg));
+        if (npg) {
+            HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipMemcpyAsync(hterr.data(), d_terr_all->p, (size_t)npg * 8, hipMemcpyDeviceToHost, s->stream));
+        }
+        HIPCHK(hipStreamSynchronize(s->stream));
+        for (int q = 0; q < npg; ++q) { for (int k = 0; k < 8; ++k) info[8 * pg[q] + k] = hinfo[8 * q + k]; terr[pg[q]] = hterr[q]; }
     }
-    { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, ng); }
-    std::vector<int> info(8 * (size_t)ng); std::vector<double> terr(ng);
-    for (int gi = 0; gi < ng; ++gi) {
-        HIPCHK(hipMemcpyAsync(&info[8 * gi], ws[gi].info->p, 8 * 4, hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipMemcpyAsync(&terr[gi], ws[gi].terr->p, 8, hipMemcpyDeviceToHost, s->stream));
+    // ---- 4b. sharded: the owner of the first vertex publishes (chi', status, truncerr, S, X2) of each gate ----------------
+    std::vector<const double*> Sptr(ng, nullptr);
+    Buf S_keep;
+    if (sharded) {
+        const size_t slot_bytes = round256(32 + (size_t)cap_max * 8 + x2_max);
+        std::vector<size_t> slot(ng, 0); std::vector<size_t> rank_bytes(s->nranks, 0);
+        for (int gi = 0; gi < ng; ++gi) { int r = s->owner[gates[gi].v1]; slot[gi] = rank_bytes[r]; rank_bytes[r] += slot_bytes; }
+        size_t stride = 0; for (size_t b : rank_bytes) stride = std::max(stride, b);
+        char* base = reinterpret_cast<char*>(s->exch);
+        std::vector<double> hdr(4 * (size_t)ng, 0.0);
+        for (int gi = 0; gi < ng; ++gi) {
+            if (s->owner[gates[gi].v1] != s->rank) continue;
+            char* dst = base + (size_t)s->rank * stride + slot[gi];
+            hdr[4 * gi] = info[8 * gi + 2]; hdr[4 * gi + 1] = info[8 * gi + 3]; hdr[4 * gi + 2] = terr[gi];
+            HIPCHK(hipMemcpyAsync(dst, &hdr[4 * gi], 32, hipMemcpyHostToDevice, s->stream));
+            HIPCHK(hipMemcpyAsync(dst + 32, ws[gi].S->p, (size_t)ws[gi].cap * 8, hipMemcpyDeviceToDevice, s->stream));
+            const SiteJob& b = sj[2 * gi + 1];
+            HIPCHK(hipMemcpyAsync(dst + 32 + (size_t)cap_max * 8, ws[gi].X2->p, (size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz, hipMemcpyDeviceToDevice, s->stream));
+        }
+        exchange(s, stride);
+        // keep a private copy of the gathered block: the exchange buffer is reused by the next batch
+        S_keep = dalloc(s, stride * (size_t)s->nranks);
+        HIPCHK(hipMemcpyAsync(S_keep->p, base, stride * (size_t)s->nranks, hipMemcpyDeviceToDevice, s->stream));
+        std::vector<double> allhdr(4 * (size_t)ng);
+        for (int gi = 0; gi < ng; ++gi)
+            HIPCHK(hipMemcpyAsync(&allhdr[4 * gi], reinterpret_cast<char*>(S_keep->p) + (size_t)s->owner[gates[gi].v1] * stride + slot[gi], 32, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        for (int gi = 0; gi < ng; ++gi) {
+            info[8 * gi + 2] = (int)allhdr[4 * gi]; info[8 * gi + 3] = (int)allhdr[4 * gi + 1]; terr[gi] = allhdr[4 * gi + 2];
+            const char* src = reinterpret_cast<const char*>(S_keep->p) + (size_t)s->owner[gates[gi].v1] * stride + slot[gi];
+            Sptr[gi] = reinterpret_cast<const double*>(src + 32);
+            const SiteJob& b = sj[2 * gi + 1];
+            if (b.owned && s->owner[gates[gi].v1] != s->rank) {       // the partner rank computed the SVD: take its X2
+                if (!ws[gi].X2) ws[gi].X2 = dalloc(s, (size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz);
+                HIPCHK(hipMemcpyAsync(ws[gi].X2->p, src + 32 + (size_t)cap_max * 8, (size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz, hipMemcpyDeviceToDevice, s->stream));
+            }
+        }
+    } else {
+        for (int gi = 0; gi < ng; ++gi) Sptr[gi] = (const double*)ws[gi].S->p;
     }
-    HIPCHK(hipStreamSynchronize(s->stream));
     // ---- 5. psi' = (psi x_outer P) x_(s,b) X  (simple_update.jl:62-64, net effect of gauge + ungauge) ----------------
-    std::vector<Chain> pch(2 * (size_t)ng);
-    for (size_t i = 0; i < sj.size(); ++i) {
-        Chain& c = pch[i]; c.v = sj[i].v; c.src = s->site[sj[i].v]->p; c.sd = sj[i].sd;
-        for (size_t q = 0; q < sj[i].env_idx.size(); ++q)
-            if (!h_flags[2 * sj[i].env_idx[q]]) c.steps.push_back({sj[i].env_leg[q], envs[sj[i].env_idx[q]].prj->p});  // rank-deficient message only
+    std::vector<Chain> pch(own_idx.size());
+    for (size_t q = 0; q < own_idx.size(); ++q) {
+        const SiteJob& j = sj[own_idx[q]];
+        Chain& c = pch[q]; c.v = j.v; c.src = s->site[j.v]->p; c.sd = j.sd;
+        for (size_t e = 0; e < j.env_idx.size(); ++e)
+            if (!h_flags[2 * j.env_idx[e]]) c.steps.push_back({j.env_leg[e], envs[j.env_idx[e]].prj->p});  // rank-deficient message only
     }
     run_chains<T>(s, pch, TNQS_PROF_GATE_MODEPROD);
-    {
+    if (!own_idx.empty()) {
         std::vector<FiberItem> items; std::vector<int> verts, tb, nt; std::vector<Buf> outs; std::vector<size_t> ne;
-        int tiles = 0; size_t KKmax = 1; double bytes = 0, flops = 0;
-        size_t NNmax = 1;
-        for (size_t i = 0; i < sj.size(); ++i) {
+        int tiles = 0; size_t KKmax = 1, NNmax = 1; double bytes = 0, flops = 0;
+        for (size_t q = 0; q < own_idx.size(); ++q) {
+            size_t i = own_idx[q];
             KKmax = std::max<size_t>(KKmax, (size_t)sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]);
             NNmax = std::max<size_t>(NNmax, (size_t)sj[i].sd.d * info[8 * (i / 2) + 2]);
         }
         int TR = pick_TR(KKmax, esz, 1);
         bool mf = false;
         if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)NNmax); if (t > 0) { TR = t; mf = true; } }
-        for (size_t i = 0; i < sj.size(); ++i) {
+        for (size_t q = 0; q < own_idx.size(); ++q) {
+            size_t i = own_idx[q];
             int gi = (int)i / 2; int chin = info[8 * gi + 2];
             const SiteJob& j = sj[i];
             size_t pre = j.sd.pre(j.bleg), post = j.sd.post(j.bleg);
             int chi = j.sd.chi[j.bleg];
             size_t nout = j.sd.n / chi * chin;
             FiberItem it{}; Buf out = dalloc(s, nout * esz);
-            it.in = pch[i].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
+            it.in = pch[q].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
             it.D = j.sd.d; it.PA = (int)(pre / j.sd.d); it.K = chi; it.PB = (int)post; it.Do = j.sd.d; it.No = chin;
             tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
             it.tpw = mf ? (TR == 32 ? 16 : 4) : 1;
@@ -798,7 +956,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
           if (mf) launch_mfma_fiber_gemm(s->stream, d, (int)items.size(), tiles, (int)KKmax, (int)NNmax, reinterpret_cast<double*>(np->p));
           else launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
         norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, ao.normalize_tensors != 0);
-        }
+    }
     // ---- 6. both bond messages := diag(S)  (apply_gates.jl:126-135), new bond dimension ---------------------------
     {
         std::vector<DiagItem> di;
@@ -808,7 +966,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             s->chi[e] = chin;
             for (int dir = 0; dir < 2; ++dir) {
                 Buf m = dalloc(s, (size_t)chin * chin * esz);
-                di.push_back(DiagItem{m->p, (const double*)ws[gi].S->p, chin});
+                di.push_back(DiagItem{m->p, Sptr[gi], chin});
                 s->msg[2 * e + dir] = m;
             }
             if (errs) errs[gates[gi].index] = terr[gi];

@@ -75,7 +75,8 @@ struct State {
     std::shared_ptr<Pool> pool;
     hipStream_t stream = nullptr; bool own_stream = false;
     // sharding
-    int rank = 0, nranks = 1; std::vector<int> owner; tnqs_allgatherv_fn ag_fn = nullptr; void* ag_ctx = nullptr;
+    int rank = 0, nranks = 1; std::vector<int> owner; tnqs_allgather_fn ag_fn = nullptr; void* ag_ctx = nullptr;
+    void* exch = nullptr; size_t exch_bytes = 0;      // host-provided device exchange buffer (nranks equal blocks)
     // profiling (shared by copies of a handle, so a loop `bpc = apply_gates(layer, bpc)` accumulates)
     std::shared_ptr<Prof> prof;
     std::vector<Buf> keepalive;    // descriptor buffers kept until the next host sync

@@ -1,0 +1,93 @@
+"""Multi-GPU sharding of the hot path (no reference analogue): one process per GPU, vertices are
+block-partitioned over the ranks, each rank holds and updates only its own site tensors, messages are replicated.
+The C library packs its exchange payloads into a device buffer owned here (a torch tensor) and calls back for an
+all-gather, which runs through torch.distributed -- backend "nccl" (= RCCL over xGMI on ROCm) in production; with
+the "gloo" backend the buffer is staged through the host, which lets two ranks share one GPU in tests."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib as L
+
+
+def partition_vertices(nv: int, world: int) -> List[int]:
+    """contiguous, balanced blocks of vertex positions: owner[v] = rank.  Any partition is valid (messages are
+    replicated, every per-vertex unit of work belongs to exactly one rank); balanced blocks give every rank the
+    same number of messages per BP level and of gate sites per colour batch."""
+    if world < 1 or nv < 1:
+        raise ValueError("partition_vertices: nv and world must be positive")
+    base, rem = divmod(nv, world)
+    owner = []
+    for r in range(world):
+        owner += [r] * (base + (1 if r < rem else 0))
+    return owner
+
+
+def exchange_bytes_needed(max_chi: int, d: int, n_edges: int, n_vertices: int, esz: int) -> int:
+    """upper bound of one exchange block set: Gram matrices of every site of a colour batch, or all raw messages of
+    one BP level, or the per-gate result records (S and X2)."""
+    n = d * max_chi
+    grams = n_vertices * (n * n * 16 + 256)
+    msgs = 2 * n_edges * (max_chi * max_chi * esz + 256)
+    recs = n_edges * (32 + max_chi * d * 8 + n * d * max_chi * esz + 256)
+    return int(max(grams, msgs, recs)) + (1 << 20)
+
+
+class Sharding:
+    """keeps the exchange tensor and the ctypes callback alive for as long as any handle copy uses them"""
+
+    def __init__(self, rank: int, world: int, owner: List[int], exch_bytes: int, group=None, device: Optional[int] = None):
+        import torch
+        import torch.distributed as dist
+        self.rank, self.world, self.owner, self.group = rank, world, list(owner), group
+        self.torch, self.dist = torch, dist
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.per_rank_cap = (exch_bytes + world - 1) // world
+        self.buf = torch.empty(self.per_rank_cap * world, dtype=torch.uint8, device=dev)
+        self.backend = dist.get_backend(group)
+        self.n_exchanges = 0
+        self.bytes_exchanged = 0
+
+        def _cb(ctx, base, bytes_per_rank, nranks):
+            try:
+                assert base == self.buf.data_ptr() and nranks == self.world
+                n = int(bytes_per_rank)
+                flat = self.buf[: n * nranks]
+                mine = flat[self.rank * n:(self.rank + 1) * n]
+                if self.backend == "nccl":
+                    self.dist.all_gather_into_tensor(flat, mine, group=self.group)
+                    self.torch.cuda.synchronize()
+                else:                                   # gloo: stage through the host (tests; ranks may share a GPU)
+                    host = mine.cpu()
+                    outs = [self.torch.empty_like(host) for _ in range(nranks)]
+                    self.dist.all_gather(outs, host, group=self.group)
+                    flat.copy_(self.torch.cat(outs).to(flat.device))
+                    self.torch.cuda.synchronize()
+                self.n_exchanges += 1
+                self.bytes_exchanged += n * nranks
+                return 0
+            except Exception as e:                      # never let an exception cross the C boundary
+                import sys
+                print(f"[tnqs dist] all-gather callback failed: {e!r}", file=sys.stderr)
+                return 1
+
+        self.cb = L.ALLGATHER_FN(_cb)
+
+
+def shard(bpc, rank: int, world: int, owner: Optional[List[int]] = None, exch_bytes: Optional[int] = None, group=None,
+          max_chi: int = 64):
+    """attach vertex sharding to a freshly created cache (call on every rank, before uploading site tensors)"""
+    g = bpc.graph
+    if owner is None:
+        owner = partition_vertices(g.nv(), world)
+    if exch_bytes is None:
+        exch_bytes = world * exchange_bytes_needed(max_chi, 2, g.ne(), g.nv(), 8 if bpc.dtype == np.complex64 else 16) // max(1, world // 2)
+    sh = Sharding(rank, world, owner, exch_bytes, group=group, device=bpc.device)
+    ow, owp = L.i32(owner)
+    L.check(L.lib.tnqs_set_sharding(bpc._h, rank, world, owp, sh.cb, None, C.c_void_p(sh.buf.data_ptr()),
+                                    C.c_int64(sh.buf.numel())))
+    bpc._shard = sh
+    return sh

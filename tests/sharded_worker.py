@@ -1,0 +1,82 @@
+"""worker of tests/test_gpu_sharded.py: run as `python -m torch.distributed.run --nproc-per-node 2 tests/sharded_worker.py out.npz`
+(gloo backend, both ranks on GPU 0): a sharded 2-rank apply_gates must reproduce the single-rank result."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tnqs_amd as tn
+
+
+def run(bpc_factory, layer, kw, bpkw, nlayers):
+    bpc = bpc_factory()
+    bpc = tn.update(bpc, **bpkw)
+    errs_all = []
+    for _ in range(nlayers):
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=bpkw)
+        errs_all.append(errs)
+    return bpc, np.array(errs_all)
+
+
+def main():
+    out = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    dtype = np.complex64 if (len(sys.argv) > 2 and sys.argv[2] == "c64") else np.complex128
+    g = tn.named_grid((4, 3))
+    groups = tn.edge_color(g, 4)
+    layer = [("Rx", [v], 0.5) for v in g.vertices] + [("Rz", [v], 0.4) for v in g.vertices]
+    seq = []
+    for grp in groups:
+        layer += [("Rzz", [a, b], 0.25) for (a, b) in grp]
+        seq += list(grp) + [(b, a) for (a, b) in grp]
+    kw = dict(maxdim=3, cutoff=1e-10, normalize_tensors=True)
+    bpkw = dict(edge_sequence=seq, maxiter=12, tolerance=None)
+    psi0 = tn.random_tensornetworkstate(dtype, g, bond_dimension=2, seed=11)
+
+    def sharded_factory():
+        b = tn.BeliefPropagationCache(tn.tensornetworkstate(dtype, lambda v: "↑", g))
+        tn.shard(b, rank, world, exch_bytes=8 << 20)
+        for v in g.vertices:
+            if b.owns(v):
+                b._set_tensor(v, psi0.tensors[v])
+            else:
+                b._declare_dims(v, psi0.tensors[v].shape)
+        return b
+
+    bs, es = run(sharded_factory, layer, kw, bpkw, 2)
+    # every rank holds all messages and bond dims; site tensors / <Z> only for owned vertices
+    ez = tn.expect_all(bs, "Z")
+    ez_t = torch.from_numpy(np.nan_to_num(ez.view(np.float64), nan=0.0).copy())
+    dist.all_reduce(ez_t)                                   # owners contribute, others contribute zeros
+    ez_full = ez_t.numpy().view(np.complex128)
+    spectra = []
+    for (a, b) in g.edges:
+        for e in ((a, b), (b, a)):
+            m = bs.message(e).astype(np.complex128)
+            w = np.linalg.eigvalsh((m + m.conj().T) / 2)
+            spectra.append(w / w.sum())
+    dims = np.array([bs.bond_dim(a, b) for (a, b) in g.edges])
+    nex = bs._shard.n_exchanges
+    if rank == 0:
+        bu, eu = run(lambda: tn.BeliefPropagationCache(psi0), layer, kw, bpkw, 2)
+        ezu = tn.expect_all(bu, "Z")
+        spu = []
+        for (a, b) in g.edges:
+            for e in ((a, b), (b, a)):
+                m = bu.message(e).astype(np.complex128)
+                w = np.linalg.eigvalsh((m + m.conj().T) / 2)
+                spu.append(w / w.sum())
+        np.savez(out, errs_sh=es, errs_un=eu, ez_sh=ez_full, ez_un=ezu, sp_sh=np.concatenate(spectra), sp_un=np.concatenate(spu),
+                 dims_sh=dims, dims_un=np.array([bu.bond_dim(a, b) for (a, b) in g.edges]), n_exchanges=nex)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

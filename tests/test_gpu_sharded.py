@@ -1,0 +1,28 @@
+"""GPU: the vertex-sharded (2-rank) path of the library against the unsharded one.  Two processes share GPU 0 and
+exchange through torch.distributed's gloo backend (host-staged); in production the same callback runs on RCCL."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("dt", ["c128", "c64"])
+def test_two_rank_sharded_apply_gates_matches_single_rank(tmp_path, dt):
+    out = str(tmp_path / "res.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "tests", "sharded_worker.py"), out, dt]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    z = np.load(out)
+    tol = 1e-9 if dt == "c128" else 2e-4
+    assert np.array_equal(z["dims_sh"], z["dims_un"])
+    assert np.max(np.abs(z["errs_sh"] - z["errs_un"])) < (1e-10 if dt == "c128" else 1e-5)
+    assert np.max(np.abs(z["ez_sh"] - z["ez_un"])) < tol
+    assert np.max(np.abs(z["sp_sh"] - z["sp_un"])) < tol
+    assert int(z["n_exchanges"]) > 0
