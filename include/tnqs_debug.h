@@ -13,6 +13,8 @@ int tnqs_dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No,
                         double* norm2_out, int use_mfma);
 /* out[i + KK*j] = sum_{(a,b)} X[i,(a,b)] conj(Y[j,(a,b)]), i,j = (s,k), KK = D*K; acc64: accumulate in double (out complex128) */
 int tnqs_dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma);
+/* c64 only: out[i + K*j] = sum ( X x_r M )[i,.] conj(Y[j,.]) with D = 1 and r = the first row leg (chi_r = 32, d = 2) */
+int tnqs_dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out);
 #ifdef __cplusplus
 }
 #endif

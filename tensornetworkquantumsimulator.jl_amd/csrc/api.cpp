@@ -150,7 +150,8 @@ int tnqs_profile_reset(tnqs_handle h) {
 // ---- kernel-level debug entry points (include/tnqs_debug.h) ---------------------------------------------------
 #include "../../include/tnqs_debug.h"
 #include "kernels.hpp"
-namespace tnqs { void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps);
+namespace tnqs { void dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out);
+                 void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps);
                  void dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, const void* in, const void* X, void* out, double* norm2, int use_mfma);
                  void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma); }
 extern "C" {
@@ -158,6 +159,7 @@ int tnqs_dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) { re
 int tnqs_dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, const void* in, const void* X, void* out, double* norm2, int use_mfma) {
     return guard([&] { dbg_fiber_gemm(dtype, D, PA, K, PB, Do, No, in, X, out, norm2, use_mfma); });
 }
+int tnqs_dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out) { return guard([&] { dbg_gram_fused(PA, K, PB, X, Y, M, out); }); }
 int tnqs_dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma) {
     return guard([&] { dbg_gram(dtype, D, PA, K, PB, X, Y, out, acc64, use_mfma); });
 }

@@ -85,4 +85,23 @@ void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void
     HIPCHK(hipDeviceSynchronize());
     dO.down(out, (size_t)KK * KK * asz);
 }
+void dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out) {
+    need_gpu();
+    size_t nin = (size_t)PA * K * PB;
+    DBuf dX(nin * 8), dY(nin * 8), dM(32 * 32 * 8), dI(sizeof(GramItem)), dR(sizeof(ReduceItem));
+    dX.up(X, nin * 8); dY.up(Y, nin * 8); dM.up(M, 32 * 32 * 8);
+    GramItem it{}; it.X = dX.p; it.Y = dY.p; it.M = dM.p; it.D = 1; it.PA = PA; it.K = K; it.PB = PB;
+    tile_params(PA, PB, 64, it.TA, it.TB, it.nta, it.ntb);
+    if (it.TA * it.TB != 64) throw Err(TNQS_ERR_INVALID, "dbg_gram_fused: tiles must hold 64 fibers");
+    int ntiles = it.nta * it.ntb; int nch = std::min(3, ntiles);
+    it.tiles_per_chunk = (ntiles + nch - 1) / nch; it.nchunks = (ntiles + it.tiles_per_chunk - 1) / it.tiles_per_chunk; it.chunk_begin = 0;
+    int npart = 4 * it.nchunks;
+    DBuf dP((size_t)npart * K * K * 8), dO((size_t)K * K * 8);
+    it.partial = dP.p; dI.up(&it, sizeof(it));
+    launch_mfma_gram32_fused(nullptr, (const GramItem*)dI.p, 1, it.nchunks);
+    ReduceItem ri{dP.p, dO.p, K * K, npart, 0, 0}; dR.up(&ri, sizeof(ri));
+    launch_reduce<float, float>(nullptr, (const ReduceItem*)dR.p, 1, K * K);
+    HIPCHK(hipDeviceSynchronize());
+    dO.down(out, (size_t)K * K * 8);
+}
 }  // namespace tnqs

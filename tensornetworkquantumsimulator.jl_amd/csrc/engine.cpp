@@ -386,21 +386,32 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
 struct GramJob {      // out[i,j] = sum X[i,.] conj(Y[j,.]) over everything but the kept index (s and/or leg)
     const void* X; const void* Y; SD sd; int leg;  /* -1: keep the site index only */ bool keep_site;
     Buf partial; int nchunks = 0; int KK = 0;
+    const void* M = nullptr;       // fused path: message absorbed on the first row leg inside the Gram kernel
 };
+// can the last absorption of a BP message be fused into the Gram?  (c64, d = 2, the first row leg r has chi_r = 32,
+// kept leg <= 32, tiles of 64 fibers = (s, i_r) aligned)
+static int fused_leg(const State* s, const SD& sd, int jo) {
+    if (s->dtype != TNQS_C64 || !use_mfma() || sd.d != 2 || sd.z < 2) return -1;
+    const char* e = std::getenv("TNQS_NO_FUSED_GRAM"); if (e && e[0] == '1') return -1;
+    int r = (jo == 0) ? 1 : 0;
+    if (sd.chi[r] != 32 || sd.chi[jo] > 32 || sd.chi[jo] < 8) return -1;
+    return r;
+}
 template <class T, class Acc> static void run_grams(State* s, std::vector<GramJob>& jobs, int cls) {
     if (jobs.empty()) return;
     const size_t esz = s->esz();
     size_t KKmax = 1;
     for (auto& j : jobs) { j.KK = (j.keep_site ? j.sd.d : 1) * (j.leg >= 0 ? j.sd.chi[j.leg] : 1); KKmax = std::max<size_t>(KKmax, j.KK); }
     int TR = pick_TR(KKmax + 1, esz, 2);
-    const bool mf = std::is_same<T, float>::value && std::is_same<Acc, float>::value && use_mfma() && KKmax <= 32 && KKmax >= 8;
+    const bool fused = jobs[0].M != nullptr;
+    const bool mf = fused || (std::is_same<T, float>::value && std::is_same<Acc, float>::value && use_mfma() && KKmax <= 32 && KKmax >= 8);
     if (mf) TR = 64;
     const int target = 2048;
     int per_item = std::max(1, target / (int)jobs.size());
     std::vector<GramItem> items; int chunks = 0; double bytes = 0, flops = 0;
     for (auto& j : jobs) {
         GramItem it{};
-        it.X = j.X; it.Y = j.Y;
+        it.X = j.X; it.Y = j.Y; it.M = j.M;
         if (j.leg >= 0) {
             size_t pre = j.sd.pre(j.leg);
             if (j.keep_site) { it.D = j.sd.d; it.PA = (int)(pre / j.sd.d); } else { it.D = 1; it.PA = (int)pre; }
@@ -415,11 +426,12 @@ template <class T, class Acc> static void run_grams(State* s, std::vector<GramJo
         j.partial = dalloc(s, (size_t)j.nchunks * j.KK * j.KK * 2 * sizeof(Acc));
         it.partial = j.partial->p; it.chunk_begin = chunks; chunks += it.nchunks;
         items.push_back(it);
-        bytes += (j.X == j.Y ? 1.0 : 2.0) * j.sd.n * esz; flops += 8.0 * j.sd.n * j.KK;
+        bytes += (j.X == j.Y ? 1.0 : 2.0) * j.sd.n * esz; flops += 8.0 * j.sd.n * j.KK * (j.M ? 2.0 : 1.0);
     }
     const GramItem* d = upload(s, items);
     ProfScope ps(s, cls, bytes, flops);
-    if (mf) launch_mfma_gram32(s->stream, d, (int)items.size(), chunks, (int)KKmax);
+    if (fused) launch_mfma_gram32_fused(s->stream, d, (int)items.size(), chunks);
+    else if (mf) launch_mfma_gram32(s->stream, d, (int)items.size(), chunks, (int)KKmax);
     else launch_gram<T, Acc>(s->stream, d, (int)items.size(), chunks, TR, (int)KKmax);
 }
 
@@ -503,28 +515,41 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     if (end > start && used + need > budget) break;
                     used += need; ++end;
                 }
-                std::vector<Chain> chains; std::vector<int> tpos;
+                std::vector<Chain> chains; std::vector<int> tpos; std::vector<const void*> fmsg;
                 for (size_t q = start; q < end; ++q) {
                     int t = lev[q]; int de = plan.seq[t]; int e = de / 2;
                     int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
                     if (!s->owns(src)) continue;
                     Chain c; c.v = src; c.src = s->site[src]->p; c.sd = site_dims(s, src);
+                    const int jo = g.leg(src, dst);
+                    const int fr = fused_leg(s, c.sd, jo);
+                    const void* fm = nullptr;
                     for (int j = 0; j < c.sd.z; ++j) {
                         int k = g.nbr[src][j]; if (k == dst) continue;
                         int din = g.dedge(k, src); int pp = plan.pos_of[din];
                         const Buf& mb = (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
-                        if (mb) c.steps.push_back({j, mb->p});        // unset message = identity: nothing to absorb
+                        if (!mb) continue;                               // unset message = identity: nothing to absorb
+                        if (j == fr) fm = mb->p;                         // absorbed inside the Gram kernel
+                        else c.steps.push_back({j, mb->p});
                     }
-                    chains.push_back(std::move(c)); tpos.push_back(t);
+                    chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(fm);
                 }
                 run_chains<T>(s, chains, TNQS_PROF_BP_MODEPROD);
                 std::vector<GramJob> jobs;
                 for (size_t i = 0; i < chains.size(); ++i) {
                     int de = plan.seq[tpos[i]]; int e = de / 2; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
                     GramJob j{}; j.X = chains[i].result; j.Y = chains[i].src; j.sd = chains[i].sd; j.leg = g.leg(chains[i].v, dst); j.keep_site = false;
+                    j.M = fmsg[i];
                     jobs.push_back(j);
                 }
-                run_grams<T, T>(s, jobs, TNQS_PROF_BP_GRAM);
+                {   // the fused and the plain Gram are different kernels: run them as two batches, keep the job order
+                    std::vector<GramJob> jf, jp; std::vector<size_t> idf, idp;
+                    for (size_t i = 0; i < jobs.size(); ++i) { if (jobs[i].M) { jf.push_back(jobs[i]); idf.push_back(i); } else { jp.push_back(jobs[i]); idp.push_back(i); } }
+                    run_grams<T, T>(s, jf, TNQS_PROF_BP_FUSED);
+                    run_grams<T, T>(s, jp, TNQS_PROF_BP_GRAM);
+                    for (size_t q = 0; q < jf.size(); ++q) jobs[idf[q]] = jf[q];
+                    for (size_t q = 0; q < jp.size(); ++q) jobs[idp[q]] = jp[q];
+                }
                 std::vector<MsgFinalItem> fin;
                 if (s->nranks <= 1) {
                     for (size_t i = 0; i < jobs.size(); ++i) {

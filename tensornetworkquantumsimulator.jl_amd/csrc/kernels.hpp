@@ -26,6 +26,7 @@ struct GramItem {         // partial[c][i + KK*j] = sum_{(a,b) in chunk c} X[i,(
     int D, PA, K, PB;
     int TA, TB, nta, ntb;
     int chunk_begin, nchunks, tiles_per_chunk;
+    const void* M;        // fused variant only: 32 x 32 message absorbed on the first row leg of X before the Gram
 };
 
 struct ReduceItem {       // out[i + n*j] = sum_c partial[c][..] (optionally conjugated)
@@ -95,5 +96,7 @@ int mfma_fiber_tile_rows(int KK, int NN);     // fibers per tile for the shape, 
 bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_tiles, int KKmax, int NNmax,
                             double* d_norm_partials);
 bool launch_mfma_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);  // tiles of 64 fibers; writes 4 partials per chunk
+// fused (X x_r M) then Gram with Y: tiles of 64 fibers = (s:2) x (first row leg: 32); writes 4 partials per chunk
+void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
 
 }  // namespace tnqs

@@ -583,6 +583,120 @@ __global__ __launch_bounds__(256) void mfma_gram32_kernel(const GramItem* __rest
         if (i < KK && j < KK) { cf v; v.re = Cr[r]; v.im = Ci[r]; part[i + (size_t)KK * j] = v; }
     }
 }
+// ------------------------------------------------------------------------------------------------------------
+// fused last mode product + Gram (BP message epilogue):
+//      out[b,b'] = sum_{s,j,rest} ( sum_i X[b,(s,i),rest] M[i,j] ) conj(Y[b',(s,j),rest])
+// A wave tile is 64 fibers = (s: 2) x (i: 32) of the first row leg, so both GEMMs of a plane chain in registers:
+//   step 1  C1[j][b] = sum_i M[i][j] X[b][s+2i]        (A = M^T held in registers, B = X from LDS)
+//   step 2  out[b][b'] += sum_j C1[j][b] conj Y[b'][s+2j]   (A = C1's accumulator registers as they are: the C layout
+//           row (r&3)+8(r>>2)+4h is exactly the k index instruction r consumes; B = Y from LDS at those rows)
+// One LDS slab per wave is used for X, then for Y; the next tensor's global loads fly during each MFMA block.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mfma_gram32_fused_kernel(const GramItem* __restrict__ items, int nitems) {
+    constexpr int PITCH = 65, NU = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
+    float* Lr = reinterpret_cast<float*>(smem) + w * (2 * 32 * PITCH);
+    float* Li = Lr + 32 * PITCH;
+    int lo = 0, hi = nitems - 1;
+    const int gc = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].chunk_begin <= gc) lo = mid; else hi = mid - 1; }
+    const GramItem it = items[lo];
+    const int lc = gc - it.chunk_begin;
+    const int K = it.K, TA = it.TA, TB = it.TB;            // D == 1, TA*TB == 64, K <= 32
+    const long long PA = it.PA;
+    const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
+    const cf* __restrict__ Yg = reinterpret_cast<const cf*>(it.Y);
+    const cf* __restrict__ Mg = reinterpret_cast<const cf*>(it.M);
+    const int ntiles = it.nta * it.ntb;
+    const int t_begin = lc * it.tiles_per_chunk;
+    const int t_end = min(ntiles, t_begin + it.tiles_per_chunk);
+    // A operand of step 1: M^T, lane (j = ln, h), k-step q -> i = q + 16h
+    float mr[16], mi[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { cf v = Mg[(q + 16 * h) + 32 * ln]; mr[q] = v.re; mi[q] = v.im; }
+    for (int e = lane; e < 32 * PITCH; e += 64) { Lr[e] = 0.f; Li[e] = 0.f; }      // rows kk >= K stay zero
+    v16f Or, Oi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { Or[r] = 0.f; Oi[r] = 0.f; }
+    const TileMap m = make_map_wave(lane, 1, TA, TB, PA, K);
+    const long long kstride = PA;
+    v4f pre[NU];
+    auto issue = [&](const cf* __restrict__ G, int t) {
+        int ta = t % it.nta, tb = t / it.nta;
+        int a0 = ta * TA, b0 = tb * TB;
+        const long long org = a0 + PA * (long long)K * b0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = m.kp + m.KP * j;
+            v4f v; v[0] = v[1] = v[2] = v[3] = 0.f;
+            if (k < K) v = *reinterpret_cast<const v4f*>(G + org + m.off + kstride * k);
+            pre[j] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = m.kp + m.KP * j;
+            if (k < K) { int o0 = k * PITCH + m.row0; Lr[o0] = pre[j][0]; Li[o0] = pre[j][1]; Lr[o0 + 1] = pre[j][2]; Li[o0 + 1] = pre[j][3]; }
+        }
+    };
+    const int t_first = t_begin + w;
+    if (t_first < t_end) issue(Xg, t_first);
+    for (int t = t_first; t < t_end; t += 4) {
+        commit();                                           // X tile -> LDS
+        __builtin_amdgcn_wave_barrier();
+        issue(Yg, t);                                       // Y tile in flight during step 1
+        v16f C1r[2], C1i[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float xr[16], xi[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { int o = ln * PITCH + s + 2 * (q + 16 * h); xr[q] = Lr[o]; xi[q] = Li[o]; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { C1r[s][r] = 0.f; C1i[s][r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                C1r[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(mr[q], xr[q], C1r[s], 0, 0, 0);
+                C1r[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(-mi[q], xi[q], C1r[s], 0, 0, 0);
+                C1i[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(mr[q], xi[q], C1i[s], 0, 0, 0);
+                C1i[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(mi[q], xr[q], C1i[s], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        commit();                                           // Y tile -> the same LDS slab (X operands are in registers)
+        __builtin_amdgcn_wave_barrier();
+        if (t + 4 < t_end) issue(Xg, t + 4);                // next X tile in flight during step 2
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float yr[16], yi[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { int j = (r & 3) + 8 * (r >> 2) + 4 * h; int o = ln * PITCH + s + 2 * j; yr[r] = Lr[o]; yi[r] = Li[o]; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                Or = __builtin_amdgcn_mfma_f32_32x32x2f32(C1r[s][r], yr[r], Or, 0, 0, 0);
+                Or = __builtin_amdgcn_mfma_f32_32x32x2f32(C1i[s][r], yi[r], Or, 0, 0, 0);
+                Oi = __builtin_amdgcn_mfma_f32_32x32x2f32(C1i[s][r], yr[r], Oi, 0, 0, 0);
+                Oi = __builtin_amdgcn_mfma_f32_32x32x2f32(-C1r[s][r], yi[r], Oi, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    cf* __restrict__ part = reinterpret_cast<cf*>(it.partial) + (size_t)(4 * lc + w) * K * K;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * h, j = ln;
+        if (i < K && j < K) { cf v; v.re = Or[r]; v.im = Oi[r]; part[i + (size_t)K * j] = v; }
+    }
+}
+void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks) {
+    if (total_chunks <= 0) return;
+    const size_t lds = (size_t)4 * 2 * 32 * 65 * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_gram32_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(mfma_gram32_fused_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems);
+}
+
 bool launch_mfma_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
     if (KKmax > 32) return false;
     if (total_chunks <= 0) return true;

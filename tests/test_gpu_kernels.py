@@ -112,3 +112,28 @@ def test_gram(dtype, acc64, mfma, D, PA, K, PB, same):
     ref = (mx @ my.conj().T).T.reshape(-1)            # out[i + KK*j]
     tol = (1e-13 if odt == np.complex128 and dtype == 1 else (1e-6 if acc64 else 3e-5)) * np.max(np.abs(ref))
     assert np.max(np.abs(out - ref)) < tol * max(1.0, np.sqrt(PA * PB / 64))
+
+
+@pytest.mark.parametrize("PA,K,PB", [(64, 32, 64), (2048, 32, 8), (2, 32, 32 * 33), (64, 17, 40), (2, 9, 64)])
+def test_gram_fused_mode_product(PA, K, PB):
+    """fused (X x_r M) + Gram: r = first row leg; rows of a 64-fiber tile are (s:2, i_r:32)"""
+    rng = np.random.default_rng(PA + K + PB)
+    dt = np.complex64
+    x = rnd(rng, PA * K * PB, dt); y = rnd(rng, PA * K * PB, dt); m = rnd(rng, 32 * 32, dt)
+    out = np.zeros(K * K, dtype=dt)
+    rc = lib.tnqs_dbg_gram_fused(PA, K, PB, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+                                 m.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0, lib.tnqs_last_error()
+    mm = m.reshape(32, 32).T.astype(np.complex128)                      # M[i, j] stored at i + 32 j
+    if PA >= 64:        # element (a, k, b), a = s + 2*i + 64*a'
+        tx = x.reshape(PB, K, PA // 64, 32, 2).astype(np.complex128)    # [b, k, a', i, s]
+        ty = y.reshape(PB, K, PA // 64, 32, 2).astype(np.complex128)
+        tx = np.einsum("bkais,ij->bkajs", tx, mm)
+        ref = np.einsum("bkajs,bqajs->kq", tx, ty.conj())
+    else:               # PA == 2 (a = s), first row leg = fastest part of b
+        tx = x.reshape(PB // 32, 32, K, 2).astype(np.complex128)        # [b', i, k, s]
+        ty = y.reshape(PB // 32, 32, K, 2).astype(np.complex128)
+        tx = np.einsum("biks,ij->bjks", tx, mm)
+        ref = np.einsum("bjks,bjqs->kq", tx, ty.conj())
+    got = out.reshape(K, K).T                                            # out[i + K j]
+    assert np.max(np.abs(got - ref)) < 2e-5 * np.max(np.abs(ref)) * max(1.0, np.sqrt(PA * PB / 64))
