@@ -17,9 +17,21 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
     DBuf dA((size_t)m * n * esz), dV((size_t)n * n * esz), dS(4), dI(sizeof(JacobiItem));
     dA.up(A, (size_t)m * n * esz);
     if (dtype == TNQS_C64) launch_identity<float>(nullptr, dV.p, n); else launch_identity<double>(nullptr, dV.p, n);
-    JacobiItem it{dA.p, dV.p, m, n, (int*)dS.p};
+    // same residency policy as the engine: A+V in LDS, else A in LDS with V recovered, else global memory
+    const size_t lim = 160 * 1024 - 64;
+    size_t lds_av = jacobi_lds_bytes(m, n, true, esz), lds_a = jacobi_lds_bytes(m, n, false, esz);
+    const bool nov = lds_av > lim && lds_a <= lim;
+    DBuf dA0((size_t)m * n * esz);
+    if (nov) dA0.up(A, (size_t)m * n * esz);
+    JacobiItem it{dA.p, nov ? nullptr : dV.p, m, n, (int*)dS.p};
     dI.up(&it, sizeof(it));
-    if (dtype == TNQS_C64) launch_jacobi<float>(nullptr, (const JacobiItem*)dI.p, 1, 60); else launch_jacobi<double>(nullptr, (const JacobiItem*)dI.p, 1, 60);
+    size_t lds = nov ? lds_a : (lds_av <= lim ? lds_av : 0);
+    if (dtype == TNQS_C64) launch_jacobi<float>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds); else launch_jacobi<double>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds);
+    if (nov) {
+        DBuf dRv(sizeof(RecoverItem)); RecoverItem rv{dA0.p, dA.p, dV.p, m, n}; dRv.up(&rv, sizeof(rv));
+        if (dtype == TNQS_C64) launch_recover_v<float>(nullptr, (const RecoverItem*)dRv.p, 1); else launch_recover_v<double>(nullptr, (const RecoverItem*)dRv.p, 1);
+        HIPCHK(hipDeviceSynchronize());
+    }
     HIPCHK(hipDeviceSynchronize());
     dA.down(A, (size_t)m * n * esz); dV.down(V, (size_t)n * n * esz);
     if (sweeps) dS.down(sweeps, 4);

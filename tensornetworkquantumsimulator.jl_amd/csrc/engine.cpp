@@ -12,6 +12,7 @@
 namespace tnqs {
 
 static size_t bp_ws_budget() { static size_t v = 0; if (!v) { const char* e = std::getenv("TNQS_BP_WS_MB"); v = (e ? (size_t)std::atoll(e) : (size_t)24576) << 20; } return v; }
+static size_t jacobi_lds(size_t bytes) { static int g = -1; if (g < 0) { const char* e = std::getenv("TNQS_JACOBI_GLOBAL"); g = (e && e[0] == '1') ? 1 : 0; } return (g || bytes > 160 * 1024 - 64) ? 0 : bytes; }
 static bool use_mfma() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_MFMA"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 
 void hipchk(hipError_t e, const char* what) {
@@ -747,7 +748,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         if (!envs.empty()) {
             const EnvItem* de = upload(s, ei); const JacobiItem* dj = upload(s, ji); const EnvFinishItem* df = upload(s, fi);
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, de, (int)ei.size()); }
-            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60); }
+            size_t lds = 0; for (auto& r : envs) lds = std::max(lds, jacobi_lds_bytes(r.n, r.n, true, 16));
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60, jacobi_lds(lds)); }
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_finish<T>(s->stream, df, (int)fi.size()); }
         }
     }
@@ -809,11 +811,12 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             const EnvItem* di = upload(s, idn);
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)idn.size()); }
             const JacobiItem* dj = upload(s, ji);
-            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60); }
+            size_t lds = 0; for (auto& j : ji) lds = std::max(lds, jacobi_lds_bytes(j.n, j.n, true, 16));
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60, jacobi_lds(lds)); }
         }
     }
     // ---- 4. theta = gate . (R1 R2), SVD, truncation, X1 / X2  (simple_update.jl:51-59) -----------------------------
-    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, X1, X2, S, info, terr; int n1, n2, chi, cap; };
+    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S, info, terr; int n1, n2, chi, cap; };
     std::vector<GateWS> ws(ng);
     std::vector<int> pg;                              // gates this rank takes part in
     for (int gi = 0; gi < ng; ++gi) if (part[gi]) pg.push_back(gi);
@@ -829,6 +832,14 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         int cap = std::min(Mr, Nc); if (ao.maxdim > 0) cap = std::min(cap, ao.maxdim);
         w.cap = cap; cap_max = std::max(cap_max, cap);
         x2_max = std::max(x2_max, (size_t)w.n2 * b.sd.d * cap * esz);
+    }
+    // SVD of theta: when theta fits in LDS but theta and V together do not, V is not accumulated but recovered afterwards
+    bool theta0_used = false;
+    {
+        size_t av = 0, a = 0;
+        for (int gi : pg) { size_t Mr = (size_t)ws[gi].n1 * sj[2 * gi].sd.d, Nc = (size_t)ws[gi].n2 * sj[2 * gi + 1].sd.d; size_t mx = std::max(Mr, Nc), mn = std::min(Mr, Nc);
+                            av = std::max(av, jacobi_lds_bytes((int)mx, (int)mn, true, esz)); a = std::max(a, jacobi_lds_bytes((int)mx, (int)mn, false, esz)); }
+        theta0_used = jacobi_lds(av) == 0 && jacobi_lds(a) != 0;
     }
     {
         std::vector<char> raw;
@@ -848,13 +859,14 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             int Mr = w.n1 * a.sd.d, Nc = w.n2 * b.sd.d, cap = w.cap;
             w.lam1 = dalloc(s, w.n1 * 8); w.lam2 = dalloc(s, w.n2 * 8); w.idx1 = dalloc(s, w.n1 * 4); w.idx2 = dalloc(s, w.n2 * 4);
             w.theta = dalloc(s, (size_t)Mr * Nc * esz); w.thetaV = dalloc(s, (size_t)std::max(Mr, Nc) * std::max(Mr, Nc) * esz);
+            if (theta0_used) w.theta0 = dalloc(s, (size_t)Mr * Nc * esz);
             w.X1 = dalloc(s, (size_t)w.n1 * a.sd.d * cap * esz); w.X2 = dalloc(s, (size_t)w.n2 * b.sd.d * cap * esz);
             w.S = dalloc(s, cap * 8); w.info = dalloc(s, 8 * 4); w.terr = dalloc(s, 8);
             it.GA1 = GA[2 * gi]->p; it.GV1 = GV[2 * gi]->p; it.GA2 = GA[2 * gi + 1]->p; it.GV2 = GV[2 * gi + 1]->p;
             it.n1 = w.n1; it.n2 = w.n2; it.d1 = a.sd.d; it.d2 = b.sd.d; it.chi = w.chi;
             it.gate = reinterpret_cast<const double*>(d_gm + off[q]);
             it.lam1 = (double*)w.lam1->p; it.lam2 = (double*)w.lam2->p; it.idx1 = (int*)w.idx1->p; it.idx2 = (int*)w.idx2->p;
-            it.theta = w.theta->p; it.thetaV = w.thetaV->p; it.X1 = w.X1->p; it.X2 = w.X2->p; it.S = (double*)w.S->p;
+            it.theta = w.theta->p; it.thetaV = w.thetaV->p; it.theta0 = w.theta0 ? w.theta0->p : nullptr; it.X1 = w.X1->p; it.X2 = w.X2->p; it.S = (double*)w.S->p;
             it.info = (int*)w.info->p; it.truncerr = (double*)w.terr->p;
             it.maxdim = ao.maxdim; it.cutoff = ao.cutoff; it.normalize = ao.normalize_tensors; it.chi_cap = cap;
         }
@@ -881,8 +893,19 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             if (Mr < Nc) std::swap(Mr, Nc);        // wide theta is stored as its adjoint (gate_theta_kernel)
             ji.push_back(JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, reinterpret_cast<int*>(ws[gi].info->p) + 4});
         }
+        // LDS residency: A and V if both fit; A only (V recovered from the unrotated copy) if only A fits; else global memory
+        size_t lds_av = 0, lds_a = 0;
+        for (auto& j : ji) { lds_av = std::max(lds_av, jacobi_lds_bytes(j.m, j.n, true, esz)); lds_a = std::max(lds_a, jacobi_lds_bytes(j.m, j.n, false, esz)); }
+        const bool novee = theta0_used;
+        if (novee) for (auto& j : ji) j.V = nullptr;
         const JacobiItem* dj = upload(s, ji);
-        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<T>(s->stream, dj, npg, 60); }
+        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<T>(s->stream, dj, npg, 60, jacobi_lds(novee ? lds_a : lds_av)); }
+        if (novee) {
+            std::vector<RecoverItem> rv;
+            for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ji[q].n});
+            const RecoverItem* dr = upload(s, rv);
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_recover_v<T>(s->stream, dr, npg); }
+        }
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
         Buf d_terr_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 8));
         for (int q = 0; q < npg; ++q) {

