@@ -150,16 +150,35 @@ def main():
     value = n2 * args.steps / elapsed
 
     # ---- roofline of the dominant kernel class ----------------------------------------------------------------
+    # bound: arithmetic intensity of the class (algorithmic flops / algorithmic bytes) against the ridge
+    # 157.3 TFLOP/s / 8 TB/s = 19.7 flop/B (MI355X_MICROARCH.md).  `achieved` = algorithmic bytes (or flops) of the
+    # class / HIP-event time of its launches on the library's stream; `traffic` = HBM bytes per launch from the PMC
+    # pass of the same command committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, see the file's header).
+    KERNEL_OF = {"bp_modeprod": "tnqs::mfma_fiber_gemm_w_kernel<1, 1, 8>", "gate_modeprod": "tnqs::mfma_fiber_gemm_w_kernel<1, 1, 8>",
+                 "bp_fused": "tnqs::mfma_gram32_fused_kernel", "bp_gram": "tnqs::mfma_gram32_kernel",
+                 "gate_gram": "tnqs::gram_kernel<float, double, 4>", "gate_apply": "tnqs::mfma_fiber_gemm_w_kernel<2, 2, 16>"}
+    traffic_db = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            traffic_db = json.load(f)["kernels"]
+    except Exception:
+        pass
     dom = max(prof, key=lambda k: prof[k]["ms"])
     p = prof[dom]
     roofline = None
-    if p["ms"] > 0:
-        tflops = p["flops"] / (p["ms"] * 1e-3) / 1e12
-        gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tflops / PEAK_F32_TFLOPS, 4), "traffic": None,
-                    "avg_launch_ms": round(p["ms"] / max(1, p["launches"]), 4), "launches": p["launches"],
-                    "alg_GBps": round(gbs, 1), "hbm_frac_of_8TBps": round(gbs / PEAK_HBM_GBS, 4)}
+    if p["ms"] > 0 and p["bytes"] > 0:
+        sec = p["ms"] * 1e-3
+        tflops, gbs = p["flops"] / sec / 1e12, p["bytes"] / sec / 1e9
+        ai = p["flops"] / p["bytes"]
+        kern = KERNEL_OF.get(dom)
+        traffic = traffic_db.get(kern, {}).get("hbm_bytes_per_launch") if (world == 1 and L == 20 and chi == 32) else None
+        common = {"kernel_class": dom, "kernel": kern, "avg_launch_ms": round(p["ms"] / max(1, p["launches"]), 4), "launches": p["launches"],
+                  "arithmetic_intensity_flop_per_B": round(ai, 2), "alg_bytes_per_launch": round(p["bytes"] / max(1, p["launches"])),
+                  "alg_TFLOPs": round(tflops, 2), "alg_GBps": round(gbs, 1), "traffic": traffic}
+        if ai < PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+            roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), **common}
+        else:
+            roofline = {"bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_F32_TFLOPS, 4), **common}
     classes = {k: {"ms": round(v["ms"], 2), "launches": v["launches"],
                    "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None}
                for k, v in prof.items() if v["launches"]}
