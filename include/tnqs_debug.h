@@ -15,6 +15,8 @@ int tnqs_dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No,
 int tnqs_dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma);
 /* c64 only: out[i + K*j] = sum ( X x_r M )[i,.] conj(Y[j,.]) with D = 1 and r = the first row leg (chi_r = 32, d = 2) */
 int tnqs_dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out);
+/* c64 only: out[c,jx,mid,jy,hi] = sum in[c,ix,mid,iy,hi] Mx[ix,jx] My[iy,jy]; element at c + C0*(ix + 32*(mid + NMID*(iy + 32*hi))) */
+int tnqs_dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const void* My, void* out);
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,20 @@ void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void
     HIPCHK(hipDeviceSynchronize());
     dO.down(out, (size_t)KK * KK * asz);
 }
+void dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const void* My, void* out) {
+    need_gpu();
+    if (C0 % 16) throw Err(TNQS_ERR_INVALID, "dbg_pair: C0 % 16 != 0");
+    size_t n = (size_t)C0 * 32 * NMID * 32 * NHI;
+    DBuf dIn(n * 8), dOut(n * 8), dX(32 * 32 * 8), dY(32 * 32 * 8), dI(sizeof(PairItem));
+    dIn.up(in, n * 8); dX.up(Mx, 32 * 32 * 8); dY.up(My, 32 * 32 * 8);
+    HIPCHK(hipMemset(dOut.p, 0xff, n * 8));
+    PairItem it{}; it.in = dIn.p; it.out = dOut.p; it.Mx = dX.p; it.My = dY.p; it.C0 = C0; it.NMID = NMID; it.NHI = NHI; it.slice_begin = 0; it.spw = 3;
+    int nslices = (C0 / 16) * NMID * NHI;
+    dI.up(&it, sizeof(it));
+    launch_mfma_pair(nullptr, (const PairItem*)dI.p, 1, (nslices + it.spw - 1) / it.spw);
+    HIPCHK(hipDeviceSynchronize());
+    dOut.down(out, n * 8);
+}
 void dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out) {
     need_gpu();
     size_t nin = (size_t)PA * K * PB;

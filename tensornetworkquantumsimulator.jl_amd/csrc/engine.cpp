@@ -350,10 +350,60 @@ struct Chain {
     const void* result = nullptr; Buf tmp[2];
 };
 
+static bool use_pair() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_PAIR"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
+
 template <class T> static void run_chains(State* s, std::vector<Chain>& chains, int cls) {
-    size_t maxsteps = 0;
-    for (auto& c : chains) { maxsteps = std::max(maxsteps, c.steps.size()); c.result = c.src; }
     const size_t esz = s->esz();
+    std::vector<int> nt(chains.size(), 0);          // temporaries written so far (ping-pong index)
+    std::vector<size_t> done(chains.size(), 0);     // steps consumed from the FRONT of c.steps after the pair stage
+    for (auto& c : chains) c.result = c.src;
+    // ---- stage 0: two slow 32-dimensional legs in one pass (mfma_pair_kernel) --------------------------------------
+    if (std::is_same<T, float>::value && use_mfma() && use_pair()) {
+        std::vector<PairItem> items; int wgs = 0; double bytes = 0, flops = 0;
+        double tot_slices = 0;
+        std::vector<std::pair<size_t, std::pair<int, int>>> sel;     // chain index, (position of x, position of y) in c.steps
+        for (size_t ci = 0; ci < chains.size(); ++ci) {
+            Chain& c = chains[ci];
+            if (c.steps.size() < 2) continue;
+            // the two highest eligible legs (steps are in ascending leg order)
+            int py = -1, px = -1;
+            for (int q = (int)c.steps.size() - 1; q >= 0 && px < 0; --q) {
+                int leg = c.steps[q].first;
+                bool ok = c.sd.chi[leg] == 32 && leg >= 1 && (c.sd.pre(leg) % 16 == 0);
+                if (!ok) continue;
+                if (py < 0) py = q; else px = q;
+            }
+            if (px < 0) continue;
+            sel.push_back({ci, {px, py}});
+            tot_slices += (double)c.sd.n / (16.0 * 1024.0);
+        }
+        if (!sel.empty()) {
+            int spw = (int)std::max(1.0, std::min(8.0, tot_slices / 2048.0));
+            for (auto& se : sel) {
+                Chain& c = chains[se.first];
+                int x = c.steps[se.second.first].first, y = c.steps[se.second.second].first;
+                PairItem it{};
+                Buf& dst = c.tmp[nt[se.first] & 1];
+                if (!dst) dst = dalloc(s, c.sd.n * esz);
+                it.in = c.result; it.out = dst->p; it.Mx = c.steps[se.second.first].second; it.My = c.steps[se.second.second].second;
+                it.C0 = (int)c.sd.pre(x);
+                size_t mid = 1; for (int i = x + 1; i < y; ++i) mid *= c.sd.chi[i];
+                it.NMID = (int)mid; it.NHI = (int)c.sd.post(y);
+                int nslices = (it.C0 / 16) * it.NMID * it.NHI;
+                it.spw = spw; it.slice_begin = wgs; wgs += (nslices + spw - 1) / spw;
+                items.push_back(it);
+                c.result = dst->p; nt[se.first]++;
+                // drop the two consumed steps
+                c.steps.erase(c.steps.begin() + se.second.second); c.steps.erase(c.steps.begin() + se.second.first);
+                bytes += 2.0 * c.sd.n * esz; flops += 2 * 8.0 * c.sd.n * 32;
+            }
+            const PairItem* d = upload(s, items);
+            ProfScope ps(s, cls, bytes, flops);
+            launch_mfma_pair(s->stream, d, (int)items.size(), wgs);
+        }
+    }
+    size_t maxsteps = 0;
+    for (auto& c : chains) maxsteps = std::max(maxsteps, c.steps.size());
     for (size_t o = 0; o < maxsteps; ++o) {
         std::vector<FiberItem> items; int tiles = 0; size_t KKmax = 1; double bytes = 0, flops = 0;
         for (auto& c : chains) if (c.steps.size() > o) KKmax = std::max<size_t>(KKmax, c.sd.chi[c.steps[o].first]);
@@ -362,11 +412,12 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
         if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)KKmax); if (t > 0) { TR = t; mf = true; } }
         int tpw = 1;
         if (mf) { double tot = 0; for (auto& c : chains) if (c.steps.size() > o) tot += (double)c.sd.n / c.sd.chi[c.steps[o].first] / TR; tpw = (int)std::max(1.0, std::min(TR == 32 ? 32.0 : 8.0, tot / 4096.0)); if (TR == 32 && tpw >= 4) tpw &= ~3; }
-        for (auto& c : chains) {
+        for (size_t ci = 0; ci < chains.size(); ++ci) {
+            Chain& c = chains[ci];
             if (c.steps.size() <= o) continue;
             int j = c.steps[o].first;
             FiberItem it{};
-            Buf& dst = c.tmp[o & 1];
+            Buf& dst = c.tmp[nt[ci] & 1];
             if (!dst) dst = dalloc(s, c.sd.n * esz);
             it.in = c.result; it.out = dst->p; it.X = c.steps[o].second;
             it.D = 1; it.PA = (int)c.sd.pre(j); it.K = c.sd.chi[j]; it.PB = (int)c.sd.post(j); it.Do = 1; it.No = it.K;
@@ -374,7 +425,7 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
             it.tpw = mf ? tpw : 1;
             it.tile_begin = tiles; tiles += (it.nta * it.ntb + it.tpw - 1) / it.tpw; it.want_norm = 0;
             items.push_back(it);
-            c.result = dst->p;
+            c.result = dst->p; nt[ci]++;
             bytes += 2.0 * c.sd.n * esz; flops += 8.0 * c.sd.n * it.K;
         }
         const FiberItem* d = upload(s, items);
@@ -382,6 +433,7 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
         if (mf) launch_mfma_fiber_gemm(s->stream, d, (int)items.size(), tiles, (int)KKmax, (int)KKmax, nullptr);
         else launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, nullptr);
     }
+    (void)done;
 }
 
 struct GramJob {      // out[i,j] = sum X[i,.] conj(Y[j,.]) over everything but the kept index (s and/or leg)

@@ -96,6 +96,13 @@ template <class T> void launch_permute(hipStream_t s, const PermItem& item);
 template <class T> void launch_identity(hipStream_t s, void* out, int n);
 void launch_sum_doubles(hipStream_t s, const double* in, int n, double* out);
 
+struct PairItem {         // out = in x_x Mx x_y My for two 32-dimensional legs x < y that are NOT memory-fastest:
+    const void* in; void* out; const void* Mx; const void* My;    // element (c, ix, mid, iy, hi) at c + C0*(ix + 32*(mid + NMID*(iy + 32*hi)))
+    int C0, NMID, NHI;    // companions (C0 % 16 == 0), indices between / above the two legs
+    int slice_begin;      // first workgroup id of this item
+    int spw;              // slices (16 companions x 32 x 32) walked by one workgroup
+};
+
 // ---- MFMA fast paths (ComplexF32 only; kernels_mfma.hip) -----------------------------------------------------------
 int mfma_fiber_tile_rows(int KK, int NN);     // fibers per tile for the shape, 0 = not covered
 bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_tiles, int KKmax, int NNmax,
@@ -103,5 +110,7 @@ bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems,
 bool launch_mfma_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);  // tiles of 64 fibers; writes 4 partials per chunk
 // fused (X x_r M) then Gram with Y: tiles of 64 fibers = (s:2) x (first row leg: 32); writes 4 partials per chunk
 void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
+// fused pair of mode products on two slow 32-dim legs (16 companions = 128-byte runs per workgroup)
+void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs);
 
 }  // namespace tnqs

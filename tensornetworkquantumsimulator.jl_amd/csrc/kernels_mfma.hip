@@ -697,6 +697,123 @@ void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems
     hipLaunchKernelGGL(mfma_gram32_fused_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// pair of mode products on two "slow" legs x < y (dimension 32 each) in ONE pass:
+//      out[c, jx, jy] = sum_{ix,iy} in[c, ix, iy] Mx[ix, jx] My[iy, jy]          for every companion index c
+// The memory-contiguous direction is c (all faster indices), so a workgroup takes 16 companions (128-byte runs = full
+// HBM efficiency) x the whole 32 x 32 plane of the two legs: 16 planes of 8 KiB staged in LDS (de-interleaved, one
+// plane per (wave, half)), both GEMMs of a plane chained in registers exactly like the fused Gram:
+//   step 1  Y[iy][jx] = sum_ix S[ix][iy] Mx[ix][jx]      (A = S^T from LDS, B = Mx in registers)
+//   step 2  S'[jx][jy] = sum_iy Y[iy][jx] My[iy][jy]      (A = Y's accumulator registers as they are, B = My in registers)
+// The next slice's 128 KiB are prefetched into registers while the matrix cores work.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restrict__ items, int nitems) {
+    constexpr int PR = 32 * 33;                // floats of one re (or im) plane, pitch 33
+    constexpr int PS = 2 * PR + 1;             // plane stride (odd: the 8 companion pairs of a run hit different banks)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* L = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
+    int lo = 0, hi_ = nitems - 1;
+    const int gw = blockIdx.x;
+    while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].slice_begin <= gw) lo = mid; else hi_ = mid - 1; }
+    const PairItem it = items[lo];
+    const long long C0 = it.C0;
+    const int NCB = it.C0 / 16, NMID = it.NMID;
+    const int nslices = NCB * NMID * it.NHI;
+    const int s_begin = (gw - it.slice_begin) * it.spw, s_end = min(nslices, s_begin + it.spw);
+    const cf* __restrict__ in = reinterpret_cast<const cf*>(it.in);
+    cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
+    const cf* __restrict__ Mx = reinterpret_cast<const cf*>(it.Mx);
+    const cf* __restrict__ My = reinterpret_cast<const cf*>(it.My);
+    // B operands: Mx[k = q+16h][j = ln] (step 1), My[k = kappa(r,h)][j = ln] (step 2); element (i,j) at i + 32 j
+    float mxr[16], mxi[16], myr[16], myi[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        cf a = Mx[(q + 16 * h) + 32 * ln]; mxr[q] = a.re; mxi[q] = a.im;
+        int kap = (q & 3) + 8 * (q >> 2) + 4 * h;
+        cf b = My[kap + 32 * ln]; myr[q] = b.re; myi[q] = b.im;
+    }
+    // cooperative mover: thread -> (f = companion pair 0..7, seg0 = first segment); a pass of 512 threads covers 64 segments
+    const int f = tid & 7, sg0 = tid >> 3;            // segments sg0, sg0 + 64, ... (16 per thread), seg = ix + 32*iy
+    auto slice_base = [&](int sl) -> long long {
+        int cb = sl % NCB; int r1 = sl / NCB; int mid = r1 % NMID; int hi = r1 / NMID;
+        return 16LL * cb + C0 * 32LL * ((long long)mid + (long long)NMID * 32LL * hi);
+    };
+    // element (c, ix, iy) of a slice: base + c + C0*ix + (C0*32*NMID)*iy
+    const long long sx = C0, sy = C0 * 32LL * NMID;
+    v4f pre[16];
+    auto issue = [&](int sl) {
+        const long long b = slice_base(sl) + 2 * f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5; pre[j] = *reinterpret_cast<const v4f*>(in + b + sx * ix + sy * iy); }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5;
+            float* p0 = L + (2 * f) * PS + iy * 33 + ix;         // plane 2f:   S[ix][iy] stored at [iy][ix]
+            p0[0] = pre[j][0]; p0[PR] = pre[j][1];
+            p0[PS] = pre[j][2]; p0[PS + PR] = pre[j][3];         // plane 2f+1
+        }
+    };
+    if (s_begin < s_end) issue(s_begin);
+    for (int sl = s_begin; sl < s_end; ++sl) {
+        lds_barrier();                                          // previous slice's results have left the LDS
+        commit();
+        lds_barrier();
+        if (sl + 1 < s_end) issue(sl + 1);
+#pragma unroll 1
+        for (int pp = 0; pp < 2; ++pp) {
+            float* Pr = L + (w + 8 * pp) * PS; float* Pi = Pr + PR;
+            float ar[16], ai[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { int o = ln * 33 + q + 16 * h; ar[q] = Pr[o]; ai[q] = Pi[o]; }     // A[i=iy=ln][k=ix]
+            v16f Yr, Yi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { Yr[r] = 0.f; Yi[r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                Yr = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], mxr[q], Yr, 0, 0, 0);
+                Yr = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai[q], mxi[q], Yr, 0, 0, 0);
+                Yi = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], mxi[q], Yi, 0, 0, 0);
+                Yi = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[q], mxr[q], Yi, 0, 0, 0);
+            }
+            v16f Sr, Si;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { Sr[r] = 0.f; Si[r] = 0.f; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                Sr = __builtin_amdgcn_mfma_f32_32x32x2f32(Yr[r], myr[r], Sr, 0, 0, 0);
+                Sr = __builtin_amdgcn_mfma_f32_32x32x2f32(-Yi[r], myi[r], Sr, 0, 0, 0);
+                Si = __builtin_amdgcn_mfma_f32_32x32x2f32(Yr[r], myi[r], Si, 0, 0, 0);
+                Si = __builtin_amdgcn_mfma_f32_32x32x2f32(Yi[r], myr[r], Si, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // S'[jx = kappa(r,h)][jy = ln] -> LDS [jy][jx] (the plane is private to this wave)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { int jx = (r & 3) + 8 * (r >> 2) + 4 * h; Pr[ln * 33 + jx] = Sr[r]; Pi[ln * 33 + jx] = Si[r]; }
+        }
+        lds_barrier();
+        {
+            const long long b = slice_base(sl) + 2 * f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5;
+                const float* p0 = L + (2 * f) * PS + iy * 33 + ix;
+                v4f v; v[0] = p0[0]; v[1] = p0[PR]; v[2] = p0[PS]; v[3] = p0[PS + PR];
+                *reinterpret_cast<v4f*>(out + b + sx * ix + sy * iy) = v;
+            }
+        }
+    }
+}
+void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs) {
+    if (total_wgs <= 0) return;
+    const size_t lds = (size_t)16 * (2 * 32 * 33 + 1) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(mfma_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
+}
+
 bool launch_mfma_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
     if (KKmax > 32) return false;
     if (total_chunks <= 0) return true;

@@ -38,7 +38,7 @@ def test_jacobi_svd(dtype, shape):
     s = np.sort(np.linalg.norm(A, axis=0))[::-1]
     assert sw < 60      # rows >= columns is required (wide matrices are handled through their adjoint)
     assert np.max(np.abs(s[:len(s_ref)] - s_ref)) < eps * s_ref[0], (s[:5], s_ref[:5])
-    assert np.max(np.abs(V.conj().T @ V - np.eye(shape[1]))) < eps                      # V unitary
+    assert np.max(np.abs(V.conj().T @ V - np.eye(shape[1]))) < 4 * eps                  # V unitary (recovered V: eps*cond)
     assert np.max(np.abs(A @ V.conj().T - a)) < 4 * eps * s_ref[0]                      # A_in = (U S) V^dagger (V may be recovered: eps*cond)
     G = A.conj().T @ A
     off = G - np.diag(np.diag(G))
@@ -137,3 +137,20 @@ def test_gram_fused_mode_product(PA, K, PB):
         ref = np.einsum("bjks,bjqs->kq", tx, ty.conj())
     got = out.reshape(K, K).T                                            # out[i + K j]
     assert np.max(np.abs(got - ref)) < 2e-5 * np.max(np.abs(ref)) * max(1.0, np.sqrt(PA * PB / 64))
+
+
+@pytest.mark.parametrize("C0,NMID,NHI", [(64, 1, 4), (16, 1, 1), (64, 32, 1), (2048, 1, 1), (32, 3, 2)])
+def test_pair_mode_products(C0, NMID, NHI):
+    """two slow 32-dimensional legs absorbed in one pass (16 companions per workgroup)"""
+    rng = np.random.default_rng(C0 + NMID + NHI)
+    dt = np.complex64
+    n = C0 * 32 * NMID * 32 * NHI
+    x = rnd(rng, n, dt); mx = rnd(rng, 1024, dt); my = rnd(rng, 1024, dt)
+    out = np.zeros(n, dtype=dt)
+    rc = lib.tnqs_dbg_pair(C0, NMID, NHI, x.ctypes.data_as(C.c_void_p), mx.ctypes.data_as(C.c_void_p), my.ctypes.data_as(C.c_void_p),
+                           out.ctypes.data_as(C.c_void_p))
+    assert rc == 0, lib.tnqs_last_error()
+    t = x.reshape(NHI, 32, NMID, 32, C0).astype(np.complex128)             # [hi, iy, mid, ix, c]
+    Mx = mx.reshape(32, 32).T.astype(np.complex128); My = my.reshape(32, 32).T.astype(np.complex128)     # M[i, j] at i + 32 j
+    ref = np.einsum("hymxc,xa,yb->hbmac", t, Mx, My).reshape(-1)
+    assert np.max(np.abs(out - ref)) < 3e-5 * np.max(np.abs(ref))
