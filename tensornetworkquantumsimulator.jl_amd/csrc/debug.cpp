@@ -80,7 +80,8 @@ void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void
     GramItem it{}; it.X = dX.p; it.Y = same ? dX.p : dY.p; it.D = D; it.PA = PA; it.K = K; it.PB = PB;
     int TR = pick_TR((size_t)KK + 1, esz, 2);
     bool mf = use_mfma && dtype == TNQS_C64 && !acc64 && KK <= 32;
-    if (mf) TR = 64;
+    bool mf64 = use_mfma && dtype == TNQS_C64 && acc64 && same && KK <= 64 && KK >= 16;
+    if (mf || mf64) TR = 64;
     tile_params(PA, PB, TR, it.TA, it.TB, it.nta, it.ntb);
     int ntiles = it.nta * it.ntb; int nch = std::min(7, ntiles);
     it.tiles_per_chunk = (ntiles + nch - 1) / nch; it.nchunks = (ntiles + it.tiles_per_chunk - 1) / it.tiles_per_chunk; it.chunk_begin = 0;
@@ -89,7 +90,8 @@ void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void
     int npart = mf ? 4 * it.nchunks : it.nchunks;
     DBuf dP((size_t)npart * KK * KK * asz), dO((size_t)KK * KK * asz);
     it.partial = dP.p; dI.up(&it, sizeof(it));
-    if (mf) launch_mfma_gram32(nullptr, (const GramItem*)dI.p, 1, it.nchunks, KK);
+    if (mf64) launch_mfma_gram64_f64(nullptr, (const GramItem*)dI.p, 1, it.nchunks, KK);
+    else if (mf) launch_mfma_gram32(nullptr, (const GramItem*)dI.p, 1, it.nchunks, KK);
     else if (dtype == TNQS_C64) { if (a64) launch_gram<float, double>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); else launch_gram<float, float>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); }
     else launch_gram<double, double>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK);
     ReduceItem ri{dP.p, dO.p, KK * KK, npart, 0, 0}; dR.up(&ri, sizeof(ri));

@@ -458,7 +458,9 @@ template <class T, class Acc> static void run_grams(State* s, std::vector<GramJo
     int TR = pick_TR(KKmax + 1, esz, 2);
     const bool fused = jobs[0].M != nullptr;
     const bool mf = fused || (std::is_same<T, float>::value && std::is_same<Acc, float>::value && use_mfma() && KKmax <= 32 && KKmax >= 8);
-    if (mf) TR = 64;
+    bool mf64 = std::is_same<T, float>::value && std::is_same<Acc, double>::value && use_mfma() && KKmax <= 64 && KKmax >= 16;
+    for (auto& j : jobs) mf64 = mf64 && (j.X == j.Y);
+    if (mf || mf64) TR = 64;
     const int target = 2048;
     int per_item = std::max(1, target / (int)jobs.size());
     std::vector<GramItem> items; int chunks = 0; double bytes = 0, flops = 0;
@@ -484,6 +486,7 @@ template <class T, class Acc> static void run_grams(State* s, std::vector<GramJo
     const GramItem* d = upload(s, items);
     ProfScope ps(s, cls, bytes, flops);
     if (fused) launch_mfma_gram32_fused(s->stream, d, (int)items.size(), chunks);
+    else if (mf64) launch_mfma_gram64_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax);
     else if (mf) launch_mfma_gram32(s->stream, d, (int)items.size(), chunks, (int)KKmax);
     else launch_gram<T, Acc>(s->stream, d, (int)items.size(), chunks, TR, (int)KKmax);
 }
@@ -707,6 +710,33 @@ template <class T> static void norm_and_replace(State* s, std::vector<int>& vert
 template <class T> static void apply_one_site_batch(State* s, const std::vector<Gate1>& gates, bool normalize) {
     if (gates.empty()) return;
     const size_t esz = s->esz();
+    if (std::is_same<T, float>::value) {
+        bool all2 = true; for (auto& g1 : gates) all2 = all2 && s->d[g1.v] == 2;
+        if (all2) {         // streaming 2x2 kernel (HBM-bound: read + write each site tensor once)
+            const int NBX = 64;
+            std::vector<Site1Item> items; std::vector<int> verts, tb, nt; std::vector<Buf> outs; std::vector<size_t> ne; double bytes = 0, flops = 0;
+            for (auto& g1 : gates) {
+                if (!s->owns(g1.v)) continue;
+                SD sd = site_dims(s, g1.v);
+                Site1Item it{}; Buf out = dalloc(s, sd.n * esz);
+                it.in = s->site[g1.v]->p; it.out = out->p; it.npairs = sd.n / 2;
+                // column-major G[s' + 2 s]: g00 = mat[0], g10 = mat[1], g01 = mat[2], g11 = mat[3]
+                const double* m = g1.mat;
+                it.g[0] = (float)m[0]; it.g[1] = (float)m[1]; it.g[2] = (float)m[4]; it.g[3] = (float)m[5];
+                it.g[4] = (float)m[2]; it.g[5] = (float)m[3]; it.g[6] = (float)m[6]; it.g[7] = (float)m[7];
+                verts.push_back(g1.v); outs.push_back(out); ne.push_back(sd.n); tb.push_back((int)items.size() * NBX); nt.push_back(NBX);
+                items.push_back(it);
+                bytes += 2.0 * sd.n * esz; flops += 8.0 * sd.n * 2;
+            }
+            if (items.empty()) return;
+            Buf np = dalloc(s, items.size() * NBX * sizeof(double));
+            const Site1Item* d = upload(s, items);
+            { ProfScope ps(s, TNQS_PROF_GATE_APPLY, bytes, flops);
+              launch_site1_c64(s->stream, d, (int)items.size(), NBX, normalize ? reinterpret_cast<double*>(np->p) : nullptr); }
+            norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, normalize);
+            return;
+        }
+    }
     std::vector<FiberItem> items; std::vector<int> verts, tb, nt; std::vector<Buf> outs; std::vector<size_t> ne;
     int tiles = 0; size_t KKmax = 1; double bytes = 0, flops = 0;
     for (auto& g1 : gates) KKmax = std::max<size_t>(KKmax, s->d[g1.v]);

@@ -848,6 +848,34 @@ template <class T> void launch_identity(hipStream_t s, void* out, int n) {
 template void launch_identity<float>(hipStream_t, void*, int);
 template void launch_identity<double>(hipStream_t, void*, int);
 
+// one-site gate, d = 2, ComplexF32: out[s'] = sum_s G[s',s] in[s] on 16-byte (s=0,1) pairs; K11 of SURVEY.md 2
+__global__ __launch_bounds__(256) void site1_c64_kernel(const Site1Item* __restrict__ items, double* __restrict__ norm_partials) {
+    __shared__ double sh[17];
+    const Site1Item it = items[blockIdx.y];
+    const float4* __restrict__ in = reinterpret_cast<const float4*>(it.in);
+    float4* __restrict__ out = reinterpret_cast<float4*>(it.out);
+    const float g00r = it.g[0], g00i = it.g[1], g01r = it.g[2], g01i = it.g[3], g10r = it.g[4], g10i = it.g[5], g11r = it.g[6], g11i = it.g[7];
+    double nrm = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < it.npairs; i += (size_t)gridDim.x * 256) {
+        float4 a = in[i];                       // (a0.re, a0.im, a1.re, a1.im)
+        float4 o;
+        o.x = g00r * a.x - g00i * a.y + g01r * a.z - g01i * a.w;
+        o.y = g00r * a.y + g00i * a.x + g01r * a.w + g01i * a.z;
+        o.z = g10r * a.x - g10i * a.y + g11r * a.z - g11i * a.w;
+        o.w = g10r * a.y + g10i * a.x + g11r * a.w + g11i * a.z;
+        out[i] = o;
+        nrm += (double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z + (double)o.w * o.w;
+    }
+    if (norm_partials) {
+        double t = block_sum(nrm, sh);
+        if (threadIdx.x == 0) norm_partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+void launch_site1_c64(hipStream_t s, const Site1Item* d_items, int nitems, int nbx, double* d_norm_partials) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(site1_c64_kernel, dim3(nbx, nitems), dim3(256), 0, s, d_items, d_norm_partials);
+}
+
 __global__ void sum_doubles_kernel(const double* in, int n, double* out) {
     __shared__ double sh[17];
     double t = 0;

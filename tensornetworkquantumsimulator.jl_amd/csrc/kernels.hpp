@@ -70,6 +70,7 @@ struct GateItem {         // everything the per-gate small-algebra kernels need 
     int maxdim; double cutoff; int normalize; int chi_cap;
 };
 
+struct Site1Item { const void* in; void* out; float g[8]; size_t npairs; };   // d = 2 one-site gate: g = (g00, g01, g10, g11) re/im
 struct DiagItem { void* out; const double* S; int chi; };          // dense diag(S) message
 struct ScaleItem { void* t; size_t n; const double* norm_partials; int npart; }; // t *= 1/sqrt(sum partials)
 struct PermItem { const void* in; void* out; int ndim; int dims_out[8]; long long stride_in[8]; size_t n; };
@@ -95,6 +96,8 @@ template <class T> void launch_scale(hipStream_t s, const ScaleItem* d_items, in
 template <class T> void launch_permute(hipStream_t s, const PermItem& item);
 template <class T> void launch_identity(hipStream_t s, void* out, int n);
 void launch_sum_doubles(hipStream_t s, const double* in, int n, double* out);
+// one-site gates on d = 2, ComplexF32: streaming 2x2 apply, norm partials [item][nbx]
+void launch_site1_c64(hipStream_t s, const Site1Item* d_items, int nitems, int nbx, double* d_norm_partials);
 
 struct PairItem {         // out = in x_x Mx x_y My for two 32-dimensional legs x < y that are NOT memory-fastest:
     const void* in; void* out; const void* Mx; const void* My;    // element (c, ix, mid, iy, hi) at c + C0*(ix + 32*(mid + NMID*(iy + 32*hi)))
@@ -110,6 +113,8 @@ bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems,
 bool launch_mfma_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);  // tiles of 64 fibers; writes 4 partials per chunk
 // fused (X x_r M) then Gram with Y: tiles of 64 fibers = (s:2) x (first row leg: 32); writes 4 partials per chunk
 void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
+// Gram with f64 accumulation on the f64 matrix cores (gate path: G = psi~^dagger psi~, D*K == 64, X == Y); tiles of 64 fibers
+bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);
 // fused pair of mode products on two slow 32-dim legs (16 companions = 128-byte runs per workgroup)
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs);
 

@@ -814,6 +814,138 @@ void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int to
     hipLaunchKernelGGL(mfma_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Gram with f64 accumulation on v_mfma_f64_16x16x4_f64 (gate path: G = X X^dagger over the fibers, KK = D*K <= 64,
+// ComplexF32 input converted on the fly; the f32 products are exact in f64, so G is the exact Gram of the rounded
+// tensor -- what the eigen factorisation replacing the thin QR needs).  f64 MFMA layout: A[i=l&15][k=l>>4],
+// B[k=l>>4][j=l&15], C[row=(l>>4)+4r][col=l&15].  Wave w owns block row w (16 rows of G) x 4 block columns.
+// ------------------------------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_gram64_f64_kernel(const GramItem* __restrict__ items, int nitems) {
+    constexpr int TR = 64, TRP = TR + 4, NU = 8;
+    __shared__ __attribute__((aligned(16))) float Xr[64 * TRP];
+    __shared__ __attribute__((aligned(16))) float Xi[64 * TRP];
+    const int tid = threadIdx.x;
+    int lo = 0, hi = nitems - 1;
+    const int gc = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].chunk_begin <= gc) lo = mid; else hi = mid - 1; }
+    const GramItem it = items[lo];
+    const int lc = gc - it.chunk_begin;
+    const int D = it.D, K = it.K, TA = it.TA, TB = it.TB, KK = D * K;
+    const long long PA = it.PA;
+    const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
+    const int ntiles = it.nta * it.ntb;
+    const int t_begin = lc * it.tiles_per_chunk;
+    const int t_end = min(ntiles, t_begin + it.tiles_per_chunk);
+    const int lane = tid & 63, w = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    v4d Cr[4], Ci[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Cr[j][r] = 0.0; Ci[j][r] = 0.0; }
+    for (int e = tid; e < 64 * TRP; e += 256) { Xr[e] = 0.f; Xi[e] = 0.f; }
+    const TileMap m = make_map(tid, D, TA, TB, PA, K);
+    const long long kstride = (long long)D * PA;
+    const bool fast = m.U <= 256 && (K + m.KP - 1) / m.KP <= NU;
+    v4f px[NU];
+    auto tile_origin = [&](int t, int& a0, int& b0, int& na, int& nb) {
+        int ta = t % it.nta, tb = t / it.nta;
+        a0 = ta * TA; b0 = tb * TB; na = min(TA, it.PA - a0); nb = min(TB, it.PB - b0);
+    };
+    auto issue_loads = [&](int t) {
+        int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
+        const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        const bool v0 = m.active && m.al < na && m.bl < nb, v1 = v0 && m.al1 < na;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = m.kp + m.KP * j;
+            v4f vx; vx[0] = vx[1] = vx[2] = vx[3] = 0.f;
+            if (k < K && v0) {
+                const long long o = org + m.off + kstride * k;
+                if (m.vec == 2 && v1) vx = *reinterpret_cast<const v4f*>(Xg + o);
+                else { cf x = Xg[o]; vx[0] = x.re; vx[1] = x.im; }
+            }
+            px[j] = vx;
+        }
+    };
+    auto commit_loads = [&]() {
+        if (!m.active) return;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = m.kp + m.KP * j;
+            if (k < K) {
+                int o0 = (m.c0 + D * k) * TRP + m.row0;
+                Xr[o0] = px[j][0]; Xi[o0] = px[j][1];
+                if (m.vec == 2) { int o1 = (m.c1 + D * k) * TRP + m.row1; Xr[o1] = px[j][2]; Xi[o1] = px[j][3]; }
+            }
+        }
+    };
+    if (fast && t_begin < t_end) issue_loads(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        lds_barrier();
+        if (fast) commit_loads();
+        else {
+            int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
+            const int ntile_el = D * TA * K * TB;
+            for (int e = tid; e < ntile_el; e += 256) {
+                int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
+                cf vx; vx.re = vx.im = 0.f;
+                if (al < na && bl < nb) vx = Xg[s + D * ((long long)(a0 + al) + PA * ((long long)k + (long long)K * (b0 + bl)))];
+                int o = (s + D * k) * TRP + (al + TA * bl);
+                Xr[o] = vx.re; Xi[o] = vx.im;
+            }
+        }
+        lds_barrier();
+        if (fast && t + 1 < t_end) issue_loads(t + 1);
+        // rows of the tile: lane quarter kq takes rows 16*kq + tt, tt = 0..15, in two halves of 8 to bound registers
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            double ar[8], ai[8];
+            const int ro = (16 * w + l15) * TRP + 16 * kq + 8 * half;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                v4f t0 = *reinterpret_cast<const v4f*>(Xr + ro + 4 * q), t1 = *reinterpret_cast<const v4f*>(Xi + ro + 4 * q);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { ar[4 * q + c] = (double)t0[c]; ai[4 * q + c] = (double)t1[c]; }
+            }
+#pragma unroll
+            for (int J = 0; J < 4; ++J) {
+                double br[8], bi[8];
+                const int rb = (16 * J + l15) * TRP + 16 * kq + 8 * half;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    v4f t0 = *reinterpret_cast<const v4f*>(Xr + rb + 4 * q), t1 = *reinterpret_cast<const v4f*>(Xi + rb + 4 * q);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { br[4 * q + c] = (double)t0[c]; bi[4 * q + c] = (double)t1[c]; }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    // out[i][j] += x[i] * conj(x[j])
+                    Cr[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[q], br[q], Cr[J], 0, 0, 0);
+                    Cr[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[q], bi[q], Cr[J], 0, 0, 0);
+                    Ci[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[q], br[q], Ci[J], 0, 0, 0);
+                    Ci[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar[q], bi[q], Ci[J], 0, 0, 0);
+                }
+            }
+        }
+    }
+    struct alignas(16) cd { double re, im; };
+    cd* __restrict__ part = reinterpret_cast<cd*>(it.partial) + (size_t)lc * KK * KK;
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int i = 16 * w + kq + 4 * r, j = 16 * J + l15;
+            if (i < KK && j < KK) { cd v; v.re = Cr[J][r]; v.im = Ci[J][r]; part[i + (size_t)KK * j] = v; }
+        }
+}
+bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
+    if (KKmax > 64) return false;
+    if (total_chunks <= 0) return true;
+    hipLaunchKernelGGL(mfma_gram64_f64_kernel, dim3(total_chunks), dim3(256), 0, s, d_items, nitems);
+    return true;
+}
+
 bool launch_mfma_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
     if (KKmax > 32) return false;
     if (total_chunks <= 0) return true;

@@ -88,13 +88,15 @@ def test_fiber_gemm(dtype, mfma, D, PA, K, PB, Do, No):
     assert abs(n2.value - np.sum(np.abs(ref) ** 2)) < 1e-5 * np.sum(np.abs(ref) ** 2)
 
 
-@pytest.mark.parametrize("dtype,acc64,mfma", [(0, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1)])
-@pytest.mark.parametrize("D,PA,K,PB,same", [(1, 64, 32, 1024, 0), (1, 2048, 32, 32, 0), (1, 2, 32, 700, 1), (1, 70, 17, 9, 0),
+@pytest.mark.parametrize("dtype,acc64,mfma", [(0, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (0, 1, 1)])
+@pytest.mark.parametrize("D,PA,K,PB,same", [(2, 1024, 32, 32, 1), (2, 32, 32, 1000, 1), (2, 1, 32, 1024, 1), (2, 77, 19, 11, 1), (1, 64, 32, 1024, 0), (1, 2048, 32, 32, 0), (1, 2, 32, 700, 1), (1, 70, 17, 9, 0),
                                            (1, 2, 3, 5, 0), (1, 100, 10, 7, 0), (1, 1, 7, 130, 1), (2, 9, 5, 40, 1), (2, 30, 1, 1, 0),
                                            (1, 64, 32, 33, 0), (2, 16, 16, 16, 1), (2, 512, 32, 8, 1), (3, 5, 5, 6, 0)])
 def test_gram(dtype, acc64, mfma, D, PA, K, PB, same):
-    if mfma and D * K > 32:
+    if mfma and not acc64 and D * K > 32:
         pytest.skip('f32 MFMA Gram covers D*K <= 32')
+    if mfma and acc64 and not (same and 16 <= D * K <= 64):
+        pytest.skip('f64 MFMA Gram covers X == Y, 16 <= D*K <= 64')
     rng = np.random.default_rng(D + PA + K + PB)
     dt = CDT[dtype]
     x = rnd(rng, D * PA * K * PB, dt)
