@@ -13,6 +13,7 @@ namespace tnqs {
 
 static size_t bp_ws_budget() { static size_t v = 0; if (!v) { const char* e = std::getenv("TNQS_BP_WS_MB"); v = (e ? (size_t)std::atoll(e) : (size_t)24576) << 20; } return v; }
 static size_t jacobi_lds(size_t bytes) { static int g = -1; if (g < 0) { const char* e = std::getenv("TNQS_JACOBI_GLOBAL"); g = (e && e[0] == '1') ? 1 : 0; } return (g || bytes > 160 * 1024 - 64) ? 0 : bytes; }
+static int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j : ji) m = std::max(m, std::max(j.m, j.n)); return m; }
 static bool use_mfma() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_MFMA"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 
 void hipchk(hipError_t e, const char* what) {
@@ -831,7 +832,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             const EnvItem* de = upload(s, ei); const JacobiItem* dj = upload(s, ji); const EnvFinishItem* df = upload(s, fi);
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, de, (int)ei.size()); }
             size_t lds = 0; for (auto& r : envs) lds = std::max(lds, jacobi_lds_bytes(r.n, r.n, true, 16));
-            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60, jacobi_lds(lds)); }
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60, jacobi_lds(lds), mmax_of(ji)); }
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_finish<T>(s->stream, df, (int)fi.size()); }
         }
     }
@@ -894,7 +895,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)idn.size()); }
             const JacobiItem* dj = upload(s, ji);
             size_t lds = 0; for (auto& j : ji) lds = std::max(lds, jacobi_lds_bytes(j.n, j.n, true, 16));
-            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60, jacobi_lds(lds)); }
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60, jacobi_lds(lds), mmax_of(ji)); }
         }
     }
     // ---- 4. theta = gate . (R1 R2), SVD, truncation, X1 / X2  (simple_update.jl:51-59) -----------------------------
@@ -981,7 +982,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         const bool novee = theta0_used;
         if (novee) for (auto& j : ji) j.V = nullptr;
         const JacobiItem* dj = upload(s, ji);
-        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<T>(s->stream, dj, npg, 60, jacobi_lds(novee ? lds_a : lds_av)); }
+        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<T>(s->stream, dj, npg, 60, jacobi_lds(novee ? lds_a : lds_av), mmax_of(ji)); }
         if (novee) {
             std::vector<RecoverItem> rv;
             for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ji[q].n});

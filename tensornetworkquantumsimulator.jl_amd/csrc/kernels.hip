@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include "kernels.hpp"
 
 namespace tnqs {
@@ -381,14 +382,17 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restri
 // A QUARTER wave (16 lanes) owns one column pair, so a 16-wave workgroup rotates 64 pairs at once (one full round of a
 // 128-column matrix); the dot products reduce inside 16-lane rows.  Columns are padded by 2 elements so the four
 // quarter-waves of a wave hit different LDS banks.
+template <class T> __device__ __forceinline__ T fast_rsqrt(T x) { return 1 / sqrt(x); }
+template <> __device__ __forceinline__ float fast_rsqrt<float>(float x) { return __frsqrt_rn(x); }
+template <class T> __device__ __forceinline__ T fast_rcp(T x) { return 1 / x; }
+template <> __device__ __forceinline__ float fast_rcp<float>(float x) { return __frcp_rn(x); }
 template <class T> __device__ __forceinline__ T row16_sum(T v) {
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
     return v;
 }
-template <class T>
+template <class T, int RQ>              // RQ = rows per lane: m <= 16*RQ
 __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __restrict__ items, int max_sweeps) {
-    constexpr int RQ = 16;                 // rows per lane (m <= 256)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_rot;
     const JacobiItem it = items[blockIdx.x];
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
                 int p = 0, q = 0; bool act = pi < ne / 2;
                 if (act) {
                     if (pi == 0) { p = ne - 1; q = round; }
-                    else { p = (round + pi) % (ne - 1); q = (round - pi + (ne - 1)) % (ne - 1); }
+                    else { p = round + pi; if (p >= ne - 1) p -= ne - 1; q = round - pi; if (q < 0) q += ne - 1; }
                     if (p > q) { int t = p; p = q; q = t; }
                     act = q < n;
                 }
@@ -438,13 +442,15 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
                 }
                 alpha = row16_sum(alpha); beta = row16_sum(beta); gre = row16_sum(gre); gim = row16_sum(gim);
                 const T g2 = gre * gre + gim * gim;
-                const bool rot = act && g2 > 0 && g2 > tol * tol * alpha * beta;
+                // f32: g2 must be a NORMAL number -- the fast reciprocal square root returns inf for (flushed) denormals
+                const bool rot = act && g2 > (sizeof(T) == 4 ? (T)1e-36 : (T)0) && g2 > tol * tol * alpha * beta;
                 if (rot) {
-                    const T ga = sqrt(g2);
-                    const T pre = gre / ga, pim = -gim / ga;
-                    const T zeta = (beta - alpha) / (2 * ga);
-                    const T t = (zeta >= 0 ? (T)1 : (T)-1) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-                    const T c = 1 / sqrt(1 + t * t), sn = c * t;
+                    const T iga = fast_rsqrt<T>(g2);
+                    const T pre = gre * iga, pim = -gim * iga;
+                    const T zeta = (beta - alpha) * (T)0.5 * iga;
+                    const T az = fabs(zeta);
+                    const T t = (zeta >= 0 ? (T)1 : (T)-1) * fast_rcp<T>(az + sqrt(1 + az * az));
+                    const T c = fast_rsqrt<T>(1 + t * t), sn = c * t;
 #pragma unroll
                     for (int r = 0; r < RQ; ++r) {
                         int i = l16 + 16 * r;
@@ -509,18 +515,25 @@ template void launch_recover_v<float>(hipStream_t, const RecoverItem*, int);
 template void launch_recover_v<double>(hipStream_t, const RecoverItem*, int);
 
 // lds_bytes: max over the items of (m*n + (V ? n*n : 0)) * sizeof(complex<T>); 0 selects the global-memory kernel
-template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes) {
+template <class T, int RQ> static void launch_jacobi_lds(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<T, RQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 64)); attr = true; }
+    hipLaunchKernelGGL((jacobi_lds_kernel<T, RQ>), dim3(nitems), dim3(1024), lds_bytes, s, d_items, max_sweeps);
+}
+// mmax: largest row count among the items (selects the rows-per-lane instantiation)
+template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax) {
     if (nitems <= 0) return;
-    if (lds_bytes > 0 && lds_bytes <= 160 * 1024 - 64) {
-        static size_t attr_set = 0;
-        if (lds_bytes > attr_set) { (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 64)); attr_set = 160 * 1024; }
-        hipLaunchKernelGGL((jacobi_lds_kernel<T>), dim3(nitems), dim3(1024), lds_bytes, s, d_items, max_sweeps);
+    if (lds_bytes > 0 && lds_bytes <= 160 * 1024 - 64 && mmax <= 256) {
+        if (mmax <= 32) launch_jacobi_lds<T, 2>(s, d_items, nitems, max_sweeps, lds_bytes);
+        else if (mmax <= 64) launch_jacobi_lds<T, 4>(s, d_items, nitems, max_sweeps, lds_bytes);
+        else if (mmax <= 128) launch_jacobi_lds<T, 8>(s, d_items, nitems, max_sweeps, lds_bytes);
+        else launch_jacobi_lds<T, 16>(s, d_items, nitems, max_sweeps, lds_bytes);
     } else {
         hipLaunchKernelGGL((jacobi_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items, max_sweeps);
     }
 }
-template void launch_jacobi<float>(hipStream_t, const JacobiItem*, int, int, size_t);
-template void launch_jacobi<double>(hipStream_t, const JacobiItem*, int, int, size_t);
+template void launch_jacobi<float>(hipStream_t, const JacobiItem*, int, int, size_t, int);
+template void launch_jacobi<double>(hipStream_t, const JacobiItem*, int, int, size_t, int);
 
 // ------------------------------------------------------------------------------------------------------------
 // environment square roots  (src/utils.jl:18-27 with safe_eigen :94-108: always f64)
@@ -690,7 +703,7 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const GateItem* __rest
     for (int u = threadIdx.x; u < ncol; u += 256) {
         double s2 = 0;
         for (int i = 0; i < ld; ++i) { cx<T> v = th[i + (size_t)ld * u]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
-        sig[u] = sqrt(s2);
+        sig[u] = (s2 == s2 && s2 < 1e300) ? sqrt(s2) : 0.0;     // a NaN / inf column must not poison the ranking below
     }
     __syncthreads();
     for (int u = threadIdx.x; u < ncol; u += 256) {    // rank by counting (descending, stable)

@@ -85,7 +85,7 @@ template <class T> void launch_msg_finalize(hipStream_t s, const MsgFinalItem* d
 struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; };   // V = A0^dagger (U Sigma) Sigma^-2
 // LDS bytes the LDS-resident Jacobi needs for an m x n matrix (columns padded by 2 elements)
 inline size_t jacobi_lds_bytes(int m, int n, bool withV, size_t esz) { return ((size_t)(m + 2) * n + (withV ? (size_t)(n + 2) * n : 0)) * esz; }
-template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes);
+template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax);
 template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems);
 template <class T> void launch_env_prepare(hipStream_t s, const EnvItem* d_items, int nitems);
 template <class T> void launch_env_finish(hipStream_t s, const EnvFinishItem* d_items, int nitems);

@@ -287,3 +287,38 @@ def test_scheduling_rule_counts():
     assert info["n_updates"] == 2 and info["n_batches"] == 3
     tn.apply_gates([("Rx", [(1, 1)], 0.3)], bpc, update_cache=False, info=info)
     assert info["n_updates"] == 0
+
+
+def test_default_tolerance_sweep_counts_and_observables_match_oracle():
+    """the benchmark circuit (README.md:42-48 angles) on a chi-saturated random ComplexF32 state with the REFERENCE
+    DEFAULT bp_update_kwargs (maxiter 25, tolerance 1e-5): the number of BP sweeps each update needs is a property of
+    the algorithm -- the HIP path must need exactly as many as the CPU oracle (same edge sequence), and reproduce its
+    truncation errors and <Z>.  (An inaccurate device SVD shows up here as extra sweeps.)"""
+    L, chi = 5, 8
+    g = tn.named_grid((L, L))
+    groups = tn.edge_color(g, 4)
+    seq = colour_sequence(g, groups)
+    layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+    rng = np.random.default_rng(1234)
+    tensors = {}
+    for v in g.vertices:
+        shp = (2,) + (chi,) * g.degree(v)
+        n = int(np.prod(shp))
+        tensors[v] = rng.standard_normal(2 * n, dtype=np.float32).view(np.complex64).reshape(shp) / np.float32(np.sqrt(n))
+    psi = tn.TensorNetworkState(g, tensors)
+    kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+    bpkw = dict(edge_sequence=seq)
+    bpc = tn.BeliefPropagationCache(psi)
+    oc = o.BeliefPropagationCache(to_oracle_state(psi), edge_sequence=seq)
+    for layer_no in range(3):
+        info, oinfo = {}, {}
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=bpkw, info=info)
+        oc, oerrs = o.apply_gates(layer, oc, apply_kwargs=kw, bp_update_kwargs=bpkw, info=oinfo)
+        assert info["n_updates"] == oinfo["n_updates"] == 5
+        assert info["n_sweeps"] == sum(oinfo["sweeps"]), (layer_no, info["n_sweeps"], oinfo["sweeps"])
+        assert np.max(np.abs(errs - oerrs)) < 1e-6
+        ez = tn.expect_all(bpc, "Z")
+        oez = np.array([o.expect_1site(oc, Z, v) for v in g.vertices])
+        assert np.max(np.abs(ez - oez)) < 1e-5          # north-star bar: expectation values within 1e-5
