@@ -899,7 +899,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         }
     }
     // ---- 4. theta = gate . (R1 R2), SVD, truncation, X1 / X2  (simple_update.jl:51-59) -----------------------------
-    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S, info, terr; int n1, n2, chi, cap; };
+    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S; int n1, n2, chi, cap; };
     std::vector<GateWS> ws(ng);
     std::vector<int> pg;                              // gates this rank takes part in
     for (int gi = 0; gi < ng; ++gi) if (part[gi]) pg.push_back(gi);
@@ -944,24 +944,26 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             w.theta = dalloc(s, (size_t)Mr * Nc * esz); w.thetaV = dalloc(s, (size_t)std::max(Mr, Nc) * std::max(Mr, Nc) * esz);
             if (theta0_used) w.theta0 = dalloc(s, (size_t)Mr * Nc * esz);
             w.X1 = dalloc(s, (size_t)w.n1 * a.sd.d * cap * esz); w.X2 = dalloc(s, (size_t)w.n2 * b.sd.d * cap * esz);
-            w.S = dalloc(s, cap * 8); w.info = dalloc(s, 8 * 4); w.terr = dalloc(s, 8);
+            w.S = dalloc(s, cap * 8);
             it.GA1 = GA[2 * gi]->p; it.GV1 = GV[2 * gi]->p; it.GA2 = GA[2 * gi + 1]->p; it.GV2 = GV[2 * gi + 1]->p;
             it.n1 = w.n1; it.n2 = w.n2; it.d1 = a.sd.d; it.d2 = b.sd.d; it.chi = w.chi;
             it.gate = reinterpret_cast<const double*>(d_gm + off[q]);
             it.lam1 = (double*)w.lam1->p; it.lam2 = (double*)w.lam2->p; it.idx1 = (int*)w.idx1->p; it.idx2 = (int*)w.idx2->p;
             it.theta = w.theta->p; it.thetaV = w.thetaV->p; it.theta0 = w.theta0 ? w.theta0->p : nullptr; it.X1 = w.X1->p; it.X2 = w.X2->p; it.S = (double*)w.S->p;
-            it.info = (int*)w.info->p; it.truncerr = (double*)w.terr->p;
             it.maxdim = ao.maxdim; it.cutoff = ao.cutoff; it.normalize = ao.normalize_tensors; it.chi_cap = cap;
         }
     }
     const int npg = (int)pg.size();
+    // per-gate (r1, r2, chi', status, sweeps, wide, -, -) and truncation error live in two contiguous arrays: one D2H each
+    Buf d_info_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 32));
+    Buf d_terr_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 8));
+    HIPCHK(hipMemsetAsync(d_info_all->p, 0, std::max<size_t>(1, (size_t)npg * 32), s->stream));
+    for (int q = 0; q < npg; ++q) { gitems[q].info = reinterpret_cast<int*>(d_info_all->p) + 8 * q; gitems[q].truncerr = reinterpret_cast<double*>(d_terr_all->p) + q; }
     const GateItem* d_gitems = upload(s, gitems);
     { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_theta<T>(s->stream, d_gitems, npg); }
     std::vector<int> info(8 * (size_t)ng, 0); std::vector<double> terr(ng, 0.0);
     {
         // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
-        Buf d_info_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 32));
-        for (int q = 0; q < npg; ++q) HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d_info_all->p) + 32 * q, ws[pg[q]].info->p, 32, hipMemcpyDeviceToDevice, s->stream));
         std::vector<int> hinfo(8 * (size_t)std::max(1, npg));
         if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
         if (!envs.empty()) HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags->p, 2 * envs.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
@@ -974,7 +976,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             int r1 = hinfo[8 * q], r2 = hinfo[8 * q + 1];
             int Mr = r1 * gitems[q].d1, Nc = r2 * gitems[q].d2;
             if (Mr < Nc) std::swap(Mr, Nc);        // wide theta is stored as its adjoint (gate_theta_kernel)
-            ji.push_back(JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, reinterpret_cast<int*>(ws[gi].info->p) + 4});
+            ji.push_back(JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, gitems[q].info + 4});
         }
         // LDS residency: A and V if both fit; A only (V recovered from the unrotated copy) if only A fits; else global memory
         size_t lds_av = 0, lds_a = 0;
@@ -990,11 +992,6 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_recover_v<T>(s->stream, dr, npg); }
         }
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
-        Buf d_terr_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 8));
-        for (int q = 0; q < npg; ++q) {
-            HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d_info_all->p) + 32 * q, ws[pg[q]].info->p, 32, hipMemcpyDeviceToDevice, s->stream));
-            HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d_terr_all->p) + 8 * q, ws[pg[q]].terr->p, 8, hipMemcpyDeviceToDevice, s->stream));
-        }
         std::vector<double> hterr(std::max(1, npg));
         if (npg) {
             HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
