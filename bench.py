@@ -154,9 +154,10 @@ def main():
     # 157.3 TFLOP/s / 8 TB/s = 19.7 flop/B (MI355X_MICROARCH.md).  `achieved` = algorithmic bytes (or flops) of the
     # class / HIP-event time of its launches on the library's stream; `traffic` = HBM bytes per launch from the PMC
     # pass of the same command committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, see the file's header).
-    KERNEL_OF = {"bp_modeprod": "tnqs::mfma_fiber_gemm_w_kernel<1, 1, 8>", "gate_modeprod": "tnqs::mfma_fiber_gemm_w_kernel<1, 1, 8>",
-                 "bp_fused": "tnqs::mfma_gram32_fused_kernel", "bp_gram": "tnqs::mfma_gram32_kernel",
-                 "gate_gram": "tnqs::gram_kernel<float, double, 4>", "gate_apply": "tnqs::mfma_fiber_gemm_w_kernel<2, 2, 16>"}
+    KERNEL_OF = {"bp_pair": "tnqs::mfma_pair_kernel", "bp_modeprod": "tnqs::mfma_fiber_gemm_w_kernel<1, 1, 8>",
+                 "gate_modeprod": "tnqs::mfma_pair_kernel", "bp_fused": "tnqs::mfma_gram32_fused_kernel",
+                 "bp_gram": "tnqs::mfma_gram32_kernel", "gate_gram": "tnqs::mfma_gram64_f64_kernel",
+                 "gate_apply": "tnqs::mfma_fiber_gemm_w_kernel<2, 2, 16>"}
     traffic_db = {}
     try:
         with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:

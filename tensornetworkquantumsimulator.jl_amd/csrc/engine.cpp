@@ -353,7 +353,8 @@ struct Chain {
 
 static bool use_pair() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_PAIR"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 
-template <class T> static void run_chains(State* s, std::vector<Chain>& chains, int cls) {
+template <class T> static void run_chains(State* s, std::vector<Chain>& chains, int cls, int cls_pair = -1) {
+    if (cls_pair < 0) cls_pair = cls;
     const size_t esz = s->esz();
     std::vector<int> nt(chains.size(), 0);          // temporaries written so far (ping-pong index)
     std::vector<size_t> done(chains.size(), 0);     // steps consumed from the FRONT of c.steps after the pair stage
@@ -399,7 +400,7 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
                 bytes += 2.0 * c.sd.n * esz; flops += 2 * 8.0 * c.sd.n * 32;
             }
             const PairItem* d = upload(s, items);
-            ProfScope ps(s, cls, bytes, flops);
+            ProfScope ps(s, cls_pair, bytes, flops);
             launch_mfma_pair(s->stream, d, (int)items.size(), wgs);
         }
     }
@@ -591,7 +592,7 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     }
                     chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(fm);
                 }
-                run_chains<T>(s, chains, TNQS_PROF_BP_MODEPROD);
+                run_chains<T>(s, chains, TNQS_PROF_BP_MODEPROD, TNQS_PROF_BP_PAIR);
                 std::vector<GramJob> jobs;
                 for (size_t i = 0; i < chains.size(); ++i) {
                     int de = plan.seq[tpos[i]]; int e = de / 2; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
