@@ -42,7 +42,7 @@ static void tile_params(size_t PA, size_t PB, int TR, int& TA, int& TB, int& nta
     nta = (int)((PA + TA - 1) / TA); ntb = (int)((PB + TB - 1) / TB);
 }
 static int pick_TR(size_t KK, size_t esz, int copies) {
-    for (int tr : {64, 32, 16}) if (KK * tr * esz * copies <= 64 * 1024) return tr;
+    for (int tr : {64, 32, 16, 8, 4}) if (KK * tr * esz * copies <= 64 * 1024) return tr;
     throw Err(TNQS_ERR_UNSUPPORTED, "too large");
 }
 

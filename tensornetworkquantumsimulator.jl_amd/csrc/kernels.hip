@@ -14,6 +14,9 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <stdexcept>
+#include <string>
+#define TNQS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP kernel launch failed (") + __func__ + "): " + hipGetErrorString(e_)); } while (0)
 #include "kernels.hpp"
 
 namespace tnqs {
@@ -120,7 +123,7 @@ void launch_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems, int 
                        double* d_norm_partials) {
     if (total_tiles <= 0) return;
     size_t lds = (size_t)KKmax * TR * sizeof(cx<T>);
-    hipLaunchKernelGGL((fiber_gemm_kernel<T, 8>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, TR, d_norm_partials);
+    hipLaunchKernelGGL((fiber_gemm_kernel<T, 8>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, TR, d_norm_partials); TNQS_CHECK_LAUNCH();
 }
 template void launch_fiber_gemm<float>(hipStream_t, const FiberItem*, int, int, int, int, double*);
 template void launch_fiber_gemm<double>(hipStream_t, const FiberItem*, int, int, int, int, double*);
@@ -218,7 +221,7 @@ template <class T, class Acc>
 void launch_gram(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int TR, int KKmax) {
     if (total_chunks <= 0) return;
     size_t lds = 2 * (size_t)TR * (KKmax + 1) * sizeof(cx<T>);
-    hipLaunchKernelGGL((gram_kernel<T, Acc, 4>), dim3(total_chunks), dim3(256), lds, s, d_items, nitems, TR);
+    hipLaunchKernelGGL((gram_kernel<T, Acc, 4>), dim3(total_chunks), dim3(256), lds, s, d_items, nitems, TR); TNQS_CHECK_LAUNCH();
 }
 template void launch_gram<float, float>(hipStream_t, const GramItem*, int, int, int, int);
 template void launch_gram<float, double>(hipStream_t, const GramItem*, int, int, int, int);
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceItem* __restric
 template <class Acc, class Out>
 void launch_reduce(hipStream_t s, const ReduceItem* d_items, int nitems, int total_elems) {
     if (total_elems <= 0) return;
-    hipLaunchKernelGGL((reduce_kernel<Acc, Out>), dim3((total_elems + 255) / 256), dim3(256), 0, s, d_items, nitems, total_elems);
+    hipLaunchKernelGGL((reduce_kernel<Acc, Out>), dim3((total_elems + 255) / 256), dim3(256), 0, s, d_items, nitems, total_elems); TNQS_CHECK_LAUNCH();
 }
 template void launch_reduce<double, double>(hipStream_t, const ReduceItem*, int, int);
 template void launch_reduce<float, float>(hipStream_t, const ReduceItem*, int, int);
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void msg_finalize_kernel(const MsgFinalItem* _
 }
 template <class T> void launch_msg_finalize(hipStream_t s, const MsgFinalItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((msg_finalize_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+    hipLaunchKernelGGL((msg_finalize_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_msg_finalize<float>(hipStream_t, const MsgFinalItem*, int);
 template void launch_msg_finalize<double>(hipStream_t, const MsgFinalItem*, int);
@@ -356,6 +359,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restri
                             A[i + (size_t)m * q] = cmake<T>(sn * ap[r].re + c * qre, sn * ap[r].im + c * qim);
                         }
                     }
+                    if (V)
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         int i = lane + 64 * r;
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(256) void recover_v_kernel(const RecoverItem* __res
 }
 template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((recover_v_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+    hipLaunchKernelGGL((recover_v_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_recover_v<float>(hipStream_t, const RecoverItem*, int);
 template void launch_recover_v<double>(hipStream_t, const RecoverItem*, int);
@@ -518,7 +522,7 @@ template void launch_recover_v<double>(hipStream_t, const RecoverItem*, int);
 template <class T, int RQ> static void launch_jacobi_lds(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<T, RQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 64)); attr = true; }
-    hipLaunchKernelGGL((jacobi_lds_kernel<T, RQ>), dim3(nitems), dim3(1024), lds_bytes, s, d_items, max_sweeps);
+    hipLaunchKernelGGL((jacobi_lds_kernel<T, RQ>), dim3(nitems), dim3(1024), lds_bytes, s, d_items, max_sweeps); TNQS_CHECK_LAUNCH();
 }
 // mmax: largest row count among the items (selects the rows-per-lane instantiation)
 template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax) {
@@ -529,7 +533,7 @@ template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, 
         else if (mmax <= 128) launch_jacobi_lds<T, 8>(s, d_items, nitems, max_sweeps, lds_bytes);
         else launch_jacobi_lds<T, 16>(s, d_items, nitems, max_sweeps, lds_bytes);
     } else {
-        hipLaunchKernelGGL((jacobi_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items, max_sweeps);
+        hipLaunchKernelGGL((jacobi_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items, max_sweeps); TNQS_CHECK_LAUNCH();
     }
 }
 template void launch_jacobi<float>(hipStream_t, const JacobiItem*, int, int, size_t, int);
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256) void env_prepare_kernel(const EnvItem* __restr
 }
 template <class T> void launch_env_prepare(hipStream_t s, const EnvItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((env_prepare_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+    hipLaunchKernelGGL((env_prepare_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_env_prepare<float>(hipStream_t, const EnvItem*, int);
 template void launch_env_prepare<double>(hipStream_t, const EnvItem*, int);
@@ -603,7 +607,7 @@ __global__ __launch_bounds__(256) void env_finish_kernel(const EnvFinishItem* __
 }
 template <class T> void launch_env_finish(hipStream_t s, const EnvFinishItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((env_finish_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+    hipLaunchKernelGGL((env_finish_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_env_finish<float>(hipStream_t, const EnvFinishItem*, int);
 template void launch_env_finish<double>(hipStream_t, const EnvFinishItem*, int);
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(256) void gate_theta_kernel(const GateItem* __restr
 }
 template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((gate_theta_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+    hipLaunchKernelGGL((gate_theta_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_gate_theta<float>(hipStream_t, const GateItem*, int);
 template void launch_gate_theta<double>(hipStream_t, const GateItem*, int);
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const GateItem* __rest
 }
 template <class T> void launch_gate_finish(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((gate_finish_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+    hipLaunchKernelGGL((gate_finish_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_gate_finish<float>(hipStream_t, const GateItem*, int);
 template void launch_gate_finish<double>(hipStream_t, const GateItem*, int);
@@ -808,7 +812,7 @@ template <class T> __global__ void diag_kernel(const DiagItem* __restrict__ item
 }
 template <class T> void launch_diag(hipStream_t s, const DiagItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((diag_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items);
+    hipLaunchKernelGGL((diag_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_diag<float>(hipStream_t, const DiagItem*, int);
 template void launch_diag<double>(hipStream_t, const DiagItem*, int);
@@ -829,7 +833,7 @@ template <class T> __global__ __launch_bounds__(256) void scale_kernel(const Sca
 }
 template <class T> void launch_scale(hipStream_t s, const ScaleItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((scale_kernel<T>), dim3(64, nitems), dim3(256), 0, s, d_items);
+    hipLaunchKernelGGL((scale_kernel<T>), dim3(64, nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_scale<float>(hipStream_t, const ScaleItem*, int);
 template void launch_scale<double>(hipStream_t, const ScaleItem*, int);
@@ -846,7 +850,7 @@ template <class T> __global__ __launch_bounds__(256) void permute_kernel(PermIte
 template <class T> void launch_permute(hipStream_t s, const PermItem& item) {
     if (item.n == 0) return;
     int blocks = (int)((item.n + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((permute_kernel<T>), dim3(blocks), dim3(256), 0, s, item);
+    hipLaunchKernelGGL((permute_kernel<T>), dim3(blocks), dim3(256), 0, s, item); TNQS_CHECK_LAUNCH();
 }
 template void launch_permute<float>(hipStream_t, const PermItem&);
 template void launch_permute<double>(hipStream_t, const PermItem&);
@@ -856,7 +860,7 @@ template <class T> __global__ void identity_kernel(cx<T>* out, int n) {
         out[e] = cmake<T>((e % n) == (e / n) ? (T)1 : (T)0, (T)0);
 }
 template <class T> void launch_identity(hipStream_t s, void* out, int n) {
-    hipLaunchKernelGGL((identity_kernel<T>), dim3((n * n + 255) / 256), dim3(256), 0, s, reinterpret_cast<cx<T>*>(out), n);
+    hipLaunchKernelGGL((identity_kernel<T>), dim3((n * n + 255) / 256), dim3(256), 0, s, reinterpret_cast<cx<T>*>(out), n); TNQS_CHECK_LAUNCH();
 }
 template void launch_identity<float>(hipStream_t, void*, int);
 template void launch_identity<double>(hipStream_t, void*, int);
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(256) void site1_c64_kernel(const Site1Item* __restr
 }
 void launch_site1_c64(hipStream_t s, const Site1Item* d_items, int nitems, int nbx, double* d_norm_partials) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL(site1_c64_kernel, dim3(nbx, nitems), dim3(256), 0, s, d_items, d_norm_partials);
+    hipLaunchKernelGGL(site1_c64_kernel, dim3(nbx, nitems), dim3(256), 0, s, d_items, d_norm_partials); TNQS_CHECK_LAUNCH();
 }
 
 __global__ void sum_doubles_kernel(const double* in, int n, double* out) {
@@ -897,7 +901,7 @@ __global__ void sum_doubles_kernel(const double* in, int n, double* out) {
     if (threadIdx.x == 0) *out = t;
 }
 void launch_sum_doubles(hipStream_t s, const double* in, int n, double* out) {
-    hipLaunchKernelGGL(sum_doubles_kernel, dim3(1), dim3(256), 0, s, in, n, out);
+    hipLaunchKernelGGL(sum_doubles_kernel, dim3(1), dim3(256), 0, s, in, n, out); TNQS_CHECK_LAUNCH();
 }
 
 }  // namespace tnqs

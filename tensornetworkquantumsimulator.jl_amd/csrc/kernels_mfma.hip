@@ -8,6 +8,9 @@
 // k = t + 16*h, so every lane reads 16 CONSECUTIVE floats of its operand row from LDS (4 x ds_read_b128).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <stdexcept>
+#include <string>
+#define TNQS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP kernel launch failed (") + __func__ + "): " + hipGetErrorString(e_)); } while (0)
 #include "kernels.hpp"
 
 namespace tnqs {
@@ -444,28 +447,28 @@ bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems,
     if (wave_private()) {
         if (KKmax <= 32 && NNmax <= 32) {
             const size_t lds = fiber_lds<1, 1, 128>();
-            hipLaunchKernelGGL((mfma_fiber_gemm_w_kernel<1, 1, 8>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials);
+            hipLaunchKernelGGL((mfma_fiber_gemm_w_kernel<1, 1, 8>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
             return true;
         }
         if (KKmax <= 64 && NNmax <= 64) {
             const size_t lds = fiber_lds<2, 2, 128>();
             static bool attr = false;
             if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_fiber_gemm_w_kernel<2, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-            hipLaunchKernelGGL((mfma_fiber_gemm_w_kernel<2, 2, 16>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials);
+            hipLaunchKernelGGL((mfma_fiber_gemm_w_kernel<2, 2, 16>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
             return true;
         }
         return false;
     }
     if (KKmax <= 32 && NNmax <= 32) {
         const size_t lds = fiber_lds<1, 1, 128>();
-        hipLaunchKernelGGL((mfma_fiber_gemm_kernel<1, 1, 128>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials);
+        hipLaunchKernelGGL((mfma_fiber_gemm_kernel<1, 1, 128>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
         return true;
     }
     if (KKmax <= 64 && NNmax <= 64) {
         const size_t lds = fiber_lds<2, 2, 64>();
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_fiber_gemm_kernel<2, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        hipLaunchKernelGGL((mfma_fiber_gemm_kernel<2, 2, 64>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials);
+        hipLaunchKernelGGL((mfma_fiber_gemm_kernel<2, 2, 64>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
         return true;
     }
     return false;
@@ -694,7 +697,7 @@ void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems
     const size_t lds = (size_t)4 * 2 * 32 * 65 * sizeof(float);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_gram32_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(mfma_gram32_fused_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems);
+    hipLaunchKernelGGL(mfma_gram32_fused_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -811,7 +814,7 @@ void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int to
     const size_t lds = (size_t)16 * (2 * 32 * 33 + 1) * sizeof(float);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(mfma_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
+    hipLaunchKernelGGL(mfma_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -942,14 +945,14 @@ __global__ __launch_bounds__(256) void mfma_gram64_f64_kernel(const GramItem* __
 bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
     if (KKmax > 64) return false;
     if (total_chunks <= 0) return true;
-    hipLaunchKernelGGL(mfma_gram64_f64_kernel, dim3(total_chunks), dim3(256), 0, s, d_items, nitems);
+    hipLaunchKernelGGL(mfma_gram64_f64_kernel, dim3(total_chunks), dim3(256), 0, s, d_items, nitems); TNQS_CHECK_LAUNCH();
     return true;
 }
 
 bool launch_mfma_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
     if (KKmax > 32) return false;
     if (total_chunks <= 0) return true;
-    hipLaunchKernelGGL(mfma_gram32_kernel, dim3(total_chunks), dim3(256), 0, s, d_items, nitems);
+    hipLaunchKernelGGL(mfma_gram32_kernel, dim3(total_chunks), dim3(256), 0, s, d_items, nitems); TNQS_CHECK_LAUNCH();
     return true;
 }
 

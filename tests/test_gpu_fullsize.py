@@ -131,3 +131,47 @@ def test_cubic_4x4x4_periodic_chi8_layer():
     # translation invariance holds up to the Trotter-order / truncation asymmetry of the colour-by-colour circuit
     assert np.max(np.abs(ez - ez[0])) < 5e-2
     assert 0.5 < ez[0].real <= 1 + 1e-5
+
+
+def test_chi64_site_path_runs():
+    """BASELINE configs[4] uses chi = 64 (256 MiB bulk tensors, 256 x 256 theta): one layer on a 3x3 patch must run through
+    the same code (K = 64 MFMA mode products, global-memory Jacobi for the 256 x 256 SVD) and keep the invariants"""
+    g = tn.named_grid((3, 3))
+    chi = 64
+    groups = tn.edge_color(g, 4)
+    layer = [("Rx", [v], 0.05) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rzz", [a, b], 0.02) for (a, b) in grp]
+    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex64, lambda v: "↑", g))
+    for v, t in random_unit_state(g, chi, np.complex64, seed=5).items():
+        bpc._set_tensor(v, t)
+    info = {}
+    tight = dict(maxiter=100, tolerance=1e-10)      # idempotence below is only meaningful at a well-converged fixed point
+    bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True),
+                               bp_update_kwargs=tight, info=info)
+    assert info["n_updates"] == 5 and info["n_two_site"] == 12
+    assert bpc.maxvirtualdim() <= chi and np.all((errs >= 0) & (errs <= 1))
+    ez = tn.expect_all(bpc, "Z")
+    assert np.all(np.abs(ez.real) <= 1 + 1e-4) and np.all(np.abs(ez.imag) < 1e-4)
+    assert abs(np.linalg.norm(bpc.tensor((2, 2))) - 1) < 1e-4
+    t = tn.truncate(bpc, maxdim=chi, edge_color=groups, bp_update_kwargs=tight)
+    assert np.max(np.abs(tn.expect_all(t, "Z") - ez)) < 2e-3
+
+
+def test_cubic_degree6_chi16_layer_runs():
+    """BASELINE configs[3] per-site shape: periodic cubic, degree 6, chi = 16 (256 MiB site tensors) on a 3x3x3 torus"""
+    g = tn.named_grid((3, 3, 3), periodic=True)
+    chi = 16
+    groups = tn.edge_color(g)
+    layer = [("Rz", [v], -0.04) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rxx", [a, b], -0.08) for (a, b) in grp]
+    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex64, lambda v: "↑", g))
+    for v, t in random_unit_state(g, chi, np.complex64, seed=6).items():
+        bpc._set_tensor(v, t)
+    info = {}
+    bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True), info=info)
+    assert info["n_updates"] == len(groups) + 1 and info["n_two_site"] == 81
+    assert bpc.maxvirtualdim() <= chi and np.all((errs >= 0) & (errs <= 1))
+    ez = tn.expect_all(bpc, "Z")
+    assert np.all(np.abs(ez.real) <= 1 + 1e-4) and np.all(np.abs(ez.imag) < 1e-4)

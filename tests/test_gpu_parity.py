@@ -322,3 +322,33 @@ def test_default_tolerance_sweep_counts_and_observables_match_oracle():
         ez = tn.expect_all(bpc, "Z")
         oez = np.array([o.expect_1site(oc, Z, v) for v in g.vertices])
         assert np.max(np.abs(ez - oez)) < 1e-5          # north-star bar: expectation values within 1e-5
+
+
+def _two_site(g, a, b, get):
+    ta, tb = get(a), get(b)
+    la = 1 + g.neighbors(a).index(b); lb = 1 + g.neighbors(b).index(a)
+    return np.tensordot(ta, tb, axes=([la], [lb]))
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.complex64, 2e-5), (np.complex128, 1e-12)])
+@pytest.mark.parametrize("lattice,chi", [("line3", 5), ("line3", 32), ("grid2x3", 24), ("grid2x3", 36), ("grid2x3", 48), ("grid2x3", 64)])
+def test_identity_gate_leaves_the_bond_contracted_pair_unchanged(dtype, tol, lattice, chi):
+    """simple_update with the identity gate and maxdim = chi only re-gauges the bond (simple_update.jl:21-77): the two-site
+    tensor contracted over the bond must not change.  Size-independent exactness check that walks through every theta
+    residency regime of the SVD kernels (LDS, LDS without V, global memory) and through leaf / degree-3 sites."""
+    g = tn.named_grid((3,)) if lattice == "line3" else tn.named_grid((2, 3))
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=chi, seed=3)
+    for v in g.vertices:
+        psi.tensors[v] = (psi.tensors[v] / np.linalg.norm(psi.tensors[v])).astype(dtype)
+    bpc = tn.update(tn.BeliefPropagationCache(psi), edge_sequence=tn.forest_cover_edge_sequence(g), maxiter=20, tolerance=None)
+    for (a, b) in g.edges:
+        out, errs = tn.apply_gates([(np.eye(4), [a, b])], bpc, apply_kwargs=dict(maxdim=chi, cutoff=1e-30, normalize_tensors=True), update_cache=False)
+        if lattice == "line3":      # leaf messages are rank 2: the sqrt_cutoff projector re-gauges the OUTER bond too -> compare states
+            T0 = sv.tns_to_statevector(to_oracle_state(psi)); T = sv.tns_to_statevector(to_oracle_state(out.network()))
+        else:
+            T0 = _two_site(g, a, b, bpc.tensor); T = _two_site(g, a, b, out.tensor)
+        T0 = T0 / np.linalg.norm(T0); T = T / np.linalg.norm(T)
+        ph = np.vdot(T0, T); ph /= abs(ph)
+        assert np.max(np.abs(T - ph * T0)) < tol * np.max(np.abs(T0)), (lattice, chi, (a, b))
+        assert errs[0] < (1e-10 if dtype == np.complex64 else 1e-24)
+        assert out.bond_dim(a, b) == min(chi, 2 * min(chi ** (g.degree(a) - 1), chi ** (g.degree(b) - 1)))
