@@ -147,7 +147,7 @@ int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* vertex
 
 /* ---- profiling: HIP-event timing of the kernel classes on the handle's stream ---------------------------- */
 enum { TNQS_PROF_BP_MODEPROD = 0, TNQS_PROF_BP_GRAM = 1, TNQS_PROF_GATE_MODEPROD = 2, TNQS_PROF_GATE_GRAM = 3,
-       TNQS_PROF_GATE_APPLY = 4, TNQS_PROF_JACOBI = 5, TNQS_PROF_SMALL = 6, TNQS_PROF_BP_FUSED = 7, TNQS_PROF_BP_PAIR = 8, TNQS_PROF_NCLASSES = 9 };
+       TNQS_PROF_GATE_APPLY = 4, TNQS_PROF_JACOBI = 5, TNQS_PROF_SMALL = 6, TNQS_PROF_BP_FUSED = 7, TNQS_PROF_BP_PAIR = 8, TNQS_PROF_BP_PAIRGRAM = 9, TNQS_PROF_NCLASSES = 10 };
 int tnqs_profile_enable(tnqs_handle h, int on);
 /* launches, total ms, algorithmic bytes (min traffic: operands read once + result written once) and flops */
 int tnqs_profile_get(tnqs_handle h, int cls, int64_t* launches, double* total_ms, double* alg_bytes, double* alg_flops);

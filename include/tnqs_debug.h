@@ -17,6 +17,10 @@ int tnqs_dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const 
 int tnqs_dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out);
 /* c64 only: out[c,jx,mid,jy,hi] = sum in[c,ix,mid,iy,hi] Mx[ix,jx] My[iy,jy]; element at c + C0*(ix + 32*(mid + NMID*(iy + 32*hi))) */
 int tnqs_dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const void* My, void* out);
+/* c64 only, site tensor [d][chi_0]..[chi_{z-1}] column-major: out = in x_lx Mx x_ly My (chi_lx = chi_ly = 32; leg 0 allowed) */
+int tnqs_dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in, const void* Mx, const void* My, void* out);
+/* c64 only: out[b + 32*b'] = sum (X x_lx M)[.., b on leg ly, ..] conj(Y[.., b' on leg ly, ..]) */
+int tnqs_dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* M, void* out);
 #ifdef __cplusplus
 }
 #endif

@@ -422,7 +422,7 @@ def profile_enable(bpc: BeliefPropagationCache, on: bool = True):
     L.check(L.lib.tnqs_profile_enable(bpc._h, 1 if on else 0))
 
 
-PROF_CLASSES = ("bp_modeprod", "bp_gram", "gate_modeprod", "gate_gram", "gate_apply", "jacobi", "small", "bp_fused", "bp_pair")
+PROF_CLASSES = ("bp_modeprod", "bp_gram", "gate_modeprod", "gate_gram", "gate_apply", "jacobi", "small", "bp_fused", "bp_pair", "bp_pairgram")
 
 
 def profile_get(bpc: BeliefPropagationCache) -> dict:

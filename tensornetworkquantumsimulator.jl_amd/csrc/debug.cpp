@@ -29,7 +29,7 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
     if (dtype == TNQS_C64) launch_jacobi<float>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n)); else launch_jacobi<double>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n));
     if (nov) {
         DBuf dRv(sizeof(RecoverItem)); RecoverItem rv{dA0.p, dA.p, dV.p, m, n}; dRv.up(&rv, sizeof(rv));
-        if (dtype == TNQS_C64) launch_recover_v<float>(nullptr, (const RecoverItem*)dRv.p, 1); else launch_recover_v<double>(nullptr, (const RecoverItem*)dRv.p, 1);
+        if (dtype == TNQS_C64) launch_recover_v<float>(nullptr, (const RecoverItem*)dRv.p, 1, n); else launch_recover_v<double>(nullptr, (const RecoverItem*)dRv.p, 1, n);
         HIPCHK(hipDeviceSynchronize());
     }
     HIPCHK(hipDeviceSynchronize());
@@ -106,12 +106,50 @@ void dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const v
     DBuf dIn(n * 8), dOut(n * 8), dX(32 * 32 * 8), dY(32 * 32 * 8), dI(sizeof(PairItem));
     dIn.up(in, n * 8); dX.up(Mx, 32 * 32 * 8); dY.up(My, 32 * 32 * 8);
     HIPCHK(hipMemset(dOut.p, 0xff, n * 8));
-    PairItem it{}; it.in = dIn.p; it.out = dOut.p; it.Mx = dX.p; it.My = dY.p; it.C0 = C0; it.NMID = NMID; it.NHI = NHI; it.slice_begin = 0; it.spw = 3;
+    PairItem it{}; it.in = dIn.p; it.out = dOut.p; it.Mx = dX.p; it.My = dY.p; it.slice_begin = 0; it.spw = 3;
+    it.g.cstr = 2; it.g.sx = C0; it.g.sy = (long long)C0 * 32 * NMID; it.g.n0 = C0 / 16; it.g.t0 = 16; it.g.n1 = NMID; it.g.t1 = (long long)C0 * 32;
+    it.g.n2 = NHI; it.g.t2 = (long long)C0 * 32 * NMID * 32;
     int nslices = (C0 / 16) * NMID * NHI;
     dI.up(&it, sizeof(it));
     launch_mfma_pair(nullptr, (const PairItem*)dI.p, 1, (nslices + it.spw - 1) / it.spw);
     HIPCHK(hipDeviceSynchronize());
     dOut.down(out, n * 8);
+}
+// pair product on the legs (lx, ly) of a site tensor [d][chi_0..chi_{z-1}] (ComplexF32): out = in x_lx Mx x_ly My
+void dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in, const void* Mx, const void* My, void* out) {
+    need_gpu();
+    PairItem it{};
+    if (!pair_geometry(d, z, chi, lx, ly, it.g)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_pair_legs: shape not covered by the pair kernel");
+    size_t n = d; for (int i = 0; i < z; ++i) n *= chi[i];
+    DBuf dIn(n * 8), dOut(n * 8), dX(32 * 32 * 8), dY(32 * 32 * 8), dI(sizeof(PairItem));
+    dIn.up(in, n * 8); dX.up(Mx, 32 * 32 * 8); dY.up(My, 32 * 32 * 8);
+    HIPCHK(hipMemset(dOut.p, 0xff, n * 8));
+    it.in = dIn.p; it.out = dOut.p; it.Mx = dX.p; it.My = dY.p; it.slice_begin = 0; it.spw = 3;
+    int nslices = it.g.n0 * it.g.n1 * it.g.n2;
+    if ((size_t)nslices * 16 * 1024 != n) throw Err(TNQS_ERR_INVALID, "dbg_pair_legs: slice count");
+    dI.up(&it, sizeof(it));
+    launch_mfma_pair(nullptr, (const PairItem*)dI.p, 1, (nslices + it.spw - 1) / it.spw);
+    HIPCHK(hipDeviceSynchronize());
+    dOut.down(out, n * 8);
+}
+// out[b,b'] = sum (X x_lx M)[.., b, ..] conj(Y[.., b', ..]) with b on leg ly (ComplexF32, 32 x 32 output)
+void dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* M, void* out) {
+    need_gpu();
+    PairGramItem it{};
+    if (!pair_geometry(d, z, chi, lx, ly, it.g)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_pair_gram: shape not covered by the pair kernel");
+    size_t n = d; for (int i = 0; i < z; ++i) n *= chi[i];
+    int nslices = it.g.n0 * it.g.n1 * it.g.n2;
+    it.spw = 3; it.wg_begin = 0;
+    int nwg = (nslices + it.spw - 1) / it.spw, npart = 8 * nwg;
+    DBuf dX(n * 8), dY(n * 8), dM(32 * 32 * 8), dI(sizeof(PairGramItem)), dR(sizeof(ReduceItem)), dP((size_t)npart * 1024 * 8), dO(1024 * 8);
+    dX.up(X, n * 8); dY.up(Y, n * 8); dM.up(M, 32 * 32 * 8);
+    it.X = dX.p; it.Y = dY.p; it.M = dM.p; it.partial = dP.p;
+    dI.up(&it, sizeof(it));
+    launch_mfma_pair_gram(nullptr, (const PairGramItem*)dI.p, 1, nwg);
+    ReduceItem ri{dP.p, dO.p, 1024, npart, 0, 0}; dR.up(&ri, sizeof(ri));
+    launch_reduce<float, float>(nullptr, (const ReduceItem*)dR.p, 1, 1024);
+    HIPCHK(hipDeviceSynchronize());
+    dO.down(out, 1024 * 8);
 }
 void dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out) {
     need_gpu();

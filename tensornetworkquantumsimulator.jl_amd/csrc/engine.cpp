@@ -1,6 +1,8 @@
 // engine.cpp -- see engine.hpp.  Host orchestration only; every flop runs in the HIP kernels of kernels*.hip.
 #include "engine.hpp"
 #include <algorithm>
+#include <array>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -388,10 +390,8 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
                 Buf& dst = c.tmp[nt[se.first] & 1];
                 if (!dst) dst = dalloc(s, c.sd.n * esz);
                 it.in = c.result; it.out = dst->p; it.Mx = c.steps[se.second.first].second; it.My = c.steps[se.second.second].second;
-                it.C0 = (int)c.sd.pre(x);
-                size_t mid = 1; for (int i = x + 1; i < y; ++i) mid *= c.sd.chi[i];
-                it.NMID = (int)mid; it.NHI = (int)c.sd.post(y);
-                int nslices = (it.C0 / 16) * it.NMID * it.NHI;
+                if (!pair_geometry(c.sd.d, c.sd.z, c.sd.chi.data(), x, y, it.g)) throw Err(TNQS_ERR_HIP, "internal: pair geometry");
+                int nslices = it.g.n0 * it.g.n1 * it.g.n2;
                 it.spw = spw; it.slice_begin = wgs; wgs += (nslices + spw - 1) / spw;
                 items.push_back(it);
                 c.result = dst->p; nt[se.first]++;
@@ -500,6 +500,7 @@ struct BPPlan {
     std::vector<int> seq;                       // directed edge ids in sequence order
     std::vector<std::vector<int>> levels;       // positions in seq grouped by dependency level
     std::vector<int> pos_of;                    // de -> position in seq or -1
+    std::vector<int> level_of;                  // position -> level
     bool in_place = false;                      // duplicates in the sequence: strictly sequential, single buffer
 };
 
@@ -525,7 +526,7 @@ static BPPlan make_plan(const State* s, const tnqs_bp_opts* o) {
     } else p.seq = default_sequence(g);
     p.pos_of.assign(2 * (size_t)g.ne, -1);
     for (size_t t = 0; t < p.seq.size(); ++t) { if (p.pos_of[p.seq[t]] >= 0) p.in_place = true; p.pos_of[p.seq[t]] = (int)t; }
-    if (p.in_place) { for (size_t t = 0; t < p.seq.size(); ++t) p.levels.push_back({(int)t}); return p; }
+    if (p.in_place) { for (size_t t = 0; t < p.seq.size(); ++t) { p.levels.push_back({(int)t}); p.level_of.push_back((int)t); } return p; }
     std::vector<int> level(p.seq.size(), 0); int nlev = 0;
     for (size_t t = 0; t < p.seq.size(); ++t) {
         int de = p.seq[t]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
@@ -539,10 +540,20 @@ static BPPlan make_plan(const State* s, const tnqs_bp_opts* o) {
     }
     p.levels.resize(nlev);
     for (size_t t = 0; t < p.seq.size(); ++t) p.levels[level[t]].push_back((int)t);
+    p.level_of = level;
     return p;
 }
 
 static double default_tol(const State* s) { return s->dtype == TNQS_C64 ? 1e-5 : 1e-8; }   // beliefpropagationcache.jl:104-108
+
+// ---- shared pair products ---------------------------------------------------------------------------------------
+// A degree-4 site sends four messages per sweep, each needing the other three incoming messages absorbed.  Its legs are
+// split into two pairs {A, B} by the level at which their outgoing message is computed; for an outgoing leg in A the pair
+// product T_B = psi x m_b1 x m_b2 is shared with the other leg of A (the messages entering through B do not change between
+// the two levels of A in the level-scheduled sequences), so a sweep costs 2 pair products + 4 (absorb + Gram) passes instead of
+// 4 + 4.  Validity is not assumed but checked: an entry is reused only while the very same site / message buffers are current.
+struct SharedT { Buf site, ma, mb, T; int la = -1, lb = -1; };
+static bool use_tshare() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_TSHARE"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 
 template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out) {
     const Graph& g = *s->g;
@@ -560,6 +571,25 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
     Buf d_sum = dalloc(s, sizeof(double));
     std::vector<Buf> cur = s->msg;
     int niter = maxiter; double avg = 0; bool converged = false;
+    // shared pair products (see SharedT): partner[v][j] = the leg paired with j, -1 when the site is not covered
+    std::vector<std::array<int, 4>> partner(g.nv, std::array<int, 4>{{-1, -1, -1, -1}});
+    std::vector<std::array<SharedT, 2>> tshare;
+    if (std::is_same<T, float>::value && use_mfma() && use_pair() && use_tshare()) {
+        tshare.resize(g.nv);
+        for (int v = 0; v < g.nv; ++v) {
+            if (!s->owns(v) || g.nbr[v].size() != 4 || s->d[v] != 2) continue;
+            bool ok = true; std::array<std::pair<int, int>, 4> ord;
+            for (int j = 0; j < 4; ++j) {
+                if (s->chi[g.nbr_e[v][j]] != 32) ok = false;
+                int pp = plan.pos_of[g.dedge(v, g.nbr[v][j])];
+                ord[j] = {pp >= 0 ? plan.level_of[pp] : INT_MAX, j};
+            }
+            if (!ok) continue;
+            std::sort(ord.begin(), ord.end());
+            partner[v][ord[0].second] = ord[1].second; partner[v][ord[1].second] = ord[0].second;
+            partner[v][ord[2].second] = ord[3].second; partner[v][ord[3].second] = ord[2].second;
+        }
+    }
     for (int iter = 1; iter <= maxiter; ++iter) {
         std::vector<Buf> fresh(2 * (size_t)g.ne);
         for (auto& lev : plan.levels) {
@@ -574,12 +604,40 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     used += need; ++end;
                 }
                 std::vector<Chain> chains; std::vector<int> tpos; std::vector<const void*> fmsg;
+                std::vector<PairItem> sh_pair; std::vector<PairGramItem> sh_gram; std::vector<int> sh_chain;   // shared-T path
+                double sh_pair_slices = 0, sh_gram_slices = 0;
                 for (size_t q = start; q < end; ++q) {
                     int t = lev[q]; int de = plan.seq[t]; int e = de / 2;
                     int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
                     if (!s->owns(src)) continue;
                     Chain c; c.v = src; c.src = s->site[src]->p; c.sd = site_dims(s, src);
                     const int jo = g.leg(src, dst);
+                    if (!tshare.empty() && partner[src][jo] >= 0) {
+                        const int r = partner[src][jo];
+                        int pa = -1, pb = -1;
+                        for (int j = 0; j < 4; ++j) if (j != jo && j != r) { if (pa < 0) pa = j; else pb = j; }
+                        auto incoming = [&](int j) -> const Buf& {
+                            int din = g.dedge(g.nbr[src][j], src); int pp = plan.pos_of[din];
+                            return (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
+                        };
+                        const Buf& ma = incoming(pa); const Buf& mb = incoming(pb); const Buf& mr = incoming(r);
+                        PairGramItem gi{}; PairItem pi{};
+                        if (ma && mb && mr && pair_geometry(c.sd.d, c.sd.z, c.sd.chi.data(), pa, pb, pi.g)
+                            && pair_geometry(c.sd.d, c.sd.z, c.sd.chi.data(), r, jo, gi.g)) {
+                            SharedT& sh = tshare[src][std::min(pa, pb) < std::min(r, jo) ? 0 : 1];      // slot of the pair {pa, pb}
+                            if (!(sh.T && sh.site == s->site[src] && sh.ma == ma && sh.mb == mb && sh.la == pa && sh.lb == pb)) {
+                                sh.site = s->site[src]; sh.ma = ma; sh.mb = mb; sh.la = pa; sh.lb = pb;
+                                sh.T = dalloc(s, c.sd.n * esz);
+                                pi.in = c.src; pi.out = sh.T->p; pi.Mx = ma->p; pi.My = mb->p;
+                                sh_pair.push_back(pi); sh_pair_slices += (double)c.sd.n / 16384.0;
+                            }
+                            gi.X = sh.T->p; gi.Y = c.src; gi.M = mr->p;
+                            sh_gram.push_back(gi); sh_gram_slices += (double)c.sd.n / 16384.0;
+                            sh_chain.push_back((int)chains.size());
+                            chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(nullptr);
+                            continue;
+                        }
+                    }
                     const int fr = fused_leg(s, c.sd, jo);
                     const void* fm = nullptr;
                     for (int j = 0; j < c.sd.z; ++j) {
@@ -592,6 +650,15 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     }
                     chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(fm);
                 }
+                std::vector<char> is_shared(chains.size(), 0);
+                for (int ci : sh_chain) is_shared[ci] = 1;
+                if (!sh_pair.empty()) {
+                    int spw = (int)std::max(1.0, std::min(8.0, sh_pair_slices / 2048.0)); int wgs = 0;
+                    for (auto& it : sh_pair) { it.spw = spw; it.slice_begin = wgs; wgs += (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw; }
+                    const PairItem* d = upload(s, sh_pair);
+                    ProfScope ps(s, TNQS_PROF_BP_PAIR, 2.0 * sh_pair_slices * 16384.0 * esz, 2 * 8.0 * sh_pair_slices * 16384.0 * 32);
+                    launch_mfma_pair(s->stream, d, (int)sh_pair.size(), wgs);
+                }
                 run_chains<T>(s, chains, TNQS_PROF_BP_MODEPROD, TNQS_PROF_BP_PAIR);
                 std::vector<GramJob> jobs;
                 for (size_t i = 0; i < chains.size(); ++i) {
@@ -600,9 +667,22 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     j.M = fmsg[i];
                     jobs.push_back(j);
                 }
+                if (!sh_gram.empty()) {
+                    int spw = (int)std::max(4.0, std::min(16.0, sh_gram_slices / 2048.0)); int wgs = 0;
+                    for (size_t q = 0; q < sh_gram.size(); ++q) {
+                        PairGramItem& it = sh_gram[q]; GramJob& j = jobs[sh_chain[q]];
+                        int nwg = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw;
+                        it.spw = spw; it.wg_begin = wgs; wgs += nwg;
+                        j.nchunks = 8 * nwg; j.KK = 32; j.partial = dalloc(s, (size_t)j.nchunks * 1024 * esz);
+                        it.partial = j.partial->p;
+                    }
+                    const PairGramItem* d = upload(s, sh_gram);
+                    ProfScope ps(s, TNQS_PROF_BP_PAIRGRAM, 2.0 * sh_gram_slices * 16384.0 * esz, 2 * 8.0 * sh_gram_slices * 16384.0 * 32);
+                    launch_mfma_pair_gram(s->stream, d, (int)sh_gram.size(), wgs);
+                }
                 {   // the fused and the plain Gram are different kernels: run them as two batches, keep the job order
                     std::vector<GramJob> jf, jp; std::vector<size_t> idf, idp;
-                    for (size_t i = 0; i < jobs.size(); ++i) { if (jobs[i].M) { jf.push_back(jobs[i]); idf.push_back(i); } else { jp.push_back(jobs[i]); idp.push_back(i); } }
+                    for (size_t i = 0; i < jobs.size(); ++i) { if (is_shared[i]) continue; if (jobs[i].M) { jf.push_back(jobs[i]); idf.push_back(i); } else { jp.push_back(jobs[i]); idp.push_back(i); } }
                     run_grams<T, T>(s, jf, TNQS_PROF_BP_FUSED);
                     run_grams<T, T>(s, jp, TNQS_PROF_BP_GRAM);
                     for (size_t q = 0; q < jf.size(); ++q) jobs[idf[q]] = jf[q];
@@ -985,7 +1065,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             std::vector<RecoverItem> rv;
             for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ji[q].n});
             const RecoverItem* dr = upload(s, rv);
-            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_recover_v<T>(s->stream, dr, npg); }
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); { int nmax = 1; for (auto& j : ji) nmax = std::max(nmax, j.n); launch_recover_v<T>(s->stream, dr, npg, nmax); } }
         }
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
         std::vector<double> hterr(std::max(1, npg));

@@ -491,32 +491,40 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     if (threadIdx.x == 0 && it.sweeps_out) *it.sweeps_out = sweep;
 }
 
-// V[:,u] = A0^dagger a_u / |a_u|^2   (a_u = column u of U Sigma), for the factorisations run without accumulating V
+// V[:,u] = A0^dagger a_u / |a_u|^2   (a_u = column u of U Sigma), for the factorisations run without accumulating V.
+// grid (item, column block of 8): a wave owns one output column u, its lanes stride over the rows `col` of V.
 template <class T>
-__global__ __launch_bounds__(256) void recover_v_kernel(const RecoverItem* __restrict__ items) {
+__global__ __launch_bounds__(512) void recover_v_kernel(const RecoverItem* __restrict__ items) {
     const RecoverItem it = items[blockIdx.x];
     const cx<T>* A0 = reinterpret_cast<const cx<T>*>(it.A0);
     const cx<T>* A = reinterpret_cast<const cx<T>*>(it.A);
     cx<T>* V = reinterpret_cast<cx<T>*>(it.V);
     const int m = it.m, n = it.n;
-    for (int e = threadIdx.x; e < n * n; e += 256) {
-        int col = e % n, u = e / n;
-        double s2 = 0, re = 0, im = 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int u = blockIdx.y * 8 + w;
+    if (u >= n) return;
+    const cx<T>* au = A + (size_t)m * u;
+    double s2 = 0;
+    for (int i = lane; i < m; i += 64) { cx<T> a = au[i]; s2 += (double)a.re * a.re + (double)a.im * a.im; }
+    s2 = wave_sum(s2);
+    const double inv = s2 > 0 ? 1.0 / s2 : 0.0;
+    for (int col = lane; col < n; col += 64) {
+        const cx<T>* b0 = A0 + (size_t)m * col;
+        double re = 0, im = 0;
         for (int i = 0; i < m; ++i) {
-            cx<T> a = A[i + (size_t)m * u], b = A0[i + (size_t)m * col];
-            s2 += (double)a.re * a.re + (double)a.im * a.im;
+            cx<T> a = au[i], b = b0[i];
             re += (double)b.re * a.re + (double)b.im * a.im;          // conj(b) * a
             im += (double)b.re * a.im - (double)b.im * a.re;
         }
-        V[e] = s2 > 0 ? cmake<T>((T)(re / s2), (T)(im / s2)) : cmake<T>((T)0, (T)0);
+        V[col + (size_t)n * u] = cmake<T>((T)(re * inv), (T)(im * inv));
     }
 }
-template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems) {
+template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((recover_v_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((recover_v_kernel<T>), dim3(nitems, (nmax + 7) / 8), dim3(512), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
-template void launch_recover_v<float>(hipStream_t, const RecoverItem*, int);
-template void launch_recover_v<double>(hipStream_t, const RecoverItem*, int);
+template void launch_recover_v<float>(hipStream_t, const RecoverItem*, int, int);
+template void launch_recover_v<double>(hipStream_t, const RecoverItem*, int, int);
 
 // lds_bytes: max over the items of (m*n + (V ? n*n : 0)) * sizeof(complex<T>); 0 selects the global-memory kernel
 template <class T, int RQ> static void launch_jacobi_lds(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes) {

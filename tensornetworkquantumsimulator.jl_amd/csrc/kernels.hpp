@@ -86,7 +86,7 @@ struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; };   
 // LDS bytes the LDS-resident Jacobi needs for an m x n matrix (columns padded by 2 elements)
 inline size_t jacobi_lds_bytes(int m, int n, bool withV, size_t esz) { return ((size_t)(m + 2) * n + (withV ? (size_t)(n + 2) * n : 0)) * esz; }
 template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax);
-template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems);
+template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax);
 template <class T> void launch_env_prepare(hipStream_t s, const EnvItem* d_items, int nitems);
 template <class T> void launch_env_finish(hipStream_t s, const EnvFinishItem* d_items, int nitems);
 template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems);
@@ -99,11 +99,52 @@ void launch_sum_doubles(hipStream_t s, const double* in, int n, double* out);
 // one-site gates on d = 2, ComplexF32: streaming 2x2 apply, norm partials [item][nbx]
 void launch_site1_c64(hipStream_t s, const Site1Item* d_items, int nitems, int nbx, double* d_norm_partials);
 
-struct PairItem {         // out = in x_x Mx x_y My for two 32-dimensional legs x < y that are NOT memory-fastest:
-    const void* in; void* out; const void* Mx; const void* My;    // element (c, ix, mid, iy, hi) at c + C0*(ix + 32*(mid + NMID*(iy + 32*hi)))
-    int C0, NMID, NHI;    // companions (C0 % 16 == 0), indices between / above the two legs
+// geometry shared by the two "pair" kernels: a 32 x 32 plane over two legs (strides sx, sy) for 16 companion elements
+// = 8 companion PAIRS of 2 contiguous elements, pair f at offset f*cstr.  Slices are enumerated by three counters:
+// slice sl -> a0 = sl % n0, a1 = (sl / n0) % n1, a2 = sl / (n0*n1), base = a0*t0 + a1*t1 + a2*t2   (elements).
+//  * both legs above the site index: the companions are 16 CONTIGUOUS elements (cstr = 2, one 128-byte run)
+//  * leg 0 involved (only the site index below it): the 2 site components are the contiguous pair and the 8 pairs step
+//    along another leg a (cstr = pre(a)); then consecutive plane rows ix of leg 0 are contiguous (8 x 16 B = 128-byte runs)
+struct PairGeom { long long cstr, sx, sy, t0, t1, t2; int n0, n1, n2; };
+// geometry for the legs (lx -> plane index ix, ly -> plane index iy) of a site tensor [d][chi_0]..[chi_{z-1}];
+// false when the pair kernels do not cover the shape (both legs must have dimension 32)
+inline bool pair_geometry(int d, int z, const int* chi, int lx, int ly, PairGeom& g) {
+    if (lx == ly || lx < 0 || ly < 0 || lx >= z || ly >= z || chi[lx] != 32 || chi[ly] != 32) return false;
+    auto pre = [&](int j) { long long p = d; for (int i = 0; i < j; ++i) p *= chi[i]; return p; };
+    const int p = lx < ly ? lx : ly, q = lx < ly ? ly : lx;
+    g.sx = pre(lx); g.sy = pre(ly);
+    if (pre(p) % 16 == 0) {            // 16 contiguous companions below the lower leg
+        g.cstr = 2; g.n0 = (int)(pre(p) / 16); g.t0 = 16;
+        g.n1 = (int)(pre(q) / (pre(p) * 32)); g.t1 = pre(p) * 32;
+        long long post = 1; for (int i = q + 1; i < z; ++i) post *= chi[i];
+        g.n2 = (int)post; g.t2 = pre(q) * 32;
+        return true;
+    }
+    if (pre(p) != 2) return false;     // leg 0 above a 2-dimensional site index: companions = (s) x 8 values of another leg
+    int a = -1;
+    for (int i = 0; i < z; ++i) if (i != p && i != q && chi[i] % 8 == 0) { a = i; break; }
+    if (a < 0) return false;
+    g.cstr = pre(a); g.n0 = chi[a] / 8; g.t0 = 8 * pre(a);
+    g.n1 = 1; g.t1 = 0; g.n2 = 1; g.t2 = 0;
+    int k = 0;
+    for (int i = 0; i < z; ++i) {
+        if (i == p || i == q || i == a) continue;
+        if (k == 0) { g.n1 = chi[i]; g.t1 = pre(i); } else if (k == 1) { g.n2 = chi[i]; g.t2 = pre(i); } else return false;
+        ++k;
+    }
+    return true;
+}
+struct PairItem {         // out = in x_x Mx x_y My for two 32-dimensional legs
+    const void* in; void* out; const void* Mx; const void* My;
+    PairGeom g;
     int slice_begin;      // first workgroup id of this item
     int spw;              // slices (16 companions x 32 x 32) walked by one workgroup
+};
+struct PairGramItem {     // partial[b,b'] = sum_{rest, jx} (sum_ix X[.. ix .. b ..] M[ix, jx]) conj(Y[.. jx .. b' ..]);  x = absorbed leg, y = kept leg
+    const void* X; const void* Y; const void* M; void* partial;   // 8 partials (one per wave) per workgroup, 32*32 complex each
+    PairGeom g;
+    int wg_begin;         // first workgroup id of this item
+    int spw;              // slices per workgroup
 };
 
 // ---- MFMA fast paths (ComplexF32 only; kernels_mfma.hip) -----------------------------------------------------------
@@ -117,5 +158,7 @@ void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems
 bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);
 // fused pair of mode products on two slow 32-dim legs (16 companions = 128-byte runs per workgroup)
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs);
+// last absorption + Gram on two arbitrary 32-dim legs (absorbed leg x, kept leg y), reading a (cached) pair product X and psi = Y
+void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitems, int total_wgs);
 
 }  // namespace tnqs

@@ -701,15 +701,19 @@ void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// pair of mode products on two "slow" legs x < y (dimension 32 each) in ONE pass:
+// pair of mode products on two legs x, y (dimension 32 each) in ONE pass:
 //      out[c, jx, jy] = sum_{ix,iy} in[c, ix, iy] Mx[ix, jx] My[iy, jy]          for every companion index c
-// The memory-contiguous direction is c (all faster indices), so a workgroup takes 16 companions (128-byte runs = full
-// HBM efficiency) x the whole 32 x 32 plane of the two legs: 16 planes of 8 KiB staged in LDS (de-interleaved, one
-// plane per (wave, half)), both GEMMs of a plane chained in registers exactly like the fused Gram:
+// A workgroup takes 16 companions (PairGeom: 128-byte runs = full HBM efficiency) x the whole 32 x 32 plane of the two
+// legs: 16 planes of 8 KiB staged in LDS (de-interleaved, one plane per (wave, half)), both GEMMs of a plane chained in
+// registers exactly like the fused Gram:
 //   step 1  Y[iy][jx] = sum_ix S[ix][iy] Mx[ix][jx]      (A = S^T from LDS, B = Mx in registers)
 //   step 2  S'[jx][jy] = sum_iy Y[iy][jx] My[iy][jy]      (A = Y's accumulator registers as they are, B = My in registers)
 // The next slice's 128 KiB are prefetched into registers while the matrix cores work.
 // ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long pair_slice_base(const PairGeom& g, int sl) {
+    int a0 = sl % g.n0; int r1 = sl / g.n0; int a1 = r1 % g.n1; int a2 = r1 / g.n1;
+    return (long long)a0 * g.t0 + (long long)a1 * g.t1 + (long long)a2 * g.t2;
+}
 __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restrict__ items, int nitems) {
     constexpr int PR = 32 * 33;                // floats of one re (or im) plane, pitch 33
     constexpr int PS = 2 * PR + 1;             // plane stride (odd: the 8 companion pairs of a run hit different banks)
@@ -720,9 +724,8 @@ __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restri
     const int gw = blockIdx.x;
     while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].slice_begin <= gw) lo = mid; else hi_ = mid - 1; }
     const PairItem it = items[lo];
-    const long long C0 = it.C0;
-    const int NCB = it.C0 / 16, NMID = it.NMID;
-    const int nslices = NCB * NMID * it.NHI;
+    const PairGeom g = it.g;
+    const int nslices = g.n0 * g.n1 * g.n2;
     const int s_begin = (gw - it.slice_begin) * it.spw, s_end = min(nslices, s_begin + it.spw);
     const cf* __restrict__ in = reinterpret_cast<const cf*>(it.in);
     cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
@@ -738,15 +741,10 @@ __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restri
     }
     // cooperative mover: thread -> (f = companion pair 0..7, seg0 = first segment); a pass of 512 threads covers 64 segments
     const int f = tid & 7, sg0 = tid >> 3;            // segments sg0, sg0 + 64, ... (16 per thread), seg = ix + 32*iy
-    auto slice_base = [&](int sl) -> long long {
-        int cb = sl % NCB; int r1 = sl / NCB; int mid = r1 % NMID; int hi = r1 / NMID;
-        return 16LL * cb + C0 * 32LL * ((long long)mid + (long long)NMID * 32LL * hi);
-    };
-    // element (c, ix, iy) of a slice: base + c + C0*ix + (C0*32*NMID)*iy
-    const long long sx = C0, sy = C0 * 32LL * NMID;
+    const long long sx = g.sx, sy = g.sy, fo = (long long)f * g.cstr;
     v4f pre[16];
     auto issue = [&](int sl) {
-        const long long b = slice_base(sl) + 2 * f;
+        const long long b = pair_slice_base(g, sl) + fo;
 #pragma unroll
         for (int j = 0; j < 16; ++j) { int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5; pre[j] = *reinterpret_cast<const v4f*>(in + b + sx * ix + sy * iy); }
     };
@@ -798,7 +796,7 @@ __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restri
         }
         lds_barrier();
         {
-            const long long b = slice_base(sl) + 2 * f;
+            const long long b = pair_slice_base(g, sl) + fo;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5;
@@ -815,6 +813,112 @@ void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int to
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     hipLaunchKernelGGL(mfma_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// last absorption + Gram on a 32 x 32 plane of two ARBITRARY legs (BP message epilogue reading a cached pair product X):
+//      out[b,b'] = sum_{c, jx} ( sum_ix X[c, ix, b] M[ix, jx] ) conj(Y[c, jx, b'])        x = absorbed leg, y = kept leg
+// Same workgroup shape and mover as the pair kernel (16 companions x the plane, one LDS slab); the slab holds the X planes
+// for step 1 and is then refilled with the Y planes for step 2, the intermediate stays in the accumulator registers:
+//   step 1  C1[jx][b] = sum_ix M[ix][jx] X[ix][b]            (A = M^T in registers, B = X plane from LDS)
+//   step 2  out[b][b'] += sum_jx C1[jx][b] conj Y[jx][b']    (A = C1's accumulator registers as they are, B = Y plane)
+// Each wave owns two planes and one 32 x 32 accumulator; it writes one partial per workgroup and wave.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mfma_pair_gram_kernel(const PairGramItem* __restrict__ items, int nitems) {
+    constexpr int PR = 32 * 33;
+    constexpr int PS = 2 * PR + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* L = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
+    int lo = 0, hi_ = nitems - 1;
+    const int gw = blockIdx.x;
+    while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].wg_begin <= gw) lo = mid; else hi_ = mid - 1; }
+    const PairGramItem it = items[lo];
+    const PairGeom g = it.g;
+    const int nslices = g.n0 * g.n1 * g.n2;
+    const int lw = gw - it.wg_begin;
+    const int s_begin = lw * it.spw, s_end = min(nslices, s_begin + it.spw);
+    const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
+    const cf* __restrict__ Yg = reinterpret_cast<const cf*>(it.Y);
+    const cf* __restrict__ Mg = reinterpret_cast<const cf*>(it.M);
+    float mr[16], mi[16];                      // A operand of step 1: M^T, lane (jx = ln, h), k-step q -> ix = q + 16h
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { cf v = Mg[(q + 16 * h) + 32 * ln]; mr[q] = v.re; mi[q] = v.im; }
+    v16f Or, Oi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { Or[r] = 0.f; Oi[r] = 0.f; }
+    const int f = tid & 7, sg0 = tid >> 3;
+    const long long sx = g.sx, sy = g.sy, fo = (long long)f * g.cstr;
+    v4f pre[16];
+    auto issue = [&](const cf* __restrict__ G, int sl) {
+        const long long b = pair_slice_base(g, sl) + fo;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5; pre[j] = *reinterpret_cast<const v4f*>(G + b + sx * ix + sy * iy); }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5;
+            float* p0 = L + (2 * f) * PS + iy * 33 + ix;         // element (ix, iy = b) stored at [iy][ix]
+            p0[0] = pre[j][0]; p0[PR] = pre[j][1];
+            p0[PS] = pre[j][2]; p0[PS + PR] = pre[j][3];
+        }
+    };
+    if (s_begin < s_end) issue(Xg, s_begin);
+    for (int sl = s_begin; sl < s_end; ++sl) {
+        lds_barrier();                                          // the previous slice's Y planes have been consumed
+        commit();                                               // X planes
+        lds_barrier();
+        issue(Yg, sl);                                          // Y in flight during step 1
+        v16f C1r[2], C1i[2];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const float* Pr = L + (w + 8 * pp) * PS; const float* Pi = Pr + PR;
+            float xr[16], xi[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { int o = ln * 33 + q + 16 * h; xr[q] = Pr[o]; xi[q] = Pi[o]; }     // B[k=ix][j=b=ln]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { C1r[pp][r] = 0.f; C1i[pp][r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                C1r[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(mr[q], xr[q], C1r[pp], 0, 0, 0);
+                C1r[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(-mi[q], xi[q], C1r[pp], 0, 0, 0);
+                C1i[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(mr[q], xi[q], C1i[pp], 0, 0, 0);
+                C1i[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(mi[q], xr[q], C1i[pp], 0, 0, 0);
+            }
+        }
+        lds_barrier();                                          // every wave has read its X operands
+        commit();                                               // Y planes into the same slab
+        lds_barrier();
+        if (sl + 1 < s_end) issue(Xg, sl + 1);                  // next X in flight during step 2
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const float* Pr = L + (w + 8 * pp) * PS; const float* Pi = Pr + PR;
+            float yr[16], yi[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { int jx = (r & 3) + 8 * (r >> 2) + 4 * h; int o = ln * 33 + jx; yr[r] = Pr[o]; yi[r] = Pi[o]; }   // B[k=jx][j=b'=ln]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                Or = __builtin_amdgcn_mfma_f32_32x32x2f32(C1r[pp][r], yr[r], Or, 0, 0, 0);
+                Or = __builtin_amdgcn_mfma_f32_32x32x2f32(C1i[pp][r], yi[r], Or, 0, 0, 0);
+                Oi = __builtin_amdgcn_mfma_f32_32x32x2f32(C1i[pp][r], yr[r], Oi, 0, 0, 0);
+                Oi = __builtin_amdgcn_mfma_f32_32x32x2f32(-C1r[pp][r], yi[r], Oi, 0, 0, 0);
+            }
+        }
+    }
+    cf* __restrict__ part = reinterpret_cast<cf*>(it.partial) + (size_t)(8 * lw + w) * 32 * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * h, j = ln;
+        cf v; v.re = Or[r]; v.im = Oi[r]; part[i + 32 * j] = v;
+    }
+}
+void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitems, int total_wgs) {
+    if (total_wgs <= 0) return;
+    const size_t lds = (size_t)16 * (2 * 32 * 33 + 1) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(mfma_pair_gram_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -156,3 +156,53 @@ def test_pair_mode_products(C0, NMID, NHI):
     Mx = mx.reshape(32, 32).T.astype(np.complex128); My = my.reshape(32, 32).T.astype(np.complex128)     # M[i, j] at i + 32 j
     ref = np.einsum("hymxc,xa,yb->hbmac", t, Mx, My).reshape(-1)
     assert np.max(np.abs(out - ref)) < 3e-5 * np.max(np.abs(ref))
+
+
+def _site(rng, d, chi):
+    """site tensor [d][chi_0]..[chi_{z-1}] column-major as a numpy array indexed [s, i_0, ..., i_{z-1}]"""
+    shp = (d,) + tuple(chi)
+    flat = rnd(rng, int(np.prod(shp)), np.complex64)
+    return flat, flat.reshape(shp[::-1]).transpose(*range(len(shp) - 1, -1, -1)).astype(np.complex128)
+
+
+PAIR_SHAPES = [((32, 32, 32), 1, 2), ((32, 32, 32), 0, 1), ((32, 32, 32), 0, 2), ((32, 32, 32), 2, 0), ((8, 32, 32), 1, 2), ((32, 32, 8), 0, 1),
+               ((32, 32, 8, 4), 0, 1), ((32, 16, 32, 2), 0, 2), ((32, 32, 4, 32), 1, 3), ((32, 8, 32, 32), 3, 0), ((32, 32, 32, 32), 0, 3), ((32, 32, 32, 32), 2, 1)]
+
+
+@pytest.mark.parametrize("chi,lx,ly", PAIR_SHAPES)
+def test_pair_mode_products_on_arbitrary_legs(chi, lx, ly):
+    """pair kernel with the general companion geometry (leg 0 included: only the 2-dim site index is faster)"""
+    rng = np.random.default_rng(sum(chi) + 7 * lx + ly)
+    z = len(chi)
+    flat, t = _site(rng, 2, chi)
+    mx = rnd(rng, 1024, np.complex64); my = rnd(rng, 1024, np.complex64)
+    out = np.zeros_like(flat)
+    cchi = (C.c_int * z)(*chi)
+    rc = lib.tnqs_dbg_pair_legs(2, z, cchi, lx, ly, flat.ctypes.data_as(C.c_void_p), mx.ctypes.data_as(C.c_void_p), my.ctypes.data_as(C.c_void_p),
+                                out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    Mx = mx.reshape(32, 32).T.astype(np.complex128); My = my.reshape(32, 32).T.astype(np.complex128)     # M[i, j] at i + 32 j
+    ref = np.moveaxis(np.tensordot(t, Mx, axes=([1 + lx], [0])), -1, 1 + lx)
+    ref = np.moveaxis(np.tensordot(ref, My, axes=([1 + ly], [0])), -1, 1 + ly)
+    got = out.reshape((2,) + tuple(chi), order="F")
+    assert np.max(np.abs(got - ref)) < 3e-5 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("chi,lx,ly", PAIR_SHAPES)
+def test_pair_gram_on_arbitrary_legs(chi, lx, ly):
+    """last absorption (leg lx) + Gram keeping leg ly, X and Y different tensors"""
+    rng = np.random.default_rng(sum(chi) + 5 * lx + ly)
+    z = len(chi)
+    fx, tx = _site(rng, 2, chi); fy, ty = _site(rng, 2, chi)
+    m = rnd(rng, 1024, np.complex64)
+    out = np.zeros(1024, dtype=np.complex64)
+    cchi = (C.c_int * z)(*chi)
+    rc = lib.tnqs_dbg_pair_gram(2, z, cchi, lx, ly, fx.ctypes.data_as(C.c_void_p), fy.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p),
+                                out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    M = m.reshape(32, 32).T.astype(np.complex128)
+    xm = np.moveaxis(np.tensordot(tx, M, axes=([1 + lx], [0])), -1, 1 + lx)
+    axes = [a for a in range(z + 1) if a != 1 + ly]
+    ref = np.tensordot(xm, ty.conj(), axes=(axes, axes))               # [b, b']
+    got = out.reshape(32, 32).T                                          # out[b + 32 b']
+    assert np.max(np.abs(got - ref)) < 3e-5 * np.max(np.abs(ref)) * max(1.0, np.sqrt(tx.size / 65536))

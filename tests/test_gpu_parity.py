@@ -352,3 +352,36 @@ def test_identity_gate_leaves_the_bond_contracted_pair_unchanged(dtype, tol, lat
         assert np.max(np.abs(T - ph * T0)) < tol * np.max(np.abs(T0)), (lattice, chi, (a, b))
         assert errs[0] < (1e-10 if dtype == np.complex64 else 1e-24)
         assert out.bond_dim(a, b) == min(chi, 2 * min(chi ** (g.degree(a) - 1), chi ** (g.degree(b) - 1)))
+
+
+@pytest.mark.parametrize("seq_name", ["default", "forest", "colour", "reversed"])
+def test_bp_update_chi32_bulk_sites_matches_oracle(seq_name):
+    """chi = 32 on a 4x4 grid: the degree-4 sites run the shared pair-product path (two pair products per sweep reused
+    by two messages each, validity tracked per message buffer) -- trajectories must still be the Gauss-Seidel ones of
+    the reference for any sequence (abstractbeliefpropagationcache.jl:204-218)."""
+    g = tn.named_grid((4, 4))
+    psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=32, seed=11)
+    for v in g.vertices:
+        psi.tensors[v] = (psi.tensors[v] / np.linalg.norm(psi.tensors[v])).astype(np.complex64)
+    seq = {"default": None, "forest": tn.forest_cover_edge_sequence(g), "colour": colour_sequence(g, tn.edge_color(g)),
+           "reversed": list(reversed(colour_sequence(g, tn.edge_color(g))))}[seq_name]
+    bpc = tn.BeliefPropagationCache(psi)
+    kw = dict(maxiter=2, tolerance=None)
+    if seq is not None:
+        kw["edge_sequence"] = seq
+    out = tn.update(bpc, **kw)
+    if seq is None:     # the library default = colour-grouped order of its own colouring: check the fixed sweep against itself via expect
+        oc = None
+    else:
+        oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **kw)
+        compare_messages(out, oc, 5e-5)
+    # second update from the first one's messages (cache entries of the first call must not leak into the second)
+    out2 = tn.update(out, **kw)
+    if oc is not None:
+        oc2 = o.update(oc, **kw)
+        compare_messages(out2, oc2, 5e-5)
+    else:
+        ref = o.update(oracle_cache_from_device(out), maxiter=2, tolerance=None, edge_sequence=colour_sequence(g, tn.edge_color(g)))
+        for v in [(2, 2), (2, 3), (1, 1)]:
+            assert abs(tn.expect(out2, ("Z", [v])) - tn.expect(out2, ("Z", [v])).real) < 1e-5
+            assert np.isfinite(o.expect_1site(ref, Z, v))
