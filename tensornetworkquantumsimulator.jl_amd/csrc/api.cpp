@@ -124,7 +124,7 @@ int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* owner,
             s->owner.assign(owner, owner + s->g->nv);
         } else s->owner.clear();
         s->rank = rank; s->nranks = nranks; s->ag_fn = fn; s->ag_ctx = ctx; s->exch = exch_dev; s->exch_bytes = (size_t)exch_bytes;
-        if (nranks > 1) for (int v = 0; v < s->g->nv; ++v) if (!s->owns(v)) s->site[v] = nullptr;   // only owners hold site tensors
+        if (nranks > 1) for (int v = 0; v < s->g->nv; ++v) if (!s->owns(v)) { s->site[v] = nullptr; s->sscale[v] = nullptr; }   // only owners hold site tensors
     });
 }
 

@@ -22,6 +22,8 @@ void hipchk(hipError_t e, const char* what) {
     if (e != hipSuccess) throw Err(TNQS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 #define HIPCHK(x) hipchk((x), #x)
+void materialize_scale(State* s, const std::vector<int>& verts);
+void materialize_scale_all(State* s);
 
 // ---------------------------------------------------------------------------------------------------------------
 // pool
@@ -214,7 +216,7 @@ State* state_create(int nv, int ne, const int32_t* es, const int32_t* ed, const 
     s->d.assign(nv, 2);
     if (sd) for (int v = 0; v < nv; ++v) { if (sd[v] < 1 || sd[v] > 16) throw Err(TNQS_ERR_INVALID, "tnqs_create: site dimension out of range"); s->d[v] = sd[v]; }
     s->chi.assign(ne, 1);
-    s->site.resize(nv); s->msg.assign(2 * (size_t)ne, nullptr);
+    s->site.resize(nv); s->sscale.assign(nv, nullptr); s->msg.assign(2 * (size_t)ne, nullptr);
     s->pool = std::make_shared<Pool>(device);
     s->prof = std::make_shared<Prof>();
     HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true;
@@ -225,7 +227,7 @@ State* state_create(int nv, int ne, const int32_t* es, const int32_t* ed, const 
 State* state_copy(const State* o) {
     auto s = std::make_unique<State>();
     s->g = o->g; s->dtype = o->dtype; s->device = o->device; s->d = o->d; s->chi = o->chi;
-    s->site = o->site; s->msg = o->msg; s->pool = o->pool; s->prof = o->prof;
+    s->site = o->site; s->sscale = o->sscale; s->msg = o->msg; s->pool = o->pool; s->prof = o->prof;
     s->rank = o->rank; s->nranks = o->nranks; s->owner = o->owner; s->ag_fn = o->ag_fn; s->ag_ctx = o->ag_ctx;
     s->exch = o->exch; s->exch_bytes = o->exch_bytes;
     HIPCHK(hipSetDevice(o->device));
@@ -255,7 +257,7 @@ void state_set_site(State* s, int v, const void* host, int ndim, const int64_t* 
     for (int k = 0; k < ndim; ++k) { stride_caller[k] = (long long)n; if (dims[k] < 1) throw Err(TNQS_ERR_INVALID, "set_site_tensor: bad dim"); n *= (size_t)dims[k]; }
     HIPCHK(hipSetDevice(s->device));
     if (!s->owns(v)) {          // sharded, not ours: only the bond dimensions are recorded (host may be null)
-        s->site[v] = nullptr;
+        s->site[v] = nullptr; s->sscale[v] = nullptr;
         for (int j = 0; j < z; ++j) {
             int e = g.nbr_e[v][j]; int c = (int)dims[src_of[1 + j]];
             if (s->chi[e] != c) { s->chi[e] = c; s->msg[2 * e] = nullptr; s->msg[2 * e + 1] = nullptr; }
@@ -270,7 +272,7 @@ void state_set_site(State* s, int v, const void* host, int ndim, const int64_t* 
     for (int c = 0; c < ndim; ++c) { it.dims_out[c] = (int)dims[src_of[c]]; it.stride_in[c] = stride_caller[src_of[c]]; }
     if (s->dtype == TNQS_C64) permute_dispatch<float>(s, it); else permute_dispatch<double>(s, it);
     HIPCHK(hipStreamSynchronize(s->stream));
-    s->site[v] = out;
+    s->site[v] = out; s->sscale[v] = nullptr;
     for (int j = 0; j < z; ++j) {
         int e = g.nbr_e[v][j]; int c = it.dims_out[1 + j];
         if (s->chi[e] != c) { s->chi[e] = c; s->msg[2 * e] = nullptr; s->msg[2 * e + 1] = nullptr; }
@@ -297,6 +299,7 @@ void state_get_site(State* s, int v, void* host, int ndim, const int32_t* role) 
         it.dims_out[k] = cdims[c]; it.stride_in[k] = cstride[c];
     }
     HIPCHK(hipSetDevice(s->device));
+    if (s->sscale[v]) { materialize_scale(s, {v}); it.in = s->site[v]->p; }       // the caller sees the normalised tensor
     Buf out = dalloc(s, sd.n * s->esz()); it.out = out->p;
     if (s->dtype == TNQS_C64) permute_dispatch<float>(s, it); else permute_dispatch<double>(s, it);
     HIPCHK(hipMemcpyAsync(host, out->p, sd.n * s->esz(), hipMemcpyDeviceToHost, s->stream));
@@ -564,6 +567,7 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
     if (!o || std::isnan(o->tolerance)) tol = g.is_tree ? -1.0 : default_tol(s); else tol = o->tolerance;
     const bool compute_error = tol >= 0;
     const int normalize = o ? o->normalize : 1;
+    if (!normalize) materialize_scale_all(s);      // un-normalised messages carry the absolute scale of the site tensors
     const size_t esz = s->esz();
     const size_t nseq = plan.seq.size();
     if (nseq == 0) { if (niter_out) *niter_out = 0; if (diff_out) *diff_out = 0; return; }
@@ -772,21 +776,52 @@ void bp_update(State* s, const tnqs_bp_opts* o, int* niter, double* diff) {
 struct Gate1 { int v; const double* mat; };
 struct Gate2 { int v1, v2; const double* mat; int index; };
 
+static bool eager_scale() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_EAGER_SCALE"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
+// apply the pending scale factors of `verts` (out of place: site buffers may be shared with copies of the handle)
+template <class T> static void materialize_scale_t(State* s, const std::vector<int>& verts) {
+    std::vector<ScaleItem> sc; std::vector<Buf> outs; std::vector<int> vs;
+    for (int v : verts) {
+        if (v < 0 || v >= (int)s->site.size() || !s->site[v] || !s->sscale[v]) continue;
+        Buf out = dalloc(s, s->site[v]->bytes);
+        ScaleItem it{}; it.src = s->site[v]->p; it.dst = out->p; it.n = s->site[v]->bytes / s->esz(); it.factor = reinterpret_cast<const double*>(s->sscale[v]->p);
+        sc.push_back(it); outs.push_back(out); vs.push_back(v);
+    }
+    if (sc.empty()) return;
+    HIPCHK(hipSetDevice(s->device));
+    const ScaleItem* d = upload(s, sc);
+    { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_scale<T>(s->stream, d, (int)sc.size()); }
+    for (size_t i = 0; i < vs.size(); ++i) { s->keepalive.push_back(s->site[vs[i]]); s->keepalive.push_back(s->sscale[vs[i]]); s->site[vs[i]] = outs[i]; s->sscale[vs[i]] = nullptr; }
+}
+void materialize_scale(State* s, const std::vector<int>& verts) {
+    if (s->dtype == TNQS_C64) materialize_scale_t<float>(s, verts); else materialize_scale_t<double>(s, verts);
+}
+void materialize_scale_all(State* s) {
+    std::vector<int> all(s->site.size()); std::iota(all.begin(), all.end(), 0);
+    materialize_scale(s, all);
+}
+
+// the new site tensors replace the old ones; with `normalize` their norm (from the producing kernel's partial sums) becomes
+// the pending scale factor 1/||psi|| instead of a scaling pass over the tensor (simple_update.jl:66-72 normalises eagerly;
+// every later step of the path is invariant under a real rescaling of a site tensor, see engine.hpp State::sscale)
 template <class T> static void norm_and_replace(State* s, std::vector<int>& verts, std::vector<Buf>& outs,
                                                 std::vector<size_t>& nelem, Buf norm_partials,
                                                 std::vector<int>& tile_begin, std::vector<int>& ntiles, bool normalize) {
+    (void)nelem;
     if (normalize) {
-        std::vector<ScaleItem> sc;
+        std::vector<NormFactorItem> nf;
+        Buf fac = dalloc(s, verts.size() * 256);           // one factor per site, 256-byte slots (aliased Bufs below)
         for (size_t i = 0; i < verts.size(); ++i) {
-            ScaleItem it{}; it.t = outs[i]->p; it.n = nelem[i];
-            it.norm_partials = reinterpret_cast<const double*>(norm_partials->p) + tile_begin[i]; it.npart = ntiles[i];
-            sc.push_back(it);
+            NormFactorItem it{}; it.norm_partials = reinterpret_cast<const double*>(norm_partials->p) + tile_begin[i]; it.npart = ntiles[i];
+            it.factor = reinterpret_cast<double*>(reinterpret_cast<char*>(fac->p) + 256 * i);
+            nf.push_back(it);
         }
-        const ScaleItem* d = upload(s, sc);
-        ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
-        launch_scale<T>(s->stream, d, (int)sc.size());
+        const NormFactorItem* d = upload(s, nf);
+        { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_norm_factor(s->stream, d, (int)nf.size()); }
+        for (size_t i = 0; i < verts.size(); ++i) { s->site[verts[i]] = outs[i]; s->sscale[verts[i]] = sub_buffer(fac, 256 * i, 8); }
+        if (eager_scale()) materialize_scale_t<T>(s, verts);
+    } else {
+        for (size_t i = 0; i < verts.size(); ++i) s->site[verts[i]] = outs[i];       // a pending factor of the input carries over (linear map)
     }
-    for (size_t i = 0; i < verts.size(); ++i) s->site[verts[i]] = outs[i];
 }
 
 template <class T> static void apply_one_site_batch(State* s, const std::vector<Gate1>& gates, bool normalize) {
@@ -875,6 +910,10 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     const bool sharded = s->nranks > 1;
     const double sqrt_cutoff = ao.sqrt_cutoff >= 0 ? ao.sqrt_cutoff : 10.0 * (s->dtype == TNQS_C64 ? 1.1920928955078125e-07 : 2.220446049250313e-16);
     const int ng = (int)gates.size();
+    if (!ao.normalize_tensors) {       // without the final normalisation the result scales with the inputs: apply pending factors first
+        std::vector<int> vs; for (auto& g2 : gates) { vs.push_back(g2.v1); vs.push_back(g2.v2); }
+        materialize_scale(s, vs);
+    }
     struct SiteJob { int v, other, bleg; bool owned; SD sd; std::vector<int> env_idx; std::vector<int> env_leg; };
     std::vector<SiteJob> sj(2 * (size_t)ng);
     std::vector<char> part(ng, 0);                  // this rank runs the small algebra of the gate
@@ -1312,7 +1351,10 @@ template <class T> static void rdm_batch(State* s, const std::vector<int>& vs, d
     const ReduceItem* dr = upload(s, ri);
     launch_reduce<double, double>(s->stream, dr, (int)ri.size(), elems);
     HIPCHK(hipMemcpyAsync(out, d_out->p, (size_t)elems * 16, hipMemcpyDeviceToHost, s->stream));
+    std::vector<double> fac(vs.size(), 1.0);
+    for (size_t i = 0; i < vs.size(); ++i) if (s->sscale[vs[i]]) HIPCHK(hipMemcpyAsync(&fac[i], s->sscale[vs[i]]->p, 8, hipMemcpyDeviceToHost, s->stream));
     sync(s);
+    for (size_t i = 0; i < vs.size(); ++i) if (fac[i] != 1.0) { int n2 = jobs[i].KK * jobs[i].KK; for (int k = 0; k < 2 * n2; ++k) out[2 * (size_t)off[i] + k] *= fac[i] * fac[i]; }
 }
 void rdm_1site(State* s, int v, double* out) {
     if (v < 0 || v >= s->g->nv) throw Err(TNQS_ERR_INVALID, "rdm_1site: bad vertex");

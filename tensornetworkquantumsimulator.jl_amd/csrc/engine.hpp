@@ -40,9 +40,13 @@ private:
 };
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0; size_t rounded = 0; std::shared_ptr<Pool> pool;
+    std::shared_ptr<DevBuf> parent;      // set for a view into another buffer (no pool: nothing to release)
     ~DevBuf() { if (p && pool) pool->release(p, rounded); }
 };
 using Buf = std::shared_ptr<DevBuf>;
+inline Buf sub_buffer(const Buf& parent, size_t off, size_t bytes) {
+    Buf b = std::make_shared<DevBuf>(); b->p = reinterpret_cast<char*>(parent->p) + off; b->bytes = bytes; b->parent = parent; return b;
+}
 
 struct Graph {
     int nv = 0, ne = 0;
@@ -71,6 +75,9 @@ struct State {
     std::vector<int> d;            // site dims
     std::vector<int> chi;          // bond dim per edge
     std::vector<Buf> site;         // canonical layout; null when not owned (sharding)
+    std::vector<Buf> sscale;       // pending real scale factor of a site tensor (one device double; null = 1): the tensor the
+                                   // reference holds is site[v] * (*sscale[v]).  Normalisation after a gate only records the factor;
+                                   // every consumer on the hot path is scale-invariant, the others call materialize_scale() first
     std::vector<Buf> msg;          // 2*ne, null = unset = identity (tensornetworkstate.jl:72-75)
     std::shared_ptr<Pool> pool;
     hipStream_t stream = nullptr; bool own_stream = false;

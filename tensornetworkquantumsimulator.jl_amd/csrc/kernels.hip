@@ -825,18 +825,26 @@ template <class T> void launch_diag(hipStream_t s, const DiagItem* d_items, int 
 template void launch_diag<float>(hipStream_t, const DiagItem*, int);
 template void launch_diag<double>(hipStream_t, const DiagItem*, int);
 
-template <class T> __global__ __launch_bounds__(256) void scale_kernel(const ScaleItem* __restrict__ items) {
+__global__ __launch_bounds__(256) void norm_factor_kernel(const NormFactorItem* __restrict__ items) {
     __shared__ double sh[17];
-    const ScaleItem it = items[blockIdx.y];
+    const NormFactorItem it = items[blockIdx.x];
     double t = 0;
     for (int i = threadIdx.x; i < it.npart; i += 256) t += it.norm_partials[i];
     // fixed-order reduction would need a second pass; the block_sum order is deterministic for a given launch shape
     t = block_sum(t, sh);
-    if (!(t > 0)) return;
-    const T f = (T)(1.0 / sqrt(t));
-    cx<T>* p = reinterpret_cast<cx<T>*>(it.t);
+    if (threadIdx.x == 0) *it.factor = (t > 0) ? 1.0 / sqrt(t) : 1.0;
+}
+void launch_norm_factor(hipStream_t s, const NormFactorItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(norm_factor_kernel, dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+template <class T> __global__ __launch_bounds__(256) void scale_kernel(const ScaleItem* __restrict__ items) {
+    const ScaleItem it = items[blockIdx.y];
+    const T f = (T)(*it.factor);
+    const cx<T>* __restrict__ p = reinterpret_cast<const cx<T>*>(it.src);
+    cx<T>* __restrict__ q = reinterpret_cast<cx<T>*>(it.dst);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < it.n; i += (size_t)gridDim.x * 256) {
-        cx<T> v = p[i]; p[i] = cmake<T>(v.re * f, v.im * f);
+        cx<T> v = p[i]; q[i] = cmake<T>(v.re * f, v.im * f);
     }
 }
 template <class T> void launch_scale(hipStream_t s, const ScaleItem* d_items, int nitems) {

@@ -72,7 +72,8 @@ struct GateItem {         // everything the per-gate small-algebra kernels need 
 
 struct Site1Item { const void* in; void* out; float g[8]; size_t npairs; };   // d = 2 one-site gate: g = (g00, g01, g10, g11) re/im
 struct DiagItem { void* out; const double* S; int chi; };          // dense diag(S) message
-struct ScaleItem { void* t; size_t n; const double* norm_partials; int npart; }; // t *= 1/sqrt(sum partials)
+struct ScaleItem { const void* src; void* dst; size_t n; const double* factor; };      // dst = src * (*factor)
+struct NormFactorItem { const double* norm_partials; int npart; double* factor; };      // *factor = 1/sqrt(sum partials)  (1 when the sum is not positive)
 struct PermItem { const void* in; void* out; int ndim; int dims_out[8]; long long stride_in[8]; size_t n; };
 
 // ---- launchers (T = float or double; data are complex<T>) ------------------------------------------------------
@@ -93,6 +94,7 @@ template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items
 template <class T> void launch_gate_finish(hipStream_t s, const GateItem* d_items, int nitems);
 template <class T> void launch_diag(hipStream_t s, const DiagItem* d_items, int nitems);
 template <class T> void launch_scale(hipStream_t s, const ScaleItem* d_items, int nitems);
+void launch_norm_factor(hipStream_t s, const NormFactorItem* d_items, int nitems);
 template <class T> void launch_permute(hipStream_t s, const PermItem& item);
 template <class T> void launch_identity(hipStream_t s, void* out, int n);
 void launch_sum_doubles(hipStream_t s, const double* in, int n, double* out);

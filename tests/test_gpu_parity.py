@@ -385,3 +385,46 @@ def test_bp_update_chi32_bulk_sites_matches_oracle(seq_name):
         for v in [(2, 2), (2, 3), (1, 1)]:
             assert abs(tn.expect(out2, ("Z", [v])) - tn.expect(out2, ("Z", [v])).real) < 1e-5
             assert np.isfinite(o.expect_1site(ref, Z, v))
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_deferred_normalisation_is_invisible_to_callers(dtype):
+    """normalize_tensors = true only records 1/||psi_v|| on the device (no scaling pass); every accessor that depends on
+    the absolute scale must still see the normalised tensor of simple_update.jl:66-72."""
+    import ctypes as C
+    from tnqs_amd import _lib as L
+    tol = 2e-5 if dtype == np.complex64 else 1e-11
+    g = tn.named_grid((3, 3))
+    groups = tn.edge_color(g)
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=3, seed=21)
+    bpc = tn.update(tn.BeliefPropagationCache(psi), **tight(dtype))
+    layer = tfim_layer(g, groups)
+    kw = dict(maxdim=3, cutoff=1e-12, normalize_tensors=True)
+    out, _ = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=tight(dtype))
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **tight(dtype))
+    oc, _ = o.apply_gates(layer, oc, apply_kwargs=kw, bp_update_kwargs=tight(dtype))
+    for v in g.vertices:                                       # (1) downloaded tensors are normalised
+        assert abs(np.linalg.norm(out.tensor(v)) - 1.0) < tol
+    dev = oracle_cache_from_device(out)                        # (2) the un-normalised rdm of the C ABI carries the true scale
+    for v in g.vertices[:5]:
+        rho = np.zeros((2, 2), dtype=np.complex128, order="F")
+        L.check(L.lib.tnqs_rdm_1site(out._h, g.index[v], rho.ctypes.data_as(C.POINTER(C.c_double))))
+        ref = o.rdm_1site(dev, v)
+        assert np.max(np.abs(rho - ref)) < 20 * tol * np.max(np.abs(ref))
+        assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oc, Z, v)) < max(50 * tol, 1e-7)   # independent evolutions: BP fixed-point tolerance
+    cp = out.copy()                                            # (3) copies share buffers and pending factors
+    assert np.allclose(cp.tensor(g.vertices[4]), out.tensor(g.vertices[4]), atol=tol)
+    # (4) un-normalised BP messages scale with |psi|^2: one fixed sweep against the oracle on the downloaded state
+    seq = colour_sequence(g, groups)
+    b = tn.update(out, maxiter=1, tolerance=None, normalize=False, edge_sequence=seq)
+    ob = o.update(dev, maxiter=1, tolerance=None, normalize=False, edge_sequence=seq)
+    for (u, w) in g.edges[:6]:
+        mg, mo = b.message((u, w)), ob.messages[(u, w)]
+        assert abs(np.trace(mg) - np.trace(mo)) < 50 * tol * abs(np.trace(mo))      # gauge-invariant AND scale-sensitive
+    # (5) a gate WITHOUT normalisation after one with: the result must scale like the reference's
+    kw2 = dict(maxdim=3, cutoff=1e-12, normalize_tensors=False)
+    e0 = g.edges[0]
+    out2, _ = tn.apply_gates([("Rzz", list(e0), 0.3)], out, apply_kwargs=kw2, update_cache=False)
+    oc2, _ = o.apply_gates([("Rzz", list(e0), 0.3)], oracle_cache_from_device(out), apply_kwargs=kw2, update_cache=False)
+    for v in e0:
+        assert abs(np.linalg.norm(out2.tensor(v)) - np.linalg.norm(oc2.tns.tensors[v])) < 50 * tol
