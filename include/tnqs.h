@@ -69,6 +69,8 @@ typedef struct {
     int n_two_site;         /* two-site gates applied */
     int bp_not_converged;   /* updates that hit maxiter (reference: @warn, abstract...:245-252) */
     double last_bp_diff;
+    int n_chol_fallbacks;   /* gate batches whose Gram matrices were numerically rank-deficient (eigen path instead of Cholesky) */
+    int reserved_;
 } tnqs_apply_stats;
 
 /* ---- library ---------------------------------------------------------------------------------------- */

@@ -16,6 +16,8 @@ namespace tnqs {
 static size_t bp_ws_budget() { static size_t v = 0; if (!v) { const char* e = std::getenv("TNQS_BP_WS_MB"); v = (e ? (size_t)std::atoll(e) : (size_t)24576) << 20; } return v; }
 static size_t jacobi_lds(size_t bytes) { static int g = -1; if (g < 0) { const char* e = std::getenv("TNQS_JACOBI_GLOBAL"); g = (e && e[0] == '1') ? 1 : 0; } return (g || bytes > 160 * 1024 - 64) ? 0 : bytes; }
 static int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j : ji) m = std::max(m, std::max(j.m, j.n)); return m; }
+static bool use_chol() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_CHOL"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
+static bool use_small_svd() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_SMALLSVD"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_mfma() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_MFMA"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 
 void hipchk(hipError_t e, const char* what) {
@@ -616,7 +618,7 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     if (!s->owns(src)) continue;
                     Chain c; c.v = src; c.src = s->site[src]->p; c.sd = site_dims(s, src);
                     const int jo = g.leg(src, dst);
-                    if (!tshare.empty() && partner[src][jo] >= 0) {
+                    if (!tshare.empty() && c.sd.z == 4 && partner[src][jo] >= 0) {
                         const int r = partner[src][jo];
                         int pa = -1, pb = -1;
                         for (int j = 0; j < 4; ++j) if (j != jo && j != r) { if (pa < 0) pa = j; else pb = j; }
@@ -1002,14 +1004,52 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                 HIPCHK(hipMemcpyAsync(GA[i]->p, reinterpret_cast<char*>(s->exch) + (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16, hipMemcpyDeviceToDevice, s->stream));
             }
         }
-        std::vector<JacobiItem> ji; std::vector<EnvItem> idn;
+    }
+    // R factor of psi~ = Q R from G = R^dagger R: Cholesky (R = L^dagger) where G has full rank by construction (at least as
+    // many fibers as columns); the f64 Jacobi eigen factorisation R = Lambda^1/2 W^dagger otherwise, and for the whole batch when
+    // a Cholesky pivot collapses (numerically rank-deficient G; the eigen path drops the null space, TNQS_RANK_TAU)
+    std::vector<Buf> GW(sj.size()); std::vector<char> is_chol(sj.size(), 0);
+    std::vector<const void*> gauged_of(sj.size(), nullptr);      // psi~ of the owned sites
+    for (size_t q = 0; q < own_idx.size(); ++q) gauged_of[own_idx[q]] = chains[q].result;
+    Buf d_cholfail = dalloc(s, sizeof(int));
+    auto factor_G = [&](bool allow_chol) {
+        std::vector<JacobiItem> ji, sji; std::vector<EnvItem> idn; std::vector<CholItem> ci; std::vector<SmallSvdItem> si; int cmax = 1;
+        HIPCHK(hipMemsetAsync(d_cholfail->p, 0, sizeof(int), s->stream));
         for (size_t i = 0; i < sj.size(); ++i) {
             if (!part[i / 2]) continue;
+            if (!allow_chol && GV[i] && !is_chol[i]) continue;      // fallback pass: the eigen sites are already factorised (GA rotated in place)
             int n = nof(i);
-            GV[i] = dalloc(s, (size_t)n * n * 16);
-            idn.push_back(EnvItem{nullptr, GV[i]->p, GV[i]->p, n});      // msg == null: H := I, V := I (same buffer)
-            ji.push_back(JacobiItem{GA[i]->p, GV[i]->p, n, n, nullptr});
+            if (!GV[i]) GV[i] = dalloc(s, (size_t)n * n * 16);
+            const size_t Nout = sj[i].sd.n / (size_t)n;
+            const bool ch = allow_chol && n <= 96 && Nout >= (size_t)n;
+            is_chol[i] = ch ? 1 : 0;
+            if (!ch && sj[i].owned && Nout < (size_t)n && n <= 256 && use_small_svd()) {
+                // fewer fibers than columns: R = Sigma U^dagger straight from the SVD of the n x N matricised psi~ (no rank-deficient G)
+                GW[i] = GV[i];
+                Buf M = dalloc(s, (size_t)n * Nout * 16); s->keepalive.push_back(M);
+                const SD& sd = sj[i].sd; const int b = sj[i].bleg;
+                si.push_back(SmallSvdItem{gauged_of[i], M->p, GA[i]->p, GV[i]->p, sd.d, (int)(sd.pre(b) / sd.d), sd.chi[b], (int)sd.post(b)});
+                sji.push_back(JacobiItem{M->p, nullptr, n, (int)Nout, nullptr});
+                continue;
+            }
+            if (ch) {
+                GW[i] = dalloc(s, (size_t)n * n * 16);
+                ci.push_back(CholItem{GA[i]->p, GV[i]->p, GW[i]->p, n, reinterpret_cast<int*>(d_cholfail->p)}); cmax = std::max(cmax, n);
+            } else {
+                GW[i] = GV[i];
+                idn.push_back(EnvItem{nullptr, GV[i]->p, GV[i]->p, n});      // msg == null: H := I, V := I (same buffer)
+                ji.push_back(JacobiItem{GA[i]->p, GV[i]->p, n, n, nullptr});
+            }
         }
+        if (!si.empty()) {
+            const SmallSvdItem* ds = upload(s, si); const JacobiItem* dj = upload(s, sji);
+            ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0);
+            launch_small_svd_prepare<T>(s->stream, ds, (int)si.size());
+            size_t lds = 0; for (auto& j : sji) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, false, 16));
+            launch_jacobi<double>(s->stream, dj, (int)sji.size(), 60, jacobi_lds(lds), mmax_of(sji));
+            launch_small_svd_finish(s->stream, ds, (int)si.size());
+        }
+        if (!ci.empty()) { const CholItem* dc = upload(s, ci); ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_chol(s->stream, dc, (int)ci.size(), cmax); }
         if (!ji.empty()) {
             const EnvItem* di = upload(s, idn);
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)idn.size()); }
@@ -1017,7 +1057,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             size_t lds = 0; for (auto& j : ji) lds = std::max(lds, jacobi_lds_bytes(j.n, j.n, true, 16));
             { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60, jacobi_lds(lds), mmax_of(ji)); }
         }
-    }
+    };
+    factor_G(use_chol());
     // ---- 4. theta = gate . (R1 R2), SVD, truncation, X1 / X2  (simple_update.jl:51-59) -----------------------------
     struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S; int n1, n2, chi, cap; };
     std::vector<GateWS> ws(ng);
@@ -1061,6 +1102,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             w.X1 = dalloc(s, (size_t)w.n1 * a.sd.d * cap * esz); w.X2 = dalloc(s, (size_t)w.n2 * b.sd.d * cap * esz);
             w.S = dalloc(s, cap * 8);
             it.GA1 = GA[2 * gi]->p; it.GV1 = GV[2 * gi]->p; it.GA2 = GA[2 * gi + 1]->p; it.GV2 = GV[2 * gi + 1]->p;
+            it.GW1 = GW[2 * gi]->p; it.GW2 = GW[2 * gi + 1]->p; it.chol1 = is_chol[2 * gi]; it.chol2 = is_chol[2 * gi + 1];
             it.n1 = w.n1; it.n2 = w.n2; it.d1 = a.sd.d; it.d2 = b.sd.d; it.chi = w.chi;
             it.gate = reinterpret_cast<const double*>(d_gm + off[q]);
             it.lam1 = (double*)w.lam1->p; it.lam2 = (double*)w.lam2->p; it.idx1 = (int*)w.idx1->p; it.idx2 = (int*)w.idx2->p;
@@ -1080,9 +1122,21 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     {
         // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
         std::vector<int> hinfo(8 * (size_t)std::max(1, npg));
+        int chol_failed = 0;
         if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
         if (!envs.empty()) HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags->p, 2 * envs.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(&chol_failed, d_cholfail->p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
+        if (chol_failed) {              // numerically rank-deficient Gram matrix somewhere in the batch: redo with the eigen path
+            factor_G(false);
+            for (int q = 0; q < npg; ++q) { int gi = pg[q]; GateItem& it = gitems[q]; it.GW1 = GW[2 * gi]->p; it.GW2 = GW[2 * gi + 1]->p; it.chol1 = 0; it.chol2 = 0; }
+            d_gitems = upload(s, gitems);
+            HIPCHK(hipMemsetAsync(d_info_all->p, 0, std::max<size_t>(1, (size_t)npg * 32), s->stream));
+            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_theta<T>(s->stream, d_gitems, npg); }
+            if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+            s->stats.n_chol_fallbacks += 1;
+        }
         for (size_t i = 0; i < envs.size(); ++i)
             if (h_flags[2 * i + 1]) throw Err(TNQS_ERR_NUMERIC, "simple_update: incoming message has a negative eigenvalue above sqrt_cutoff (DomainError in the reference, src/utils.jl:21)");
         std::vector<JacobiItem> ji;

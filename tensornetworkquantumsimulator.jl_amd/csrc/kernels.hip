@@ -492,9 +492,11 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
 }
 
 // V[:,u] = A0^dagger a_u / |a_u|^2   (a_u = column u of U Sigma), for the factorisations run without accumulating V.
-// grid (item, column block of 8): a wave owns one output column u, its lanes stride over the rows `col` of V.
+// grid (item, column block of 8): a wave owns one output column u and keeps a_u in registers (lanes = rows, coalesced);
+// every V[col, u] is one coalesced column read of A0 and a wave reduction.
 template <class T>
 __global__ __launch_bounds__(512) void recover_v_kernel(const RecoverItem* __restrict__ items) {
+    constexpr int R = 4;                     // m <= 256 rows
     const RecoverItem it = items[blockIdx.x];
     const cx<T>* A0 = reinterpret_cast<const cx<T>*>(it.A0);
     const cx<T>* A = reinterpret_cast<const cx<T>*>(it.A);
@@ -503,20 +505,25 @@ __global__ __launch_bounds__(512) void recover_v_kernel(const RecoverItem* __res
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int u = blockIdx.y * 8 + w;
     if (u >= n) return;
-    const cx<T>* au = A + (size_t)m * u;
-    double s2 = 0;
-    for (int i = lane; i < m; i += 64) { cx<T> a = au[i]; s2 += (double)a.re * a.re + (double)a.im * a.im; }
+    double are[R], aim[R], s2 = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int i = lane + 64 * r;
+        cx<T> a = (i < m) ? A[i + (size_t)m * u] : cmake<T>((T)0, (T)0);
+        are[r] = a.re; aim[r] = a.im; s2 += are[r] * are[r] + aim[r] * aim[r];
+    }
     s2 = wave_sum(s2);
     const double inv = s2 > 0 ? 1.0 / s2 : 0.0;
-    for (int col = lane; col < n; col += 64) {
+    for (int col = 0; col < n; ++col) {
         const cx<T>* b0 = A0 + (size_t)m * col;
         double re = 0, im = 0;
-        for (int i = 0; i < m; ++i) {
-            cx<T> a = au[i], b = b0[i];
-            re += (double)b.re * a.re + (double)b.im * a.im;          // conj(b) * a
-            im += (double)b.re * a.im - (double)b.im * a.re;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int i = lane + 64 * r;
+            if (i < m) { cx<T> b = b0[i]; re += (double)b.re * are[r] + (double)b.im * aim[r]; im += (double)b.re * aim[r] - (double)b.im * are[r]; }   // conj(b) * a
         }
-        V[col + (size_t)n * u] = cmake<T>((T)(re * inv), (T)(im * inv));
+        re = wave_sum(re); im = wave_sum(im);
+        if (lane == 0) V[col + (size_t)n * u] = cmake<T>((T)(re * inv), (T)(im * inv));
     }
 }
 template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax) {
@@ -546,6 +553,129 @@ template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, 
 }
 template void launch_jacobi<float>(hipStream_t, const JacobiItem*, int, int, size_t, int);
 template void launch_jacobi<double>(hipStream_t, const JacobiItem*, int, int, size_t, int);
+
+// ------------------------------------------------------------------------------------------------------------
+// small sites (N < n): matricise psi~ to f64, and turn the rotated columns (U Sigma) into the (A, V) pair gate_eigs reads
+// ------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void small_svd_prepare_kernel(const SmallSvdItem* __restrict__ items) {
+    const SmallSvdItem it = items[blockIdx.x];
+    const cx<T>* src = reinterpret_cast<const cx<T>*>(it.src);
+    cx<double>* M = reinterpret_cast<cx<double>*>(it.M);
+    const int n = it.d * it.chi_b; const size_t tot = (size_t)n * it.low * it.hi;
+    for (size_t e = threadIdx.x; e < tot; e += 256) {
+        int s = (int)(e % it.d); size_t r = e / it.d; int lo = (int)(r % it.low); size_t r2 = r / it.low; int ib = (int)(r2 % it.chi_b); int hi = (int)(r2 / it.chi_b);
+        cx<T> v = src[e];
+        M[(s + it.d * ib) + (size_t)n * (lo + (size_t)it.low * hi)] = cmake<double>((double)v.re, -(double)v.im);     // M = Psi^dagger: G = M M^dagger, eigenvectors = left singular vectors
+    }
+}
+template <class T> void launch_small_svd_prepare(hipStream_t s, const SmallSvdItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((small_svd_prepare_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+template void launch_small_svd_prepare<float>(hipStream_t, const SmallSvdItem*, int);
+template void launch_small_svd_prepare<double>(hipStream_t, const SmallSvdItem*, int);
+// column j of M J = sigma_j u_j:  V[:,j] = u_j, A[:,j] = sigma_j^2 u_j (so that Re(v_j^dagger a_j) = sigma_j^2 = the eigenvalue of G)
+__global__ __launch_bounds__(256) void small_svd_finish_kernel(const SmallSvdItem* __restrict__ items) {
+    const SmallSvdItem it = items[blockIdx.x];
+    const cx<double>* M = reinterpret_cast<const cx<double>*>(it.M);
+    cx<double>* A = reinterpret_cast<cx<double>*>(it.GA);
+    cx<double>* V = reinterpret_cast<cx<double>*>(it.GV);
+    const int n = it.d * it.chi_b, N = it.low * it.hi;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int j = w; j < n; j += 4) {
+        double s2 = 0;
+        if (j < N) for (int i = lane; i < n; i += 64) { cx<double> v = M[i + (size_t)n * j]; s2 += v.re * v.re + v.im * v.im; }
+        s2 = wave_sum(s2);
+        const double sg = sqrt(s2), inv = sg > 0 ? 1.0 / sg : 0.0;
+        for (int i = lane; i < n; i += 64) {
+            cx<double> v = (j < N) ? M[i + (size_t)n * j] : cmake<double>(0, 0);
+            V[i + (size_t)n * j] = cmake<double>(v.re * inv, v.im * inv);
+            A[i + (size_t)n * j] = cmake<double>(v.re * sg, v.im * sg);
+        }
+    }
+}
+void launch_small_svd_finish(hipStream_t s, const SmallSvdItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(small_svd_finish_kernel, dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+
+#define TNQS_RANK_TAU 1e-12
+// ------------------------------------------------------------------------------------------------------------
+// Cholesky factor of the Gram matrix (the R factor of the thin QR, simple_update.jl:45-48, when G has full rank)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double s_piv; __shared__ double s_dmax;
+    const CholItem it = items[blockIdx.x];
+    const int n = it.n, np = n + 1, tid = threadIdx.x;
+    cx<double>* A = reinterpret_cast<cx<double>*>(smem);          // [col j][row i] at i + np*j, lower triangle becomes L
+    const cx<double>* G = reinterpret_cast<const cx<double>*>(it.G);
+    for (int e = tid; e < n * n; e += 256) {                       // Hermitian part, as the eigen path sees it
+        int i = e % n, j = e / n; cx<double> a = G[i + (size_t)n * j], b = G[j + (size_t)n * i];
+        A[i + np * j] = cmake<double>(0.5 * (a.re + b.re), 0.5 * (a.im - b.im));
+    }
+    __syncthreads();
+    if (tid == 0) { double m = 0; for (int i = 0; i < n; ++i) m = fmax(m, A[i + np * i].re); s_dmax = m; }
+    __syncthreads();
+    const double tiny = TNQS_RANK_TAU * s_dmax;
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) {
+            double d = A[k + np * k].re;
+            if (!(d > tiny)) { *it.fail = 1; d = (tiny > 0 ? tiny : 1.0); }
+            s_piv = sqrt(d);
+        }
+        __syncthreads();
+        const double inv = 1.0 / s_piv;
+        for (int i = k + tid; i < n; i += 256) {
+            if (i == k) A[k + np * k] = cmake<double>(s_piv, 0.0);
+            else { cx<double> v = A[i + np * k]; A[i + np * k] = cmake<double>(v.re * inv, v.im * inv); }
+        }
+        __syncthreads();
+        const int m = n - k - 1;                                   // trailing update, lower triangle: A[i][j] -= L[i][k] conj(L[j][k])
+        for (int e = tid; e < m * m; e += 256) {
+            int i = k + 1 + e % m, j = k + 1 + e / m;
+            if (i < j) continue;
+            cx<double> li = A[i + np * k], lj = A[j + np * k];
+            cx<double> v = A[i + np * j];
+            v.re -= li.re * lj.re + li.im * lj.im; v.im -= li.im * lj.re - li.re * lj.im;
+            A[i + np * j] = v;
+        }
+        __syncthreads();
+    }
+    cx<double>* L = reinterpret_cast<cx<double>*>(it.L);
+    cx<double>* W = reinterpret_cast<cx<double>*>(it.Winv);
+    for (int e = tid; e < n * n; e += 256) { int i = e % n, j = e / n; L[e] = (i >= j) ? A[i + np * j] : cmake<double>(0, 0); }
+    __syncthreads();
+    // column c of L^-1 by forward substitution, thread per column; conj(Linv[i, c]) (i > c) goes to the free strict upper triangle
+    // A[c + np*i] (L[i][j] is a broadcast read, the x_j of neighbouring threads are neighbouring addresses)
+    for (int c = tid; c < n; c += 256) {
+        const double dc = 1.0 / A[c + np * c].re;
+        for (int i = c + 1; i < n; ++i) {
+            cx<double> l = A[i + np * c];
+            cx<double> acc = cmake<double>(-l.re * dc, -l.im * dc);                 // - L[i][c] x_c
+            for (int j = c + 1; j < i; ++j) {
+                cx<double> lj = A[i + np * j], x = A[c + np * j]; x.im = -x.im;      // stored conjugated
+                acc.re -= lj.re * x.re - lj.im * x.im; acc.im -= lj.re * x.im + lj.im * x.re;
+            }
+            const double inv = 1.0 / A[i + np * i].re;
+            A[c + np * i] = cmake<double>(acc.re * inv, -acc.im * inv);
+        }
+    }
+    __syncthreads();
+    // W = (L^-1)^dagger (upper triangular): W[i + n*a] = conj(Linv[a, i])
+    for (int e = tid; e < n * n; e += 256) {
+        int i = e % n, a = e / n;
+        W[e] = (i < a) ? A[i + np * a] : (i == a ? cmake<double>(1.0 / A[i + np * i].re, 0.0) : cmake<double>(0, 0));
+    }
+}
+void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {
+    if (nitems <= 0) return;
+    const size_t lds = (size_t)nmax * (nmax + 1) * 16;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 64)); attr = true; }
+    hipLaunchKernelGGL(chol_kernel, dim3(nitems), dim3(256), lds, s, d_items); TNQS_CHECK_LAUNCH();
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // environment square roots  (src/utils.jl:18-27 with safe_eigen :94-108: always f64)
@@ -624,7 +754,6 @@ template void launch_env_finish<double>(hipStream_t, const EnvFinishItem*, int);
 // per-gate small algebra.  With G_i = psi~_i^dagger psi~_i = W L W^dagger:  R_i = L^{1/2} W^dagger (any
 // orthogonal factorisation psi~ = Q R gives the same gauge-invariant result as the reference's QR).
 // ------------------------------------------------------------------------------------------------------------
-#define TNQS_RANK_TAU 1e-12
 
 __device__ void gate_eigs(const cx<double>* A, const cx<double>* V, int n, double* lam_tmp /*LDS n*/, double* lam_out,
                           int* idx_out, int* r_out, int* s_r /*LDS*/) {
@@ -645,8 +774,15 @@ __device__ void gate_eigs(const cx<double>* A, const cx<double>* V, int n, doubl
     __syncthreads();
 }
 
+// Cholesky site: R = L^dagger is read through the same (eigenvector, eigenvalue) interface with lambda = 1, all columns kept
+__device__ void gate_full_rank(int n, double* lam_out, int* idx_out, int* r_out, int* s_r) {
+    for (int j = threadIdx.x; j < n; j += blockDim.x) { lam_out[j] = 1.0; idx_out[j] = j; }
+    if (threadIdx.x == 0) { *r_out = n; *s_r = n; }
+    __syncthreads();
+}
+
 template <class T>
-__global__ __launch_bounds__(256) void gate_theta_kernel(const GateItem* __restrict__ items) {
+__global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __restrict__ items) {
     __shared__ double lam_tmp[256];
     __shared__ int s_r1, s_r2;
     const GateItem it = items[blockIdx.x];
@@ -654,8 +790,8 @@ __global__ __launch_bounds__(256) void gate_theta_kernel(const GateItem* __restr
     const cx<double>* V1 = reinterpret_cast<const cx<double>*>(it.GV1);
     const cx<double>* A2 = reinterpret_cast<const cx<double>*>(it.GA2);
     const cx<double>* V2 = reinterpret_cast<const cx<double>*>(it.GV2);
-    gate_eigs(A1, V1, it.n1, lam_tmp, it.lam1, it.idx1, &it.info[0], &s_r1);
-    gate_eigs(A2, V2, it.n2, lam_tmp, it.lam2, it.idx2, &it.info[1], &s_r2);
+    if (it.chol1) gate_full_rank(it.n1, it.lam1, it.idx1, &it.info[0], &s_r1); else gate_eigs(A1, V1, it.n1, lam_tmp, it.lam1, it.idx1, &it.info[0], &s_r1);
+    if (it.chol2) gate_full_rank(it.n2, it.lam2, it.idx2, &it.info[1], &s_r2); else gate_eigs(A2, V2, it.n2, lam_tmp, it.lam2, it.idx2, &it.info[1], &s_r2);
     const int r1 = s_r1, r2 = s_r2, d1 = it.d1, d2 = it.d2, chi = it.chi;
     const int Mr = r1 * d1, Nc = r2 * d2;
     const bool wide = Mr < Nc;
@@ -664,7 +800,7 @@ __global__ __launch_bounds__(256) void gate_theta_kernel(const GateItem* __restr
     const cx<double>* g = reinterpret_cast<const cx<double>*>(it.gate);
     const int dd = d1 * d2;
     // theta[(a,s1'),(c,s2')] = sum_{s1,s2} g[(s1' s2'),(s1 s2)] sum_b R1[a,(s1,b)] R2[c,(s2,b)],  R_i[a,(s,b)] = sqrt(l_a) conj(W_i[(s,b),a])
-    for (int e = threadIdx.x; e < Mr * Nc; e += 256) {
+    for (int e = threadIdx.x; e < Mr * Nc; e += blockDim.x) {
         int row = e % Mr, col = e / Mr;
         int a = row % r1, s1p = row / r1, c = col % r2, s2p = col / r2;
         const cx<double>* w1 = V1 + (size_t)it.n1 * it.idx1[a];
@@ -690,18 +826,18 @@ __global__ __launch_bounds__(256) void gate_theta_kernel(const GateItem* __restr
         else { cx<T> v = cmake<T>((T)(acc.re * sc), (T)(-acc.im * sc)); th[col + (size_t)Nc * row] = v; if (th0) th0[col + (size_t)Nc * row] = v; }
     }
     const int nI = wide ? Mr : Nc;
-    for (int e = threadIdx.x; e < nI * nI; e += 256) tv[e] = cmake<T>((e % nI) == (e / nI) ? (T)1 : (T)0, (T)0);
+    for (int e = threadIdx.x; e < nI * nI; e += blockDim.x) tv[e] = cmake<T>((e % nI) == (e / nI) ? (T)1 : (T)0, (T)0);
     if (threadIdx.x == 0) it.info[5] = wide ? 1 : 0;
 }
 template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((gate_theta_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gate_theta_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_gate_theta<float>(hipStream_t, const GateItem*, int);
 template void launch_gate_theta<double>(hipStream_t, const GateItem*, int);
 
 template <class T>
-__global__ __launch_bounds__(256) void gate_finish_kernel(const GateItem* __restrict__ items) {
+__global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __restrict__ items) {
     __shared__ double sig[256];
     __shared__ int perm[256];
     __shared__ int s_keep;
@@ -712,13 +848,13 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const GateItem* __rest
     const int ncol = wide ? Mr : Nc, ld = wide ? Nc : Mr;
     const cx<T>* th = reinterpret_cast<const cx<T>*>(it.theta);      // rotated columns: U Sigma (or V Sigma when wide)
     const cx<T>* tv = reinterpret_cast<const cx<T>*>(it.thetaV);     // accumulated rotations: V (or U when wide)
-    for (int u = threadIdx.x; u < ncol; u += 256) {
+    for (int u = threadIdx.x; u < ncol; u += blockDim.x) {
         double s2 = 0;
         for (int i = 0; i < ld; ++i) { cx<T> v = th[i + (size_t)ld * u]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
         sig[u] = (s2 == s2 && s2 < 1e300) ? sqrt(s2) : 0.0;     // a NaN / inf column must not poison the ranking below
     }
     __syncthreads();
-    for (int u = threadIdx.x; u < ncol; u += 256) {    // rank by counting (descending, stable)
+    for (int u = threadIdx.x; u < ncol; u += blockDim.x) {    // rank by counting (descending, stable)
         int rk = 0; double su = sig[u];
         for (int v = 0; v < ncol; ++v) rk += (sig[v] > su) || (sig[v] == su && v < u);
         perm[rk] = u;
@@ -755,13 +891,13 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const GateItem* __rest
     }
     __syncthreads();
     const int nk = s_keep;
-    const cx<double>* V1 = reinterpret_cast<const cx<double>*>(it.GV1);
-    const cx<double>* V2 = reinterpret_cast<const cx<double>*>(it.GV2);
+    const cx<double>* V1 = reinterpret_cast<const cx<double>*>(it.GW1);       // R^+ = W diag(lambda^-1/2)
+    const cx<double>* V2 = reinterpret_cast<const cx<double>*>(it.GW2);
     cx<T>* X1 = reinterpret_cast<cx<T>*>(it.X1);
     cx<T>* X2 = reinterpret_cast<cx<T>*>(it.X2);
     const int n1 = it.n1, n2 = it.n2;
     // X1[(s,b),(s1',u)] = sum_a W1[(s,b),a] / sqrt(l1_a) * (U Sigma)[(a,s1'),pi(u)] / sqrt(sigma_u)
-    for (int e = threadIdx.x; e < n1 * d1 * nk; e += 256) {
+    for (int e = threadIdx.x; e < n1 * d1 * nk; e += blockDim.x) {
         int kk = e % n1, nn = e / n1;
         int s1p = nn % d1, u = nn / d1;
         int pu = perm[u];
@@ -781,7 +917,7 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const GateItem* __rest
         X1[e] = cmake<T>((T)acc.re, (T)acc.im);
     }
     // X2[(s,b),(s2',u)] = sum_c W2[(s,b),c] / sqrt(l2_c) * sqrt(sigma_u) conj(Vtheta[(c,s2'),pi(u)])
-    for (int e = threadIdx.x; e < n2 * d2 * nk; e += 256) {
+    for (int e = threadIdx.x; e < n2 * d2 * nk; e += blockDim.x) {
         int kk = e % n2, nn = e / n2;
         int s2p = nn % d2, u = nn / d2;
         int pu = perm[u];
@@ -802,7 +938,7 @@ __global__ __launch_bounds__(256) void gate_finish_kernel(const GateItem* __rest
 }
 template <class T> void launch_gate_finish(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((gate_finish_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gate_finish_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_gate_finish<float>(hipStream_t, const GateItem*, int);
 template void launch_gate_finish<double>(hipStream_t, const GateItem*, int);

@@ -55,6 +55,9 @@ struct EnvFinishItem {    // (H rotated, V) -> M^{1/2} and P = M^{1/2} M^{-1/2} 
 struct GateItem {         // everything the per-gate small-algebra kernels need (pointers into the workspace)
     // Gram factors: Jacobi output for G1, G2 (f64): A = G V, V
     const void* GA1; const void* GV1; const void* GA2; const void* GV2;
+    // pseudo-inverse factor W with R^+ = W diag(lambda^-1/2): the eigenvectors again, or (Cholesky sites) the conjugate-transposed
+    // inverse triangle; chol != 0: lambda = 1 and every column is kept (GA unused, GV = L with R = L^dagger)
+    const void* GW1; const void* GW2; int chol1, chol2;
     int n1, n2;           // d1*chi, d2*chi
     int d1, d2, chi;      // bond dim before the gate
     const double* gate;   // (d1 d2) x (d1 d2) complex128 column-major, first vertex most significant
@@ -87,6 +90,15 @@ struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; };   
 // LDS bytes the LDS-resident Jacobi needs for an m x n matrix (columns padded by 2 elements)
 inline size_t jacobi_lds_bytes(int m, int n, bool withV, size_t esz) { return ((size_t)(m + 2) * n + (withV ? (size_t)(n + 2) * n : 0)) * esz; }
 template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax);
+// sites with fewer fibers than columns (N < n = d*chi): the R factor comes from a one-sided Jacobi SVD of the n x N matrix
+// M[(s,b), outer] = conj(psi~[outer,(s,b)]) (f64) instead of the eigen factorisation of the rank-deficient n x n Gram matrix
+struct SmallSvdItem { const void* src; void* M; void* GA; void* GV; int d, low, chi_b, hi; };   // low = pre(b)/d, hi = post(b); n = d*chi_b, N = low*hi
+template <class T> void launch_small_svd_prepare(hipStream_t s, const SmallSvdItem* d_items, int nitems);
+void launch_small_svd_finish(hipStream_t s, const SmallSvdItem* d_items, int nitems);
+// Cholesky of a Hermitian positive definite n x n f64 matrix (column-major): L (lower, G = L L^dagger) and Winv = (L^-1)^dagger;
+// *fail is set when a pivot drops below 1e-12 * max diagonal (the caller falls back to the eigen factorisation)
+struct CholItem { const void* G; void* L; void* Winv; int n; int* fail; };
+void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax);
 template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax);
 template <class T> void launch_env_prepare(hipStream_t s, const EnvItem* d_items, int nitems);
 template <class T> void launch_env_finish(hipStream_t s, const EnvFinishItem* d_items, int nitems);
