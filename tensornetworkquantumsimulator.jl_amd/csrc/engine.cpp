@@ -18,6 +18,7 @@ static size_t jacobi_lds(size_t bytes) { static int g = -1; if (g < 0) { const c
 static int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j : ji) m = std::max(m, std::max(j.m, j.n)); return m; }
 static bool use_chol() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_CHOL"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_small_svd() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_SMALLSVD"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
+static bool use_apply64() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_APPLY64"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_mfma() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_MFMA"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 
 void hipchk(hipError_t e, const char* what) {
@@ -1229,7 +1230,35 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         int TR = pick_TR(KKmax, esz, 1);
         bool mf = false;
         if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)NNmax); if (t > 0) { TR = t; mf = true; } }
+        // plane kernel for the common shape d = 2, chi_b = chi_b' = 32 (pair-kernel geometry, two waves per SIMD)
+        std::vector<Apply64Item> a64; std::vector<XbItem> xbi; std::vector<int> a64_verts; std::vector<Buf> a64_outs; std::vector<size_t> a64_ne;
+        std::vector<char> via64(own_idx.size(), 0); double a64_slices = 0;
+        if (std::is_same<T, float>::value && use_mfma() && use_apply64()) {
+            for (size_t q = 0; q < own_idx.size(); ++q) {
+                size_t i = own_idx[q]; int gi = (int)i / 2; const SiteJob& j = sj[i];
+                Apply64Item it{};
+                if (info[8 * gi + 2] != 32 || j.sd.chi[j.bleg] != 32 || !apply64_geometry(j.sd.d, j.sd.z, j.sd.chi.data(), j.bleg, it.g)) continue;
+                Buf out = dalloc(s, j.sd.n * esz); Buf xb = dalloc(s, 2048 * 16); s->keepalive.push_back(xb);
+                it.in = pch[q].result; it.out = out->p; it.Xb = xb->p;
+                xbi.push_back(XbItem{(i & 1) ? ws[gi].X2->p : ws[gi].X1->p, xb->p});
+                a64.push_back(it); a64_verts.push_back(j.v); a64_outs.push_back(out); a64_ne.push_back(j.sd.n);
+                a64_slices += (double)j.sd.n / 16384.0; via64[q] = 1;
+            }
+        }
+        if (!a64.empty()) {
+            const int spw = (int)std::max(1.0, std::min(8.0, a64_slices / 2048.0));
+            std::vector<int> tb64, nt64; int wgs = 0;
+            for (auto& it : a64) { int nwg = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw; it.spw = spw; it.wg_begin = wgs; tb64.push_back(wgs); nt64.push_back(nwg); wgs += nwg; }
+            Buf np64 = dalloc(s, (size_t)wgs * sizeof(double));
+            for (size_t k = 0; k < a64.size(); ++k) a64[k].norm_partial = ao.normalize_tensors ? reinterpret_cast<double*>(np64->p) + tb64[k] : nullptr;
+            const XbItem* dx = upload(s, xbi); const Apply64Item* da = upload(s, a64);
+            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_make_xb(s->stream, dx, (int)xbi.size()); }
+            { ProfScope ps(s, TNQS_PROF_GATE_APPLY, 2.0 * a64_slices * 16384.0 * esz, 8.0 * a64_slices * 16384.0 * 64);
+              launch_mfma_apply64(s->stream, da, (int)a64.size(), wgs); }
+            norm_and_replace<T>(s, a64_verts, a64_outs, a64_ne, np64, tb64, nt64, ao.normalize_tensors != 0);
+        }
         for (size_t q = 0; q < own_idx.size(); ++q) {
+            if (via64[q]) continue;
             size_t i = own_idx[q];
             int gi = (int)i / 2; int chin = info[8 * gi + 2];
             const SiteJob& j = sj[i];
@@ -1249,6 +1278,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         }
         Buf np = dalloc(s, std::max(1, tiles) * sizeof(double));
         const FiberItem* d = upload(s, items);
+        if (!items.empty())
         { ProfScope ps(s, TNQS_PROF_GATE_APPLY, bytes, flops);
           if (mf) launch_mfma_fiber_gemm(s->stream, d, (int)items.size(), tiles, (int)KKmax, (int)NNmax, reinterpret_cast<double*>(np->p));
           else launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }

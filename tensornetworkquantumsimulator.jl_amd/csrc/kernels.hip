@@ -514,16 +514,30 @@ __global__ __launch_bounds__(512) void recover_v_kernel(const RecoverItem* __res
     }
     s2 = wave_sum(s2);
     const double inv = s2 > 0 ? 1.0 / s2 : 0.0;
-    for (int col = 0; col < n; ++col) {
-        const cx<T>* b0 = A0 + (size_t)m * col;
-        double re = 0, im = 0;
+    constexpr int CU = 8;                    // columns in flight per iteration (loads of 8 columns overlap the reductions)
+    for (int col0 = 0; col0 < n; col0 += CU) {
+        double re[CU], im[CU];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            int i = lane + 64 * r;
-            if (i < m) { cx<T> b = b0[i]; re += (double)b.re * are[r] + (double)b.im * aim[r]; im += (double)b.re * aim[r] - (double)b.im * are[r]; }   // conj(b) * a
+        for (int c = 0; c < CU; ++c) {
+            re[c] = 0; im[c] = 0;
+            const int col = col0 + c;
+            if (col < n) {
+                const cx<T>* b0 = A0 + (size_t)m * col;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    int i = lane + 64 * r;
+                    if (i < m) { cx<T> b = b0[i]; re[c] += (double)b.re * are[r] + (double)b.im * aim[r]; im[c] += (double)b.re * aim[r] - (double)b.im * are[r]; }   // conj(b) * a
+                }
+            }
         }
-        re = wave_sum(re); im = wave_sum(im);
-        if (lane == 0) V[col + (size_t)n * u] = cmake<T>((T)(re * inv), (T)(im * inv));
+#pragma unroll
+        for (int c = 0; c < CU; ++c) { re[c] = wave_sum(re[c]); im[c] = wave_sum(im[c]); }
+        if (lane < CU && col0 + lane < n) {
+            double rr = 0, ii = 0;
+#pragma unroll
+            for (int c = 0; c < CU; ++c) if (lane == c) { rr = re[c]; ii = im[c]; }
+            V[col0 + lane + (size_t)n * u] = cmake<T>((T)(rr * inv), (T)(ii * inv));
+        }
     }
 }
 template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax) {

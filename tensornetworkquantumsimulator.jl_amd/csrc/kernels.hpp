@@ -148,6 +148,12 @@ inline bool pair_geometry(int d, int z, const int* chi, int lx, int ly, PairGeom
     }
     return true;
 }
+// plane geometry (bond leg b, any other 32-dim leg y) for the gate epilogue kernel; needs d = 2 and chi_b = 32
+inline bool apply64_geometry(int d, int z, const int* chi, int b, PairGeom& g) {
+    if (d != 2 || b < 0 || b >= z || chi[b] != 32) return false;
+    for (int y = 0; y < z; ++y) if (y != b && pair_geometry(d, z, chi, b, y, g)) return true;
+    return false;
+}
 struct PairItem {         // out = in x_x Mx x_y My for two 32-dimensional legs
     const void* in; void* out; const void* Mx; const void* My;
     PairGeom g;
@@ -172,6 +178,12 @@ void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems
 bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);
 // fused pair of mode products on two slow 32-dim legs (16 companions = 128-byte runs per workgroup)
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs);
+// gate epilogue psi' = psi x_(s,b) X for d = 2, chi_b = chi_b' = 32 (K = N = 64) in the pair-kernel shape: plane (b, y) per companion,
+// the two site components of a companion are the planes of one wave.  Xb = X rearranged into MFMA B-operand order (make_xb).
+struct Apply64Item { const void* in; void* out; const void* Xb; PairGeom g; int wg_begin; int spw; double* norm_partial; };
+struct XbItem { const void* X; void* Xb; };       // X[(s + 2 b) + 64 (s' + 2 b')] complex64 -> 2048 float4
+void launch_make_xb(hipStream_t s, const XbItem* d_items, int nitems);
+void launch_mfma_apply64(hipStream_t s, const Apply64Item* d_items, int nitems, int total_wgs);
 // last absorption + Gram on two arbitrary 32-dim legs (absorbed leg x, kept leg y), reading a (cached) pair product X and psi = Y
 void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitems, int total_wgs);
 
