@@ -184,6 +184,13 @@ def main():
                    "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None}
                for k, v in prof.items() if v["launches"]}
 
+    # seconds per BP sweep and per colour batch (HIP-event time of the kernel classes of each phase, per step)
+    nst = max(1, args.steps)
+    bp_ms = sum(prof[k]["ms"] for k in prof if k.startswith("bp_")) / nst
+    gate_ms = sum(prof[k]["ms"] for k in ("gate_modeprod", "gate_gram", "gate_apply", "jacobi") if k in prof) / nst
+    phases = {"ms_per_bp_sweep": round(bp_ms / max(1.0, float(np.mean(sweeps))), 3), "ms_per_colour_batch": round(gate_ms / max(1, len(groups)), 3),
+              "bp_ms_per_step": round(bp_ms, 2), "gate_ms_per_step": round(gate_ms, 2)}
+
     out = {"metric": "two-site gates/sec at fixed chi (LxL TFIM Trotter layer)", "value": round(value, 2),
            "unit": "two-site gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -193,7 +200,7 @@ def main():
                       "two_site_gates_per_step": n2, "bp_updates_per_step": updates, "bp_sweeps_per_step": sweeps,
                       "apply_kwargs": {"maxdim": chi, "cutoff": 1e-10, "normalize_tensors": True},
                       "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)", "parallelism": f"vertex-shard x{world}"},
-           "roofline": roofline, "kernel_classes": classes}
+           "roofline": roofline, "phases": phases, "kernel_classes": classes}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -1159,7 +1159,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             std::vector<RecoverItem> rv;
             for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ji[q].n});
             const RecoverItem* dr = upload(s, rv);
-            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); { int nmax = 1; for (auto& j : ji) nmax = std::max(nmax, j.n); launch_recover_v<T>(s->stream, dr, npg, nmax); } }
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); { int nmax = 1; for (auto& j : ji) nmax = std::max(nmax, j.n); if (std::is_same<T, float>::value && use_mfma()) launch_recover_v_mfma(s->stream, dr, npg, nmax); else launch_recover_v<T>(s->stream, dr, npg, nmax); } }
         }
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
         std::vector<double> hterr(std::max(1, npg));

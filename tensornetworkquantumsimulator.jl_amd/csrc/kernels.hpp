@@ -100,6 +100,7 @@ void launch_small_svd_finish(hipStream_t s, const SmallSvdItem* d_items, int nit
 struct CholItem { const void* G; void* L; void* Winv; int n; int* fail; };
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax);
 template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax);
+void launch_recover_v_mfma(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax);    // ComplexF32, MFMA (kernels_mfma.hip)
 template <class T> void launch_env_prepare(hipStream_t s, const EnvItem* d_items, int nitems);
 template <class T> void launch_env_finish(hipStream_t s, const EnvFinishItem* d_items, int nitems);
 template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems);

@@ -944,11 +944,14 @@ void launch_make_xb(hipStream_t s, const XbItem* d_items, int nitems) {
     hipLaunchKernelGGL(make_xb_kernel, dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 __global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __restrict__ items, int nitems) {
-    constexpr int PR = 32 * 33;
-    constexpr int PS = 2 * PR + 1;
+    // LDS (exactly 160 KiB, no static LDS in this kernel): 16 planes x (re, im) x 32 x 32 floats with an XOR swizzle instead of a
+    // padded pitch -- element (ix, iy) of plane p at iy*32 + ((ix ^ iy ^ sw(p)) & 31), sw(p) = ((p >> 1) & 3) << 3 -- followed by the
+    // four 32 x 32 blocks of X in B-operand order (32 KiB).  Every access pattern below is at most 2-way (= 64 lanes / 32 banks).
+    constexpr int PR = 32 * 32;                 // floats of one re (or im) plane
+    constexpr int PS = 2 * PR;                  // plane stride
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* L = reinterpret_cast<float*>(smem);
-    __shared__ double sh_n[8];
+    v4f* Xl = reinterpret_cast<v4f*>(L + 16 * PS);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
     int lo = 0, hi_ = nitems - 1;
     const int gw = blockIdx.x;
@@ -960,14 +963,19 @@ __global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __
     const int s_begin = lw * it.spw, s_end = min(nslices, s_begin + it.spw);
     const cf* __restrict__ in = reinterpret_cast<const cf*>(it.in);
     cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
-    const v4f* __restrict__ Xb = reinterpret_cast<const v4f*>(it.Xb) + lane;
+    {
+        const v4f* __restrict__ Xb = reinterpret_cast<const v4f*>(it.Xb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Xl[tid + 512 * j] = Xb[tid + 512 * j];
+    }
     const int f = tid & 7, sg0 = tid >> 3;
     const long long sx = g.sx, sy = g.sy, fo = (long long)f * g.cstr;
-    v4f pre[16];
     // segment j of this thread: ix = sg0 & 31 (fixed), iy = (sg0 >> 5) + 2 j  ->  one base address and a constant stride
     const int ix0 = sg0 & 31, iy0 = sg0 >> 5;
     const long long toff = fo + sx * ix0 + sy * iy0, tstr = 2 * sy;
-    float* const lbase = L + (2 * f) * PS + iy0 * 33 + ix0;         // plane 2f = site component 0, 2f+1 = component 1; element (b, y) at [y][b]
+    const int swf = (f & 3) << 3;               // planes 2f and 2f+1 share the swizzle constant
+    float* const lplane = L + (2 * f) * PS;     // plane 2f = site component 0, 2f+1 = component 1
+    v4f pre[16];
     auto issue = [&](int sl) {
         const cf* p = in + pair_slice_base(g, sl) + toff;
 #pragma unroll
@@ -976,11 +984,13 @@ __global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __
     auto commit = [&]() {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            float* p0 = lbase + 66 * j;
+            const int iy = iy0 + 2 * j;
+            float* p0 = lplane + iy * 32 + ((ix0 ^ iy ^ swf) & 31);
             p0[0] = pre[j][0]; p0[PR] = pre[j][1];
             p0[PS] = pre[j][2]; p0[PS + PR] = pre[j][3];
         }
     };
+    const int sww = (w & 3) << 3;               // swizzle constant of this wave's planes 2w, 2w+1
     double nrm = 0;
     if (s_begin < s_end) issue(s_begin);
     for (int sl = s_begin; sl < s_end; ++sl) {
@@ -1000,13 +1010,13 @@ __global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __
             const float* Ps = s ? P1 : P0;
             float ar[16], ai[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { int o = ln * 33 + q + 16 * h; ar[q] = Ps[o]; ai[q] = Ps[PR + o]; }     // A[i = y = ln][k = b]
+            for (int q = 0; q < 16; ++q) { int o = ln * 32 + (((q + 16 * h) ^ ln ^ sww) & 31); ar[q] = Ps[o]; ai[q] = Ps[PR + o]; }     // A[i = y = ln][k = b]
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
-                __builtin_amdgcn_sched_barrier(0);                 // keep the four X blocks from being loaded all at once (VGPR budget)
-                v4f bb[8];                                         // block (s, s') of X, index 2 s + s' in Xb
+                __builtin_amdgcn_sched_barrier(0);                 // one X block in registers at a time (VGPR budget)
+                v4f bb[8];                                         // block (s, s') of X, index 2 s + s'
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bb[j] = Xb[((2 * s + sp) * 8 + j) * 64];
+                for (int j = 0; j < 8; ++j) bb[j] = Xl[((2 * s + sp) * 8 + j) * 64 + lane];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
 #pragma unroll
@@ -1029,7 +1039,8 @@ __global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int y = (r & 3) + 8 * (r >> 2) + 4 * h;
-                Po[y * 33 + ln] = Cr[sp][r]; Po[PR + y * 33 + ln] = Ci[sp][r];
+                int o = y * 32 + ((ln ^ y ^ sww) & 31);
+                Po[o] = Cr[sp][r]; Po[PR + o] = Ci[sp][r];
                 nrm_f += Cr[sp][r] * Cr[sp][r] + Ci[sp][r] * Ci[sp][r];
             }
         }
@@ -1039,7 +1050,8 @@ __global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __
             cf* p = out + pair_slice_base(g, sl) + toff;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float* p0 = lbase + 66 * j;
+                const int iy = iy0 + 2 * j;
+                const float* p0 = lplane + iy * 32 + ((ix0 ^ iy ^ swf) & 31);
                 v4f v; v[0] = p0[0]; v[1] = p0[PR]; v[2] = p0[PS]; v[3] = p0[PS + PR];
                 *reinterpret_cast<v4f*>(p + tstr * j) = v;
             }
@@ -1048,17 +1060,69 @@ __global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __
     if (it.norm_partial) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nrm += __shfl_xor(nrm, o, 64);
+        lds_barrier();                                              // the planes are free: reuse the first bytes for the 8 wave sums
+        double* sh_n = reinterpret_cast<double*>(L);
         if (lane == 0) sh_n[w] = nrm;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) { double t = 0; for (int i = 0; i < 8; ++i) t += sh_n[i]; it.norm_partial[lw] = t; }
     }
 }
 void launch_mfma_apply64(hipStream_t s, const Apply64Item* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
-    const size_t lds = (size_t)16 * (2 * 32 * 33 + 1) * sizeof(float);
+    const size_t lds = (size_t)16 * (2 * 32 * 32) * sizeof(float) + 2048 * 16;        // 160 KiB: the whole LDS of a CU
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_apply64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     hipLaunchKernelGGL(mfma_apply64_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// right singular vectors of the theta SVD, recovered: V = theta0^dagger (U Sigma) Sigma^-2  -- an n x n x m complex GEMM
+// per gate (m, n <= 256).  A wave owns one 32 x 32 tile of V; operands are read straight from L2 (both matrices are <= 512 KiB).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void recover_v_mfma_kernel(const RecoverItem* __restrict__ items) {
+    const RecoverItem it = items[blockIdx.x];
+    const cf* __restrict__ A0 = reinterpret_cast<const cf*>(it.A0);
+    const cf* __restrict__ A = reinterpret_cast<const cf*>(it.A);
+    cf* __restrict__ V = reinterpret_cast<cf*>(it.V);
+    const int m = it.m, n = it.n;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, ln = lane & 31, h = lane >> 5;
+    const int nt = (n + 31) >> 5;
+    const int tile = blockIdx.y * 4 + w;
+    if (tile >= nt * nt) return;
+    const int c0 = 32 * (tile % nt), u0 = 32 * (tile / nt);
+    const int col = c0 + ln, u = u0 + ln;
+    const cf* pa = A0 + (size_t)m * min(col, n - 1);
+    const cf* pb = A + (size_t)m * min(u, n - 1);
+    const bool okc = col < n, oku = u < n;
+    v16f Cr, Ci;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }
+    float s2 = 0.f;                                           // |a_u|^2 (rows split over the two half waves)
+    for (int k0 = 0; k0 < m; k0 += 2) {
+        const int row = k0 + h;
+        cf a = {0.f, 0.f}, b = {0.f, 0.f};
+        if (row < m) { if (okc) a = pa[row]; if (oku) b = pb[row]; }
+        s2 += b.re * b.re + b.im * b.im;
+        // C[col][u] += conj(a) * b
+        Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.re, b.re, Cr, 0, 0, 0);
+        Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.im, b.im, Cr, 0, 0, 0);
+        Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(a.re, b.im, Ci, 0, 0, 0);
+        Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.im, b.re, Ci, 0, 0, 0);
+    }
+    s2 += __shfl_xor(s2, 32, 64);                             // lane ln (and ln+32) now hold |a_{u0+ln}|^2
+    const float inv = s2 > 0.f ? 1.0f / s2 : 0.f;
+    if (oku) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;      // C[row = col index][col = u = ln]
+            if (c < n) { cf v; v.re = Cr[r] * inv; v.im = Ci[r] * inv; V[c + (size_t)n * u] = v; }
+        }
+    }
+}
+void launch_recover_v_mfma(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax) {
+    if (nitems <= 0) return;
+    const int nt = (nmax + 31) / 32;
+    hipLaunchKernelGGL(recover_v_mfma_kernel, dim3(nitems, (nt * nt + 3) / 4), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------

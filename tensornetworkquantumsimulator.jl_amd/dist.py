@@ -58,7 +58,9 @@ class Sharding:
                 flat = self.buf[: n * nranks]
                 mine = flat[self.rank * n:(self.rank + 1) * n]
                 if self.backend == "nccl":
-                    self.dist.all_gather_into_tensor(flat, mine, group=self.group)
+                    # RCCL all-gather straight between the GPUs' exchange buffers (xGMI); the send block is copied out first so
+                    # that input and output never alias
+                    self.dist.all_gather_into_tensor(flat, mine.clone(), group=self.group)
                     self.torch.cuda.synchronize()
                 else:                                   # gloo: stage through the host (tests; ranks may share a GPU)
                     host = mine.cpu()
