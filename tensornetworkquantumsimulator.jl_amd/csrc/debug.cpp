@@ -1,5 +1,6 @@
 // debug.cpp -- kernel-level test entry points (include/tnqs_debug.h): host arrays in, host arrays out.
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 #include "engine.hpp"
 #include "kernels.hpp"
@@ -84,10 +85,11 @@ void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void
     if (mf || mf64) TR = 64;
     tile_params(PA, PB, TR, it.TA, it.TB, it.nta, it.ntb);
     int ntiles = it.nta * it.ntb; int nch = std::min(7, ntiles);
+    if (const char* e = std::getenv("TNQS_DBG_GRAM_CHUNKS")) nch = std::min(ntiles, std::max(1, std::atoi(e)));
     it.tiles_per_chunk = (ntiles + nch - 1) / nch; it.nchunks = (ntiles + it.tiles_per_chunk - 1) / it.tiles_per_chunk; it.chunk_begin = 0;
     bool a64 = acc64 || dtype == TNQS_C128;
     size_t asz = a64 ? 16 : 8;
-    int npart = mf ? 4 * it.nchunks : it.nchunks;
+    int npart = mf ? 4 * it.nchunks : (mf64 ? 2 * it.nchunks : it.nchunks);
     DBuf dP((size_t)npart * KK * KK * asz), dO((size_t)KK * KK * asz);
     it.partial = dP.p; dI.up(&it, sizeof(it));
     if (mf64) launch_mfma_gram64_f64(nullptr, (const GramItem*)dI.p, 1, it.nchunks, KK);

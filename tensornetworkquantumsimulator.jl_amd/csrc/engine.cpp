@@ -485,7 +485,7 @@ template <class T, class Acc> static void run_grams(State* s, std::vector<GramJo
         int nch = std::min(per_item, ntiles);
         it.tiles_per_chunk = (ntiles + nch - 1) / nch;
         it.nchunks = (ntiles + it.tiles_per_chunk - 1) / it.tiles_per_chunk;
-        j.nchunks = mf ? 4 * it.nchunks : it.nchunks;          // the MFMA kernel writes one partial per wave
+        j.nchunks = mf ? 4 * it.nchunks : (mf64 ? 2 * it.nchunks : it.nchunks);     // f32 MFMA kernels: one partial per wave; f64 MFMA kernel: one per tile parity
         j.partial = dalloc(s, (size_t)j.nchunks * j.KK * j.KK * 2 * sizeof(Acc));
         it.partial = j.partial->p; it.chunk_begin = chunks; chunks += it.nchunks;
         items.push_back(it);

@@ -1129,13 +1129,17 @@ void launch_recover_v_mfma(hipStream_t s, const RecoverItem* d_items, int nitems
 // Gram with f64 accumulation on v_mfma_f64_16x16x4_f64 (gate path: G = X X^dagger over the fibers, KK = D*K <= 64,
 // ComplexF32 input converted on the fly; the f32 products are exact in f64, so G is the exact Gram of the rounded
 // tensor -- what the eigen factorisation replacing the thin QR needs).  f64 MFMA layout: A[i=l&15][k=l>>4],
-// B[k=l>>4][j=l&15], C[row=(l>>4)+4r][col=l&15].  Wave w owns block row w (16 rows of G) x 4 block columns.
+// B[k=l>>4][j=l&15], C[row=(l>>4)+4r][col=l&15].  G is Hermitian: only the 16 x 16 blocks (I, J >= I) are computed (ten for a
+// 64 x 64 G) and mirrored when the partials are written.  The blocks are dealt round-robin to the four waves, forwards on even
+// tiles and backwards on odd tiles, so every wave (= SIMD) does 5 blocks per two tiles instead of 8; the two tile parities
+// accumulate into separate partials (2 per chunk) because a block changes wave with the parity.
 // ------------------------------------------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void mfma_gram64_f64_kernel(const GramItem* __restrict__ items, int nitems) {
+__global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem* __restrict__ items, int nitems, int dbg_skip) {
     constexpr int TR = 64, TRP = TR + 4, NU = 8;
-    __shared__ __attribute__((aligned(16))) float Xr[64 * TRP];
-    __shared__ __attribute__((aligned(16))) float Xi[64 * TRP];
+    // two tile buffers (re, im planes each): the next tile is committed while other waves still multiply the current one
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const Xbuf = reinterpret_cast<float*>(smem);          // [buf][re|im][64 * TRP]
     const int tid = threadIdx.x;
     int lo = 0, hi = nitems - 1;
     const int gc = blockIdx.x;
@@ -1149,12 +1153,26 @@ __global__ __launch_bounds__(256) void mfma_gram64_f64_kernel(const GramItem* __
     const int t_begin = lc * it.tiles_per_chunk;
     const int t_end = min(ntiles, t_begin + it.tiles_per_chunk);
     const int lane = tid & 63, w = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-    v4d Cr[4], Ci[4];
+    // upper-triangle blocks in row-major order, dealt to the waves: slot q of parity p holds block  p ? nblk-1-(w+4q) ... see below
+    const int nb = (KK + 15) >> 4, nblk = nb * (nb + 1) / 2;
+    // waves 0, 1 own three blocks on even tiles and two on odd tiles, waves 2, 3 the other way round: slot sets A (3) and B (2)
+    const int parA = (w < 2) ? 0 : 1;                          // tile parity on which this wave uses set A
+    int aI[3], aJ[3], bI[2], bJ[2]; bool aOn[3], bOn[2];
+    auto block_of = [&](int idx, int& I, int& J) { I = 0; int rem = idx; while (rem >= nb - I) { rem -= nb - I; ++I; } J = I + rem; };
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int q = 0; q < 3; ++q) { const int wv = parA ? 3 - w : w; int idx = wv + 4 * q; aOn[q] = idx < nblk; block_of(aOn[q] ? idx : 0, aI[q], aJ[q]); }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { Cr[j][r] = 0.0; Ci[j][r] = 0.0; }
-    for (int e = tid; e < 64 * TRP; e += 256) { Xr[e] = 0.f; Xi[e] = 0.f; }
+    for (int q = 0; q < 2; ++q) { const int wv = parA ? w : 3 - w; int idx = wv + 4 * q; bOn[q] = idx < nblk; block_of(bOn[q] ? idx : 0, bI[q], bJ[q]); }
+    v4d CAr[3], CAi[3], CBr[2], CBi[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { CAr[j][r] = 0.0; CAi[j][r] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { CBr[j][r] = 0.0; CBi[j][r] = 0.0; }
+    for (int e = tid; e < 4 * 64 * TRP; e += 256) Xbuf[e] = 0.f;
     const TileMap m = make_map(tid, D, TA, TB, PA, K);
     const long long kstride = (long long)D * PA;
     const bool fast = m.U <= 256 && (K + m.KP - 1) / m.KP <= NU;
@@ -1179,8 +1197,9 @@ __global__ __launch_bounds__(256) void mfma_gram64_f64_kernel(const GramItem* __
             px[j] = vx;
         }
     };
-    auto commit_loads = [&]() {
+    auto commit_loads = [&](int buf) {
         if (!m.active) return;
+        float* Xr = Xbuf + buf * (2 * 64 * TRP); float* Xi = Xr + 64 * TRP;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             int k = m.kp + m.KP * j;
@@ -1191,69 +1210,88 @@ __global__ __launch_bounds__(256) void mfma_gram64_f64_kernel(const GramItem* __
             }
         }
     };
-    if (fast && t_begin < t_end) issue_loads(t_begin);
-    for (int t = t_begin; t < t_end; ++t) {
-        lds_barrier();
-        if (fast) commit_loads();
-        else {
-            int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
-            const int ntile_el = D * TA * K * TB;
-            for (int e = tid; e < ntile_el; e += 256) {
-                int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
-                cf vx; vx.re = vx.im = 0.f;
-                if (al < na && bl < nb) vx = Xg[s + D * ((long long)(a0 + al) + PA * ((long long)k + (long long)K * (b0 + bl)))];
-                int o = (s + D * k) * TRP + (al + TA * bl);
-                Xr[o] = vx.re; Xi[o] = vx.im;
-            }
+    auto fill_slow = [&](int t, int buf) {
+        float* Xr = Xbuf + buf * (2 * 64 * TRP); float* Xi = Xr + 64 * TRP;
+        int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
+        const int ntile_el = D * TA * K * TB;
+        for (int e = tid; e < ntile_el; e += 256) {
+            int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
+            cf vx; vx.re = vx.im = 0.f;
+            if (al < na && bl < nb) vx = Xg[s + D * ((long long)(a0 + al) + PA * ((long long)k + (long long)K * (b0 + bl)))];
+            int o = (s + D * k) * TRP + (al + TA * bl);
+            Xr[o] = vx.re; Xi[o] = vx.im;
         }
-        lds_barrier();
-        if (fast && t + 1 < t_end) issue_loads(t + 1);
+    };
+    // software pipeline over the tiles of this chunk: loads run two tiles ahead (registers), the LDS commit one tile ahead
+    lds_barrier();                                               // zero fill done
+    if (t_begin < t_end) { if (fast) { issue_loads(t_begin); commit_loads(0); if (t_begin + 1 < t_end) issue_loads(t_begin + 1); } else fill_slow(t_begin, 0); }
+    lds_barrier();
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        if (t + 1 < t_end) {                                     // buffer cur^1 was last read at tile t-1: every wave passed the barrier since
+            if (fast) { commit_loads(cur ^ 1); if (t + 2 < t_end) issue_loads(t + 2); } else fill_slow(t + 1, cur ^ 1);
+        }
+        const float* Xr = Xbuf + cur * (2 * 64 * TRP); const float* Xi = Xr + 64 * TRP;
         // rows of the tile: lane quarter kq takes rows 16*kq + tt, tt = 0..15, in two halves of 8 to bound registers
+        auto block_pass = [&](int I, int J, v4d& cr, v4d& ci) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            double ar[8], ai[8];
-            const int ro = (16 * w + l15) * TRP + 16 * kq + 8 * half;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                v4f t0 = *reinterpret_cast<const v4f*>(Xr + ro + 4 * q), t1 = *reinterpret_cast<const v4f*>(Xi + ro + 4 * q);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { ar[4 * q + c] = (double)t0[c]; ai[4 * q + c] = (double)t1[c]; }
-            }
-#pragma unroll
-            for (int J = 0; J < 4; ++J) {
-                double br[8], bi[8];
+            for (int half = 0; half < 2; ++half) {
+                const int ro = (16 * I + l15) * TRP + 16 * kq + 8 * half;
                 const int rb = (16 * J + l15) * TRP + 16 * kq + 8 * half;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    v4f t0 = *reinterpret_cast<const v4f*>(Xr + rb + 4 * q), t1 = *reinterpret_cast<const v4f*>(Xi + rb + 4 * q);
+                    const v4f t0 = *reinterpret_cast<const v4f*>(Xr + ro + 4 * q), t1 = *reinterpret_cast<const v4f*>(Xi + ro + 4 * q);
+                    const v4f u0 = *reinterpret_cast<const v4f*>(Xr + rb + 4 * q), u1 = *reinterpret_cast<const v4f*>(Xi + rb + 4 * q);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { br[4 * q + c] = (double)t0[c]; bi[4 * q + c] = (double)t1[c]; }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    // out[i][j] += x[i] * conj(x[j])
-                    Cr[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[q], br[q], Cr[J], 0, 0, 0);
-                    Cr[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[q], bi[q], Cr[J], 0, 0, 0);
-                    Ci[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[q], br[q], Ci[J], 0, 0, 0);
-                    Ci[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar[q], bi[q], Ci[J], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c) {
+                        const double ar = (double)t0[c], ai = (double)t1[c], br = (double)u0[c], bi = (double)u1[c];
+                        // out[i][j] += x[i] * conj(x[j])
+                        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr, 0, 0, 0);
+                        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
+                        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, cr, 0, 0, 0);
+                        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, bi, ci, 0, 0, 0);
+                    }
                 }
             }
+        };
+        if (dbg_skip != 1) {
+            if (((t - t_begin) & 1) == parA) {                    // wave-uniform
+#pragma unroll
+                for (int q = 0; q < 3; ++q) if (aOn[q]) block_pass(aI[q], aJ[q], CAr[q], CAi[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) if (bOn[q]) block_pass(bI[q], bJ[q], CBr[q], CBi[q]);
+            }
         }
+        lds_barrier();                                           // tile t consumed by everybody, tile t+1 committed by everybody
     }
     struct alignas(16) cd { double re, im; };
-    cd* __restrict__ part = reinterpret_cast<cd*>(it.partial) + (size_t)lc * KK * KK;
-#pragma unroll
-    for (int J = 0; J < 4; ++J)
+    auto write_block = [&](cd* __restrict__ part, int I, int J, const v4d& cr, const v4d& ci) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int i = 16 * w + kq + 4 * r, j = 16 * J + l15;
-            if (i < KK && j < KK) { cd v; v.re = Cr[J][r]; v.im = Ci[J][r]; part[i + (size_t)KK * j] = v; }
+            int i = 16 * I + kq + 4 * r, j = 16 * J + l15;
+            if (i < KK && j < KK) {
+                cd v; v.re = cr[r]; v.im = ci[r]; part[i + (size_t)KK * j] = v;
+                if (I != J) { cd c; c.re = v.re; c.im = -v.im; part[j + (size_t)KK * i] = c; }     // G[j][i] = conj(G[i][j])
+            }
         }
+    };
+    // partial 2*lc + p collects the blocks accumulated on tiles of parity p (each block exactly once per parity)
+    cd* __restrict__ partA = reinterpret_cast<cd*>(it.partial) + (size_t)(2 * lc + parA) * KK * KK;
+    cd* __restrict__ partB = reinterpret_cast<cd*>(it.partial) + (size_t)(2 * lc + (parA ^ 1)) * KK * KK;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) if (aOn[q]) write_block(partA, aI[q], aJ[q], CAr[q], CAi[q]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) if (bOn[q]) write_block(partB, bI[q], bJ[q], CBr[q], CBi[q]);
 }
 bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
     if (KKmax > 64) return false;
     if (total_chunks <= 0) return true;
-    hipLaunchKernelGGL(mfma_gram64_f64_kernel, dim3(total_chunks), dim3(256), 0, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+    const size_t lds = (size_t)4 * 64 * 68 * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_gram64_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static int skip = -1; if (skip < 0) { const char* e = std::getenv("TNQS_DBG_GRAM_SKIP"); skip = e ? std::atoi(e) : 0; }
+    hipLaunchKernelGGL(mfma_gram64_f64_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems, skip); TNQS_CHECK_LAUNCH();
     return true;
 }
 
