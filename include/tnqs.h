@@ -133,6 +133,17 @@ int tnqs_expect_1site(tnqs_handle h, int v, const double* op, double* out_re_im)
 /* all-vertex <op_v>: ops is nv consecutive d x d matrices; out is nv complex128 */
 int tnqs_expect_all(tnqs_handle h, const double* ops, double* out_re_im);
 
+/* ---- BP scalars and normalisation --------------------------------------------------------
+ * vertex scalar  tr(rho_v)  = [psi_v, conj psi_v, incoming messages] contracted (abstractbeliefpropagationcache.jl:22-28),
+ * edge scalar    sum_ij m_e[i,j] m_rev(e)[i,j]                                    (beliefpropagationcache.jl:47-49);
+ * free energy = sum log(vertex scalars) - sum log(edge scalars) (abstract...:289-304) is left to the host.
+ * out_vertex: nv complex128 (NaN for vertices owned by another rank); out_edge: ne complex128, edges in tnqs_create order.
+ * tnqs_rescale: rescale_messages! then rescale_vertices! (beliefpropagationcache.jl:82-140, abstract...:318-322) in place:
+ * afterwards every vertex and edge scalar is 1 (the BP norm of the state is 1). */
+int tnqs_vertex_scalars(tnqs_handle h, double* out_vertex);
+int tnqs_edge_scalars(tnqs_handle h, double* out_edge);
+int tnqs_rescale(tnqs_handle h);
+
 /* ---- multi-GPU sharding (no reference analogue).  A rank owns a vertex subset: it holds only
  *      those site tensors and does all per-vertex work for them; messages are replicated.  The library calls
  *      the host-supplied all-gather at the exchange points (host side: torch.distributed over RCCL). --------- */

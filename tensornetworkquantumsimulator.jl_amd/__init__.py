@@ -6,7 +6,8 @@ from .graphs import (NamedGraph, named_grid, named_hexagonal_lattice_graph, heav
 from .gates import (GATES, ALIASES, BUILTIN_GATES, gate_matrix, register_gate, register_alias, unregister_gate, levenshtein)
 from .core import (TensorNetworkState, tensornetworkstate, random_tensornetworkstate, BeliefPropagationCache, network,
                    scalartype, maxvirtualdim, default_bp_update_kwargs, default_tolerance, update, apply_gates,
-                   apply_circuit, truncate, expect, expect_all, rdm, profile_enable, profile_get, profile_reset,
+                   apply_circuit, truncate, expect, expect_all, rdm, vertex_scalars, edge_scalars, freenergy, partitionfunction,
+                   rescale, normalize, profile_enable, profile_get, profile_reset,
                    PROF_CLASSES)
 from . import dist
 from .dist import partition_vertices, shard

@@ -418,6 +418,51 @@ def expect_all(bpc: BeliefPropagationCache, op) -> np.ndarray:
     return out
 
 
+# ---- BP scalars and normalisation ------------------------------------------------------------
+def vertex_scalars(bpc: BeliefPropagationCache) -> np.ndarray:
+    """vertex_scalars (abstractbeliefpropagationcache.jl:22-28,134-138): tr(rho_v) for every vertex (NaN for other ranks' vertices)"""
+    out = np.zeros(bpc.graph.nv(), dtype=np.complex128)
+    L.check(L.lib.tnqs_vertex_scalars(bpc._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def edge_scalars(bpc: BeliefPropagationCache) -> np.ndarray:
+    """edge_scalars (beliefpropagationcache.jl:47-49, abstract...:140-144), in the order of `bpc.graph.edges`"""
+    out = np.zeros(bpc.graph.ne(), dtype=np.complex128)
+    L.check(L.lib.tnqs_edge_scalars(bpc._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def freenergy(bpc: BeliefPropagationCache) -> complex:
+    """freenergy (abstract...:289-300): sum log(vertex scalars) - sum log(edge scalars); -inf when an edge scalar is zero"""
+    num, den = vertex_scalars(bpc), edge_scalars(bpc)
+    if np.any(den == 0):
+        return -np.inf
+    f = np.sum(np.log(num.astype(np.complex128))) - np.sum(np.log(den.astype(np.complex128)))
+    return complex(f)
+
+
+def partitionfunction(bpc: BeliefPropagationCache) -> complex:
+    """partitionfunction (abstract...:302-304) = exp(freenergy): the BP estimate of <psi|psi>"""
+    return complex(np.exp(freenergy(bpc)))
+
+
+def rescale(bpc: BeliefPropagationCache) -> BeliefPropagationCache:
+    """rescale (abstract...:324-328): copy, rescale_messages! then rescale_vertices! -- every vertex / edge scalar becomes 1"""
+    out = bpc.copy()
+    L.check(L.lib.tnqs_rescale(out._h))
+    return out
+
+
+def normalize(tns: TensorNetworkState, alg: str = "bp", cache_update_kwargs=None, device: int = 0) -> TensorNetworkState:
+    """normalize(tns; alg = "bp") (src/normalize.jl:1-6): BP-converge, rescale!, return the network (norm_sqr(bp) = 1)"""
+    if alg != "bp":
+        raise L.TnqsError(f"normalize: only alg = \"bp\" is implemented on the HIP path; received {alg!r}")
+    bpc = BeliefPropagationCache(tns, device=device)
+    bpc = update(bpc, **(cache_update_kwargs or {}))
+    return rescale(bpc).network()
+
+
 def profile_enable(bpc: BeliefPropagationCache, on: bool = True):
     L.check(L.lib.tnqs_profile_enable(bpc._h, 1 if on else 0))
 

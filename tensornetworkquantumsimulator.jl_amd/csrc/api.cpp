@@ -109,6 +109,9 @@ int tnqs_expect_1site(tnqs_handle h, int v, const double* op, double* out) {
         out[0] = (nre * tre + nim * tim) / den; out[1] = (nim * tre - nre * tim) / den;
     });
 }
+int tnqs_vertex_scalars(tnqs_handle h, double* out) { return guard([&] { if (!out) throw Err(TNQS_ERR_INVALID, "vertex_scalars: null"); vertex_scalars(S(h), out); }); }
+int tnqs_edge_scalars(tnqs_handle h, double* out) { return guard([&] { if (!out) throw Err(TNQS_ERR_INVALID, "edge_scalars: null"); edge_scalars(S(h), out); }); }
+int tnqs_rescale(tnqs_handle h) { return guard([&] { rescale(S(h)); }); }
 int tnqs_expect_all(tnqs_handle h, const double* ops, double* out) {
     return guard([&] { if (!ops || !out) throw Err(TNQS_ERR_INVALID, "expect_all: null"); expect_all(S(h), ops, out); });
 }

@@ -1445,6 +1445,81 @@ void rdm_1site(State* s, int v, double* out) {
     std::vector<int> vs{v};
     if (s->dtype == TNQS_C64) rdm_batch<float>(s, vs, out); else rdm_batch<double>(s, vs, out);
 }
+// ---------------------------------------------------------------------------------------------------------------
+// BP scalars and normalisation: vertex_scalar (abstract...:22-28), edge_scalar (beliefpropagationcache.jl:47-49),
+// rescale! = rescale_messages! (:127-140) then rescale_vertices! (:82-101)
+// ---------------------------------------------------------------------------------------------------------------
+void vertex_scalars(State* s, double* out /* nv complex128; NaN for vertices of other ranks */) {
+    const Graph& g = *s->g;
+    std::vector<int> vs; std::vector<size_t> off; size_t tot = 0;
+    for (int v = 0; v < g.nv; ++v) if (s->owns(v)) { vs.push_back(v); off.push_back(tot); tot += 2 * (size_t)s->d[v] * s->d[v]; }
+    std::vector<double> rho(tot);
+    if (!vs.empty()) { if (s->dtype == TNQS_C64) rdm_batch<float>(s, vs, rho.data()); else rdm_batch<double>(s, vs, rho.data()); }
+    for (int v = 0; v < g.nv; ++v) { out[2 * v] = std::nan(""); out[2 * v + 1] = std::nan(""); }
+    for (size_t q = 0; q < vs.size(); ++q) {
+        int v = vs[q], d = s->d[v]; double tre = 0, tim = 0;
+        for (int si = 0; si < d; ++si) { tre += rho[off[q] + 2 * (si + d * si)]; tim += rho[off[q] + 2 * (si + d * si) + 1]; }
+        out[2 * v] = tre; out[2 * v + 1] = tim;
+    }
+}
+template <class T> static void edge_scalars_t(State* s, double* out) {
+    const Graph& g = *s->g;
+    HIPCHK(hipSetDevice(s->device));
+    if (g.ne == 0) return;
+    Buf d_out = dalloc(s, (size_t)g.ne * 16);
+    std::vector<EdgeScalarItem> items;
+    for (int e = 0; e < g.ne; ++e)
+        items.push_back(EdgeScalarItem{s->msg[2 * e] ? s->msg[2 * e]->p : nullptr, s->msg[2 * e + 1] ? s->msg[2 * e + 1]->p : nullptr, s->chi[e],
+                                       reinterpret_cast<double*>(d_out->p) + 2 * e});
+    const EdgeScalarItem* d = upload(s, items);
+    launch_edge_scalar<T>(s->stream, d, (int)items.size());
+    HIPCHK(hipMemcpyAsync(out, d_out->p, (size_t)g.ne * 16, hipMemcpyDeviceToHost, s->stream));
+    sync(s);
+}
+void edge_scalars(State* s, double* out) { if (s->dtype == TNQS_C64) edge_scalars_t<float>(s, out); else edge_scalars_t<double>(s, out); }
+
+template <class T> static void rescale_t(State* s) {
+    const Graph& g = *s->g;
+    const size_t esz = s->esz();
+    HIPCHK(hipSetDevice(s->device));
+    // rescale_messages!: every edge, both directions (replicated on every rank when sharded)
+    if (g.ne > 0) {
+        std::vector<MsgRescaleItem> items; std::vector<Buf> na(g.ne), nb(g.ne);
+        for (int e = 0; e < g.ne; ++e) {
+            size_t bytes = (size_t)s->chi[e] * s->chi[e] * esz;
+            na[e] = dalloc(s, bytes); nb[e] = dalloc(s, bytes);
+            items.push_back(MsgRescaleItem{s->msg[2 * e] ? s->msg[2 * e]->p : nullptr, s->msg[2 * e + 1] ? s->msg[2 * e + 1]->p : nullptr, na[e]->p, nb[e]->p, s->chi[e]});
+        }
+        const MsgRescaleItem* d = upload(s, items);
+        launch_msg_rescale<T>(s->stream, d, (int)items.size());
+        for (int e = 0; e < g.ne; ++e) { s->keepalive.push_back(s->msg[2 * e]); s->keepalive.push_back(s->msg[2 * e + 1]); s->msg[2 * e] = na[e]; s->msg[2 * e + 1] = nb[e]; }
+    }
+    // rescale_vertices!: psi_v *= sign(vn) / sqrt(vn) with vn = vertex_scalar under the rescaled messages
+    std::vector<double> vn(2 * (size_t)g.nv);
+    vertex_scalars(s, vn.data());
+    materialize_scale_all(s);
+    std::vector<CScaleItem> cs; std::vector<Buf> outs; std::vector<int> vs;
+    for (int v = 0; v < g.nv; ++v) {
+        if (!s->owns(v) || !s->site[v]) continue;
+        double re = vn[2 * v], im = vn[2 * v + 1];
+        double sgn = 1.0;
+        if (im == 0.0) sgn = (re > 0) - (re < 0);             // isreal(vn) ? sign(vn) : one(vn)
+        const double mod = std::sqrt(re * re + im * im), arg = std::atan2(im, re);
+        if (!(mod > 0)) throw Err(TNQS_ERR_NUMERIC, "rescale: a vertex scalar is zero");
+        const double r = sgn / std::sqrt(mod), ph = -0.5 * arg;
+        Buf out = dalloc(s, s->site[v]->bytes);
+        cs.push_back(CScaleItem{s->site[v]->p, out->p, s->site[v]->bytes / esz, r * std::cos(ph), r * std::sin(ph)});
+        outs.push_back(out); vs.push_back(v);
+    }
+    if (!cs.empty()) {
+        const CScaleItem* d = upload(s, cs);
+        launch_cscale<T>(s->stream, d, (int)cs.size());
+        for (size_t i = 0; i < vs.size(); ++i) { s->keepalive.push_back(s->site[vs[i]]); s->site[vs[i]] = outs[i]; }
+    }
+    sync(s);
+}
+void rescale(State* s) { if (s->dtype == TNQS_C64) rescale_t<float>(s); else rescale_t<double>(s); }
+
 void expect_all(State* s, const double* ops, double* out) {
     const Graph& g = *s->g;
     std::vector<int> vs; std::vector<size_t> off; size_t tot = 0;

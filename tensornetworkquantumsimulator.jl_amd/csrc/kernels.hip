@@ -1004,6 +1004,82 @@ template <class T> void launch_scale(hipStream_t s, const ScaleItem* d_items, in
 template void launch_scale<float>(hipStream_t, const ScaleItem*, int);
 template void launch_scale<double>(hipStream_t, const ScaleItem*, int);
 
+// ------------------------------------------------------------------------------------------------------------
+// BP normalisation (rescale!, beliefpropagationcache.jl:82-140)
+// ------------------------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ cx<double> msg_elem(const cx<T>* m, int e, int chi) {
+    if (m) return cmake<double>((double)m[e].re, (double)m[e].im);
+    return cmake<double>((e % chi) == (e / chi) ? 1.0 : 0.0, 0.0);
+}
+template <class T> __global__ __launch_bounds__(256) void msg_rescale_kernel(const MsgRescaleItem* __restrict__ items) {
+    __shared__ double sh[17];
+    const MsgRescaleItem it = items[blockIdx.x];
+    const cx<T>* a = reinterpret_cast<const cx<T>*>(it.me); const cx<T>* b = reinterpret_cast<const cx<T>*>(it.mer);
+    const int n2 = it.chi * it.chi;
+    double na = 0, nb = 0, pr = 0, pi = 0;
+    for (int e = threadIdx.x; e < n2; e += 256) {
+        cx<double> x = msg_elem(a, e, it.chi), y = msg_elem(b, e, it.chi);
+        na += x.re * x.re + x.im * x.im; nb += y.re * y.re + y.im * y.im;
+        pr += x.re * y.re - x.im * y.im; pi += x.re * y.im + x.im * y.re;
+    }
+    na = block_sum(na, sh); nb = block_sum(nb, sh); pr = block_sum(pr, sh); pi = block_sum(pi, sh);
+    const double ia = na > 0 ? 1.0 / sqrt(na) : 0.0, ib = nb > 0 ? 1.0 / sqrt(nb) : 0.0;
+    double nr = pr * ia * ib, ni = pi * ia * ib;             // n = scalar(normalize(me) * normalize(mer))
+    double sgn = 1.0;
+    if (ni == 0.0) { sgn = (nr > 0) - (nr < 0); nr *= sgn; }  // isreal(n): me *= sign(n), n *= sign(n)
+    // 1/sqrt(n), principal branch
+    const double mod = sqrt(nr * nr + ni * ni), arg = atan2(ni, nr);
+    const double r = mod > 0 ? 1.0 / sqrt(mod) : 0.0, ph = -0.5 * arg;
+    const double fr = r * cos(ph), fi = r * sin(ph);
+    cx<T>* ao = reinterpret_cast<cx<T>*>(it.me_out); cx<T>* bo = reinterpret_cast<cx<T>*>(it.mer_out);
+    for (int e = threadIdx.x; e < n2; e += 256) {
+        cx<double> x = msg_elem(a, e, it.chi), y = msg_elem(b, e, it.chi);
+        x.re *= ia * sgn; x.im *= ia * sgn; y.re *= ib; y.im *= ib;
+        ao[e] = cmake<T>((T)(x.re * fr - x.im * fi), (T)(x.re * fi + x.im * fr));
+        bo[e] = cmake<T>((T)(y.re * fr - y.im * fi), (T)(y.re * fi + y.im * fr));
+    }
+}
+template <class T> void launch_msg_rescale(hipStream_t s, const MsgRescaleItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((msg_rescale_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+template void launch_msg_rescale<float>(hipStream_t, const MsgRescaleItem*, int);
+template void launch_msg_rescale<double>(hipStream_t, const MsgRescaleItem*, int);
+template <class T> __global__ __launch_bounds__(256) void edge_scalar_kernel(const EdgeScalarItem* __restrict__ items) {
+    __shared__ double sh[17];
+    const EdgeScalarItem it = items[blockIdx.x];
+    const cx<T>* a = reinterpret_cast<const cx<T>*>(it.me); const cx<T>* b = reinterpret_cast<const cx<T>*>(it.mer);
+    const int n2 = it.chi * it.chi;
+    double pr = 0, pi = 0;
+    for (int e = threadIdx.x; e < n2; e += 256) {
+        cx<double> x = msg_elem(a, e, it.chi), y = msg_elem(b, e, it.chi);
+        pr += x.re * y.re - x.im * y.im; pi += x.re * y.im + x.im * y.re;
+    }
+    pr = block_sum(pr, sh); pi = block_sum(pi, sh);
+    if (threadIdx.x == 0) { it.out[0] = pr; it.out[1] = pi; }
+}
+template <class T> void launch_edge_scalar(hipStream_t s, const EdgeScalarItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((edge_scalar_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+template void launch_edge_scalar<float>(hipStream_t, const EdgeScalarItem*, int);
+template void launch_edge_scalar<double>(hipStream_t, const EdgeScalarItem*, int);
+template <class T> __global__ __launch_bounds__(256) void cscale_kernel(const CScaleItem* __restrict__ items) {
+    const CScaleItem it = items[blockIdx.y];
+    const double fr = it.re, fi = it.im;
+    const cx<T>* __restrict__ p = reinterpret_cast<const cx<T>*>(it.src);
+    cx<T>* __restrict__ q = reinterpret_cast<cx<T>*>(it.dst);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < it.n; i += (size_t)gridDim.x * 256) {
+        cx<T> v = p[i]; q[i] = cmake<T>((T)(v.re * fr - v.im * fi), (T)(v.re * fi + v.im * fr));
+    }
+}
+template <class T> void launch_cscale(hipStream_t s, const CScaleItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((cscale_kernel<T>), dim3(64, nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+template void launch_cscale<float>(hipStream_t, const CScaleItem*, int);
+template void launch_cscale<double>(hipStream_t, const CScaleItem*, int);
+
 template <class T> __global__ __launch_bounds__(256) void permute_kernel(PermItem it) {
     const cx<T>* in = reinterpret_cast<const cx<T>*>(it.in);
     cx<T>* out = reinterpret_cast<cx<T>*>(it.out);

@@ -77,6 +77,16 @@ struct Site1Item { const void* in; void* out; float g[8]; size_t npairs; };   //
 struct DiagItem { void* out; const double* S; int chi; };          // dense diag(S) message
 struct ScaleItem { const void* src; void* dst; size_t n; const double* factor; };      // dst = src * (*factor)
 struct NormFactorItem { const double* norm_partials; int npart; double* factor; };      // *factor = 1/sqrt(sum partials)  (1 when the sum is not positive)
+// rescale_messages! (beliefpropagationcache.jl:127-140) for one edge: both messages normalised to unit Frobenius norm, then divided by
+// sqrt(n), n = sum_ij me[i,j] mer[i,j] (sign folded into me when n is exactly real); null inputs = identity (tensornetworkstate.jl:72-75)
+struct MsgRescaleItem { const void* me; const void* mer; void* me_out; void* mer_out; int chi; };
+template <class T> void launch_msg_rescale(hipStream_t s, const MsgRescaleItem* d_items, int nitems);
+// edge_scalar (beliefpropagationcache.jl:47-49): out[e] = sum_ij me[i,j] mer[i,j] (complex128)
+struct EdgeScalarItem { const void* me; const void* mer; int chi; double* out; };
+template <class T> void launch_edge_scalar(hipStream_t s, const EdgeScalarItem* d_items, int nitems);
+// dst = src * (re + i im)
+struct CScaleItem { const void* src; void* dst; size_t n; double re, im; };
+template <class T> void launch_cscale(hipStream_t s, const CScaleItem* d_items, int nitems);
 struct PermItem { const void* in; void* out; int ndim; int dims_out[8]; long long stride_in[8]; size_t n; };
 
 // ---- launchers (T = float or double; data are complex<T>) ------------------------------------------------------

@@ -428,3 +428,41 @@ def test_deferred_normalisation_is_invisible_to_callers(dtype):
     oc2, _ = o.apply_gates([("Rzz", list(e0), 0.3)], oracle_cache_from_device(out), apply_kwargs=kw2, update_cache=False)
     for v in e0:
         assert abs(np.linalg.norm(out2.tensor(v)) - np.linalg.norm(oc2.tns.tensors[v])) < 50 * tol
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+@pytest.mark.parametrize("lattice", ["grid3x3", "comb33", "hh11"])
+def test_bp_scalars_and_rescale_match_oracle(dtype, lattice):
+    """8f N2: vertex / edge scalars, partition function (abstract...:22-28, 289-304) and rescale! (beliefpropagationcache.jl:82-140)"""
+    g = {"grid3x3": lambda: tn.named_grid((3, 3)), "comb33": lambda: tn.named_comb_tree((3, 3)), "hh11": lambda: tn.heavy_hexagonal_lattice(1, 1)}[lattice]()
+    tol = 5e-5 if dtype == np.complex64 else 1e-10
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=3, seed=9)
+    seq = tn.forest_cover_edge_sequence(g)
+    kw = dict(maxiter=6, tolerance=None, edge_sequence=seq)
+    bpc = tn.update(tn.BeliefPropagationCache(psi), **kw)
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **kw)
+    vs, es = tn.vertex_scalars(bpc), tn.edge_scalars(bpc)
+    for i, v in enumerate(g.vertices):
+        ref = o.vertex_scalar(oc, v)
+        assert abs(vs[i] - ref) < tol * abs(ref)
+    # the message gauge differs (both sides normalise by the sum of elements, so the scalars agree once the trajectories agree)
+    for i, e in enumerate(g.edges):
+        ref = o.edge_scalar(oc, e)
+        assert abs(es[i] - ref) < 20 * tol * abs(ref)
+    zf, zo = tn.partitionfunction(bpc), o.partitionfunction(oc)
+    assert abs(zf - zo) < 50 * tol * abs(zo)
+    if lattice == "comb33":      # BP is exact on trees: Z = <psi|psi>
+        v = sv.tns_to_statevector(to_oracle_state(psi))
+        assert abs(zf - np.vdot(v, v)) < 50 * tol * abs(np.vdot(v, v))
+    r = tn.rescale(bpc)
+    assert np.max(np.abs(tn.vertex_scalars(r) - 1)) < 20 * tol and np.max(np.abs(tn.edge_scalars(r) - 1)) < 20 * tol
+    assert abs(tn.partitionfunction(r) - 1) < 100 * tol
+    ro = o.rescale(oc)
+    for v in g.vertices[:4]:     # same tensors up to the (real positive) factor both sides derive from the same scalars
+        assert abs(np.linalg.norm(r.tensor(v)) - np.linalg.norm(ro.tns.tensors[v])) < 50 * tol * np.linalg.norm(ro.tns.tensors[v])
+        assert abs(tn.expect(r, ("Z", [v])) - o.expect_1site(ro, Z, v)) < 50 * tol
+    # the input cache is untouched, and normalize() returns a state of BP norm 1
+    assert abs(tn.vertex_scalars(bpc)[0] - vs[0]) == 0
+    nrm = tn.normalize(psi, cache_update_kwargs=kw)
+    b2 = tn.update(tn.BeliefPropagationCache(nrm), **kw)
+    assert abs(tn.partitionfunction(b2) - 1) < 200 * tol
