@@ -133,6 +133,14 @@ int tnqs_expect_1site(tnqs_handle h, int v, const double* op, double* out_re_im)
 /* all-vertex <op_v>: ops is nv consecutive d x d matrices; out is nv complex128 */
 int tnqs_expect_all(tnqs_handle h, const double* ops, double* out_re_im);
 
+/* ---- multi-site observables (src/expect.jl:59-82) ------------------------------------------
+ * The caller passes the region = the vertices of the Steiner tree of the observable's support (expect.jl:68), as a rooted
+ * tree: region_parent[i] = index (into region_verts) of the parent of vertex i, -1 for the single root; the induced
+ * subgraph of the region must be that tree.  ops = one d x d complex128 column-major matrix op[s',s] per region vertex
+ * (identity off the support).  out = {Re, Im numerator, Re, Im denominator}; <O> = coeff * numer / denom. */
+int tnqs_expect_region(tnqs_handle h, int n_region, const int32_t* region_verts, const int32_t* region_parent,
+                       const double* ops, double* out_numer_denom);
+
 /* ---- BP scalars and normalisation --------------------------------------------------------
  * vertex scalar  tr(rho_v)  = [psi_v, conj psi_v, incoming messages] contracted (abstractbeliefpropagationcache.jl:22-28),
  * edge scalar    sum_ij m_e[i,j] m_rev(e)[i,j]                                    (beliefpropagationcache.jl:47-49);

@@ -65,6 +65,15 @@ def expect_statevector(psi: np.ndarray, g, op: np.ndarray, v) -> complex:
     return complex(np.vdot(psi, t) / np.vdot(psi, psi))
 
 
+def expect_statevector_multi(psi: np.ndarray, g, ops: Dict) -> complex:
+    """<psi| prod_v op_v |psi> / <psi|psi> for operators on several vertices (op[s', s])"""
+    t = psi
+    for v, op in ops.items():
+        ax = g.pos[v]
+        t = np.moveaxis(np.tensordot(np.asarray(op, dtype=complex), t, axes=([1], [ax])), 0, ax)
+    return complex(np.vdot(psi, t) / np.vdot(psi, psi))
+
+
 def rdm_statevector(psi: np.ndarray, g, v) -> np.ndarray:
     ax = g.pos[v]
     m = np.moveaxis(psi, ax, 0).reshape(psi.shape[ax], -1)

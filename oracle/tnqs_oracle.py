@@ -725,6 +725,41 @@ def expect_1site(bpc: BeliefPropagationCache, op: np.ndarray, v: Vertex) -> comp
     return complex(numer / np.trace(rho))
 
 
+def expect_region(bpc: BeliefPropagationCache, ops: Dict, region: Sequence[Vertex]) -> complex:
+    """expect(alg"bp", cache, obs) for a multi-site observable (expect.jl:59-82): the norm network of `region` (the Steiner tree
+    of the observable's support, :68) with the cache's messages on the boundary edges (:69), operators `ops[v]` (op[s', s])
+    inserted on the support and identities elsewhere (:72-77); numer / denom (:79-82).  Dense einsum: small regions only."""
+    g = bpc.g
+    rset = set(region)
+
+    def contract(with_ops: bool) -> complex:
+        operands = []
+        ids: Dict = {}
+
+        def idx(key):
+            if key not in ids:
+                ids[key] = len(ids)
+            return ids[key]
+
+        for v in region:
+            psi = bpc.tns.tensors[v].astype(np.complex128)
+            ket_sub = [idx(("s", v, "k"))]; bra_sub = [idx(("s", v, "b"))]
+            for k in g.nbrs[v]:
+                e = (v, k) if g.pos[v] < g.pos[k] else (k, v)
+                if k in rset:
+                    ket_sub.append(idx(("e", e, "k"))); bra_sub.append(idx(("e", e, "b")))
+                else:
+                    ket_sub.append(idx(("m", v, k, "k"))); bra_sub.append(idx(("m", v, k, "b")))
+                    operands += [bpc.message((k, v)).astype(np.complex128), [idx(("m", v, k, "k")), idx(("m", v, k, "b"))]]
+            operands += [psi, ket_sub, psi.conj(), bra_sub]
+            o = ops.get(v) if with_ops else None
+            m = np.eye(psi.shape[0], dtype=np.complex128) if o is None else np.asarray(o, dtype=np.complex128)
+            operands += [m, [idx(("s", v, "b")), idx(("s", v, "k"))]]          # op[s', s]: s' contracts with the bra, s with the ket
+        return complex(np.einsum(*operands, [], optimize=True))
+
+    return contract(True) / contract(False)
+
+
 def vertex_scalar(bpc: BeliefPropagationCache, v: Vertex) -> complex:   # abstract...:22-28
     return complex(np.trace(rdm_1site(bpc, v)))
 

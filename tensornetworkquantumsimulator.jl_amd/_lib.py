@@ -65,6 +65,7 @@ _SIGS = {
     "tnqs_rdm_1site": ([H, C.c_int, _DP], C.c_int),
     "tnqs_expect_1site": ([H, C.c_int, _DP, _DP], C.c_int),
     "tnqs_expect_all": ([H, _DP, _DP], C.c_int),
+    "tnqs_expect_region": ([H, C.c_int, _I32P, _I32P, _DP, _DP], C.c_int),
     "tnqs_vertex_scalars": ([H, _DP], C.c_int),
     "tnqs_edge_scalars": ([H, _DP], C.c_int),
     "tnqs_rescale": ([H], C.c_int),

@@ -398,11 +398,40 @@ def expect(bpc: BeliefPropagationCache, observable):
     if coeff == 0:
         return 0.0 * coeff
     if len(verts) != 1:
-        raise NotImplementedError("expect: only single-site observables are on the HIP path (multi-site: SURVEY.md 8f N1)")
+        return coeff * _expect_region(bpc, op, verts)
     m = np.asfortranarray(gate_matrix(op) if isinstance(op, str) else np.asarray(op), dtype=np.complex128)
     out = (C.c_double * 2)()
     L.check(L.lib.tnqs_expect_1site(bpc._h, bpc.graph.index[verts[0]], m.ctypes.data_as(C.POINTER(C.c_double)), out))
     return coeff * complex(out[0], out[1])
+
+
+def _expect_region(bpc: BeliefPropagationCache, op, verts) -> complex:
+    """multi-site observable (src/expect.jl:59-82): operators on `verts`, identities on the rest of their Steiner tree, the
+    cache's messages on the region's boundary; numerator / denominator"""
+    from .graphs import steiner_region
+    g = bpc.graph
+    if isinstance(op, str):
+        ops = [c for c in op]                       # one Pauli character per vertex (collectobservable, expect.jl:159-175)
+    else:
+        ops = list(op)
+    if len(ops) != len(verts):
+        raise L.TnqsError("Invalid observable: need as many operators as vertices passed.")
+    try:
+        region, parent = steiner_region(g, verts)
+    except ValueError as e:
+        raise L.TnqsError(str(e))
+    opmap = {v: o for v, o in zip(verts, ops)}
+    mats = []
+    for v in region:
+        d = bpc._site_dim(v)
+        o = opmap.get(v)
+        m = np.eye(d) if o is None else (gate_matrix(o) if isinstance(o, str) else np.asarray(o))
+        mats.append(np.asarray(m, dtype=np.complex128).ravel(order="F"))
+    flat = np.ascontiguousarray(np.concatenate(mats))
+    rv, rvp = L.i32([g.index[v] for v in region]); pa, pap = L.i32(parent)
+    out = (C.c_double * 4)()
+    L.check(L.lib.tnqs_expect_region(bpc._h, len(region), rvp, pap, flat.ctypes.data_as(C.POINTER(C.c_double)), out))
+    return complex(out[0], out[1]) / complex(out[2], out[3])
 
 
 def expect_all(bpc: BeliefPropagationCache, op) -> np.ndarray:

@@ -109,6 +109,9 @@ int tnqs_expect_1site(tnqs_handle h, int v, const double* op, double* out) {
         out[0] = (nre * tre + nim * tim) / den; out[1] = (nim * tre - nre * tim) / den;
     });
 }
+int tnqs_expect_region(tnqs_handle h, int nr, const int32_t* rv, const int32_t* parent, const double* ops, double* out4) {
+    return guard([&] { expect_region(S(h), nr, rv, parent, ops, out4); });
+}
 int tnqs_vertex_scalars(tnqs_handle h, double* out) { return guard([&] { if (!out) throw Err(TNQS_ERR_INVALID, "vertex_scalars: null"); vertex_scalars(S(h), out); }); }
 int tnqs_edge_scalars(tnqs_handle h, double* out) { return guard([&] { if (!out) throw Err(TNQS_ERR_INVALID, "edge_scalars: null"); edge_scalars(S(h), out); }); }
 int tnqs_rescale(tnqs_handle h) { return guard([&] { rescale(S(h)); }); }

@@ -1520,6 +1520,99 @@ template <class T> static void rescale_t(State* s) {
 }
 void rescale(State* s) { if (s->dtype == TNQS_C64) rescale_t<float>(s); else rescale_t<double>(s); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// multi-site expectation value on a tree-shaped region (src/expect.jl:59-82): the norm network of the region's
+// vertices with the cache's messages on the boundary edges and operators inserted, numerator (ops) over denominator (identities).
+// The region is contracted leaves-to-root with the message kernels: m_{u->parent} = sum (O_u psi_u) conj(psi_u) prod(incoming).
+// ---------------------------------------------------------------------------------------------------------------
+template <class T> static void region_contract(State* s, int nr, const int32_t* rv, const int32_t* parent, const double* ops /* may be null */,
+                                               double* out_re_im) {
+    const Graph& g = *s->g;
+    const size_t esz = s->esz();
+    std::vector<int> pos(g.nv, -1);
+    for (int i = 0; i < nr; ++i) pos[rv[i]] = i;
+    // post-order: children before parents (depth descending)
+    std::vector<int> depth(nr, 0), order(nr);
+    for (int i = 0; i < nr; ++i) { int d = 0, p = i; while (parent[p] >= 0) { p = parent[p]; if (++d > nr) throw Err(TNQS_ERR_INVALID, "expect_region: parent array has a cycle"); } depth[i] = d; }
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return depth[a] > depth[b]; });
+    std::vector<Buf> up(nr);                       // message from region vertex i to its parent
+    for (int oi = 0; oi < nr; ++oi) {
+        const int i = order[oi], u = rv[i], par = parent[i] >= 0 ? rv[parent[i]] : -1;
+        SD sd = site_dims(s, u);
+        const void* ket = s->site[u]->p; Buf opbuf;
+        if (ops) {                                  // ket := O_u psi_u   (out[s'] = sum_s O[s', s] psi[s])
+            const double* m = ops + 2 * (size_t)0; size_t off = 0; for (int q = 0; q < i; ++q) off += 2 * (size_t)s->d[rv[q]] * s->d[rv[q]];
+            m = ops + off;
+            const int d = sd.d; bool ident = true;
+            for (int a = 0; a < d && ident; ++a) for (int b = 0; b < d; ++b) if (m[2 * (a + d * b)] != (a == b ? 1.0 : 0.0) || m[2 * (a + d * b) + 1] != 0.0) { ident = false; break; }
+            if (!ident) {
+                std::vector<T> hx;
+                for (int nn = 0; nn < d; ++nn) for (int kk = 0; kk < d; ++kk) { hx.push_back((T)m[2 * (nn + d * kk)]); hx.push_back((T)m[2 * (nn + d * kk) + 1]); }
+                std::vector<char> raw(reinterpret_cast<char*>(hx.data()), reinterpret_cast<char*>(hx.data()) + hx.size() * sizeof(T));
+                const char* dx = upload(s, raw);
+                opbuf = dalloc(s, sd.n * esz);
+                FiberItem it{}; it.in = ket; it.out = opbuf->p; it.X = dx;
+                it.D = d; it.PA = (int)(sd.n / d); it.K = 1; it.PB = 1; it.Do = d; it.No = 1;
+                const int TR = pick_TR(d, esz, 1);
+                tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
+                it.tpw = 1; it.tile_begin = 0; it.want_norm = 0;
+                std::vector<FiberItem> items{it};
+                const FiberItem* dI = upload(s, items);
+                launch_fiber_gemm<T>(s->stream, dI, 1, it.nta * it.ntb, TR, d, nullptr);
+                ket = opbuf->p;
+            }
+        }
+        std::vector<Chain> chains(1); Chain& c = chains[0]; c.v = u; c.src = ket; c.sd = sd;
+        for (int j = 0; j < sd.z; ++j) {
+            int k = g.nbr[u][j]; if (k == par) continue;
+            const void* mp = nullptr;
+            if (pos[k] >= 0) {
+                if (parent[pos[k]] < 0 || rv[parent[pos[k]]] != u) throw Err(TNQS_ERR_INVALID, "expect_region: the region's induced subgraph is not the given tree");
+                mp = up[pos[k]]->p;
+            } else { int de = g.dedge(k, u); if (s->msg[de]) mp = s->msg[de]->p; }
+            if (mp) c.steps.push_back({j, mp});
+        }
+        run_chains<T>(s, chains, TNQS_PROF_SMALL);
+        std::vector<GramJob> jobs(1);
+        GramJob& j = jobs[0]; j.X = chains[0].result; j.Y = s->site[u]->p; j.sd = sd;
+        if (par >= 0) { j.leg = g.leg(u, par); j.keep_site = false; } else { j.leg = -1; j.keep_site = true; }
+        if (par >= 0) run_grams<T, T>(s, jobs, TNQS_PROF_SMALL); else run_grams<T, double>(s, jobs, TNQS_PROF_SMALL);
+        const int n2 = j.KK * j.KK;
+        if (par >= 0) {
+            up[i] = dalloc(s, (size_t)n2 * esz);
+            std::vector<ReduceItem> ri{ReduceItem{j.partial->p, up[i]->p, n2, j.nchunks, 0, 0}};
+            const ReduceItem* dr = upload(s, ri);
+            launch_reduce<T, T>(s->stream, dr, 1, n2);
+        } else {
+            Buf d_out = dalloc(s, (size_t)n2 * 16);
+            std::vector<ReduceItem> ri{ReduceItem{j.partial->p, d_out->p, n2, j.nchunks, 0, 0}};
+            const ReduceItem* dr = upload(s, ri);
+            launch_reduce<double, double>(s->stream, dr, 1, n2);
+            std::vector<double> rho(2 * (size_t)n2);
+            HIPCHK(hipMemcpyAsync(rho.data(), d_out->p, (size_t)n2 * 16, hipMemcpyDeviceToHost, s->stream));
+            sync(s);
+            double tre = 0, tim = 0; const int d = sd.d;
+            for (int si = 0; si < d; ++si) { tre += rho[2 * (si + d * si)]; tim += rho[2 * (si + d * si) + 1]; }
+            out_re_im[0] = tre; out_re_im[1] = tim;
+        }
+    }
+}
+void expect_region(State* s, int nr, const int32_t* rv, const int32_t* parent, const double* ops, double* out4) {
+    const Graph& g = *s->g;
+    if (nr < 1 || !rv || !parent || !ops || !out4) throw Err(TNQS_ERR_INVALID, "expect_region: bad arguments");
+    if (s->nranks > 1) throw Err(TNQS_ERR_UNSUPPORTED, "expect_region: multi-site observables are not implemented for sharded handles");
+    int roots = 0;
+    for (int i = 0; i < nr; ++i) {
+        if (rv[i] < 0 || rv[i] >= g.nv) throw Err(TNQS_ERR_INVALID, "expect_region: bad vertex");
+        if (parent[i] < 0) ++roots; else if (parent[i] >= nr || g.edge(rv[i], rv[parent[i]]) < 0) throw Err(TNQS_ERR_INVALID, "expect_region: parent is not a neighbour");
+    }
+    if (roots != 1) throw Err(TNQS_ERR_INVALID, "expect_region: exactly one root expected");
+    HIPCHK(hipSetDevice(s->device));
+    if (s->dtype == TNQS_C64) { region_contract<float>(s, nr, rv, parent, ops, out4); region_contract<float>(s, nr, rv, parent, nullptr, out4 + 2); }
+    else { region_contract<double>(s, nr, rv, parent, ops, out4); region_contract<double>(s, nr, rv, parent, nullptr, out4 + 2); }
+}
+
 void expect_all(State* s, const double* ops, double* out) {
     const Graph& g = *s->g;
     std::vector<int> vs; std::vector<size_t> off; size_t tot = 0;

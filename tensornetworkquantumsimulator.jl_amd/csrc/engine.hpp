@@ -109,6 +109,7 @@ void truncate_bp(State* s, int maxdim, double cutoff, int normalize, int ngroups
                  const int32_t* eu, const int32_t* ev, const tnqs_bp_opts* bp);
 void rdm_1site(State* s, int v, double* out);
 void expect_all(State* s, const double* ops, double* out);
+void expect_region(State* s, int nr, const int32_t* rv, const int32_t* parent, const double* ops, double* out4);
 void vertex_scalars(State* s, double* out);
 void edge_scalars(State* s, double* out);
 void rescale(State* s);

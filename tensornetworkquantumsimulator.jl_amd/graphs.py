@@ -278,3 +278,55 @@ def forest_cover_edge_sequence(g: NamedGraph) -> List[Tuple[Vertex, Vertex]]:
             seq.extend((b, a) for (a, b) in reversed(post))
         remaining -= used
     return seq
+
+
+def steiner_region(g: "NamedGraph", verts) -> Tuple[List[Vertex], List[int]]:
+    """Vertices of the Steiner tree of `verts` (src/expect.jl:68 uses Graphs.steiner_tree) as (region, parent) with
+    parent[i] = index of the parent of region[i], -1 for the root region[0] = verts[0].  The tree is grown by attaching each
+    further vertex through its shortest path to the tree; the construction only accepts UNIQUE shortest paths and a region whose
+    induced subgraph is that tree, so that the result does not depend on tie-breaking inside a Steiner-tree heuristic
+    (neighbouring vertices, vertices on a line, any vertices of a tree graph); otherwise a ValueError explains why."""
+    verts = list(verts)
+    if len(set(verts)) != len(verts):
+        raise ValueError("steiner_region: repeated vertex")
+    tree = [verts[0]]
+    tset = {verts[0]}
+    for v in verts[1:]:
+        if v in tset:
+            continue
+        # BFS from v, counting shortest paths
+        dist, cnt, prev = {v: 0}, {v: 1}, {v: None}
+        frontier, hit = [v], []
+        while frontier and not hit:
+            nxt = []
+            for a in frontier:
+                for b in g.neighbors(a):
+                    if b not in dist:
+                        dist[b], cnt[b], prev[b] = dist[a] + 1, cnt[a], a
+                        nxt.append(b)
+                    elif dist[b] == dist[a] + 1:
+                        cnt[b] += cnt[a]
+            hit = [b for b in nxt if b in tset]
+            frontier = nxt
+        if not hit:
+            raise ValueError("steiner_region: the observable's vertices are not connected")
+        if len(hit) > 1 or cnt[hit[0]] != 1:
+            raise ValueError("steiner_region: the Steiner tree of these vertices is not unique (several shortest paths); "
+                             "only observables with an unambiguous region are supported on the HIP path")
+        a = prev[hit[0]]
+        while a is not None:
+            tree.append(a); tset.add(a)
+            a = prev[a]
+    n_int = sum(1 for (a, b) in g.edges if a in tset and b in tset)
+    if n_int != len(tree) - 1:
+        raise ValueError("steiner_region: the region's induced subgraph contains a loop")
+    # root at verts[0]
+    region, parent, seen = [verts[0]], [-1], {verts[0]: 0}
+    q = 0
+    while q < len(region):
+        a = region[q]
+        for b in g.neighbors(a):
+            if b in tset and b not in seen:
+                seen[b] = len(region); region.append(b); parent.append(q)
+        q += 1
+    return region, parent

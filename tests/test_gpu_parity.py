@@ -466,3 +466,39 @@ def test_bp_scalars_and_rescale_match_oracle(dtype, lattice):
     nrm = tn.normalize(psi, cache_update_kwargs=kw)
     b2 = tn.update(tn.BeliefPropagationCache(nrm), **kw)
     assert abs(tn.partitionfunction(b2) - 1) < 200 * tol
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_multi_site_expect_matches_oracle(dtype):
+    """8f N1: ("ZX", [v, w]) on the Steiner tree of the support with the cache's messages on its boundary (expect.jl:59-82)"""
+    tol = 1e-4 if dtype == np.complex64 else 1e-10
+    X = np.array([[0, 1], [1, 0.0]])
+    cases = [(tn.named_grid((3, 3)), [((1, 1), (1, 2)), ((2, 2), (3, 2)), ((1, 1), (1, 3)), ((2, 1), (2, 3))]),
+             (tn.named_comb_tree((3, 3)), [((1, 1), (1, 2)), ((1, 2), (3, 1)), ((1, 3), (3, 3))]),
+             (tn.heavy_hexagonal_lattice(1, 1), None)]
+    for g, pairs in cases:
+        psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=3, seed=13)
+        kw = dict(maxiter=8, tolerance=None, edge_sequence=tn.forest_cover_edge_sequence(g))
+        bpc = tn.update(tn.BeliefPropagationCache(psi), **kw)
+        oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **kw)
+        if pairs is None:
+            pairs = [g.edges[0], g.edges[3]]
+        for (a, b) in pairs:
+            region, parent = tn.steiner_region(g, [a, b])
+            got = tn.expect(bpc, ("ZX", [a, b]))
+            ref = o.expect_region(oc, {a: Z, b: X}, region)
+            assert abs(got - ref) < tol, (a, b, got, ref)
+            got3 = tn.expect(bpc, ("ZX", [a, b], 0.5))
+            assert abs(got3 - 0.5 * ref) < tol
+    # three sites on a line of the grid, operators given as a list
+    g = tn.named_grid((3, 3))
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=2, seed=3)
+    bpc = tn.update(tn.BeliefPropagationCache(psi), maxiter=10, tolerance=None)
+    oc = oracle_cache_from_device(bpc)
+    vs = [(2, 1), (2, 2), (2, 3)]
+    assert abs(tn.expect(bpc, (["Z", "X", "Z"], vs)) - o.expect_region(oc, {vs[0]: Z, vs[1]: X, vs[2]: Z}, vs)) < tol
+    # an ambiguous Steiner tree (two shortest paths around a plaquette) is refused, not guessed
+    with pytest.raises(tn.TnqsError):
+        tn.expect(bpc, ("ZZ", [(1, 1), (2, 2)]))
+    with pytest.raises(tn.TnqsError):
+        tn.expect(bpc, ("ZZZ", [(1, 1), (2, 2)]))

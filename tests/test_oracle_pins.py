@@ -168,3 +168,17 @@ def test_apply_gate_errors():
         o.apply_gate(bpc, np.eye(4), [(1, 1), (3, 3)])
     with pytest.raises(RuntimeError):
         o.apply_gate(bpc, np.eye(8), [(1, 1), (2, 1), (3, 1)])
+
+
+def test_multi_site_expect_bp_exact_on_trees():
+    """expect(alg"bp") with several vertices (expect.jl:59-82): the region contraction is exact on trees, so it must equal
+    the state-vector value (the known answer test_expect.jl:26-28 uses for single sites)."""
+    Zm = np.diag([1.0, -1.0]); Xm = np.array([[0, 1], [1, 0.0]])
+    for g, pairs in ((o.named_grid((5,)), [(((1,), (2,)), [(1,), (2,)]), (((1,), (4,)), [(1,), (2,), (3,), (4,)])]),
+                     (o.comb_tree((3, 3)), [(((1, 1), (1, 2)), [(1, 1), (1, 2)]), (((1, 2), (3, 1)), [(1, 2), (1, 1), (2, 1), (3, 1)])])):
+        psi = o.random_state(np.complex128, g, 3, seed=1)
+        bpc = o.update(o.BeliefPropagationCache(psi))
+        v = sv.tns_to_statevector(psi)
+        for (a, b), region in pairs:
+            val = o.expect_region(bpc, {a: Zm, b: Xm}, region)
+            assert abs(val - sv.expect_statevector_multi(v, g, {a: Zm, b: Xm})) < 1e-12
