@@ -19,7 +19,7 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
     dA.up(A, (size_t)m * n * esz);
     if (dtype == TNQS_C64) launch_identity<float>(nullptr, dV.p, n); else launch_identity<double>(nullptr, dV.p, n);
     // same residency policy as the engine: A+V in LDS, else A in LDS with V recovered, else global memory
-    const size_t lim = 160 * 1024 - 64;
+    const size_t lim = 160 * 1024 - 256;
     size_t lds_av = jacobi_lds_bytes(m, n, true, esz), lds_a = jacobi_lds_bytes(m, n, false, esz);
     const bool nov = lds_av > lim && lds_a <= lim;
     DBuf dA0((size_t)m * n * esz);

@@ -14,7 +14,7 @@
 namespace tnqs {
 
 static size_t bp_ws_budget() { static size_t v = 0; if (!v) { const char* e = std::getenv("TNQS_BP_WS_MB"); v = (e ? (size_t)std::atoll(e) : (size_t)24576) << 20; } return v; }
-static size_t jacobi_lds(size_t bytes) { static int g = -1; if (g < 0) { const char* e = std::getenv("TNQS_JACOBI_GLOBAL"); g = (e && e[0] == '1') ? 1 : 0; } return (g || bytes > 160 * 1024 - 64) ? 0 : bytes; }
+static size_t jacobi_lds(size_t bytes) { static int g = -1; if (g < 0) { const char* e = std::getenv("TNQS_JACOBI_GLOBAL"); g = (e && e[0] == '1') ? 1 : 0; } return (g || bytes > 160 * 1024 - 256) ? 0 : bytes; }
 static int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j : ji) m = std::max(m, std::max(j.m, j.n)); return m; }
 static bool use_chol() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_CHOL"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_small_svd() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_SMALLSVD"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }

@@ -417,6 +417,14 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     const int rq = (m + 15) >> 4, rqv = (n + 15) >> 4;
     int sweep = 0;
     __syncthreads();
+    // ||A||_F^2 is invariant under the rotations.  A pair of columns that are BOTH below n eps^2 ||A||_F^2 (singular values under
+    // ~sqrt(n) eps ||A||_F: rounding noise of a rank-deficient matrix) is left alone -- otherwise noise columns keep rotating
+    // against each other for many sweeps without changing any singular value that matters.
+    __shared__ double s_red[17];
+    double fro = 0;
+    for (int e = threadIdx.x; e < m * n; e += blockDim.x) { cx<T> v = A[(e % m) + mp * (e / m)]; fro += (double)v.re * v.re + (double)v.im * v.im; }
+    fro = block_sum(fro, s_red);
+    const T tiny = (T)((double)n * (double)eps_of<T>() * (double)eps_of<T>() * fro);
     for (; sweep < max_sweeps && n > 1; ++sweep) {
         if (threadIdx.x == 0) s_rot = 0;
         __syncthreads();
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
                 alpha = row16_sum(alpha); beta = row16_sum(beta); gre = row16_sum(gre); gim = row16_sum(gim);
                 const T g2 = gre * gre + gim * gim;
                 // f32: g2 must be a NORMAL number -- the fast reciprocal square root returns inf for (flushed) denormals
-                const bool rot = act && g2 > (sizeof(T) == 4 ? (T)1e-36 : (T)0) && g2 > tol * tol * alpha * beta;
+                const bool rot = act && g2 > (sizeof(T) == 4 ? (T)1e-36 : (T)0) && g2 > tol * tol * alpha * beta && !(alpha < tiny && beta < tiny);
                 if (rot) {
                     const T iga = fast_rsqrt<T>(g2);
                     const T pre = gre * iga, pim = -gim * iga;
@@ -550,13 +558,13 @@ template void launch_recover_v<double>(hipStream_t, const RecoverItem*, int, int
 // lds_bytes: max over the items of (m*n + (V ? n*n : 0)) * sizeof(complex<T>); 0 selects the global-memory kernel
 template <class T, int RQ> static void launch_jacobi_lds(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<T, RQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 64)); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<T, RQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 256)); attr = true; }
     hipLaunchKernelGGL((jacobi_lds_kernel<T, RQ>), dim3(nitems), dim3(1024), lds_bytes, s, d_items, max_sweeps); TNQS_CHECK_LAUNCH();
 }
 // mmax: largest row count among the items (selects the rows-per-lane instantiation)
 template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax) {
     if (nitems <= 0) return;
-    if (lds_bytes > 0 && lds_bytes <= 160 * 1024 - 64 && mmax <= 256) {
+    if (lds_bytes > 0 && lds_bytes <= 160 * 1024 - 256 && mmax <= 256) {
         if (mmax <= 32) launch_jacobi_lds<T, 2>(s, d_items, nitems, max_sweeps, lds_bytes);
         else if (mmax <= 64) launch_jacobi_lds<T, 4>(s, d_items, nitems, max_sweeps, lds_bytes);
         else if (mmax <= 128) launch_jacobi_lds<T, 8>(s, d_items, nitems, max_sweeps, lds_bytes);
@@ -687,7 +695,7 @@ void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {
     if (nitems <= 0) return;
     const size_t lds = (size_t)nmax * (nmax + 1) * 16;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 64)); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 256)); attr = true; }
     hipLaunchKernelGGL(chol_kernel, dim3(nitems), dim3(256), lds, s, d_items); TNQS_CHECK_LAUNCH();
 }
 
