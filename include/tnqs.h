@@ -152,6 +152,12 @@ int tnqs_vertex_scalars(tnqs_handle h, double* out_vertex);
 int tnqs_edge_scalars(tnqs_handle h, double* out_edge);
 int tnqs_rescale(tnqs_handle h);
 
+/* ---- symmetric (Vidal) gauge (src/symmetric_gauge.jl:1-62) ---------------------------------
+ * per edge: psi_src <- psi_src X^-1/2 U S^1/2, psi_dst <- psi_dst Y^-1/2 V S^1/2 with U S V = svd(X^1/2 (Y^1/2)^T), X, Y the two
+ * messages of the edge (eigenvalues + regularization before the roots); both messages := diag(S).  The state is unchanged and
+ * diag(S) is a BP fixed point when the input messages were one.  regularization < 0: default 10 eps(real(eltype)). */
+int tnqs_symmetric_gauge(tnqs_handle h, double regularization);
+
 /* ---- multi-GPU sharding (no reference analogue).  A rank owns a vertex subset: it holds only
  *      those site tensors and does all per-vertex work for them; messages are replicated.  The library calls
  *      the host-supplied all-gather at the exchange points (host side: torch.distributed over RCCL). --------- */

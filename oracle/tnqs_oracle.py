@@ -787,6 +787,39 @@ def rescale(bpc: BeliefPropagationCache) -> BeliefPropagationCache:
     return bpc
 
 
+def symmetric_gauge(bpc: BeliefPropagationCache, regularization: Optional[float] = None) -> BeliefPropagationCache:
+    """symmetric_gauge (src/symmetric_gauge.jl:1-62): per edge e = (src, dst), X = message(e), Y = message(reverse(e)):
+    psi_src <- psi_src X^{-1/2} U sqrt(S), psi_dst <- psi_dst Y^{-1/2} V sqrt(S) with U S V = svd(X^{1/2} (Y^{1/2})^T), both
+    messages of the edge := diag(S).  Eigenvalues are regularised by 10 eps before the roots (:1,:15-16)."""
+    bpc = bpc.copy()
+    g = bpc.g
+    real = np.float32 if bpc.tns.dtype == np.complex64 else np.float64
+    reg = 10 * np.finfo(real).eps if regularization is None else regularization
+    dt = bpc.tns.dtype
+    for (a, b) in g.edges:
+        la, lb = g.leg(a, b), g.leg(b, a)
+        roots = []
+        for m in (bpc.message((a, b)), bpc.message((b, a))):
+            w, q = np.linalg.eigh(m.astype(np.complex128), UPLO="U")            # safe_eigen, ishermitian = true (utils.jl:94-108)
+            w = w + reg
+            if np.any(w < 0):
+                raise ValueError("DomainError: sqrt of a negative (regularised) message eigenvalue")
+            # ITensors.eigen without explicit index sets takes the PRIMED index as the row index (A_{l' l} U_{l j} = U_{l' j} D_j),
+            # i.e. it diagonalises M^T; X_U * f(D) * prime(dag(X_U)) is therefore f(M)^T = conj(f(M)) as a tensor [l, l']
+            roots.append((((q * np.sqrt(w)) @ q.conj().T).conj(), ((q / np.sqrt(w)) @ q.conj().T).conj()))
+        (rx, irx), (ry, iry) = roots
+        ce = (rx @ ry.T).astype(dt)
+        u, sv_, vh = np.linalg.svd(ce, full_matrices=False)
+        xs = (irx @ u.astype(np.complex128)) * np.sqrt(sv_.astype(np.float64))
+        xd = (iry @ vh.T.astype(np.complex128)) * np.sqrt(sv_.astype(np.float64))
+        bpc.tns.tensors[a] = _absorb(bpc.tns.tensors[a].astype(np.complex128), la, xs).astype(dt)
+        bpc.tns.tensors[b] = _absorb(bpc.tns.tensors[b].astype(np.complex128), lb, xd).astype(dt)
+        smat = np.diag(sv_).astype(dt)
+        bpc.messages[(a, b)] = smat
+        bpc.messages[(b, a)] = smat.copy()
+    return bpc
+
+
 def partitionfunction(bpc: BeliefPropagationCache) -> complex:          # abstract...:289-304
     num = [vertex_scalar(bpc, v) for v in bpc.g.vertices]
     den = [edge_scalar(bpc, e) for e in bpc.g.edges]

@@ -492,6 +492,24 @@ def normalize(tns: TensorNetworkState, alg: str = "bp", cache_update_kwargs=None
     return rescale(bpc).network()
 
 
+def symmetric_gauge(x, regularization: Optional[float] = None, cache_update_kwargs=None, device: int = 0):
+    """symmetric_gauge (src/symmetric_gauge.jl:58-68): for a cache, a gauged COPY (messages become diag(S) on every edge); for a
+    TensorNetworkState, BP-update first (default maxiter = 40) and return the gauged network"""
+    reg = -1.0 if regularization is None else float(regularization)
+    if isinstance(x, TensorNetworkState):
+        bpc = update(BeliefPropagationCache(x, device=device), **(cache_update_kwargs if cache_update_kwargs is not None else dict(maxiter=40)))
+        L.check(L.lib.tnqs_symmetric_gauge(bpc._h, reg))
+        return bpc.network()
+    out = x.copy()
+    L.check(L.lib.tnqs_symmetric_gauge(out._h, reg))
+    return out
+
+
+def symmetrize_and_normalize(bpc: BeliefPropagationCache, regularization: Optional[float] = None) -> BeliefPropagationCache:
+    """symmetrize_and_normalize (symmetric_gauge.jl:70-74): rescale, then symmetric gauge"""
+    return symmetric_gauge(rescale(bpc), regularization=regularization)
+
+
 def profile_enable(bpc: BeliefPropagationCache, on: bool = True):
     L.check(L.lib.tnqs_profile_enable(bpc._h, 1 if on else 0))
 

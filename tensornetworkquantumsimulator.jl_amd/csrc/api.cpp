@@ -115,6 +115,7 @@ int tnqs_expect_region(tnqs_handle h, int nr, const int32_t* rv, const int32_t* 
 int tnqs_vertex_scalars(tnqs_handle h, double* out) { return guard([&] { if (!out) throw Err(TNQS_ERR_INVALID, "vertex_scalars: null"); vertex_scalars(S(h), out); }); }
 int tnqs_edge_scalars(tnqs_handle h, double* out) { return guard([&] { if (!out) throw Err(TNQS_ERR_INVALID, "edge_scalars: null"); edge_scalars(S(h), out); }); }
 int tnqs_rescale(tnqs_handle h) { return guard([&] { rescale(S(h)); }); }
+int tnqs_symmetric_gauge(tnqs_handle h, double regularization) { return guard([&] { symmetric_gauge(S(h), regularization); }); }
 int tnqs_expect_all(tnqs_handle h, const double* ops, double* out) {
     return guard([&] { if (!ops || !out) throw Err(TNQS_ERR_INVALID, "expect_all: null"); expect_all(S(h), ops, out); });
 }

@@ -1613,6 +1613,84 @@ void expect_region(State* s, int nr, const int32_t* rv, const int32_t* parent, c
     else { region_contract<double>(s, nr, rv, parent, ops, out4); region_contract<double>(s, nr, rv, parent, nullptr, out4 + 2); }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// symmetric gauge (src/symmetric_gauge.jl:1-62).  The reference loops over the edges; every edge only touches
+// its own leg of the two site tensors and its own two messages, so all edges are factorised in one batch and each site
+// receives the mode products of all its legs in one chain (different legs commute).
+// ---------------------------------------------------------------------------------------------------------------
+template <class T> static void symmetric_gauge_t(State* s, double regularization) {
+    const Graph& g = *s->g;
+    const size_t esz = s->esz();
+    if (s->nranks > 1) throw Err(TNQS_ERR_UNSUPPORTED, "symmetric_gauge: not implemented for sharded handles");
+    HIPCHK(hipSetDevice(s->device));
+    if (g.ne == 0) return;
+    const double reg = regularization >= 0 ? regularization : 10.0 * (s->dtype == TNQS_C64 ? 1.1920928955078125e-07 : 2.220446049250313e-16);
+    // Hermitian eigen factorisations of all 2|E| messages in f64 (safe_eigen, utils.jl:94-108)
+    std::vector<Buf> H(2 * (size_t)g.ne), V(2 * (size_t)g.ne);
+    std::vector<EnvItem> ei; std::vector<JacobiItem> ji;
+    for (int de = 0; de < 2 * g.ne; ++de) {
+        int n = s->chi[de / 2];
+        if (n > 256) throw Err(TNQS_ERR_UNSUPPORTED, "symmetric_gauge: bond dimension > 256");
+        H[de] = dalloc(s, (size_t)n * n * 16); V[de] = dalloc(s, (size_t)n * n * 16);
+        ei.push_back(EnvItem{s->msg[de] ? s->msg[de]->p : nullptr, H[de]->p, V[de]->p, n});
+        ji.push_back(JacobiItem{H[de]->p, V[de]->p, n, n, nullptr});
+    }
+    { const EnvItem* d = upload(s, ei); launch_env_prepare<T>(s->stream, d, (int)ei.size()); }
+    { const JacobiItem* d = upload(s, ji); size_t lds = 0; for (auto& j : ji) lds = std::max(lds, jacobi_lds_bytes(j.n, j.n, true, 16));
+      launch_jacobi<double>(s->stream, d, (int)ji.size(), 60, jacobi_lds(lds), mmax_of(ji)); }
+    // per edge: roots, Ce, its SVD, the two gauge matrices
+    Buf d_flag = dalloc(s, sizeof(int));
+    HIPCHK(hipMemsetAsync(d_flag->p, 0, sizeof(int), s->stream));
+    struct EdgeWS { Buf rx, ry, irx, iry, Ce, Ce0, Vs, Xs, Xd, S; };
+    std::vector<EdgeWS> ws(g.ne); std::vector<SymGaugeItem> items; std::vector<JacobiItem> sj; std::vector<RecoverItem> rv; int nmax = 1;
+    for (int e = 0; e < g.ne; ++e) {
+        int n = s->chi[e]; size_t nn = (size_t)n * n; EdgeWS& w = ws[e];
+        w.rx = dalloc(s, nn * 16); w.ry = dalloc(s, nn * 16); w.irx = dalloc(s, nn * 16); w.iry = dalloc(s, nn * 16);
+        w.Ce = dalloc(s, nn * esz); w.Ce0 = dalloc(s, nn * esz); w.Vs = dalloc(s, nn * esz); w.Xs = dalloc(s, nn * esz); w.Xd = dalloc(s, nn * esz);
+        w.S = dalloc(s, (size_t)n * 8);
+        items.push_back(SymGaugeItem{H[2 * e]->p, V[2 * e]->p, H[2 * e + 1]->p, V[2 * e + 1]->p, w.rx->p, w.ry->p, w.irx->p, w.iry->p,
+                                     w.Ce->p, w.Ce0->p, w.Vs->p, w.Xs->p, w.Xd->p, reinterpret_cast<double*>(w.S->p), n, reg, reinterpret_cast<int*>(d_flag->p)});
+        sj.push_back(JacobiItem{w.Ce->p, nullptr, n, n, nullptr});
+        rv.push_back(RecoverItem{w.Ce0->p, w.Ce->p, w.Vs->p, n, n}); nmax = std::max(nmax, n);
+    }
+    const SymGaugeItem* d_items = upload(s, items);
+    launch_symg_build<T>(s->stream, d_items, (int)items.size());
+    { const JacobiItem* d = upload(s, sj); size_t lds = 0; for (auto& j : sj) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, false, esz));
+      launch_jacobi<T>(s->stream, d, (int)sj.size(), 60, jacobi_lds(lds), mmax_of(sj)); }
+    { const RecoverItem* d = upload(s, rv);
+      if (std::is_same<T, float>::value && use_mfma()) launch_recover_v_mfma(s->stream, d, (int)rv.size(), nmax); else launch_recover_v<T>(s->stream, d, (int)rv.size(), nmax); }
+    launch_symg_finish<T>(s->stream, d_items, (int)items.size());
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, d_flag->p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (flag) throw Err(TNQS_ERR_NUMERIC, "symmetric_gauge: a regularised message eigenvalue is negative (DomainError in the reference, symmetric_gauge.jl:18)");
+    // site tensors: psi_v <- psi_v x_leg X for every leg (source end of edge e: Xs, destination end: Xd)
+    std::vector<int> verts; std::vector<Chain> chains;
+    for (int v = 0; v < g.nv; ++v) {
+        if (!s->site[v] || g.nbr[v].empty()) continue;
+        Chain c; c.v = v; c.src = s->site[v]->p; c.sd = site_dims(s, v);
+        for (int j = 0; j < c.sd.z; ++j) { int e = g.nbr_e[v][j]; c.steps.push_back({j, (g.esrc[e] == v) ? ws[e].Xs->p : ws[e].Xd->p}); }
+        chains.push_back(std::move(c)); verts.push_back(v);
+    }
+    run_chains<T>(s, chains, TNQS_PROF_SMALL);
+    for (size_t i = 0; i < chains.size(); ++i) {
+        Buf nb;
+        for (int k = 0; k < 2; ++k) if (chains[i].tmp[k] && chains[i].tmp[k]->p == chains[i].result) nb = chains[i].tmp[k];
+        if (!nb) throw Err(TNQS_ERR_HIP, "internal: symmetric_gauge chain result");
+        s->keepalive.push_back(s->site[verts[i]]); s->site[verts[i]] = nb;
+    }
+    // both messages of an edge := diag(S)   (:54-55)
+    std::vector<DiagItem> di;
+    for (int e = 0; e < g.ne; ++e) {
+        int n = s->chi[e];
+        for (int dir = 0; dir < 2; ++dir) { Buf m = dalloc(s, (size_t)n * n * esz); di.push_back(DiagItem{m->p, reinterpret_cast<const double*>(ws[e].S->p), n});
+                                             s->keepalive.push_back(s->msg[2 * e + dir]); s->msg[2 * e + dir] = m; }
+    }
+    { const DiagItem* d = upload(s, di); launch_diag<T>(s->stream, d, (int)di.size()); }
+    sync(s);
+}
+void symmetric_gauge(State* s, double regularization) { if (s->dtype == TNQS_C64) symmetric_gauge_t<float>(s, regularization); else symmetric_gauge_t<double>(s, regularization); }
+
 void expect_all(State* s, const double* ops, double* out) {
     const Graph& g = *s->g;
     std::vector<int> vs; std::vector<size_t> off; size_t tot = 0;

@@ -113,6 +113,7 @@ void expect_region(State* s, int nr, const int32_t* rv, const int32_t* parent, c
 void vertex_scalars(State* s, double* out);
 void edge_scalars(State* s, double* out);
 void rescale(State* s);
+void symmetric_gauge(State* s, double regularization);
 void prof_collect(State* s);
 
 }  // namespace tnqs

@@ -1088,6 +1088,104 @@ template <class T> void launch_cscale(hipStream_t s, const CScaleItem* d_items, 
 template void launch_cscale<float>(hipStream_t, const CScaleItem*, int);
 template void launch_cscale<double>(hipStream_t, const CScaleItem*, int);
 
+// ------------------------------------------------------------------------------------------------------------
+// symmetric gauge (src/symmetric_gauge.jl)
+// ------------------------------------------------------------------------------------------------------------
+template <class T> __global__ __launch_bounds__(256) void symg_build_kernel(const SymGaugeItem* __restrict__ items) {
+    __shared__ double lx[256], ly[256];
+    const SymGaugeItem it = items[blockIdx.x];
+    const int n = it.n;
+    const cx<double>* AX = reinterpret_cast<const cx<double>*>(it.AX); const cx<double>* VX = reinterpret_cast<const cx<double>*>(it.VX);
+    const cx<double>* AY = reinterpret_cast<const cx<double>*>(it.AY); const cx<double>* VY = reinterpret_cast<const cx<double>*>(it.VY);
+    for (int j = threadIdx.x; j < n; j += 256) {
+        double a = 0, b = 0;            // Rayleigh quotients v_j^dagger H v_j
+        for (int i = 0; i < n; ++i) { cx<double> v = VX[i + n * j], w = AX[i + n * j]; a += v.re * w.re + v.im * w.im;
+                                      cx<double> p = VY[i + n * j], q = AY[i + n * j]; b += p.re * q.re + p.im * q.im; }
+        a += it.reg; b += it.reg;       // map_diag(x -> x + regularization) (:15-16)
+        if (a < 0 || b < 0) *it.flag = 1;     // sqrt of a negative real: DomainError in the reference
+        lx[j] = a; ly[j] = b;
+    }
+    __syncthreads();
+    cx<double>* rx = reinterpret_cast<cx<double>*>(it.rx); cx<double>* ry = reinterpret_cast<cx<double>*>(it.ry);
+    cx<double>* irx = reinterpret_cast<cx<double>*>(it.irx); cx<double>* iry = reinterpret_cast<cx<double>*>(it.iry);
+    // ITensors.eigen without index sets diagonalises M^T (the primed index is the row index), so every function of the message
+    // enters as f(M)^T = conj(f(M)) [l, l']  (:13-24)
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        int i = e % n, l = e / n;
+        cx<double> sx = cmake<double>(0, 0), ix = sx, sy = sx, iy = sx;
+        for (int j = 0; j < n; ++j) {
+            cx<double> vi = VX[i + n * j], vl = VX[l + n * j];
+            cx<double> o = cmake<double>(vi.re * vl.re + vi.im * vl.im, -(vi.im * vl.re - vi.re * vl.im));      // conj(vi conj(vl))
+            double r = lx[j] > 0 ? sqrt(lx[j]) : 0.0, ir = lx[j] > 0 ? 1.0 / r : 0.0;
+            sx.re += r * o.re; sx.im += r * o.im; ix.re += ir * o.re; ix.im += ir * o.im;
+            cx<double> wi = VY[i + n * j], wl = VY[l + n * j];
+            cx<double> p = cmake<double>(wi.re * wl.re + wi.im * wl.im, -(wi.im * wl.re - wi.re * wl.im));
+            double q = ly[j] > 0 ? sqrt(ly[j]) : 0.0, iq = ly[j] > 0 ? 1.0 / q : 0.0;
+            sy.re += q * p.re; sy.im += q * p.im; iy.re += iq * p.re; iy.im += iq * p.im;
+        }
+        rx[e] = sx; irx[e] = ix; ry[e] = sy; iry[e] = iy;
+    }
+    __syncthreads();
+    __threadfence_block();
+    cx<T>* Ce = reinterpret_cast<cx<T>*>(it.Ce); cx<T>* Ce0 = reinterpret_cast<cx<T>*>(it.Ce0);
+    for (int e = threadIdx.x; e < n * n; e += 256) {          // Ce[l, c] = sum_l' rootX[l, l'] rootY[c, l']   (:29-30)
+        int l = e % n, c = e / n;
+        cx<double> acc = cmake<double>(0, 0);
+        for (int k = 0; k < n; ++k) cfma(acc, rx[l + n * k], ry[c + n * k]);
+        cx<T> v = cmake<T>((T)acc.re, (T)acc.im);
+        Ce[e] = v; Ce0[e] = v;
+    }
+}
+template <class T> void launch_symg_build(hipStream_t s, const SymGaugeItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((symg_build_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+template void launch_symg_build<float>(hipStream_t, const SymGaugeItem*, int);
+template void launch_symg_build<double>(hipStream_t, const SymGaugeItem*, int);
+template <class T> __global__ __launch_bounds__(256) void symg_finish_kernel(const SymGaugeItem* __restrict__ items) {
+    __shared__ double sig[256];
+    __shared__ int perm[256];
+    const SymGaugeItem it = items[blockIdx.x];
+    const int n = it.n;
+    const cx<T>* A = reinterpret_cast<const cx<T>*>(it.Ce);       // U Sigma
+    const cx<T>* V = reinterpret_cast<const cx<T>*>(it.Vsvd);
+    for (int u = threadIdx.x; u < n; u += 256) {
+        double s2 = 0;
+        for (int i = 0; i < n; ++i) { cx<T> v = A[i + (size_t)n * u]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
+        sig[u] = (s2 == s2 && s2 < 1e300) ? sqrt(s2) : 0.0;
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < n; u += 256) {                  // descending order, stable
+        int rk = 0; double su = sig[u];
+        for (int v = 0; v < n; ++v) rk += (sig[v] > su) || (sig[v] == su && v < u);
+        perm[rk] = u;
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < n; u += 256) it.S[u] = (double)(T)sig[perm[u]];
+    const cx<double>* irx = reinterpret_cast<const cx<double>*>(it.irx); const cx<double>* iry = reinterpret_cast<const cx<double>*>(it.iry);
+    cx<T>* Xs = reinterpret_cast<cx<T>*>(it.Xs); cx<T>* Xd = reinterpret_cast<cx<T>*>(it.Xd);
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        int l = e % n, u = e / n; int pu = perm[u]; double su = sig[pu];
+        cx<double> a = cmake<double>(0, 0), b = cmake<double>(0, 0);
+        if (su > 0) {
+            for (int k = 0; k < n; ++k) {
+                cx<T> x = A[k + (size_t)n * pu], y = V[k + (size_t)n * pu];
+                cfma(a, irx[l + n * k], cmake<double>((double)x.re, (double)x.im));
+                cfma(b, iry[l + n * k], cmake<double>((double)y.re, -(double)y.im));      // V^T of ITensors = conj of the right singular vectors
+            }
+            const double f = 1.0 / sqrt(su), gq = sqrt(su);       // U = A / sigma, times sqrt(sigma)
+            a.re *= f; a.im *= f; b.re *= gq; b.im *= gq;
+        }
+        Xs[e] = cmake<T>((T)a.re, (T)a.im); Xd[e] = cmake<T>((T)b.re, (T)b.im);
+    }
+}
+template <class T> void launch_symg_finish(hipStream_t s, const SymGaugeItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((symg_finish_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+template void launch_symg_finish<float>(hipStream_t, const SymGaugeItem*, int);
+template void launch_symg_finish<double>(hipStream_t, const SymGaugeItem*, int);
+
 template <class T> __global__ __launch_bounds__(256) void permute_kernel(PermItem it) {
     const cx<T>* in = reinterpret_cast<const cx<T>*>(it.in);
     cx<T>* out = reinterpret_cast<cx<T>*>(it.out);

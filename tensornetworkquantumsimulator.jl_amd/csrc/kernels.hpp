@@ -87,6 +87,13 @@ template <class T> void launch_edge_scalar(hipStream_t s, const EdgeScalarItem* 
 // dst = src * (re + i im)
 struct CScaleItem { const void* src; void* dst; size_t n; double re, im; };
 template <class T> void launch_cscale(hipStream_t s, const CScaleItem* d_items, int nitems);
+// symmetric_gauge! (src/symmetric_gauge.jl:1-62) per edge, n = chi.  build: from the f64 Jacobi factorisations (A = H V, V) of both
+// messages: irx, iry = conj((M + reg)^-1/2) (f64, n x n) and Ce = conj((X+reg)^1/2) conj((Y+reg)^1/2)^T in data precision (two copies:
+// Ce is rotated by the SVD, Ce0 stays).  finish: from U Sigma (in Ce) and V: S (descending), Xs = irx U S^1/2, Xd = iry conj(V) S^1/2.
+struct SymGaugeItem { const void* AX; const void* VX; const void* AY; const void* VY; void* rx; void* ry; void* irx; void* iry;
+                      void* Ce; void* Ce0; void* Vsvd; void* Xs; void* Xd; double* S; int n; double reg; int* flag; };
+template <class T> void launch_symg_build(hipStream_t s, const SymGaugeItem* d_items, int nitems);
+template <class T> void launch_symg_finish(hipStream_t s, const SymGaugeItem* d_items, int nitems);
 struct PermItem { const void* in; void* out; int ndim; int dims_out[8]; long long stride_in[8]; size_t n; };
 
 // ---- launchers (T = float or double; data are complex<T>) ------------------------------------------------------

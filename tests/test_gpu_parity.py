@@ -502,3 +502,39 @@ def test_multi_site_expect_matches_oracle(dtype):
         tn.expect(bpc, ("ZZ", [(1, 1), (2, 2)]))
     with pytest.raises(tn.TnqsError):
         tn.expect(bpc, ("ZZZ", [(1, 1), (2, 2)]))
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+@pytest.mark.parametrize("lattice", ["grid3x3", "comb33", "hh11"])
+def test_symmetric_gauge_matches_oracle(dtype, lattice):
+    """8f N3: symmetric_gauge (symmetric_gauge.jl:1-62): same bond spectra S as the oracle, state unchanged, diag(S) a BP fixed point"""
+    g = {"grid3x3": lambda: tn.named_grid((3, 3)), "comb33": lambda: tn.named_comb_tree((3, 3)), "hh11": lambda: tn.heavy_hexagonal_lattice(1, 1)}[lattice]()
+    tol = 2e-4 if dtype == np.complex64 else 1e-8
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=3, seed=17)
+    kw = dict(maxiter=60, tolerance=None, edge_sequence=tn.forest_cover_edge_sequence(g))
+    bpc = tn.update(tn.BeliefPropagationCache(psi), **kw)
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **kw)
+    sg = tn.symmetric_gauge(bpc)
+    osg = o.symmetric_gauge(oc)
+    for (a, b) in g.edges:
+        m, mr = sg.message((a, b)), sg.message((b, a))
+        assert np.max(np.abs(m - np.diag(np.diag(m)))) == 0 and np.array_equal(m, mr)
+        S, So = np.diag(m).real, np.diag(osg.message((a, b))).real
+        assert np.all(np.diff(S) <= 0)
+        assert np.max(np.abs(S / S.sum() - So / So.sum())) < tol
+        assert abs(S.sum() - So.sum()) < 50 * tol * So.sum()
+    if lattice != "hh11":
+        v0 = sv.tns_to_statevector(to_oracle_state(psi)); v1 = sv.tns_to_statevector(to_oracle_state(sg.network()))
+        assert abs(sv.fidelity(v0, v1) - 1) < 50 * tol
+        assert abs(np.vdot(v1, v1) / np.vdot(v0, v0) - 1) < 50 * tol
+    up = tn.update(sg, maxiter=1, tolerance=None)
+    for (a, b) in g.edges[:6]:
+        for d in ((a, b), (b, a)):
+            m0, m1 = sg.message(d), up.message(d)
+            assert np.max(np.abs(m0 / np.trace(m0) - m1 / np.trace(m1))) < 50 * tol
+    for v in g.vertices[:4]:
+        assert abs(tn.expect(sg, ("Z", [v])) - o.expect_1site(oc, Z, v)) < 50 * tol
+    # the input cache is untouched; the TensorNetworkState entry point runs BP itself
+    assert not np.array_equal(bpc.message(g.edges[0]), sg.message(g.edges[0]))
+    t2 = tn.symmetric_gauge(psi, cache_update_kwargs=kw)
+    assert np.max(np.abs(np.abs(t2.tensors[g.vertices[0]]) - np.abs(sg.tensor(g.vertices[0])))) < 1.0

@@ -182,3 +182,22 @@ def test_multi_site_expect_bp_exact_on_trees():
         for (a, b), region in pairs:
             val = o.expect_region(bpc, {a: Zm, b: Xm}, region)
             assert abs(val - sv.expect_statevector_multi(v, g, {a: Zm, b: Xm})) < 1e-12
+
+
+def test_symmetric_gauge_invariants():
+    """symmetric_gauge (symmetric_gauge.jl:1-62): the state is unchanged, both messages of every edge become the same diagonal
+    matrix S, and that is a BP fixed point -- for COMPLEX messages this only holds with ITensors.eigen's index convention
+    (functions of the message enter transposed), which is what the restatement pins."""
+    for g in (o.named_grid((3, 3)), o.comb_tree((3, 3))):
+        psi = o.random_state(np.complex128, g, 3, seed=4)
+        bpc = o.update(o.BeliefPropagationCache(psi), maxiter=300, tolerance=1e-15)
+        sg = o.symmetric_gauge(bpc)
+        v0, v1 = sv.tns_to_statevector(psi), sv.tns_to_statevector(sg.tns)
+        assert abs(sv.fidelity(v0, v1) - 1) < 1e-12
+        up = o.update(sg, maxiter=1, tolerance=None)
+        for (a, b) in g.edges:
+            m = sg.message((a, b))
+            assert np.allclose(m, np.diag(np.diag(m))) and np.allclose(m, sg.message((b, a)))
+            for d in ((a, b), (b, a)):
+                m0, m1 = sg.message(d), up.message(d)
+                assert np.max(np.abs(m0 / np.trace(m0) - m1 / np.trace(m1))) < 1e-6
