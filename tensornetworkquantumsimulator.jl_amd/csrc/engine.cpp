@@ -1,6 +1,8 @@
 // engine.cpp -- see engine.hpp.  Host orchestration only; every flop runs in the HIP kernels of kernels*.hip.
 #include "engine.hpp"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <array>
 #include <climits>
 #include <cmath>
@@ -19,6 +21,17 @@ static int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j 
 static bool use_chol() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_CHOL"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_small_svd() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_SMALLSVD"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_apply64() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_APPLY64"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
+// optional host-side phase timing (TNQS_HOST_TIMING=1): printed when the process exits
+struct HostTimer {
+    static double acc[8]; static long cnt[8];
+    int k; std::chrono::steady_clock::time_point t0; bool on;
+    explicit HostTimer(int kk) : k(kk), t0(std::chrono::steady_clock::now()), on(true) {}
+    void stop() { if (on) { acc[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); cnt[k]++; on = false; } }
+    ~HostTimer() { stop(); }
+};
+double HostTimer::acc[8] = {0}; long HostTimer::cnt[8] = {0};
+static struct HostTimerReport { ~HostTimerReport() { const char* e = std::getenv("TNQS_HOST_TIMING"); if (e && e[0] == '1') for (int k = 0; k < 8; ++k) if (HostTimer::cnt[k])
+    std::fprintf(stderr, "[tnqs host timing] phase %d: %.2f ms total, %ld calls, %.1f us each\n", k, HostTimer::acc[k], HostTimer::cnt[k], 1e3 * HostTimer::acc[k] / HostTimer::cnt[k]); } } g_host_timer_report;
 static bool use_mfma() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_MFMA"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 
 void hipchk(hipError_t e, const char* what) {
@@ -603,6 +616,7 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
             // sub-batches bounded by workspace bytes
             size_t start = 0;
             while (start < lev.size()) {
+                HostTimer ht_prep(0);
                 size_t budget = bp_ws_budget(), used = 0, end = start;
                 while (end < lev.size()) {
                     int de = plan.seq[lev[end]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
@@ -657,8 +671,10 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     }
                     chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(fm);
                 }
+                ht_prep.stop();
                 std::vector<char> is_shared(chains.size(), 0);
                 for (int ci : sh_chain) is_shared[ci] = 1;
+                HostTimer ht_launch(1);
                 if (!sh_pair.empty()) {
                     int spw = (int)std::max(1.0, std::min(8.0, sh_pair_slices / 2048.0)); int wgs = 0;
                     for (auto& it : sh_pair) { it.spw = spw; it.slice_begin = wgs; wgs += (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw; }
@@ -695,6 +711,8 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     for (size_t q = 0; q < jf.size(); ++q) jobs[idf[q]] = jf[q];
                     for (size_t q = 0; q < jp.size(); ++q) jobs[idp[q]] = jp[q];
                 }
+                ht_launch.stop();
+                HostTimer ht_fin(2);
                 std::vector<MsgFinalItem> fin;
                 if (s->nranks <= 1) {
                     for (size_t i = 0; i < jobs.size(); ++i) {
@@ -745,7 +763,9 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
                     launch_msg_finalize<T>(s->stream, d, (int)fin.size());
                 }
-                if (s->nranks > 1) HIPCHK(hipStreamSynchronize(s->stream));    // the exchange buffer is reused by the next sub-batch
+                ht_fin.stop();
+                // (sharded) the next sub-batch writes the exchange buffer again: ordered after this finalize by the stream; the host-side
+                // all-gather callback is always preceded by a stream synchronisation inside exchange()
                 start = end;
             }
         }
@@ -998,11 +1018,14 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, dr, (int)ri.size(), elems); }
         if (sharded) {
             exchange(s, stride);
+            // one private copy of the gathered block (the exchange buffer is reused by the record exchange of this batch); the G of
+            // every site this rank needs is a view into it
+            Buf G_keep = dalloc(s, std::max<size_t>(256, stride * (size_t)s->nranks));
+            HIPCHK(hipMemcpyAsync(G_keep->p, s->exch, stride * (size_t)s->nranks, hipMemcpyDeviceToDevice, s->stream));
             for (size_t i = 0; i < sj.size(); ++i) {
                 if (!part[i / 2]) continue;
                 size_t nn = (size_t)nof(i) * nof(i);
-                if (!GA[i]) GA[i] = dalloc(s, nn * 16);
-                HIPCHK(hipMemcpyAsync(GA[i]->p, reinterpret_cast<char*>(s->exch) + (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16, hipMemcpyDeviceToDevice, s->stream));
+                GA[i] = sub_buffer(G_keep, (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16);
             }
         }
     }
@@ -1179,33 +1202,38 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         for (int gi = 0; gi < ng; ++gi) { int r = s->owner[gates[gi].v1]; slot[gi] = rank_bytes[r]; rank_bytes[r] += slot_bytes; }
         size_t stride = 0; for (size_t b : rank_bytes) stride = std::max(stride, b);
         char* base = reinterpret_cast<char*>(s->exch);
-        std::vector<double> hdr(4 * (size_t)ng, 0.0);
-        for (int gi = 0; gi < ng; ++gi) {
-            if (s->owner[gates[gi].v1] != s->rank) continue;
-            char* dst = base + (size_t)s->rank * stride + slot[gi];
-            hdr[4 * gi] = info[8 * gi + 2]; hdr[4 * gi + 1] = info[8 * gi + 3]; hdr[4 * gi + 2] = terr[gi];
-            HIPCHK(hipMemcpyAsync(dst, &hdr[4 * gi], 32, hipMemcpyHostToDevice, s->stream));
-            HIPCHK(hipMemcpyAsync(dst + 32, ws[gi].S->p, (size_t)ws[gi].cap * 8, hipMemcpyDeviceToDevice, s->stream));
-            const SiteJob& b = sj[2 * gi + 1];
-            HIPCHK(hipMemcpyAsync(dst + 32 + (size_t)cap_max * 8, ws[gi].X2->p, (size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz, hipMemcpyDeviceToDevice, s->stream));
+        {   // pack the records of the gates whose first vertex is ours (one launch)
+            std::vector<RecordPackItem> rp;
+            std::vector<int> qof(ng, -1); for (int q = 0; q < npg; ++q) qof[pg[q]] = q;
+            for (int gi = 0; gi < ng; ++gi) {
+                if (s->owner[gates[gi].v1] != s->rank) continue;
+                const SiteJob& b = sj[2 * gi + 1]; const int q = qof[gi];
+                rp.push_back(RecordPackItem{base + (size_t)s->rank * stride + slot[gi], gitems[q].info, gitems[q].truncerr, reinterpret_cast<const double*>(ws[gi].S->p),
+                                            ws[gi].cap, ws[gi].X2->p, (long long)((size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz / 8), (long long)(32 + (size_t)cap_max * 8)});
+            }
+            if (!rp.empty()) { const RecordPackItem* d = upload(s, rp); launch_record_pack(s->stream, d, (int)rp.size()); }
         }
         exchange(s, stride);
         // keep a private copy of the gathered block: the exchange buffer is reused by the next batch
-        S_keep = dalloc(s, stride * (size_t)s->nranks);
+        S_keep = dalloc(s, std::max<size_t>(256, stride * (size_t)s->nranks));
         HIPCHK(hipMemcpyAsync(S_keep->p, base, stride * (size_t)s->nranks, hipMemcpyDeviceToDevice, s->stream));
-        std::vector<double> allhdr(4 * (size_t)ng);
-        for (int gi = 0; gi < ng; ++gi)
-            HIPCHK(hipMemcpyAsync(&allhdr[4 * gi], reinterpret_cast<char*>(S_keep->p) + (size_t)s->owner[gates[gi].v1] * stride + slot[gi], 32, hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));
+        std::vector<double> allhdr(4 * (size_t)std::max(1, ng));
+        {   // all headers in one gather + one D2H
+            std::vector<const void*> srcs(ng);
+            for (int gi = 0; gi < ng; ++gi) srcs[gi] = reinterpret_cast<char*>(S_keep->p) + (size_t)s->owner[gates[gi].v1] * stride + slot[gi];
+            Buf d_hdr = dalloc(s, (size_t)std::max(1, ng) * 32);
+            const void* const* d_srcs = upload(s, srcs);
+            launch_header_gather(s->stream, d_srcs, ng, reinterpret_cast<double*>(d_hdr->p));
+            if (ng) HIPCHK(hipMemcpyAsync(allhdr.data(), d_hdr->p, (size_t)ng * 32, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+        }
         for (int gi = 0; gi < ng; ++gi) {
             info[8 * gi + 2] = (int)allhdr[4 * gi]; info[8 * gi + 3] = (int)allhdr[4 * gi + 1]; terr[gi] = allhdr[4 * gi + 2];
-            const char* src = reinterpret_cast<const char*>(S_keep->p) + (size_t)s->owner[gates[gi].v1] * stride + slot[gi];
-            Sptr[gi] = reinterpret_cast<const double*>(src + 32);
+            const size_t off = (size_t)s->owner[gates[gi].v1] * stride + slot[gi];
+            Sptr[gi] = reinterpret_cast<const double*>(reinterpret_cast<const char*>(S_keep->p) + off + 32);
             const SiteJob& b = sj[2 * gi + 1];
-            if (b.owned && s->owner[gates[gi].v1] != s->rank) {       // the partner rank computed the SVD: take its X2
-                if (!ws[gi].X2) ws[gi].X2 = dalloc(s, (size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz);
-                HIPCHK(hipMemcpyAsync(ws[gi].X2->p, src + 32 + (size_t)cap_max * 8, (size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz, hipMemcpyDeviceToDevice, s->stream));
-            }
+            if (b.owned && s->owner[gates[gi].v1] != s->rank)          // the partner rank computed the SVD: its X2 is used in place (a view)
+                ws[gi].X2 = sub_buffer(S_keep, off + 32 + (size_t)cap_max * 8, (size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz);
         }
     } else {
         for (int gi = 0; gi < ng; ++gi) Sptr[gi] = (const double*)ws[gi].S->p;

@@ -1186,6 +1186,29 @@ template <class T> void launch_symg_finish(hipStream_t s, const SymGaugeItem* d_
 template void launch_symg_finish<float>(hipStream_t, const SymGaugeItem*, int);
 template void launch_symg_finish<double>(hipStream_t, const SymGaugeItem*, int);
 
+__global__ __launch_bounds__(256) void record_pack_kernel(const RecordPackItem* __restrict__ items) {
+    const RecordPackItem it = items[blockIdx.x];
+    char* dst = reinterpret_cast<char*>(it.dst);
+    if (threadIdx.x == 0) { double* h = reinterpret_cast<double*>(dst); h[0] = (double)it.info[2]; h[1] = (double)it.info[3]; h[2] = *it.terr; h[3] = 0.0; }
+    double* sd = reinterpret_cast<double*>(dst + 32);
+    for (int i = threadIdx.x; i < it.nS; i += 256) sd[i] = it.S[i];
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(it.X2);
+    unsigned long long* xd = reinterpret_cast<unsigned long long*>(dst + it.x2_off);
+    for (long long i = threadIdx.x; i < it.x2_words; i += 256) xd[i] = src[i];
+}
+void launch_record_pack(hipStream_t s, const RecordPackItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(record_pack_kernel, dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+__global__ void header_gather_kernel(const void* const* __restrict__ srcs, int n, double* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4 * n) out[i] = reinterpret_cast<const double*>(srcs[i >> 2])[i & 3];
+}
+void launch_header_gather(hipStream_t s, const void* const* d_srcs, int n, double* d_out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(header_gather_kernel, dim3((4 * n + 255) / 256), dim3(256), 0, s, d_srcs, n, d_out); TNQS_CHECK_LAUNCH();
+}
+
 template <class T> __global__ __launch_bounds__(256) void permute_kernel(PermItem it) {
     const cx<T>* in = reinterpret_cast<const cx<T>*>(it.in);
     cx<T>* out = reinterpret_cast<cx<T>*>(it.out);

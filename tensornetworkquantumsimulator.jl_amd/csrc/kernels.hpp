@@ -94,6 +94,11 @@ struct SymGaugeItem { const void* AX; const void* VX; const void* AY; const void
                       void* Ce; void* Ce0; void* Vsvd; void* Xs; void* Xd; double* S; int n; double reg; int* flag; };
 template <class T> void launch_symg_build(hipStream_t s, const SymGaugeItem* d_items, int nitems);
 template <class T> void launch_symg_finish(hipStream_t s, const SymGaugeItem* d_items, int nitems);
+// sharded gate batches: the (chi', status, truncerr | S | X2) record of a gate packed into its exchange slot, and the 32-byte
+// headers of all records gathered into one contiguous array (one launch each instead of three copies per gate)
+struct RecordPackItem { void* dst; const int* info; const double* terr; const double* S; int nS; const void* X2; long long x2_words; long long x2_off; };
+void launch_record_pack(hipStream_t s, const RecordPackItem* d_items, int nitems);
+void launch_header_gather(hipStream_t s, const void* const* d_srcs, int n, double* d_out);
 struct PermItem { const void* in; void* out; int ndim; int dims_out[8]; long long stride_in[8]; size_t n; };
 
 // ---- launchers (T = float or double; data are complex<T>) ------------------------------------------------------
