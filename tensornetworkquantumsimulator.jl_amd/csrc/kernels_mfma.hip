@@ -714,7 +714,7 @@ __device__ __forceinline__ long long pair_slice_base(const PairGeom& g, int sl) 
     int a0 = sl % g.n0; int r1 = sl / g.n0; int a1 = r1 % g.n1; int a2 = r1 / g.n1;
     return (long long)a0 * g.t0 + (long long)a1 * g.t1 + (long long)a2 * g.t2;
 }
-__global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restrict__ items, int nitems) {
+__global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restrict__ items, int nitems, int dbg_skip) {
     constexpr int PR = 32 * 33;                // floats of one re (or im) plane, pitch 33
     constexpr int PS = 2 * PR + 1;             // plane stride (odd: the 8 companion pairs of a run hit different banks)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -765,6 +765,7 @@ __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restri
         if (sl + 1 < s_end) issue(sl + 1);
 #pragma unroll 1
         for (int pp = 0; pp < 2; ++pp) {
+            if (dbg_skip == 1) break;
             float* Pr = L + (w + 8 * pp) * PS; float* Pi = Pr + PR;
             float ar[16], ai[16];
 #pragma unroll
@@ -812,7 +813,8 @@ void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int to
     const size_t lds = (size_t)16 * (2 * 32 * 33 + 1) * sizeof(float);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(mfma_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+    static int skip = -1; if (skip < 0) { const char* e = std::getenv("TNQS_DBG_PAIR_SKIP"); skip = e ? std::atoi(e) : 0; }
+    hipLaunchKernelGGL(mfma_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems, skip); TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------
