@@ -31,11 +31,16 @@ def tfim_layer(tn, g, groups, J=1.0, hx=2.5, dt=0.01):
     return layer
 
 
-def random_state_tensors(g, chi, d, seed, dtype):
-    rng = np.random.default_rng(seed)
-    for v in g.vertices:
+def random_state_tensors(g, chi, d, seed, dtype, wanted=None):
+    """iid complex-normal site tensors at bond dimension chi; one counter-based stream per vertex (seed, vertex position), so that a
+    rank of a sharded run only generates its own tensors.  Yields (v, tensor) for wanted vertices and (v, shape) for the others."""
+    for i, v in enumerate(g.vertices):
         shp = (d,) + (chi,) * g.degree(v)
+        if wanted is not None and not wanted(v):
+            yield v, shp
+            continue
         n = int(np.prod(shp))
+        rng = np.random.default_rng([seed, i])
         t = rng.standard_normal(2 * n, dtype=np.float32).view(np.complex64).reshape(shp)
         t *= np.float32(1.0 / np.sqrt(n))                       # unit Frobenius norm (f32-friendly scale)
         yield v, t.astype(dtype, copy=False)
@@ -98,8 +103,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one rank per GPU over RCCL; TNQS_BENCH_BACKEND=gloo lets several ranks share one GPU (functional test of this script only)
+        local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("TNQS_BENCH_BACKEND", "nccl"))
     import tnqs_amd as tn
 
     L, chi, d = args.L, args.chi, 2
@@ -116,11 +123,11 @@ def main():
     if world > 1:
         from tnqs_amd import dist as tdist
         tdist.shard(bpc, rank, world)
-    for v, t in random_state_tensors(g, chi, d, 1234, dtype):
-        if world == 1 or bpc.owns(v):
-            bpc._set_tensor(v, t)
+    for v, t in random_state_tensors(g, chi, d, 1234, dtype, wanted=(None if world == 1 else bpc.owns)):
+        if isinstance(t, tuple):
+            bpc._declare_dims(v, t)
         else:
-            bpc._declare_dims(v, t.shape)
+            bpc._set_tensor(v, t)
     sweeps, updates = [], []
     for _ in range(args.warmup):
         info = {}
@@ -142,7 +149,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device="cuda")
+        tmax = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     prof = tn.profile_get(bpc)
