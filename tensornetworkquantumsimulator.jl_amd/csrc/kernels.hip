@@ -390,25 +390,31 @@ template <class T> __device__ __forceinline__ T fast_rsqrt(T x) { return 1 / sqr
 template <> __device__ __forceinline__ float fast_rsqrt<float>(float x) { return __frsqrt_rn(x); }
 template <class T> __device__ __forceinline__ T fast_rcp(T x) { return 1 / x; }
 template <> __device__ __forceinline__ float fast_rcp<float>(float x) { return __frcp_rn(x); }
-template <class T> __device__ __forceinline__ T row16_sum(T v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+// all-reduce over a 16-lane row with DPP row rotations (VALU, no LDS crossbar): after adding the rotations by 8, 4, 2, 1 every lane
+// holds the row sum (the same summation tree in every lane of the row, so the four quarter-waves' decisions stay uniform per row)
+template <int ROR> __device__ __forceinline__ float dpp_ror_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + ROR, 0xf, 0xf, false));
+}
+template <int ROR> __device__ __forceinline__ double dpp_ror_d(double v) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + ROR, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + ROR, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_ror_f<8>(v); v += dpp_ror_f<4>(v); v += dpp_ror_f<2>(v); v += dpp_ror_f<1>(v);
     return v;
 }
-template <class T, int RQ>              // RQ = rows per lane: m <= 16*RQ
-__global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __restrict__ items, int max_sweeps) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_rot;
-    const JacobiItem it = items[blockIdx.x];
-    cx<T>* Ag = reinterpret_cast<cx<T>*>(it.A);
-    cx<T>* Vg = reinterpret_cast<cx<T>*>(it.V);
-    const int m = it.m, n = it.n;
-    const int mp = m + 2, np_ = n + 2;     // padded column pitches
-    cx<T>* A = reinterpret_cast<cx<T>*>(smem);
-    cx<T>* V = A + (size_t)mp * n;
-    const bool hasV = Vg != nullptr;
-    for (int e = threadIdx.x; e < m * n; e += blockDim.x) A[(e % m) + mp * (e / m)] = Ag[e];
-    if (hasV) for (int e = threadIdx.x; e < n * n; e += blockDim.x) V[(e % n) + np_ * (e / n)] = cmake<T>((e % n) == (e / n) ? (T)1 : (T)0, (T)0);
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_ror_d<8>(v); v += dpp_ror_d<4>(v); v += dpp_ror_d<2>(v); v += dpp_ror_d<1>(v);
+    return v;
+}
+// the sweeps of the LDS-resident factorisation.  FULL: m == 16*RQ, n even and n/2 a multiple of 4 -- every quarter-wave of every
+// participating wave owns a real pair and all RQ row slots are real rows, so the per-row / per-pair guards (exec-mask juggling in the
+// hottest loop) disappear.
+template <class T, int RQ, bool FULL>
+__device__ __forceinline__ int jacobi_lds_sweeps(cx<T>* A, cx<T>* V, bool hasV, int m, int n, int mp, int np_, int max_sweeps, T tiny, int* s_rot) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int grp = lane >> 4, l16 = lane & 15;
     const int ne = n + (n & 1);
@@ -416,35 +422,26 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     const T tol = eps_of<T>() * sqrt((T)(m > 4 ? m : 4));
     const int rq = (m + 15) >> 4, rqv = (n + 15) >> 4;
     int sweep = 0;
-    __syncthreads();
-    // ||A||_F^2 is invariant under the rotations.  A pair of columns that are BOTH below n eps^2 ||A||_F^2 (singular values under
-    // ~sqrt(n) eps ||A||_F: rounding noise of a rank-deficient matrix) is left alone -- otherwise noise columns keep rotating
-    // against each other for many sweeps without changing any singular value that matters.
-    __shared__ double s_red[17];
-    double fro = 0;
-    for (int e = threadIdx.x; e < m * n; e += blockDim.x) { cx<T> v = A[(e % m) + mp * (e / m)]; fro += (double)v.re * v.re + (double)v.im * v.im; }
-    fro = block_sum(fro, s_red);
-    const T tiny = (T)((double)n * (double)eps_of<T>() * (double)eps_of<T>() * fro);
     for (; sweep < max_sweeps && n > 1; ++sweep) {
-        if (threadIdx.x == 0) s_rot = 0;
+        if (threadIdx.x == 0) *s_rot = 0;
         __syncthreads();
         for (int round = 0; round < ne - 1; ++round) {
             for (int base = 4 * w; base < ne / 2; base += nslots) {
-                // wave-uniform trip count (the shuffles need all four quarter-waves); idle quarters are predicated off
+                // wave-uniform trip count (the row reductions need all four quarter-waves); idle quarters are predicated off
                 const int pi = base + grp;
-                int p = 0, q = 0; bool act = pi < ne / 2;
+                int p = 0, q = 0; bool act = FULL || pi < ne / 2;
                 if (act) {
                     if (pi == 0) { p = ne - 1; q = round; }
                     else { p = round + pi; if (p >= ne - 1) p -= ne - 1; q = round - pi; if (q < 0) q += ne - 1; }
                     if (p > q) { int t = p; p = q; q = t; }
-                    act = q < n;
+                    if (!FULL) act = q < n;
                 }
                 cx<T> ap[RQ], aq[RQ];
                 T alpha = 0, beta = 0, gre = 0, gim = 0;
 #pragma unroll
                 for (int r = 0; r < RQ; ++r) {
                     int i = l16 + 16 * r;
-                    if (r < rq && act && i < m) {
+                    if (FULL || (r < rq && act && i < m)) {
                         ap[r] = A[i + mp * p]; aq[r] = A[i + mp * q];
                         alpha += ap[r].re * ap[r].re + ap[r].im * ap[r].im;
                         beta += aq[r].re * aq[r].re + aq[r].im * aq[r].im;
@@ -466,7 +463,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
 #pragma unroll
                     for (int r = 0; r < RQ; ++r) {
                         int i = l16 + 16 * r;
-                        if (r < rq && i < m) {
+                        if (FULL || (r < rq && i < m)) {
                             T qre = aq[r].re * pre - aq[r].im * pim, qim = aq[r].re * pim + aq[r].im * pre;
                             A[i + mp * p] = cmake<T>(c * ap[r].re - sn * qre, c * ap[r].im - sn * qim);
                             A[i + mp * q] = cmake<T>(sn * ap[r].re + c * qre, sn * ap[r].im + c * qim);
@@ -484,15 +481,44 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
                             }
                         }
                     }
-                    if (l16 == 0) s_rot = 1;
+                    if (l16 == 0) *s_rot = 1;
                 }
             }
             __syncthreads();
         }
-        const int rotd = s_rot;
+        const int rotd = *s_rot;
         __syncthreads();
         if (!rotd) { ++sweep; break; }
     }
+    return sweep;
+}
+template <class T, int RQ>              // RQ = rows per lane: m <= 16*RQ
+__global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __restrict__ items, int max_sweeps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_rot;
+    const JacobiItem it = items[blockIdx.x];
+    cx<T>* Ag = reinterpret_cast<cx<T>*>(it.A);
+    cx<T>* Vg = reinterpret_cast<cx<T>*>(it.V);
+    const int m = it.m, n = it.n;
+    const int mp = m + 2, np_ = n + 2;     // padded column pitches
+    cx<T>* A = reinterpret_cast<cx<T>*>(smem);
+    cx<T>* V = A + (size_t)mp * n;
+    const bool hasV = Vg != nullptr;
+    for (int e = threadIdx.x; e < m * n; e += blockDim.x) A[(e % m) + mp * (e / m)] = Ag[e];
+    if (hasV) for (int e = threadIdx.x; e < n * n; e += blockDim.x) V[(e % n) + np_ * (e / n)] = cmake<T>((e % n) == (e / n) ? (T)1 : (T)0, (T)0);
+    __syncthreads();
+    // ||A||_F^2 is invariant under the rotations.  A pair of columns that are BOTH below n eps^2 ||A||_F^2 (singular values under
+    // ~sqrt(n) eps ||A||_F: rounding noise of a rank-deficient matrix) is left alone -- otherwise noise columns keep rotating
+    // against each other for many sweeps without changing any singular value that matters.
+    __shared__ double s_red[17];
+    double fro = 0;
+    for (int e = threadIdx.x; e < m * n; e += blockDim.x) { cx<T> v = A[(e % m) + mp * (e / m)]; fro += (double)v.re * v.re + (double)v.im * v.im; }
+    fro = block_sum(fro, s_red);
+    const T tiny = (T)((double)n * (double)eps_of<T>() * (double)eps_of<T>() * fro);
+    const bool full = (m == 16 * RQ) && !(n & 1) && !((n >> 1) & 3);
+    int sweep;
+    if (full) sweep = jacobi_lds_sweeps<T, RQ, true>(A, V, hasV, m, n, mp, np_, max_sweeps, tiny, &s_rot);
+    else sweep = jacobi_lds_sweeps<T, RQ, false>(A, V, hasV, m, n, mp, np_, max_sweeps, tiny, &s_rot);
     __syncthreads();
     for (int e = threadIdx.x; e < m * n; e += blockDim.x) Ag[e] = A[(e % m) + mp * (e / m)];
     if (hasV) for (int e = threadIdx.x; e < n * n; e += blockDim.x) Vg[e] = V[(e % n) + np_ * (e / n)];
