@@ -492,6 +492,66 @@ __device__ __forceinline__ int jacobi_lds_sweeps(cx<T>* A, cx<T>* V, bool hasV, 
     }
     return sweep;
 }
+// ComplexF32, full tiles: the same sweeps written on (re, im) pairs so that the compiler emits packed f32 operations
+// (v_pk_fma_f32 with operand swizzles): 10 packed operations per row instead of ~22
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+template <int RQ>
+__device__ __forceinline__ int jacobi_lds_sweeps_f32_full(cx<float>* A, int m, int n, int mp, int max_sweeps, float tiny, int* s_rot) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int grp = lane >> 4, l16 = lane & 15;
+    const int ne = n;                                   // n is even here
+    const int nslots = 4 * nw;
+    const float tol = eps_of<float>() * sqrtf((float)(m > 4 ? m : 4));
+    v2f_t* Av = reinterpret_cast<v2f_t*>(A);
+    int sweep = 0;
+    for (; sweep < max_sweeps && n > 1; ++sweep) {
+        if (threadIdx.x == 0) *s_rot = 0;
+        __syncthreads();
+        for (int round = 0; round < ne - 1; ++round) {
+            for (int base = 4 * w; base < ne / 2; base += nslots) {
+                const int pi = base + grp;
+                int p, q;
+                if (pi == 0) { p = ne - 1; q = round; }
+                else { p = round + pi; if (p >= ne - 1) p -= ne - 1; q = round - pi; if (q < 0) q += ne - 1; }
+                if (p > q) { int t = p; p = q; q = t; }
+                v2f_t* cp = Av + l16 + mp * p; v2f_t* cq = Av + l16 + mp * q;
+                v2f_t ap[RQ], aq[RQ];
+                v2f_t sa = {0.f, 0.f}, sb = {0.f, 0.f}, g1 = {0.f, 0.f}, g2v = {0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < RQ; ++r) {
+                    ap[r] = cp[16 * r]; aq[r] = cq[16 * r];
+                    sa += ap[r] * ap[r]; sb += aq[r] * aq[r];
+                    g1 += ap[r] * aq[r];
+                    g2v += ap[r] * __builtin_shufflevector(aq[r], aq[r], 1, 0);
+                }
+                float alpha = row16_sum(sa.x + sa.y), beta = row16_sum(sb.x + sb.y), gre = row16_sum(g1.x + g1.y), gim = row16_sum(g2v.x - g2v.y);
+                const float g2 = gre * gre + gim * gim;
+                const bool rot = g2 > 1e-36f && g2 > tol * tol * alpha * beta && !(alpha < tiny && beta < tiny);
+                if (rot) {
+                    const float iga = fast_rsqrt<float>(g2);
+                    const float pre = gre * iga, pim = -gim * iga;
+                    const float zeta = (beta - alpha) * 0.5f * iga;
+                    const float az = fabsf(zeta);
+                    const float t = (zeta >= 0 ? 1.f : -1.f) * fast_rcp<float>(az + sqrtf(1 + az * az));
+                    const float c = fast_rsqrt<float>(1 + t * t), sn = c * t;
+                    const v2f_t e1 = {pre, pim}, e2 = {-pim, pre}, cc = {c, c}, ss = {sn, sn};
+#pragma unroll
+                    for (int r = 0; r < RQ; ++r) {
+                        const v2f_t qv = __builtin_shufflevector(aq[r], aq[r], 0, 0) * e1 + __builtin_shufflevector(aq[r], aq[r], 1, 1) * e2;
+                        cp[16 * r] = cc * ap[r] - ss * qv;
+                        cq[16 * r] = ss * ap[r] + cc * qv;
+                    }
+                    if (l16 == 0) *s_rot = 1;
+                }
+            }
+            __syncthreads();
+        }
+        const int rotd = *s_rot;
+        __syncthreads();
+        if (!rotd) { ++sweep; break; }
+    }
+    return sweep;
+}
 template <class T, int RQ>              // RQ = rows per lane: m <= 16*RQ
 __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __restrict__ items, int max_sweeps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -517,7 +577,8 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     const T tiny = (T)((double)n * (double)eps_of<T>() * (double)eps_of<T>() * fro);
     const bool full = (m == 16 * RQ) && !(n & 1) && !((n >> 1) & 3);
     int sweep;
-    if (full) sweep = jacobi_lds_sweeps<T, RQ, true>(A, V, hasV, m, n, mp, np_, max_sweeps, tiny, &s_rot);
+    if (full && sizeof(T) == 4 && !hasV) sweep = jacobi_lds_sweeps_f32_full<RQ>(reinterpret_cast<cx<float>*>(A), m, n, mp, max_sweeps, (float)tiny, &s_rot);
+    else if (full) sweep = jacobi_lds_sweeps<T, RQ, true>(A, V, hasV, m, n, mp, np_, max_sweeps, tiny, &s_rot);
     else sweep = jacobi_lds_sweeps<T, RQ, false>(A, V, hasV, m, n, mp, np_, max_sweeps, tiny, &s_rot);
     __syncthreads();
     for (int e = threadIdx.x; e < m * n; e += blockDim.x) Ag[e] = A[(e % m) + mp * (e / m)];
@@ -593,6 +654,7 @@ template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, 
     if (lds_bytes > 0 && lds_bytes <= 160 * 1024 - 256 && mmax <= 256) {
         if (mmax <= 32) launch_jacobi_lds<T, 2>(s, d_items, nitems, max_sweeps, lds_bytes);
         else if (mmax <= 64) launch_jacobi_lds<T, 4>(s, d_items, nitems, max_sweeps, lds_bytes);
+        else if (mmax <= 96) launch_jacobi_lds<T, 6>(s, d_items, nitems, max_sweeps, lds_bytes);
         else if (mmax <= 128) launch_jacobi_lds<T, 8>(s, d_items, nitems, max_sweeps, lds_bytes);
         else launch_jacobi_lds<T, 16>(s, d_items, nitems, max_sweeps, lds_bytes);
     } else {
