@@ -27,21 +27,29 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
-    dtype = np.complex64 if (len(sys.argv) > 2 and sys.argv[2] == "c64") else np.complex128
-    g = tn.named_grid((4, 3))
+    mode = sys.argv[2] if len(sys.argv) > 2 else "c128"
+    dtype = np.complex64 if mode in ("c64", "chi32") else np.complex128
+    # "chi32": 4x4 grid at bond dimension 32 -- the degree-4 sites run the plane kernels (shared pair products, epilogue kernel,
+    # Cholesky factors, deferred normalisation) under sharding
+    big = mode == "chi32"
+    g = tn.named_grid((4, 4)) if big else tn.named_grid((4, 3))
     groups = tn.edge_color(g, 4)
     layer = [("Rx", [v], 0.5) for v in g.vertices] + [("Rz", [v], 0.4) for v in g.vertices]
     seq = []
     for grp in groups:
         layer += [("Rzz", [a, b], 0.25) for (a, b) in grp]
         seq += list(grp) + [(b, a) for (a, b) in grp]
-    kw = dict(maxdim=3, cutoff=1e-10, normalize_tensors=True)
-    bpkw = dict(edge_sequence=seq, maxiter=12, tolerance=None)
-    psi0 = tn.random_tensornetworkstate(dtype, g, bond_dimension=2, seed=11)
+    kw = dict(maxdim=32 if big else 3, cutoff=1e-10, normalize_tensors=True)
+    bpkw = dict(edge_sequence=seq, maxiter=3 if big else 12, tolerance=None)
+    psi0 = tn.random_tensornetworkstate(dtype, g, bond_dimension=32 if big else 2, seed=11)
+    if big:
+        for v in g.vertices:
+            psi0.tensors[v] = (psi0.tensors[v] / np.linalg.norm(psi0.tensors[v])).astype(dtype)
+    nlayers = 1 if big else 2
 
     def sharded_factory():
         b = tn.BeliefPropagationCache(tn.tensornetworkstate(dtype, lambda v: "↑", g))
-        tn.shard(b, rank, world, exch_bytes=8 << 20)
+        tn.shard(b, rank, world, exch_bytes=(64 << 20) if big else (8 << 20))
         for v in g.vertices:
             if b.owns(v):
                 b._set_tensor(v, psi0.tensors[v])
@@ -49,7 +57,7 @@ def main():
                 b._declare_dims(v, psi0.tensors[v].shape)
         return b
 
-    bs, es = run(sharded_factory, layer, kw, bpkw, 2)
+    bs, es = run(sharded_factory, layer, kw, bpkw, nlayers)
     # every rank holds all messages and bond dims; site tensors / <Z> only for owned vertices
     ez = tn.expect_all(bs, "Z")
     ez_t = torch.from_numpy(np.nan_to_num(ez.view(np.float64), nan=0.0).copy())
@@ -64,7 +72,7 @@ def main():
     dims = np.array([bs.bond_dim(a, b) for (a, b) in g.edges])
     nex = bs._shard.n_exchanges
     if rank == 0:
-        bu, eu = run(lambda: tn.BeliefPropagationCache(psi0), layer, kw, bpkw, 2)
+        bu, eu = run(lambda: tn.BeliefPropagationCache(psi0), layer, kw, bpkw, nlayers)
         ezu = tn.expect_all(bu, "Z")
         spu = []
         for (a, b) in g.edges:
