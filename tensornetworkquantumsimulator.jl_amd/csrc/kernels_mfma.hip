@@ -17,6 +17,7 @@ namespace tnqs {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 struct alignas(8) cf { float re, im; };
 
 // LDS-only workgroup barrier: __syncthreads() also drains vmcnt (global loads AND stores in flight), which would
@@ -715,10 +716,10 @@ __device__ __forceinline__ long long pair_slice_base(const PairGeom& g, int sl) 
     return (long long)a0 * g.t0 + (long long)a1 * g.t1 + (long long)a2 * g.t2;
 }
 __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restrict__ items, int nitems, int dbg_skip) {
-    constexpr int PR = 32 * 33;                // floats of one re (or im) plane, pitch 33
-    constexpr int PS = 2 * PR + 1;             // plane stride (odd: the 8 companion pairs of a run hit different banks)
+    // a plane holds (re, im) pairs: every LDS access moves a whole complex number (ds_*_b64)
+    constexpr int PS = 32 * 33 + 1;            // plane stride in complex elements, pitch 33 (odd: the 8 companion pairs of a run hit different banks)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* L = reinterpret_cast<float*>(smem);
+    v2f* L = reinterpret_cast<v2f*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
     int lo = 0, hi_ = nitems - 1;
     const int gw = blockIdx.x;
@@ -743,20 +744,24 @@ __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restri
     const int f = tid & 7, sg0 = tid >> 3;            // segments sg0, sg0 + 64, ... (16 per thread), seg = ix + 32*iy
     const long long sx = g.sx, sy = g.sy, fo = (long long)f * g.cstr;
     v4f pre[16];
+    // segment j of this thread: ix = sg0 & 31 (fixed), iy = (sg0 >> 5) + 2 j  ->  one base address and a constant stride
+    const int ix0 = sg0 & 31, iy0 = sg0 >> 5;
+    const long long toff = fo + sx * ix0 + sy * iy0, tstr = 2 * sy;
+    v2f* const lbase = L + (2 * f) * PS + iy0 * 33 + ix0;
     auto issue = [&](int sl) {
-        const long long b = pair_slice_base(g, sl) + fo;
+        const cf* p = in + pair_slice_base(g, sl) + toff;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5; pre[j] = *reinterpret_cast<const v4f*>(in + b + sx * ix + sy * iy); }
+        for (int j = 0; j < 16; ++j) pre[j] = *reinterpret_cast<const v4f*>(p + tstr * j);
     };
     auto commit = [&]() {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5;
-            float* p0 = L + (2 * f) * PS + iy * 33 + ix;         // plane 2f:   S[ix][iy] stored at [iy][ix]
-            p0[0] = pre[j][0]; p0[PR] = pre[j][1];
-            p0[PS] = pre[j][2]; p0[PS + PR] = pre[j][3];         // plane 2f+1
+            v2f* p0 = lbase + 66 * j;                            // plane 2f: element (ix, iy) stored at [iy][ix]; plane 2f+1 one stride further
+            v2f a; a[0] = pre[j][0]; a[1] = pre[j][1]; v2f b; b[0] = pre[j][2]; b[1] = pre[j][3];
+            p0[0] = a; p0[PS] = b;
         }
     };
+
     if (s_begin < s_end) issue(s_begin);
     for (int sl = s_begin; sl < s_end; ++sl) {
         lds_barrier();                                          // previous slice's results have left the LDS
@@ -766,10 +771,10 @@ __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restri
 #pragma unroll 1
         for (int pp = 0; pp < 2; ++pp) {
             if (dbg_skip == 1) break;
-            float* Pr = L + (w + 8 * pp) * PS; float* Pi = Pr + PR;
+            v2f* P = L + (w + 8 * pp) * PS;
             float ar[16], ai[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { int o = ln * 33 + q + 16 * h; ar[q] = Pr[o]; ai[q] = Pi[o]; }     // A[i=iy=ln][k=ix]
+            for (int q = 0; q < 16; ++q) { v2f v = P[ln * 33 + q + 16 * h]; ar[q] = v[0]; ai[q] = v[1]; }     // A[i=iy=ln][k=ix]
             v16f Yr, Yi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { Yr[r] = 0.f; Yi[r] = 0.f; }
@@ -793,24 +798,24 @@ __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restri
             __builtin_amdgcn_wave_barrier();
             // S'[jx = kappa(r,h)][jy = ln] -> LDS [jy][jx] (the plane is private to this wave)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { int jx = (r & 3) + 8 * (r >> 2) + 4 * h; Pr[ln * 33 + jx] = Sr[r]; Pi[ln * 33 + jx] = Si[r]; }
+            for (int r = 0; r < 16; ++r) { int jx = (r & 3) + 8 * (r >> 2) + 4 * h; v2f v; v[0] = Sr[r]; v[1] = Si[r]; P[ln * 33 + jx] = v; }
         }
         lds_barrier();
         {
-            const long long b = pair_slice_base(g, sl) + fo;
+            cf* p = out + pair_slice_base(g, sl) + toff;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5;
-                const float* p0 = L + (2 * f) * PS + iy * 33 + ix;
-                v4f v; v[0] = p0[0]; v[1] = p0[PR]; v[2] = p0[PS]; v[3] = p0[PS + PR];
-                *reinterpret_cast<v4f*>(out + b + sx * ix + sy * iy) = v;
+                const v2f* p0 = lbase + 66 * j;
+                const v2f a = p0[0], c = p0[PS];
+                v4f v; v[0] = a[0]; v[1] = a[1]; v[2] = c[0]; v[3] = c[1];
+                *reinterpret_cast<v4f*>(p + tstr * j) = v;
             }
         }
     }
 }
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
-    const size_t lds = (size_t)16 * (2 * 32 * 33 + 1) * sizeof(float);
+    const size_t lds = (size_t)16 * (32 * 33 + 1) * 2 * sizeof(float);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     static int skip = -1; if (skip < 0) { const char* e = std::getenv("TNQS_DBG_PAIR_SKIP"); skip = e ? std::atoi(e) : 0; }
@@ -827,10 +832,9 @@ void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int to
 // Each wave owns two planes and one 32 x 32 accumulator; it writes one partial per workgroup and wave.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void mfma_pair_gram_kernel(const PairGramItem* __restrict__ items, int nitems) {
-    constexpr int PR = 32 * 33;
-    constexpr int PS = 2 * PR + 1;
+    constexpr int PS = 32 * 33 + 1;            // plane stride in complex elements ((re, im) pairs, ds_*_b64 accesses)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* L = reinterpret_cast<float*>(smem);
+    v2f* L = reinterpret_cast<v2f*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
     int lo = 0, hi_ = nitems - 1;
     const int gw = blockIdx.x;
@@ -852,20 +856,23 @@ __global__ __launch_bounds__(512) void mfma_pair_gram_kernel(const PairGramItem*
     const int f = tid & 7, sg0 = tid >> 3;
     const long long sx = g.sx, sy = g.sy, fo = (long long)f * g.cstr;
     v4f pre[16];
+    const int ix0 = sg0 & 31, iy0 = sg0 >> 5;            // segment j: ix = ix0, iy = iy0 + 2 j
+    const long long toff = fo + sx * ix0 + sy * iy0, tstr = 2 * sy;
+    v2f* const lbase = L + (2 * f) * PS + iy0 * 33 + ix0;
     auto issue = [&](const cf* __restrict__ G, int sl) {
-        const long long b = pair_slice_base(g, sl) + fo;
+        const cf* p = G + pair_slice_base(g, sl) + toff;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5; pre[j] = *reinterpret_cast<const v4f*>(G + b + sx * ix + sy * iy); }
+        for (int j = 0; j < 16; ++j) pre[j] = *reinterpret_cast<const v4f*>(p + tstr * j);
     };
     auto commit = [&]() {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            int seg = sg0 + 64 * j; int ix = seg & 31, iy = seg >> 5;
-            float* p0 = L + (2 * f) * PS + iy * 33 + ix;         // element (ix, iy = b) stored at [iy][ix]
-            p0[0] = pre[j][0]; p0[PR] = pre[j][1];
-            p0[PS] = pre[j][2]; p0[PS + PR] = pre[j][3];
+            v2f* p0 = lbase + 66 * j;                            // plane 2f: element (ix, iy) stored at [iy][ix]; plane 2f+1 one stride further
+            v2f a; a[0] = pre[j][0]; a[1] = pre[j][1]; v2f b; b[0] = pre[j][2]; b[1] = pre[j][3];
+            p0[0] = a; p0[PS] = b;
         }
     };
+
     if (s_begin < s_end) issue(Xg, s_begin);
     for (int sl = s_begin; sl < s_end; ++sl) {
         lds_barrier();                                          // the previous slice's Y planes have been consumed
@@ -875,10 +882,10 @@ __global__ __launch_bounds__(512) void mfma_pair_gram_kernel(const PairGramItem*
         v16f C1r[2], C1i[2];
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
-            const float* Pr = L + (w + 8 * pp) * PS; const float* Pi = Pr + PR;
+            const v2f* P = L + (w + 8 * pp) * PS;
             float xr[16], xi[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { int o = ln * 33 + q + 16 * h; xr[q] = Pr[o]; xi[q] = Pi[o]; }     // B[k=ix][j=b=ln]
+            for (int q = 0; q < 16; ++q) { v2f v = P[ln * 33 + q + 16 * h]; xr[q] = v[0]; xi[q] = v[1]; }     // B[k=ix][j=b=ln]
 #pragma unroll
             for (int r = 0; r < 16; ++r) { C1r[pp][r] = 0.f; C1i[pp][r] = 0.f; }
 #pragma unroll
@@ -895,10 +902,10 @@ __global__ __launch_bounds__(512) void mfma_pair_gram_kernel(const PairGramItem*
         if (sl + 1 < s_end) issue(Xg, sl + 1);                  // next X in flight during step 2
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
-            const float* Pr = L + (w + 8 * pp) * PS; const float* Pi = Pr + PR;
+            const v2f* P = L + (w + 8 * pp) * PS;
             float yr[16], yi[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { int jx = (r & 3) + 8 * (r >> 2) + 4 * h; int o = ln * 33 + jx; yr[r] = Pr[o]; yi[r] = Pi[o]; }   // B[k=jx][j=b'=ln]
+            for (int r = 0; r < 16; ++r) { int jx = (r & 3) + 8 * (r >> 2) + 4 * h; v2f v = P[ln * 33 + jx]; yr[r] = v[0]; yi[r] = v[1]; }   // B[k=jx][j=b'=ln]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 Or = __builtin_amdgcn_mfma_f32_32x32x2f32(C1r[pp][r], yr[r], Or, 0, 0, 0);
@@ -917,7 +924,7 @@ __global__ __launch_bounds__(512) void mfma_pair_gram_kernel(const PairGramItem*
 }
 void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
-    const size_t lds = (size_t)16 * (2 * 32 * 33 + 1) * sizeof(float);
+    const size_t lds = (size_t)16 * (32 * 33 + 1) * 2 * sizeof(float);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     hipLaunchKernelGGL(mfma_pair_gram_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
