@@ -711,18 +711,25 @@ void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems
 //   step 2  S'[jx][jy] = sum_iy Y[iy][jx] My[iy][jy]      (A = Y's accumulator registers as they are, B = My in registers)
 // The next slice's 128 KiB are prefetched into registers while the matrix cores work.
 // ------------------------------------------------------------------------------------------------------------
+// XCD-aware workgroup order: consecutive workgroup ids go round-robin over the 8 XCDs, so XCD x sees ids x, x+8, ...  Remapping id ->
+// (id % 8) * (n/8) + id / 8 gives every XCD one contiguous range of the work list (neighbouring slices share DRAM pages and L2 sets).
+__device__ __forceinline__ int xcd_remap(int id, int n, int mode) {
+    if (!mode) return id;
+    const int n8 = (n >> 3) << 3;
+    return id < n8 ? (id & 7) * (n8 >> 3) + (id >> 3) : id;
+}
 __device__ __forceinline__ long long pair_slice_base(const PairGeom& g, int sl) {
     int a0 = sl % g.n0; int r1 = sl / g.n0; int a1 = r1 % g.n1; int a2 = r1 / g.n1;
     return (long long)a0 * g.t0 + (long long)a1 * g.t1 + (long long)a2 * g.t2;
 }
-__global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restrict__ items, int nitems, int dbg_skip) {
+__global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restrict__ items, int nitems, int dbg_skip, int xcd) {
     // a plane holds (re, im) pairs: every LDS access moves a whole complex number (ds_*_b64)
     constexpr int PS = 32 * 33 + 1;            // plane stride in complex elements, pitch 33 (odd: the 8 companion pairs of a run hit different banks)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v2f* L = reinterpret_cast<v2f*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
     int lo = 0, hi_ = nitems - 1;
-    const int gw = blockIdx.x;
+    const int gw = xcd_remap(blockIdx.x, gridDim.x, xcd);
     while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].slice_begin <= gw) lo = mid; else hi_ = mid - 1; }
     const PairItem it = items[lo];
     const PairGeom g = it.g;
@@ -819,7 +826,8 @@ void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int to
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     static int skip = -1; if (skip < 0) { const char* e = std::getenv("TNQS_DBG_PAIR_SKIP"); skip = e ? std::atoi(e) : 0; }
-    hipLaunchKernelGGL(mfma_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems, skip); TNQS_CHECK_LAUNCH();
+    static int xcd = -1; if (xcd < 0) { const char* e = std::getenv("TNQS_XCD_REMAP"); xcd = e ? std::atoi(e) : 0; }
+    hipLaunchKernelGGL(mfma_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems, skip, xcd); TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -831,13 +839,13 @@ void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int to
 //   step 2  out[b][b'] += sum_jx C1[jx][b] conj Y[jx][b']    (A = C1's accumulator registers as they are, B = Y plane)
 // Each wave owns two planes and one 32 x 32 accumulator; it writes one partial per workgroup and wave.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void mfma_pair_gram_kernel(const PairGramItem* __restrict__ items, int nitems) {
+__global__ __launch_bounds__(512) void mfma_pair_gram_kernel(const PairGramItem* __restrict__ items, int nitems, int xcd) {
     constexpr int PS = 32 * 33 + 1;            // plane stride in complex elements ((re, im) pairs, ds_*_b64 accesses)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v2f* L = reinterpret_cast<v2f*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
     int lo = 0, hi_ = nitems - 1;
-    const int gw = blockIdx.x;
+    const int gw = xcd_remap(blockIdx.x, gridDim.x, xcd);
     while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].wg_begin <= gw) lo = mid; else hi_ = mid - 1; }
     const PairGramItem it = items[lo];
     const PairGeom g = it.g;
@@ -927,7 +935,8 @@ void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitem
     const size_t lds = (size_t)16 * (32 * 33 + 1) * 2 * sizeof(float);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(mfma_pair_gram_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+    static int xcd = -1; if (xcd < 0) { const char* e = std::getenv("TNQS_XCD_REMAP"); xcd = e ? std::atoi(e) : 0; }
+    hipLaunchKernelGGL(mfma_pair_gram_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems, xcd); TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------
