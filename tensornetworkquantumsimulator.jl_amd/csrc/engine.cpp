@@ -1,6 +1,7 @@
 // engine.cpp -- see engine.hpp.  Host orchestration only; every flop runs in the HIP kernels of kernels*.hip.
 #include "engine.hpp"
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <cstdio>
 #include <array>
@@ -523,13 +524,68 @@ struct BPPlan {
     bool in_place = false;                      // duplicates in the sequence: strictly sequential, single buffer
 };
 
+// Default sweep order (the reference's default is NamedGraphs' forest-cover sequence, not available here; any sequence gives the
+// same fixed point, abstractbeliefpropagationcache.jl:204-218).  The edges are decomposed into LINEAR FORESTS (disjoint simple paths);
+// inside a forest the messages are ordered so that every message is computed from the OLD values of the other messages of the same
+// forest: along a path v0..vk the hops v_i -> v_{i+1} are listed last hop first, the hops v_{i+1} -> v_i first hop first (a message
+// u -> w depends on the message entering u through its other path edge, which therefore must come LATER in the sequence).  Level
+// scheduling then puts a whole forest into one level: 2 levels per sweep on a square lattice (rows, columns), and both outgoing
+// messages of a site inside a forest share one pair product.  It is an ordinary sequential Gauss-Seidel order.
+struct DSU { std::vector<int> p; explicit DSU(int n) : p(n) { std::iota(p.begin(), p.end(), 0); } int f(int x) { while (p[x] != x) x = p[x] = p[p[x]]; return x; }
+             bool join(int a, int b) { a = f(a); b = f(b); if (a == b) return false; p[a] = b; return true; } };
 static std::vector<int> default_sequence(const Graph& g) {
-    // edge-colour grouped order: within one colour no message depends on another, so each colour is one level
-    std::vector<int> seq;
-    for (int c = 0; c < g.ncolors; ++c) {
-        for (int e = 0; e < g.ne; ++e) if (g.ecolor[e] == c) seq.push_back(2 * e);
-        for (int e = 0; e < g.ne; ++e) if (g.ecolor[e] == c) seq.push_back(2 * e + 1);
+    std::vector<int> forest(g.ne, -1);
+    int nf = 0;
+    // 1. unions of two colour classes that contain no cycle are linear forests (straight lines on lattices): pair the colours up
+    std::vector<std::vector<char>> ok(g.ncolors, std::vector<char>(g.ncolors, 0));
+    for (int a = 0; a < g.ncolors; ++a) for (int b = a + 1; b < g.ncolors; ++b) {
+        DSU d(g.nv); bool acyclic = true;
+        for (int e = 0; e < g.ne && acyclic; ++e) if (g.ecolor[e] == a || g.ecolor[e] == b) acyclic = d.join(g.esrc[e], g.edst[e]);
+        ok[a][b] = ok[b][a] = acyclic ? 1 : 0;
     }
+    std::vector<int> mate(g.ncolors, -1), best;
+    int best_pairs = -1;
+    std::function<void(int, int)> rec = [&](int c, int pairs) {          // maximum matching of the colours (few colours: brute force)
+        while (c < g.ncolors && mate[c] >= 0) ++c;
+        if (c >= g.ncolors) { if (pairs > best_pairs) { best_pairs = pairs; best = mate; } return; }
+        mate[c] = c; rec(c + 1, pairs); mate[c] = -1;                     // leave c single
+        for (int b = c + 1; b < g.ncolors; ++b) if (mate[b] < 0 && ok[c][b]) { mate[c] = b; mate[b] = c; rec(c + 1, pairs + 1); mate[c] = mate[b] = -1; }
+    };
+    if (g.ncolors <= 10) rec(0, 0);
+    // 2. greedy linear forests: an edge joins the first forest where both ends still have degree < 2 and no cycle closes
+    std::vector<int> gforest(g.ne, -1); int gnf = 0;
+    {
+        std::vector<std::vector<int>> deg; std::vector<DSU> comp;
+        for (int e = 0; e < g.ne; ++e) {
+            int a = g.esrc[e], b = g.edst[e], f = 0;
+            for (;; ++f) {
+                if (f == gnf) { deg.emplace_back(g.nv, 0); comp.emplace_back(g.nv); ++gnf; }
+                if (deg[f][a] < 2 && deg[f][b] < 2 && comp[f].f(a) != comp[f].f(b)) break;
+            }
+            comp[f].join(a, b); ++deg[f][a]; ++deg[f][b]; gforest[e] = f;
+        }
+    }
+    // the decomposition with fewer forests (= fewer levels per sweep) wins; ties go to the colour pairs (straight lines on lattices)
+    if (best_pairs > 0 && g.ncolors - best_pairs <= gnf) {
+        std::vector<int> fof(g.ncolors, -1);
+        for (int c = 0; c < g.ncolors; ++c) if (fof[c] < 0) { fof[c] = nf; if (best[c] != c && best[c] >= 0) fof[best[c]] = nf; ++nf; }
+        for (int e = 0; e < g.ne; ++e) forest[e] = fof[g.ecolor[e]];
+    } else { forest = gforest; nf = gnf; }
+    std::vector<int> seq;
+    for (int f = 0; f < nf; ++f) {
+        std::vector<std::vector<int>> adj(g.nv);
+        for (int e = 0; e < g.ne; ++e) if (forest[e] == f) { adj[g.esrc[e]].push_back(g.edst[e]); adj[g.edst[e]].push_back(g.esrc[e]); }
+        std::vector<char> seen(g.nv, 0);
+        for (int v = 0; v < g.nv; ++v) {
+            if (adj[v].size() != 1 || seen[v]) continue;                   // start at a path end
+            std::vector<int> path{v}; seen[v] = 1; int prev = -1, cur = v;
+            for (;;) { int nxt = -1; for (int w : adj[cur]) if (w != prev) nxt = w; if (nxt < 0) break; prev = cur; cur = nxt; path.push_back(cur); seen[cur] = 1; }
+            const int k = (int)path.size() - 1;
+            for (int i = k - 1; i >= 0; --i) seq.push_back(g.dedge(path[i], path[i + 1]));
+            for (int i = 0; i < k; ++i) seq.push_back(g.dedge(path[i + 1], path[i]));
+        }
+    }
+    if ((int)seq.size() != 2 * g.ne) throw Err(TNQS_ERR_HIP, "internal: default sequence does not cover every message");
     return seq;
 }
 
