@@ -21,6 +21,8 @@ int tnqs_dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, con
 int tnqs_dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in, const void* Mx, const void* My, void* out);
 /* c64 only: out[b + 32*b'] = sum (X x_lx M)[.., b on leg ly, ..] conj(Y[.., b' on leg ly, ..]) */
 int tnqs_dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* M, void* out);
+/* c64 only: both Grams of the plane (lx, ly) in one pass: out_y keeps ly (lx absorbed with Mx), out_x keeps lx (ly absorbed with My) */
+int tnqs_dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* Mx, const void* My, void* out_y, void* out_x);
 /* c64 only, d = 2, chi_b = 32: out[s',b',rest] = sum in[s,b,rest] X[(s + 2 b) + 64 (s' + 2 b')]; *norm2 = |out|^2 */
 int tnqs_dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2);
 #ifdef __cplusplus

@@ -162,6 +162,7 @@ namespace tnqs { void dbg_pair(int C0, int NMID, int NHI, const void* in, const 
                  void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps);
                  void dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in, const void* Mx, const void* My, void* out);
                  void dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2);
+                 void dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* Mx, const void* My, void* out_y, void* out_x);
                  void dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* M, void* out);
                  void dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, const void* in, const void* X, void* out, double* norm2, int use_mfma);
                  void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma); }
@@ -173,6 +174,9 @@ int tnqs_dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No,
 int tnqs_dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const void* My, void* out) { return guard([&] { dbg_pair(C0, NMID, NHI, in, Mx, My, out); }); }
 int tnqs_dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in, const void* Mx, const void* My, void* out) { return guard([&] { dbg_pair_legs(d, z, chi, lx, ly, in, Mx, My, out); }); }
 int tnqs_dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2) { return guard([&] { dbg_apply64(z, chi, b, in, X, out, norm2); }); }
+int tnqs_dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* Mx, const void* My, void* out_y, void* out_x) {
+    return guard([&] { dbg_pair_gram2(d, z, chi, lx, ly, X, Y, Mx, My, out_y, out_x); });
+}
 int tnqs_dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* M, void* out) { return guard([&] { dbg_pair_gram(d, z, chi, lx, ly, X, Y, M, out); }); }
 int tnqs_dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out) { return guard([&] { dbg_gram_fused(PA, K, PB, X, Y, M, out); }); }
 int tnqs_dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma) {

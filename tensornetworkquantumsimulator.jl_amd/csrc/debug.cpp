@@ -154,6 +154,27 @@ void dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, 
     dO.down(out, 1024 * 8);
 }
 // psi' = psi x_(s,b) X for d = 2, chi_b = chi_b' = 32 through the plane kernel; returns |psi'|^2 in *norm2
+// both messages of a plane in one pass: out_y keeps leg ly (lx absorbed with Mx), out_x keeps leg lx (ly absorbed with My)
+void dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* Mx, const void* My, void* out_y, void* out_x) {
+    need_gpu();
+    PairGram2Item it{};
+    if (!pair_geometry(d, z, chi, lx, ly, it.g)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_pair_gram2: shape not covered");
+    size_t n = d; for (int i = 0; i < z; ++i) n *= chi[i];
+    int nslices = 2 * it.g.n0 * it.g.n1 * it.g.n2;
+    it.spw = 5; it.wg_begin = 0;
+    int nwg = (nslices + it.spw - 1) / it.spw, npart = 8 * nwg;
+    DBuf dX(n * 8), dY(n * 8), dMx(1024 * 8), dMy(1024 * 8), dI(sizeof(PairGram2Item)), dR(2 * sizeof(ReduceItem)), dP1((size_t)npart * 1024 * 8), dP2((size_t)npart * 1024 * 8), dO(2 * 1024 * 8);
+    dX.up(X, n * 8); dY.up(Y, n * 8); dMx.up(Mx, 1024 * 8); dMy.up(My, 1024 * 8);
+    it.X = dX.p; it.Y = dY.p; it.Mx = dMx.p; it.My = dMy.p; it.partial_y = dP1.p; it.partial_x = dP2.p;
+    dI.up(&it, sizeof(it));
+    launch_mfma_pair_gram2(nullptr, (const PairGram2Item*)dI.p, 1, nwg);
+    ReduceItem ri[2] = {{dP1.p, dO.p, 1024, npart, 0, 0}, {dP2.p, (char*)dO.p + 1024 * 8, 1024, npart, 0, 1024}};
+    dR.up(ri, sizeof(ri));
+    launch_reduce<float, float>(nullptr, (const ReduceItem*)dR.p, 2, 2048);
+    HIPCHK(hipDeviceSynchronize());
+    dO.down(out_y, 1024 * 8);
+    HIPCHK(hipMemcpy(out_x, (char*)dO.p + 1024 * 8, 1024 * 8, hipMemcpyDeviceToHost));
+}
 void dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2) {
     need_gpu();
     Apply64Item it{};

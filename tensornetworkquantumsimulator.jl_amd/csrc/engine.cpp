@@ -1,6 +1,7 @@
 // engine.cpp -- see engine.hpp.  Host orchestration only; every flop runs in the HIP kernels of kernels*.hip.
 #include "engine.hpp"
 #include <algorithm>
+#include <unordered_map>
 #include <functional>
 #include <chrono>
 #include <cstdio>
@@ -33,6 +34,7 @@ struct HostTimer {
 double HostTimer::acc[8] = {0}; long HostTimer::cnt[8] = {0};
 static struct HostTimerReport { ~HostTimerReport() { const char* e = std::getenv("TNQS_HOST_TIMING"); if (e && e[0] == '1') for (int k = 0; k < 8; ++k) if (HostTimer::cnt[k])
     std::fprintf(stderr, "[tnqs host timing] phase %d: %.2f ms total, %ld calls, %.1f us each\n", k, HostTimer::acc[k], HostTimer::cnt[k], 1e3 * HostTimer::acc[k] / HostTimer::cnt[k]); } } g_host_timer_report;
+static bool use_dbl() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_DOUBLE_GRAM"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_mfma() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_MFMA"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 
 void hipchk(hipError_t e, const char* what) {
@@ -682,7 +684,11 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                 }
                 std::vector<Chain> chains; std::vector<int> tpos; std::vector<const void*> fmsg;
                 std::vector<PairItem> sh_pair; std::vector<PairGramItem> sh_gram; std::vector<int> sh_chain;   // shared-T path
-                double sh_pair_slices = 0, sh_gram_slices = 0;
+                std::vector<int> is_shared_chain;
+                std::vector<PairGram2Item> sh_dbl; std::vector<std::pair<int, int>> sh_dbl_chain;              // both messages of a forest in one pass
+                struct Pend { int idx, jo, r; };                                                                // first message of a (site, T) seen in this level
+                std::unordered_map<long long, Pend> pend;
+                double sh_pair_slices = 0, sh_gram_slices = 0, sh_dbl_slices = 0;
                 for (size_t q = start; q < end; ++q) {
                     int t = lev[q]; int de = plan.seq[t]; int e = de / 2;
                     int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
@@ -709,8 +715,23 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                                 sh_pair.push_back(pi); sh_pair_slices += (double)c.sd.n / 16384.0;
                             }
                             gi.X = sh.T->p; gi.Y = c.src; gi.M = mr->p;
-                            sh_gram.push_back(gi); sh_gram_slices += (double)c.sd.n / 16384.0;
-                            sh_chain.push_back((int)chains.size());
+                            const long long key = ((long long)src << 1) | (std::min(pa, pb) < std::min(r, jo) ? 0 : 1);
+                            auto pit = use_dbl() ? pend.find(key) : pend.end();
+                            if (pit != pend.end() && pit->second.jo == r && pit->second.r == jo && sh_gram[pit->second.idx].X == gi.X) {
+                                // the partner message of the same forest is in this level too: one pass computes both
+                                PairGramItem& first = sh_gram[pit->second.idx];       // plane (lx = r_first = jo, ly = jo_first = r)
+                                PairGram2Item d2{}; d2.X = first.X; d2.Y = first.Y; d2.Mx = first.M; d2.My = gi.M; d2.g = first.g;
+                                sh_dbl.push_back(d2); sh_dbl_chain.push_back({sh_chain[pit->second.idx], (int)chains.size()});
+                                sh_dbl_slices += (double)c.sd.n / 8192.0;
+                                first.X = nullptr;                                     // retired from the single list
+                                sh_gram_slices -= (double)c.sd.n / 16384.0;
+                                pend.erase(pit);
+                            } else {
+                                if (use_dbl()) pend[key] = Pend{(int)sh_gram.size(), jo, r};
+                                sh_gram.push_back(gi); sh_gram_slices += (double)c.sd.n / 16384.0;
+                                sh_chain.push_back((int)chains.size());
+                            }
+                            is_shared_chain.push_back((int)chains.size());
                             chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(nullptr);
                             continue;
                         }
@@ -729,7 +750,7 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                 }
                 ht_prep.stop();
                 std::vector<char> is_shared(chains.size(), 0);
-                for (int ci : sh_chain) is_shared[ci] = 1;
+                for (int ci : is_shared_chain) is_shared[ci] = 1;
                 HostTimer ht_launch(1);
                 if (!sh_pair.empty()) {
                     int spw = (int)std::max(1.0, std::min(8.0, sh_pair_slices / 2048.0)); int wgs = 0;
@@ -745,6 +766,25 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     GramJob j{}; j.X = chains[i].result; j.Y = chains[i].src; j.sd = chains[i].sd; j.leg = g.leg(chains[i].v, dst); j.keep_site = false;
                     j.M = fmsg[i];
                     jobs.push_back(j);
+                }
+                if (!sh_dbl.empty()) {
+                    int spw = (int)std::max(8.0, std::min(32.0, sh_dbl_slices / 2048.0)); int wgs = 0;
+                    for (size_t q = 0; q < sh_dbl.size(); ++q) {
+                        PairGram2Item& it = sh_dbl[q]; GramJob& jy = jobs[sh_dbl_chain[q].first]; GramJob& jx = jobs[sh_dbl_chain[q].second];
+                        int nwg = (2 * it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw;
+                        it.spw = spw; it.wg_begin = wgs; wgs += nwg;
+                        jy.nchunks = jx.nchunks = 8 * nwg; jy.KK = jx.KK = 32;
+                        jy.partial = dalloc(s, (size_t)jy.nchunks * 1024 * esz); jx.partial = dalloc(s, (size_t)jx.nchunks * 1024 * esz);
+                        it.partial_y = jy.partial->p; it.partial_x = jx.partial->p;
+                    }
+                    const PairGram2Item* d = upload(s, sh_dbl);
+                    ProfScope ps(s, TNQS_PROF_BP_PAIRGRAM, 2.0 * sh_dbl_slices * 8192.0 * esz, 4 * 8.0 * sh_dbl_slices * 8192.0 * 32);
+                    launch_mfma_pair_gram2(s->stream, d, (int)sh_dbl.size(), wgs);
+                }
+                {   // singles: drop the entries that were merged into a double item
+                    std::vector<PairGramItem> keep; std::vector<int> keepc;
+                    for (size_t q = 0; q < sh_gram.size(); ++q) if (sh_gram[q].X) { keep.push_back(sh_gram[q]); keepc.push_back(sh_chain[q]); }
+                    sh_gram.swap(keep); sh_chain.swap(keepc);
                 }
                 if (!sh_gram.empty()) {
                     int spw = (int)std::max(4.0, std::min(16.0, sh_gram_slices / 2048.0)); int wgs = 0;

@@ -207,6 +207,11 @@ struct Apply64Item { const void* in; void* out; const void* Xb; PairGeom g; int 
 struct XbItem { const void* X; void* Xb; };       // X[(s + 2 b) + 64 (s' + 2 b')] complex64 -> 2048 float4
 void launch_make_xb(hipStream_t s, const XbItem* d_items, int nitems);
 void launch_mfma_apply64(hipStream_t s, const Apply64Item* d_items, int nitems, int total_wgs);
+// both messages a site sends into one linear forest in ONE pass over (X, Y): legs (lx, ly) span the plane;
+//   partial_y[b,b'] = sum (X x_lx Mx)[.. b on ly ..] conj(Y[.. b' on ly ..])      (message leaving through ly: lx absorbed with Mx)
+//   partial_x[d,d'] = sum (X x_ly My)[.. d on lx ..] conj(Y[.. d' on lx ..])      (message leaving through lx: ly absorbed with My)
+struct PairGram2Item { const void* X; const void* Y; const void* Mx; const void* My; void* partial_y; void* partial_x; PairGeom g; int wg_begin; int spw; };
+void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs);
 // last absorption + Gram on two arbitrary 32-dim legs (absorbed leg x, kept leg y), reading a (cached) pair product X and psi = Y
 void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitems, int total_wgs);
 

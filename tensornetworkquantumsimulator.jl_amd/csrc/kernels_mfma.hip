@@ -940,6 +940,136 @@ void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitem
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// BOTH messages a degree-4 site sends into a linear forest, from one pass over the shared pair product X and psi = Y:
+//      out_y[b,b'] = sum_{c,jx} ( sum_ix X[c,ix,b] Mx[ix,jx] ) conj Y[c,jx,b']      (kept leg y, leg x absorbed)
+//      out_x[d,d'] = sum_{c,jy} ( sum_iy X[c,d,iy] My[iy,jy] ) conj Y[c,d',jy]      (kept leg x, leg y absorbed)
+// Twice the matrix work of the single kernel per byte (64 flop/B): MFMA-bound, so 8 companions per slice (64-byte runs) are
+// enough and X and Y planes of a slice are resident TOGETHER: wave w owns companion w, its X and Y planes never leave it, the
+// second message uses the same planes read transposed.  Mx, My sit in LDS as A operands.  Two barriers per slice.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mfma_pair_gram2_kernel(const PairGram2Item* __restrict__ items, int nitems) {
+    constexpr int PS = 32 * 33 + 1;            // plane stride in complex elements
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2f* L = reinterpret_cast<v2f*>(smem);     // planes 0..7: X of companions 0..7, planes 8..15: Y
+    v2f* Mxl = L + 16 * PS;                    // Mx^T as an A operand: element (i, j) at j*33 + i
+    v2f* Myl = Mxl + 32 * 33;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
+    int lo = 0, hi_ = nitems - 1;
+    const int gw = blockIdx.x;
+    while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].wg_begin <= gw) lo = mid; else hi_ = mid - 1; }
+    const PairGram2Item it = items[lo];
+    const PairGeom g = it.g;
+    const int nslices = 2 * g.n0 * g.n1 * g.n2;           // half slices: 8 companions each
+    const int lw = gw - it.wg_begin;
+    const int s_begin = lw * it.spw, s_end = min(nslices, s_begin + it.spw);
+    const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
+    const cf* __restrict__ Yg = reinterpret_cast<const cf*>(it.Y);
+    {
+        const cf* __restrict__ Mx = reinterpret_cast<const cf*>(it.Mx); const cf* __restrict__ My = reinterpret_cast<const cf*>(it.My);
+        for (int e = tid; e < 1024; e += 512) {
+            int i = e & 31, j = e >> 5; cf a = Mx[e], b = My[e];
+            v2f va; va[0] = a.re; va[1] = a.im; v2f vb; vb[0] = b.re; vb[1] = b.im;
+            Mxl[j * 33 + i] = va; Myl[j * 33 + i] = vb;
+        }
+    }
+    v16f O1r, O1i, O2r, O2i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { O1r[r] = 0.f; O1i[r] = 0.f; O2r[r] = 0.f; O2i[r] = 0.f; }
+    // mover: thread -> (companion pair f4 = 0..3, first segment sg0 = 0..127); segment j: ix = sg0 & 31, iy = (sg0 >> 5) + 4 j
+    const int f4 = tid & 3, sg0 = tid >> 2;
+    const int ix0 = sg0 & 31, iy0 = sg0 >> 5;
+    const long long toff = (long long)f4 * g.cstr + g.sx * ix0 + g.sy * iy0, tstr = 4 * g.sy, hoff = 4 * g.cstr;
+    v2f* const lbase = L + (2 * f4) * PS + iy0 * 33 + ix0;
+    v4f px[8], py[8];
+    auto issue = [&](int sl2) {
+        const long long b = pair_slice_base(g, sl2 >> 1) + (sl2 & 1) * hoff + toff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { px[j] = *reinterpret_cast<const v4f*>(Xg + b + tstr * j); py[j] = *reinterpret_cast<const v4f*>(Yg + b + tstr * j); }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v2f* p0 = lbase + 132 * j;                           // element (ix, iy) at [iy][ix]; iy advances by 4 per j
+            v2f a; a[0] = px[j][0]; a[1] = px[j][1]; v2f b; b[0] = px[j][2]; b[1] = px[j][3];
+            p0[0] = a; p0[PS] = b;
+            v2f c; c[0] = py[j][0]; c[1] = py[j][1]; v2f d; d[0] = py[j][2]; d[1] = py[j][3];
+            p0[8 * PS] = c; p0[9 * PS] = d;
+        }
+    };
+    if (s_begin < s_end) issue(s_begin);
+    for (int sl = s_begin; sl < s_end; ++sl) {
+        lds_barrier();                                          // the previous slice's planes have been consumed
+        commit();
+        lds_barrier();
+        if (sl + 1 < s_end) issue(sl + 1);
+        const v2f* PX = L + w * PS; const v2f* PY = L + (8 + w) * PS;
+        // ---- message through ly: absorb lx ----------------------------------------------------------------------
+        {
+            v16f Cr, Ci;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2f m = Mxl[ln * 33 + q + 16 * h];          // A[i = jx = ln][k = ix]
+                const v2f x = PX[ln * 33 + q + 16 * h];           // B[k = ix][j = b = ln]
+                Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(m[0], x[0], Cr, 0, 0, 0);
+                Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(m[0], x[1], Ci, 0, 0, 0);
+                Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(m[1], x[0], Ci, 0, 0, 0);
+                Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(-m[1], x[1], Cr, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jx = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const v2f y = PY[ln * 33 + jx];                   // B[k = jx][j = b' = ln]
+                O1r = __builtin_amdgcn_mfma_f32_32x32x2f32(Cr[r], y[0], O1r, 0, 0, 0);
+                O1i = __builtin_amdgcn_mfma_f32_32x32x2f32(Ci[r], y[0], O1i, 0, 0, 0);
+                O1r = __builtin_amdgcn_mfma_f32_32x32x2f32(Ci[r], y[1], O1r, 0, 0, 0);
+                O1i = __builtin_amdgcn_mfma_f32_32x32x2f32(-Cr[r], y[1], O1i, 0, 0, 0);
+            }
+        }
+        // ---- message through lx: absorb ly (the same planes, read transposed) -----------------------------------------
+        {
+            v16f Cr, Ci;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2f m = Myl[ln * 33 + q + 16 * h];          // A[i = jy = ln][k = iy]
+                const v2f x = PX[(q + 16 * h) * 33 + ln];         // B[k = iy][j = d = ln]
+                Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(m[0], x[0], Cr, 0, 0, 0);
+                Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(m[0], x[1], Ci, 0, 0, 0);
+                Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(m[1], x[0], Ci, 0, 0, 0);
+                Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(-m[1], x[1], Cr, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jy = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const v2f y = PY[jy * 33 + ln];                   // B[k = jy][j = d' = ln]
+                O2r = __builtin_amdgcn_mfma_f32_32x32x2f32(Cr[r], y[0], O2r, 0, 0, 0);
+                O2i = __builtin_amdgcn_mfma_f32_32x32x2f32(Ci[r], y[0], O2i, 0, 0, 0);
+                O2r = __builtin_amdgcn_mfma_f32_32x32x2f32(Ci[r], y[1], O2r, 0, 0, 0);
+                O2i = __builtin_amdgcn_mfma_f32_32x32x2f32(-Cr[r], y[1], O2i, 0, 0, 0);
+            }
+        }
+    }
+    cf* __restrict__ p1 = reinterpret_cast<cf*>(it.partial_y) + (size_t)(8 * lw + w) * 1024;
+    cf* __restrict__ p2 = reinterpret_cast<cf*>(it.partial_x) + (size_t)(8 * lw + w) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * h, j = ln;
+        cf v; v.re = O1r[r]; v.im = O1i[r]; p1[i + 32 * j] = v;
+        cf u; u.re = O2r[r]; u.im = O2i[r]; p2[i + 32 * j] = u;
+    }
+}
+void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs) {
+    if (total_wgs <= 0) return;
+    const size_t lds = ((size_t)16 * (32 * 33 + 1) + 2 * 32 * 33) * 2 * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_gram2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(mfma_pair_gram2_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // gate epilogue for d = 2, chi = chi' = 32:   out[s', b', rest] = sum_{s, b} in[s, b, rest] X[(s,b), (s',b')]
 // Pair-kernel shape: a workgroup stages 16 companions x the 32 x 32 plane (b, y) of the bond leg and one other leg; the
 // companions are 8 (s = 0, 1) pairs, and wave w owns both planes of pair w:  C_{s'}[y][b'] = sum_s sum_b in_s[b][y] X_{s s'}[b][b'].

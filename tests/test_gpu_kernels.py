@@ -227,3 +227,24 @@ def test_gate_epilogue_plane_kernel(chi, b):
     got = out.reshape((2,) + tuple(chi), order="F")
     assert np.max(np.abs(got - ref)) < 3e-5 * np.max(np.abs(ref))
     assert abs(nrm.value - np.sum(np.abs(ref) ** 2)) < 1e-5 * np.sum(np.abs(ref) ** 2)
+
+
+@pytest.mark.parametrize("chi,lx,ly", PAIR_SHAPES)
+def test_double_pair_gram(chi, lx, ly):
+    """both messages of a plane from one pass over (X, Y): the second one reads the same LDS planes transposed"""
+    rng = np.random.default_rng(sum(chi) + 3 * lx + ly)
+    z = len(chi)
+    fx, tx = _site(rng, 2, chi); fy, ty = _site(rng, 2, chi)
+    mx = rnd(rng, 1024, np.complex64); my = rnd(rng, 1024, np.complex64)
+    oy = np.zeros(1024, dtype=np.complex64); ox = np.zeros(1024, dtype=np.complex64)
+    cchi = (C.c_int * z)(*chi)
+    rc = lib.tnqs_dbg_pair_gram2(2, z, cchi, lx, ly, fx.ctypes.data_as(C.c_void_p), fy.ctypes.data_as(C.c_void_p), mx.ctypes.data_as(C.c_void_p),
+                                 my.ctypes.data_as(C.c_void_p), oy.ctypes.data_as(C.c_void_p), ox.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    Mx = mx.reshape(32, 32).T.astype(np.complex128); My = my.reshape(32, 32).T.astype(np.complex128)
+    scale = max(1.0, np.sqrt(tx.size / 65536))
+    for (absorbed, kept, M, got) in ((lx, ly, Mx, oy), (ly, lx, My, ox)):
+        xm = np.moveaxis(np.tensordot(tx, M, axes=([1 + absorbed], [0])), -1, 1 + absorbed)
+        axes = [a for a in range(z + 1) if a != 1 + kept]
+        ref = np.tensordot(xm, ty.conj(), axes=(axes, axes))
+        assert np.max(np.abs(got.reshape(32, 32).T - ref)) < 3e-5 * np.max(np.abs(ref)) * scale
