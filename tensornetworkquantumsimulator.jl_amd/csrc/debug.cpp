@@ -160,9 +160,9 @@ void dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X,
     PairGram2Item it{};
     if (!pair_geometry(d, z, chi, lx, ly, it.g)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_pair_gram2: shape not covered");
     size_t n = d; for (int i = 0; i < z; ++i) n *= chi[i];
-    int nslices = 2 * it.g.n0 * it.g.n1 * it.g.n2;
-    it.spw = 5; it.wg_begin = 0;
-    int nwg = (nslices + it.spw - 1) / it.spw, npart = 8 * nwg;
+    int nslices = it.g.n0 * it.g.n1 * it.g.n2;
+    it.spw = 3; it.wg_begin = 0;
+    int npairs = (nslices + it.spw - 1) / it.spw, nwg = 16 * ((npairs + 7) / 8), npart = 8 * nwg;
     DBuf dX(n * 8), dY(n * 8), dMx(1024 * 8), dMy(1024 * 8), dI(sizeof(PairGram2Item)), dR(2 * sizeof(ReduceItem)), dP1((size_t)npart * 1024 * 8), dP2((size_t)npart * 1024 * 8), dO(2 * 1024 * 8);
     dX.up(X, n * 8); dY.up(Y, n * 8); dMx.up(Mx, 1024 * 8); dMy.up(My, 1024 * 8);
     it.X = dX.p; it.Y = dY.p; it.Mx = dMx.p; it.My = dMy.p; it.partial_y = dP1.p; it.partial_x = dP2.p;

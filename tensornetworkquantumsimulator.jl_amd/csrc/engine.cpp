@@ -768,10 +768,11 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     jobs.push_back(j);
                 }
                 if (!sh_dbl.empty()) {
-                    int spw = (int)std::max(8.0, std::min(32.0, sh_dbl_slices / 2048.0)); int wgs = 0;
+                    int spw = (int)std::max(4.0, std::min(16.0, sh_dbl_slices / 4096.0)); int wgs = 0;      // full slices per workgroup pair
                     for (size_t q = 0; q < sh_dbl.size(); ++q) {
                         PairGram2Item& it = sh_dbl[q]; GramJob& jy = jobs[sh_dbl_chain[q].first]; GramJob& jx = jobs[sh_dbl_chain[q].second];
-                        int nwg = (2 * it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw;
+                        const int npairs = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw;     // workgroup pairs (one per half), in groups of 8 pairs
+                        const int nwg = 16 * ((npairs + 7) / 8);
                         it.spw = spw; it.wg_begin = wgs; wgs += nwg;
                         jy.nchunks = jx.nchunks = 8 * nwg; jy.KK = jx.KK = 32;
                         jy.partial = dalloc(s, (size_t)jy.nchunks * 1024 * esz); jx.partial = dalloc(s, (size_t)jx.nchunks * 1024 * esz);

@@ -959,9 +959,13 @@ __global__ __launch_bounds__(512) void mfma_pair_gram2_kernel(const PairGram2Ite
     while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].wg_begin <= gw) lo = mid; else hi_ = mid - 1; }
     const PairGram2Item it = items[lo];
     const PairGeom g = it.g;
-    const int nslices = 2 * g.n0 * g.n1 * g.n2;           // half slices: 8 companions each
-    const int lw = gw - it.wg_begin;
-    const int s_begin = lw * it.spw, s_end = min(nslices, s_begin + it.spw);
+    // A slice of the geometry (16 companions = one 128-byte run per plane element) is processed as two HALF slices of 8 companions by
+    // two different workgroups, lw and lw + 8 of a group of 16: they sit on the same XCD (workgroups go round-robin over the 8
+    // XCDs) and walk the same slices at the same time, so the second 64-byte half of every line is an L2 hit instead of a re-fetch.
+    const int nslices = g.n0 * g.n1 * g.n2;
+    const int lw = gw - it.wg_begin;                        // wg_begin is a multiple of 16
+    const int half = (lw >> 3) & 1, pw = ((lw >> 4) << 3) | (lw & 7);
+    const int s_begin = pw * it.spw, s_end = min(nslices, s_begin + it.spw);
     const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
     const cf* __restrict__ Yg = reinterpret_cast<const cf*>(it.Y);
     {
@@ -981,8 +985,8 @@ __global__ __launch_bounds__(512) void mfma_pair_gram2_kernel(const PairGram2Ite
     const long long toff = (long long)f4 * g.cstr + g.sx * ix0 + g.sy * iy0, tstr = 4 * g.sy, hoff = 4 * g.cstr;
     v2f* const lbase = L + (2 * f4) * PS + iy0 * 33 + ix0;
     v4f px[8], py[8];
-    auto issue = [&](int sl2) {
-        const long long b = pair_slice_base(g, sl2 >> 1) + (sl2 & 1) * hoff + toff;
+    auto issue = [&](int sl) {
+        const long long b = pair_slice_base(g, sl) + half * hoff + toff;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { px[j] = *reinterpret_cast<const v4f*>(Xg + b + tstr * j); py[j] = *reinterpret_cast<const v4f*>(Yg + b + tstr * j); }
     };
