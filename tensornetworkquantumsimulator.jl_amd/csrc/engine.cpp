@@ -768,7 +768,14 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     jobs.push_back(j);
                 }
                 if (!sh_dbl.empty()) {
-                    int spw = (int)std::max(4.0, std::min(16.0, sh_dbl_slices / 4096.0)); int wgs = 0;      // full slices per workgroup pair
+                    // full slices per workgroup pair: the largest power of two that still gives >= 4 workgroups per CU; an item gets groups
+                    // of 16 workgroups (8 pairs), so powers of two avoid idle workgroups for the usual 2^k slices per site
+                    int spw = 16, wgs = 0;
+                    for (; spw > 1; spw >>= 1) {
+                        long tot = 0;
+                        for (auto& it : sh_dbl) { int np = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw; tot += 16 * ((np + 7) / 8); }
+                        if (tot >= 1024) break;
+                    }
                     for (size_t q = 0; q < sh_dbl.size(); ++q) {
                         PairGram2Item& it = sh_dbl[q]; GramJob& jy = jobs[sh_dbl_chain[q].first]; GramJob& jx = jobs[sh_dbl_chain[q].second];
                         const int npairs = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw;     // workgroup pairs (one per half), in groups of 8 pairs
