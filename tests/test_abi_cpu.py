@@ -47,3 +47,19 @@ def test_product_package_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "tnqs_oracle" not in txt and "import statevector" not in txt and "oracle/" not in txt, f
+
+
+def test_c_driver_compiles_against_the_abi_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/c_driver.c (plain C, gcc) links against libtnqs_hip.so through include/tnqs.h alone; without a GPU the library
+    refuses to run (no CPU fallback) and the driver reports the library's error string"""
+    import subprocess
+    import torch
+    exe = str(tmp_path / "c_driver")
+    pkg = os.path.join(ROOT, "tensornetworkquantumsimulator.jl_amd")
+    r = subprocess.run(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_driver.c"), "-o", exe,
+                        "-L" + pkg, "-ltnqs_hip", "-lm", "-Wl,-rpath," + pkg], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the run itself is covered by tests/test_gpu_parity.py")
+    p = subprocess.run([exe, "3", "2"], capture_output=True, text=True)
+    assert p.returncode == 1 and "no HIP device" in p.stderr

@@ -538,3 +538,39 @@ def test_symmetric_gauge_matches_oracle(dtype, lattice):
     assert not np.array_equal(bpc.message(g.edges[0]), sg.message(g.edges[0]))
     t2 = tn.symmetric_gauge(psi, cache_update_kwargs=kw)
     assert np.max(np.abs(np.abs(t2.tensors[g.vertices[0]]) - np.abs(sg.tensor(g.vertices[0])))) < 1.0
+
+
+def test_plain_c_driver_reproduces_the_python_host(tmp_path):
+    """examples/c_driver.c drives the C ABI from C (no Python, no torch): same <Z_v> and truncation errors as the ctypes host"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "tensornetworkquantumsimulator.jl_amd")
+    exe = str(tmp_path / "c_driver")
+    r = subprocess.run(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_driver.c"), "-o", exe,
+                        "-L" + pkg, "-ltnqs_hip", "-lm", "-Wl,-rpath," + pkg], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    L = 3
+    p = subprocess.run([exe, str(L), "2"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.strip().splitlines()
+    ez_c = np.array([float(l.split()[1]) for l in lines[:L * L]])
+    tsum_c = float(lines[-1].split()[1])
+    g = tn.named_grid((L, L))
+    layer = [("Rx", [v], 2 * 1.0 * 0.25) for v in g.vertices]
+    # same gate order as the driver: per colour, edges in the driver's edge order (right edge, then down edge of each vertex in row-major order)
+    edges = []
+    for r_ in range(1, L + 1):
+        for c_ in range(1, L + 1):
+            if c_ < L: edges.append(((r_, c_), (r_, c_ + 1), True))
+            if r_ < L: edges.append(((r_, c_), (r_ + 1, c_), False))
+    for colour in range(4):
+        for (a, b, horiz) in edges:
+            par = ((a[1] - 1) % 2) if horiz else ((a[0] - 1) % 2)
+            if (0 if horiz else 2) + par == colour:
+                layer.append(("Rzz", [a, b], 2 * 0.5 * 0.25))
+    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex128, lambda v: "↑", g))
+    out, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=2, cutoff=1e-12, normalize_tensors=True), bp_update_kwargs=dict(maxiter=200, tolerance=1e-13))
+    ez = tn.expect_all(out, "Z").real
+    assert np.max(np.abs(ez - ez_c)) < 1e-10
+    assert abs(float(np.sum(errs)) - tsum_c) < 1e-12
