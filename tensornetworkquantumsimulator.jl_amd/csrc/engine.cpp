@@ -600,7 +600,7 @@ static BPPlan make_plan(const State* s, const tnqs_bp_opts* o) {
             if (de < 0) throw Err(TNQS_ERR_INVALID, "bp_update: edge_sequence contains a pair of non-adjacent vertices");
             p.seq.push_back(de);
         }
-    } else p.seq = default_sequence(g);
+    } else { if (g.default_seq.empty() && g.ne > 0) g.default_seq = default_sequence(g); p.seq = g.default_seq; }
     p.pos_of.assign(2 * (size_t)g.ne, -1);
     for (size_t t = 0; t < p.seq.size(); ++t) { if (p.pos_of[p.seq[t]] >= 0) p.in_place = true; p.pos_of[p.seq[t]] = (int)t; }
     if (p.in_place) { for (size_t t = 0; t < p.seq.size(); ++t) { p.levels.push_back({(int)t}); p.level_of.push_back((int)t); } return p; }
