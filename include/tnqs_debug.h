@@ -3,6 +3,7 @@
 #ifndef TNQS_DEBUG_H
 #define TNQS_DEBUG_H
 #include <stdint.h>
+#include "tnqs.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -25,6 +26,8 @@ int tnqs_dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void*
 int tnqs_dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* Mx, const void* My, void* out_y, void* out_x);
 /* c64 only, d = 2, chi_b = 32: out[s',b',rest] = sum in[s,b,rest] X[(s + 2 b) + 64 (s' + 2 b')]; *norm2 = |out|^2 */
 int tnqs_dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2);
+/* the BP sweep order bp_update uses when no edge_sequence is given, as (src[i] -> dst[i]) vertex indices; *n_out = its length (2 ne) */
+int tnqs_dbg_default_sequence(tnqs_handle h, int* src, int* dst, int cap, int* n_out);
 #ifdef __cplusplus
 }
 #endif

@@ -157,7 +157,8 @@ int tnqs_profile_reset(tnqs_handle h) {
 // ---- kernel-level debug entry points (include/tnqs_debug.h) ---------------------------------------------------
 #include "../../include/tnqs_debug.h"
 #include "kernels.hpp"
-namespace tnqs { void dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const void* My, void* out);
+namespace tnqs { void dbg_default_sequence(const State* s, std::vector<int>& src, std::vector<int>& dst);
+                 void dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const void* My, void* out);
                  void dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out);
                  void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps);
                  void dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in, const void* Mx, const void* My, void* out);
@@ -167,6 +168,10 @@ namespace tnqs { void dbg_pair(int C0, int NMID, int NHI, const void* in, const 
                  void dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, const void* in, const void* X, void* out, double* norm2, int use_mfma);
                  void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma); }
 extern "C" {
+int tnqs_dbg_default_sequence(tnqs_handle h, int* src, int* dst, int cap, int* n_out) {
+    return guard([&] { std::vector<int> a, b; dbg_default_sequence(S(h), a, b); *n_out = (int)a.size();
+                       for (int i = 0; i < (int)a.size() && i < cap; ++i) { src[i] = a[i]; dst[i] = b[i]; } });
+}
 int tnqs_dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) { return guard([&] { dbg_jacobi(dtype, m, n, A, V, sweeps); }); }
 int tnqs_dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, const void* in, const void* X, void* out, double* norm2, int use_mfma) {
     return guard([&] { dbg_fiber_gemm(dtype, D, PA, K, PB, Do, No, in, X, out, norm2, use_mfma); });

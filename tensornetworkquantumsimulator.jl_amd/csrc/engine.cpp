@@ -591,6 +591,13 @@ static std::vector<int> default_sequence(const Graph& g) {
     return seq;
 }
 
+// the default order as (src, dst) vertex pairs, for tests that replay it on the oracle (include/tnqs_debug.h)
+void dbg_default_sequence(const State* s, std::vector<int>& src, std::vector<int>& dst) {
+    const Graph& g = *s->g;
+    if (g.default_seq.empty() && g.ne > 0) g.default_seq = default_sequence(g);
+    for (int de : g.default_seq) { const int e = de / 2; src.push_back((de & 1) ? g.edst[e] : g.esrc[e]); dst.push_back((de & 1) ? g.esrc[e] : g.edst[e]); }
+}
+
 static BPPlan make_plan(const State* s, const tnqs_bp_opts* o) {
     const Graph& g = *s->g;
     BPPlan p;

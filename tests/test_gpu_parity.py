@@ -574,3 +574,90 @@ def test_plain_c_driver_reproduces_the_python_host(tmp_path):
     ez = tn.expect_all(out, "Z").real
     assert np.max(np.abs(ez - ez_c)) < 1e-10
     assert abs(float(np.sum(errs)) - tsum_c) < 1e-12
+
+
+def _random_graph(rng, kind):
+    if kind == "tree":
+        n = int(rng.integers(4, 9))
+        edges = [(int(rng.integers(0, i)), i) for i in range(1, n)]
+    elif kind == "ring":
+        n = int(rng.integers(4, 8)); edges = [(i, (i + 1) % n) for i in range(n)]
+    elif kind == "ladder":
+        m = int(rng.integers(2, 5)); n = 2 * m
+        edges = [(i, i + 1) for i in range(m - 1)] + [(m + i, m + i + 1) for i in range(m - 1)] + [(i, m + i) for i in range(m)]
+    else:   # random connected graph with a few extra edges
+        n = int(rng.integers(5, 9))
+        edges = [(int(rng.integers(0, i)), i) for i in range(1, n)]
+        for _ in range(int(rng.integers(1, 4))):
+            a, b = sorted(rng.choice(n, size=2, replace=False).tolist())
+            if (a, b) not in edges and sum(1 for e in edges if a in e) < 4 and sum(1 for e in edges if b in e) < 4:
+                edges.append((a, b))
+    verts = [(i + 1,) for i in range(n)]
+    return tn.NamedGraph(verts, [(verts[a], verts[b]) for (a, b) in edges])
+
+
+def device_default_sequence(bpc):
+    """the sweep order the engine uses when no edge_sequence is given (engine.cpp default_sequence), as vertex pairs"""
+    import ctypes as C
+    lib = C.CDLL(tn.LIB_PATH)
+    g = bpc.graph; cap = 2 * g.ne(); src = (C.c_int * cap)(); dst = (C.c_int * cap)(); n = C.c_int(0)
+    lib.tnqs_dbg_default_sequence.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    lib.tnqs_dbg_default_sequence.restype = C.c_int
+    assert lib.tnqs_dbg_default_sequence(bpc._h, src, dst, cap, C.byref(n)) == 0 and n.value == cap
+    return [(g.vertices[src[i]], g.vertices[dst[i]]) for i in range(cap)]
+
+
+@pytest.mark.parametrize("order", ["forest_cover", "device_default"])
+@pytest.mark.parametrize("seed", list(range(48)))
+def test_random_graphs_random_circuits_match_oracle(seed, order):
+    """stress: random graphs (trees, rings, ladders, sparse random), random bond dimensions, random gate lists with repeated and
+    overlapping gates, both precisions -- device against oracle on gauge-invariant quantities, and against the exact state vector
+    when nothing is truncated (simple_update.jl:4)"""
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["tree", "ring", "ladder", "random"][seed % 4]
+    dtype = np.complex128 if (seed // 4) % 2 == 0 else np.complex64
+    tol = 1e-9 if dtype == np.complex128 else 5e-4
+    g = _random_graph(rng, kind)
+    chi0 = int(rng.integers(1, 4))
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=chi0, seed=seed)
+    names1 = ["Rx", "Ry", "Rz", "H", "X"]; names2 = ["Rzz", "Rxx", "CPHASE", "CNOT", "SWAP"]
+    circuit = []
+    for _ in range(int(rng.integers(6, 14))):
+        if rng.random() < 0.35:
+            v = g.vertices[int(rng.integers(0, g.nv()))]; nm = names1[int(rng.integers(0, len(names1)))]
+            circuit.append((nm, [v], float(rng.uniform(0.1, 1.5))) if nm.startswith("R") else (nm, [v]))
+        else:
+            a, b = g.edges[int(rng.integers(0, g.ne()))]
+            if rng.random() < 0.5:
+                a, b = b, a
+            nm = names2[int(rng.integers(0, len(names2)))]
+            circuit.append((nm, [a, b], float(rng.uniform(0.1, 1.5))) if nm in ("Rzz", "Rxx", "CPHASE") else (nm, [a, b]))
+    truncated = seed % 3 == 0
+    kw = dict(maxdim=(2 if truncated else 64), cutoff=1e-14, normalize_tensors=bool(seed % 2))
+    # Both sides must sweep in the SAME order: the engine's default (linear forests) and the oracle's default (forest cover) reach
+    # fixed points that agree only to ~sqrt(tolerance), which shows up as 1e-8-level differences in truncation errors of loopy
+    # graphs.  "forest_cover": that order given explicitly to both; "device_default": the engine left on its own default, and the
+    # oracle replaying that order (read back through tnqs_dbg_default_sequence).
+    bpc = tn.BeliefPropagationCache(psi)
+    if order == "forest_cover":
+        bpkw = okw = dict(tight(dtype), edge_sequence=tn.forest_cover_edge_sequence(g))
+    else:
+        bpkw = tight(dtype); okw = dict(bpkw, edge_sequence=device_default_sequence(bpc))
+    bpc = tn.update(bpc, **bpkw)
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **okw)
+    out, errs = tn.apply_gates(circuit, bpc, apply_kwargs=kw, bp_update_kwargs=bpkw)
+    oo, oerrs = o.apply_gates(circuit, oc, apply_kwargs=kw, bp_update_kwargs=okw)
+    assert [out.bond_dim(a, b) for (a, b) in g.edges] == [oo.tns.bond_dim(a, b) for (a, b) in g.edges]
+    assert np.max(np.abs(errs - np.array(oerrs))) < (1e-9 if dtype == np.complex128 else 2e-5)
+    for v in g.vertices:
+        assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oo, Z, v)) < 20 * tol
+    if not truncated:
+        from tnqs_oracle import resolve_gate
+        v0 = sv.tns_to_statevector(to_oracle_state(psi))
+        og = to_oracle_graph(g)
+        ex = v0
+        for gate in circuit:
+            mat, verts = resolve_gate(gate)
+            ex = sv.apply_gate_statevector(ex, og, mat, verts)
+        got = sv.tns_to_statevector(to_oracle_state(out.network()))
+        assert abs(sv.fidelity(ex, got) - 1) < 20 * tol
