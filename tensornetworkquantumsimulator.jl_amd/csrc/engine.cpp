@@ -1142,7 +1142,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     }
     // R factor of psi~ = Q R from G = R^dagger R: Cholesky (R = L^dagger) where G has full rank by construction (at least as
     // many fibers as columns); the f64 Jacobi eigen factorisation R = Lambda^1/2 W^dagger otherwise, and for the whole batch when
-    // a Cholesky pivot collapses (numerically rank-deficient G; the eigen path drops the null space, TNQS_RANK_TAU)
+    // a Cholesky pivot collapses (numerically rank-deficient G; the eigen path drops the null space, rank_tau in kernels.hpp)
     std::vector<Buf> GW(sj.size()); std::vector<char> is_chol(sj.size(), 0);
     std::vector<const void*> gauged_of(sj.size(), nullptr);      // psi~ of the owned sites
     for (size_t q = 0; q < own_idx.size(); ++q) gauged_of[own_idx[q]] = chains[q].result;
@@ -1169,7 +1169,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             }
             if (ch) {
                 GW[i] = dalloc(s, (size_t)n * n * 16);
-                ci.push_back(CholItem{GA[i]->p, GV[i]->p, GW[i]->p, n, reinterpret_cast<int*>(d_cholfail->p)}); cmax = std::max(cmax, n);
+                ci.push_back(CholItem{GA[i]->p, GV[i]->p, GW[i]->p, n, reinterpret_cast<int*>(d_cholfail->p), rank_tau(std::is_same<T, float>::value, n)}); cmax = std::max(cmax, n);
             } else {
                 GW[i] = GV[i];
                 idn.push_back(EnvItem{nullptr, GV[i]->p, GV[i]->p, n});      // msg == null: H := I, V := I (same buffer)

@@ -710,7 +710,6 @@ void launch_small_svd_finish(hipStream_t s, const SmallSvdItem* d_items, int nit
     hipLaunchKernelGGL(small_svd_finish_kernel, dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 
-#define TNQS_RANK_TAU 1e-12
 // ------------------------------------------------------------------------------------------------------------
 // Cholesky factor of the Gram matrix (the R factor of the thin QR, simple_update.jl:45-48, when G has full rank)
 // ------------------------------------------------------------------------------------------------------------
@@ -728,7 +727,7 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
     __syncthreads();
     if (tid == 0) { double m = 0; for (int i = 0; i < n; ++i) m = fmax(m, A[i + np * i].re); s_dmax = m; }
     __syncthreads();
-    const double tiny = TNQS_RANK_TAU * s_dmax;
+    const double tiny = it.tau * s_dmax;
     for (int k = 0; k < n; ++k) {
         if (tid == 0) {
             double d = A[k + np * k].re;
@@ -866,7 +865,7 @@ template void launch_env_finish<double>(hipStream_t, const EnvFinishItem*, int);
 // ------------------------------------------------------------------------------------------------------------
 
 __device__ void gate_eigs(const cx<double>* A, const cx<double>* V, int n, double* lam_tmp /*LDS n*/, double* lam_out,
-                          int* idx_out, int* r_out, int* s_r /*LDS*/) {
+                          int* idx_out, int* r_out, int* s_r /*LDS*/, double tau) {
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         double l = 0;
         for (int i = 0; i < n; ++i) { cx<double> v = V[i + n * j], a = A[i + n * j]; l += v.re * a.re + v.im * a.im; }
@@ -878,7 +877,7 @@ __device__ void gate_eigs(const cx<double>* A, const cx<double>* V, int n, doubl
         for (int j = 0; j < n; ++j) lmax = fmax(lmax, lam_tmp[j]);
         int r = 0;
         for (int j = 0; j < n; ++j)
-            if (lam_tmp[j] > TNQS_RANK_TAU * lmax && lam_tmp[j] > 0) { lam_out[r] = lam_tmp[j]; idx_out[r] = j; ++r; }
+            if (lam_tmp[j] > tau * lmax && lam_tmp[j] > 0) { lam_out[r] = lam_tmp[j]; idx_out[r] = j; ++r; }
         *r_out = r; *s_r = r;
     }
     __syncthreads();
@@ -900,8 +899,8 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
     const cx<double>* V1 = reinterpret_cast<const cx<double>*>(it.GV1);
     const cx<double>* A2 = reinterpret_cast<const cx<double>*>(it.GA2);
     const cx<double>* V2 = reinterpret_cast<const cx<double>*>(it.GV2);
-    if (it.chol1) gate_full_rank(it.n1, it.lam1, it.idx1, &it.info[0], &s_r1); else gate_eigs(A1, V1, it.n1, lam_tmp, it.lam1, it.idx1, &it.info[0], &s_r1);
-    if (it.chol2) gate_full_rank(it.n2, it.lam2, it.idx2, &it.info[1], &s_r2); else gate_eigs(A2, V2, it.n2, lam_tmp, it.lam2, it.idx2, &it.info[1], &s_r2);
+    if (it.chol1) gate_full_rank(it.n1, it.lam1, it.idx1, &it.info[0], &s_r1); else gate_eigs(A1, V1, it.n1, lam_tmp, it.lam1, it.idx1, &it.info[0], &s_r1, rank_tau(sizeof(T) == 4, it.n1));
+    if (it.chol2) gate_full_rank(it.n2, it.lam2, it.idx2, &it.info[1], &s_r2); else gate_eigs(A2, V2, it.n2, lam_tmp, it.lam2, it.idx2, &it.info[1], &s_r2, rank_tau(sizeof(T) == 4, it.n2));
     const int r1 = s_r1, r2 = s_r2, d1 = it.d1, d2 = it.d2, chi = it.chi;
     const int Mr = r1 * d1, Nc = r2 * d2;
     const bool wide = Mr < Nc;

@@ -119,7 +119,13 @@ template <class T> void launch_small_svd_prepare(hipStream_t s, const SmallSvdIt
 void launch_small_svd_finish(hipStream_t s, const SmallSvdItem* d_items, int nitems);
 // Cholesky of a Hermitian positive definite n x n f64 matrix (column-major): L (lower, G = L L^dagger) and Winv = (L^-1)^dagger;
 // *fail is set when a pivot drops below 1e-12 * max diagonal (the caller falls back to the eigen factorisation)
-struct CholItem { const void* G; void* L; void* Winv; int n; int* fail; };
+// Rank threshold of the Gram-matrix factorisations: a direction of psi~ whose Gram eigenvalue (Cholesky pivot) is below tau * max is
+// treated as null.  tau is what the f64 Gram matrix can resolve -- not more: for ComplexF32 states the f32 rounding of psi~ itself
+// (6e-8 in amplitude, 4e-15 n in the eigenvalue) sits under 1e-12; for ComplexF64 states the f64 accumulation leaves ~n eps, and the
+// reference's QR keeps everything above that (a flat 1e-12 here dropped singular directions of relative size < 1e-6 and cost 1e-9
+// per layer in log Z on the reference's thermal-state example, cutoff = 1e-14).
+__host__ __device__ inline double rank_tau(bool f32_state, int n) { return f32_state ? 1e-12 : 4.0 * (double)n * 2.220446049250313e-16; }
+struct CholItem { const void* G; void* L; void* Winv; int n; int* fail; double tau; };
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax);
 template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax);
 void launch_recover_v_mfma(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax);    // ComplexF32, MFMA (kernels_mfma.hip)

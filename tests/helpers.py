@@ -42,3 +42,35 @@ def tfim_layer(g, groups, dt=0.25, hx=1.0, hz=0.8, J=0.5):
 
 def msg_close(a, b, tol):
     return np.max(np.abs(np.asarray(a) - np.asarray(b))) <= tol * max(1.0, np.max(np.abs(b)))
+
+
+def htse_free_energy(mod, nsteps=25, dbeta=0.01, J=1.0, maxdim=16, dtype=np.complex128, every=5, bp_update_kwargs=None, cutoff=1e-14):
+    """the reference's thermal-state example (examples/hexagonal_heisenbergmodel_thermalstate.jl:7-40) on either side
+    (`mod` = the oracle module or the device package): identity operator on two site indices per vertex (here one d = 4
+    site, index (s, ancilla)), imaginary-time Heisenberg gates Rxxyyzz(theta = -i J dbeta / 2) on the first index, log Z
+    accumulated from freenergy + rescale! after every layer.  The 2x2 periodic hexagonal lattice of the example is an
+    8-vertex 3-regular graph; BP sees only the degree, so any 3-regular graph gives the same density -- built here as
+    the periodic 4x2 grid (two rings of 4 joined by rungs).  Returns [(beta, f_bp, f_htse4)]."""
+    pauli = [np.array([[0, 1], [1, 0]], complex), np.array([[0, -1j], [1j, 0]]), np.diag([1.0, -1.0]).astype(complex)]
+    h = 0.5 * sum(np.kron(np.kron(p, np.eye(2)), np.kron(p, np.eye(2))) for p in pauli)      # gate_definitions.jl:276-279
+    w, q = np.linalg.eigh(h)
+    gate = (q * np.exp(-0.5 * J * dbeta * w)) @ q.conj().T                                   # exp(-i theta h), theta = -i J dbeta / 2
+    g = mod.named_grid((4, 2), periodic=True)
+    assert all(g.degree(v) == 3 for v in g.vertices)
+    tensors = {v: np.eye(2, dtype=dtype).reshape((4, 1, 1, 1)) for v in g.vertices}         # tensornetworkstate_constructors.jl:21-39
+    bpkw = dict(bp_update_kwargs(g)) if bp_update_kwargs is not None else {}     # the example runs on the defaults
+    bpc = mod.update(mod.BeliefPropagationCache(mod.TensorNetworkState(g, tensors)), **bpkw)
+    gates = [(gate, [a, b]) for grp in mod.edge_color(g) for (a, b) in grp]
+    kw = dict(maxdim=maxdim, cutoff=cutoff, normalize_tensors=False)
+    logz = -np.log(complex(mod.partitionfunction(bpc)))
+    bpc = mod.rescale(bpc)
+    out = []
+    for i in range(1, nsteps + 1):
+        bpc, _ = mod.apply_gates(gates, bpc, apply_kwargs=kw, bp_update_kwargs=bpkw or None)
+        logz -= np.log(complex(mod.partitionfunction(bpc)))
+        bpc = mod.rescale(bpc)
+        if i % every == 0:
+            b = 2 * i * dbeta
+            out.append((b, (logz / len(g.vertices)).real,
+                        -np.log(2) - 9 / 64 * (J * b) ** 2 - 3 / 128 * (J * b) ** 3 + 27 / 2048 * (J * b) ** 4))
+    return out
