@@ -70,7 +70,7 @@ typedef struct {
     int bp_not_converged;   /* updates that hit maxiter (reference: @warn, abstract...:245-252) */
     double last_bp_diff;
     int n_chol_fallbacks;   /* gate batches whose Gram matrices were numerically rank-deficient (eigen path instead of Cholesky) */
-    int reserved_;
+    int n_qr2_sites;        /* ComplexF64 sites that went through the second factorisation pass (ill-conditioned psi~) */
 } tnqs_apply_stats;
 
 /* ---- library ---------------------------------------------------------------------------------------- */

@@ -21,6 +21,7 @@ static size_t bp_ws_budget() { static size_t v = 0; if (!v) { const char* e = st
 static size_t jacobi_lds(size_t bytes) { static int g = -1; if (g < 0) { const char* e = std::getenv("TNQS_JACOBI_GLOBAL"); g = (e && e[0] == '1') ? 1 : 0; } return (g || bytes > 160 * 1024 - 256) ? 0 : bytes; }
 static int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j : ji) m = std::max(m, std::max(j.m, j.n)); return m; }
 static bool use_chol() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_CHOL"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
+static bool use_qr2() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_QR2"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_small_svd() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_SMALLSVD"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_apply64() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_APPLY64"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 // optional host-side phase timing (TNQS_HOST_TIMING=1): printed when the process exits
@@ -1143,7 +1144,11 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     // R factor of psi~ = Q R from G = R^dagger R: Cholesky (R = L^dagger) where G has full rank by construction (at least as
     // many fibers as columns); the f64 Jacobi eigen factorisation R = Lambda^1/2 W^dagger otherwise, and for the whole batch when
     // a Cholesky pivot collapses (numerically rank-deficient G; the eigen path drops the null space, rank_tau in kernels.hpp)
-    std::vector<Buf> GW(sj.size()); std::vector<char> is_chol(sj.size(), 0);
+    std::vector<Buf> GW(sj.size()); std::vector<char> is_chol(sj.size(), 0), is_small(sj.size(), 0);
+    // ComplexF64, single rank: ill-conditioned sites get a second factorisation pass below, which sorts out what is signal and what is
+    // noise among the smallest directions -- so the first pass keeps everything above the f64 noise floor instead of rank_tau
+    const bool qr2 = !std::is_same<T, float>::value && !sharded && use_qr2();
+    auto tau_of = [&](int n) { return qr2 ? 1e-15 : rank_tau(std::is_same<T, float>::value, n); };
     std::vector<const void*> gauged_of(sj.size(), nullptr);      // psi~ of the owned sites
     for (size_t q = 0; q < own_idx.size(); ++q) gauged_of[own_idx[q]] = chains[q].result;
     Buf d_cholfail = dalloc(s, sizeof(int));
@@ -1160,7 +1165,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             is_chol[i] = ch ? 1 : 0;
             if (!ch && sj[i].owned && Nout < (size_t)n && n <= 256 && use_small_svd()) {
                 // fewer fibers than columns: R = Sigma U^dagger straight from the SVD of the n x N matricised psi~ (no rank-deficient G)
-                GW[i] = GV[i];
+                GW[i] = GV[i]; is_small[i] = 1;
                 Buf M = dalloc(s, (size_t)n * Nout * 16); s->keepalive.push_back(M);
                 const SD& sd = sj[i].sd; const int b = sj[i].bleg;
                 si.push_back(SmallSvdItem{gauged_of[i], M->p, GA[i]->p, GV[i]->p, sd.d, (int)(sd.pre(b) / sd.d), sd.chi[b], (int)sd.post(b)});
@@ -1169,7 +1174,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             }
             if (ch) {
                 GW[i] = dalloc(s, (size_t)n * n * 16);
-                ci.push_back(CholItem{GA[i]->p, GV[i]->p, GW[i]->p, n, reinterpret_cast<int*>(d_cholfail->p), rank_tau(std::is_same<T, float>::value, n)}); cmax = std::max(cmax, n);
+                ci.push_back(CholItem{GA[i]->p, GV[i]->p, GW[i]->p, n, reinterpret_cast<int*>(d_cholfail->p), tau_of(n)}); cmax = std::max(cmax, n);
             } else {
                 GW[i] = GV[i];
                 idn.push_back(EnvItem{nullptr, GV[i]->p, GV[i]->p, n});      // msg == null: H := I, V := I (same buffer)
@@ -1243,6 +1248,11 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             it.lam1 = (double*)w.lam1->p; it.lam2 = (double*)w.lam2->p; it.idx1 = (int*)w.idx1->p; it.idx2 = (int*)w.idx2->p;
             it.theta = w.theta->p; it.thetaV = w.thetaV->p; it.theta0 = w.theta0 ? w.theta0->p : nullptr; it.X1 = w.X1->p; it.X2 = w.X2->p; it.S = (double*)w.S->p;
             it.maxdim = ao.maxdim; it.cutoff = ao.cutoff; it.normalize = ao.normalize_tensors; it.chi_cap = cap;
+            // second-pass mode: the eigen route of the first pass is shifted (negative tau, gate_eigs) -- it must not drop a direction the
+            // second pass could still resolve
+            // (the small-SVD sites are factorised without a Gram matrix and are never refined: ordinary threshold)
+            auto site_tau = [&](size_t i, int n) { return (qr2 && !is_small[i] && sj[i].owned) ? -rank_tau(false, n) : rank_tau(std::is_same<T, float>::value, n); };
+            it.tau1 = site_tau(2 * (size_t)gi, w.n1); it.tau2 = site_tau(2 * (size_t)gi + 1, w.n2); it.rk1 = nullptr; it.rk2 = nullptr;
         }
     }
     const int npg = (int)pg.size();
@@ -1271,6 +1281,77 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipStreamSynchronize(s->stream));
             s->stats.n_chol_fallbacks += 1;
+        }
+        if (qr2) {
+            // ---- second factorisation pass (CholeskyQR2) of the sites gate_theta flagged as ill-conditioned: a Gram matrix resolves the
+            // singular directions of psi~ only down to sigma_rel ~ 1e-7, the reference's QR to eps.  Q1 = psi~ R1^+ is formed explicitly;
+            // its Gram matrix is close to the identity on everything the first pass resolved and shows the true weight of what it did not,
+            // so R = R2 R1 is as accurate as a Householder R.  
+            std::vector<size_t> rs; std::vector<int> rq;
+            for (int q = 0; q < npg; ++q) for (int side = 0; side < 2; ++side) {
+                const size_t i = 2 * (size_t)pg[q] + side;
+                static const bool all = [] { const char* v = std::getenv("TNQS_QR2_ALL"); return v && v[0] == '1'; }();      // debug: refine every site
+                if ((all || hinfo[8 * q + 6 + side]) && !is_small[i] && sj[i].owned) { rs.push_back(i); rq.push_back(q); }
+            }
+            if (!rs.empty()) {
+                const size_t m = rs.size();
+                std::vector<Buf> X1(m), Q1(m), G2(m), V2(m), GVn(m), GWn(m); Buf d_rk = dalloc(s, m * sizeof(int));
+                std::vector<Qr2RinvItem> ri; std::vector<FiberItem> fi; std::vector<GramJob> gj; size_t KKmax = 1; int tiles = 0;
+                for (size_t k = 0; k < m; ++k) {
+                    const size_t i = rs[k]; const int q = rq[k]; const bool second = (i & 1) != 0; const int n = nof(i); const size_t nn = (size_t)n * n;
+                    X1[k] = dalloc(s, nn * 16); Q1[k] = dalloc(s, sj[i].sd.n * esz); G2[k] = dalloc(s, nn * 16); V2[k] = dalloc(s, nn * 16);
+                    GVn[k] = dalloc(s, nn * 16); GWn[k] = dalloc(s, nn * 16);
+                    ri.push_back(Qr2RinvItem{GW[i]->p, second ? gitems[q].lam2 : gitems[q].lam1, second ? gitems[q].idx2 : gitems[q].idx1, gitems[q].info + (second ? 1 : 0), n, X1[k]->p});
+                    KKmax = std::max<size_t>(KKmax, (size_t)n);
+                }
+                const int TR = pick_TR(KKmax, esz, 1);
+                for (size_t k = 0; k < m; ++k) {
+                    const size_t i = rs[k]; const SiteJob& j = sj[i]; const int chi = j.sd.chi[j.bleg];
+                    FiberItem it{}; it.in = gauged_of[i]; it.out = Q1[k]->p; it.X = X1[k]->p;
+                    it.D = j.sd.d; it.PA = (int)(j.sd.pre(j.bleg) / j.sd.d); it.K = chi; it.PB = (int)j.sd.post(j.bleg); it.Do = j.sd.d; it.No = chi;
+                    tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb); it.tpw = 1; it.tile_begin = tiles; it.want_norm = 0;
+                    tiles += it.nta * it.ntb; fi.push_back(it);
+                    GramJob g2{}; g2.X = Q1[k]->p; g2.Y = Q1[k]->p; g2.sd = j.sd; g2.leg = j.bleg; g2.keep_site = true; gj.push_back(g2);
+                }
+                { const Qr2RinvItem* d = upload(s, ri); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_rinv(s->stream, d, (int)m); }
+                { Buf np = dalloc(s, std::max(1, tiles) * sizeof(double)); const FiberItem* d = upload(s, fi);
+                  ProfScope ps(s, TNQS_PROF_GATE_APPLY, 0, 0); launch_fiber_gemm<T>(s->stream, d, (int)m, tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); s->keepalive.push_back(np); }
+                run_grams<T, double>(s, gj, TNQS_PROF_GATE_GRAM);
+                {
+                    std::vector<ReduceItem> rd; int elems = 0;
+                    for (size_t k = 0; k < m; ++k) { const int nn = gj[k].KK * gj[k].KK; rd.push_back(ReduceItem{gj[k].partial->p, G2[k]->p, nn, gj[k].nchunks, 1, elems}); elems += nn; }
+                    const ReduceItem* d = upload(s, rd); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, d, (int)m, elems);
+                }
+                {
+                    std::vector<EnvItem> idn; std::vector<JacobiItem> ji; size_t lds = 0;
+                    for (size_t k = 0; k < m; ++k) { const int n = nof(rs[k]); idn.push_back(EnvItem{nullptr, V2[k]->p, V2[k]->p, n}); ji.push_back(JacobiItem{G2[k]->p, V2[k]->p, n, n, nullptr}); lds = std::max(lds, jacobi_lds_bytes(n, n, true, 16)); }
+                    const EnvItem* di = upload(s, idn); const JacobiItem* dj = upload(s, ji);
+                    { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)m); }
+                    { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)m, 60, jacobi_lds(lds), mmax_of(ji)); }
+                }
+                {
+                    std::vector<Qr2ComposeItem> ci;
+                    for (size_t k = 0; k < m; ++k) {
+                        const size_t i = rs[k]; const int q = rq[k]; const bool second = (i & 1) != 0; const int n = nof(i);
+                        ci.push_back(Qr2ComposeItem{G2[k]->p, V2[k]->p, X1[k]->p, GV[i]->p, second ? gitems[q].lam2 : gitems[q].lam1, second ? gitems[q].idx2 : gitems[q].idx1,
+                                                    gitems[q].info + (second ? 1 : 0), n, rank_tau(false, n), GVn[k]->p, GWn[k]->p, reinterpret_cast<int*>(d_rk->p) + k});
+                    }
+                    const Qr2ComposeItem* d = upload(s, ci); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_compose(s->stream, d, (int)m);
+                }
+                for (size_t k = 0; k < m; ++k) {
+                    const size_t i = rs[k]; GateItem& it = gitems[rq[k]];
+                    GV[i] = GVn[k]; GW[i] = GWn[k]; s->keepalive.push_back(X1[k]); s->keepalive.push_back(Q1[k]); s->keepalive.push_back(G2[k]); s->keepalive.push_back(V2[k]);
+                    if (i & 1) { it.GV2 = GV[i]->p; it.GW2 = GW[i]->p; it.chol2 = 2; it.rk2 = reinterpret_cast<int*>(d_rk->p) + k; }
+                    else { it.GV1 = GV[i]->p; it.GW1 = GW[i]->p; it.chol1 = 2; it.rk1 = reinterpret_cast<int*>(d_rk->p) + k; }
+                }
+                s->keepalive.push_back(d_rk);
+                d_gitems = upload(s, gitems);
+                // gate_theta reads the first-pass (lambda, idx, r) of the untouched partner site again and overwrites them with the same values
+                { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_theta<T>(s->stream, d_gitems, npg); }
+                if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
+                HIPCHK(hipStreamSynchronize(s->stream));
+                s->stats.n_qr2_sites += (int)m;
+            }
         }
         for (size_t i = 0; i < envs.size(); ++i)
             if (h_flags[2 * i + 1]) throw Err(TNQS_ERR_NUMERIC, "simple_update: incoming message has a negative eigenvalue above sqrt_cutoff (DomainError in the reference, src/utils.jl:21)");

@@ -876,6 +876,10 @@ __device__ void gate_eigs(const cx<double>* A, const cx<double>* V, int n, doubl
         double lmax = 0;
         for (int j = 0; j < n; ++j) lmax = fmax(lmax, lam_tmp[j]);
         int r = 0;
+        if (tau < 0) {       // shifted first pass (a second factorisation pass follows): nothing is dropped, l := max(l, 0) + |tau| l_max
+            for (int j = 0; j < n; ++j) { lam_out[j] = fmax(lam_tmp[j], 0.0) - tau * lmax; idx_out[j] = j; }
+            r = n;
+        } else
         for (int j = 0; j < n; ++j)
             if (lam_tmp[j] > tau * lmax && lam_tmp[j] > 0) { lam_out[r] = lam_tmp[j]; idx_out[r] = j; ++r; }
         *r_out = r; *s_r = r;
@@ -884,10 +888,18 @@ __device__ void gate_eigs(const cx<double>* A, const cx<double>* V, int n, doubl
 }
 
 // Cholesky site: R = L^dagger is read through the same (eigenvector, eigenvalue) interface with lambda = 1, all columns kept
-__device__ void gate_full_rank(int n, double* lam_out, int* idx_out, int* r_out, int* s_r) {
+__device__ void gate_full_rank(int n, double* lam_out, int* idx_out, int* r_out, int* s_r, const int* rk = nullptr) {
     for (int j = threadIdx.x; j < n; j += blockDim.x) { lam_out[j] = 1.0; idx_out[j] = j; }
-    if (threadIdx.x == 0) { *r_out = n; *s_r = n; }
+    if (threadIdx.x == 0) { const int r = rk ? *rk : n; *r_out = r; *s_r = r; }
     __syncthreads();
+}
+// is the kept part of the factor ill-conditioned (smallest / largest squared singular value of psi~ below 1e-4: the f64 Gram route alone leaves a relative error eps / that ratio)?  Such ComplexF64
+// sites get a second factorisation pass (engine.cpp).  Cholesky: from the pivots diag(L)^2; eigen: from the kept eigenvalues.
+__device__ int gate_ill_conditioned(int chol, const cx<double>* L, int n, const double* lam, int r) {
+    double lo = 1e300, hi = 0;
+    if (chol) for (int j = 0; j < n; ++j) { double d = L[j + (size_t)n * j].re; d *= d; lo = fmin(lo, d); hi = fmax(hi, d); }
+    else for (int j = 0; j < r; ++j) { lo = fmin(lo, lam[j]); hi = fmax(hi, lam[j]); }
+    return (hi > 0 && lo < 1e-4 * hi) ? 1 : 0;
 }
 
 template <class T>
@@ -899,8 +911,12 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
     const cx<double>* V1 = reinterpret_cast<const cx<double>*>(it.GV1);
     const cx<double>* A2 = reinterpret_cast<const cx<double>*>(it.GA2);
     const cx<double>* V2 = reinterpret_cast<const cx<double>*>(it.GV2);
-    if (it.chol1) gate_full_rank(it.n1, it.lam1, it.idx1, &it.info[0], &s_r1); else gate_eigs(A1, V1, it.n1, lam_tmp, it.lam1, it.idx1, &it.info[0], &s_r1, rank_tau(sizeof(T) == 4, it.n1));
-    if (it.chol2) gate_full_rank(it.n2, it.lam2, it.idx2, &it.info[1], &s_r2); else gate_eigs(A2, V2, it.n2, lam_tmp, it.lam2, it.idx2, &it.info[1], &s_r2, rank_tau(sizeof(T) == 4, it.n2));
+    if (it.chol1) gate_full_rank(it.n1, it.lam1, it.idx1, &it.info[0], &s_r1, it.chol1 == 2 ? it.rk1 : nullptr); else gate_eigs(A1, V1, it.n1, lam_tmp, it.lam1, it.idx1, &it.info[0], &s_r1, it.tau1);
+    if (it.chol2) gate_full_rank(it.n2, it.lam2, it.idx2, &it.info[1], &s_r2, it.chol2 == 2 ? it.rk2 : nullptr); else gate_eigs(A2, V2, it.n2, lam_tmp, it.lam2, it.idx2, &it.info[1], &s_r2, it.tau2);
+    if (threadIdx.x == 0) {
+        it.info[6] = it.chol1 == 2 ? 0 : gate_ill_conditioned(it.chol1, V1, it.n1, it.lam1, s_r1);
+        it.info[7] = it.chol2 == 2 ? 0 : gate_ill_conditioned(it.chol2, V2, it.n2, it.lam2, s_r2);
+    }
     const int r1 = s_r1, r2 = s_r2, d1 = it.d1, d2 = it.d2, chi = it.chi;
     const int Mr = r1 * d1, Nc = r2 * d2;
     const bool wide = Mr < Nc;
@@ -944,6 +960,65 @@ template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items
 }
 template void launch_gate_theta<float>(hipStream_t, const GateItem*, int);
 template void launch_gate_theta<double>(hipStream_t, const GateItem*, int);
+
+// ---- second factorisation pass (CholeskyQR2) of ill-conditioned ComplexF64 sites: kernels.hpp, Qr2RinvItem / Qr2ComposeItem ----------
+__global__ __launch_bounds__(256) void qr2_rinv_kernel(const Qr2RinvItem* __restrict__ items) {
+    const Qr2RinvItem it = items[blockIdx.x];
+    const int n = it.n, r = *it.r;
+    const cx<double>* W = reinterpret_cast<const cx<double>*>(it.GW);
+    cx<double>* X = reinterpret_cast<cx<double>*>(it.X1);
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e % n, a = e / n;
+        if (a < r) { const double sc = 1.0 / sqrt(it.lam[a]); cx<double> w = W[i + (size_t)n * it.idx[a]]; X[e] = cmake<double>(w.re * sc, w.im * sc); }
+        else X[e] = cmake<double>(0, 0);
+    }
+}
+void launch_qr2_rinv(hipStream_t s, const Qr2RinvItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(qr2_rinv_kernel, dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+__global__ __launch_bounds__(256) void qr2_compose_kernel(const Qr2ComposeItem* __restrict__ items) {
+    __shared__ double lam2[256]; __shared__ int sel[256]; __shared__ int s_r2;
+    const Qr2ComposeItem it = items[blockIdx.x];
+    const int n = it.n, r1 = *it.r1;
+    const cx<double>* A2 = reinterpret_cast<const cx<double>*>(it.A2);
+    const cx<double>* V2 = reinterpret_cast<const cx<double>*>(it.V2);
+    const cx<double>* X1 = reinterpret_cast<const cx<double>*>(it.X1);
+    const cx<double>* W1 = reinterpret_cast<const cx<double>*>(it.GV1);
+    for (int j = threadIdx.x; j < n; j += 256) {          // Rayleigh quotients, as gate_eigs
+        double l = 0;
+        for (int i = 0; i < n; ++i) { cx<double> v = V2[i + (size_t)n * j], a = A2[i + (size_t)n * j]; l += v.re * a.re + v.im * a.im; }
+        lam2[j] = l;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double lmax = 0; for (int j = 0; j < n; ++j) lmax = fmax(lmax, lam2[j]);
+        int r = 0; for (int j = 0; j < n; ++j) if (lam2[j] > it.tau * lmax && lam2[j] > 0) sel[r++] = j;
+        s_r2 = r; *it.rk = r;
+    }
+    __syncthreads();
+    const int r2 = s_r2;
+    cx<double>* GV = reinterpret_cast<cx<double>*>(it.GVout);
+    cx<double>* GW = reinterpret_cast<cx<double>*>(it.GWout);
+    // GW[:,c] = X1 V2[:,j_c] / sqrt(l2_c);   GV[:,c] = sqrt(l2_c) sum_a sqrt(l1_a) W1[:, idx1_a] V2[a, j_c]   (= conj of row c of R2 R1)
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e % n, c = e / n;
+        if (c >= r2) { GV[e] = cmake<double>(0, 0); GW[e] = cmake<double>(0, 0); continue; }
+        const int j = sel[c]; const double sq = sqrt(lam2[j]);
+        cx<double> gw = cmake<double>(0, 0), gv = cmake<double>(0, 0);
+        for (int a = 0; a < r1; ++a) {
+            const cx<double> v = V2[a + (size_t)n * j];
+            cfma(gw, X1[i + (size_t)n * a], v);
+            const double s1 = sqrt(it.lam1[a]); const cx<double> w = W1[i + (size_t)n * it.idx1[a]];
+            cfma(gv, cmake<double>(w.re * s1, w.im * s1), v);
+        }
+        GW[e] = cmake<double>(gw.re / sq, gw.im / sq); GV[e] = cmake<double>(gv.re * sq, gv.im * sq);
+    }
+}
+void launch_qr2_compose(hipStream_t s, const Qr2ComposeItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(qr2_compose_kernel, dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
 
 template <class T>
 __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __restrict__ items) {

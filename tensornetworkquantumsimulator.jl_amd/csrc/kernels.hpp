@@ -68,10 +68,24 @@ struct GateItem {         // everything the per-gate small-algebra kernels need 
     void* theta0;                   // optional second copy of theta (kept unrotated for the V recovery), may be null
     void* X1; void* X2;             // n1 x (d1 chi') , n2 x (d2 chi') in data precision (allocated for chi' <= chi_cap)
     double* S;                      // chi_cap reals
-    int* info;                      // [0]=r1 [1]=r2 [2]=chi' [3]=status [4]=svd sweeps
+    int* info;                      // [0]=r1 [1]=r2 [2]=chi' [3]=status [4]=svd sweeps [5]=wide [6],[7]=site 1 / 2 is ill-conditioned
     double* truncerr;               // one double
     int maxdim; double cutoff; int normalize; int chi_cap;
+    // per-site rank threshold of the eigen route (rank_tau; negative: shifted first pass of a site that a second factorisation pass
+    // can follow, gate_eigs); chol == 2: the site carries an
+    // explicit factor from that second pass (GV = R^dagger, GW = R^+, lambda = 1, *rk columns) -- see Qr2ComposeItem
+    double tau1, tau2; const int* rk1; const int* rk2;
 };
+// Second factorisation pass of an ill-conditioned ComplexF64 site (CholeskyQR2).  With the first-pass factor R1 (interface of
+// GateItem: R1[a,(s,b)] = sqrt(l_a) conj(GV[(s,b), idx_a]), R1^+[:,a] = GW[:, idx_a] / sqrt(l_a), r kept columns):
+//   Qr2RinvItem:    X1 = R1^+ as an explicit n x n matrix (columns >= r zero), so that Q1 = psi~ x_(s,b) X1 can be formed;
+//   Qr2ComposeItem: with the Jacobi eigen factorisation (A2 = G2 V2, V2) of G2 = Q1^dagger Q1 = W2 L2 W2^dagger, R2 = L2^1/2 W2^dagger:
+//                   GVout = (R2 R1)^dagger, GWout = R1^+ R2^+ (n x n, the first *rk columns valid), *rk = number of l2 above tau.
+struct Qr2RinvItem { const void* GW; const double* lam; const int* idx; const int* r; int n; void* X1; };
+struct Qr2ComposeItem { const void* A2; const void* V2; const void* X1; const void* GV1; const double* lam1; const int* idx1; const int* r1;
+                        int n; double tau; void* GVout; void* GWout; int* rk; };
+void launch_qr2_rinv(hipStream_t s, const Qr2RinvItem* d_items, int nitems);
+void launch_qr2_compose(hipStream_t s, const Qr2ComposeItem* d_items, int nitems);
 
 struct Site1Item { const void* in; void* out; float g[8]; size_t npairs; };   // d = 2 one-site gate: g = (g00, g01, g10, g11) re/im
 struct DiagItem { void* out; const double* S; int chi; };          // dense diag(S) message
