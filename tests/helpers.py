@@ -74,3 +74,37 @@ def htse_free_energy(mod, nsteps=25, dbeta=0.01, J=1.0, maxdim=16, dtype=np.comp
             out.append((b, (logz / len(g.vertices)).real,
                         -np.log(2) - 9 / 64 * (J * b) ** 2 - 3 / 128 * (J * b) ** 3 + 27 / 2048 * (J * b) ** 4))
     return out
+
+
+def two_site_tensor(og, a, b, ta, tb):
+    """psi_a psi_b contracted over their shared bond: [s_a, outer legs of a..., s_b, outer legs of b...] -- invariant under the gauge
+    freedom of the bond (SVD phases, rotations inside degenerate clusters)"""
+    return np.tensordot(ta, tb, axes=([og.leg(a, b)], [og.leg(b, a)]))
+
+
+def gauged_two_site(bo, a, b, T):
+    """T with sqrt(incoming message) on every outer leg: the metric in which simple update truncates (simple_update.jl:27-44).
+    `bo` is the oracle cache BEFORE the gate (its messages define the metric)."""
+    og = bo.g
+    pos = 1
+    for site, other in ((a, b), (b, a)):
+        for k in og.nbrs[site]:
+            if k == other:
+                continue
+            m = np.asarray(bo.message((k, site)), dtype=np.complex128)
+            ev, q = np.linalg.eigh((m + m.conj().T) / 2)
+            T = np.moveaxis(np.tensordot(T, (q * np.sqrt(np.clip(ev, 0, None))) @ q.conj().T, axes=([pos], [0])), -1, pos)
+            pos += 1
+        pos += 1
+    return T
+
+
+def exact_two_site(bo, a, b, gate):
+    """the untruncated gate application on the two-site tensor; gate is (d_a d_b) x (d_a d_b), first vertex most significant"""
+    ta, tb = np.asarray(bo.tns.tensors[a], dtype=np.complex128), np.asarray(bo.tns.tensors[b], dtype=np.complex128)
+    T0 = two_site_tensor(bo.g, a, b, ta, tb)
+    da, db = ta.shape[0], tb.shape[0]
+    na = ta.ndim - 1
+    T0 = np.moveaxis(T0, na, 1)                                           # [s_a, s_b, outer a..., outer b...]
+    Tex = np.tensordot(np.asarray(gate, dtype=np.complex128).reshape(da, db, da, db), T0, axes=([2, 3], [0, 1]))
+    return np.moveaxis(Tex, 1, na)

@@ -693,7 +693,7 @@ def test_ill_conditioned_c128_gate_keeps_the_oracles_subspace():
     2e-13 / 2.6e-11 when theta is perturbed by 1e-15, so the bound is taken relative to that measured spread.  A Gram-matrix factorisation
     without the second pass keeps a subspace rotated by 5 % of the truncation amplitude (4.4e-9): invisible in
     log Z after one gate, a 1e-12 cross term after two neighbouring gates, 2e-8 in the free energy after 25 layers."""
-    from helpers import oracle_cache_from_device
+    from helpers import oracle_cache_from_device, two_site_tensor, gauged_two_site, exact_two_site
     pauli = [np.array([[0, 1], [1, 0]], complex), np.array([[0, -1j], [1j, 0]]), np.diag([1.0, -1.0]).astype(complex)]
     h = 0.5 * sum(np.kron(np.kron(p, np.eye(2)), np.kron(p, np.eye(2))) for p in pauli)
     w, q = np.linalg.eigh(h); gate = (q * np.exp(-0.5 * 0.01 * w)) @ q.conj().T
@@ -714,21 +714,11 @@ def test_ill_conditioned_c128_gate_keeps_the_oracles_subspace():
         b2, e2 = tn.apply_gates([gt], bd, apply_kwargs=kw, bp_update_kwargs=bpkw, update_cache=False, info=info)
         o2, eo = o.apply_gates([gt], bo, apply_kwargs=kw, bp_update_kwargs=bpkw, update_cache=False)
         assert info["n_qr2_sites"] == 2                      # both sites went through the second pass
-        la, lb = og.leg(a, b), og.leg(b, a)
         nd = b2.network()
-        two = lambda t1, t2: np.tensordot(t1, t2, axes=([la], [lb]))          # [s_a, outer legs of a, s_b, outer legs of b]
-        def gauged(T):
-            pos = 1
-            for site, other in ((a, b), (b, a)):
-                for k in og.nbrs[site]:
-                    if k == other:
-                        continue
-                    m = bo.message((k, site)); ev, qq = np.linalg.eigh((m + m.conj().T) / 2)
-                    T = np.moveaxis(np.tensordot(T, (qq * np.sqrt(np.clip(ev, 0, None))) @ qq.conj().T, axes=([pos], [0])), -1, pos); pos += 1
-                pos += 1
-            return T
+        two = lambda x, y: two_site_tensor(og, a, b, x, y)
+        gauged = lambda T: gauged_two_site(bo, a, b, T)
         d, r = gauged(two(nd.tensors[a], nd.tensors[b])), gauged(two(o2.tns.tensors[a], o2.tns.tensors[b]))
-        e = gauged(np.einsum("xyab,apqbrs->xpqyrs", gate.reshape(4, 4, 4, 4), two(bo.tns.tensors[a], bo.tns.tensors[b])))
+        e = gauged(exact_two_site(bo, a, b, gate))
         nrm = np.linalg.norm(e)
         # the oracle's own sensitivity: theta perturbed by 1e-15 before its SVD (which vectors of a degenerate cluster survive the cut)
         spread = 0.0
@@ -749,3 +739,37 @@ def test_ill_conditioned_c128_gate_keeps_the_oracles_subspace():
         assert abs(e2[0] - eo[0]) < 1e-18 + 1e-9 * abs(eo[0])
         tight += diff < 1e-13
     assert tight >= 8                                         # the well-separated cuts agree to rounding
+
+
+@pytest.mark.parametrize("chi,maxdim", [(4, 4), (6, 4), (8, 8)])
+def test_c64_gate_subspace_is_at_least_as_good_as_the_f32_oracles(chi, maxdim):
+    """ComplexF32 (the benchmark dtype), random state on a 3x3 grid, BP-converged, one two-site gate truncated back to maxdim: the
+    gauge-invariant two-site tensor in the simple-update metric.  The oracle runs the reference's arithmetic in f32; the device
+    factorises through an f64 Gram matrix, so it must not be further from the exact (f64) gate application than the oracle is,
+    and the two agree to f32 rounding: measured 2e-7 ... 1.7e-6 relative to |T| (bound 1e-5), with truncations of 17 % ... 57 % of |T|
+    (random states).  Truncation errors agree to 1e-5 absolute (the documented c64 tolerance)."""
+    from helpers import oracle_cache_from_device, two_site_tensor, gauged_two_site, exact_two_site
+    from tnqs_oracle import resolve_gate
+    g = tn.named_grid((3, 3))
+    psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=chi, seed=11)
+    bpkw = fixed(40)
+    bd = tn.rescale(tn.update(tn.BeliefPropagationCache(psi), **bpkw))
+    bo = oracle_cache_from_device(bd); og = bo.g
+    kw = dict(maxdim=maxdim, cutoff=1e-10, normalize_tensors=False)
+    for (a, b) in [g.edges[0], g.edges[5], g.edges[len(g.edges) - 1]]:
+        for gt in (("Rzz", [a, b], 0.7), ("Rxx", [a, b], 1.1), ("CNOT", [a, b])):
+            mat = resolve_gate(gt)[0]
+            b2, e2 = tn.apply_gates([gt], bd, apply_kwargs=kw, bp_update_kwargs=bpkw, update_cache=False)
+            o2, eo = o.apply_gates([gt], bo, apply_kwargs=kw, bp_update_kwargs=bpkw, update_cache=False)
+            assert b2.bond_dim(a, b) == o2.tns.bond_dim(a, b)
+            nd = b2.network()
+            c = lambda t: np.asarray(t, dtype=np.complex128)
+            d = gauged_two_site(bo, a, b, two_site_tensor(og, a, b, c(nd.tensors[a]), c(nd.tensors[b])))
+            r = gauged_two_site(bo, a, b, two_site_tensor(og, a, b, c(o2.tns.tensors[a]), c(o2.tns.tensors[b])))
+            e = gauged_two_site(bo, a, b, exact_two_site(bo, a, b, mat))
+            nrm = np.linalg.norm(e)
+            dd, rr = np.linalg.norm(d - e) / nrm, np.linalg.norm(r - e) / nrm
+            print(f"chi {chi} maxdim {maxdim} {gt[0]:5s} {a}-{b}: |dev - exact| {dd:.4e}  |oracle(f32) - exact| {rr:.4e}  |dev - oracle| {np.linalg.norm(d - r) / nrm:.2e}")
+            assert dd <= rr + 2e-6, (gt, dd, rr)
+            assert np.linalg.norm(d - r) / nrm < 1e-5, (gt, np.linalg.norm(d - r) / nrm)
+            assert abs(e2[0] - eo[0]) < 1e-5
