@@ -20,7 +20,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib as L
-from .gates import gate_matrix, resolve_gate
+from .gates import gate_matrix, resolve_gate, resolve_gate_flat
 from .graphs import NamedGraph, edge_color as _edge_color
 
 _DT = {np.dtype(np.complex64): L.TNQS_C64, np.dtype(np.complex128): L.TNQS_C128}
@@ -315,11 +315,13 @@ def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_
         raise TypeError("apply_gates: expected a TensorNetworkState or a BeliefPropagationCache")
     g = psi.graph
     nverts, verts, mats = [], [], []
+    index = g.index
     for gate in circuit:
-        m, vs = resolve_gate(gate, g)
+        m, vs = resolve_gate_flat(gate, g)
         nverts.append(len(vs))
-        verts += [g.index[v] for v in vs]
-        mats.append(np.asarray(m, dtype=np.complex128).ravel(order="F"))
+        for v in vs:
+            verts.append(index[v])
+        mats.append(m)
     ng = len(nverts)
     nv_a, nv_p = L.i32(nverts if ng else [0])
     vs_a, vs_p = L.i32(verts if verts else [0])

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <mutex>
 #include <set>
 #include "kernels.hpp"
 #include <cstdlib>
@@ -142,12 +143,37 @@ struct HostArena {   // pinned staging for descriptor uploads, reset at host syn
     char* base = nullptr; size_t cap = 0, off = 0;
 };
 static thread_local std::unordered_map<State*, HostArena> g_arenas;
+// apply_gates has value semantics (apply_gates.jl:55): every call works on a copy of the handle, so a Trotter loop creates and destroys
+// one State per layer.  A stream and a pinned staging arena cost milliseconds to create and to release; the ones of destroyed States are
+// recycled through these small free lists instead (a State still owns its stream and arena exclusively while it lives).
+static std::mutex g_recycle_mu;
+static std::vector<HostArena> g_spare_arenas;                              // pinned, device independent
+static std::vector<std::pair<int, hipStream_t>> g_spare_streams;           // (device, idle stream)
+static const size_t kMaxSpares = 8;
+static hipStream_t acquire_stream(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_recycle_mu);
+        for (size_t i = 0; i < g_spare_streams.size(); ++i)
+            if (g_spare_streams[i].first == device) { hipStream_t st = g_spare_streams[i].second; g_spare_streams.erase(g_spare_streams.begin() + i); return st; }
+    }
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    return st;
+}
 
 State::~State() {
-    auto it = g_arenas.find(this);
-    if (it != g_arenas.end()) { if (it->second.base) (void)hipHostFree(it->second.base); g_arenas.erase(it); }
+    if (own_stream && stream) (void)hipStreamSynchronize(stream);           // nothing of this State is in flight past this point
     keepalive.clear(); site.clear(); msg.clear();
-    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    auto it = g_arenas.find(this);
+    HostArena ar{}; if (it != g_arenas.end()) { ar = it->second; g_arenas.erase(it); }
+    hipStream_t st = (own_stream && stream) ? stream : nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_recycle_mu);
+        if (ar.base && g_spare_arenas.size() < kMaxSpares) { ar.off = 0; g_spare_arenas.push_back(ar); ar.base = nullptr; }
+        if (st && g_spare_streams.size() < kMaxSpares) { g_spare_streams.push_back({device, st}); st = nullptr; }
+    }
+    if (ar.base) (void)hipHostFree(ar.base);
+    if (st) (void)hipStreamDestroy(st);
 }
 
 static void sync(State* s) {
@@ -161,7 +187,10 @@ template <class Item> static const Item* upload(State* s, const std::vector<Item
     if (v.empty()) return nullptr;
     size_t bytes = v.size() * sizeof(Item);
     HostArena& ar = g_arenas[s];
-    if (!ar.base) { ar.cap = size_t(32) << 20; HIPCHK(hipHostMalloc((void**)&ar.base, ar.cap, hipHostMallocDefault)); }
+    if (!ar.base) {
+        { std::lock_guard<std::mutex> lk(g_recycle_mu); if (!g_spare_arenas.empty()) { ar = g_spare_arenas.back(); g_spare_arenas.pop_back(); ar.off = 0; } }
+        if (!ar.base) { ar.cap = size_t(32) << 20; HIPCHK(hipHostMalloc((void**)&ar.base, ar.cap, hipHostMallocDefault)); }
+    }
     size_t aligned = (bytes + 255) & ~size_t(255);
     if (aligned > ar.cap) throw Err(TNQS_ERR_UNSUPPORTED, "descriptor batch too large");
     if (ar.off + aligned > ar.cap) sync(s);
@@ -239,7 +268,7 @@ State* state_create(int nv, int ne, const int32_t* es, const int32_t* ed, const 
     s->site.resize(nv); s->sscale.assign(nv, nullptr); s->msg.assign(2 * (size_t)ne, nullptr);
     s->pool = std::make_shared<Pool>(device);
     s->prof = std::make_shared<Prof>();
-    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true;
+    s->stream = acquire_stream(device); s->own_stream = true;
     for (int v = 0; v < nv; ++v) { if (dtype == TNQS_C64) fill_product_up<float>(s.get(), v); else fill_product_up<double>(s.get(), v); }
     return s.release();
 }
@@ -251,7 +280,7 @@ State* state_copy(const State* o) {
     s->rank = o->rank; s->nranks = o->nranks; s->owner = o->owner; s->ag_fn = o->ag_fn; s->ag_ctx = o->ag_ctx;
     s->exch = o->exch; s->exch_bytes = o->exch_bytes;
     HIPCHK(hipSetDevice(o->device));
-    if (o->own_stream) { HIPCHK(hipStreamSynchronize(o->stream)); HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
+    if (o->own_stream) { HIPCHK(hipStreamSynchronize(o->stream)); s->stream = acquire_stream(o->device); s->own_stream = true; }
     else { s->stream = o->stream; s->own_stream = false; }
     return s.release();
 }

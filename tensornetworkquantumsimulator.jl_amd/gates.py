@@ -137,34 +137,60 @@ def unregister_gate(name: str):
     return name
 
 
-def gate_matrix(name, *params) -> np.ndarray:
-    """name -> complex128 matrix (toitensor :118-153)"""
-    if isinstance(name, np.ndarray):
-        return np.asarray(name, dtype=complex)
-    if len(name) > 1 and all(c in "XYZxyz" for c in name):          # Pauli-string sugar (:123-128)
+# (name, params) -> (GateSpec it was built from, matrix, its column-major flattening); a layer of a circuit repeats a handful of
+# distinct gates a thousand times, and building each matrix costs an eigendecomposition.  Entries are read-only arrays and are
+# only reused while the registry still maps the name to the same GateSpec object (GATES / ALIASES are public dicts).
+_MATRIX_CACHE: Dict[tuple, tuple] = {}
+_PAULI_STRING = object()
+
+
+def _cached_gate(name: str, params: tuple):
+    if len(params) == 1 and isinstance(params[0], (tuple, list)):
+        params = tuple(params[0])
+    key = (name, params)
+    try:
+        hit = _MATRIX_CACHE.get(key)
+    except TypeError:                 # unhashable parameter (e.g. an array): not cached
+        key, hit = None, None
+    pauli = len(name) > 1 and all(c in "XYZxyz" for c in name)          # Pauli-string sugar (:123-128)
+    spec = _PAULI_STRING if pauli else _resolve(name)
+    if hit is not None and hit[0] is spec:
+        return hit
+    if pauli:
         m = np.ones((1, 1), dtype=complex)
         for c in name:
             m = np.kron(m, _PAULI[c.upper()])
-        return m
-    spec = _resolve(name)
-    if spec is None:
-        sug = _suggestions(name)
-        msg = f'Unknown gate "{name}".'
-        msg += (" Did you mean: " + ", ".join(f'"{s}"' for s in sug) + "?") if sug else f" Registered gates: {sorted(GATES)}."
-        raise ValueError(msg)
-    if spec.nparams == 0:
-        return np.asarray(spec.fn(), dtype=complex)
-    if len(params) == 1 and isinstance(params[0], (tuple, list)):
-        params = tuple(params[0])
-    if len(params) != spec.nparams:
-        raise ValueError(f'Gate "{name}" expects {spec.nparams} parameter(s), got {len(params)}.')
-    scaled = spec.rescale(*params)
-    return np.asarray(spec.fn(*scaled), dtype=complex)
+    else:
+        if spec is None:
+            sug = _suggestions(name)
+            msg = f'Unknown gate "{name}".'
+            msg += (" Did you mean: " + ", ".join(f'"{s}"' for s in sug) + "?") if sug else f" Registered gates: {sorted(GATES)}."
+            raise ValueError(msg)
+        if spec.nparams == 0:
+            m = np.array(spec.fn(), dtype=complex)
+        else:
+            if len(params) != spec.nparams:
+                raise ValueError(f'Gate "{name}" expects {spec.nparams} parameter(s), got {len(params)}.')
+            m = np.array(spec.fn(*spec.rescale(*params)), dtype=complex)
+    flat = np.ascontiguousarray(m.ravel(order="F"))
+    m.flags.writeable = False; flat.flags.writeable = False
+    entry = (spec, m, flat)
+    if key is not None:
+        if len(_MATRIX_CACHE) >= 4096:
+            _MATRIX_CACHE.clear()
+        _MATRIX_CACHE[key] = entry
+    return entry
 
 
-def resolve_gate(gate, graph) -> Tuple[np.ndarray, list]:
-    """circuit tuple -> (matrix, [vertices]) with collect_vertices semantics (src/utils.jl:137-160)"""
-    name, verts = gate[0], gate[1]
+def gate_matrix(name, *params) -> np.ndarray:
+    """name -> complex128 matrix (toitensor :118-153).  The returned array is shared and read-only; copy it before modifying."""
+    if isinstance(name, np.ndarray):
+        return np.asarray(name, dtype=complex)
+    return _cached_gate(name, params)[1]
+
+
+def _verts_of(gate, graph) -> list:
+    verts = gate[1]
     if not isinstance(verts, (list,)):
         verts = [verts] if verts in graph.index else list(verts)
     verts = list(verts)
@@ -173,4 +199,18 @@ def resolve_gate(gate, graph) -> Tuple[np.ndarray, list]:
             raise RuntimeError("Vertex does not match the vertex type of the tensor network")
     if len(set(verts)) != len(verts):
         raise RuntimeError("Repeated vertex in collection")
-    return gate_matrix(name, *gate[2:]), verts
+    return verts
+
+
+def resolve_gate_flat(gate, graph) -> Tuple[np.ndarray, list]:
+    """circuit tuple -> (column-major flattened complex128 matrix, [vertices]): what tnqs_apply_gates takes"""
+    name = gate[0]
+    verts = _verts_of(gate, graph)
+    if isinstance(name, np.ndarray):
+        return np.asarray(name, dtype=np.complex128).ravel(order="F"), verts
+    return _cached_gate(name, tuple(gate[2:]))[2], verts
+
+
+def resolve_gate(gate, graph) -> Tuple[np.ndarray, list]:
+    """circuit tuple -> (matrix, [vertices]) with collect_vertices semantics (src/utils.jl:137-160)"""
+    return gate_matrix(gate[0], *gate[2:]), _verts_of(gate, graph)

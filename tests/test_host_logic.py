@@ -68,3 +68,35 @@ def test_gate_registry_behaviour():
     assert np.allclose(tn.gate_matrix("rzz", 0.3), tn.gate_matrix("Rzz", 0.3))
     assert np.allclose(tn.gate_matrix("cp", 0.3), tn.gate_matrix("CPHASE", 0.3))
     assert np.allclose(tn.gate_matrix("XZ"), np.kron(tn.gate_matrix("X"), tn.gate_matrix("Z")))
+
+
+def test_gate_matrix_cache_follows_the_registry():
+    """gate matrices are memoised per (name, params) (a layer repeats two distinct gates 1160 times); the cache must never serve a
+    matrix of a gate that was re-registered, unregistered, aliased away or replaced directly in the public GATES dict"""
+    a = tn.gate_matrix("Rzz", 0.3)
+    assert tn.gate_matrix("Rzz", 0.3) is a and not a.flags.writeable
+    assert tn.gate_matrix("Rzz", 0.31) is not a
+    assert np.allclose(tn.gate_matrix("Rzz", 0.3), o.gate_matrix("Rzz", 0.3))
+    assert tn.gate_matrix("Rzz", (0.3,)) is a                                    # tuple-wrapped parameter (:137-139)
+    tn.register_gate("MyPhase", lambda t: np.diag([1.0, np.exp(1j * t)]), nparams=1)
+    try:
+        m1 = tn.gate_matrix("MyPhase", 0.5)
+        assert np.allclose(m1, np.diag([1.0, np.exp(0.5j)]))
+        tn.unregister_gate("MyPhase")
+        with pytest.raises(ValueError):
+            tn.gate_matrix("MyPhase", 0.5)
+        tn.register_gate("MyPhase", lambda t: np.diag([np.exp(-1j * t), 1.0]), nparams=1)
+        assert np.allclose(tn.gate_matrix("MyPhase", 0.5), np.diag([np.exp(-0.5j), 1.0]))
+        spec = tn.GATES["MyPhase"]
+        tn.GATES["MyPhase"] = type(spec)(lambda t: np.eye(2) * t, 1)                 # replaced behind the registry's back
+        assert np.allclose(tn.gate_matrix("MyPhase", 0.5), 0.5 * np.eye(2))
+        tn.register_alias("Ph", "MyPhase")
+        assert np.allclose(tn.gate_matrix("Ph", 2.0), 2.0 * np.eye(2))
+    finally:
+        tn.unregister_gate("MyPhase")
+    with pytest.raises(ValueError):
+        tn.gate_matrix("Ph", 2.0)
+    assert np.allclose(tn.gate_matrix("XZ"), np.kron(o.gate_matrix("X"), o.gate_matrix("Z")))      # Pauli-string sugar is cached too
+    assert tn.gate_matrix("XZ") is tn.gate_matrix("XZ")
+    with pytest.raises(ValueError):
+        tn.gate_matrix("Rzz")                                                    # wrong parameter count still raises
