@@ -71,6 +71,8 @@ typedef struct {
     double last_bp_diff;
     int n_chol_fallbacks;   /* gate batches whose Gram matrices were numerically rank-deficient (eigen path instead of Cholesky) */
     int n_qr2_sites;        /* ComplexF64 sites that went through the second factorisation pass (ill-conditioned psi~) */
+    int n_lowrank_svd;      /* two-site gates whose theta SVD ran on the low-rank factor (gate of operator Schmidt rank kappa, kappa chi < d chi) */
+    int reserved_;
 } tnqs_apply_stats;
 
 /* ---- library ---------------------------------------------------------------------------------------- */

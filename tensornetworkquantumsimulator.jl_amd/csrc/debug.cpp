@@ -29,7 +29,7 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
     size_t lds = nov ? lds_a : (lds_av <= lim ? lds_av : 0);
     if (dtype == TNQS_C64) launch_jacobi<float>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n)); else launch_jacobi<double>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n));
     if (nov) {
-        DBuf dRv(sizeof(RecoverItem)); RecoverItem rv{dA0.p, dA.p, dV.p, m, n}; dRv.up(&rv, sizeof(rv));
+        DBuf dRv(sizeof(RecoverItem)); RecoverItem rv{dA0.p, dA.p, dV.p, m, n, n}; dRv.up(&rv, sizeof(rv));
         if (dtype == TNQS_C64) launch_recover_v_mfma(nullptr, (const RecoverItem*)dRv.p, 1, n); else launch_recover_v<double>(nullptr, (const RecoverItem*)dRv.p, 1, n);
         HIPCHK(hipDeviceSynchronize());
     }

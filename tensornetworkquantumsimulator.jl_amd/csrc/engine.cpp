@@ -8,6 +8,7 @@
 #include <array>
 #include <climits>
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <numeric>
 #include <mutex>
@@ -23,6 +24,7 @@ static size_t jacobi_lds(size_t bytes) { static int g = -1; if (g < 0) { const c
 static int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j : ji) m = std::max(m, std::max(j.m, j.n)); return m; }
 static bool use_chol() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_CHOL"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_qr2() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_QR2"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
+static bool use_lowrank() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_LOWRANK"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_small_svd() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_SMALLSVD"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_apply64() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_APPLY64"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 // optional host-side phase timing (TNQS_HOST_TIMING=1): printed when the process exits
@@ -1229,7 +1231,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     };
     factor_G(use_chol());
     // ---- 4. theta = gate . (R1 R2), SVD, truncation, X1 / X2  (simple_update.jl:51-59) -----------------------------
-    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S; int n1, n2, chi, cap; };
+    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S, lowA, lowB, lowG, lowL, lowW; int n1, n2, chi, cap; };
     std::vector<GateWS> ws(ng);
     std::vector<int> pg;                              // gates this rank takes part in
     for (int gi = 0; gi < ng; ++gi) if (part[gi]) pg.push_back(gi);
@@ -1251,13 +1253,41 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     const bool theta0_used = true;
     {
         std::vector<char> raw;
-        std::vector<size_t> off(pg.size());
+        std::vector<size_t> off(pg.size()), offA(pg.size(), 0), offB(pg.size(), 0); std::vector<int> kappa(pg.size(), 0);
+        const bool lowrank_on = std::is_same<T, float>::value && use_lowrank();
         for (size_t q = 0; q < pg.size(); ++q) {
             int gi = pg[q];
-            int dd = s->d[gates[gi].v1] * s->d[gates[gi].v2];
+            const int d1 = s->d[gates[gi].v1], d2 = s->d[gates[gi].v2];
+            int dd = d1 * d2;
             off[q] = raw.size();
             const char* p = reinterpret_cast<const char*>(gates[gi].mat);
             raw.insert(raw.end(), p, p + (size_t)dd * dd * 16);
+            if (!lowrank_on) continue;
+            // the gate as an operator sum g = sum_k a_k (x) b_k: O[(s1',s1),(s2',s2)] = g[(s1' s2'),(s1 s2)] factorised by elimination with
+            // complete pivoting (exact rank factorisation; kappa = operator Schmidt rank: 2 for Rzz / Rxx / CNOT / CPHASE, 4 for SWAP)
+            const int na = d1 * d1, nb = d2 * d2;
+            std::vector<std::complex<double>> O((size_t)na * nb), fa, fb;
+            const std::complex<double>* gm = reinterpret_cast<const std::complex<double>*>(gates[gi].mat);
+            double amax = 0;
+            for (int s1p = 0; s1p < d1; ++s1p) for (int s1 = 0; s1 < d1; ++s1) for (int s2p = 0; s2p < d2; ++s2p) for (int s2 = 0; s2 < d2; ++s2) {
+                auto v = gm[(s1p * d2 + s2p) + (size_t)dd * (s1 * d2 + s2)];
+                O[(s1p + d1 * s1) + (size_t)na * (s2p + d2 * s2)] = v; amax = std::max(amax, std::abs(v));
+            }
+            int kp = 0;
+            for (; kp < std::min(na, nb); ++kp) {
+                int pi = 0, pj = 0; double best = 0;
+                for (int j = 0; j < nb; ++j) for (int i = 0; i < na; ++i) { double a = std::abs(O[i + (size_t)na * j]); if (a > best) { best = a; pi = i; pj = j; } }
+                if (!(best > 1e-13 * amax)) break;
+                const std::complex<double> piv = O[pi + (size_t)na * pj];
+                std::vector<std::complex<double>> col(na), row(nb);
+                for (int i = 0; i < na; ++i) col[i] = O[i + (size_t)na * pj];
+                for (int j = 0; j < nb; ++j) row[j] = O[pi + (size_t)na * j] / piv;
+                for (int j = 0; j < nb; ++j) for (int i = 0; i < na; ++i) O[i + (size_t)na * j] -= col[i] * row[j];
+                fa.insert(fa.end(), col.begin(), col.end()); fb.insert(fb.end(), row.begin(), row.end());
+            }
+            kappa[q] = kp;
+            offA[q] = raw.size(); raw.insert(raw.end(), reinterpret_cast<const char*>(fa.data()), reinterpret_cast<const char*>(fa.data()) + fa.size() * 16);
+            offB[q] = raw.size(); raw.insert(raw.end(), reinterpret_cast<const char*>(fb.data()), reinterpret_cast<const char*>(fb.data()) + fb.size() * 16);
         }
         const char* d_gm = pg.empty() ? nullptr : upload(s, raw);
         for (size_t q = 0; q < pg.size(); ++q) {
@@ -1274,6 +1304,16 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             it.GW1 = GW[2 * gi]->p; it.GW2 = GW[2 * gi + 1]->p; it.chol1 = is_chol[2 * gi]; it.chol2 = is_chol[2 * gi + 1];
             it.n1 = w.n1; it.n2 = w.n2; it.d1 = a.sd.d; it.d2 = b.sd.d; it.chi = w.chi;
             it.gate = reinterpret_cast<const double*>(d_gm + off[q]);
+            it.kappa = 0; it.opA = it.opB = nullptr; it.lowA = it.lowB = it.lowG = nullptr; it.lowL = nullptr; it.lowfail = nullptr;
+            {   // low-rank route of the theta SVD (GateItem): only where it can apply -- K = kappa chi below the theta columns and chol_kernel's size
+                const int K = kappa[q] * w.chi;
+                if (lowrank_on && kappa[q] > 0 && K < Nc && K <= 96 && cap <= K && Mr >= Nc) {
+                    w.lowA = dalloc(s, (size_t)Mr * K * 16); w.lowB = dalloc(s, (size_t)Nc * K * 16); w.lowG = dalloc(s, (size_t)K * K * 16);
+                    w.lowL = dalloc(s, (size_t)K * K * 16); w.lowW = dalloc(s, (size_t)K * K * 16);
+                    it.kappa = kappa[q]; it.opA = reinterpret_cast<const double*>(d_gm + offA[q]); it.opB = reinterpret_cast<const double*>(d_gm + offB[q]);
+                    it.lowA = w.lowA->p; it.lowB = w.lowB->p; it.lowG = w.lowG->p; it.lowL = w.lowL->p;
+                }
+            }
             it.lam1 = (double*)w.lam1->p; it.lam2 = (double*)w.lam2->p; it.idx1 = (int*)w.idx1->p; it.idx2 = (int*)w.idx2->p;
             it.theta = w.theta->p; it.thetaV = w.thetaV->p; it.theta0 = w.theta0 ? w.theta0->p : nullptr; it.X1 = w.X1->p; it.X2 = w.X2->p; it.S = (double*)w.S->p;
             it.maxdim = ao.maxdim; it.cutoff = ao.cutoff; it.normalize = ao.normalize_tensors; it.chi_cap = cap;
@@ -1290,8 +1330,25 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     Buf d_terr_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 8));
     HIPCHK(hipMemsetAsync(d_info_all->p, 0, std::max<size_t>(1, (size_t)npg * 32), s->stream));
     for (int q = 0; q < npg; ++q) { gitems[q].info = reinterpret_cast<int*>(d_info_all->p) + 8 * q; gitems[q].truncerr = reinterpret_cast<double*>(d_terr_all->p) + q; }
+    // low-rank route: one failure flag per gate for the Cholesky factorisation of B^dagger B
+    Buf d_lowfail = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));
+    for (int q = 0; q < npg; ++q) gitems[q].lowfail = reinterpret_cast<const int*>(d_lowfail->p) + q;
     const GateItem* d_gitems = upload(s, gitems);
-    { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_theta<T>(s->stream, d_gitems, npg); }
+    auto run_theta = [&]() {
+        HIPCHK(hipMemsetAsync(d_info_all->p, 0, std::max<size_t>(1, (size_t)npg * 32), s->stream));
+        HIPCHK(hipMemsetAsync(d_lowfail->p, 0, std::max<size_t>(1, (size_t)npg * sizeof(int)), s->stream));
+        ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
+        launch_gate_theta<T>(s->stream, d_gitems, npg);
+        std::vector<CholItem> lc; int kmax = 1;
+        for (int q = 0; q < npg; ++q) {
+            if (!gitems[q].lowG) continue;
+            const int K = gitems[q].kappa * gitems[q].chi;
+            lc.push_back(CholItem{gitems[q].lowG, const_cast<void*>(gitems[q].lowL), ws[pg[q]].lowW->p, K, reinterpret_cast<int*>(d_lowfail->p) + q, rank_tau(true, K)});
+            kmax = std::max(kmax, K);
+        }
+        if (!lc.empty()) { const CholItem* dc = upload(s, lc); launch_chol(s->stream, dc, (int)lc.size(), kmax); launch_lowrank_m(s->stream, d_gitems, npg); }
+    };
+    run_theta();
     std::vector<int> info(8 * (size_t)ng, 0); std::vector<double> terr(ng, 0.0);
     {
         // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
@@ -1305,8 +1362,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             factor_G(false);
             for (int q = 0; q < npg; ++q) { int gi = pg[q]; GateItem& it = gitems[q]; it.GW1 = GW[2 * gi]->p; it.GW2 = GW[2 * gi + 1]->p; it.chol1 = 0; it.chol2 = 0; }
             d_gitems = upload(s, gitems);
-            HIPCHK(hipMemsetAsync(d_info_all->p, 0, std::max<size_t>(1, (size_t)npg * 32), s->stream));
-            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_theta<T>(s->stream, d_gitems, npg); }
+            run_theta();
             if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipStreamSynchronize(s->stream));
             s->stats.n_chol_fallbacks += 1;
@@ -1320,7 +1376,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             for (int q = 0; q < npg; ++q) for (int side = 0; side < 2; ++side) {
                 const size_t i = 2 * (size_t)pg[q] + side;
                 static const bool all = [] { const char* v = std::getenv("TNQS_QR2_ALL"); return v && v[0] == '1'; }();      // debug: refine every site
-                if ((all || hinfo[8 * q + 6 + side]) && !is_small[i] && sj[i].owned) { rs.push_back(i); rq.push_back(q); }
+                if ((all || ((hinfo[8 * q + 6] >> side) & 1)) && !is_small[i] && sj[i].owned) { rs.push_back(i); rq.push_back(q); }
             }
             if (!rs.empty()) {
                 const size_t m = rs.size();
@@ -1376,7 +1432,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                 s->keepalive.push_back(d_rk);
                 d_gitems = upload(s, gitems);
                 // gate_theta reads the first-pass (lambda, idx, r) of the untouched partner site again and overwrites them with the same values
-                { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_theta<T>(s->stream, d_gitems, npg); }
+                run_theta();
                 if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
                 HIPCHK(hipStreamSynchronize(s->stream));
                 s->stats.n_qr2_sites += (int)m;
@@ -1384,13 +1440,15 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         }
         for (size_t i = 0; i < envs.size(); ++i)
             if (h_flags[2 * i + 1]) throw Err(TNQS_ERR_NUMERIC, "simple_update: incoming message has a negative eigenvalue above sqrt_cutoff (DomainError in the reference, src/utils.jl:21)");
-        std::vector<JacobiItem> ji;
+        std::vector<JacobiItem> ji; std::vector<int> ncfull;
         for (int q = 0; q < npg; ++q) {
             int gi = pg[q];
             int r1 = hinfo[8 * q], r2 = hinfo[8 * q + 1];
             int Mr = r1 * gitems[q].d1, Nc = r2 * gitems[q].d2;
             if (Mr < Nc) std::swap(Mr, Nc);        // wide theta is stored as its adjoint (gate_theta_kernel)
-            ji.push_back(JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, gitems[q].info + 4});
+            const int ncolJ = hinfo[8 * q + 7] > 0 ? hinfo[8 * q + 7] : Nc;      // low-rank route: the SVD runs on M (Mr x K), same U and Sigma
+            ji.push_back(JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, ncolJ, gitems[q].info + 4});
+            ncfull.push_back(Nc); s->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0;
         }
         // LDS residency: A and V if both fit; A only (V recovered from the unrotated copy) if only A fits; else global memory
         size_t lds_av = 0, lds_a = 0;
@@ -1401,9 +1459,9 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<T>(s->stream, dj, npg, 60, jacobi_lds(novee ? lds_a : lds_av), mmax_of(ji)); }
         if (novee) {
             std::vector<RecoverItem> rv;
-            for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ji[q].n});
+            for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ncfull[q], ji[q].n});
             const RecoverItem* dr = upload(s, rv);
-            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); { int nmax = 1; for (auto& j : ji) nmax = std::max(nmax, j.n); if (std::is_same<T, float>::value && use_mfma()) launch_recover_v_mfma(s->stream, dr, npg, nmax); else launch_recover_v<T>(s->stream, dr, npg, nmax); } }
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); { int nmax = 1; for (int nc : ncfull) nmax = std::max(nmax, nc); if (std::is_same<T, float>::value && use_mfma()) launch_recover_v_mfma(s->stream, dr, npg, nmax); else launch_recover_v<T>(s->stream, dr, npg, nmax); } }
         }
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
         std::vector<double> hterr(std::max(1, npg));
@@ -1900,7 +1958,7 @@ template <class T> static void symmetric_gauge_t(State* s, double regularization
         items.push_back(SymGaugeItem{H[2 * e]->p, V[2 * e]->p, H[2 * e + 1]->p, V[2 * e + 1]->p, w.rx->p, w.ry->p, w.irx->p, w.iry->p,
                                      w.Ce->p, w.Ce0->p, w.Vs->p, w.Xs->p, w.Xd->p, reinterpret_cast<double*>(w.S->p), n, reg, reinterpret_cast<int*>(d_flag->p)});
         sj.push_back(JacobiItem{w.Ce->p, nullptr, n, n, nullptr});
-        rv.push_back(RecoverItem{w.Ce0->p, w.Ce->p, w.Vs->p, n, n}); nmax = std::max(nmax, n);
+        rv.push_back(RecoverItem{w.Ce0->p, w.Ce->p, w.Vs->p, n, n, n}); nmax = std::max(nmax, n);
     }
     const SymGaugeItem* d_items = upload(s, items);
     launch_symg_build<T>(s->stream, d_items, (int)items.size());

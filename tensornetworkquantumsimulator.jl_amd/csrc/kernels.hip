@@ -599,7 +599,7 @@ __global__ __launch_bounds__(512) void recover_v_kernel(const RecoverItem* __res
     const int m = it.m, n = it.n;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int u = blockIdx.y * 8 + w;
-    if (u >= n) return;
+    if (u >= it.nu) return;
     double are[R], aim[R], s2 = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -914,8 +914,9 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
     if (it.chol1) gate_full_rank(it.n1, it.lam1, it.idx1, &it.info[0], &s_r1, it.chol1 == 2 ? it.rk1 : nullptr); else gate_eigs(A1, V1, it.n1, lam_tmp, it.lam1, it.idx1, &it.info[0], &s_r1, it.tau1);
     if (it.chol2) gate_full_rank(it.n2, it.lam2, it.idx2, &it.info[1], &s_r2, it.chol2 == 2 ? it.rk2 : nullptr); else gate_eigs(A2, V2, it.n2, lam_tmp, it.lam2, it.idx2, &it.info[1], &s_r2, it.tau2);
     if (threadIdx.x == 0) {
-        it.info[6] = it.chol1 == 2 ? 0 : gate_ill_conditioned(it.chol1, V1, it.n1, it.lam1, s_r1);
-        it.info[7] = it.chol2 == 2 ? 0 : gate_ill_conditioned(it.chol2, V2, it.n2, it.lam2, s_r2);
+        it.info[6] = (it.chol1 == 2 ? 0 : gate_ill_conditioned(it.chol1, V1, it.n1, it.lam1, s_r1))
+                   | ((it.chol2 == 2 ? 0 : gate_ill_conditioned(it.chol2, V2, it.n2, it.lam2, s_r2)) << 1);
+        it.info[7] = 0;
     }
     const int r1 = s_r1, r2 = s_r2, d1 = it.d1, d2 = it.d2, chi = it.chi;
     const int Mr = r1 * d1, Nc = r2 * d2;
@@ -953,6 +954,67 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
     const int nI = wide ? Mr : Nc;
     for (int e = threadIdx.x; e < nI * nI; e += blockDim.x) tv[e] = cmake<T>((e % nI) == (e / nI) ? (T)1 : (T)0, (T)0);
     if (threadIdx.x == 0) it.info[5] = wide ? 1 : 0;
+    // low-rank route (GateItem): A[(a,s1'),(k,b)] = sum_s1 a_k[s1',s1] R1[a,(s1,b)],  B[(c,s2'),(k,b)] = sum_s2 b_k[s2',s2] R2[c,(s2,b)],  G = B^dagger B
+    const int K = it.kappa * chi;
+    if (sizeof(T) == 4 && it.kappa > 0 && it.lowG && !wide && K < Nc && it.chi_cap <= K) {
+        cx<double>* LA = reinterpret_cast<cx<double>*>(it.lowA);
+        cx<double>* LB = reinterpret_cast<cx<double>*>(it.lowB);
+        cx<double>* LG = reinterpret_cast<cx<double>*>(it.lowG);
+        const cx<double>* oa = reinterpret_cast<const cx<double>*>(it.opA);
+        const cx<double>* ob = reinterpret_cast<const cx<double>*>(it.opB);
+        for (int e = threadIdx.x; e < Mr * K; e += blockDim.x) {
+            const int row = e % Mr, l = e / Mr, a = row % r1, s1p = row / r1, b = l % chi, k = l / chi;
+            const cx<double>* w1 = V1 + (size_t)it.n1 * it.idx1[a];
+            cx<double> acc = cmake<double>(0, 0);
+            for (int s1 = 0; s1 < d1; ++s1) { cx<double> x = w1[s1 + d1 * b]; cfma(acc, oa[k * d1 * d1 + s1p + d1 * s1], cmake<double>(x.re, -x.im)); }
+            const double sc = sqrt(it.lam1[a]);
+            LA[e] = cmake<double>(acc.re * sc, acc.im * sc);
+        }
+        for (int e = threadIdx.x; e < Nc * K; e += blockDim.x) {
+            const int row = e % Nc, l = e / Nc, c = row % r2, s2p = row / r2, b = l % chi, k = l / chi;
+            const cx<double>* w2 = V2 + (size_t)it.n2 * it.idx2[c];
+            cx<double> acc = cmake<double>(0, 0);
+            for (int s2 = 0; s2 < d2; ++s2) { cx<double> y = w2[s2 + d2 * b]; cfma(acc, ob[k * d2 * d2 + s2p + d2 * s2], cmake<double>(y.re, -y.im)); }
+            const double sc = sqrt(it.lam2[c]);
+            LB[e] = cmake<double>(acc.re * sc, acc.im * sc);
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int e = threadIdx.x; e < K * K; e += blockDim.x) {            // G[i,j] = sum_row conj(B[row,i]) B[row,j]
+            const int i = e % K, j = e / K;
+            if (i > j) continue;
+            cx<double> acc = cmake<double>(0, 0);
+            const cx<double>* bi = LB + (size_t)Nc * i; const cx<double>* bj = LB + (size_t)Nc * j;
+            for (int row = 0; row < Nc; ++row) cfma_conj(acc, bj[row], bi[row]);
+            LG[i + (size_t)K * j] = acc; if (i != j) LG[j + (size_t)K * i] = cmake<double>(acc.re, -acc.im);
+        }
+        if (threadIdx.x == 0) it.info[7] = K;
+    } else if (it.lowG && it.kappa > 0) {      // not taken: give chol_kernel a harmless identity
+        cx<double>* LG = reinterpret_cast<cx<double>*>(it.lowG);
+        for (int e = threadIdx.x; e < K * K; e += blockDim.x) LG[e] = cmake<double>((e % K) == (e / K) ? 1.0 : 0.0, 0.0);
+    }
+}
+// theta[:, 0..K) := M = A conj(L) where G = L L^dagger (chol_kernel); on a collapsed pivot the full theta (already in place) stays
+template <class T>
+__global__ __launch_bounds__(1024) void lowrank_m_kernel(const GateItem* __restrict__ items) {
+    const GateItem it = items[blockIdx.x];
+    const int K = it.info[7];
+    if (K <= 0) return;
+    if (*it.lowfail) { if (threadIdx.x == 0) it.info[7] = 0; return; }
+    const int Mr = it.info[0] * it.d1;
+    const cx<double>* LA = reinterpret_cast<const cx<double>*>(it.lowA);
+    const cx<double>* L = reinterpret_cast<const cx<double>*>(it.lowL);
+    cx<T>* th = reinterpret_cast<cx<T>*>(it.theta);
+    for (int e = threadIdx.x; e < Mr * K; e += blockDim.x) {
+        const int i = e % Mr, j = e / Mr;
+        cx<double> acc = cmake<double>(0, 0);
+        for (int l = j; l < K; ++l) cfma_conj(acc, LA[i + (size_t)Mr * l], L[l + (size_t)K * j]);      // A[i,l] conj(L[l,j]), L lower triangular
+        th[e] = cmake<T>((T)acc.re, (T)acc.im);
+    }
+}
+void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((lowrank_m_kernel<float>), dim3(nitems), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
@@ -1032,9 +1094,10 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
     const int ncol = wide ? Mr : Nc, ld = wide ? Nc : Mr;
     const cx<T>* th = reinterpret_cast<const cx<T>*>(it.theta);      // rotated columns: U Sigma (or V Sigma when wide)
     const cx<T>* tv = reinterpret_cast<const cx<T>*>(it.thetaV);     // accumulated rotations: V (or U when wide)
+    const int ncolK = (!wide && it.info[7] > 0) ? it.info[7] : ncol;        // low-rank route: the remaining singular values are zero
     for (int u = threadIdx.x; u < ncol; u += blockDim.x) {
         double s2 = 0;
-        for (int i = 0; i < ld; ++i) { cx<T> v = th[i + (size_t)ld * u]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
+        if (u < ncolK) for (int i = 0; i < ld; ++i) { cx<T> v = th[i + (size_t)ld * u]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
         sig[u] = (s2 == s2 && s2 < 1e300) ? sqrt(s2) : 0.0;     // a NaN / inf column must not poison the ranking below
     }
     __syncthreads();

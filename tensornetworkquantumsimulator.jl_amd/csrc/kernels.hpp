@@ -68,14 +68,21 @@ struct GateItem {         // everything the per-gate small-algebra kernels need 
     void* theta0;                   // optional second copy of theta (kept unrotated for the V recovery), may be null
     void* X1; void* X2;             // n1 x (d1 chi') , n2 x (d2 chi') in data precision (allocated for chi' <= chi_cap)
     double* S;                      // chi_cap reals
-    int* info;                      // [0]=r1 [1]=r2 [2]=chi' [3]=status [4]=svd sweeps [5]=wide [6],[7]=site 1 / 2 is ill-conditioned
+    int* info;                      // [0]=r1 [1]=r2 [2]=chi' [3]=status [4]=svd sweeps [5]=wide [6]=bit 0 / 1: site 1 / 2 is ill-conditioned [7]=columns of the SVD input (low-rank route) or 0
     double* truncerr;               // one double
     int maxdim; double cutoff; int normalize; int chi_cap;
     // per-site rank threshold of the eigen route (rank_tau; negative: shifted first pass of a site that a second factorisation pass
     // can follow, gate_eigs); chol == 2: the site carries an
     // explicit factor from that second pass (GV = R^dagger, GW = R^+, lambda = 1, *rk columns) -- see Qr2ComposeItem
     double tau1, tau2; const int* rk1; const int* rk2;
+    // low-rank route of the theta SVD (ComplexF32): the gate as an operator sum  g = sum_k a_k (x) b_k  (kappa terms; opA: kappa x d1 x d1,
+    // opB: kappa x d2 x d2 complex128, [k][s' + d s]) makes theta = A B^T with K = kappa chi columns in A ((r1 d1) x K) and B ((r2 d2) x K).
+    // When K < r2 d2, theta is not wide and chi_cap <= K, gate_theta also writes A, B and G = B^dagger B (lowA / lowB / lowG, complex128);
+    // chol_kernel factors G = L L^dagger and lowrank_m_kernel overwrites the first K columns of theta with M = A conj(L), whose left
+    // singular vectors and singular values are theta's (theta = M Q^T, Q = B L^-dagger orthonormal).  info[7] = columns the SVD runs on.
+    int kappa; const double* opA; const double* opB; void* lowA; void* lowB; void* lowG; const void* lowL; const int* lowfail;
 };
+void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems);
 // Second factorisation pass of an ill-conditioned ComplexF64 site (CholeskyQR2).  With the first-pass factor R1 (interface of
 // GateItem: R1[a,(s,b)] = sqrt(l_a) conj(GV[(s,b), idx_a]), R1^+[:,a] = GW[:, idx_a] / sqrt(l_a), r kept columns):
 //   Qr2RinvItem:    X1 = R1^+ as an explicit n x n matrix (columns >= r zero), so that Q1 = psi~ x_(s,b) X1 can be formed;
@@ -122,7 +129,7 @@ template <class T, class Acc> void launch_gram(hipStream_t s, const GramItem* d_
                                                int TR, int KKmax);
 template <class Acc, class Out> void launch_reduce(hipStream_t s, const ReduceItem* d_items, int nitems, int total_elems);
 template <class T> void launch_msg_finalize(hipStream_t s, const MsgFinalItem* d_items, int nitems);
-struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; };   // V = A0^dagger (U Sigma) Sigma^-2
+struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; int nu; };   // V (n x nu) = A0^dagger (U Sigma) Sigma^-2; A0: m x n, U Sigma: m x nu
 // LDS bytes the LDS-resident Jacobi needs for an m x n matrix (columns padded by 2 elements)
 inline size_t jacobi_lds_bytes(int m, int n, bool withV, size_t esz) { return ((size_t)(m + 2) * n + (withV ? (size_t)(n + 2) * n : 0)) * esz; }
 template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax);

@@ -1244,8 +1244,9 @@ __global__ __launch_bounds__(256) void recover_v_mfma_kernel(const RecoverItem* 
     const int c0 = 32 * (tile % nt), u0 = 32 * (tile / nt);
     const int col = c0 + ln, u = u0 + ln;
     const cf* pa = A0 + (size_t)m * min(col, n - 1);
-    const cf* pb = A + (size_t)m * min(u, n - 1);
-    const bool okc = col < n, oku = u < n;
+    const cf* pb = A + (size_t)m * min(u, it.nu - 1);
+    if (u0 >= it.nu) return;
+    const bool okc = col < n, oku = u < it.nu;
     v16f Cr, Ci;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }

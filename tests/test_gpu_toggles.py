@@ -1,0 +1,39 @@
+"""GPU: alternative routes of the gate path give the same results as the default route.  Each variant runs in its own process
+(tests/toggle_worker.py) because the library reads its switches once."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_worker(env):
+    r = subprocess.run([sys.executable, os.path.join(HERE, "toggle_worker.py")], env=dict(os.environ, PYTHONPATH=os.pathsep.join(sys.path), **env),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_lowrank_theta_route_matches_the_full_svd():
+    """theta of a gate with operator Schmidt rank kappa has rank <= kappa chi; when that is below its column count the SVD runs on the
+    (r d) x (kappa chi) factor M = A conj(L) instead (GateItem in kernels.hpp).  Same bond dimensions, truncation
+    errors and <Z> to f32 rounding (measured 3e-7 / 5e-7 on errors of 0.04 ... 0.4); taken for kappa = 2 gates in the bulk, never for
+    kappa = 4 gates, and never when the requested bond cap exceeds kappa chi (the reference would keep the zero singular values too)."""
+    on, off = run_worker({}), run_worker({"TNQS_NO_LOWRANK": "1"})
+    for name in ("Rzz", "CNOT", "CPHASE", "SWAP", "Rxxyyzz"):
+        a, b = on[name], off[name]
+        assert b["lowrank"] == 0
+        assert a["dims"] == b["dims"]
+        assert np.max(np.abs(np.array(a["errs"]) - np.array(b["errs"]))) < 2e-6
+        assert np.max(np.abs(np.array(a["z"]) - np.array(b["z"]))) < 5e-6
+    for name in ("Rzz", "CNOT", "CPHASE"):
+        assert 0 < on[name]["lowrank"] <= on[name]["n2"]
+    for name in ("SWAP", "Rxxyyzz"):
+        assert on[name]["lowrank"] == 0
+    # uncapped: both routes keep all singular values of theta (31 here), more than kappa chi = 16 -- only the full SVD can deliver them
+    assert on["uncapped"]["lowrank"] == 0 and on["uncapped"]["dim"] == off["uncapped"]["dim"] and on["uncapped"]["dim"] > 16

@@ -1,0 +1,32 @@
+"""child process of tests/test_gpu_toggles.py: one fixed circuit, results as JSON on the last stdout line.  The library reads its
+TNQS_NO_* switches once per process, so every variant needs its own process."""
+import json
+import sys
+
+import numpy as np
+
+import tnqs_amd as tn
+
+
+def main():
+    g = tn.named_grid((4, 4))
+    psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=8, seed=3)
+    bpc = tn.update(tn.BeliefPropagationCache(psi), maxiter=30, tolerance=None)
+    out = {}
+    for name in ("Rzz", "CNOT", "CPHASE", "SWAP", "Rxxyyzz"):
+        layer = [((name, [a, b], 0.4) if name in ("Rzz", "CPHASE", "Rxxyyzz") else (name, [a, b])) for grp in tn.edge_color(g) for (a, b) in grp]
+        info = {}
+        b2, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=8, cutoff=1e-10, normalize_tensors=True),
+                                  bp_update_kwargs=dict(maxiter=20, tolerance=None), info=info)
+        out[name] = dict(errs=errs.tolist(), z=[float(np.real(tn.expect(b2, ("Z", [v])))) for v in g.vertices],
+                         dims=[b2.bond_dim(a, b) for a, b in g.edges], lowrank=info["n_lowrank_svd"], n2=info["n_two_site"])
+    # no truncation requested: the reference keeps every singular value, the zero ones too -- the low-rank route must stand back
+    info = {}
+    b3, _ = tn.apply_gates([("Rzz", list(g.edges[5]), 0.4)], bpc, apply_kwargs=dict(maxdim=64, cutoff=None, normalize_tensors=True),
+                           bp_update_kwargs=dict(maxiter=2, tolerance=None), info=info)
+    out["uncapped"] = dict(dim=b3.bond_dim(*g.edges[5]), lowrank=info["n_lowrank_svd"])
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
