@@ -77,7 +77,15 @@ def cpu_baseline(chi, seed=1234, max_seconds=60.0):
     except Exception:
         cores = os.cpu_count() or 1
     n2 = len(g.edges)
-    return {"value": n2 / dt, "unit": "two-site gates/s", "cores": int(cores), "kind": "port",
+    host = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            models = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
+        if models:
+            host = f"{models[0]} ({len(models)} hardware threads)"
+    except OSError:
+        pass
+    return {"value": n2 / dt, "unit": "two-site gates/s", "cores": int(cores), "kind": "port", "host": host,
             "sample": f"1 TFIM layer ({n2} two-site gates, {info.get('n_updates')} BP updates, sweeps {info.get('sweeps')}) on a "
                       f"4x4 periodic torus (all sites degree 4), chi={chi}, complex64, numpy oracle; {dt:.1f} s"}
 
