@@ -1142,10 +1142,11 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     run_grams<T, double>(s, jobs, TNQS_PROF_GATE_GRAM);
     std::vector<Buf> GA(sj.size()), GV(sj.size());
     auto nof = [&](size_t i) { return sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]; };
+    // G slots: in the sharded case every rank needs G1 and G2 of the gates it takes part in -> all-gather all of them (the same layout
+    // serves the Gram matrices of the second factorisation pass further down)
+    std::vector<size_t> slot(sj.size(), 0); size_t stride = 0;
     {
-        // G slots: in the sharded case every rank needs G1 and G2 of the gates it takes part in -> all-gather all of them
-        std::vector<size_t> slot(sj.size(), 0); std::vector<size_t> rank_bytes(s->nranks, 0);
-        size_t stride = 0;
+        std::vector<size_t> rank_bytes(s->nranks, 0);
         if (sharded) {
             for (size_t i = 0; i < sj.size(); ++i) { int r = s->owner[sj[i].v]; slot[i] = rank_bytes[r]; rank_bytes[r] += round256((size_t)nof(i) * nof(i) * 16); }
             for (size_t b : rank_bytes) stride = std::max(stride, b);
@@ -1178,8 +1179,11 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     std::vector<Buf> GW(sj.size()); std::vector<char> is_chol(sj.size(), 0), is_small(sj.size(), 0);
     // ComplexF64, single rank: ill-conditioned sites get a second factorisation pass below, which sorts out what is signal and what is
     // noise among the smallest directions -- so the first pass keeps everything above the f64 noise floor instead of rank_tau
-    const bool qr2 = !std::is_same<T, float>::value && !sharded && use_qr2();
+    const bool qr2 = !std::is_same<T, float>::value && use_qr2();
     auto tau_of = [&](int n) { return qr2 ? 1e-15 : rank_tau(std::is_same<T, float>::value, n); };
+    // sites with fewer fibers than columns are factorised by their owner without a Gram matrix (small-SVD route) and never refined; the
+    // criterion must not depend on ownership, every rank taking part in a gate has to reach the same decision
+    auto small_shape = [&](size_t i) { const int n = nof(i); return sj[i].sd.n / (size_t)n < (size_t)n && n <= 256 && use_small_svd(); };
     std::vector<const void*> gauged_of(sj.size(), nullptr);      // psi~ of the owned sites
     for (size_t q = 0; q < own_idx.size(); ++q) gauged_of[own_idx[q]] = chains[q].result;
     Buf d_cholfail = dalloc(s, sizeof(int));
@@ -1320,7 +1324,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             // second-pass mode: the eigen route of the first pass is shifted (negative tau, gate_eigs) -- it must not drop a direction the
             // second pass could still resolve
             // (the small-SVD sites are factorised without a Gram matrix and are never refined: ordinary threshold)
-            auto site_tau = [&](size_t i, int n) { return (qr2 && !is_small[i] && sj[i].owned) ? -rank_tau(false, n) : rank_tau(std::is_same<T, float>::value, n); };
+            auto site_tau = [&](size_t i, int n) { return (qr2 && !small_shape(i)) ? -rank_tau(false, n) : rank_tau(std::is_same<T, float>::value, n); };
             it.tau1 = site_tau(2 * (size_t)gi, w.n1); it.tau2 = site_tau(2 * (size_t)gi + 1, w.n2); it.rk1 = nullptr; it.rk2 = nullptr;
         }
     }
@@ -1372,25 +1376,27 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             // singular directions of psi~ only down to sigma_rel ~ 1e-7, the reference's QR to eps.  Q1 = psi~ R1^+ is formed explicitly;
             // its Gram matrix is close to the identity on everything the first pass resolved and shows the true weight of what it did not,
             // so R = R2 R1 is as accurate as a Householder R.  
+            // Sharded: the owner of a site forms Q1 and its Gram matrix, one more all-gather (same slots as the first Gram exchange, issued
+            // by every rank whether or not it has a flagged site -- it is a collective) hands it to the partner rank, and both compose the
+            // same factor from the same inputs.
             std::vector<size_t> rs; std::vector<int> rq;
             for (int q = 0; q < npg; ++q) for (int side = 0; side < 2; ++side) {
                 const size_t i = 2 * (size_t)pg[q] + side;
                 static const bool all = [] { const char* v = std::getenv("TNQS_QR2_ALL"); return v && v[0] == '1'; }();      // debug: refine every site
-                if ((all || ((hinfo[8 * q + 6] >> side) & 1)) && !is_small[i] && sj[i].owned) { rs.push_back(i); rq.push_back(q); }
+                if ((all || ((hinfo[8 * q + 6] >> side) & 1)) && !small_shape(i)) { rs.push_back(i); rq.push_back(q); }
             }
-            if (!rs.empty()) {
+            if (sharded || !rs.empty()) {
                 const size_t m = rs.size();
-                std::vector<Buf> X1(m), Q1(m), G2(m), V2(m), GVn(m), GWn(m); Buf d_rk = dalloc(s, m * sizeof(int));
-                std::vector<Qr2RinvItem> ri; std::vector<FiberItem> fi; std::vector<GramJob> gj; size_t KKmax = 1; int tiles = 0;
+                std::vector<Buf> X1(m), Q1(m), G2(m), V2(m), GVn(m), GWn(m); Buf d_rk = dalloc(s, std::max<size_t>(1, m) * sizeof(int));
+                std::vector<Qr2RinvItem> ri; std::vector<FiberItem> fi; std::vector<GramJob> gj; std::vector<size_t> own_k; size_t KKmax = 1; int tiles = 0;
                 for (size_t k = 0; k < m; ++k) {
                     const size_t i = rs[k]; const int q = rq[k]; const bool second = (i & 1) != 0; const int n = nof(i); const size_t nn = (size_t)n * n;
-                    X1[k] = dalloc(s, nn * 16); Q1[k] = dalloc(s, sj[i].sd.n * esz); G2[k] = dalloc(s, nn * 16); V2[k] = dalloc(s, nn * 16);
-                    GVn[k] = dalloc(s, nn * 16); GWn[k] = dalloc(s, nn * 16);
+                    X1[k] = dalloc(s, nn * 16); V2[k] = dalloc(s, nn * 16); GVn[k] = dalloc(s, nn * 16); GWn[k] = dalloc(s, nn * 16);
                     ri.push_back(Qr2RinvItem{GW[i]->p, second ? gitems[q].lam2 : gitems[q].lam1, second ? gitems[q].idx2 : gitems[q].idx1, gitems[q].info + (second ? 1 : 0), n, X1[k]->p});
-                    KKmax = std::max<size_t>(KKmax, (size_t)n);
+                    if (sj[i].owned) { own_k.push_back(k); KKmax = std::max<size_t>(KKmax, (size_t)n); Q1[k] = dalloc(s, sj[i].sd.n * esz); }
                 }
                 const int TR = pick_TR(KKmax, esz, 1);
-                for (size_t k = 0; k < m; ++k) {
+                for (size_t k : own_k) {
                     const size_t i = rs[k]; const SiteJob& j = sj[i]; const int chi = j.sd.chi[j.bleg];
                     FiberItem it{}; it.in = gauged_of[i]; it.out = Q1[k]->p; it.X = X1[k]->p;
                     it.D = j.sd.d; it.PA = (int)(j.sd.pre(j.bleg) / j.sd.d); it.K = chi; it.PB = (int)j.sd.post(j.bleg); it.Do = j.sd.d; it.No = chi;
@@ -1398,44 +1404,55 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                     tiles += it.nta * it.ntb; fi.push_back(it);
                     GramJob g2{}; g2.X = Q1[k]->p; g2.Y = Q1[k]->p; g2.sd = j.sd; g2.leg = j.bleg; g2.keep_site = true; gj.push_back(g2);
                 }
-                { const Qr2RinvItem* d = upload(s, ri); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_rinv(s->stream, d, (int)m); }
-                { Buf np = dalloc(s, std::max(1, tiles) * sizeof(double)); const FiberItem* d = upload(s, fi);
-                  ProfScope ps(s, TNQS_PROF_GATE_APPLY, 0, 0); launch_fiber_gemm<T>(s->stream, d, (int)m, tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); s->keepalive.push_back(np); }
-                run_grams<T, double>(s, gj, TNQS_PROF_GATE_GRAM);
-                {
+                if (m) { const Qr2RinvItem* d = upload(s, ri); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_rinv(s->stream, d, (int)m); }
+                if (!fi.empty()) {
+                    Buf np = dalloc(s, std::max(1, tiles) * sizeof(double)); const FiberItem* d = upload(s, fi);
+                    { ProfScope ps(s, TNQS_PROF_GATE_APPLY, 0, 0); launch_fiber_gemm<T>(s->stream, d, (int)fi.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
+                    s->keepalive.push_back(np);
+                    run_grams<T, double>(s, gj, TNQS_PROF_GATE_GRAM);
                     std::vector<ReduceItem> rd; int elems = 0;
-                    for (size_t k = 0; k < m; ++k) { const int nn = gj[k].KK * gj[k].KK; rd.push_back(ReduceItem{gj[k].partial->p, G2[k]->p, nn, gj[k].nchunks, 1, elems}); elems += nn; }
-                    const ReduceItem* d = upload(s, rd); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, d, (int)m, elems);
+                    for (size_t t = 0; t < own_k.size(); ++t) {
+                        const size_t k = own_k[t], i = rs[k]; const int nn = gj[t].KK * gj[t].KK;
+                        void* dst;
+                        if (sharded) dst = reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride + slot[i];
+                        else { G2[k] = dalloc(s, (size_t)nn * 16); dst = G2[k]->p; }
+                        rd.push_back(ReduceItem{gj[t].partial->p, dst, nn, gj[t].nchunks, 1, elems}); elems += nn;
+                    }
+                    const ReduceItem* d2 = upload(s, rd); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, d2, (int)rd.size(), elems);
                 }
-                {
+                if (sharded) {
+                    exchange(s, stride);
+                    Buf G2_keep = dalloc(s, std::max<size_t>(256, stride * (size_t)s->nranks));
+                    HIPCHK(hipMemcpyAsync(G2_keep->p, s->exch, stride * (size_t)s->nranks, hipMemcpyDeviceToDevice, s->stream));
+                    for (size_t k = 0; k < m; ++k) { const size_t i = rs[k]; const size_t nn = (size_t)nof(i) * nof(i); G2[k] = sub_buffer(G2_keep, (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16); }
+                }
+                if (m) {
                     std::vector<EnvItem> idn; std::vector<JacobiItem> ji; size_t lds = 0;
                     for (size_t k = 0; k < m; ++k) { const int n = nof(rs[k]); idn.push_back(EnvItem{nullptr, V2[k]->p, V2[k]->p, n}); ji.push_back(JacobiItem{G2[k]->p, V2[k]->p, n, n, nullptr}); lds = std::max(lds, jacobi_lds_bytes(n, n, true, 16)); }
                     const EnvItem* di = upload(s, idn); const JacobiItem* dj = upload(s, ji);
                     { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)m); }
                     { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)m, 60, jacobi_lds(lds), mmax_of(ji)); }
-                }
-                {
                     std::vector<Qr2ComposeItem> ci;
                     for (size_t k = 0; k < m; ++k) {
                         const size_t i = rs[k]; const int q = rq[k]; const bool second = (i & 1) != 0; const int n = nof(i);
                         ci.push_back(Qr2ComposeItem{G2[k]->p, V2[k]->p, X1[k]->p, GV[i]->p, second ? gitems[q].lam2 : gitems[q].lam1, second ? gitems[q].idx2 : gitems[q].idx1,
                                                     gitems[q].info + (second ? 1 : 0), n, rank_tau(false, n), GVn[k]->p, GWn[k]->p, reinterpret_cast<int*>(d_rk->p) + k});
                     }
-                    const Qr2ComposeItem* d = upload(s, ci); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_compose(s->stream, d, (int)m);
+                    { const Qr2ComposeItem* d = upload(s, ci); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_compose(s->stream, d, (int)m); }
+                    for (size_t k = 0; k < m; ++k) {
+                        const size_t i = rs[k]; GateItem& it = gitems[rq[k]];
+                        GV[i] = GVn[k]; GW[i] = GWn[k]; s->keepalive.push_back(X1[k]); if (Q1[k]) s->keepalive.push_back(Q1[k]); s->keepalive.push_back(G2[k]); s->keepalive.push_back(V2[k]);
+                        if (i & 1) { it.GV2 = GV[i]->p; it.GW2 = GW[i]->p; it.chol2 = 2; it.rk2 = reinterpret_cast<int*>(d_rk->p) + k; }
+                        else { it.GV1 = GV[i]->p; it.GW1 = GW[i]->p; it.chol1 = 2; it.rk1 = reinterpret_cast<int*>(d_rk->p) + k; }
+                    }
+                    s->keepalive.push_back(d_rk);
+                    d_gitems = upload(s, gitems);
+                    // gate_theta reads the first-pass (lambda, idx, r) of the untouched partner site again and overwrites them with the same values
+                    run_theta();
+                    if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
+                    HIPCHK(hipStreamSynchronize(s->stream));
+                    for (size_t k = 0; k < m; ++k) s->stats.n_qr2_sites += sj[rs[k]].owned ? 1 : 0;
                 }
-                for (size_t k = 0; k < m; ++k) {
-                    const size_t i = rs[k]; GateItem& it = gitems[rq[k]];
-                    GV[i] = GVn[k]; GW[i] = GWn[k]; s->keepalive.push_back(X1[k]); s->keepalive.push_back(Q1[k]); s->keepalive.push_back(G2[k]); s->keepalive.push_back(V2[k]);
-                    if (i & 1) { it.GV2 = GV[i]->p; it.GW2 = GW[i]->p; it.chol2 = 2; it.rk2 = reinterpret_cast<int*>(d_rk->p) + k; }
-                    else { it.GV1 = GV[i]->p; it.GW1 = GW[i]->p; it.chol1 = 2; it.rk1 = reinterpret_cast<int*>(d_rk->p) + k; }
-                }
-                s->keepalive.push_back(d_rk);
-                d_gitems = upload(s, gitems);
-                // gate_theta reads the first-pass (lambda, idx, r) of the untouched partner site again and overwrites them with the same values
-                run_theta();
-                if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
-                HIPCHK(hipStreamSynchronize(s->stream));
-                s->stats.n_qr2_sites += (int)m;
             }
         }
         for (size_t i = 0; i < envs.size(); ++i)

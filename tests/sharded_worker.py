@@ -46,6 +46,18 @@ def main():
         for v in g.vertices:
             psi0.tensors[v] = (psi0.tensors[v] / np.linalg.norm(psi0.tensors[v])).astype(dtype)
     nlayers = 1 if big else 2
+    if mode == "illc128":
+        # ComplexF64 with cutoff = 1e-14 from a product state: kept singular values span 1e-7, the regime in which the gate path needs its
+        # second factorisation pass -- sharded and single-rank runs must both take it
+        g = tn.named_grid((4, 4)); groups = tn.edge_color(g, 4)
+        layer = [("Rx", [v], 2 * 2.5 * 0.05) for v in g.vertices]; seq = []
+        for grp in groups:
+            layer += [("Rzz", [a, b], 2 * 1.0 * 0.05) for (a, b) in grp]
+            seq += list(grp) + [(b, a) for (a, b) in grp]
+        kw = dict(maxdim=8, cutoff=1e-14, normalize_tensors=True)
+        bpkw = dict(edge_sequence=seq, maxiter=100, tolerance=1e-14)
+        psi0 = tn.tensornetworkstate(dtype, lambda v: "↑", g)
+        nlayers = 8
 
     def sharded_factory():
         b = tn.BeliefPropagationCache(tn.tensornetworkstate(dtype, lambda v: "↑", g))

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("dt", ["c128", "c64", "chi32"])
+@pytest.mark.parametrize("dt", ["c128", "c64", "chi32", "illc128"])
 def test_two_rank_sharded_apply_gates_matches_single_rank(tmp_path, dt):
     out = str(tmp_path / "res.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -20,9 +20,11 @@ def test_two_rank_sharded_apply_gates_matches_single_rank(tmp_path, dt):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     z = np.load(out)
-    tol = 1e-9 if dt == "c128" else (2e-4 if dt == "c64" else 5e-4)
+    # "illc128": ComplexF64, cutoff = 1e-14 -- agreement to 1e-11 needs the second factorisation pass on both sides (1e-9 with a single pass)
+    tol = 1e-9 if dt == "c128" else (1e-11 if dt == "illc128" else (2e-4 if dt == "c64" else 5e-4))
     assert np.array_equal(z["dims_sh"], z["dims_un"])
-    assert np.max(np.abs(z["errs_sh"] - z["errs_un"])) < (1e-10 if dt == "c128" else 1e-5)
+    assert np.max(np.abs(z["errs_sh"] - z["errs_un"])) < (1e-10 if dt in ("c128", "illc128") else 1e-5)
+    print(dt, "max |<Z>_sharded - <Z>_single| =", np.max(np.abs(z["ez_sh"] - z["ez_un"])), " spectra:", np.max(np.abs(z["sp_sh"] - z["sp_un"])))
     assert np.max(np.abs(z["ez_sh"] - z["ez_un"])) < tol
     assert np.max(np.abs(z["sp_sh"] - z["sp_un"])) < tol
     assert int(z["n_exchanges"]) > 0
