@@ -1186,13 +1186,14 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     auto small_shape = [&](size_t i) { const int n = nof(i); return sj[i].sd.n / (size_t)n < (size_t)n && n <= 256 && use_small_svd(); };
     std::vector<const void*> gauged_of(sj.size(), nullptr);      // psi~ of the owned sites
     for (size_t q = 0; q < own_idx.size(); ++q) gauged_of[own_idx[q]] = chains[q].result;
-    Buf d_cholfail = dalloc(s, sizeof(int));
-    auto factor_G = [&](bool allow_chol) {
+    Buf d_cholfail = dalloc(s, std::max<size_t>(1, sj.size()) * sizeof(int));      // one flag per site: only the sites whose pivot collapsed are redone
+    std::vector<int> h_cholfail(sj.size(), 0);
+    auto factor_G = [&](bool allow_chol, bool fallback = false) {
         std::vector<JacobiItem> ji, sji; std::vector<EnvItem> idn; std::vector<CholItem> ci; std::vector<SmallSvdItem> si; int cmax = 1;
-        HIPCHK(hipMemsetAsync(d_cholfail->p, 0, sizeof(int), s->stream));
+        if (!fallback) HIPCHK(hipMemsetAsync(d_cholfail->p, 0, std::max<size_t>(1, sj.size()) * sizeof(int), s->stream));
         for (size_t i = 0; i < sj.size(); ++i) {
             if (!part[i / 2]) continue;
-            if (!allow_chol && GV[i] && !is_chol[i]) continue;      // fallback pass: the eigen sites are already factorised (GA rotated in place)
+            if (fallback && !(is_chol[i] && h_cholfail[i])) continue;      // fallback pass: only the Cholesky sites whose pivot collapsed (the eigen sites are factorised, GA rotated in place)
             int n = nof(i);
             if (!GV[i]) GV[i] = dalloc(s, (size_t)n * n * 16);
             const size_t Nout = sj[i].sd.n / (size_t)n;
@@ -1209,7 +1210,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             }
             if (ch) {
                 GW[i] = dalloc(s, (size_t)n * n * 16);
-                ci.push_back(CholItem{GA[i]->p, GV[i]->p, GW[i]->p, n, reinterpret_cast<int*>(d_cholfail->p), tau_of(n)}); cmax = std::max(cmax, n);
+                ci.push_back(CholItem{GA[i]->p, GV[i]->p, GW[i]->p, n, reinterpret_cast<int*>(d_cholfail->p) + i, tau_of(n)}); cmax = std::max(cmax, n);
             } else {
                 GW[i] = GV[i];
                 idn.push_back(EnvItem{nullptr, GV[i]->p, GV[i]->p, n});      // msg == null: H := I, V := I (same buffer)
@@ -1360,11 +1361,12 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         int chol_failed = 0;
         if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
         if (!envs.empty()) HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags->p, 2 * envs.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipMemcpyAsync(&chol_failed, d_cholfail->p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        if (!sj.empty()) HIPCHK(hipMemcpyAsync(h_cholfail.data(), d_cholfail->p, sj.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
+        for (size_t i = 0; i < sj.size(); ++i) chol_failed += (part[i / 2] && is_chol[i] && h_cholfail[i]) ? 1 : 0;
         if (chol_failed) {              // numerically rank-deficient Gram matrix somewhere in the batch: redo with the eigen path
-            factor_G(false);
-            for (int q = 0; q < npg; ++q) { int gi = pg[q]; GateItem& it = gitems[q]; it.GW1 = GW[2 * gi]->p; it.GW2 = GW[2 * gi + 1]->p; it.chol1 = 0; it.chol2 = 0; }
+            factor_G(false, true);
+            for (int q = 0; q < npg; ++q) { int gi = pg[q]; GateItem& it = gitems[q]; it.GW1 = GW[2 * gi]->p; it.GW2 = GW[2 * gi + 1]->p; it.chol1 = is_chol[2 * gi]; it.chol2 = is_chol[2 * gi + 1]; }
             d_gitems = upload(s, gitems);
             run_theta();
             if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
