@@ -142,7 +142,7 @@ void dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, 
     size_t n = d; for (int i = 0; i < z; ++i) n *= chi[i];
     int nslices = it.g.n0 * it.g.n1 * it.g.n2;
     it.spw = 3; it.wg_begin = 0;
-    int nwg = (nslices + it.spw - 1) / it.spw, npart = 8 * nwg;
+    int nwg = (nslices + it.spw - 1) / it.spw, npart = nwg;
     DBuf dX(n * 8), dY(n * 8), dM(32 * 32 * 8), dI(sizeof(PairGramItem)), dR(sizeof(ReduceItem)), dP((size_t)npart * 1024 * 8), dO(1024 * 8);
     dX.up(X, n * 8); dY.up(Y, n * 8); dM.up(M, 32 * 32 * 8);
     it.X = dX.p; it.Y = dY.p; it.M = dM.p; it.partial = dP.p;
@@ -162,7 +162,7 @@ void dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X,
     size_t n = d; for (int i = 0; i < z; ++i) n *= chi[i];
     int nslices = it.g.n0 * it.g.n1 * it.g.n2;
     it.spw = 3; it.wg_begin = 0;
-    int npairs = (nslices + it.spw - 1) / it.spw, nwg = 16 * ((npairs + 7) / 8), npart = 8 * nwg;
+    int npairs = (nslices + it.spw - 1) / it.spw, nwg = 16 * ((npairs + 7) / 8), npart = nwg;
     DBuf dX(n * 8), dY(n * 8), dMx(1024 * 8), dMy(1024 * 8), dI(sizeof(PairGram2Item)), dR(2 * sizeof(ReduceItem)), dP1((size_t)npart * 1024 * 8), dP2((size_t)npart * 1024 * 8), dO(2 * 1024 * 8);
     dX.up(X, n * 8); dY.up(Y, n * 8); dMx.up(Mx, 1024 * 8); dMy.up(My, 1024 * 8);
     it.X = dX.p; it.Y = dY.p; it.Mx = dMx.p; it.My = dMy.p; it.partial_y = dP1.p; it.partial_x = dP2.p;

@@ -820,7 +820,7 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                         const int npairs = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw;     // workgroup pairs (one per half), in groups of 8 pairs
                         const int nwg = 16 * ((npairs + 7) / 8);
                         it.spw = spw; it.wg_begin = wgs; wgs += nwg;
-                        jy.nchunks = jx.nchunks = 8 * nwg; jy.KK = jx.KK = 32;
+                        jy.nchunks = jx.nchunks = nwg; jy.KK = jx.KK = 32;             // one partial per workgroup
                         jy.partial = dalloc(s, (size_t)jy.nchunks * 1024 * esz); jx.partial = dalloc(s, (size_t)jx.nchunks * 1024 * esz);
                         it.partial_y = jy.partial->p; it.partial_x = jx.partial->p;
                     }
@@ -839,7 +839,7 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                         PairGramItem& it = sh_gram[q]; GramJob& j = jobs[sh_chain[q]];
                         int nwg = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw;
                         it.spw = spw; it.wg_begin = wgs; wgs += nwg;
-                        j.nchunks = 8 * nwg; j.KK = 32; j.partial = dalloc(s, (size_t)j.nchunks * 1024 * esz);
+                        j.nchunks = nwg; j.KK = 32; j.partial = dalloc(s, (size_t)j.nchunks * 1024 * esz);
                         it.partial = j.partial->p;
                     }
                     const PairGramItem* d = upload(s, sh_gram);

@@ -923,11 +923,23 @@ __global__ __launch_bounds__(512) void mfma_pair_gram_kernel(const PairGramItem*
             }
         }
     }
-    cf* __restrict__ part = reinterpret_cast<cf*>(it.partial) + (size_t)(8 * lw + w) * 32 * 32;
+    // one partial per workgroup (see mfma_pair_gram2_kernel)
+    cf* __restrict__ part = reinterpret_cast<cf*>(it.partial) + (size_t)lw * 1024;
+    v2f* const R = L;
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        int i = (r & 3) + 8 * (r >> 2) + 4 * h, j = ln;
-        cf v; v.re = Or[r]; v.im = Oi[r]; part[i + 32 * j] = v;
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        v2f v; v[0] = Or[r]; v[1] = Oi[r];
+        R[w * (32 * 33) + ln * 33 + i] = v;
+    }
+    lds_barrier();
+    for (int e = threadIdx.x; e < 1024; e += 512) {
+        const int i = e & 31, j = e >> 5;
+        float sr = 0.f, si = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) { const v2f v = R[ww * (32 * 33) + j * 33 + i]; sr += v[0]; si += v[1]; }
+        cf o; o.re = sr; o.im = si; part[e] = o;
     }
 }
 void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitems, int total_wgs) {
@@ -1056,13 +1068,29 @@ __global__ __launch_bounds__(512) void mfma_pair_gram2_kernel(const PairGram2Ite
             }
         }
     }
-    cf* __restrict__ p1 = reinterpret_cast<cf*>(it.partial_y) + (size_t)(8 * lw + w) * 1024;
-    cf* __restrict__ p2 = reinterpret_cast<cf*>(it.partial_x) + (size_t)(8 * lw + w) * 1024;
+    // one partial per workgroup: the eight waves' accumulators are summed through the (now free) slab, in wave order -- eight times fewer
+    // partial blocks to write here and to read back in msg_finalize_kernel
+    cf* __restrict__ p1 = reinterpret_cast<cf*>(it.partial_y) + (size_t)lw * 1024;
+    cf* __restrict__ p2 = reinterpret_cast<cf*>(it.partial_x) + (size_t)lw * 1024;
+    v2f* const R = L;                                           // 8 blocks of 32 x 33
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int i = (r & 3) + 8 * (r >> 2) + 4 * h, j = ln;
-        cf v; v.re = O1r[r]; v.im = O1i[r]; p1[i + 32 * j] = v;
-        cf u; u.re = O2r[r]; u.im = O2i[r]; p2[i + 32 * j] = u;
+    for (int pass = 0; pass < 2; ++pass) {
+        lds_barrier();                                          // the slab (or the previous pass) has been consumed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            v2f v; v[0] = pass ? O2r[r] : O1r[r]; v[1] = pass ? O2i[r] : O1i[r];
+            R[w * (32 * 33) + ln * 33 + i] = v;                 // element (i, j = ln)
+        }
+        lds_barrier();
+        cf* __restrict__ dst = pass ? p2 : p1;
+        for (int e = threadIdx.x; e < 1024; e += 512) {
+            const int i = e & 31, j = e >> 5;
+            float sr = 0.f, si = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) { const v2f v = R[ww * (32 * 33) + j * 33 + i]; sr += v[0]; si += v[1]; }
+            cf o; o.re = sr; o.im = si; dst[e] = o;
+        }
     }
 }
 void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs) {
