@@ -1351,7 +1351,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             lc.push_back(CholItem{gitems[q].lowG, const_cast<void*>(gitems[q].lowL), ws[pg[q]].lowW->p, K, reinterpret_cast<int*>(d_lowfail->p) + q, rank_tau(true, K)});
             kmax = std::max(kmax, K);
         }
-        if (!lc.empty()) { const CholItem* dc = upload(s, lc); launch_chol(s->stream, dc, (int)lc.size(), kmax); launch_lowrank_m(s->stream, d_gitems, npg); }
+        if (!lc.empty()) { const CholItem* dc = upload(s, lc); launch_lowrank_g(s->stream, d_gitems, npg); launch_chol(s->stream, dc, (int)lc.size(), kmax); launch_lowrank_m(s->stream, d_gitems, npg); }
     };
     run_theta();
     std::vector<int> info(8 * (size_t)ng, 0); std::vector<double> terr(ng, 0.0);

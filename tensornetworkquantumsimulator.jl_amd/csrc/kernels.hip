@@ -906,17 +906,19 @@ template <class T>
 __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __restrict__ items) {
     __shared__ double lam_tmp[256];
     __shared__ int s_r1, s_r2;
+    // grid (gate, part): every part repeats the small serial prologue (identical values) and takes a strided share of the element loops --
+    // with one workgroup per gate the kernel was pure latency (0.56 ms per colour batch whatever the batch size)
     const GateItem it = items[blockIdx.x];
+    const int part = blockIdx.y, tid0 = part * blockDim.x + threadIdx.x, tstride = gridDim.y * blockDim.x;
     const cx<double>* A1 = reinterpret_cast<const cx<double>*>(it.GA1);
     const cx<double>* V1 = reinterpret_cast<const cx<double>*>(it.GV1);
     const cx<double>* A2 = reinterpret_cast<const cx<double>*>(it.GA2);
     const cx<double>* V2 = reinterpret_cast<const cx<double>*>(it.GV2);
     if (it.chol1) gate_full_rank(it.n1, it.lam1, it.idx1, &it.info[0], &s_r1, it.chol1 == 2 ? it.rk1 : nullptr); else gate_eigs(A1, V1, it.n1, lam_tmp, it.lam1, it.idx1, &it.info[0], &s_r1, it.tau1);
     if (it.chol2) gate_full_rank(it.n2, it.lam2, it.idx2, &it.info[1], &s_r2, it.chol2 == 2 ? it.rk2 : nullptr); else gate_eigs(A2, V2, it.n2, lam_tmp, it.lam2, it.idx2, &it.info[1], &s_r2, it.tau2);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && part == 0) {
         it.info[6] = (it.chol1 == 2 ? 0 : gate_ill_conditioned(it.chol1, V1, it.n1, it.lam1, s_r1))
                    | ((it.chol2 == 2 ? 0 : gate_ill_conditioned(it.chol2, V2, it.n2, it.lam2, s_r2)) << 1);
-        it.info[7] = 0;
     }
     const int r1 = s_r1, r2 = s_r2, d1 = it.d1, d2 = it.d2, chi = it.chi;
     const int Mr = r1 * d1, Nc = r2 * d2;
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
     const cx<double>* g = reinterpret_cast<const cx<double>*>(it.gate);
     const int dd = d1 * d2;
     // theta[(a,s1'),(c,s2')] = sum_{s1,s2} g[(s1' s2'),(s1 s2)] sum_b R1[a,(s1,b)] R2[c,(s2,b)],  R_i[a,(s,b)] = sqrt(l_a) conj(W_i[(s,b),a])
-    for (int e = threadIdx.x; e < Mr * Nc; e += blockDim.x) {
+    for (int e = tid0; e < Mr * Nc; e += tstride) {
         int row = e % Mr, col = e / Mr;
         int a = row % r1, s1p = row / r1, c = col % r2, s2p = col / r2;
         const cx<double>* w1 = V1 + (size_t)it.n1 * it.idx1[a];
@@ -952,17 +954,17 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
         else { cx<T> v = cmake<T>((T)(acc.re * sc), (T)(-acc.im * sc)); th[col + (size_t)Nc * row] = v; if (th0) th0[col + (size_t)Nc * row] = v; }
     }
     const int nI = wide ? Mr : Nc;
-    for (int e = threadIdx.x; e < nI * nI; e += blockDim.x) tv[e] = cmake<T>((e % nI) == (e / nI) ? (T)1 : (T)0, (T)0);
-    if (threadIdx.x == 0) it.info[5] = wide ? 1 : 0;
+    for (int e = tid0; e < nI * nI; e += tstride) tv[e] = cmake<T>((e % nI) == (e / nI) ? (T)1 : (T)0, (T)0);
     // low-rank route (GateItem): A[(a,s1'),(k,b)] = sum_s1 a_k[s1',s1] R1[a,(s1,b)],  B[(c,s2'),(k,b)] = sum_s2 b_k[s2',s2] R2[c,(s2,b)],  G = B^dagger B
     const int K = it.kappa * chi;
-    if (sizeof(T) == 4 && it.kappa > 0 && it.lowG && !wide && K < Nc && it.chi_cap <= K) {
+    const bool low = sizeof(T) == 4 && it.kappa > 0 && it.lowG && !wide && K < Nc && it.chi_cap <= K;
+    if (threadIdx.x == 0 && part == 0) { it.info[5] = wide ? 1 : 0; it.info[7] = low ? K : 0; }       // info[7]: lowrank_g / chol / lowrank_m follow
+    if (low) {
         cx<double>* LA = reinterpret_cast<cx<double>*>(it.lowA);
         cx<double>* LB = reinterpret_cast<cx<double>*>(it.lowB);
-        cx<double>* LG = reinterpret_cast<cx<double>*>(it.lowG);
         const cx<double>* oa = reinterpret_cast<const cx<double>*>(it.opA);
         const cx<double>* ob = reinterpret_cast<const cx<double>*>(it.opB);
-        for (int e = threadIdx.x; e < Mr * K; e += blockDim.x) {
+        for (int e = tid0; e < Mr * K; e += tstride) {
             const int row = e % Mr, l = e / Mr, a = row % r1, s1p = row / r1, b = l % chi, k = l / chi;
             const cx<double>* w1 = V1 + (size_t)it.n1 * it.idx1[a];
             cx<double> acc = cmake<double>(0, 0);
@@ -970,7 +972,7 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
             const double sc = sqrt(it.lam1[a]);
             LA[e] = cmake<double>(acc.re * sc, acc.im * sc);
         }
-        for (int e = threadIdx.x; e < Nc * K; e += blockDim.x) {
+        for (int e = tid0; e < Nc * K; e += tstride) {
             const int row = e % Nc, l = e / Nc, c = row % r2, s2p = row / r2, b = l % chi, k = l / chi;
             const cx<double>* w2 = V2 + (size_t)it.n2 * it.idx2[c];
             cx<double> acc = cmake<double>(0, 0);
@@ -978,21 +980,31 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
             const double sc = sqrt(it.lam2[c]);
             LB[e] = cmake<double>(acc.re * sc, acc.im * sc);
         }
-        __threadfence_block();
-        __syncthreads();
-        for (int e = threadIdx.x; e < K * K; e += blockDim.x) {            // G[i,j] = sum_row conj(B[row,i]) B[row,j]
-            const int i = e % K, j = e / K;
-            if (i > j) continue;
-            cx<double> acc = cmake<double>(0, 0);
-            const cx<double>* bi = LB + (size_t)Nc * i; const cx<double>* bj = LB + (size_t)Nc * j;
-            for (int row = 0; row < Nc; ++row) cfma_conj(acc, bj[row], bi[row]);
-            LG[i + (size_t)K * j] = acc; if (i != j) LG[j + (size_t)K * i] = cmake<double>(acc.re, -acc.im);
-        }
-        if (threadIdx.x == 0) it.info[7] = K;
     } else if (it.lowG && it.kappa > 0) {      // not taken: give chol_kernel a harmless identity
         cx<double>* LG = reinterpret_cast<cx<double>*>(it.lowG);
-        for (int e = threadIdx.x; e < K * K; e += blockDim.x) LG[e] = cmake<double>((e % K) == (e / K) ? 1.0 : 0.0, 0.0);
+        for (int e = tid0; e < K * K; e += tstride) LG[e] = cmake<double>((e % K) == (e / K) ? 1.0 : 0.0, 0.0);
     }
+}
+// G = B^dagger B of the low-rank route (GateItem), the same (gate, part) grid
+__global__ __launch_bounds__(1024) void lowrank_g_kernel(const GateItem* __restrict__ items) {
+    const GateItem it = items[blockIdx.x];
+    const int K = it.info[7];
+    if (K <= 0) return;
+    const int Nc = it.info[1] * it.d2;
+    const cx<double>* LB = reinterpret_cast<const cx<double>*>(it.lowB);
+    cx<double>* LG = reinterpret_cast<cx<double>*>(it.lowG);
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < K * K; e += gridDim.y * blockDim.x) {      // G[i,j] = sum_row conj(B[row,i]) B[row,j]
+        const int i = e % K, j = e / K;
+        if (i > j) continue;
+        cx<double> acc = cmake<double>(0, 0);
+        const cx<double>* bi = LB + (size_t)Nc * i; const cx<double>* bj = LB + (size_t)Nc * j;
+        for (int row = 0; row < Nc; ++row) cfma_conj(acc, bj[row], bi[row]);
+        LG[i + (size_t)K * j] = acc; if (i != j) LG[j + (size_t)K * i] = cmake<double>(acc.re, -acc.im);
+    }
+}
+void launch_lowrank_g(hipStream_t s, const GateItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(lowrank_g_kernel, dim3(nitems, 4), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 // theta[:, 0..K) := M = A conj(L) where G = L L^dagger (chol_kernel); on a collapsed pivot the full theta (already in place) stays
 template <class T>
@@ -1000,12 +1012,12 @@ __global__ __launch_bounds__(1024) void lowrank_m_kernel(const GateItem* __restr
     const GateItem it = items[blockIdx.x];
     const int K = it.info[7];
     if (K <= 0) return;
-    if (*it.lowfail) { if (threadIdx.x == 0) it.info[7] = 0; return; }
+    if (*it.lowfail) { if (threadIdx.x == 0 && blockIdx.y == 0) it.info[7] = 0; return; }
     const int Mr = it.info[0] * it.d1;
     const cx<double>* LA = reinterpret_cast<const cx<double>*>(it.lowA);
     const cx<double>* L = reinterpret_cast<const cx<double>*>(it.lowL);
     cx<T>* th = reinterpret_cast<cx<T>*>(it.theta);
-    for (int e = threadIdx.x; e < Mr * K; e += blockDim.x) {
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < Mr * K; e += gridDim.y * blockDim.x) {
         const int i = e % Mr, j = e / Mr;
         cx<double> acc = cmake<double>(0, 0);
         for (int l = j; l < K; ++l) cfma_conj(acc, LA[i + (size_t)Mr * l], L[l + (size_t)K * j]);      // A[i,l] conj(L[l,j]), L lower triangular
@@ -1014,11 +1026,11 @@ __global__ __launch_bounds__(1024) void lowrank_m_kernel(const GateItem* __restr
 }
 void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((lowrank_m_kernel<float>), dim3(nitems), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((lowrank_m_kernel<float>), dim3(nitems, 4), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((gate_theta_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gate_theta_kernel<T>), dim3(nitems, 8), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_gate_theta<float>(hipStream_t, const GateItem*, int);
 template void launch_gate_theta<double>(hipStream_t, const GateItem*, int);
@@ -1087,7 +1099,9 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
     __shared__ double sig[256];
     __shared__ int perm[256];
     __shared__ int s_keep;
+    // grid (gate, part) as gate_theta_kernel: the ranking / truncation prologue is repeated per part, only part 0 writes its results
     const GateItem it = items[blockIdx.x];
+    const int part = blockIdx.y, tid0 = part * blockDim.x + threadIdx.x, tstride = gridDim.y * blockDim.x;
     const int r1 = it.info[0], r2 = it.info[1], d1 = it.d1, d2 = it.d2, chi = it.chi;
     const int Mr = r1 * d1, Nc = r2 * d2;
     const bool wide = it.info[5] != 0;                                // theta stored as theta^dagger (Nc x Mr)
@@ -1129,11 +1143,13 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
         double nrm = 0;
         for (int i = 0; i < n; ++i) nrm += sig[perm[i]] * sig[perm[i]];
         nrm = sqrt(nrm);
-        for (int i = 0; i < n; ++i) {
-            double s = sig[perm[i]];
-            it.S[i] = (it.normalize && nrm > 0) ? (double)((T)s / (T)nrm) : (double)(T)s;
+        if (part == 0) {
+            for (int i = 0; i < n; ++i) {
+                double s = sig[perm[i]];
+                it.S[i] = (it.normalize && nrm > 0) ? (double)((T)s / (T)nrm) : (double)(T)s;
+            }
+            it.info[2] = n; it.info[3] = status; *it.truncerr = (double)truncerr;
         }
-        it.info[2] = n; it.info[3] = status; *it.truncerr = (double)truncerr;
         s_keep = n;
     }
     __syncthreads();
@@ -1144,7 +1160,7 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
     cx<T>* X2 = reinterpret_cast<cx<T>*>(it.X2);
     const int n1 = it.n1, n2 = it.n2;
     // X1[(s,b),(s1',u)] = sum_a W1[(s,b),a] / sqrt(l1_a) * (U Sigma)[(a,s1'),pi(u)] / sqrt(sigma_u)
-    for (int e = threadIdx.x; e < n1 * d1 * nk; e += blockDim.x) {
+    for (int e = tid0; e < n1 * d1 * nk; e += tstride) {
         int kk = e % n1, nn = e / n1;
         int s1p = nn % d1, u = nn / d1;
         int pu = perm[u];
@@ -1164,7 +1180,7 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
         X1[e] = cmake<T>((T)acc.re, (T)acc.im);
     }
     // X2[(s,b),(s2',u)] = sum_c W2[(s,b),c] / sqrt(l2_c) * sqrt(sigma_u) conj(Vtheta[(c,s2'),pi(u)])
-    for (int e = threadIdx.x; e < n2 * d2 * nk; e += blockDim.x) {
+    for (int e = tid0; e < n2 * d2 * nk; e += tstride) {
         int kk = e % n2, nn = e / n2;
         int s2p = nn % d2, u = nn / d2;
         int pu = perm[u];
@@ -1185,7 +1201,7 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
 }
 template <class T> void launch_gate_finish(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((gate_finish_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gate_finish_kernel<T>), dim3(nitems, 4), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_gate_finish<float>(hipStream_t, const GateItem*, int);
 template void launch_gate_finish<double>(hipStream_t, const GateItem*, int);

@@ -82,6 +82,7 @@ struct GateItem {         // everything the per-gate small-algebra kernels need 
     // singular vectors and singular values are theta's (theta = M Q^T, Q = B L^-dagger orthonormal).  info[7] = columns the SVD runs on.
     int kappa; const double* opA; const double* opB; void* lowA; void* lowB; void* lowG; const void* lowL; const int* lowfail;
 };
+void launch_lowrank_g(hipStream_t s, const GateItem* d_items, int nitems);
 void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems);
 // Second factorisation pass of an ill-conditioned ComplexF64 site (CholeskyQR2).  With the first-pass factor R1 (interface of
 // GateItem: R1[a,(s,b)] = sqrt(l_a) conj(GV[(s,b), idx_a]), R1^+[:,a] = GW[:, idx_a] / sqrt(l_a), r kept columns):
