@@ -31,6 +31,9 @@ known-answer / invariant test the reference holds for this path (tests/test_orac
   test/test_constructors.jl:69-74  GHZ bond entropy == log 2
   test/test_expect.jl:19-28        <Z> bp == exact on a line
   src/Apply/simple_update.jl:4     "exact if no truncation is performed" -> state-vector check
+  examples/hexagonal_heisenbergmodel_thermalstate.jl:36   4th-order high-temperature series of the Heisenberg free energy
+                                   (imaginary-time gates on d = 4 sites, freenergy + rescale!), reproduced to the next series order
+  test/test_truncate.jl:29-33, src/symmetric_gauge.jl   truncate / symmetric-gauge invariants
 and against an independent dense state-vector simulator (oracle/statevector.py).
 Numeric parity with the Julia package itself is therefore "pinned by invariants only".
 
