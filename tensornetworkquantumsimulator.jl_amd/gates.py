@@ -191,6 +191,15 @@ def gate_matrix(name, *params) -> np.ndarray:
 
 def _verts_of(gate, graph) -> list:
     verts = gate[1]
+    if type(verts) is list:                      # fast path: the usual ("Rzz", [v1, v2], theta) / ("Rx", [v], theta) forms
+        index = graph.index
+        n = len(verts)
+        if n == 2:
+            a, b = verts
+            if a in index and b in index and a != b:
+                return verts
+        elif n == 1 and verts[0] in index:
+            return verts
     if not isinstance(verts, (list,)):
         verts = [verts] if verts in graph.index else list(verts)
     verts = list(verts)
@@ -208,7 +217,14 @@ def resolve_gate_flat(gate, graph) -> Tuple[np.ndarray, list]:
     verts = _verts_of(gate, graph)
     if isinstance(name, np.ndarray):
         return np.asarray(name, dtype=np.complex128).ravel(order="F"), verts
-    return _cached_gate(name, tuple(gate[2:]))[2], verts
+    params = gate[2:] if type(gate) is tuple else tuple(gate[2:])
+    try:                                         # fast path: an exact cache hit whose GateSpec is still the registered one
+        hit = _MATRIX_CACHE[(name, params)]
+        if hit[0] is GATES.get(name):
+            return hit[2], verts
+    except (KeyError, TypeError):
+        pass
+    return _cached_gate(name, params)[2], verts
 
 
 def resolve_gate(gate, graph) -> Tuple[np.ndarray, list]:
