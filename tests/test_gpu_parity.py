@@ -608,7 +608,7 @@ def device_default_sequence(bpc):
 
 
 @pytest.mark.parametrize("order", ["forest_cover", "device_default"])
-@pytest.mark.parametrize("seed", list(range(48)))
+@pytest.mark.parametrize("seed", list(range(48)) + [53])
 def test_random_graphs_random_circuits_match_oracle(seed, order):
     """stress: random graphs (trees, rings, ladders, sparse random), random bond dimensions, random gate lists with repeated and
     overlapping gates, both precisions -- device against oracle on gauge-invariant quantities, and against the exact state vector
@@ -647,7 +647,12 @@ def test_random_graphs_random_circuits_match_oracle(seed, order):
     oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **okw)
     out, errs = tn.apply_gates(circuit, bpc, apply_kwargs=kw, bp_update_kwargs=bpkw)
     oo, oerrs = o.apply_gates(circuit, oc, apply_kwargs=kw, bp_update_kwargs=okw)
-    assert [out.bond_dim(a, b) for (a, b) in g.edges] == [oo.tns.bond_dim(a, b) for (a, b) in g.edges]
+    # bond dimensions must agree whenever the cut is not decided by rounding: ComplexF64, or a cut made by maxdim.  ComplexF32 with
+    # cutoff = 1e-14 alone cuts at the square of the f32 rounding level, where one more or one fewer noise-level singular value is kept
+    # (seed 53: 8 vs 6 on one bond, truncation errors 9.6e-15 vs 3.6e-16, both states exact to 1e-12 in fidelity)
+    dims_dev, dims_ora = [out.bond_dim(a, b) for (a, b) in g.edges], [oo.tns.bond_dim(a, b) for (a, b) in g.edges]
+    if dtype == np.complex128 or truncated:
+        assert dims_dev == dims_ora
     assert np.max(np.abs(errs - np.array(oerrs))) < (1e-9 if dtype == np.complex128 else 2e-5)
     for v in g.vertices:
         assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oo, Z, v)) < 20 * tol
