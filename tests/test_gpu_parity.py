@@ -778,3 +778,54 @@ def test_c64_gate_subspace_is_at_least_as_good_as_the_f32_oracles(chi, maxdim):
             assert dd <= rr + 2e-6, (gt, dd, rr)
             assert np.linalg.norm(d - r) / nrm < 1e-5, (gt, np.linalg.norm(d - r) / nrm)
             assert abs(e2[0] - eo[0]) < 1e-5
+
+
+@pytest.mark.parametrize("seed", list(range(32)) + [103])
+def test_random_nonunitary_c128_circuits_match_oracle(seed):
+    """stress for the ComplexF64 gate path on ill-conditioned states: random graphs, product-state start, random circuits mixing rotations
+    with imaginary-time gates (Heisenberg, ZZ, XX + field), cutoff 1e-14 ... 1e-12, maxdim 4 ... 16, both settings of normalize_tensors.
+    The kept singular values span many orders of magnitude, the regime of the second factorisation pass.  A
+    one-off soak of 400 seeds of this generator: 581 sites went through the pass, worst deviation from the oracle 6.3e-14 in <Z>.  With
+    the pass switched off (TNQS_NO_QR2=1) 399 of the 400 seeds still agree to 1e-12 -- on circuits this small the single pass is usually
+    enough -- and seed 103 deviates by 2.1e-11; it is in the list, so this test fails without the pass.  The first 32 seeds are coverage.
+    Same bond dimensions, <Z> to 1e-12, truncation errors to 1e-11."""
+    pauli = [np.array([[0, 1], [1, 0]], complex), np.array([[0, -1j], [1j, 0]]), np.diag([1.0, -1.0]).astype(complex)]
+
+    def expm_h(h, tau):
+        w, q = np.linalg.eigh(h)
+        return (q * np.exp(-tau * w)) @ q.conj().T
+
+    rng = np.random.default_rng(5000 + seed)
+    g = _random_graph(rng, ["tree", "ring", "ladder", "random"][seed % 4])
+    if seed % 2:
+        psi = tn.tensornetworkstate(np.complex128, lambda v: "↑" if rng.random() < 0.5 else "↓", g)
+    else:
+        psi = tn.random_tensornetworkstate(np.complex128, g, bond_dimension=1, seed=seed)
+    circuit = []
+    for _ in range(int(rng.integers(10, 30))):
+        r = rng.random()
+        if r < 0.25:
+            v = g.vertices[int(rng.integers(0, g.nv()))]; k = int(rng.integers(0, 3))
+            circuit.append(("H", [v]) if k == 2 else (["Rx", "Ry"][k], [v], float(rng.uniform(0.1, 1.5))))
+        else:
+            a, b = g.edges[int(rng.integers(0, g.ne()))]
+            tau = float(rng.uniform(0.005, 0.3))
+            if r < 0.5:
+                m = expm_h(sum(np.kron(p, p) for p in pauli), tau)
+            elif r < 0.7:
+                m = expm_h(np.kron(pauli[2], pauli[2]), tau)
+            elif r < 0.85:
+                m = expm_h(np.kron(pauli[0], pauli[0]) + 0.3 * np.kron(pauli[2], np.eye(2)), tau)
+            else:
+                m = o.gate_matrix("Rzz", tau * 3)
+            circuit.append((m, [a, b]))
+    kw = dict(maxdim=int(rng.choice([4, 8, 16])), cutoff=float(rng.choice([1e-14, 1e-13, 1e-12])), normalize_tensors=bool(seed % 3))
+    bpkw = dict(maxiter=300, tolerance=1e-14, edge_sequence=tn.forest_cover_edge_sequence(g))
+    bpc = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)
+    out, errs = tn.apply_gates(circuit, bpc, apply_kwargs=kw, bp_update_kwargs=bpkw)
+    oo, oerrs = o.apply_gates(circuit, oc, apply_kwargs=kw, bp_update_kwargs=bpkw)
+    assert [out.bond_dim(a, b) for (a, b) in g.edges] == [oo.tns.bond_dim(a, b) for (a, b) in g.edges]
+    assert np.max(np.abs(errs - np.array(oerrs))) < 1e-11
+    for v in g.vertices:
+        assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oo, Z, v)) < 1e-12
