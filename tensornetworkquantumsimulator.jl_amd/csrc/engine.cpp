@@ -656,6 +656,10 @@ static BPPlan make_plan(const State* s, const tnqs_bp_opts* o) {
     }
     p.levels.resize(nlev);
     for (size_t t = 0; t < p.seq.size(); ++t) p.levels[level[t]].push_back((int)t);
+    // the messages of a level are independent of each other: list them by source vertex, so that a workspace-bounded sub-batch (bp_update_t)
+    // holds all messages of the sites it touches (they share the pair product and the double pair-Gram pass)
+    auto src_of = [&](int t) { int de = p.seq[t]; int e = de / 2; return (de & 1) ? g.edst[e] : g.esrc[e]; };
+    for (auto& lev : p.levels) std::stable_sort(lev.begin(), lev.end(), [&](int a, int b) { return src_of(a) < src_of(b); });
     p.level_of = level;
     return p;
 }
