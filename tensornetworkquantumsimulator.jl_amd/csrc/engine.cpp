@@ -678,7 +678,14 @@ static bool use_tshare() { static int v = -1; if (v < 0) { const char* e = std::
 template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out) {
     const Graph& g = *s->g;
     HIPCHK(hipSetDevice(s->device));
-    BPPlan plan = make_plan(s, o);
+    // the level schedule depends on the graph and the sequence only: the one of the default sequence is kept with the graph
+    std::shared_ptr<const BPPlan> plan_p;
+    if (o && o->n_sequence > 0) plan_p = std::make_shared<const BPPlan>(make_plan(s, o));
+    else {
+        if (!g.default_plan) g.default_plan = std::make_shared<const BPPlan>(make_plan(s, o));
+        plan_p = std::static_pointer_cast<const BPPlan>(g.default_plan);
+    }
+    const BPPlan& plan = *plan_p;
     int maxiter = (o && o->maxiter > 0) ? o->maxiter : (g.is_tree ? 1 : 25);                  // :39,:103
     double tol;
     if (!o || std::isnan(o->tolerance)) tol = g.is_tree ? -1.0 : default_tol(s); else tol = o->tolerance;
@@ -1088,7 +1095,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     std::vector<SiteJob> sj(2 * (size_t)ng);
     std::vector<char> part(ng, 0);                  // this rank runs the small algebra of the gate
     // ---- 1. environments: sqrt(M) and projector for every incoming message of an owned site (utils.jl:18-27) ------
-    struct EnvRec { int de; int n; Buf H, V, msq, prj; };
+    struct EnvRec { int de; int n; void *H, *V, *msq, *prj; };      // views into one arena (env_arena): thousands of 16 KiB pool allocations per batch
+                                                                    // were a third of the host time between a BP update and the first kernel of a batch
     std::vector<EnvRec> envs;
     for (int gi = 0; gi < ng; ++gi) {
         for (int side = 0; side < 2; ++side) {
@@ -1109,14 +1117,20 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     }
     std::vector<int> h_flags(2 * envs.size() + 2, 0);
     Buf d_flags = dalloc(s, h_flags.size() * sizeof(int));
+    Buf env_arena;
     {
         std::vector<EnvItem> ei; std::vector<JacobiItem> ji; std::vector<EnvFinishItem> fi;
+        size_t env_bytes = 0;
+        for (auto& r : envs) { const size_t nn = (size_t)r.n * r.n; env_bytes += 2 * round256(nn * 16) + 2 * round256(nn * esz); }
+        env_arena = dalloc(s, std::max<size_t>(256, env_bytes));
+        char* ap = reinterpret_cast<char*>(env_arena->p);
+        ei.reserve(envs.size()); ji.reserve(envs.size()); fi.reserve(envs.size());
         for (size_t i = 0; i < envs.size(); ++i) {
             EnvRec& r = envs[i]; size_t nn = (size_t)r.n * r.n;
-            r.H = dalloc(s, nn * 16); r.V = dalloc(s, nn * 16); r.msq = dalloc(s, nn * esz); r.prj = dalloc(s, nn * esz);
-            ei.push_back(EnvItem{s->msg[r.de]->p, r.H->p, r.V->p, r.n});
-            ji.push_back(JacobiItem{r.H->p, r.V->p, r.n, r.n, nullptr});
-            fi.push_back(EnvFinishItem{r.H->p, r.V->p, r.msq->p, r.prj->p, r.n, sqrt_cutoff, reinterpret_cast<int*>(d_flags->p) + 2 * i});
+            r.H = ap; ap += round256(nn * 16); r.V = ap; ap += round256(nn * 16); r.msq = ap; ap += round256(nn * esz); r.prj = ap; ap += round256(nn * esz);
+            ei.push_back(EnvItem{s->msg[r.de]->p, r.H, r.V, r.n});
+            ji.push_back(JacobiItem{r.H, r.V, r.n, r.n, nullptr});
+            fi.push_back(EnvFinishItem{r.H, r.V, r.msq, r.prj, r.n, sqrt_cutoff, reinterpret_cast<int*>(d_flags->p) + 2 * i});
         }
         if (!envs.empty()) {
             const EnvItem* de = upload(s, ei); const JacobiItem* dj = upload(s, ji); const EnvFinishItem* df = upload(s, fi);
@@ -1133,7 +1147,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     for (size_t q = 0; q < own_idx.size(); ++q) {
         const SiteJob& j = sj[own_idx[q]];
         Chain& c = chains[q]; c.v = j.v; c.src = s->site[j.v]->p; c.sd = j.sd;
-        for (size_t e = 0; e < j.env_idx.size(); ++e) c.steps.push_back({j.env_leg[e], envs[j.env_idx[e]].msq->p});
+        for (size_t e = 0; e < j.env_idx.size(); ++e) c.steps.push_back({j.env_leg[e], envs[j.env_idx[e]].msq});
     }
     run_chains<T>(s, chains, TNQS_PROF_GATE_MODEPROD);
     // ---- 3. G = psi~^dagger psi~ over the outer legs, f64 accumulation (replaces the thin QR, simple_update.jl:45-48) --
@@ -1546,7 +1560,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         const SiteJob& j = sj[own_idx[q]];
         Chain& c = pch[q]; c.v = j.v; c.src = s->site[j.v]->p; c.sd = j.sd;
         for (size_t e = 0; e < j.env_idx.size(); ++e)
-            if (!h_flags[2 * j.env_idx[e]]) c.steps.push_back({j.env_leg[e], envs[j.env_idx[e]].prj->p});  // rank-deficient message only
+            if (!h_flags[2 * j.env_idx[e]]) c.steps.push_back({j.env_leg[e], envs[j.env_idx[e]].prj});  // rank-deficient message only
     }
     run_chains<T>(s, pch, TNQS_PROF_GATE_MODEPROD);
     if (!own_idx.empty()) {

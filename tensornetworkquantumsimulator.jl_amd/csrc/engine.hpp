@@ -56,6 +56,7 @@ struct Graph {
     bool is_tree = false;
     std::vector<int> ecolor; int ncolors = 0;     // deterministic greedy proper edge colouring
     mutable std::vector<int> default_seq;         // default BP sweep order (engine.cpp default_sequence), built on first use
+    mutable std::shared_ptr<const void> default_plan;   // its level schedule (engine.cpp BPPlan), built on first use
     int edge(int u, int v) const;                 // -1 if absent
     int leg(int v, int w) const;                  // position of neighbour w in nbr[v], -1 if absent
     int dedge(int src, int dst) const;            // directed edge id 2*e + (src == edst[e]), -1 if absent
