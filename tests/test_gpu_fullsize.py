@@ -175,3 +175,32 @@ def test_cubic_degree6_chi16_layer_runs():
     assert bpc.maxvirtualdim() <= chi and np.all((errs >= 0) & (errs <= 1))
     ez = tn.expect_all(bpc, "Z")
     assert np.all(np.abs(ez.real) <= 1 + 1e-4) and np.all(np.abs(ez.imag) < 1e-4)
+
+
+def test_c2_physical_evolution_from_product_state():
+    """the benchmark lattice on PHYSICAL states: 20x20 TFIM (J = 1, hx = 2.5, dt = 0.1) from all-up, maxdim 32, cutoff 1e-10 -- bond
+    dimensions grow 2 -> 32 over 11 layers, so every route is exercised at scale (small-SVD corners, per-site Cholesky fallbacks, the
+    low-rank theta SVD once kappa chi reaches the cap).  No oracle at this size: scheduling counts, bounds, the known first layer."""
+    L, chi = 20, 32
+    g = tn.named_grid((L, L))
+    groups = tn.edge_color(g, 4)
+    layer = [("Rx", [v], 2 * 2.5 * 0.1) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rzz", [a, b], 2 * 1.0 * 0.1) for (a, b) in grp]
+    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex64, lambda v: "↑", g))
+    kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+    fid, used_lowrank = 1.0, 0
+    for it in range(14):
+        info = {}
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=kw, info=info)
+        assert info["n_updates"] == 5 and info["n_two_site"] == g.ne() and info["bp_not_converged"] == 0
+        assert np.all((errs >= 0) & (errs < 1e-5))
+        fid *= float(np.prod(1 - errs))
+        used_lowrank += info["n_lowrank_svd"]
+        ez = tn.expect_all(bpc, "Z")
+        assert np.all(np.isfinite(ez)) and np.all(np.abs(ez.real) <= 1 + 1e-4) and np.all(np.abs(ez.imag) < 1e-4)
+        if it == 0:
+            assert np.max(np.abs(ez.real - np.cos(0.5))) < 1e-5      # first layer: Rx(0.5) then diagonal gates: <Z> = cos(0.5) on every site
+    assert bpc.maxvirtualdim() == chi and 0.999 < fid <= 1.0
+    assert used_lowrank > 700                                       # saturated layers run the theta SVD on the low-rank factor
+    check_messages_psd(bpc, g.edges[:8], 1e-4)
