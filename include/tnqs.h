@@ -69,7 +69,7 @@ typedef struct {
     int n_two_site;         /* two-site gates applied */
     int bp_not_converged;   /* updates that hit maxiter (reference: @warn, abstract...:245-252) */
     double last_bp_diff;
-    int n_chol_fallbacks;   /* gate batches whose Gram matrices were numerically rank-deficient (eigen path instead of Cholesky) */
+    int n_chol_fallbacks;   /* gate batches in which at least one site had a numerically rank-deficient Gram matrix (those sites take the eigen path) */
     int n_qr2_sites;        /* ComplexF64 sites that went through the second factorisation pass (ill-conditioned psi~) */
     int n_lowrank_svd;      /* two-site gates whose theta SVD ran on the low-rank factor (gate of operator Schmidt rank kappa, kappa chi < d chi) */
     int reserved_;
