@@ -13,6 +13,31 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(or tensornetworkquantumsimulator.jl_amd/csrc/build.sh). There is no CPU fallback.")
 
+
+
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own HIP / HSA runtimes (same SONAMEs as /opt/rocm's).  Whoever loads first wins: if this
+    library pulled in /opt/rocm's copies and `import torch` came later, torch would bring up a second runtime stack and find no GPU.
+    Loading torch's copies first (only the shared objects -- torch itself is not imported) makes both orders share one runtime, which
+    is the configuration the tests and bench.py run in."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("TNQS_NO_TORCH_RUNTIME") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:                 # never fatal: without torch's copies the system runtime is used
+        pass
+
+
+_share_torch_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 TNQS_C64, TNQS_C128 = 0, 1

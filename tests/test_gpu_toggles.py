@@ -53,3 +53,21 @@ def test_alternative_routes_match_the_default(switch):
         assert a["dims"] == b["dims"], name
         assert np.max(np.abs(np.array(a["errs"]) - np.array(b["errs"]))) < 2e-5, name
         assert np.max(np.abs(np.array(a["z"]) - np.array(b["z"]))) < 5e-5, name
+
+
+def test_torch_can_be_imported_after_the_library():
+    """PyTorch-ROCm bundles its own HIP / HSA runtimes; the loader (_lib.py) shares them so that the import order does not matter.
+    Without that, `import torch` after the library finds no GPU (checked with TNQS_NO_TORCH_RUNTIME=1)."""
+    code = (
+        "import sys; sys.path[:0] = %r\n"
+        "import numpy as np, tnqs_amd as tn\n"
+        "g = tn.named_grid((3, 3))\n"
+        "bpc = tn.update(tn.BeliefPropagationCache(tn.random_tensornetworkstate(np.complex64, g, bond_dimension=2, seed=1)))\n"
+        "z1 = tn.expect(bpc, ('Z', [g.vertices[0]]))\n"
+        "import torch\n"
+        "assert torch.cuda.is_available()\n"
+        "assert torch.ones(4, device='cuda').sum().item() == 4.0\n"
+        "assert abs(tn.expect(bpc, ('Z', [g.vertices[0]])) - z1) < 1e-12\n"
+        "print('ok')\n") % (sys.path,)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
