@@ -25,6 +25,7 @@ static int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j 
 static bool use_chol() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_CHOL"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_qr2() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_QR2"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_lowrank() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_LOWRANK"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
+static bool use_prefix() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_PREFIX"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_small_svd() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_SMALLSVD"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 static bool use_apply64() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_APPLY64"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 // optional host-side phase timing (TNQS_HOST_TIMING=1): printed when the process exits
@@ -403,6 +404,7 @@ static size_t round256(size_t b);
 // a chain = one site tensor pushed through several mode products (leg j with matrix X_j, chi_j x chi_j)
 struct Chain {
     int v = -1; const void* src = nullptr; SD sd;
+    const void* y = nullptr;                     // the untouched site tensor when src is a shared partial product of it (BP prefix sharing)
     std::vector<std::pair<int, const void*>> steps;
     const void* result = nullptr; Buf tmp[2];
 };
@@ -739,6 +741,48 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                 struct Pend { int idx, jo, r; };                                                                // first message of a (site, T) seen in this level
                 std::unordered_map<long long, Pend> pend;
                 double sh_pair_slices = 0, sh_gram_slices = 0, sh_dbl_slices = 0;
+                // ---- shared partial products for the sites the plane kernels do not cover (any degree, any bond dimension): a site that sends
+                // several messages in this level absorbs the messages on its OTHER legs once (T = psi x_{legs not going out here} m) and every
+                // outgoing message continues from T.  With the default linear-forest order a site sends two messages per level, so a degree-6
+                // site does 4 + 2 x 1 absorption passes per level instead of 2 x 5.  Reuse is decided by buffer identity per message (the
+                // Gauss-Seidel rule may give two messages of a site different versions of an incoming message), never assumed.
+                struct Prefix { Buf site; std::vector<std::pair<int, const void*>> legs; Buf prod; };
+                std::unordered_map<int, Prefix> prefix;
+                auto select_in = [&](int src, int j, int t) -> const Buf& {
+                    int din = g.dedge(g.nbr[src][j], src); int pp = plan.pos_of[din];
+                    return (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
+                };
+                if (use_prefix() && !plan.in_place) {
+                    std::unordered_map<int, std::vector<int>> outl;            // source site -> legs going out in this sub-batch
+                    auto generic_site = [&](int src, int jo) { return tshare.empty() || site_dims(s, src).z != 4 || partner[src][jo] < 0; };
+                    for (size_t q = start; q < end; ++q) {
+                        int de = plan.seq[lev[q]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
+                        if (s->owns(src) && generic_site(src, g.leg(src, dst))) outl[src].push_back(g.leg(src, dst));
+                    }
+                    std::vector<Chain> pch; std::vector<int> psrc;
+                    for (size_t q = start; q < end; ++q) {
+                        int t = lev[q]; int de = plan.seq[t]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
+                        auto ol = outl.find(src);
+                        if (ol == outl.end() || ol->second.size() < 2 || prefix.count(src)) continue;
+                        Chain cp; cp.v = src; cp.src = s->site[src]->p; cp.sd = site_dims(s, src);
+                        Prefix pf; pf.site = s->site[src];
+                        for (int j = 0; j < cp.sd.z; ++j) {
+                            if (std::find(ol->second.begin(), ol->second.end(), j) != ol->second.end()) continue;
+                            const Buf& mb = select_in(src, j, t);
+                            if (!mb) continue;
+                            cp.steps.push_back({j, mb->p}); pf.legs.push_back({j, mb->p});
+                        }
+                        if (pf.legs.empty()) continue;
+                        prefix[src] = pf; pch.push_back(std::move(cp)); psrc.push_back(src);
+                    }
+                    if (!pch.empty()) {
+                        run_chains<T>(s, pch, TNQS_PROF_BP_MODEPROD, TNQS_PROF_BP_PAIR);
+                        for (size_t i = 0; i < pch.size(); ++i) {
+                            Prefix& pf = prefix[psrc[i]];
+                            for (int k = 0; k < 2; ++k) if (pch[i].tmp[k] && pch[i].tmp[k]->p == pch[i].result) pf.prod = pch[i].tmp[k];
+                        }
+                    }
+                }
                 for (size_t q = start; q < end; ++q) {
                     int t = lev[q]; int de = plan.seq[t]; int e = de / 2;
                     int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
@@ -788,8 +832,17 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     }
                     const int fr = fused_leg(s, c.sd, jo);
                     const void* fm = nullptr;
+                    std::vector<char> done(c.sd.z, 0);                   // legs already absorbed in the shared partial product
+                    {
+                        auto pf = prefix.find(src);
+                        if (pf != prefix.end() && pf->second.prod && pf->second.site == s->site[src]) {
+                            bool same = true;
+                            for (auto& lm : pf->second.legs) { if (lm.first == jo) { same = false; break; } const Buf& mb = select_in(src, lm.first, t); if (!mb || mb->p != lm.second) { same = false; break; } }
+                            if (same) { c.y = c.src; c.src = pf->second.prod->p; for (auto& lm : pf->second.legs) done[lm.first] = 1; }
+                        }
+                    }
                     for (int j = 0; j < c.sd.z; ++j) {
-                        int k = g.nbr[src][j]; if (k == dst) continue;
+                        int k = g.nbr[src][j]; if (k == dst || done[j]) continue;
                         int din = g.dedge(k, src); int pp = plan.pos_of[din];
                         const Buf& mb = (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
                         if (!mb) continue;                               // unset message = identity: nothing to absorb
@@ -813,7 +866,7 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                 std::vector<GramJob> jobs;
                 for (size_t i = 0; i < chains.size(); ++i) {
                     int de = plan.seq[tpos[i]]; int e = de / 2; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
-                    GramJob j{}; j.X = chains[i].result; j.Y = chains[i].src; j.sd = chains[i].sd; j.leg = g.leg(chains[i].v, dst); j.keep_site = false;
+                    GramJob j{}; j.X = chains[i].result; j.Y = chains[i].y ? chains[i].y : chains[i].src; j.sd = chains[i].sd; j.leg = g.leg(chains[i].v, dst); j.keep_site = false;
                     j.M = fmsg[i];
                     jobs.push_back(j);
                 }

@@ -40,11 +40,11 @@ def test_lowrank_theta_route_matches_the_full_svd():
 
 
 @pytest.mark.parametrize("switch", ["TNQS_NO_CHOL", "TNQS_NO_SMALLSVD", "TNQS_JACOBI_GLOBAL", "TNQS_NO_PAIR", "TNQS_NO_TSHARE", "TNQS_NO_FUSED_GRAM",
-                                    "TNQS_NO_APPLY64", "TNQS_NO_MFMA", "TNQS_EAGER_SCALE"])
+                                    "TNQS_NO_APPLY64", "TNQS_NO_MFMA", "TNQS_EAGER_SCALE", "TNQS_NO_PREFIX"])
 def test_alternative_routes_match_the_default(switch):
     """every documented switch selects an alternative route of the same algorithm: all-eigen factorisation instead
     of Cholesky, Gram-eigen instead of the small-SVD route, global-memory Jacobi, single-leg mode products, per-message BP products,
-    unfused Grams, generic apply, no MFMA kernels at all, eager normalisation.  Same bond dimensions; truncation errors and <Z> to f32
+    unfused Grams, generic apply, no MFMA kernels at all, eager normalisation, no shared partial products in BP.  Same bond dimensions; truncation errors and <Z> to f32
     rounding of the whole layer (bounds 2e-5 / 5e-5; the switch must at least run -- an intermediate version of the per-site Cholesky
     fallback crashed under TNQS_NO_CHOL without any test noticing)."""
     ref, alt = run_worker({}), run_worker({switch: "1"})
