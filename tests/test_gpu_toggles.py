@@ -48,7 +48,7 @@ def test_alternative_routes_match_the_default(switch):
     rounding of the whole layer (bounds 2e-5 / 5e-5; the switch must at least run -- an intermediate version of the per-site Cholesky
     fallback crashed under TNQS_NO_CHOL without any test noticing)."""
     ref, alt = run_worker({}), run_worker({switch: "1"})
-    for name in ("Rzz", "CNOT", "CPHASE", "SWAP", "Rxxyyzz"):
+    for name in ("Rzz", "CNOT", "CPHASE", "SWAP", "Rxxyyzz", "cubic"):       # "cubic": degree-6 sites, two layers
         a, b = ref[name], alt[name]
         assert a["dims"] == b["dims"], name
         assert np.max(np.abs(np.array(a["errs"]) - np.array(b["errs"]))) < 2e-5, name

@@ -25,6 +25,16 @@ def main():
     b3, _ = tn.apply_gates([("Rzz", list(g.edges[5]), 0.4)], bpc, apply_kwargs=dict(maxdim=64, cutoff=None, normalize_tensors=True),
                            bp_update_kwargs=dict(maxiter=2, tolerance=None), info=info)
     out["uncapped"] = dict(dim=b3.bond_dim(*g.edges[5]), lowrank=info["n_lowrank_svd"])
+    # degree-6 sites (3x3x3 periodic cubic, the per-site shape of BASELINE's cubic configuration at a small bond dimension): two layers
+    gc = tn.named_grid((3, 3, 3), periodic=True)
+    psic = tn.random_tensornetworkstate(np.complex64, gc, bond_dimension=3, seed=5)
+    bc = tn.update(tn.BeliefPropagationCache(psic), maxiter=30, tolerance=None)
+    layer = [("Rz", [v], -0.04) for v in gc.vertices] + [("Rxx", [a, b], 0.3) for grp in tn.edge_color(gc) for (a, b) in grp]
+    errs_all = []
+    for _ in range(2):
+        bc, errs = tn.apply_gates(layer, bc, apply_kwargs=dict(maxdim=3, cutoff=1e-10, normalize_tensors=True), bp_update_kwargs=dict(maxiter=20, tolerance=None))
+        errs_all += errs.tolist()
+    out["cubic"] = dict(errs=errs_all, z=[float(np.real(tn.expect(bc, ("Z", [v])))) for v in gc.vertices], dims=[bc.bond_dim(a, b) for a, b in gc.edges])
     print(json.dumps(out))
 
 
