@@ -21,12 +21,14 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
     // same residency policy as the engine: A+V in LDS, else A in LDS with V recovered, else global memory
     const size_t lim = 160 * 1024 - 256;
     size_t lds_av = jacobi_lds_bytes(m, n, true, esz), lds_a = jacobi_lds_bytes(m, n, false, esz);
-    const bool nov = lds_av > lim && lds_a <= lim;
+    const char* fg = std::getenv("TNQS_DBG_NOV_GLOBAL");      // the engine's combination for matrices beyond the LDS: global-memory kernel, V recovered
+    const bool force_global_nov = fg && fg[0] == '1';
+    const bool nov = force_global_nov || (lds_av > lim && lds_a <= lim);
     DBuf dA0((size_t)m * n * esz);
     if (nov) dA0.up(A, (size_t)m * n * esz);
     JacobiItem it{dA.p, nov ? nullptr : dV.p, m, n, (int*)dS.p};
     dI.up(&it, sizeof(it));
-    size_t lds = nov ? lds_a : (lds_av <= lim ? lds_av : 0);
+    size_t lds = force_global_nov ? 0 : (nov ? lds_a : (lds_av <= lim ? lds_av : 0));
     if (dtype == TNQS_C64) launch_jacobi<float>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n)); else launch_jacobi<double>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n));
     if (nov) {
         DBuf dRv(sizeof(RecoverItem)); RecoverItem rv{dA0.p, dA.p, dV.p, m, n, n}; dRv.up(&rv, sizeof(rv));

@@ -1383,7 +1383,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             it.kappa = 0; it.opA = it.opB = nullptr; it.lowA = it.lowB = it.lowG = nullptr; it.lowL = nullptr; it.lowfail = nullptr;
             {   // low-rank route of the theta SVD (GateItem): only where it can apply -- K = kappa chi below the theta columns and chol_kernel's size
                 const int K = kappa[q] * w.chi;
-                if (lowrank_on && kappa[q] > 0 && K < Nc && K <= 96 && cap <= K && Mr >= Nc) {
+                if (lowrank_on && kappa[q] > 0 && K < Nc && K <= 128 && cap <= K && Mr >= Nc) {
                     w.lowA = dalloc(s, (size_t)Mr * K * 16); w.lowB = dalloc(s, (size_t)Nc * K * 16); w.lowG = dalloc(s, (size_t)K * K * 16);
                     w.lowL = dalloc(s, (size_t)K * K * 16); w.lowW = dalloc(s, (size_t)K * K * 16);
                     it.kappa = kappa[q]; it.opA = reinterpret_cast<const double*>(d_gm + offA[q]); it.opB = reinterpret_cast<const double*>(d_gm + offB[q]);
@@ -1408,7 +1408,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     for (int q = 0; q < npg; ++q) { gitems[q].info = reinterpret_cast<int*>(d_info_all->p) + 8 * q; gitems[q].truncerr = reinterpret_cast<double*>(d_terr_all->p) + q; }
     // low-rank route: one failure flag per gate for the Cholesky factorisation of B^dagger B
     Buf d_lowfail = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));
-    for (int q = 0; q < npg; ++q) gitems[q].lowfail = reinterpret_cast<const int*>(d_lowfail->p) + q;
+    Buf d_texp = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));
+    for (int q = 0; q < npg; ++q) { gitems[q].lowfail = reinterpret_cast<const int*>(d_lowfail->p) + q; gitems[q].texp = reinterpret_cast<int*>(d_texp->p) + q; }
     const GateItem* d_gitems = upload(s, gitems);
     auto run_theta = [&]() {
         HIPCHK(hipMemsetAsync(d_info_all->p, 0, std::max<size_t>(1, (size_t)npg * 32), s->stream));
@@ -1422,7 +1423,12 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             lc.push_back(CholItem{gitems[q].lowG, const_cast<void*>(gitems[q].lowL), ws[pg[q]].lowW->p, K, reinterpret_cast<int*>(d_lowfail->p) + q, rank_tau(true, K)});
             kmax = std::max(kmax, K);
         }
-        if (!lc.empty()) { const CholItem* dc = upload(s, lc); launch_lowrank_g(s->stream, d_gitems, npg); launch_chol(s->stream, dc, (int)lc.size(), kmax); launch_lowrank_m(s->stream, d_gitems, npg); }
+        if (!lc.empty()) {
+            const CholItem* dc = upload(s, lc); launch_lowrank_g(s->stream, d_gitems, npg);
+            if (kmax <= 96) launch_chol(s->stream, dc, (int)lc.size(), kmax); else launch_chol_packed(s->stream, dc, (int)lc.size(), kmax);      // only L is used here
+            launch_lowrank_m(s->stream, d_gitems, npg);
+        }
+        launch_theta_scale<T>(s->stream, d_gitems, npg);       // theta (or M) and theta0 to O(1), exponent kept per gate for gate_finish
     };
     run_theta();
     std::vector<int> info(8 * (size_t)ng, 0); std::vector<double> terr(ng, 0.0);

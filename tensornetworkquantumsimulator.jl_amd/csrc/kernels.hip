@@ -318,6 +318,16 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restri
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int ne = n + (n & 1);
     const T tol = eps_of<T>() * sqrt((T)(m > 4 ? m : 4));
+    // scale to ||A||_F = O(1) by an exact power of two for the sweeps (see jacobi_lds_kernel: squared inner products underflow in f32)
+    __shared__ double s_redg[17];
+    double frog = 0;
+    for (int e = threadIdx.x; e < m * n; e += blockDim.x) { cx<T> v = A[e]; frog += (double)v.re * v.re + (double)v.im * v.im; }
+    frog = block_sum(frog, s_redg);
+    int kexp = 0;
+    if (frog > 0 && frog < 1e300) { kexp = -(ilogb(frog) / 2); kexp = kexp > 120 ? 120 : (kexp < -120 ? -120 : kexp); }
+    const T sc_in = (T)ldexp(1.0, kexp), sc_out = (T)ldexp(1.0, -kexp);
+    if (kexp != 0) { for (int e = threadIdx.x; e < m * n; e += blockDim.x) { cx<T> v = A[e]; A[e] = cmake<T>(v.re * sc_in, v.im * sc_in); } }
+    __syncthreads();
     int sweep = 0;
     for (; sweep < max_sweeps && n > 1; ++sweep) {
         if (threadIdx.x == 0) s_rot = 0;
@@ -379,6 +389,8 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restri
         __syncthreads();
         if (!rot) { ++sweep; break; }
     }
+    __syncthreads();
+    if (kexp != 0) { for (int e = threadIdx.x; e < m * n; e += blockDim.x) { cx<T> v = A[e]; A[e] = cmake<T>(v.re * sc_out, v.im * sc_out); } }
     if (threadIdx.x == 0 && it.sweeps_out) *it.sweeps_out = sweep;
 }
 // LDS-resident variant: A (and V when it fits / is wanted) live in LDS for the whole factorisation; global memory is
@@ -574,6 +586,18 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     double fro = 0;
     for (int e = threadIdx.x; e < m * n; e += blockDim.x) { cx<T> v = A[(e % m) + mp * (e / m)]; fro += (double)v.re * v.re + (double)v.im * v.im; }
     fro = block_sum(fro, s_red);
+    // The sweeps square inner products (g^2, alpha*beta): in f32 that underflows for a matrix of small magnitude (theta of a state whose
+    // tensors carry a small norm: singular values 1e-5 already put the products of the smaller columns into the denormal range, the
+    // rotation phases lose their unit modulus and the "rotations" stop being unitary).  The matrix is therefore scaled by an exact power
+    // of two to ||A||_F = O(1) for the sweeps and scaled back when it is written out; V does not change.
+    int kexp = 0;
+    if (fro > 0 && fro < 1e300) { kexp = -(ilogb(fro) / 2); kexp = kexp > 120 ? 120 : (kexp < -120 ? -120 : kexp); }
+    const T sc_in = (T)ldexp(1.0, kexp), sc_out = (T)ldexp(1.0, -kexp);
+    if (kexp != 0) {
+        for (int e = threadIdx.x; e < m * n; e += blockDim.x) { cx<T>& v = A[(e % m) + mp * (e / m)]; v.re *= sc_in; v.im *= sc_in; }
+        fro = ldexp(fro, 2 * kexp);
+        __syncthreads();
+    }
     const T tiny = (T)((double)n * (double)eps_of<T>() * (double)eps_of<T>() * fro);
     const bool full = (m == 16 * RQ) && !(n & 1) && !((n >> 1) & 3);
     int sweep;
@@ -581,7 +605,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     else if (full) sweep = jacobi_lds_sweeps<T, RQ, true>(A, V, hasV, m, n, mp, np_, max_sweeps, tiny, &s_rot);
     else sweep = jacobi_lds_sweeps<T, RQ, false>(A, V, hasV, m, n, mp, np_, max_sweeps, tiny, &s_rot);
     __syncthreads();
-    for (int e = threadIdx.x; e < m * n; e += blockDim.x) Ag[e] = A[(e % m) + mp * (e / m)];
+    for (int e = threadIdx.x; e < m * n; e += blockDim.x) { cx<T> v = A[(e % m) + mp * (e / m)]; Ag[e] = cmake<T>(v.re * sc_out, v.im * sc_out); }
     if (hasV) for (int e = threadIdx.x; e < n * n; e += blockDim.x) Vg[e] = V[(e % n) + np_ * (e / n)];
     if (threadIdx.x == 0 && it.sweeps_out) *it.sweeps_out = sweep;
 }
@@ -777,6 +801,60 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
         int i = e % n, a = e / n;
         W[e] = (i < a) ? A[i + np * a] : (i == a ? cmake<double>(1.0 / A[i + np * i].re, 0.0) : cmake<double>(0, 0));
     }
+}
+// Same factorisation with the lower triangle PACKED in LDS (column j holds rows j..n-1): n up to 128 fits (132 KB), which the low-rank theta
+// route needs at chi = 64 (K = kappa chi = 128).  Only L is produced (CholItem::Winv is not written: the packed layout has no spare triangle
+// for the inverse, and that route does not use it).
+__global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double s_piv; __shared__ double s_dmax;
+    const CholItem it = items[blockIdx.x];
+    const int n = it.n, tid = threadIdx.x;
+    cx<double>* A = reinterpret_cast<cx<double>*>(smem);
+    auto at = [n](int i, int j) { return (size_t)j * n - (size_t)j * (j - 1) / 2 + (i - j); };      // i >= j
+    const cx<double>* G = reinterpret_cast<const cx<double>*>(it.G);
+    for (int e = tid; e < n * n; e += 256) {
+        int i = e % n, j = e / n; if (i < j) continue;
+        cx<double> a = G[i + (size_t)n * j], b = G[j + (size_t)n * i];
+        A[at(i, j)] = cmake<double>(0.5 * (a.re + b.re), 0.5 * (a.im - b.im));
+    }
+    __syncthreads();
+    if (tid == 0) { double m = 0; for (int i = 0; i < n; ++i) m = fmax(m, A[at(i, i)].re); s_dmax = m; }
+    __syncthreads();
+    const double tiny = it.tau * s_dmax;
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) {
+            double d = A[at(k, k)].re;
+            if (!(d > tiny)) { *it.fail = 1; d = (tiny > 0 ? tiny : 1.0); }
+            s_piv = sqrt(d);
+        }
+        __syncthreads();
+        const double inv = 1.0 / s_piv;
+        for (int i = k + tid; i < n; i += 256) {
+            if (i == k) A[at(k, k)] = cmake<double>(s_piv, 0.0);
+            else { cx<double> v = A[at(i, k)]; A[at(i, k)] = cmake<double>(v.re * inv, v.im * inv); }
+        }
+        __syncthreads();
+        const int m = n - k - 1;
+        for (int e = tid; e < m * m; e += 256) {
+            int i = k + 1 + e % m, j = k + 1 + e / m;
+            if (i < j) continue;
+            cx<double> li = A[at(i, k)], lj = A[at(j, k)];
+            cx<double> v = A[at(i, j)];
+            v.re -= li.re * lj.re + li.im * lj.im; v.im -= li.im * lj.re - li.re * lj.im;
+            A[at(i, j)] = v;
+        }
+        __syncthreads();
+    }
+    cx<double>* L = reinterpret_cast<cx<double>*>(it.L);
+    for (int e = tid; e < n * n; e += 256) { int i = e % n, j = e / n; L[e] = (i >= j) ? A[at(i, j)] : cmake<double>(0, 0); }
+}
+void launch_chol_packed(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {
+    if (nitems <= 0) return;
+    const size_t lds = (size_t)nmax * (nmax + 1) / 2 * 16;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)chol_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 256)); attr = true; }
+    hipLaunchKernelGGL(chol_packed_kernel, dim3(nitems), dim3(256), lds, s, d_items); TNQS_CHECK_LAUNCH();
 }
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {
     if (nitems <= 0) return;
@@ -1024,6 +1102,38 @@ __global__ __launch_bounds__(1024) void lowrank_m_kernel(const GateItem* __restr
         th[e] = cmake<T>((T)acc.re, (T)acc.im);
     }
 }
+// theta, theta0 *= 2^k with k = -exponent of the largest |entry| of theta0 (exact); *texp = k.  Runs after gate_theta / lowrank_m.
+template <class T>
+__global__ __launch_bounds__(1024) void theta_scale_kernel(const GateItem* __restrict__ items) {
+    __shared__ float s_max[16];
+    __shared__ int s_k;
+    const GateItem it = items[blockIdx.x];
+    const int ne = it.info[0] * it.d1 * it.info[1] * it.d2;
+    cx<T>* th = reinterpret_cast<cx<T>*>(it.theta);
+    cx<T>* th0 = reinterpret_cast<cx<T>*>(it.theta0);
+    float mx = 0.f;
+    for (int e = threadIdx.x; e < ne; e += blockDim.x) { cx<T> v = th0[e]; mx = fmaxf(mx, fmaxf(fabsf((float)v.re), fabsf((float)v.im))); }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m2 = 0.f; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m2 = fmaxf(m2, s_max[w]);
+        int k = 0;
+        if (m2 > 0.f && m2 < 3e38f) { k = -ilogbf(m2); k = k > 120 ? 120 : (k < -120 ? -120 : k); }
+        s_k = k; *it.texp = k;
+    }
+    __syncthreads();
+    const int k = s_k;
+    if (k == 0) return;
+    const T sc = (T)ldexp(1.0, k);
+    for (int e = threadIdx.x; e < ne; e += blockDim.x) { cx<T> a = th[e], b = th0[e]; th[e] = cmake<T>(a.re * sc, a.im * sc); th0[e] = cmake<T>(b.re * sc, b.im * sc); }
+}
+template <class T> void launch_theta_scale(hipStream_t s, const GateItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((theta_scale_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+template void launch_theta_scale<float>(hipStream_t, const GateItem*, int);
+template void launch_theta_scale<double>(hipStream_t, const GateItem*, int);
 void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
     hipLaunchKernelGGL((lowrank_m_kernel<float>), dim3(nitems, 4), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
@@ -1109,10 +1219,11 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
     const cx<T>* th = reinterpret_cast<const cx<T>*>(it.theta);      // rotated columns: U Sigma (or V Sigma when wide)
     const cx<T>* tv = reinterpret_cast<const cx<T>*>(it.thetaV);     // accumulated rotations: V (or U when wide)
     const int ncolK = (!wide && it.info[7] > 0) ? it.info[7] : ncol;        // low-rank route: the remaining singular values are zero
+    const double tsc = ldexp(1.0, -(*it.texp));                               // theta was scaled by 2^texp
     for (int u = threadIdx.x; u < ncol; u += blockDim.x) {
         double s2 = 0;
         if (u < ncolK) for (int i = 0; i < ld; ++i) { cx<T> v = th[i + (size_t)ld * u]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
-        sig[u] = (s2 == s2 && s2 < 1e300) ? sqrt(s2) : 0.0;     // a NaN / inf column must not poison the ranking below
+        sig[u] = (s2 == s2 && s2 < 1e300) ? sqrt(s2) * tsc : 0.0;     // a NaN / inf column must not poison the ranking below; tsc undoes theta_scale_kernel
     }
     __syncthreads();
     for (int u = threadIdx.x; u < ncol; u += blockDim.x) {    // rank by counting (descending, stable)
@@ -1170,7 +1281,7 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
             for (int a = 0; a < r1; ++a) {
                 cx<double> w = V1[kk + (size_t)n1 * it.idx1[a]];
                 cx<T> l = wide ? tv[(a + r1 * s1p) + (size_t)Mr * pu] : th[(a + r1 * s1p) + (size_t)Mr * pu];
-                double f = 1.0 / sqrt(it.lam1[a]);
+                double f = (wide ? 1.0 : tsc) / sqrt(it.lam1[a]);      // th holds the scaled U Sigma (tv, the recovered vectors, is scale free)
                 cx<double> lv = cmake<double>(l.re * f, l.im * f);
                 cfma(acc, w, lv);
             }
@@ -1190,7 +1301,7 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
             for (int c = 0; c < r2; ++c) {
                 cx<double> w = V2[kk + (size_t)n2 * it.idx2[c]];
                 cx<T> v = wide ? th[(c + r2 * s2p) + (size_t)Nc * pu] : tv[(c + r2 * s2p) + (size_t)Nc * pu];
-                double f = 1.0 / sqrt(it.lam2[c]);
+                double f = (wide ? tsc : 1.0) / sqrt(it.lam2[c]);
                 cx<double> vd = cmake<double>(v.re * f, -v.im * f);
                 cfma(acc, w, vd);
             }

@@ -81,7 +81,11 @@ struct GateItem {         // everything the per-gate small-algebra kernels need 
     // chol_kernel factors G = L L^dagger and lowrank_m_kernel overwrites the first K columns of theta with M = A conj(L), whose left
     // singular vectors and singular values are theta's (theta = M Q^T, Q = B L^-dagger orthonormal).  info[7] = columns the SVD runs on.
     int kappa; const double* opA; const double* opB; void* lowA; void* lowB; void* lowG; const void* lowL; const int* lowfail;
+    // theta (or its low-rank factor) and theta0 are scaled by 2^(*texp) so that their largest entry is O(1) (theta_scale_kernel): the f32
+    // SVD pipeline squares and multiplies these entries; gate_finish puts the factor back into the singular values
+    int* texp;
 };
+template <class T> void launch_theta_scale(hipStream_t s, const GateItem* d_items, int nitems);
 void launch_lowrank_g(hipStream_t s, const GateItem* d_items, int nitems);
 void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems);
 // Second factorisation pass of an ill-conditioned ComplexF64 site (CholeskyQR2).  With the first-pass factor R1 (interface of
@@ -149,6 +153,7 @@ void launch_small_svd_finish(hipStream_t s, const SmallSvdItem* d_items, int nit
 __host__ __device__ inline double rank_tau(bool f32_state, int n) { return f32_state ? 1e-12 : 4.0 * (double)n * 2.220446049250313e-16; }
 struct CholItem { const void* G; void* L; void* Winv; int n; int* fail; double tau; };
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax);
+void launch_chol_packed(hipStream_t s, const CholItem* d_items, int nitems, int nmax);      // L only, n <= 128 (packed triangle in LDS)
 template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax);
 void launch_recover_v_mfma(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax);    // ComplexF32, MFMA (kernels_mfma.hip)
 template <class T> void launch_env_prepare(hipStream_t s, const EnvItem* d_items, int nitems);

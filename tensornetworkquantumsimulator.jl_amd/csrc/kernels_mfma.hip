@@ -1278,12 +1278,12 @@ __global__ __launch_bounds__(256) void recover_v_mfma_kernel(const RecoverItem* 
     v16f Cr, Ci;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }
-    float s2 = 0.f;                                           // |a_u|^2 (rows split over the two half waves)
+    double s2 = 0.0;                                          // |a_u|^2 (rows split over the two half waves); double: squares of small f32 columns underflow
     for (int k0 = 0; k0 < m; k0 += 2) {
         const int row = k0 + h;
         cf a = {0.f, 0.f}, b = {0.f, 0.f};
         if (row < m) { if (okc) a = pa[row]; if (oku) b = pb[row]; }
-        s2 += b.re * b.re + b.im * b.im;
+        s2 += (double)b.re * b.re + (double)b.im * b.im;
         // C[col][u] += conj(a) * b
         Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.re, b.re, Cr, 0, 0, 0);
         Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.im, b.im, Cr, 0, 0, 0);
@@ -1291,12 +1291,12 @@ __global__ __launch_bounds__(256) void recover_v_mfma_kernel(const RecoverItem* 
         Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.im, b.re, Ci, 0, 0, 0);
     }
     s2 += __shfl_xor(s2, 32, 64);                             // lane ln (and ln+32) now hold |a_{u0+ln}|^2
-    const float inv = s2 > 0.f ? 1.0f / s2 : 0.f;
+    const double inv = s2 > 0.0 ? 1.0 / s2 : 0.0;
     if (oku) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;      // C[row = col index][col = u = ln]
-            if (c < n) { cf v; v.re = Cr[r] * inv; v.im = Ci[r] * inv; V[c + (size_t)n * u] = v; }
+            if (c < n) { cf v; v.re = (float)(Cr[r] * inv); v.im = (float)(Ci[r] * inv); V[c + (size_t)n * u] = v; }
         }
     }
 }

@@ -248,3 +248,25 @@ def test_double_pair_gram(chi, lx, ly):
         axes = [a for a in range(z + 1) if a != 1 + kept]
         ref = np.tensordot(xm, ty.conj(), axes=(axes, axes))
         assert np.max(np.abs(got.reshape(32, 32).T - ref)) < 3e-5 * np.max(np.abs(ref)) * scale
+
+
+@pytest.mark.parametrize("shape,rank", [((64, 64), 64), ((128, 128), 64), ((144, 144), 72), ((200, 120), 120)])
+@pytest.mark.parametrize("scale", [1e-18, 1e-10, 1e-5, 1.0, 1e12])
+def test_jacobi_svd_is_scale_invariant(shape, rank, scale):
+    """ComplexF32: the sweeps square inner products, which underflows for matrices of small magnitude (singular values of 1e-5 are
+    enough: the rotation phases of the smaller columns lose their unit modulus).  Both kernels (LDS-resident up to 136 rows here, global
+    memory beyond) scale the matrix by an exact power of two first.  Before that fix the global-memory kernel returned singular values
+    off by 20-40 % for theta matrices of chi >= 36 whose tensors carried a small norm; the LDS kernel skipped rotations below 1e-36."""
+    rng = np.random.default_rng(shape[0] + rank)
+    m, n = shape
+    b0 = (rnd(rng, (m, rank), np.complex128) @ rnd(rng, (rank, n), np.complex128)) / rank
+    b = (b0 * scale).astype(np.complex64)
+    s_ref = np.linalg.svd(b.astype(np.complex128), compute_uv=False)
+    A, V, sw = jacobi(b, 0)
+    s = np.sort(np.linalg.norm(A.astype(np.complex128), axis=0))[::-1]
+    assert sw < 60
+    assert np.max(np.abs(s[:len(s_ref)] - s_ref)) < 3e-5 * s_ref[0]
+    assert np.all(np.isfinite(V))
+    if scale >= 1e-15:                                   # V is recovered by an f32 GEMM of theta0 with U Sigma: its products underflow below ~1e-18;
+        rec = (A.astype(np.complex128) @ V.conj().T.astype(np.complex128))      # inside the engine theta is scaled to O(1) first (theta_scale_kernel)
+        assert np.max(np.abs(rec - b)) < 2e-5 * s_ref[0]

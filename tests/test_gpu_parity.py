@@ -829,3 +829,60 @@ def test_random_nonunitary_c128_circuits_match_oracle(seed):
     assert np.max(np.abs(errs - np.array(oerrs))) < 1e-11
     for v in g.vertices:
         assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oo, Z, v)) < 1e-12
+
+
+@pytest.mark.parametrize("chi", [36, 48])
+def test_theta_svd_beyond_the_lds_matches_oracle(chi):
+    """chi >= 36: theta of a bulk gate is 4 chi x 4 chi >= 144 x 144 and no longer fits the LDS, so a gate of operator Schmidt rank 4 (full
+    theta) runs its SVD in the global-memory Jacobi kernel, a rank-2 gate on the low-rank factor.  Site tensors with a small norm (as the
+    benchmark's random states) make theta small (singular values ~1e-5), which is what exposed the f32 underflow in that kernel: singular
+    values off by 30 % at chi = 36 ... 64 while every existing test stayed green (they use chi <= 34 or tolerances in absolute terms).
+    One gate at a time on the centre of a 3x3 grid against the oracle: spectrum to 2e-5 of the largest value, truncation errors to 1e-4
+    relative, route as expected."""
+    from helpers import oracle_cache_from_device
+    g = tn.named_grid((3, 3))
+    psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=chi, seed=4)
+    for v in g.vertices:                                   # small-norm tensors, like bench.py's synthetic state
+        t = psi.tensors[v]; psi.tensors[v] = (t / np.linalg.norm(t) / np.sqrt(t.size)).astype(np.complex64)
+    bpkw = dict(maxiter=4, tolerance=None, edge_sequence=tn.forest_cover_edge_sequence(g))
+    bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
+    bo = oracle_cache_from_device(bd)
+    kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+    c = g.vertices[4]; nb = list(g.neighbors(c))[0]
+    for gt, lowrank in ((("Rzz", [c, nb], 0.02), 1), (("Rxxyyzz", [nb, c], 0.7), 0), (("SWAP", [c, nb]), 0), (("CNOT", [c, nb]), 1)):
+        info = {}
+        b2, ed = tn.apply_gates([gt], bd, apply_kwargs=kw, bp_update_kwargs=bpkw, update_cache=False, info=info)
+        o2, eo = o.apply_gates([gt], bo, apply_kwargs=kw, bp_update_kwargs=bpkw, update_cache=False)
+        assert info["n_lowrank_svd"] == lowrank, gt[0]
+        assert b2.bond_dim(c, nb) == o2.tns.bond_dim(c, nb)
+        sd = np.sort(np.abs(np.diag(b2.message((c, nb)))))[::-1]; so = np.sort(np.abs(np.diag(o2.message((c, nb)))))[::-1]
+        assert np.max(np.abs(sd / sd[0] - so / so[0])) < 2e-5, gt[0]
+        assert abs(ed[0] - eo[0]) < 1e-4 * eo[0] + 1e-9, (gt[0], ed[0], eo[0])
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1e-9, 1e6])
+def test_gate_path_is_invariant_under_the_norm_of_the_tensors(scale):
+    """ComplexF32 with normalize_tensors = false (imaginary-time runs): tensor norms drift by orders of magnitude, and the SVD pipeline
+    squares and multiplies entries of theta in f32.  theta is scaled to O(1) by an exact power of two per gate (theta_scale_kernel) and the
+    factor goes back into the singular values, so bond dimensions, relative truncation errors and <Z> must not depend on an overall factor
+    on the site tensors (theta scales with its square: 1e-18 for 1e-9)."""
+    g = tn.named_grid((4, 4))
+    psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=8, seed=21)
+    layer = [("Rx", [v], 0.3) for v in g.vertices] + [("Rzz", [a, b], 0.4) for grp in tn.edge_color(g) for (a, b) in grp]
+    layer += [("SWAP", list(g.edges[0])), ("Rxxyyzz", list(g.edges[7]), 0.5)]
+    kw = dict(maxdim=8, cutoff=1e-10, normalize_tensors=False)
+    bpkw = fixed(12)
+
+    def run(c):
+        t = {v: (psi.tensors[v] * np.float32(c)).astype(np.complex64) for v in g.vertices}
+        bpc = tn.update(tn.BeliefPropagationCache(tn.TensorNetworkState(g, t)), **bpkw)
+        out = []
+        for _ in range(2):
+            bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=bpkw)
+            out.append((errs, tn.expect_all(bpc, "Z").real, [bpc.bond_dim(a, b) for (a, b) in g.edges]))
+        return out
+
+    ref, alt = run(1.0), run(scale)
+    for (e0, z0, d0), (e1, z1, d1) in zip(ref, alt):
+        assert d0 == d1
+        assert np.max(np.abs(e0 - e1)) < 2e-6 and np.max(np.abs(z0 - z1)) < 2e-5
