@@ -45,13 +45,16 @@ def test_alternative_routes_match_the_default(switch):
     """every documented switch selects an alternative route of the same algorithm: all-eigen factorisation instead
     of Cholesky, Gram-eigen instead of the small-SVD route, global-memory Jacobi, single-leg mode products, per-message BP products,
     unfused Grams, generic apply, no MFMA kernels at all, eager normalisation, no shared partial products in BP.  Same bond dimensions; truncation errors and <Z> to f32
-    rounding of the whole layer (bounds 2e-5 / 5e-5; the switch must at least run -- an intermediate version of the per-site Cholesky
+    rounding of the whole layer (bounds 2e-3 relative / 5e-5; the switch must at least run -- an intermediate version of the per-site Cholesky
     fallback crashed under TNQS_NO_CHOL without any test noticing)."""
     ref, alt = run_worker({}), run_worker({switch: "1"})
     for name in ("Rzz", "CNOT", "CPHASE", "SWAP", "Rxxyyzz", "cubic"):       # "cubic": degree-6 sites, two layers
         a, b = ref[name], alt[name]
         assert a["dims"] == b["dims"], name
-        assert np.max(np.abs(np.array(a["errs"]) - np.array(b["errs"]))) < 2e-5, name
+        ea, eb = np.array(a["errs"]), np.array(b["errs"])
+        # relative: an absolute 2e-5 here once hid a 6 % error in truncation errors of 1e-4 (the f32 underflow of the global-memory Jacobi
+        # kernel, DESIGN.md 4.2, ran under TNQS_JACOBI_GLOBAL at every size and this test stayed green)
+        assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7), (name, float(np.max(np.abs(ea - eb))))
         assert np.max(np.abs(np.array(a["z"]) - np.array(b["z"]))) < 5e-5, name
 
 
