@@ -108,3 +108,10 @@ def exact_two_site(bo, a, b, gate):
     T0 = np.moveaxis(T0, na, 1)                                           # [s_a, s_b, outer a..., outer b...]
     Tex = np.tensordot(np.asarray(gate, dtype=np.complex128).reshape(da, db, da, db), T0, axes=([2, 3], [0, 1]))
     return np.moveaxis(Tex, 1, na)
+
+
+def c64_errs_close(errs, oerrs, rel=2e-3, floor=3e-7):
+    """ComplexF32 truncation errors against the oracle: relative (an absolute 1e-5 would pass a 10 % error on a truncation error of 1e-4),
+    with a floor at the f32 rounding level of the normalised spectrum"""
+    e, f = np.asarray(errs, dtype=float), np.asarray(oerrs, dtype=float)
+    return bool(np.all(np.abs(e - f) < rel * np.maximum(np.abs(e), np.abs(f)) + floor))

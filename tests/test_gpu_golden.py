@@ -1,10 +1,11 @@
 """GPU: the HIP path (through the C ABI) against the committed golden fixtures (tests/golden/*.npz).  These tests do
-not need the oracle at run time.  Tolerances: complex128 1e-8 (<Z>, spectra, truncation errors), complex64 3e-4 / 1e-5."""
+not need the oracle at run time.  Tolerances: complex128 1e-8 (<Z>, spectra, truncation errors), complex64 3e-4 / truncation errors 2e-3 relative."""
 import numpy as np
 import pytest
 
 import tnqs_amd as tn
 from golden_util import load, layer_from_meta, TFIM_CASES, BP_CASES
+from helpers import c64_errs_close
 
 pytestmark = pytest.mark.gpu
 
@@ -39,7 +40,7 @@ def test_apply_gates_matches_golden(name):
         bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=bpkw, info=info)
         assert info["n_updates"] == len(meta["groups"]) + 1
         assert np.array_equal(np.array([bpc.bond_dim(a, b) for (a, b) in g.edges]), z["bond_dims"][l]), l
-        assert np.max(np.abs(errs - z["errs"][l])) < (1e-9 if c128 else 1e-5), l
+        assert (np.max(np.abs(errs - z["errs"][l])) < 1e-9) if c128 else c64_errs_close(errs, z["errs"][l]), l
         scale = (l + 1) * (1e-8 if c128 else 3e-4)
         ez = tn.expect_all(bpc, "Z")
         assert np.max(np.abs(ez - z["expZ"][l])) < scale, (l, np.max(np.abs(ez - z["expZ"][l])))

@@ -1,6 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
 Tolerances: complex128 -> 1e-9 relative on gauge-invariant quantities (messages, S, truncerr, <Z>, state vector);
-complex64 -> 2e-4 on messages / S / <Z>, 1e-5 absolute on truncation errors.  Index work (leg permutations,
+complex64 -> 2e-4 on messages / S / <Z>, 2e-3 relative (floor 3e-7) on truncation errors.  Index work (leg permutations,
 bond dimensions, scheduling counts) is exact."""
 import itertools
 import math
@@ -11,7 +11,7 @@ import pytest
 import tnqs_amd as tn
 import tnqs_oracle as o
 import statevector as sv
-from helpers import (to_oracle_graph, to_oracle_state, oracle_cache_from_device, colour_sequence, tfim_layer)
+from helpers import (to_oracle_graph, to_oracle_state, oracle_cache_from_device, colour_sequence, tfim_layer, c64_errs_close)
 
 pytestmark = pytest.mark.gpu
 
@@ -161,7 +161,7 @@ def test_two_site_gate_on_a_dimer(dtype):
     ref = sv.run_circuit_statevector(to_oracle_graph(g), {v: [0, 1] for v in g.vertices}, circuit)
     assert abs(np.vdot(vec, vec).real - 1) < 10 * tol               # test/test_apply.jl:20
     assert sv.fidelity(vec, ref) > 1 - 10 * tol
-    assert np.allclose(errs, oerrs, atol=1e-5 if dtype == np.complex64 else 1e-12)
+    assert c64_errs_close(errs, oerrs) if dtype == np.complex64 else np.allclose(errs, oerrs, atol=1e-12)
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
@@ -207,7 +207,7 @@ def test_tfim_layers_truncated_match_oracle(dtype, maxdim):
         assert info["n_two_site"] == g.ne()
         for (a, b) in g.edges:
             assert bpc.bond_dim(a, b) == oc.tns.bond_dim(a, b), (layer_no, a, b)
-        assert np.max(np.abs(errs - oerrs)) < (1e-5 if dtype == np.complex64 else 1e-9), (layer_no, errs, oerrs)
+        assert (c64_errs_close(errs, oerrs) if dtype == np.complex64 else np.max(np.abs(errs - oerrs)) < 1e-9), (layer_no, errs, oerrs)
         scale = 30 * (layer_no + 1)
         compare_messages(bpc, oc, scale * tol, spectra=True)
         for v in g.vertices:
@@ -318,7 +318,7 @@ def test_default_tolerance_sweep_counts_and_observables_match_oracle():
         oc, oerrs = o.apply_gates(layer, oc, apply_kwargs=kw, bp_update_kwargs=bpkw, info=oinfo)
         assert info["n_updates"] == oinfo["n_updates"] == 5
         assert info["n_sweeps"] == sum(oinfo["sweeps"]), (layer_no, info["n_sweeps"], oinfo["sweeps"])
-        assert np.max(np.abs(errs - oerrs)) < 1e-5      # c64: the documented absolute tolerance on truncation errors
+        assert c64_errs_close(errs, oerrs)             # c64: 2e-3 relative with a floor of 3e-7
         ez = tn.expect_all(bpc, "Z")
         oez = np.array([o.expect_1site(oc, Z, v) for v in g.vertices])
         assert np.max(np.abs(ez - oez)) < 1e-5          # north-star bar: expectation values within 1e-5
@@ -653,7 +653,7 @@ def test_random_graphs_random_circuits_match_oracle(seed, order):
     dims_dev, dims_ora = [out.bond_dim(a, b) for (a, b) in g.edges], [oo.tns.bond_dim(a, b) for (a, b) in g.edges]
     if dtype == np.complex128 or truncated:
         assert dims_dev == dims_ora
-    assert np.max(np.abs(errs - np.array(oerrs))) < (1e-9 if dtype == np.complex128 else 2e-5)
+    assert (np.max(np.abs(errs - np.array(oerrs))) < 1e-9) if dtype == np.complex128 else c64_errs_close(errs, oerrs)
     for v in g.vertices:
         assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oo, Z, v)) < 20 * tol
     if not truncated:
