@@ -232,3 +232,61 @@ def test_cubic_degree6_chi16_gate_matches_oracle():
         sd = np.sort(np.abs(np.diag(b2.message((a, b)))))[::-1]; so = np.sort(np.abs(np.diag(o2.message((a, b)))))[::-1]
         assert np.max(np.abs(sd / sd[0] - so / so[0])) < 2e-5, gt[0]
         assert abs(ed[0] - eo[0]) < 1e-4 * eo[0] + 1e-9, (gt[0], ed[0], eo[0])
+
+
+def test_c1_full_run_matches_oracle():
+    """BASELINE configs[0] in full: 5x5 TFIM (README quick start: J = 1, hx = 2.5, dt = 0.01), 50 Trotter layers, maxdim 10, ComplexF64,
+    BP with the default stopping rule on an explicit common sweep order -- device against the oracle after every tenth layer:
+    bond dimensions, truncation errors (1e-9 relative), <Z> on every site (bound 1e-9; measured 6.5e-13 after the 50 layers)."""
+    import tnqs_oracle as o
+    from helpers import to_oracle_state
+    g = tn.named_grid((5, 5))
+    groups = tn.edge_color(g, 4)
+    layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+    psi = tn.tensornetworkstate(np.complex128, lambda v: "↑", g)
+    bpkw = dict(edge_sequence=tn.forest_cover_edge_sequence(g))
+    kw = dict(maxdim=10, cutoff=1e-12, normalize_tensors=True)
+    bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
+    bo = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)
+    zop = np.diag([1.0, -1.0]).astype(complex)
+    for it in range(1, 51):
+        bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw)
+        bo, eo = o.apply_gates(layer, bo, apply_kwargs=kw, bp_update_kwargs=bpkw)
+        if it % 10 == 0:
+            eo = np.array(eo)
+            assert [bd.bond_dim(a, b) for (a, b) in g.edges] == [bo.tns.bond_dim(a, b) for (a, b) in g.edges], it
+            assert np.all(np.abs(ed - eo) < 1e-9 * np.maximum(ed, eo) + 1e-18), (it, float(np.max(np.abs(ed - eo))))
+            zd = tn.expect_all(bd, "Z").real
+            zo = np.array([o.expect_1site(bo, zop, v).real for v in g.vertices])
+            print(f"C1 layer {it}: max|dZ| {np.max(np.abs(zd - zo)):.1e}  max rel derr {np.max(np.abs(ed - eo) / np.maximum(np.maximum(ed, eo), 1e-300)):.1e}  chi {bd.maxvirtualdim()}")
+            assert np.max(np.abs(zd - zo)) < 1e-9, (it, float(np.max(np.abs(zd - zo))))
+
+
+def test_c3_layers_match_oracle():
+    """BASELINE configs[2]: heavy-hex (5,5), Rx(0.4) + Rzz(pi/2) layers (examples/heavyhexIsing_dynamics.jl), maxdim 16, ComplexF32, five
+    layers from the product state with a common explicit sweep order and a fixed number of sweeps: bond dimensions, truncation errors
+    (relative), <Z> to 2e-4 against the oracle (measured 9.4e-7 after five layers, chi = 16)."""
+    import tnqs_oracle as o
+    from helpers import to_oracle_state, c64_errs_close
+    g = tn.heavy_hexagonal_lattice(5, 5)
+    groups = tn.edge_color(g, 3)
+    layer = [("Rx", [v], 0.4) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rzz", [a, b], np.pi / 2) for (a, b) in grp]
+    psi = tn.tensornetworkstate(np.complex64, lambda v: "↑", g)
+    bpkw = dict(edge_sequence=tn.forest_cover_edge_sequence(g), maxiter=6, tolerance=None)
+    kw = dict(maxdim=16, cutoff=1e-12, normalize_tensors=True)
+    bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
+    bo = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)
+    zop = np.diag([1.0, -1.0]).astype(complex)
+    for it in range(5):
+        bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw)
+        bo, eo = o.apply_gates(layer, bo, apply_kwargs=kw, bp_update_kwargs=bpkw)
+        assert [bd.bond_dim(a, b) for (a, b) in g.edges] == [bo.tns.bond_dim(a, b) for (a, b) in g.edges], it
+        assert c64_errs_close(ed, eo, rel=5e-3, floor=1e-6), (it, float(np.max(np.abs(ed - np.array(eo)))))
+        zd = tn.expect_all(bd, "Z").real
+        zo = np.array([o.expect_1site(bo, zop, v).real for v in g.vertices])
+        print(f"C3 layer {it}: max|dZ| {np.max(np.abs(zd - zo)):.1e}  max|derr| {np.max(np.abs(ed - np.array(eo))):.1e}  max err {max(eo):.1e}  chi {bd.maxvirtualdim()}")
+        assert np.max(np.abs(zd - zo)) < 2e-4, (it, float(np.max(np.abs(zd - zo))))
