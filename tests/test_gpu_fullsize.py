@@ -290,3 +290,43 @@ def test_c3_layers_match_oracle():
         zo = np.array([o.expect_1site(bo, zop, v).real for v in g.vertices])
         print(f"C3 layer {it}: max|dZ| {np.max(np.abs(zd - zo)):.1e}  max|derr| {np.max(np.abs(ed - np.array(eo))):.1e}  max err {max(eo):.1e}  chi {bd.maxvirtualdim()}")
         assert np.max(np.abs(zd - zo)) < 2e-4, (it, float(np.max(np.abs(zd - zo))))
+
+
+def test_c2_shape_layer_matches_oracle():
+    """BASELINE configs[1] at the size the oracle can follow: 4x4 grid, chi = 32, ComplexF32, small-norm random tensors as in bench.py, ONE
+    full TFIM layer with the benchmark's gates and apply_kwargs (Rx on every site, Rzz per edge colour, the BP updates in between; explicit
+    common sweep order, two sweeps per update).  The four bulk sites run the whole MFMA path -- pair products, double pair-Gram, f64 Gram,
+    Cholesky, low-rank theta SVD, apply64, deferred normalisation.  Truncation errors (relative), bond dimensions, <Z> and message spectra;
+    measured: <Z> to 1.8e-6, truncation errors to 4e-6 relative (1e-4 in size), message spectra to 1.4e-7."""
+    import tnqs_oracle as o
+    from helpers import to_oracle_state, c64_errs_close
+    g = tn.named_grid((4, 4))
+    chi = 32
+    psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=chi, seed=12)
+    for v in g.vertices:
+        t = psi.tensors[v]; psi.tensors[v] = (t / np.linalg.norm(t) / np.sqrt(t.size)).astype(np.complex64)
+    groups = tn.edge_color(g, 4)
+    layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+    bpkw = dict(edge_sequence=tn.forest_cover_edge_sequence(g), maxiter=2, tolerance=None)
+    kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+    bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
+    bo = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)
+    info = {}
+    bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw, info=info)
+    bo, eo = o.apply_gates(layer, bo, apply_kwargs=kw, bp_update_kwargs=bpkw)
+    assert info["n_updates"] == 5 and info["n_lowrank_svd"] > 0
+    assert [bd.bond_dim(a, b) for (a, b) in g.edges] == [bo.tns.bond_dim(a, b) for (a, b) in g.edges]
+    assert c64_errs_close(ed, eo, rel=5e-3, floor=1e-6), float(np.max(np.abs(ed - np.array(eo))))
+    zop = np.diag([1.0, -1.0]).astype(complex)
+    zd = tn.expect_all(bd, "Z").real
+    zo = np.array([o.expect_1site(bo, zop, v).real for v in g.vertices])
+    worst = 0.0
+    for (a, b) in g.edges:
+        for e in ((a, b), (b, a)):
+            md, mo = bd.message(e).astype(np.complex128), np.asarray(bo.message(e), dtype=np.complex128)
+            wd, wo = np.linalg.eigvalsh((md + md.conj().T) / 2), np.linalg.eigvalsh((mo + mo.conj().T) / 2)
+            worst = max(worst, float(np.max(np.abs(wd / wd.sum() - wo / wo.sum()))))
+    print(f"C2 shape, one layer: max|dZ| {np.max(np.abs(zd - zo)):.1e}  max|derr| {np.max(np.abs(ed - np.array(eo))):.1e} (max err {max(eo):.1e})  message spectra {worst:.1e}")
+    assert np.max(np.abs(zd - zo)) < 2e-4 and worst < 2e-4
