@@ -462,14 +462,15 @@ def message_diff(a: np.ndarray, b: np.ndarray) -> float:
     return float(1 - f)
 
 
-def update(bpc: BeliefPropagationCache, maxiter: Optional[int] = None, tolerance="default",
+def update(bpc: BeliefPropagationCache, maxiter: Optional[int] = None, tolerance: Optional[float] = None,
            edge_sequence: Optional[List[DEdge]] = None, normalize: bool = True, info: Optional[dict] = None):
-    """abstract...:223-259 (Gauss-Seidel over edge_sequence, newest messages used immediately)."""
+    """abstract...:223-259 (Gauss-Seidel over edge_sequence, newest messages used immediately).  Defaults as set_default_kwargs
+    (beliefpropagationcache.jl:63-72): maxiter = default_bp_maxiter (25, 1 on trees; :39), tolerance = nothing (:62) -- i.e. a bare
+    `update(bpc)` or `update(bpc; maxiter = 10)` never checks convergence; the dtype tolerance only comes with default_bp_update_kwargs
+    (:110-117), which apply_gates / truncate use when bp_update_kwargs is omitted."""
     dk = bpc.default_bp_update_kwargs()
     if maxiter is None:
         maxiter = dk["maxiter"]
-    if tolerance == "default":
-        tolerance = dk["tolerance"]
     seq = edge_sequence if edge_sequence is not None else bpc.edge_sequence
     bpc = bpc.copy()
     niter, avg = maxiter, None
@@ -662,7 +663,7 @@ def apply_gates(circuit: Sequence, bpc: BeliefPropagationCache, apply_kwargs: Op
                 bp_update_kwargs: Optional[dict] = None, update_cache: bool = True, info: Optional[dict] = None):
     """apply_gates (apply_gates.jl:46-98): returns (new cache, truncation errors)."""
     apply_kwargs = dict(apply_kwargs or {})
-    bp_kw = dict(bp_update_kwargs) if bp_update_kwargs is not None else {}
+    bp_kw = dict(bp_update_kwargs) if bp_update_kwargs is not None else bpc.default_bp_update_kwargs()   # :51
     bpc = bpc.copy()                                                                # :55
     affected = set()
     errs = np.zeros(len(circuit))
@@ -693,7 +694,7 @@ def truncate(bpc: BeliefPropagationCache, maxdim: int, cutoff=None, normalize_te
              bp_update_kwargs: Optional[dict] = None):
     """truncate.jl:12-38 (edge_color=true branch; colouring supplied by the caller)."""
     bpc = bpc.copy()
-    bp_kw = dict(bp_update_kwargs) if bp_update_kwargs is not None else {}
+    bp_kw = dict(bp_update_kwargs) if bp_update_kwargs is not None else bpc.default_bp_update_kwargs()    # truncate.jl:12
     if edge_groups is None:
         edge_groups = edge_color(bpc.g)
     for eg in edge_groups:

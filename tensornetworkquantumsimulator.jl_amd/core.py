@@ -231,9 +231,13 @@ def default_bp_update_kwargs(x) -> dict:
     return dict(maxiter=25, tolerance=default_tolerance(x.dtype))
 
 
-def _bp_opts(g: NamedGraph, kw: Optional[dict]):
-    """kwargs of `update` -> tnqs_bp_opts (+ the arrays that must stay alive during the call)"""
-    kw = dict(kw or {})
+def _bp_opts(g: NamedGraph, kw: Optional[dict], defaults: Optional[dict] = None):
+    """kwargs of `update` -> tnqs_bp_opts (+ the arrays that must stay alive during the call).
+    `kw is None` means the caller omitted `bp_update_kwargs` altogether: `defaults` (= default_bp_update_kwargs, the only
+    place where the reference carries a tolerance, beliefpropagationcache.jl:110-117) applies.  An explicit kwargs set
+    without `tolerance` means NO convergence check, exactly like `update(bpc; maxiter = 10)` in the reference
+    (`default_tolerance(::Algorithm"bp") = nothing`, beliefpropagationcache.jl:62-67)."""
+    kw = dict(defaults or {}) if kw is None else dict(kw)
     o = L.BpOpts()
     keep = []
     unknown = set(kw) - {"maxiter", "tolerance", "edge_sequence", "normalize", "verbose"}
@@ -241,10 +245,8 @@ def _bp_opts(g: NamedGraph, kw: Optional[dict]):
         raise TypeError(f"update: unknown keyword(s) {sorted(unknown)}")
     mi = kw.get("maxiter")
     o.maxiter = int(mi) if mi is not None else 0
-    if "tolerance" not in kw:
-        o.tolerance = float("nan")                 # reference default for the dtype / graph
-    else:
-        o.tolerance = -1.0 if kw["tolerance"] is None else float(kw["tolerance"])
+    tol = kw.get("tolerance")
+    o.tolerance = -1.0 if tol is None else float(tol)
     o.normalize = 1 if kw.get("normalize", True) else 0
     seq = kw.get("edge_sequence")
     if seq is not None:
@@ -268,9 +270,6 @@ def update(bpc: BeliefPropagationCache, info: Optional[dict] = None, **kwargs) -
     niter, diff = C.c_int(), C.c_double()
     L.check(L.lib.tnqs_bp_update(out._h, C.byref(o), C.byref(niter), C.byref(diff)))
     tol = o.tolerance
-    if math.isnan(tol):
-        dk = bpc.default_bp_update_kwargs()
-        tol = -1.0 if dk["tolerance"] is None else dk["tolerance"]
     if tol >= 0:
         if diff.value <= tol:
             if verbose:
@@ -307,7 +306,8 @@ def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_
     psi may be a TensorNetworkState (wrapped, BP-updated first, network returned; apply_gates.jl:17-27) or a
     BeliefPropagationCache (returned as a new cache; the input is untouched, :55)."""
     if isinstance(psi, TensorNetworkState):
-        bpc = update(BeliefPropagationCache(psi), **(bp_update_kwargs or {}))
+        b0 = BeliefPropagationCache(psi)
+        bpc = update(b0, **(b0.default_bp_update_kwargs() if bp_update_kwargs is None else bp_update_kwargs))
         out, errs = apply_gates(circuit, bpc, apply_kwargs=apply_kwargs, bp_update_kwargs=bp_update_kwargs,
                                 update_cache=update_cache, verbose=verbose, info=info)
         return out.network(), errs
@@ -328,7 +328,7 @@ def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_
     mat_a = np.ascontiguousarray(np.concatenate(mats) if mats else np.zeros(1, dtype=np.complex128))
     errs = np.zeros(max(ng, 1), dtype=np.float64)
     ao = _apply_opts(apply_kwargs, update_cache)
-    bo, keep = _bp_opts(g, bp_update_kwargs)
+    bo, keep = _bp_opts(g, bp_update_kwargs, psi.default_bp_update_kwargs())
     st = L.ApplyStats()
     out = psi.copy()
     L.check(L.lib.tnqs_apply_gates(out._h, ng, nv_p, vs_p, mat_a.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ao),
@@ -364,7 +364,7 @@ def truncate(bpc: BeliefPropagationCache, maxdim: int, cutoff: Optional[float] =
     o_a, o_p = L.i32(offs)
     u_a, u_p = L.i32(eu if eu else [0])
     v_a, v_p = L.i32(ev if ev else [0])
-    bo, keep = _bp_opts(g, bp_update_kwargs)
+    bo, keep = _bp_opts(g, bp_update_kwargs, bpc.default_bp_update_kwargs())
     st = L.ApplyStats()
     out = bpc.copy()
     L.check(L.lib.tnqs_truncate(out._h, int(maxdim), -1.0 if cutoff is None else float(cutoff), 1 if normalize_tensors else 0,
@@ -490,7 +490,7 @@ def normalize(tns: TensorNetworkState, alg: str = "bp", cache_update_kwargs=None
     if alg != "bp":
         raise L.TnqsError(f"normalize: only alg = \"bp\" is implemented on the HIP path; received {alg!r}")
     bpc = BeliefPropagationCache(tns, device=device)
-    bpc = update(bpc, **(cache_update_kwargs or {}))
+    bpc = update(bpc, **(bpc.default_bp_update_kwargs() if cache_update_kwargs is None else cache_update_kwargs))
     return rescale(bpc).network()
 
 

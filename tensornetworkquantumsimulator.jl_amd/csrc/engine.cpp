@@ -399,6 +399,7 @@ static void tile_params(size_t PA, size_t PB, int TR, int& TA, int& TB, int& nta
 }
 
 static void exchange(State* s, size_t bytes_per_rank);
+static void check_exchange(const State* s, size_t bytes_per_rank);      // call BEFORE enqueuing anything that writes into s->exch
 static size_t round256(size_t b);
 
 // a chain = one site tensor pushed through several mode products (leg j with matrix X_j, chi_j x chi_j)
@@ -569,7 +570,41 @@ struct BPPlan {
 // messages of a site inside a forest share one pair product.  It is an ordinary sequential Gauss-Seidel order.
 struct DSU { std::vector<int> p; explicit DSU(int n) : p(n) { std::iota(p.begin(), p.end(), 0); } int f(int x) { while (p[x] != x) x = p[x] = p[p[x]]; return x; }
              bool join(int a, int b) { a = f(a); b = f(b); if (a == b) return false; p[a] = b; return true; } };
+// Forests: the reference's own default order (NamedGraphs forest_cover_edge_sequence: per component, post-order DFS edges towards the
+// root, then their reverses in reverse order).  With it ONE sweep is exact on a tree -- which is what the reference's tree defaults
+// (maxiter = 1, no tolerance; beliefpropagationcache.jl:39,110-113) rely on.  The linear-forest order below lists every message BEFORE
+// the one it depends on (so that a forest is one level), i.e. information moves one hop per sweep: right for loopy graphs, where the
+// fixed point is iterated anyway, wrong for the single sweep of a tree.
+static std::vector<int> tree_sequence(const Graph& g) {
+    std::vector<int> seq; std::vector<char> seen(g.nv, 0);
+    for (int root = 0; root < g.nv; ++root) {
+        if (seen[root] || g.nbr[root].empty()) continue;
+        std::vector<std::pair<int, int>> post;                          // (child, parent)
+        std::vector<std::pair<int, size_t>> stack{{root, 0}}; std::vector<int> par(1, -1);
+        seen[root] = 1;
+        while (!stack.empty()) {
+            auto& top = stack.back(); const int x = top.first;
+            bool pushed = false;
+            while (top.second < g.nbr[x].size()) {
+                const int y = g.nbr[x][top.second++];
+                if (seen[y]) continue;
+                seen[y] = 1; stack.push_back({y, 0}); par.push_back(x); pushed = true; break;
+            }
+            if (pushed) continue;
+            if (par.back() >= 0) post.push_back({x, par.back()});
+            stack.pop_back(); par.pop_back();
+        }
+        for (auto& e : post) seq.push_back(g.dedge(e.first, e.second));
+        for (auto it = post.rbegin(); it != post.rend(); ++it) seq.push_back(g.dedge(it->second, it->first));
+    }
+    return seq;
+}
 static std::vector<int> default_sequence(const Graph& g) {
+    if (g.is_tree) {
+        std::vector<int> seq = tree_sequence(g);
+        if ((int)seq.size() != 2 * g.ne) throw Err(TNQS_ERR_HIP, "internal: tree sequence does not cover every message");
+        return seq;
+    }
     std::vector<int> forest(g.ne, -1);
     int nf = 0;
     // 1. unions of two colour classes that contain no cycle are linear forests (straight lines on lattices): pair the colours up
@@ -942,6 +977,7 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                         rank_bytes[r] += round256((size_t)s->chi[e] * s->chi[e] * esz);
                     }
                     size_t stride = 0; for (size_t b : rank_bytes) stride = std::max(stride, b);
+                    check_exchange(s, stride);
                     char* base = reinterpret_cast<char*>(s->exch);
                     std::vector<ReduceItem> ri; int elems = 0; size_t oi = 0;
                     for (size_t q = start; q < end; ++q) {
@@ -1123,10 +1159,16 @@ template <class T> static void apply_one_site_batch(State* s, const std::vector<
 }
 
 // all-gather of equal-sized per-rank blocks laid out back to back in the host-provided exchange buffer
+void check_exchange(const State* s, size_t bytes_per_rank) {
+    if (s->nranks <= 1) return;
+    if (bytes_per_rank * (size_t)s->nranks > s->exch_bytes)
+        throw Err(TNQS_ERR_COMM, "exchange buffer too small for this batch: " + std::to_string(bytes_per_rank * (size_t)s->nranks) + " bytes needed, " +
+                                     std::to_string(s->exch_bytes) + " available (raise the buffer size passed to tnqs_set_sharding)");
+}
 void exchange(State* s, size_t bytes_per_rank) {
     if (s->nranks <= 1) return;
     if (!s->ag_fn) throw Err(TNQS_ERR_COMM, "sharded handle without an all-gather callback");
-    if (bytes_per_rank * (size_t)s->nranks > s->exch_bytes) throw Err(TNQS_ERR_COMM, "exchange buffer too small for this batch (raise the buffer size passed to tnqs_set_sharding)");
+    check_exchange(s, bytes_per_rank);
     HIPCHK(hipStreamSynchronize(s->stream));
     int rc = s->ag_fn(s->ag_ctx, s->exch, (int64_t)bytes_per_rank, s->nranks);
     if (rc != 0) throw Err(TNQS_ERR_COMM, "all-gather callback failed");
@@ -1221,6 +1263,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         if (sharded) {
             for (size_t i = 0; i < sj.size(); ++i) { int r = s->owner[sj[i].v]; slot[i] = rank_bytes[r]; rank_bytes[r] += round256((size_t)nof(i) * nof(i) * 16); }
             for (size_t b : rank_bytes) stride = std::max(stride, b);
+            check_exchange(s, stride);
         }
         std::vector<ReduceItem> ri; int elems = 0;
         for (size_t q = 0; q < own_idx.size(); ++q) {
@@ -1576,6 +1619,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         std::vector<size_t> slot(ng, 0); std::vector<size_t> rank_bytes(s->nranks, 0);
         for (int gi = 0; gi < ng; ++gi) { int r = s->owner[gates[gi].v1]; slot[gi] = rank_bytes[r]; rank_bytes[r] += slot_bytes; }
         size_t stride = 0; for (size_t b : rank_bytes) stride = std::max(stride, b);
+        check_exchange(s, stride);
         char* base = reinterpret_cast<char*>(s->exch);
         {   // pack the records of the gates whose first vertex is ours (one launch)
             std::vector<RecordPackItem> rp;
@@ -1613,6 +1657,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     } else {
         for (int gi = 0; gi < ng; ++gi) Sptr[gi] = (const double*)ws[gi].S->p;
     }
+    // every gate's status is checked before anything of the handle is replaced: a failing batch leaves the state as it was
+    for (int gi = 0; gi < ng; ++gi) if (info[8 * gi + 3] != 0) throw Err(TNQS_ERR_NUMERIC, "simple_update: internal bond capacity exceeded");
     // ---- 5. psi' = (psi x_outer P) x_(s,b) X  (simple_update.jl:62-64, net effect of gauge + ungauge) ----------------
     std::vector<Chain> pch(own_idx.size());
     for (size_t q = 0; q < own_idx.size(); ++q) {
@@ -1692,7 +1738,6 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         std::vector<DiagItem> di;
         for (int gi = 0; gi < ng; ++gi) {
             int e = g.edge(gates[gi].v1, gates[gi].v2); int chin = info[8 * gi + 2];
-            if (info[8 * gi + 3] != 0) throw Err(TNQS_ERR_NUMERIC, "simple_update: internal bond capacity exceeded");
             s->chi[e] = chin;
             for (int dir = 0; dir < 2; ++dir) {
                 Buf m = dalloc(s, (size_t)chin * chin * esz);

@@ -43,7 +43,20 @@ def _half(t):
     return (t / 2,)
 
 
+def _upstream_only(name: str):
+    """"Rz+" and "Rz+z+" are entries of the reference's registry (gate_definitions.jl:33,58) whose matrices the reference does not define:
+    the name is forwarded to `ITensors.op(name, ...)`, and no such op exists in the ITensors sources the reference pins (0.9) nor anywhere
+    under the reference tree -- building the gate fails there as well.  The names are registered here (locked built-ins, lowercase aliases,
+    one parameter) so that name resolution, aliasing and `register_gate` conflicts behave like the reference; asking for the matrix raises
+    with this explanation instead of guessing a convention.  A user who has the definition registers it under another name."""
+    def fn(*_params):
+        raise ValueError(f'gate "{name}" is listed in the reference registry but its matrix is only defined by an upstream ITensors.op '
+                         f'method that is not part of the reference sources; register the matrix under a custom name with register_gate')
+    return fn
+
+
 GATES: Dict[str, GateSpec] = {
+    "Rz+": GateSpec(_upstream_only("Rz+"), 1), "Rz+z+": GateSpec(_upstream_only("Rz+z+"), 1),
     "X": GateSpec(lambda: _PX.copy()), "Y": GateSpec(lambda: _PY.copy()), "Z": GateSpec(lambda: _PZ.copy()),
     "H": GateSpec(lambda: np.array([[1, 1], [1, -1]], dtype=complex) / math.sqrt(2)),
     "Rx": GateSpec(lambda t: _rot(_PX, t / 2), 1), "Ry": GateSpec(lambda t: _rot(_PY, t / 2), 1),

@@ -246,7 +246,7 @@ def test_c1_full_run_matches_oracle():
     for grp in groups:
         layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
     psi = tn.tensornetworkstate(np.complex128, lambda v: "↑", g)
-    bpkw = dict(edge_sequence=tn.forest_cover_edge_sequence(g))
+    bpkw = dict(tn.default_bp_update_kwargs(psi), edge_sequence=tn.forest_cover_edge_sequence(g))     # maxiter 25, tolerance 1e-8
     kw = dict(maxdim=10, cutoff=1e-12, normalize_tensors=True)
     bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
     bo = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)

@@ -309,7 +309,8 @@ def test_default_tolerance_sweep_counts_and_observables_match_oracle():
         tensors[v] = rng.standard_normal(2 * n, dtype=np.float32).view(np.complex64).reshape(shp) / np.float32(np.sqrt(n))
     psi = tn.TensorNetworkState(g, tensors)
     kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
-    bpkw = dict(edge_sequence=seq)
+    bpkw = dict(tn.default_bp_update_kwargs(psi), edge_sequence=seq)      # (maxiter = 25, tolerance = 1e-5) + the common order
+    assert bpkw["maxiter"] == 25 and bpkw["tolerance"] == 1e-5
     bpc = tn.BeliefPropagationCache(psi)
     oc = o.BeliefPropagationCache(to_oracle_state(psi), edge_sequence=seq)
     for layer_no in range(3):
@@ -370,21 +371,17 @@ def test_bp_update_chi32_bulk_sites_matches_oracle(seq_name):
     if seq is not None:
         kw["edge_sequence"] = seq
     out = tn.update(bpc, **kw)
-    if seq is None:     # the library default = colour-grouped order of its own colouring: check the fixed sweep against itself via expect
-        oc = None
-    else:
-        oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **kw)
-        compare_messages(out, oc, 5e-5)
+    # the device default order is replayed on the oracle (read back through tnqs_dbg_default_sequence): same trajectory, not just the
+    # same fixed point
+    okw = dict(kw, edge_sequence=seq if seq is not None else device_default_sequence(bpc))
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **okw)
+    compare_messages(out, oc, 5e-5)
     # second update from the first one's messages (cache entries of the first call must not leak into the second)
     out2 = tn.update(out, **kw)
-    if oc is not None:
-        oc2 = o.update(oc, **kw)
-        compare_messages(out2, oc2, 5e-5)
-    else:
-        ref = o.update(oracle_cache_from_device(out), maxiter=2, tolerance=None, edge_sequence=colour_sequence(g, tn.edge_color(g)))
-        for v in [(2, 2), (2, 3), (1, 1)]:
-            assert abs(tn.expect(out2, ("Z", [v])) - tn.expect(out2, ("Z", [v])).real) < 1e-5
-            assert np.isfinite(o.expect_1site(ref, Z, v))
+    oc2 = o.update(oc, **okw)
+    compare_messages(out2, oc2, 5e-5)
+    for v in [(2, 2), (2, 3), (1, 1)]:
+        assert abs(tn.expect(out2, ("Z", [v])) - o.expect_1site(oc2, Z, v)) < 2e-5
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
@@ -890,3 +887,33 @@ def test_gate_path_is_invariant_under_the_norm_of_the_tensors(scale):
     for (e0, z0, d0), (e1, z1, d1) in zip(ref, alt):
         assert d0 == d1
         assert np.max(np.abs(e0 - e1)) < 2e-6 and np.max(np.abs(z0 - z1)) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+@pytest.mark.parametrize("lattice", ["line6", "comb33", "star"])
+def test_default_update_is_exact_on_trees(dtype, lattice):
+    """`update(bpc)` with NO kwargs on a tree: the reference's defaults are one sweep, no tolerance (beliefpropagationcache.jl:39,110-113)
+    over forest_cover_edge_sequence, for which one sweep is exact (test/test_beliefpropagation.jl:28-54, test_expect.jl:26-28).  The
+    engine's default order on forests must have the same property: <Z> equals the converged value and the exact state-vector value, the
+    partition function equals <psi|psi>."""
+    from statevector import tns_to_statevector
+    if lattice == "line6":
+        g = tn.named_grid((6,))
+    elif lattice == "comb33":
+        g = tn.named_comb_tree((3, 3))
+    else:
+        g = tn.NamedGraph(list(range(6)), [(0, k) for k in range(1, 6)])
+    assert g.is_tree()
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=3, seed=21)
+    one = tn.update(tn.BeliefPropagationCache(psi))                       # defaults: 1 sweep, no check
+    many = tn.update(tn.BeliefPropagationCache(psi), maxiter=12, tolerance=None)
+    sv = tns_to_statevector(to_oracle_state(psi))
+    nrm = float(np.vdot(sv, sv).real)
+    tol = 2e-5 if dtype == np.complex64 else 1e-11
+    vs = list(g.vertices)
+    for i, v in enumerate(vs):
+        z1, zm = tn.expect(one, ("Z", [v])), tn.expect(many, ("Z", [v]))
+        t = sv.reshape((2,) * len(vs)); ax = tuple(k for k in range(len(vs)) if k != i)
+        p = np.sum(np.abs(t) ** 2, axis=ax); zex = (p[0] - p[1]) / nrm
+        assert abs(z1 - zm) < tol and abs(z1 - zex) < tol, (lattice, v, z1, zm, zex)
+    assert abs(tn.partitionfunction(one) / nrm - 1) < (2e-4 if dtype == np.complex64 else 1e-10)

@@ -100,3 +100,29 @@ def test_gate_matrix_cache_follows_the_registry():
     assert tn.gate_matrix("XZ") is tn.gate_matrix("XZ")
     with pytest.raises(ValueError):
         tn.gate_matrix("Rzz")                                                    # wrong parameter count still raises
+
+
+def test_bp_kwargs_follow_the_reference_defaults():
+    """`update(bpc; maxiter = 10)` has NO tolerance in the reference (`default_tolerance(::Algorithm"bp") = nothing`,
+    beliefpropagationcache.jl:62-67); only `default_bp_update_kwargs` -- what apply_gates / truncate / normalize use when
+    `bp_update_kwargs` is omitted -- carries the dtype tolerance (:110-117)."""
+    from tnqs_amd.core import _bp_opts
+    g = tn.named_grid((3, 3))
+    o1, _ = _bp_opts(g, dict(maxiter=10))
+    assert o1.maxiter == 10 and o1.tolerance < 0
+    o2, _ = _bp_opts(g, {})
+    assert o2.maxiter == 0 and o2.tolerance < 0
+    o3, _ = _bp_opts(g, None, dict(maxiter=25, tolerance=1e-5))
+    assert o3.maxiter == 25 and o3.tolerance == 1e-5
+    o4, _ = _bp_opts(g, dict(maxiter=7, tolerance=1e-9), dict(maxiter=25, tolerance=1e-5))
+    assert o4.maxiter == 7 and o4.tolerance == 1e-9
+
+
+def test_upstream_only_registry_entries_resolve_but_do_not_guess_a_matrix():
+    """"Rz+" / "Rz+z+" (gate_definitions.jl:33,58): registered, aliased, locked -- their matrices live in an upstream ITensors.op the
+    reference does not carry, so building them explains that instead of inventing a convention"""
+    assert "Rz+" in tn.GATES and "Rz+z+" in tn.GATES and tn.ALIASES["rz+"] == "Rz+" and tn.ALIASES["rz+z+"] == "Rz+z+"
+    with pytest.raises(ValueError, match="built-in"):
+        tn.register_gate("Rz+", lambda t: np.eye(2))
+    with pytest.raises(ValueError, match="upstream"):
+        tn.gate_matrix("Rz+", 0.3)
