@@ -428,10 +428,79 @@ def incoming_edges(g: Graph, verts: Sequence[Vertex], ignore: Sequence[DEdge] = 
     return out
 
 
+_BIG = 1 << 22          # elements from which the chunked, threaded contractions below replace the plain tensordot calls
+_POOL = None
+
+
+def _pool():
+    """thread pool for the large-tensor paths (numpy releases the GIL inside matmul / tensordot): at the per-site shapes of the
+    BASELINE configurations (2 * 16^6 or 2 * 64^4 elements per tensor) the plain tensordot + moveaxis formulation spends its time
+    in single-threaded transposition copies -- minutes per BP sweep.  Same arithmetic, same index conventions, only the loop
+    over the untouched indices is split into chunks."""
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(32, (os.cpu_count() or 2) // 2)))
+    return _POOL
+
+
+def _chunks(n: int, parts: int):
+    parts = max(1, min(parts, n))
+    step = (n + parts - 1) // parts
+    return [(a, min(n, a + step)) for a in range(0, n, step)]
+
+
 def _absorb(t: np.ndarray, axis: int, m: np.ndarray) -> np.ndarray:
     """t[.. l ..] m[l, l'] -> axis replaced by l' (kept in place)."""
-    r = np.tensordot(t, m, axes=([axis], [0]))
-    return np.moveaxis(r, -1, axis)
+    if t.size < _BIG:
+        r = np.tensordot(t, m, axes=([axis], [0]))
+        return np.moveaxis(r, -1, axis)
+    t = np.ascontiguousarray(t)
+    shape = t.shape
+    k, kn = shape[axis], m.shape[1]
+    pre = int(np.prod(shape[:axis], dtype=np.int64)); post = int(np.prod(shape[axis + 1:], dtype=np.int64))
+    dt = np.result_type(t.dtype, m.dtype)
+    pool = _pool(); nw = pool._max_workers
+    if post == 1:                                        # last axis: one tall GEMM, split by rows
+        t2 = t.reshape(pre, k); out = np.empty((pre, kn), dtype=dt); mm = np.ascontiguousarray(m.astype(dt))
+        def job(ab):
+            out[ab[0]:ab[1]] = t2[ab[0]:ab[1]] @ mm
+        list(pool.map(job, _chunks(pre, 4 * nw)))
+        return out.reshape(shape[:axis] + (kn,))
+    t3 = t.reshape(pre, k, post); out = np.empty((pre, kn, post), dtype=dt); mt = np.ascontiguousarray(m.T.astype(dt))
+    if pre >= 4 * nw:                                    # out[p] = m^T t3[p], split over p
+        def job(ab):
+            out[ab[0]:ab[1]] = np.matmul(mt, t3[ab[0]:ab[1]])
+        list(pool.map(job, _chunks(pre, 4 * nw)))
+    else:                                                # few, wide slabs: 2-D products on column ranges of each slab (no copies)
+        def job(pab):
+            q, a, b = pab
+            out[q, :, a:b] = mt @ t3[q, :, a:b]
+        list(pool.map(job, [(q, a, b) for q in range(pre) for (a, b) in _chunks(post, max(1, 4 * nw // pre))]))
+    return out.reshape(shape[:axis] + (kn,) + shape[axis + 1:])
+
+
+def _gram(t: np.ndarray, y: np.ndarray, ax: int) -> np.ndarray:
+    """m[b, b'] = sum over every other index of t[.. b ..] conj(y[.. b' ..]) (both in the same index order)"""
+    if t.size < _BIG:
+        other = [i for i in range(t.ndim) if i != ax]
+        return np.tensordot(t, y.conj(), axes=(other, other))
+    t = np.ascontiguousarray(t); y = np.ascontiguousarray(y)
+    shape = t.shape; k = shape[ax]
+    pre = int(np.prod(shape[:ax], dtype=np.int64)); post = int(np.prod(shape[ax + 1:], dtype=np.int64))
+    pool = _pool(); nw = pool._max_workers
+    if post == 1:
+        t2, y2 = t.reshape(pre, k), y.reshape(pre, k)
+        parts = list(pool.map(lambda ab: t2[ab[0]:ab[1]].T @ y2[ab[0]:ab[1]].conj(), _chunks(pre, 4 * nw)))
+        return sum(parts[1:], parts[0])
+    t3, y3 = t.reshape(pre, k, post), y.reshape(pre, k, post)
+    if pre >= 4 * nw:
+        parts = list(pool.map(lambda ab: np.tensordot(t3[ab[0]:ab[1]], y3[ab[0]:ab[1]].conj(), axes=([0, 2], [0, 2])), _chunks(pre, 4 * nw)))
+    else:
+        parts = list(pool.map(lambda pab: t3[pab[0], :, pab[1]:pab[2]] @ y3[pab[0], :, pab[1]:pab[2]].conj().T,
+                              [(q, a, b) for q in range(pre) for (a, b) in _chunks(post, max(1, 4 * nw // pre))]))
+    return sum(parts[1:], parts[0])
 
 
 def updated_message(bpc: BeliefPropagationCache, e: DEdge, normalize: bool = True) -> np.ndarray:
@@ -446,8 +515,7 @@ def updated_message(bpc: BeliefPropagationCache, e: DEdge, normalize: bool = Tru
             continue
         t = _absorb(t, g.leg(u, k), bpc.message((k, u)))
     ax = g.leg(u, v)
-    other = [i for i in range(psi.ndim) if i != ax]
-    m = np.tensordot(t, psi.conj(), axes=(other, other))   # [b, b']
+    m = _gram(t, psi, ax)                                   # [b, b']
     if normalize:
         s = m.sum()
         if s != 0:
@@ -593,7 +661,7 @@ def simple_update(gate: np.ndarray, psis: List[np.ndarray], bond_axes: Optional[
             qt = q.reshape(oshape + (q.shape[1],))
             for i, ax in enumerate(outer):
                 mi = [m for (a, _, m) in sq if a == ax][0]
-                qt = np.moveaxis(np.tensordot(qt, mi.conj(), axes=([i], [1])), -1, i)
+                qt = _absorb(qt, i, mi.conj().T)                                 # same contraction: sum_l' Q[l'] conj(M^-1/2)[l, l']
             return qt
         q1t = ungauge(q1, outer1, oshape1, sq1)
         q2t = ungauge(q2, outer2, oshape2, sq2)

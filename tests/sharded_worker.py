@@ -46,6 +46,30 @@ def main():
         for v in g.vertices:
             psi0.tensors[v] = (psi0.tensors[v] / np.linalg.norm(psi0.tensors[v])).astype(dtype)
     nlayers = 1 if big else 2
+    if mode in ("z6chi16", "z4chi64"):
+        # the per-site shapes of BASELINE configs[3] / [4] under sharding: two adjacent degree-6 hubs at chi = 16 on different ranks (the
+        # bulk gate of the cubic lattice as a cross-rank gate; tests/test_gpu_fullsize.py double_wheel), and the 3x3 grid at chi = 64
+        # (268 MB centre tensor, 256 x 256 theta) -- one layer, sharded against single rank
+        dtype = np.complex64
+        if mode == "z6chi16":
+            g = tn.NamedGraph(list(range(12)), [(0, 6)] + [(0, 1 + i) for i in range(5)] + [(6, 7 + i) for i in range(5)] + [(1 + i, 7 + i) for i in range(5)])
+            chi = 16; groups = tn.edge_color(g)
+            layer = [("Rz", [v], -0.04) for v in g.vertices]; seq = []
+            for grp in groups:
+                layer += [("Rxx", [a, b], -0.08) for (a, b) in grp]
+                seq += list(grp) + [(b, a) for (a, b) in grp]
+        else:
+            g = tn.named_grid((3, 3)); chi = 64; groups = tn.edge_color(g, 4)
+            layer = [("Rx", [v], 0.05) for v in g.vertices]; seq = []
+            for grp in groups:
+                layer += [("Rzz", [a, b], 0.02) for (a, b) in grp]
+                seq += list(grp) + [(b, a) for (a, b) in grp]
+        kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+        bpkw = dict(edge_sequence=seq, maxiter=2, tolerance=None)
+        psi0 = tn.random_tensornetworkstate(dtype, g, bond_dimension=chi, seed=13)
+        for v in g.vertices:
+            psi0.tensors[v] = (psi0.tensors[v] / np.linalg.norm(psi0.tensors[v])).astype(dtype)
+        nlayers = 1; big = True
     if mode == "illc128":
         # ComplexF64 with cutoff = 1e-14 from a product state: kept singular values span 1e-7, the regime in which the gate path needs its
         # second factorisation pass -- sharded and single-rank runs must both take it
@@ -61,7 +85,7 @@ def main():
 
     def sharded_factory():
         b = tn.BeliefPropagationCache(tn.tensornetworkstate(dtype, lambda v: "↑", g))
-        tn.shard(b, rank, world, exch_bytes=(64 << 20) if big else (8 << 20))
+        tn.shard(b, rank, world, exch_bytes=(64 << 20) if big else (8 << 20), max_chi=64)
         for v in g.vertices:
             if b.owns(v):
                 b._set_tensor(v, psi0.tensors[v])

@@ -330,3 +330,108 @@ def test_c2_shape_layer_matches_oracle():
             worst = max(worst, float(np.max(np.abs(wd / wd.sum() - wo / wo.sum()))))
     print(f"C2 shape, one layer: max|dZ| {np.max(np.abs(zd - zo)):.1e}  max|derr| {np.max(np.abs(ed - np.array(eo))):.1e} (max err {max(eo):.1e})  message spectra {worst:.1e}")
     assert np.max(np.abs(zd - zo)) < 2e-4 and worst < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] / [4] per-site shapes with the ORACLE computing its own BP messages (no device message is copied into it).
+# The 3x3x3 torus of configs[3] has 27 degree-6 sites: one oracle sweep over it (162 messages of 26 GFLOP each through numpy) takes
+# about ten minutes, so the degree-6 shape is exercised on the smallest loopy graph that has two ADJACENT degree-6 sites -- a gate
+# between them is the bulk gate of the cubic lattice (both tensors 2 x 16^6 = 268 MB, five gauge legs each), every message the
+# hubs send is a bulk cubic message (five absorbed legs), and the spokes close 4-cycles through both hubs so BP is not exact.
+# ---------------------------------------------------------------------------------------------------------------
+def double_wheel():
+    """vertices 0 (hub A), 1..5 (spokes of A), 6 (hub B), 7..11 (spokes of B); edges A-B, A-a_i, B-b_i, a_i-b_i: degrees 6, 6, 2 x 10"""
+    edges = [(0, 6)] + [(0, 1 + i) for i in range(5)] + [(6, 7 + i) for i in range(5)] + [(1 + i, 7 + i) for i in range(5)]
+    return tn.NamedGraph(list(range(12)), edges)
+
+
+def small_norm_state(g, chi, seed):
+    psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=chi, seed=seed)
+    for v in g.vertices:
+        t = psi.tensors[v]; psi.tensors[v] = (t / np.linalg.norm(t) / np.sqrt(t.size)).astype(np.complex64)
+    return psi
+
+
+def compare_with_oracle_after_layer(g, bd, bo, ed, eo, label):
+    import tnqs_oracle as o
+    from helpers import c64_errs_close
+    assert [bd.bond_dim(a, b) for (a, b) in g.edges] == [bo.tns.bond_dim(a, b) for (a, b) in g.edges]
+    assert c64_errs_close(ed, eo, rel=5e-3, floor=1e-6), float(np.max(np.abs(ed - np.array(eo))))
+    zop = np.diag([1.0, -1.0]).astype(complex)
+    zd = tn.expect_all(bd, "Z").real
+    zo = np.array([o.expect_1site(bo, zop, v).real for v in g.vertices])
+    worst = 0.0
+    for (a, b) in g.edges:
+        for e in ((a, b), (b, a)):
+            md, mo = bd.message(e).astype(np.complex128), np.asarray(bo.message(e), dtype=np.complex128)
+            wd, wo = np.linalg.eigvalsh((md + md.conj().T) / 2), np.linalg.eigvalsh((mo + mo.conj().T) / 2)
+            worst = max(worst, float(np.max(np.abs(wd / wd.sum() - wo / wo.sum()))))
+    print(f"{label}: max|dZ| {np.max(np.abs(zd - zo)):.1e}  max|derr| {np.max(np.abs(ed - np.array(eo))):.1e} (max err {max(eo):.1e})  message spectra {worst:.1e}")
+    assert np.max(np.abs(zd - zo)) < 2e-4 and worst < 2e-4
+
+
+def messages_elementwise(bd, bo, g, tol):
+    worst = 0.0
+    for (a, b) in g.edges:
+        for e in ((a, b), (b, a)):
+            md, mo = bd.message(e), np.asarray(bo.message(e))
+            worst = max(worst, float(np.max(np.abs(md - mo)) / np.max(np.abs(mo))))
+    assert worst < tol, worst
+    return worst
+
+
+def test_c4_shape_bp_and_layer_match_oracle():
+    """BASELINE configs[3] per-site shape (degree 6, chi = 16, ComplexF32) end to end against the oracle, the oracle iterating its OWN
+    messages: (i) two BP sweeps in a common explicit order from unset messages -- every message elementwise (same site tensors on both
+    sides, so the gauge is the same); (ii) one full layer of the 3-D Ising circuit (examples/3dIsing_dynamics.jl:15-26: Rz, Rxx per
+    colour, Rz) with a BP update per colour group: bond dimensions, truncation errors, <Z>, message spectra."""
+    import tnqs_oracle as o
+    from helpers import to_oracle_state
+    g = double_wheel()
+    assert sorted(g.degree(v) for v in g.vertices)[-2:] == [6, 6]
+    chi = 16
+    psi = small_norm_state(g, chi, seed=31)
+    seq = tn.forest_cover_edge_sequence(g)
+    bd = tn.update(tn.BeliefPropagationCache(psi), edge_sequence=seq, maxiter=2, tolerance=None)
+    bo = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), edge_sequence=seq, maxiter=2, tolerance=None)
+    w = messages_elementwise(bd, bo, g, 5e-5)
+    print(f"C4 shape, two BP sweeps: messages elementwise to {w:.1e}")
+    groups = tn.edge_color(g)
+    J, h, dt = -1.0, -1.0, 0.04
+    layer = [("Rz", [v], h * dt) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rxx", [a, b], 2 * J * dt) for (a, b) in grp]
+    layer += [("Rz", [v], h * dt) for v in g.vertices]
+    kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+    bpkw = dict(edge_sequence=seq, maxiter=1, tolerance=None)
+    info = {}
+    bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw, info=info)
+    bo, eo = o.apply_gates(layer, bo, apply_kwargs=kw, bp_update_kwargs=bpkw)
+    assert info["n_updates"] == len(groups) + 1 and info["n_two_site"] == g.ne()
+    compare_with_oracle_after_layer(g, bd, bo, ed, eo, "C4 shape, one layer")
+
+
+def test_c5_shape_bp_and_layer_match_oracle():
+    """BASELINE configs[4] per-site shape (degree 4, chi = 64, ComplexF32; 268 MB bulk tensor, 256 x 256 theta) on a 3x3 grid, the oracle
+    iterating its own messages: two BP sweeps elementwise, then one full TFIM layer (Rx, Rzz per colour, two sweeps per update)."""
+    import tnqs_oracle as o
+    from helpers import to_oracle_state
+    g = tn.named_grid((3, 3))
+    chi = 64
+    psi = small_norm_state(g, chi, seed=32)
+    seq = tn.forest_cover_edge_sequence(g)
+    bpkw = dict(edge_sequence=seq, maxiter=2, tolerance=None)
+    bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
+    bo = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)
+    w = messages_elementwise(bd, bo, g, 5e-5)
+    print(f"C5 shape, two BP sweeps: messages elementwise to {w:.1e}")
+    groups = tn.edge_color(g, 4)
+    layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+    kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+    info = {}
+    bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw, info=info)
+    bo, eo = o.apply_gates(layer, bo, apply_kwargs=kw, bp_update_kwargs=bpkw)
+    assert info["n_updates"] == 5 and info["n_two_site"] == 12
+    compare_with_oracle_after_layer(g, bd, bo, ed, eo, "C5 shape, one layer")
