@@ -72,7 +72,7 @@ typedef struct {
     int n_chol_fallbacks;   /* gate batches in which at least one site had a numerically rank-deficient Gram matrix (those sites take the eigen path) */
     int n_qr2_sites;        /* ComplexF64 sites that went through the second factorisation pass (ill-conditioned psi~) */
     int n_lowrank_svd;      /* two-site gates whose theta SVD ran on the low-rank factor (gate of operator Schmidt rank kappa, kappa chi < d chi) */
-    int reserved_;
+    int n_tall_svd;         /* theta SVDs that went through the Cholesky-QR preprocessing (matrix too tall for the LDS-resident Jacobi: 256 x 128 at chi = 64) */
 } tnqs_apply_stats;
 
 /* ---- library ---------------------------------------------------------------------------------------- */

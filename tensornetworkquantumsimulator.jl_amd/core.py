@@ -337,7 +337,7 @@ def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_
         warnings.warn(f"BP did not converge in {st.bp_not_converged} of {st.n_bp_updates} cache updates "
                       f"(final average message change: {st.last_bp_diff}).")
     if info is not None:
-        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
+        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_tall_svd=st.n_tall_svd, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
                     n_two_site=st.n_two_site, bp_not_converged=st.bp_not_converged)
     return out, errs[:ng]
 
@@ -370,7 +370,7 @@ def truncate(bpc: BeliefPropagationCache, maxdim: int, cutoff: Optional[float] =
     L.check(L.lib.tnqs_truncate(out._h, int(maxdim), -1.0 if cutoff is None else float(cutoff), 1 if normalize_tensors else 0,
                                 len(groups), o_p, u_p, v_p, C.byref(bo), C.byref(st)))
     if info is not None:
-        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_two_site=st.n_two_site)
+        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_tall_svd=st.n_tall_svd, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_two_site=st.n_two_site)
     return out
 
 

@@ -418,7 +418,8 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
     std::vector<int> nt(chains.size(), 0);          // temporaries written so far (ping-pong index)
     std::vector<size_t> done(chains.size(), 0);     // steps consumed from the FRONT of c.steps after the pair stage
     for (auto& c : chains) c.result = c.src;
-    // ---- stage 0: two slow 32-dimensional legs in one pass (mfma_pair_kernel) --------------------------------------
+    // ---- stage 0: two legs per pass over the tensor -- 32-dimensional legs: mfma_pair_kernel (once), 16-dimensional legs:
+    // mfma_pair16_kernel, repeated while a chain still has two of them (a degree-6 site absorbs its legs in 3 passes instead of 5) ---
     if (std::is_same<T, float>::value && use_mfma() && use_pair()) {
         std::vector<PairItem> items; int wgs = 0; double bytes = 0, flops = 0;
         double tot_slices = 0;
@@ -460,6 +461,37 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
             ProfScope ps(s, cls_pair, bytes, flops);
             launch_mfma_pair(s->stream, d, (int)items.size(), wgs);
         }
+        for (;;) {                                                  // 16-dimensional legs, two per round
+            std::vector<Pair16Item> it16; std::vector<std::pair<size_t, std::pair<int, int>>> sel16; double slices16 = 0, by16 = 0, fl16 = 0;
+            for (size_t ci = 0; ci < chains.size(); ++ci) {
+                Chain& c = chains[ci];
+                if (c.steps.size() < 2 || c.sd.n < (size_t)(1u << 14)) continue;     // small tensors stay on the single-leg kernel (launch bound)
+                bool found = false;
+                for (int qy = (int)c.steps.size() - 1; qy >= 1 && !found; --qy)
+                    for (int qx = qy - 1; qx >= 0 && !found; --qx) {
+                        Pair16Item it{};
+                        if (!plane_geometry(c.sd.d, c.sd.z, c.sd.chi.data(), c.steps[qx].first, c.steps[qy].first, 16, it.g)) continue;
+                        it.Mx = c.steps[qx].second; it.My = c.steps[qy].second;
+                        it16.push_back(it); sel16.push_back({ci, {qx, qy}}); slices16 += (double)it.g.nslices(); found = true;
+                    }
+            }
+            if (it16.empty()) break;
+            // slices per workgroup: a multiple of 4 (8 waves = 4 slices x 2 halves), at least ~8 workgroups per CU overall
+            int spw = 4; while (spw < 64 && slices16 / (2 * spw) >= 2048.0) spw *= 2;
+            int wgs16 = 0;
+            for (size_t q = 0; q < it16.size(); ++q) {
+                Chain& c = chains[sel16[q].first]; Pair16Item& it = it16[q];
+                Buf& dst = c.tmp[nt[sel16[q].first] & 1];
+                if (!dst) dst = dalloc(s, c.sd.n * esz);
+                it.in = c.result; it.out = dst->p; it.spw = spw; it.wg_begin = wgs16; wgs16 += (it.g.nslices() + spw - 1) / spw;
+                c.result = dst->p; nt[sel16[q].first]++;
+                c.steps.erase(c.steps.begin() + sel16[q].second.second); c.steps.erase(c.steps.begin() + sel16[q].second.first);
+                by16 += 2.0 * c.sd.n * esz; fl16 += 2 * 8.0 * c.sd.n * 16;
+            }
+            const Pair16Item* d = upload(s, it16);
+            ProfScope ps(s, cls_pair, by16, fl16);
+            launch_mfma_pair16(s->stream, d, (int)it16.size(), wgs16);
+        }
     }
     size_t maxsteps = 0;
     for (auto& c : chains) maxsteps = std::max(maxsteps, c.steps.size());
@@ -495,6 +527,73 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
     (void)done;
 }
 
+// One-sided Jacobi SVD of a batch of matrices (A <- U Sigma in place; V accumulated only when the items carry one).  Three routes:
+//   * the matrix fits the LDS (jacobi_lds_kernel);
+//   * ComplexF32, no V wanted, too tall for the LDS but its n x n triangle fits (256 x 128 at chi = 64): Cholesky-QR preprocessing --
+//     G = A^dagger A (f64) -> R = chol(G + delta I)^dagger -> Jacobi on R in LDS -> J = R^dagger (U_R S_R) S_R^-2 -> A <- A J
+//     (kernels_chi64.hip; the rotations that orthogonalise R's columns orthogonalise A's, delta only conditions R);
+//   * anything else: the global-memory kernel.
+static bool use_tall_svd() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_TALLSVD"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
+template <class T> static void svd_batch(State* s, const std::vector<JacobiItem>& all, bool with_v) {
+    const size_t esz = s->esz();
+    const size_t cap = 160 * 1024 - 256;
+    std::vector<JacobiItem> fit, tall, rest;
+    static const bool force_global = [] { const char* e = std::getenv("TNQS_JACOBI_GLOBAL"); return e && e[0] == '1'; }();
+    for (auto& j : all) {
+        if (j.n < 1 || j.m < 1) continue;
+        if (!force_global && jacobi_lds_bytes(j.m, j.n, with_v, esz) <= cap && std::max(j.m, j.n) <= 256) fit.push_back(j);
+        else if (!force_global && std::is_same<T, float>::value && !with_v && !j.V && use_mfma() && use_tall_svd() && j.m >= j.n && j.n <= 128 && j.n >= 2 &&
+                 jacobi_lds_bytes(j.n, j.n, false, esz) <= cap) tall.push_back(j);
+        else rest.push_back(j);
+    }
+    if (!fit.empty()) {
+        size_t lds = 0; for (auto& j : fit) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, with_v, esz));
+        const JacobiItem* d = upload(s, fit);
+        launch_jacobi<T>(s->stream, d, (int)fit.size(), 60, lds, mmax_of(fit));
+    }
+    if (!rest.empty()) {
+        const JacobiItem* d = upload(s, rest);
+        launch_jacobi<T>(s->stream, d, (int)rest.size(), 60, 0, mmax_of(rest));
+    }
+    if (!tall.empty()) {
+        const size_t nt = tall.size();
+        size_t off = 0; std::vector<size_t> oG(nt), oL(nt), oR0(nt), oRr(nt), oJ(nt), oT(nt);
+        for (size_t i = 0; i < nt; ++i) {
+            const size_t nn = (size_t)tall[i].n * tall[i].n, mn = (size_t)tall[i].m * tall[i].n;
+            oG[i] = off; off += round256(nn * 16); oL[i] = off; off += round256(nn * 16);
+            oR0[i] = off; off += round256(nn * 8); oRr[i] = off; off += round256(nn * 8); oJ[i] = off; off += round256(nn * 8); oT[i] = off; off += round256(mn * 8);
+        }
+        Buf arena = dalloc(s, off); s->keepalive.push_back(arena);
+        Buf d_fail = dalloc(s, nt * sizeof(int)); s->keepalive.push_back(d_fail);
+        HIPCHK(hipMemsetAsync(d_fail->p, 0, nt * sizeof(int), s->stream));
+        char* ap = reinterpret_cast<char*>(arena->p);
+        std::vector<TallSvdItem> ti; std::vector<CholItem> ci; std::vector<JacobiItem> rj; std::vector<RecoverItem> rv; std::vector<SmallGemmItem> gi; std::vector<CopyItem> cp;
+        int nmax = 1, mmax = 1;
+        for (size_t i = 0; i < nt; ++i) {
+            const int m = tall[i].m, n = tall[i].n; nmax = std::max(nmax, n); mmax = std::max(mmax, m);
+            ti.push_back(TallSvdItem{tall[i].A, ap + oG[i], ap + oL[i], ap + oR0[i], ap + oRr[i], m, n});
+            // delta = 1e-14 of the largest diagonal entry: singular directions below 1e-7 sigma_max are f32 noise of the data anyway, and R keeps
+            // a condition number <= 1e7 whatever the rank of A (no failure branch: a rank-deficient theta is the normal case early in an evolution)
+            ci.push_back(CholItem{ap + oG[i], ap + oL[i], nullptr, n, reinterpret_cast<int*>(d_fail->p) + i, 0.0, 1e-14});
+            rj.push_back(JacobiItem{ap + oRr[i], nullptr, n, n, tall[i].sweeps_out});
+            rv.push_back(RecoverItem{ap + oR0[i], ap + oRr[i], ap + oJ[i], n, n, n});
+            gi.push_back(SmallGemmItem{tall[i].A, ap + oJ[i], ap + oT[i], m, n, n});
+            cp.push_back(CopyItem{ap + oT[i], tall[i].A, (size_t)m * n * 8 / 16});
+        }
+        const TallSvdItem* dt = upload(s, ti); const CholItem* dc = upload(s, ci); const JacobiItem* dj = upload(s, rj);
+        const RecoverItem* dr = upload(s, rv); const SmallGemmItem* dg = upload(s, gi); const CopyItem* dcp = upload(s, cp);
+        launch_tall_gram(s->stream, dt, (int)nt, nmax);
+        launch_chol_packed(s->stream, dc, (int)nt, nmax);
+        launch_tall_rt(s->stream, dt, (int)nt);
+        size_t lds = 0; for (auto& j : rj) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, false, esz));
+        launch_jacobi<T>(s->stream, dj, (int)nt, 60, lds, nmax);
+        launch_recover_v_mfma(s->stream, dr, (int)nt, nmax);
+        launch_small_cgemm(s->stream, dg, (int)nt, mmax, nmax);
+        launch_copy_items(s->stream, dcp, (int)nt);
+        s->stats.n_tall_svd += (int)nt;
+    }
+}
+
 struct GramJob {      // out[i,j] = sum X[i,.] conj(Y[j,.]) over everything but the kept index (s and/or leg)
     const void* X; const void* Y; SD sd; int leg;  /* -1: keep the site index only */ bool keep_site;
     Buf partial; int nchunks = 0; int KK = 0;
@@ -516,7 +615,7 @@ template <class T, class Acc> static void run_grams(State* s, std::vector<GramJo
     for (auto& j : jobs) { j.KK = (j.keep_site ? j.sd.d : 1) * (j.leg >= 0 ? j.sd.chi[j.leg] : 1); KKmax = std::max<size_t>(KKmax, j.KK); }
     int TR = pick_TR(KKmax + 1, esz, 2);
     const bool fused = jobs[0].M != nullptr;
-    const bool mf = fused || (std::is_same<T, float>::value && std::is_same<Acc, float>::value && use_mfma() && KKmax <= 32 && KKmax >= 8);
+    const bool mf = fused || (std::is_same<T, float>::value && std::is_same<Acc, float>::value && use_mfma() && KKmax <= 64 && KKmax >= 8);
     bool mf64 = std::is_same<T, float>::value && std::is_same<Acc, double>::value && use_mfma() && KKmax <= 64 && KKmax >= 16;
     for (auto& j : jobs) mf64 = mf64 && (j.X == j.Y);
     if (mf || mf64) TR = 64;
@@ -546,7 +645,7 @@ template <class T, class Acc> static void run_grams(State* s, std::vector<GramJo
     ProfScope ps(s, cls, bytes, flops);
     if (fused) launch_mfma_gram32_fused(s->stream, d, (int)items.size(), chunks);
     else if (mf64) launch_mfma_gram64_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax);
-    else if (mf) launch_mfma_gram32(s->stream, d, (int)items.size(), chunks, (int)KKmax);
+    else if (mf) { if (KKmax <= 32) launch_mfma_gram32(s->stream, d, (int)items.size(), chunks, (int)KKmax); else launch_mfma_gram64(s->stream, d, (int)items.size(), chunks, (int)KKmax); }
     else launch_gram<T, Acc>(s->stream, d, (int)items.size(), chunks, TR, (int)KKmax);
 }
 
@@ -886,6 +985,28 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     }
                     chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(fm);
                 }
+                // ---- 16-dimensional planes: the two messages a site sends in this level, both continuing from the same shared product and
+                // each absorbing exactly the other's outgoing leg, come from ONE pass over (T, psi) (mfma_pair_gram2x16_kernel) ------------
+                std::vector<PairGram2x16Item> g16; std::vector<std::pair<int, int>> g16_chain;       // (chain of the message through ly, through lx)
+                if (std::is_same<T, float>::value && use_mfma() && use_pair() && use_dbl()) {
+                    std::unordered_map<int, std::vector<int>> by_src;
+                    for (size_t ci = 0; ci < chains.size(); ++ci)
+                        if (chains[ci].y && chains[ci].steps.size() == 1 && !fmsg[ci] && chains[ci].sd.n >= (size_t)(1u << 14)) by_src[chains[ci].v].push_back((int)ci);
+                    for (auto& kv : by_src) {
+                        if (kv.second.size() != 2) continue;
+                        const int ci = kv.second[0], cj = kv.second[1];
+                        Chain& a = chains[ci]; Chain& b = chains[cj];
+                        auto out_leg = [&](int c) { int de = plan.seq[tpos[c]]; int e = de / 2; int dst = (de & 1) ? g.esrc[e] : g.edst[e]; return g.leg(chains[c].v, dst); };
+                        const int ly = out_leg(ci), lx = out_leg(cj);
+                        if (a.src != b.src || a.y != b.y || a.steps[0].first != lx || b.steps[0].first != ly) continue;
+                        PairGram2x16Item it{};
+                        if (!plane_geometry(a.sd.d, a.sd.z, a.sd.chi.data(), lx, ly, 16, it.g)) continue;
+                        it.X = a.src; it.Y = a.y; it.Mx = a.steps[0].second; it.My = b.steps[0].second;
+                        g16.push_back(it); g16_chain.push_back({ci, cj});
+                        a.steps.clear(); b.steps.clear();
+                        is_shared_chain.push_back(ci); is_shared_chain.push_back(cj);
+                    }
+                }
                 ht_prep.stop();
                 std::vector<char> is_shared(chains.size(), 0);
                 for (int ci : is_shared_chain) is_shared[ci] = 1;
@@ -926,6 +1047,23 @@ template <class T> static void bp_update_t(State* s, const tnqs_bp_opts* o, int*
                     const PairGram2Item* d = upload(s, sh_dbl);
                     ProfScope ps(s, TNQS_PROF_BP_PAIRGRAM, 2.0 * sh_dbl_slices * 8192.0 * esz, 4 * 8.0 * sh_dbl_slices * 8192.0 * 32);
                     launch_mfma_pair_gram2(s->stream, d, (int)sh_dbl.size(), wgs);
+                }
+                if (!g16.empty()) {
+                    double tot = 0; for (auto& it : g16) tot += it.g.nslices();
+                    int spw = 2; while (spw < 128 && tot / (2 * spw) >= 2048.0) spw *= 2;       // a multiple of 2: 4 waves = 2 slices x 2 halves
+                    int wgs = 0; double by = 0, fl = 0;
+                    for (size_t q = 0; q < g16.size(); ++q) {
+                        PairGram2x16Item& it = g16[q]; GramJob& jy = jobs[g16_chain[q].first]; GramJob& jx = jobs[g16_chain[q].second];
+                        const int nwg = (it.g.nslices() + spw - 1) / spw;
+                        it.spw = spw; it.wg_begin = wgs; wgs += nwg;
+                        jy.nchunks = jx.nchunks = nwg; jy.KK = jx.KK = 16;
+                        jy.partial = dalloc(s, (size_t)nwg * 256 * esz); jx.partial = dalloc(s, (size_t)nwg * 256 * esz);
+                        it.partial_y = jy.partial->p; it.partial_x = jx.partial->p;
+                        by += 2.0 * jy.sd.n * esz; fl += 4 * 8.0 * jy.sd.n * 16;
+                    }
+                    const PairGram2x16Item* d = upload(s, g16);
+                    ProfScope ps(s, TNQS_PROF_BP_PAIRGRAM, by, fl);
+                    launch_mfma_pair_gram2x16(s->stream, d, (int)g16.size(), wgs);
                 }
                 {   // singles: drop the entries that were merged into a double item
                     std::vector<PairGramItem> keep; std::vector<int> keepc;
@@ -1311,7 +1449,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             int n = nof(i);
             if (!GV[i]) GV[i] = dalloc(s, (size_t)n * n * 16);
             const size_t Nout = sj[i].sd.n / (size_t)n;
-            const bool ch = allow_chol && n <= 96 && Nout >= (size_t)n;
+            const bool ch = allow_chol && n <= 128 && Nout >= (size_t)n;
             is_chol[i] = ch ? 1 : 0;
             if (!ch && sj[i].owned && Nout < (size_t)n && n <= 256 && use_small_svd()) {
                 // fewer fibers than columns: R = Sigma U^dagger straight from the SVD of the n x N matricised psi~ (no rank-deficient G)
@@ -1339,7 +1477,10 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             launch_jacobi<double>(s->stream, dj, (int)sji.size(), 60, jacobi_lds(lds), mmax_of(sji));
             launch_small_svd_finish(s->stream, ds, (int)si.size());
         }
-        if (!ci.empty()) { const CholItem* dc = upload(s, ci); ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_chol(s->stream, dc, (int)ci.size(), cmax); }
+        if (!ci.empty()) {      // n <= 96: square LDS array; 96 < n <= 128 (chi = 64 sites): packed triangle
+            const CholItem* dc = upload(s, ci); ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0);
+            if (cmax <= 96) launch_chol(s->stream, dc, (int)ci.size(), cmax); else launch_chol_packed(s->stream, dc, (int)ci.size(), cmax);
+        }
         if (!ji.empty()) {
             const EnvItem* di = upload(s, idn);
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)idn.size()); }
@@ -1463,7 +1604,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         for (int q = 0; q < npg; ++q) {
             if (!gitems[q].lowG) continue;
             const int K = gitems[q].kappa * gitems[q].chi;
-            lc.push_back(CholItem{gitems[q].lowG, const_cast<void*>(gitems[q].lowL), ws[pg[q]].lowW->p, K, reinterpret_cast<int*>(d_lowfail->p) + q, rank_tau(true, K)});
+            lc.push_back(CholItem{gitems[q].lowG, const_cast<void*>(gitems[q].lowL), K <= 96 ? ws[pg[q]].lowW->p : nullptr, K, reinterpret_cast<int*>(d_lowfail->p) + q, rank_tau(true, K)});
             kmax = std::max(kmax, K);
         }
         if (!lc.empty()) {
@@ -1594,8 +1735,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         for (auto& j : ji) { lds_av = std::max(lds_av, jacobi_lds_bytes(j.m, j.n, true, esz)); lds_a = std::max(lds_a, jacobi_lds_bytes(j.m, j.n, false, esz)); }
         const bool novee = theta0_used;
         if (novee) for (auto& j : ji) j.V = nullptr;
-        const JacobiItem* dj = upload(s, ji);
-        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<T>(s->stream, dj, npg, 60, jacobi_lds(novee ? lds_a : lds_av), mmax_of(ji)); }
+        (void)lds_av; (void)lds_a;
+        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); svd_batch<T>(s, ji, !novee); }
         if (novee) {
             std::vector<RecoverItem> rv;
             for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ncfull[q], ji[q].n});

@@ -18,6 +18,7 @@
 #include <string>
 #define TNQS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP kernel launch failed (") + __func__ + "): " + hipGetErrorString(e_)); } while (0)
 #include "kernels.hpp"
+#include "launch_util.hpp"
 
 namespace tnqs {
 
@@ -668,8 +669,7 @@ template void launch_recover_v<double>(hipStream_t, const RecoverItem*, int, int
 
 // lds_bytes: max over the items of (m*n + (V ? n*n : 0)) * sizeof(complex<T>); 0 selects the global-memory kernel
 template <class T, int RQ> static void launch_jacobi_lds(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<T, RQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 256)); attr = true; }
+    set_max_dynamic_lds((const void*)jacobi_lds_kernel<T, RQ>, (size_t)(160 * 1024 - 256));
     hipLaunchKernelGGL((jacobi_lds_kernel<T, RQ>), dim3(nitems), dim3(1024), lds_bytes, s, d_items, max_sweeps); TNQS_CHECK_LAUNCH();
 }
 // mmax: largest row count among the items (selects the rows-per-lane instantiation)
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
 }
 // Same factorisation with the lower triangle PACKED in LDS (column j holds rows j..n-1): n up to 128 fits (132 KB), which the low-rank theta
 // route needs at chi = 64 (K = kappa chi = 128).  Only L is produced (CholItem::Winv is not written: the packed layout has no spare triangle
-// for the inverse, and that route does not use it).
+// for the inverse: when CholItem::Winv is given, (L^-1)^dagger is built in place in global memory by a second phase).
 __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_piv; __shared__ double s_dmax;
@@ -821,6 +821,7 @@ __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __rest
     __syncthreads();
     if (tid == 0) { double m = 0; for (int i = 0; i < n; ++i) m = fmax(m, A[at(i, i)].re); s_dmax = m; }
     __syncthreads();
+    if (it.shift > 0) { for (int i = tid; i < n; i += 256) A[at(i, i)].re += it.shift * s_dmax; __syncthreads(); }
     const double tiny = it.tau * s_dmax;
     for (int k = 0; k < n; ++k) {
         if (tid == 0) {
@@ -848,19 +849,35 @@ __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __rest
     }
     cx<double>* L = reinterpret_cast<cx<double>*>(it.L);
     for (int e = tid; e < n * n; e += 256) { int i = e % n, j = e / n; L[e] = (i >= j) ? A[at(i, j)] : cmake<double>(0, 0); }
+    if (!it.Winv) return;
+    // W = (L^-1)^dagger (upper triangular), W[c + n*i] = conj(Linv[i, c]): column c of L^-1 by forward substitution, one thread per column;
+    // the packed layout has no spare triangle, so the running column lives in W itself (thread c only ever touches row c of W: the
+    // accesses of neighbouring threads are neighbouring addresses)
+    cx<double>* W = reinterpret_cast<cx<double>*>(it.Winv);
+    for (int e = tid; e < n * n; e += 256) { int i = e % n, a = e / n; if (i > a) W[e] = cmake<double>(0, 0); }
+    for (int c = tid; c < n; c += 256) {
+        W[c + (size_t)n * c] = cmake<double>(1.0 / A[at(c, c)].re, 0.0);
+        for (int i = c + 1; i < n; ++i) {
+            cx<double> acc = cmake<double>(0, 0);
+            for (int j = c; j < i; ++j) {
+                const cx<double> lj = A[at(i, j)]; cx<double> x = W[c + (size_t)n * j]; x.im = -x.im;      // stored conjugated
+                acc.re -= lj.re * x.re - lj.im * x.im; acc.im -= lj.re * x.im + lj.im * x.re;
+            }
+            const double inv = 1.0 / A[at(i, i)].re;
+            W[c + (size_t)n * i] = cmake<double>(acc.re * inv, -acc.im * inv);
+        }
+    }
 }
 void launch_chol_packed(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {
     if (nitems <= 0) return;
     const size_t lds = (size_t)nmax * (nmax + 1) / 2 * 16;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)chol_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 256)); attr = true; }
+    set_max_dynamic_lds((const void*)chol_packed_kernel, (size_t)(160 * 1024 - 256));
     hipLaunchKernelGGL(chol_packed_kernel, dim3(nitems), dim3(256), lds, s, d_items); TNQS_CHECK_LAUNCH();
 }
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {
     if (nitems <= 0) return;
     const size_t lds = (size_t)nmax * (nmax + 1) * 16;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 256)); attr = true; }
+    set_max_dynamic_lds((const void*)chol_kernel, (size_t)(160 * 1024 - 256));
     hipLaunchKernelGGL(chol_kernel, dim3(nitems), dim3(256), lds, s, d_items); TNQS_CHECK_LAUNCH();
 }
 

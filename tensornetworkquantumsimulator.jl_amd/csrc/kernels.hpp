@@ -151,9 +151,17 @@ void launch_small_svd_finish(hipStream_t s, const SmallSvdItem* d_items, int nit
 // reference's QR keeps everything above that (a flat 1e-12 here dropped singular directions of relative size < 1e-6 and cost 1e-9
 // per layer in log Z on the reference's thermal-state example, cutoff = 1e-14).
 __host__ __device__ inline double rank_tau(bool f32_state, int n) { return f32_state ? 1e-12 : 4.0 * (double)n * 2.220446049250313e-16; }
-struct CholItem { const void* G; void* L; void* Winv; int n; int* fail; double tau; };
+struct CholItem { const void* G; void* L; void* Winv; int n; int* fail; double tau; double shift; };      // shift (packed kernel only): G + shift * max diag * I is factorised
+// Cholesky-QR preprocessing of a tall theta for the LDS-resident Jacobi (kernels_chi64.hip): A m x n (ComplexF32, ld = m)
+struct TallSvdItem { const void* A; void* G; const void* L; void* R0; void* Rrot; int m, n; };
+struct SmallGemmItem { const void* A; const void* B; void* C; int m, n, k; };           // C (m x n) = A (m x k) B (k x n), ComplexF32
+struct CopyItem { const void* src; void* dst; size_t n16; };                             // n16 16-byte words
+void launch_tall_gram(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);
+void launch_tall_rt(hipStream_t s, const TallSvdItem* d_items, int nitems);
+void launch_small_cgemm(hipStream_t s, const SmallGemmItem* d_items, int nitems, int mmax, int nmax);
+void launch_copy_items(hipStream_t s, const CopyItem* d_items, int nitems);
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax);
-void launch_chol_packed(hipStream_t s, const CholItem* d_items, int nitems, int nmax);      // L only, n <= 128 (packed triangle in LDS)
+void launch_chol_packed(hipStream_t s, const CholItem* d_items, int nitems, int nmax);      // n <= 128 (packed triangle in LDS); Winv may be null
 template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax);
 void launch_recover_v_mfma(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax);    // ComplexF32, MFMA (kernels_mfma.hip)
 template <class T> void launch_env_prepare(hipStream_t s, const EnvItem* d_items, int nitems);
@@ -223,11 +231,57 @@ struct PairGramItem {     // partial[b,b'] = sum_{rest, jx} (sum_ix X[.. ix .. b
     int spw;              // slices per workgroup
 };
 
+// ---- 16-dimensional planes (kernels_plane.hip): the per-site shape of BASELINE configs[3] (degree 6, chi = 16) and of heavy-hex ------
+// Same idea as PairGeom for two legs of dimension DIM = 16, with one more slice counter (a degree-6 site has four legs besides the
+// plane): slice sl -> a0 = sl % n0, a1 = (sl / n0) % n1, a2 = (sl / (n0 n1)) % n2, a3 = sl / (n0 n1 n2), base = sum a_i t_i.
+// A slice holds 16 companion elements = 8 (re, im) PAIRS of 2 contiguous elements, pair f at f * cstr, and is processed as two
+// half slices of 8 companions (64-byte runs) by two waves of one workgroup at the same time.
+struct PlaneGeom { long long cstr, sx, sy, t0, t1, t2, t3; int n0, n1, n2, n3; int nslices() const { return n0 * n1 * n2 * n3; } };
+inline bool plane_geometry(int d, int z, const int* chi, int lx, int ly, int DIM, PlaneGeom& g) {
+    if (lx == ly || lx < 0 || ly < 0 || lx >= z || ly >= z || chi[lx] != DIM || chi[ly] != DIM) return false;
+    auto pre = [&](int j) { long long p = d; for (int i = 0; i < j; ++i) p *= chi[i]; return p; };
+    const int p = lx < ly ? lx : ly, q = lx < ly ? ly : lx;
+    g.sx = pre(lx); g.sy = pre(ly);
+    g.n1 = g.n2 = g.n3 = 1; g.t1 = g.t2 = g.t3 = 0;
+    if (pre(p) % 16 == 0) {            // 16 contiguous companions below the lower leg
+        g.cstr = 2; g.n0 = (int)(pre(p) / 16); g.t0 = 16;
+        g.n1 = (int)(pre(q) / (pre(p) * DIM)); g.t1 = pre(p) * DIM;
+        long long post = 1; for (int i = q + 1; i < z; ++i) post *= chi[i];
+        g.n2 = (int)post; g.t2 = pre(q) * DIM;
+        return true;
+    }
+    if (pre(p) != 2) return false;     // leg 0 above a 2-dimensional site index: companions = (s) x 8 values of another leg
+    int a = -1;
+    for (int i = 0; i < z; ++i) if (i != p && i != q && chi[i] % 8 == 0) { a = i; break; }
+    if (a < 0) return false;
+    g.cstr = pre(a); g.n0 = chi[a] / 8; g.t0 = 8 * pre(a);
+    int k = 0;
+    for (int i = 0; i < z; ++i) {
+        if (i == p || i == q || i == a) continue;
+        if (k == 0) { g.n1 = chi[i]; g.t1 = pre(i); } else if (k == 1) { g.n2 = chi[i]; g.t2 = pre(i); } else if (k == 2) { g.n3 = chi[i]; g.t3 = pre(i); } else return false;
+        ++k;
+    }
+    return true;
+}
+struct Pair16Item {       // out = in x_x Mx x_y My for two 16-dimensional legs
+    const void* in; void* out; const void* Mx; const void* My;
+    PlaneGeom g;
+    int wg_begin;         // first workgroup id of this item
+    int spw;              // slices walked by one workgroup (a multiple of 4: the 8 waves take 4 slices x 2 halves at a time)
+};
+// both messages a site sends into one linear forest from one pass over (X = shared partial product, Y = psi), 16 x 16 plane (lx, ly):
+//   partial_y[b,b'] = sum (X x_lx Mx)[.. b on ly ..] conj(Y[.. b' on ly ..]),   partial_x[d,d'] = sum (X x_ly My)[.. d on lx ..] conj(Y[.. d' on lx ..])
+// one 16 x 16 partial per workgroup each
+struct PairGram2x16Item { const void* X; const void* Y; const void* Mx; const void* My; void* partial_y; void* partial_x; PlaneGeom g; int wg_begin; int spw; };
+void launch_mfma_pair16(hipStream_t s, const Pair16Item* d_items, int nitems, int total_wgs);
+void launch_mfma_pair_gram2x16(hipStream_t s, const PairGram2x16Item* d_items, int nitems, int total_wgs);
+
 // ---- MFMA fast paths (ComplexF32 only; kernels_mfma.hip) -----------------------------------------------------------
 int mfma_fiber_tile_rows(int KK, int NN);     // fibers per tile for the shape, 0 = not covered
 bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_tiles, int KKmax, int NNmax,
                             double* d_norm_partials);
 bool launch_mfma_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);  // tiles of 64 fibers; writes 4 partials per chunk
+bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);  // same for 32 < KK <= 64 (kernels_chi64.hip)
 // fused (X x_r M) then Gram with Y: tiles of 64 fibers = (s:2) x (first row leg: 32); writes 4 partials per chunk
 void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
 // Gram with f64 accumulation on the f64 matrix cores (gate path: G = psi~^dagger psi~, D*K == 64, X == Y); tiles of 64 fibers

@@ -12,54 +12,10 @@
 #include <string>
 #define TNQS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP kernel launch failed (") + __func__ + "): " + hipGetErrorString(e_)); } while (0)
 #include "kernels.hpp"
+#include "mfma_common.hpp"
+#include "launch_util.hpp"
 
 namespace tnqs {
-
-typedef float v16f __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-struct alignas(8) cf { float re, im; };
-
-// LDS-only workgroup barrier: __syncthreads() also drains vmcnt (global loads AND stores in flight), which would
-// serialise the prefetch / store streams against the LDS hand-offs (cdna_hip_programming.md, "Pipelining across barriers").
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// tile <-> thread map (division-free inner loops).  A tile holds TA x TB fibers; one "unit" is VEC memory-adjacent
-// elements of one k-slice ((s=0,s=1) of a fiber when D == 2, fibers (a, a+1) when D == 1 and TA is even).  Thread t
-// owns unit u = t % U of the k-slices kp, kp+KP, ... .
-// ------------------------------------------------------------------------------------------------------------
-struct TileMap {
-    int U, KP, u, kp;          // units per k-slice, k phases, this thread's unit / first k
-    int row0, row1, c0, c1;    // LDS row and (s) column offset of the unit's two elements (row1 < 0: single)
-    int al, bl, al1;           // tile-local fiber coordinates (validity tests)
-    int vec;                   // elements per unit (1 or 2)
-    long long off;             // element offset of the unit inside the tile's origin (k = 0)
-    bool active;
-};
-__device__ __forceinline__ TileMap make_map(int tid, int D, int TA, int TB, long long PA, int K) {
-    TileMap m;
-    const int rows = TA * TB;
-    m.vec = (D == 2) ? 2 : ((D == 1 && (TA % 2 == 0) && (PA % 2 == 0)) ? 2 : 1);
-    m.U = D * rows / m.vec;
-    m.KP = m.U >= 256 ? 1 : 256 / m.U;
-    m.u = tid % m.U; m.kp = tid / m.U;
-    m.active = tid < m.U * m.KP;
-    int e0 = m.u * m.vec;                 // first element index in (s, al, bl) order
-    int s = e0 % D; int row = e0 / D;
-    m.al = row % TA; m.bl = row / TA;
-    m.row0 = row; m.c0 = s;
-    if (m.vec == 2) { if (D == 2) { m.row1 = row; m.c1 = 1; m.al1 = m.al; } else { m.row1 = row + 1; m.c1 = 0; m.al1 = m.al + 1; } }
-    else { m.row1 = -1; m.c1 = 0; m.al1 = m.al; }
-    m.off = s + (long long)D * (m.al + PA * (long long)K * m.bl);
-    return m;
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // fiber GEMM:  out[(s',n),(a,b)] = sum_{(s,k)} in[(s,k),(a,b)] X[(s,k),(s',n)]   with D*K <= 32*KB, Do*No <= 32*NB.
@@ -240,24 +196,6 @@ __global__ __launch_bounds__(256) void mfma_fiber_gemm_kernel(const FiberItem* _
 // the tile loop -- the 3-4 waves resident on a SIMD drift apart and one wave's MFMA block overlaps the others'
 // global / LDS phases.  This is the production kernel; the workgroup-tile kernel above is kept for A/B.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ TileMap make_map_wave(int lane, int D, int TA, int TB, long long PA, int K) {
-    TileMap m;
-    const int rows = TA * TB;
-    m.vec = (D == 2) ? 2 : ((D == 1 && (TA % 2 == 0) && (PA % 2 == 0)) ? 2 : 1);
-    m.U = D * rows / m.vec;
-    m.KP = m.U >= 64 ? 1 : 64 / m.U;
-    m.u = lane % m.U; m.kp = lane / m.U;
-    m.active = lane < m.U * m.KP;
-    int e0 = m.u * m.vec;
-    int s = e0 % D; int row = e0 / D;
-    m.al = row % TA; m.bl = row / TA;
-    m.row0 = row; m.c0 = s;
-    if (m.vec == 2) { if (D == 2) { m.row1 = row; m.c1 = 1; m.al1 = m.al; } else { m.row1 = row + 1; m.c1 = 0; m.al1 = m.al + 1; } }
-    else { m.row1 = -1; m.c1 = 0; m.al1 = m.al; }
-    m.off = s + (long long)D * (m.al + PA * (long long)K * m.bl);
-    return m;
-}
-
 template <int KB, int NB, int NU>
 __global__ __launch_bounds__(256) void mfma_fiber_gemm_w_kernel(const FiberItem* __restrict__ items, int nitems,
                                                                 double* __restrict__ norm_partials) {
@@ -453,8 +391,7 @@ bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems,
         }
         if (KKmax <= 64 && NNmax <= 64) {
             const size_t lds = fiber_lds<2, 2, 128>();
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_fiber_gemm_w_kernel<2, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+            set_max_dynamic_lds((const void*)mfma_fiber_gemm_w_kernel<2, 2, 16>, (size_t)lds);
             hipLaunchKernelGGL((mfma_fiber_gemm_w_kernel<2, 2, 16>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
             return true;
         }
@@ -467,8 +404,7 @@ bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems,
     }
     if (KKmax <= 64 && NNmax <= 64) {
         const size_t lds = fiber_lds<2, 2, 64>();
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_fiber_gemm_kernel<2, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        set_max_dynamic_lds((const void*)mfma_fiber_gemm_kernel<2, 2, 64>, (size_t)lds);
         hipLaunchKernelGGL((mfma_fiber_gemm_kernel<2, 2, 64>), dim3(total_tiles), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
         return true;
     }
@@ -696,8 +632,7 @@ __global__ __launch_bounds__(256) void mfma_gram32_fused_kernel(const GramItem* 
 void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks) {
     if (total_chunks <= 0) return;
     const size_t lds = (size_t)4 * 2 * 32 * 65 * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_gram32_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    set_max_dynamic_lds((const void*)mfma_gram32_fused_kernel, lds);
     hipLaunchKernelGGL(mfma_gram32_fused_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
 }
 
@@ -823,8 +758,7 @@ __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restri
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
     const size_t lds = (size_t)16 * (32 * 33 + 1) * 2 * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    set_max_dynamic_lds((const void*)mfma_pair_kernel, lds);
     static int skip = -1; if (skip < 0) { const char* e = std::getenv("TNQS_DBG_PAIR_SKIP"); skip = e ? std::atoi(e) : 0; }
     static int xcd = -1; if (xcd < 0) { const char* e = std::getenv("TNQS_XCD_REMAP"); xcd = e ? std::atoi(e) : 0; }
     hipLaunchKernelGGL(mfma_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems, skip, xcd); TNQS_CHECK_LAUNCH();
@@ -945,8 +879,7 @@ __global__ __launch_bounds__(512) void mfma_pair_gram_kernel(const PairGramItem*
 void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
     const size_t lds = (size_t)16 * (32 * 33 + 1) * 2 * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    set_max_dynamic_lds((const void*)mfma_pair_gram_kernel, lds);
     static int xcd = -1; if (xcd < 0) { const char* e = std::getenv("TNQS_XCD_REMAP"); xcd = e ? std::atoi(e) : 0; }
     hipLaunchKernelGGL(mfma_pair_gram_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems, xcd); TNQS_CHECK_LAUNCH();
 }
@@ -1096,8 +1029,7 @@ __global__ __launch_bounds__(512) void mfma_pair_gram2_kernel(const PairGram2Ite
 void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
     const size_t lds = ((size_t)16 * (32 * 33 + 1) + 2 * 32 * 33) * 2 * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_pair_gram2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    set_max_dynamic_lds((const void*)mfma_pair_gram2_kernel, lds);
     hipLaunchKernelGGL(mfma_pair_gram2_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
 }
 
@@ -1250,8 +1182,7 @@ __global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __
 void launch_mfma_apply64(hipStream_t s, const Apply64Item* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
     const size_t lds = (size_t)16 * (2 * 32 * 32) * sizeof(float) + 2048 * 16;        // 160 KiB: the whole LDS of a CU
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_apply64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    set_max_dynamic_lds((const void*)mfma_apply64_kernel, lds);
     hipLaunchKernelGGL(mfma_apply64_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
 }
 
@@ -1469,8 +1400,7 @@ bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, 
     if (KKmax > 64) return false;
     if (total_chunks <= 0) return true;
     const size_t lds = (size_t)4 * 64 * 68 * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)mfma_gram64_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    set_max_dynamic_lds((const void*)mfma_gram64_f64_kernel, lds);
     static int skip = -1; if (skip < 0) { const char* e = std::getenv("TNQS_DBG_GRAM_SKIP"); skip = e ? std::atoi(e) : 0; }
     hipLaunchKernelGGL(mfma_gram64_f64_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems, skip); TNQS_CHECK_LAUNCH();
     return true;

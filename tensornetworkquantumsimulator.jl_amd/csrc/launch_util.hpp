@@ -1,0 +1,24 @@
+// launch_util.hpp -- host-side helpers shared by the kernel translation units.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <map>
+#include <mutex>
+#include <utility>
+
+namespace tnqs {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device, per-function attribute: remember it per (device, function) behind a lock
+// (handles on different devices, used from different threads, each get the attribute set once on THEIR device).
+inline void set_max_dynamic_lds(const void* func, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_pair(dev, func);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return;
+    (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    done[key] = bytes;
+}
+
+}  // namespace tnqs

@@ -1,0 +1,72 @@
+// mfma_common.hpp -- device-side helpers shared by the MFMA translation units (kernels_mfma.hip, kernels_plane.hip, kernels_chi64.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tnqs {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct alignas(8) cf { float re, im; };
+
+// LDS-only workgroup barrier: __syncthreads() also drains vmcnt (global loads AND stores in flight), which would
+// serialise the prefetch / store streams against the LDS hand-offs (cdna_hip_programming.md, "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// tile <-> thread map (division-free inner loops).  A tile holds TA x TB fibers; one "unit" is VEC memory-adjacent
+// elements of one k-slice ((s=0,s=1) of a fiber when D == 2, fibers (a, a+1) when D == 1 and TA is even).  Thread t
+// owns unit u = t % U of the k-slices kp, kp+KP, ... .
+// ------------------------------------------------------------------------------------------------------------
+struct TileMap {
+    int U, KP, u, kp;          // units per k-slice, k phases, this thread's unit / first k
+    int row0, row1, c0, c1;    // LDS row and (s) column offset of the unit's two elements (row1 < 0: single)
+    int al, bl, al1;           // tile-local fiber coordinates (validity tests)
+    int vec;                   // elements per unit (1 or 2)
+    long long off;             // element offset of the unit inside the tile's origin (k = 0)
+    bool active;
+};
+__device__ __forceinline__ TileMap make_map(int tid, int D, int TA, int TB, long long PA, int K) {
+    TileMap m;
+    const int rows = TA * TB;
+    m.vec = (D == 2) ? 2 : ((D == 1 && (TA % 2 == 0) && (PA % 2 == 0)) ? 2 : 1);
+    m.U = D * rows / m.vec;
+    m.KP = m.U >= 256 ? 1 : 256 / m.U;
+    m.u = tid % m.U; m.kp = tid / m.U;
+    m.active = tid < m.U * m.KP;
+    int e0 = m.u * m.vec;                 // first element index in (s, al, bl) order
+    int s = e0 % D; int row = e0 / D;
+    m.al = row % TA; m.bl = row / TA;
+    m.row0 = row; m.c0 = s;
+    if (m.vec == 2) { if (D == 2) { m.row1 = row; m.c1 = 1; m.al1 = m.al; } else { m.row1 = row + 1; m.c1 = 0; m.al1 = m.al + 1; } }
+    else { m.row1 = -1; m.c1 = 0; m.al1 = m.al; }
+    m.off = s + (long long)D * (m.al + PA * (long long)K * m.bl);
+    return m;
+}
+
+__device__ __forceinline__ TileMap make_map_wave(int lane, int D, int TA, int TB, long long PA, int K) {
+    TileMap m;
+    const int rows = TA * TB;
+    m.vec = (D == 2) ? 2 : ((D == 1 && (TA % 2 == 0) && (PA % 2 == 0)) ? 2 : 1);
+    m.U = D * rows / m.vec;
+    m.KP = m.U >= 64 ? 1 : 64 / m.U;
+    m.u = lane % m.U; m.kp = lane / m.U;
+    m.active = lane < m.U * m.KP;
+    int e0 = m.u * m.vec;
+    int s = e0 % D; int row = e0 / D;
+    m.al = row % TA; m.bl = row / TA;
+    m.row0 = row; m.c0 = s;
+    if (m.vec == 2) { if (D == 2) { m.row1 = row; m.c1 = 1; m.al1 = m.al; } else { m.row1 = row + 1; m.c1 = 0; m.al1 = m.al + 1; } }
+    else { m.row1 = -1; m.c1 = 0; m.al1 = m.al; }
+    m.off = s + (long long)D * (m.al + PA * (long long)K * m.bl);
+    return m;
+}
+
+
+}  // namespace tnqs

@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_worker(env):
-    r = subprocess.run([sys.executable, os.path.join(HERE, "toggle_worker.py")], env=dict(os.environ, PYTHONPATH=os.pathsep.join(sys.path), **env),
+def run_worker(env, *args):
+    r = subprocess.run([sys.executable, os.path.join(HERE, "toggle_worker.py"), *args], env=dict(os.environ, PYTHONPATH=os.pathsep.join(sys.path), **env),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -74,3 +74,21 @@ def test_torch_can_be_imported_after_the_library():
         "print('ok')\n") % (sys.path,)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_chi16_plane_kernels_match_the_single_leg_route():
+    """BASELINE configs[3] per-site shape on the 3x3x3 torus: BP messages after two sweeps in the default order (elementwise: same site
+    tensors, same order), then one layer (bond dimensions, truncation errors, <Z>) -- 16 x 16 plane kernels against single-leg products +
+    plain Grams.  The plane route must actually have been taken (kernel-class launch counts)."""
+    on, off = run_worker({}, "cubic16"), run_worker({"TNQS_NO_PAIR": "1"}, "cubic16")
+    assert on["pairgram"] > 0 and on["pair"] > 0 and off["pairgram"] == 0 and off["pair"] == 0
+    worst = 0.0
+    for ma, mb in zip(on["msgs"], off["msgs"]):
+        a = np.array(ma[0]) + 1j * np.array(ma[1]); b = np.array(mb[0]) + 1j * np.array(mb[1])
+        worst = max(worst, float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
+    print("chi = 16 plane kernels vs single-leg route: messages", worst)
+    assert worst < 2e-5
+    assert on["dims"] == off["dims"]
+    ea, eb = np.array(on["errs"]), np.array(off["errs"])
+    assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7)
+    assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 5e-5

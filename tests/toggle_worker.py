@@ -8,7 +8,31 @@ import numpy as np
 import tnqs_amd as tn
 
 
+def cubic16():
+    """3x3x3 periodic cubic lattice at chi = 16 (the per-site shape of BASELINE configs[3]: 27 tensors of 268 MB): two BP sweeps in the
+    library's default order and one layer -- the 16 x 16 plane kernels (two legs per pass, both messages of a forest per pass) against
+    the single-leg route (TNQS_NO_PAIR=1), which the oracle tests cover"""
+    g = tn.named_grid((3, 3, 3), periodic=True)
+    chi = 16
+    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex64, lambda v: "↑", g))
+    rng = np.random.default_rng(7)
+    for v in g.vertices:
+        shp = (2,) + (chi,) * g.degree(v); n = int(np.prod(shp))
+        bpc._set_tensor(v, rng.standard_normal(2 * n, dtype=np.float32).view(np.complex64).reshape(shp) / np.float32(np.sqrt(n)))
+    tn.profile_enable(bpc, True)
+    bpc = tn.update(bpc, maxiter=2, tolerance=None)
+    prof = tn.profile_get(bpc)
+    msgs = [bpc.message(e) for (a, b) in g.edges[:20] for e in ((a, b), (b, a))]
+    layer = [("Rz", [v], -0.04) for v in g.vertices] + [("Rxx", [a, b], -0.08) for grp in tn.edge_color(g) for (a, b) in grp]
+    b2, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True), bp_update_kwargs=dict(maxiter=2, tolerance=None))
+    out = dict(msgs=[[m.real.tolist(), m.imag.tolist()] for m in msgs], errs=errs.tolist(), z=[float(np.real(x)) for x in tn.expect_all(b2, "Z")],
+               dims=[b2.bond_dim(a, b) for a, b in g.edges], pairgram=prof["bp_pairgram"]["launches"], pair=prof["bp_pair"]["launches"])
+    print(json.dumps(out))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "cubic16":
+        return cubic16()
     g = tn.named_grid((4, 4))
     psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=8, seed=3)
     bpc = tn.update(tn.BeliefPropagationCache(psi), maxiter=30, tolerance=None)
