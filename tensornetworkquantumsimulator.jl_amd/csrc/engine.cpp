@@ -410,6 +410,11 @@ struct Chain {
     const void* result = nullptr; Buf tmp[2];
 };
 
+static bool envflag(const char* name) { const char* e = std::getenv(name); return e && e[0] == '1'; }
+static bool use_rowgemm() { static int v = -1; if (v < 0) v = (envflag("TNQS_NO_ROWGEMM") || envflag("TNQS_NO_CHI64")) ? 0 : 1; return v == 1; }
+static bool use_gram64() { static int v = -1; if (v < 0) v = (envflag("TNQS_NO_GRAM64") || envflag("TNQS_NO_CHI64")) ? 0 : 1; return v == 1; }
+static bool use_gram128() { static int v = -1; if (v < 0) v = (envflag("TNQS_NO_GRAM128") || envflag("TNQS_NO_CHI64")) ? 0 : 1; return v == 1; }
+static bool use_chol128() { static int v = -1; if (v < 0) v = (envflag("TNQS_NO_CHOL128") || envflag("TNQS_NO_CHI64")) ? 0 : 1; return v == 1; }
 static bool use_pair() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_PAIR"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
 
 template <class T> static void run_chains(State* s, std::vector<Chain>& chains, int cls, int cls_pair = -1) {
@@ -503,6 +508,7 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
         if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)KKmax); if (t > 0) { TR = t; mf = true; } }
         int tpw = 1;
         if (mf) { double tot = 0; for (auto& c : chains) if (c.steps.size() > o) tot += (double)c.sd.n / c.sd.chi[c.steps[o].first] / TR; tpw = (int)std::max(1.0, std::min(TR == 32 ? 32.0 : 8.0, tot / 4096.0)); if (TR == 32 && tpw >= 4) tpw &= ~3; }
+        std::vector<FiberItem> rg_items; double rg_tiles = 0, rg_bytes = 0, rg_flops = 0;      // chi = 64 legs: register-direct MFMA kernel
         for (size_t ci = 0; ci < chains.size(); ++ci) {
             Chain& c = chains[ci];
             if (c.steps.size() <= o) continue;
@@ -512,6 +518,13 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
             if (!dst) dst = dalloc(s, c.sd.n * esz);
             it.in = c.result; it.out = dst->p; it.X = c.steps[o].second;
             it.D = 1; it.PA = (int)c.sd.pre(j); it.K = c.sd.chi[j]; it.PB = (int)c.sd.post(j); it.Do = 1; it.No = it.K;
+            if (std::is_same<T, float>::value && use_mfma() && use_rowgemm() && rowgemm_covers(it)) {
+                it.TA = 32; it.TB = 1; it.nta = it.PA / 32; it.ntb = it.PB; it.want_norm = 0;
+                rg_items.push_back(it); rg_tiles += (double)it.nta * it.ntb;
+                c.result = dst->p; nt[ci]++;
+                rg_bytes += 2.0 * c.sd.n * esz; rg_flops += 8.0 * c.sd.n * it.K;
+                continue;
+            }
             tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
             it.tpw = mf ? tpw : 1;
             it.tile_begin = tiles; tiles += (it.nta * it.ntb + it.tpw - 1) / it.tpw; it.want_norm = 0;
@@ -519,6 +532,14 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
             c.result = dst->p; nt[ci]++;
             bytes += 2.0 * c.sd.n * esz; flops += 8.0 * c.sd.n * it.K;
         }
+        if (!rg_items.empty()) {
+            int tpw = (int)std::max(4.0, std::min(64.0, rg_tiles / 2048.0)); tpw &= ~3; int wgs = 0;
+            for (auto& it : rg_items) { it.tpw = tpw; it.tile_begin = wgs; wgs += (it.nta * it.ntb + tpw - 1) / tpw; }
+            const FiberItem* d = upload(s, rg_items);
+            ProfScope ps(s, cls, rg_bytes, rg_flops);
+            launch_mfma_rowgemm(s->stream, d, (int)rg_items.size(), wgs, 1, nullptr);
+        }
+        if (items.empty()) continue;
         const FiberItem* d = upload(s, items);
         ProfScope ps(s, cls, bytes, flops);
         if (mf) launch_mfma_fiber_gemm(s->stream, d, (int)items.size(), tiles, (int)KKmax, (int)KKmax, nullptr);
@@ -530,10 +551,11 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
 // One-sided Jacobi SVD of a batch of matrices (A <- U Sigma in place; V accumulated only when the items carry one).  Three routes:
 //   * the matrix fits the LDS (jacobi_lds_kernel);
 //   * ComplexF32, no V wanted, too tall for the LDS but its n x n triangle fits (256 x 128 at chi = 64): Cholesky-QR preprocessing --
-//     G = A^dagger A (f64) -> R = chol(G + delta I)^dagger -> Jacobi on R in LDS -> J = R^dagger (U_R S_R) S_R^-2 -> A <- A J
-//     (kernels_chi64.hip; the rotations that orthogonalise R's columns orthogonalise A's, delta only conditions R);
+//     G = A^dagger A (f64) -> R = chol(G + delta I)^dagger -> Jacobi on R in LDS -> J = R^-1 (U_R S_R) (f64) -> A <- A J
+//     (kernels_chi64.hip; the rotations that orthogonalise R's columns orthogonalise A's, delta only conditions R), followed by
+//     polishing sweeps of the global-memory kernel on A J (relative orthogonality of the small columns);
 //   * anything else: the global-memory kernel.
-static bool use_tall_svd() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_TALLSVD"); v = (e && e[0] == '1') ? 0 : 1; } return v == 1; }
+static bool use_tall_svd() { static int v = -1; if (v < 0) { const char* e = std::getenv("TNQS_NO_TALLSVD"); const char* f = std::getenv("TNQS_NO_CHI64"); v = ((e && e[0] == '1') || (f && f[0] == '1')) ? 0 : 1; } return v == 1; }
 template <class T> static void svd_batch(State* s, const std::vector<JacobiItem>& all, bool with_v) {
     const size_t esz = s->esz();
     const size_t cap = 160 * 1024 - 256;
@@ -557,39 +579,48 @@ template <class T> static void svd_batch(State* s, const std::vector<JacobiItem>
     }
     if (!tall.empty()) {
         const size_t nt = tall.size();
-        size_t off = 0; std::vector<size_t> oG(nt), oL(nt), oR0(nt), oRr(nt), oJ(nt), oT(nt);
+        size_t off = 0; std::vector<size_t> oG(nt), oL(nt), oW(nt), oR0(nt), oRr(nt), oJ(nt), oT(nt);
         for (size_t i = 0; i < nt; ++i) {
             const size_t nn = (size_t)tall[i].n * tall[i].n, mn = (size_t)tall[i].m * tall[i].n;
-            oG[i] = off; off += round256(nn * 16); oL[i] = off; off += round256(nn * 16);
+            oG[i] = off; off += round256(nn * 16); oL[i] = off; off += round256(nn * 16); oW[i] = off; off += round256(nn * 16);
             oR0[i] = off; off += round256(nn * 8); oRr[i] = off; off += round256(nn * 8); oJ[i] = off; off += round256(nn * 8); oT[i] = off; off += round256(mn * 8);
         }
         Buf arena = dalloc(s, off); s->keepalive.push_back(arena);
         Buf d_fail = dalloc(s, nt * sizeof(int)); s->keepalive.push_back(d_fail);
         HIPCHK(hipMemsetAsync(d_fail->p, 0, nt * sizeof(int), s->stream));
         char* ap = reinterpret_cast<char*>(arena->p);
-        std::vector<TallSvdItem> ti; std::vector<CholItem> ci; std::vector<JacobiItem> rj; std::vector<RecoverItem> rv; std::vector<SmallGemmItem> gi; std::vector<CopyItem> cp;
+        std::vector<TallSvdItem> ti, wi; std::vector<CholItem> ci; std::vector<JacobiItem> rj; std::vector<SmallGemmItem> gi; std::vector<CopyItem> cp;
         int nmax = 1, mmax = 1;
         for (size_t i = 0; i < nt; ++i) {
             const int m = tall[i].m, n = tall[i].n; nmax = std::max(nmax, n); mmax = std::max(mmax, m);
             ti.push_back(TallSvdItem{tall[i].A, ap + oG[i], ap + oL[i], ap + oR0[i], ap + oRr[i], m, n});
             // delta = 1e-14 of the largest diagonal entry: singular directions below 1e-7 sigma_max are f32 noise of the data anyway, and R keeps
             // a condition number <= 1e7 whatever the rank of A (no failure branch: a rank-deficient theta is the normal case early in an evolution)
-            ci.push_back(CholItem{ap + oG[i], ap + oL[i], nullptr, n, reinterpret_cast<int*>(d_fail->p) + i, 0.0, 1e-14});
+            ci.push_back(CholItem{ap + oG[i], ap + oL[i], ap + oW[i], n, reinterpret_cast<int*>(d_fail->p) + i, 0.0, 1e-14});      // Winv = (L^-1)^dagger = R^-1
             rj.push_back(JacobiItem{ap + oRr[i], nullptr, n, n, tall[i].sweeps_out});
-            rv.push_back(RecoverItem{ap + oR0[i], ap + oRr[i], ap + oJ[i], n, n, n});
+            wi.push_back(TallSvdItem{nullptr, nullptr, ap + oW[i], ap + oJ[i], ap + oRr[i], n, n});                                 // J = R^-1 (R J), f64
             gi.push_back(SmallGemmItem{tall[i].A, ap + oJ[i], ap + oT[i], m, n, n});
             cp.push_back(CopyItem{ap + oT[i], tall[i].A, (size_t)m * n * 8 / 16});
         }
         const TallSvdItem* dt = upload(s, ti); const CholItem* dc = upload(s, ci); const JacobiItem* dj = upload(s, rj);
-        const RecoverItem* dr = upload(s, rv); const SmallGemmItem* dg = upload(s, gi); const CopyItem* dcp = upload(s, cp);
+        const TallSvdItem* dw = upload(s, wi); const SmallGemmItem* dg = upload(s, gi); const CopyItem* dcp = upload(s, cp);
         launch_tall_gram(s->stream, dt, (int)nt, nmax);
         launch_chol_packed(s->stream, dc, (int)nt, nmax);
         launch_tall_rt(s->stream, dt, (int)nt);
         size_t lds = 0; for (auto& j : rj) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, false, esz));
         launch_jacobi<T>(s->stream, dj, (int)nt, 60, lds, nmax);
-        launch_recover_v_mfma(s->stream, dr, (int)nt, nmax);
+        launch_tall_w(s->stream, dw, (int)nt, nmax);
         launch_small_cgemm(s->stream, dg, (int)nt, mmax, nmax);
         launch_copy_items(s->stream, dcp, (int)nt);
+        // polish: J comes out of f32 arithmetic, so a column of A J with a small singular value carries rounding residue ALONG the large left
+        // singular vectors (absolute size eps sigma_max -- large relative to the column itself), which the V recovery that follows
+        // (theta0^dagger (U Sigma) Sigma^-2) would amplify by sigma_max / sigma_j.  One-sided Jacobi on A itself guarantees orthogonality
+        // RELATIVE to the column norms; a few sweeps of the global-memory kernel on the already orthogonalised A J restore exactly that
+        // (they find almost nothing to rotate: 1-2 sweeps instead of the 8-10 of a cold start).
+        std::vector<JacobiItem> pol;
+        for (auto& j : tall) pol.push_back(JacobiItem{j.A, nullptr, j.m, j.n, nullptr});
+        const JacobiItem* dp = upload(s, pol);
+        launch_jacobi<T>(s->stream, dp, (int)nt, 6, 0, mmax);
         s->stats.n_tall_svd += (int)nt;
     }
 }
@@ -615,10 +646,11 @@ template <class T, class Acc> static void run_grams(State* s, std::vector<GramJo
     for (auto& j : jobs) { j.KK = (j.keep_site ? j.sd.d : 1) * (j.leg >= 0 ? j.sd.chi[j.leg] : 1); KKmax = std::max<size_t>(KKmax, j.KK); }
     int TR = pick_TR(KKmax + 1, esz, 2);
     const bool fused = jobs[0].M != nullptr;
-    const bool mf = fused || (std::is_same<T, float>::value && std::is_same<Acc, float>::value && use_mfma() && KKmax <= 64 && KKmax >= 8);
+    const bool mf = fused || (std::is_same<T, float>::value && std::is_same<Acc, float>::value && use_mfma() && KKmax <= (use_gram64() ? 64 : 32) && KKmax >= 8);
     bool mf64 = std::is_same<T, float>::value && std::is_same<Acc, double>::value && use_mfma() && KKmax <= 64 && KKmax >= 16;
-    for (auto& j : jobs) mf64 = mf64 && (j.X == j.Y);
-    if (mf || mf64) TR = 64;
+    bool mf128 = std::is_same<T, float>::value && std::is_same<Acc, double>::value && use_mfma() && use_gram128() && KKmax <= 128 && KKmax > 64;
+    for (auto& j : jobs) { mf64 = mf64 && (j.X == j.Y); mf128 = mf128 && (j.X == j.Y); }
+    if (mf || mf64 || mf128) TR = 64;
     const int target = 2048;
     int per_item = std::max(1, target / (int)jobs.size());
     std::vector<GramItem> items; int chunks = 0; double bytes = 0, flops = 0;
@@ -645,6 +677,7 @@ template <class T, class Acc> static void run_grams(State* s, std::vector<GramJo
     ProfScope ps(s, cls, bytes, flops);
     if (fused) launch_mfma_gram32_fused(s->stream, d, (int)items.size(), chunks);
     else if (mf64) launch_mfma_gram64_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax);
+    else if (mf128) launch_mfma_gram128_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax);
     else if (mf) { if (KKmax <= 32) launch_mfma_gram32(s->stream, d, (int)items.size(), chunks, (int)KKmax); else launch_mfma_gram64(s->stream, d, (int)items.size(), chunks, (int)KKmax); }
     else launch_gram<T, Acc>(s->stream, d, (int)items.size(), chunks, TR, (int)KKmax);
 }
@@ -1449,7 +1482,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             int n = nof(i);
             if (!GV[i]) GV[i] = dalloc(s, (size_t)n * n * 16);
             const size_t Nout = sj[i].sd.n / (size_t)n;
-            const bool ch = allow_chol && n <= 128 && Nout >= (size_t)n;
+            const bool ch = allow_chol && n <= (use_chol128() ? 128 : 96) && Nout >= (size_t)n;
             is_chol[i] = ch ? 1 : 0;
             if (!ch && sj[i].owned && Nout < (size_t)n && n <= 256 && use_small_svd()) {
                 // fewer fibers than columns: R = Sigma U^dagger straight from the SVD of the n x N matricised psi~ (no rank-deficient G)
@@ -1846,6 +1879,31 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             { ProfScope ps(s, TNQS_PROF_GATE_APPLY, 2.0 * a64_slices * 16384.0 * esz, 8.0 * a64_slices * 16384.0 * 64);
               launch_mfma_apply64(s->stream, da, (int)a64.size(), wgs); }
             norm_and_replace<T>(s, a64_verts, a64_outs, a64_ne, np64, tb64, nt64, ao.normalize_tensors != 0);
+        }
+        {   // chi = 64 sites: K = (s, b) = 128 -> N = (s', b') <= 128 on the register-direct MFMA kernel
+            std::vector<FiberItem> rg; std::vector<int> rverts, rtb, rnt; std::vector<Buf> routs; std::vector<size_t> rne; double rt = 0, rby = 0, rfl = 0;
+            if (std::is_same<T, float>::value && use_mfma() && use_rowgemm())
+                for (size_t q = 0; q < own_idx.size(); ++q) {
+                    if (via64[q]) continue;
+                    size_t i = own_idx[q]; int gi = (int)i / 2; int chin = info[8 * gi + 2]; const SiteJob& j = sj[i];
+                    FiberItem it{};
+                    it.D = j.sd.d; it.PA = (int)(j.sd.pre(j.bleg) / j.sd.d); it.K = j.sd.chi[j.bleg]; it.PB = (int)j.sd.post(j.bleg); it.Do = j.sd.d; it.No = chin;
+                    if (!rowgemm_covers(it) || it.D != 2) continue;
+                    const size_t nout = j.sd.n / it.K * chin;
+                    Buf out = dalloc(s, nout * esz);
+                    it.in = pch[q].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
+                    it.TA = 32; it.TB = 1; it.nta = it.PA / 32; it.ntb = it.PB; it.want_norm = ao.normalize_tensors ? 1 : 0;
+                    rg.push_back(it); rverts.push_back(j.v); routs.push_back(out); rne.push_back(nout); rt += (double)it.nta * it.ntb;
+                    rby += (double)(j.sd.n + nout) * esz; rfl += 8.0 * j.sd.n * j.sd.d * chin; via64[q] = 1;
+                }
+            if (!rg.empty()) {
+                int tpw = (int)std::max(4.0, std::min(32.0, rt / 2048.0)); tpw &= ~3; int wgs = 0;
+                for (auto& it : rg) { const int nwg = (it.nta * it.ntb + tpw - 1) / tpw; it.tpw = tpw; it.tile_begin = wgs; rtb.push_back(wgs); rnt.push_back(nwg); wgs += nwg; }
+                Buf npr = dalloc(s, (size_t)wgs * sizeof(double));
+                const FiberItem* d = upload(s, rg);
+                { ProfScope ps(s, TNQS_PROF_GATE_APPLY, rby, rfl); launch_mfma_rowgemm(s->stream, d, (int)rg.size(), wgs, 2, reinterpret_cast<double*>(npr->p)); }
+                norm_and_replace<T>(s, rverts, routs, rne, npr, rtb, rnt, ao.normalize_tensors != 0);
+            }
         }
         for (size_t q = 0; q < own_idx.size(); ++q) {
             if (via64[q]) continue;

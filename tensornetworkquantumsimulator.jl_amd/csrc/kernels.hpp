@@ -156,8 +156,12 @@ struct CholItem { const void* G; void* L; void* Winv; int n; int* fail; double t
 struct TallSvdItem { const void* A; void* G; const void* L; void* R0; void* Rrot; int m, n; };
 struct SmallGemmItem { const void* A; const void* B; void* C; int m, n, k; };           // C (m x n) = A (m x k) B (k x n), ComplexF32
 struct CopyItem { const void* src; void* dst; size_t n16; };                             // n16 16-byte words
+// register-direct MFMA fiber GEMM for chi = 64 sites (kernels_chi64.hip): items use TA = 32, TB = 1, nta = PA / 32, ntb = PB
+bool rowgemm_covers(const FiberItem& it);
+void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, double* d_norm_partials);
 void launch_tall_gram(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);
 void launch_tall_rt(hipStream_t s, const TallSvdItem* d_items, int nitems);
+void launch_tall_w(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);      // R0 slot (out, ComplexF32) = [L slot: R^-1, complex128] x Rrot
 void launch_small_cgemm(hipStream_t s, const SmallGemmItem* d_items, int nitems, int mmax, int nmax);
 void launch_copy_items(hipStream_t s, const CopyItem* d_items, int nitems);
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax);
@@ -286,6 +290,8 @@ bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int 
 void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
 // Gram with f64 accumulation on the f64 matrix cores (gate path: G = psi~^dagger psi~, D*K == 64, X == Y); tiles of 64 fibers
 bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);
+// the same for 64 < D*K <= 128 (chi = 64 sites; kernels_chi64.hip); writes ONE partial per chunk
+bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);
 // fused pair of mode products on two slow 32-dim legs (16 companions = 128-byte runs per workgroup)
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs);
 // gate epilogue psi' = psi x_(s,b) X for d = 2, chi_b = chi_b' = 32 (K = N = 64) in the pair-kernel shape: plane (b, y) per companion,

@@ -168,7 +168,7 @@ bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int 
 // theta SVD for matrices that do not fit the LDS-resident one-sided Jacobi (256 x 128 at chi = 64): Cholesky-QR preprocessing.
 //   G = A^dagger A + delta I (f64, n x n)  ->  G = L L^dagger (chol_packed_kernel, shift delta)  ->  R = L^dagger (n x n, f32)
 //   one-sided Jacobi on R in LDS: R J = U_R Sigma_R            (jacobi_lds_kernel<float>)
-//   J = R^dagger (U_R Sigma_R) Sigma_R^-2                      (recover_v: the rotations are never accumulated in f32)
+//   J = R^-1 (U_R Sigma_R)                                      (tall_w_kernel, f64: the rotations are never accumulated in f32)
 //   A <- A J = U Sigma of A                                    (small_cgemm: the same rotations orthogonalise the columns of A, because
 //                                                               R^dagger R and A^dagger A have the same eigenvectors; the shift only
 //                                                               bounds the condition number of R, it cancels in R^-1 (R J) = J)
@@ -226,6 +226,55 @@ __global__ __launch_bounds__(256) void tall_rt_kernel(const TallSvdItem* __restr
         if (i <= j) { const cd l = L[j + (size_t)n * i]; v.re = (float)l.re; v.im = (float)(-l.im); }
         R0[e] = v; Rr[e] = v;
     }
+}
+// W (n x n, ComplexF32) = Rinv (n x n upper triangular, complex128) Rrot (n x n, ComplexF32), accumulated in f64: with Rrot = R J from the
+// Jacobi sweeps this is J itself, accurate to the Jacobi tolerance in EVERY direction (R^-1 damps the large singular directions; the
+// V-recovery formula R^dagger (R J) S^-2 would amplify them by sigma_max / sigma_j, which turns a rank-deficient theta into wrong large
+// singular values after the product A J).  The terms of the sum are huge and cancel (|Rinv| ~ 1 / sigma_min): f64 throughout.
+__global__ __launch_bounds__(256) void tall_w_kernel(const TallSvdItem* __restrict__ items) {
+    const TallSvdItem it = items[blockIdx.x];
+    const int n = it.n, nt = (n + 31) >> 5;
+    const int I = blockIdx.y % nt, J = blockIdx.y / nt;
+    if (J >= nt) return;
+    struct alignas(16) cd { double re, im; };
+    __shared__ double Ar[32][33], Ai[32][33], Br[32][33], Bi[32][33];       // A = Rinv[32 I + i][j0 + j], B = Rrot[j0 + j][32 J + c]
+    const cd* __restrict__ Rinv = reinterpret_cast<const cd*>(it.L);        // the caller passes R^-1 in the L slot of this launch
+    const cf* __restrict__ Rrot = reinterpret_cast<const cf*>(it.Rrot);
+    cf* __restrict__ W = reinterpret_cast<cf*>(it.R0);                     // and the output in the R0 slot
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    double cr[2][2] = {{0, 0}, {0, 0}}, ci[2][2] = {{0, 0}, {0, 0}};
+    for (int j0 = 32 * I; j0 < n; j0 += 32) {                               // Rinv is upper triangular: rows 32 I.. only see columns >= 32 I
+        for (int e = tid; e < 1024; e += 256) {
+            const int a = e & 31, b = e >> 5;
+            cd x = {0.0, 0.0}; cf y = {0.f, 0.f};
+            if (32 * I + a < n && j0 + b < n) x = Rinv[(32 * I + a) + (size_t)n * (j0 + b)];
+            if (j0 + a < n && 32 * J + b < n) y = Rrot[(j0 + a) + (size_t)n * (32 * J + b)];
+            Ar[a][b] = x.re; Ai[a][b] = x.im; Br[a][b] = (double)y.re; Bi[a][b] = (double)y.im;
+        }
+        __syncthreads();
+        for (int j = 0; j < 32; ++j) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const double ar = Ar[2 * tx + p][j], ai = Ai[2 * tx + p][j], br = Br[j][2 * ty + q], bi = Bi[j][2 * ty + q];
+                    cr[p][q] += ar * br - ai * bi; ci[p][q] += ar * bi + ai * br;
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = 32 * I + 2 * tx + p, c = 32 * J + 2 * ty + q;
+            if (i < n && c < n) { cf v; v.re = (float)cr[p][q]; v.im = (float)ci[p][q]; W[i + (size_t)n * c] = v; }
+        }
+}
+void launch_tall_w(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax) {
+    if (nitems <= 0) return;
+    const int nt = (nmax + 31) / 32;
+    hipLaunchKernelGGL(tall_w_kernel, dim3(nitems, nt * nt), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 // C (m x n) = A (m x k) B (k x n), ComplexF32 column-major, one wave per 32 x 32 tile of C, operands straight from L2 (all <= 512 KiB)
 __global__ __launch_bounds__(256) void small_cgemm_kernel(const SmallGemmItem* __restrict__ items) {
@@ -285,6 +334,287 @@ void launch_small_cgemm(hipStream_t s, const SmallGemmItem* d_items, int nitems,
 void launch_copy_items(hipStream_t s, const CopyItem* d_items, int nitems) {
     if (nitems <= 0) return;
     hipLaunchKernelGGL(copy_items_kernel, dim3(nitems, 16), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// register-direct fiber GEMM:  out[(s',n),(a,b)] = sum_{(s,k)} in[(s,k),(a,b)] X[(s,k),(s',n)]  with D*K = 32 KB exactly, Do*No <= 32 NB,
+// PA a multiple of 32 (every leg but the first of a chi = 64 site; K = 64 mode products and the K = N = 128 gate epilogue).
+// The product is computed TRANSPOSED, C'[nn][row] = sum_kk X^T[nn][kk] in[row][kk], with row = 32 CONSECUTIVE a-indices on the lanes:
+//   * B' operand = the tensor itself: lane (ln = row, h) loads in[row][kk(q, h)] for every k-step q straight from global memory into
+//     the registers the MFMAs read -- 256-byte (D = 1) / 512-byte (D = 2, both site components as one 16-byte load) runs per half wave,
+//     no LDS staging, no transposition, no bank conflicts; the next tile's loads are issued before the current tile's matrix work;
+//   * A' operand = X^T, staged once per workgroup in LDS in exact operand order (one conflict-free ds_read_b64 per lane and k-step);
+//   * C' accumulators hold out[row = ln][nn = kappa(r, h) + 32 nb]: stores run along the lanes again (D = 2: registers 2j, 2j+1 are the
+//     two site components of one n, one 16-byte store).
+// One wave per SIMD (the accumulators and two in-flight tiles take up to 384 registers); the wave never waits on a workgroup barrier.
+// ------------------------------------------------------------------------------------------------------------
+template <int KB, int NB, int D>
+__global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __restrict__ items, int nitems, double* __restrict__ norm_partials) {
+    constexpr int KK = 32 * KB, NQ = KK / 2;                   // k-steps per tile
+    constexpr int NL = (D == 1) ? NQ : NQ / 2;                 // loads per lane and tile (8 bytes each for D = 1, 16 bytes for D = 2)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2f* const Xl = reinterpret_cast<v2f*>(smem);             // [q][nb][lane]
+    __shared__ double sh_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
+    int lo = 0, hi = nitems - 1;
+    const int gw = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].tile_begin <= gw) lo = mid; else hi = mid - 1; }
+    const FiberItem it = items[lo];
+    const int K = it.K, No = it.No, NN = it.Do * No;
+    const long long PA = it.PA;
+    const int ntiles = it.nta * it.ntb;                        // nta = PA / 32 row blocks, ntb = PB
+    const int t_begin = (gw - it.tile_begin) * it.tpw, t_end = min(ntiles, t_begin + it.tpw);
+    const cf* __restrict__ in = reinterpret_cast<const cf*>(it.in);
+    const cf* __restrict__ X = reinterpret_cast<const cf*>(it.X);
+    cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
+    // k-step q of lane half hh reads kk: D = 1: kk = 2 q + hh;  D = 2: q = 2 t + s -> kk = s + 2 (2 t + hh)
+    for (int e = tid; e < NQ * NB * 64; e += 256) {
+        const int l = e & 63, nb = (e >> 6) % NB, q = e / (64 * NB);
+        const int hh = l >> 5, nn = 32 * nb + (l & 31);
+        const int kk = (D == 1) ? 2 * q + hh : (q & 1) + 2 * (2 * (q >> 1) + hh);
+        cf v = {0.f, 0.f};
+        if (nn < NN) v = X[kk + (size_t)KK * nn];
+        v2f o = {v.re, v.im}; Xl[e] = o;
+    }
+    __syncthreads();                                           // the only workgroup barrier
+    float pre[2][2 * NQ];                                      // two tiles in flight: current operands and the prefetch
+    auto issue = [&](int t, int buf) {
+        const int ta = t % it.nta, tb = t / it.nta;
+        if (D == 1) {
+            const cf* p = in + (32 * ta + ln) + PA * ((long long)K * tb + h);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { const cf v = p[PA * 2 * j]; pre[buf][2 * j] = v.re; pre[buf][2 * j + 1] = v.im; }
+        } else {
+            const cf* p = in + 2 * ((32 * ta + ln) + PA * ((long long)K * tb + h));
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { const v4f v = *reinterpret_cast<const v4f*>(p + 2 * PA * 2 * j);
+                                           pre[buf][4 * j] = v[0]; pre[buf][4 * j + 1] = v[1]; pre[buf][4 * j + 2] = v[2]; pre[buf][4 * j + 3] = v[3]; }
+        }
+    };
+    double nrm = 0;
+    int t = t_begin + w;
+    if (t < t_end) issue(t, 0);
+    for (int it2 = 0; t < t_end; t += 4, ++it2) {
+        // the two register sets alternate; the loop is unrolled by two so that every access has a compile-time set index
+#pragma unroll
+        for (int cur = 0; cur < 2; ++cur) {
+            if (cur == 1) { t += 4; if (t >= t_end) break; }
+            if (t + 4 < t_end) issue(t + 4, cur ^ 1);
+            v16f Cr[NB], Ci[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { Cr[nb][r] = 0.f; Ci[nb][r] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float br = pre[cur][2 * q], bi = pre[cur][2 * q + 1];      // in[row][kk(q, h)]
+                const float nbi = -bi;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const v2f a = Xl[(q * NB + nb) * 64 + lane];                  // X[kk(q, h)][32 nb + ln]
+                    Cr[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], br, Cr[nb], 0, 0, 0);
+                    Ci[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bi, Ci[nb], 0, 0, 0);
+                    Cr[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], nbi, Cr[nb], 0, 0, 0);
+                    Ci[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], br, Ci[nb], 0, 0, 0);
+                }
+            }
+            const int ta = t % it.nta, tb = t / it.nta;
+            float nf = 0.f;
+            if (D == 1) {
+                cf* p = out + (32 * ta + ln) + PA * ((long long)No * tb);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (n < No) { cf v; v.re = Cr[nb][r]; v.im = Ci[nb][r]; p[PA * n] = v; nf += v.re * v.re + v.im * v.im; }
+                    }
+            } else {
+                cf* p = out + 2 * ((32 * ta + ln) + PA * ((long long)No * tb));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int nn = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;  // even: s' = 0 of n = nn / 2; register r + 1 is s' = 1
+                        const int n = nn >> 1;
+                        if (n < No) {
+                            v4f v = {Cr[nb][r], Ci[nb][r], Cr[nb][r + 1], Ci[nb][r + 1]};
+                            *reinterpret_cast<v4f*>(p + 2 * PA * n) = v;
+                            nf += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                        }
+                    }
+            }
+            nrm += (double)nf;
+        }
+    }
+    if (it.want_norm) {
+        nrm = wave_sum_d(nrm);
+        if (lane == 0) sh_red[w] = nrm;
+        __syncthreads();
+        if (tid == 0) norm_partials[gw] = sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3];
+    }
+}
+// shapes: (KK, NN) in {(64, 64): D = 1 mode products at chi = 64;  (128, <= 128): D = 2 gate epilogue at chi = 64}
+bool rowgemm_covers(const FiberItem& it) {
+    if (it.PA < 32 || it.PA % 32 != 0) return false;
+    if (it.D == 1 && it.Do == 1 && it.K == 64 && it.No <= 64 && it.No >= 1) return true;
+    if (it.D == 2 && it.Do == 2 && it.K == 64 && it.No <= 64 && it.No >= 1) return true;
+    return false;
+}
+void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, double* d_norm_partials) {
+    if (total_wgs <= 0) return;
+    if (D == 1) {
+        const size_t lds = (size_t)32 * 2 * 64 * sizeof(v2f);
+        set_max_dynamic_lds((const void*)mfma_rowgemm_kernel<2, 2, 1>, lds);
+        hipLaunchKernelGGL((mfma_rowgemm_kernel<2, 2, 1>), dim3(total_wgs), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
+    } else {
+        const size_t lds = (size_t)64 * 4 * 64 * sizeof(v2f);
+        set_max_dynamic_lds((const void*)mfma_rowgemm_kernel<4, 4, 2>, lds);
+        hipLaunchKernelGGL((mfma_rowgemm_kernel<4, 4, 2>), dim3(total_wgs), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Gram with f64 accumulation on v_mfma_f64_16x16x4_f64 for 64 < KK = D*K <= 128 (gate path at chi = 64: G = psi~^dagger psi~ over the
+// outer legs, 128 x 128).  Same scheme as mfma_gram64_f64_kernel (kernels_mfma.hip): ComplexF32 tiles of 64 fibers, double-buffered in
+// LDS as [kk][row], converted on the fly (f32 products are exact in f64); G is Hermitian, so only the 16 x 16 blocks (I <= J) are
+// computed -- 36 for KK = 128, dealt round-robin to the four waves (9 each) -- and mirrored when the partial is written.
+// One partial per chunk.  f64 MFMA layout: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], C[row = (l >> 4) + 4 r][col = l & 15].
+// ------------------------------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_gram128_f64_kernel(const GramItem* __restrict__ items, int nitems) {
+    constexpr int TR = 64, TRP = TR + 4, NU = 16, KKP = 128, NBW = 9;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const Xbuf = reinterpret_cast<float*>(smem);          // [buf][re|im][KKP * TRP]
+    const int tid = threadIdx.x;
+    int lo = 0, hi = nitems - 1;
+    const int gc = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].chunk_begin <= gc) lo = mid; else hi = mid - 1; }
+    const GramItem it = items[lo];
+    const int lc = gc - it.chunk_begin;
+    const int D = it.D, K = it.K, TA = it.TA, TB = it.TB, KK = D * K;
+    const long long PA = it.PA;
+    const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
+    const int ntiles = it.nta * it.ntb;
+    const int t_begin = lc * it.tiles_per_chunk;
+    const int t_end = min(ntiles, t_begin + it.tiles_per_chunk);
+    const int lane = tid & 63, w = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int nb = (KK + 15) >> 4, nblk = nb * (nb + 1) / 2;
+    int bI[NBW], bJ[NBW]; bool bOn[NBW];
+#pragma unroll
+    for (int q = 0; q < NBW; ++q) {
+        int idx = w + 4 * q; bOn[q] = idx < nblk;
+        int I = 0, rem = bOn[q] ? idx : 0; while (rem >= nb - I) { rem -= nb - I; ++I; }
+        bI[q] = I; bJ[q] = I + rem;
+    }
+    v4d Cr[NBW], Ci[NBW];
+#pragma unroll
+    for (int q = 0; q < NBW; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Cr[q][r] = 0.0; Ci[q][r] = 0.0; }
+    for (int e = tid; e < 4 * KKP * TRP; e += 256) Xbuf[e] = 0.f;
+    const TileMap m = make_map(tid, D, TA, TB, PA, K);
+    const long long kstride = (long long)D * PA;
+    const bool fast = m.U <= 256 && (K + m.KP - 1) / m.KP <= NU;
+    v4f px[NU];
+    auto tile_origin = [&](int t, int& a0, int& b0, int& na, int& nbb) {
+        int ta = t % it.nta, tb = t / it.nta;
+        a0 = ta * TA; b0 = tb * TB; na = min(TA, it.PA - a0); nbb = min(TB, it.PB - b0);
+    };
+    auto issue_loads = [&](int t) {
+        int a0, b0, na, nbb; tile_origin(t, a0, b0, na, nbb);
+        const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        const bool v0 = m.active && m.al < na && m.bl < nbb, v1 = v0 && m.al1 < na;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = m.kp + m.KP * j;
+            v4f vx; vx[0] = vx[1] = vx[2] = vx[3] = 0.f;
+            if (k < K && v0) {
+                const long long o = org + m.off + kstride * k;
+                if (m.vec == 2 && v1) vx = *reinterpret_cast<const v4f*>(Xg + o);
+                else { cf x = Xg[o]; vx[0] = x.re; vx[1] = x.im; }
+            }
+            px[j] = vx;
+        }
+    };
+    auto commit_loads = [&](int buf) {
+        if (!m.active) return;
+        float* Xr = Xbuf + buf * (2 * KKP * TRP); float* Xi = Xr + KKP * TRP;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = m.kp + m.KP * j;
+            if (k < K) {
+                int o0 = (m.c0 + D * k) * TRP + m.row0;
+                Xr[o0] = px[j][0]; Xi[o0] = px[j][1];
+                if (m.vec == 2) { int o1 = (m.c1 + D * k) * TRP + m.row1; Xr[o1] = px[j][2]; Xi[o1] = px[j][3]; }
+            }
+        }
+    };
+    auto fill_slow = [&](int t, int buf) {
+        float* Xr = Xbuf + buf * (2 * KKP * TRP); float* Xi = Xr + KKP * TRP;
+        int a0, b0, na, nbb; tile_origin(t, a0, b0, na, nbb);
+        const int ntile_el = D * TA * K * TB;
+        for (int e = tid; e < ntile_el; e += 256) {
+            int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
+            cf vx; vx.re = vx.im = 0.f;
+            if (al < na && bl < nbb) vx = Xg[s + D * ((long long)(a0 + al) + PA * ((long long)k + (long long)K * (b0 + bl)))];
+            int o = (s + D * k) * TRP + (al + TA * bl);
+            Xr[o] = vx.re; Xi[o] = vx.im;
+        }
+    };
+    lds_barrier();                                               // zero fill done
+    if (t_begin < t_end) { if (fast) { issue_loads(t_begin); commit_loads(0); if (t_begin + 1 < t_end) issue_loads(t_begin + 1); } else fill_slow(t_begin, 0); }
+    lds_barrier();
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        if (t + 1 < t_end) { if (fast) { commit_loads(cur ^ 1); if (t + 2 < t_end) issue_loads(t + 2); } else fill_slow(t + 1, cur ^ 1); }
+        const float* Xr = Xbuf + cur * (2 * KKP * TRP); const float* Xi = Xr + KKP * TRP;
+#pragma unroll
+        for (int q = 0; q < NBW; ++q) {
+            if (!bOn[q]) continue;                               // wave-uniform
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int ro = (16 * bI[q] + l15) * TRP + 16 * kq + 8 * half;
+                const int rb = (16 * bJ[q] + l15) * TRP + 16 * kq + 8 * half;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const v4f t0 = *reinterpret_cast<const v4f*>(Xr + ro + 4 * qq), t1 = *reinterpret_cast<const v4f*>(Xi + ro + 4 * qq);
+                    const v4f u0 = *reinterpret_cast<const v4f*>(Xr + rb + 4 * qq), u1 = *reinterpret_cast<const v4f*>(Xi + rb + 4 * qq);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double ar = (double)t0[c], ai = (double)t1[c], br = (double)u0[c], bi = (double)u1[c];
+                        Cr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, Cr[q], 0, 0, 0);      // out[i][j] += x[i] conj(x[j])
+                        Ci[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, Ci[q], 0, 0, 0);
+                        Cr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, Cr[q], 0, 0, 0);
+                        Ci[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, bi, Ci[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        lds_barrier();                                           // tile t consumed by everybody, tile t+1 committed by everybody
+    }
+    struct alignas(16) cd { double re, im; };
+    cd* __restrict__ part = reinterpret_cast<cd*>(it.partial) + (size_t)lc * KK * KK;
+#pragma unroll
+    for (int q = 0; q < NBW; ++q) {
+        if (!bOn[q]) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * bI[q] + kq + 4 * r, j = 16 * bJ[q] + l15;
+            if (i < KK && j < KK) {
+                cd v; v.re = Cr[q][r]; v.im = Ci[q][r]; part[i + (size_t)KK * j] = v;
+                if (bI[q] != bJ[q]) { cd c; c.re = v.re; c.im = -v.im; part[j + (size_t)KK * i] = c; }
+            }
+        }
+    }
+}
+bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
+    if (KKmax > 128) return false;
+    if (total_chunks <= 0) return true;
+    const size_t lds = (size_t)4 * 128 * 68 * sizeof(float);
+    set_max_dynamic_lds((const void*)mfma_gram128_f64_kernel, lds);
+    hipLaunchKernelGGL(mfma_gram128_f64_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+    return true;
 }
 
 }  // namespace tnqs
