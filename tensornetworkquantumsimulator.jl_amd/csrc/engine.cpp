@@ -519,7 +519,7 @@ template <class T> static void run_chains(State* s, std::vector<Chain>& chains, 
             it.in = c.result; it.out = dst->p; it.X = c.steps[o].second;
             it.D = 1; it.PA = (int)c.sd.pre(j); it.K = c.sd.chi[j]; it.PB = (int)c.sd.post(j); it.Do = 1; it.No = it.K;
             if (std::is_same<T, float>::value && use_mfma() && use_rowgemm() && rowgemm_covers(it)) {
-                it.TA = 32; it.TB = 1; it.nta = it.PA / 32; it.ntb = it.PB; it.want_norm = 0;
+                rowgemm_tiles(it); it.want_norm = 0;
                 rg_items.push_back(it); rg_tiles += (double)it.nta * it.ntb;
                 c.result = dst->p; nt[ci]++;
                 rg_bytes += 2.0 * c.sd.n * esz; rg_flops += 8.0 * c.sd.n * it.K;
@@ -667,7 +667,8 @@ template <class T, class Acc> static void run_grams(State* s, std::vector<GramJo
         int nch = std::min(per_item, ntiles);
         it.tiles_per_chunk = (ntiles + nch - 1) / nch;
         it.nchunks = (ntiles + it.tiles_per_chunk - 1) / it.tiles_per_chunk;
-        j.nchunks = mf ? 4 * it.nchunks : (mf64 ? 2 * it.nchunks : it.nchunks);     // f32 MFMA kernels: one partial per wave; f64 MFMA kernel: one per tile parity
+        // 32 x 32 f32 MFMA kernels: one partial per wave; f64 64 x 64 MFMA kernel: one per tile parity; the chi = 64 kernels: one per chunk
+        j.nchunks = (mf && (fused || KKmax <= 32)) ? 4 * it.nchunks : (mf64 ? 2 * it.nchunks : it.nchunks);
         j.partial = dalloc(s, (size_t)j.nchunks * j.KK * j.KK * 2 * sizeof(Acc));
         it.partial = j.partial->p; it.chunk_begin = chunks; chunks += it.nchunks;
         items.push_back(it);
@@ -1892,7 +1893,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                     const size_t nout = j.sd.n / it.K * chin;
                     Buf out = dalloc(s, nout * esz);
                     it.in = pch[q].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
-                    it.TA = 32; it.TB = 1; it.nta = it.PA / 32; it.ntb = it.PB; it.want_norm = ao.normalize_tensors ? 1 : 0;
+                    rowgemm_tiles(it); it.want_norm = ao.normalize_tensors ? 1 : 0;
                     rg.push_back(it); rverts.push_back(j.v); routs.push_back(out); rne.push_back(nout); rt += (double)it.nta * it.ntb;
                     rby += (double)(j.sd.n + nout) * esz; rfl += 8.0 * j.sd.n * j.sd.d * chin; via64[q] = 1;
                 }

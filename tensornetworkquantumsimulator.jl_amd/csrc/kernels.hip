@@ -268,8 +268,17 @@ __global__ __launch_bounds__(256) void msg_finalize_kernel(const MsgFinalItem* _
     // pass 1: reduce chunks (fixed order) into new_msg, accumulate the element sum
     double sre = 0, sim = 0;
     for (int e = threadIdx.x; e < n2; e += 256) {
-        T re = 0, im = 0;
-        for (int c = 0; c < it.nchunks; ++c) { cx<T> v = p[(size_t)c * n2 + e]; re += v.re; im += v.im; }
+        // eight independent partial sums (fixed order): the loads of a thread do not depend on each other, so eight are in flight at a
+        // time instead of one -- a message with thousands of partials took a millisecond here
+        T pr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int c = 0;
+        for (; c + 8 <= it.nchunks; c += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { cx<T> v = p[(size_t)(c + u) * n2 + e]; pr[u] += v.re; pi[u] += v.im; }
+        }
+        for (; c < it.nchunks; ++c) { cx<T> v = p[(size_t)c * n2 + e]; pr[c & 7] += v.re; pi[c & 7] += v.im; }
+        const T re = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
+        const T im = ((pi[0] + pi[1]) + (pi[2] + pi[3])) + ((pi[4] + pi[5]) + (pi[6] + pi[7]));
         out[e] = cmake<T>(re, im);
         sre += re; sim += im;
     }
@@ -858,11 +867,21 @@ __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __rest
     for (int c = tid; c < n; c += 256) {
         W[c + (size_t)n * c] = cmake<double>(1.0 / A[at(c, c)].re, 0.0);
         for (int i = c + 1; i < n; ++i) {
-            cx<double> acc = cmake<double>(0, 0);
-            for (int j = c; j < i; ++j) {
-                const cx<double> lj = A[at(i, j)]; cx<double> x = W[c + (size_t)n * j]; x.im = -x.im;      // stored conjugated
-                acc.re -= lj.re * x.re - lj.im * x.im; acc.im -= lj.re * x.im + lj.im * x.re;
+            // four independent partial sums: the loads of W do not depend on the running sum, so four are in flight at a time
+            double ar[4] = {0, 0, 0, 0}, ai[4] = {0, 0, 0, 0};
+            int j = c;
+            for (; j + 4 <= i; j += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const cx<double> lj = A[at(i, j + u)]; cx<double> x = W[c + (size_t)n * (j + u)]; x.im = -x.im;      // stored conjugated
+                    ar[u] -= lj.re * x.re - lj.im * x.im; ai[u] -= lj.re * x.im + lj.im * x.re;
+                }
             }
+            for (; j < i; ++j) {
+                const cx<double> lj = A[at(i, j)]; cx<double> x = W[c + (size_t)n * j]; x.im = -x.im;
+                ar[0] -= lj.re * x.re - lj.im * x.im; ai[0] -= lj.re * x.im + lj.im * x.re;
+            }
+            cx<double> acc = cmake<double>((ar[0] + ar[1]) + (ar[2] + ar[3]), (ai[0] + ai[1]) + (ai[2] + ai[3]));
             const double inv = 1.0 / A[at(i, i)].re;
             W[c + (size_t)n * i] = cmake<double>(acc.re * inv, -acc.im * inv);
         }

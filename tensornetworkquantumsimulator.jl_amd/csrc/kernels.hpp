@@ -156,8 +156,9 @@ struct CholItem { const void* G; void* L; void* Winv; int n; int* fail; double t
 struct TallSvdItem { const void* A; void* G; const void* L; void* R0; void* Rrot; int m, n; };
 struct SmallGemmItem { const void* A; const void* B; void* C; int m, n, k; };           // C (m x n) = A (m x k) B (k x n), ComplexF32
 struct CopyItem { const void* src; void* dst; size_t n16; };                             // n16 16-byte words
-// register-direct MFMA fiber GEMM for chi = 64 sites (kernels_chi64.hip): items use TA = 32, TB = 1, nta = PA / 32, ntb = PB
+// register-direct MFMA fiber GEMM for chi = 64 sites (kernels_chi64.hip): rowgemm_tiles() sets the tile grid of an item
 bool rowgemm_covers(const FiberItem& it);
+void rowgemm_tiles(FiberItem& it);
 void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, double* d_norm_partials);
 void launch_tall_gram(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);
 void launch_tall_rt(hipStream_t s, const TallSvdItem* d_items, int nitems);
@@ -285,7 +286,7 @@ int mfma_fiber_tile_rows(int KK, int NN);     // fibers per tile for the shape, 
 bool launch_mfma_fiber_gemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_tiles, int KKmax, int NNmax,
                             double* d_norm_partials);
 bool launch_mfma_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);  // tiles of 64 fibers; writes 4 partials per chunk
-bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);  // same for 32 < KK <= 64 (kernels_chi64.hip)
+bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);  // 32 < KK <= 64 (kernels_chi64.hip): ONE partial per chunk
 // fused (X x_r M) then Gram with Y: tiles of 64 fibers = (s:2) x (first row leg: 32); writes 4 partials per chunk
 void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
 // Gram with f64 accumulation on the f64 matrix cores (gate path: G = psi~^dagger psi~, D*K == 64, X == Y); tiles of 64 fibers

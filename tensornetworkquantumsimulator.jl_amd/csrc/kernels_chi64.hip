@@ -19,11 +19,11 @@
 namespace tnqs {
 
 // ------------------------------------------------------------------------------------------------------------
-// Gram (f32 accumulate), KK = D*K <= 64:  partial[4*c + w][i + KK*j] = sum_{rows of chunk c handled by wave w} X[i,row] conj(Y[j,row])
+// Gram (f32 accumulate), KK = D*K <= 64:  partial[c][i + KK*j] = sum_{rows of chunk c} X[i,row] conj(Y[j,row])
 // Tiles of 64 fibers, LDS layout [kk][row] (rows contiguous = memory order); wave w takes 16 rows of every tile and the whole 64 x 64
 // output (four 32 x 32 accumulator pairs); the next tile's loads are in flight during the MFMA block.  32 flop/B when X != Y.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mfma_gram64_kernel(const GramItem* __restrict__ items, int nitems) {
+__global__ __launch_bounds__(256, 2) void mfma_gram64_kernel(const GramItem* __restrict__ items, int nitems) {
     constexpr int TR = 64, TRP = TR + 4, NU = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const Xr = reinterpret_cast<float*>(smem);
@@ -45,13 +45,14 @@ __global__ __launch_bounds__(256) void mfma_gram64_kernel(const GramItem* __rest
     const int t_begin = lc * it.tiles_per_chunk;
     const int t_end = min(ntiles, t_begin + it.tiles_per_chunk);
     const int lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
-    v16f Cr[2][2], Ci[2][2];
+    // wave w: output rows block a = w & 1 (i in [32 a, 32 a + 32)) x all 64 columns, tile rows 32 (w >> 1) .. + 32 -- 64 accumulator
+    // registers per wave instead of 128, so that TWO workgroups fit a CU (one's barriers and LDS commits hide behind the other's MFMAs)
+    const int a = w & 1, rh = w >> 1;
+    v16f Cr[2], Ci[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { Cr[a][b][r] = 0.f; Ci[a][b][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { Cr[b][r] = 0.f; Ci[b][r] = 0.f; }
     for (int e = tid; e < 64 * TRP; e += 256) { Xr[e] = 0.f; Xi[e] = 0.f; Yr[e] = 0.f; Yi[e] = 0.f; }
     const TileMap m = make_map(tid, D, TA, TB, PA, K);
     const long long kstride = (long long)D * PA;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void mfma_gram64_kernel(const GramItem* __rest
             px[j] = vx; py[j] = vy;
         }
     };
-    auto commit_loads = [&]() {
+    auto commit_loads = [&]() {                  // invalid cells were loaded as zeros, so edge tiles need no extra clearing
         if (!m.active) return;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void mfma_gram64_kernel(const GramItem* __rest
     if (fast && t_begin < t_end) issue_loads(t_begin);
     for (int t = t_begin; t < t_end; ++t) {
         lds_barrier();
-        if (fast) commit_loads();       // invalid cells were loaded as zeros, so edge tiles need no extra clearing
+        if (fast) commit_loads();
         else {
             int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
             const int ntile_el = D * TA * K * TB;
@@ -109,51 +110,61 @@ __global__ __launch_bounds__(256) void mfma_gram64_kernel(const GramItem* __rest
         }
         lds_barrier();
         if (fast && t + 1 < t_end) issue_loads(t + 1);
-        // wave w: rows 16w .. 16w+15; lane half h takes rows 16w + 8h + q
-        float yr[2][8], yi[2][8];
+        // rows 32 rh .. 32 rh + 31 in two halves of 16 (lane half h takes 8 of them): bounds the operand registers
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int ro = (32 * b + ln) * TRP + 16 * w + 8 * h;
+        for (int hf = 0; hf < 2; ++hf) {
+            const int r0 = 32 * rh + 16 * hf + 8 * h;
+            float xr[8], xi[8], yr[2][8], yi[2][8];
+            {
+                const int ro = (32 * a + ln) * TRP + r0;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                v4f t2 = *reinterpret_cast<const v4f*>(Yr + ro + 4 * q), t3 = *reinterpret_cast<const v4f*>(Yi + ro + 4 * q);
+                for (int q = 0; q < 2; ++q) {
+                    v4f t0 = *reinterpret_cast<const v4f*>(Xr + ro + 4 * q), t1 = *reinterpret_cast<const v4f*>(Xi + ro + 4 * q);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { yr[b][4 * q + c] = t2[c]; yi[b][4 * q + c] = t3[c]; }
+                    for (int c = 0; c < 4; ++c) { xr[4 * q + c] = t0[c]; xi[4 * q + c] = t1[c]; }
+                }
             }
-        }
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            float xr[8], xi[8];
-            const int ro = (32 * a + ln) * TRP + 16 * w + 8 * h;
+            for (int b = 0; b < 2; ++b) {
+                const int ro = (32 * b + ln) * TRP + r0;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                v4f t0 = *reinterpret_cast<const v4f*>(Xr + ro + 4 * q), t1 = *reinterpret_cast<const v4f*>(Xi + ro + 4 * q);
+                for (int q = 0; q < 2; ++q) {
+                    v4f t2 = *reinterpret_cast<const v4f*>(Yr + ro + 4 * q), t3 = *reinterpret_cast<const v4f*>(Yi + ro + 4 * q);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { xr[4 * q + c] = t0[c]; xi[4 * q + c] = t1[c]; }
+                    for (int c = 0; c < 4; ++c) { yr[b][4 * q + c] = t2[c]; yi[b][4 * q + c] = t3[c]; }
+                }
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     // out[i][j] += x[i] * conj(y[j])
-                    Cr[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[q], yr[b][q], Cr[a][b], 0, 0, 0);
-                    Ci[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[q], yr[b][q], Ci[a][b], 0, 0, 0);
-                    Cr[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[q], yi[b][q], Cr[a][b], 0, 0, 0);
-                    Ci[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(-xr[q], yi[b][q], Ci[a][b], 0, 0, 0);
+                    Cr[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[q], yr[b][q], Cr[b], 0, 0, 0);
+                    Ci[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[q], yr[b][q], Ci[b], 0, 0, 0);
+                    Cr[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[q], yi[b][q], Cr[b], 0, 0, 0);
+                    Ci[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(-xr[q], yi[b][q], Ci[b], 0, 0, 0);
                 }
             }
         }
     }
-    cf* __restrict__ part = reinterpret_cast<cf*>(it.partial) + (size_t)(4 * lc + w) * KK * KK;
+    // one partial per chunk: the two row halves (waves w, w + 2) are summed through the free tile buffers
+    lds_barrier();
+    v2f* const R = reinterpret_cast<v2f*>(smem);                // [rh][j][i], pitch 65: 2 * 64 * 65 * 8 B = 66.5 KB
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int i = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, j = 32 * b + ln;
-                if (i < KK && j < KK) { cf v; v.re = Cr[a][b][r]; v.im = Ci[a][b][r]; part[i + (size_t)KK * j] = v; }
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, j = 32 * b + ln;
+            v2f v = {Cr[b][r], Ci[b][r]};
+            R[(rh * 64 + j) * 65 + i] = v;
+        }
+    lds_barrier();
+    cf* __restrict__ part = reinterpret_cast<cf*>(it.partial) + (size_t)lc * KK * KK;
+    for (int e = tid; e < KK * KK; e += 256) {
+        const int i = e % KK, j = e / KK;
+        const v2f u = R[j * 65 + i], v = R[(64 + j) * 65 + i];
+        cf o; o.re = u[0] + v[0]; o.im = u[1] + v[1]; part[e] = o;
+    }
 }
 bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
     if (KKmax > 64) return false;
@@ -338,7 +349,7 @@ void launch_copy_items(hipStream_t s, const CopyItem* d_items, int nitems) {
 
 // ------------------------------------------------------------------------------------------------------------
 // register-direct fiber GEMM:  out[(s',n),(a,b)] = sum_{(s,k)} in[(s,k),(a,b)] X[(s,k),(s',n)]  with D*K = 32 KB exactly, Do*No <= 32 NB,
-// PA a multiple of 32 (every leg but the first of a chi = 64 site; K = 64 mode products and the K = N = 128 gate epilogue).
+// any leg of a chi = 64 site (K = 64 mode products and the K = N = 128 gate epilogue).
 // The product is computed TRANSPOSED, C'[nn][row] = sum_kk X^T[nn][kk] in[row][kk], with row = 32 CONSECUTIVE a-indices on the lanes:
 //   * B' operand = the tensor itself: lane (ln = row, h) loads in[row][kk(q, h)] for every k-step q straight from global memory into
 //     the registers the MFMAs read -- 256-byte (D = 1) / 512-byte (D = 2, both site components as one 16-byte load) runs per half wave,
@@ -378,16 +389,24 @@ __global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __re
     }
     __syncthreads();                                           // the only workgroup barrier
     float pre[2][2 * NQ];                                      // two tiles in flight: current operands and the prefetch
+    // rows of a tile: 32 consecutive a-indices (PA >= 32), or -- first leg of the tensor, PA < 32 -- all PA a-indices of 32 / PA consecutive
+    // b-indices (the lanes then sit 1 KiB apart and each streams its own contiguous fiber over the k-steps: 16-byte pieces instead of
+    // 256-byte runs per instruction, which the matrix work per byte of these shapes hides)
+    const bool rows_b = PA < 32;
+    const int RB = rows_b ? 32 / (int)PA : 1;
+    const long long kst = (long long)D * PA;                                                   // stride of the contracted index (elements)
+    const long long lane_in = rows_b ? (long long)D * (ln % (int)PA) + kst * K * (ln / (int)PA) : (long long)D * ln;
+    const long long lane_out = rows_b ? (long long)D * (ln % (int)PA) + kst * No * (ln / (int)PA) : (long long)D * ln;
+    auto base_in = [&](int t) { return rows_b ? kst * K * RB * t : (long long)D * 32 * (t % it.nta) + kst * K * (t / it.nta); };
+    auto base_out = [&](int t) { return rows_b ? kst * No * RB * t : (long long)D * 32 * (t % it.nta) + kst * No * (t / it.nta); };
     auto issue = [&](int t, int buf) {
-        const int ta = t % it.nta, tb = t / it.nta;
+        const cf* p = in + base_in(t) + lane_in + kst * h;
         if (D == 1) {
-            const cf* p = in + (32 * ta + ln) + PA * ((long long)K * tb + h);
 #pragma unroll
-            for (int j = 0; j < NL; ++j) { const cf v = p[PA * 2 * j]; pre[buf][2 * j] = v.re; pre[buf][2 * j + 1] = v.im; }
+            for (int j = 0; j < NL; ++j) { const cf v = p[kst * 2 * j]; pre[buf][2 * j] = v.re; pre[buf][2 * j + 1] = v.im; }
         } else {
-            const cf* p = in + 2 * ((32 * ta + ln) + PA * ((long long)K * tb + h));
 #pragma unroll
-            for (int j = 0; j < NL; ++j) { const v4f v = *reinterpret_cast<const v4f*>(p + 2 * PA * 2 * j);
+            for (int j = 0; j < NL; ++j) { const v4f v = *reinterpret_cast<const v4f*>(p + kst * 2 * j);
                                            pre[buf][4 * j] = v[0]; pre[buf][4 * j + 1] = v[1]; pre[buf][4 * j + 2] = v[2]; pre[buf][4 * j + 3] = v[3]; }
         }
     };
@@ -418,10 +437,9 @@ __global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __re
                     Ci[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], br, Ci[nb], 0, 0, 0);
                 }
             }
-            const int ta = t % it.nta, tb = t / it.nta;
             float nf = 0.f;
             if (D == 1) {
-                cf* p = out + (32 * ta + ln) + PA * ((long long)No * tb);
+                cf* p = out + base_out(t) + lane_out;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -430,7 +448,7 @@ __global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __re
                         if (n < No) { cf v; v.re = Cr[nb][r]; v.im = Ci[nb][r]; p[PA * n] = v; nf += v.re * v.re + v.im * v.im; }
                     }
             } else {
-                cf* p = out + 2 * ((32 * ta + ln) + PA * ((long long)No * tb));
+                cf* p = out + base_out(t) + lane_out;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -456,10 +474,15 @@ __global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __re
 }
 // shapes: (KK, NN) in {(64, 64): D = 1 mode products at chi = 64;  (128, <= 128): D = 2 gate epilogue at chi = 64}
 bool rowgemm_covers(const FiberItem& it) {
-    if (it.PA < 32 || it.PA % 32 != 0) return false;
+    if (it.PA >= 32) { if (it.PA % 32 != 0) return false; }
+    else if (it.PA < 1 || 32 % it.PA != 0 || it.PB % (32 / it.PA) != 0) return false;
     if (it.D == 1 && it.Do == 1 && it.K == 64 && it.No <= 64 && it.No >= 1) return true;
     if (it.D == 2 && it.Do == 2 && it.K == 64 && it.No <= 64 && it.No >= 1) return true;
     return false;
+}
+void rowgemm_tiles(FiberItem& it) {       // tile grid of an item rowgemm_covers() accepted
+    it.TA = 32; it.TB = 1;
+    if (it.PA >= 32) { it.nta = it.PA / 32; it.ntb = it.PB; } else { it.nta = 1; it.ntb = it.PB / (32 / it.PA); }
 }
 void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, double* d_norm_partials) {
     if (total_wgs <= 0) return;
