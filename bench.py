@@ -7,7 +7,9 @@ BASELINE.json (20x20 TFIM, chi=32, ComplexF32, batched edge-colour apply on one 
 (iid complex-normal site tensors at bond dimension chi) and resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel class (HIP-event timed inside the
-library on its own stream) and "cpu_baseline" (the numpy oracle timed on the host cores on a bounded sample).
+library on its own stream) and "cpu_baseline" (oracle/cpu_layer.py: the threaded CPU restatement of the same path, timed on the host
+cores on a bounded sample, next to the host's measured BLAS rates).  With --gpus N the lattice is sharded by vertex over N ranks and
+every exchange is an ncclAllGather the library enqueues on its own stream (RCCL inside the library, tnqs_set_sharding_rccl).
 """
 import argparse
 import json
@@ -46,37 +48,14 @@ def random_state_tensors(g, chi, d, seed, dtype, wanted=None):
         yield v, t.astype(dtype, copy=False)
 
 
-def cpu_baseline(chi, seed=1234, max_seconds=60.0):
-    """the CPU oracle (numpy restatement of the reference path, BLAS threads = host cores) on a bounded sample:
-    one TFIM layer on a 4x4 PERIODIC torus at the same chi / dtype (every site has the bulk degree 4 of the 20x20
-    lattice, so the per-gate work equals the bulk per-gate work of the benchmark workload)."""
-    import tnqs_oracle as o
-    L = 4
-    g = o.named_grid((L, L), periodic=True)
-    groups = o.edge_color(g)
-    layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
-    for grp in groups:
-        layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
-    rng = np.random.default_rng(seed)
-    tensors = {}
-    for v in g.vertices:
-        shp = (2,) + (chi,) * g.degree(v)
-        n = int(np.prod(shp))
-        tensors[v] = (rng.standard_normal(2 * n, dtype=np.float32).view(np.complex64).reshape(shp) / np.float32(np.sqrt(n)))
-    bpc = o.BeliefPropagationCache(o.TensorNetworkState(g, tensors))
-    kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
-    # warm-up outside the timing: one BP update so that the timed layer starts from converged messages
-    bpc = o.update(bpc)
-    t0 = time.perf_counter()
-    info = {}
-    bpc, errs = o.apply_gates(layer, bpc, apply_kwargs=kw, info=info)
-    dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    n2 = len(g.edges)
+def cpu_baseline(chi, seed=1234):
+    """CPU restatement of the reference path, organised for a many-core host (oracle/cpu_layer.py: the oracle's arithmetic -- GEMM-shaped
+    mode products, LAPACK QR / SVD, f64 eigen -- with the messages of a BP dependency level and the gates of a colour group running
+    concurrently, one BLAS thread each) on a bounded sample of the benchmark workload: ONE TFIM layer on an 8x8 PERIODIC torus at the same
+    chi / dtype (64 sites, all of the bulk degree 4 of the 20x20 lattice, 128 two-site gates, reference-default BP kwargs).  Reported
+    with the host BLAS rates measured in the same process, so that the number can be judged (it is NOT the Julia package)."""
+    import cpu_layer
+    m = cpu_layer.measure(chi=chi, L=8, seed=seed)
     host = "unknown CPU"
     try:
         with open("/proc/cpuinfo") as f:
@@ -85,9 +64,14 @@ def cpu_baseline(chi, seed=1234, max_seconds=60.0):
             host = f"{models[0]} ({len(models)} hardware threads)"
     except OSError:
         pass
-    return {"value": n2 / dt, "unit": "two-site gates/s", "cores": int(cores), "kind": "port", "host": host,
-            "sample": f"1 TFIM layer ({n2} two-site gates, {info.get('n_updates')} BP updates, sweeps {info.get('sweeps')}) on a "
-                      f"4x4 periodic torus (all sites degree 4), chi={chi}, complex64, numpy oracle; {dt:.1f} s"}
+    return {"value": m["gates_per_s"], "unit": "two-site gates/s", "cores": int(m["threads"]), "kind": "restatement", "host": host,
+            "algorithmic_gflops": m["algorithmic_gflops"], "host_square_cgemm_gflops": m["square_cgemm_gflops"],
+            "host_mode_product_shape_gflops": m["mode_product_shape_gflops"],
+            "frac_of_host_square_cgemm": m["frac_of_square_cgemm"], "frac_of_host_mode_product_shape": m["frac_of_mode_product_shape"],
+            "bp_sweeps": m["bp_sweeps"],
+            "sample": f"1 TFIM layer ({m['n_two_site']} two-site gates, {len(m['bp_sweeps'])} BP updates, sweeps {m['bp_sweeps']}) on an 8x8 "
+                      f"periodic torus ({m['sites']} sites, all degree 4), chi={chi}, complex64, threaded numpy/LAPACK restatement "
+                      f"(oracle/cpu_layer.py), {m['threads']} threads; {m['seconds_per_layer']:.1f} s"}
 
 
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix (= vector) peak
@@ -214,7 +198,10 @@ def main():
                                   f"apply_gates incl. BP updates; BASELINE.json configs[1]",
                       "two_site_gates_per_step": n2, "bp_updates_per_step": updates, "bp_sweeps_per_step": sweeps,
                       "apply_kwargs": {"maxdim": chi, "cutoff": 1e-10, "normalize_tensors": True},
-                      "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)", "parallelism": f"vertex-shard x{world}"},
+                      "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)", "parallelism": f"vertex-shard x{world}",
+                      "transport": (None if world == 1 else {"kind": type(bpc._shard).__name__,
+                                                             "allgathers_per_step": round(bpc._shard.n_exchanges / max(1, args.steps + args.warmup), 1),
+                                                             "MB_gathered_per_step": round(bpc._shard.bytes_exchanged / max(1, args.steps + args.warmup) / 1e6, 2)})},
            "roofline": roofline, "phases": phases, "kernel_classes": classes}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -174,6 +174,22 @@ typedef int (*tnqs_allgather_fn)(void* ctx, void* exch_base, int64_t bytes_per_r
 int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* vertex_owner, tnqs_allgather_fn fn, void* ctx,
                       void* exch_dev, int64_t exch_bytes);
 
+/* The same sharding with the transport INSIDE the library: RCCL (librccl.so, loaded at run time) over xGMI.  One rank calls
+ * tnqs_rccl_unique_id and hands the 128 opaque bytes (an ncclUniqueId) to every rank by whatever means the host has (MPI, a file,
+ * torch.distributed's store); every rank then calls tnqs_set_sharding_rccl right after tnqs_create -- it joins the communicator
+ * (collective: blocks until all nranks ranks have called) and allocates the exchange buffer (exch_bytes, on the handle's device).
+ * From then on every exchange point is ONE in-place ncclAllGather enqueued on the handle's stream: no stream synchronisation, no
+ * host callback.  Copies of the handle share the communicator; it is destroyed with the last of them.  nranks == 1 is allowed
+ * (nothing is exchanged). */
+int tnqs_rccl_unique_id(void* out_128_bytes);
+int tnqs_set_sharding_rccl(tnqs_handle h, int rank, int nranks, const int32_t* vertex_owner, const void* unique_id_128_bytes,
+                           int64_t exch_bytes);
+/* all-gathers issued through RCCL by this handle and its copies, and the bytes they gathered (0 in callback mode) */
+int tnqs_sharding_stats(tnqs_handle h, int64_t* n_exchanges, int64_t* bytes_exchanged);
+/* one-rank round trip through RCCL on `device` (unique id, communicator, in-place all-gather of `bytes` bytes, teardown): lets a
+ * single-GPU box check that the transport loads and runs -- RCCL refuses two ranks on one GPU */
+int tnqs_rccl_selftest(int device, int64_t bytes);
+
 /* ---- profiling: HIP-event timing of the kernel classes on the handle's stream ---------------------------- */
 enum { TNQS_PROF_BP_MODEPROD = 0, TNQS_PROF_BP_GRAM = 1, TNQS_PROF_GATE_MODEPROD = 2, TNQS_PROF_GATE_GRAM = 3,
        TNQS_PROF_GATE_APPLY = 4, TNQS_PROF_JACOBI = 5, TNQS_PROF_SMALL = 6, TNQS_PROF_BP_FUSED = 7, TNQS_PROF_BP_PAIR = 8, TNQS_PROF_BP_PAIRGRAM = 9, TNQS_PROF_NCLASSES = 10 };

@@ -96,6 +96,10 @@ _SIGS = {
     "tnqs_rescale": ([H], C.c_int),
     "tnqs_symmetric_gauge": ([H, C.c_double], C.c_int),
     "tnqs_set_sharding": ([H, C.c_int, C.c_int, _I32P, ALLGATHER_FN, C.c_void_p, C.c_void_p, C.c_int64], C.c_int),
+    "tnqs_rccl_unique_id": ([C.c_void_p], C.c_int),
+    "tnqs_set_sharding_rccl": ([H, C.c_int, C.c_int, _I32P, C.c_void_p, C.c_int64], C.c_int),
+    "tnqs_sharding_stats": ([H, _I64P, _I64P], C.c_int),
+    "tnqs_rccl_selftest": ([C.c_int, C.c_int64], C.c_int),
     "tnqs_profile_enable": ([H, C.c_int], C.c_int),
     "tnqs_profile_get": ([H, C.c_int, _I64P, _DP, _DP, _DP], C.c_int),
     "tnqs_profile_reset": ([H], C.c_int),

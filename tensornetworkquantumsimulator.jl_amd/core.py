@@ -181,6 +181,8 @@ class BeliefPropagationCache:
         L.check(L.lib.tnqs_copy(self._h, C.byref(h)))
         out = BeliefPropagationCache(self.graph, (self.dtype, self.device), _handle=h)
         out._shard = self._shard          # copies share the sharding state (and keep its callback alive)
+        if hasattr(self._shard, "attach"):
+            self._shard.attach(out)
         return out
 
     def owns(self, v) -> bool:

@@ -135,6 +135,15 @@ int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* owner,
     });
 }
 
+int tnqs_rccl_unique_id(void* out128) { return guard([&] { if (!out128) throw Err(TNQS_ERR_INVALID, "rccl_unique_id: null output"); rccl_unique_id(out128); }); }
+int tnqs_set_sharding_rccl(tnqs_handle h, int rank, int nranks, const int32_t* owner, const void* unique_id128, int64_t exch_bytes) {
+    return guard([&] { set_sharding_rccl(S(h), rank, nranks, owner, unique_id128, exch_bytes); });
+}
+int tnqs_sharding_stats(tnqs_handle h, int64_t* n_exchanges, int64_t* bytes_exchanged) {
+    return guard([&] { State* s = S(h); if (n_exchanges) *n_exchanges = s->comm ? s->comm->n_exchanges : 0; if (bytes_exchanged) *bytes_exchanged = s->comm ? s->comm->bytes_exchanged : 0; });
+}
+int tnqs_rccl_selftest(int device, int64_t bytes) { return guard([&] { rccl_selftest(device, bytes); }); }
+
 int tnqs_profile_enable(tnqs_handle h, int on) { return guard([&] { S(h)->prof->on = on != 0; }); }
 int tnqs_profile_get(tnqs_handle h, int cls, int64_t* launches, double* ms, double* bytes, double* flops) {
     return guard([&] {

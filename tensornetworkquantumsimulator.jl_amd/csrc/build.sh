@@ -6,7 +6,7 @@ OUT=../libtnqs_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in kernels.hip kernels_mfma.hip kernels_plane.hip kernels_chi64.hip engine.cpp api.cpp debug.cpp; do
+for f in kernels.hip kernels_mfma.hip kernels_plane.hip kernels_chi64.hip engine.cpp sharding.cpp api.cpp debug.cpp; do
   [ -f "$f" ] || continue
   o=build/${f%.*}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ kernels.hpp -nt "$o" ] || [ engine.hpp -nt "$o" ] || [ launch_util.hpp -nt "$o" ] || [ mfma_common.hpp -nt "$o" ] || [ ../../include/tnqs.h -nt "$o" ]; then
@@ -15,5 +15,5 @@ for f in kernels.hip kernels_mfma.hip kernels_plane.hip kernels_chi64.hip engine
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -ldl -o $OUT
 echo "built $OUT"

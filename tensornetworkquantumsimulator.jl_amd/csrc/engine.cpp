@@ -281,7 +281,7 @@ State* state_copy(const State* o) {
     s->g = o->g; s->dtype = o->dtype; s->device = o->device; s->d = o->d; s->chi = o->chi;
     s->site = o->site; s->sscale = o->sscale; s->msg = o->msg; s->pool = o->pool; s->prof = o->prof;
     s->rank = o->rank; s->nranks = o->nranks; s->owner = o->owner; s->ag_fn = o->ag_fn; s->ag_ctx = o->ag_ctx;
-    s->exch = o->exch; s->exch_bytes = o->exch_bytes;
+    s->exch = o->exch; s->exch_bytes = o->exch_bytes; s->comm = o->comm;
     HIPCHK(hipSetDevice(o->device));
     if (o->own_stream) { HIPCHK(hipStreamSynchronize(o->stream)); s->stream = acquire_stream(o->device); s->own_stream = true; }
     else { s->stream = o->stream; s->own_stream = false; }
@@ -1339,8 +1339,9 @@ void check_exchange(const State* s, size_t bytes_per_rank) {
 }
 void exchange(State* s, size_t bytes_per_rank) {
     if (s->nranks <= 1) return;
-    if (!s->ag_fn) throw Err(TNQS_ERR_COMM, "sharded handle without an all-gather callback");
     check_exchange(s, bytes_per_rank);
+    if (s->comm) { rccl_allgather(s, bytes_per_rank); return; }       // RCCL: enqueued on the handle's stream, nothing to wait for here
+    if (!s->ag_fn) throw Err(TNQS_ERR_COMM, "sharded handle without a transport (tnqs_set_sharding_rccl or tnqs_set_sharding)");
     HIPCHK(hipStreamSynchronize(s->stream));
     int rc = s->ag_fn(s->ag_ctx, s->exch, (int64_t)bytes_per_rank, s->nranks);
     if (rc != 0) throw Err(TNQS_ERR_COMM, "all-gather callback failed");
@@ -2185,63 +2186,80 @@ template <class T> static void region_contract(State* s, int nr, const int32_t* 
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return depth[a] > depth[b]; });
     std::vector<Buf> up(nr);                       // message from region vertex i to its parent
+    const bool sharded = s->nranks > 1;
+    // sharded handles: the owner of a region vertex contracts it; its message to the parent (chi x chi) -- or, at the root, the d x d
+    // result -- reaches every rank through one exchange per region vertex (all ranks walk the region in the same order)
     for (int oi = 0; oi < nr; ++oi) {
         const int i = order[oi], u = rv[i], par = parent[i] >= 0 ? rv[parent[i]] : -1;
-        SD sd = site_dims(s, u);
-        const void* ket = s->site[u]->p; Buf opbuf;
-        if (ops) {                                  // ket := O_u psi_u   (out[s'] = sum_s O[s', s] psi[s])
-            const double* m = ops + 2 * (size_t)0; size_t off = 0; for (int q = 0; q < i; ++q) off += 2 * (size_t)s->d[rv[q]] * s->d[rv[q]];
-            m = ops + off;
-            const int d = sd.d; bool ident = true;
-            for (int a = 0; a < d && ident; ++a) for (int b = 0; b < d; ++b) if (m[2 * (a + d * b)] != (a == b ? 1.0 : 0.0) || m[2 * (a + d * b) + 1] != 0.0) { ident = false; break; }
-            if (!ident) {
-                std::vector<T> hx;
-                for (int nn = 0; nn < d; ++nn) for (int kk = 0; kk < d; ++kk) { hx.push_back((T)m[2 * (nn + d * kk)]); hx.push_back((T)m[2 * (nn + d * kk) + 1]); }
-                std::vector<char> raw(reinterpret_cast<char*>(hx.data()), reinterpret_cast<char*>(hx.data()) + hx.size() * sizeof(T));
-                const char* dx = upload(s, raw);
-                opbuf = dalloc(s, sd.n * esz);
-                FiberItem it{}; it.in = ket; it.out = opbuf->p; it.X = dx;
-                it.D = d; it.PA = (int)(sd.n / d); it.K = 1; it.PB = 1; it.Do = d; it.No = 1;
-                const int TR = pick_TR(d, esz, 1);
-                tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
-                it.tpw = 1; it.tile_begin = 0; it.want_norm = 0;
-                std::vector<FiberItem> items{it};
-                const FiberItem* dI = upload(s, items);
-                launch_fiber_gemm<T>(s->stream, dI, 1, it.nta * it.ntb, TR, d, nullptr);
-                ket = opbuf->p;
+        const bool mine = s->owns(u);
+        const int dU = s->d[u];
+        const int n2 = par >= 0 ? s->chi[g.edge(u, par)] * s->chi[g.edge(u, par)] : dU * dU;
+        const size_t out_esz = par >= 0 ? esz : 16;
+        const size_t stride = round256((size_t)n2 * out_esz);
+        if (sharded) check_exchange(s, stride);
+        Buf result = dalloc(s, (size_t)n2 * out_esz);
+        void* reduce_dst = sharded ? (void*)(reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride) : result->p;
+        if (mine) {
+            SD sd = site_dims(s, u);
+            const void* ket = s->site[u]->p; Buf opbuf;
+            if (ops) {                                  // ket := O_u psi_u   (out[s'] = sum_s O[s', s] psi[s])
+                size_t off = 0; for (int q = 0; q < i; ++q) off += 2 * (size_t)s->d[rv[q]] * s->d[rv[q]];
+                const double* m = ops + off;
+                const int d = sd.d; bool ident = true;
+                for (int aa = 0; aa < d && ident; ++aa) for (int bb = 0; bb < d; ++bb) if (m[2 * (aa + d * bb)] != (aa == bb ? 1.0 : 0.0) || m[2 * (aa + d * bb) + 1] != 0.0) { ident = false; break; }
+                if (!ident) {
+                    std::vector<T> hx;
+                    for (int nn = 0; nn < d; ++nn) for (int kk = 0; kk < d; ++kk) { hx.push_back((T)m[2 * (nn + d * kk)]); hx.push_back((T)m[2 * (nn + d * kk) + 1]); }
+                    std::vector<char> raw(reinterpret_cast<char*>(hx.data()), reinterpret_cast<char*>(hx.data()) + hx.size() * sizeof(T));
+                    const char* dx = upload(s, raw);
+                    opbuf = dalloc(s, sd.n * esz);
+                    FiberItem it{}; it.in = ket; it.out = opbuf->p; it.X = dx;
+                    it.D = d; it.PA = (int)(sd.n / d); it.K = 1; it.PB = 1; it.Do = d; it.No = 1;
+                    const int TR = pick_TR(d, esz, 1);
+                    tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
+                    it.tpw = 1; it.tile_begin = 0; it.want_norm = 0;
+                    std::vector<FiberItem> items{it};
+                    const FiberItem* dI = upload(s, items);
+                    launch_fiber_gemm<T>(s->stream, dI, 1, it.nta * it.ntb, TR, d, nullptr);
+                    ket = opbuf->p;
+                }
             }
-        }
-        std::vector<Chain> chains(1); Chain& c = chains[0]; c.v = u; c.src = ket; c.sd = sd;
-        for (int j = 0; j < sd.z; ++j) {
-            int k = g.nbr[u][j]; if (k == par) continue;
-            const void* mp = nullptr;
-            if (pos[k] >= 0) {
-                if (parent[pos[k]] < 0 || rv[parent[pos[k]]] != u) throw Err(TNQS_ERR_INVALID, "expect_region: the region's induced subgraph is not the given tree");
-                mp = up[pos[k]]->p;
-            } else { int de = g.dedge(k, u); if (s->msg[de]) mp = s->msg[de]->p; }
-            if (mp) c.steps.push_back({j, mp});
-        }
-        run_chains<T>(s, chains, TNQS_PROF_SMALL);
-        std::vector<GramJob> jobs(1);
-        GramJob& j = jobs[0]; j.X = chains[0].result; j.Y = s->site[u]->p; j.sd = sd;
-        if (par >= 0) { j.leg = g.leg(u, par); j.keep_site = false; } else { j.leg = -1; j.keep_site = true; }
-        if (par >= 0) run_grams<T, T>(s, jobs, TNQS_PROF_SMALL); else run_grams<T, double>(s, jobs, TNQS_PROF_SMALL);
-        const int n2 = j.KK * j.KK;
-        if (par >= 0) {
-            up[i] = dalloc(s, (size_t)n2 * esz);
-            std::vector<ReduceItem> ri{ReduceItem{j.partial->p, up[i]->p, n2, j.nchunks, 0, 0}};
+            std::vector<Chain> chains(1); Chain& c = chains[0]; c.v = u; c.src = ket; c.sd = sd;
+            for (int j = 0; j < sd.z; ++j) {
+                int k = g.nbr[u][j]; if (k == par) continue;
+                const void* mp = nullptr;
+                if (pos[k] >= 0) {
+                    if (parent[pos[k]] < 0 || rv[parent[pos[k]]] != u) throw Err(TNQS_ERR_INVALID, "expect_region: the region's induced subgraph is not the given tree");
+                    mp = up[pos[k]]->p;
+                } else { int de = g.dedge(k, u); if (s->msg[de]) mp = s->msg[de]->p; }
+                if (mp) c.steps.push_back({j, mp});
+            }
+            run_chains<T>(s, chains, TNQS_PROF_SMALL);
+            std::vector<GramJob> jobs(1);
+            GramJob& j = jobs[0]; j.X = chains[0].result; j.Y = s->site[u]->p; j.sd = sd;
+            if (par >= 0) { j.leg = g.leg(u, par); j.keep_site = false; } else { j.leg = -1; j.keep_site = true; }
+            if (par >= 0) run_grams<T, T>(s, jobs, TNQS_PROF_SMALL); else run_grams<T, double>(s, jobs, TNQS_PROF_SMALL);
+            if (j.KK * j.KK != n2) throw Err(TNQS_ERR_HIP, "internal: expect_region result size");
+            std::vector<ReduceItem> ri{ReduceItem{j.partial->p, reduce_dst, n2, j.nchunks, 0, 0}};
             const ReduceItem* dr = upload(s, ri);
-            launch_reduce<T, T>(s->stream, dr, 1, n2);
+            if (par >= 0) launch_reduce<T, T>(s->stream, dr, 1, n2); else launch_reduce<double, double>(s->stream, dr, 1, n2);
         } else {
-            Buf d_out = dalloc(s, (size_t)n2 * 16);
-            std::vector<ReduceItem> ri{ReduceItem{j.partial->p, d_out->p, n2, j.nchunks, 0, 0}};
-            const ReduceItem* dr = upload(s, ri);
-            launch_reduce<double, double>(s->stream, dr, 1, n2);
+            // the tree-shape check of the owner is repeated here so that every rank fails (or not) together
+            for (size_t j = 0; j < g.nbr[u].size(); ++j) { int k = g.nbr[u][j]; if (k == par) continue;
+                if (pos[k] >= 0 && (parent[pos[k]] < 0 || rv[parent[pos[k]]] != u)) throw Err(TNQS_ERR_INVALID, "expect_region: the region's induced subgraph is not the given tree"); }
+        }
+        if (sharded) {
+            exchange(s, stride);
+            HIPCHK(hipMemcpyAsync(result->p, reinterpret_cast<char*>(s->exch) + (size_t)s->owner[u] * stride, (size_t)n2 * out_esz, hipMemcpyDeviceToDevice, s->stream));
+        }
+        if (par >= 0) up[i] = result;
+        else {
             std::vector<double> rho(2 * (size_t)n2);
-            HIPCHK(hipMemcpyAsync(rho.data(), d_out->p, (size_t)n2 * 16, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipMemcpyAsync(rho.data(), result->p, (size_t)n2 * 16, hipMemcpyDeviceToHost, s->stream));
             sync(s);
-            double tre = 0, tim = 0; const int d = sd.d;
+            double tre = 0, tim = 0; const int d = dU;
             for (int si = 0; si < d; ++si) { tre += rho[2 * (si + d * si)]; tim += rho[2 * (si + d * si) + 1]; }
+            // a pending normalisation factor of a site tensor cancels between numerator and denominator
             out_re_im[0] = tre; out_re_im[1] = tim;
         }
     }
@@ -2249,7 +2267,6 @@ template <class T> static void region_contract(State* s, int nr, const int32_t* 
 void expect_region(State* s, int nr, const int32_t* rv, const int32_t* parent, const double* ops, double* out4) {
     const Graph& g = *s->g;
     if (nr < 1 || !rv || !parent || !ops || !out4) throw Err(TNQS_ERR_INVALID, "expect_region: bad arguments");
-    if (s->nranks > 1) throw Err(TNQS_ERR_UNSUPPORTED, "expect_region: multi-site observables are not implemented for sharded handles");
     int roots = 0;
     for (int i = 0; i < nr; ++i) {
         if (rv[i] < 0 || rv[i] >= g.nv) throw Err(TNQS_ERR_INVALID, "expect_region: bad vertex");
@@ -2269,7 +2286,8 @@ void expect_region(State* s, int nr, const int32_t* rv, const int32_t* parent, c
 template <class T> static void symmetric_gauge_t(State* s, double regularization) {
     const Graph& g = *s->g;
     const size_t esz = s->esz();
-    if (s->nranks > 1) throw Err(TNQS_ERR_UNSUPPORTED, "symmetric_gauge: not implemented for sharded handles");
+    // sharded handles: the per-edge algebra (2|E| eigen problems, |E| SVDs of chi x chi matrices) is replicated -- every rank runs the same
+    // kernels on the same replicated messages -- and each rank gauges the site tensors it owns; nothing is exchanged
     HIPCHK(hipSetDevice(s->device));
     if (g.ne == 0) return;
     const double reg = regularization >= 0 ? regularization : 10.0 * (s->dtype == TNQS_C64 ? 1.1920928955078125e-07 : 2.220446049250313e-16);

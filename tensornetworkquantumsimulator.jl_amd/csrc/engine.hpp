@@ -70,6 +70,14 @@ struct Prof {
     ~Prof() { for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); } for (auto e : ev_free) (void)hipEventDestroy(e); }
 };
 
+// RCCL transport of the exchange step (sharding.cpp): communicator + the exchange buffer the library owns in that mode; shared by the
+// copies of a handle, released with the last of them
+struct RcclComm {
+    void* comm = nullptr; int device = 0; void* exch_owned = nullptr;
+    long long n_exchanges = 0, bytes_exchanged = 0;
+    ~RcclComm();
+};
+
 struct State {
     std::shared_ptr<Graph> g;
     int dtype = TNQS_C64;
@@ -85,7 +93,8 @@ struct State {
     hipStream_t stream = nullptr; bool own_stream = false;
     // sharding
     int rank = 0, nranks = 1; std::vector<int> owner; tnqs_allgather_fn ag_fn = nullptr; void* ag_ctx = nullptr;
-    void* exch = nullptr; size_t exch_bytes = 0;      // host-provided device exchange buffer (nranks equal blocks)
+    void* exch = nullptr; size_t exch_bytes = 0;      // device exchange buffer (nranks equal blocks): the host's (callback mode) or comm->exch_owned
+    std::shared_ptr<RcclComm> comm;                   // set: the all-gather is an ncclAllGather enqueued on the handle's stream
     // profiling (shared by copies of a handle, so a loop `bpc = apply_gates(layer, bpc)` accumulates)
     std::shared_ptr<Prof> prof;
     std::vector<Buf> keepalive;    // descriptor buffers kept until the next host sync
@@ -117,5 +126,10 @@ void edge_scalars(State* s, double* out);
 void rescale(State* s);
 void symmetric_gauge(State* s, double regularization);
 void prof_collect(State* s);
+// sharding.cpp
+void rccl_unique_id(void* out128);
+void set_sharding_rccl(State* s, int rank, int nranks, const int32_t* owner, const void* unique_id128, int64_t exch_bytes);
+void rccl_allgather(State* s, size_t bytes_per_rank);
+void rccl_selftest(int device, int64_t bytes);
 
 }  // namespace tnqs

@@ -79,14 +79,81 @@ class Sharding:
         self.cb = L.ALLGATHER_FN(_cb)
 
 
+class RcclSharding:
+    """transport = RCCL inside the library (tnqs_set_sharding_rccl): nothing of the data path runs in Python.  Only the 128-byte
+    ncclUniqueId travels through the host once: rank 0 creates it, `broadcast` hands it to the other ranks (default:
+    torch.distributed.broadcast_object_list on whatever backend the process group has -- gloo is fine, it is not the data path)."""
+
+    def __init__(self, bpc, rank: int, world: int, owner: List[int], exch_bytes: int, group=None, broadcast=None):
+        import weakref
+        self.rank, self.world, self.owner, self.group = rank, world, list(owner), group
+        self._ref = weakref.ref(bpc)              # any live handle of the family will do for the counters (core.copy re-attaches)
+        self._last = (0, 0)
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            L.check(L.lib.tnqs_rccl_unique_id(uid))
+        payload = [bytes(uid.raw)]
+        if world > 1:
+            if broadcast is not None:
+                payload = [broadcast(payload[0])]
+            else:
+                import torch.distributed as dist
+                dist.broadcast_object_list(payload, src=0, group=group)
+        self.uid = C.create_string_buffer(payload[0], 128)
+        ow, owp = L.i32(owner)
+        L.check(L.lib.tnqs_set_sharding_rccl(bpc._h, rank, world, owp, self.uid, C.c_int64(int(exch_bytes))))
+
+    def attach(self, bpc):
+        import weakref
+        self._ref = weakref.ref(bpc)
+
+    def _stats(self):
+        bpc = self._ref()
+        if bpc is not None and getattr(bpc, "_h", None) is not None:
+            n, b = C.c_int64(), C.c_int64()
+            L.check(L.lib.tnqs_sharding_stats(bpc._h, C.byref(n), C.byref(b)))
+            self._last = (n.value, b.value)
+        return self._last
+
+    @property
+    def n_exchanges(self) -> int:
+        return self._stats()[0]
+
+    @property
+    def bytes_exchanged(self) -> int:
+        return self._stats()[1]
+
+
+def rccl_selftest(device: int = 0, nbytes: int = 1 << 20):
+    """one-rank round trip through the library's RCCL transport (a single GPU cannot host two RCCL ranks)"""
+    L.check(L.lib.tnqs_rccl_selftest(int(device), C.c_int64(int(nbytes))))
+
+
 def shard(bpc, rank: int, world: int, owner: Optional[List[int]] = None, exch_bytes: Optional[int] = None, group=None,
-          max_chi: int = 64):
-    """attach vertex sharding to a freshly created cache (call on every rank, before uploading site tensors)"""
+          max_chi: int = 64, transport: Optional[str] = None, broadcast=None):
+    """attach vertex sharding to a freshly created cache (call on every rank, before uploading site tensors).
+    transport = "rccl": the library's own RCCL all-gather on its stream (production; one rank per GPU);
+                "callback": torch.distributed through a host callback (gloo tests in which ranks share a GPU);
+                None: "rccl" when the process group's backend is nccl, else "callback"."""
     g = bpc.graph
     if owner is None:
         owner = partition_vertices(g.nv(), world)
     if exch_bytes is None:
         exch_bytes = world * exchange_bytes_needed(max_chi, 2, g.ne(), g.nv(), 8 if bpc.dtype == np.complex64 else 16) // max(1, world // 2)
+    if transport is None:
+        transport = "callback"
+        try:
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_backend(group) == "nccl":
+                transport = "rccl"
+        except Exception:
+            pass
+    if transport == "rccl":
+        sh = RcclSharding(bpc, rank, world, owner, exch_bytes, group=group, broadcast=broadcast)
+        bpc._shard = sh
+        return sh
+    if transport != "callback":
+        raise ValueError(f"shard: unknown transport {transport!r}")
     sh = Sharding(rank, world, owner, exch_bytes, group=group, device=bpc.device)
     ow, owp = L.i32(owner)
     L.check(L.lib.tnqs_set_sharding(bpc._h, rank, world, owp, sh.cb, None, C.c_void_p(sh.buf.data_ptr()),

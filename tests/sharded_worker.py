@@ -24,9 +24,13 @@ def run(bpc_factory, layer, kw, bpkw, nlayers):
 
 def main():
     out = sys.argv[1]
-    dist.init_process_group("gloo")
+    backend = os.environ.get("TNQS_WORKER_BACKEND", "gloo")      # "nccl": one rank per GPU, the library's own RCCL transport
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
+    dev = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
     mode = sys.argv[2] if len(sys.argv) > 2 else "c128"
     dtype = np.complex64 if mode in ("c64", "chi32") else np.complex128
     # "chi32": 4x4 grid at bond dimension 32 -- the degree-4 sites run the plane kernels (shared pair products, epilogue kernel,
@@ -84,7 +88,7 @@ def main():
         nlayers = 8
 
     def sharded_factory():
-        b = tn.BeliefPropagationCache(tn.tensornetworkstate(dtype, lambda v: "↑", g))
+        b = tn.BeliefPropagationCache(tn.tensornetworkstate(dtype, lambda v: "↑", g), device=dev)
         tn.shard(b, rank, world, exch_bytes=(64 << 20) if big else (8 << 20), max_chi=64)
         for v in g.vertices:
             if b.owns(v):
@@ -106,9 +110,31 @@ def main():
             w = np.linalg.eigvalsh((m + m.conj().T) / 2)
             spectra.append(w / w.sum())
     dims = np.array([bs.bond_dim(a, b) for (a, b) in g.edges])
+    # multi-site observables and the symmetric gauge on the sharded handle (every rank takes part in the region's exchanges)
+    extra = mode in ("c128", "c64")
+    vs = list(g.vertices)
+    regions = [[vs[0], vs[1]], [vs[0], vs[-1]], [vs[len(vs) // 2 - 1], vs[len(vs) // 2]]] if extra else []
+    def multi(b):
+        out = []
+        for r in regions:
+            try:
+                out.append(complex(tn.expect(b, ("Z" * len(r), r))))
+            except ValueError:                      # no unique Steiner tree for this pair: skipped on both sides
+                out.append(complex("nan"))
+        return np.array(out)
+    zz_sh = multi(bs) if extra else np.zeros(0)
+    if extra:
+        bg = tn.symmetric_gauge(bs)
+        ezg = tn.expect_all(bg, "Z")
+        ezg_t = torch.from_numpy(np.nan_to_num(ezg.view(np.float64), nan=0.0).copy())
+        dist.all_reduce(ezg_t)
+        ezg_full = ezg_t.numpy().view(np.complex128)
+        sg = np.sort(np.abs(np.diag(bg.message((vs[0], vs[1])))))
+    else:
+        ezg_full, sg = np.zeros(0), np.zeros(0)
     nex = bs._shard.n_exchanges
     if rank == 0:
-        bu, eu = run(lambda: tn.BeliefPropagationCache(psi0), layer, kw, bpkw, nlayers)
+        bu, eu = run(lambda: tn.BeliefPropagationCache(psi0, device=dev), layer, kw, bpkw, nlayers)
         ezu = tn.expect_all(bu, "Z")
         spu = []
         for (a, b) in g.edges:
@@ -116,8 +142,13 @@ def main():
                 m = bu.message(e).astype(np.complex128)
                 w = np.linalg.eigvalsh((m + m.conj().T) / 2)
                 spu.append(w / w.sum())
-        np.savez(out, errs_sh=es, errs_un=eu, ez_sh=ez_full, ez_un=ezu, sp_sh=np.concatenate(spectra), sp_un=np.concatenate(spu),
-                 dims_sh=dims, dims_un=np.array([bu.bond_dim(a, b) for (a, b) in g.edges]), n_exchanges=nex)
+        if extra:
+            zz_un = multi(bu); bgu = tn.symmetric_gauge(bu); ezg_un = tn.expect_all(bgu, "Z"); sg_un = np.sort(np.abs(np.diag(bgu.message((vs[0], vs[1])))))
+        else:
+            zz_un, ezg_un, sg_un = np.zeros(0), np.zeros(0), np.zeros(0)
+        np.savez(out, zz_sh=zz_sh, zz_un=zz_un, ezg_sh=ezg_full, ezg_un=ezg_un, sg_sh=sg, sg_un=sg_un, errs_sh=es, errs_un=eu, ez_sh=ez_full, ez_un=ezu, sp_sh=np.concatenate(spectra), sp_un=np.concatenate(spu),
+                 dims_sh=dims, dims_un=np.array([bu.bond_dim(a, b) for (a, b) in g.edges]), n_exchanges=nex,
+                 transport=type(bs._shard).__name__)
     dist.barrier()
     dist.destroy_process_group()
 

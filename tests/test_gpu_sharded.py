@@ -31,3 +31,42 @@ def test_sharded_apply_gates_matches_single_rank(tmp_path, dt, nranks):
     assert np.max(np.abs(z["ez_sh"] - z["ez_un"])) < tol
     assert np.max(np.abs(z["sp_sh"] - z["sp_un"])) < tol
     assert int(z["n_exchanges"]) > 0
+    if len(z["zz_sh"]):       # multi-site expectation values (one exchange per region vertex) and the symmetric gauge on the sharded handle
+        ok = ~np.isnan(z["zz_un"])
+        assert np.array_equal(np.isnan(z["zz_sh"]), np.isnan(z["zz_un"])) and ok.any()
+        assert np.max(np.abs(z["zz_sh"][ok] - z["zz_un"][ok])) < tol
+        assert np.max(np.abs(z["ezg_sh"] - z["ezg_un"])) < tol and np.max(np.abs(z["sg_sh"] - z["sg_un"])) < tol
+
+
+def test_rccl_transport_loads_and_runs_on_one_gpu():
+    """the library's own RCCL transport (tnqs_set_sharding_rccl: librccl.so loaded at run time, in-place ncclAllGather on the handle's
+    stream): unique id, one-rank communicator, all-gather round trip, teardown.  RCCL refuses two ranks on one GPU, so this is what a
+    single-GPU box can check of it; the two-rank test below needs two GPUs."""
+    import tnqs_amd as tn
+    tn.dist.rccl_selftest(0, 1 << 20)
+    # a one-rank sharded handle goes through tnqs_set_sharding_rccl as well (communicator of size 1, nothing to exchange)
+    g = tn.named_grid((2, 2))
+    b = tn.BeliefPropagationCache(tn.random_tensornetworkstate(np.complex64, g, bond_dimension=2, seed=1))
+    sh = tn.shard(b, 0, 1, transport="rccl", exch_bytes=1 << 20)
+    b2 = tn.update(b, maxiter=3, tolerance=None)
+    assert np.isfinite(tn.expect(b2, ("Z", [g.vertices[0]]))) and sh.n_exchanges == 0
+
+
+@pytest.mark.parametrize("dt", ["c64", "chi32", "illc128"])
+def test_sharded_over_rccl_matches_single_rank(tmp_path, dt):
+    """two ranks on two GPUs, torch.distributed backend nccl for the rendezvous, the data path on the library's RCCL transport"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL does not allow two ranks on one device (the gloo-backed tests above cover the protocol, "
+                    "test_rccl_transport_loads_and_runs_on_one_gpu the transport)")
+    out = str(tmp_path / "res.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", TNQS_WORKER_BACKEND="nccl")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(ROOT, "tests", "sharded_worker.py"), out, dt]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    z = np.load(out)
+    assert str(z["transport"]) == "RcclSharding" and int(z["n_exchanges"]) > 0
+    tol = 1e-11 if dt == "illc128" else (2e-4 if dt == "c64" else 5e-4)
+    assert np.array_equal(z["dims_sh"], z["dims_un"])
+    assert np.max(np.abs(z["ez_sh"] - z["ez_un"])) < tol and np.max(np.abs(z["sp_sh"] - z["sp_un"])) < tol
