@@ -30,7 +30,13 @@ extern "C" {
 
 typedef struct tnqs_state_s* tnqs_handle;
 
-enum { TNQS_C64 = 0, TNQS_C128 = 1, TNQS_F32 = 2, TNQS_F64 = 3 }; /* F32/F64: TNQS_ERR_UNSUPPORTED for now */
+/* Element types (the reference's default is Float64, README.md:86; its BP tests run all four, test/test_beliefpropagation.jl:14,34).
+ * A handle created as TNQS_F32 / TNQS_F64 takes and returns REAL site tensors and messages (tnqs_set/get_site_tensor,
+ * tnqs_set/get_message); the device stores them as complex numbers with zero imaginary parts and runs the complex kernels.  Applying
+ * a gate with a non-zero imaginary part promotes the handle to the complex type of the same precision, as in the reference
+ * (`adapt_gate`, src/Apply/apply_gates.jl:41-44: a complex gate stays complex, and contracting it promotes the site tensors);
+ * tnqs_scalartype tells which type the getters / setters currently speak. */
+enum { TNQS_C64 = 0, TNQS_C128 = 1, TNQS_F32 = 2, TNQS_F64 = 3 };
 
 enum {
     TNQS_OK = 0,
@@ -90,6 +96,8 @@ int tnqs_destroy(tnqs_handle h);
 /* Base.copy(::BeliefPropagationCache) (beliefpropagationcache.jl:35-37): shallow, buffers are shared and
  * never mutated in place, so the copy is O(nv + ne). */
 int tnqs_copy(tnqs_handle h, tnqs_handle* out);
+/* scalartype(bpc) (abstractbeliefpropagationcache.jl:13): the element type host buffers of this handle are read / written in */
+int tnqs_scalartype(tnqs_handle h, int* dtype);
 /* use an existing HIP stream (e.g. torch's current stream) instead of the handle's own */
 int tnqs_set_stream(tnqs_handle h, void* hip_stream);
 

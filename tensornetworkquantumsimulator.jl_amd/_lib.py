@@ -40,7 +40,7 @@ def _share_torch_hip_runtime():
 _share_torch_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
-TNQS_C64, TNQS_C128 = 0, 1
+TNQS_C64, TNQS_C128, TNQS_F32, TNQS_F64 = 0, 1, 2, 3
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NUMERIC, ERR_COMM = 0, -1, -2, -3, -4, -5
 
 
@@ -74,6 +74,7 @@ _SIGS = {
     "tnqs_create": ([C.c_int, C.c_int, _I32P, _I32P, _I32P, C.c_int, C.c_int, C.POINTER(H)], C.c_int),
     "tnqs_destroy": ([H], C.c_int),
     "tnqs_copy": ([H, C.POINTER(H)], C.c_int),
+    "tnqs_scalartype": ([H, C.POINTER(C.c_int)], C.c_int),
     "tnqs_set_stream": ([H, C.c_void_p], C.c_int),
     "tnqs_set_site_tensor": ([H, C.c_int, C.c_void_p, C.c_int, _I64P, _I32P], C.c_int),
     "tnqs_get_site_tensor": ([H, C.c_int, C.c_void_p, C.c_int, _I32P], C.c_int),

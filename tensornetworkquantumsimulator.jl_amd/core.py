@@ -23,7 +23,8 @@ from . import _lib as L
 from .gates import gate_matrix, resolve_gate, resolve_gate_flat
 from .graphs import NamedGraph, edge_color as _edge_color
 
-_DT = {np.dtype(np.complex64): L.TNQS_C64, np.dtype(np.complex128): L.TNQS_C128}
+_DT = {np.dtype(np.complex64): L.TNQS_C64, np.dtype(np.complex128): L.TNQS_C128, np.dtype(np.float32): L.TNQS_F32, np.dtype(np.float64): L.TNQS_F64}
+_DT_INV = {v: k for k, v in _DT.items()}
 _STATES = {"↑": (1, 0), "Up": (1, 0), "0": (1, 0), "Z+": (1, 0), "↓": (0, 1), "Dn": (0, 1), "1": (0, 1), "Z-": (0, 1),
            "+": (1 / math.sqrt(2), 1 / math.sqrt(2)), "X+": (1 / math.sqrt(2), 1 / math.sqrt(2)),
            "-": (1 / math.sqrt(2), -1 / math.sqrt(2)), "X-": (1 / math.sqrt(2), -1 / math.sqrt(2))}
@@ -107,14 +108,14 @@ class BeliefPropagationCache:
     def __init__(self, network, device: int = 0, _handle=None):
         self._shard = None
         if _handle is not None:
-            self.graph, self.dtype, self._h, self.device = network, device[0], _handle, device[1]
+            self.graph, self._h, self.device = network, _handle, device[1]
             return
         if not isinstance(network, TensorNetworkState):
             raise TypeError("BeliefPropagationCache(network): expected a TensorNetworkState")
         g = network.graph
         if network.dtype not in _DT:
-            raise TypeError(f"unsupported element type {network.dtype}; supported: complex64, complex128")
-        self.graph, self.dtype, self.device = g, network.dtype, device
+            raise TypeError(f"unsupported element type {network.dtype}; supported: float32, float64, complex64, complex128")
+        self.graph, self.device = g, device
         es, esp = L.i32([g.index[a] for (a, b) in g.edges])
         ed, edp = L.i32([g.index[b] for (a, b) in g.edges])
         sd, sdp = L.i32([network.tensors[v].shape[0] for v in g.vertices])
@@ -125,6 +126,15 @@ class BeliefPropagationCache:
         for v in g.vertices:
             self._set_tensor(v, network.tensors[v])
 
+    @property
+    def dtype(self):
+        """scalartype(bpc): the element type the handle speaks at the boundary.  A cache created from a real network stays real until a
+        complex gate is applied to it (adapt_gate keeps a complex gate complex, apply_gates.jl:41-44) -- then it is the complex type of
+        the same precision, like the reference's promoted network."""
+        c = C.c_int()
+        L.check(L.lib.tnqs_scalartype(self._h, C.byref(c)))
+        return _DT_INV[c.value]
+
     # -- marshalling ---------------------------------------------------------------------------------------
     def _roles(self, v):
         # numpy C-order axes (s, n0, n1, ...) == column-major axes (..., n1, n0, s)
@@ -132,7 +142,10 @@ class BeliefPropagationCache:
         return list(reversed([-1] + nb))
 
     def _set_tensor(self, v, t):
-        t = np.ascontiguousarray(t, dtype=self.dtype)
+        dt = self.dtype
+        if np.iscomplexobj(t) and not np.issubdtype(dt, np.complexfloating):
+            raise TypeError("cannot store a complex tensor in a cache whose element type is real (create it from a complex network)")
+        t = np.ascontiguousarray(t, dtype=dt)
         dims = np.array(list(reversed(t.shape)), dtype=np.int64)
         roles, rp = L.i32(self._roles(v))
         L.check(L.lib.tnqs_set_site_tensor(self._h, self.graph.index[v], t.ctypes.data_as(C.c_void_p), t.ndim,
@@ -179,7 +192,7 @@ class BeliefPropagationCache:
     def copy(self) -> "BeliefPropagationCache":
         h = L.H()
         L.check(L.lib.tnqs_copy(self._h, C.byref(h)))
-        out = BeliefPropagationCache(self.graph, (self.dtype, self.device), _handle=h)
+        out = BeliefPropagationCache(self.graph, (None, self.device), _handle=h)
         out._shard = self._shard          # copies share the sharding state (and keep its callback alive)
         if hasattr(self._shard, "attach"):
             self._shard.attach(out)

@@ -41,6 +41,7 @@ int tnqs_destroy(tnqs_handle h) {
 int tnqs_copy(tnqs_handle h, tnqs_handle* out) {
     return guard([&] { if (!out) throw Err(TNQS_ERR_INVALID, "tnqs_copy: out is null"); *out = new tnqs_state_s{state_copy(S(h))}; });
 }
+int tnqs_scalartype(tnqs_handle h, int* dtype) { return guard([&] { if (!dtype) throw Err(TNQS_ERR_INVALID, "scalartype: null output"); *dtype = S(h)->scalartype(); }); }
 int tnqs_set_stream(tnqs_handle h, void* stream) {
     return guard([&] {
         State* s = S(h);

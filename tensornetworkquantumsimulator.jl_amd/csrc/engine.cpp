@@ -257,14 +257,16 @@ template <class T> static void fill_product_up(State* s, int v) {
 
 State* state_create(int nv, int ne, const int32_t* es, const int32_t* ed, const int32_t* sd, int dtype, int device) {
     if (nv <= 0 || ne < 0) throw Err(TNQS_ERR_INVALID, "tnqs_create: nv must be > 0 and ne >= 0");
-    if (dtype != TNQS_C64 && dtype != TNQS_C128) throw Err(TNQS_ERR_UNSUPPORTED, "tnqs_create: only TNQS_C64 / TNQS_C128 are implemented");
+    if (dtype != TNQS_C64 && dtype != TNQS_C128 && dtype != TNQS_F32 && dtype != TNQS_F64) throw Err(TNQS_ERR_INVALID, "tnqs_create: unknown dtype");
+    const bool real_io = (dtype == TNQS_F32 || dtype == TNQS_F64);
+    if (dtype == TNQS_F32) dtype = TNQS_C64; else if (dtype == TNQS_F64) dtype = TNQS_C128;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw Err(TNQS_ERR_HIP, "tnqs_create: no HIP device available (the HIP path has no CPU fallback)");
     if (device < 0 || device >= ndev) throw Err(TNQS_ERR_INVALID, "tnqs_create: bad device index");
     HIPCHK(hipSetDevice(device));
     auto s = std::make_unique<State>();
     s->g = make_graph(nv, ne, es, ed);
-    s->dtype = dtype; s->device = device;
+    s->dtype = dtype; s->real_io = real_io; s->device = device;
     s->d.assign(nv, 2);
     if (sd) for (int v = 0; v < nv; ++v) { if (sd[v] < 1 || sd[v] > 16) throw Err(TNQS_ERR_INVALID, "tnqs_create: site dimension out of range"); s->d[v] = sd[v]; }
     s->chi.assign(ne, 1);
@@ -278,7 +280,7 @@ State* state_create(int nv, int ne, const int32_t* es, const int32_t* ed, const 
 
 State* state_copy(const State* o) {
     auto s = std::make_unique<State>();
-    s->g = o->g; s->dtype = o->dtype; s->device = o->device; s->d = o->d; s->chi = o->chi;
+    s->g = o->g; s->dtype = o->dtype; s->real_io = o->real_io; s->device = o->device; s->d = o->d; s->chi = o->chi;
     s->site = o->site; s->sscale = o->sscale; s->msg = o->msg; s->pool = o->pool; s->prof = o->prof;
     s->rank = o->rank; s->nranks = o->nranks; s->owner = o->owner; s->ag_fn = o->ag_fn; s->ag_ctx = o->ag_ctx;
     s->exch = o->exch; s->exch_bytes = o->exch_bytes; s->comm = o->comm;
@@ -289,6 +291,19 @@ State* state_copy(const State* o) {
 }
 
 template <class T> static void permute_dispatch(State* s, const PermItem& it) { launch_permute<T>(s->stream, it); }
+
+// real element types at the boundary: the caller's real array becomes (re, 0) pairs on the way in and loses its (zero) imaginary parts on
+// the way out; everything in between is the complex path
+static std::vector<char> widen_real(const State* s, const void* host, size_t n) {
+    std::vector<char> out(n * s->esz());
+    if (s->dtype == TNQS_C64) { const float* p = static_cast<const float*>(host); float* q = reinterpret_cast<float*>(out.data()); for (size_t i = 0; i < n; ++i) { q[2 * i] = p[i]; q[2 * i + 1] = 0.f; } }
+    else { const double* p = static_cast<const double*>(host); double* q = reinterpret_cast<double*>(out.data()); for (size_t i = 0; i < n; ++i) { q[2 * i] = p[i]; q[2 * i + 1] = 0.0; } }
+    return out;
+}
+static void narrow_real(const State* s, const std::vector<char>& cplx, void* host, size_t n) {
+    if (s->dtype == TNQS_C64) { const float* q = reinterpret_cast<const float*>(cplx.data()); float* p = static_cast<float*>(host); for (size_t i = 0; i < n; ++i) p[i] = q[2 * i]; }
+    else { const double* q = reinterpret_cast<const double*>(cplx.data()); double* p = static_cast<double*>(host); for (size_t i = 0; i < n; ++i) p[i] = q[2 * i]; }
+}
 
 void state_set_site(State* s, int v, const void* host, int ndim, const int64_t* dims, const int32_t* role) {
     const Graph& g = *s->g;
@@ -318,6 +333,7 @@ void state_set_site(State* s, int v, const void* host, int ndim, const int64_t* 
     }
     if (!host) throw Err(TNQS_ERR_INVALID, "set_site_tensor: null data for an owned vertex");
     Buf raw = dalloc(s, n * s->esz());
+    std::vector<char> widened; if (s->real_io) { widened = widen_real(s, host, n); host = widened.data(); }
     HIPCHK(hipMemcpyAsync(raw->p, host, n * s->esz(), hipMemcpyHostToDevice, s->stream));
     Buf out = dalloc(s, n * s->esz());
     PermItem it{}; it.in = raw->p; it.out = out->p; it.ndim = ndim; it.n = n;
@@ -354,8 +370,10 @@ void state_get_site(State* s, int v, void* host, int ndim, const int32_t* role) 
     if (s->sscale[v]) { materialize_scale(s, {v}); it.in = s->site[v]->p; }       // the caller sees the normalised tensor
     Buf out = dalloc(s, sd.n * s->esz()); it.out = out->p;
     if (s->dtype == TNQS_C64) permute_dispatch<float>(s, it); else permute_dispatch<double>(s, it);
-    HIPCHK(hipMemcpyAsync(host, out->p, sd.n * s->esz(), hipMemcpyDeviceToHost, s->stream));
+    std::vector<char> tmp; void* dst = host; if (s->real_io) { tmp.resize(sd.n * s->esz()); dst = tmp.data(); }
+    HIPCHK(hipMemcpyAsync(dst, out->p, sd.n * s->esz(), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->real_io) narrow_real(s, tmp, host, sd.n);
 }
 
 void state_set_message(State* s, int src, int dst, const void* host, int chi) {
@@ -364,6 +382,7 @@ void state_set_message(State* s, int src, int dst, const void* host, int chi) {
     if (chi != s->chi[de / 2]) throw Err(TNQS_ERR_INVALID, "set_message: dimension does not match the bond");
     HIPCHK(hipSetDevice(s->device));
     Buf b = dalloc(s, (size_t)chi * chi * s->esz());
+    std::vector<char> widened; if (s->real_io) { widened = widen_real(s, host, (size_t)chi * chi); host = widened.data(); }
     HIPCHK(hipMemcpyAsync(b->p, host, (size_t)chi * chi * s->esz(), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->msg[de] = b;
@@ -375,15 +394,18 @@ void state_get_message(State* s, int src, int dst, void* host, int chi) {
     HIPCHK(hipSetDevice(s->device));
     size_t bytes = (size_t)chi * chi * s->esz();
     if (!s->msg[de]) {      // default_message: identity
-        std::memset(host, 0, bytes);
+        const size_t st = s->real_io ? 1 : 2;
+        std::memset(host, 0, (size_t)chi * chi * s->io_esz());
         for (int i = 0; i < chi; ++i) {
-            if (s->dtype == TNQS_C64) reinterpret_cast<float*>(host)[2 * (size_t)(i + (size_t)chi * i)] = 1.f;
-            else reinterpret_cast<double*>(host)[2 * (size_t)(i + (size_t)chi * i)] = 1.0;
+            if (s->dtype == TNQS_C64) reinterpret_cast<float*>(host)[st * (size_t)(i + (size_t)chi * i)] = 1.f;
+            else reinterpret_cast<double*>(host)[st * (size_t)(i + (size_t)chi * i)] = 1.0;
         }
         return;
     }
-    HIPCHK(hipMemcpyAsync(host, s->msg[de]->p, bytes, hipMemcpyDeviceToHost, s->stream));
+    std::vector<char> tmp; void* hdst = host; if (s->real_io) { tmp.resize(bytes); hdst = tmp.data(); }
+    HIPCHK(hipMemcpyAsync(hdst, s->msg[de]->p, bytes, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->real_io) narrow_real(s, tmp, host, (size_t)chi * chi);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1986,6 +2008,11 @@ template <class T> static void apply_gates_t(State* s, int ngates, const int32_t
         }
     }
     if (errs) std::fill(errs, errs + ngates, 0.0);
+    if (s->real_io) {       // adapt_gate (apply_gates.jl:41-44): a real gate takes the state's real type, a complex gate stays complex and promotes
+        bool cplx = false;
+        for (size_t k = 1; k < moff[ngates] && !cplx; k += 2) cplx = mats[k] != 0.0;
+        if (cplx) s->real_io = false;
+    }
     std::set<int> affected, batch_verts;
     std::vector<Gate1> b1; std::vector<Gate2> b2;
     for (int i = 0; i < ngates; ++i) {

@@ -80,7 +80,12 @@ struct RcclComm {
 
 struct State {
     std::shared_ptr<Graph> g;
-    int dtype = TNQS_C64;
+    int dtype = TNQS_C64;          // STORAGE / arithmetic type: TNQS_C64 or TNQS_C128 (real element types are stored as complex numbers
+                                   // with zero imaginary parts and computed by the complex kernels)
+    // element type at the boundary (tnqs_scalartype): a handle created as TNQS_F32 / TNQS_F64 takes and returns REAL tensors and messages
+    // until a complex gate is applied to it -- from then on it is ComplexF32 / ComplexF64, exactly like the reference's network after
+    // `adapt_gate` kept a complex gate complex (src/Apply/apply_gates.jl:41-44) and the contraction promoted the site tensors
+    bool real_io = false;
     int device = 0;
     std::vector<int> d;            // site dims
     std::vector<int> chi;          // bond dim per edge
@@ -101,6 +106,8 @@ struct State {
     tnqs_apply_stats stats{};
 
     size_t esz() const { return dtype == TNQS_C64 ? 8 : 16; }
+    int scalartype() const { return real_io ? (dtype == TNQS_C64 ? TNQS_F32 : TNQS_F64) : dtype; }
+    size_t io_esz() const { return real_io ? esz() / 2 : esz(); }
     bool owns(int v) const { return nranks == 1 || owner[v] == rank; }
     ~State();
 };

@@ -139,7 +139,7 @@ def shard(bpc, rank: int, world: int, owner: Optional[List[int]] = None, exch_by
     if owner is None:
         owner = partition_vertices(g.nv(), world)
     if exch_bytes is None:
-        exch_bytes = world * exchange_bytes_needed(max_chi, 2, g.ne(), g.nv(), 8 if bpc.dtype == np.complex64 else 16) // max(1, world // 2)
+        exch_bytes = world * exchange_bytes_needed(max_chi, 2, g.ne(), g.nv(), 8 if np.dtype(bpc.dtype) in (np.dtype(np.complex64), np.dtype(np.float32)) else 16) // max(1, world // 2)
     if transport is None:
         transport = "callback"
         try:

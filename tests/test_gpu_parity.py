@@ -917,3 +917,65 @@ def test_default_update_is_exact_on_trees(dtype, lattice):
         p = np.sum(np.abs(t) ** 2, axis=ax); zex = (p[0] - p[1]) / nrm
         assert abs(z1 - zm) < tol and abs(z1 - zex) < tol, (lattice, v, z1, zm, zex)
     assert abs(tn.partitionfunction(one) / nrm - 1) < (2e-4 if dtype == np.complex64 else 1e-10)
+
+
+@pytest.mark.parametrize("eltype", [np.float32, np.float64, np.complex64, np.complex128])
+def test_four_eltypes_bp_on_a_comb_tree(eltype):
+    """test/test_beliefpropagation.jl:34-56 on the device, all four element types of the reference: the cache speaks the network's scalartype,
+    starts without messages, holds 2|E| messages after `update`, its partition function is the exact <psi|psi>, and the BP one-site
+    reduced density matrix at the centre equals the exact one to 10 eps of the element type (:54)."""
+    from statevector import tns_to_statevector, rdm_statevector
+    g = tn.named_comb_tree((3, 3))
+    psi = tn.random_tensornetworkstate(eltype, g, bond_dimension=2, seed=123)
+    bpc = tn.BeliefPropagationCache(psi)
+    assert tn.scalartype(bpc) == np.dtype(eltype) and bpc.graph is g
+    e0 = g.edges[0]
+    m0 = bpc.message(e0)
+    assert m0.dtype == np.dtype(eltype) and np.array_equal(m0, np.eye(2, dtype=eltype))            # unset = identity of the element type
+    t0 = bpc.tensor(g.vertices[0])
+    assert t0.dtype == np.dtype(eltype) and np.array_equal(t0, psi.tensors[g.vertices[0]])         # bit-exact round trip, real stays real
+    bpc = tn.update(bpc)
+    assert tn.scalartype(bpc) == np.dtype(eltype) and bpc.message(e0).dtype == np.dtype(eltype)
+    sv = tns_to_statevector(to_oracle_state(psi))
+    z_exact = float(np.vdot(sv, sv).real)
+    eps = np.finfo(np.dtype(eltype)).eps if np.dtype(eltype).kind == "f" else np.finfo(np.zeros(1, eltype).real.dtype).eps
+    assert abs(complex(tn.partitionfunction(bpc)) - z_exact) <= np.sqrt(eps) * z_exact                # `≈` of the reference: rtol sqrt(eps)
+    vc = (2, 1)                                       # centre of the comb's backbone (first(center(g)) in the reference)
+    rho_bp = tn.rdm(bpc, vc)
+    rho_ex = rdm_statevector(sv.reshape((2,) * g.nv()), to_oracle_graph(g), vc)
+    err = np.linalg.norm(rho_bp - rho_ex)
+    print(np.dtype(eltype).name, "rdm error / eps =", err / eps)
+    assert err <= 10 * eps
+
+
+@pytest.mark.parametrize("real,cplx", [(np.float32, np.complex64), (np.float64, np.complex128)])
+def test_real_network_real_gates_then_promotion_by_a_complex_gate(real, cplx):
+    """adapt_gate (apply_gates.jl:41-44): a real gate takes the network's real type -- the cache stays real and matches the oracle run on the
+    real arrays; a complex gate stays complex, and from that call on the cache is the complex type of the same precision (the
+    reference's network after the contraction promoted the site tensors) -- it matches the oracle run in complex arithmetic."""
+    g = tn.named_grid((3, 3))
+    psi = tn.random_tensornetworkstate(real, g, bond_dimension=2, seed=5)
+    groups = tn.edge_color(g, 4)
+    seq = colour_sequence(g, groups)
+    bpkw = dict(edge_sequence=seq, **fixed(20))
+    kw = dict(maxdim=4, cutoff=1e-12, normalize_tensors=True)
+    real_layer = [("Ry", [v], 0.3) for v in g.vertices] + [("CNOT", [a, b]) for (a, b) in groups[0]] + [("H", [g.vertices[0]])]
+    bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
+    bo = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)
+    bd, ed = tn.apply_gates(real_layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw)
+    bo, eo = o.apply_gates(real_layer, bo, apply_kwargs=kw, bp_update_kwargs=bpkw)
+    assert tn.scalartype(bd) == np.dtype(real) and bd.tensor(g.vertices[4]).dtype == np.dtype(real) and bd.message(g.edges[0]).dtype == np.dtype(real)
+    tol = TOL[np.dtype(cplx)]
+    assert np.max(np.abs(ed - eo)) < max(tol, 1e-6) * 10
+    for v in g.vertices:
+        assert abs(tn.expect(bd, ("Z", [v])) - o.expect_1site(bo, Z, v)) < tol
+    cplx_layer = [("Rx", [v], 0.4) for v in g.vertices] + [("Rzz", [a, b], 0.3) for (a, b) in groups[1]]
+    bd2, ed2 = tn.apply_gates(cplx_layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw)
+    assert tn.scalartype(bd) == np.dtype(real)                      # value semantics: the input cache keeps its type
+    assert tn.scalartype(bd2) == np.dtype(cplx) and bd2.tensor(g.vertices[4]).dtype == np.dtype(cplx)
+    boc = o.BeliefPropagationCache(o.TensorNetworkState(bo.g, {v: bo.tns.tensors[v].astype(cplx) for v in bo.g.vertices}),
+                                   messages={e: m.astype(cplx) for e, m in bo.messages.items()}, edge_sequence=bo.edge_sequence)
+    bo2, eo2 = o.apply_gates(cplx_layer, boc, apply_kwargs=kw, bp_update_kwargs=bpkw)
+    assert np.max(np.abs(ed2 - eo2)) < max(tol, 1e-6) * 10
+    for v in g.vertices:
+        assert abs(tn.expect(bd2, ("Z", [v])) - o.expect_1site(bo2, Z, v)) < tol
