@@ -10,8 +10,8 @@ it on a many-core host, so that `bench.py`'s `cpu_baseline` can adjudicate a GPU
   * the schedule is the reference's (apply_gates.jl:46-98: a BP update before every colour group, a final one; Gauss-Seidel sweeps over
     the cache's edge sequence), executed the way the device engine executes it: the messages of a sweep are grouped into dependency
     levels (a message only waits for the messages it reads that precede it in the sequence -- same values as the sequential loop), the
-    gates of a colour group are vertex-disjoint; the members of a level / group run on a thread pool, one BLAS thread each (numpy
-    releases the GIL inside BLAS / LAPACK and its copy loops).
+    gates of a colour group are vertex-disjoint; the members of a level / group run on a thread pool, with cores / members BLAS threads
+    each (numpy releases the GIL inside BLAS / LAPACK and its copy loops).
 
 `measure()` also measures what the host's BLAS delivers on (a) a large square ComplexF32 GEMM with all threads and (b) the mode-product
 shape of the workload ((2 chi^3) x chi times chi x chi) on the same thread pool, and reports the layer's algorithmic GFLOP/s
@@ -78,6 +78,13 @@ def _message(bpc, fresh: Dict, pos: Dict, t: int, e, normalize=True) -> np.ndarr
     return m.astype(psi.dtype, copy=False)
 
 
+def _blas_threads(ntasks: int, nthreads: int):
+    """BLAS threads per task so that tasks x threads fills the host: a level / colour group with fewer members than cores gives each
+    member several BLAS threads (threadpoolctl's limit is process wide, which is what is wanted: all members of one map get the same)"""
+    from threadpoolctl import threadpool_limits
+    return threadpool_limits(limits=max(1, nthreads // max(1, ntasks)))
+
+
 def update(bpc, pool: ThreadPoolExecutor, maxiter: Optional[int] = None, tolerance: Optional[float] = None, info: Optional[dict] = None):
     """update (abstract...:223-259) with the messages of a dependency level computed concurrently"""
     dk = bpc.default_bp_update_kwargs()
@@ -91,7 +98,8 @@ def update(bpc, pool: ThreadPoolExecutor, maxiter: Optional[int] = None, toleran
         fresh: Dict = {}
         diffs = [0.0] * len(seq)
         for lev in levels:
-            res = list(pool.map(lambda t: _message(bpc, fresh, pos, t, seq[t]), lev))
+            with _blas_threads(len(lev), pool._max_workers):
+                res = list(pool.map(lambda t: _message(bpc, fresh, pos, t, seq[t]), lev))
             for t, m in zip(lev, res):
                 if tolerance is not None:
                     diffs[t] = o.message_diff(m, bpc.message(seq[t]))
@@ -115,7 +123,8 @@ def apply_layer(bpc, one_site: List, colour_groups: List[List], pool: ThreadPool
     def one(gate):
         mat, verts = o.resolve_gate(gate)
         return o.apply_gate(bpc, mat, verts, **apply_kwargs)
-    list(pool.map(one, one_site))
+    with _blas_threads(len(one_site), pool._max_workers):
+        list(pool.map(one, one_site))
     errs = []
     for grp in colour_groups:
         inf = {}
@@ -126,7 +135,8 @@ def apply_layer(bpc, one_site: List, colour_groups: List[List], pool: ThreadPool
         def two(gate, b=bpc):
             mat, verts = o.resolve_gate(gate)
             return o.apply_gate(b, mat, verts, **apply_kwargs)
-        errs += list(pool.map(two, grp))
+        with _blas_threads(len(grp), pool._max_workers):
+            errs += list(pool.map(two, grp))
     inf = {}
     bpc = update(bpc, pool, info=inf, **bp_kwargs)
     sweeps.append(inf["niter"])
@@ -174,7 +184,13 @@ def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int
         shp = (2,) + (chi,) * g.degree(v)
         n = int(np.prod(shp))
         tensors[v] = rng.standard_normal(2 * n, dtype=np.float32).view(np.complex64).reshape(shp) / np.float32(np.sqrt(n))
-    bpc = o.BeliefPropagationCache(o.TensorNetworkState(g, tensors))
+    # edge sequence: per colour, all messages a -> b, then all b -> a.  Any sequence is a valid Gauss-Seidel order (abstract...:204-218); the
+    # reference's default (a DFS post-order over spanning forests) chains almost every message behind another one, this one gives 8 levels of
+    # |E| / 4 independent messages per sweep -- the order a CPU code that wants to use its cores would pick
+    seq = []
+    for grp in groups:
+        seq += [(a, b) for (a, b) in grp] + [(b, a) for (a, b) in grp]
+    bpc = o.BeliefPropagationCache(o.TensorNetworkState(g, tensors), edge_sequence=seq)
     kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
     bpkw = dict(bpc.default_bp_update_kwargs())
     saved = (o._POOL, o._BIG)
@@ -182,14 +198,13 @@ def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int
     try:
         with ThreadPoolExecutor(max_workers=nthreads) as pool:
             rates = _gemm_rates(chi, nthreads, pool)
-            with threadpool_limits(limits=1):
-                bpc = update(bpc, pool, **bpkw)                        # warm-up outside the timing: converged messages
-                t0 = time.perf_counter()
-                sweeps_all = []
-                for _ in range(nlayers):
-                    bpc, errs, sweeps = apply_layer(bpc, one_site, colour_groups, pool, kw, bpkw)
-                    sweeps_all.append(sweeps)
-                dt = (time.perf_counter() - t0) / nlayers
+            bpc = update(bpc, pool, **bpkw)                            # warm-up outside the timing: converged messages
+            t0 = time.perf_counter()
+            sweeps_all = []
+            for _ in range(nlayers):
+                bpc, errs, sweeps = apply_layer(bpc, one_site, colour_groups, pool, kw, bpkw)
+                sweeps_all.append(sweeps)
+            dt = (time.perf_counter() - t0) / nlayers
     finally:
         o._POOL, o._BIG = saved
     n2 = len(g.edges)

@@ -113,13 +113,15 @@ def main():
     # multi-site observables and the symmetric gauge on the sharded handle (every rank takes part in the region's exchanges)
     extra = mode in ("c128", "c64")
     vs = list(g.vertices)
-    regions = [[vs[0], vs[1]], [vs[0], vs[-1]], [vs[len(vs) // 2 - 1], vs[len(vs) // 2]]] if extra else []
+    # regions with a unique Steiner tree: neighbours, and vertices on one lattice line (also across the rank boundary)
+    line = [v for v in vs if v[0] == vs[0][0]] if extra else []
+    regions = [[vs[0], vs[1]], [line[0], line[-1]], [line[0], line[1], line[-1]]] if extra else []
     def multi(b):
         out = []
         for r in regions:
             try:
                 out.append(complex(tn.expect(b, ("Z" * len(r), r))))
-            except ValueError:                      # no unique Steiner tree for this pair: skipped on both sides
+            except (ValueError, tn.TnqsError):      # no unique Steiner tree for this pair: skipped on both sides
                 out.append(complex("nan"))
         return np.array(out)
     zz_sh = multi(bs) if extra else np.zeros(0)
