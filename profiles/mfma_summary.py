@@ -4,8 +4,11 @@
 usage: mfma_summary.py <dir of the pass> <out.json>
 
 Per kernel, over its full-batch launches (GRBM_GUI_ACTIVE above 50 % of the kernel's maximum):
-  mfma_busy      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)   -- the gfx94x `MfmaUtil` formula, which rocprofv3 falls back
-                   to on gfx950 (MI355X_MICROARCH.md, "rocprofv3 PMC slots"); 1.0 = every matrix core issuing back to back for the whole kernel
+  mfma_busy      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs)   -- the gfx94x `MfmaUtil` formula (rocprofv3 falls back to
+                   it on gfx950, MI355X_MICROARCH.md "rocprofv3 PMC slots") with GRBM_GUI_ACTIVE divided by the 8 XCDs: the value rocprofv3
+                   reports is the SUM over the XCDs' GRBMs (checked on mfma_pair_gram2_kernel: 111.9 M "active" for a 6.32 ms launch = 8 x 13.99 M
+                   cycles at 2.21 GHz).  1.0 = every matrix core issuing back to back for the whole kernel.  Cross-check: BUSY_CYCLES equals
+                   8 cycles x MOPS exactly for the f32 32x32x2 kernels, i.e. the 64-cycle issue of an instruction that is 8 MOPS
   mfma_flops     = 512 * (SQ_INSTS_VALU_MFMA_MOPS_F32 + SQ_INSTS_VALU_MFMA_MOPS_F64) per launch (one MOP = 512 flop), to be compared with the
                    algorithmic flops the engine accounts for the kernel's class (bench.py "kernel_classes")
   mfma_tflops    = mfma_flops / kernel duration from the kernel trace of the same pass
@@ -17,7 +20,7 @@ import re
 import sys
 from collections import defaultdict
 
-NCU, NSIMD = 256, 4
+NCU, NSIMD, NXCD = 256, 4, 8
 
 
 def main():
@@ -48,14 +51,14 @@ def main():
         mops = mean("SQ_INSTS_VALU_MFMA_MOPS_F32") + mean("SQ_INSTS_VALU_MFMA_MOPS_F64")
         ns = [dur[k][i] for i in big if i in dur.get(k, {})]
         t = sum(ns) / len(ns) * 1e-9 if ns else None
-        res[k] = {"launches_full_batch": len(big), "mfma_busy": round(busy / (gui * NCU * NSIMD), 4) if gui > 0 else None,
+        res[k] = {"launches_full_batch": len(big), "mfma_busy": round(busy / (gui / NXCD * NCU * NSIMD), 4) if gui > 0 else None,
                   "mfma_flops_per_launch": 512.0 * mops, "mfma_tflops": round(512.0 * mops / t / 1e12, 2) if t else None,
                   "avg_ms": round(t * 1e3, 4) if t else None,
                   "raw_means": {c: mean(c) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32",
                                                      "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")}}
     doc = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 "
                       "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE (one pass; profiles/collect_mfma.sh)",
-           "formulas": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 * 4); mfma_flops = 512 * MOPS; full-batch launches only",
+           "formulas": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 * 4); mfma_flops = 512 * MOPS; full-batch launches only",
            "kernels": res}
     json.dump(doc, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -(kv[1]["mfma_flops_per_launch"] or 0))[:14]:

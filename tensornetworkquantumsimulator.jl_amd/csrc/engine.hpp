@@ -1,5 +1,7 @@
 // engine.hpp -- host-side engine behind the C ABI: state container (TensorNetworkState + BeliefPropagationCache),
-// BP update driver, apply_gates scheduler, truncate, parity probes.  Mirrors (paths relative to the reference):
+// BP update driver, apply_gates scheduler, truncate, parity probes (implemented in engine_*.cpp, see engine_internal.hpp).
+// Threading: a handle AND ALL ITS COPIES (tnqs_copy shares the buffer pool, the profiler and the graph's cached BP plan) must be used
+// from one thread at a time; different handle families are independent.  Mirrors (paths relative to the reference):
 //   src/MessagePassing/beliefpropagationcache.jl:9-15   struct BeliefPropagationCache {network, messages, edge_sequence}
 //   src/TensorNetworks/tensornetworkstate.jl:12-15       TensorNetworkState
 //   src/Apply/apply_gates.jl:46-143                      apply_gates / apply_gate!
@@ -78,6 +80,10 @@ struct RcclComm {
     ~RcclComm();
 };
 
+struct HostArena {   // pinned staging for descriptor uploads, reset at host sync points
+    char* base = nullptr; size_t cap = 0, off = 0;
+};
+
 struct State {
     std::shared_ptr<Graph> g;
     int dtype = TNQS_C64;          // STORAGE / arithmetic type: TNQS_C64 or TNQS_C128 (real element types are stored as complex numbers
@@ -103,6 +109,7 @@ struct State {
     // profiling (shared by copies of a handle, so a loop `bpc = apply_gates(layer, bpc)` accumulates)
     std::shared_ptr<Prof> prof;
     std::vector<Buf> keepalive;    // descriptor buffers kept until the next host sync
+    HostArena arena;               // this handle's pinned staging arena (taken from / returned to a small free list, engine_core.cpp)
     tnqs_apply_stats stats{};
 
     size_t esz() const { return dtype == TNQS_C64 ? 8 : 16; }

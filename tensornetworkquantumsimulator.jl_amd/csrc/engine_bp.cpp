@@ -1,0 +1,542 @@
+// engine_bp.cpp -- BP update (abstractbeliefpropagationcache.jl:223-259): default sweep order, level schedule, message launches.
+#include "engine_internal.hpp"
+
+namespace tnqs {
+
+// can the last absorption of a BP message be fused into the Gram?  (c64, d = 2, the first row leg r has chi_r = 32,
+// kept leg <= 32, tiles of 64 fibers = (s, i_r) aligned)
+static int fused_leg(const State* s, const SD& sd, int jo) {
+    if (s->dtype != TNQS_C64 || !use_mfma() || sd.d != 2 || sd.z < 2) return -1;
+    const char* e = std::getenv("TNQS_NO_FUSED_GRAM"); if (e && e[0] == '1') return -1;
+    int r = (jo == 0) ? 1 : 0;
+    if (sd.chi[r] != 32 || sd.chi[jo] > 32 || sd.chi[jo] < 8) return -1;
+    return r;
+}
+// ---------------------------------------------------------------------------------------------------------------
+// BP update  (abstractbeliefpropagationcache.jl:223-259; Gauss-Seidel over edge_sequence, executed level by level)
+// ---------------------------------------------------------------------------------------------------------------
+struct BPPlan {
+    std::vector<int> seq;                       // directed edge ids in sequence order
+    std::vector<std::vector<int>> levels;       // positions in seq grouped by dependency level
+    std::vector<int> pos_of;                    // de -> position in seq or -1
+    std::vector<int> level_of;                  // position -> level
+    bool in_place = false;                      // duplicates in the sequence: strictly sequential, single buffer
+};
+
+// Default sweep order (the reference's default is NamedGraphs' forest-cover sequence, not available here; any sequence gives the
+// same fixed point, abstractbeliefpropagationcache.jl:204-218).  The edges are decomposed into LINEAR FORESTS (disjoint simple paths);
+// inside a forest the messages are ordered so that every message is computed from the OLD values of the other messages of the same
+// forest: along a path v0..vk the hops v_i -> v_{i+1} are listed last hop first, the hops v_{i+1} -> v_i first hop first (a message
+// u -> w depends on the message entering u through its other path edge, which therefore must come LATER in the sequence).  Level
+// scheduling then puts a whole forest into one level: 2 levels per sweep on a square lattice (rows, columns), and both outgoing
+// messages of a site inside a forest share one pair product.  It is an ordinary sequential Gauss-Seidel order.
+struct DSU { std::vector<int> p; explicit DSU(int n) : p(n) { std::iota(p.begin(), p.end(), 0); } int f(int x) { while (p[x] != x) x = p[x] = p[p[x]]; return x; }
+             bool join(int a, int b) { a = f(a); b = f(b); if (a == b) return false; p[a] = b; return true; } };
+// Forests: the reference's own default order (NamedGraphs forest_cover_edge_sequence: per component, post-order DFS edges towards the
+// root, then their reverses in reverse order).  With it ONE sweep is exact on a tree -- which is what the reference's tree defaults
+// (maxiter = 1, no tolerance; beliefpropagationcache.jl:39,110-113) rely on.  The linear-forest order below lists every message BEFORE
+// the one it depends on (so that a forest is one level), i.e. information moves one hop per sweep: right for loopy graphs, where the
+// fixed point is iterated anyway, wrong for the single sweep of a tree.
+static std::vector<int> tree_sequence(const Graph& g) {
+    std::vector<int> seq; std::vector<char> seen(g.nv, 0);
+    for (int root = 0; root < g.nv; ++root) {
+        if (seen[root] || g.nbr[root].empty()) continue;
+        std::vector<std::pair<int, int>> post;                          // (child, parent)
+        std::vector<std::pair<int, size_t>> stack{{root, 0}}; std::vector<int> par(1, -1);
+        seen[root] = 1;
+        while (!stack.empty()) {
+            auto& top = stack.back(); const int x = top.first;
+            bool pushed = false;
+            while (top.second < g.nbr[x].size()) {
+                const int y = g.nbr[x][top.second++];
+                if (seen[y]) continue;
+                seen[y] = 1; stack.push_back({y, 0}); par.push_back(x); pushed = true; break;
+            }
+            if (pushed) continue;
+            if (par.back() >= 0) post.push_back({x, par.back()});
+            stack.pop_back(); par.pop_back();
+        }
+        for (auto& e : post) seq.push_back(g.dedge(e.first, e.second));
+        for (auto it = post.rbegin(); it != post.rend(); ++it) seq.push_back(g.dedge(it->second, it->first));
+    }
+    return seq;
+}
+static std::vector<int> default_sequence(const Graph& g) {
+    if (g.is_tree) {
+        std::vector<int> seq = tree_sequence(g);
+        if ((int)seq.size() != 2 * g.ne) throw Err(TNQS_ERR_HIP, "internal: tree sequence does not cover every message");
+        return seq;
+    }
+    std::vector<int> forest(g.ne, -1);
+    int nf = 0;
+    // 1. unions of two colour classes that contain no cycle are linear forests (straight lines on lattices): pair the colours up
+    std::vector<std::vector<char>> ok(g.ncolors, std::vector<char>(g.ncolors, 0));
+    for (int a = 0; a < g.ncolors; ++a) for (int b = a + 1; b < g.ncolors; ++b) {
+        DSU d(g.nv); bool acyclic = true;
+        for (int e = 0; e < g.ne && acyclic; ++e) if (g.ecolor[e] == a || g.ecolor[e] == b) acyclic = d.join(g.esrc[e], g.edst[e]);
+        ok[a][b] = ok[b][a] = acyclic ? 1 : 0;
+    }
+    std::vector<int> mate(g.ncolors, -1), best;
+    int best_pairs = -1;
+    std::function<void(int, int)> rec = [&](int c, int pairs) {          // maximum matching of the colours (few colours: brute force)
+        while (c < g.ncolors && mate[c] >= 0) ++c;
+        if (c >= g.ncolors) { if (pairs > best_pairs) { best_pairs = pairs; best = mate; } return; }
+        mate[c] = c; rec(c + 1, pairs); mate[c] = -1;                     // leave c single
+        for (int b = c + 1; b < g.ncolors; ++b) if (mate[b] < 0 && ok[c][b]) { mate[c] = b; mate[b] = c; rec(c + 1, pairs + 1); mate[c] = mate[b] = -1; }
+    };
+    if (g.ncolors <= 10) rec(0, 0);
+    // 2. greedy linear forests: an edge joins the first forest where both ends still have degree < 2 and no cycle closes
+    std::vector<int> gforest(g.ne, -1); int gnf = 0;
+    {
+        std::vector<std::vector<int>> deg; std::vector<DSU> comp;
+        for (int e = 0; e < g.ne; ++e) {
+            int a = g.esrc[e], b = g.edst[e], f = 0;
+            for (;; ++f) {
+                if (f == gnf) { deg.emplace_back(g.nv, 0); comp.emplace_back(g.nv); ++gnf; }
+                if (deg[f][a] < 2 && deg[f][b] < 2 && comp[f].f(a) != comp[f].f(b)) break;
+            }
+            comp[f].join(a, b); ++deg[f][a]; ++deg[f][b]; gforest[e] = f;
+        }
+    }
+    // the decomposition with fewer forests (= fewer levels per sweep) wins; ties go to the colour pairs (straight lines on lattices)
+    if (best_pairs > 0 && g.ncolors - best_pairs <= gnf) {
+        std::vector<int> fof(g.ncolors, -1);
+        for (int c = 0; c < g.ncolors; ++c) if (fof[c] < 0) { fof[c] = nf; if (best[c] != c && best[c] >= 0) fof[best[c]] = nf; ++nf; }
+        for (int e = 0; e < g.ne; ++e) forest[e] = fof[g.ecolor[e]];
+    } else { forest = gforest; nf = gnf; }
+    std::vector<int> seq;
+    for (int f = 0; f < nf; ++f) {
+        std::vector<std::vector<int>> adj(g.nv);
+        for (int e = 0; e < g.ne; ++e) if (forest[e] == f) { adj[g.esrc[e]].push_back(g.edst[e]); adj[g.edst[e]].push_back(g.esrc[e]); }
+        std::vector<char> seen(g.nv, 0);
+        for (int v = 0; v < g.nv; ++v) {
+            if (adj[v].size() != 1 || seen[v]) continue;                   // start at a path end
+            std::vector<int> path{v}; seen[v] = 1; int prev = -1, cur = v;
+            for (;;) { int nxt = -1; for (int w : adj[cur]) if (w != prev) nxt = w; if (nxt < 0) break; prev = cur; cur = nxt; path.push_back(cur); seen[cur] = 1; }
+            const int k = (int)path.size() - 1;
+            for (int i = k - 1; i >= 0; --i) seq.push_back(g.dedge(path[i], path[i + 1]));
+            for (int i = 0; i < k; ++i) seq.push_back(g.dedge(path[i + 1], path[i]));
+        }
+    }
+    if ((int)seq.size() != 2 * g.ne) throw Err(TNQS_ERR_HIP, "internal: default sequence does not cover every message");
+    return seq;
+}
+
+// the default order as (src, dst) vertex pairs, for tests that replay it on the oracle (include/tnqs_debug.h)
+void dbg_default_sequence(const State* s, std::vector<int>& src, std::vector<int>& dst) {
+    const Graph& g = *s->g;
+    if (g.default_seq.empty() && g.ne > 0) g.default_seq = default_sequence(g);
+    for (int de : g.default_seq) { const int e = de / 2; src.push_back((de & 1) ? g.edst[e] : g.esrc[e]); dst.push_back((de & 1) ? g.esrc[e] : g.edst[e]); }
+}
+
+static BPPlan make_plan(const State* s, const tnqs_bp_opts* o) {
+    const Graph& g = *s->g;
+    BPPlan p;
+    if (o && o->n_sequence > 0) {
+        for (int i = 0; i < o->n_sequence; ++i) {
+            int de = g.dedge(o->seq_src[i], o->seq_dst[i]);
+            if (de < 0) throw Err(TNQS_ERR_INVALID, "bp_update: edge_sequence contains a pair of non-adjacent vertices");
+            p.seq.push_back(de);
+        }
+    } else { if (g.default_seq.empty() && g.ne > 0) g.default_seq = default_sequence(g); p.seq = g.default_seq; }
+    p.pos_of.assign(2 * (size_t)g.ne, -1);
+    for (size_t t = 0; t < p.seq.size(); ++t) { if (p.pos_of[p.seq[t]] >= 0) p.in_place = true; p.pos_of[p.seq[t]] = (int)t; }
+    if (p.in_place) { for (size_t t = 0; t < p.seq.size(); ++t) { p.levels.push_back({(int)t}); p.level_of.push_back((int)t); } return p; }
+    std::vector<int> level(p.seq.size(), 0); int nlev = 0;
+    for (size_t t = 0; t < p.seq.size(); ++t) {
+        int de = p.seq[t]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
+        int lv = 0;
+        for (size_t j = 0; j < g.nbr[src].size(); ++j) {
+            int k = g.nbr[src][j]; if (k == dst) continue;
+            int din = g.dedge(k, src); int pp = p.pos_of[din];
+            if (pp >= 0 && pp < (int)t) lv = std::max(lv, level[pp] + 1);
+        }
+        level[t] = lv; nlev = std::max(nlev, lv + 1);
+    }
+    p.levels.resize(nlev);
+    for (size_t t = 0; t < p.seq.size(); ++t) p.levels[level[t]].push_back((int)t);
+    // the messages of a level are independent of each other: list them by source vertex, so that a workspace-bounded sub-batch (bp_update_t)
+    // holds all messages of the sites it touches (they share the pair product and the double pair-Gram pass)
+    auto src_of = [&](int t) { int de = p.seq[t]; int e = de / 2; return (de & 1) ? g.edst[e] : g.esrc[e]; };
+    for (auto& lev : p.levels) std::stable_sort(lev.begin(), lev.end(), [&](int a, int b) { return src_of(a) < src_of(b); });
+    p.level_of = level;
+    return p;
+}
+
+static double default_tol(const State* s) { return s->dtype == TNQS_C64 ? 1e-5 : 1e-8; }   // beliefpropagationcache.jl:104-108
+
+// ---- shared pair products ---------------------------------------------------------------------------------------
+// A degree-4 site sends four messages per sweep, each needing the other three incoming messages absorbed.  Its legs are
+// split into two pairs {A, B} by the level at which their outgoing message is computed; for an outgoing leg in A the pair
+// product T_B = psi x m_b1 x m_b2 is shared with the other leg of A (the messages entering through B do not change between
+// the two levels of A in the level-scheduled sequences), so a sweep costs 2 pair products + 4 (absorb + Gram) passes instead of
+// 4 + 4.  Validity is not assumed but checked: an entry is reused only while the very same site / message buffers are current.
+struct SharedT { Buf site, ma, mb, T; int la = -1, lb = -1; };
+
+template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out) {
+    const Graph& g = *s->g;
+    HIPCHK(hipSetDevice(s->device));
+    // the level schedule depends on the graph and the sequence only: the one of the default sequence is kept with the graph
+    std::shared_ptr<const BPPlan> plan_p;
+    if (o && o->n_sequence > 0) plan_p = std::make_shared<const BPPlan>(make_plan(s, o));
+    else {
+        if (!g.default_plan) g.default_plan = std::make_shared<const BPPlan>(make_plan(s, o));
+        plan_p = std::static_pointer_cast<const BPPlan>(g.default_plan);
+    }
+    const BPPlan& plan = *plan_p;
+    int maxiter = (o && o->maxiter > 0) ? o->maxiter : (g.is_tree ? 1 : 25);                  // :39,:103
+    double tol;
+    if (!o || std::isnan(o->tolerance)) tol = g.is_tree ? -1.0 : default_tol(s); else tol = o->tolerance;
+    const bool compute_error = tol >= 0;
+    const int normalize = o ? o->normalize : 1;
+    if (!normalize) materialize_scale_all(s);      // un-normalised messages carry the absolute scale of the site tensors
+    const size_t esz = s->esz();
+    const size_t nseq = plan.seq.size();
+    if (nseq == 0) { if (niter_out) *niter_out = 0; if (diff_out) *diff_out = 0; return; }
+    Buf d_diffs = dalloc(s, nseq * sizeof(double));
+    Buf d_sum = dalloc(s, sizeof(double));
+    std::vector<Buf> cur = s->msg;
+    int niter = maxiter; double avg = 0; bool converged = false;
+    // shared pair products (see SharedT): partner[v][j] = the leg paired with j, -1 when the site is not covered
+    std::vector<std::array<int, 4>> partner(g.nv, std::array<int, 4>{{-1, -1, -1, -1}});
+    std::vector<std::array<SharedT, 2>> tshare;
+    if (std::is_same<T, float>::value && use_mfma() && use_pair() && use_tshare()) {
+        tshare.resize(g.nv);
+        for (int v = 0; v < g.nv; ++v) {
+            if (!s->owns(v) || g.nbr[v].size() != 4 || s->d[v] != 2) continue;
+            bool ok = true; std::array<std::pair<int, int>, 4> ord;
+            for (int j = 0; j < 4; ++j) {
+                if (s->chi[g.nbr_e[v][j]] != 32) ok = false;
+                int pp = plan.pos_of[g.dedge(v, g.nbr[v][j])];
+                ord[j] = {pp >= 0 ? plan.level_of[pp] : INT_MAX, j};
+            }
+            if (!ok) continue;
+            std::sort(ord.begin(), ord.end());
+            partner[v][ord[0].second] = ord[1].second; partner[v][ord[1].second] = ord[0].second;
+            partner[v][ord[2].second] = ord[3].second; partner[v][ord[3].second] = ord[2].second;
+        }
+    }
+    for (int iter = 1; iter <= maxiter; ++iter) {
+        std::vector<Buf> fresh(2 * (size_t)g.ne);
+        for (auto& lev : plan.levels) {
+            // sub-batches bounded by workspace bytes
+            size_t start = 0;
+            while (start < lev.size()) {
+                HostTimer ht_prep(0);
+                size_t budget = bp_ws_budget(), used = 0, end = start;
+                while (end < lev.size()) {
+                    int de = plan.seq[lev[end]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
+                    size_t need = 2 * site_dims(s, src).n * esz;
+                    if (end > start && used + need > budget) break;
+                    used += need; ++end;
+                }
+                std::vector<Chain> chains; std::vector<int> tpos; std::vector<const void*> fmsg;
+                std::vector<PairItem> sh_pair; std::vector<PairGramItem> sh_gram; std::vector<int> sh_chain;   // shared-T path
+                std::vector<int> is_shared_chain;
+                std::vector<PairGram2Item> sh_dbl; std::vector<std::pair<int, int>> sh_dbl_chain;              // both messages of a forest in one pass
+                struct Pend { int idx, jo, r; };                                                                // first message of a (site, T) seen in this level
+                std::unordered_map<long long, Pend> pend;
+                double sh_pair_slices = 0, sh_gram_slices = 0, sh_dbl_slices = 0;
+                // ---- shared partial products for the sites the plane kernels do not cover (any degree, any bond dimension): a site that sends
+                // several messages in this level absorbs the messages on its OTHER legs once (T = psi x_{legs not going out here} m) and every
+                // outgoing message continues from T.  With the default linear-forest order a site sends two messages per level, so a degree-6
+                // site does 4 + 2 x 1 absorption passes per level instead of 2 x 5.  Reuse is decided by buffer identity per message (the
+                // Gauss-Seidel rule may give two messages of a site different versions of an incoming message), never assumed.
+                struct Prefix { Buf site; std::vector<std::pair<int, const void*>> legs; Buf prod; };
+                std::unordered_map<int, Prefix> prefix;
+                auto select_in = [&](int src, int j, int t) -> const Buf& {
+                    int din = g.dedge(g.nbr[src][j], src); int pp = plan.pos_of[din];
+                    return (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
+                };
+                if (use_prefix() && !plan.in_place) {
+                    std::unordered_map<int, std::vector<int>> outl;            // source site -> legs going out in this sub-batch
+                    auto generic_site = [&](int src, int jo) { return tshare.empty() || site_dims(s, src).z != 4 || partner[src][jo] < 0; };
+                    for (size_t q = start; q < end; ++q) {
+                        int de = plan.seq[lev[q]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
+                        if (s->owns(src) && generic_site(src, g.leg(src, dst))) outl[src].push_back(g.leg(src, dst));
+                    }
+                    std::vector<Chain> pch; std::vector<int> psrc;
+                    for (size_t q = start; q < end; ++q) {
+                        int t = lev[q]; int de = plan.seq[t]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
+                        auto ol = outl.find(src);
+                        if (ol == outl.end() || ol->second.size() < 2 || prefix.count(src)) continue;
+                        Chain cp; cp.v = src; cp.src = s->site[src]->p; cp.sd = site_dims(s, src);
+                        Prefix pf; pf.site = s->site[src];
+                        for (int j = 0; j < cp.sd.z; ++j) {
+                            if (std::find(ol->second.begin(), ol->second.end(), j) != ol->second.end()) continue;
+                            const Buf& mb = select_in(src, j, t);
+                            if (!mb) continue;
+                            cp.steps.push_back({j, mb->p}); pf.legs.push_back({j, mb->p});
+                        }
+                        if (pf.legs.empty()) continue;
+                        prefix[src] = pf; pch.push_back(std::move(cp)); psrc.push_back(src);
+                    }
+                    if (!pch.empty()) {
+                        run_chains<T>(s, pch, TNQS_PROF_BP_MODEPROD, TNQS_PROF_BP_PAIR);
+                        for (size_t i = 0; i < pch.size(); ++i) {
+                            Prefix& pf = prefix[psrc[i]];
+                            for (int k = 0; k < 2; ++k) if (pch[i].tmp[k] && pch[i].tmp[k]->p == pch[i].result) pf.prod = pch[i].tmp[k];
+                        }
+                    }
+                }
+                for (size_t q = start; q < end; ++q) {
+                    int t = lev[q]; int de = plan.seq[t]; int e = de / 2;
+                    int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
+                    if (!s->owns(src)) continue;
+                    Chain c; c.v = src; c.src = s->site[src]->p; c.sd = site_dims(s, src);
+                    const int jo = g.leg(src, dst);
+                    if (!tshare.empty() && c.sd.z == 4 && partner[src][jo] >= 0) {
+                        const int r = partner[src][jo];
+                        int pa = -1, pb = -1;
+                        for (int j = 0; j < 4; ++j) if (j != jo && j != r) { if (pa < 0) pa = j; else pb = j; }
+                        auto incoming = [&](int j) -> const Buf& {
+                            int din = g.dedge(g.nbr[src][j], src); int pp = plan.pos_of[din];
+                            return (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
+                        };
+                        const Buf& ma = incoming(pa); const Buf& mb = incoming(pb); const Buf& mr = incoming(r);
+                        PairGramItem gi{}; PairItem pi{};
+                        if (ma && mb && mr && pair_geometry(c.sd.d, c.sd.z, c.sd.chi.data(), pa, pb, pi.g)
+                            && pair_geometry(c.sd.d, c.sd.z, c.sd.chi.data(), r, jo, gi.g)) {
+                            SharedT& sh = tshare[src][std::min(pa, pb) < std::min(r, jo) ? 0 : 1];      // slot of the pair {pa, pb}
+                            if (!(sh.T && sh.site == s->site[src] && sh.ma == ma && sh.mb == mb && sh.la == pa && sh.lb == pb)) {
+                                sh.site = s->site[src]; sh.ma = ma; sh.mb = mb; sh.la = pa; sh.lb = pb;
+                                sh.T = dalloc(s, c.sd.n * esz);
+                                pi.in = c.src; pi.out = sh.T->p; pi.Mx = ma->p; pi.My = mb->p;
+                                sh_pair.push_back(pi); sh_pair_slices += (double)c.sd.n / 16384.0;
+                            }
+                            gi.X = sh.T->p; gi.Y = c.src; gi.M = mr->p;
+                            const long long key = ((long long)src << 1) | (std::min(pa, pb) < std::min(r, jo) ? 0 : 1);
+                            auto pit = use_dbl() ? pend.find(key) : pend.end();
+                            if (pit != pend.end() && pit->second.jo == r && pit->second.r == jo && sh_gram[pit->second.idx].X == gi.X) {
+                                // the partner message of the same forest is in this level too: one pass computes both
+                                PairGramItem& first = sh_gram[pit->second.idx];       // plane (lx = r_first = jo, ly = jo_first = r)
+                                PairGram2Item d2{}; d2.X = first.X; d2.Y = first.Y; d2.Mx = first.M; d2.My = gi.M; d2.g = first.g;
+                                sh_dbl.push_back(d2); sh_dbl_chain.push_back({sh_chain[pit->second.idx], (int)chains.size()});
+                                sh_dbl_slices += (double)c.sd.n / 8192.0;
+                                first.X = nullptr;                                     // retired from the single list
+                                sh_gram_slices -= (double)c.sd.n / 16384.0;
+                                pend.erase(pit);
+                            } else {
+                                if (use_dbl()) pend[key] = Pend{(int)sh_gram.size(), jo, r};
+                                sh_gram.push_back(gi); sh_gram_slices += (double)c.sd.n / 16384.0;
+                                sh_chain.push_back((int)chains.size());
+                            }
+                            is_shared_chain.push_back((int)chains.size());
+                            chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(nullptr);
+                            continue;
+                        }
+                    }
+                    const int fr = fused_leg(s, c.sd, jo);
+                    const void* fm = nullptr;
+                    std::vector<char> done(c.sd.z, 0);                   // legs already absorbed in the shared partial product
+                    {
+                        auto pf = prefix.find(src);
+                        if (pf != prefix.end() && pf->second.prod && pf->second.site == s->site[src]) {
+                            bool same = true;
+                            for (auto& lm : pf->second.legs) { if (lm.first == jo) { same = false; break; } const Buf& mb = select_in(src, lm.first, t); if (!mb || mb->p != lm.second) { same = false; break; } }
+                            if (same) { c.y = c.src; c.src = pf->second.prod->p; for (auto& lm : pf->second.legs) done[lm.first] = 1; }
+                        }
+                    }
+                    for (int j = 0; j < c.sd.z; ++j) {
+                        int k = g.nbr[src][j]; if (k == dst || done[j]) continue;
+                        int din = g.dedge(k, src); int pp = plan.pos_of[din];
+                        const Buf& mb = (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
+                        if (!mb) continue;                               // unset message = identity: nothing to absorb
+                        if (j == fr) fm = mb->p;                         // absorbed inside the Gram kernel
+                        else c.steps.push_back({j, mb->p});
+                    }
+                    chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(fm);
+                }
+                // ---- 16-dimensional planes: the two messages a site sends in this level, both continuing from the same shared product and
+                // each absorbing exactly the other's outgoing leg, come from ONE pass over (T, psi) (mfma_pair_gram2x16_kernel) ------------
+                std::vector<PairGram2x16Item> g16; std::vector<std::pair<int, int>> g16_chain;       // (chain of the message through ly, through lx)
+                if (std::is_same<T, float>::value && use_mfma() && use_pair() && use_dbl()) {
+                    std::unordered_map<int, std::vector<int>> by_src;
+                    for (size_t ci = 0; ci < chains.size(); ++ci)
+                        if (chains[ci].y && chains[ci].steps.size() == 1 && !fmsg[ci] && chains[ci].sd.n >= (size_t)(1u << 14)) by_src[chains[ci].v].push_back((int)ci);
+                    for (auto& kv : by_src) {
+                        if (kv.second.size() != 2) continue;
+                        const int ci = kv.second[0], cj = kv.second[1];
+                        Chain& a = chains[ci]; Chain& b = chains[cj];
+                        auto out_leg = [&](int c) { int de = plan.seq[tpos[c]]; int e = de / 2; int dst = (de & 1) ? g.esrc[e] : g.edst[e]; return g.leg(chains[c].v, dst); };
+                        const int ly = out_leg(ci), lx = out_leg(cj);
+                        if (a.src != b.src || a.y != b.y || a.steps[0].first != lx || b.steps[0].first != ly) continue;
+                        PairGram2x16Item it{};
+                        if (!plane_geometry(a.sd.d, a.sd.z, a.sd.chi.data(), lx, ly, 16, it.g)) continue;
+                        it.X = a.src; it.Y = a.y; it.Mx = a.steps[0].second; it.My = b.steps[0].second;
+                        g16.push_back(it); g16_chain.push_back({ci, cj});
+                        a.steps.clear(); b.steps.clear();
+                        is_shared_chain.push_back(ci); is_shared_chain.push_back(cj);
+                    }
+                }
+                ht_prep.stop();
+                std::vector<char> is_shared(chains.size(), 0);
+                for (int ci : is_shared_chain) is_shared[ci] = 1;
+                HostTimer ht_launch(1);
+                if (!sh_pair.empty()) {
+                    int spw = (int)std::max(1.0, std::min(8.0, sh_pair_slices / 2048.0)); int wgs = 0;
+                    for (auto& it : sh_pair) { it.spw = spw; it.slice_begin = wgs; wgs += (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw; }
+                    const PairItem* d = upload(s, sh_pair);
+                    ProfScope ps(s, TNQS_PROF_BP_PAIR, 2.0 * sh_pair_slices * 16384.0 * esz, 2 * 8.0 * sh_pair_slices * 16384.0 * 32);
+                    launch_mfma_pair(s->stream, d, (int)sh_pair.size(), wgs);
+                }
+                run_chains<T>(s, chains, TNQS_PROF_BP_MODEPROD, TNQS_PROF_BP_PAIR);
+                std::vector<GramJob> jobs;
+                for (size_t i = 0; i < chains.size(); ++i) {
+                    int de = plan.seq[tpos[i]]; int e = de / 2; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
+                    GramJob j{}; j.X = chains[i].result; j.Y = chains[i].y ? chains[i].y : chains[i].src; j.sd = chains[i].sd; j.leg = g.leg(chains[i].v, dst); j.keep_site = false;
+                    j.M = fmsg[i];
+                    jobs.push_back(j);
+                }
+                if (!sh_dbl.empty()) {
+                    // full slices per workgroup pair: the largest power of two that still gives >= 4 workgroups per CU; an item gets groups
+                    // of 16 workgroups (8 pairs), so powers of two avoid idle workgroups for the usual 2^k slices per site
+                    int spw = 16, wgs = 0;
+                    for (; spw > 1; spw >>= 1) {
+                        long tot = 0;
+                        for (auto& it : sh_dbl) { int np = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw; tot += 16 * ((np + 7) / 8); }
+                        if (tot >= 1024) break;
+                    }
+                    for (size_t q = 0; q < sh_dbl.size(); ++q) {
+                        PairGram2Item& it = sh_dbl[q]; GramJob& jy = jobs[sh_dbl_chain[q].first]; GramJob& jx = jobs[sh_dbl_chain[q].second];
+                        const int npairs = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw;     // workgroup pairs (one per half), in groups of 8 pairs
+                        const int nwg = 16 * ((npairs + 7) / 8);
+                        it.spw = spw; it.wg_begin = wgs; wgs += nwg;
+                        jy.nchunks = jx.nchunks = nwg; jy.KK = jx.KK = 32;             // one partial per workgroup
+                        jy.partial = dalloc(s, (size_t)jy.nchunks * 1024 * esz); jx.partial = dalloc(s, (size_t)jx.nchunks * 1024 * esz);
+                        it.partial_y = jy.partial->p; it.partial_x = jx.partial->p;
+                    }
+                    const PairGram2Item* d = upload(s, sh_dbl);
+                    ProfScope ps(s, TNQS_PROF_BP_PAIRGRAM, 2.0 * sh_dbl_slices * 8192.0 * esz, 4 * 8.0 * sh_dbl_slices * 8192.0 * 32);
+                    launch_mfma_pair_gram2(s->stream, d, (int)sh_dbl.size(), wgs);
+                }
+                if (!g16.empty()) {
+                    double tot = 0; for (auto& it : g16) tot += it.g.nslices();
+                    int spw = 2; while (spw < 128 && tot / (2 * spw) >= 2048.0) spw *= 2;       // a multiple of 2: 4 waves = 2 slices x 2 halves
+                    int wgs = 0; double by = 0, fl = 0;
+                    for (size_t q = 0; q < g16.size(); ++q) {
+                        PairGram2x16Item& it = g16[q]; GramJob& jy = jobs[g16_chain[q].first]; GramJob& jx = jobs[g16_chain[q].second];
+                        const int nwg = (it.g.nslices() + spw - 1) / spw;
+                        it.spw = spw; it.wg_begin = wgs; wgs += nwg;
+                        jy.nchunks = jx.nchunks = nwg; jy.KK = jx.KK = 16;
+                        jy.partial = dalloc(s, (size_t)nwg * 256 * esz); jx.partial = dalloc(s, (size_t)nwg * 256 * esz);
+                        it.partial_y = jy.partial->p; it.partial_x = jx.partial->p;
+                        by += 2.0 * jy.sd.n * esz; fl += 4 * 8.0 * jy.sd.n * 16;
+                    }
+                    const PairGram2x16Item* d = upload(s, g16);
+                    ProfScope ps(s, TNQS_PROF_BP_PAIRGRAM, by, fl);
+                    launch_mfma_pair_gram2x16(s->stream, d, (int)g16.size(), wgs);
+                }
+                {   // singles: drop the entries that were merged into a double item
+                    std::vector<PairGramItem> keep; std::vector<int> keepc;
+                    for (size_t q = 0; q < sh_gram.size(); ++q) if (sh_gram[q].X) { keep.push_back(sh_gram[q]); keepc.push_back(sh_chain[q]); }
+                    sh_gram.swap(keep); sh_chain.swap(keepc);
+                }
+                if (!sh_gram.empty()) {
+                    int spw = (int)std::max(4.0, std::min(16.0, sh_gram_slices / 2048.0)); int wgs = 0;
+                    for (size_t q = 0; q < sh_gram.size(); ++q) {
+                        PairGramItem& it = sh_gram[q]; GramJob& j = jobs[sh_chain[q]];
+                        int nwg = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw;
+                        it.spw = spw; it.wg_begin = wgs; wgs += nwg;
+                        j.nchunks = nwg; j.KK = 32; j.partial = dalloc(s, (size_t)j.nchunks * 1024 * esz);
+                        it.partial = j.partial->p;
+                    }
+                    const PairGramItem* d = upload(s, sh_gram);
+                    ProfScope ps(s, TNQS_PROF_BP_PAIRGRAM, 2.0 * sh_gram_slices * 16384.0 * esz, 2 * 8.0 * sh_gram_slices * 16384.0 * 32);
+                    launch_mfma_pair_gram(s->stream, d, (int)sh_gram.size(), wgs);
+                }
+                {   // the fused and the plain Gram are different kernels: run them as two batches, keep the job order
+                    std::vector<GramJob> jf, jp; std::vector<size_t> idf, idp;
+                    for (size_t i = 0; i < jobs.size(); ++i) { if (is_shared[i]) continue; if (jobs[i].M) { jf.push_back(jobs[i]); idf.push_back(i); } else { jp.push_back(jobs[i]); idp.push_back(i); } }
+                    run_grams<T, T>(s, jf, TNQS_PROF_BP_FUSED);
+                    run_grams<T, T>(s, jp, TNQS_PROF_BP_GRAM);
+                    for (size_t q = 0; q < jf.size(); ++q) jobs[idf[q]] = jf[q];
+                    for (size_t q = 0; q < jp.size(); ++q) jobs[idp[q]] = jp[q];
+                }
+                ht_launch.stop();
+                HostTimer ht_fin(2);
+                std::vector<MsgFinalItem> fin;
+                if (s->nranks <= 1) {
+                    for (size_t i = 0; i < jobs.size(); ++i) {
+                        int t = tpos[i]; int de = plan.seq[t]; int c = s->chi[de / 2];
+                        Buf nb = dalloc(s, (size_t)c * c * esz);
+                        MsgFinalItem f{}; f.partial = jobs[i].partial->p; f.nchunks = jobs[i].nchunks; f.chi = c;
+                        const Buf& oldb = plan.in_place && fresh[de] ? fresh[de] : cur[de];
+                        f.old_msg = oldb ? oldb->p : nullptr; f.new_msg = nb->p;
+                        f.diff_out = reinterpret_cast<double*>(d_diffs->p) + t; f.normalize = normalize;
+                        fin.push_back(f);
+                        fresh[de] = nb;
+                    }
+                } else {
+                    // sharded: owners reduce their raw messages into the exchange buffer, all-gather, then EVERY rank
+                    // normalises / diffs every message of the sub-batch (messages are replicated)
+                    std::vector<size_t> slot(end - start, 0); std::vector<size_t> rank_bytes(s->nranks, 0);
+                    for (size_t q = start; q < end; ++q) {
+                        int de = plan.seq[lev[q]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
+                        int r = s->owner[src]; slot[q - start] = rank_bytes[r];
+                        rank_bytes[r] += round256((size_t)s->chi[e] * s->chi[e] * esz);
+                    }
+                    size_t stride = 0; for (size_t b : rank_bytes) stride = std::max(stride, b);
+                    check_exchange(s, stride);
+                    char* base = reinterpret_cast<char*>(s->exch);
+                    std::vector<ReduceItem> ri; int elems = 0; size_t oi = 0;
+                    for (size_t q = start; q < end; ++q) {
+                        int de = plan.seq[lev[q]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
+                        if (!s->owns(src)) continue;
+                        int n2 = s->chi[e] * s->chi[e];
+                        ri.push_back(ReduceItem{jobs[oi].partial->p, base + (size_t)s->rank * stride + slot[q - start], n2, jobs[oi].nchunks, 0, elems});
+                        elems += n2; ++oi;
+                    }
+                    if (!ri.empty()) { const ReduceItem* dr = upload(s, ri); launch_reduce<T, T>(s->stream, dr, (int)ri.size(), elems); }
+                    exchange(s, stride);
+                    for (size_t q = start; q < end; ++q) {
+                        int t = lev[q]; int de = plan.seq[t]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
+                        int c = s->chi[e];
+                        Buf nb = dalloc(s, (size_t)c * c * esz);
+                        MsgFinalItem f{}; f.partial = base + (size_t)s->owner[src] * stride + slot[q - start]; f.nchunks = 1; f.chi = c;
+                        const Buf& oldb = plan.in_place && fresh[de] ? fresh[de] : cur[de];
+                        f.old_msg = oldb ? oldb->p : nullptr; f.new_msg = nb->p;
+                        f.diff_out = reinterpret_cast<double*>(d_diffs->p) + t; f.normalize = normalize;
+                        fin.push_back(f);
+                        fresh[de] = nb;
+                    }
+                }
+                {
+                    const MsgFinalItem* d = upload(s, fin);
+                    ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
+                    launch_msg_finalize<T>(s->stream, d, (int)fin.size());
+                }
+                ht_fin.stop();
+                // (sharded) the next sub-batch writes the exchange buffer again: ordered after this finalize by the stream; the host-side
+                // all-gather callback is always preceded by a stream synchronisation inside exchange()
+                start = end;
+            }
+        }
+        for (size_t t = 0; t < nseq; ++t) if (fresh[plan.seq[t]]) cur[plan.seq[t]] = fresh[plan.seq[t]];
+        s->stats.n_bp_sweeps += 1;
+        if (compute_error) {
+            launch_sum_doubles(s->stream, reinterpret_cast<const double*>(d_diffs->p), (int)nseq, reinterpret_cast<double*>(d_sum->p));
+            double tot = 0;
+            HIPCHK(hipMemcpyAsync(&tot, d_sum->p, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            sync(s);
+            avg = tot / (double)nseq;
+            if (avg <= tol) { converged = true; niter = iter; break; }
+        }
+    }
+    sync(s);
+    s->msg = cur;
+    s->stats.n_bp_updates += 1;
+    if (compute_error && !converged) s->stats.bp_not_converged += 1;
+    s->stats.last_bp_diff = avg;
+    if (niter_out) *niter_out = niter;
+    if (diff_out) *diff_out = compute_error ? avg : -1.0;
+}
+
+void bp_update(State* s, const tnqs_bp_opts* o, int* niter, double* diff) {
+    if (s->dtype == TNQS_C64) bp_update_t<float>(s, o, niter, diff); else bp_update_t<double>(s, o, niter, diff);
+}
+
+template void bp_update_t<float>(State*, const tnqs_bp_opts*, int*, double*);
+template void bp_update_t<double>(State*, const tnqs_bp_opts*, int*, double*);
+
+}  // namespace tnqs

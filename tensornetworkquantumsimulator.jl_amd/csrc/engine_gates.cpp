@@ -1,0 +1,841 @@
+// engine_gates.cpp -- apply_gates (src/Apply/apply_gates.jl:46-143), simple_update as batched launches, truncate (src/truncate.jl).
+#include "engine_internal.hpp"
+
+namespace tnqs {
+
+// ---------------------------------------------------------------------------------------------------------------
+// gates
+// ---------------------------------------------------------------------------------------------------------------
+struct Gate1 { int v; const double* mat; };
+struct Gate2 { int v1, v2; const double* mat; int index; };
+
+// apply the pending scale factors of `verts` (out of place: site buffers may be shared with copies of the handle)
+template <class T> static void materialize_scale_t(State* s, const std::vector<int>& verts) {
+    std::vector<ScaleItem> sc; std::vector<Buf> outs; std::vector<int> vs;
+    for (int v : verts) {
+        if (v < 0 || v >= (int)s->site.size() || !s->site[v] || !s->sscale[v]) continue;
+        Buf out = dalloc(s, s->site[v]->bytes);
+        ScaleItem it{}; it.src = s->site[v]->p; it.dst = out->p; it.n = s->site[v]->bytes / s->esz(); it.factor = reinterpret_cast<const double*>(s->sscale[v]->p);
+        sc.push_back(it); outs.push_back(out); vs.push_back(v);
+    }
+    if (sc.empty()) return;
+    HIPCHK(hipSetDevice(s->device));
+    const ScaleItem* d = upload(s, sc);
+    { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_scale<T>(s->stream, d, (int)sc.size()); }
+    for (size_t i = 0; i < vs.size(); ++i) { s->keepalive.push_back(s->site[vs[i]]); s->keepalive.push_back(s->sscale[vs[i]]); s->site[vs[i]] = outs[i]; s->sscale[vs[i]] = nullptr; }
+}
+void materialize_scale(State* s, const std::vector<int>& verts) {
+    if (s->dtype == TNQS_C64) materialize_scale_t<float>(s, verts); else materialize_scale_t<double>(s, verts);
+}
+void materialize_scale_all(State* s) {
+    std::vector<int> all(s->site.size()); std::iota(all.begin(), all.end(), 0);
+    materialize_scale(s, all);
+}
+
+// the new site tensors replace the old ones; with `normalize` their norm (from the producing kernel's partial sums) becomes
+// the pending scale factor 1/||psi|| instead of a scaling pass over the tensor (simple_update.jl:66-72 normalises eagerly;
+// every later step of the path is invariant under a real rescaling of a site tensor, see engine.hpp State::sscale)
+template <class T> static void norm_and_replace(State* s, std::vector<int>& verts, std::vector<Buf>& outs,
+                                                std::vector<size_t>& nelem, Buf norm_partials,
+                                                std::vector<int>& tile_begin, std::vector<int>& ntiles, bool normalize) {
+    (void)nelem;
+    if (normalize) {
+        std::vector<NormFactorItem> nf;
+        Buf fac = dalloc(s, verts.size() * 256);           // one factor per site, 256-byte slots (aliased Bufs below)
+        for (size_t i = 0; i < verts.size(); ++i) {
+            NormFactorItem it{}; it.norm_partials = reinterpret_cast<const double*>(norm_partials->p) + tile_begin[i]; it.npart = ntiles[i];
+            it.factor = reinterpret_cast<double*>(reinterpret_cast<char*>(fac->p) + 256 * i);
+            nf.push_back(it);
+        }
+        const NormFactorItem* d = upload(s, nf);
+        { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_norm_factor(s->stream, d, (int)nf.size()); }
+        for (size_t i = 0; i < verts.size(); ++i) { s->site[verts[i]] = outs[i]; s->sscale[verts[i]] = sub_buffer(fac, 256 * i, 8); }
+        if (eager_scale()) materialize_scale_t<T>(s, verts);
+    } else {
+        for (size_t i = 0; i < verts.size(); ++i) s->site[verts[i]] = outs[i];       // a pending factor of the input carries over (linear map)
+    }
+}
+
+template <class T> static void apply_one_site_batch(State* s, const std::vector<Gate1>& gates, bool normalize) {
+    if (gates.empty()) return;
+    const size_t esz = s->esz();
+    if (std::is_same<T, float>::value) {
+        bool all2 = true; for (auto& g1 : gates) all2 = all2 && s->d[g1.v] == 2;
+        if (all2) {         // streaming 2x2 kernel (HBM-bound: read + write each site tensor once)
+            const int NBX = 64;
+            std::vector<Site1Item> items; std::vector<int> verts, tb, nt; std::vector<Buf> outs; std::vector<size_t> ne; double bytes = 0, flops = 0;
+            for (auto& g1 : gates) {
+                if (!s->owns(g1.v)) continue;
+                SD sd = site_dims(s, g1.v);
+                Site1Item it{}; Buf out = dalloc(s, sd.n * esz);
+                it.in = s->site[g1.v]->p; it.out = out->p; it.npairs = sd.n / 2;
+                // column-major G[s' + 2 s]: g00 = mat[0], g10 = mat[1], g01 = mat[2], g11 = mat[3]
+                const double* m = g1.mat;
+                it.g[0] = (float)m[0]; it.g[1] = (float)m[1]; it.g[2] = (float)m[4]; it.g[3] = (float)m[5];
+                it.g[4] = (float)m[2]; it.g[5] = (float)m[3]; it.g[6] = (float)m[6]; it.g[7] = (float)m[7];
+                verts.push_back(g1.v); outs.push_back(out); ne.push_back(sd.n); tb.push_back((int)items.size() * NBX); nt.push_back(NBX);
+                items.push_back(it);
+                bytes += 2.0 * sd.n * esz; flops += 8.0 * sd.n * 2;
+            }
+            if (items.empty()) return;
+            Buf np = dalloc(s, items.size() * NBX * sizeof(double));
+            const Site1Item* d = upload(s, items);
+            { ProfScope ps(s, TNQS_PROF_GATE_APPLY, bytes, flops);
+              launch_site1_c64(s->stream, d, (int)items.size(), NBX, normalize ? reinterpret_cast<double*>(np->p) : nullptr); }
+            norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, normalize);
+            return;
+        }
+    }
+    std::vector<FiberItem> items; std::vector<int> verts, tb, nt; std::vector<Buf> outs; std::vector<size_t> ne;
+    int tiles = 0; size_t KKmax = 1; double bytes = 0, flops = 0;
+    for (auto& g1 : gates) KKmax = std::max<size_t>(KKmax, s->d[g1.v]);
+    const int TR = pick_TR(KKmax, esz, 1);
+    std::vector<T> hx;       // X[kk + d*nn] = G[nn, kk]  (out[s'] = sum_s G[s', s] psi[s], simple_update.jl:27)
+    std::vector<size_t> xoff;
+    for (auto& g1 : gates) {
+        int d = s->d[g1.v]; xoff.push_back(hx.size());
+        for (int nn = 0; nn < d; ++nn) for (int kk = 0; kk < d; ++kk) { hx.push_back((T)g1.mat[2 * (nn + d * kk)]); hx.push_back((T)g1.mat[2 * (nn + d * kk) + 1]); }
+    }
+    // note: column-major X means index kk + d*nn; the loop above emits nn-major order, i.e. X[kk + d*nn] at position nn*d + kk
+    const char* dxp;
+    {
+        std::vector<char> raw(reinterpret_cast<char*>(hx.data()), reinterpret_cast<char*>(hx.data()) + hx.size() * sizeof(T));
+        dxp = upload(s, raw);
+    }
+    size_t gi = 0;
+    for (auto& g1 : gates) {
+        if (!s->owns(g1.v)) { ++gi; continue; }
+        SD sd = site_dims(s, g1.v);
+        FiberItem it{}; Buf out = dalloc(s, sd.n * esz);
+        it.in = s->site[g1.v]->p; it.out = out->p; it.X = dxp + xoff[gi] * sizeof(T);
+        it.D = sd.d; it.PA = (int)(sd.n / sd.d); it.K = 1; it.PB = 1; it.Do = sd.d; it.No = 1;
+        tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
+        it.tpw = 1; it.tile_begin = tiles; it.want_norm = normalize ? 1 : 0;
+        verts.push_back(g1.v); outs.push_back(out); ne.push_back(sd.n); tb.push_back(tiles); nt.push_back(it.nta * it.ntb);
+        tiles += it.nta * it.ntb; items.push_back(it);
+        bytes += 2.0 * sd.n * esz; flops += 8.0 * sd.n * sd.d;
+        ++gi;
+    }
+    if (items.empty()) return;
+    Buf np = dalloc(s, std::max(1, tiles) * sizeof(double));
+    const FiberItem* d = upload(s, items);
+    { ProfScope ps(s, TNQS_PROF_GATE_APPLY, bytes, flops);
+      launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
+    norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, normalize);
+}
+
+template <class T> static void apply_two_site_batch(State* s, const std::vector<Gate2>& gates, const tnqs_apply_opts& ao, double* errs) {
+    if (gates.empty()) return;
+    const Graph& g = *s->g;
+    const size_t esz = s->esz();
+    const bool sharded = s->nranks > 1;
+    const double sqrt_cutoff = ao.sqrt_cutoff >= 0 ? ao.sqrt_cutoff : 10.0 * (s->dtype == TNQS_C64 ? 1.1920928955078125e-07 : 2.220446049250313e-16);
+    const int ng = (int)gates.size();
+    if (!ao.normalize_tensors) {       // without the final normalisation the result scales with the inputs: apply pending factors first
+        std::vector<int> vs; for (auto& g2 : gates) { vs.push_back(g2.v1); vs.push_back(g2.v2); }
+        materialize_scale(s, vs);
+    }
+    struct SiteJob { int v, other, bleg; bool owned; SD sd; std::vector<int> env_idx; std::vector<int> env_leg; };
+    std::vector<SiteJob> sj(2 * (size_t)ng);
+    std::vector<char> part(ng, 0);                  // this rank runs the small algebra of the gate
+    // ---- 1. environments: sqrt(M) and projector for every incoming message of an owned site (utils.jl:18-27) ------
+    struct EnvRec { int de; int n; void *H, *V, *msq, *prj; };      // views into one arena (env_arena): thousands of 16 KiB pool allocations per batch
+                                                                    // were a third of the host time between a BP update and the first kernel of a batch
+    std::vector<EnvRec> envs;
+    for (int gi = 0; gi < ng; ++gi) {
+        for (int side = 0; side < 2; ++side) {
+            SiteJob& j = sj[2 * gi + side];
+            j.v = side == 0 ? gates[gi].v1 : gates[gi].v2; j.other = side == 0 ? gates[gi].v2 : gates[gi].v1;
+            j.sd = site_dims(s, j.v); j.bleg = g.leg(j.v, j.other); j.owned = s->owns(j.v);
+            if (j.owned) part[gi] = 1;
+            if (!j.owned) continue;
+            for (int l = 0; l < j.sd.z; ++l) {
+                if (l == j.bleg) continue;
+                int de = g.dedge(g.nbr[j.v][l], j.v);
+                if (!s->msg[de]) continue;                  // identity message: sqrt = I, nothing to absorb
+                EnvRec r; r.de = de; r.n = j.sd.chi[l];
+                j.env_idx.push_back((int)envs.size()); j.env_leg.push_back(l);
+                envs.push_back(r);
+            }
+        }
+    }
+    std::vector<int> h_flags(2 * envs.size() + 2, 0);
+    Buf d_flags = dalloc(s, h_flags.size() * sizeof(int));
+    Buf env_arena;
+    {
+        std::vector<EnvItem> ei; std::vector<JacobiItem> ji; std::vector<EnvFinishItem> fi;
+        size_t env_bytes = 0;
+        for (auto& r : envs) { const size_t nn = (size_t)r.n * r.n; env_bytes += 2 * round256(nn * 16) + 2 * round256(nn * esz); }
+        env_arena = dalloc(s, std::max<size_t>(256, env_bytes));
+        char* ap = reinterpret_cast<char*>(env_arena->p);
+        ei.reserve(envs.size()); ji.reserve(envs.size()); fi.reserve(envs.size());
+        for (size_t i = 0; i < envs.size(); ++i) {
+            EnvRec& r = envs[i]; size_t nn = (size_t)r.n * r.n;
+            r.H = ap; ap += round256(nn * 16); r.V = ap; ap += round256(nn * 16); r.msq = ap; ap += round256(nn * esz); r.prj = ap; ap += round256(nn * esz);
+            ei.push_back(EnvItem{s->msg[r.de]->p, r.H, r.V, r.n});
+            ji.push_back(JacobiItem{r.H, r.V, r.n, r.n, nullptr});
+            fi.push_back(EnvFinishItem{r.H, r.V, r.msq, r.prj, r.n, sqrt_cutoff, reinterpret_cast<int*>(d_flags->p) + 2 * i});
+        }
+        if (!envs.empty()) {
+            const EnvItem* de = upload(s, ei); const JacobiItem* dj = upload(s, ji); const EnvFinishItem* df = upload(s, fi);
+            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, de, (int)ei.size()); }
+            size_t lds = 0; for (auto& r : envs) lds = std::max(lds, jacobi_lds_bytes(r.n, r.n, true, 16));
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60, jacobi_lds(lds), mmax_of(ji)); }
+            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_finish<T>(s->stream, df, (int)fi.size()); }
+        }
+    }
+    // ---- 2. gauge: psi~ = psi x_outer M^{1/2}  (simple_update.jl:43-44), owned sites only -----------------------------
+    std::vector<int> own_idx;                        // indices into sj of the owned sites
+    for (size_t i = 0; i < sj.size(); ++i) if (sj[i].owned) own_idx.push_back((int)i);
+    std::vector<Chain> chains(own_idx.size());
+    for (size_t q = 0; q < own_idx.size(); ++q) {
+        const SiteJob& j = sj[own_idx[q]];
+        Chain& c = chains[q]; c.v = j.v; c.src = s->site[j.v]->p; c.sd = j.sd;
+        for (size_t e = 0; e < j.env_idx.size(); ++e) c.steps.push_back({j.env_leg[e], envs[j.env_idx[e]].msq});
+    }
+    run_chains<T>(s, chains, TNQS_PROF_GATE_MODEPROD);
+    // ---- 3. G = psi~^dagger psi~ over the outer legs, f64 accumulation (replaces the thin QR, simple_update.jl:45-48) --
+    std::vector<GramJob> jobs;
+    for (size_t q = 0; q < own_idx.size(); ++q) {
+        const SiteJob& sjq = sj[own_idx[q]];
+        GramJob j{}; j.X = chains[q].result; j.Y = chains[q].result; j.sd = sjq.sd; j.leg = sjq.bleg; j.keep_site = true;
+        jobs.push_back(j);
+    }
+    run_grams<T, double>(s, jobs, TNQS_PROF_GATE_GRAM);
+    std::vector<Buf> GA(sj.size()), GV(sj.size());
+    auto nof = [&](size_t i) { return sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]; };
+    // G slots: in the sharded case every rank needs G1 and G2 of the gates it takes part in -> all-gather all of them (the same layout
+    // serves the Gram matrices of the second factorisation pass further down)
+    std::vector<size_t> slot(sj.size(), 0); size_t stride = 0;
+    {
+        std::vector<size_t> rank_bytes(s->nranks, 0);
+        if (sharded) {
+            for (size_t i = 0; i < sj.size(); ++i) { int r = s->owner[sj[i].v]; slot[i] = rank_bytes[r]; rank_bytes[r] += round256((size_t)nof(i) * nof(i) * 16); }
+            for (size_t b : rank_bytes) stride = std::max(stride, b);
+            check_exchange(s, stride);
+        }
+        std::vector<ReduceItem> ri; int elems = 0;
+        for (size_t q = 0; q < own_idx.size(); ++q) {
+            size_t i = own_idx[q]; int n = jobs[q].KK; size_t nn = (size_t)n * n;
+            GA[i] = dalloc(s, nn * 16);
+            void* dst = sharded ? (void*)(reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride + slot[i]) : GA[i]->p;
+            ri.push_back(ReduceItem{jobs[q].partial->p, dst, (int)nn, jobs[q].nchunks, 1, elems}); elems += (int)nn;
+        }
+        const ReduceItem* dr = upload(s, ri);
+        { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, dr, (int)ri.size(), elems); }
+        if (sharded) {
+            exchange(s, stride);
+            // one private copy of the gathered block (the exchange buffer is reused by the record exchange of this batch); the G of
+            // every site this rank needs is a view into it
+            Buf G_keep = dalloc(s, std::max<size_t>(256, stride * (size_t)s->nranks));
+            HIPCHK(hipMemcpyAsync(G_keep->p, s->exch, stride * (size_t)s->nranks, hipMemcpyDeviceToDevice, s->stream));
+            for (size_t i = 0; i < sj.size(); ++i) {
+                if (!part[i / 2]) continue;
+                size_t nn = (size_t)nof(i) * nof(i);
+                GA[i] = sub_buffer(G_keep, (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16);
+            }
+        }
+    }
+    // R factor of psi~ = Q R from G = R^dagger R: Cholesky (R = L^dagger) where G has full rank by construction (at least as
+    // many fibers as columns); the f64 Jacobi eigen factorisation R = Lambda^1/2 W^dagger otherwise, and for the whole batch when
+    // a Cholesky pivot collapses (numerically rank-deficient G; the eigen path drops the null space, rank_tau in kernels.hpp)
+    std::vector<Buf> GW(sj.size()); std::vector<char> is_chol(sj.size(), 0), is_small(sj.size(), 0);
+    // ComplexF64, single rank: ill-conditioned sites get a second factorisation pass below, which sorts out what is signal and what is
+    // noise among the smallest directions -- so the first pass keeps everything above the f64 noise floor instead of rank_tau
+    const bool qr2 = !std::is_same<T, float>::value && use_qr2();
+    auto tau_of = [&](int n) { return qr2 ? 1e-15 : rank_tau(std::is_same<T, float>::value, n); };
+    // sites with fewer fibers than columns are factorised by their owner without a Gram matrix (small-SVD route) and never refined; the
+    // criterion must not depend on ownership, every rank taking part in a gate has to reach the same decision
+    auto small_shape = [&](size_t i) { const int n = nof(i); return sj[i].sd.n / (size_t)n < (size_t)n && n <= 256 && use_small_svd(); };
+    std::vector<const void*> gauged_of(sj.size(), nullptr);      // psi~ of the owned sites
+    for (size_t q = 0; q < own_idx.size(); ++q) gauged_of[own_idx[q]] = chains[q].result;
+    Buf d_cholfail = dalloc(s, std::max<size_t>(1, sj.size()) * sizeof(int));      // one flag per site: only the sites whose pivot collapsed are redone
+    std::vector<int> h_cholfail(sj.size(), 0);
+    auto factor_G = [&](bool allow_chol, bool fallback = false) {
+        std::vector<JacobiItem> ji, sji; std::vector<EnvItem> idn; std::vector<CholItem> ci; std::vector<SmallSvdItem> si; int cmax = 1;
+        if (!fallback) HIPCHK(hipMemsetAsync(d_cholfail->p, 0, std::max<size_t>(1, sj.size()) * sizeof(int), s->stream));
+        for (size_t i = 0; i < sj.size(); ++i) {
+            if (!part[i / 2]) continue;
+            if (fallback && !(is_chol[i] && h_cholfail[i])) continue;      // fallback pass: only the Cholesky sites whose pivot collapsed (the eigen sites are factorised, GA rotated in place)
+            int n = nof(i);
+            if (!GV[i]) GV[i] = dalloc(s, (size_t)n * n * 16);
+            const size_t Nout = sj[i].sd.n / (size_t)n;
+            const bool ch = allow_chol && n <= (use_chol128() ? 128 : 96) && Nout >= (size_t)n;
+            is_chol[i] = ch ? 1 : 0;
+            if (!ch && sj[i].owned && Nout < (size_t)n && n <= 256 && use_small_svd()) {
+                // fewer fibers than columns: R = Sigma U^dagger straight from the SVD of the n x N matricised psi~ (no rank-deficient G)
+                GW[i] = GV[i]; is_small[i] = 1;
+                Buf M = dalloc(s, (size_t)n * Nout * 16); s->keepalive.push_back(M);
+                const SD& sd = sj[i].sd; const int b = sj[i].bleg;
+                si.push_back(SmallSvdItem{gauged_of[i], M->p, GA[i]->p, GV[i]->p, sd.d, (int)(sd.pre(b) / sd.d), sd.chi[b], (int)sd.post(b)});
+                sji.push_back(JacobiItem{M->p, nullptr, n, (int)Nout, nullptr});
+                continue;
+            }
+            if (ch) {
+                GW[i] = dalloc(s, (size_t)n * n * 16);
+                ci.push_back(CholItem{GA[i]->p, GV[i]->p, GW[i]->p, n, reinterpret_cast<int*>(d_cholfail->p) + i, tau_of(n)}); cmax = std::max(cmax, n);
+            } else {
+                GW[i] = GV[i];
+                idn.push_back(EnvItem{nullptr, GV[i]->p, GV[i]->p, n});      // msg == null: H := I, V := I (same buffer)
+                ji.push_back(JacobiItem{GA[i]->p, GV[i]->p, n, n, nullptr});
+            }
+        }
+        if (!si.empty()) {
+            const SmallSvdItem* ds = upload(s, si); const JacobiItem* dj = upload(s, sji);
+            ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0);
+            launch_small_svd_prepare<T>(s->stream, ds, (int)si.size());
+            size_t lds = 0; for (auto& j : sji) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, false, 16));
+            launch_jacobi<double>(s->stream, dj, (int)sji.size(), 60, jacobi_lds(lds), mmax_of(sji));
+            launch_small_svd_finish(s->stream, ds, (int)si.size());
+        }
+        if (!ci.empty()) {      // n <= 96: square LDS array; 96 < n <= 128 (chi = 64 sites): packed triangle
+            const CholItem* dc = upload(s, ci); ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0);
+            if (cmax <= 96) launch_chol(s->stream, dc, (int)ci.size(), cmax); else launch_chol_packed(s->stream, dc, (int)ci.size(), cmax);
+        }
+        if (!ji.empty()) {
+            const EnvItem* di = upload(s, idn);
+            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)idn.size()); }
+            const JacobiItem* dj = upload(s, ji);
+            size_t lds = 0; for (auto& j : ji) lds = std::max(lds, jacobi_lds_bytes(j.n, j.n, true, 16));
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60, jacobi_lds(lds), mmax_of(ji)); }
+        }
+    };
+    factor_G(use_chol());
+    // ---- 4. theta = gate . (R1 R2), SVD, truncation, X1 / X2  (simple_update.jl:51-59) -----------------------------
+    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S, lowA, lowB, lowG, lowL, lowW; int n1, n2, chi, cap; };
+    std::vector<GateWS> ws(ng);
+    std::vector<int> pg;                              // gates this rank takes part in
+    for (int gi = 0; gi < ng; ++gi) if (part[gi]) pg.push_back(gi);
+    std::vector<GateItem> gitems(pg.size());
+    int cap_max = 1; size_t x2_max = 0;
+    for (int gi = 0; gi < ng; ++gi) {
+        GateWS& w = ws[gi];
+        const SiteJob& a = sj[2 * gi]; const SiteJob& b = sj[2 * gi + 1];
+        int chi = a.sd.chi[a.bleg];
+        w.n1 = a.sd.d * chi; w.n2 = b.sd.d * chi; w.chi = chi;
+        int Mr = w.n1 * a.sd.d, Nc = w.n2 * b.sd.d;
+        if (Mr > 256 || Nc > 256) throw Err(TNQS_ERR_UNSUPPORTED, "two-site gate: d^2*chi > 256 is not supported by the Jacobi SVD kernel yet");
+        int cap = std::min(Mr, Nc); if (ao.maxdim > 0) cap = std::min(cap, ao.maxdim);
+        w.cap = cap; cap_max = std::max(cap_max, cap);
+        x2_max = std::max(x2_max, (size_t)w.n2 * b.sd.d * cap * esz);
+    }
+    // SVD of theta: the right factor is never accumulated from the rotations (in f32 its orthogonality degrades with the
+    // rotation count, ~1e-5 at 150 columns) but recovered from an unrotated copy: V = theta0^dagger (U S) S^-2
+    const bool theta0_used = true;
+    {
+        std::vector<char> raw;
+        std::vector<size_t> off(pg.size()), offA(pg.size(), 0), offB(pg.size(), 0); std::vector<int> kappa(pg.size(), 0);
+        const bool lowrank_on = std::is_same<T, float>::value && use_lowrank();
+        for (size_t q = 0; q < pg.size(); ++q) {
+            int gi = pg[q];
+            const int d1 = s->d[gates[gi].v1], d2 = s->d[gates[gi].v2];
+            int dd = d1 * d2;
+            off[q] = raw.size();
+            const char* p = reinterpret_cast<const char*>(gates[gi].mat);
+            raw.insert(raw.end(), p, p + (size_t)dd * dd * 16);
+            if (!lowrank_on) continue;
+            // the gate as an operator sum g = sum_k a_k (x) b_k: O[(s1',s1),(s2',s2)] = g[(s1' s2'),(s1 s2)] factorised by elimination with
+            // complete pivoting (exact rank factorisation; kappa = operator Schmidt rank: 2 for Rzz / Rxx / CNOT / CPHASE, 4 for SWAP)
+            const int na = d1 * d1, nb = d2 * d2;
+            std::vector<std::complex<double>> O((size_t)na * nb), fa, fb;
+            const std::complex<double>* gm = reinterpret_cast<const std::complex<double>*>(gates[gi].mat);
+            double amax = 0;
+            for (int s1p = 0; s1p < d1; ++s1p) for (int s1 = 0; s1 < d1; ++s1) for (int s2p = 0; s2p < d2; ++s2p) for (int s2 = 0; s2 < d2; ++s2) {
+                auto v = gm[(s1p * d2 + s2p) + (size_t)dd * (s1 * d2 + s2)];
+                O[(s1p + d1 * s1) + (size_t)na * (s2p + d2 * s2)] = v; amax = std::max(amax, std::abs(v));
+            }
+            int kp = 0;
+            for (; kp < std::min(na, nb); ++kp) {
+                int pi = 0, pj = 0; double best = 0;
+                for (int j = 0; j < nb; ++j) for (int i = 0; i < na; ++i) { double a = std::abs(O[i + (size_t)na * j]); if (a > best) { best = a; pi = i; pj = j; } }
+                if (!(best > 1e-13 * amax)) break;
+                const std::complex<double> piv = O[pi + (size_t)na * pj];
+                std::vector<std::complex<double>> col(na), row(nb);
+                for (int i = 0; i < na; ++i) col[i] = O[i + (size_t)na * pj];
+                for (int j = 0; j < nb; ++j) row[j] = O[pi + (size_t)na * j] / piv;
+                for (int j = 0; j < nb; ++j) for (int i = 0; i < na; ++i) O[i + (size_t)na * j] -= col[i] * row[j];
+                fa.insert(fa.end(), col.begin(), col.end()); fb.insert(fb.end(), row.begin(), row.end());
+            }
+            kappa[q] = kp;
+            offA[q] = raw.size(); raw.insert(raw.end(), reinterpret_cast<const char*>(fa.data()), reinterpret_cast<const char*>(fa.data()) + fa.size() * 16);
+            offB[q] = raw.size(); raw.insert(raw.end(), reinterpret_cast<const char*>(fb.data()), reinterpret_cast<const char*>(fb.data()) + fb.size() * 16);
+        }
+        const char* d_gm = pg.empty() ? nullptr : upload(s, raw);
+        for (size_t q = 0; q < pg.size(); ++q) {
+            int gi = pg[q];
+            GateWS& w = ws[gi]; GateItem& it = gitems[q];
+            const SiteJob& a = sj[2 * gi]; const SiteJob& b = sj[2 * gi + 1];
+            int Mr = w.n1 * a.sd.d, Nc = w.n2 * b.sd.d, cap = w.cap;
+            w.lam1 = dalloc(s, w.n1 * 8); w.lam2 = dalloc(s, w.n2 * 8); w.idx1 = dalloc(s, w.n1 * 4); w.idx2 = dalloc(s, w.n2 * 4);
+            w.theta = dalloc(s, (size_t)Mr * Nc * esz); w.thetaV = dalloc(s, (size_t)std::max(Mr, Nc) * std::max(Mr, Nc) * esz);
+            if (theta0_used) w.theta0 = dalloc(s, (size_t)Mr * Nc * esz);
+            w.X1 = dalloc(s, (size_t)w.n1 * a.sd.d * cap * esz); w.X2 = dalloc(s, (size_t)w.n2 * b.sd.d * cap * esz);
+            w.S = dalloc(s, cap * 8);
+            it.GA1 = GA[2 * gi]->p; it.GV1 = GV[2 * gi]->p; it.GA2 = GA[2 * gi + 1]->p; it.GV2 = GV[2 * gi + 1]->p;
+            it.GW1 = GW[2 * gi]->p; it.GW2 = GW[2 * gi + 1]->p; it.chol1 = is_chol[2 * gi]; it.chol2 = is_chol[2 * gi + 1];
+            it.n1 = w.n1; it.n2 = w.n2; it.d1 = a.sd.d; it.d2 = b.sd.d; it.chi = w.chi;
+            it.gate = reinterpret_cast<const double*>(d_gm + off[q]);
+            it.kappa = 0; it.opA = it.opB = nullptr; it.lowA = it.lowB = it.lowG = nullptr; it.lowL = nullptr; it.lowfail = nullptr;
+            {   // low-rank route of the theta SVD (GateItem): only where it can apply -- K = kappa chi below the theta columns and chol_kernel's size
+                const int K = kappa[q] * w.chi;
+                if (lowrank_on && kappa[q] > 0 && K < Nc && K <= 128 && cap <= K && Mr >= Nc) {
+                    w.lowA = dalloc(s, (size_t)Mr * K * 16); w.lowB = dalloc(s, (size_t)Nc * K * 16); w.lowG = dalloc(s, (size_t)K * K * 16);
+                    w.lowL = dalloc(s, (size_t)K * K * 16); w.lowW = dalloc(s, (size_t)K * K * 16);
+                    it.kappa = kappa[q]; it.opA = reinterpret_cast<const double*>(d_gm + offA[q]); it.opB = reinterpret_cast<const double*>(d_gm + offB[q]);
+                    it.lowA = w.lowA->p; it.lowB = w.lowB->p; it.lowG = w.lowG->p; it.lowL = w.lowL->p;
+                }
+            }
+            it.lam1 = (double*)w.lam1->p; it.lam2 = (double*)w.lam2->p; it.idx1 = (int*)w.idx1->p; it.idx2 = (int*)w.idx2->p;
+            it.theta = w.theta->p; it.thetaV = w.thetaV->p; it.theta0 = w.theta0 ? w.theta0->p : nullptr; it.X1 = w.X1->p; it.X2 = w.X2->p; it.S = (double*)w.S->p;
+            it.maxdim = ao.maxdim; it.cutoff = ao.cutoff; it.normalize = ao.normalize_tensors; it.chi_cap = cap;
+            // second-pass mode: the eigen route of the first pass is shifted (negative tau, gate_eigs) -- it must not drop a direction the
+            // second pass could still resolve
+            // (the small-SVD sites are factorised without a Gram matrix and are never refined: ordinary threshold)
+            auto site_tau = [&](size_t i, int n) { return (qr2 && !small_shape(i)) ? -rank_tau(false, n) : rank_tau(std::is_same<T, float>::value, n); };
+            it.tau1 = site_tau(2 * (size_t)gi, w.n1); it.tau2 = site_tau(2 * (size_t)gi + 1, w.n2); it.rk1 = nullptr; it.rk2 = nullptr;
+        }
+    }
+    const int npg = (int)pg.size();
+    // per-gate (r1, r2, chi', status, sweeps, wide, -, -) and truncation error live in two contiguous arrays: one D2H each
+    Buf d_info_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 32));
+    Buf d_terr_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 8));
+    HIPCHK(hipMemsetAsync(d_info_all->p, 0, std::max<size_t>(1, (size_t)npg * 32), s->stream));
+    for (int q = 0; q < npg; ++q) { gitems[q].info = reinterpret_cast<int*>(d_info_all->p) + 8 * q; gitems[q].truncerr = reinterpret_cast<double*>(d_terr_all->p) + q; }
+    // low-rank route: one failure flag per gate for the Cholesky factorisation of B^dagger B
+    Buf d_lowfail = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));
+    Buf d_texp = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));
+    for (int q = 0; q < npg; ++q) { gitems[q].lowfail = reinterpret_cast<const int*>(d_lowfail->p) + q; gitems[q].texp = reinterpret_cast<int*>(d_texp->p) + q; }
+    const GateItem* d_gitems = upload(s, gitems);
+    auto run_theta = [&]() {
+        HIPCHK(hipMemsetAsync(d_info_all->p, 0, std::max<size_t>(1, (size_t)npg * 32), s->stream));
+        HIPCHK(hipMemsetAsync(d_lowfail->p, 0, std::max<size_t>(1, (size_t)npg * sizeof(int)), s->stream));
+        ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
+        launch_gate_theta<T>(s->stream, d_gitems, npg);
+        std::vector<CholItem> lc; int kmax = 1;
+        for (int q = 0; q < npg; ++q) {
+            if (!gitems[q].lowG) continue;
+            const int K = gitems[q].kappa * gitems[q].chi;
+            lc.push_back(CholItem{gitems[q].lowG, const_cast<void*>(gitems[q].lowL), K <= 96 ? ws[pg[q]].lowW->p : nullptr, K, reinterpret_cast<int*>(d_lowfail->p) + q, rank_tau(true, K)});
+            kmax = std::max(kmax, K);
+        }
+        if (!lc.empty()) {
+            const CholItem* dc = upload(s, lc); launch_lowrank_g(s->stream, d_gitems, npg);
+            if (kmax <= 96) launch_chol(s->stream, dc, (int)lc.size(), kmax); else launch_chol_packed(s->stream, dc, (int)lc.size(), kmax);      // only L is used here
+            launch_lowrank_m(s->stream, d_gitems, npg);
+        }
+        launch_theta_scale<T>(s->stream, d_gitems, npg);       // theta (or M) and theta0 to O(1), exponent kept per gate for gate_finish
+    };
+    run_theta();
+    std::vector<int> info(8 * (size_t)ng, 0); std::vector<double> terr(ng, 0.0);
+    {
+        // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
+        std::vector<int> hinfo(8 * (size_t)std::max(1, npg));
+        int chol_failed = 0;
+        if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
+        if (!envs.empty()) HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags->p, 2 * envs.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        if (!sj.empty()) HIPCHK(hipMemcpyAsync(h_cholfail.data(), d_cholfail->p, sj.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        for (size_t i = 0; i < sj.size(); ++i) chol_failed += (part[i / 2] && is_chol[i] && h_cholfail[i]) ? 1 : 0;
+        if (chol_failed) {              // numerically rank-deficient Gram matrix somewhere in the batch: redo with the eigen path
+            factor_G(false, true);
+            for (int q = 0; q < npg; ++q) { int gi = pg[q]; GateItem& it = gitems[q]; it.GW1 = GW[2 * gi]->p; it.GW2 = GW[2 * gi + 1]->p; it.chol1 = is_chol[2 * gi]; it.chol2 = is_chol[2 * gi + 1]; }
+            d_gitems = upload(s, gitems);
+            run_theta();
+            if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+            s->stats.n_chol_fallbacks += 1;
+        }
+        if (qr2) {
+            // ---- second factorisation pass (CholeskyQR2) of the sites gate_theta flagged as ill-conditioned: a Gram matrix resolves the
+            // singular directions of psi~ only down to sigma_rel ~ 1e-7, the reference's QR to eps.  Q1 = psi~ R1^+ is formed explicitly;
+            // its Gram matrix is close to the identity on everything the first pass resolved and shows the true weight of what it did not,
+            // so R = R2 R1 is as accurate as a Householder R.  
+            // Sharded: the owner of a site forms Q1 and its Gram matrix, one more all-gather (same slots as the first Gram exchange, issued
+            // by every rank whether or not it has a flagged site -- it is a collective) hands it to the partner rank, and both compose the
+            // same factor from the same inputs.
+            std::vector<size_t> rs; std::vector<int> rq;
+            for (int q = 0; q < npg; ++q) for (int side = 0; side < 2; ++side) {
+                const size_t i = 2 * (size_t)pg[q] + side;
+                static const bool all = [] { const char* v = std::getenv("TNQS_QR2_ALL"); return v && v[0] == '1'; }();      // debug: refine every site
+                if ((all || ((hinfo[8 * q + 6] >> side) & 1)) && !small_shape(i)) { rs.push_back(i); rq.push_back(q); }
+            }
+            if (sharded || !rs.empty()) {
+                const size_t m = rs.size();
+                std::vector<Buf> X1(m), Q1(m), G2(m), V2(m), GVn(m), GWn(m); Buf d_rk = dalloc(s, std::max<size_t>(1, m) * sizeof(int));
+                std::vector<Qr2RinvItem> ri; std::vector<FiberItem> fi; std::vector<GramJob> gj; std::vector<size_t> own_k; size_t KKmax = 1; int tiles = 0;
+                for (size_t k = 0; k < m; ++k) {
+                    const size_t i = rs[k]; const int q = rq[k]; const bool second = (i & 1) != 0; const int n = nof(i); const size_t nn = (size_t)n * n;
+                    X1[k] = dalloc(s, nn * 16); V2[k] = dalloc(s, nn * 16); GVn[k] = dalloc(s, nn * 16); GWn[k] = dalloc(s, nn * 16);
+                    ri.push_back(Qr2RinvItem{GW[i]->p, second ? gitems[q].lam2 : gitems[q].lam1, second ? gitems[q].idx2 : gitems[q].idx1, gitems[q].info + (second ? 1 : 0), n, X1[k]->p});
+                    if (sj[i].owned) { own_k.push_back(k); KKmax = std::max<size_t>(KKmax, (size_t)n); Q1[k] = dalloc(s, sj[i].sd.n * esz); }
+                }
+                const int TR = pick_TR(KKmax, esz, 1);
+                for (size_t k : own_k) {
+                    const size_t i = rs[k]; const SiteJob& j = sj[i]; const int chi = j.sd.chi[j.bleg];
+                    FiberItem it{}; it.in = gauged_of[i]; it.out = Q1[k]->p; it.X = X1[k]->p;
+                    it.D = j.sd.d; it.PA = (int)(j.sd.pre(j.bleg) / j.sd.d); it.K = chi; it.PB = (int)j.sd.post(j.bleg); it.Do = j.sd.d; it.No = chi;
+                    tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb); it.tpw = 1; it.tile_begin = tiles; it.want_norm = 0;
+                    tiles += it.nta * it.ntb; fi.push_back(it);
+                    GramJob g2{}; g2.X = Q1[k]->p; g2.Y = Q1[k]->p; g2.sd = j.sd; g2.leg = j.bleg; g2.keep_site = true; gj.push_back(g2);
+                }
+                if (m) { const Qr2RinvItem* d = upload(s, ri); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_rinv(s->stream, d, (int)m); }
+                if (!fi.empty()) {
+                    Buf np = dalloc(s, std::max(1, tiles) * sizeof(double)); const FiberItem* d = upload(s, fi);
+                    { ProfScope ps(s, TNQS_PROF_GATE_APPLY, 0, 0); launch_fiber_gemm<T>(s->stream, d, (int)fi.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
+                    s->keepalive.push_back(np);
+                    run_grams<T, double>(s, gj, TNQS_PROF_GATE_GRAM);
+                    std::vector<ReduceItem> rd; int elems = 0;
+                    for (size_t t = 0; t < own_k.size(); ++t) {
+                        const size_t k = own_k[t], i = rs[k]; const int nn = gj[t].KK * gj[t].KK;
+                        void* dst;
+                        if (sharded) dst = reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride + slot[i];
+                        else { G2[k] = dalloc(s, (size_t)nn * 16); dst = G2[k]->p; }
+                        rd.push_back(ReduceItem{gj[t].partial->p, dst, nn, gj[t].nchunks, 1, elems}); elems += nn;
+                    }
+                    const ReduceItem* d2 = upload(s, rd); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, d2, (int)rd.size(), elems);
+                }
+                if (sharded) {
+                    exchange(s, stride);
+                    Buf G2_keep = dalloc(s, std::max<size_t>(256, stride * (size_t)s->nranks));
+                    HIPCHK(hipMemcpyAsync(G2_keep->p, s->exch, stride * (size_t)s->nranks, hipMemcpyDeviceToDevice, s->stream));
+                    for (size_t k = 0; k < m; ++k) { const size_t i = rs[k]; const size_t nn = (size_t)nof(i) * nof(i); G2[k] = sub_buffer(G2_keep, (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16); }
+                }
+                if (m) {
+                    std::vector<EnvItem> idn; std::vector<JacobiItem> ji; size_t lds = 0;
+                    for (size_t k = 0; k < m; ++k) { const int n = nof(rs[k]); idn.push_back(EnvItem{nullptr, V2[k]->p, V2[k]->p, n}); ji.push_back(JacobiItem{G2[k]->p, V2[k]->p, n, n, nullptr}); lds = std::max(lds, jacobi_lds_bytes(n, n, true, 16)); }
+                    const EnvItem* di = upload(s, idn); const JacobiItem* dj = upload(s, ji);
+                    { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)m); }
+                    { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)m, 60, jacobi_lds(lds), mmax_of(ji)); }
+                    std::vector<Qr2ComposeItem> ci;
+                    for (size_t k = 0; k < m; ++k) {
+                        const size_t i = rs[k]; const int q = rq[k]; const bool second = (i & 1) != 0; const int n = nof(i);
+                        ci.push_back(Qr2ComposeItem{G2[k]->p, V2[k]->p, X1[k]->p, GV[i]->p, second ? gitems[q].lam2 : gitems[q].lam1, second ? gitems[q].idx2 : gitems[q].idx1,
+                                                    gitems[q].info + (second ? 1 : 0), n, rank_tau(false, n), GVn[k]->p, GWn[k]->p, reinterpret_cast<int*>(d_rk->p) + k});
+                    }
+                    { const Qr2ComposeItem* d = upload(s, ci); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_compose(s->stream, d, (int)m); }
+                    for (size_t k = 0; k < m; ++k) {
+                        const size_t i = rs[k]; GateItem& it = gitems[rq[k]];
+                        GV[i] = GVn[k]; GW[i] = GWn[k]; s->keepalive.push_back(X1[k]); if (Q1[k]) s->keepalive.push_back(Q1[k]); s->keepalive.push_back(G2[k]); s->keepalive.push_back(V2[k]);
+                        if (i & 1) { it.GV2 = GV[i]->p; it.GW2 = GW[i]->p; it.chol2 = 2; it.rk2 = reinterpret_cast<int*>(d_rk->p) + k; }
+                        else { it.GV1 = GV[i]->p; it.GW1 = GW[i]->p; it.chol1 = 2; it.rk1 = reinterpret_cast<int*>(d_rk->p) + k; }
+                    }
+                    s->keepalive.push_back(d_rk);
+                    d_gitems = upload(s, gitems);
+                    // gate_theta reads the first-pass (lambda, idx, r) of the untouched partner site again and overwrites them with the same values
+                    run_theta();
+                    if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
+                    HIPCHK(hipStreamSynchronize(s->stream));
+                    for (size_t k = 0; k < m; ++k) s->stats.n_qr2_sites += sj[rs[k]].owned ? 1 : 0;
+                }
+            }
+        }
+        for (size_t i = 0; i < envs.size(); ++i)
+            if (h_flags[2 * i + 1]) throw Err(TNQS_ERR_NUMERIC, "simple_update: incoming message has a negative eigenvalue above sqrt_cutoff (DomainError in the reference, src/utils.jl:21)");
+        std::vector<JacobiItem> ji; std::vector<int> ncfull;
+        for (int q = 0; q < npg; ++q) {
+            int gi = pg[q];
+            int r1 = hinfo[8 * q], r2 = hinfo[8 * q + 1];
+            int Mr = r1 * gitems[q].d1, Nc = r2 * gitems[q].d2;
+            if (Mr < Nc) std::swap(Mr, Nc);        // wide theta is stored as its adjoint (gate_theta_kernel)
+            const int ncolJ = hinfo[8 * q + 7] > 0 ? hinfo[8 * q + 7] : Nc;      // low-rank route: the SVD runs on M (Mr x K), same U and Sigma
+            ji.push_back(JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, ncolJ, gitems[q].info + 4});
+            ncfull.push_back(Nc); s->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0;
+        }
+        // LDS residency: A and V if both fit; A only (V recovered from the unrotated copy) if only A fits; else global memory
+        size_t lds_av = 0, lds_a = 0;
+        for (auto& j : ji) { lds_av = std::max(lds_av, jacobi_lds_bytes(j.m, j.n, true, esz)); lds_a = std::max(lds_a, jacobi_lds_bytes(j.m, j.n, false, esz)); }
+        const bool novee = theta0_used;
+        if (novee) for (auto& j : ji) j.V = nullptr;
+        (void)lds_av; (void)lds_a;
+        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); svd_batch<T>(s, ji, !novee); }
+        if (novee) {
+            std::vector<RecoverItem> rv;
+            for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ncfull[q], ji[q].n});
+            const RecoverItem* dr = upload(s, rv);
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); { int nmax = 1; for (int nc : ncfull) nmax = std::max(nmax, nc); if (std::is_same<T, float>::value && use_mfma()) launch_recover_v_mfma(s->stream, dr, npg, nmax); else launch_recover_v<T>(s->stream, dr, npg, nmax); } }
+        }
+        { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
+        std::vector<double> hterr(std::max(1, npg));
+        if (npg) {
+            HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipMemcpyAsync(hterr.data(), d_terr_all->p, (size_t)npg * 8, hipMemcpyDeviceToHost, s->stream));
+        }
+        HIPCHK(hipStreamSynchronize(s->stream));
+        for (int q = 0; q < npg; ++q) { for (int k = 0; k < 8; ++k) info[8 * pg[q] + k] = hinfo[8 * q + k]; terr[pg[q]] = hterr[q]; }
+    }
+    // ---- 4b. sharded: the owner of the first vertex publishes (chi', status, truncerr, S, X2) of each gate ----------------
+    std::vector<const double*> Sptr(ng, nullptr);
+    Buf S_keep;
+    if (sharded) {
+        const size_t slot_bytes = round256(32 + (size_t)cap_max * 8 + x2_max);
+        std::vector<size_t> slot(ng, 0); std::vector<size_t> rank_bytes(s->nranks, 0);
+        for (int gi = 0; gi < ng; ++gi) { int r = s->owner[gates[gi].v1]; slot[gi] = rank_bytes[r]; rank_bytes[r] += slot_bytes; }
+        size_t stride = 0; for (size_t b : rank_bytes) stride = std::max(stride, b);
+        check_exchange(s, stride);
+        char* base = reinterpret_cast<char*>(s->exch);
+        {   // pack the records of the gates whose first vertex is ours (one launch)
+            std::vector<RecordPackItem> rp;
+            std::vector<int> qof(ng, -1); for (int q = 0; q < npg; ++q) qof[pg[q]] = q;
+            for (int gi = 0; gi < ng; ++gi) {
+                if (s->owner[gates[gi].v1] != s->rank) continue;
+                const SiteJob& b = sj[2 * gi + 1]; const int q = qof[gi];
+                rp.push_back(RecordPackItem{base + (size_t)s->rank * stride + slot[gi], gitems[q].info, gitems[q].truncerr, reinterpret_cast<const double*>(ws[gi].S->p),
+                                            ws[gi].cap, ws[gi].X2->p, (long long)((size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz / 8), (long long)(32 + (size_t)cap_max * 8)});
+            }
+            if (!rp.empty()) { const RecordPackItem* d = upload(s, rp); launch_record_pack(s->stream, d, (int)rp.size()); }
+        }
+        exchange(s, stride);
+        // keep a private copy of the gathered block: the exchange buffer is reused by the next batch
+        S_keep = dalloc(s, std::max<size_t>(256, stride * (size_t)s->nranks));
+        HIPCHK(hipMemcpyAsync(S_keep->p, base, stride * (size_t)s->nranks, hipMemcpyDeviceToDevice, s->stream));
+        std::vector<double> allhdr(4 * (size_t)std::max(1, ng));
+        {   // all headers in one gather + one D2H
+            std::vector<const void*> srcs(ng);
+            for (int gi = 0; gi < ng; ++gi) srcs[gi] = reinterpret_cast<char*>(S_keep->p) + (size_t)s->owner[gates[gi].v1] * stride + slot[gi];
+            Buf d_hdr = dalloc(s, (size_t)std::max(1, ng) * 32);
+            const void* const* d_srcs = upload(s, srcs);
+            launch_header_gather(s->stream, d_srcs, ng, reinterpret_cast<double*>(d_hdr->p));
+            if (ng) HIPCHK(hipMemcpyAsync(allhdr.data(), d_hdr->p, (size_t)ng * 32, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+        }
+        for (int gi = 0; gi < ng; ++gi) {
+            info[8 * gi + 2] = (int)allhdr[4 * gi]; info[8 * gi + 3] = (int)allhdr[4 * gi + 1]; terr[gi] = allhdr[4 * gi + 2];
+            const size_t off = (size_t)s->owner[gates[gi].v1] * stride + slot[gi];
+            Sptr[gi] = reinterpret_cast<const double*>(reinterpret_cast<const char*>(S_keep->p) + off + 32);
+            const SiteJob& b = sj[2 * gi + 1];
+            if (b.owned && s->owner[gates[gi].v1] != s->rank)          // the partner rank computed the SVD: its X2 is used in place (a view)
+                ws[gi].X2 = sub_buffer(S_keep, off + 32 + (size_t)cap_max * 8, (size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz);
+        }
+    } else {
+        for (int gi = 0; gi < ng; ++gi) Sptr[gi] = (const double*)ws[gi].S->p;
+    }
+    // every gate's status is checked before anything of the handle is replaced: a failing batch leaves the state as it was
+    for (int gi = 0; gi < ng; ++gi) if (info[8 * gi + 3] != 0) throw Err(TNQS_ERR_NUMERIC, "simple_update: internal bond capacity exceeded");
+    // ---- 5. psi' = (psi x_outer P) x_(s,b) X  (simple_update.jl:62-64, net effect of gauge + ungauge) ----------------
+    std::vector<Chain> pch(own_idx.size());
+    for (size_t q = 0; q < own_idx.size(); ++q) {
+        const SiteJob& j = sj[own_idx[q]];
+        Chain& c = pch[q]; c.v = j.v; c.src = s->site[j.v]->p; c.sd = j.sd;
+        for (size_t e = 0; e < j.env_idx.size(); ++e)
+            if (!h_flags[2 * j.env_idx[e]]) c.steps.push_back({j.env_leg[e], envs[j.env_idx[e]].prj});  // rank-deficient message only
+    }
+    run_chains<T>(s, pch, TNQS_PROF_GATE_MODEPROD);
+    if (!own_idx.empty()) {
+        std::vector<FiberItem> items; std::vector<int> verts, tb, nt; std::vector<Buf> outs; std::vector<size_t> ne;
+        int tiles = 0; size_t KKmax = 1, NNmax = 1; double bytes = 0, flops = 0;
+        for (size_t q = 0; q < own_idx.size(); ++q) {
+            size_t i = own_idx[q];
+            KKmax = std::max<size_t>(KKmax, (size_t)sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]);
+            NNmax = std::max<size_t>(NNmax, (size_t)sj[i].sd.d * info[8 * (i / 2) + 2]);
+        }
+        int TR = pick_TR(KKmax, esz, 1);
+        bool mf = false;
+        if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)NNmax); if (t > 0) { TR = t; mf = true; } }
+        // plane kernel for the common shape d = 2, chi_b = chi_b' = 32 (pair-kernel geometry, two waves per SIMD)
+        std::vector<Apply64Item> a64; std::vector<XbItem> xbi; std::vector<int> a64_verts; std::vector<Buf> a64_outs; std::vector<size_t> a64_ne;
+        std::vector<char> via64(own_idx.size(), 0); double a64_slices = 0;
+        if (std::is_same<T, float>::value && use_mfma() && use_apply64()) {
+            for (size_t q = 0; q < own_idx.size(); ++q) {
+                size_t i = own_idx[q]; int gi = (int)i / 2; const SiteJob& j = sj[i];
+                Apply64Item it{};
+                if (info[8 * gi + 2] != 32 || j.sd.chi[j.bleg] != 32 || !apply64_geometry(j.sd.d, j.sd.z, j.sd.chi.data(), j.bleg, it.g)) continue;
+                Buf out = dalloc(s, j.sd.n * esz); Buf xb = dalloc(s, 2048 * 16); s->keepalive.push_back(xb);
+                it.in = pch[q].result; it.out = out->p; it.Xb = xb->p;
+                xbi.push_back(XbItem{(i & 1) ? ws[gi].X2->p : ws[gi].X1->p, xb->p});
+                a64.push_back(it); a64_verts.push_back(j.v); a64_outs.push_back(out); a64_ne.push_back(j.sd.n);
+                a64_slices += (double)j.sd.n / 16384.0; via64[q] = 1;
+            }
+        }
+        if (!a64.empty()) {
+            const int spw = (int)std::max(1.0, std::min(8.0, a64_slices / 2048.0));
+            std::vector<int> tb64, nt64; int wgs = 0;
+            for (auto& it : a64) { int nwg = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw; it.spw = spw; it.wg_begin = wgs; tb64.push_back(wgs); nt64.push_back(nwg); wgs += nwg; }
+            Buf np64 = dalloc(s, (size_t)wgs * sizeof(double));
+            for (size_t k = 0; k < a64.size(); ++k) a64[k].norm_partial = ao.normalize_tensors ? reinterpret_cast<double*>(np64->p) + tb64[k] : nullptr;
+            const XbItem* dx = upload(s, xbi); const Apply64Item* da = upload(s, a64);
+            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_make_xb(s->stream, dx, (int)xbi.size()); }
+            { ProfScope ps(s, TNQS_PROF_GATE_APPLY, 2.0 * a64_slices * 16384.0 * esz, 8.0 * a64_slices * 16384.0 * 64);
+              launch_mfma_apply64(s->stream, da, (int)a64.size(), wgs); }
+            norm_and_replace<T>(s, a64_verts, a64_outs, a64_ne, np64, tb64, nt64, ao.normalize_tensors != 0);
+        }
+        {   // chi = 64 sites: K = (s, b) = 128 -> N = (s', b') <= 128 on the register-direct MFMA kernel
+            std::vector<FiberItem> rg; std::vector<int> rverts, rtb, rnt; std::vector<Buf> routs; std::vector<size_t> rne; double rt = 0, rby = 0, rfl = 0;
+            if (std::is_same<T, float>::value && use_mfma() && use_rowgemm())
+                for (size_t q = 0; q < own_idx.size(); ++q) {
+                    if (via64[q]) continue;
+                    size_t i = own_idx[q]; int gi = (int)i / 2; int chin = info[8 * gi + 2]; const SiteJob& j = sj[i];
+                    FiberItem it{};
+                    it.D = j.sd.d; it.PA = (int)(j.sd.pre(j.bleg) / j.sd.d); it.K = j.sd.chi[j.bleg]; it.PB = (int)j.sd.post(j.bleg); it.Do = j.sd.d; it.No = chin;
+                    if (!rowgemm_covers(it) || it.D != 2) continue;
+                    const size_t nout = j.sd.n / it.K * chin;
+                    Buf out = dalloc(s, nout * esz);
+                    it.in = pch[q].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
+                    rowgemm_tiles(it); it.want_norm = ao.normalize_tensors ? 1 : 0;
+                    rg.push_back(it); rverts.push_back(j.v); routs.push_back(out); rne.push_back(nout); rt += (double)it.nta * it.ntb;
+                    rby += (double)(j.sd.n + nout) * esz; rfl += 8.0 * j.sd.n * j.sd.d * chin; via64[q] = 1;
+                }
+            if (!rg.empty()) {
+                int tpw = (int)std::max(4.0, std::min(32.0, rt / 2048.0)); tpw &= ~3; int wgs = 0;
+                for (auto& it : rg) { const int nwg = (it.nta * it.ntb + tpw - 1) / tpw; it.tpw = tpw; it.tile_begin = wgs; rtb.push_back(wgs); rnt.push_back(nwg); wgs += nwg; }
+                Buf npr = dalloc(s, (size_t)wgs * sizeof(double));
+                const FiberItem* d = upload(s, rg);
+                { ProfScope ps(s, TNQS_PROF_GATE_APPLY, rby, rfl); launch_mfma_rowgemm(s->stream, d, (int)rg.size(), wgs, 2, reinterpret_cast<double*>(npr->p)); }
+                norm_and_replace<T>(s, rverts, routs, rne, npr, rtb, rnt, ao.normalize_tensors != 0);
+            }
+        }
+        for (size_t q = 0; q < own_idx.size(); ++q) {
+            if (via64[q]) continue;
+            size_t i = own_idx[q];
+            int gi = (int)i / 2; int chin = info[8 * gi + 2];
+            const SiteJob& j = sj[i];
+            size_t pre = j.sd.pre(j.bleg), post = j.sd.post(j.bleg);
+            int chi = j.sd.chi[j.bleg];
+            size_t nout = j.sd.n / chi * chin;
+            FiberItem it{}; Buf out = dalloc(s, nout * esz);
+            it.in = pch[q].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
+            it.D = j.sd.d; it.PA = (int)(pre / j.sd.d); it.K = chi; it.PB = (int)post; it.Do = j.sd.d; it.No = chin;
+            tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
+            it.tpw = mf ? (TR == 32 ? 16 : 4) : 1;
+            const int nwg = (it.nta * it.ntb + it.tpw - 1) / it.tpw;
+            it.tile_begin = tiles; it.want_norm = ao.normalize_tensors ? 1 : 0;
+            verts.push_back(j.v); outs.push_back(out); ne.push_back(nout); tb.push_back(tiles); nt.push_back(nwg);
+            tiles += nwg; items.push_back(it);
+            bytes += (double)(j.sd.n + nout) * esz; flops += 8.0 * j.sd.n * j.sd.d * chin;
+        }
+        Buf np = dalloc(s, std::max(1, tiles) * sizeof(double));
+        const FiberItem* d = upload(s, items);
+        if (!items.empty())
+        { ProfScope ps(s, TNQS_PROF_GATE_APPLY, bytes, flops);
+          if (mf) launch_mfma_fiber_gemm(s->stream, d, (int)items.size(), tiles, (int)KKmax, (int)NNmax, reinterpret_cast<double*>(np->p));
+          else launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
+        norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, ao.normalize_tensors != 0);
+    }
+    // ---- 6. both bond messages := diag(S)  (apply_gates.jl:126-135), new bond dimension ---------------------------
+    {
+        std::vector<DiagItem> di;
+        for (int gi = 0; gi < ng; ++gi) {
+            int e = g.edge(gates[gi].v1, gates[gi].v2); int chin = info[8 * gi + 2];
+            s->chi[e] = chin;
+            for (int dir = 0; dir < 2; ++dir) {
+                Buf m = dalloc(s, (size_t)chin * chin * esz);
+                di.push_back(DiagItem{m->p, Sptr[gi], chin});
+                s->msg[2 * e + dir] = m;
+            }
+            if (errs) errs[gates[gi].index] = terr[gi];
+        }
+        const DiagItem* d = upload(s, di);
+        { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_diag<T>(s->stream, d, (int)di.size()); }
+    }
+    s->stats.n_two_site += ng;
+    sync(s);   // workspace of this batch is released to the pool after the stream drained
+}
+
+template <class T> static void flush_batch(State* s, std::vector<Gate1>& b1, std::vector<Gate2>& b2, const tnqs_apply_opts& ao, double* errs) {
+    if (b1.empty() && b2.empty()) return;
+    apply_one_site_batch<T>(s, b1, ao.normalize_tensors != 0);
+    apply_two_site_batch<T>(s, b2, ao, errs);
+    s->stats.n_batches += 1;
+    b1.clear(); b2.clear();
+    sync(s);
+}
+
+template <class T> static void apply_gates_t(State* s, int ngates, const int32_t* nverts, const int32_t* verts, const double* mats,
+                                             const tnqs_apply_opts* opts, const tnqs_bp_opts* bp, double* errs) {
+    const Graph& g = *s->g;
+    HIPCHK(hipSetDevice(s->device));
+    tnqs_apply_opts ao; ao.maxdim = 0; ao.cutoff = -1; ao.normalize_tensors = 1; ao.sqrt_cutoff = -1; ao.update_cache = 1;
+    if (opts) ao = *opts;
+    // validation first (apply_gates.jl:109-120): nothing is mutated when an argument is bad
+    std::vector<int> voff(ngates + 1, 0); std::vector<size_t> moff(ngates + 1, 0);
+    for (int i = 0; i < ngates; ++i) {
+        int nv = nverts[i];
+        if (nv < 1 || nv > 2) throw Err(TNQS_ERR_INVALID, "apply_gate!: only one- and two-site gates are supported; received a gate acting on " + std::to_string(nv) + " vertices.");
+        voff[i + 1] = voff[i] + nv;
+        size_t dd = 1;
+        for (int k = 0; k < nv; ++k) { int v = verts[voff[i] + k]; if (v < 0 || v >= g.nv) throw Err(TNQS_ERR_INVALID, "apply_gates: vertex out of range"); dd *= s->d[v]; }
+        moff[i + 1] = moff[i] + 2 * dd * dd;
+        if (nv == 2) {
+            int a = verts[voff[i]], b = verts[voff[i] + 1];
+            if (a == b || g.edge(a, b) < 0)
+                throw Err(TNQS_ERR_INVALID, "apply_gate!: cannot apply a two-site gate on the non-adjacent vertices " + std::to_string(a) + " and " + std::to_string(b) +
+                                                ". Simple update requires the two sites to share an edge of the tensor-network graph.");
+        }
+    }
+    if (errs) std::fill(errs, errs + ngates, 0.0);
+    if (s->real_io) {       // adapt_gate (apply_gates.jl:41-44): a real gate takes the state's real type, a complex gate stays complex and promotes
+        bool cplx = false;
+        for (size_t k = 1; k < moff[ngates] && !cplx; k += 2) cplx = mats[k] != 0.0;
+        if (cplx) s->real_io = false;
+    }
+    std::set<int> affected, batch_verts;
+    std::vector<Gate1> b1; std::vector<Gate2> b2;
+    for (int i = 0; i < ngates; ++i) {
+        const int nv = nverts[i]; const int32_t* vs = verts + voff[i];
+        bool need = false;
+        if (nv >= 2) for (int k = 0; k < nv; ++k) need = need || affected.count(vs[k]);            // apply_gates.jl:68
+        if (ao.update_cache && need) {
+            flush_batch<T>(s, b1, b2, ao, errs); batch_verts.clear();
+            bp_update_t<T>(s, bp, nullptr, nullptr);                                               // :76
+            affected.clear();                                                                      // :78
+        }
+        bool overlap = false;
+        for (int k = 0; k < nv; ++k) overlap = overlap || batch_verts.count(vs[k]);
+        if (overlap) { flush_batch<T>(s, b1, b2, ao, errs); batch_verts.clear(); }
+        if (nv == 1) b1.push_back(Gate1{vs[0], mats + moff[i]}); else b2.push_back(Gate2{vs[0], vs[1], mats + moff[i], i});
+        for (int k = 0; k < nv; ++k) { batch_verts.insert(vs[k]); affected.insert(vs[k]); }         // :88-90
+    }
+    flush_batch<T>(s, b1, b2, ao, errs);
+    if (ao.update_cache) bp_update_t<T>(s, bp, nullptr, nullptr);                                   // :93-95
+}
+
+void apply_gates(State* s, int ngates, const int32_t* nverts, const int32_t* verts, const double* mats,
+                 const tnqs_apply_opts* opts, const tnqs_bp_opts* bp, double* errs) {
+    s->stats = tnqs_apply_stats{};
+    if (s->dtype == TNQS_C64) apply_gates_t<float>(s, ngates, nverts, verts, mats, opts, bp, errs);
+    else apply_gates_t<double>(s, ngates, nverts, verts, mats, opts, bp, errs);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// truncate (src/truncate.jl:12-38)
+// ---------------------------------------------------------------------------------------------------------------
+template <class T> static void truncate_t(State* s, int maxdim, double cutoff, int normalize, int ngroups, const int32_t* offs,
+                                          const int32_t* eu, const int32_t* ev, const tnqs_bp_opts* bp) {
+    const Graph& g = *s->g;
+    HIPCHK(hipSetDevice(s->device));
+    if (maxdim <= 0) throw Err(TNQS_ERR_INVALID, "truncate: maxdim must be a positive integer");
+    tnqs_apply_opts ao; ao.maxdim = maxdim; ao.cutoff = cutoff; ao.normalize_tensors = normalize; ao.sqrt_cutoff = -1; ao.update_cache = 1;
+    std::vector<std::vector<double>> idmats;
+    auto ident = [&](int dd) { std::vector<double> m(2 * (size_t)dd * dd, 0.0); for (int i = 0; i < dd; ++i) m[2 * (size_t)(i + (size_t)dd * i)] = 1.0; return m; };
+    auto run_group = [&](const std::vector<std::pair<int, int>>& edges) {
+        std::vector<Gate2> b2; std::set<int> seen; idmats.clear(); idmats.reserve(edges.size());
+        for (auto& pr : edges) {
+            int e = g.edge(pr.first, pr.second);
+            if (e < 0) throw Err(TNQS_ERR_INVALID, "truncate: colour group contains a non-edge");
+            if (s->chi[e] == 1) continue;                                   // truncatable_edge (:5-10)
+            if (seen.count(pr.first) || seen.count(pr.second)) throw Err(TNQS_ERR_INVALID, "truncate: edges of one colour group must be vertex-disjoint");
+            seen.insert(pr.first); seen.insert(pr.second);
+            idmats.push_back(ident(s->d[pr.first] * s->d[pr.second]));
+            b2.push_back(Gate2{pr.first, pr.second, idmats.back().data(), 0});
+        }
+        apply_two_site_batch<T>(s, b2, ao, nullptr);
+        if (!b2.empty()) s->stats.n_batches += 1;
+        bp_update_t<T>(s, bp, nullptr, nullptr);                               // :28 / :34
+    };
+    if (ngroups > 0) {
+        for (int c = 0; c < ngroups; ++c) {
+            std::vector<std::pair<int, int>> edges;
+            for (int i = offs[c]; i < offs[c + 1]; ++i) edges.push_back({eu[i], ev[i]});
+            run_group(edges);
+        }
+    } else {
+        for (int e = 0; e < g.ne; ++e) run_group({{g.esrc[e], g.edst[e]}});
+    }
+}
+void truncate_bp(State* s, int maxdim, double cutoff, int normalize, int ngroups, const int32_t* offs,
+                 const int32_t* eu, const int32_t* ev, const tnqs_bp_opts* bp) {
+    s->stats = tnqs_apply_stats{};
+    if (s->dtype == TNQS_C64) truncate_t<float>(s, maxdim, cutoff, normalize, ngroups, offs, eu, ev, bp);
+    else truncate_t<double>(s, maxdim, cutoff, normalize, ngroups, offs, eu, ev, bp);
+}
+
+}  // namespace tnqs

@@ -1,0 +1,159 @@
+// engine_internal.hpp -- declarations shared by the translation units of the host engine:
+//   engine_core.cpp   pool, graph, state container, tensor / message I/O
+//   engine_batch.cpp  batched building blocks: mode-product chains, Gram jobs, the SVD batch
+//   engine_bp.cpp     BP update (default sequence, level schedule, message kernels)
+//   engine_gates.cpp  apply_gates scheduler, one- and two-site gate batches, truncate
+//   engine_obs.cpp    observables, BP scalars / rescale, symmetric gauge
+//   sharding.cpp      exchange step (RCCL or host callback)
+#pragma once
+#include "engine.hpp"
+#include "kernels.hpp"
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <numeric>
+#include <set>
+#include <type_traits>
+#include <unordered_map>
+
+namespace tnqs {
+
+#define HIPCHK(x) hipchk((x), #x)
+
+// ---- environment switches (all default off; read once per process).  They select alternative routes of the SAME algorithm for A/B
+// measurements and for the route-equivalence tests (tests/test_gpu_toggles.py); nothing else steers the hot path. -----------------------
+inline bool envflag(const char* name) { const char* e = std::getenv(name); return e && e[0] == '1'; }
+#define TNQS_SWITCH(fn, expr) inline bool fn() { static const bool v = (expr); return v; }
+TNQS_SWITCH(use_mfma, !envflag("TNQS_NO_MFMA"))                  // no matrix-core kernel at all: the generic tiled kernels (kernels.hip)
+TNQS_SWITCH(use_pair, !envflag("TNQS_NO_PAIR"))                  // no plane kernels (two legs per pass, pair-Gram, chi = 16 / 32): single-leg products
+TNQS_SWITCH(use_tshare, !envflag("TNQS_NO_TSHARE"))              // degree-4 chi = 32 sites: no pair product shared by the two messages of a forest
+TNQS_SWITCH(use_dbl, !envflag("TNQS_NO_DOUBLE_GRAM"))            // one pair-Gram pass per message instead of both messages of a forest per pass
+TNQS_SWITCH(use_prefix, !envflag("TNQS_NO_PREFIX"))              // BP: no shared partial product for the messages a site sends in one level
+TNQS_SWITCH(use_chol, !envflag("TNQS_NO_CHOL"))                  // R factor from the eigen factorisation of the Gram matrix instead of Cholesky
+TNQS_SWITCH(use_qr2, !envflag("TNQS_NO_QR2"))                    // ComplexF64: no second factorisation pass; TNQS_QR2_ALL=1: on every site
+TNQS_SWITCH(use_lowrank, !envflag("TNQS_NO_LOWRANK"))            // theta SVD on the full theta instead of the low-rank factor
+TNQS_SWITCH(use_small_svd, !envflag("TNQS_NO_SMALLSVD"))         // sites with fewer fibers than columns: Gram + eigen instead of the direct SVD
+TNQS_SWITCH(use_apply64, !envflag("TNQS_NO_APPLY64"))            // chi = 32 gate epilogue on the fiber kernel instead of the plane kernel
+TNQS_SWITCH(eager_scale, envflag("TNQS_EAGER_SCALE"))            // apply 1/||psi|| after every gate instead of deferring it
+// chi = 64 kernels (kernels_chi64.hip); TNQS_NO_CHI64=1 switches all of them off
+TNQS_SWITCH(use_rowgemm, !(envflag("TNQS_NO_ROWGEMM") || envflag("TNQS_NO_CHI64")))      // register-direct MFMA fiber GEMM
+TNQS_SWITCH(use_gram64, !(envflag("TNQS_NO_GRAM64") || envflag("TNQS_NO_CHI64")))        // 64 x 64 f32 MFMA Gram
+TNQS_SWITCH(use_gram128, !(envflag("TNQS_NO_GRAM128") || envflag("TNQS_NO_CHI64")))      // 128 x 128 f64 MFMA Gram
+TNQS_SWITCH(use_chol128, !(envflag("TNQS_NO_CHOL128") || envflag("TNQS_NO_CHI64")))      // Cholesky for 96 < n <= 128 (packed triangle)
+TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64")))     // Cholesky-QR preprocessed theta SVD
+#undef TNQS_SWITCH
+// TNQS_JACOBI_GLOBAL=1: every Jacobi factorisation in the global-memory kernel;  TNQS_BP_WS_MB: workspace bound of a BP sub-batch (MiB);
+// TNQS_HOST_TIMING=1: host-side phase timers printed at exit;  TNQS_RCCL_LIB: path of librccl.so (sharding.cpp);
+// kernels_mfma.hip reads TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP, TNQS_DBG_PAIR_SKIP, TNQS_DBG_GRAM_SKIP (kernel experiments)
+inline size_t bp_ws_budget() { static const size_t v = [] { const char* e = std::getenv("TNQS_BP_WS_MB"); return (e ? (size_t)std::atoll(e) : (size_t)24576) << 20; }(); return v; }
+inline size_t jacobi_lds(size_t bytes) { static const bool g = envflag("TNQS_JACOBI_GLOBAL"); return (g || bytes > 160 * 1024 - 256) ? 0 : bytes; }
+inline int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j : ji) m = std::max(m, std::max(j.m, j.n)); return m; }
+
+// optional host-side phase timing (TNQS_HOST_TIMING=1): printed when the process exits
+struct HostTimer {
+    static double acc[8]; static long cnt[8];
+    int k; std::chrono::steady_clock::time_point t0; bool on;
+    explicit HostTimer(int kk) : k(kk), t0(std::chrono::steady_clock::now()), on(true) {}
+    void stop() { if (on) { acc[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); cnt[k]++; on = false; } }
+    ~HostTimer() { stop(); }
+};
+
+void sync(State* s);                                   // stream synchronise + release of the batch's descriptor buffers
+void materialize_scale(State* s, const std::vector<int>& verts);
+void materialize_scale_all(State* s);
+inline Buf dalloc(State* s, size_t bytes) {
+    auto b = std::make_shared<DevBuf>();
+    b->pool = s->pool; b->bytes = bytes;
+    b->p = s->pool->alloc(bytes ? bytes : 1, &b->rounded);
+    return b;
+}
+// descriptor upload through the handle's pinned staging arena (reset at host sync points)
+HostArena acquire_arena();                          // a recycled or freshly pinned 32 MiB arena (engine_core.cpp)
+template <class Item> const Item* upload(State* s, const std::vector<Item>& v) {
+    if (v.empty()) return nullptr;
+    size_t bytes = v.size() * sizeof(Item);
+    HostArena& ar = s->arena;
+    if (!ar.base) ar = acquire_arena();
+    size_t aligned = (bytes + 255) & ~size_t(255);
+    if (aligned > ar.cap) throw Err(TNQS_ERR_UNSUPPORTED, "descriptor batch too large");
+    if (ar.off + aligned > ar.cap) sync(s);
+    char* h = ar.base + ar.off; ar.off += aligned;
+    std::memcpy(h, v.data(), bytes);
+    Buf b = dalloc(s, bytes);
+    HIPCHK(hipMemcpyAsync(b->p, h, bytes, hipMemcpyHostToDevice, s->stream));
+    s->keepalive.push_back(b);
+    return reinterpret_cast<const Item*>(b->p);
+}
+
+struct ProfScope {
+    State* s; int cls; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(State* st, int c, double bytes, double flops) : s(st), cls(c) {
+        Prof& P = *s->prof;
+        if (!P.on) return;
+        P.cls[c].bytes += bytes; P.cls[c].flops += flops; P.cls[c].launches += 1;
+        auto get = [&]() { hipEvent_t e; if (!P.ev_free.empty()) { e = P.ev_free.back(); P.ev_free.pop_back(); } else HIPCHK(hipEventCreate(&e)); return e; };
+        a = get(); b = get();
+        HIPCHK(hipEventRecord(a, s->stream));
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, s->stream);
+        s->prof->pending.push_back({cls, a, b});
+    }
+};
+
+struct SD {       // dims of a site tensor in canonical layout
+    int z = 0, d = 1; std::vector<int> chi; size_t n = 1;
+    size_t pre(int j) const { size_t p = d; for (int i = 0; i < j; ++i) p *= chi[i]; return p; }
+    size_t post(int j) const { size_t p = 1; for (int i = j + 1; i < z; ++i) p *= chi[i]; return p; }
+};
+inline SD site_dims(const State* s, int v) {
+    SD r; const Graph& g = *s->g;
+    r.z = (int)g.nbr[v].size(); r.d = s->d[v]; r.n = r.d;
+    for (int j = 0; j < r.z; ++j) { int c = s->chi[g.nbr_e[v][j]]; r.chi.push_back(c); r.n *= c; }
+    return r;
+}
+
+inline size_t round256(size_t b) { return (b + 255) & ~size_t(255); }
+void exchange(State* s, size_t bytes_per_rank);                       // sharding.cpp
+void check_exchange(const State* s, size_t bytes_per_rank);           // call BEFORE enqueuing anything that writes into s->exch
+
+inline int pick_TR(size_t KK, size_t esz, int copies) {
+    for (int tr : {64, 32, 16, 8, 4}) if (KK * tr * esz * copies <= 64 * 1024) return tr;
+    throw Err(TNQS_ERR_UNSUPPORTED, "bond dimension too large for the fiber-tile kernels (d*chi*16*elemsize must fit 64 KiB of LDS)");
+}
+inline void tile_params(size_t PA, size_t PB, int TR, int& TA, int& TB, int& nta, int& ntb) {
+    TA = (int)std::min<size_t>(PA, TR); TB = std::max(1, TR / TA); TB = (int)std::min<size_t>(TB, PB);
+    nta = (int)((PA + TA - 1) / TA); ntb = (int)((PB + TB - 1) / TB);
+}
+
+
+// a chain = one site tensor pushed through several mode products (leg j with matrix X_j, chi_j x chi_j)
+struct Chain {
+    int v = -1; const void* src = nullptr; SD sd;
+    const void* y = nullptr;                     // the untouched site tensor when src is a shared partial product of it (BP prefix sharing)
+    std::vector<std::pair<int, const void*>> steps;
+    const void* result = nullptr; Buf tmp[2];
+};
+
+
+struct GramJob {      // out[i,j] = sum X[i,.] conj(Y[j,.]) over everything but the kept index (s and/or leg)
+    const void* X; const void* Y; SD sd; int leg;  /* -1: keep the site index only */ bool keep_site;
+    Buf partial; int nchunks = 0; int KK = 0;
+    const void* M = nullptr;       // fused path: message absorbed on the first row leg inside the Gram kernel
+};
+
+template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls, int cls_pair = -1);
+template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& jobs, int cls);
+template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, bool with_v);
+template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out);
+
+}  // namespace tnqs

@@ -5,7 +5,7 @@
 //     torch.distributed's store), and the in-place ncclAllGather is ENQUEUED ON THE HANDLE'S STREAM -- no stream synchronisation, no
 //     host callback, no Python in the loop;
 //   * a host callback (tnqs_set_sharding), kept for the gloo-based tests in which several ranks share one GPU (RCCL refuses that).
-#include "engine.hpp"
+#include "engine_internal.hpp"
 #include <dlfcn.h>
 #include <cstring>
 #include <mutex>
@@ -105,5 +105,24 @@ void rccl_selftest(int device, int64_t bytes) {
     ncclchk(rc, "ncclAllGather"); hipchk(e1, "D2H"); hipchk(e2, "hipStreamSynchronize");
     if (back != host) throw Err(TNQS_ERR_COMM, "rccl_selftest: data mismatch after the all-gather");
 }
+
+
+// all-gather of equal-sized per-rank blocks laid out back to back in the host-provided exchange buffer
+void check_exchange(const State* s, size_t bytes_per_rank) {
+    if (s->nranks <= 1) return;
+    if (bytes_per_rank * (size_t)s->nranks > s->exch_bytes)
+        throw Err(TNQS_ERR_COMM, "exchange buffer too small for this batch: " + std::to_string(bytes_per_rank * (size_t)s->nranks) + " bytes needed, " +
+                                     std::to_string(s->exch_bytes) + " available (raise the buffer size passed to tnqs_set_sharding)");
+}
+void exchange(State* s, size_t bytes_per_rank) {
+    if (s->nranks <= 1) return;
+    check_exchange(s, bytes_per_rank);
+    if (s->comm) { rccl_allgather(s, bytes_per_rank); return; }       // RCCL: enqueued on the handle's stream, nothing to wait for here
+    if (!s->ag_fn) throw Err(TNQS_ERR_COMM, "sharded handle without a transport (tnqs_set_sharding_rccl or tnqs_set_sharding)");
+    HIPCHK(hipStreamSynchronize(s->stream));
+    int rc = s->ag_fn(s->ag_ctx, s->exch, (int64_t)bytes_per_rank, s->nranks);
+    if (rc != 0) throw Err(TNQS_ERR_COMM, "all-gather callback failed");
+}
+
 
 }  // namespace tnqs

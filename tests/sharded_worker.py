@@ -125,6 +125,7 @@ def main():
                 out.append(complex("nan"))
         return np.array(out)
     zz_sh = multi(bs) if extra else np.zeros(0)
+    mraw_sh = [bs.message(e) for e in ((vs[0], vs[1]), (vs[1], vs[0]))] if extra else []
     if extra:
         bg = tn.symmetric_gauge(bs)
         ezg = tn.expect_all(bg, "Z")
@@ -148,6 +149,11 @@ def main():
             zz_un = multi(bu); bgu = tn.symmetric_gauge(bu); ezg_un = tn.expect_all(bgu, "Z"); sg_un = np.sort(np.abs(np.diag(bgu.message((vs[0], vs[1])))))
         else:
             zz_un, ezg_un, sg_un = np.zeros(0), np.zeros(0), np.zeros(0)
+        if extra:
+            mraw_un = [bu.message(e) for e in ((vs[0], vs[1]), (vs[1], vs[0]))]
+            print("raw message difference before the gauge:", [float(np.max(np.abs(a - b))) for a, b in zip(mraw_sh, mraw_un)],
+                  " sums:", [complex(a.sum()) for a in mraw_sh], [complex(b.sum()) for b in mraw_un], flush=True)
+            print("S sharded:", sg[-4:], " S single:", sg_un[-4:], " normalised difference:", float(np.max(np.abs(sg / np.linalg.norm(sg) - sg_un / np.linalg.norm(sg_un)))), flush=True)
         np.savez(out, zz_sh=zz_sh, zz_un=zz_un, ezg_sh=ezg_full, ezg_un=ezg_un, sg_sh=sg, sg_un=sg_un, errs_sh=es, errs_un=eu, ez_sh=ez_full, ez_un=ezu, sp_sh=np.concatenate(spectra), sp_un=np.concatenate(spu),
                  dims_sh=dims, dims_un=np.array([bu.bond_dim(a, b) for (a, b) in g.edges]), n_exchanges=nex,
                  transport=type(bs._shard).__name__)

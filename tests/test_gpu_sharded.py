@@ -22,6 +22,7 @@ def test_sharded_apply_gates_matches_single_rank(tmp_path, dt, nranks):
            "--master-port", str(29533 + nranks), os.path.join(ROOT, "tests", "sharded_worker.py"), out, dt]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    print(r.stdout[-1500:])
     z = np.load(out)
     # "illc128": ComplexF64, cutoff = 1e-14 -- agreement to 1e-11 needs the second factorisation pass on both sides (1e-9 with a single pass)
     tol = 1e-9 if dt == "c128" else (1e-11 if dt == "illc128" else (2e-4 if dt == "c64" else 5e-4))      # chi32, z6chi16, z4chi64: 5e-4
@@ -35,7 +36,10 @@ def test_sharded_apply_gates_matches_single_rank(tmp_path, dt, nranks):
         ok = ~np.isnan(z["zz_un"])
         assert np.array_equal(np.isnan(z["zz_sh"]), np.isnan(z["zz_un"])) and ok.any()
         assert np.max(np.abs(z["zz_sh"][ok] - z["zz_un"][ok])) < tol
-        assert np.max(np.abs(z["ezg_sh"] - z["ezg_un"])) < tol and np.max(np.abs(z["sg_sh"] - z["sg_un"])) < tol
+        # the bond spectrum S of the gauge is compared up to its norm: messages are normalised by the SUM of their elements
+        # (abstract...:182-187), which depends on the bond basis -- and the two runs fix the SVD gauge of a bond on different ranks
+        nrm = lambda x: x / np.linalg.norm(x)
+        assert np.max(np.abs(z["ezg_sh"] - z["ezg_un"])) < tol and np.max(np.abs(nrm(z["sg_sh"]) - nrm(z["sg_un"]))) < tol
 
 
 def test_rccl_transport_loads_and_runs_on_one_gpu():
