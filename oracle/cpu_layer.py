@@ -10,8 +10,9 @@ it on a many-core host, so that `bench.py`'s `cpu_baseline` can adjudicate a GPU
   * the schedule is the reference's (apply_gates.jl:46-98: a BP update before every colour group, a final one; Gauss-Seidel sweeps over
     the cache's edge sequence), executed the way the device engine executes it: the messages of a sweep are grouped into dependency
     levels (a message only waits for the messages it reads that precede it in the sequence -- same values as the sequential loop), the
-    gates of a colour group are vertex-disjoint; the members of a level / group run on a thread pool, with cores / members BLAS threads
-    each (numpy releases the GIL inside BLAS / LAPACK and its copy loops).
+    gates of a colour group are vertex-disjoint; the members of a level / group run on a thread pool (numpy releases the GIL inside
+    BLAS / LAPACK and its copy loops), and when there are fewer members than cores the contractions of a member are chunked onto the
+    idle workers of the same pool; BLAS itself runs single-threaded per call.
 
 `measure()` also measures what the host's BLAS delivers on (a) a large square ComplexF32 GEMM with all threads and (b) the mode-product
 shape of the workload ((2 chi^3) x chi times chi x chi) on the same thread pool, and reports the layer's algorithmic GFLOP/s
@@ -78,11 +79,23 @@ def _message(bpc, fresh: Dict, pos: Dict, t: int, e, normalize=True) -> np.ndarr
     return m.astype(psi.dtype, copy=False)
 
 
-def _blas_threads(ntasks: int, nthreads: int):
-    """BLAS threads per task so that tasks x threads fills the host: a level / colour group with fewer members than cores gives each
-    member several BLAS threads (threadpoolctl's limit is process wide, which is what is wanted: all members of one map get the same)"""
-    from threadpoolctl import threadpool_limits
-    return threadpool_limits(limits=max(1, nthreads // max(1, ntasks)))
+class _Inner:
+    """the oracle's chunked contractions (tnqs_oracle._absorb / _gram split their loop over the untouched indices into 4 x _max_workers
+    chunks) running on the SAME thread pool as the tasks that call them: a level / colour group with fewer members than cores gives every
+    member cores / members workers' worth of chunks.  BLAS itself stays single-threaded: concurrent callers of a multi-threaded OpenBLAS
+    queue up behind its global lock (measured: 2 BLAS threads x 64 tasks ran 1.6x SLOWER than 1 x 64).  No deadlock: the members of a map
+    (<= cores / 2 of them block waiting for their chunks) leave at least as many workers free."""
+
+    def __init__(self, pool: ThreadPoolExecutor, width: int):
+        self._pool, self._max_workers = pool, max(1, width)
+
+    def map(self, fn, it):
+        return self._pool.map(fn, it)
+
+
+def _inner(pool: ThreadPoolExecutor, ntasks: int):
+    width = pool._max_workers // max(1, ntasks) // 2
+    return _Inner(pool, width) if (width >= 1 and ntasks * 2 <= pool._max_workers) else _Serial()
 
 
 def update(bpc, pool: ThreadPoolExecutor, maxiter: Optional[int] = None, tolerance: Optional[float] = None, info: Optional[dict] = None):
@@ -98,8 +111,8 @@ def update(bpc, pool: ThreadPoolExecutor, maxiter: Optional[int] = None, toleran
         fresh: Dict = {}
         diffs = [0.0] * len(seq)
         for lev in levels:
-            with _blas_threads(len(lev), pool._max_workers):
-                res = list(pool.map(lambda t: _message(bpc, fresh, pos, t, seq[t]), lev))
+            o._POOL = _inner(pool, len(lev))
+            res = list(pool.map(lambda t: _message(bpc, fresh, pos, t, seq[t]), lev))
             for t, m in zip(lev, res):
                 if tolerance is not None:
                     diffs[t] = o.message_diff(m, bpc.message(seq[t]))
@@ -123,8 +136,8 @@ def apply_layer(bpc, one_site: List, colour_groups: List[List], pool: ThreadPool
     def one(gate):
         mat, verts = o.resolve_gate(gate)
         return o.apply_gate(bpc, mat, verts, **apply_kwargs)
-    with _blas_threads(len(one_site), pool._max_workers):
-        list(pool.map(one, one_site))
+    o._POOL = _inner(pool, len(one_site))
+    list(pool.map(one, one_site))
     errs = []
     for grp in colour_groups:
         inf = {}
@@ -135,8 +148,8 @@ def apply_layer(bpc, one_site: List, colour_groups: List[List], pool: ThreadPool
         def two(gate, b=bpc):
             mat, verts = o.resolve_gate(gate)
             return o.apply_gate(b, mat, verts, **apply_kwargs)
-        with _blas_threads(len(grp), pool._max_workers):
-            errs += list(pool.map(two, grp))
+        o._POOL = _inner(pool, len(grp))
+        errs += list(pool.map(two, grp))
     inf = {}
     bpc = update(bpc, pool, info=inf, **bp_kwargs)
     sweeps.append(inf["niter"])
@@ -198,13 +211,14 @@ def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int
     try:
         with ThreadPoolExecutor(max_workers=nthreads) as pool:
             rates = _gemm_rates(chi, nthreads, pool)
-            bpc = update(bpc, pool, **bpkw)                            # warm-up outside the timing: converged messages
-            t0 = time.perf_counter()
-            sweeps_all = []
-            for _ in range(nlayers):
-                bpc, errs, sweeps = apply_layer(bpc, one_site, colour_groups, pool, kw, bpkw)
-                sweeps_all.append(sweeps)
-            dt = (time.perf_counter() - t0) / nlayers
+            with threadpool_limits(limits=1):
+                bpc = update(bpc, pool, **bpkw)                        # warm-up outside the timing: converged messages
+                t0 = time.perf_counter()
+                sweeps_all = []
+                for _ in range(nlayers):
+                    bpc, errs, sweeps = apply_layer(bpc, one_site, colour_groups, pool, kw, bpkw)
+                    sweeps_all.append(sweeps)
+                dt = (time.perf_counter() - t0) / nlayers
     finally:
         o._POOL, o._BIG = saved
     n2 = len(g.edges)
