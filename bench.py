@@ -159,7 +159,7 @@ def main():
                  "gate_apply": "tnqs::mfma_fiber_gemm_w_kernel<2, 2, 16>", "bp_pairgram": "tnqs::mfma_pair_gram2_kernel"}
     traffic_db = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
             traffic_db = json.load(f)["kernels"]
     except Exception:
         pass

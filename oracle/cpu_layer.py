@@ -186,7 +186,9 @@ def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int
     """one TFIM layer (README.md:42-48 angles) on an L x L PERIODIC torus -- every site has the bulk degree 4, L^2 sites, 2 L^2 edges, four
     colours for even L -- at bond dimension chi, ComplexF32, from BP-converged messages, reference-default bp_update_kwargs."""
     from threadpoolctl import threadpool_limits
-    nthreads = nthreads or max(1, (os.cpu_count() or 2) // 2)          # physical cores on an SMT-2 host
+    # physical cores on an SMT-2 host, capped at 64: numpy's bundled OpenBLAS is built for at most 64 concurrent callers (NUM_THREADS = 64;
+    # beyond that it warns, and with the nested chunk maps of this module it crashed on the 128-core box)
+    nthreads = nthreads or max(1, min(64, (os.cpu_count() or 2) // 2))
     g = o.named_grid((L, L), periodic=True)
     groups = o.edge_color(g)
     one_site = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]

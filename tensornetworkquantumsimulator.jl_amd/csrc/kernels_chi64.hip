@@ -62,9 +62,25 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_kernel(const GramItem* __r
         int ta = t % it.nta, tb = t / it.nta;
         a0 = ta * TA; b0 = tb * TB; na = min(TA, it.PA - a0); nb = min(TB, it.PB - b0);
     };
+    // full tiles of the usual shape (every thread owns NU two-element units): straight-line loads.  The guarded path below compiles
+    // into one branch per load with an s_waitcnt vmcnt(0) in front of the next one, i.e. the NU loads of a tile are SERIALISED (seen in the
+    // ISA; a 64-row tile then costs NU memory latencies, ~10 us instead of the 3.4 us of its matrix work)
+    const bool straight = fast && m.active && m.vec == 2 && K == m.KP * NU;
     auto issue_loads = [&](int t) {
         int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
         const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        if (straight && na == TA && nb == TB) {
+            const cf* px0 = Xg + org + m.off + kstride * m.kp; const cf* py0 = Yg + org + m.off + kstride * m.kp;
+            const long long st = kstride * m.KP;
+            if (same) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) { px[j] = ldg4(px0 + st * j); py[j] = px[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) { px[j] = ldg4(px0 + st * j); py[j] = ldg4(py0 + st * j); }
+            }
+            return;
+        }
         const bool v0 = m.active && m.al < na && m.bl < nb, v1 = v0 && m.al1 < na;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -72,8 +88,8 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_kernel(const GramItem* __r
             v4f vx, vy; vx[0] = vx[1] = vx[2] = vx[3] = 0.f; vy = vx;
             if (k < K && v0) {
                 const long long o = org + m.off + kstride * k;
-                if (m.vec == 2 && v1) { vx = *reinterpret_cast<const v4f*>(Xg + o); vy = same ? vx : *reinterpret_cast<const v4f*>(Yg + o); }
-                else { cf x = Xg[o]; vx[0] = x.re; vx[1] = x.im; if (same) vy = vx; else { cf y = Yg[o]; vy[0] = y.re; vy[1] = y.im; } }
+                if (m.vec == 2 && v1) { vx = ldg4(Xg + o); vy = same ? vx : ldg4(Yg + o); }
+                else { cf x = ldgc(Xg + o); vx[0] = x.re; vx[1] = x.im; if (same) vy = vx; else { cf y = ldgc(Yg + o); vy[0] = y.re; vy[1] = y.im; } }
             }
             px[j] = vx; py[j] = vy;
         }
@@ -357,7 +373,7 @@ void launch_copy_items(hipStream_t s, const CopyItem* d_items, int nitems) {
 //   * A' operand = X^T, staged once per workgroup in LDS in exact operand order (one conflict-free ds_read_b64 per lane and k-step);
 //   * C' accumulators hold out[row = ln][nn = kappa(r, h) + 32 nb]: stores run along the lanes again (D = 2: registers 2j, 2j+1 are the
 //     two site components of one n, one 16-byte store).
-// One wave per SIMD (the accumulators and two in-flight tiles take up to 384 registers); the wave never waits on a workgroup barrier.
+// One wave per SIMD (accumulators + the two half-tile operand sets: up to 256 registers); the wave never waits on a workgroup barrier.
 // ------------------------------------------------------------------------------------------------------------
 template <int KB, int NB, int D>
 __global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __restrict__ items, int nitems, double* __restrict__ norm_partials) {
@@ -388,7 +404,11 @@ __global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __re
         v2f o = {v.re, v.im}; Xl[e] = o;
     }
     __syncthreads();                                           // the only workgroup barrier
-    float pre[2][2 * NQ];                                      // two tiles in flight: current operands and the prefetch
+    // Operand registers: TWO HALF tiles (k-steps [0, NQ/2) and [NQ/2, NQ)).  A half is refilled with the next tile's data as soon as its
+    // MFMAs have been issued, so loads are always in flight behind the matrix work while only one tile's worth of operands (NQ floats x 2)
+    // is live next to the accumulators -- a whole second tile (the first version) spilled 1200 registers at K = N = 128.
+    constexpr int HQ = NQ / 2, HL = NL / 2;
+    float hb[2][2 * HQ];
     // rows of a tile: 32 consecutive a-indices (PA >= 32), or -- first leg of the tensor, PA < 32 -- all PA a-indices of 32 / PA consecutive
     // b-indices (the lanes then sit 1 KiB apart and each streams its own contiguous fiber over the k-steps: 16-byte pieces instead of
     // 256-byte runs per instruction, which the matrix work per byte of these shapes hides)
@@ -399,71 +419,70 @@ __global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __re
     const long long lane_out = rows_b ? (long long)D * (ln % (int)PA) + kst * No * (ln / (int)PA) : (long long)D * ln;
     auto base_in = [&](int t) { return rows_b ? kst * K * RB * t : (long long)D * 32 * (t % it.nta) + kst * K * (t / it.nta); };
     auto base_out = [&](int t) { return rows_b ? kst * No * RB * t : (long long)D * 32 * (t % it.nta) + kst * No * (t / it.nta); };
-    auto issue = [&](int t, int buf) {
-        const cf* p = in + base_in(t) + lane_in + kst * h;
+    auto issue_half = [&](int t, int hf) {
+        const cf* p = in + base_in(t) + lane_in + kst * (h + 2 * HL * hf);
         if (D == 1) {
 #pragma unroll
-            for (int j = 0; j < NL; ++j) { const cf v = p[kst * 2 * j]; pre[buf][2 * j] = v.re; pre[buf][2 * j + 1] = v.im; }
+            for (int j = 0; j < HL; ++j) { const v2f v = ldg2(p + kst * 2 * j); hb[hf][2 * j] = v[0]; hb[hf][2 * j + 1] = v[1]; }
         } else {
 #pragma unroll
-            for (int j = 0; j < NL; ++j) { const v4f v = *reinterpret_cast<const v4f*>(p + kst * 2 * j);
-                                           pre[buf][4 * j] = v[0]; pre[buf][4 * j + 1] = v[1]; pre[buf][4 * j + 2] = v[2]; pre[buf][4 * j + 3] = v[3]; }
+            for (int j = 0; j < HL; ++j) { const v4f v = ldg4(p + kst * 2 * j);
+                                           hb[hf][4 * j] = v[0]; hb[hf][4 * j + 1] = v[1]; hb[hf][4 * j + 2] = v[2]; hb[hf][4 * j + 3] = v[3]; }
         }
     };
     double nrm = 0;
     int t = t_begin + w;
-    if (t < t_end) issue(t, 0);
-    for (int it2 = 0; t < t_end; t += 4, ++it2) {
-        // the two register sets alternate; the loop is unrolled by two so that every access has a compile-time set index
+    if (t < t_end) { issue_half(t, 0); issue_half(t, 1); }
+    for (; t < t_end; t += 4) {
+        v16f Cr[NB], Ci[NB];
 #pragma unroll
-        for (int cur = 0; cur < 2; ++cur) {
-            if (cur == 1) { t += 4; if (t >= t_end) break; }
-            if (t + 4 < t_end) issue(t + 4, cur ^ 1);
-            v16f Cr[NB], Ci[NB];
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            for (int r = 0; r < 16; ++r) { Cr[nb][r] = 0.f; Ci[nb][r] = 0.f; }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { Cr[nb][r] = 0.f; Ci[nb][r] = 0.f; }
+        for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const float br = pre[cur][2 * q], bi = pre[cur][2 * q + 1];      // in[row][kk(q, h)]
+            for (int q = 0; q < HQ; ++q) {
+                const float br = hb[hf][2 * q], bi = hb[hf][2 * q + 1];          // in[row][kk(q + HQ hf, h)]
                 const float nbi = -bi;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const v2f a = Xl[(q * NB + nb) * 64 + lane];                  // X[kk(q, h)][32 nb + ln]
+                    const v2f a = Xl[((q + HQ * hf) * NB + nb) * 64 + lane];      // X[kk][32 nb + ln]
                     Cr[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], br, Cr[nb], 0, 0, 0);
                     Ci[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bi, Ci[nb], 0, 0, 0);
                     Cr[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], nbi, Cr[nb], 0, 0, 0);
                     Ci[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], br, Ci[nb], 0, 0, 0);
                 }
             }
-            float nf = 0.f;
-            if (D == 1) {
-                cf* p = out + base_out(t) + lane_out;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int n = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (n < No) { cf v; v.re = Cr[nb][r]; v.im = Ci[nb][r]; p[PA * n] = v; nf += v.re * v.re + v.im * v.im; }
-                    }
-            } else {
-                cf* p = out + base_out(t) + lane_out;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const int nn = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;  // even: s' = 0 of n = nn / 2; register r + 1 is s' = 1
-                        const int n = nn >> 1;
-                        if (n < No) {
-                            v4f v = {Cr[nb][r], Ci[nb][r], Cr[nb][r + 1], Ci[nb][r + 1]};
-                            *reinterpret_cast<v4f*>(p + 2 * PA * n) = v;
-                            nf += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-                        }
-                    }
-            }
-            nrm += (double)nf;
+            __builtin_amdgcn_sched_barrier(0);                                   // the refill must not be hoisted above the MFMAs that read the half
+            if (t + 4 < t_end) issue_half(t + 4, hf);
         }
+        float nf = 0.f;
+        if (D == 1) {
+            cf* p = out + base_out(t) + lane_out;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (n < No) { cf v; v.re = Cr[nb][r]; v.im = Ci[nb][r]; stgc(p + PA * n, v); nf += v.re * v.re + v.im * v.im; }
+                }
+        } else {
+            cf* p = out + base_out(t) + lane_out;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int nn = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;  // even: s' = 0 of n = nn / 2; register r + 1 is s' = 1
+                    const int n = nn >> 1;
+                    if (n < No) {
+                        v4f v = {Cr[nb][r], Ci[nb][r], Cr[nb][r + 1], Ci[nb][r + 1]};
+                        stg4(p + 2 * PA * n, v);
+                        nf += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                    }
+                }
+        }
+        nrm += (double)nf;
     }
     if (it.want_norm) {
         nrm = wave_sum_d(nrm);
@@ -544,9 +563,16 @@ __global__ __launch_bounds__(256) void mfma_gram128_f64_kernel(const GramItem* _
         int ta = t % it.nta, tb = t / it.nta;
         a0 = ta * TA; b0 = tb * TB; na = min(TA, it.PA - a0); nbb = min(TB, it.PB - b0);
     };
+    const bool straight = fast && m.active && m.vec == 2 && K == m.KP * NU;      // see mfma_gram64_kernel: guarded loads are serialised
     auto issue_loads = [&](int t) {
         int a0, b0, na, nbb; tile_origin(t, a0, b0, na, nbb);
         const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        if (straight && na == TA && nbb == TB) {
+            const cf* p0 = Xg + org + m.off + kstride * m.kp; const long long st = kstride * m.KP;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) px[j] = ldg4(p0 + st * j);
+            return;
+        }
         const bool v0 = m.active && m.al < na && m.bl < nbb, v1 = v0 && m.al1 < na;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -554,8 +580,8 @@ __global__ __launch_bounds__(256) void mfma_gram128_f64_kernel(const GramItem* _
             v4f vx; vx[0] = vx[1] = vx[2] = vx[3] = 0.f;
             if (k < K && v0) {
                 const long long o = org + m.off + kstride * k;
-                if (m.vec == 2 && v1) vx = *reinterpret_cast<const v4f*>(Xg + o);
-                else { cf x = Xg[o]; vx[0] = x.re; vx[1] = x.im; }
+                if (m.vec == 2 && v1) vx = ldg4(Xg + o);
+                else { cf x = ldgc(Xg + o); vx[0] = x.re; vx[1] = x.im; }
             }
             px[j] = vx;
         }

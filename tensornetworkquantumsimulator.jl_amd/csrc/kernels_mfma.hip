@@ -75,6 +75,14 @@ __global__ __launch_bounds__(256) void mfma_fiber_gemm_kernel(const FiberItem* _
     auto issue_loads = [&](int t) {
         int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
         const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        if (mi.vec == 2 && na == TA && nb == TB) {
+            // full tile: branch-free loads (k clamped to the last valid slice; commit_loads ignores the surplus).  The guarded loop below
+            // compiles into one branch per load with an s_waitcnt vmcnt(0) before the next one, which serialises the loads of a tile
+            const cf* p0 = in + org + mi.off;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) pre[j] = ldg4(p0 + kstride_in * min(mi.kp + mi.KP * j, K - 1));
+            return;
+        }
         const bool v0 = mi.active && mi.al < na && mi.bl < nb, v1 = v0 && mi.al1 < na;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -82,8 +90,8 @@ __global__ __launch_bounds__(256) void mfma_fiber_gemm_kernel(const FiberItem* _
             v4f v; v[0] = v[1] = v[2] = v[3] = 0.f;
             if (k < K && v0) {
                 const cf* p = in + org + mi.off + kstride_in * k;
-                if (mi.vec == 2 && v1) v = *reinterpret_cast<const v4f*>(p);
-                else { cf x = *p; v[0] = x.re; v[1] = x.im; }
+                if (mi.vec == 2 && v1) v = ldg4(p);
+                else { cf x = ldgc(p); v[0] = x.re; v[1] = x.im; }
             }
             pre[j] = v;
         }
@@ -161,8 +169,8 @@ __global__ __launch_bounds__(256) void mfma_fiber_gemm_kernel(const FiberItem* _
                         int nn1 = mo.c1 + Do * n;
                         v[2] = At_re[mo.row1 * PT + nn1]; v[3] = At_im[mo.row1 * PT + nn1];
                         nrm += (double)v[2] * v[2] + (double)v[3] * v[3];
-                        *reinterpret_cast<v4f*>(p) = v;
-                    } else { cf x; x.re = v[0]; x.im = v[1]; *p = x; }
+                        stg4(p, v);
+                    } else { cf x; x.re = v[0]; x.im = v[1]; stgc(p, x); }
                 }
             }
         } else {
@@ -242,6 +250,14 @@ __global__ __launch_bounds__(256) void mfma_fiber_gemm_w_kernel(const FiberItem*
     auto issue_loads = [&](int t) {
         int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
         const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        if (mi.vec == 2 && na == TA && nb == TB) {
+            // full tile: branch-free loads (k clamped to the last valid slice; commit_loads ignores the surplus).  The guarded loop below
+            // compiles into one branch per load with an s_waitcnt vmcnt(0) before the next one, which serialises the loads of a tile
+            const cf* p0 = in + org + mi.off;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) pre[j] = ldg4(p0 + kstride_in * min(mi.kp + mi.KP * j, K - 1));
+            return;
+        }
         const bool v0 = mi.active && mi.al < na && mi.bl < nb, v1 = v0 && mi.al1 < na;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -249,8 +265,8 @@ __global__ __launch_bounds__(256) void mfma_fiber_gemm_w_kernel(const FiberItem*
             v4f v; v[0] = v[1] = v[2] = v[3] = 0.f;
             if (k < K && v0) {
                 const cf* p = in + org + mi.off + kstride_in * k;
-                if (mi.vec == 2 && v1) v = *reinterpret_cast<const v4f*>(p);
-                else { cf x = *p; v[0] = x.re; v[1] = x.im; }
+                if (mi.vec == 2 && v1) v = ldg4(p);
+                else { cf x = ldgc(p); v[0] = x.re; v[1] = x.im; }
             }
             pre[j] = v;
         }
@@ -337,8 +353,8 @@ __global__ __launch_bounds__(256) void mfma_fiber_gemm_w_kernel(const FiberItem*
                         int nn1 = mo.c1 + Do * n;
                         v[2] = At_re[mo.row1 * PT + nn1]; v[3] = At_im[mo.row1 * PT + nn1];
                         nrm += (double)v[2] * v[2] + (double)v[3] * v[3];
-                        *reinterpret_cast<v4f*>(p) = v;
-                    } else { cf x; x.re = v[0]; x.im = v[1]; *p = x; }
+                        stg4(p, v);
+                    } else { cf x; x.re = v[0]; x.im = v[1]; stgc(p, x); }
                 }
             }
         } else {
@@ -452,6 +468,12 @@ __global__ __launch_bounds__(256) void mfma_gram32_kernel(const GramItem* __rest
     auto issue_loads = [&](int t) {
         int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
         const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        if (m.vec == 2 && na == TA && nb == TB) {       // full tile: branch-free loads, see mfma_fiber_gemm_w_kernel
+            const cf* px0 = Xg + org + m.off; const cf* py0 = Yg + org + m.off;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { const long long o = kstride * min(m.kp + m.KP * j, K - 1); px[j] = ldg4(px0 + o); py[j] = same ? px[j] : ldg4(py0 + o); }
+            return;
+        }
         const bool v0 = m.active && m.al < na && m.bl < nb, v1 = v0 && m.al1 < na;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -459,8 +481,8 @@ __global__ __launch_bounds__(256) void mfma_gram32_kernel(const GramItem* __rest
             v4f vx, vy; vx[0] = vx[1] = vx[2] = vx[3] = 0.f; vy = vx;
             if (k < K && v0) {
                 const long long o = org + m.off + kstride * k;
-                if (m.vec == 2 && v1) { vx = *reinterpret_cast<const v4f*>(Xg + o); vy = same ? vx : *reinterpret_cast<const v4f*>(Yg + o); }
-                else { cf x = Xg[o]; vx[0] = x.re; vx[1] = x.im; if (same) vy = vx; else { cf y = Yg[o]; vy[0] = y.re; vy[1] = y.im; } }
+                if (m.vec == 2 && v1) { vx = ldg4(Xg + o); vy = same ? vx : ldg4(Yg + o); }
+                else { cf x = ldgc(Xg + o); vx[0] = x.re; vx[1] = x.im; if (same) vy = vx; else { cf y = ldgc(Yg + o); vy[0] = y.re; vy[1] = y.im; } }
             }
             px[j] = vx; py[j] = vy;
         }
@@ -570,7 +592,7 @@ __global__ __launch_bounds__(256) void mfma_gram32_fused_kernel(const GramItem* 
         for (int j = 0; j < NU; ++j) {
             int k = m.kp + m.KP * j;
             v4f v; v[0] = v[1] = v[2] = v[3] = 0.f;
-            if (k < K) v = *reinterpret_cast<const v4f*>(G + org + m.off + kstride * k);
+            if (k < K) v = ldg4(G + org + m.off + kstride * k);
             pre[j] = v;
         }
     };
@@ -693,7 +715,7 @@ __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restri
     auto issue = [&](int sl) {
         const cf* p = in + pair_slice_base(g, sl) + toff;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) pre[j] = *reinterpret_cast<const v4f*>(p + tstr * j);
+        for (int j = 0; j < 16; ++j) pre[j] = ldg4(p + tstr * j);
     };
     auto commit = [&]() {
 #pragma unroll
@@ -750,7 +772,7 @@ __global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restri
                 const v2f* p0 = lbase + 66 * j;
                 const v2f a = p0[0], c = p0[PS];
                 v4f v; v[0] = a[0]; v[1] = a[1]; v[2] = c[0]; v[3] = c[1];
-                *reinterpret_cast<v4f*>(p + tstr * j) = v;
+                stg4(p + tstr * j, v);
             }
         }
     }
@@ -804,7 +826,7 @@ __global__ __launch_bounds__(512) void mfma_pair_gram_kernel(const PairGramItem*
     auto issue = [&](const cf* __restrict__ G, int sl) {
         const cf* p = G + pair_slice_base(g, sl) + toff;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) pre[j] = *reinterpret_cast<const v4f*>(p + tstr * j);
+        for (int j = 0; j < 16; ++j) pre[j] = ldg4(p + tstr * j);
     };
     auto commit = [&]() {
 #pragma unroll
@@ -933,7 +955,7 @@ __global__ __launch_bounds__(512) void mfma_pair_gram2_kernel(const PairGram2Ite
     auto issue = [&](int sl) {
         const long long b = pair_slice_base(g, sl) + half * hoff + toff;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { px[j] = *reinterpret_cast<const v4f*>(Xg + b + tstr * j); py[j] = *reinterpret_cast<const v4f*>(Yg + b + tstr * j); }
+        for (int j = 0; j < 8; ++j) { px[j] = ldg4(Xg + b + tstr * j); py[j] = ldg4(Yg + b + tstr * j); }
     };
     auto commit = [&]() {
 #pragma unroll
@@ -1078,7 +1100,7 @@ __global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __
     {
         const v4f* __restrict__ Xb = reinterpret_cast<const v4f*>(it.Xb);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Xl[tid + 512 * j] = Xb[tid + 512 * j];
+        for (int j = 0; j < 4; ++j) Xl[tid + 512 * j] = ldg4(Xb + tid + 512 * j);
     }
     const int f = tid & 7, sg0 = tid >> 3;
     const long long sx = g.sx, sy = g.sy, fo = (long long)f * g.cstr;
@@ -1091,7 +1113,7 @@ __global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __
     auto issue = [&](int sl) {
         const cf* p = in + pair_slice_base(g, sl) + toff;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) pre[j] = *reinterpret_cast<const v4f*>(p + tstr * j);
+        for (int j = 0; j < 16; ++j) pre[j] = ldg4(p + tstr * j);
     };
     auto commit = [&]() {
 #pragma unroll
@@ -1165,7 +1187,7 @@ __global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __
                 const int iy = iy0 + 2 * j;
                 const float* p0 = lplane + iy * 32 + ((ix0 ^ iy ^ swf) & 31);
                 v4f v; v[0] = p0[0]; v[1] = p0[PR]; v[2] = p0[PS]; v[3] = p0[PS + PR];
-                *reinterpret_cast<v4f*>(p + tstr * j) = v;
+                stg4(p + tstr * j, v);
             }
         }
     }
@@ -1293,9 +1315,18 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem*
         int ta = t % it.nta, tb = t / it.nta;
         a0 = ta * TA; b0 = tb * TB; na = min(TA, it.PA - a0); nb = min(TB, it.PB - b0);
     };
+    // full tiles with NU two-element units per thread: straight-line loads (the guarded loop compiles into one branch per load with an
+    // s_waitcnt vmcnt(0) before the next, which serialises the NU loads of a tile -- kernels_chi64.hip, mfma_gram64_kernel)
+    const bool straight = fast && m.active && m.vec == 2 && K == m.KP * NU;
     auto issue_loads = [&](int t) {
         int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
         const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        if (straight && na == TA && nb == TB) {
+            const cf* p0 = Xg + org + m.off + kstride * m.kp; const long long st = kstride * m.KP;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) px[j] = ldg4(p0 + st * j);
+            return;
+        }
         const bool v0 = m.active && m.al < na && m.bl < nb, v1 = v0 && m.al1 < na;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -1303,8 +1334,8 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem*
             v4f vx; vx[0] = vx[1] = vx[2] = vx[3] = 0.f;
             if (k < K && v0) {
                 const long long o = org + m.off + kstride * k;
-                if (m.vec == 2 && v1) vx = *reinterpret_cast<const v4f*>(Xg + o);
-                else { cf x = Xg[o]; vx[0] = x.re; vx[1] = x.im; }
+                if (m.vec == 2 && v1) vx = ldg4(Xg + o);
+                else { cf x = ldgc(Xg + o); vx[0] = x.re; vx[1] = x.im; }
             }
             px[j] = vx;
         }

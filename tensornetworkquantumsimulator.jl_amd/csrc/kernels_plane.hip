@@ -74,7 +74,7 @@ __global__ __launch_bounds__(512) void mfma_pair16_kernel(const Pair16Item* __re
     auto issue = [&](int sl) {
         const cf* p = in + plane_slice_base(g, sl) + toff;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) pre[j] = *reinterpret_cast<const v4f*>(p + g.sy * j);
+        for (int j = 0; j < 16; ++j) pre[j] = ldg4(p + g.sy * j);
     };
     auto commit = [&]() {
 #pragma unroll
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) void mfma_pair16_kernel(const Pair16Item* __re
             for (int j = 0; j < 16; ++j) {
                 const v2f a = lbase[P16 * j], b = lbase[P16 * j + PS16];
                 v4f v = {a[0], a[1], b[0], b[1]};
-                *reinterpret_cast<v4f*>(p + g.sy * j) = v;
+                stg4(p + g.sy * j, v);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void mfma_pair_gram2x16_kernel(const PairGram2
     auto issue = [&](int sl) {
         const long long b = plane_slice_base(g, sl) + toff;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { px[j] = *reinterpret_cast<const v4f*>(Xg + b + g.sy * j); py[j] = *reinterpret_cast<const v4f*>(Yg + b + g.sy * j); }
+        for (int j = 0; j < 16; ++j) { px[j] = ldg4(Xg + b + g.sy * j); py[j] = ldg4(Yg + b + g.sy * j); }
     };
     auto commit = [&]() {
 #pragma unroll

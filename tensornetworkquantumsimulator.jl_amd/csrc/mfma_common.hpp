@@ -9,6 +9,19 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct alignas(8) cf { float re, im; };
 
+// GLOBAL-memory loads / stores.  The tensor pointers reach the kernels through item structs in device memory, so the compiler knows
+// nothing about their address space and emits FLAT instructions; a flat load counts on BOTH vmcnt and lgkmcnt and returns out of order
+// with respect to LDS traffic, so the first `s_waitcnt lgkmcnt(0)` in front of an LDS-fed MFMA also waits for every prefetch load in
+// flight -- the "prefetch" is synchronous and a full memory latency is exposed per tile (seen in the ISA of every kernel of round 1).
+// Casting to address space 1 gives global_load / global_store, which count on vmcnt only.
+#define TNQS_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ v4f ldg4(const void* p) { return *(const v4f TNQS_AS1*)(p); }
+__device__ __forceinline__ v2f ldg2(const void* p) { return *(const v2f TNQS_AS1*)(p); }
+__device__ __forceinline__ void stg4(void* p, v4f v) { *(v4f TNQS_AS1*)(p) = v; }
+__device__ __forceinline__ void stg2(void* p, v2f v) { *(v2f TNQS_AS1*)(p) = v; }
+__device__ __forceinline__ cf ldgc(const cf* p) { const v2f t = ldg2(p); cf r; r.re = t[0]; r.im = t[1]; return r; }
+__device__ __forceinline__ void stgc(cf* p, cf v) { v2f t = {v.re, v.im}; stg2(p, t); }
+
 // LDS-only workgroup barrier: __syncthreads() also drains vmcnt (global loads AND stores in flight), which would
 // serialise the prefetch / store streams against the LDS hand-offs (cdna_hip_programming.md, "Pipelining across barriers").
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
