@@ -75,14 +75,6 @@ __global__ __launch_bounds__(256) void mfma_fiber_gemm_kernel(const FiberItem* _
     auto issue_loads = [&](int t) {
         int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
         const long long org = (long long)D * (a0 + PA * (long long)K * b0);
-        if (mi.vec == 2 && na == TA && nb == TB) {
-            // full tile: branch-free loads (k clamped to the last valid slice; commit_loads ignores the surplus).  The guarded loop below
-            // compiles into one branch per load with an s_waitcnt vmcnt(0) before the next one, which serialises the loads of a tile
-            const cf* p0 = in + org + mi.off;
-#pragma unroll
-            for (int j = 0; j < NU; ++j) pre[j] = ldg4(p0 + kstride_in * min(mi.kp + mi.KP * j, K - 1));
-            return;
-        }
         const bool v0 = mi.active && mi.al < na && mi.bl < nb, v1 = v0 && mi.al1 < na;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -250,14 +242,6 @@ __global__ __launch_bounds__(256) void mfma_fiber_gemm_w_kernel(const FiberItem*
     auto issue_loads = [&](int t) {
         int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
         const long long org = (long long)D * (a0 + PA * (long long)K * b0);
-        if (mi.vec == 2 && na == TA && nb == TB) {
-            // full tile: branch-free loads (k clamped to the last valid slice; commit_loads ignores the surplus).  The guarded loop below
-            // compiles into one branch per load with an s_waitcnt vmcnt(0) before the next one, which serialises the loads of a tile
-            const cf* p0 = in + org + mi.off;
-#pragma unroll
-            for (int j = 0; j < NU; ++j) pre[j] = ldg4(p0 + kstride_in * min(mi.kp + mi.KP * j, K - 1));
-            return;
-        }
         const bool v0 = mi.active && mi.al < na && mi.bl < nb, v1 = v0 && mi.al1 < na;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -468,12 +452,6 @@ __global__ __launch_bounds__(256) void mfma_gram32_kernel(const GramItem* __rest
     auto issue_loads = [&](int t) {
         int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
         const long long org = (long long)D * (a0 + PA * (long long)K * b0);
-        if (m.vec == 2 && na == TA && nb == TB) {       // full tile: branch-free loads, see mfma_fiber_gemm_w_kernel
-            const cf* px0 = Xg + org + m.off; const cf* py0 = Yg + org + m.off;
-#pragma unroll
-            for (int j = 0; j < NU; ++j) { const long long o = kstride * min(m.kp + m.KP * j, K - 1); px[j] = ldg4(px0 + o); py[j] = same ? px[j] : ldg4(py0 + o); }
-            return;
-        }
         const bool v0 = m.active && m.al < na && m.bl < nb, v1 = v0 && m.al1 < na;
 #pragma unroll
         for (int j = 0; j < NU; ++j) {

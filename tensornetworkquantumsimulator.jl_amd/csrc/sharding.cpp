@@ -27,11 +27,13 @@ struct RcclApi {
 static RcclApi& rccl() {
     static RcclApi api; static std::once_flag once;
     std::call_once(once, [] {
-        // a copy that is already in the process (PyTorch-ROCm ships its own librccl.so) is reused, so that one process never runs two
+        // a copy that is already in the process (PyTorch-ROCm ships its own librccl.so) is reused, so that one process never runs two; a copy
+        // loaded here stays out of the global symbol scope (RTLD_LOCAL): with RTLD_GLOBAL a second copy loaded later (import torch) bound
+        // its own globals to this one's and the process died with a double free at exit
         const char* env = std::getenv("TNQS_RCCL_LIB");
         const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* n : names) { if (!n || !*n) continue; void* h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (h) { api.lib = h; api.path = n; break; } }
-        if (!api.lib) for (const char* n : names) { if (!n || !*n) continue; void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) { api.lib = h; api.path = n; break; } }
+        for (const char* n : names) { if (!n || !*n) continue; void* h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL); if (h) { api.lib = h; api.path = n; break; } }
+        if (!api.lib) for (const char* n : names) { if (!n || !*n) continue; void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) { api.lib = h; api.path = n; break; } }
         if (!api.lib) return;
         api.get_unique_id = (fn_get_unique_id)dlsym(api.lib, "ncclGetUniqueId");
         api.comm_init_rank = (fn_comm_init_rank)dlsym(api.lib, "ncclCommInitRank");

@@ -79,6 +79,24 @@ class Sharding:
         self.cb = L.ALLGATHER_FN(_cb)
 
 
+def _prefer_torch_rccl():
+    """PyTorch-ROCm bundles its own librccl.so (same SONAME as /opt/rocm's).  If the library loaded /opt/rocm's copy and `import torch` came
+    later, the process would hold two RCCLs; pointing the library at torch's copy (TNQS_RCCL_LIB, read on its first RCCL call) makes both
+    use one -- the same arrangement _lib.py makes for the HIP runtime.  torch itself is not imported here."""
+    import os
+    if os.environ.get("TNQS_RCCL_LIB"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+            if os.path.exists(path):
+                os.environ["TNQS_RCCL_LIB"] = path
+    except Exception:
+        pass
+
+
 class RcclSharding:
     """transport = RCCL inside the library (tnqs_set_sharding_rccl): nothing of the data path runs in Python.  Only the 128-byte
     ncclUniqueId travels through the host once: rank 0 creates it, `broadcast` hands it to the other ranks (default:
@@ -86,6 +104,7 @@ class RcclSharding:
 
     def __init__(self, bpc, rank: int, world: int, owner: List[int], exch_bytes: int, group=None, broadcast=None):
         import weakref
+        _prefer_torch_rccl()
         self.rank, self.world, self.owner, self.group = rank, world, list(owner), group
         self._ref = weakref.ref(bpc)              # any live handle of the family will do for the counters (core.copy re-attaches)
         self._last = (0, 0)
@@ -126,6 +145,7 @@ class RcclSharding:
 
 def rccl_selftest(device: int = 0, nbytes: int = 1 << 20):
     """one-rank round trip through the library's RCCL transport (a single GPU cannot host two RCCL ranks)"""
+    _prefer_torch_rccl()
     L.check(L.lib.tnqs_rccl_selftest(int(device), C.c_int64(int(nbytes))))
 
 
