@@ -92,3 +92,18 @@ def test_chi16_plane_kernels_match_the_single_leg_route():
     ea, eb = np.array(on["errs"]), np.array(off["errs"])
     assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7)
     assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 5e-5
+
+
+def test_chi64_kernels_match_the_generic_route_on_a_physical_evolution():
+    """nine TFIM layers from the product state at maxdim 64 (bonds grow 2 -> 64, theta rank deficient on the way): the chi = 64 kernels
+    (kernels_chi64.hip and the Cholesky-QR theta SVD) against the generic route (TNQS_NO_CHI64=1: round-1 kernels, global-memory Jacobi).
+    Same bond dimensions layer by layer; truncation errors and <Z> to f32 rounding of the whole evolution."""
+    on, off = run_worker({}, "chi64phys"), run_worker({"TNQS_NO_CHI64": "1"}, "chi64phys")
+    print("bond dimensions per layer:", [max(d) for d in on["dims"]], " tall SVDs:", on["tall"])
+    assert on["dims"] == off["dims"] and max(on["dims"][-1]) == 64
+    assert on["tall"] > 0 and off["tall"] == 0
+    ea, eb = np.array(on["errs"]), np.array(off["errs"])
+    print("chi = 64 physical evolution: max |derr|", float(np.max(np.abs(ea - eb))), " max err", float(ea.max()), " max |dZ|", float(np.max(np.abs(np.array(on["z"]) - np.array(off["z"])))))
+    assert np.all(np.abs(ea - eb) < 5e-3 * np.maximum(ea, eb) + 5e-7)
+    assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-4
+    assert abs(on["norm"] - 1) < 1e-4 and np.all(ea >= 0) and np.all(ea <= 1)

@@ -30,9 +30,29 @@ def cubic16():
     print(json.dumps(out))
 
 
+def chi64phys():
+    """PHYSICAL evolution up to the chi = 64 cap: 4x4 TFIM (J = 1, hx = 2.5, dt = 0.25: large steps, so that the bonds saturate within a few layers) from the product state, maxdim 64, cutoff 1e-13 -- the bond
+    dimensions grow 2 -> 64 over the layers, theta is rank deficient on the way (the normal case early in an evolution), and the saturated layers
+    run the chi = 64 kernels: register-direct products / epilogue, 64 x 64 and 128 x 128 MFMA Grams, Cholesky at n = 128, the Cholesky-QR theta SVD"""
+    g = tn.named_grid((4, 4))
+    groups = tn.edge_color(g, 4)
+    layer = [("Rx", [v], 2 * 2.5 * 0.25) for v in g.vertices] + [("Rzz", [a, b], 2 * 1.0 * 0.25) for grp in groups for (a, b) in grp]
+    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex64, lambda v: "↑", g))
+    kw = dict(maxdim=64, cutoff=1e-13, normalize_tensors=True)
+    errs_all, z_all, dims, tall = [], [], [], 0
+    for it in range(9):
+        info = {}
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=kw, info=info)
+        errs_all += errs.tolist(); z_all += [float(np.real(x)) for x in tn.expect_all(bpc, "Z")]
+        dims.append([bpc.bond_dim(a, b) for a, b in g.edges]); tall += info.get("n_tall_svd", 0)
+    print(json.dumps(dict(errs=errs_all, z=z_all, dims=dims, tall=tall, norm=float(np.linalg.norm(bpc.tensor((2, 2)))))))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "cubic16":
         return cubic16()
+    if len(sys.argv) > 1 and sys.argv[1] == "chi64phys":
+        return chi64phys()
     g = tn.named_grid((4, 4))
     psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=8, seed=3)
     bpc = tn.update(tn.BeliefPropagationCache(psi), maxiter=30, tolerance=None)
