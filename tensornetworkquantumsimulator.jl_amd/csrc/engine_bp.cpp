@@ -369,6 +369,27 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                         is_shared_chain.push_back(ci); is_shared_chain.push_back(cj);
                     }
                 }
+                // a site that sends ONE message in this level (no shared product): its last absorption is fused with the Gram too -- the chain
+                // stops one leg early and the same kernel computes (T x_lx M) conj(psi) for that single message (My = null)
+                std::vector<int> g16_single;                          // index into g16 of the single items (their chain runs first, X is set after it)
+                if (std::is_same<T, float>::value && use_mfma() && use_pair() && use_dbl()) {
+                    for (size_t ci = 0; ci < chains.size(); ++ci) {
+                        Chain& c = chains[ci];
+                        if (c.y || fmsg[ci] || c.steps.empty() || (c.steps.size() & 1) == 0 || c.sd.n < (size_t)(1u << 14)) continue;
+                        bool sh = false; for (int q : is_shared_chain) sh = sh || q == (int)ci;
+                        if (sh) continue;
+                        const int de = plan.seq[tpos[ci]]; const int e = de / 2; const int dst = (de & 1) ? g.esrc[e] : g.edst[e];
+                        const int ly = g.leg(c.v, dst), lx = c.steps.back().first;
+                        PairGram2x16Item it{};
+                        if (!plane_geometry(c.sd.d, c.sd.z, c.sd.chi.data(), lx, ly, 16, it.g)) continue;
+                        bool all16 = true; for (auto& st : c.steps) all16 = all16 && c.sd.chi[st.first] == 16;
+                        if (!all16) continue;
+                        it.Y = c.src; it.Mx = c.steps.back().second; it.My = nullptr; it.X = nullptr;      // X = the chain's result, known after run_chains
+                        c.steps.pop_back();
+                        g16_single.push_back((int)g16.size());
+                        g16.push_back(it); g16_chain.push_back({(int)ci, -1});
+                    }
+                }
                 ht_prep.stop();
                 std::vector<char> is_shared(chains.size(), 0);
                 for (int ci : is_shared_chain) is_shared[ci] = 1;
@@ -410,18 +431,21 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     ProfScope ps(s, TNQS_PROF_BP_PAIRGRAM, 2.0 * sh_dbl_slices * 8192.0 * esz, 4 * 8.0 * sh_dbl_slices * 8192.0 * 32);
                     launch_mfma_pair_gram2(s->stream, d, (int)sh_dbl.size(), wgs);
                 }
+                for (int q : g16_single) { g16[q].X = chains[g16_chain[q].first].result; is_shared[g16_chain[q].first] = 1; }
                 if (!g16.empty()) {
                     double tot = 0; for (auto& it : g16) tot += it.g.nslices();
                     int spw = 2; while (spw < 128 && tot / (2 * spw) >= 2048.0) spw *= 2;       // a multiple of 2: 4 waves = 2 slices x 2 halves
                     int wgs = 0; double by = 0, fl = 0;
                     for (size_t q = 0; q < g16.size(); ++q) {
-                        PairGram2x16Item& it = g16[q]; GramJob& jy = jobs[g16_chain[q].first]; GramJob& jx = jobs[g16_chain[q].second];
+                        PairGram2x16Item& it = g16[q]; GramJob& jy = jobs[g16_chain[q].first];
                         const int nwg = (it.g.nslices() + spw - 1) / spw;
                         it.spw = spw; it.wg_begin = wgs; wgs += nwg;
-                        jy.nchunks = jx.nchunks = nwg; jy.KK = jx.KK = 16;
-                        jy.partial = dalloc(s, (size_t)nwg * 256 * esz); jx.partial = dalloc(s, (size_t)nwg * 256 * esz);
-                        it.partial_y = jy.partial->p; it.partial_x = jx.partial->p;
-                        by += 2.0 * jy.sd.n * esz; fl += 4 * 8.0 * jy.sd.n * 16;
+                        jy.nchunks = nwg; jy.KK = 16; jy.partial = dalloc(s, (size_t)nwg * 256 * esz); it.partial_y = jy.partial->p;
+                        if (g16_chain[q].second >= 0) {
+                            GramJob& jx = jobs[g16_chain[q].second];
+                            jx.nchunks = nwg; jx.KK = 16; jx.partial = dalloc(s, (size_t)nwg * 256 * esz); it.partial_x = jx.partial->p;
+                        } else it.partial_x = nullptr;
+                        by += 2.0 * jy.sd.n * esz; fl += (g16_chain[q].second >= 0 ? 4 : 2) * 8.0 * jy.sd.n * 16;
                     }
                     const PairGram2x16Item* d = upload(s, g16);
                     ProfScope ps(s, TNQS_PROF_BP_PAIRGRAM, by, fl);

@@ -164,9 +164,10 @@ __global__ __launch_bounds__(256) void mfma_pair_gram2x16_kernel(const PairGram2
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             cf a = Mx[(4 * g4 + t) + 16 * c16]; mxr[t] = a.re; mxi[t] = a.im;
-            cf b = My[(4 * g4 + t) + 16 * c16]; myr[t] = b.re; myi[t] = b.im;
+            cf b = {0.f, 0.f}; if (My) b = My[(4 * g4 + t) + 16 * c16]; myr[t] = b.re; myi[t] = b.im;
         }
     }
+    const bool both = it.My != nullptr;                 // My == null: only the message through ly is wanted (a site that sends one message in this level)
     v4f O1r = {0.f, 0.f, 0.f, 0.f}, O1i = O1r, O2r = O1r, O2i = O1r;
     const int f = lane & 3, ix0 = lane >> 2, half = w & 1;
     const long long toff = (long long)(4 * half + f) * g.cstr + g.sx * ix0;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void mfma_pair_gram2x16_kernel(const PairGram2
                 }
             }
             // ---- message through lx: absorb ly (the same planes, read transposed) ------------------------------------------
-            {
+            if (both) {
                 float xr[4], xi[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { const v2f x = PX[(4 * g4 + t) * P16 + c16]; xr[t] = x[0]; xi[t] = x[1]; }   // B[k = iy = 4 g + t][j = d = ix = c16]
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void mfma_pair_gram2x16_kernel(const PairGram2
         float sr = 0.f, si = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) { const v2f v = R[(msg * 4 + ww) * 272 + j * 17 + i]; sr += v[0]; si += v[1]; }
-        cf o; o.re = sr; o.im = si; (msg ? p2 : p1)[q] = o;
+        cf o; o.re = sr; o.im = si; if (msg == 0) p1[q] = o; else if (both) p2[q] = o;
     }
 }
 void launch_mfma_pair_gram2x16(hipStream_t s, const PairGram2x16Item* d_items, int nitems, int total_wgs) {
