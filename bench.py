@@ -156,11 +156,17 @@ def main():
     KERNEL_OF = {"bp_pair": "tnqs::mfma_pair_kernel", "bp_modeprod": "tnqs::mfma_fiber_gemm_w_kernel<1, 1, 8>",
                  "gate_modeprod": "tnqs::mfma_pair_kernel", "bp_fused": "tnqs::mfma_gram32_fused_kernel",
                  "bp_gram": "tnqs::mfma_gram32_kernel", "gate_gram": "tnqs::mfma_gram64_f64_kernel",
-                 "gate_apply": "tnqs::mfma_fiber_gemm_w_kernel<2, 2, 16>", "bp_pairgram": "tnqs::mfma_pair_gram2_kernel"}
+                 "gate_apply": "tnqs::mfma_apply64_kernel", "bp_pairgram": "tnqs::mfma_pair_gram2_kernel"}
     traffic_db = {}
     try:
         with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
             traffic_db = json.load(f)["kernels"]
+    except Exception:
+        pass
+    mfma_db = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r2_mfma_util.json")) as f:
+            mfma_db = json.load(f)["kernels"]
     except Exception:
         pass
     dom = max(prof, key=lambda k: prof[k]["ms"])
@@ -174,7 +180,11 @@ def main():
         traffic = traffic_db.get(kern, {}).get("hbm_bytes_per_launch") if (world == 1 and L == 20 and chi == 32) else None
         common = {"kernel_class": dom, "kernel": kern, "avg_launch_ms": round(p["ms"] / max(1, p["launches"]), 4), "launches": p["launches"],
                   "arithmetic_intensity_flop_per_B": round(ai, 2), "alg_bytes_per_launch": round(p["bytes"] / max(1, p["launches"])),
-                  "alg_TFLOPs": round(tflops, 2), "alg_GBps": round(gbs, 1), "traffic": traffic}
+                  "alg_TFLOPs": round(tflops, 2), "alg_GBps": round(gbs, 1), "traffic": traffic,
+                  # matrix-core utilisation of the same kernel from the committed counter pass (profiles/r2_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES /
+                  # (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs)); like `traffic` it is a profile of this command, not re-measured in this run
+                  "mfma_busy": (mfma_db.get(kern, {}).get("mfma_busy") if (world == 1 and L == 20 and chi == 32) else None),
+                  "mfma_executed_TFLOPs": (mfma_db.get(kern, {}).get("mfma_tflops") if (world == 1 and L == 20 and chi == 32) else None)}
         if ai < PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
             roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), **common}
         else:

@@ -98,7 +98,7 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
         if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)KKmax); if (t > 0) { TR = t; mf = true; } }
         int tpw = 1;
         if (mf) { double tot = 0; for (auto& c : chains) if (c.steps.size() > o) tot += (double)c.sd.n / c.sd.chi[c.steps[o].first] / TR; tpw = (int)std::max(1.0, std::min(TR == 32 ? 32.0 : 8.0, tot / 4096.0)); if (TR == 32 && tpw >= 4) tpw &= ~3; }
-        std::vector<FiberItem> rg_items; double rg_tiles = 0, rg_bytes = 0, rg_flops = 0;      // chi = 64 legs: register-direct MFMA kernel
+        std::vector<FiberItem> rg_items, rg32_items; double rg_tiles = 0, rg32_tiles = 0, rg_bytes = 0, rg_flops = 0;      // chi = 64 (32) legs: register-direct MFMA kernel
         for (size_t ci = 0; ci < chains.size(); ++ci) {
             Chain& c = chains[ci];
             if (c.steps.size() <= o) continue;
@@ -108,9 +108,9 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
             if (!dst) dst = dalloc(s, c.sd.n * esz);
             it.in = c.result; it.out = dst->p; it.X = c.steps[o].second;
             it.D = 1; it.PA = (int)c.sd.pre(j); it.K = c.sd.chi[j]; it.PB = (int)c.sd.post(j); it.Do = 1; it.No = it.K;
-            if (std::is_same<T, float>::value && use_mfma() && use_rowgemm() && rowgemm_covers(it)) {
+            if (std::is_same<T, float>::value && use_mfma() && use_rowgemm() && rowgemm_covers(it) && (it.K == 64 || use_rowgemm32())) {
                 rowgemm_tiles(it); it.want_norm = 0;
-                rg_items.push_back(it); rg_tiles += (double)it.nta * it.ntb;
+                (it.K == 64 ? rg_items : rg32_items).push_back(it); (it.K == 64 ? rg_tiles : rg32_tiles) += (double)it.nta * it.ntb;
                 c.result = dst->p; nt[ci]++;
                 rg_bytes += 2.0 * c.sd.n * esz; rg_flops += 8.0 * c.sd.n * it.K;
                 continue;
@@ -122,12 +122,16 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
             c.result = dst->p; nt[ci]++;
             bytes += 2.0 * c.sd.n * esz; flops += 8.0 * c.sd.n * it.K;
         }
-        if (!rg_items.empty()) {
-            int tpw = (int)std::max(4.0, std::min(64.0, rg_tiles / 2048.0)); tpw &= ~3; int wgs = 0;
-            for (auto& it : rg_items) { it.tpw = tpw; it.tile_begin = wgs; wgs += (it.nta * it.ntb + tpw - 1) / tpw; }
-            const FiberItem* d = upload(s, rg_items);
-            ProfScope ps(s, cls, rg_bytes, rg_flops);
-            launch_mfma_rowgemm(s->stream, d, (int)rg_items.size(), wgs, 1, nullptr);
+        bool booked = false;
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<FiberItem>& ri = pass ? rg32_items : rg_items;
+            if (ri.empty()) continue;
+            const double nt = pass ? rg32_tiles : rg_tiles;
+            int tpw = (int)std::max(4.0, std::min(64.0, nt / 2048.0)); tpw &= ~3; int wgs = 0;
+            for (auto& it : ri) { it.tpw = tpw; it.tile_begin = wgs; wgs += (it.nta * it.ntb + tpw - 1) / tpw; }
+            const FiberItem* d = upload(s, ri);
+            ProfScope ps(s, cls, booked ? 0.0 : rg_bytes, booked ? 0.0 : rg_flops); booked = true;      // bytes / flops of both groups are booked on the first scope
+            launch_mfma_rowgemm(s->stream, d, (int)ri.size(), wgs, 1, pass ? 32 : 64, nullptr);
         }
         if (items.empty()) continue;
         const FiberItem* d = upload(s, items);

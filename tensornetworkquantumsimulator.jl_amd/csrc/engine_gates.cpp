@@ -634,7 +634,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         // plane kernel for the common shape d = 2, chi_b = chi_b' = 32 (pair-kernel geometry, two waves per SIMD)
         std::vector<Apply64Item> a64; std::vector<XbItem> xbi; std::vector<int> a64_verts; std::vector<Buf> a64_outs; std::vector<size_t> a64_ne;
         std::vector<char> via64(own_idx.size(), 0); double a64_slices = 0;
-        if (std::is_same<T, float>::value && use_mfma() && use_apply64()) {
+        if (std::is_same<T, float>::value && use_mfma() && use_apply64() && !use_rowgemm32()) {
             for (size_t q = 0; q < own_idx.size(); ++q) {
                 size_t i = own_idx[q]; int gi = (int)i / 2; const SiteJob& j = sj[i];
                 Apply64Item it{};
@@ -666,7 +666,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                     size_t i = own_idx[q]; int gi = (int)i / 2; int chin = info[8 * gi + 2]; const SiteJob& j = sj[i];
                     FiberItem it{};
                     it.D = j.sd.d; it.PA = (int)(j.sd.pre(j.bleg) / j.sd.d); it.K = j.sd.chi[j.bleg]; it.PB = (int)j.sd.post(j.bleg); it.Do = j.sd.d; it.No = chin;
-                    if (!rowgemm_covers(it) || it.D != 2) continue;
+                    if (!rowgemm_covers(it) || it.D != 2 || !(it.K == 64 || use_rowgemm32())) continue;
                     const size_t nout = j.sd.n / it.K * chin;
                     Buf out = dalloc(s, nout * esz);
                     it.in = pch[q].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
@@ -674,13 +674,17 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                     rg.push_back(it); rverts.push_back(j.v); routs.push_back(out); rne.push_back(nout); rt += (double)it.nta * it.ntb;
                     rby += (double)(j.sd.n + nout) * esz; rfl += 8.0 * j.sd.n * j.sd.d * chin; via64[q] = 1;
                 }
-            if (!rg.empty()) {
-                int tpw = (int)std::max(4.0, std::min(32.0, rt / 2048.0)); tpw &= ~3; int wgs = 0;
-                for (auto& it : rg) { const int nwg = (it.nta * it.ntb + tpw - 1) / tpw; it.tpw = tpw; it.tile_begin = wgs; rtb.push_back(wgs); rnt.push_back(nwg); wgs += nwg; }
+            bool booked = false;
+            for (int kk : {64, 32}) {          // one launch per contracted dimension
+                std::vector<FiberItem> sub; std::vector<int> sv, stb, snt; std::vector<Buf> so; std::vector<size_t> sn; double st = 0;
+                for (size_t q = 0; q < rg.size(); ++q) if (rg[q].K == kk) { sub.push_back(rg[q]); sv.push_back(rverts[q]); so.push_back(routs[q]); sn.push_back(rne[q]); st += (double)rg[q].nta * rg[q].ntb; }
+                if (sub.empty()) continue;
+                int tpw = (int)std::max(4.0, std::min(32.0, st / 2048.0)); tpw &= ~3; int wgs = 0;
+                for (auto& it : sub) { const int nwg = (it.nta * it.ntb + tpw - 1) / tpw; it.tpw = tpw; it.tile_begin = wgs; stb.push_back(wgs); snt.push_back(nwg); wgs += nwg; }
                 Buf npr = dalloc(s, (size_t)wgs * sizeof(double));
-                const FiberItem* d = upload(s, rg);
-                { ProfScope ps(s, TNQS_PROF_GATE_APPLY, rby, rfl); launch_mfma_rowgemm(s->stream, d, (int)rg.size(), wgs, 2, reinterpret_cast<double*>(npr->p)); }
-                norm_and_replace<T>(s, rverts, routs, rne, npr, rtb, rnt, ao.normalize_tensors != 0);
+                const FiberItem* d = upload(s, sub);
+                { ProfScope ps(s, TNQS_PROF_GATE_APPLY, booked ? 0.0 : rby, booked ? 0.0 : rfl); booked = true; launch_mfma_rowgemm(s->stream, d, (int)sub.size(), wgs, 2, kk, reinterpret_cast<double*>(npr->p)); }
+                norm_and_replace<T>(s, sv, so, sn, npr, stb, snt, ao.normalize_tensors != 0);
             }
         }
         for (size_t q = 0; q < own_idx.size(); ++q) {

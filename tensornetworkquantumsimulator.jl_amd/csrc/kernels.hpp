@@ -159,7 +159,7 @@ struct CopyItem { const void* src; void* dst; size_t n16; };                    
 // register-direct MFMA fiber GEMM for chi = 64 sites (kernels_chi64.hip): rowgemm_tiles() sets the tile grid of an item
 bool rowgemm_covers(const FiberItem& it);
 void rowgemm_tiles(FiberItem& it);
-void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, double* d_norm_partials);
+void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, int K, double* d_norm_partials);   // all items: the same K and D
 void launch_tall_gram(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);
 void launch_tall_rt(hipStream_t s, const TallSvdItem* d_items, int nitems);
 void launch_tall_w(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);      // R0 slot (out, ComplexF32) = [L slot: R^-1, complex128] x Rrot

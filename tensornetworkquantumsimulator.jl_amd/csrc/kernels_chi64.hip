@@ -491,29 +491,36 @@ __global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __re
         if (tid == 0) norm_partials[gw] = sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3];
     }
 }
-// shapes: (KK, NN) in {(64, 64): D = 1 mode products at chi = 64;  (128, <= 128): D = 2 gate epilogue at chi = 64}
+// shapes (K = bond dimension of the contracted leg, D = 1: mode product, D = 2: gate epilogue with the site index folded in):
+//   chi = 64: <2,2,1> (KK = NN = 64), <4,4,2> (KK = NN = 128);   chi = 32: <1,1,1> (KK = NN = 32), <2,2,2> (KK = NN = 64)
+static int rowgemm_variant(const FiberItem& it) {
+    if (it.D != it.Do || (it.D != 1 && it.D != 2) || it.No < 1 || it.No > it.K) return -1;
+    if (it.K == 64) return it.D == 1 ? 0 : 1;
+    if (it.K == 32) return it.D == 1 ? 2 : 3;
+    return -1;
+}
 bool rowgemm_covers(const FiberItem& it) {
     if (it.PA >= 32) { if (it.PA % 32 != 0) return false; }
     else if (it.PA < 1 || 32 % it.PA != 0 || it.PB % (32 / it.PA) != 0) return false;
-    if (it.D == 1 && it.Do == 1 && it.K == 64 && it.No <= 64 && it.No >= 1) return true;
-    if (it.D == 2 && it.Do == 2 && it.K == 64 && it.No <= 64 && it.No >= 1) return true;
-    return false;
+    return rowgemm_variant(it) >= 0;
 }
 void rowgemm_tiles(FiberItem& it) {       // tile grid of an item rowgemm_covers() accepted
     it.TA = 32; it.TB = 1;
     if (it.PA >= 32) { it.nta = it.PA / 32; it.ntb = it.PB; } else { it.nta = 1; it.ntb = it.PB / (32 / it.PA); }
 }
-void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, double* d_norm_partials) {
+template <int KB, int NB, int D> static void launch_rowgemm_t(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, double* d_norm_partials) {
+    const size_t lds = (size_t)(16 * KB) * NB * 64 * sizeof(v2f);
+    set_max_dynamic_lds((const void*)mfma_rowgemm_kernel<KB, NB, D>, lds);
+    hipLaunchKernelGGL((mfma_rowgemm_kernel<KB, NB, D>), dim3(total_wgs), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
+}
+// all items of one launch must share K and D (the caller groups them)
+void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, int K, double* d_norm_partials) {
     if (total_wgs <= 0) return;
-    if (D == 1) {
-        const size_t lds = (size_t)32 * 2 * 64 * sizeof(v2f);
-        set_max_dynamic_lds((const void*)mfma_rowgemm_kernel<2, 2, 1>, lds);
-        hipLaunchKernelGGL((mfma_rowgemm_kernel<2, 2, 1>), dim3(total_wgs), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
-    } else {
-        const size_t lds = (size_t)64 * 4 * 64 * sizeof(v2f);
-        set_max_dynamic_lds((const void*)mfma_rowgemm_kernel<4, 4, 2>, lds);
-        hipLaunchKernelGGL((mfma_rowgemm_kernel<4, 4, 2>), dim3(total_wgs), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
-    }
+    if (K == 64 && D == 1) launch_rowgemm_t<2, 2, 1>(s, d_items, nitems, total_wgs, d_norm_partials);
+    else if (K == 64 && D == 2) launch_rowgemm_t<4, 4, 2>(s, d_items, nitems, total_wgs, d_norm_partials);
+    else if (K == 32 && D == 1) launch_rowgemm_t<1, 1, 1>(s, d_items, nitems, total_wgs, d_norm_partials);
+    else if (K == 32 && D == 2) launch_rowgemm_t<2, 2, 2>(s, d_items, nitems, total_wgs, d_norm_partials);
+    else throw std::runtime_error("launch_mfma_rowgemm: shape not covered");
 }
 
 // ------------------------------------------------------------------------------------------------------------
