@@ -156,7 +156,7 @@ def main():
     KERNEL_OF = {"bp_pair": "tnqs::mfma_pair_kernel", "bp_modeprod": "tnqs::mfma_fiber_gemm_w_kernel<1, 1, 8>",
                  "gate_modeprod": "tnqs::mfma_pair_kernel", "bp_fused": "tnqs::mfma_gram32_fused_kernel",
                  "bp_gram": "tnqs::mfma_gram32_kernel", "gate_gram": "tnqs::mfma_gram64_f64_kernel",
-                 "gate_apply": "tnqs::mfma_apply64_kernel", "bp_pairgram": "tnqs::mfma_pair_gram2_kernel"}
+                 "gate_apply": "tnqs::mfma_rowgemm_kernel<2, 2, 2>", "bp_pairgram": "tnqs::mfma_pair_gram2_kernel"}
     traffic_db = {}
     try:
         with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
