@@ -51,7 +51,10 @@ enum {
  * (src/MessagePassing/abstractbeliefpropagationcache.jl:223-259, beliefpropagationcache.jl:51-72,103-117). */
 typedef struct {
     int maxiter;          /* <= 0: reference default (25 on loopy graphs, 1 on trees) */
-    double tolerance;     /* < 0: none (no convergence check);  NaN: reference default (1e-5 c64 / 1e-8 c128, none on trees) */
+    double tolerance;     /* < 0: none (no convergence check) -- what `update(bpc; maxiter = 10)` means in the reference, whose
+                           * default_tolerance(::Algorithm"bp") is `nothing`;  NaN: the tolerance of default_bp_update_kwargs
+                           * (1e-5 f32 / c64, 1e-8 f64 / c128, none on trees), i.e. what apply_gates / truncate / normalize use when
+                           * bp_update_kwargs is omitted.  A NULL opts pointer = default_bp_update_kwargs altogether */
     int normalize;        /* message_update_alg "contract" kwarg `normalize` (default true): m <- m / sum(m) */
     int n_sequence;       /* 0: library default edge sequence (edge-colour grouped Gauss-Seidel) */
     const int32_t* seq_src; /* explicit `edge_sequence` kwarg: directed edges, swept sequentially (Gauss-Seidel) */
