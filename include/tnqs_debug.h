@@ -24,6 +24,9 @@ int tnqs_dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void*
 int tnqs_dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* M, void* out);
 /* c64 only: both Grams of the plane (lx, ly) in one pass: out_y keeps ly (lx absorbed with Mx), out_x keeps lx (ly absorbed with My) */
 int tnqs_dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* Mx, const void* My, void* out_y, void* out_x);
+/* timing only: average launch duration (ms, HIP events) of a chi = 32 plane kernel over `nsites` device-resident tensors [2][32]^4;
+ * which = 0 pair product on legs (lx, ly), 1 both-messages pair-Gram */
+int tnqs_dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms);
 /* c64 only, d = 2, chi_b = 32: out[s',b',rest] = sum in[s,b,rest] X[(s + 2 b) + 64 (s' + 2 b')]; *norm2 = |out|^2 */
 int tnqs_dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2);
 /* the BP sweep order bp_update uses when no edge_sequence is given, as (src[i] -> dst[i]) vertex indices; *n_out = its length (2 ne) */

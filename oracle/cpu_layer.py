@@ -182,6 +182,22 @@ def _gemm_rates(chi: int, nthreads: int, pool: ThreadPoolExecutor) -> dict:
     return {"square_cgemm_gflops": round(square, 1), "mode_product_shape_gflops": round(skinny, 1)}
 
 
+def _keep_big_blocks_on_the_heap():
+    """glibc hands every allocation above 128 KiB to mmap and gives it back on free: each 16 MB temporary of a contraction is mapped, page-
+    faulted in (4096 faults) and unmapped again -- with 64 threads doing that at once the kernel's mm lock, not the arithmetic, sets the
+    pace.  Raising the mmap / trim thresholds keeps those blocks in the malloc arenas, where they are reused warm.  (What a compiled CPU
+    code gets for free by owning its workspaces.)"""
+    try:
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 1 << 30)        # M_MMAP_THRESHOLD
+        libc.mallopt(-1, 1 << 30)        # M_TRIM_THRESHOLD (int argument)
+        libc.mallopt(-2, 1 << 28)        # M_TOP_PAD
+        return True
+    except Exception:
+        return False
+
+
 def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int = 1234, nlayers: int = 1) -> dict:
     """one TFIM layer (README.md:42-48 angles) on an L x L PERIODIC torus -- every site has the bulk degree 4, L^2 sites, 2 L^2 edges, four
     colours for even L -- at bond dimension chi, ComplexF32, from BP-converged messages, reference-default bp_update_kwargs."""
@@ -189,6 +205,8 @@ def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int
     # physical cores on an SMT-2 host, capped at 64: numpy's bundled OpenBLAS is built for at most 64 concurrent callers (NUM_THREADS = 64;
     # beyond that it warns, and with the nested chunk maps of this module it crashed on the 128-core box)
     nthreads = nthreads or max(1, min(64, (os.cpu_count() or 2) // 2))
+    if os.environ.get("TNQS_CPU_NO_MALLOPT") != "1":
+        _keep_big_blocks_on_the_heap()
     g = o.named_grid((L, L), periodic=True)
     groups = o.edge_color(g)
     one_site = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]

@@ -174,6 +174,7 @@ namespace tnqs { void dbg_default_sequence(const State* s, std::vector<int>& src
                  void dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in, const void* Mx, const void* My, void* out);
                  void dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2);
                  void dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* Mx, const void* My, void* out_y, void* out_x);
+                 void dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms);
                  void dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* M, void* out);
                  void dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, const void* in, const void* X, void* out, double* norm2, int use_mfma);
                  void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma); }
@@ -192,6 +193,7 @@ int tnqs_dbg_apply64(int z, const int* chi, int b, const void* in, const void* X
 int tnqs_dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* Mx, const void* My, void* out_y, void* out_x) {
     return guard([&] { dbg_pair_gram2(d, z, chi, lx, ly, X, Y, Mx, My, out_y, out_x); });
 }
+int tnqs_dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms) { return guard([&] { dbg_bench_plane(which, nsites, lx, ly, reps, ms); }); }
 int tnqs_dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* M, void* out) { return guard([&] { dbg_pair_gram(d, z, chi, lx, ly, X, Y, M, out); }); }
 int tnqs_dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out) { return guard([&] { dbg_gram_fused(PA, K, PB, X, Y, M, out); }); }
 int tnqs_dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma) {

@@ -115,7 +115,7 @@ void dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const v
     it.g.n2 = NHI; it.g.t2 = (long long)C0 * 32 * NMID * 32;
     int nslices = (C0 / 16) * NMID * NHI;
     dI.up(&it, sizeof(it));
-    launch_mfma_pair(nullptr, (const PairItem*)dI.p, 1, (nslices + it.spw - 1) / it.spw);
+    launch_mfma_pair(nullptr, (const PairItem*)dI.p, 1, pair_wgs(nslices, it.spw));
     HIPCHK(hipDeviceSynchronize());
     dOut.down(out, n * 8);
 }
@@ -132,7 +132,7 @@ void dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in,
     int nslices = it.g.n0 * it.g.n1 * it.g.n2;
     if ((size_t)nslices * 16 * 1024 != n) throw Err(TNQS_ERR_INVALID, "dbg_pair_legs: slice count");
     dI.up(&it, sizeof(it));
-    launch_mfma_pair(nullptr, (const PairItem*)dI.p, 1, (nslices + it.spw - 1) / it.spw);
+    launch_mfma_pair(nullptr, (const PairItem*)dI.p, 1, pair_wgs(nslices, it.spw));
     HIPCHK(hipDeviceSynchronize());
     dOut.down(out, n * 8);
 }
@@ -164,7 +164,7 @@ void dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X,
     size_t n = d; for (int i = 0; i < z; ++i) n *= chi[i];
     int nslices = it.g.n0 * it.g.n1 * it.g.n2;
     it.spw = 3; it.wg_begin = 0;
-    int npairs = (nslices + it.spw - 1) / it.spw, nwg = 16 * ((npairs + 7) / 8), npart = nwg;
+    int npairs = (nslices + it.spw - 1) / it.spw, nwg = pair_gram2_group() * ((npairs + 7) / 8), npart = nwg;
     DBuf dX(n * 8), dY(n * 8), dMx(1024 * 8), dMy(1024 * 8), dI(sizeof(PairGram2Item)), dR(2 * sizeof(ReduceItem)), dP1((size_t)npart * 1024 * 8), dP2((size_t)npart * 1024 * 8), dO(2 * 1024 * 8);
     dX.up(X, n * 8); dY.up(Y, n * 8); dMx.up(Mx, 1024 * 8); dMy.up(My, 1024 * 8);
     it.X = dX.p; it.Y = dY.p; it.Mx = dMx.p; it.My = dMy.p; it.partial_y = dP1.p; it.partial_x = dP2.p;
@@ -176,6 +176,53 @@ void dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X,
     HIPCHK(hipDeviceSynchronize());
     dO.down(out_y, 1024 * 8);
     HIPCHK(hipMemcpy(out_x, (char*)dO.p + 1024 * 8, 1024 * 8, hipMemcpyDeviceToHost));
+}
+// timing of the chi = 32 plane kernels on `nsites` degree-4 site tensors [2][32]^4 resident in HBM (which: 0 pair product on legs (lx, ly),
+// 1 both-messages pair-Gram); *ms = average launch duration over `reps` launches (HIP events), after one untimed launch
+void dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms) {
+    need_gpu();
+    const int chi[4] = {32, 32, 32, 32};
+    PairGeom g{};
+    if (!pair_geometry(2, 4, chi, lx, ly, g)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_bench_plane: legs not covered");
+    const size_t n = (size_t)2 * 32 * 32 * 32 * 32, nslices = (size_t)g.n0 * g.n1 * g.n2;
+    DBuf dA((size_t)nsites * n * 8), dB((size_t)nsites * n * 8), dM(2 * 1024 * 8);
+    HIPCHK(hipMemsetD32((hipDeviceptr_t)dA.p, 0x3c23d70a, (size_t)nsites * n * 2));       // 0.01f everywhere: the timing does not depend on the data
+    HIPCHK(hipMemsetD32((hipDeviceptr_t)dB.p, 0x3c23d70a, (size_t)nsites * n * 2));
+    HIPCHK(hipMemsetD32((hipDeviceptr_t)dM.p, 0x3c23d70a, 2 * 1024 * 2));
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    float t = 0.f;
+    if (which == 0) {
+        std::vector<PairItem> items(nsites);
+        const int spw = pair_spw((double)nsites * nslices); int wgs = 0;
+        for (int i = 0; i < nsites; ++i) {
+            PairItem& it = items[i]; it.g = g; it.in = (char*)dA.p + (size_t)i * n * 8; it.out = (char*)dB.p + (size_t)i * n * 8;
+            it.Mx = dM.p; it.My = (char*)dM.p + 1024 * 8; it.slice_begin = wgs; it.spw = spw; wgs += pair_wgs((int)nslices, spw);
+        }
+        DBuf dI(items.size() * sizeof(PairItem)); dI.up(items.data(), items.size() * sizeof(PairItem));
+        launch_mfma_pair(nullptr, (const PairItem*)dI.p, nsites, wgs);
+        HIPCHK(hipEventRecord(e0, nullptr));
+        for (int r = 0; r < reps; ++r) launch_mfma_pair(nullptr, (const PairItem*)dI.p, nsites, wgs);
+        HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1)); HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    } else {
+        std::vector<PairGram2Item> items(nsites);
+        const int spw = 16; int wgs = 0;
+        const int npairs = (int)((nslices + spw - 1) / spw), nwg = pair_gram2_group() * ((npairs + 7) / 8);
+        DBuf dP((size_t)2 * nsites * nwg * 1024 * 8);
+        for (int i = 0; i < nsites; ++i) {
+            PairGram2Item& it = items[i]; it.g = g; it.X = (char*)dA.p + (size_t)i * n * 8; it.Y = (char*)dB.p + (size_t)i * n * 8;
+            it.Mx = dM.p; it.My = (char*)dM.p + 1024 * 8; it.wg_begin = wgs; it.spw = spw;
+            it.partial_y = (char*)dP.p + (size_t)(2 * i) * nwg * 1024 * 8; it.partial_x = (char*)dP.p + (size_t)(2 * i + 1) * nwg * 1024 * 8;
+            wgs += nwg;
+        }
+        DBuf dI(items.size() * sizeof(PairGram2Item)); dI.up(items.data(), items.size() * sizeof(PairGram2Item));
+        launch_mfma_pair_gram2(nullptr, (const PairGram2Item*)dI.p, nsites, wgs);
+        HIPCHK(hipEventRecord(e0, nullptr));
+        for (int r = 0; r < reps; ++r) launch_mfma_pair_gram2(nullptr, (const PairGram2Item*)dI.p, nsites, wgs);
+        HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1)); HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms = (double)t / reps;
 }
 void dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2) {
     need_gpu();

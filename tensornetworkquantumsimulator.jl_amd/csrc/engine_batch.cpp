@@ -35,7 +35,7 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
             tot_slices += (double)c.sd.n / (16.0 * 1024.0);
         }
         if (!sel.empty()) {
-            int spw = (int)std::max(1.0, std::min(8.0, tot_slices / 2048.0));
+            const int spw = pair_spw(tot_slices);
             for (auto& se : sel) {
                 Chain& c = chains[se.first];
                 int x = c.steps[se.second.first].first, y = c.steps[se.second.second].first;
@@ -45,7 +45,7 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
                 it.in = c.result; it.out = dst->p; it.Mx = c.steps[se.second.first].second; it.My = c.steps[se.second.second].second;
                 if (!pair_geometry(c.sd.d, c.sd.z, c.sd.chi.data(), x, y, it.g)) throw Err(TNQS_ERR_HIP, "internal: pair geometry");
                 int nslices = it.g.n0 * it.g.n1 * it.g.n2;
-                it.spw = spw; it.slice_begin = wgs; wgs += (nslices + spw - 1) / spw;
+                it.spw = spw; it.slice_begin = wgs; wgs += pair_wgs(nslices, spw);
                 items.push_back(it);
                 c.result = dst->p; nt[se.first]++;
                 // drop the two consumed steps

@@ -395,8 +395,8 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 for (int ci : is_shared_chain) is_shared[ci] = 1;
                 HostTimer ht_launch(1);
                 if (!sh_pair.empty()) {
-                    int spw = (int)std::max(1.0, std::min(8.0, sh_pair_slices / 2048.0)); int wgs = 0;
-                    for (auto& it : sh_pair) { it.spw = spw; it.slice_begin = wgs; wgs += (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw; }
+                    const int spw = pair_spw(sh_pair_slices); int wgs = 0;
+                    for (auto& it : sh_pair) { it.spw = spw; it.slice_begin = wgs; wgs += pair_wgs(it.g.n0 * it.g.n1 * it.g.n2, spw); }
                     const PairItem* d = upload(s, sh_pair);
                     ProfScope ps(s, TNQS_PROF_BP_PAIR, 2.0 * sh_pair_slices * 16384.0 * esz, 2 * 8.0 * sh_pair_slices * 16384.0 * 32);
                     launch_mfma_pair(s->stream, d, (int)sh_pair.size(), wgs);
@@ -415,13 +415,13 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     int spw = 16, wgs = 0;
                     for (; spw > 1; spw >>= 1) {
                         long tot = 0;
-                        for (auto& it : sh_dbl) { int np = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw; tot += 16 * ((np + 7) / 8); }
+                        for (auto& it : sh_dbl) { int np = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw; tot += 16 * ((np + 7) / 8); }      // (counted in half-slice workgroups for both kernels)
                         if (tot >= 1024) break;
                     }
                     for (size_t q = 0; q < sh_dbl.size(); ++q) {
                         PairGram2Item& it = sh_dbl[q]; GramJob& jy = jobs[sh_dbl_chain[q].first]; GramJob& jx = jobs[sh_dbl_chain[q].second];
                         const int npairs = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw;     // workgroup pairs (one per half), in groups of 8 pairs
-                        const int nwg = 16 * ((npairs + 7) / 8);
+                        const int nwg = pair_gram2_group() * ((npairs + 7) / 8);
                         it.spw = spw; it.wg_begin = wgs; wgs += nwg;
                         jy.nchunks = jx.nchunks = nwg; jy.KK = jx.KK = 32;             // one partial per workgroup
                         jy.partial = dalloc(s, (size_t)jy.nchunks * 1024 * esz); jx.partial = dalloc(s, (size_t)jx.nchunks * 1024 * esz);

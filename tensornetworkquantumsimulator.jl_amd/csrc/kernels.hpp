@@ -226,8 +226,8 @@ inline bool apply64_geometry(int d, int z, const int* chi, int b, PairGeom& g) {
 struct PairItem {         // out = in x_x Mx x_y My for two 32-dimensional legs
     const void* in; void* out; const void* Mx; const void* My;
     PairGeom g;
-    int slice_begin;      // first workgroup id of this item
-    int spw;              // slices (16 companions x 32 x 32) walked by one workgroup
+    int slice_begin;      // first workgroup id of this item (a multiple of 16)
+    int spw;              // slices (16 companions x 32 x 32) walked by one PAIR of workgroups (each takes 8 of the 16 companions)
 };
 struct PairGramItem {     // partial[b,b'] = sum_{rest, jx} (sum_ix X[.. ix .. b ..] M[ix, jx]) conj(Y[.. jx .. b' ..]);  x = absorbed leg, y = kept leg
     const void* X; const void* Y; const void* M; void* partial;   // 8 partials (one per wave) per workgroup, 32*32 complex each
@@ -295,6 +295,10 @@ bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, 
 bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);
 // fused pair of mode products on two slow 32-dim legs (16 companions = 128-byte runs per workgroup)
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs);
+// workgroups of one PairItem: ceil(nslices / spw) slice ranges in groups of 8, two workgroups (one per 8-companion half) per range
+inline int pair_wgs(int nslices, int spw) { const int np = (nslices + spw - 1) / spw; return 16 * ((np + 7) / 8); }
+// slices per workgroup for a batch of `total_slices`: the largest power of two <= 16 that still gives >= 1024 workgroups
+inline int pair_spw(double total_slices) { int spw = 16; while (spw > 1 && 2.0 * total_slices / spw < 1024.0) spw >>= 1; return spw; }
 // gate epilogue psi' = psi x_(s,b) X for d = 2, chi_b = chi_b' = 32 (K = N = 64) in the pair-kernel shape: plane (b, y) per companion,
 // the two site components of a companion are the planes of one wave.  Xb = X rearranged into MFMA B-operand order (make_xb).
 struct Apply64Item { const void* in; void* out; const void* Xb; PairGeom g; int wg_begin; int spw; double* norm_partial; };
@@ -306,6 +310,7 @@ void launch_mfma_apply64(hipStream_t s, const Apply64Item* d_items, int nitems, 
 //   partial_x[d,d'] = sum (X x_ly My)[.. d on lx ..] conj(Y[.. d' on lx ..])      (message leaving through lx: ly absorbed with My)
 struct PairGram2Item { const void* X; const void* Y; const void* Mx; const void* My; void* partial_y; void* partial_x; PairGeom g; int wg_begin; int spw; };
 void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs);
+int pair_gram2_group();      // workgroups of one group of 8 slice ranges: 32 (a workgroup walks one quarter of each slice)
 // last absorption + Gram on two arbitrary 32-dim legs (absorbed leg x, kept leg y), reading a (cached) pair product X and psi = Y
 void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitems, int total_wgs);
 

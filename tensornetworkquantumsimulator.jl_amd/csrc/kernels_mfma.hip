@@ -13,6 +13,7 @@
 #define TNQS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP kernel launch failed (") + __func__ + "): " + hipGetErrorString(e_)); } while (0)
 #include "kernels.hpp"
 #include "mfma_common.hpp"
+#include <type_traits>
 #include "launch_util.hpp"
 
 namespace tnqs {
@@ -639,12 +640,15 @@ void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems
 // ------------------------------------------------------------------------------------------------------------
 // pair of mode products on two legs x, y (dimension 32 each) in ONE pass:
 //      out[c, jx, jy] = sum_{ix,iy} in[c, ix, iy] Mx[ix, jx] My[iy, jy]          for every companion index c
-// A workgroup takes 16 companions (PairGeom: 128-byte runs = full HBM efficiency) x the whole 32 x 32 plane of the two
-// legs: 16 planes of 8 KiB staged in LDS (de-interleaved, one plane per (wave, half)), both GEMMs of a plane chained in
-// registers exactly like the fused Gram:
-//   step 1  Y[iy][jx] = sum_ix S[ix][iy] Mx[ix][jx]      (A = S^T from LDS, B = Mx in registers)
+// A slice is 16 companions (PairGeom: 128-byte runs) x the 32 x 32 plane of the two legs; a workgroup walks HALF slices (8 companions,
+// one plane per wave; workgroups lw and lw + 8 of a group of 16 sit on the same XCD and take the two 64-byte halves of every line at the
+// same time).  Both GEMMs of a plane are chained in registers:
+//   step 1  Y[iy][jx] = sum_ix S[ix][iy] Mx[ix][jx]      (A = S^T from LDS, four updates ahead of their use; B = Mx in registers)
 //   step 2  S'[jx][jy] = sum_iy Y[iy][jx] My[iy][jy]      (A = Y's accumulator registers as they are, B = My in registers)
-// The next slice's 128 KiB are prefetched into registers while the matrix cores work.
+// with Gauss' three-multiplication complex product (CAcc32).  The planes are double-buffered in LDS (2 x 8 x 8.3 KiB): a phase computes
+// its plane in place, and the NEXT phase moves the result out (LDS -> global, one 16-byte store every six MFMAs of its step 2) while the
+// loads of the phase after it arrive (one every six MFMAs of step 1) and are committed over the locations the same thread just stored
+// from -- so one barrier per phase orders everything.
 // ------------------------------------------------------------------------------------------------------------
 // XCD-aware workgroup order: consecutive workgroup ids go round-robin over the 8 XCDs, so XCD x sees ids x, x+8, ...  Remapping id ->
 // (id % 8) * (n/8) + id / 8 gives every XCD one contiguous range of the work list (neighbouring slices share DRAM pages and L2 sets).
@@ -657,111 +661,123 @@ __device__ __forceinline__ long long pair_slice_base(const PairGeom& g, int sl) 
     int a0 = sl % g.n0; int r1 = sl / g.n0; int a1 = r1 % g.n1; int a2 = r1 / g.n1;
     return (long long)a0 * g.t0 + (long long)a1 * g.t1 + (long long)a2 * g.t2;
 }
-__global__ __launch_bounds__(512) void mfma_pair_kernel(const PairItem* __restrict__ items, int nitems, int dbg_skip, int xcd) {
-    // a plane holds (re, im) pairs: every LDS access moves a whole complex number (ds_*_b64)
-    constexpr int PS = 32 * 33 + 1;            // plane stride in complex elements, pitch 33 (odd: the 8 companion pairs of a run hit different banks)
+template <bool M3>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mfma_pair_kernel(const PairItem* __restrict__ items, int nitems) {
+    constexpr int PS = 32 * 33 + 1;            // plane stride in complex elements, pitch 33 (rows and columns both conflict-free)
+    constexpr int BUF = 8 * PS;
+    #define TNQS_PIN() __builtin_amdgcn_sched_barrier(0x2 | 0x4)      // VALU / SALU may cross; LDS, global and matrix instructions keep their order
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v2f* L = reinterpret_cast<v2f*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
     int lo = 0, hi_ = nitems - 1;
-    const int gw = xcd_remap(blockIdx.x, gridDim.x, xcd);
+    const int gw = blockIdx.x;
     while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].slice_begin <= gw) lo = mid; else hi_ = mid - 1; }
     const PairItem it = items[lo];
     const PairGeom g = it.g;
     const int nslices = g.n0 * g.n1 * g.n2;
-    const int s_begin = (gw - it.slice_begin) * it.spw, s_end = min(nslices, s_begin + it.spw);
+    const int lw = gw - it.slice_begin;                     // slice_begin is a multiple of 16
+    const int half = (lw >> 3) & 1, pw = ((lw >> 4) << 3) | (lw & 7);
+    const int s_begin = pw * it.spw, s_end = min(nslices, s_begin + it.spw);
     const cf* __restrict__ in = reinterpret_cast<const cf*>(it.in);
     cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
-    const cf* __restrict__ Mx = reinterpret_cast<const cf*>(it.Mx);
-    const cf* __restrict__ My = reinterpret_cast<const cf*>(it.My);
     // B operands: Mx[k = q+16h][j = ln] (step 1), My[k = kappa(r,h)][j = ln] (step 2); element (i,j) at i + 32 j
     float mxr[16], mxi[16], myr[16], myi[16];
+    {
+        const cf* __restrict__ Mx = reinterpret_cast<const cf*>(it.Mx) + 32 * ln; const cf* __restrict__ My = reinterpret_cast<const cf*>(it.My) + 32 * ln;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        cf a = Mx[(q + 16 * h) + 32 * ln]; mxr[q] = a.re; mxi[q] = a.im;
-        int kap = (q & 3) + 8 * (q >> 2) + 4 * h;
-        cf b = My[kap + 32 * ln]; myr[q] = b.re; myi[q] = b.im;
+        for (int q = 0; q < 16; q += 2) { const v4f v = ldg4(Mx + q + 16 * h); mxr[q] = v[0]; mxi[q] = v[1]; mxr[q + 1] = v[2]; mxi[q + 1] = v[3]; }
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {                   // kappa(q..q+3, h) = 2 q + 4 h + (0..3): four consecutive elements
+            const v4f u = ldg4(My + 2 * q + 4 * h), v = ldg4(My + 2 * q + 4 * h + 2);
+            myr[q] = u[0]; myi[q] = u[1]; myr[q + 1] = u[2]; myi[q + 1] = u[3]; myr[q + 2] = v[0]; myi[q + 2] = v[1]; myr[q + 3] = v[2]; myi[q + 3] = v[3];
+        }
     }
-    // cooperative mover: thread -> (f = companion pair 0..7, seg0 = first segment); a pass of 512 threads covers 64 segments
-    const int f = tid & 7, sg0 = tid >> 3;            // segments sg0, sg0 + 64, ... (16 per thread), seg = ix + 32*iy
-    const long long sx = g.sx, sy = g.sy, fo = (long long)f * g.cstr;
-    v4f pre[16];
-    // segment j of this thread: ix = sg0 & 31 (fixed), iy = (sg0 >> 5) + 2 j  ->  one base address and a constant stride
+    // mover: thread -> (companion pair f4 = 0..3 of the half, first segment sg0 = 0..127); segment j: ix = sg0 & 31, iy = (sg0 >> 5) + 4 j
+    const int f4 = tid & 3, sg0 = tid >> 2;
     const int ix0 = sg0 & 31, iy0 = sg0 >> 5;
-    const long long toff = fo + sx * ix0 + sy * iy0, tstr = 2 * sy;
-    v2f* const lbase = L + (2 * f) * PS + iy0 * 33 + ix0;
-    auto issue = [&](int sl) {
-        const cf* p = in + pair_slice_base(g, sl) + toff;
+    const long long toff = (long long)(4 * half + f4) * g.cstr + g.sx * ix0 + g.sy * iy0, tstr = 4 * g.sy;
+    v2f* const lbase = L + (2 * f4) * PS + iy0 * 33 + ix0;           // element (ix, iy) of a plane at [iy][ix]; iy advances by 4 per j (132 elements)
+    v4f pre[8];
+    auto commit = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) pre[j] = ldg4(p + tstr * j);
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            v2f* p0 = lbase + 66 * j;                            // plane 2f: element (ix, iy) stored at [iy][ix]; plane 2f+1 one stride further
+        for (int j = 0; j < 8; ++j) {
+            v2f* p0 = lbase + buf * BUF + 132 * j;
             v2f a; a[0] = pre[j][0]; a[1] = pre[j][1]; v2f b; b[0] = pre[j][2]; b[1] = pre[j][3];
             p0[0] = a; p0[PS] = b;
         }
     };
-
-    if (s_begin < s_end) issue(s_begin);
-    for (int sl = s_begin; sl < s_end; ++sl) {
-        lds_barrier();                                          // previous slice's results have left the LDS
-        commit();
-        lds_barrier();
-        if (sl + 1 < s_end) issue(sl + 1);
-#pragma unroll 1
-        for (int pp = 0; pp < 2; ++pp) {
-            if (dbg_skip == 1) break;
-            v2f* P = L + (w + 8 * pp) * PS;
-            float ar[16], ai[16];
+    auto store1 = [&](int buf, long long ob, int j) {            // one 16-byte piece of a finished phase: LDS -> global
+        const v2f* p0 = lbase + buf * BUF + 132 * j;
+        const v2f a = p0[0], c = p0[PS];
+        v4f v; v[0] = a[0]; v[1] = a[1]; v[2] = c[0]; v[3] = c[1];
+        stg4(out + ob + tstr * j, v);
+    };
+    if (s_begin < s_end) {
+        const long long b = pair_slice_base(g, s_begin) + toff;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { v2f v = P[ln * 33 + q + 16 * h]; ar[q] = v[0]; ai[q] = v[1]; }     // A[i=iy=ln][k=ix]
-            v16f Yr, Yi;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { Yr[r] = 0.f; Yi[r] = 0.f; }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                Yr = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], mxr[q], Yr, 0, 0, 0);
-                Yr = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai[q], mxi[q], Yr, 0, 0, 0);
-                Yi = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], mxi[q], Yi, 0, 0, 0);
-                Yi = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[q], mxr[q], Yi, 0, 0, 0);
-            }
-            v16f Sr, Si;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { Sr[r] = 0.f; Si[r] = 0.f; }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                Sr = __builtin_amdgcn_mfma_f32_32x32x2f32(Yr[r], myr[r], Sr, 0, 0, 0);
-                Sr = __builtin_amdgcn_mfma_f32_32x32x2f32(-Yi[r], myi[r], Sr, 0, 0, 0);
-                Si = __builtin_amdgcn_mfma_f32_32x32x2f32(Yr[r], myi[r], Si, 0, 0, 0);
-                Si = __builtin_amdgcn_mfma_f32_32x32x2f32(Yi[r], myr[r], Si, 0, 0, 0);
-            }
-            __builtin_amdgcn_wave_barrier();
-            // S'[jx = kappa(r,h)][jy = ln] -> LDS [jy][jx] (the plane is private to this wave)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { int jx = (r & 3) + 8 * (r >> 2) + 4 * h; v2f v; v[0] = Sr[r]; v[1] = Si[r]; P[ln * 33 + jx] = v; }
-        }
-        lds_barrier();
-        {
-            cf* p = out + pair_slice_base(g, sl) + toff;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const v2f* p0 = lbase + 66 * j;
-                const v2f a = p0[0], c = p0[PS];
-                v4f v; v[0] = a[0]; v[1] = a[1]; v[2] = c[0]; v[3] = c[1];
-                stg4(p + tstr * j, v);
-            }
-        }
+        for (int j = 0; j < 8; ++j) pre[j] = ldg4(in + b + tstr * j);
+        commit(0);
     }
+    lds_barrier();
+    for (int sl = s_begin; sl < s_end; ++sl) {
+        const int buf = (sl - s_begin) & 1;
+        const bool more = sl + 1 < s_end, prev = sl > s_begin;
+        const long long nb = pair_slice_base(g, more ? sl + 1 : sl) + toff;      // (the last phase re-reads its own slice: no branch in the stream)
+        const long long ob = pair_slice_base(g, prev ? sl - 1 : sl) + toff;
+        v2f* P = L + buf * BUF + w * PS;
+        v2f xc[4], xn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xc[i] = P[ln * 33 + i + 16 * h];            // A[i = iy = ln][k = ix]
+        // ---- step 1 ---------------------------------------------------------------------------------------------------------------
+        CAcc32<M3> Y;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            if (c4 < 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xn[i] = P[ln * 33 + 4 * (c4 + 1) + i + 16 * h];
+            }
+            TNQS_PIN();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = 4 * c4 + i;
+                const float br = mxr[q], bi = mxi[q];
+                if (q == 0) Y.template mac_bpre<true>(xc[i][0], xc[i][1], br, M3 ? bi - br : bi, M3 ? br + bi : -bi);
+                else Y.template mac_bpre<false>(xc[i][0], xc[i][1], br, M3 ? bi - br : bi, M3 ? br + bi : -bi);
+                if ((q & 1) == 0) { pre[q >> 1] = ldg4(in + nb + tstr * (q >> 1)); TNQS_PIN(); }      // next phase's loads, one every two updates
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xc[i] = xn[i];
+        }
+        // ---- step 2 (and the previous phase's plane on its way out) -----------------------------------------------------------------
+        CAcc32<M3> S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float br = myr[r], bi = myi[r];
+            if (r == 0) S.template mac_bpre<true>(Y.re(r), Y.im(r), br, M3 ? bi - br : bi, M3 ? br + bi : -bi);
+            else S.template mac_bpre<false>(Y.re(r), Y.im(r), br, M3 ? bi - br : bi, M3 ? br + bi : -bi);
+            if ((r & 1) == 0) { if (prev) store1(buf ^ 1, ob, r >> 1); TNQS_PIN(); }
+        }
+        S.finish();
+        // S'[jx = kappa(r,h)][jy = ln] -> LDS [jy][jx] (the plane is private to this wave; its reads are complete)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int jx = (r & 3) + 8 * (r >> 2) + 4 * h; v2f v; v[0] = S.a[r]; v[1] = S.b[r]; P[ln * 33 + jx] = v; }
+        if (more) commit(buf ^ 1);                // over the locations this thread stored from above
+        lds_barrier();
+    }
+    if (s_begin < s_end) {                         // the last phase's plane
+        const int buf = (s_end - 1 - s_begin) & 1;
+        const long long ob = pair_slice_base(g, s_end - 1) + toff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) store1(buf, ob, j);
+    }
+    #undef TNQS_PIN
 }
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
     const size_t lds = (size_t)16 * (32 * 33 + 1) * 2 * sizeof(float);
-    set_max_dynamic_lds((const void*)mfma_pair_kernel, lds);
-    static int skip = -1; if (skip < 0) { const char* e = std::getenv("TNQS_DBG_PAIR_SKIP"); skip = e ? std::atoi(e) : 0; }
-    static int xcd = -1; if (xcd < 0) { const char* e = std::getenv("TNQS_XCD_REMAP"); xcd = e ? std::atoi(e) : 0; }
-    hipLaunchKernelGGL(mfma_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems, skip, xcd); TNQS_CHECK_LAUNCH();
+    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_pair_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    else { set_max_dynamic_lds((const void*)mfma_pair_kernel<false>, lds); hipLaunchKernelGGL(mfma_pair_kernel<false>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -888,149 +904,168 @@ void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitem
 // BOTH messages a degree-4 site sends into a linear forest, from one pass over the shared pair product X and psi = Y:
 //      out_y[b,b'] = sum_{c,jx} ( sum_ix X[c,ix,b] Mx[ix,jx] ) conj Y[c,jx,b']      (kept leg y, leg x absorbed)
 //      out_x[d,d'] = sum_{c,jy} ( sum_iy X[c,d,iy] My[iy,jy] ) conj Y[c,d',jy]      (kept leg x, leg y absorbed)
-// Twice the matrix work of the single kernel per byte (64 flop/B): MFMA-bound, so 8 companions per slice (64-byte runs) are
-// enough and X and Y planes of a slice are resident TOGETHER: wave w owns companion w, its X and Y planes never leave it, the
-// second message uses the same planes read transposed.  Mx, My sit in LDS as A operands.  Two barriers per slice.
+// 64 algorithmic flop per byte: matrix-core bound.  QUARTER slices: a workgroup takes 4 of a slice's 16 companions per phase (workgroups
+// lw, lw+8, lw+16, lw+24 of a group of 32 sit on the same XCD and walk the same slices at the same time, so the other three 32-byte
+// quarters of every line are L2 hits), and its eight waves are (companion c = w & 3) x (message m = w >> 2): a wave carries ONE output
+// accumulator, which leaves the registers for Gauss' three-multiplication product (CAcc32<true>: 3 accumulators per complex tile) on both
+// steps,   step 1  C[j'][kept] = sum_k M[k][j'] X[k][kept]     step 2  O[kept][kept'] += sum_j' C[j'][kept] conj Y[j'][kept']
+// with C's accumulator registers as step 2's A operand.  A phase's planes (4 X + 4 Y = 66 KiB) are double-buffered in LDS: the next
+// phase's planes are loaded to registers while the matrix cores work and written into the other buffer at the end of the phase -- one
+// barrier per phase, no dead time between barriers.  The wave's matrix (Mx or My, by its message) lives in REGISTERS as the A operands
+// of step 1 (m_r + m_i, m_r, m_i: 48 registers, no LDS traffic and no VALU work for them); the plane operands are read from LDS four
+// updates ahead of their use (explicit register double buffer, pinned by scheduling barriers -- left to itself the compiler issues each
+// ds_read directly in front of the MFMA that needs it); the eight global loads of the next phase are spread over the first half of the
+// phase, one every six MFMAs (a burst of eight 32-lines-per-instruction loads at the phase start stalled the issue: 129 -> 143 TFLOP/s).
+// Measured on 100 device-resident sites (profiles/plane_bench.py): 147 TFLOP/s algorithmic (8 flop per complex multiply-add), against
+// 129 for the same kernel with LDS-resident matrices and compiler-scheduled reads and 114 for the round-2 half-slice kernel it replaces.
+// M3 = false (TNQS_NO_3M=1): the same schedule with the four-multiplication product.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void mfma_pair_gram2_kernel(const PairGram2Item* __restrict__ items, int nitems) {
+template <bool M3>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mfma_pair_gram2_kernel(const PairGram2Item* __restrict__ items, int nitems) {
     constexpr int PS = 32 * 33 + 1;            // plane stride in complex elements
+    constexpr int BUF = 8 * PS;                // one phase: X planes of companions 0..3, then their Y planes
+    // scheduling barrier: VALU / SALU may cross, LDS, global-memory and matrix instructions keep their program order
+    #define TNQS_PIN() __builtin_amdgcn_sched_barrier(0x2 | 0x4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    v2f* L = reinterpret_cast<v2f*>(smem);     // planes 0..7: X of companions 0..7, planes 8..15: Y
-    v2f* Mxl = L + 16 * PS;                    // Mx^T as an A operand: element (i, j) at j*33 + i
-    v2f* Myl = Mxl + 32 * 33;
+    v2f* L = reinterpret_cast<v2f*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
     int lo = 0, hi_ = nitems - 1;
     const int gw = blockIdx.x;
     while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].wg_begin <= gw) lo = mid; else hi_ = mid - 1; }
     const PairGram2Item it = items[lo];
     const PairGeom g = it.g;
-    // A slice of the geometry (16 companions = one 128-byte run per plane element) is processed as two HALF slices of 8 companions by
-    // two different workgroups, lw and lw + 8 of a group of 16: they sit on the same XCD (workgroups go round-robin over the 8
-    // XCDs) and walk the same slices at the same time, so the second 64-byte half of every line is an L2 hit instead of a re-fetch.
     const int nslices = g.n0 * g.n1 * g.n2;
-    const int lw = gw - it.wg_begin;                        // wg_begin is a multiple of 16
-    const int half = (lw >> 3) & 1, pw = ((lw >> 4) << 3) | (lw & 7);
+    const int lw = gw - it.wg_begin;                        // wg_begin is a multiple of 32
+    const int quarter = (lw >> 3) & 3, pw = ((lw >> 5) << 3) | (lw & 7);
     const int s_begin = pw * it.spw, s_end = min(nslices, s_begin + it.spw);
     const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
     const cf* __restrict__ Yg = reinterpret_cast<const cf*>(it.Y);
+    const int comp = w & 3, msg = w >> 2;
+    // A operands of step 1: A[i = ln][k = q + 16 h] = M[(q + 16 h) + 32 ln], 16 consecutive complex numbers per lane
+    float m0[16], mr[16], mi[16];                            // m0: the A-side combination of CAcc32::mac_pre
     {
-        const cf* __restrict__ Mx = reinterpret_cast<const cf*>(it.Mx); const cf* __restrict__ My = reinterpret_cast<const cf*>(it.My);
-        for (int e = tid; e < 1024; e += 512) {
-            int i = e & 31, j = e >> 5; cf a = Mx[e], b = My[e];
-            v2f va; va[0] = a.re; va[1] = a.im; v2f vb; vb[0] = b.re; vb[1] = b.im;
-            Mxl[j * 33 + i] = va; Myl[j * 33 + i] = vb;
-        }
+        const cf* __restrict__ M = reinterpret_cast<const cf*>(msg ? it.My : it.Mx) + 16 * h + 32 * ln;
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) { const v4f v = ldg4(M + q); mr[q] = v[0]; mi[q] = v[1]; mr[q + 1] = v[2]; mi[q + 1] = v[3]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) m0[q] = M3 ? mr[q] + mi[q] : -mi[q];
     }
-    v16f O1r, O1i, O2r, O2i;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { O1r[r] = 0.f; O1i[r] = 0.f; O2r[r] = 0.f; O2i[r] = 0.f; }
-    // mover: thread -> (companion pair f4 = 0..3, first segment sg0 = 0..127); segment j: ix = sg0 & 31, iy = (sg0 >> 5) + 4 j
-    const int f4 = tid & 3, sg0 = tid >> 2;
+    // mover: thread -> (companion pair f2 = 0..1 of the quarter, first segment sg0 = 0..255); segment j: ix = sg0 & 31, iy = (sg0 >> 5) + 8 j
+    const int f2 = tid & 1, sg0 = tid >> 1;
     const int ix0 = sg0 & 31, iy0 = sg0 >> 5;
-    const long long toff = (long long)f4 * g.cstr + g.sx * ix0 + g.sy * iy0, tstr = 4 * g.sy, hoff = 4 * g.cstr;
-    v2f* const lbase = L + (2 * f4) * PS + iy0 * 33 + ix0;
-    v4f px[8], py[8];
-    auto issue = [&](int sl) {
-        const long long b = pair_slice_base(g, sl) + half * hoff + toff;
+    const long long toff = (long long)(2 * quarter + f2) * g.cstr + g.sx * ix0 + g.sy * iy0, tstr = 8 * g.sy;
+    v2f* const lbase = L + (2 * f2) * PS + iy0 * 33 + ix0;
+    v4f px[4], py[4];
+    auto commit = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { px[j] = ldg4(Xg + b + tstr * j); py[j] = ldg4(Yg + b + tstr * j); }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v2f* p0 = lbase + 132 * j;                           // element (ix, iy) at [iy][ix]; iy advances by 4 per j
+        for (int j = 0; j < 4; ++j) {
+            v2f* p0 = lbase + buf * BUF + 264 * j;                // element (ix, iy) at [iy][ix]; iy advances by 8 per j
             v2f a; a[0] = px[j][0]; a[1] = px[j][1]; v2f b; b[0] = px[j][2]; b[1] = px[j][3];
             p0[0] = a; p0[PS] = b;
             v2f c; c[0] = py[j][0]; c[1] = py[j][1]; v2f d; d[0] = py[j][2]; d[1] = py[j][3];
-            p0[8 * PS] = c; p0[9 * PS] = d;
+            p0[4 * PS] = c; p0[5 * PS] = d;
         }
     };
-    if (s_begin < s_end) issue(s_begin);
-    for (int sl = s_begin; sl < s_end; ++sl) {
-        lds_barrier();                                          // the previous slice's planes have been consumed
-        commit();
-        lds_barrier();
-        if (sl + 1 < s_end) issue(sl + 1);
-        const v2f* PX = L + w * PS; const v2f* PY = L + (8 + w) * PS;
-        // ---- message through ly: absorb lx ----------------------------------------------------------------------
-        {
-            v16f Cr, Ci;
+    CAcc32<M3> O; O.zero();
+    if (s_begin < s_end) {
+        const long long b = pair_slice_base(g, s_begin) + toff;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const v2f m = Mxl[ln * 33 + q + 16 * h];          // A[i = jx = ln][k = ix]
-                const v2f x = PX[ln * 33 + q + 16 * h];           // B[k = ix][j = b = ln]
-                Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(m[0], x[0], Cr, 0, 0, 0);
-                Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(m[0], x[1], Ci, 0, 0, 0);
-                Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(m[1], x[0], Ci, 0, 0, 0);
-                Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(-m[1], x[1], Cr, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jx = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const v2f y = PY[ln * 33 + jx];                   // B[k = jx][j = b' = ln]
-                O1r = __builtin_amdgcn_mfma_f32_32x32x2f32(Cr[r], y[0], O1r, 0, 0, 0);
-                O1i = __builtin_amdgcn_mfma_f32_32x32x2f32(Ci[r], y[0], O1i, 0, 0, 0);
-                O1r = __builtin_amdgcn_mfma_f32_32x32x2f32(Ci[r], y[1], O1r, 0, 0, 0);
-                O1i = __builtin_amdgcn_mfma_f32_32x32x2f32(-Cr[r], y[1], O1i, 0, 0, 0);
-            }
-        }
-        // ---- message through lx: absorb ly (the same planes, read transposed) -----------------------------------------
-        {
-            v16f Cr, Ci;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const v2f m = Myl[ln * 33 + q + 16 * h];          // A[i = jy = ln][k = iy]
-                const v2f x = PX[(q + 16 * h) * 33 + ln];         // B[k = iy][j = d = ln]
-                Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(m[0], x[0], Cr, 0, 0, 0);
-                Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(m[0], x[1], Ci, 0, 0, 0);
-                Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(m[1], x[0], Ci, 0, 0, 0);
-                Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(-m[1], x[1], Cr, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jy = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const v2f y = PY[jy * 33 + ln];                   // B[k = jy][j = d' = ln]
-                O2r = __builtin_amdgcn_mfma_f32_32x32x2f32(Cr[r], y[0], O2r, 0, 0, 0);
-                O2i = __builtin_amdgcn_mfma_f32_32x32x2f32(Ci[r], y[0], O2i, 0, 0, 0);
-                O2r = __builtin_amdgcn_mfma_f32_32x32x2f32(Ci[r], y[1], O2r, 0, 0, 0);
-                O2i = __builtin_amdgcn_mfma_f32_32x32x2f32(-Cr[r], y[1], O2i, 0, 0, 0);
-            }
-        }
+        for (int j = 0; j < 4; ++j) { px[j] = ldg4(Xg + b + tstr * j); py[j] = ldg4(Yg + b + tstr * j); }
+        commit(0);
     }
-    // one partial per workgroup: the eight waves' accumulators are summed through the (now free) slab, in wave order -- eight times fewer
-    // partial blocks to write here and to read back in msg_finalize_kernel
+    lds_barrier();
+    // the phase loop, once per message (the plane operands are read as rows or as columns): waves 0..3 and 4..7 run different copies
+    auto run = [&](auto msg_c) {
+    constexpr int MSG = decltype(msg_c)::value;
+    for (int sl = s_begin; sl < s_end; ++sl) {
+        const int buf = (sl - s_begin) & 1;
+        const bool more = sl + 1 < s_end;
+        const v2f* PX = L + buf * BUF + comp * PS; const v2f* PY = PX + 4 * PS;
+        const long long nb = pair_slice_base(g, more ? sl + 1 : sl) + toff;         // (the last phase re-reads its own slice: no branch in the stream)
+        // plane operand k of the kept index ln: message 0 reads rows ([ln][k]), message 1 the same planes transposed ([k][ln])
+        auto xat = [&](int k) { return MSG ? PX[k * 33 + ln] : PX[ln * 33 + k]; };
+        auto yat = [&](int k) { return MSG ? PY[k * 33 + ln] : PY[ln * 33 + k]; };
+        v2f xc[4], xn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xc[i] = xat(i + 16 * h);
+        // ---- step 1: C[j'][kept] = sum_k M[k][j'] X[k][kept] ---------------------------------------------------------------
+        CAcc32<M3> C;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (c4 < 3) xn[i] = xat(4 * (c4 + 1) + i + 16 * h);
+                else { const int r = i, k = (r & 3) + 8 * (r >> 2) + 4 * h; xn[i] = yat(k); }      // first four operands of step 2
+            }
+            TNQS_PIN();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = 4 * c4 + i;
+                if (q == 0) C.template mac_pre<true>(m0[q], mr[q], mi[q], xc[i][0], xc[i][1]);
+                else C.template mac_pre<false>(m0[q], mr[q], mi[q], xc[i][0], xc[i][1]);
+                if ((q & 1) == 0) {                                   // one global load of the next phase every two updates
+                    const int j = q >> 2;
+                    if ((q & 2) == 0) px[j] = ldg4(Xg + nb + tstr * j); else py[j] = ldg4(Yg + nb + tstr * j);
+                    TNQS_PIN();
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xc[i] = xn[i];
+        }
+        // ---- step 2: O[kept][kept'] += sum_j' C[j'][kept] conj Y[j'][kept'] ----------------------------------------------------
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            if (c4 < 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int r = 4 * (c4 + 1) + i, k = (r & 3) + 8 * (r >> 2) + 4 * h; xn[i] = yat(k); }
+            }
+            TNQS_PIN();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * c4 + i;
+                O.mac_conj(C.re(r), C.im(r), xc[i][0], xc[i][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xc[i] = xn[i];
+        }
+        if (more) commit(buf ^ 1);                                      // the other buffer was consumed before the previous barrier
+        lds_barrier();
+    }
+    };
+    if (msg == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+    // one partial per workgroup and message: the four waves of a message are summed through the (now free) buffers
+    O.finish_conj();
     cf* __restrict__ p1 = reinterpret_cast<cf*>(it.partial_y) + (size_t)lw * 1024;
     cf* __restrict__ p2 = reinterpret_cast<cf*>(it.partial_x) + (size_t)lw * 1024;
     v2f* const R = L;                                           // 8 blocks of 32 x 33
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        lds_barrier();                                          // the slab (or the previous pass) has been consumed
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            v2f v; v[0] = pass ? O2r[r] : O1r[r]; v[1] = pass ? O2i[r] : O1i[r];
-            R[w * (32 * 33) + ln * 33 + i] = v;                 // element (i, j = ln)
-        }
-        lds_barrier();
-        cf* __restrict__ dst = pass ? p2 : p1;
-        for (int e = threadIdx.x; e < 1024; e += 512) {
-            const int i = e & 31, j = e >> 5;
-            float sr = 0.f, si = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 8; ++ww) { const v2f v = R[ww * (32 * 33) + j * 33 + i]; sr += v[0]; si += v[1]; }
-            cf o; o.re = sr; o.im = si; dst[e] = o;
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        v2f v; v[0] = O.a[r]; v[1] = O.b[r];
+        R[w * (32 * 33) + ln * 33 + i] = v;                     // element (i, j = ln)
     }
+    lds_barrier();
+    for (int e = tid; e < 2048; e += 512) {
+        const int mm = e >> 10, ee = e & 1023, i = ee & 31, j = ee >> 5;
+        float sr = 0.f, si = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { const v2f v = R[(4 * mm + ww) * (32 * 33) + j * 33 + i]; sr += v[0]; si += v[1]; }
+        cf o; o.re = sr; o.im = si; stgc((mm ? p2 : p1) + ee, o);
+    }
+    #undef TNQS_PIN
 }
+int pair_gram2_group() { return 32; }
 void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
-    const size_t lds = ((size_t)16 * (32 * 33 + 1) + 2 * 32 * 33) * 2 * sizeof(float);
-    set_max_dynamic_lds((const void*)mfma_pair_gram2_kernel, lds);
-    hipLaunchKernelGGL(mfma_pair_gram2_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+    const size_t lds = (size_t)16 * (32 * 33 + 1) * 2 * sizeof(float);
+    if (mfma_use_3m()) {
+        set_max_dynamic_lds((const void*)mfma_pair_gram2_kernel<true>, lds);
+        hipLaunchKernelGGL(mfma_pair_gram2_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
+    } else {
+        set_max_dynamic_lds((const void*)mfma_pair_gram2_kernel<false>, lds);
+        hipLaunchKernelGGL(mfma_pair_gram2_kernel<false>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
+    }
+    TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 // launch_util.hpp -- host-side helpers shared by the kernel translation units.
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -20,5 +21,8 @@ inline void set_max_dynamic_lds(const void* func, size_t bytes) {
     (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     done[key] = bytes;
 }
+
+// Gauss' three-multiplication complex product in the plane kernels (mfma_common.hpp, CAcc32); TNQS_NO_3M=1 restores the four-MFMA product.
+inline bool mfma_use_3m() { static const bool v = [] { const char* e = std::getenv("TNQS_NO_3M"); return !(e && e[0] == '1'); }(); return v; }
 
 }  // namespace tnqs

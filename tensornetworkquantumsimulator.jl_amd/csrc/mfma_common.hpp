@@ -26,6 +26,97 @@ __device__ __forceinline__ void stgc(cf* p, cf v) { v2f t = {v.re, v.im}; stg2(p
 // serialise the prefetch / store streams against the LDS hand-offs (cdna_hip_programming.md, "Pipelining across barriers").
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ------------------------------------------------------------------------------------------------------------
+// complex 32 x 32 accumulator tile for v_mfma_f32_32x32x2_f32 (k = 2 per instruction: lanes 0..31 hold k = 0, lanes 32..63 k = 1).
+//   M3 = false: the textbook product, four real MFMAs per complex rank-2 update, two accumulators (re, im).
+//   M3 = true : Gauss' three-multiplication product, three real MFMAs and three accumulators
+//                   k1 = (ar + ai) br,   k2 = ar (bi - br),   k3 = ai (br + bi);      re = k1 - k3,  im = k1 + k2
+//               The operand sums cost three VALU instructions per update (they overlap the 3 x 64 matrix-core cycles); the recombination
+//               is two VALU instructions per accumulator register, once per tile.  Error: |delta| <= c u (|a_r| + |a_i|)(|b_r| + |b_i|) per
+//               term, i.e. the same NORMWISE bound as the four-multiplication product; the componentwise bound of the imaginary part is
+//               lost (a tiny imaginary part next to a large real one carries the large one's rounding), which the BP messages and site
+//               tensors -- compared and used normwise everywhere -- do not rely on.  TNQS_NO_3M=1 selects M3 = false everywhere.
+// ------------------------------------------------------------------------------------------------------------
+template <bool M3> struct CAcc32 {
+    v16f a, b, c;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a[r] = 0.f; b[r] = 0.f; if (M3) c[r] = 0.f; }
+    }
+    // acc += (ar + i ai) (br + i bi)
+    __device__ __forceinline__ void mac(float ar, float ai, float br, float bi) {
+        if (M3) {
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(ar + ai, br, a, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi - br, c, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br + bi, b, 0, 0, 0);
+        } else {
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai, bi, a, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi, b, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br, b, 0, 0, 0);
+        }
+    }
+    // the same update with the A-side combination supplied by the caller (a0 = ar + ai when M3, -ai otherwise: a constant of the wave in
+    // the kernels that keep their matrix in registers); FIRST: the accumulators start from zero (inline constant, no register clearing)
+    template <bool FIRST> __device__ __forceinline__ void mac_pre(float a0, float ar, float ai, float br, float bi) {
+        const v16f z = (v16f)(0.f);
+        if (M3) {
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, br, FIRST ? z : a, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi - br, FIRST ? z : c, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br + bi, FIRST ? z : b, 0, 0, 0);
+        } else {
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, FIRST ? z : a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bi, a, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi, FIRST ? z : b, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br, b, 0, 0, 0);
+        }
+    }
+    // the same update with the B-side combinations supplied by the caller: (bd, bs) = (bi - br, br + bi) when M3, (bi, -bi) otherwise
+    template <bool FIRST> __device__ __forceinline__ void mac_bpre(float ar, float ai, float br, float bd, float bs) {
+        const v16f z = (v16f)(0.f);
+        if (M3) {
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(ar + ai, br, FIRST ? z : a, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bd, FIRST ? z : c, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, bs, FIRST ? z : b, 0, 0, 0);
+        } else {
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, FIRST ? z : a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, bs, a, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bd, FIRST ? z : b, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br, b, 0, 0, 0);
+        }
+    }
+    // (re, im) of every accumulator register, in place: a <- re, b <- im  (after mac / mac_pre / mac_bpre)
+    __device__ __forceinline__ void finish() {
+        if (M3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float k1 = a[r]; a[r] = k1 - b[r]; b[r] = k1 + c[r]; }
+        }
+    }
+    // the same, one register at a time (the accumulators stay as they are): for accumulator tiles that are the next product's A operand
+    __device__ __forceinline__ float re(int r) const { return M3 ? a[r] - b[r] : a[r]; }
+    __device__ __forceinline__ float im(int r) const { return M3 ? a[r] + c[r] : b[r]; }
+    // acc += (ar + i ai) conj(br + i bi); M3 keeps  sum (ar + ai) br,  sum ar (bi + br),  sum ai (br - bi)  -- no negated operand -- and
+    // finish_conj() recombines  re = k1 - k3,  im = k1 - sum ar (bi + br)
+    __device__ __forceinline__ void mac_conj(float ar, float ai, float br, float bi) {
+        if (M3) {
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(ar + ai, br, a, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi + br, c, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br - bi, b, 0, 0, 0);
+        } else {
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, bi, a, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br, b, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_32x32x2f32(-ar, bi, b, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void finish_conj() {
+        if (M3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float k1 = a[r]; a[r] = k1 - b[r]; b[r] = k1 - c[r]; }
+        }
+    }
+};
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
