@@ -375,8 +375,8 @@ void launch_copy_items(hipStream_t s, const CopyItem* d_items, int nitems) {
 //     two site components of one n, one 16-byte store).
 // One wave per SIMD (accumulators + the two half-tile operand sets: up to 256 registers); the wave never waits on a workgroup barrier.
 // ------------------------------------------------------------------------------------------------------------
-template <int KB, int NB, int D>
-__global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __restrict__ items, int nitems, double* __restrict__ norm_partials) {
+template <int KB, int NB, int D, bool M3>
+__global__ __launch_bounds__(256, (KB * NB <= 4 ? 2 : 1)) void mfma_rowgemm_kernel(const FiberItem* __restrict__ items, int nitems, double* __restrict__ norm_partials) {
     constexpr int KK = 32 * KB, NQ = KK / 2;                   // k-steps per tile
     constexpr int NL = (D == 1) ? NQ : NQ / 2;                 // loads per lane and tile (8 bytes each for D = 1, 16 bytes for D = 2)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -434,29 +434,25 @@ __global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __re
     int t = t_begin + w;
     if (t < t_end) { issue_half(t, 0); issue_half(t, 1); }
     for (; t < t_end; t += 4) {
-        v16f Cr[NB], Ci[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { Cr[nb][r] = 0.f; Ci[nb][r] = 0.f; }
+        CAcc32<M3> C[NB];                                                        // three accumulators per block with the three-multiplication product
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
             for (int q = 0; q < HQ; ++q) {
                 const float br = hb[hf][2 * q], bi = hb[hf][2 * q + 1];          // in[row][kk(q + HQ hf, h)]
-                const float nbi = -bi;
+                const float bd = M3 ? bi - br : bi, bs = M3 ? br + bi : -bi;     // B-side combinations, shared by the NB blocks
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const v2f a = Xl[((q + HQ * hf) * NB + nb) * 64 + lane];      // X[kk][32 nb + ln]
-                    Cr[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], br, Cr[nb], 0, 0, 0);
-                    Ci[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bi, Ci[nb], 0, 0, 0);
-                    Cr[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], nbi, Cr[nb], 0, 0, 0);
-                    Ci[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], br, Ci[nb], 0, 0, 0);
+                    if (hf == 0 && q == 0) C[nb].template mac_bpre<true>(a[0], a[1], br, bd, bs);
+                    else C[nb].template mac_bpre<false>(a[0], a[1], br, bd, bs);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                                   // the refill must not be hoisted above the MFMAs that read the half
             if (t + 4 < t_end) issue_half(t + 4, hf);
         }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) C[nb].finish();
         float nf = 0.f;
         if (D == 1) {
             cf* p = out + base_out(t) + lane_out;
@@ -465,7 +461,7 @@ __global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int n = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (n < No) { cf v; v.re = Cr[nb][r]; v.im = Ci[nb][r]; stgc(p + PA * n, v); nf += v.re * v.re + v.im * v.im; }
+                    if (n < No) { cf v; v.re = C[nb].a[r]; v.im = C[nb].b[r]; stgc(p + PA * n, v); nf += v.re * v.re + v.im * v.im; }
                 }
         } else {
             cf* p = out + base_out(t) + lane_out;
@@ -476,7 +472,7 @@ __global__ __launch_bounds__(256) void mfma_rowgemm_kernel(const FiberItem* __re
                     const int nn = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;  // even: s' = 0 of n = nn / 2; register r + 1 is s' = 1
                     const int n = nn >> 1;
                     if (n < No) {
-                        v4f v = {Cr[nb][r], Ci[nb][r], Cr[nb][r + 1], Ci[nb][r + 1]};
+                        v4f v = {C[nb].a[r], C[nb].b[r], C[nb].a[r + 1], C[nb].b[r + 1]};
                         stg4(p + 2 * PA * n, v);
                         nf += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     }
@@ -510,8 +506,16 @@ void rowgemm_tiles(FiberItem& it) {       // tile grid of an item rowgemm_covers
 }
 template <int KB, int NB, int D> static void launch_rowgemm_t(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, double* d_norm_partials) {
     const size_t lds = (size_t)(16 * KB) * NB * 64 * sizeof(v2f);
-    set_max_dynamic_lds((const void*)mfma_rowgemm_kernel<KB, NB, D>, lds);
-    hipLaunchKernelGGL((mfma_rowgemm_kernel<KB, NB, D>), dim3(total_wgs), dim3(256), lds, s, d_items, nitems, d_norm_partials); TNQS_CHECK_LAUNCH();
+    // three-multiplication product except for K = N = 128: its 16 blocks x 3 accumulators do not fit next to the operand registers (21 spills)
+    constexpr bool fits3 = KB * NB <= 4;
+    if (fits3 && mfma_use_3m()) {
+        set_max_dynamic_lds((const void*)mfma_rowgemm_kernel<KB, NB, D, fits3>, lds);
+        hipLaunchKernelGGL((mfma_rowgemm_kernel<KB, NB, D, fits3>), dim3(total_wgs), dim3(256), lds, s, d_items, nitems, d_norm_partials);
+    } else {
+        set_max_dynamic_lds((const void*)mfma_rowgemm_kernel<KB, NB, D, false>, lds);
+        hipLaunchKernelGGL((mfma_rowgemm_kernel<KB, NB, D, false>), dim3(total_wgs), dim3(256), lds, s, d_items, nitems, d_norm_partials);
+    }
+    TNQS_CHECK_LAUNCH();
 }
 // all items of one launch must share K and D (the caller groups them)
 void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, int K, double* d_norm_partials) {
