@@ -1282,6 +1282,7 @@ void launch_recover_v_mfma(hipStream_t s, const RecoverItem* d_items, int nitems
 // accumulate into separate partials (2 per chunk) because a block changes wave with the parity.
 // ------------------------------------------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
+template <bool M3>
 __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem* __restrict__ items, int nitems, int dbg_skip) {
     constexpr int TR = 64, TRP = TR + 4, NU = 8;
     // two tile buffers (re, im planes each): the next tile is committed while other waves still multiply the current one
@@ -1310,15 +1311,16 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem*
     for (int q = 0; q < 3; ++q) { const int wv = parA ? 3 - w : w; int idx = wv + 4 * q; aOn[q] = idx < nblk; block_of(aOn[q] ? idx : 0, aI[q], aJ[q]); }
 #pragma unroll
     for (int q = 0; q < 2; ++q) { const int wv = parA ? w : 3 - w; int idx = wv + 4 * q; bOn[q] = idx < nblk; block_of(bOn[q] ? idx : 0, bI[q], bJ[q]); }
-    v4d CAr[3], CAi[3], CBr[2], CBi[2];
+    // M3: Gauss' three-multiplication product in f64 (mfma_common.hpp, CAcc32::mac_conj): per block  sum (ar+ai) br,  sum ai (br-bi),  sum ar (bi+br)
+    v4d CAr[3], CAi[3], CBr[2], CBi[2], CAc[3], CBc[2];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { CAr[j][r] = 0.0; CAi[j][r] = 0.0; }
+        for (int r = 0; r < 4; ++r) { CAr[j][r] = 0.0; CAi[j][r] = 0.0; CAc[j][r] = 0.0; }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { CBr[j][r] = 0.0; CBi[j][r] = 0.0; }
+        for (int r = 0; r < 4; ++r) { CBr[j][r] = 0.0; CBi[j][r] = 0.0; CBc[j][r] = 0.0; }
     for (int e = tid; e < 4 * 64 * TRP; e += 256) Xbuf[e] = 0.f;
     const TileMap m = make_map(tid, D, TA, TB, PA, K);
     const long long kstride = (long long)D * PA;
@@ -1389,7 +1391,7 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem*
         }
         const float* Xr = Xbuf + cur * (2 * 64 * TRP); const float* Xi = Xr + 64 * TRP;
         // rows of the tile: lane quarter kq takes rows 16*kq + tt, tt = 0..15, in two halves of 8 to bound registers
-        auto block_pass = [&](int I, int J, v4d& cr, v4d& ci) {
+        auto block_pass = [&](int I, int J, v4d& cr, v4d& ci, v4d& cc) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int ro = (16 * I + l15) * TRP + 16 * kq + 8 * half;
@@ -1402,10 +1404,16 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem*
                     for (int c = 0; c < 4; ++c) {
                         const double ar = (double)t0[c], ai = (double)t1[c], br = (double)u0[c], bi = (double)u1[c];
                         // out[i][j] += x[i] * conj(x[j])
-                        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr, 0, 0, 0);
-                        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
-                        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, cr, 0, 0, 0);
-                        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, bi, ci, 0, 0, 0);
+                        if (M3) {
+                            cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar + ai, br, cr, 0, 0, 0);
+                            ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br - bi, ci, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi + br, cc, 0, 0, 0);
+                        } else {
+                            cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr, 0, 0, 0);
+                            ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
+                            cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, cr, 0, 0, 0);
+                            ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, bi, ci, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -1413,21 +1421,21 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem*
         if (dbg_skip != 1) {
             if (((t - t_begin) & 1) == parA) {                    // wave-uniform
 #pragma unroll
-                for (int q = 0; q < 3; ++q) if (aOn[q]) block_pass(aI[q], aJ[q], CAr[q], CAi[q]);
+                for (int q = 0; q < 3; ++q) if (aOn[q]) block_pass(aI[q], aJ[q], CAr[q], CAi[q], CAc[q]);
             } else {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) if (bOn[q]) block_pass(bI[q], bJ[q], CBr[q], CBi[q]);
+                for (int q = 0; q < 2; ++q) if (bOn[q]) block_pass(bI[q], bJ[q], CBr[q], CBi[q], CBc[q]);
             }
         }
         lds_barrier();                                           // tile t consumed by everybody, tile t+1 committed by everybody
     }
     struct alignas(16) cd { double re, im; };
-    auto write_block = [&](cd* __restrict__ part, int I, int J, const v4d& cr, const v4d& ci) {
+    auto write_block = [&](cd* __restrict__ part, int I, int J, const v4d& cr, const v4d& ci, const v4d& cc) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int i = 16 * I + kq + 4 * r, j = 16 * J + l15;
             if (i < KK && j < KK) {
-                cd v; v.re = cr[r]; v.im = ci[r]; part[i + (size_t)KK * j] = v;
+                cd v; v.re = M3 ? cr[r] - ci[r] : cr[r]; v.im = M3 ? cr[r] - cc[r] : ci[r]; part[i + (size_t)KK * j] = v;
                 if (I != J) { cd c; c.re = v.re; c.im = -v.im; part[j + (size_t)KK * i] = c; }     // G[j][i] = conj(G[i][j])
             }
         }
@@ -1436,17 +1444,18 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem*
     cd* __restrict__ partA = reinterpret_cast<cd*>(it.partial) + (size_t)(2 * lc + parA) * KK * KK;
     cd* __restrict__ partB = reinterpret_cast<cd*>(it.partial) + (size_t)(2 * lc + (parA ^ 1)) * KK * KK;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) if (aOn[q]) write_block(partA, aI[q], aJ[q], CAr[q], CAi[q]);
+    for (int q = 0; q < 3; ++q) if (aOn[q]) write_block(partA, aI[q], aJ[q], CAr[q], CAi[q], CAc[q]);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) if (bOn[q]) write_block(partB, bI[q], bJ[q], CBr[q], CBi[q]);
+    for (int q = 0; q < 2; ++q) if (bOn[q]) write_block(partB, bI[q], bJ[q], CBr[q], CBi[q], CBc[q]);
 }
 bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
     if (KKmax > 64) return false;
     if (total_chunks <= 0) return true;
     const size_t lds = (size_t)4 * 64 * 68 * sizeof(float);
-    set_max_dynamic_lds((const void*)mfma_gram64_f64_kernel, lds);
     static int skip = -1; if (skip < 0) { const char* e = std::getenv("TNQS_DBG_GRAM_SKIP"); skip = e ? std::atoi(e) : 0; }
-    hipLaunchKernelGGL(mfma_gram64_f64_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems, skip); TNQS_CHECK_LAUNCH();
+    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_gram64_f64_kernel<true>, lds); hipLaunchKernelGGL(mfma_gram64_f64_kernel<true>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems, skip); }
+    else { set_max_dynamic_lds((const void*)mfma_gram64_f64_kernel<false>, lds); hipLaunchKernelGGL(mfma_gram64_f64_kernel<false>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems, skip); }
+    TNQS_CHECK_LAUNCH();
     return true;
 }
 
