@@ -228,6 +228,27 @@ def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int
     bpkw = dict(bpc.default_bp_update_kwargs())
     saved = (o._POOL, o._BIG)
     o._POOL, o._BIG = _Serial(), 1 << 12          # every site-tensor contraction takes the copy-free batched-matmul path, serial inside
+    prof: Dict[str, float] = {}
+    unwrap = []
+    if os.environ.get("TNQS_CPU_PROFILE") == "1":     # thread-seconds per primitive (sum over the pool's threads)
+        import threading
+        lock = threading.Lock()
+
+        def wrap(mod, name):
+            fn = getattr(mod, name)
+
+            def timed(*a, **k):
+                t = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    dt_ = time.perf_counter() - t
+                    with lock:
+                        prof[name] = prof.get(name, 0.0) + dt_
+            setattr(mod, name, timed)
+            unwrap.append((mod, name, fn))
+        for mod, name in ((o, "_absorb"), (o, "_gram"), (np.linalg, "qr"), (np.linalg, "svd"), (np.linalg, "eigh"), (o, "apply_gate")):
+            wrap(mod, name)
     try:
         with ThreadPoolExecutor(max_workers=nthreads) as pool:
             rates = _gemm_rates(chi, nthreads, pool)
@@ -241,6 +262,8 @@ def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int
                 dt = (time.perf_counter() - t0) / nlayers
     finally:
         o._POOL, o._BIG = saved
+        for mod, name, fn in unwrap:
+            setattr(mod, name, fn)
     n2 = len(g.edges)
     nsweeps = float(np.mean([sum(s) for s in sweeps_all]))
     flops = 384.0 * chi ** 5 * n2 + 64.0 * chi ** 5 * 2 * n2 * nsweeps              # SURVEY.md 8d, bulk sites
@@ -249,7 +272,8 @@ def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int
             "bp_sweeps": sweeps_all[-1], "algorithmic_gflops": round(gf, 1), **rates,
             "frac_of_square_cgemm": round(gf / rates["square_cgemm_gflops"], 3),
             "frac_of_mode_product_shape": round(gf / rates["mode_product_shape_gflops"], 3),
-            "max_truncation_error": float(np.max(errs)) if len(errs) else 0.0}
+            "max_truncation_error": float(np.max(errs)) if len(errs) else 0.0,
+            **({"profile_thread_seconds": {k: round(v, 2) for k, v in prof.items()}} if prof else {})}
 
 
 if __name__ == "__main__":

@@ -451,6 +451,27 @@ def _chunks(n: int, parts: int):
     return [(a, min(n, a + step)) for a in range(0, n, step)]
 
 
+def _qr_thin(a: np.ndarray):
+    """thin Householder QR.  Tall matrices (>= 8192 rows) go through the communication-avoiding arrangement of the same factorisation (TSQR):
+    row blocks of 4096 are factorised on their own (LAPACK geqrf/ungqr on a cache-resident block), the stacked R factors once more, and
+    Q = blockdiag(Q_i) [Q'_1; ...; Q'_p].  A 65536 x 64 LAPACK geqrf streams the 33 MB matrix through memory once per reflector (level-2
+    panel): 1.1 s on one core, 4.3 s with 64 of them running side by side (profiles/cpu_prim_bench.py).  Q R is the same product either
+    way; R's diagonal phases may differ from LAPACK's, which simple_update is invariant to (Q D^* D R)."""
+    mrows, n = a.shape
+    blk = _QR_BLOCK
+    if mrows < 4 * blk or mrows < 4 * n or mrows % blk != 0:
+        return np.linalg.qr(a, mode="reduced")
+    nb = mrows // blk
+    a3 = a.reshape(nb, blk, n)
+    qs, rs = np.linalg.qr(a3, mode="reduced")                       # gufunc: one LAPACK call per block
+    q2, r = _qr_thin(rs.reshape(nb * n, n))                         # the stacked R factors, again in blocks while they are tall
+    q = np.matmul(qs, q2.reshape(nb, n, n)).reshape(mrows, n)
+    return q, r
+
+
+_QR_BLOCK = 4096        # rows per block: 1.3 s per 65536 x 64 factorisation with 64 concurrent callers (2048: 2.4 s, 8192: 2.8 s, one LAPACK call: 4.3 s)
+
+
 def _absorb(t: np.ndarray, axis: int, m: np.ndarray) -> np.ndarray:
     """t[.. l ..] m[l, l'] -> axis replaced by l' (kept in place)."""
     if t.size < _BIG:
@@ -469,14 +490,33 @@ def _absorb(t: np.ndarray, axis: int, m: np.ndarray) -> np.ndarray:
         list(pool.map(job, _chunks(pre, 4 * nw)))
         return out.reshape(shape[:axis] + (kn,))
     t3 = t.reshape(pre, k, post); out = np.empty((pre, kn, post), dtype=dt); mt = np.ascontiguousarray(m.T.astype(dt))
-    if pre >= 4 * nw:                                    # out[p] = m^T t3[p], split over p
+    if pre >= 4 * nw and post <= 64:                     # many small slabs: one tall GEMM per block of slabs through a cache-sized transpose
+        # (batched matmul would issue one k x k by k x post BLAS call per slab -- 2048 calls of 260 kflop for the third bond leg at chi = 32;
+        #  with 64 threads doing that at once OpenBLAS spends its time in the per-call buffer lock: measured 38 GFLOP/s for the whole box)
+        mm = np.ascontiguousarray(m.astype(dt))
+        def job(ab):
+            step = max(1, 65536 // (k * post))           # <= 512 KiB of complex64 per block
+            for a in range(ab[0], ab[1], step):
+                b = min(ab[1], a + step)
+                x = np.ascontiguousarray(t3[a:b].transpose(0, 2, 1)).reshape(-1, k)       # ((b - a) post) x k
+                out[a:b] = (x @ mm).reshape(b - a, post, kn).transpose(0, 2, 1)
+        list(pool.map(job, _chunks(pre, 4 * nw)))
+    elif pre >= 4 * nw:                                  # out[p] = m^T t3[p], split over p
         def job(ab):
             out[ab[0]:ab[1]] = np.matmul(mt, t3[ab[0]:ab[1]])
         list(pool.map(job, _chunks(pre, 4 * nw)))
-    else:                                                # few, wide slabs: 2-D products on column ranges of each slab (no copies)
+    else:                                                # few, wide slabs: 2-D products on column ranges of each slab
+        # Column blocks of 8192 are gathered into a contiguous scratch first: the rows of a slab lie `post` elements apart (a power of
+        # two, 256 KiB at chi = 32), so a strided B operand puts all k rows of a column into the same cache sets -- measured on 8 threads
+        # 130 -> 13 ms for the first bond leg of a chi = 32 site tensor, and worse with 64 threads sharing an L3.
         def job(pab):
             q, a, b = pab
-            out[q, :, a:b] = mt @ t3[q, :, a:b]
+            nbk = 8192
+            buf = np.empty((k, min(nbk, b - a)), dtype=dt)
+            for c in range(a, b, nbk):
+                d = min(b, c + nbk)
+                np.copyto(buf[:, :d - c], t3[q, :, c:d])
+                np.matmul(mt, buf[:, :d - c], out=out[q, :, c:d])
         list(pool.map(job, [(q, a, b) for q in range(pre) for (a, b) in _chunks(post, max(1, 4 * nw // pre))]))
     return out.reshape(shape[:axis] + (kn,) + shape[axis + 1:])
 
@@ -638,7 +678,7 @@ def simple_update(gate: np.ndarray, psis: List[np.ndarray], bond_axes: Optional[
             tm = np.transpose(t, outer + [0, bax])
             oshape = tm.shape[:len(outer)]
             d, chi = t.shape[0], t.shape[bax]
-            q, r = np.linalg.qr(tm.reshape(-1, d * chi), mode="reduced")
+            q, r = _qr_thin(np.ascontiguousarray(tm).reshape(-1, d * chi))
             return q, r.reshape(r.shape[0], d, chi), outer, oshape
 
         q1, r1, outer1, oshape1 = qr_split(t1, b1)
