@@ -112,9 +112,25 @@ def main():
     # ---- state: bond dimension 1 handle, then upload the synthetic chi-saturated tensors ---------------------
     psi0 = tn.tensornetworkstate(dtype, lambda v: "↑", g)
     bpc = tn.BeliefPropagationCache(psi0, device=local if world > 1 else 0)
+    transport_note = None
     if world > 1:
         from tnqs_amd import dist as tdist
-        tdist.shard(bpc, rank, world)
+        if dist.get_backend() == "nccl":
+            # the library's own RCCL communicator; if it cannot be set up on EVERY rank (the ranks agree through torch's communicator), all of
+            # them fall back to the callback transport (the same all-gathers through torch.distributed) and the JSON line says so
+            ok, why = 1, ""
+            try:
+                tdist.shard(bpc, rank, world, transport="rccl")
+            except Exception as e:                                   # noqa: BLE001 -- any failure means "no in-library RCCL on this node"
+                ok, why = 0, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([ok], device=f"cuda:{local}", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                transport_note = "callback (in-library RCCL set-up failed on at least one rank" + (f": {why}" if why else "") + ")"
+                bpc = tn.BeliefPropagationCache(psi0, device=local)
+                tdist.shard(bpc, rank, world, transport="callback")
+        else:
+            tdist.shard(bpc, rank, world)
     for v, t in random_state_tensors(g, chi, d, 1234, dtype, wanted=(None if world == 1 else bpc.owns)):
         if isinstance(t, tuple):
             bpc._declare_dims(v, t)
@@ -153,10 +169,12 @@ def main():
     # 157.3 TFLOP/s / 8 TB/s = 19.7 flop/B (MI355X_MICROARCH.md).  `achieved` = algorithmic bytes (or flops) of the
     # class / HIP-event time of its launches on the library's stream; `traffic` = HBM bytes per launch from the PMC
     # pass of the same command committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, see the file's header).
-    KERNEL_OF = {"bp_pair": "tnqs::mfma_pair_kernel", "bp_modeprod": "tnqs::mfma_fiber_gemm_w_kernel<1, 1, 8>",
-                 "gate_modeprod": "tnqs::mfma_pair_kernel", "bp_fused": "tnqs::mfma_gram32_fused_kernel",
-                 "bp_gram": "tnqs::mfma_gram32_kernel", "gate_gram": "tnqs::mfma_gram64_f64_kernel",
-                 "gate_apply": "tnqs::mfma_rowgemm_kernel<2, 2, 2>", "bp_pairgram": "tnqs::mfma_pair_gram2_kernel"}
+    m3 = os.environ.get("TNQS_NO_3M") != "1"
+    tf = "<true>" if m3 else "<false>"
+    KERNEL_OF = {"bp_pair": "tnqs::mfma_pair_kernel" + tf, "bp_modeprod": "tnqs::mfma_rowgemm_kernel<1, 1, 1, %s>" % ("true" if m3 else "false"),
+                 "gate_modeprod": "tnqs::mfma_pair_kernel" + tf, "bp_fused": "tnqs::mfma_gram32_fused_kernel",
+                 "bp_gram": "tnqs::mfma_gram32_kernel", "gate_gram": "tnqs::mfma_gram64_f64_kernel" + tf,
+                 "gate_apply": "tnqs::mfma_rowgemm_kernel<2, 2, 2, %s>" % ("true" if m3 else "false"), "bp_pairgram": "tnqs::mfma_pair_gram2_kernel" + tf}
     traffic_db = {}
     try:
         with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
@@ -184,7 +202,12 @@ def main():
                   # matrix-core utilisation of the same kernel from the committed counter pass (profiles/r2_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES /
                   # (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs)); like `traffic` it is a profile of this command, not re-measured in this run
                   "mfma_busy": (mfma_db.get(kern, {}).get("mfma_busy") if (world == 1 and L == 20 and chi == 32) else None),
-                  "mfma_executed_TFLOPs": (mfma_db.get(kern, {}).get("mfma_tflops") if (world == 1 and L == 20 and chi == 32) else None)}
+                  "mfma_executed_TFLOPs": (mfma_db.get(kern, {}).get("mfma_tflops") if (world == 1 and L == 20 and chi == 32) else None),
+                  # `achieved` counts ALGORITHMIC flops (8 per complex multiply-add).  The plane kernels form the complex product with Gauss' three
+                  # real multiplications (csrc/mfma_common.hpp, CAcc32): the matrix cores execute 0.75 x the algorithmic count, so the
+                  # algorithmic rate can exceed what `peak` allows a four-multiplication kernel; executed / peak is the matrix-core load
+                  "complex_product": ("3M: three real MFMAs per complex update" if m3 else "4M"),
+                  "executed_over_peak": round((0.75 if m3 else 1.0) * tflops / PEAK_F32_TFLOPS, 4)}
         if ai < PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
             roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), **common}
         else:
@@ -209,7 +232,7 @@ def main():
                       "two_site_gates_per_step": n2, "bp_updates_per_step": updates, "bp_sweeps_per_step": sweeps,
                       "apply_kwargs": {"maxdim": chi, "cutoff": 1e-10, "normalize_tensors": True},
                       "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)", "parallelism": f"vertex-shard x{world}",
-                      "transport": (None if world == 1 else {"kind": type(bpc._shard).__name__,
+                      "transport": (None if world == 1 else {"kind": type(bpc._shard).__name__, **({"note": transport_note} if transport_note else {}),
                                                              "allgathers_per_step": round(bpc._shard.n_exchanges / max(1, args.steps + args.warmup), 1),
                                                              "MB_gathered_per_step": round(bpc._shard.bytes_exchanged / max(1, args.steps + args.warmup) / 1e6, 2)})},
            "roofline": roofline, "phases": phases, "kernel_classes": classes}

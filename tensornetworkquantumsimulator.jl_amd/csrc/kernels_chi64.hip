@@ -23,6 +23,7 @@ namespace tnqs {
 // Tiles of 64 fibers, LDS layout [kk][row] (rows contiguous = memory order); wave w takes 16 rows of every tile and the whole 64 x 64
 // output (four 32 x 32 accumulator pairs); the next tile's loads are in flight during the MFMA block.  32 flop/B when X != Y.
 // ------------------------------------------------------------------------------------------------------------
+template <bool M3>
 __global__ __launch_bounds__(256, 2) void mfma_gram64_kernel(const GramItem* __restrict__ items, int nitems) {
     constexpr int TR = 64, TRP = TR + 4, NU = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -48,11 +49,8 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_kernel(const GramItem* __r
     // wave w: output rows block a = w & 1 (i in [32 a, 32 a + 32)) x all 64 columns, tile rows 32 (w >> 1) .. + 32 -- 64 accumulator
     // registers per wave instead of 128, so that TWO workgroups fit a CU (one's barriers and LDS commits hide behind the other's MFMAs)
     const int a = w & 1, rh = w >> 1;
-    v16f Cr[2], Ci[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { Cr[b][r] = 0.f; Ci[b][r] = 0.f; }
+    CAcc32<M3> C[2];                                             // M3: three-multiplication product (mfma_common.hpp)
+    C[0].zero(); C[1].zero();
     for (int e = tid; e < 64 * TRP; e += 256) { Xr[e] = 0.f; Xi[e] = 0.f; Yr[e] = 0.f; Yi[e] = 0.f; }
     const TileMap m = make_map(tid, D, TA, TB, PA, K);
     const long long kstride = (long long)D * PA;
@@ -154,24 +152,21 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_kernel(const GramItem* __r
             for (int q = 0; q < 8; ++q) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    // out[i][j] += x[i] * conj(y[j])
-                    Cr[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[q], yr[b][q], Cr[b], 0, 0, 0);
-                    Ci[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[q], yr[b][q], Ci[b], 0, 0, 0);
-                    Cr[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xi[q], yi[b][q], Cr[b], 0, 0, 0);
-                    Ci[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(-xr[q], yi[b][q], Ci[b], 0, 0, 0);
+                    C[b].mac_conj(xr[q], xi[q], yr[b][q], yi[b][q]);       // out[i][j] += x[i] * conj(y[j])
                 }
             }
         }
     }
     // one partial per chunk: the two row halves (waves w, w + 2) are summed through the free tile buffers
     lds_barrier();
+    C[0].finish_conj(); C[1].finish_conj();
     v2f* const R = reinterpret_cast<v2f*>(smem);                // [rh][j][i], pitch 65: 2 * 64 * 65 * 8 B = 66.5 KB
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, j = 32 * b + ln;
-            v2f v = {Cr[b][r], Ci[b][r]};
+            v2f v = {C[b].a[r], C[b].b[r]};
             R[(rh * 64 + j) * 65 + i] = v;
         }
     lds_barrier();
@@ -186,8 +181,9 @@ bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int 
     if (KKmax > 64) return false;
     if (total_chunks <= 0) return true;
     const size_t lds = (size_t)4 * 64 * 68 * sizeof(float);
-    set_max_dynamic_lds((const void*)mfma_gram64_kernel, lds);
-    hipLaunchKernelGGL(mfma_gram64_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_gram64_kernel<true>, lds); hipLaunchKernelGGL(mfma_gram64_kernel<true>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }
+    else { set_max_dynamic_lds((const void*)mfma_gram64_kernel<false>, lds); hipLaunchKernelGGL(mfma_gram64_kernel<false>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }
+    TNQS_CHECK_LAUNCH();
     return true;
 }
 
@@ -535,6 +531,7 @@ void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, in
 // One partial per chunk.  f64 MFMA layout: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], C[row = (l >> 4) + 4 r][col = l & 15].
 // ------------------------------------------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
+template <bool M3>
 __global__ __launch_bounds__(256) void mfma_gram128_f64_kernel(const GramItem* __restrict__ items, int nitems) {
     constexpr int TR = 64, TRP = TR + 4, NU = 16, KKP = 128, NBW = 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -560,11 +557,11 @@ __global__ __launch_bounds__(256) void mfma_gram128_f64_kernel(const GramItem* _
         int I = 0, rem = bOn[q] ? idx : 0; while (rem >= nb - I) { rem -= nb - I; ++I; }
         bI[q] = I; bJ[q] = I + rem;
     }
-    v4d Cr[NBW], Ci[NBW];
+    v4d Cr[NBW], Ci[NBW], Cc[NBW];                             // M3: sum (ar+ai) br,  sum ai (br-bi),  sum ar (bi+br)  (CAcc32::mac_conj in f64)
 #pragma unroll
     for (int q = 0; q < NBW; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { Cr[q][r] = 0.0; Ci[q][r] = 0.0; }
+        for (int r = 0; r < 4; ++r) { Cr[q][r] = 0.0; Ci[q][r] = 0.0; Cc[q][r] = 0.0; }
     for (int e = tid; e < 4 * KKP * TRP; e += 256) Xbuf[e] = 0.f;
     const TileMap m = make_map(tid, D, TA, TB, PA, K);
     const long long kstride = (long long)D * PA;
@@ -643,10 +640,16 @@ __global__ __launch_bounds__(256) void mfma_gram128_f64_kernel(const GramItem* _
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const double ar = (double)t0[c], ai = (double)t1[c], br = (double)u0[c], bi = (double)u1[c];
-                        Cr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, Cr[q], 0, 0, 0);      // out[i][j] += x[i] conj(x[j])
-                        Ci[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, Ci[q], 0, 0, 0);
-                        Cr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, Cr[q], 0, 0, 0);
-                        Ci[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, bi, Ci[q], 0, 0, 0);
+                        if (M3) {                                                                      // out[i][j] += x[i] conj(x[j])
+                            Cr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar + ai, br, Cr[q], 0, 0, 0);
+                            Ci[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br - bi, Ci[q], 0, 0, 0);
+                            Cc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi + br, Cc[q], 0, 0, 0);
+                        } else {
+                            Cr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, Cr[q], 0, 0, 0);
+                            Ci[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, Ci[q], 0, 0, 0);
+                            Cr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, Cr[q], 0, 0, 0);
+                            Ci[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, bi, Ci[q], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(256) void mfma_gram128_f64_kernel(const GramItem* _
         for (int r = 0; r < 4; ++r) {
             const int i = 16 * bI[q] + kq + 4 * r, j = 16 * bJ[q] + l15;
             if (i < KK && j < KK) {
-                cd v; v.re = Cr[q][r]; v.im = Ci[q][r]; part[i + (size_t)KK * j] = v;
+                cd v; v.re = M3 ? Cr[q][r] - Ci[q][r] : Cr[q][r]; v.im = M3 ? Cr[q][r] - Cc[q][r] : Ci[q][r]; part[i + (size_t)KK * j] = v;
                 if (bI[q] != bJ[q]) { cd c; c.re = v.re; c.im = -v.im; part[j + (size_t)KK * i] = c; }
             }
         }
@@ -672,8 +675,9 @@ bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems,
     if (KKmax > 128) return false;
     if (total_chunks <= 0) return true;
     const size_t lds = (size_t)4 * 128 * 68 * sizeof(float);
-    set_max_dynamic_lds((const void*)mfma_gram128_f64_kernel, lds);
-    hipLaunchKernelGGL(mfma_gram128_f64_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_gram128_f64_kernel<true>, lds); hipLaunchKernelGGL(mfma_gram128_f64_kernel<true>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }
+    else { set_max_dynamic_lds((const void*)mfma_gram128_f64_kernel<false>, lds); hipLaunchKernelGGL(mfma_gram128_f64_kernel<false>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }
+    TNQS_CHECK_LAUNCH();
     return true;
 }
 

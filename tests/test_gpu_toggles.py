@@ -100,7 +100,12 @@ def test_chi64_kernels_match_the_generic_route_on_a_physical_evolution():
     Same bond dimensions layer by layer; truncation errors and <Z> to f32 rounding of the whole evolution."""
     on, off = run_worker({}, "chi64phys"), run_worker({"TNQS_NO_CHI64": "1"}, "chi64phys")
     print("bond dimensions per layer:", [max(d) for d in on["dims"]], " tall SVDs:", on["tall"])
-    assert on["dims"] == off["dims"] and max(on["dims"][-1]) == 64
+    # the cutoff of this evolution (1e-13 on S^2, chosen so that the bonds saturate) sits at f32 rounding: a singular value on the threshold may fall
+    # either side of it when the rounding of the contractions changes (three- vs four-multiplication products) -- bond dimensions may differ
+    # by one on a few bonds, nothing more
+    da, db = np.array(on["dims"]), np.array(off["dims"])
+    assert da.shape == db.shape and np.max(np.abs(da - db)) <= 1 and np.count_nonzero(da != db) <= max(1, da.size // 50), (da - db).tolist()
+    assert max(on["dims"][-1]) == 64
     assert on["tall"] > 0 and off["tall"] == 0
     ea, eb = np.array(on["errs"]), np.array(off["errs"])
     print("chi = 64 physical evolution: max |derr|", float(np.max(np.abs(ea - eb))), " max err", float(ea.max()), " max |dZ|", float(np.max(np.abs(np.array(on["z"]) - np.array(off["z"])))))
