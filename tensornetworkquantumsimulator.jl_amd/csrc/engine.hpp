@@ -108,7 +108,8 @@ struct State {
     std::shared_ptr<RcclComm> comm;                   // set: the all-gather is an ncclAllGather enqueued on the handle's stream
     // profiling (shared by copies of a handle, so a loop `bpc = apply_gates(layer, bpc)` accumulates)
     std::shared_ptr<Prof> prof;
-    std::vector<Buf> keepalive;    // descriptor buffers kept until the next host sync
+    std::vector<Buf> keepalive;    // descriptor buffers and workspaces kept until the next host sync
+    size_t keep_mark = 0;          // keepalive[0, keep_mark) belongs to phases that have ended: released at the next stream synchronisation (soft_sync)
     HostArena arena;               // this handle's pinned staging arena (taken from / returned to a small free list, engine_core.cpp)
     tnqs_apply_stats stats{};
 

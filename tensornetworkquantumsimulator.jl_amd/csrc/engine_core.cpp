@@ -137,7 +137,7 @@ State::~State() {
 
 void sync(State* s) {
     HIPCHK(hipStreamSynchronize(s->stream));
-    s->keepalive.clear();
+    s->keepalive.clear(); s->keep_mark = 0;
     s->arena.off = 0;
 }
 

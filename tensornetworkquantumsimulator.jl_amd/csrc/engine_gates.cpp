@@ -434,7 +434,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
         if (!envs.empty()) HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags->p, 2 * envs.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
         if (!sj.empty()) HIPCHK(hipMemcpyAsync(h_cholfail.data(), d_cholfail->p, sj.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
         for (size_t i = 0; i < sj.size(); ++i) chol_failed += (part[i / 2] && is_chol[i] && h_cholfail[i]) ? 1 : 0;
         if (chol_failed) {              // numerically rank-deficient Gram matrix somewhere in the batch: redo with the eigen path
             factor_G(false, true);
@@ -442,7 +442,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             d_gitems = upload(s, gitems);
             run_theta();
             if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
-            HIPCHK(hipStreamSynchronize(s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
             s->stats.n_chol_fallbacks += 1;
         }
         if (qr2) {
@@ -524,7 +524,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                     // gate_theta reads the first-pass (lambda, idx, r) of the untouched partner site again and overwrites them with the same values
                     run_theta();
                     if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
-                    HIPCHK(hipStreamSynchronize(s->stream));
+                    HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
                     for (size_t k = 0; k < m; ++k) s->stats.n_qr2_sites += sj[rs[k]].owned ? 1 : 0;
                 }
             }
@@ -560,7 +560,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipMemcpyAsync(hterr.data(), d_terr_all->p, (size_t)npg * 8, hipMemcpyDeviceToHost, s->stream));
         }
-        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
         for (int q = 0; q < npg; ++q) { for (int k = 0; k < 8; ++k) info[8 * pg[q] + k] = hinfo[8 * q + k]; terr[pg[q]] = hterr[q]; }
     }
     // ---- 4b. sharded: the owner of the first vertex publishes (chi', status, truncerr, S, X2) of each gate ----------------
@@ -596,7 +596,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             const void* const* d_srcs = upload(s, srcs);
             launch_header_gather(s->stream, d_srcs, ng, reinterpret_cast<double*>(d_hdr->p));
             if (ng) HIPCHK(hipMemcpyAsync(allhdr.data(), d_hdr->p, (size_t)ng * 32, hipMemcpyDeviceToHost, s->stream));
-            HIPCHK(hipStreamSynchronize(s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
         }
         for (int gi = 0; gi < ng; ++gi) {
             info[8 * gi + 2] = (int)allhdr[4 * gi]; info[8 * gi + 3] = (int)allhdr[4 * gi + 1]; terr[gi] = allhdr[4 * gi + 2];
@@ -731,7 +731,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_diag<T>(s->stream, d, (int)di.size()); }
     }
     s->stats.n_two_site += ng;
-    sync(s);   // workspace of this batch is released to the pool after the stream drained
+    soft_sync(s);   // workspace of this batch goes back to the pool at the next stream synchronisation (the BP update's first read-back)
 }
 
 template <class T> static void flush_batch(State* s, std::vector<Gate1>& b1, std::vector<Gate2>& b2, const tnqs_apply_opts& ao, double* errs) {
@@ -740,7 +740,7 @@ template <class T> static void flush_batch(State* s, std::vector<Gate1>& b1, std
     apply_two_site_batch<T>(s, b2, ao, errs);
     s->stats.n_batches += 1;
     b1.clear(); b2.clear();
-    sync(s);
+    soft_sync(s);
 }
 
 template <class T> static void apply_gates_t(State* s, int ngates, const int32_t* nverts, const int32_t* verts, const double* mats,
@@ -790,6 +790,7 @@ template <class T> static void apply_gates_t(State* s, int ngates, const int32_t
     }
     flush_batch<T>(s, b1, b2, ao, errs);
     if (ao.update_cache) bp_update_t<T>(s, bp, nullptr, nullptr);                                   // :93-95
+    sync(s);                                                                                        // the call returns with the stream drained
 }
 
 void apply_gates(State* s, int ngates, const int32_t* nverts, const int32_t* verts, const double* mats,
@@ -834,6 +835,7 @@ template <class T> static void truncate_t(State* s, int maxdim, double cutoff, i
     } else {
         for (int e = 0; e < g.ne; ++e) run_group({{g.esrc[e], g.edst[e]}});
     }
+    sync(s);
 }
 void truncate_bp(State* s, int maxdim, double cutoff, int normalize, int ngroups, const int32_t* offs,
                  const int32_t* eu, const int32_t* ev, const tnqs_bp_opts* bp) {

@@ -71,6 +71,13 @@ struct HostTimer {
 };
 
 void sync(State* s);                                   // stream synchronise + release of the batch's descriptor buffers
+// End of a phase WITHOUT draining the stream: everything in the keep-alive list so far may go once the stream has been synchronised for some
+// other reason (the next read-back), so the host can start preparing the next phase while this one's last kernels still run.
+inline void soft_sync(State* s) { s->keep_mark = s->keepalive.size(); }
+// after a raw hipStreamSynchronize(s->stream): release what soft_sync() marked (later entries belong to the phase in progress)
+inline void drained(State* s) {
+    if (s->keep_mark) { s->keepalive.erase(s->keepalive.begin(), s->keepalive.begin() + (std::ptrdiff_t)std::min(s->keep_mark, s->keepalive.size())); s->keep_mark = 0; }
+}
 void materialize_scale(State* s, const std::vector<int>& verts);
 void materialize_scale_all(State* s);
 inline Buf dalloc(State* s, size_t bytes) {
