@@ -131,6 +131,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     const bool sharded = s->nranks > 1;
     const double sqrt_cutoff = ao.sqrt_cutoff >= 0 ? ao.sqrt_cutoff : 10.0 * (s->dtype == TNQS_C64 ? 1.1920928955078125e-07 : 2.220446049250313e-16);
     const int ng = (int)gates.size();
+    HostTimer ht_a(3);                 // TNQS_HOST_TIMING=1: host time of the batch up to the first read-back (3), between the read-backs (4), after them (5)
     if (!ao.normalize_tensors) {       // without the final normalisation the result scales with the inputs: apply pending factors first
         std::vector<int> vs; for (auto& g2 : gates) { vs.push_back(g2.v1); vs.push_back(g2.v2); }
         materialize_scale(s, vs);
@@ -434,7 +435,9 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
         if (!envs.empty()) HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags->p, 2 * envs.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
         if (!sj.empty()) HIPCHK(hipMemcpyAsync(h_cholfail.data(), d_cholfail->p, sj.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        ht_a.stop();
         HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
+        HostTimer ht_b(4);
         for (size_t i = 0; i < sj.size(); ++i) chol_failed += (part[i / 2] && is_chol[i] && h_cholfail[i]) ? 1 : 0;
         if (chol_failed) {              // numerically rank-deficient Gram matrix somewhere in the batch: redo with the eigen path
             factor_G(false, true);
@@ -560,6 +563,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipMemcpyAsync(hterr.data(), d_terr_all->p, (size_t)npg * 8, hipMemcpyDeviceToHost, s->stream));
         }
+        ht_b.stop();
         HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
         for (int q = 0; q < npg; ++q) { for (int k = 0; k < 8; ++k) info[8 * pg[q] + k] = hinfo[8 * q + k]; terr[pg[q]] = hterr[q]; }
     }
@@ -609,6 +613,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     } else {
         for (int gi = 0; gi < ng; ++gi) Sptr[gi] = (const double*)ws[gi].S->p;
     }
+    HostTimer ht_c(5);
     // every gate's status is checked before anything of the handle is replaced: a failing batch leaves the state as it was
     for (int gi = 0; gi < ng; ++gi) if (info[8 * gi + 3] != 0) throw Err(TNQS_ERR_NUMERIC, "simple_update: internal bond capacity exceeded");
     // ---- 5. psi' = (psi x_outer P) x_(s,b) X  (simple_update.jl:62-64, net effect of gauge + ungauge) ----------------
