@@ -94,7 +94,7 @@ void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void
     int npart = mf ? 4 * it.nchunks : (mf64 ? 2 * it.nchunks : it.nchunks);
     DBuf dP((size_t)npart * KK * KK * asz), dO((size_t)KK * KK * asz);
     it.partial = dP.p; dI.up(&it, sizeof(it));
-    if (mf64) launch_mfma_gram64_f64(nullptr, (const GramItem*)dI.p, 1, it.nchunks, KK);
+    if (mf64) launch_mfma_gram64_f64(nullptr, (const GramItem*)dI.p, 1, it.nchunks, KK, KK == 64);
     else if (mf) launch_mfma_gram32(nullptr, (const GramItem*)dI.p, 1, it.nchunks, KK);
     else if (dtype == TNQS_C64) { if (a64) launch_gram<float, double>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); else launch_gram<float, float>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); }
     else launch_gram<double, double>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK);

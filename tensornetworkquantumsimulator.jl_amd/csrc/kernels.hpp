@@ -4,6 +4,7 @@
 // contracted / kept, (s) the site index when it takes part (D = d) or folded into a (D = 1), and (a, b) the
 // remaining indices before / after leg k.  No explicit transposes are ever materialised.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime_api.h>
 #include <cstddef>
 #include <cstdint>
@@ -290,7 +291,7 @@ bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int 
 // fused (X x_r M) then Gram with Y: tiles of 64 fibers = (s:2) x (first row leg: 32); writes 4 partials per chunk
 void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
 // Gram with f64 accumulation on the f64 matrix cores (gate path: G = psi~^dagger psi~, D*K == 64, X == Y); tiles of 64 fibers
-bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);
+bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax, bool all_kk64 = false);   // all_kk64: every item has D * K = 64
 // the same for 64 < D*K <= 128 (chi = 64 sites; kernels_chi64.hip); writes ONE partial per chunk
 bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);
 // fused pair of mode products on two slow 32-dim legs (16 companions = 128-byte runs per workgroup)
@@ -298,7 +299,11 @@ void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int to
 // workgroups of one PairItem: ceil(nslices / spw) slice ranges in groups of 8, two workgroups (one per 8-companion half) per range
 inline int pair_wgs(int nslices, int spw) { const int np = (nslices + spw - 1) / spw; return 16 * ((np + 7) / 8); }
 // slices per workgroup for a batch of `total_slices`: the largest power of two <= 16 that still gives >= 1024 workgroups
-inline int pair_spw(double total_slices) { int spw = 16; while (spw > 1 && 2.0 * total_slices / spw < 1024.0) spw >>= 1; return spw; }
+inline int pair_spw(double total_slices) {
+    static const int forced = [] { const char* e = std::getenv("TNQS_PAIR_SPW"); return e ? std::atoi(e) : 0; }();      // kernel experiments
+    if (forced > 0) return forced;
+    int spw = 16; while (spw > 1 && 2.0 * total_slices / spw < 1024.0) spw >>= 1; return spw;
+}
 // gate epilogue psi' = psi x_(s,b) X for d = 2, chi_b = chi_b' = 32 (K = N = 64) in the pair-kernel shape: plane (b, y) per companion,
 // the two site components of a companion are the planes of one wave.  Xb = X rearranged into MFMA B-operand order (make_xb).
 struct Apply64Item { const void* in; void* out; const void* Xb; PairGeom g; int wg_begin; int spw; double* norm_partial; };

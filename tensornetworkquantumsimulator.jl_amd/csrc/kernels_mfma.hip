@@ -1282,7 +1282,58 @@ void launch_recover_v_mfma(hipStream_t s, const RecoverItem* d_items, int nitems
 // accumulate into separate partials (2 per chunk) because a block changes wave with the parity.
 // ------------------------------------------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
-template <bool M3>
+// A set of upper-triangle blocks that share one 16-column panel P of the tile: ROW = P supplies the rows (A operand) of every block and Q[j] the
+// columns, !ROW = P supplies the columns (B operand) and Q[j] the rows; DIAG0 / DIAG1: block 0 / 1 is (P, P).  The shared panel's values are
+// read from LDS, converted to f64 and combined ONCE per k-step for all N blocks (a block on its own converts four values and forms three sums
+// per k-step: with N = 3 the VALU work per MFMA drops by a third), and the 3 N accumulators interleave (no back-to-back dependent MFMAs).
+template <int N, bool ROW, bool DIAG0, bool DIAG1, bool M3>
+__device__ __forceinline__ void gram_f64_shared(const float* __restrict__ Xr, const float* __restrict__ Xi, int TRP, int l15, int kq, int P,
+                                                const int (&Q)[N], v4d (&cr)[N], v4d (&ci)[N], v4d (&cc)[N]) {
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int ro = (16 * P + l15) * TRP + 16 * kq + 8 * half;
+#pragma unroll 1
+        for (int q = 0; q < 2; ++q) {
+            const v4f p0 = *reinterpret_cast<const v4f*>(Xr + ro + 4 * q), p1 = *reinterpret_cast<const v4f*>(Xi + ro + 4 * q);
+            v4f o0[N], o1[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if ((j == 0 && DIAG0) || (j == 1 && DIAG1)) continue;
+                const int rb = (16 * Q[j] + l15) * TRP + 16 * kq + 8 * half;
+                o0[j] = *reinterpret_cast<const v4f*>(Xr + rb + 4 * q); o1[j] = *reinterpret_cast<const v4f*>(Xi + rb + 4 * q);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double pr = (double)p0[c], pi = (double)p1[c];
+                const double psum = pr + pi, pdif = pr - pi, npr = -pr;            // (the compiler drops what a variant does not use)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const bool dg = (j == 0 && DIAG0) || (j == 1 && DIAG1);
+                    const double qr = dg ? pr : (double)o0[j][c], qi = dg ? pi : (double)o1[j][c];
+                    // out[i][j] += x[i] conj(x[j]):  ROW: a = p, b = q;  !ROW: a = q, b = p
+                    if (M3) {
+                        if (ROW) {
+                            cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(psum, qr, cr[j], 0, 0, 0);
+                            ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pi, qr - qi, ci[j], 0, 0, 0);
+                            cc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pr, qi + qr, cc[j], 0, 0, 0);
+                        } else {
+                            cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(qr + qi, pr, cr[j], 0, 0, 0);
+                            ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(qi, pdif, ci[j], 0, 0, 0);
+                            cc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(qr, psum, cc[j], 0, 0, 0);
+                        }
+                    } else {
+                        const double ar = ROW ? pr : qr, ai = ROW ? pi : qi, br = ROW ? qr : pr, bi = ROW ? qi : pi, nar = ROW ? npr : -qr;
+                        cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr[j], 0, 0, 0);
+                        ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci[j], 0, 0, 0);
+                        cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, cr[j], 0, 0, 0);
+                        ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nar, bi, ci[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+template <bool M3, bool SHARED>         // SHARED: every item of the launch has KK = 64 (four panels): blocks dealt in panel-sharing sets
 __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem* __restrict__ items, int nitems, int dbg_skip) {
     constexpr int TR = 64, TRP = TR + 4, NU = 8;
     // two tile buffers (re, im planes each): the next tile is committed while other waves still multiply the current one
@@ -1311,6 +1362,16 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem*
     for (int q = 0; q < 3; ++q) { const int wv = parA ? 3 - w : w; int idx = wv + 4 * q; aOn[q] = idx < nblk; block_of(aOn[q] ? idx : 0, aI[q], aJ[q]); }
 #pragma unroll
     for (int q = 0; q < 2; ++q) { const int wv = parA ? w : 3 - w; int idx = wv + 4 * q; bOn[q] = idx < nblk; block_of(bOn[q] ? idx : 0, bI[q], bJ[q]); }
+    // KK = 64 (four panels, ten blocks): sets that share a panel (gram_f64_shared) instead of the round-robin deal --
+    //   even waves: A = {(0,0),(0,1),(0,2)} (rows from panel 0), B = {(1,1),(1,2)} (rows from panel 1)
+    //   odd waves : A = {(0,3),(1,3),(2,3)} (columns from panel 3), B = {(2,2),(3,3)}
+    constexpr bool shared_sets = SHARED;
+    if (shared_sets) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { aOn[q] = true; aI[q] = (w & 1) ? q : 0; aJ[q] = (w & 1) ? 3 : q; }
+        bOn[0] = bOn[1] = true;
+        bI[0] = (w & 1) ? 2 : 1; bJ[0] = (w & 1) ? 2 : 1; bI[1] = (w & 1) ? 3 : 1; bJ[1] = (w & 1) ? 3 : 2;
+    }
     // M3: Gauss' three-multiplication product in f64 (mfma_common.hpp, CAcc32::mac_conj): per block  sum (ar+ai) br,  sum ai (br-bi),  sum ar (bi+br)
     v4d CAr[3], CAi[3], CBr[2], CBi[2], CAc[3], CBc[2];
 #pragma unroll
@@ -1418,7 +1479,25 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem*
                 }
             }
         };
-        if (dbg_skip != 1) {
+        if (dbg_skip != 1 && shared_sets) {
+            if (((t - t_begin) & 1) == parA) {                    // wave-uniform
+                const int q3[3] = {0, 1, 2};
+                if (w & 1) gram_f64_shared<3, false, false, false, M3>(Xr, Xi, TRP, l15, kq, 3, q3, CAr, CAi, CAc);
+                else       gram_f64_shared<3, true, true, false, M3>(Xr, Xi, TRP, l15, kq, 0, q3, CAr, CAi, CAc);
+            } else if (w & 1) {
+                const int q2[1] = {2}, q3b[1] = {3};
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {                      // two diagonal blocks, each on its own panel (register copies, no address taken)
+                    v4d r1[1] = {CBr[b]}, i1[1] = {CBi[b]}, c1[1] = {CBc[b]};
+                    if (b == 0) gram_f64_shared<1, true, true, false, M3>(Xr, Xi, TRP, l15, kq, 2, q2, r1, i1, c1);
+                    else        gram_f64_shared<1, true, true, false, M3>(Xr, Xi, TRP, l15, kq, 3, q3b, r1, i1, c1);
+                    CBr[b] = r1[0]; CBi[b] = i1[0]; CBc[b] = c1[0];
+                }
+            } else {
+                const int q12[2] = {1, 2};
+                gram_f64_shared<2, true, true, false, M3>(Xr, Xi, TRP, l15, kq, 1, q12, CBr, CBi, CBc);
+            }
+        } else if (dbg_skip != 1) {
             if (((t - t_begin) & 1) == parA) {                    // wave-uniform
 #pragma unroll
                 for (int q = 0; q < 3; ++q) if (aOn[q]) block_pass(aI[q], aJ[q], CAr[q], CAi[q], CAc[q]);
@@ -1448,13 +1527,15 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem*
 #pragma unroll
     for (int q = 0; q < 2; ++q) if (bOn[q]) write_block(partB, bI[q], bJ[q], CBr[q], CBi[q], CBc[q]);
 }
-bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
+bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax, bool all_kk64) {
     if (KKmax > 64) return false;
     if (total_chunks <= 0) return true;
     const size_t lds = (size_t)4 * 64 * 68 * sizeof(float);
     static int skip = -1; if (skip < 0) { const char* e = std::getenv("TNQS_DBG_GRAM_SKIP"); skip = e ? std::atoi(e) : 0; }
-    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_gram64_f64_kernel<true>, lds); hipLaunchKernelGGL(mfma_gram64_f64_kernel<true>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems, skip); }
-    else { set_max_dynamic_lds((const void*)mfma_gram64_f64_kernel<false>, lds); hipLaunchKernelGGL(mfma_gram64_f64_kernel<false>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems, skip); }
+#define TNQS_G64(M3, SH) { set_max_dynamic_lds((const void*)mfma_gram64_f64_kernel<M3, SH>, lds); hipLaunchKernelGGL((mfma_gram64_f64_kernel<M3, SH>), dim3(total_chunks), dim3(256), lds, s, d_items, nitems, skip); }
+    if (mfma_use_3m()) { if (all_kk64) TNQS_G64(true, true) else TNQS_G64(true, false) }
+    else { if (all_kk64) TNQS_G64(false, true) else TNQS_G64(false, false) }
+#undef TNQS_G64
     TNQS_CHECK_LAUNCH();
     return true;
 }
