@@ -173,7 +173,7 @@ def main():
     tf = "<true>" if m3 else "<false>"
     KERNEL_OF = {"bp_pair": "tnqs::mfma_pair_kernel" + tf, "bp_modeprod": "tnqs::mfma_rowgemm_kernel<1, 1, 1, %s>" % ("true" if m3 else "false"),
                  "gate_modeprod": "tnqs::mfma_pair_kernel" + tf, "bp_fused": "tnqs::mfma_gram32_fused_kernel",
-                 "bp_gram": "tnqs::mfma_gram32_kernel", "gate_gram": "tnqs::mfma_gram64_f64_kernel" + tf,
+                 "bp_gram": "tnqs::mfma_gram32_kernel", "gate_gram": "tnqs::mfma_gram64_f64_kernel<%s, true>" % ("true" if m3 else "false"),
                  "gate_apply": "tnqs::mfma_rowgemm_kernel<2, 2, 2, %s>" % ("true" if m3 else "false"), "bp_pairgram": "tnqs::mfma_pair_gram2_kernel" + tf}
     traffic_db = {}
     try:
