@@ -56,7 +56,8 @@ TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64
 // TNQS_JACOBI_GLOBAL=1: every Jacobi factorisation in the global-memory kernel;  TNQS_BP_WS_MB: workspace bound of a BP sub-batch (MiB);
 // TNQS_HOST_TIMING=1: host-side phase timers printed at exit;  TNQS_RCCL_LIB: path of librccl.so (sharding.cpp);
 // TNQS_NO_3M=1 (launch_util.hpp): four-multiplication complex product in every MFMA kernel instead of Gauss' three (mfma_common.hpp, CAcc32);
-// kernels_mfma.hip reads TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP (single-message pair-Gram), TNQS_DBG_GRAM_SKIP (kernel experiments)
+// kernels_mfma.hip reads TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP (single-message pair-Gram), TNQS_DBG_GRAM_SKIP; kernels.hpp reads TNQS_PAIR_SPW
+// (slices per workgroup pair of the chi = 32 pair product) -- kernel experiments
 inline size_t bp_ws_budget() { static const size_t v = [] { const char* e = std::getenv("TNQS_BP_WS_MB"); return (e ? (size_t)std::atoll(e) : (size_t)24576) << 20; }(); return v; }
 inline size_t jacobi_lds(size_t bytes) { static const bool g = envflag("TNQS_JACOBI_GLOBAL"); return (g || bytes > 160 * 1024 - 256) ? 0 : bytes; }
 inline int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j : ji) m = std::max(m, std::max(j.m, j.n)); return m; }
