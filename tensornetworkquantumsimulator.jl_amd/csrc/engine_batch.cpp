@@ -257,7 +257,7 @@ template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& job
     ProfScope ps(s, cls, bytes, flops);
     if (fused) launch_mfma_gram32_fused(s->stream, d, (int)items.size(), chunks);
     else if (mf64) { bool all64 = true; for (auto& j : jobs) all64 = all64 && j.KK == 64; launch_mfma_gram64_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax, all64); }
-    else if (mf128) launch_mfma_gram128_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax);
+    else if (mf128) { bool all128 = true; for (auto& j : jobs) all128 = all128 && j.KK == 128; launch_mfma_gram128_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax, all128); }
     else if (mf) { if (KKmax <= 32) launch_mfma_gram32(s->stream, d, (int)items.size(), chunks, (int)KKmax); else launch_mfma_gram64(s->stream, d, (int)items.size(), chunks, (int)KKmax); }
     else launch_gram<T, Acc>(s->stream, d, (int)items.size(), chunks, TR, (int)KKmax);
 }

@@ -293,7 +293,7 @@ void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems
 // Gram with f64 accumulation on the f64 matrix cores (gate path: G = psi~^dagger psi~, D*K == 64, X == Y); tiles of 64 fibers
 bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax, bool all_kk64 = false);   // all_kk64: every item has D * K = 64
 // the same for 64 < D*K <= 128 (chi = 64 sites; kernels_chi64.hip); writes ONE partial per chunk
-bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);
+bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax, bool all_kk128 = false);   // all_kk128: every item has D * K = 128
 // fused pair of mode products on two slow 32-dim legs (16 companions = 128-byte runs per workgroup)
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs);
 // workgroups of one PairItem: ceil(nslices / spw) slice ranges in groups of 8, two workgroups (one per 8-companion half) per range

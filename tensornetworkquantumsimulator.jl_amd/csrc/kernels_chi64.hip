@@ -530,8 +530,20 @@ void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, in
 // computed -- 36 for KK = 128, dealt round-robin to the four waves (9 each) -- and mirrored when the partial is written.
 // One partial per chunk.  f64 MFMA layout: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], C[row = (l >> 4) + 4 r][col = l & 15].
 // ------------------------------------------------------------------------------------------------------------
-typedef double v4d __attribute__((ext_vector_type(4)));
-template <bool M3>
+// SHARED (every item of the launch has KK = 128: eight panels, 36 upper blocks): twelve sets of three blocks that share a panel
+// (gram_f64_shared, mfma_common.hpp), three sets per wave --
+//   wave w = 0, 1, 2:  {(w,w),(w,w+1),(w,w+2)},  {(w+3,w+3),(w+3,w+4),(w+3,w+5)},  {(w,w+3),(w,w+4),(w,w+5)}      (rows from one panel)
+//   wave 3          :  {(0,7),(1,7),(3,7)},  {(4,7),(6,7),(7,7)},  {(0,6),(3,6),(6,6)}                              (columns from one panel)
+// set s of a wave owns accumulator slots 3 s .. 3 s + 2
+template <bool ROW, int DIAGJ, bool M3>
+__device__ __forceinline__ void gram128_set(const float* __restrict__ Xr, const float* __restrict__ Xi, int TRP, int l15, int kq, int P, int q0, int q1, int q2,
+                                            v4d& r0, v4d& r1, v4d& r2, v4d& i0, v4d& i1, v4d& i2, v4d& c0, v4d& c1, v4d& c2) {
+    const int Q[3] = {q0, q1, q2};
+    v4d r[3] = {r0, r1, r2}, i[3] = {i0, i1, i2}, c[3] = {c0, c1, c2};
+    gram_f64_shared<3, ROW, DIAGJ, M3>(Xr, Xi, TRP, l15, kq, P, Q, r, i, c);
+    r0 = r[0]; r1 = r[1]; r2 = r[2]; i0 = i[0]; i1 = i[1]; i2 = i[2]; c0 = c[0]; c1 = c[1]; c2 = c[2];
+}
+template <bool M3, bool SHARED>
 __global__ __launch_bounds__(256) void mfma_gram128_f64_kernel(const GramItem* __restrict__ items, int nitems) {
     constexpr int TR = 64, TRP = TR + 4, NU = 16, KKP = 128, NBW = 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -556,6 +568,15 @@ __global__ __launch_bounds__(256) void mfma_gram128_f64_kernel(const GramItem* _
         int idx = w + 4 * q; bOn[q] = idx < nblk;
         int I = 0, rem = bOn[q] ? idx : 0; while (rem >= nb - I) { rem -= nb - I; ++I; }
         bI[q] = I; bJ[q] = I + rem;
+    }
+    if (SHARED) {
+        const int rI[9] = {0, 1, 3, 4, 6, 7, 0, 3, 6}, rJ[9] = {7, 7, 7, 7, 7, 7, 6, 6, 6};            // wave 3
+#pragma unroll
+        for (int q = 0; q < NBW; ++q) {
+            bOn[q] = true;
+            if (w < 3) { const int st = q / 3, k = q % 3; bI[q] = st == 1 ? w + 3 : w; bJ[q] = st == 0 ? w + k : (st == 1 ? w + 3 + k : w + 3 + k); }
+            else { bI[q] = rI[q]; bJ[q] = rJ[q]; }
+        }
     }
     v4d Cr[NBW], Ci[NBW], Cc[NBW];                             // M3: sum (ar+ai) br,  sum ai (br-bi),  sum ar (bi+br)  (CAcc32::mac_conj in f64)
 #pragma unroll
@@ -626,6 +647,20 @@ __global__ __launch_bounds__(256) void mfma_gram128_f64_kernel(const GramItem* _
         const int cur = (t - t_begin) & 1;
         if (t + 1 < t_end) { if (fast) { commit_loads(cur ^ 1); if (t + 2 < t_end) issue_loads(t + 2); } else fill_slow(t + 1, cur ^ 1); }
         const float* Xr = Xbuf + cur * (2 * KKP * TRP); const float* Xi = Xr + KKP * TRP;
+        if (SHARED) {
+#define TNQS_SET(ROW, DJ, S, P, A, B, C) gram128_set<ROW, DJ, M3>(Xr, Xi, TRP, l15, kq, P, A, B, C, Cr[3 * S], Cr[3 * S + 1], Cr[3 * S + 2], \
+                                                                  Ci[3 * S], Ci[3 * S + 1], Ci[3 * S + 2], Cc[3 * S], Cc[3 * S + 1], Cc[3 * S + 2])
+            if (w < 3) {
+                TNQS_SET(true, 0, 0, w, w, w + 1, w + 2);
+                TNQS_SET(true, 0, 1, w + 3, w + 3, w + 4, w + 5);
+                TNQS_SET(true, -1, 2, w, w + 3, w + 4, w + 5);
+            } else {
+                TNQS_SET(false, -1, 0, 7, 0, 1, 3);
+                TNQS_SET(false, 2, 1, 7, 4, 6, 7);
+                TNQS_SET(false, 2, 2, 6, 0, 3, 6);
+            }
+#undef TNQS_SET
+        } else
 #pragma unroll
         for (int q = 0; q < NBW; ++q) {
             if (!bOn[q]) continue;                               // wave-uniform
@@ -671,12 +706,14 @@ __global__ __launch_bounds__(256) void mfma_gram128_f64_kernel(const GramItem* _
         }
     }
 }
-bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
+bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax, bool all_kk128) {
     if (KKmax > 128) return false;
     if (total_chunks <= 0) return true;
     const size_t lds = (size_t)4 * 128 * 68 * sizeof(float);
-    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_gram128_f64_kernel<true>, lds); hipLaunchKernelGGL(mfma_gram128_f64_kernel<true>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }
-    else { set_max_dynamic_lds((const void*)mfma_gram128_f64_kernel<false>, lds); hipLaunchKernelGGL(mfma_gram128_f64_kernel<false>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }
+#define TNQS_G128(M3, SH) { set_max_dynamic_lds((const void*)mfma_gram128_f64_kernel<M3, SH>, lds); hipLaunchKernelGGL((mfma_gram128_f64_kernel<M3, SH>), dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }
+    if (mfma_use_3m()) { if (all_kk128) TNQS_G128(true, true) else TNQS_G128(true, false) }
+    else { if (all_kk128) TNQS_G128(false, true) else TNQS_G128(false, false) }
+#undef TNQS_G128
     TNQS_CHECK_LAUNCH();
     return true;
 }

@@ -1281,58 +1281,6 @@ void launch_recover_v_mfma(hipStream_t s, const RecoverItem* d_items, int nitems
 // tiles and backwards on odd tiles, so every wave (= SIMD) does 5 blocks per two tiles instead of 8; the two tile parities
 // accumulate into separate partials (2 per chunk) because a block changes wave with the parity.
 // ------------------------------------------------------------------------------------------------------------
-typedef double v4d __attribute__((ext_vector_type(4)));
-// A set of upper-triangle blocks that share one 16-column panel P of the tile: ROW = P supplies the rows (A operand) of every block and Q[j] the
-// columns, !ROW = P supplies the columns (B operand) and Q[j] the rows; DIAG0 / DIAG1: block 0 / 1 is (P, P).  The shared panel's values are
-// read from LDS, converted to f64 and combined ONCE per k-step for all N blocks (a block on its own converts four values and forms three sums
-// per k-step: with N = 3 the VALU work per MFMA drops by a third), and the 3 N accumulators interleave (no back-to-back dependent MFMAs).
-template <int N, bool ROW, bool DIAG0, bool DIAG1, bool M3>
-__device__ __forceinline__ void gram_f64_shared(const float* __restrict__ Xr, const float* __restrict__ Xi, int TRP, int l15, int kq, int P,
-                                                const int (&Q)[N], v4d (&cr)[N], v4d (&ci)[N], v4d (&cc)[N]) {
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        const int ro = (16 * P + l15) * TRP + 16 * kq + 8 * half;
-#pragma unroll 1
-        for (int q = 0; q < 2; ++q) {
-            const v4f p0 = *reinterpret_cast<const v4f*>(Xr + ro + 4 * q), p1 = *reinterpret_cast<const v4f*>(Xi + ro + 4 * q);
-            v4f o0[N], o1[N];
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                if ((j == 0 && DIAG0) || (j == 1 && DIAG1)) continue;
-                const int rb = (16 * Q[j] + l15) * TRP + 16 * kq + 8 * half;
-                o0[j] = *reinterpret_cast<const v4f*>(Xr + rb + 4 * q); o1[j] = *reinterpret_cast<const v4f*>(Xi + rb + 4 * q);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const double pr = (double)p0[c], pi = (double)p1[c];
-                const double psum = pr + pi, pdif = pr - pi, npr = -pr;            // (the compiler drops what a variant does not use)
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    const bool dg = (j == 0 && DIAG0) || (j == 1 && DIAG1);
-                    const double qr = dg ? pr : (double)o0[j][c], qi = dg ? pi : (double)o1[j][c];
-                    // out[i][j] += x[i] conj(x[j]):  ROW: a = p, b = q;  !ROW: a = q, b = p
-                    if (M3) {
-                        if (ROW) {
-                            cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(psum, qr, cr[j], 0, 0, 0);
-                            ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pi, qr - qi, ci[j], 0, 0, 0);
-                            cc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pr, qi + qr, cc[j], 0, 0, 0);
-                        } else {
-                            cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(qr + qi, pr, cr[j], 0, 0, 0);
-                            ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(qi, pdif, ci[j], 0, 0, 0);
-                            cc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(qr, psum, cc[j], 0, 0, 0);
-                        }
-                    } else {
-                        const double ar = ROW ? pr : qr, ai = ROW ? pi : qi, br = ROW ? qr : pr, bi = ROW ? qi : pi, nar = ROW ? npr : -qr;
-                        cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr[j], 0, 0, 0);
-                        ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci[j], 0, 0, 0);
-                        cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, cr[j], 0, 0, 0);
-                        ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nar, bi, ci[j], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-}
 template <bool M3, bool SHARED>         // SHARED: every item of the launch has KK = 64 (four panels): blocks dealt in panel-sharing sets
 __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem* __restrict__ items, int nitems, int dbg_skip) {
     constexpr int TR = 64, TRP = TR + 4, NU = 8;
@@ -1482,20 +1430,20 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_f64_kernel(const GramItem*
         if (dbg_skip != 1 && shared_sets) {
             if (((t - t_begin) & 1) == parA) {                    // wave-uniform
                 const int q3[3] = {0, 1, 2};
-                if (w & 1) gram_f64_shared<3, false, false, false, M3>(Xr, Xi, TRP, l15, kq, 3, q3, CAr, CAi, CAc);
-                else       gram_f64_shared<3, true, true, false, M3>(Xr, Xi, TRP, l15, kq, 0, q3, CAr, CAi, CAc);
+                if (w & 1) gram_f64_shared<3, false, -1, M3>(Xr, Xi, TRP, l15, kq, 3, q3, CAr, CAi, CAc);
+                else       gram_f64_shared<3, true, 0, M3>(Xr, Xi, TRP, l15, kq, 0, q3, CAr, CAi, CAc);
             } else if (w & 1) {
                 const int q2[1] = {2}, q3b[1] = {3};
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {                      // two diagonal blocks, each on its own panel (register copies, no address taken)
                     v4d r1[1] = {CBr[b]}, i1[1] = {CBi[b]}, c1[1] = {CBc[b]};
-                    if (b == 0) gram_f64_shared<1, true, true, false, M3>(Xr, Xi, TRP, l15, kq, 2, q2, r1, i1, c1);
-                    else        gram_f64_shared<1, true, true, false, M3>(Xr, Xi, TRP, l15, kq, 3, q3b, r1, i1, c1);
+                    if (b == 0) gram_f64_shared<1, true, 0, M3>(Xr, Xi, TRP, l15, kq, 2, q2, r1, i1, c1);
+                    else        gram_f64_shared<1, true, 0, M3>(Xr, Xi, TRP, l15, kq, 3, q3b, r1, i1, c1);
                     CBr[b] = r1[0]; CBi[b] = i1[0]; CBc[b] = c1[0];
                 }
             } else {
                 const int q12[2] = {1, 2};
-                gram_f64_shared<2, true, true, false, M3>(Xr, Xi, TRP, l15, kq, 1, q12, CBr, CBi, CBc);
+                gram_f64_shared<2, true, 0, M3>(Xr, Xi, TRP, l15, kq, 1, q12, CBr, CBi, CBc);
             }
         } else if (dbg_skip != 1) {
             if (((t - t_begin) & 1) == parA) {                    // wave-uniform

@@ -117,6 +117,55 @@ template <bool M3> struct CAcc32 {
     }
 };
 
+// ------------------------------------------------------------------------------------------------------------
+// f64 Gram tiles (v_mfma_f64_16x16x4_f64; LDS tile: planes Xr / Xi, element (column c, tile row r) at c * TRP + r; lane = (l15, kq): column
+// l15 of a 16-column panel, tile rows 16 kq .. 16 kq + 15).  A set of upper-triangle blocks that share one panel P: ROW = P supplies the rows
+// (A operand) of every block and Q[j] the columns, !ROW = P supplies the columns (B operand) and Q[j] the rows; DIAGJ >= 0: block DIAGJ is (P, P).
+// The shared panel's values are read from LDS, converted to f64 and combined ONCE per four k-steps for all N blocks (a block on its own
+// converts four values and forms three sums per k-step).  out[i][j] += x[i] conj(x[j]); M3: (cr, ci, cc) accumulate
+// sum (ar+ai) br, sum ai (br-bi), sum ar (bi+br), i.e. re = cr - ci, im = cr - cc.
+// ------------------------------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+template <int N, bool ROW, int DIAGJ, bool M3>
+__device__ __forceinline__ void gram_f64_shared(const float* __restrict__ Xr, const float* __restrict__ Xi, int TRP, int l15, int kq, int P,
+                                                const int (&Q)[N], v4d (&cr)[N], v4d (&ci)[N], v4d (&cc)[N]) {
+#pragma unroll 1
+    for (int hq = 0; hq < 4; ++hq) {                              // tile rows 16 kq + 4 hq .. + 3
+        const int ro = (16 * P + l15) * TRP + 16 * kq + 4 * hq;
+        const v4f p0 = *reinterpret_cast<const v4f*>(Xr + ro), p1 = *reinterpret_cast<const v4f*>(Xi + ro);
+        double pr[4], pi[4], ps[4], pd[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { pr[c] = (double)p0[c]; pi[c] = (double)p1[c]; ps[c] = pr[c] + pi[c]; pd[c] = pr[c] - pi[c]; }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const bool dg = (j == DIAGJ);
+            v4f o0 = p0, o1 = p1;
+            if (!dg) { const int rb = (16 * Q[j] + l15) * TRP + 16 * kq + 4 * hq; o0 = *reinterpret_cast<const v4f*>(Xr + rb); o1 = *reinterpret_cast<const v4f*>(Xi + rb); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double qr = dg ? pr[c] : (double)o0[c], qi = dg ? pi[c] : (double)o1[c];
+                if (M3) {
+                    if (ROW) {                                       // a = p, b = q
+                        cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ps[c], qr, cr[j], 0, 0, 0);
+                        ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pi[c], qr - qi, ci[j], 0, 0, 0);
+                        cc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[c], qi + qr, cc[j], 0, 0, 0);
+                    } else {                                         // a = q, b = p
+                        cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(qr + qi, pr[c], cr[j], 0, 0, 0);
+                        ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(qi, pd[c], ci[j], 0, 0, 0);
+                        cc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(qr, ps[c], cc[j], 0, 0, 0);
+                    }
+                } else {
+                    const double ar = ROW ? pr[c] : qr, ai = ROW ? pi[c] : qi, br = ROW ? qr : pr[c], bi = ROW ? qi : pi[c];
+                    cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr[j], 0, 0, 0);
+                    ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci[j], 0, 0, 0);
+                    cr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, cr[j], 0, 0, 0);
+                    ci[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, bi, ci[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
