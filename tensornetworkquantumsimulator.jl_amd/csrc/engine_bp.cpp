@@ -540,9 +540,9 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
         s->stats.n_bp_sweeps += 1;
         if (compute_error) {
             launch_sum_doubles(s->stream, reinterpret_cast<const double*>(d_diffs->p), (int)nseq, reinterpret_cast<double*>(d_sum->p));
-            double tot = 0;
-            HIPCHK(hipMemcpyAsync(&tot, d_sum->p, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            const double* st_tot = readback<double>(s, d_sum->p, 1);
             sync(s);
+            const double tot = *st_tot;                                  // (the arena's memory is untouched until the next upload)
             avg = tot / (double)nseq;
             if (avg <= tol) { converged = true; niter = iter; break; }
         }

@@ -432,11 +432,14 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
         std::vector<int> hinfo(8 * (size_t)std::max(1, npg));
         int chol_failed = 0;
-        if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
-        if (!envs.empty()) HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags->p, 2 * envs.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-        if (!sj.empty()) HIPCHK(hipMemcpyAsync(h_cholfail.data(), d_cholfail->p, sj.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        const int* st_info = npg ? readback<int>(s, d_info_all->p, (size_t)npg * 8) : nullptr;
+        const int* st_flags = !envs.empty() ? readback<int>(s, d_flags->p, 2 * envs.size()) : nullptr;
+        const int* st_chol = !sj.empty() ? readback<int>(s, d_cholfail->p, sj.size()) : nullptr;
         ht_a.stop();
         HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
+        if (st_info) std::copy(st_info, st_info + (size_t)npg * 8, hinfo.begin());
+        if (st_flags) std::copy(st_flags, st_flags + 2 * envs.size(), h_flags.begin());
+        if (st_chol) std::copy(st_chol, st_chol + sj.size(), h_cholfail.begin());
         HostTimer ht_b(4);
         for (size_t i = 0; i < sj.size(); ++i) chol_failed += (part[i / 2] && is_chol[i] && h_cholfail[i]) ? 1 : 0;
         if (chol_failed) {              // numerically rank-deficient Gram matrix somewhere in the batch: redo with the eigen path
@@ -559,12 +562,11 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         }
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
         std::vector<double> hterr(std::max(1, npg));
-        if (npg) {
-            HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
-            HIPCHK(hipMemcpyAsync(hterr.data(), d_terr_all->p, (size_t)npg * 8, hipMemcpyDeviceToHost, s->stream));
-        }
+        const int* st_info2 = npg ? readback<int>(s, d_info_all->p, (size_t)npg * 8) : nullptr;
+        const double* st_terr = npg ? readback<double>(s, d_terr_all->p, (size_t)npg) : nullptr;
         ht_b.stop();
         HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
+        if (npg) { std::copy(st_info2, st_info2 + (size_t)npg * 8, hinfo.begin()); std::copy(st_terr, st_terr + npg, hterr.begin()); }
         for (int q = 0; q < npg; ++q) { for (int k = 0; k < 8; ++k) info[8 * pg[q] + k] = hinfo[8 * q + k]; terr[pg[q]] = hterr[q]; }
     }
     // ---- 4b. sharded: the owner of the first vertex publishes (chi', status, truncerr, S, X2) of each gate ----------------

@@ -72,6 +72,21 @@ struct HostTimer {
 };
 
 void sync(State* s);                                   // stream synchronise + release of the batch's descriptor buffers
+HostArena acquire_arena();                             // a recycled or freshly pinned 32 MiB arena (engine_core.cpp)
+// Read-back through the pinned staging arena: the copy is enqueued and the staged host pointer returned; it holds the data once the stream
+// has been synchronised (a read-back into pageable memory is staged by the runtime and BLOCKS per call).  The staged bytes stay valid until the
+// next upload() / readback() after a sync(s) reuses the arena.
+template <class X> const X* readback(State* s, const void* dsrc, size_t count) {
+    const size_t bytes = count * sizeof(X);
+    HostArena& ar = s->arena;
+    if (!ar.base) ar = acquire_arena();
+    const size_t aligned = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+    if (aligned > ar.cap) throw Err(TNQS_ERR_UNSUPPORTED, "read-back too large for the staging arena");
+    if (ar.off + aligned > ar.cap) { HIPCHK(hipStreamSynchronize(s->stream)); ar.off = 0; }     // pending uploads have been copied: the host side is free
+    char* h = ar.base + ar.off; ar.off += aligned;
+    if (bytes) HIPCHK(hipMemcpyAsync(h, dsrc, bytes, hipMemcpyDeviceToHost, s->stream));
+    return reinterpret_cast<const X*>(h);
+}
 // End of a phase WITHOUT draining the stream: everything in the keep-alive list so far may go once the stream has been synchronised for some
 // other reason (the next read-back), so the host can start preparing the next phase while this one's last kernels still run.
 inline void soft_sync(State* s) { s->keep_mark = s->keepalive.size(); }
@@ -88,7 +103,6 @@ inline Buf dalloc(State* s, size_t bytes) {
     return b;
 }
 // descriptor upload through the handle's pinned staging arena (reset at host sync points)
-HostArena acquire_arena();                          // a recycled or freshly pinned 32 MiB arena (engine_core.cpp)
 template <class Item> const Item* upload(State* s, const std::vector<Item>& v) {
     if (v.empty()) return nullptr;
     size_t bytes = v.size() * sizeof(Item);
