@@ -140,7 +140,7 @@ def main():
     for _ in range(args.warmup):
         info = {}
         bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=apply_kwargs, info=info)
-    tn.profile_enable(bpc, True)
+    tn.profile_enable(bpc, os.environ.get("TNQS_BENCH_NOPROF") != "1")      # (experiment: what the per-class HIP events cost)
     tn.profile_reset(bpc)
 
     def barrier():
