@@ -67,9 +67,12 @@ struct Graph {
 struct ProfClass { int64_t launches = 0; double ms = 0, bytes = 0, flops = 0; };
 struct Prof {
     bool on = false; ProfClass cls[TNQS_PROF_NCLASSES];
-    struct Pending { int cls; hipEvent_t a, b; };
+    struct Pending { int cls; hipEvent_t a, b; bool own_a; };
     std::vector<Pending> pending; std::vector<hipEvent_t> ev_free;
-    ~Prof() { for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); } for (auto e : ev_free) (void)hipEventDestroy(e); }
+    // A scope that directly follows another one (no host synchronisation in between) starts at the previous scope's end event instead of
+    // recording its own: half the events in the launch chains.  `chain` is cleared wherever the host waits for the stream.
+    hipEvent_t last_b = nullptr; bool chain = false; hipStream_t last_stream = nullptr;
+    ~Prof() { for (auto& p : pending) { if (p.own_a) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); } for (auto e : ev_free) (void)hipEventDestroy(e); }
 };
 
 // RCCL transport of the exchange step (sharding.cpp): communicator + the exchange buffer the library owns in that mode; shared by the

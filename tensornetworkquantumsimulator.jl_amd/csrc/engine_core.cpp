@@ -139,6 +139,7 @@ void sync(State* s) {
     HIPCHK(hipStreamSynchronize(s->stream));
     s->keepalive.clear(); s->keep_mark = 0;
     s->arena.off = 0;
+    if (s->prof) s->prof->chain = false;
 }
 
 void prof_collect(State* s) {
@@ -148,9 +149,9 @@ void prof_collect(State* s) {
     for (auto& p : P.pending) {
         float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b);
         P.cls[p.cls].ms += ms;
-        P.ev_free.push_back(p.a); P.ev_free.push_back(p.b);
     }
-    P.pending.clear();
+    for (auto& p : P.pending) { if (p.own_a) P.ev_free.push_back(p.a); P.ev_free.push_back(p.b); }
+    P.pending.clear(); P.last_b = nullptr; P.chain = false;
 }
 
 int64_t state_site_size(const State* s, int v) { return (int64_t)site_dims(s, v).n; }

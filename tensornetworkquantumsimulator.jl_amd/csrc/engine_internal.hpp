@@ -92,6 +92,7 @@ template <class X> const X* readback(State* s, const void* dsrc, size_t count) {
 inline void soft_sync(State* s) { s->keep_mark = s->keepalive.size(); }
 // after a raw hipStreamSynchronize(s->stream): release what soft_sync() marked (later entries belong to the phase in progress)
 inline void drained(State* s) {
+    s->prof->chain = false;                    // the host waited: the next profiled scope records its own start event
     if (s->keep_mark) { s->keepalive.erase(s->keepalive.begin(), s->keepalive.begin() + (std::ptrdiff_t)std::min(s->keep_mark, s->keepalive.size())); s->keep_mark = 0; }
 }
 void materialize_scale(State* s, const std::vector<int>& verts);
@@ -120,19 +121,23 @@ template <class Item> const Item* upload(State* s, const std::vector<Item>& v) {
 }
 
 struct ProfScope {
-    State* s; int cls; hipEvent_t a = nullptr, b = nullptr;
+    State* s; int cls; hipEvent_t a = nullptr, b = nullptr; bool own_a = true;
     ProfScope(State* st, int c, double bytes, double flops) : s(st), cls(c) {
         Prof& P = *s->prof;
         if (!P.on) return;
         P.cls[c].bytes += bytes; P.cls[c].flops += flops; P.cls[c].launches += 1;
         auto get = [&]() { hipEvent_t e; if (!P.ev_free.empty()) { e = P.ev_free.back(); P.ev_free.pop_back(); } else HIPCHK(hipEventCreate(&e)); return e; };
-        a = get(); b = get();
-        HIPCHK(hipEventRecord(a, s->stream));
+        static const bool nochain = envflag("TNQS_PROF_NOCHAIN");                       // A/B: every scope records its own start event
+        if (P.chain && P.last_b && P.last_stream == s->stream && !nochain) { a = P.last_b; own_a = false; }
+        else { a = get(); own_a = true; HIPCHK(hipEventRecord(a, s->stream)); }
+        b = get();
     }
     ~ProfScope() {
         if (!a) return;
+        Prof& P = *s->prof;
         (void)hipEventRecord(b, s->stream);
-        s->prof->pending.push_back({cls, a, b});
+        P.pending.push_back({cls, a, b, own_a});
+        P.last_b = b; P.chain = true; P.last_stream = s->stream;
     }
 };
 

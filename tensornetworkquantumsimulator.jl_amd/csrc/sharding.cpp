@@ -121,7 +121,7 @@ void exchange(State* s, size_t bytes_per_rank) {
     check_exchange(s, bytes_per_rank);
     if (s->comm) { rccl_allgather(s, bytes_per_rank); return; }       // RCCL: enqueued on the handle's stream, nothing to wait for here
     if (!s->ag_fn) throw Err(TNQS_ERR_COMM, "sharded handle without a transport (tnqs_set_sharding_rccl or tnqs_set_sharding)");
-    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
     int rc = s->ag_fn(s->ag_ctx, s->exch, (int64_t)bytes_per_rank, s->nranks);
     if (rc != 0) throw Err(TNQS_ERR_COMM, "all-gather callback failed");
 }
