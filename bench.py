@@ -74,6 +74,40 @@ def cpu_baseline(chi, seed=1234):
                       f"(oracle/cpu_layer.py), {m['threads']} threads; {m['seconds_per_layer']:.1f} s"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it (the driver's command shape): re-run this script under torch.distributed.run
+    with N ranks on this node, one per GPU (RCCL; TNQS_BENCH_BACKEND=gloo lets the ranks share one device -- a functional test of the
+    launch path only).  Fails loudly when fewer than N devices are visible: a silent 1-rank run would print a wrong n_gpus."""
+    import socket
+    import subprocess
+    import torch
+    backend = os.environ.get("TNQS_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < n:
+        raise SystemExit(f"bench.py: --gpus {n} needs {n} visible GPUs (one rank per GPU over RCCL), found {ndev}")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def profile_db(name):
+    """counters of a committed profile of THIS command (profiles/<name>) with their provenance: the build id stored in the file against the
+    build id of the tree this script runs from (profiles/buildid.py) -- the JSON line says when the two differ instead of quoting counters
+    of another build silently"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from buildid import build_id
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            doc = json.load(f)
+        have, now = doc.get("build_id"), build_id()
+        return doc["kernels"], {"file": "profiles/" + name, "profile_build_id": have, "this_build_id": now, "same_build": have == now}
+    except Exception:
+        return {}, None
+
+
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix (= vector) peak
 PEAK_HBM_GBS = 8000.0
 
@@ -90,9 +124,15 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)                     # `python bench.py --gpus N` without a launcher: become N ranks
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one rank per GPU over RCCL; TNQS_BENCH_BACKEND=gloo lets several ranks share one GPU (functional test of this script only)
@@ -175,18 +215,8 @@ def main():
                  "gate_modeprod": "tnqs::mfma_pair_kernel" + tf, "bp_fused": "tnqs::mfma_gram32_fused_kernel",
                  "bp_gram": "tnqs::mfma_gram32_kernel", "gate_gram": "tnqs::mfma_gram64_f64_kernel<%s, true>" % ("true" if m3 else "false"),
                  "gate_apply": "tnqs::mfma_rowgemm_kernel<2, 2, 2, %s>" % ("true" if m3 else "false"), "bp_pairgram": "tnqs::mfma_pair_gram2_kernel" + tf}
-    traffic_db = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
-            traffic_db = json.load(f)["kernels"]
-    except Exception:
-        pass
-    mfma_db = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r2_mfma_util.json")) as f:
-            mfma_db = json.load(f)["kernels"]
-    except Exception:
-        pass
+    traffic_db, traffic_src = profile_db(os.environ.get("TNQS_BENCH_PMC_PROFILE", "r3_pmc_traffic.json"))
+    mfma_db, mfma_src = profile_db(os.environ.get("TNQS_BENCH_MFMA_PROFILE", "r3_mfma_util.json"))
     dom = max(prof, key=lambda k: prof[k]["ms"])
     p = prof[dom]
     roofline = None
@@ -207,7 +237,9 @@ def main():
                   # real multiplications (csrc/mfma_common.hpp, CAcc32): the matrix cores execute 0.75 x the algorithmic count, so the
                   # algorithmic rate can exceed what `peak` allows a four-multiplication kernel; executed / peak is the matrix-core load
                   "complex_product": ("3M: three real MFMAs per complex update" if m3 else "4M"),
-                  "executed_over_peak": round((0.75 if m3 else 1.0) * tflops / PEAK_F32_TFLOPS, 4)}
+                  "executed_over_peak": round((0.75 if m3 else 1.0) * tflops / PEAK_F32_TFLOPS, 4),
+                  # `traffic`, `mfma_busy`, `mfma_executed_TFLOPs` are NOT measured in this run: they are read from the committed counter passes
+                  "from_profile": {"traffic": traffic_src, "mfma": mfma_src}}
         if ai < PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
             roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), **common}
         else:
@@ -232,7 +264,8 @@ def main():
                       "two_site_gates_per_step": n2, "bp_updates_per_step": updates, "bp_sweeps_per_step": sweeps,
                       "apply_kwargs": {"maxdim": chi, "cutoff": 1e-10, "normalize_tensors": True},
                       "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)", "parallelism": f"vertex-shard x{world}",
-                      "transport": (None if world == 1 else {"kind": type(bpc._shard).__name__, **({"note": transport_note} if transport_note else {}),
+                      "transport": (None if world == 1 else {"kind": type(bpc._shard).__name__, "nranks": world, "backend": dist.get_backend(),
+                                                             **({"note": transport_note} if transport_note else {}),
                                                              "allgathers_per_step": round(bpc._shard.n_exchanges / max(1, args.steps + args.warmup), 1),
                                                              "MB_gathered_per_step": round(bpc._shard.bytes_exchanged / max(1, args.steps + args.warmup) / 1e6, 2)})},
            "roofline": roofline, "phases": phases, "kernel_classes": classes}

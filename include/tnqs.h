@@ -200,6 +200,10 @@ int tnqs_sharding_stats(tnqs_handle h, int64_t* n_exchanges, int64_t* bytes_exch
 /* one-rank round trip through RCCL on `device` (unique id, communicator, in-place all-gather of `bytes` bytes, teardown): lets a
  * single-GPU box check that the transport loads and runs -- RCCL refuses two ranks on one GPU */
 int tnqs_rccl_selftest(int device, int64_t bytes);
+/* LOCAL preflight, no collective: librccl.so loads and exports every entry point the transport uses.  A host that is about to call
+ * tnqs_set_sharding_rccl on N ranks runs this (or tnqs_rccl_selftest) on every rank first and lets the ranks AGREE on the outcome over
+ * a channel it already trusts, so that no rank enters the communicator set-up while another one has already failed. */
+int tnqs_rccl_preflight(void);
 
 /* ---- profiling: HIP-event timing of the kernel classes on the handle's stream ---------------------------- */
 enum { TNQS_PROF_BP_MODEPROD = 0, TNQS_PROF_BP_GRAM = 1, TNQS_PROF_GATE_MODEPROD = 2, TNQS_PROF_GATE_GRAM = 3,

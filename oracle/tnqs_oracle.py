@@ -605,18 +605,23 @@ def update(bpc: BeliefPropagationCache, maxiter: Optional[int] = None, tolerance
 # simple update
 # --------------------------------------------------------------------------------------
 def pseudo_sqrt_inv_sqrt(m: np.ndarray, cutoff: float) -> Tuple[np.ndarray, np.ndarray]:
-    """utils.jl:18-27 with safe_eigen (:94-108): Hermitian eigen in f64, thresholded sqrt / inv sqrt,
-    result cast back to the message precision."""
+    """utils.jl:18-27 with safe_eigen (:94-108): Hermitian eigen in f64; D and U are cast back to the message precision FIRST
+    (`adapt(dtype)(D), adapt(dtype)(U)`, :102,:106), then the cutoff test, the square roots and the products Q D Q^dagger all run in the
+    message precision (:20-25).  For f32 messages an eigenvalue within an f32 ulp of the cutoff therefore lands where the reference puts it."""
     dt = m.dtype
-    m64 = m.astype(np.complex128)
-    w, q = np.linalg.eigh(m64, UPLO="U")
-    zero = (w == 0) | (np.abs(w) < cutoff)
+    rt = np.float32 if dt in (np.dtype(np.complex64), np.dtype(np.float32)) else np.float64
+    w64, q64 = np.linalg.eigh(m.astype(np.complex128), UPLO="U")
+    w, q = w64.astype(rt), q64.astype(dt if np.iscomplexobj(m) else (np.complex64 if rt is np.float32 else np.complex128))
+    cut = rt(cutoff)
+    zero = (w == 0) | (np.abs(w) < cut)
     if np.any(w[~zero] < 0):
         raise ValueError("DomainError: sqrt of negative message eigenvalue (reference assumes PSD messages)")
-    ws = np.where(zero, 0.0, np.sqrt(np.where(zero, 1.0, w)))
-    wi = np.where(zero, 0.0, 1.0 / np.where(zero, 1.0, ws))
+    ws = np.where(zero, rt(0), np.sqrt(np.where(zero, rt(1), w))).astype(rt)
+    wi = np.where(zero, rt(0), rt(1) / np.where(zero, rt(1), ws)).astype(rt)
     msqrt = (q * ws) @ q.conj().T
     minv = (q * wi) @ q.conj().T
+    if not np.iscomplexobj(m):
+        msqrt, minv = msqrt.real, minv.real
     return msqrt.astype(dt), minv.astype(dt)
 
 

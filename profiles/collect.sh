@@ -12,6 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 CMD=${2:-"python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline"}
 CMD1=${2:-"python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline"}
 MODE=${3:-all}
+export PROFILE_CMD="$CMD1"
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

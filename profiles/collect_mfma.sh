@@ -8,6 +8,7 @@ TAG=${1:-r2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 CMD=${2:-"python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline"}
 OUT=$ROOT/gpurun_out
+export PROFILE_CMD="$CMD"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/pmc_mfma

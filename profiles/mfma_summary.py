@@ -17,8 +17,12 @@ import csv
 import glob
 import json
 import re
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from buildid import build_id  # noqa: E402
 
 NCU, NSIMD, NXCD = 256, 4, 8
 
@@ -57,7 +61,8 @@ def main():
                   "raw_means": {c: mean(c) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32",
                                                      "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")}}
     doc = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 "
-                      "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE (one pass; profiles/collect_mfma.sh)",
+                      "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- " + os.environ.get("PROFILE_CMD", "<command not recorded>") + " (one pass; profiles/collect_mfma.sh)",
+           "build_id": build_id(),
            "formulas": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 * 4); mfma_flops = 512 * MOPS; full-batch launches only",
            "kernels": res}
     json.dump(doc, open(out, "w"), indent=1)

@@ -11,8 +11,12 @@ import csv
 import glob
 import json
 import re
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from buildid import build_id  # noqa: E402
 
 
 def load(d, counter):
@@ -44,8 +48,9 @@ def main():
         wr = 1024.0 * (sum(wb) / len(wb)) if wb else 0.0
         res[k] = {"launches_full_batch": max(len(fb), len(wb)), "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                   "hbm_bytes_per_launch": rd + wr}
-    doc = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python bench.py --steps 1 --warmup 1 "
-                      "--no-cpu-baseline (two separate passes, 20x20 chi=32 ComplexF32); profiles/collect.sh",
+    doc = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- "
+                      + os.environ.get("PROFILE_CMD", "<command not recorded>") + " (two separate passes; profiles/collect.sh)",
+           "build_id": build_id(),
            "corrections": "FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE x2 on gfx950 (calibration: permute_kernel copies 16384 KiB per launch of a "
                           "bulk site tensor, see 'calibration'); WRITE_SIZE x1.  Means over the full-batch launches (> 50 % of the kernel's maximum).",
            "calibration": cal, "kernels": res}

@@ -101,6 +101,7 @@ _SIGS = {
     "tnqs_set_sharding_rccl": ([H, C.c_int, C.c_int, _I32P, C.c_void_p, C.c_int64], C.c_int),
     "tnqs_sharding_stats": ([H, _I64P, _I64P], C.c_int),
     "tnqs_rccl_selftest": ([C.c_int, C.c_int64], C.c_int),
+    "tnqs_rccl_preflight": ([], C.c_int),
     "tnqs_profile_enable": ([H, C.c_int], C.c_int),
     "tnqs_profile_get": ([H, C.c_int, _I64P, _DP, _DP, _DP], C.c_int),
     "tnqs_profile_reset": ([H], C.c_int),

@@ -123,8 +123,9 @@ class BeliefPropagationCache:
         L.check(L.lib.tnqs_create(g.nv(), g.ne(), esp, edp, sdp, _DT[network.dtype], device, C.byref(h)))
         self._h = h
         self._shard_pending = None
+        dt = self.dtype
         for v in g.vertices:
-            self._set_tensor(v, network.tensors[v])
+            self._set_tensor(v, network.tensors[v], dt)
 
     @property
     def dtype(self):
@@ -141,8 +142,8 @@ class BeliefPropagationCache:
         nb = [self.graph.index[w] for w in self.graph.neighbors(v)]
         return list(reversed([-1] + nb))
 
-    def _set_tensor(self, v, t):
-        dt = self.dtype
+    def _set_tensor(self, v, t, dt=None):
+        dt = self.dtype if dt is None else dt          # (one FFI call; loops over the vertices read it once and pass it in)
         if np.iscomplexobj(t) and not np.issubdtype(dt, np.complexfloating):
             raise TypeError("cannot store a complex tensor in a cache whose element type is real (create it from a complex network)")
         t = np.ascontiguousarray(t, dtype=dt)
@@ -151,10 +152,10 @@ class BeliefPropagationCache:
         L.check(L.lib.tnqs_set_site_tensor(self._h, self.graph.index[v], t.ctypes.data_as(C.c_void_p), t.ndim,
                                            dims.ctypes.data_as(C.POINTER(C.c_int64)), rp))
 
-    def tensor(self, v) -> np.ndarray:
+    def tensor(self, v, dt=None) -> np.ndarray:
         g = self.graph
         shape = [self._site_dim(v)] + [self.bond_dim(v, w) for w in g.neighbors(v)]
-        out = np.empty(shape, dtype=self.dtype)
+        out = np.empty(shape, dtype=self.dtype if dt is None else dt)
         roles, rp = L.i32(self._roles(v))
         L.check(L.lib.tnqs_get_site_tensor(self._h, g.index[v], out.ctypes.data_as(C.c_void_p), out.ndim, rp))
         return out
@@ -182,12 +183,17 @@ class BeliefPropagationCache:
 
     def setmessage(self, e, m):
         a, b = e
-        m = np.asfortranarray(m, dtype=self.dtype)
+        dt = self.dtype
+        if np.iscomplexobj(m) and not np.issubdtype(dt, np.complexfloating):
+            # same rule as _set_tensor: a real cache does not silently drop imaginary parts
+            raise TypeError("cannot store a complex message in a cache whose element type is real (create it from a complex network)")
+        m = np.asfortranarray(m, dtype=dt)
         L.check(L.lib.tnqs_set_message(self._h, self.graph.index[a], self.graph.index[b], m.ctypes.data_as(C.c_void_p), m.shape[0]))
         return self
 
     def network(self) -> TensorNetworkState:
-        return TensorNetworkState(self.graph, {v: self.tensor(v) for v in self.graph.vertices})
+        dt = self.dtype
+        return TensorNetworkState(self.graph, {v: self.tensor(v, dt) for v in self.graph.vertices})
 
     def copy(self) -> "BeliefPropagationCache":
         h = L.H()

@@ -131,6 +131,7 @@ int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* owner,
             for (int v = 0; v < s->g->nv; ++v) if (owner[v] < 0 || owner[v] >= nranks) throw Err(TNQS_ERR_INVALID, "set_sharding: owner out of range");
             s->owner.assign(owner, owner + s->g->nv);
         } else s->owner.clear();
+        s->comm.reset();       // callback transport from here on: a communicator of an earlier tnqs_set_sharding_rccl must not keep serving exchange()
         s->rank = rank; s->nranks = nranks; s->ag_fn = fn; s->ag_ctx = ctx; s->exch = exch_dev; s->exch_bytes = (size_t)exch_bytes;
         if (nranks > 1) for (int v = 0; v < s->g->nv; ++v) if (!s->owns(v)) { s->site[v] = nullptr; s->sscale[v] = nullptr; }   // only owners hold site tensors
     });
@@ -144,6 +145,7 @@ int tnqs_sharding_stats(tnqs_handle h, int64_t* n_exchanges, int64_t* bytes_exch
     return guard([&] { State* s = S(h); if (n_exchanges) *n_exchanges = s->comm ? s->comm->n_exchanges : 0; if (bytes_exchanged) *bytes_exchanged = s->comm ? s->comm->bytes_exchanged : 0; });
 }
 int tnqs_rccl_selftest(int device, int64_t bytes) { return guard([&] { rccl_selftest(device, bytes); }); }
+int tnqs_rccl_preflight(void) { return guard([&] { rccl_preflight(); }); }
 
 int tnqs_profile_enable(tnqs_handle h, int on) { return guard([&] { S(h)->prof->on = on != 0; }); }
 int tnqs_profile_get(tnqs_handle h, int cls, int64_t* launches, double* ms, double* bytes, double* flops) {

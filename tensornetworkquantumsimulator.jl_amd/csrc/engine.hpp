@@ -149,5 +149,6 @@ void rccl_unique_id(void* out128);
 void set_sharding_rccl(State* s, int rank, int nranks, const int32_t* owner, const void* unique_id128, int64_t exch_bytes);
 void rccl_allgather(State* s, size_t bytes_per_rank);
 void rccl_selftest(int device, int64_t bytes);
+void rccl_preflight();
 
 }  // namespace tnqs

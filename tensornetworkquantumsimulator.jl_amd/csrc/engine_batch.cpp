@@ -191,7 +191,7 @@ template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, 
             // a condition number <= 1e7 whatever the rank of A (no failure branch: a rank-deficient theta is the normal case early in an evolution)
             ci.push_back(CholItem{ap + oG[i], ap + oL[i], ap + oW[i], n, reinterpret_cast<int*>(d_fail->p) + i, 0.0, 1e-14});      // Winv = (L^-1)^dagger = R^-1
             rj.push_back(JacobiItem{ap + oRr[i], nullptr, n, n, tall[i].sweeps_out});
-            wi.push_back(TallSvdItem{nullptr, nullptr, ap + oW[i], ap + oJ[i], ap + oRr[i], n, n});                                 // J = R^-1 (R J), f64
+            wi.push_back(TallSvdItem{nullptr, reinterpret_cast<int*>(d_fail->p) + i, ap + oW[i], ap + oJ[i], ap + oRr[i], n, n});   // J = R^-1 (R J), f64; G slot: the item's Cholesky failure flag (J := I then)
             gi.push_back(SmallGemmItem{tall[i].A, ap + oJ[i], ap + oT[i], m, n, n});
             cp.push_back(CopyItem{ap + oT[i], tall[i].A, (size_t)m * n * 8 / 16});
         }
@@ -213,7 +213,9 @@ template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, 
         std::vector<JacobiItem> pol;
         for (auto& j : tall) pol.push_back(JacobiItem{j.A, nullptr, j.m, j.n, nullptr});
         const JacobiItem* dp = upload(s, pol);
-        launch_jacobi<T>(s->stream, dp, (int)nt, 6, 0, mmax);
+        // (the kernel stops at convergence: 1-2 sweeps here; the cap is the ordinary one, so an item whose preprocessing did not help --
+        // failure flag above, or a J that came out far from unitary -- is still factorised to the same tolerance as everything else)
+        launch_jacobi<T>(s->stream, dp, (int)nt, 60, 0, mmax);
         s->stats.n_tall_svd += (int)nt;
     }
 }

@@ -107,7 +107,11 @@ static const size_t kMaxSpares = 8;
 HostArena acquire_arena() {
     HostArena ar{};
     { std::lock_guard<std::mutex> lk(g_recycle_mu); if (!g_spare_arenas.empty()) { ar = g_spare_arenas.back(); g_spare_arenas.pop_back(); ar.off = 0; } }
-    if (!ar.base) { ar.cap = size_t(32) << 20; HIPCHK(hipHostMalloc((void**)&ar.base, ar.cap, hipHostMallocDefault)); }
+    if (!ar.base) {
+        // TNQS_ARENA_KB: a small arena makes every phase overflow it (tests/test_gpu_toggles.py drives the overflow path that way)
+        static const size_t cap = [] { const char* e = std::getenv("TNQS_ARENA_KB"); return e ? std::max<size_t>(16, (size_t)std::atoll(e)) << 10 : size_t(32) << 20; }();
+        ar.cap = cap; HIPCHK(hipHostMalloc((void**)&ar.base, ar.cap, hipHostMallocDefault));
+    }
     return ar;
 }
 static hipStream_t acquire_stream(int device) {

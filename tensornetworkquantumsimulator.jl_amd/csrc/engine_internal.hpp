@@ -93,6 +93,7 @@ inline void soft_sync(State* s) { s->keep_mark = s->keepalive.size(); }
 // after a raw hipStreamSynchronize(s->stream): release what soft_sync() marked (later entries belong to the phase in progress)
 inline void drained(State* s) {
     s->prof->chain = false;                    // the host waited: the next profiled scope records its own start event
+    s->arena.off = 0;                          // every staged upload has been copied; staged read-backs are consumed by the caller before its next upload
     if (s->keep_mark) { s->keepalive.erase(s->keepalive.begin(), s->keepalive.begin() + (std::ptrdiff_t)std::min(s->keep_mark, s->keepalive.size())); s->keep_mark = 0; }
 }
 void materialize_scale(State* s, const std::vector<int>& verts);
@@ -111,7 +112,10 @@ template <class Item> const Item* upload(State* s, const std::vector<Item>& v) {
     if (!ar.base) ar = acquire_arena();
     size_t aligned = (bytes + 255) & ~size_t(255);
     if (aligned > ar.cap) throw Err(TNQS_ERR_UNSUPPORTED, "descriptor batch too large");
-    if (ar.off + aligned > ar.cap) sync(s);
+    // arena full: wait for the copies that still read it and start over.  ONLY the host staging is recycled here -- the device buffers of
+    // earlier uploads (descriptor arrays whose kernels are not launched yet) stay in the keep-alive list: a sync(s) at this point would hand
+    // them back to the pool in the middle of a phase and the next dalloc of the same size class could alias them
+    if (ar.off + aligned > ar.cap) { HIPCHK(hipStreamSynchronize(s->stream)); ar.off = 0; s->prof->chain = false; }
     char* h = ar.base + ar.off; ar.off += aligned;
     std::memcpy(h, v.data(), bytes);
     Buf b = dalloc(s, bytes);

@@ -942,9 +942,12 @@ __global__ __launch_bounds__(256) void env_finish_kernel(const EnvFinishItem* __
         double l = 0;       // Rayleigh quotient v_j^dagger H v_j = Re(v_j^dagger a_j)
         for (int i = 0; i < n; ++i) { cx<double> v = V[i + n * j], a = A[i + n * j]; l += v.re * a.re + v.im * a.im; }
         lam[j] = l;
-        const bool zero = (l == 0) || (fabs(l) < it.cutoff);
+        // the reference casts the eigenvalues back to the message precision BEFORE the cutoff test (safe_eigen, src/utils.jl:100-107, then
+        // `abs(x) < cutoff` on the Float32 value, :21-22): an eigenvalue within an f32 ulp of the cutoff must land on the same side here
+        const double lt = (double)(T)l;
+        const bool zero = (lt == 0) || (fabs(lt) < it.cutoff);
         if (zero) s_full = 0;
-        else if (l < 0) s_err = 1;        // Julia: sqrt(negative) -> DomainError (src/utils.jl:21)
+        else if (lt < 0) s_err = 1;       // Julia: sqrt(negative) -> DomainError (src/utils.jl:21)
     }
     __syncthreads();
     cx<T>* ms = reinterpret_cast<cx<T>*>(it.msqrt);
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(256) void env_finish_kernel(const EnvFinishItem* __
         cx<double> s1 = cmake<double>(0, 0), s2 = cmake<double>(0, 0);
         for (int j = 0; j < n; ++j) {
             double lj = lam[j];
-            if ((lj == 0) || (fabs(lj) < it.cutoff) || lj < 0) continue;
+            { const double lt = (double)(T)lj; if ((lt == 0) || (fabs(lt) < it.cutoff) || lt < 0) continue; }
             cx<double> vi = V[i + n * j], vl = V[l + n * j];
             cx<double> o = cmake<double>(vi.re * vl.re + vi.im * vl.im, vi.im * vl.re - vi.re * vl.im);  // vi conj(vl)
             double sq = sqrt(lj);

@@ -265,6 +265,19 @@ __global__ __launch_bounds__(256) void tall_w_kernel(const TallSvdItem* __restri
     const cf* __restrict__ Rrot = reinterpret_cast<const cf*>(it.Rrot);
     cf* __restrict__ W = reinterpret_cast<cf*>(it.R0);                     // and the output in the R0 slot
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    // a Cholesky pivot of this item collapsed in spite of the shift (flag in the G slot of this launch): R is not a usable preconditioner,
+    // so J := I -- A stays as it is and the sweeps on A that follow (svd_batch, full sweep cap) do the whole factorisation themselves
+    const int* fail = reinterpret_cast<const int*>(it.G);
+    if (fail && *fail) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = 32 * I + 2 * tx + p, c = 32 * J + 2 * ty + q;
+                if (i < n && c < n) { cf v; v.re = (i == c) ? 1.f : 0.f; v.im = 0.f; W[i + (size_t)n * c] = v; }
+            }
+        return;
+    }
     double cr[2][2] = {{0, 0}, {0, 0}}, ci[2][2] = {{0, 0}, {0, 0}};
     for (int j0 = 32 * I; j0 < n; j0 += 32) {                               // Rinv is upper triangular: rows 32 I.. only see columns >= 32 I
         for (int e = tid; e < 1024; e += 256) {

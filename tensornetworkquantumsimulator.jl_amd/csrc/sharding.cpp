@@ -68,16 +68,23 @@ void set_sharding_rccl(State* s, int rank, int nranks, const int32_t* owner, con
     if (nranks > 1 && !owner) throw Err(TNQS_ERR_INVALID, "set_sharding_rccl: vertex_owner is required for nranks > 1");
     if (owner) for (int v = 0; v < s->g->nv; ++v) if (owner[v] < 0 || owner[v] >= nranks) throw Err(TNQS_ERR_INVALID, "set_sharding_rccl: owner out of range");
     hipchk(hipSetDevice(s->device), "hipSetDevice");
+    // everything that can fail locally happens BEFORE the collective communicator set-up: a rank that threw after ncclCommInitRank would
+    // leave its peers joined to a communicator that is about to be destroyed
+    RcclApi& api = rccl();
     auto c = std::make_shared<RcclComm>();
     c->device = s->device;
-    NcclId id; std::memcpy(&id, unique_id128, sizeof id);
-    ncclchk(rccl().comm_init_rank(&c->comm, nranks, id, rank), "ncclCommInitRank");
     hipchk(hipMalloc(&c->exch_owned, (size_t)exch_bytes), "hipMalloc (exchange buffer)");
+    std::vector<int> owner_copy; if (owner) owner_copy.assign(owner, owner + s->g->nv);
+    NcclId id; std::memcpy(&id, unique_id128, sizeof id);
+    ncclchk(api.comm_init_rank(&c->comm, nranks, id, rank), "ncclCommInitRank");
     s->comm = c;
     s->rank = rank; s->nranks = nranks; s->ag_fn = nullptr; s->ag_ctx = nullptr; s->exch = c->exch_owned; s->exch_bytes = (size_t)exch_bytes;
-    if (owner) s->owner.assign(owner, owner + s->g->nv); else s->owner.clear();
+    s->owner.swap(owner_copy);
     if (nranks > 1) for (int v = 0; v < s->g->nv; ++v) if (!s->owns(v)) { s->site[v] = nullptr; s->sscale[v] = nullptr; }
 }
+
+// local preflight of the RCCL transport, no collective involved: the library loads and exports what is needed (throws otherwise)
+void rccl_preflight() { (void)rccl(); }
 
 // in-place all-gather on the handle's stream: rank r's block sits at exch + r * bytes_per_rank
 void rccl_allgather(State* s, size_t bytes_per_rank) {

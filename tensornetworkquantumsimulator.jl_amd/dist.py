@@ -97,10 +97,39 @@ def _prefer_torch_rccl():
         pass
 
 
+def rccl_preflight(selftest_device: Optional[int] = None) -> Optional[str]:
+    """LOCAL check of the in-library RCCL transport, no collective: librccl.so loads and exports what is needed (tnqs_rccl_preflight) and,
+    when a device is named, a one-rank communicator round trip runs on it (tnqs_rccl_selftest).  Returns None when fine, else the reason."""
+    _prefer_torch_rccl()
+    try:
+        L.check(L.lib.tnqs_rccl_preflight())
+        if selftest_device is not None:
+            L.check(L.lib.tnqs_rccl_selftest(int(selftest_device), C.c_int64(1 << 16)))
+    except Exception as e:                                      # noqa: BLE001 -- any failure means "no in-library RCCL in this process"
+        return f"{type(e).__name__}: {e}"
+    return None
+
+
+def ranks_agree(ok: bool, group=None, device: Optional[int] = None) -> bool:
+    """all ranks learn whether EVERY rank said ok (all_reduce MIN over the process group the host already has)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(ok)
+    on_gpu = dist.get_backend(group) == "nccl"
+    if on_gpu and device is not None:
+        torch.cuda.set_device(device)                           # collectives of an nccl group run on the current device
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=(f"cuda:{torch.cuda.current_device()}" if on_gpu else "cpu"))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
+
+
 class RcclSharding:
     """transport = RCCL inside the library (tnqs_set_sharding_rccl): nothing of the data path runs in Python.  Only the 128-byte
     ncclUniqueId travels through the host once: rank 0 creates it, `broadcast` hands it to the other ranks (default:
-    torch.distributed.broadcast_object_list on whatever backend the process group has -- gloo is fine, it is not the data path)."""
+    torch.distributed.broadcast_object_list on whatever backend the process group has -- gloo is fine, it is not the data path).
+    No rank may fail ALONE before the collective communicator set-up (its peers would wait for it forever): every rank runs the local
+    preflight first and the ranks agree on the outcome; rank 0 broadcasts an error marker instead of the id if it cannot create one."""
 
     def __init__(self, bpc, rank: int, world: int, owner: List[int], exch_bytes: int, group=None, broadcast=None):
         import weakref
@@ -108,16 +137,28 @@ class RcclSharding:
         self.rank, self.world, self.owner, self.group = rank, world, list(owner), group
         self._ref = weakref.ref(bpc)              # any live handle of the family will do for the counters (core.copy re-attaches)
         self._last = (0, 0)
+        why = rccl_preflight()
+        if world > 1 and broadcast is None:
+            if not ranks_agree(why is None, group=group, device=bpc.device):
+                raise L.TnqsError("RCCL transport unavailable on at least one rank" + (f" (this rank: {why})" if why else ""))
+        elif why is not None:
+            raise L.TnqsError("RCCL transport unavailable: " + why)
         uid = C.create_string_buffer(128)
+        payload = [b""]
         if rank == 0:
-            L.check(L.lib.tnqs_rccl_unique_id(uid))
-        payload = [bytes(uid.raw)]
+            try:
+                L.check(L.lib.tnqs_rccl_unique_id(uid))
+                payload = [bytes(uid.raw)]
+            except Exception as e:                              # noqa: BLE001 -- the other ranks must hear about it, not wait for an id
+                payload = [("ERR " + repr(e)).encode()]
         if world > 1:
             if broadcast is not None:
                 payload = [broadcast(payload[0])]
             else:
                 import torch.distributed as dist
                 dist.broadcast_object_list(payload, src=0, group=group)
+        if len(payload[0]) != 128:
+            raise L.TnqsError("RCCL: rank 0 could not create the communicator id: " + payload[0].decode("utf-8", "replace"))
         self.uid = C.create_string_buffer(payload[0], 128)
         ow, owp = L.i32(owner)
         L.check(L.lib.tnqs_set_sharding_rccl(bpc._h, rank, world, owp, self.uid, C.c_int64(int(exch_bytes))))

@@ -1,0 +1,55 @@
+"""bench.py's launch contract: `python bench.py --gpus N` with no launcher around it (the driver's command shape) must become N ranks and
+print "n_gpus": N -- or fail loudly; it must never run one rank and print n_gpus 1."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    return env
+
+
+def test_gpus_flag_without_enough_devices_fails_loudly():
+    """CPU box (or any box with fewer than 64 GPUs): the request cannot be served, the script says so and exits non-zero without a JSON line"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=clean_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs 64 visible GPUs" in r.stderr
+    assert '"n_gpus"' not in r.stdout
+
+
+def test_world_size_must_agree_with_the_gpus_flag():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=clean_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.gpu
+def test_gpus_2_spawns_two_ranks_and_reports_them():
+    """functional test of the launch path on a one-GPU box: gloo rendezvous, the two ranks share the device (callback transport).  With
+    two real GPUs the same command without TNQS_BENCH_BACKEND runs one rank per GPU on the library's RCCL transport."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--L", "4", "--chi", "4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=clean_env(TNQS_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["transport"]["nranks"] == 2
+    assert out["config"]["transport"]["allgathers_per_step"] > 0 and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_carries_roofline_and_no_transport():
+    r = subprocess.run([sys.executable, BENCH, "--L", "4", "--chi", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=clean_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["transport"] is None and "kernel_classes" in out

@@ -1,5 +1,5 @@
 """GPU: the HIP path (through the C ABI) against the committed golden fixtures (tests/golden/*.npz).  These tests do
-not need the oracle at run time.  Tolerances: complex128 1e-8 (<Z>, spectra, truncation errors), complex64 3e-4 / truncation errors 2e-3 relative."""
+not need the oracle at run time.  Tolerances: complex128 1e-8 (<Z>, spectra, truncation errors), complex64 1e-5 per layer (the north star's bound on expectation values) / truncation errors 2e-3 relative."""
 import numpy as np
 import pytest
 
@@ -41,7 +41,7 @@ def test_apply_gates_matches_golden(name):
         assert info["n_updates"] == len(meta["groups"]) + 1
         assert np.array_equal(np.array([bpc.bond_dim(a, b) for (a, b) in g.edges]), z["bond_dims"][l]), l
         assert (np.max(np.abs(errs - z["errs"][l])) < 1e-9) if c128 else c64_errs_close(errs, z["errs"][l]), l
-        scale = (l + 1) * (1e-8 if c128 else 3e-4)
+        scale = (l + 1) * (1e-8 if c128 else 1e-5)
         ez = tn.expect_all(bpc, "Z")
         assert np.max(np.abs(ez - z["expZ"][l])) < scale, (l, np.max(np.abs(ez - z["expZ"][l])))
         sp = []
@@ -64,7 +64,7 @@ def test_bp_update_matches_golden(name):
     meta, z = load(name)
     g = tn.NamedGraph(meta["vertices"], meta["edges"])
     psi = tn.TensorNetworkState(g, {v: z[f"psi_{i}"] for i, v in enumerate(g.vertices)})
-    tol = 1e-10 if meta["dtype"] == "complex128" else 1e-4
+    tol = 1e-10 if meta["dtype"] == "complex128" else 1e-5
     bpc = tn.BeliefPropagationCache(psi)
     for ns in (1, 2, 5):
         out = tn.update(bpc, maxiter=ns, tolerance=None, edge_sequence=meta["seq"])

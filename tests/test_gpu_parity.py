@@ -1,6 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
 Tolerances: complex128 -> 1e-9 relative on gauge-invariant quantities (messages, S, truncerr, <Z>, state vector);
-complex64 -> 2e-4 on messages / S / <Z>, 2e-3 relative (floor 3e-7) on truncation errors.  Index work (leg permutations,
+complex64 -> 1e-5 on messages / S / <Z> (BASELINE.json north star), 2e-3 relative (floor 3e-7) on truncation errors.  Index work (leg permutations,
 bond dimensions, scheduling counts) is exact."""
 import itertools
 import math
@@ -16,7 +16,7 @@ from helpers import (to_oracle_graph, to_oracle_state, oracle_cache_from_device,
 pytestmark = pytest.mark.gpu
 
 Z = np.diag([1.0, -1.0]).astype(complex)
-TOL = {np.dtype(np.complex128): 1e-9, np.dtype(np.complex64): 2e-4}
+TOL = {np.dtype(np.complex128): 1e-9, np.dtype(np.complex64): 1e-5}      # c64: the north star's bound on expectation values
 
 
 def tight(dtype):
@@ -432,7 +432,7 @@ def test_deferred_normalisation_is_invisible_to_callers(dtype):
 def test_bp_scalars_and_rescale_match_oracle(dtype, lattice):
     """8f N2: vertex / edge scalars, partition function (abstract...:22-28, 289-304) and rescale! (beliefpropagationcache.jl:82-140)"""
     g = {"grid3x3": lambda: tn.named_grid((3, 3)), "comb33": lambda: tn.named_comb_tree((3, 3)), "hh11": lambda: tn.heavy_hexagonal_lattice(1, 1)}[lattice]()
-    tol = 5e-5 if dtype == np.complex64 else 1e-10
+    tol = 1e-5 if dtype == np.complex64 else 1e-10
     psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=3, seed=9)
     seq = tn.forest_cover_edge_sequence(g)
     kw = dict(maxiter=6, tolerance=None, edge_sequence=seq)
@@ -468,7 +468,7 @@ def test_bp_scalars_and_rescale_match_oracle(dtype, lattice):
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_multi_site_expect_matches_oracle(dtype):
     """8f N1: ("ZX", [v, w]) on the Steiner tree of the support with the cache's messages on its boundary (expect.jl:59-82)"""
-    tol = 1e-4 if dtype == np.complex64 else 1e-10
+    tol = 1e-5 if dtype == np.complex64 else 1e-10
     X = np.array([[0, 1], [1, 0.0]])
     cases = [(tn.named_grid((3, 3)), [((1, 1), (1, 2)), ((2, 2), (3, 2)), ((1, 1), (1, 3)), ((2, 1), (2, 3))]),
              (tn.named_comb_tree((3, 3)), [((1, 1), (1, 2)), ((1, 2), (3, 1)), ((1, 3), (3, 3))]),
@@ -506,7 +506,7 @@ def test_multi_site_expect_matches_oracle(dtype):
 def test_symmetric_gauge_matches_oracle(dtype, lattice):
     """8f N3: symmetric_gauge (symmetric_gauge.jl:1-62): same bond spectra S as the oracle, state unchanged, diag(S) a BP fixed point"""
     g = {"grid3x3": lambda: tn.named_grid((3, 3)), "comb33": lambda: tn.named_comb_tree((3, 3)), "hh11": lambda: tn.heavy_hexagonal_lattice(1, 1)}[lattice]()
-    tol = 2e-4 if dtype == np.complex64 else 1e-8
+    tol = 1e-5 if dtype == np.complex64 else 1e-8
     psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=3, seed=17)
     kw = dict(maxiter=60, tolerance=None, edge_sequence=tn.forest_cover_edge_sequence(g))
     bpc = tn.update(tn.BeliefPropagationCache(psi), **kw)
@@ -613,7 +613,7 @@ def test_random_graphs_random_circuits_match_oracle(seed, order):
     rng = np.random.default_rng(1000 + seed)
     kind = ["tree", "ring", "ladder", "random"][seed % 4]
     dtype = np.complex128 if (seed // 4) % 2 == 0 else np.complex64
-    tol = 1e-9 if dtype == np.complex128 else 5e-4
+    tol = 1e-9 if dtype == np.complex128 else 1e-5
     g = _random_graph(rng, kind)
     chi0 = int(rng.integers(1, 4))
     psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=chi0, seed=seed)
@@ -916,7 +916,7 @@ def test_default_update_is_exact_on_trees(dtype, lattice):
         t = sv.reshape((2,) * len(vs)); ax = tuple(k for k in range(len(vs)) if k != i)
         p = np.sum(np.abs(t) ** 2, axis=ax); zex = (p[0] - p[1]) / nrm
         assert abs(z1 - zm) < tol and abs(z1 - zex) < tol, (lattice, v, z1, zm, zex)
-    assert abs(tn.partitionfunction(one) / nrm - 1) < (2e-4 if dtype == np.complex64 else 1e-10)
+    assert abs(tn.partitionfunction(one) / nrm - 1) < (2e-5 if dtype == np.complex64 else 1e-10)
 
 
 @pytest.mark.parametrize("eltype", [np.float32, np.float64, np.complex64, np.complex128])

@@ -45,7 +45,7 @@ def test_alternative_routes_match_the_default(switch):
     """every documented switch selects an alternative route of the same algorithm: all-eigen factorisation instead
     of Cholesky, Gram-eigen instead of the small-SVD route, global-memory Jacobi, single-leg mode products, per-message BP products,
     unfused Grams, generic apply, no MFMA kernels at all, eager normalisation, no shared partial products in BP.  Same bond dimensions; truncation errors and <Z> to f32
-    rounding of the whole layer (bounds 2e-3 relative / 5e-5; the switch must at least run -- an intermediate version of the per-site Cholesky
+    rounding of the whole layer (bounds 2e-3 relative / 1e-5; the switch must at least run -- an intermediate version of the per-site Cholesky
     fallback crashed under TNQS_NO_CHOL without any test noticing)."""
     ref, alt = run_worker({}), run_worker({switch: "1"})
     for name in ("Rzz", "CNOT", "CPHASE", "SWAP", "Rxxyyzz", "cubic"):       # "cubic": degree-6 sites, two layers
@@ -55,7 +55,19 @@ def test_alternative_routes_match_the_default(switch):
         # relative: an absolute 2e-5 here once hid a 6 % error in truncation errors of 1e-4 (the f32 underflow of the global-memory Jacobi
         # kernel, DESIGN.md 4.2, ran under TNQS_JACOBI_GLOBAL at every size and this test stayed green)
         assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7), (name, float(np.max(np.abs(ea - eb))))
-        assert np.max(np.abs(np.array(a["z"]) - np.array(b["z"]))) < 5e-5, name
+        assert np.max(np.abs(np.array(a["z"]) - np.array(b["z"]))) < 1e-5, name
+
+
+def test_staging_arena_overflow_keeps_descriptors_alive():
+    """the pinned staging arena of descriptor uploads wraps around in the middle of a phase (TNQS_ARENA_KB=48: a few uploads fill it): only the
+    HOST staging may be recycled at that point -- the device copies of descriptor arrays whose kernels are not launched yet must stay
+    allocated (round-2 advisor finding: the overflow path released them, and the next allocation of the same size class could alias them).
+    Bit-identical results to the default run, since nothing of the arithmetic changes."""
+    ref, alt = run_worker({}), run_worker({"TNQS_ARENA_KB": "48"})
+    for name in ("Rzz", "CNOT", "CPHASE", "SWAP", "Rxxyyzz", "cubic"):
+        assert ref[name]["dims"] == alt[name]["dims"], name
+        assert ref[name]["errs"] == alt[name]["errs"], name
+        assert ref[name]["z"] == alt[name]["z"], name
 
 
 def test_torch_can_be_imported_after_the_library():
@@ -91,7 +103,7 @@ def test_chi16_plane_kernels_match_the_single_leg_route():
     assert on["dims"] == off["dims"]
     ea, eb = np.array(on["errs"]), np.array(off["errs"])
     assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7)
-    assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 5e-5
+    assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-5
 
 
 def test_chi64_kernels_match_the_generic_route_on_a_physical_evolution():

@@ -212,3 +212,30 @@ def test_htse_known_answer():
     assert [round(b, 6) for (b, _, _) in res] == [0.1, 0.2, 0.3, 0.4, 0.5]
     for b, f, f4 in res:
         assert abs(f - f4) < 0.01 * b ** 5
+
+
+def test_pseudo_sqrt_casts_eigen_factors_to_the_message_precision_first():
+    """src/utils.jl:100-107 (`safe_eigen`: D, U back to Float32) then :20-25 (cutoff test, sqrt, Q D Q^dagger in Float32): an eigenvalue
+    that is below the cutoff in f64 but rounds ONTO it in f32 is kept by the reference (`abs(x) < cutoff` is false), one a little lower
+    is dropped.  Everything downstream of the test runs in f32: the result has f32-level, not f64-level, residuals."""
+    rng = np.random.default_rng(5)
+    n = 6
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    cut = float(np.float32(10 * np.finfo(np.float32).eps))
+    for lam_small, kept in ((cut * (1 - 2e-8), True), (cut * (1 - 3e-7), False)):
+        assert (np.float32(lam_small) < np.float32(cut)) == (not kept)
+        w = np.array([1.0, 0.5, 0.2, 0.1, 0.01, lam_small])
+        # the test matrix is built in f64 and handed over as complex64: the eigenvalues move by ~1e-8 -- far more than the 2e-8 relative
+        # margin around the cutoff -- so the expected side is read off the f32-rounded eigenvalue of the ROUNDED matrix
+        m = ((q * w) @ q.conj().T).astype(np.complex64)
+        w32 = np.linalg.eigvalsh(m.astype(np.complex128)).astype(np.float32)
+        expect_rank = int(np.count_nonzero(~((w32 == 0) | (np.abs(w32) < np.float32(cut)))))
+        ms, mi = o.pseudo_sqrt_inv_sqrt(m, cut)
+        assert ms.dtype == np.complex64 and mi.dtype == np.complex64
+        proj = ms.astype(np.complex128) @ mi.astype(np.complex128)
+        assert int(round(np.trace(proj).real)) == expect_rank
+        w64, q64 = np.linalg.eigh(m.astype(np.complex128))
+        keep = ~((w64.astype(np.float32) == 0) | (np.abs(w64.astype(np.float32)) < np.float32(cut)))
+        m_kept = (q64[:, keep] * w64[keep]) @ q64[:, keep].conj().T
+        res = np.linalg.norm(ms.astype(np.complex128) @ ms.astype(np.complex128) - m_kept)
+        assert 1e-9 < res < 1e-5          # f32 arithmetic throughout (products of f32-rounded Q and sqrt(D)), not f64 cast at the end
