@@ -164,6 +164,12 @@ int tnqs_expect_region(tnqs_handle h, int n_region, const int32_t* region_verts,
 int tnqs_vertex_scalars(tnqs_handle h, double* out_vertex);
 int tnqs_edge_scalars(tnqs_handle h, double* out_edge);
 int tnqs_rescale(tnqs_handle h);
+/* the two halves on their own, as the abstract cache interface has them (abstractbeliefpropagationcache.jl:11-20,306-316): generic callers
+ * invoke either one.  tnqs_rescale_messages: rescale_messages!(bpc, edges) (beliefpropagationcache.jl:127-140) on the listed edges
+ * (edge_u[i], edge_v[i]), both directions each; edge_u == NULL: every edge.  tnqs_rescale_vertices: rescale_vertices!(bpc, vertices)
+ * (beliefpropagationcache.jl:82-101) with the vertex scalars under the CURRENT messages; vertices == NULL: every vertex. */
+int tnqs_rescale_messages(tnqs_handle h, int n_edges, const int32_t* edge_u, const int32_t* edge_v);
+int tnqs_rescale_vertices(tnqs_handle h, int n_vertices, const int32_t* vertices);
 
 /* ---- symmetric (Vidal) gauge (src/symmetric_gauge.jl:1-62) ---------------------------------
  * per edge: psi_src <- psi_src X^-1/2 U S^1/2, psi_dst <- psi_dst Y^-1/2 V S^1/2 with U S V = svd(X^1/2 (Y^1/2)^T), X, Y the two

@@ -1,0 +1,445 @@
+# TNQSHipExt.jl -- Julia shim of libtnqs_hip.so (C ABI: include/tnqs.h): the drop-in cache type for TensorNetworkQuantumSimulator.jl's
+# BP-gauged gate-application path.
+#
+# STATUS: UNTESTED.  The build image of this repository has no Julia toolchain (`julia` absent, no depot, no network), so this file has
+# never been parsed by Julia.  It is written against the reference sources v0.4.4; every method it adds is either required by the abstract
+# cache interface (src/MessagePassing/abstractbeliefpropagationcache.jl:7-37) or typed on the concrete `BeliefPropagationCache` in the
+# reference and therefore needs a twin for the new type (apply_gates src/Apply/apply_gates.jl:29-39,46-98; update :257-259 through
+# set_default_kwargs beliefpropagationcache.jl:63-72; expect src/expect.jl:54-82; truncate src/truncate.jl:12-38).  The identical call
+# sequence into the library is exercised by the Python ctypes host (tensornetworkquantumsimulator.jl_amd/core.py), which the parity tests
+# drive, and by examples/c_driver.c.
+#
+# Use:   ENV["TNQS_HIP_LIB"] = "/path/to/libtnqs_hip.so";  using TNQSHipExt
+#        c = HipBeliefPropagationCache(psi)                 # or  Adapt.adapt(HipStorage(), BeliefPropagationCache(psi))
+#        c, errs = apply_gates(layer, c; apply_kwargs = (; maxdim = 32, cutoff = 1e-10))
+module TNQSHipExt
+
+using TensorNetworkQuantumSimulator
+const TN = TensorNetworkQuantumSimulator
+using ITensors: ITensors, ITensor, Index, inds, dim, array, itensor, prime, op
+using NamedGraphs: NamedGraphs, NamedEdge, vertices, edges, src, dst, neighbors
+using Graphs: Graphs
+using Dictionaries: Dictionaries, Dictionary
+import Adapt
+
+export HipBeliefPropagationCache, HipStorage, shard!
+
+const LIB = get(ENV, "TNQS_HIP_LIB", "libtnqs_hip.so")
+
+# status codes of include/tnqs.h: 0 ok; -4 = TNQS_ERR_NUMERIC (DomainError in the reference, src/utils.jl:21); the rest mirror error(...)
+function check(rc)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:tnqs_last_error, LIB), Cstring, ()))
+    rc == -4 ? throw(DomainError(msg)) : error(msg)
+end
+
+# tnqs_bp_opts / tnqs_apply_opts (include/tnqs.h:52-71), field for field
+struct BpOpts
+    maxiter::Cint
+    tolerance::Cdouble
+    normalize::Cint
+    n_sequence::Cint
+    seq_src::Ptr{Int32}
+    seq_dst::Ptr{Int32}
+end
+struct ApplyOpts
+    maxdim::Cint
+    cutoff::Cdouble
+    normalize_tensors::Cint
+    sqrt_cutoff::Cdouble
+    update_cache::Cint
+end
+
+mutable struct HipBeliefPropagationCache{V} <: TN.AbstractBeliefPropagationCache{V}
+    handle::Ptr{Cvoid}
+    g::Any                               # NamedGraph{V}
+    vid::Dict{V, Int32}                  # vertex -> 0-based id (order of vertices(g)) = the ids tnqs_create was given
+    siteinds::Any                        # Dictionary{V, Vector{<:Index}} of the state (tensornetworkstate.jl:14)
+    linkinds::Dict{Tuple{Int32, Int32}, Index}   # (min id, max id) -> link Index; re-created when a gate changes the bond dimension
+    function HipBeliefPropagationCache{V}(h, g, vid, s, l) where {V}
+        c = new{V}(h, g, vid, s, l)
+        finalizer(x -> ccall((:tnqs_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), c)
+        return c
+    end
+end
+
+const DTYPE_CODE = Dict(ComplexF32 => 0, ComplexF64 => 1, Float32 => 2, Float64 => 3)     # enum of include/tnqs.h:39
+const DTYPE_OF = (ComplexF32, ComplexF64, Float32, Float64)
+
+# ---- construction: BeliefPropagationCache(psi) -> device (beliefpropagationcache.jl:27-31) ----------------------------------------------
+function HipBeliefPropagationCache(ψ::TN.TensorNetworkState; device::Integer = 0)
+    g = TN.graph(ψ)
+    vs = collect(vertices(g))
+    V = eltype(vs)
+    vid = Dict{V, Int32}(v => Int32(i - 1) for (i, v) in enumerate(vs))
+    es = collect(edges(g))
+    esrc = Int32[vid[src(e)] for e in es]
+    edst = Int32[vid[dst(e)] for e in es]
+    sd = Int32[dim(only(TN.siteinds(ψ, v))) for v in vs]
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:tnqs_create, LIB), Cint, (Cint, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Cint, Cint, Ptr{Ptr{Cvoid}}),
+                length(vs), length(es), esrc, edst, sd, DTYPE_CODE[TN.scalartype(ψ)], device, h))
+    c = HipBeliefPropagationCache{V}(h[], g, vid, TN.siteinds(ψ), Dict{Tuple{Int32, Int32}, Index}())
+    for v in vs
+        upload_site!(c, ψ, v)
+    end
+    return c
+end
+
+# setindex_preserve! (abstracttensornetwork.jl:40-43): the ITensor goes over column-major in its own leg order; leg_role names each leg
+# (-1 = site leg, otherwise the 0-based id of the neighbour it connects to) and the library permutes into its canonical layout (bit-exact)
+function upload_site!(c::HipBeliefPropagationCache, ψ, v)
+    t = ψ[v]
+    is = collect(inds(t))
+    sv = TN.siteinds(ψ, v)
+    role = Int32[]
+    for i in is
+        if i in sv
+            push!(role, Int32(-1))
+        else
+            w = only(filter(w -> i in inds(ψ[w]), collect(neighbors(c.g, v))))
+            push!(role, c.vid[w])
+            c.linkinds[linkkey(c, v, w)] = i
+        end
+    end
+    T = TN.scalartype(c)
+    a = Array{T}(array(t, is...))
+    dims = Int64[size(a)...]
+    GC.@preserve a dims role check(ccall((:tnqs_set_site_tensor, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Int32}), c.handle, c.vid[v], a, ndims(a), dims, role))
+    return c
+end
+
+linkkey(c, u, v) = (min(c.vid[u], c.vid[v]), max(c.vid[u], c.vid[v]))
+
+# Base.copy (beliefpropagationcache.jl:35-37): O(V + E) on the device (buffers are shared and never mutated in place)
+function Base.copy(c::HipBeliefPropagationCache{V}) where {V}
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:tnqs_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), c.handle, h))
+    return HipBeliefPropagationCache{V}(h[], c.g, c.vid, c.siteinds, copy(c.linkinds))
+end
+
+# ---- the abstract cache interface (abstractbeliefpropagationcache.jl:7-37) ------------------------------------------------------------
+function ITensors.NDTensors.scalartype(c::HipBeliefPropagationCache)
+    r = Ref{Cint}(0)
+    check(ccall((:tnqs_scalartype, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), c.handle, r))
+    return DTYPE_OF[r[] + 1]
+end
+TN.graph(c::HipBeliefPropagationCache) = c.g
+TN.siteinds(c::HipBeliefPropagationCache) = c.siteinds
+TN.siteinds(c::HipBeliefPropagationCache, v) = c.siteinds[v]
+TN.contraction_sequences(::HipBeliefPropagationCache) = nothing          # fixed contraction order on the device; invalidate_… accepts nothing (:58-60)
+TN.default_update_alg(::HipBeliefPropagationCache) = "bp"
+TN.default_message_update_alg(::HipBeliefPropagationCache) = "contract"
+
+function bonddim(c::HipBeliefPropagationCache, u, v)
+    r = Ref{Cint}(0)
+    check(ccall((:tnqs_bond_dim, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}), c.handle, c.vid[u], c.vid[v], r))
+    return Int(r[])
+end
+function TN.maxvirtualdim(c::HipBeliefPropagationCache)
+    r = Ref{Cint}(0)
+    check(ccall((:tnqs_maxvirtualdim, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), c.handle, r))
+    return Int(r[])
+end
+
+# the link Index of an edge: kept while its dimension is current, re-created when a gate changed the bond dimension
+# (the reference makes new indices in every simple update too, src/Apply/apply_gates.jl:129-133)
+function linkind!(c::HipBeliefPropagationCache, u, v)
+    χ = bonddim(c, u, v)
+    k = linkkey(c, u, v)
+    if !(haskey(c.linkinds, k) && dim(c.linkinds[k]) == χ)
+        c.linkinds[k] = Index(χ, "Link")
+    end
+    return c.linkinds[k]
+end
+TN.virtualinds(c::HipBeliefPropagationCache, e::NamedEdge) = Index[linkind!(c, src(e), dst(e))]
+
+# message(bpc, e): chi x chi with inds (l, l') = (ket, bra) (abstract…:99-102); an unset message comes back as the identity, which is what
+# default_message gives (tensornetworkstate.jl:72-75)
+function TN.message(c::HipBeliefPropagationCache, e::NamedGraphs.AbstractEdge; kwargs...)
+    l = linkind!(c, src(e), dst(e))
+    χ = dim(l)
+    a = Matrix{TN.scalartype(c)}(undef, χ, χ)
+    GC.@preserve a check(ccall((:tnqs_get_message, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint),
+                               c.handle, c.vid[src(e)], c.vid[dst(e)], a, χ))
+    return itensor(a, l, prime(l))
+end
+# messages(bpc): the dictionary view the reference's generic code iterates, downloaded on demand
+function TN.messages(c::HipBeliefPropagationCache)
+    es = NamedEdge[]
+    for e in edges(c.g)
+        push!(es, e)
+        push!(es, reverse(e))
+    end
+    return Dictionary(es, [TN.message(c, e) for e in es])
+end
+function TN.setmessage!(c::HipBeliefPropagationCache, e::NamedGraphs.AbstractEdge, m::ITensor)     # abstract…:93-97
+    l = linkind!(c, src(e), dst(e))
+    # the caller's message may live on its own pair of indices (e.g. a cache that came from the CPU): read it as (unprimed, primed)
+    mi = collect(inds(m))
+    a = Matrix{TN.scalartype(c)}(array(m, first(filter(i -> ITensors.plev(i) == 0, mi)), first(filter(i -> ITensors.plev(i) == 1, mi))))
+    size(a, 1) == dim(l) || error("setmessage!: message dimension $(size(a, 1)) does not match the bond dimension $(dim(l))")
+    GC.@preserve a check(ccall((:tnqs_set_message, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint),
+                               c.handle, c.vid[src(e)], c.vid[dst(e)], a, size(a, 1)))
+    return c
+end
+
+# network(bpc): download the site tensors in the leg order (site, neighbours...) as a TensorNetworkState on fresh-or-kept link indices
+function TN.network(c::HipBeliefPropagationCache{V}) where {V}
+    T = TN.scalartype(c)
+    ts = Dictionary{V, ITensor}()
+    for v in vertices(c.g)
+        nb = collect(neighbors(c.g, v))
+        is = Index[only(c.siteinds[v]); Index[linkind!(c, v, w) for w in nb]]
+        role = Int32[-1; Int32[c.vid[w] for w in nb]]
+        a = Array{T}(undef, dim.(is)...)
+        GC.@preserve a role check(ccall((:tnqs_get_site_tensor, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Int32}),
+                                        c.handle, c.vid[v], a, ndims(a), role))
+        Dictionaries.set!(ts, v, itensor(a, is...))
+    end
+    return TN.TensorNetworkState(TN.TensorNetwork(ts, c.g), c.siteinds)
+end
+
+# ---- BP options: kwargs of update / bp_update_kwargs -> tnqs_bp_opts ------------------------------------------------------------------
+# maxiter missing / nothing -> 0 (library default = default_bp_maxiter: 25 loopy, 1 on trees, beliefpropagationcache.jl:39);
+# tolerance missing / nothing -> -1 = none (default_tolerance(::Algorithm"bp") = nothing, beliefpropagationcache.jl:62: `update(bpc; maxiter = 10)`
+# runs all ten sweeps); edge_sequence passes through (set_default_kwargs :66); normalize of the "contract" message update (:54,:58)
+function with_bpopts(f, c::HipBeliefPropagationCache, kw)
+    seq = get(kw, :edge_sequence, nothing)
+    ss = seq === nothing ? Int32[] : Int32[c.vid[src(e)] for e in seq]
+    sd = seq === nothing ? Int32[] : Int32[c.vid[dst(e)] for e in seq]
+    mua = get(kw, :message_update_alg, nothing)
+    normalize = mua === nothing ? true : get(mua.kwargs, :normalize, true)
+    maxiter = get(kw, :maxiter, nothing)
+    tol = get(kw, :tolerance, nothing)
+    GC.@preserve ss sd begin
+        o = BpOpts(maxiter === nothing ? 0 : maxiter, tol === nothing ? -1.0 : tol, normalize ? 1 : 0,
+                   length(ss), isempty(ss) ? Ptr{Int32}(C_NULL) : pointer(ss), isempty(sd) ? Ptr{Int32}(C_NULL) : pointer(sd))
+        return f(o)
+    end
+end
+
+# default_bp_update_kwargs (beliefpropagationcache.jl:110-119 is typed on AbstractTensorNetwork / BeliefPropagationCache)
+function TN.default_bp_update_kwargs(c::HipBeliefPropagationCache)
+    Graphs.is_tree(c.g) && return (; maxiter = 1, tolerance = nothing, verbose = false)
+    return (; maxiter = 25, tolerance = TN.default_tolerance(TN.scalartype(c)), verbose = false)
+end
+
+# update(bpc; maxiter, tolerance, edge_sequence, verbose, …)   (abstract…:223-259); value semantics (:228)
+function TN.update(c::HipBeliefPropagationCache; alg = "bp", verbose = false, kwargs...)
+    alg == "bp" || error("HipBeliefPropagationCache: only alg = \"bp\" is implemented")
+    c = copy(c)
+    niter = Ref{Cint}(0)
+    diff = Ref{Cdouble}(0.0)
+    with_bpopts(c, kwargs) do o
+        check(ccall((:tnqs_bp_update, LIB), Cint, (Ptr{Cvoid}, Ref{BpOpts}, Ptr{Cint}, Ptr{Cdouble}), c.handle, o, niter, diff))
+    end
+    tol = get(kwargs, :tolerance, nothing)
+    if tol !== nothing                                             # non-convergence is a warning, not an error (:245-252)
+        if diff[] <= tol
+            verbose && println("BP converged to desired precision after $(niter[]) iterations.")
+        else
+            msg = "BP did not converge to tolerance $(tol) after $(niter[]) iterations (final average message change: $(diff[]))."
+            verbose ? println(msg) : @warn(msg)
+        end
+    end
+    return c
+end
+
+# ---- apply_gates ----------------------------------------------------------------------------------------------------------------------
+# the tuple-circuit entry the examples use (apply_gates.jl:29-39 is typed on the concrete BeliefPropagationCache): names -> ITensors through
+# the reference's own registry (gate_definitions.jl:110-153), then the ITensor method below
+function TN.apply_gates(circuit::Vector, c::HipBeliefPropagationCache; kwargs...)
+    gates = TN.toitensor(circuit, c.g, c.siteinds)
+    return TN.apply_gates(ITensor[g[1] for g in gates], c; gate_vertices = [g[2] for g in gates], kwargs...)
+end
+
+# the d^k x d^k matrix of a gate ITensor: rows = primed site indices, columns = unprimed, FIRST listed vertex most significant
+# (include/tnqs.h:124-129).  array(gt, s1', s2', s1, s2) is column-major with s1' fastest, so the (s1, s2) pairs are reversed to make the
+# first vertex the slow (most significant) index of both the row and the column.
+function gate_matrix(gt::ITensor, sinds::Vector{<:Index})
+    r = reverse(sinds)
+    a = array(gt, prime.(r)..., r...)
+    n = prod(dim.(sinds))
+    return ComplexF64.(reshape(a, n, n))
+end
+
+# vertices(gate::ITensor, tns) (tensornetworkstate.jl:191-194) from the cache's own site indices -- no download of the state
+gate_verts(gt::ITensor, c::HipBeliefPropagationCache) = filter(v -> !isempty(intersect(collect(inds(gt)), c.siteinds[v])), collect(vertices(c.g)))
+
+function TN.apply_gates(circuit::Vector{<:ITensor}, c::HipBeliefPropagationCache;
+                        gate_vertices::Vector = [gate_verts(g, c) for g in circuit],
+                        apply_kwargs = (;), bp_update_kwargs = TN.default_bp_update_kwargs(c), update_cache = true, verbose = false)
+    c = copy(c)                                                    # apply_gates.jl:55
+    nverts = Int32[length(vs) for vs in gate_vertices]
+    verts = Int32[c.vid[v] for vs in gate_vertices for v in vs]
+    mats = ComplexF64[]
+    for (gt, vs) in zip(circuit, gate_vertices)
+        append!(mats, vec(gate_matrix(gt, Index[only(c.siteinds[v]) for v in vs])))
+    end
+    maxdim = get(apply_kwargs, :maxdim, nothing)
+    cutoff = get(apply_kwargs, :cutoff, nothing)
+    sqrt_cutoff = get(apply_kwargs, :sqrt_cutoff, nothing)
+    ao = ApplyOpts(maxdim === nothing ? 0 : maxdim, cutoff === nothing ? -1.0 : cutoff,
+                   get(apply_kwargs, :normalize_tensors, true) ? 1 : 0, sqrt_cutoff === nothing ? -1.0 : sqrt_cutoff, update_cache ? 1 : 0)
+    errs = zeros(Float64, length(circuit))                         # apply_gates.jl:61
+    with_bpopts(c, bp_update_kwargs) do bo
+        GC.@preserve nverts verts mats errs check(ccall((:tnqs_apply_gates, LIB), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ref{ApplyOpts}, Ref{BpOpts}, Ptr{Float64}, Ptr{Cvoid}),
+            c.handle, length(circuit), nverts, verts, mats, ao, bo, errs, C_NULL))
+    end
+    return c, errs                                                 # apply_gates.jl:97
+end
+
+# truncate(bpc; maxdim, cutoff, …)   (src/truncate.jl:12-38; groups = edge_color(g, maxdegree), :19-20)
+function ITensors.truncate(c::HipBeliefPropagationCache; maxdim::Integer, cutoff = nothing, normalize_tensors = true, edge_color = true,
+                     bp_update_kwargs = TN.default_bp_update_kwargs(c))
+    c = copy(c)
+    offs = Int32[0]
+    eu = Int32[]
+    ev = Int32[]
+    ngroups = 0
+    if edge_color
+        groups = TN.edge_color(c.g, maximum(length(neighbors(c.g, v)) for v in vertices(c.g)))
+        for grp in groups
+            for e in grp
+                push!(eu, c.vid[src(e)])
+                push!(ev, c.vid[dst(e)])
+            end
+            push!(offs, length(eu))
+        end
+        ngroups = length(groups)
+    end
+    with_bpopts(c, bp_update_kwargs) do bo
+        GC.@preserve offs eu ev check(ccall((:tnqs_truncate, LIB), Cint,
+            (Ptr{Cvoid}, Cint, Cdouble, Cint, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ref{BpOpts}, Ptr{Cvoid}),
+            c.handle, maxdim, cutoff === nothing ? -1.0 : cutoff, normalize_tensors ? 1 : 0, ngroups, offs, eu, ev, bo, C_NULL))
+    end
+    return c
+end
+
+# ---- expect(alg"bp", cache, obs)   (src/expect.jl:59-82,159-181) ----------------------------------------------------------------------
+function opmatrix(c::HipBeliefPropagationCache, name::String, v)
+    s = only(c.siteinds[v])
+    return ComplexF64.(array(op(name, s), prime(s), s))           # op[s', s], column-major
+end
+
+function TN.expect(c::HipBeliefPropagationCache, obs::Tuple; alg = "bp", kwargs...)
+    alg == "bp" || error("HipBeliefPropagationCache: only alg = \"bp\" is implemented")
+    ops, vs, coeff = TN.collectobservable(obs, c.g)
+    iszero(coeff) && return zero(coeff)
+    if length(vs) == 1
+        m = opmatrix(c, ops[1], vs[1])
+        out = zeros(Float64, 2)
+        GC.@preserve m out check(ccall((:tnqs_expect_1site, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{ComplexF64}, Ptr{Float64}),
+                                       c.handle, c.vid[vs[1]], m, out))
+        return coeff * complex(out[1], out[2])
+    end
+    # several sites: the region = vertices of the Steiner tree of the support (expect.jl:67), handed over as a rooted tree (BFS parents)
+    region = collect(vertices(NamedGraphs.steiner_tree(c.g, vs)))
+    order = [first(vs)]
+    par = Dict(first(vs) => Int32(-1))
+    i = 1
+    while i <= length(order)
+        u = order[i]
+        for w in neighbors(c.g, u)
+            if (w in region) && !haskey(par, w)
+                par[w] = Int32(i - 1)
+                push!(order, w)
+            end
+        end
+        i += 1
+    end
+    rv = Int32[c.vid[v] for v in order]
+    rp = Int32[par[v] for v in order]
+    opd = Dict(zip(vs, ops))
+    mats = ComplexF64[]
+    for v in order
+        append!(mats, vec(opmatrix(c, get(opd, v, "I"), v)))
+    end
+    out = zeros(Float64, 4)
+    GC.@preserve rv rp mats out check(ccall((:tnqs_expect_region, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{ComplexF64}, Ptr{Float64}), c.handle, length(order), rv, rp, mats, out))
+    return coeff * complex(out[1], out[2]) / complex(out[3], out[4])
+end
+TN.expect(c::HipBeliefPropagationCache, observables::Vector{<:Tuple}; kwargs...) = map(obs -> TN.expect(c, obs; kwargs...), observables)
+
+# ---- BP scalars, rescale!, free energy   (abstract…:22-28,134-148,289-328; beliefpropagationcache.jl:47-49,82-140) ---------------------
+function cvector(c::HipBeliefPropagationCache, f::Symbol, n::Integer)
+    x = zeros(ComplexF64, n)
+    GC.@preserve x check(ccall((f, LIB), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}), c.handle, x))
+    return x
+end
+all_vertex_scalars(c::HipBeliefPropagationCache) = cvector(c, :tnqs_vertex_scalars, length(vertices(c.g)))
+all_edge_scalars(c::HipBeliefPropagationCache) = cvector(c, :tnqs_edge_scalars, length(edges(c.g)))
+TN.vertex_scalar(c::HipBeliefPropagationCache, v) = all_vertex_scalars(c)[c.vid[v] + 1]
+function TN.edge_scalar(c::HipBeliefPropagationCache, e::NamedGraphs.AbstractEdge; kwargs...)
+    k = findfirst(x -> x == e || x == reverse(e), collect(edges(c.g)))
+    return all_edge_scalars(c)[k]
+end
+# one device call each for the whole graph instead of |V| / |E| single look-ups
+TN.vertex_scalars(c::HipBeliefPropagationCache, vs = collect(vertices(c.g)); kwargs...) = (x = all_vertex_scalars(c); [x[c.vid[v] + 1] for v in vs])
+function TN.edge_scalars(c::HipBeliefPropagationCache, es = edges(c.g); kwargs...)
+    x = all_edge_scalars(c)
+    all_es = collect(edges(c.g))
+    return [x[findfirst(y -> y == e || y == reverse(e), all_es)] for e in es]
+end
+
+# the two halves of rescale! with the reference's names and meanings (abstract…:11-20,306-316), so that a generic caller invoking only one of
+# them gets exactly that half: rescale_messages!(bpc, edges) = tnqs_rescale_messages, rescale_vertices!(bpc, vertices) = tnqs_rescale_vertices
+function TN.rescale_messages!(c::HipBeliefPropagationCache, es::Vector{<:NamedGraphs.AbstractEdge}; kwargs...)
+    eu = Int32[c.vid[src(e)] for e in es]
+    ev = Int32[c.vid[dst(e)] for e in es]
+    GC.@preserve eu ev check(ccall((:tnqs_rescale_messages, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int32}), c.handle, length(es), eu, ev))
+    return c
+end
+TN.rescale_messages!(c::HipBeliefPropagationCache) =
+    (check(ccall((:tnqs_rescale_messages, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int32}), c.handle, 0, C_NULL, C_NULL)); c)
+function TN.rescale_vertices!(c::HipBeliefPropagationCache, vs::Vector; kwargs...)
+    ids = Int32[c.vid[v] for v in vs]
+    GC.@preserve ids check(ccall((:tnqs_rescale_vertices, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int32}), c.handle, length(ids), ids))
+    return c
+end
+# rescale!(bpc) = rescale_messages! then rescale_vertices! is inherited from the abstract type (abstract…:318-322) and now does the right thing
+
+function TN.symmetric_gauge!(c::HipBeliefPropagationCache; regularization = 10 * eps(real(TN.scalartype(c))))     # src/symmetric_gauge.jl:1-62
+    check(ccall((:tnqs_symmetric_gauge, LIB), Cint, (Ptr{Cvoid}, Cdouble), c.handle, regularization))
+    return c
+end
+
+# ---- Adapt parity (abstract…:261-287): moves between the CPU cache and the device cache ----------------------------------------------
+struct HipStorage end          # Adapt.adapt(HipStorage(), bpc::BeliefPropagationCache) -> HipBeliefPropagationCache, messages included
+function Adapt.adapt_structure(::HipStorage, b::TN.BeliefPropagationCache)
+    c = HipBeliefPropagationCache(TN.network(b))
+    for e in keys(TN.messages(b))
+        TN.setmessage!(c, e, TN.message(b, e))
+    end
+    return c
+end
+function Adapt.adapt_structure(::Type{Array}, c::HipBeliefPropagationCache)      # Adapt.adapt(Array, hipcache) -> CPU BeliefPropagationCache
+    b = TN.BeliefPropagationCache(TN.network(c))
+    for e in edges(c.g), d in (e, reverse(e))
+        TN.setmessage!(b, d, TN.message(c, d))
+    end
+    return b
+end
+
+# ---- multi-GPU: one Julia process per GPU, RCCL inside the library (tnqs_set_sharding_rccl, include/tnqs.h:188-202) -------------------
+# `bcast128` must hand rank 0's 128-byte id to every rank (with MPI.jl: id -> MPI.Bcast!(id, 0, comm)); `allmin` must return the minimum of
+# an Int over the ranks (MPI.Allreduce(x, MPI.MIN, comm)).  Every rank runs the local preflight first and the ranks agree on it, so that no
+# rank enters the collective communicator set-up while another has already failed.
+function shard!(c::HipBeliefPropagationCache, rank::Integer, nranks::Integer, bcast128, allmin; exch_bytes::Integer = 1 << 28)
+    ok = ccall((:tnqs_rccl_preflight, LIB), Cint, ()) == 0 ? 1 : 0
+    allmin(ok) == 1 || error("RCCL transport unavailable on at least one rank")
+    id = zeros(UInt8, 128)
+    rank == 0 && check(ccall((:tnqs_rccl_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+    bcast128(id)
+    nv = length(vertices(c.g))
+    owner = Int32[min(nranks - 1, (i - 1) * nranks ÷ nv) for i in 1:nv]                 # contiguous, balanced vertex blocks
+    GC.@preserve owner id check(ccall((:tnqs_set_sharding_rccl, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Int32}, Ptr{UInt8}, Int64),
+                                      c.handle, rank, nranks, owner, id, exch_bytes))
+    return c
+end
+
+end # module

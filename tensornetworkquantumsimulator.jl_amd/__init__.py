@@ -7,7 +7,7 @@ from .gates import (GATES, ALIASES, BUILTIN_GATES, gate_matrix, register_gate, r
 from .core import (TensorNetworkState, tensornetworkstate, random_tensornetworkstate, BeliefPropagationCache, network,
                    scalartype, maxvirtualdim, default_bp_update_kwargs, default_tolerance, update, apply_gates,
                    apply_circuit, truncate, expect, expect_all, rdm, vertex_scalars, edge_scalars, freenergy, partitionfunction,
-                   rescale, normalize, symmetric_gauge, symmetrize_and_normalize, profile_enable, profile_get, profile_reset,
+                   rescale, rescale_messages, rescale_vertices, normalize, symmetric_gauge, symmetrize_and_normalize, profile_enable, profile_get, profile_reset,
                    PROF_CLASSES)
 from . import dist
 from .dist import partition_vertices, shard

@@ -95,6 +95,8 @@ _SIGS = {
     "tnqs_vertex_scalars": ([H, _DP], C.c_int),
     "tnqs_edge_scalars": ([H, _DP], C.c_int),
     "tnqs_rescale": ([H], C.c_int),
+    "tnqs_rescale_messages": ([H, C.c_int, _I32P, _I32P], C.c_int),
+    "tnqs_rescale_vertices": ([H, C.c_int, _I32P], C.c_int),
     "tnqs_symmetric_gauge": ([H, C.c_double], C.c_int),
     "tnqs_set_sharding": ([H, C.c_int, C.c_int, _I32P, ALLGATHER_FN, C.c_void_p, C.c_void_p, C.c_int64], C.c_int),
     "tnqs_rccl_unique_id": ([C.c_void_p], C.c_int),

@@ -506,6 +506,31 @@ def rescale(bpc: BeliefPropagationCache) -> BeliefPropagationCache:
     return out
 
 
+def rescale_messages(bpc: BeliefPropagationCache, edges=None) -> BeliefPropagationCache:
+    """rescale_messages!(bpc, edges) on a copy (beliefpropagationcache.jl:127-140): each listed edge's two messages are normalised and
+    divided by sqrt of their overlap, so that the edge scalar becomes 1; edges = None: every edge (abstract...:310-312)"""
+    out = bpc.copy()
+    if edges is None:
+        L.check(L.lib.tnqs_rescale_messages(out._h, 0, None, None))
+    else:
+        g = bpc.graph
+        (_, eup), (_, evp) = L.i32([g.index[a] for (a, b) in edges]), L.i32([g.index[b] for (a, b) in edges])
+        L.check(L.lib.tnqs_rescale_messages(out._h, len(edges), eup, evp))
+    return out
+
+
+def rescale_vertices(bpc: BeliefPropagationCache, vertices=None) -> BeliefPropagationCache:
+    """rescale_vertices!(bpc, vertices) on a copy (beliefpropagationcache.jl:82-101): psi_v *= sign(vn) / sqrt(vn) with vn the vertex
+    scalar under the cache's current messages; vertices = None: every vertex (abstract...:314-316)"""
+    out = bpc.copy()
+    if vertices is None:
+        L.check(L.lib.tnqs_rescale_vertices(out._h, 0, None))
+    else:
+        _, vp = L.i32([bpc.graph.index[v] for v in vertices])
+        L.check(L.lib.tnqs_rescale_vertices(out._h, len(vertices), vp))
+    return out
+
+
 def normalize(tns: TensorNetworkState, alg: str = "bp", cache_update_kwargs=None, device: int = 0) -> TensorNetworkState:
     """normalize(tns; alg = "bp") (src/normalize.jl:1-6): BP-converge, rescale!, return the network (norm_sqr(bp) = 1)"""
     if alg != "bp":

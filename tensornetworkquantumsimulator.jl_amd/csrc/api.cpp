@@ -116,6 +116,12 @@ int tnqs_expect_region(tnqs_handle h, int nr, const int32_t* rv, const int32_t* 
 int tnqs_vertex_scalars(tnqs_handle h, double* out) { return guard([&] { if (!out) throw Err(TNQS_ERR_INVALID, "vertex_scalars: null"); vertex_scalars(S(h), out); }); }
 int tnqs_edge_scalars(tnqs_handle h, double* out) { return guard([&] { if (!out) throw Err(TNQS_ERR_INVALID, "edge_scalars: null"); edge_scalars(S(h), out); }); }
 int tnqs_rescale(tnqs_handle h) { return guard([&] { rescale(S(h)); }); }
+int tnqs_rescale_messages(tnqs_handle h, int n_edges, const int32_t* eu, const int32_t* ev) {
+    return guard([&] { if (n_edges < 0) throw Err(TNQS_ERR_INVALID, "rescale_messages: negative count"); rescale_messages(S(h), n_edges, eu, ev); });
+}
+int tnqs_rescale_vertices(tnqs_handle h, int n_vertices, const int32_t* verts) {
+    return guard([&] { if (n_vertices < 0) throw Err(TNQS_ERR_INVALID, "rescale_vertices: negative count"); rescale_vertices(S(h), n_vertices, verts); });
+}
 int tnqs_symmetric_gauge(tnqs_handle h, double regularization) { return guard([&] { symmetric_gauge(S(h), regularization); }); }
 int tnqs_expect_all(tnqs_handle h, const double* ops, double* out) {
     return guard([&] { if (!ops || !out) throw Err(TNQS_ERR_INVALID, "expect_all: null"); expect_all(S(h), ops, out); });

@@ -142,6 +142,8 @@ void expect_region(State* s, int nr, const int32_t* rv, const int32_t* parent, c
 void vertex_scalars(State* s, double* out);
 void edge_scalars(State* s, double* out);
 void rescale(State* s);
+void rescale_messages(State* s, int n, const int32_t* eu, const int32_t* ev);     // null lists: all edges / all vertices
+void rescale_vertices(State* s, int n, const int32_t* verts);
 void symmetric_gauge(State* s, double regularization);
 void prof_collect(State* s);
 // sharding.cpp

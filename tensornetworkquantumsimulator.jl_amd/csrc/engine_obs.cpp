@@ -73,29 +73,46 @@ template <class T> static void edge_scalars_t(State* s, double* out) {
 }
 void edge_scalars(State* s, double* out) { if (s->dtype == TNQS_C64) edge_scalars_t<float>(s, out); else edge_scalars_t<double>(s, out); }
 
-template <class T> static void rescale_t(State* s) {
+// rescale_messages!(bpc, edges) (beliefpropagationcache.jl:127-140): both directions of every listed edge (replicated on every rank when
+// sharded); edges == nullptr: all of them
+template <class T> static void rescale_messages_t(State* s, int n, const int32_t* eu, const int32_t* ev) {
     const Graph& g = *s->g;
     const size_t esz = s->esz();
     HIPCHK(hipSetDevice(s->device));
-    // rescale_messages!: every edge, both directions (replicated on every rank when sharded)
-    if (g.ne > 0) {
-        std::vector<MsgRescaleItem> items; std::vector<Buf> na(g.ne), nb(g.ne);
-        for (int e = 0; e < g.ne; ++e) {
-            size_t bytes = (size_t)s->chi[e] * s->chi[e] * esz;
-            na[e] = dalloc(s, bytes); nb[e] = dalloc(s, bytes);
-            items.push_back(MsgRescaleItem{s->msg[2 * e] ? s->msg[2 * e]->p : nullptr, s->msg[2 * e + 1] ? s->msg[2 * e + 1]->p : nullptr, na[e]->p, nb[e]->p, s->chi[e]});
-        }
-        const MsgRescaleItem* d = upload(s, items);
-        launch_msg_rescale<T>(s->stream, d, (int)items.size());
-        for (int e = 0; e < g.ne; ++e) { s->keepalive.push_back(s->msg[2 * e]); s->keepalive.push_back(s->msg[2 * e + 1]); s->msg[2 * e] = na[e]; s->msg[2 * e + 1] = nb[e]; }
+    std::vector<int> es;
+    if (!eu || !ev) { es.resize(g.ne); std::iota(es.begin(), es.end(), 0); }
+    else for (int i = 0; i < n; ++i) {
+        const int e = g.edge(eu[i], ev[i]);
+        if (e < 0) throw Err(TNQS_ERR_INVALID, "rescale_messages: not an edge");
+        if (std::find(es.begin(), es.end(), e) == es.end()) es.push_back(e);      // (u, v) and (v, u) name the same pair of messages
     }
-    // rescale_vertices!: psi_v *= sign(vn) / sqrt(vn) with vn = vertex_scalar under the rescaled messages
+    if (es.empty()) return;
+    std::vector<MsgRescaleItem> items; std::vector<Buf> na(es.size()), nb(es.size());
+    for (size_t q = 0; q < es.size(); ++q) {
+        const int e = es[q];
+        size_t bytes = (size_t)s->chi[e] * s->chi[e] * esz;
+        na[q] = dalloc(s, bytes); nb[q] = dalloc(s, bytes);
+        items.push_back(MsgRescaleItem{s->msg[2 * e] ? s->msg[2 * e]->p : nullptr, s->msg[2 * e + 1] ? s->msg[2 * e + 1]->p : nullptr, na[q]->p, nb[q]->p, s->chi[e]});
+    }
+    const MsgRescaleItem* d = upload(s, items);
+    launch_msg_rescale<T>(s->stream, d, (int)items.size());
+    for (size_t q = 0; q < es.size(); ++q) { const int e = es[q]; s->keepalive.push_back(s->msg[2 * e]); s->keepalive.push_back(s->msg[2 * e + 1]); s->msg[2 * e] = na[q]; s->msg[2 * e + 1] = nb[q]; }
+    sync(s);
+}
+// rescale_vertices!(bpc, vertices) (beliefpropagationcache.jl:82-101): psi_v *= sign(vn) / sqrt(vn), vn = vertex_scalar under the CURRENT
+// messages; vertices == nullptr: all of them (a sharded rank rescales the ones it owns)
+template <class T> static void rescale_vertices_t(State* s, int n, const int32_t* verts) {
+    const Graph& g = *s->g;
+    const size_t esz = s->esz();
+    HIPCHK(hipSetDevice(s->device));
+    std::vector<char> want(g.nv, verts ? 0 : 1);
+    if (verts) for (int i = 0; i < n; ++i) { if (verts[i] < 0 || verts[i] >= g.nv) throw Err(TNQS_ERR_INVALID, "rescale_vertices: bad vertex"); want[verts[i]] = 1; }
     std::vector<double> vn(2 * (size_t)g.nv);
     vertex_scalars(s, vn.data());
     materialize_scale_all(s);
     std::vector<CScaleItem> cs; std::vector<Buf> outs; std::vector<int> vs;
     for (int v = 0; v < g.nv; ++v) {
-        if (!s->owns(v) || !s->site[v]) continue;
+        if (!want[v] || !s->owns(v) || !s->site[v]) continue;
         double re = vn[2 * v], im = vn[2 * v + 1];
         double sgn = 1.0;
         if (im == 0.0) sgn = (re > 0) - (re < 0);             // isreal(vn) ? sign(vn) : one(vn)
@@ -113,7 +130,11 @@ template <class T> static void rescale_t(State* s) {
     }
     sync(s);
 }
-void rescale(State* s) { if (s->dtype == TNQS_C64) rescale_t<float>(s); else rescale_t<double>(s); }
+void rescale_messages(State* s, int n, const int32_t* eu, const int32_t* ev) { if (s->dtype == TNQS_C64) rescale_messages_t<float>(s, n, eu, ev); else rescale_messages_t<double>(s, n, eu, ev); }
+void rescale_vertices(State* s, int n, const int32_t* verts) { if (s->dtype == TNQS_C64) rescale_vertices_t<float>(s, n, verts); else rescale_vertices_t<double>(s, n, verts); }
+// rescale! = rescale_messages! then rescale_vertices! (abstract...:318-322)
+void rescale(State* s) { rescale_messages(s, 0, nullptr, nullptr); rescale_vertices(s, 0, nullptr); }
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // multi-site expectation value on a tree-shaped region (src/expect.jl:59-82): the norm network of the region's

@@ -458,6 +458,21 @@ def test_bp_scalars_and_rescale_match_oracle(dtype, lattice):
     for v in g.vertices[:4]:     # same tensors up to the (real positive) factor both sides derive from the same scalars
         assert abs(np.linalg.norm(r.tensor(v)) - np.linalg.norm(ro.tns.tensors[v])) < 50 * tol * np.linalg.norm(ro.tns.tensors[v])
         assert abs(tn.expect(r, ("Z", [v])) - o.expect_1site(ro, Z, v)) < 50 * tol
+    # the two halves on their own (abstract cache interface, abstract...:11-20,306-316): a generic caller may invoke only one of them.
+    # rescale_messages! alone: every edge scalar 1, site tensors untouched, vertex scalars NOT yet 1; then rescale_vertices! completes rescale!
+    rm = tn.rescale_messages(bpc)
+    assert np.max(np.abs(tn.edge_scalars(rm) - 1)) < 20 * tol
+    assert np.array_equal(rm.tensor(g.vertices[0]), bpc.tensor(g.vertices[0]))
+    assert np.max(np.abs(tn.vertex_scalars(rm) - 1)) > 1e-3
+    rv = tn.rescale_vertices(rm)
+    assert np.max(np.abs(tn.vertex_scalars(rv) - tn.vertex_scalars(r))) < 20 * tol and np.max(np.abs(tn.edge_scalars(rv) - 1)) < 20 * tol
+    # subsets: only the listed edge / vertices change
+    e0 = g.edges[0]
+    rs = tn.rescale_messages(bpc, [e0])
+    assert abs(tn.edge_scalars(rs)[0] - 1) < 20 * tol and np.array_equal(rs.message(g.edges[1]), bpc.message(g.edges[1]))
+    r1 = tn.rescale_vertices(rm, [g.vertices[1]])
+    sc = tn.vertex_scalars(r1)
+    assert abs(sc[1] - 1) < 20 * tol and abs(sc[0] - tn.vertex_scalars(rm)[0]) < 1e-6 * abs(sc[0])
     # the input cache is untouched, and normalize() returns a state of BP norm 1
     assert abs(tn.vertex_scalars(bpc)[0] - vs[0]) == 0
     nrm = tn.normalize(psi, cache_update_kwargs=kw)
