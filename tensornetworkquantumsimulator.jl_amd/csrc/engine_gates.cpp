@@ -429,20 +429,43 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     run_theta();
     std::vector<int> info(8 * (size_t)ng, 0); std::vector<double> terr(ng, 0.0);
     {
-        // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
         std::vector<int> hinfo(8 * (size_t)std::max(1, npg));
-        int chol_failed = 0;
-        const int* st_info = npg ? readback<int>(s, d_info_all->p, (size_t)npg * 8) : nullptr;
-        const int* st_flags = !envs.empty() ? readback<int>(s, d_flags->p, 2 * envs.size()) : nullptr;
-        const int* st_chol = !sj.empty() ? readback<int>(s, d_cholfail->p, sj.size()) : nullptr;
-        ht_a.stop();
-        HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
-        if (st_info) std::copy(st_info, st_info + (size_t)npg * 8, hinfo.begin());
-        if (st_flags) std::copy(st_flags, st_flags + 2 * envs.size(), h_flags.begin());
-        if (st_chol) std::copy(st_chol, st_chol + sj.size(), h_cholfail.begin());
-        HostTimer ht_b(4);
-        for (size_t i = 0; i < sj.size(); ++i) chol_failed += (part[i / 2] && is_chol[i] && h_cholfail[i]) ? 1 : 0;
-        if (chol_failed) {              // numerically rank-deficient Gram matrix somewhere in the batch: redo with the eigen path
+        std::vector<double> hterr(std::max(1, npg));
+        // SVD of theta (rotated in place to U Sigma), recovery of V from the unrotated copy, truncation and X1 / X2.  `dims` = the ranks
+        // read back from the device, or null: the kernels read them from the gates' info arrays themselves (JacobiItem::dyn) and the
+        // host sizes the launches with upper bounds
+        auto svd_and_finish = [&](const int* dims) {
+            std::vector<JacobiItem> ji; std::vector<int> ncfull;
+            for (int q = 0; q < npg; ++q) {
+                int gi = pg[q];
+                JacobiItem j{};
+                if (dims) {
+                    int Mr, Nc, ncolJ; theta_dims(dims + 8 * q, gitems[q].d1, gitems[q].d2, Mr, Nc, ncolJ);
+                    j = JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, ncolJ, gitems[q].info + 4};
+                    ncfull.push_back(Nc);
+                } else {
+                    const int Mr = std::max(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2), Nc = std::min(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2);
+                    j = JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, gitems[q].info + 4, gitems[q].info, gitems[q].d1, gitems[q].d2};
+                    ncfull.push_back(Nc);
+                }
+                j.V = nullptr;          // V is never accumulated from the rotations (theta0_used): recovered below
+                ji.push_back(j);
+            }
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); svd_batch<T>(s, ji, false); }
+            std::vector<RecoverItem> rv;
+            for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ncfull[q], ji[q].n, ji[q].dyn, ji[q].dm, ji[q].dn});
+            const RecoverItem* dr = upload(s, rv);
+            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); { int nmax = 1; for (int nc : ncfull) nmax = std::max(nmax, nc); if (std::is_same<T, float>::value && use_mfma()) launch_recover_v_mfma(s->stream, dr, npg, nmax); else launch_recover_v<T>(s->stream, dr, npg, nmax); } }
+            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
+        };
+        auto read_results = [&]() {          // (r1, r2, chi', status, ...) and the truncation errors of every gate: one synchronisation
+            const int* st_info2 = npg ? readback<int>(s, d_info_all->p, (size_t)npg * 8) : nullptr;
+            const double* st_terr = npg ? readback<double>(s, d_terr_all->p, (size_t)npg) : nullptr;
+            HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
+            if (npg) { std::copy(st_info2, st_info2 + (size_t)npg * 8, hinfo.begin()); std::copy(st_terr, st_terr + npg, hterr.begin()); }
+        };
+        auto chol_failures = [&]() { int c = 0; for (size_t i = 0; i < sj.size(); ++i) c += (part[i / 2] && is_chol[i] && h_cholfail[i]) ? 1 : 0; return c; };
+        auto redo_with_eigen = [&]() {      // numerically rank-deficient Gram matrix somewhere in the batch: those sites take the eigen path
             factor_G(false, true);
             for (int q = 0; q < npg; ++q) { int gi = pg[q]; GateItem& it = gitems[q]; it.GW1 = GW[2 * gi]->p; it.GW2 = GW[2 * gi + 1]->p; it.chol1 = is_chol[2 * gi]; it.chol2 = is_chol[2 * gi + 1]; }
             d_gitems = upload(s, gitems);
@@ -450,124 +473,133 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
             s->stats.n_chol_fallbacks += 1;
+        };
+        // ONE host round trip per batch where the whole chain can be sized from upper bounds: ComplexF32 (no second factorisation pass), every
+        // theta small enough for the LDS-resident Jacobi at its largest possible size.  The ranks of the R factors stay on the device; the
+        // Cholesky failure flags and the message-eigenvalue flags are read together with the results, and a failure (rare) redoes the chain
+        static const bool two_trips = envflag("TNQS_TWO_ROUNDTRIPS");          // A/B: the round-2 flow (ranks read back before the SVD)
+        bool one_trip = !qr2 && !two_trips && npg > 0;
+        for (int q = 0; q < npg && one_trip; ++q) {
+            const int gi = pg[q];
+            const int Mr = std::max(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2), Nc = std::min(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2);
+            one_trip = jacobi_lds(jacobi_lds_bytes(Mr, Nc, false, esz)) > 0 && Mr <= 256;
         }
-        if (qr2) {
-            // ---- second factorisation pass (CholeskyQR2) of the sites gate_theta flagged as ill-conditioned: a Gram matrix resolves the
-            // singular directions of psi~ only down to sigma_rel ~ 1e-7, the reference's QR to eps.  Q1 = psi~ R1^+ is formed explicitly;
-            // its Gram matrix is close to the identity on everything the first pass resolved and shows the true weight of what it did not,
-            // so R = R2 R1 is as accurate as a Householder R.  
-            // Sharded: the owner of a site forms Q1 and its Gram matrix, one more all-gather (same slots as the first Gram exchange, issued
-            // by every rank whether or not it has a flagged site -- it is a collective) hands it to the partner rank, and both compose the
-            // same factor from the same inputs.
-            std::vector<size_t> rs; std::vector<int> rq;
-            for (int q = 0; q < npg; ++q) for (int side = 0; side < 2; ++side) {
-                const size_t i = 2 * (size_t)pg[q] + side;
-                static const bool all = [] { const char* v = std::getenv("TNQS_QR2_ALL"); return v && v[0] == '1'; }();      // debug: refine every site
-                if ((all || ((hinfo[8 * q + 6] >> side) & 1)) && !small_shape(i)) { rs.push_back(i); rq.push_back(q); }
-            }
-            if (sharded || !rs.empty()) {
-                const size_t m = rs.size();
-                std::vector<Buf> X1(m), Q1(m), G2(m), V2(m), GVn(m), GWn(m); Buf d_rk = dalloc(s, std::max<size_t>(1, m) * sizeof(int));
-                std::vector<Qr2RinvItem> ri; std::vector<FiberItem> fi; std::vector<GramJob> gj; std::vector<size_t> own_k; size_t KKmax = 1; int tiles = 0;
-                for (size_t k = 0; k < m; ++k) {
-                    const size_t i = rs[k]; const int q = rq[k]; const bool second = (i & 1) != 0; const int n = nof(i); const size_t nn = (size_t)n * n;
-                    X1[k] = dalloc(s, nn * 16); V2[k] = dalloc(s, nn * 16); GVn[k] = dalloc(s, nn * 16); GWn[k] = dalloc(s, nn * 16);
-                    ri.push_back(Qr2RinvItem{GW[i]->p, second ? gitems[q].lam2 : gitems[q].lam1, second ? gitems[q].idx2 : gitems[q].idx1, gitems[q].info + (second ? 1 : 0), n, X1[k]->p});
-                    if (sj[i].owned) { own_k.push_back(k); KKmax = std::max<size_t>(KKmax, (size_t)n); Q1[k] = dalloc(s, sj[i].sd.n * esz); }
+        const int* st_flags = nullptr; const int* st_chol = nullptr;
+        if (one_trip) {
+            svd_and_finish(nullptr);
+            st_flags = !envs.empty() ? readback<int>(s, d_flags->p, 2 * envs.size()) : nullptr;
+            st_chol = !sj.empty() ? readback<int>(s, d_cholfail->p, sj.size()) : nullptr;
+            ht_a.stop();
+            read_results();
+            if (st_flags) std::copy(st_flags, st_flags + 2 * envs.size(), h_flags.begin());
+            if (st_chol) std::copy(st_chol, st_chol + sj.size(), h_cholfail.begin());
+            if (chol_failures()) { redo_with_eigen(); svd_and_finish(hinfo.data()); read_results(); }
+        } else {
+            // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
+            const int* st_info = npg ? readback<int>(s, d_info_all->p, (size_t)npg * 8) : nullptr;
+            st_flags = !envs.empty() ? readback<int>(s, d_flags->p, 2 * envs.size()) : nullptr;
+            st_chol = !sj.empty() ? readback<int>(s, d_cholfail->p, sj.size()) : nullptr;
+            ht_a.stop();
+            HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
+            if (st_info) std::copy(st_info, st_info + (size_t)npg * 8, hinfo.begin());
+            if (st_flags) std::copy(st_flags, st_flags + 2 * envs.size(), h_flags.begin());
+            if (st_chol) std::copy(st_chol, st_chol + sj.size(), h_cholfail.begin());
+            if (chol_failures()) redo_with_eigen();
+            if (qr2) {
+                // ---- second factorisation pass (CholeskyQR2) of the sites gate_theta flagged as ill-conditioned: a Gram matrix resolves the
+                // singular directions of psi~ only down to sigma_rel ~ 1e-7, the reference's QR to eps.  Q1 = psi~ R1^+ is formed explicitly;
+                // its Gram matrix is close to the identity on everything the first pass resolved and shows the true weight of what it did not,
+                // so R = R2 R1 is as accurate as a Householder R.  
+                // Sharded: the owner of a site forms Q1 and its Gram matrix, one more all-gather (same slots as the first Gram exchange, issued
+                // by every rank whether or not it has a flagged site -- it is a collective) hands it to the partner rank, and both compose the
+                // same factor from the same inputs.
+                std::vector<size_t> rs; std::vector<int> rq;
+                for (int q = 0; q < npg; ++q) for (int side = 0; side < 2; ++side) {
+                    const size_t i = 2 * (size_t)pg[q] + side;
+                    static const bool all = [] { const char* v = std::getenv("TNQS_QR2_ALL"); return v && v[0] == '1'; }();      // debug: refine every site
+                    if ((all || ((hinfo[8 * q + 6] >> side) & 1)) && !small_shape(i)) { rs.push_back(i); rq.push_back(q); }
                 }
-                const int TR = pick_TR(KKmax, esz, 1);
-                for (size_t k : own_k) {
-                    const size_t i = rs[k]; const SiteJob& j = sj[i]; const int chi = j.sd.chi[j.bleg];
-                    FiberItem it{}; it.in = gauged_of[i]; it.out = Q1[k]->p; it.X = X1[k]->p;
-                    it.D = j.sd.d; it.PA = (int)(j.sd.pre(j.bleg) / j.sd.d); it.K = chi; it.PB = (int)j.sd.post(j.bleg); it.Do = j.sd.d; it.No = chi;
-                    tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb); it.tpw = 1; it.tile_begin = tiles; it.want_norm = 0;
-                    tiles += it.nta * it.ntb; fi.push_back(it);
-                    GramJob g2{}; g2.X = Q1[k]->p; g2.Y = Q1[k]->p; g2.sd = j.sd; g2.leg = j.bleg; g2.keep_site = true; gj.push_back(g2);
-                }
-                if (m) { const Qr2RinvItem* d = upload(s, ri); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_rinv(s->stream, d, (int)m); }
-                if (!fi.empty()) {
-                    Buf np = dalloc(s, std::max(1, tiles) * sizeof(double)); const FiberItem* d = upload(s, fi);
-                    { ProfScope ps(s, TNQS_PROF_GATE_APPLY, 0, 0); launch_fiber_gemm<T>(s->stream, d, (int)fi.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
-                    s->keepalive.push_back(np);
-                    run_grams<T, double>(s, gj, TNQS_PROF_GATE_GRAM);
-                    std::vector<ReduceItem> rd; int elems = 0;
-                    for (size_t t = 0; t < own_k.size(); ++t) {
-                        const size_t k = own_k[t], i = rs[k]; const int nn = gj[t].KK * gj[t].KK;
-                        void* dst;
-                        if (sharded) dst = reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride + slot[i];
-                        else { G2[k] = dalloc(s, (size_t)nn * 16); dst = G2[k]->p; }
-                        rd.push_back(ReduceItem{gj[t].partial->p, dst, nn, gj[t].nchunks, 1, elems}); elems += nn;
-                    }
-                    const ReduceItem* d2 = upload(s, rd); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, d2, (int)rd.size(), elems);
-                }
-                if (sharded) {
-                    exchange(s, stride);
-                    Buf G2_keep = dalloc(s, std::max<size_t>(256, stride * (size_t)s->nranks));
-                    HIPCHK(hipMemcpyAsync(G2_keep->p, s->exch, stride * (size_t)s->nranks, hipMemcpyDeviceToDevice, s->stream));
-                    for (size_t k = 0; k < m; ++k) { const size_t i = rs[k]; const size_t nn = (size_t)nof(i) * nof(i); G2[k] = sub_buffer(G2_keep, (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16); }
-                }
-                if (m) {
-                    std::vector<EnvItem> idn; std::vector<JacobiItem> ji; size_t lds = 0;
-                    for (size_t k = 0; k < m; ++k) { const int n = nof(rs[k]); idn.push_back(EnvItem{nullptr, V2[k]->p, V2[k]->p, n}); ji.push_back(JacobiItem{G2[k]->p, V2[k]->p, n, n, nullptr}); lds = std::max(lds, jacobi_lds_bytes(n, n, true, 16)); }
-                    const EnvItem* di = upload(s, idn); const JacobiItem* dj = upload(s, ji);
-                    { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)m); }
-                    { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)m, 60, jacobi_lds(lds), mmax_of(ji)); }
-                    std::vector<Qr2ComposeItem> ci;
+                if (sharded || !rs.empty()) {
+                    const size_t m = rs.size();
+                    std::vector<Buf> X1(m), Q1(m), G2(m), V2(m), GVn(m), GWn(m); Buf d_rk = dalloc(s, std::max<size_t>(1, m) * sizeof(int));
+                    std::vector<Qr2RinvItem> ri; std::vector<FiberItem> fi; std::vector<GramJob> gj; std::vector<size_t> own_k; size_t KKmax = 1; int tiles = 0;
                     for (size_t k = 0; k < m; ++k) {
-                        const size_t i = rs[k]; const int q = rq[k]; const bool second = (i & 1) != 0; const int n = nof(i);
-                        ci.push_back(Qr2ComposeItem{G2[k]->p, V2[k]->p, X1[k]->p, GV[i]->p, second ? gitems[q].lam2 : gitems[q].lam1, second ? gitems[q].idx2 : gitems[q].idx1,
-                                                    gitems[q].info + (second ? 1 : 0), n, rank_tau(false, n), GVn[k]->p, GWn[k]->p, reinterpret_cast<int*>(d_rk->p) + k});
+                        const size_t i = rs[k]; const int q = rq[k]; const bool second = (i & 1) != 0; const int n = nof(i); const size_t nn = (size_t)n * n;
+                        X1[k] = dalloc(s, nn * 16); V2[k] = dalloc(s, nn * 16); GVn[k] = dalloc(s, nn * 16); GWn[k] = dalloc(s, nn * 16);
+                        ri.push_back(Qr2RinvItem{GW[i]->p, second ? gitems[q].lam2 : gitems[q].lam1, second ? gitems[q].idx2 : gitems[q].idx1, gitems[q].info + (second ? 1 : 0), n, X1[k]->p});
+                        if (sj[i].owned) { own_k.push_back(k); KKmax = std::max<size_t>(KKmax, (size_t)n); Q1[k] = dalloc(s, sj[i].sd.n * esz); }
                     }
-                    { const Qr2ComposeItem* d = upload(s, ci); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_compose(s->stream, d, (int)m); }
-                    for (size_t k = 0; k < m; ++k) {
-                        const size_t i = rs[k]; GateItem& it = gitems[rq[k]];
-                        GV[i] = GVn[k]; GW[i] = GWn[k]; s->keepalive.push_back(X1[k]); if (Q1[k]) s->keepalive.push_back(Q1[k]); s->keepalive.push_back(G2[k]); s->keepalive.push_back(V2[k]);
-                        if (i & 1) { it.GV2 = GV[i]->p; it.GW2 = GW[i]->p; it.chol2 = 2; it.rk2 = reinterpret_cast<int*>(d_rk->p) + k; }
-                        else { it.GV1 = GV[i]->p; it.GW1 = GW[i]->p; it.chol1 = 2; it.rk1 = reinterpret_cast<int*>(d_rk->p) + k; }
+                    const int TR = pick_TR(KKmax, esz, 1);
+                    for (size_t k : own_k) {
+                        const size_t i = rs[k]; const SiteJob& j = sj[i]; const int chi = j.sd.chi[j.bleg];
+                        FiberItem it{}; it.in = gauged_of[i]; it.out = Q1[k]->p; it.X = X1[k]->p;
+                        it.D = j.sd.d; it.PA = (int)(j.sd.pre(j.bleg) / j.sd.d); it.K = chi; it.PB = (int)j.sd.post(j.bleg); it.Do = j.sd.d; it.No = chi;
+                        tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb); it.tpw = 1; it.tile_begin = tiles; it.want_norm = 0;
+                        tiles += it.nta * it.ntb; fi.push_back(it);
+                        GramJob g2{}; g2.X = Q1[k]->p; g2.Y = Q1[k]->p; g2.sd = j.sd; g2.leg = j.bleg; g2.keep_site = true; gj.push_back(g2);
                     }
-                    s->keepalive.push_back(d_rk);
-                    d_gitems = upload(s, gitems);
-                    // gate_theta reads the first-pass (lambda, idx, r) of the untouched partner site again and overwrites them with the same values
-                    run_theta();
-                    if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
-                    HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
-                    for (size_t k = 0; k < m; ++k) s->stats.n_qr2_sites += sj[rs[k]].owned ? 1 : 0;
+                    if (m) { const Qr2RinvItem* d = upload(s, ri); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_rinv(s->stream, d, (int)m); }
+                    if (!fi.empty()) {
+                        Buf np = dalloc(s, std::max(1, tiles) * sizeof(double)); const FiberItem* d = upload(s, fi);
+                        { ProfScope ps(s, TNQS_PROF_GATE_APPLY, 0, 0); launch_fiber_gemm<T>(s->stream, d, (int)fi.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
+                        s->keepalive.push_back(np);
+                        run_grams<T, double>(s, gj, TNQS_PROF_GATE_GRAM);
+                        std::vector<ReduceItem> rd; int elems = 0;
+                        for (size_t t = 0; t < own_k.size(); ++t) {
+                            const size_t k = own_k[t], i = rs[k]; const int nn = gj[t].KK * gj[t].KK;
+                            void* dst;
+                            if (sharded) dst = reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride + slot[i];
+                            else { G2[k] = dalloc(s, (size_t)nn * 16); dst = G2[k]->p; }
+                            rd.push_back(ReduceItem{gj[t].partial->p, dst, nn, gj[t].nchunks, 1, elems}); elems += nn;
+                        }
+                        const ReduceItem* d2 = upload(s, rd); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, d2, (int)rd.size(), elems);
+                    }
+                    if (sharded) {
+                        exchange(s, stride);
+                        Buf G2_keep = dalloc(s, std::max<size_t>(256, stride * (size_t)s->nranks));
+                        HIPCHK(hipMemcpyAsync(G2_keep->p, s->exch, stride * (size_t)s->nranks, hipMemcpyDeviceToDevice, s->stream));
+                        for (size_t k = 0; k < m; ++k) { const size_t i = rs[k]; const size_t nn = (size_t)nof(i) * nof(i); G2[k] = sub_buffer(G2_keep, (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16); }
+                    }
+                    if (m) {
+                        std::vector<EnvItem> idn; std::vector<JacobiItem> ji; size_t lds = 0;
+                        for (size_t k = 0; k < m; ++k) { const int n = nof(rs[k]); idn.push_back(EnvItem{nullptr, V2[k]->p, V2[k]->p, n}); ji.push_back(JacobiItem{G2[k]->p, V2[k]->p, n, n, nullptr}); lds = std::max(lds, jacobi_lds_bytes(n, n, true, 16)); }
+                        const EnvItem* di = upload(s, idn); const JacobiItem* dj = upload(s, ji);
+                        { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)m); }
+                        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)m, 60, jacobi_lds(lds), mmax_of(ji)); }
+                        std::vector<Qr2ComposeItem> ci;
+                        for (size_t k = 0; k < m; ++k) {
+                            const size_t i = rs[k]; const int q = rq[k]; const bool second = (i & 1) != 0; const int n = nof(i);
+                            ci.push_back(Qr2ComposeItem{G2[k]->p, V2[k]->p, X1[k]->p, GV[i]->p, second ? gitems[q].lam2 : gitems[q].lam1, second ? gitems[q].idx2 : gitems[q].idx1,
+                                                        gitems[q].info + (second ? 1 : 0), n, rank_tau(false, n), GVn[k]->p, GWn[k]->p, reinterpret_cast<int*>(d_rk->p) + k});
+                        }
+                        { const Qr2ComposeItem* d = upload(s, ci); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_qr2_compose(s->stream, d, (int)m); }
+                        for (size_t k = 0; k < m; ++k) {
+                            const size_t i = rs[k]; GateItem& it = gitems[rq[k]];
+                            GV[i] = GVn[k]; GW[i] = GWn[k]; s->keepalive.push_back(X1[k]); if (Q1[k]) s->keepalive.push_back(Q1[k]); s->keepalive.push_back(G2[k]); s->keepalive.push_back(V2[k]);
+                            if (i & 1) { it.GV2 = GV[i]->p; it.GW2 = GW[i]->p; it.chol2 = 2; it.rk2 = reinterpret_cast<int*>(d_rk->p) + k; }
+                            else { it.GV1 = GV[i]->p; it.GW1 = GW[i]->p; it.chol1 = 2; it.rk1 = reinterpret_cast<int*>(d_rk->p) + k; }
+                        }
+                        s->keepalive.push_back(d_rk);
+                        d_gitems = upload(s, gitems);
+                        // gate_theta reads the first-pass (lambda, idx, r) of the untouched partner site again and overwrites them with the same values
+                        run_theta();
+                        if (npg) HIPCHK(hipMemcpyAsync(hinfo.data(), d_info_all->p, (size_t)npg * 32, hipMemcpyDeviceToHost, s->stream));
+                        HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
+                        for (size_t k = 0; k < m; ++k) s->stats.n_qr2_sites += sj[rs[k]].owned ? 1 : 0;
+                    }
                 }
             }
+            svd_and_finish(hinfo.data());
+            read_results();
         }
+        HostTimer ht_b(4);
         for (size_t i = 0; i < envs.size(); ++i)
             if (h_flags[2 * i + 1]) throw Err(TNQS_ERR_NUMERIC, "simple_update: incoming message has a negative eigenvalue above sqrt_cutoff (DomainError in the reference, src/utils.jl:21)");
-        std::vector<JacobiItem> ji; std::vector<int> ncfull;
         for (int q = 0; q < npg; ++q) {
-            int gi = pg[q];
-            int r1 = hinfo[8 * q], r2 = hinfo[8 * q + 1];
-            int Mr = r1 * gitems[q].d1, Nc = r2 * gitems[q].d2;
-            if (Mr < Nc) std::swap(Mr, Nc);        // wide theta is stored as its adjoint (gate_theta_kernel)
-            const int ncolJ = hinfo[8 * q + 7] > 0 ? hinfo[8 * q + 7] : Nc;      // low-rank route: the SVD runs on M (Mr x K), same U and Sigma
-            ji.push_back(JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, ncolJ, gitems[q].info + 4});
-            ncfull.push_back(Nc); s->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0;
+            int Mr, Nc, ncolJ; theta_dims(hinfo.data() + 8 * q, gitems[q].d1, gitems[q].d2, Mr, Nc, ncolJ);
+            s->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0;
+            for (int k = 0; k < 8; ++k) info[8 * pg[q] + k] = hinfo[8 * q + k]; terr[pg[q]] = hterr[q];
         }
-        // LDS residency: A and V if both fit; A only (V recovered from the unrotated copy) if only A fits; else global memory
-        size_t lds_av = 0, lds_a = 0;
-        for (auto& j : ji) { lds_av = std::max(lds_av, jacobi_lds_bytes(j.m, j.n, true, esz)); lds_a = std::max(lds_a, jacobi_lds_bytes(j.m, j.n, false, esz)); }
-        const bool novee = theta0_used;
-        if (novee) for (auto& j : ji) j.V = nullptr;
-        (void)lds_av; (void)lds_a;
-        { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); svd_batch<T>(s, ji, !novee); }
-        if (novee) {
-            std::vector<RecoverItem> rv;
-            for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ncfull[q], ji[q].n});
-            const RecoverItem* dr = upload(s, rv);
-            { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); { int nmax = 1; for (int nc : ncfull) nmax = std::max(nmax, nc); if (std::is_same<T, float>::value && use_mfma()) launch_recover_v_mfma(s->stream, dr, npg, nmax); else launch_recover_v<T>(s->stream, dr, npg, nmax); } }
-        }
-        { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
-        std::vector<double> hterr(std::max(1, npg));
-        const int* st_info2 = npg ? readback<int>(s, d_info_all->p, (size_t)npg * 8) : nullptr;
-        const double* st_terr = npg ? readback<double>(s, d_terr_all->p, (size_t)npg) : nullptr;
-        ht_b.stop();
-        HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
-        if (npg) { std::copy(st_info2, st_info2 + (size_t)npg * 8, hinfo.begin()); std::copy(st_terr, st_terr + npg, hterr.begin()); }
-        for (int q = 0; q < npg; ++q) { for (int k = 0; k < 8; ++k) info[8 * pg[q] + k] = hinfo[8 * q + k]; terr[pg[q]] = hterr[q]; }
     }
     // ---- 4b. sharded: the owner of the first vertex publishes (chi', status, truncerr, S, X2) of each gate ----------------
     std::vector<const double*> Sptr(ng, nullptr);

@@ -324,7 +324,9 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restri
     const JacobiItem it = items[blockIdx.x];
     cx<T>* A = reinterpret_cast<cx<T>*>(it.A);
     cx<T>* V = reinterpret_cast<cx<T>*>(it.V);
-    const int m = it.m, n = it.n;
+    int m_ = it.m, n_ = it.n;
+    if (it.dyn) { int nf; theta_dims(it.dyn, it.dm, it.dn, m_, nf, n_); }
+    const int m = m_, n = n_;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int ne = n + (n & 1);
     const T tol = eps_of<T>() * sqrt((T)(m > 4 ? m : 4));
@@ -581,7 +583,9 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     const JacobiItem it = items[blockIdx.x];
     cx<T>* Ag = reinterpret_cast<cx<T>*>(it.A);
     cx<T>* Vg = reinterpret_cast<cx<T>*>(it.V);
-    const int m = it.m, n = it.n;
+    int m_ = it.m, n_ = it.n;
+    if (it.dyn) { int nf; theta_dims(it.dyn, it.dm, it.dn, m_, nf, n_); }      // dimensions found on the device (JacobiItem::dyn)
+    const int m = m_, n = n_;
     const int mp = m + 2, np_ = n + 2;     // padded column pitches
     cx<T>* A = reinterpret_cast<cx<T>*>(smem);
     cx<T>* V = A + (size_t)mp * n;
@@ -630,10 +634,12 @@ __global__ __launch_bounds__(512) void recover_v_kernel(const RecoverItem* __res
     const cx<T>* A0 = reinterpret_cast<const cx<T>*>(it.A0);
     const cx<T>* A = reinterpret_cast<const cx<T>*>(it.A);
     cx<T>* V = reinterpret_cast<cx<T>*>(it.V);
-    const int m = it.m, n = it.n;
+    int m_ = it.m, n_ = it.n, nu_ = it.nu;
+    if (it.dyn) theta_dims(it.dyn, it.dm, it.dn, m_, n_, nu_);
+    const int m = m_, n = n_, nu = nu_;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int u = blockIdx.y * 8 + w;
-    if (u >= it.nu) return;
+    if (u >= nu) return;
     double are[R], aim[R], s2 = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -44,7 +44,17 @@ struct MsgFinalItem {     // BP epilogue: reduce partials, m /= sum(m), message_
 
 struct JacobiItem {       // one-sided Jacobi on A (m x n, col-major, ld = m); V (n x n) accumulates the rotations (null: not wanted)
     void* A; void* V; int m; int n; int* sweeps_out;
+    // dyn != null: the dimensions are decided ON THE DEVICE by an earlier kernel of the same stream (the theta of a gate: ranks of the two
+    // R factors) and read from its info array (GateItem::info) -- m, n above are then upper bounds the host sized the launch with.  This
+    // is what lets a gate batch run from the Gram matrices to the truncated factors without a host round trip in between.
+    const int* dyn; int dm, dn;
 };
+// dimensions of a gate's theta SVD from its info array (gate_theta_kernel): rows, columns of theta, columns the Jacobi runs on
+__host__ __device__ inline void theta_dims(const int* info, int d1, int d2, int& m, int& nfull, int& ncol) {
+    int Mr = info[0] * d1, Nc = info[1] * d2;
+    if (Mr < Nc) { const int t = Mr; Mr = Nc; Nc = t; }        // a wide theta is stored as its adjoint
+    m = Mr; nfull = Nc; ncol = info[7] > 0 ? info[7] : Nc;     // low-rank route: the SVD runs on M (Mr x K)
+}
 
 struct EnvItem {          // env message -> Hermitian f64 matrix H (= (M + M^dagger)/2), V = I
     const void* msg; void* H; void* V; int n;
@@ -135,7 +145,7 @@ template <class T, class Acc> void launch_gram(hipStream_t s, const GramItem* d_
                                                int TR, int KKmax);
 template <class Acc, class Out> void launch_reduce(hipStream_t s, const ReduceItem* d_items, int nitems, int total_elems);
 template <class T> void launch_msg_finalize(hipStream_t s, const MsgFinalItem* d_items, int nitems);
-struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; int nu; };   // V (n x nu) = A0^dagger (U Sigma) Sigma^-2; A0: m x n, U Sigma: m x nu
+struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; int nu; const int* dyn; int dm, dn; };   // dyn: as in JacobiItem   // V (n x nu) = A0^dagger (U Sigma) Sigma^-2; A0: m x n, U Sigma: m x nu
 // LDS bytes the LDS-resident Jacobi needs for an m x n matrix (columns padded by 2 elements)
 inline size_t jacobi_lds_bytes(int m, int n, bool withV, size_t esz) { return ((size_t)(m + 2) * n + (withV ? (size_t)(n + 2) * n : 0)) * esz; }
 template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax);

@@ -1230,17 +1230,19 @@ __global__ __launch_bounds__(256) void recover_v_mfma_kernel(const RecoverItem* 
     const cf* __restrict__ A0 = reinterpret_cast<const cf*>(it.A0);
     const cf* __restrict__ A = reinterpret_cast<const cf*>(it.A);
     cf* __restrict__ V = reinterpret_cast<cf*>(it.V);
-    const int m = it.m, n = it.n;
+    int m_ = it.m, n_ = it.n, nu_ = it.nu;
+    if (it.dyn) theta_dims(it.dyn, it.dm, it.dn, m_, n_, nu_);      // dimensions found on the device (RecoverItem::dyn)
+    const int m = m_, n = n_, nu = nu_;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, ln = lane & 31, h = lane >> 5;
     const int nt = (n + 31) >> 5;
     const int tile = blockIdx.y * 4 + w;
-    if (tile >= nt * nt) return;
+    if (tile >= nt * nt || n < 1 || nu < 1) return;
     const int c0 = 32 * (tile % nt), u0 = 32 * (tile / nt);
     const int col = c0 + ln, u = u0 + ln;
     const cf* pa = A0 + (size_t)m * min(col, n - 1);
-    const cf* pb = A + (size_t)m * min(u, it.nu - 1);
-    if (u0 >= it.nu) return;
-    const bool okc = col < n, oku = u < it.nu;
+    const cf* pb = A + (size_t)m * min(u, nu - 1);
+    if (u0 >= nu) return;
+    const bool okc = col < n, oku = u < nu;
     v16f Cr, Ci;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }

@@ -543,7 +543,11 @@ def test_symmetric_gauge_matches_oracle(dtype, lattice):
     for (a, b) in g.edges[:6]:
         for d in ((a, b), (b, a)):
             m0, m1 = sg.message(d), up.message(d)
-            assert np.max(np.abs(m0 / np.trace(m0) - m1 / np.trace(m1))) < 50 * tol
+            # diag(S) is a fixed point only up to sqrt(regularization): symmetric_gauge adds 10 eps to the message eigenvalues before the
+            # roots (symmetric_gauge.jl:1,15-16), so a rank-deficient message (a leaf of the comb with chi = 3 > d = 2) gets a singular value
+            # sqrt(10 eps) = 1.1e-3 in ComplexF32 where the BP fixed point has an exact zero -- the reference's own behaviour
+            fp_tol = max(50 * tol, 2 * np.sqrt(10 * np.finfo(np.float32 if dtype == np.complex64 else np.float64).eps))
+            assert np.max(np.abs(m0 / np.trace(m0) - m1 / np.trace(m1))) < fp_tol
     for v in g.vertices[:4]:
         assert abs(tn.expect(sg, ("Z", [v])) - o.expect_1site(oc, Z, v)) < 50 * tol
     # the input cache is untouched; the TensorNetworkState entry point runs BP itself
