@@ -198,6 +198,32 @@ def _keep_big_blocks_on_the_heap():
         return False
 
 
+class parallel_oracle:
+    """context manager for callers other than measure() (the parity tests at the 268 MB-per-site shapes): a thread pool for update() /
+    apply_layer(), single-threaded BLAS per call, every site-tensor contraction on the copy-free batched-matmul path; restores the
+    oracle's module state on exit.  `with parallel_oracle() as pool: bpc = update(bpc, pool, ...)`"""
+
+    def __init__(self, nthreads: Optional[int] = None):
+        self.nthreads = nthreads or max(1, min(64, (os.cpu_count() or 2) // 2))
+
+    def __enter__(self):
+        from threadpoolctl import threadpool_limits
+        if os.environ.get("TNQS_CPU_NO_MALLOPT") != "1":
+            _keep_big_blocks_on_the_heap()
+        self._saved = (o._POOL, o._BIG)
+        o._POOL, o._BIG = _Serial(), 1 << 12
+        self._pool = ThreadPoolExecutor(max_workers=self.nthreads)
+        self._limits = threadpool_limits(limits=1)
+        self._limits.__enter__()
+        return self._pool
+
+    def __exit__(self, *exc):
+        self._limits.__exit__(*exc)
+        self._pool.shutdown()
+        o._POOL, o._BIG = self._saved
+        return False
+
+
 def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int = 1234, nlayers: int = 1) -> dict:
     """one TFIM layer (README.md:42-48 angles) on an L x L PERIODIC torus -- every site has the bulk degree 4, L^2 sites, 2 L^2 edges, four
     colours for even L -- at bond dimension chi, ComplexF32, from BP-converged messages, reference-default bp_update_kwargs."""

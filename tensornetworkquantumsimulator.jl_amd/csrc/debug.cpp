@@ -23,13 +23,16 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
     size_t lds_av = jacobi_lds_bytes(m, n, true, esz), lds_a = jacobi_lds_bytes(m, n, false, esz);
     const char* fg = std::getenv("TNQS_DBG_NOV_GLOBAL");      // the engine's combination for matrices beyond the LDS: global-memory kernel, V recovered
     const bool force_global_nov = fg && fg[0] == '1';
-    const bool nov = force_global_nov || (lds_av > lim && lds_a <= lim);
+    const char* ft = std::getenv("TNQS_DBG_THETA_SVD");       // the engine's theta route: launch_theta_svd (Gram route where the shape allows), V recovered
+    const bool theta_route = ft && ft[0] == '1' && dtype == TNQS_C64 && lds_a <= lim;
+    const bool nov = force_global_nov || theta_route || (lds_av > lim && lds_a <= lim);
     DBuf dA0((size_t)m * n * esz);
     if (nov) dA0.up(A, (size_t)m * n * esz);
     JacobiItem it{dA.p, nov ? nullptr : dV.p, m, n, (int*)dS.p};
     dI.up(&it, sizeof(it));
     size_t lds = force_global_nov ? 0 : (nov ? lds_a : (lds_av <= lim ? lds_av : 0));
-    if (dtype == TNQS_C64) launch_jacobi<float>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n)); else launch_jacobi<double>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n));
+    if (theta_route && launch_theta_svd(nullptr, (const JacobiItem*)dI.p, 1, 60, lds_a, std::max(m, n), n)) {}
+    else if (dtype == TNQS_C64) launch_jacobi<float>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n)); else launch_jacobi<double>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n));
     if (nov) {
         DBuf dRv(sizeof(RecoverItem)); RecoverItem rv{dA0.p, dA.p, dV.p, m, n, n}; dRv.up(&rv, sizeof(rv));
         if (dtype == TNQS_C64) launch_recover_v_mfma(nullptr, (const RecoverItem*)dRv.p, 1, n); else launch_recover_v<double>(nullptr, (const RecoverItem*)dRv.p, 1, n);

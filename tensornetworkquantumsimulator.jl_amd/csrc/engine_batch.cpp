@@ -164,7 +164,10 @@ template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, 
     if (!fit.empty()) {
         size_t lds = 0; for (auto& j : fit) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, with_v, esz));
         const JacobiItem* d = upload(s, fit);
-        launch_jacobi<T>(s->stream, d, (int)fit.size(), 60, lds, mmax_of(fit));
+        static const bool grameig = !envflag("TNQS_NO_GRAMEIG");          // A/B: theta SVD by one-sided Jacobi on theta itself
+        int nmax = 1; for (auto& j : fit) nmax = std::max(nmax, j.n);
+        if (!(std::is_same<T, float>::value && !with_v && grameig && launch_theta_svd(s->stream, d, (int)fit.size(), 60, lds, mmax_of(fit), nmax)))
+            launch_jacobi<T>(s->stream, d, (int)fit.size(), 60, lds, mmax_of(fit));
     }
     if (!rest.empty()) {
         const JacobiItem* d = upload(s, rest);
@@ -226,11 +229,15 @@ template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& job
     size_t KKmax = 1;
     for (auto& j : jobs) { j.KK = (j.keep_site ? j.sd.d : 1) * (j.leg >= 0 ? j.sd.chi[j.leg] : 1); KKmax = std::max<size_t>(KKmax, j.KK); }
     int TR = pick_TR(KKmax + 1, esz, 2);
-    const bool fused = jobs[0].M != nullptr;
+    // M set: the BP Gram absorbs the first row leg (f32 accumulation, mfma_gram32_fused_kernel); the gate-path Gram (f64 accumulation)
+    // absorbs the last gauge leg (mfma_gauge_gram64_kernel) -- a batch is one or the other
+    const bool gauge_fused = jobs[0].M != nullptr && std::is_same<T, float>::value && std::is_same<Acc, double>::value;
+    const bool fused = jobs[0].M != nullptr && !gauge_fused;
     const bool mf = fused || (std::is_same<T, float>::value && std::is_same<Acc, float>::value && use_mfma() && KKmax <= (use_gram64() ? 64 : 32) && KKmax >= 8);
     bool mf64 = std::is_same<T, float>::value && std::is_same<Acc, double>::value && use_mfma() && KKmax <= 64 && KKmax >= 16;
     bool mf128 = std::is_same<T, float>::value && std::is_same<Acc, double>::value && use_mfma() && use_gram128() && KKmax <= 128 && KKmax > 64;
     for (auto& j : jobs) { mf64 = mf64 && (j.X == j.Y); mf128 = mf128 && (j.X == j.Y); }
+    if (gauge_fused) { mf64 = true; mf128 = false; }
     if (mf || mf64 || mf128) TR = 64;
     const int target = 2048;
     int per_item = std::max(1, target / (int)jobs.size());
@@ -253,11 +260,12 @@ template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& job
         j.partial = dalloc(s, (size_t)j.nchunks * j.KK * j.KK * 2 * sizeof(Acc));
         it.partial = j.partial->p; it.chunk_begin = chunks; chunks += it.nchunks;
         items.push_back(it);
-        bytes += (j.X == j.Y ? 1.0 : 2.0) * j.sd.n * esz; flops += 8.0 * j.sd.n * j.KK * (j.M ? 2.0 : 1.0);
+        bytes += (j.X == j.Y ? 1.0 : 2.0) * j.sd.n * esz; flops += gauge_fused ? 8.0 * j.sd.n * (j.KK + 32.0) : 8.0 * j.sd.n * j.KK * (j.M ? 2.0 : 1.0);
     }
     const GramItem* d = upload(s, items);
     ProfScope ps(s, cls, bytes, flops);
-    if (fused) launch_mfma_gram32_fused(s->stream, d, (int)items.size(), chunks);
+    if (gauge_fused) launch_mfma_gauge_gram64(s->stream, d, (int)items.size(), chunks);
+    else if (fused) launch_mfma_gram32_fused(s->stream, d, (int)items.size(), chunks);
     else if (mf64) { bool all64 = true; for (auto& j : jobs) all64 = all64 && j.KK == 64; launch_mfma_gram64_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax, all64); }
     else if (mf128) { bool all128 = true; for (auto& j : jobs) all128 = all128 && j.KK == 128; launch_mfma_gram128_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax, all128); }
     else if (mf) { if (KKmax <= 32) launch_mfma_gram32(s->stream, d, (int)items.size(), chunks, (int)KKmax); else launch_mfma_gram64(s->stream, d, (int)items.size(), chunks, (int)KKmax); }

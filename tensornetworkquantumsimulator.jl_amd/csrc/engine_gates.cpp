@@ -189,20 +189,36 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     std::vector<int> own_idx;                        // indices into sj of the owned sites
     for (size_t i = 0; i < sj.size(); ++i) if (sj[i].owned) own_idx.push_back((int)i);
     std::vector<Chain> chains(own_idx.size());
+    // bulk shape (d = 2, chi = 32, three gauged legs): the LAST gauge leg -- the fastest outer leg, which the two-leg kernel leaves over -- is
+    // absorbed inside the Gram kernel instead of in a pass of its own (kernels_gate.hip); fused_M[q] = its matrix
+    std::vector<const void*> fused_M(own_idx.size(), nullptr);
+    static const bool fuse_on = !envflag("TNQS_NO_GAUGE_GRAM");
     for (size_t q = 0; q < own_idx.size(); ++q) {
         const SiteJob& j = sj[own_idx[q]];
         Chain& c = chains[q]; c.v = j.v; c.src = s->site[j.v]->p; c.sd = j.sd;
         for (size_t e = 0; e < j.env_idx.size(); ++e) c.steps.push_back({j.env_leg[e], envs[j.env_idx[e]].msq});
+        if (fuse_on && std::is_same<T, float>::value && use_mfma() && use_pair() && c.steps.size() == 3 && c.steps[0].first == (j.bleg == 0 ? 1 : 0) &&
+            j.sd.n / ((size_t)j.sd.d * j.sd.chi[j.bleg]) >= (size_t)j.sd.d * j.sd.chi[j.bleg] &&
+            gauge_gram64_covers(j.sd.d, j.sd.z, j.sd.chi.data(), j.bleg, c.steps[0].first)) {
+            fused_M[q] = c.steps[0].second; c.steps.erase(c.steps.begin());
+        }
     }
     run_chains<T>(s, chains, TNQS_PROF_GATE_MODEPROD);
     // ---- 3. G = psi~^dagger psi~ over the outer legs, f64 accumulation (replaces the thin QR, simple_update.jl:45-48) --
     std::vector<GramJob> jobs;
     for (size_t q = 0; q < own_idx.size(); ++q) {
         const SiteJob& sjq = sj[own_idx[q]];
-        GramJob j{}; j.X = chains[q].result; j.Y = chains[q].result; j.sd = sjq.sd; j.leg = sjq.bleg; j.keep_site = true;
+        GramJob j{}; j.X = chains[q].result; j.Y = chains[q].result; j.sd = sjq.sd; j.leg = sjq.bleg; j.keep_site = true; j.M = fused_M[q];
         jobs.push_back(j);
     }
-    run_grams<T, double>(s, jobs, TNQS_PROF_GATE_GRAM);
+    {   // the fused and the plain Gram are different kernels: two batches, job order kept
+        std::vector<GramJob> jf, jp; std::vector<size_t> idf, idp;
+        for (size_t q = 0; q < jobs.size(); ++q) { if (jobs[q].M) { jf.push_back(jobs[q]); idf.push_back(q); } else { jp.push_back(jobs[q]); idp.push_back(q); } }
+        run_grams<T, double>(s, jf, TNQS_PROF_GATE_GRAM);
+        run_grams<T, double>(s, jp, TNQS_PROF_GATE_GRAM);
+        for (size_t q = 0; q < jf.size(); ++q) jobs[idf[q]] = jf[q];
+        for (size_t q = 0; q < jp.size(); ++q) jobs[idp[q]] = jp[q];
+    }
     std::vector<Buf> GA(sj.size()), GV(sj.size());
     auto nof = [&](size_t i) { return sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]; };
     // G slots: in the sharded case every rank needs G1 and G2 of the gates it takes part in -> all-gather all of them (the same layout

@@ -149,6 +149,9 @@ struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; int n
 // LDS bytes the LDS-resident Jacobi needs for an m x n matrix (columns padded by 2 elements)
 inline size_t jacobi_lds_bytes(int m, int n, bool withV, size_t esz) { return ((size_t)(m + 2) * n + (withV ? (size_t)(n + 2) * n : 0)) * esz; }
 template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax);
+// ComplexF32 theta SVD without V (kernels.hip, theta_svd_kernel): through the f64 Gram matrix where the shape allows (n <= 64 <= m), the
+// LDS-resident one-sided sweeps otherwise; false: the batch does not fit the LDS (the caller uses launch_jacobi)
+bool launch_theta_svd(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax, int nmax);
 // sites with fewer fibers than columns (N < n = d*chi): the R factor comes from a one-sided Jacobi SVD of the n x N matrix
 // M[(s,b), outer] = conj(psi~[outer,(s,b)]) (f64) instead of the eigen factorisation of the rank-deficient n x n Gram matrix
 struct SmallSvdItem { const void* src; void* M; void* GA; void* GV; int d, low, chi_b, hi; };   // low = pre(b)/d, hi = post(b); n = d*chi_b, N = low*hi
@@ -302,6 +305,10 @@ bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int 
 void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
 // Gram with f64 accumulation on the f64 matrix cores (gate path: G = psi~^dagger psi~, D*K == 64, X == Y); tiles of 64 fibers
 bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax, bool all_kk64 = false);   // all_kk64: every item has D * K = 64
+// the third gauge leg absorbed inside the f64 Gram (kernels_gate.hip): GramItem::M = the 32 x 32 matrix of the fastest outer leg `rleg`; same
+// tiles and partial layout as launch_mfma_gram64_f64 (2 partials per chunk)
+bool gauge_gram64_covers(int d, int z, const int* chi, int bleg, int rleg);
+void launch_mfma_gauge_gram64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
 // the same for 64 < D*K <= 128 (chi = 64 sites; kernels_chi64.hip); writes ONE partial per chunk
 bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax, bool all_kk128 = false);   // all_kk128: every item has D * K = 128
 // fused pair of mode products on two slow 32-dim legs (16 companions = 128-byte runs per workgroup)

@@ -411,6 +411,42 @@ def test_c4_shape_bp_and_layer_match_oracle():
     compare_with_oracle_after_layer(g, bd, bo, ed, eo, "C4 shape, one layer")
 
 
+def test_c4_periodic_cubic_layer_matches_oracle():
+    """BASELINE configs[3] on its own lattice type: the 3x3x3 PERIODIC cubic lattice at chi = 16, ComplexF32 (27 degree-6 sites of 268 MB, 81
+    edges, 7 colours) -- the oracle iterating its OWN messages, no stand-in graph.  The oracle's arithmetic runs through oracle/cpu_layer.py
+    (the same functions, the messages of a dependency level and the gates of a colour group on a thread pool), which makes a sweep a matter
+    of a minute on the GPU box's host.  (i) two BP sweeps in a common explicit order from unset messages: every message elementwise;
+    (ii) one layer of the 3-D Ising circuit (examples/3dIsing_dynamics.jl:15-26: Rz on every vertex, Rxx per colour) with one BP sweep per
+    update: bond dimensions, truncation errors, <Z>, message spectra."""
+    import tnqs_oracle as o
+    import cpu_layer
+    from helpers import to_oracle_state
+    g = tn.named_grid((3, 3, 3), periodic=True)
+    assert all(g.degree(v) == 6 for v in g.vertices) and g.ne() == 81
+    chi = 16
+    psi = small_norm_state(g, chi, seed=33)
+    groups = tn.edge_color(g)
+    seq = []
+    for grp in groups:
+        seq += list(grp) + [(b, a) for (a, b) in grp]
+    bd = tn.update(tn.BeliefPropagationCache(psi), edge_sequence=seq, maxiter=2, tolerance=None)
+    J, h, dt = -1.0, -1.0, 0.04
+    one_site = [("Rz", [v], h * dt) for v in g.vertices]
+    colour_groups = [[("Rxx", [a, b], 2 * J * dt) for (a, b) in grp] for grp in groups]
+    layer = one_site + [gt for grp in colour_groups for gt in grp]
+    kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+    with cpu_layer.parallel_oracle() as pool:
+        bo = o.BeliefPropagationCache(to_oracle_state(psi), edge_sequence=seq)
+        bo = cpu_layer.update(bo, pool, maxiter=2, tolerance=None)
+        w = messages_elementwise(bd, bo, g, 5e-5)
+        print(f"C4 lattice (3x3x3 periodic), two BP sweeps: messages elementwise to {w:.1e}")
+        info = {}
+        bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=dict(edge_sequence=seq, maxiter=1, tolerance=None), info=info)
+        bo, eo, _ = cpu_layer.apply_layer(bo, one_site, colour_groups, pool, kw, dict(maxiter=1, tolerance=None))
+    assert info["n_updates"] == len(groups) + 1 and info["n_two_site"] == g.ne()
+    compare_with_oracle_after_layer(g, bd, bo, ed[len(one_site):], eo, "C4 lattice (3x3x3 periodic), one layer")
+
+
 def test_c5_shape_bp_and_layer_match_oracle():
     """BASELINE configs[4] per-site shape (degree 4, chi = 64, ComplexF32; 268 MB bulk tensor, 256 x 256 theta) on a 3x3 grid, the oracle
     iterating its own messages: two BP sweeps elementwise, then one full TFIM layer (Rx, Rzz per colour, two sweeps per update)."""

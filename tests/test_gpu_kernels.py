@@ -270,3 +270,31 @@ def test_jacobi_svd_is_scale_invariant(shape, rank, scale):
     if scale >= 1e-15:                                   # V is recovered by an f32 GEMM of theta0 with U Sigma: its products underflow below ~1e-18;
         rec = (A.astype(np.complex128) @ V.conj().T.astype(np.complex128))      # inside the engine theta is scaled to O(1) first (theta_scale_kernel)
         assert np.max(np.abs(rec - b)) < 2e-5 * s_ref[0]
+
+
+@pytest.mark.parametrize("shape,rank", [((128, 64), 64), ((128, 64), 20), ((128, 40), 40), ((64, 64), 64), ((100, 33), 33), ((256, 64), 48), ((72, 8), 8),
+                                        ((130, 70), 70), ((40, 40), 3)])
+@pytest.mark.parametrize("scale", [1e-9, 1.0, 1e6])
+def test_theta_svd_kernel(shape, rank, scale, monkeypatch):
+    """the engine's theta SVD kernel (theta_svd_kernel: f64 Gram matrix + Jacobi eigen + U Sigma = A W accumulated in f64 for n <= 64 <= m,
+    one-sided f32 sweeps otherwise), V recovered from the unrotated copy as in the engine: singular values against LAPACK relative to the
+    largest one, the reconstruction A = (U Sigma) V^dagger, and -- what the V recovery depends on -- the orthogonality of the columns of U Sigma
+    relative to their OWN norms, for full-rank, rank-deficient and badly scaled inputs"""
+    monkeypatch.setenv("TNQS_DBG_THETA_SVD", "1")
+    rng = np.random.default_rng(shape[0] + 7 * rank)
+    m, n = shape
+    dec = np.exp(-np.arange(rank) * (8.0 / max(rank, 1)))                    # singular values spread over 3.5 decades, as a truncating theta has them
+    q1, _ = np.linalg.qr(rnd(rng, (m, rank), np.complex128)); q2, _ = np.linalg.qr(rnd(rng, (n, rank), np.complex128))
+    b = ((q1 * dec) @ q2.conj().T * scale).astype(np.complex64)
+    s_ref = np.linalg.svd(b.astype(np.complex128), compute_uv=False)
+    A, V, sw = jacobi(b, 0)
+    A = A.astype(np.complex128)
+    nrm = np.linalg.norm(A, axis=0)
+    s = np.sort(nrm)[::-1]
+    assert sw < 60
+    assert np.max(np.abs(s[:len(s_ref)] - s_ref)) < 2e-6 * s_ref[0], (s[:4], s_ref[:4])
+    big = nrm > 1e-4 * s_ref[0]                                             # columns that carry signal: mutually orthogonal relative to their own norms
+    U = A[:, big] / nrm[big]
+    assert np.max(np.abs(U.conj().T @ U - np.eye(U.shape[1]))) < 5e-6
+    rec = A @ V.conj().T.astype(np.complex128)
+    assert np.max(np.abs(rec - b)) < 2e-5 * s_ref[0]

@@ -41,7 +41,7 @@ def test_lowrank_theta_route_matches_the_full_svd():
 
 @pytest.mark.parametrize("switch", ["TNQS_NO_CHOL", "TNQS_NO_SMALLSVD", "TNQS_JACOBI_GLOBAL", "TNQS_NO_PAIR", "TNQS_NO_TSHARE", "TNQS_NO_FUSED_GRAM",
                                     "TNQS_NO_APPLY64", "TNQS_NO_MFMA", "TNQS_EAGER_SCALE", "TNQS_NO_PREFIX", "TNQS_NO_ROWGEMM32", "TNQS_NO_3M",
-                                    "TNQS_TWO_ROUNDTRIPS"])
+                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_GRAMEIG"])
 def test_alternative_routes_match_the_default(switch):
     """every documented switch selects an alternative route of the same algorithm: all-eigen factorisation instead
     of Cholesky, Gram-eigen instead of the small-SVD route, global-memory Jacobi, single-leg mode products, per-message BP products,
@@ -69,6 +69,22 @@ def test_staging_arena_overflow_keeps_descriptors_alive():
         assert ref[name]["dims"] == alt[name]["dims"], name
         assert ref[name]["errs"] == alt[name]["errs"], name
         assert ref[name]["z"] == alt[name]["z"], name
+
+
+@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_GRAMEIG"])
+def test_bulk_shape_routes_match(switch):
+    """the chi = 32 bulk shape (BASELINE configs[1]): the third gauge leg absorbed inside the f64 Gram kernel (kernels_gate.hip) against the
+    separate single-leg pass + plain Gram; ranks of the R factors left on the device against read back; three- against four-multiplication
+    products.  Same bond dimensions, truncation errors (relative), <Z> and message spectra to 1e-5."""
+    ref, alt = run_worker({}, "chi32"), run_worker({switch: "1"}, "chi32")
+    assert ref["dims"] == alt["dims"]
+    ea, eb = np.array(ref["errs"]), np.array(alt["errs"])
+    assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7), float(np.max(np.abs(ea - eb)))
+    dz = float(np.max(np.abs(np.array(ref["z"]) - np.array(alt["z"])))); dsp = float(np.max(np.abs(np.array(ref["spectra"]) - np.array(alt["spectra"]))))
+    print(switch, "max |dZ|", dz, " spectra", dsp, " max |derr|", float(np.max(np.abs(ea - eb))))
+    assert dz < 1e-5 and dsp < 1e-5
+    if switch == "TNQS_NO_GAUGE_GRAM":      # the fused route must actually have been taken: it saves the single-leg launches of the gauge
+        assert ref["modeprod_launches"] < alt["modeprod_launches"] and ref["gram_launches"] > alt["gram_launches"]
 
 
 def test_torch_can_be_imported_after_the_library():

@@ -48,7 +48,30 @@ def chi64phys():
     print(json.dumps(dict(errs=errs_all, z=z_all, dims=dims, tall=tall, norm=float(np.linalg.norm(bpc.tensor((2, 2)))))))
 
 
+def chi32():
+    """BASELINE configs[1] per-site shape on a 4x4 lattice (the four inner sites are bulk sites: degree 4, chi = 32, three gauged legs): one
+    benchmark-style TFIM layer from a random chi = 32 state"""
+    g = tn.named_grid((4, 4)); chi = 32
+    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex64, lambda v: "↑", g))
+    rng = np.random.default_rng(11)
+    for v in g.vertices:
+        shp = (2,) + (chi,) * g.degree(v); n = int(np.prod(shp))
+        bpc._set_tensor(v, rng.standard_normal(2 * n, dtype=np.float32).view(np.complex64).reshape(shp) / np.float32(np.sqrt(n)))
+    bpc = tn.update(bpc, maxiter=3, tolerance=None)
+    layer = [("Rx", [v], 0.05) for v in g.vertices] + [("Rzz", [a, b], 0.3) for grp in tn.edge_color(g, 4) for (a, b) in grp]
+    tn.profile_enable(bpc, True)
+    b2, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True), bp_update_kwargs=dict(maxiter=3, tolerance=None))
+    prof = tn.profile_get(b2)
+    sp = []
+    for (a, b) in g.edges:
+        m = b2.message((a, b)).astype(np.complex128); w = np.linalg.eigvalsh((m + m.conj().T) / 2); sp += (w / w.sum()).tolist()
+    print(json.dumps(dict(errs=errs.tolist(), z=[float(np.real(x)) for x in tn.expect_all(b2, "Z")], dims=[b2.bond_dim(a, b) for a, b in g.edges], spectra=sp,
+                          modeprod_launches=prof["gate_modeprod"]["launches"], gram_launches=prof["gate_gram"]["launches"])))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "chi32":
+        return chi32()
     if len(sys.argv) > 1 and sys.argv[1] == "cubic16":
         return cubic16()
     if len(sys.argv) > 1 and sys.argv[1] == "chi64phys":
