@@ -9,6 +9,9 @@ extern "C" {
 #endif
 /* one-sided Jacobi on A (m x n): on return A = U*Sigma (columns), V (n x n) with A_in = (U Sigma) V^dagger. dtype: 0 c64, 1 c128 */
 int tnqs_dbg_jacobi(int dtype, int m, int n, void* A_inout, void* V_out, int* sweeps_out);
+/* Cholesky of a Hermitian positive definite n x n complex128 matrix (n <= 128): L lower with G = L L^dagger, W = (L^-1)^dagger; *fail = 1 when a
+ * pivot fell to tau * max diagonal or below */
+int tnqs_dbg_chol(int n, const void* G, void* L_out, void* W_out, int* fail_out, double tau);
 /* out[(s',n),(a,b)] = sum_{(s,k)} in[(s,k),(a,b)] X[(s,k),(s',n)] with in element (s,a,k,b) at s + D*(a + PA*(k + K*b)) */
 int tnqs_dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, const void* in, const void* X, void* out,
                         double* norm2_out, int use_mfma);

@@ -23,7 +23,7 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
     size_t lds_av = jacobi_lds_bytes(m, n, true, esz), lds_a = jacobi_lds_bytes(m, n, false, esz);
     const char* fg = std::getenv("TNQS_DBG_NOV_GLOBAL");      // the engine's combination for matrices beyond the LDS: global-memory kernel, V recovered
     const bool force_global_nov = fg && fg[0] == '1';
-    const char* ft = std::getenv("TNQS_DBG_THETA_SVD");       // the engine's theta route: launch_theta_svd (Gram route where the shape allows), V recovered
+    const char* ft = std::getenv("TNQS_DBG_THETA_SVD");       // the engine's theta route: A only in LDS, V recovered from the unrotated copy
     const bool theta_route = ft && ft[0] == '1' && dtype == TNQS_C64 && lds_a <= lim;
     const bool nov = force_global_nov || theta_route || (lds_av > lim && lds_a <= lim);
     DBuf dA0((size_t)m * n * esz);
@@ -31,8 +31,7 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
     JacobiItem it{dA.p, nov ? nullptr : dV.p, m, n, (int*)dS.p};
     dI.up(&it, sizeof(it));
     size_t lds = force_global_nov ? 0 : (nov ? lds_a : (lds_av <= lim ? lds_av : 0));
-    if (theta_route && launch_theta_svd(nullptr, (const JacobiItem*)dI.p, 1, 60, lds_a, std::max(m, n), n)) {}
-    else if (dtype == TNQS_C64) launch_jacobi<float>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n)); else launch_jacobi<double>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n));
+    if (dtype == TNQS_C64) launch_jacobi<float>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n)); else launch_jacobi<double>(nullptr, (const JacobiItem*)dI.p, 1, 60, lds, std::max(m, n));
     if (nov) {
         DBuf dRv(sizeof(RecoverItem)); RecoverItem rv{dA0.p, dA.p, dV.p, m, n, n}; dRv.up(&rv, sizeof(rv));
         if (dtype == TNQS_C64) launch_recover_v_mfma(nullptr, (const RecoverItem*)dRv.p, 1, n); else launch_recover_v<double>(nullptr, (const RecoverItem*)dRv.p, 1, n);
@@ -41,6 +40,20 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
     HIPCHK(hipDeviceSynchronize());
     dA.down(A, (size_t)m * n * esz); dV.down(V, (size_t)n * n * esz);
     if (sweeps) dS.down(sweeps, 4);
+}
+
+// Cholesky kernels on one Hermitian n x n complex128 matrix: L (lower), W = (L^-1)^dagger, *fail; n <= 96: chol_kernel, else packed
+void dbg_chol(int n, const void* G, void* Lout, void* Wout, int* fail, double tau) {
+    need_gpu();
+    if (n < 1 || n > 128) throw Err(TNQS_ERR_INVALID, "dbg_chol: 1 <= n <= 128");
+    const size_t b = (size_t)n * n * 16;
+    DBuf dG(b), dL(b), dW(b), dF(4), dI(sizeof(CholItem));
+    dG.up(G, b); HIPCHK(hipMemset(dF.p, 0, 4)); HIPCHK(hipMemset(dW.p, 0, b));
+    CholItem it{dG.p, dL.p, dW.p, n, (int*)dF.p, tau, 0.0};
+    dI.up(&it, sizeof(it));
+    if (n <= 96) launch_chol(nullptr, (const CholItem*)dI.p, 1, n); else launch_chol_packed(nullptr, (const CholItem*)dI.p, 1, n);
+    HIPCHK(hipDeviceSynchronize());
+    dL.down(Lout, b); dW.down(Wout, b); dF.down(fail, 4);
 }
 
 static void tile_params(size_t PA, size_t PB, int TR, int& TA, int& TB, int& nta, int& ntb) {

@@ -164,10 +164,7 @@ template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, 
     if (!fit.empty()) {
         size_t lds = 0; for (auto& j : fit) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, with_v, esz));
         const JacobiItem* d = upload(s, fit);
-        static const bool grameig = !envflag("TNQS_NO_GRAMEIG");          // A/B: theta SVD by one-sided Jacobi on theta itself
-        int nmax = 1; for (auto& j : fit) nmax = std::max(nmax, j.n);
-        if (!(std::is_same<T, float>::value && !with_v && grameig && launch_theta_svd(s->stream, d, (int)fit.size(), 60, lds, mmax_of(fit), nmax)))
-            launch_jacobi<T>(s->stream, d, (int)fit.size(), 60, lds, mmax_of(fit));
+        launch_jacobi<T>(s->stream, d, (int)fit.size(), 60, lds, mmax_of(fit));
     }
     if (!rest.empty()) {
         const JacobiItem* d = upload(s, rest);

@@ -53,7 +53,6 @@ TNQS_SWITCH(use_gram128, !(envflag("TNQS_NO_GRAM128") || envflag("TNQS_NO_CHI64"
 TNQS_SWITCH(use_chol128, !(envflag("TNQS_NO_CHOL128") || envflag("TNQS_NO_CHI64")))      // Cholesky for 96 < n <= 128 (packed triangle)
 TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64")))     // Cholesky-QR preprocessed theta SVD
 #undef TNQS_SWITCH
-// TNQS_NO_GRAMEIG=1 (engine_batch.cpp): ComplexF32 theta SVD by one-sided Jacobi on theta itself instead of through its f64 Gram matrix (theta_svd_kernel);
 // TNQS_NO_GAUGE_GRAM=1 (engine_gates.cpp): bulk chi = 32 sites absorb their third gauge leg in a pass of its own instead of inside the f64 Gram kernel (kernels_gate.hip);
 // TNQS_TWO_ROUNDTRIPS=1 (engine_gates.cpp): a ComplexF32 gate batch reads the ranks of the R factors back before the theta SVD (round-2 flow) instead of
 // leaving them on the device (one host round trip per batch);  TNQS_ARENA_KB: size of the pinned staging arena (tests of its overflow path);

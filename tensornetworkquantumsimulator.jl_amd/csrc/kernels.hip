@@ -624,135 +624,6 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     if (threadIdx.x == 0 && it.sweeps_out) *it.sweeps_out = sweep;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// theta SVD through the Gram matrix (ComplexF32, V not wanted: the caller recovers it from the unrotated copy).  For an m x n matrix A
-// with n <= 64 <= m the workgroup forms G = A^dagger A in f64 (products of f32 numbers are exact in f64: G is the exact Gram matrix of
-// the data), diagonalises it with the LDS-resident Jacobi in f64 (G W = W Lambda, W accumulated from the rotations: unitary to 1e-15)
-// and writes U Sigma = A W, accumulated in f64 and rounded once -- every column is accurate relative to its OWN norm, which is what the
-// V recovery behind it needs.  Compared with one-sided Jacobi on A itself: half the rows per rotation, f64 headroom instead of the
-// underflow guards, and far fewer sweeps on these matrices (a Gram matrix of decaying spectrum is already almost diagonal-dominant in
-// the basis the sweeps find); directions below 1e-8 sigma_max are lost in G, sixteen times under the f32 rounding of A.
-// Any other shape (n > 64 after the device found the ranks, wide matrices) takes the f32 one-sided sweeps in the same kernel.
-// ------------------------------------------------------------------------------------------------------------
-template <int RQ>
-__global__ __launch_bounds__(1024) void theta_svd_kernel(const JacobiItem* __restrict__ items, int max_sweeps) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_rot;
-    __shared__ double s_red[17];
-    const JacobiItem it = items[blockIdx.x];
-    cx<float>* Ag = reinterpret_cast<cx<float>*>(it.A);
-    int m_ = it.m, n_ = it.n;
-    if (it.dyn) { int nf; theta_dims(it.dyn, it.dm, it.dn, m_, nf, n_); }
-    const int m = m_, n = n_;
-    const int tid = threadIdx.x;
-    if (n <= 64 && m >= n && n >= 2) {
-        const int np_ = n + 2;
-        cx<double>* G = reinterpret_cast<cx<double>*>(smem);            // n columns of pitch np_
-        cx<double>* W = G + (size_t)np_ * n;
-        cx<float>* As = reinterpret_cast<cx<float>*>(W);                // phase 1 staging (row-major rows of A) lives in W's space
-        const int rows_fit = (int)(((size_t)np_ * n * 16) / ((size_t)n * 8));        // rows of A that fit there: 2 (n + 2)
-        // ---- G = A^dagger A: thread -> entries e = tid, tid + 1024, ...; e = i + n j; lanes run along i (contiguous LDS reads), j is shared
-        cx<double> acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = cmake<double>(0.0, 0.0);
-        for (int r0 = 0; r0 < m; r0 += rows_fit) {
-            const int nr = min(rows_fit, m - r0);
-            __syncthreads();
-            for (int e = tid; e < nr * n; e += 1024) { const int r = e % nr, c = e / nr; As[c + n * r] = Ag[(r0 + r) + (size_t)m * c]; }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = tid + 1024 * q;
-                if (e < n * n) {
-                    const int i = e % n, j = e / n;
-                    double sr = 0, si = 0;
-                    for (int r = 0; r < nr; ++r) {
-                        const cx<float> a = As[i + n * r], b = As[j + n * r];
-                        sr += (double)a.re * b.re + (double)a.im * b.im;         // conj(a) b
-                        si += (double)a.re * b.im - (double)a.im * b.re;
-                    }
-                    acc[q].re += sr; acc[q].im += si;
-                }
-            }
-        }
-        __syncthreads();
-        double fro = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + 1024 * q;
-            if (e < n * n) { const int i = e % n, j = e / n; G[i + np_ * j] = acc[q]; W[i + np_ * j] = cmake<double>(i == j ? 1.0 : 0.0, 0.0); fro += acc[q].re * acc[q].re + acc[q].im * acc[q].im; }
-        }
-        fro = block_sum(fro, s_red);
-        __syncthreads();
-        const double tiny = (double)n * DBL_EPSILON * DBL_EPSILON * fro;
-        int sweep;
-        if (n == 64) sweep = jacobi_lds_sweeps<double, 4, true>(G, W, true, n, n, np_, np_, max_sweeps, tiny, &s_rot);
-        else sweep = jacobi_lds_sweeps<double, 4, false>(G, W, true, n, n, np_, np_, max_sweeps, tiny, &s_rot);
-        __syncthreads();
-        // ---- U Sigma = A W (f64 accumulation), rows in chunks staged column-major (pitch nr + 1) in G's space; written over A
-        cx<float>* Ac = reinterpret_cast<cx<float>*>(G);
-        const int rows_fit3 = (int)(((size_t)np_ * n * 16) / ((size_t)n * 8)) - 1;
-        for (int r0 = 0; r0 < m; r0 += rows_fit3) {
-            const int nr = min(rows_fit3, m - r0), pr = nr + 1;
-            __syncthreads();
-            for (int e = tid; e < nr * n; e += 1024) { const int r = e % nr, c = e / nr; Ac[r + pr * c] = Ag[(r0 + r) + (size_t)m * c]; }
-            __syncthreads();
-            for (int e = tid; e < nr * n; e += 1024) {
-                const int r = e % nr, j = e / nr;
-                double sr = 0, si = 0;
-                for (int i = 0; i < n; ++i) {
-                    const cx<float> a = Ac[r + pr * i]; const cx<double> w = W[i + np_ * j];
-                    sr += (double)a.re * w.re - (double)a.im * w.im; si += (double)a.re * w.im + (double)a.im * w.re;
-                }
-                Ag[(r0 + r) + (size_t)m * j] = cmake<float>((float)sr, (float)si);
-            }
-        }
-        if (tid == 0 && it.sweeps_out) *it.sweeps_out = sweep;
-        return;
-    }
-    // ---- generic shape: one-sided Jacobi on A in f32 (jacobi_lds_kernel<float, RQ> without V)
-    const int mp = m + 2;
-    cx<float>* A = reinterpret_cast<cx<float>*>(smem);
-    for (int e = tid; e < m * n; e += blockDim.x) A[(e % m) + mp * (e / m)] = Ag[e];
-    __syncthreads();
-    double fro = 0;
-    for (int e = tid; e < m * n; e += blockDim.x) { cx<float> v = A[(e % m) + mp * (e / m)]; fro += (double)v.re * v.re + (double)v.im * v.im; }
-    fro = block_sum(fro, s_red);
-    int kexp = 0;
-    if (fro > 0 && fro < 1e300) { kexp = -(ilogb(fro) / 2); kexp = kexp > 120 ? 120 : (kexp < -120 ? -120 : kexp); }
-    const float sc_in = (float)ldexp(1.0, kexp), sc_out = (float)ldexp(1.0, -kexp);
-    if (kexp != 0) {
-        for (int e = tid; e < m * n; e += blockDim.x) { cx<float>& v = A[(e % m) + mp * (e / m)]; v.re *= sc_in; v.im *= sc_in; }
-        fro = ldexp(fro, 2 * kexp);
-        __syncthreads();
-    }
-    const float tiny = (float)((double)n * (double)FLT_EPSILON * (double)FLT_EPSILON * fro);
-    const bool full = (m == 16 * RQ) && !(n & 1) && !((n >> 1) & 3);
-    int sweep;
-    if (full) sweep = jacobi_lds_sweeps_f32_full<RQ>(A, m, n, mp, max_sweeps, tiny, &s_rot);
-    else sweep = jacobi_lds_sweeps<float, RQ, false>(A, nullptr, false, m, n, mp, n + 2, max_sweeps, tiny, &s_rot);
-    __syncthreads();
-    for (int e = tid; e < m * n; e += blockDim.x) { cx<float> v = A[(e % m) + mp * (e / m)]; Ag[e] = cmake<float>(v.re * sc_out, v.im * sc_out); }
-    if (tid == 0 && it.sweeps_out) *it.sweeps_out = sweep;
-}
-// lds_bytes: the f32 route's need at the largest item (jacobi_lds_bytes); the Gram route needs 2 (nn + 2) nn 16 with nn = min(nmax, 64)
-template <int RQ> static void launch_theta_svd_rq(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes) {
-    set_max_dynamic_lds((const void*)theta_svd_kernel<RQ>, (size_t)(160 * 1024 - 256));
-    hipLaunchKernelGGL((theta_svd_kernel<RQ>), dim3(nitems), dim3(1024), lds_bytes, s, d_items, max_sweeps); TNQS_CHECK_LAUNCH();
-}
-bool launch_theta_svd(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax, int nmax) {
-    if (nitems <= 0) return true;
-    const int nn = nmax < 64 ? nmax : 64;
-    lds_bytes = std::max(lds_bytes, (size_t)2 * (nn + 2) * nn * 16);
-    if (lds_bytes > 160 * 1024 - 256 || mmax > 256) return false;
-    if (mmax <= 32) launch_theta_svd_rq<2>(s, d_items, nitems, max_sweeps, lds_bytes);
-    else if (mmax <= 64) launch_theta_svd_rq<4>(s, d_items, nitems, max_sweeps, lds_bytes);
-    else if (mmax <= 96) launch_theta_svd_rq<6>(s, d_items, nitems, max_sweeps, lds_bytes);
-    else if (mmax <= 128) launch_theta_svd_rq<8>(s, d_items, nitems, max_sweeps, lds_bytes);
-    else launch_theta_svd_rq<16>(s, d_items, nitems, max_sweeps, lds_bytes);
-    return true;
-}
-
 // V[:,u] = A0^dagger a_u / |a_u|^2   (a_u = column u of U Sigma), for the factorisations run without accumulating V.
 // grid (item, column block of 8): a wave owns one output column u and keeps a_u in registers (lanes = rows, coalesced);
 // every V[col, u] is one coalesced column read of A0 and a wave reduction.
@@ -881,9 +752,16 @@ void launch_small_svd_finish(hipStream_t s, const SmallSvdItem* d_items, int nit
 // ------------------------------------------------------------------------------------------------------------
 // Cholesky factor of the Gram matrix (the R factor of the thin QR, simple_update.jl:45-48, when G has full rank)
 // ------------------------------------------------------------------------------------------------------------
+// Right-looking, ONE workgroup barrier per column: the trailing update of step k works from the UNSCALED column k,
+//   A[i][j] -= A[i][k] conj(A[j][k]) / A[k][k]     (columns j > k; column k itself is never written again),
+// every thread derives the pivot from A[k][k] by the same rule, and the scaling L[i][k] = A[i][k] / sqrt(A[k][k]) happens for all columns
+// at once at the end.  (The first version scaled the column between two extra barriers per step, paid two integer divisions per updated
+// element and inverted L with one serial thread per column: 214 us per launch on a 64 x 64 matrix, the second largest latency item of a
+// colour batch.)  The inverse triangle is built by FOUR lanes per column (adjacent lanes of one wave: partial sums meet through DPP-free
+// shuffles, no barrier): column c of L^-1 only depends on L and on its own earlier entries.
 __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double s_piv; __shared__ double s_dmax;
+    __shared__ double s_dmax;
     const CholItem it = items[blockIdx.x];
     const int n = it.n, np = n + 1, tid = threadIdx.x;
     cx<double>* A = reinterpret_cast<cx<double>*>(smem);          // [col j][row i] at i + np*j, lower triangle becomes L
@@ -893,50 +771,71 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
         A[i + np * j] = cmake<double>(0.5 * (a.re + b.re), 0.5 * (a.im - b.im));
     }
     __syncthreads();
-    if (tid == 0) { double m = 0; for (int i = 0; i < n; ++i) m = fmax(m, A[i + np * i].re); s_dmax = m; }
+    if (tid < 64) {                                                // largest diagonal entry (one wave)
+        double m = 0; for (int i = tid; i < n; i += 64) m = fmax(m, A[i + np * i].re);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+        if (tid == 0) s_dmax = m;
+    }
     __syncthreads();
     const double tiny = it.tau * s_dmax;
+    // the pivot rule: a pivot at or below tiny (or not a number) flags the item and is replaced, so that the factorisation completes
+    auto pivot_of = [&](int k, bool& bad) { double d = A[k + np * k].re; bad = !(d > tiny); return bad ? (tiny > 0 ? tiny : 1.0) : d; };
+    const int ti = tid & 63, tj = tid >> 6;
     for (int k = 0; k < n; ++k) {
-        if (tid == 0) {
-            double d = A[k + np * k].re;
-            if (!(d > tiny)) { *it.fail = 1; d = (tiny > 0 ? tiny : 1.0); }
-            s_piv = sqrt(d);
-        }
-        __syncthreads();
-        const double inv = 1.0 / s_piv;
-        for (int i = k + tid; i < n; i += 256) {
-            if (i == k) A[k + np * k] = cmake<double>(s_piv, 0.0);
-            else { cx<double> v = A[i + np * k]; A[i + np * k] = cmake<double>(v.re * inv, v.im * inv); }
-        }
-        __syncthreads();
-        const int m = n - k - 1;                                   // trailing update, lower triangle: A[i][j] -= L[i][k] conj(L[j][k])
-        for (int e = tid; e < m * m; e += 256) {
-            int i = k + 1 + e % m, j = k + 1 + e / m;
-            if (i < j) continue;
-            cx<double> li = A[i + np * k], lj = A[j + np * k];
-            cx<double> v = A[i + np * j];
-            v.re -= li.re * lj.re + li.im * lj.im; v.im -= li.im * lj.re - li.re * lj.im;
-            A[i + np * j] = v;
+        bool bad; const double d = pivot_of(k, bad);
+        if (bad && tid == 0) *it.fail = 1;
+        const double dinv = 1.0 / d;
+        for (int i = k + 1 + ti; i < n; i += 64) {
+            const cx<double> li = A[i + np * k];
+            const cx<double> ls = cmake<double>(li.re * dinv, li.im * dinv);
+            for (int j = k + 1 + tj; j <= i; j += 4) {
+                const cx<double> lj = A[j + np * k];
+                cx<double> v = A[i + np * j];
+                v.re -= ls.re * lj.re + ls.im * lj.im; v.im -= ls.im * lj.re - ls.re * lj.im;
+                A[i + np * j] = v;
+            }
         }
         __syncthreads();
     }
-    cx<double>* L = reinterpret_cast<cx<double>*>(it.L);
-    cx<double>* W = reinterpret_cast<cx<double>*>(it.Winv);
-    for (int e = tid; e < n * n; e += 256) { int i = e % n, j = e / n; L[e] = (i >= j) ? A[i + np * j] : cmake<double>(0, 0); }
+    // L[i][k] = A[i][k] / sqrt(pivot_k), L[k][k] = sqrt(pivot_k): all columns at once (the pivots are taken before any diagonal entry changes)
+    __shared__ double s_piv[96];
+    for (int k = tid; k < n; k += 256) { bool bad; s_piv[k] = sqrt(pivot_of(k, bad)); }
     __syncthreads();
-    // column c of L^-1 by forward substitution, thread per column; conj(Linv[i, c]) (i > c) goes to the free strict upper triangle
-    // A[c + np*i] (L[i][j] is a broadcast read, the x_j of neighbouring threads are neighbouring addresses)
-    for (int c = tid; c < n; c += 256) {
-        const double dc = 1.0 / A[c + np * c].re;
-        for (int i = c + 1; i < n; ++i) {
-            cx<double> l = A[i + np * c];
-            cx<double> acc = cmake<double>(-l.re * dc, -l.im * dc);                 // - L[i][c] x_c
-            for (int j = c + 1; j < i; ++j) {
-                cx<double> lj = A[i + np * j], x = A[c + np * j]; x.im = -x.im;      // stored conjugated
-                acc.re -= lj.re * x.re - lj.im * x.im; acc.im -= lj.re * x.im + lj.im * x.re;
+    cx<double>* L = reinterpret_cast<cx<double>*>(it.L);
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e % n, k = e / n;
+        cx<double> l = cmake<double>(0, 0);
+        if (i == k) l = cmake<double>(s_piv[k], 0.0);
+        else if (i > k) { const cx<double> v = A[i + np * k]; const double r = 1.0 / s_piv[k]; l = cmake<double>(v.re * r, v.im * r); }
+        if (i >= k) A[i + np * k] = l;
+        L[e] = l;
+    }
+    __syncthreads();
+    cx<double>* W = reinterpret_cast<cx<double>*>(it.Winv);
+    if (!W) return;
+    // column c of L^-1 by forward substitution, four adjacent lanes per column (j-sum split four ways); conj(Linv[i, c]) (i > c) goes to the
+    // free strict upper triangle A[c + np*i]
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int c = c0 + (tid >> 2), part = tid & 3;
+        const bool on = c < n;
+        const double dc = on ? 1.0 / A[c + np * c].re : 0.0;
+        for (int i = c0 + 1; i < n; ++i) {                         // wave-uniform trip count; lanes whose column has not started yet (i <= c) idle
+            double sr = 0, si = 0;
+            if (on && i > c) {
+                for (int j = c + 1 + part; j < i; j += 4) {
+                    cx<double> lj = A[i + np * j], x = A[c + np * j]; x.im = -x.im;      // stored conjugated
+                    sr += lj.re * x.re - lj.im * x.im; si += lj.re * x.im + lj.im * x.re;
+                }
             }
-            const double inv = 1.0 / A[i + np * i].re;
-            A[c + np * i] = cmake<double>(acc.re * inv, -acc.im * inv);
+            sr += __shfl_xor(sr, 1, 64); si += __shfl_xor(si, 1, 64);
+            sr += __shfl_xor(sr, 2, 64); si += __shfl_xor(si, 2, 64);
+            if (on && i > c && part == 0) {
+                const cx<double> l = A[i + np * c];
+                const double inv = 1.0 / A[i + np * i].re;
+                A[c + np * i] = cmake<double>(-(l.re * dc + sr) * inv, (l.im * dc + si) * inv);
+            }
+            __builtin_amdgcn_wave_barrier();                      // the four lanes of a column read what lane 0 just wrote (same wave: LDS is in order)
         }
     }
     __syncthreads();

@@ -149,9 +149,6 @@ struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; int n
 // LDS bytes the LDS-resident Jacobi needs for an m x n matrix (columns padded by 2 elements)
 inline size_t jacobi_lds_bytes(int m, int n, bool withV, size_t esz) { return ((size_t)(m + 2) * n + (withV ? (size_t)(n + 2) * n : 0)) * esz; }
 template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax);
-// ComplexF32 theta SVD without V (kernels.hip, theta_svd_kernel): through the f64 Gram matrix where the shape allows (n <= 64 <= m), the
-// LDS-resident one-sided sweeps otherwise; false: the batch does not fit the LDS (the caller uses launch_jacobi)
-bool launch_theta_svd(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax, int nmax);
 // sites with fewer fibers than columns (N < n = d*chi): the R factor comes from a one-sided Jacobi SVD of the n x N matrix
 // M[(s,b), outer] = conj(psi~[outer,(s,b)]) (f64) instead of the eigen factorisation of the rank-deficient n x n Gram matrix
 struct SmallSvdItem { const void* src; void* M; void* GA; void* GV; int d, low, chi_b, hi; };   // low = pre(b)/d, hi = post(b); n = d*chi_b, N = low*hi

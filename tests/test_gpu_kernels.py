@@ -276,10 +276,10 @@ def test_jacobi_svd_is_scale_invariant(shape, rank, scale):
                                         ((130, 70), 70), ((40, 40), 3)])
 @pytest.mark.parametrize("scale", [1e-9, 1.0, 1e6])
 def test_theta_svd_kernel(shape, rank, scale, monkeypatch):
-    """the engine's theta SVD kernel (theta_svd_kernel: f64 Gram matrix + Jacobi eigen + U Sigma = A W accumulated in f64 for n <= 64 <= m,
-    one-sided f32 sweeps otherwise), V recovered from the unrotated copy as in the engine: singular values against LAPACK relative to the
-    largest one, the reconstruction A = (U Sigma) V^dagger, and -- what the V recovery depends on -- the orthogonality of the columns of U Sigma
-    relative to their OWN norms, for full-rank, rank-deficient and badly scaled inputs"""
+    """the engine's theta SVD route at the shapes a gate batch produces (one-sided f32 sweeps on A in LDS, V not accumulated but recovered from
+    the unrotated copy): singular values against LAPACK relative to the largest one, the reconstruction A = (U Sigma) V^dagger, and -- what
+    the V recovery depends on -- the orthogonality of the columns of U Sigma relative to their OWN norms, for full-rank, rank-deficient and
+    badly scaled inputs with spectra spread over 3.5 decades"""
     monkeypatch.setenv("TNQS_DBG_THETA_SVD", "1")
     rng = np.random.default_rng(shape[0] + 7 * rank)
     m, n = shape
@@ -292,9 +292,36 @@ def test_theta_svd_kernel(shape, rank, scale, monkeypatch):
     nrm = np.linalg.norm(A, axis=0)
     s = np.sort(nrm)[::-1]
     assert sw < 60
-    assert np.max(np.abs(s[:len(s_ref)] - s_ref)) < 2e-6 * s_ref[0], (s[:4], s_ref[:4])
+    assert np.max(np.abs(s[:len(s_ref)] - s_ref)) < 1e-5 * s_ref[0], (s[:4], s_ref[:4])
     big = nrm > 1e-4 * s_ref[0]                                             # columns that carry signal: mutually orthogonal relative to their own norms
     U = A[:, big] / nrm[big]
     assert np.max(np.abs(U.conj().T @ U - np.eye(U.shape[1]))) < 5e-6
     rec = A @ V.conj().T.astype(np.complex128)
     assert np.max(np.abs(rec - b)) < 2e-5 * s_ref[0]
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 16, 33, 64, 65, 96, 128])
+@pytest.mark.parametrize("cond", [1e2, 1e10])
+def test_cholesky_kernels(n, cond):
+    """chol_kernel (n <= 96: one barrier per column, unscaled trailing updates, four lanes per column of the inverse) and the packed kernel
+    (n <= 128): G = L L^dagger, W = (L^-1)^dagger, against numpy in f64, for well- and ill-conditioned Gram matrices; a numerically singular
+    matrix raises the failure flag instead of producing NaNs"""
+    rng = np.random.default_rng(n)
+    q, _ = np.linalg.qr(rnd(rng, (n, n), np.complex128))
+    lam = np.logspace(0, -np.log10(cond), n)
+    g = np.asfortranarray((q * lam) @ q.conj().T)
+    L = np.zeros((n, n), dtype=np.complex128, order="F"); W = np.zeros((n, n), dtype=np.complex128, order="F"); fail = C.c_int(-1)
+    rc = lib.tnqs_dbg_chol(n, g.ctypes.data_as(C.c_void_p), L.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p), C.byref(fail), C.c_double(1e-12))
+    assert rc == 0, lib.tnqs_last_error()
+    assert fail.value == 0
+    assert np.max(np.abs(np.triu(L, 1))) == 0 and np.all(np.diag(L).real > 0) and np.max(np.abs(np.diag(L).imag)) == 0
+    assert np.max(np.abs(L @ L.conj().T - g)) < 1e-13 * n
+    ref = np.linalg.cholesky(g)
+    assert np.max(np.abs(L - ref)) < 1e-11 * cond ** 0.5
+    assert np.max(np.abs(W.conj().T @ L - np.eye(n))) < 1e-13 * n * cond ** 0.5            # W^dagger = L^-1
+    # singular: rank n - 1 (n >= 2) -> flagged, finite output
+    if n >= 2:
+        lam2 = lam.copy(); lam2[-1] = 0.0
+        g2 = np.asfortranarray((q * lam2) @ q.conj().T)
+        rc = lib.tnqs_dbg_chol(n, g2.ctypes.data_as(C.c_void_p), L.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p), C.byref(fail), C.c_double(1e-12))
+        assert rc == 0 and (fail.value == 1 or cond > 1e9) and np.all(np.isfinite(L))
