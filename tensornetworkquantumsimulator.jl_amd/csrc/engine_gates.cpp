@@ -339,6 +339,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     // SVD of theta: the right factor is never accumulated from the rotations (in f32 its orthogonality degrades with the
     // rotation count, ~1e-5 at 150 columns) but recovered from an unrotated copy: V = theta0^dagger (U S) S^-2
     const bool theta0_used = true;
+    bool lowrank_on_batch = false;          // some gate of the batch carries operator-sum factors
     {
         std::vector<char> raw;
         std::vector<size_t> off(pg.size()), offA(pg.size(), 0), offB(pg.size(), 0); std::vector<int> kappa(pg.size(), 0);
@@ -393,13 +394,17 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             it.n1 = w.n1; it.n2 = w.n2; it.d1 = a.sd.d; it.d2 = b.sd.d; it.chi = w.chi;
             it.gate = reinterpret_cast<const double*>(d_gm + off[q]);
             it.kappa = 0; it.opA = it.opB = nullptr; it.lowA = it.lowB = it.lowG = nullptr; it.lowL = nullptr; it.lowfail = nullptr;
-            {   // low-rank route of the theta SVD (GateItem): only where it can apply -- K = kappa chi below the theta columns and chol_kernel's size
+            {   // the operator-sum factors A ((r1 d1) x K), B ((r2 d2) x K), K = kappa chi: theta = A B^T is formed from them (gate_theta_mm_kernel);
+                // the low-rank route of the theta SVD (lowG / lowL) only where it can apply -- K below the theta columns and chol_kernel's size
                 const int K = kappa[q] * w.chi;
-                if (lowrank_on && kappa[q] > 0 && K < Nc && K <= 128 && cap <= K && Mr >= Nc) {
-                    w.lowA = dalloc(s, (size_t)Mr * K * 16); w.lowB = dalloc(s, (size_t)Nc * K * 16); w.lowG = dalloc(s, (size_t)K * K * 16);
-                    w.lowL = dalloc(s, (size_t)K * K * 16); w.lowW = dalloc(s, (size_t)K * K * 16);
+                if (lowrank_on && kappa[q] > 0) {
+                    w.lowA = dalloc(s, (size_t)Mr * K * 16); w.lowB = dalloc(s, (size_t)Nc * K * 16);
                     it.kappa = kappa[q]; it.opA = reinterpret_cast<const double*>(d_gm + offA[q]); it.opB = reinterpret_cast<const double*>(d_gm + offB[q]);
-                    it.lowA = w.lowA->p; it.lowB = w.lowB->p; it.lowG = w.lowG->p; it.lowL = w.lowL->p;
+                    it.lowA = w.lowA->p; it.lowB = w.lowB->p; lowrank_on_batch = true;
+                    if (K < Nc && K <= 128 && cap <= K && Mr >= Nc) {
+                        w.lowG = dalloc(s, (size_t)K * K * 16); w.lowL = dalloc(s, (size_t)K * K * 16); w.lowW = dalloc(s, (size_t)K * K * 16);
+                        it.lowG = w.lowG->p; it.lowL = w.lowL->p;
+                    }
                 }
             }
             it.lam1 = (double*)w.lam1->p; it.lam2 = (double*)w.lam2->p; it.idx1 = (int*)w.idx1->p; it.idx2 = (int*)w.idx2->p;
@@ -428,6 +433,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         HIPCHK(hipMemsetAsync(d_lowfail->p, 0, std::max<size_t>(1, (size_t)npg * sizeof(int)), s->stream));
         ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
         launch_gate_theta<T>(s->stream, d_gitems, npg);
+        if (lowrank_on_batch) launch_gate_theta_mm<T>(s->stream, d_gitems, npg);        // theta = A B^T on the f64 matrix cores (gates with operator-sum factors)
         std::vector<CholItem> lc; int kmax = 1;
         for (int q = 0; q < npg; ++q) {
             if (!gitems[q].lowG) continue;

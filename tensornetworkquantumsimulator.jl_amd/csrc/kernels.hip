@@ -930,7 +930,7 @@ void launch_chol_packed(hipStream_t s, const CholItem* d_items, int nitems, int 
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {
     if (nitems <= 0) return;
     const size_t lds = (size_t)nmax * (nmax + 1) * 16;
-    set_max_dynamic_lds((const void*)chol_kernel, (size_t)(160 * 1024 - 256));
+    set_max_dynamic_lds((const void*)chol_kernel, (size_t)(160 * 1024 - 1024));       // (the kernel also has ~0.8 KB of static LDS: pivots)
     hipLaunchKernelGGL(chol_kernel, dim3(nitems), dim3(256), lds, s, d_items); TNQS_CHECK_LAUNCH();
 }
 
@@ -1079,6 +1079,11 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
     const cx<double>* g = reinterpret_cast<const cx<double>*>(it.gate);
     const int dd = d1 * d2;
     // theta[(a,s1'),(c,s2')] = sum_{s1,s2} g[(s1' s2'),(s1 s2)] sum_b R1[a,(s1,b)] R2[c,(s2,b)],  R_i[a,(s,b)] = sqrt(l_a) conj(W_i[(s,b),a])
+    // With the gate as an operator sum (opA / opB, lowA / lowB given: every ComplexF32 batch) theta = A B^T is formed from the factors by
+    // gate_theta_mm_kernel on the f64 matrix cores; the element-wise loop below (128 dependent, uncoalesced loads per entry: 285 us per
+    // 190-gate batch) only serves states without the factorisation (ComplexF64)
+    const bool via_factors = it.kappa > 0 && it.lowA && it.lowB;
+    if (!via_factors)
     for (int e = tid0; e < Mr * Nc; e += tstride) {
         int row = e % Mr, col = e / Mr;
         int a = row % r1, s1p = row / r1, c = col % r2, s2p = col / r2;
@@ -1110,7 +1115,7 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
     const int K = it.kappa * chi;
     const bool low = sizeof(T) == 4 && it.kappa > 0 && it.lowG && !wide && K < Nc && it.chi_cap <= K;
     if (threadIdx.x == 0 && part == 0) { it.info[5] = wide ? 1 : 0; it.info[7] = low ? K : 0; }       // info[7]: lowrank_g / chol / lowrank_m follow
-    if (low) {
+    if (via_factors) {
         cx<double>* LA = reinterpret_cast<cx<double>*>(it.lowA);
         cx<double>* LB = reinterpret_cast<cx<double>*>(it.lowB);
         const cx<double>* oa = reinterpret_cast<const cx<double>*>(it.opA);
@@ -1131,12 +1136,70 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
             const double sc = sqrt(it.lam2[c]);
             LB[e] = cmake<double>(acc.re * sc, acc.im * sc);
         }
-    } else if (it.lowG && it.kappa > 0) {      // not taken: give chol_kernel a harmless identity
+    }
+    if (!low && it.lowG && it.kappa > 0) {      // low-rank SVD route not taken: give chol_kernel a harmless identity
         cx<double>* LG = reinterpret_cast<cx<double>*>(it.lowG);
         for (int e = tid0; e < K * K; e += tstride) LG[e] = cmake<double>((e % K) == (e / K) ? 1.0 : 0.0, 0.0);
     }
 }
-// G = B^dagger B of the low-rank route (GateItem), the same (gate, part) grid
+// ---- small complex f64 products on v_mfma_f64_16x16x4_f64: one wave per 16 x 16 tile  C[i][j] (+)= sum_k a(i, k) b(k, j) -------------------
+// Operand layout of the instruction: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], C[row = (lane >> 4) + 4 r][col = lane & 15].
+// fa(i, k) / fb(k, j) return the operand (zero outside the matrix); four real products per complex step (these kernels are latency, not
+// throughput: the gain over the scalar loops is that a tile takes 2 loads per 4 x 256 multiply-adds instead of 2 per multiply-add)
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+template <class FA, class FB> __device__ __forceinline__ void ztile_mm(int K, int i, int j, FA fa, FB fb, v4d_t& cr, v4d_t& ci) {
+    const int kq = (threadIdx.x & 63) >> 4;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const cx<double> a = fa(i, k0 + kq), b = fb(k0 + kq, j);
+        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, cr, 0, 0, 0);
+        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b.im, cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.im, ci, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.re, ci, 0, 0, 0);
+    }
+}
+// theta = A B^T from the operator-sum factors gate_theta_kernel wrote (lowA: Mr x K, lowB: Nc x K, complex128), to theta and theta0 in
+// the state's precision; a wide theta is stored as its adjoint.  The tile orientation is chosen so that the lanes run along the
+// contiguous index of the destination.
+template <class T>
+__global__ __launch_bounds__(1024) void gate_theta_mm_kernel(const GateItem* __restrict__ items) {
+    const GateItem it = items[blockIdx.x];
+    if (!(it.kappa > 0 && it.lowA && it.lowB)) return;
+    const int Mr = it.info[0] * it.d1, Nc = it.info[1] * it.d2, K = it.kappa * it.chi;
+    const bool wide = it.info[5] != 0;
+    const cx<double>* LA = reinterpret_cast<const cx<double>*>(it.lowA);
+    const cx<double>* LB = reinterpret_cast<const cx<double>*>(it.lowB);
+    cx<T>* th = reinterpret_cast<cx<T>*>(it.theta);
+    cx<T>* th0 = reinterpret_cast<cx<T>*>(it.theta0);
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    const int w = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.y * (blockDim.x >> 6);
+    // rows of the tile product = the index that is NOT contiguous in the destination: (c, s2') for theta[i + Mr j], (a, s1') for the adjoint
+    const int R = wide ? Mr : Nc, Cn = wide ? Nc : Mr;              // tile rows run over R, tile columns (lanes) over Cn
+    const cx<double>* PR = wide ? LA : LB; const cx<double>* PC = wide ? LB : LA;
+    const int tr = (R + 15) >> 4, tc = (Cn + 15) >> 4;
+    for (int t = w; t < tr * tc; t += nw) {
+        const int r0 = 16 * (t % tr), c0 = 16 * (t / tr);
+        v4d_t cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+        ztile_mm(K, r0 + l15, c0 + l15,
+                 [&](int i, int k) { return (i < R && k < K) ? PR[i + (size_t)R * k] : cmake<double>(0, 0); },
+                 [&](int k, int j) { return (j < Cn && k < K) ? PC[j + (size_t)Cn * k] : cmake<double>(0, 0); }, cr, ci);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + kq + 4 * r, col = c0 + l15;
+            if (row < R && col < Cn) {
+                // not wide: theta[i = col][j = row] at col + Mr * row;  wide: stored adjoint theta^dagger[j = col][i = row] at col + Nc * row, conjugated
+                const cx<T> v = cmake<T>((T)cr[r], (T)(wide ? -ci[r] : ci[r]));
+                th[col + (size_t)Cn * row] = v; if (th0) th0[col + (size_t)Cn * row] = v;
+            }
+        }
+    }
+}
+template <class T> void launch_gate_theta_mm(hipStream_t s, const GateItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL((gate_theta_mm_kernel<T>), dim3(nitems, 2), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+template void launch_gate_theta_mm<float>(hipStream_t, const GateItem*, int);
+template void launch_gate_theta_mm<double>(hipStream_t, const GateItem*, int);
+// G = B^dagger B of the low-rank route (GateItem): upper 16 x 16 tiles on the f64 matrix cores, mirrored
 __global__ __launch_bounds__(1024) void lowrank_g_kernel(const GateItem* __restrict__ items) {
     const GateItem it = items[blockIdx.x];
     const int K = it.info[7];
@@ -1144,20 +1207,29 @@ __global__ __launch_bounds__(1024) void lowrank_g_kernel(const GateItem* __restr
     const int Nc = it.info[1] * it.d2;
     const cx<double>* LB = reinterpret_cast<const cx<double>*>(it.lowB);
     cx<double>* LG = reinterpret_cast<cx<double>*>(it.lowG);
-    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < K * K; e += gridDim.y * blockDim.x) {      // G[i,j] = sum_row conj(B[row,i]) B[row,j]
-        const int i = e % K, j = e / K;
-        if (i > j) continue;
-        cx<double> acc = cmake<double>(0, 0);
-        const cx<double>* bi = LB + (size_t)Nc * i; const cx<double>* bj = LB + (size_t)Nc * j;
-        for (int row = 0; row < Nc; ++row) cfma_conj(acc, bj[row], bi[row]);
-        LG[i + (size_t)K * j] = acc; if (i != j) LG[j + (size_t)K * i] = cmake<double>(acc.re, -acc.im);
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    const int w = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.y * (blockDim.x >> 6);
+    const int nt = (K + 15) >> 4;
+    for (int t = w; t < nt * nt; t += nw) {
+        const int ti = t % nt, tj = t / nt;
+        if (ti > tj) continue;
+        v4d_t cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+        ztile_mm(Nc, 16 * ti + l15, 16 * tj + l15,                                   // G[i][j] = sum_row conj(B[row, i]) B[row, j]
+                 [&](int i, int k) { cx<double> v = (i < K && k < Nc) ? LB[k + (size_t)Nc * i] : cmake<double>(0, 0); v.im = -v.im; return v; },
+                 [&](int k, int j) { return (j < K && k < Nc) ? LB[k + (size_t)Nc * j] : cmake<double>(0, 0); }, cr, ci);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + kq + 4 * r, j = 16 * tj + l15;
+            if (i < K && j < K && i <= j) { LG[i + (size_t)K * j] = cmake<double>(cr[r], ci[r]); if (i != j) LG[j + (size_t)K * i] = cmake<double>(cr[r], -ci[r]); }
+        }
     }
 }
 void launch_lowrank_g(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
     hipLaunchKernelGGL(lowrank_g_kernel, dim3(nitems, 4), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
-// theta[:, 0..K) := M = A conj(L) where G = L L^dagger (chol_kernel); on a collapsed pivot the full theta (already in place) stays
+// theta[:, 0..K) := M = A conj(L) where G = L L^dagger (chol_kernel); on a collapsed pivot the full theta (already in place) stays.
+// Tiles with rows = column index j of M, lanes = row index i (contiguous in theta).
 template <class T>
 __global__ __launch_bounds__(1024) void lowrank_m_kernel(const GateItem* __restrict__ items) {
     const GateItem it = items[blockIdx.x];
@@ -1168,11 +1240,20 @@ __global__ __launch_bounds__(1024) void lowrank_m_kernel(const GateItem* __restr
     const cx<double>* LA = reinterpret_cast<const cx<double>*>(it.lowA);
     const cx<double>* L = reinterpret_cast<const cx<double>*>(it.lowL);
     cx<T>* th = reinterpret_cast<cx<T>*>(it.theta);
-    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < Mr * K; e += gridDim.y * blockDim.x) {
-        const int i = e % Mr, j = e / Mr;
-        cx<double> acc = cmake<double>(0, 0);
-        for (int l = j; l < K; ++l) cfma_conj(acc, LA[i + (size_t)Mr * l], L[l + (size_t)K * j]);      // A[i,l] conj(L[l,j]), L lower triangular
-        th[e] = cmake<T>((T)acc.re, (T)acc.im);
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    const int w = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.y * (blockDim.x >> 6);
+    const int tr = (K + 15) >> 4, tc = (Mr + 15) >> 4;
+    for (int t = w; t < tr * tc; t += nw) {
+        const int j0 = 16 * (t % tr), i0 = 16 * (t / tr);
+        v4d_t cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+        ztile_mm(K, j0 + l15, i0 + l15,                                              // M[i][j] = sum_{l >= j} A[i, l] conj(L[l, j]), L lower triangular
+                 [&](int j, int l) { cx<double> v = (j < K && l < K && l >= j) ? L[l + (size_t)K * j] : cmake<double>(0, 0); v.im = -v.im; return v; },
+                 [&](int l, int i) { return (i < Mr && l < K) ? LA[i + (size_t)Mr * l] : cmake<double>(0, 0); }, cr, ci);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + kq + 4 * r, i = i0 + l15;
+            if (i < Mr && j < K) th[i + (size_t)Mr * j] = cmake<T>((T)cr[r], (T)ci[r]);
+        }
     }
 }
 // theta, theta0 *= 2^k with k = -exponent of the largest |entry| of theta0 (exact); *texp = k.  Runs after gate_theta / lowrank_m.
@@ -1336,6 +1417,11 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
         }
         s_keep = n;
     }
+    // per-column factors of R^+ = W diag(lambda^-1/2) (and of the theta scaling), once per workgroup: a square root and a division per
+    // INNER iteration were most of this kernel's time
+    __shared__ double fa1[256], fa2[256];
+    for (int a = threadIdx.x; a < r1; a += blockDim.x) fa1[a] = (wide ? 1.0 : tsc) / sqrt(it.lam1[a]);      // th holds the scaled U Sigma (tv, the recovered vectors, is scale free)
+    for (int c = threadIdx.x; c < r2; c += blockDim.x) fa2[c] = (wide ? tsc : 1.0) / sqrt(it.lam2[c]);
     __syncthreads();
     const int nk = s_keep;
     const cx<double>* V1 = reinterpret_cast<const cx<double>*>(it.GW1);       // R^+ = W diag(lambda^-1/2)
@@ -1354,7 +1440,7 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
             for (int a = 0; a < r1; ++a) {
                 cx<double> w = V1[kk + (size_t)n1 * it.idx1[a]];
                 cx<T> l = wide ? tv[(a + r1 * s1p) + (size_t)Mr * pu] : th[(a + r1 * s1p) + (size_t)Mr * pu];
-                double f = (wide ? 1.0 : tsc) / sqrt(it.lam1[a]);      // th holds the scaled U Sigma (tv, the recovered vectors, is scale free)
+                const double f = fa1[a];
                 cx<double> lv = cmake<double>(l.re * f, l.im * f);
                 cfma(acc, w, lv);
             }
@@ -1374,7 +1460,7 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
             for (int c = 0; c < r2; ++c) {
                 cx<double> w = V2[kk + (size_t)n2 * it.idx2[c]];
                 cx<T> v = wide ? th[(c + r2 * s2p) + (size_t)Nc * pu] : tv[(c + r2 * s2p) + (size_t)Nc * pu];
-                double f = (wide ? tsc : 1.0) / sqrt(it.lam2[c]);
+                const double f = fa2[c];
                 cx<double> vd = cmake<double>(v.re * f, -v.im * f);
                 cfma(acc, w, vd);
             }

@@ -183,6 +183,7 @@ void launch_recover_v_mfma(hipStream_t s, const RecoverItem* d_items, int nitems
 template <class T> void launch_env_prepare(hipStream_t s, const EnvItem* d_items, int nitems);
 template <class T> void launch_env_finish(hipStream_t s, const EnvFinishItem* d_items, int nitems);
 template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems);
+template <class T> void launch_gate_theta_mm(hipStream_t s, const GateItem* d_items, int nitems);      // theta = A B^T from the operator-sum factors (after gate_theta)
 template <class T> void launch_gate_finish(hipStream_t s, const GateItem* d_items, int nitems);
 template <class T> void launch_diag(hipStream_t s, const DiagItem* d_items, int nitems);
 template <class T> void launch_scale(hipStream_t s, const ScaleItem* d_items, int nitems);

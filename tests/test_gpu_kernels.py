@@ -312,7 +312,7 @@ def test_cholesky_kernels(n, cond):
     g = np.asfortranarray((q * lam) @ q.conj().T)
     L = np.zeros((n, n), dtype=np.complex128, order="F"); W = np.zeros((n, n), dtype=np.complex128, order="F"); fail = C.c_int(-1)
     rc = lib.tnqs_dbg_chol(n, g.ctypes.data_as(C.c_void_p), L.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p), C.byref(fail), C.c_double(1e-12))
-    assert rc == 0, lib.tnqs_last_error()
+    assert rc == 0, tn._lib.lib.tnqs_last_error()
     assert fail.value == 0
     assert np.max(np.abs(np.triu(L, 1))) == 0 and np.all(np.diag(L).real > 0) and np.max(np.abs(np.diag(L).imag)) == 0
     assert np.max(np.abs(L @ L.conj().T - g)) < 1e-13 * n
