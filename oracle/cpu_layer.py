@@ -224,16 +224,17 @@ class parallel_oracle:
         return False
 
 
-def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int = 1234, nlayers: int = 1) -> dict:
-    """one TFIM layer (README.md:42-48 angles) on an L x L PERIODIC torus -- every site has the bulk degree 4, L^2 sites, 2 L^2 edges, four
-    colours for even L -- at bond dimension chi, ComplexF32, from BP-converged messages, reference-default bp_update_kwargs."""
+def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int = 1234, nlayers: int = 1, periodic: bool = True) -> dict:
+    """one TFIM layer (README.md:42-48 angles) on an L x L lattice at bond dimension chi, ComplexF32, from BP-converged messages,
+    reference-default bp_update_kwargs.  periodic = True: the torus (every site has the bulk degree 4, L^2 sites, 2 L^2 edges, four colours
+    for even L); periodic = False: the open lattice of the benchmark itself (BASELINE.json configs[1] at L = 20: 400 sites, 760 edges)."""
     from threadpoolctl import threadpool_limits
     # physical cores on an SMT-2 host, capped at 64: numpy's bundled OpenBLAS is built for at most 64 concurrent callers (NUM_THREADS = 64;
     # beyond that it warns, and with the nested chunk maps of this module it crashed on the 128-core box)
     nthreads = nthreads or max(1, min(64, (os.cpu_count() or 2) // 2))
     if os.environ.get("TNQS_CPU_NO_MALLOPT") != "1":
         _keep_big_blocks_on_the_heap()
-    g = o.named_grid((L, L), periodic=True)
+    g = o.named_grid((L, L), periodic=periodic)
     groups = o.edge_color(g)
     one_site = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
     colour_groups = [[("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp] for grp in groups]
@@ -292,7 +293,12 @@ def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int
             setattr(mod, name, fn)
     n2 = len(g.edges)
     nsweeps = float(np.mean([sum(s) for s in sweeps_all]))
-    flops = 384.0 * chi ** 5 * n2 + 64.0 * chi ** 5 * 2 * n2 * nsweeps              # SURVEY.md 8d, bulk sites
+    # SURVEY.md 8d per site degree z (n = z - 1 absorbed legs): a message costs (n + 1) d chi^(z+1) cMAC, a gate 2 (2 n d + 3 d^2) chi^(z+1) per
+    # PAIR of bulk sites, i.e. (2 n d + 3 d^2) chi^(z+1) per site; on the torus every site has z = 4 (384 chi^5 flop per gate, 64 chi^5 per message)
+    flops = 0.0
+    for (a, b) in g.edges:
+        for v in (a, b):
+            z = g.degree(v); flops += 8.0 * (2 * (z - 1) * 2 + 12) * chi ** (z + 1) + nsweeps * 8.0 * z * 2 * chi ** (z + 1)
     gf = flops / dt / 1e9
     return {"gates_per_s": n2 / dt, "seconds_per_layer": dt, "n_two_site": n2, "sites": len(g.vertices), "threads": nthreads,
             "bp_sweeps": sweeps_all[-1], "algorithmic_gflops": round(gf, 1), **rates,
@@ -302,9 +308,53 @@ def measure(chi: int = 32, L: int = 8, nthreads: Optional[int] = None, seed: int
             **({"profile_thread_seconds": {k: round(v, 2) for k, v in prof.items()}} if prof else {})}
 
 
+def measure_host(chi: int = 32, L: int = 20, periodic: bool = False, nproc: Optional[int] = None, seed: int = 1234) -> dict:
+    """the whole host: numpy's OpenBLAS admits at most 64 concurrent callers per process, so a 128-core box is driven by `nproc` PROCESSES of
+    64 threads, each pinned to its own block of cores (one socket each on the 2 x 64-core GPU box) and each running one layer of its own copy
+    of the workload at the same time.  Reported: the AGGREGATE rate (sum of the processes' gates over the common wall time) and the
+    per-process figures -- a throughput baseline; the latency of a single layer is that of one process."""
+    import json
+    import subprocess
+    import sys
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    ncores = max(1, len(cpus) // 2) if len(cpus) >= 4 else len(cpus)          # SMT-2: physical cores = half the hardware threads
+    nproc = nproc or max(1, min(4, ncores // 64))
+    per = max(1, min(64, ncores // nproc))
+    procs = []
+    t0 = time.perf_counter()
+    for r in range(nproc):
+        mask = cpus[r * per:(r + 1) * per]                                  # first hardware thread of consecutive cores (Linux numbers siblings last)
+        code = ("import os, sys, json; os.sched_setaffinity(0, %r); sys.path.insert(0, %r); import cpu_layer; "
+                "print(json.dumps(cpu_layer.measure(%d, %d, nthreads=%d, seed=%d, periodic=%r)))"
+                % (set(mask), os.path.dirname(os.path.abspath(__file__)), chi, L, per, seed + r, periodic))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for pr in procs:
+        so, se = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("cpu_layer worker failed: " + se[-2000:])
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    wall = time.perf_counter() - t0
+    slowest = max(x["seconds_per_layer"] for x in outs)
+    total_gates = sum(x["n_two_site"] for x in outs)
+    agg = dict(outs[0])
+    agg.update(gates_per_s=total_gates / slowest, seconds_per_layer=slowest, threads=per * nproc, processes=nproc, threads_per_process=per,
+               per_process_gates_per_s=[round(x["gates_per_s"], 2) for x in outs], algorithmic_gflops=round(sum(x["algorithmic_gflops"] for x in outs), 1),
+               wall_seconds_incl_setup=round(wall, 1), periodic=periodic, L=L)
+    agg["frac_of_square_cgemm"] = round(agg["algorithmic_gflops"] / (nproc * outs[0]["square_cgemm_gflops"]), 3)
+    agg["frac_of_mode_product_shape"] = round(agg["algorithmic_gflops"] / (nproc * outs[0]["mode_product_shape_gflops"]), 3)
+    return agg
+
+
 if __name__ == "__main__":
     import json
     import sys
     chi = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     L = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    print(json.dumps(measure(chi, L)))
+    if len(sys.argv) > 3 and sys.argv[3] == "host":
+        print(json.dumps(measure_host(chi, L)))
+    else:
+        print(json.dumps(measure(chi, L, periodic=not (len(sys.argv) > 3 and sys.argv[3] == "open"))))
