@@ -467,7 +467,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                     ncfull.push_back(Nc);
                 } else {
                     const int Mr = std::max(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2), Nc = std::min(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2);
-                    j = JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, gitems[q].info + 4, gitems[q].info, gitems[q].d1, gitems[q].d2};
+                    j = JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, gitems[q].info + 4, gitems[q].info, gitems[q].d1, gitems[q].d2,
+                                   gitems[q].lowG ? gitems[q].kappa * gitems[q].chi : 0};      // low-rank route expected: K columns
                     ncfull.push_back(Nc);
                 }
                 j.V = nullptr;          // V is never accumulated from the rotations (theta0_used): recovered below

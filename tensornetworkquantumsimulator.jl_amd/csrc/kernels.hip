@@ -683,25 +683,31 @@ template void launch_recover_v<float>(hipStream_t, const RecoverItem*, int, int)
 template void launch_recover_v<double>(hipStream_t, const RecoverItem*, int, int);
 
 // lds_bytes: max over the items of (m*n + (V ? n*n : 0)) * sizeof(complex<T>); 0 selects the global-memory kernel
-template <class T, int RQ> static void launch_jacobi_lds(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes) {
+// A quarter wave rotates one column pair, so a round of an n-column matrix keeps n / 8 waves busy; waves beyond that only add to every
+// barrier of the sweep (and a 1024-thread workgroup per 32 x 32 message matrix left three quarters of each CU's wave slots idling at
+// barriers: 1140 such matrices per colour batch).  The workgroup is sized for the columns the matrices are expected to have (`ncols`;
+// more columns than that still work: the slots loop).
+template <class T, int RQ> static void launch_jacobi_lds(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int ncols) {
     set_max_dynamic_lds((const void*)jacobi_lds_kernel<T, RQ>, (size_t)(160 * 1024 - 256));
-    hipLaunchKernelGGL((jacobi_lds_kernel<T, RQ>), dim3(nitems), dim3(1024), lds_bytes, s, d_items, max_sweeps); TNQS_CHECK_LAUNCH();
+    int waves = (ncols + 7) / 8; waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
+    hipLaunchKernelGGL((jacobi_lds_kernel<T, RQ>), dim3(nitems), dim3(64 * waves), lds_bytes, s, d_items, max_sweeps); TNQS_CHECK_LAUNCH();
 }
-// mmax: largest row count among the items (selects the rows-per-lane instantiation)
-template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax) {
+// mmax: largest row count among the items (selects the rows-per-lane instantiation); ncols: expected column count (0: mmax)
+template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax, int ncols) {
     if (nitems <= 0) return;
+    if (ncols <= 0) ncols = mmax;
     if (lds_bytes > 0 && lds_bytes <= 160 * 1024 - 256 && mmax <= 256) {
-        if (mmax <= 32) launch_jacobi_lds<T, 2>(s, d_items, nitems, max_sweeps, lds_bytes);
-        else if (mmax <= 64) launch_jacobi_lds<T, 4>(s, d_items, nitems, max_sweeps, lds_bytes);
-        else if (mmax <= 96) launch_jacobi_lds<T, 6>(s, d_items, nitems, max_sweeps, lds_bytes);
-        else if (mmax <= 128) launch_jacobi_lds<T, 8>(s, d_items, nitems, max_sweeps, lds_bytes);
-        else launch_jacobi_lds<T, 16>(s, d_items, nitems, max_sweeps, lds_bytes);
+        if (mmax <= 32) launch_jacobi_lds<T, 2>(s, d_items, nitems, max_sweeps, lds_bytes, ncols);
+        else if (mmax <= 64) launch_jacobi_lds<T, 4>(s, d_items, nitems, max_sweeps, lds_bytes, ncols);
+        else if (mmax <= 96) launch_jacobi_lds<T, 6>(s, d_items, nitems, max_sweeps, lds_bytes, ncols);
+        else if (mmax <= 128) launch_jacobi_lds<T, 8>(s, d_items, nitems, max_sweeps, lds_bytes, ncols);
+        else launch_jacobi_lds<T, 16>(s, d_items, nitems, max_sweeps, lds_bytes, ncols);
     } else {
         hipLaunchKernelGGL((jacobi_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items, max_sweeps); TNQS_CHECK_LAUNCH();
     }
 }
-template void launch_jacobi<float>(hipStream_t, const JacobiItem*, int, int, size_t, int);
-template void launch_jacobi<double>(hipStream_t, const JacobiItem*, int, int, size_t, int);
+template void launch_jacobi<float>(hipStream_t, const JacobiItem*, int, int, size_t, int, int);
+template void launch_jacobi<double>(hipStream_t, const JacobiItem*, int, int, size_t, int, int);
 
 // ------------------------------------------------------------------------------------------------------------
 // small sites (N < n): matricise psi~ to f64, and turn the rotated columns (U Sigma) into the (A, V) pair gate_eigs reads

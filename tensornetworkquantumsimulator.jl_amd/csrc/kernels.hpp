@@ -48,6 +48,7 @@ struct JacobiItem {       // one-sided Jacobi on A (m x n, col-major, ld = m); V
     // R factors) and read from its info array (GateItem::info) -- m, n above are then upper bounds the host sized the launch with.  This
     // is what lets a gate batch run from the Gram matrices to the truncated factors without a host round trip in between.
     const int* dyn; int dm, dn;
+    int nhint;            // host only: the column count the item is EXPECTED to have when dyn decides it (0: n)
 };
 // dimensions of a gate's theta SVD from its info array (gate_theta_kernel): rows, columns of theta, columns the Jacobi runs on
 __host__ __device__ inline void theta_dims(const int* info, int d1, int d2, int& m, int& nfull, int& ncol) {
@@ -148,7 +149,7 @@ template <class T> void launch_msg_finalize(hipStream_t s, const MsgFinalItem* d
 struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; int nu; const int* dyn; int dm, dn; };   // dyn: as in JacobiItem   // V (n x nu) = A0^dagger (U Sigma) Sigma^-2; A0: m x n, U Sigma: m x nu
 // LDS bytes the LDS-resident Jacobi needs for an m x n matrix (columns padded by 2 elements)
 inline size_t jacobi_lds_bytes(int m, int n, bool withV, size_t esz) { return ((size_t)(m + 2) * n + (withV ? (size_t)(n + 2) * n : 0)) * esz; }
-template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax);
+template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax, int ncols = 0);   // ncols: expected columns (sizes the workgroup of the LDS kernel)
 // sites with fewer fibers than columns (N < n = d*chi): the R factor comes from a one-sided Jacobi SVD of the n x N matrix
 // M[(s,b), outer] = conj(psi~[outer,(s,b)]) (f64) instead of the eigen factorisation of the rank-deficient n x n Gram matrix
 struct SmallSvdItem { const void* src; void* M; void* GA; void* GV; int d, low, chi_b, hi; };   // low = pre(b)/d, hi = post(b); n = d*chi_b, N = low*hi
