@@ -82,6 +82,7 @@ typedef struct {
     int n_qr2_sites;        /* ComplexF64 sites that went through the second factorisation pass (ill-conditioned psi~) */
     int n_lowrank_svd;      /* two-site gates whose theta SVD ran on the low-rank factor (gate of operator Schmidt rank kappa, kappa chi < d chi) */
     int n_tall_svd;         /* theta SVDs that went through the Cholesky-QR preprocessing (matrix too tall for the LDS-resident Jacobi: 256 x 128 at chi = 64) */
+    int n_deferred_1site;   /* unitary one-site gates that were only recorded and later absorbed by a two-site gate on the vertex (or applied when the tensor was read) */
 } tnqs_apply_stats;
 
 /* ---- library ---------------------------------------------------------------------------------------- */

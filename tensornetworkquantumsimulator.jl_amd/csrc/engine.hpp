@@ -102,6 +102,13 @@ struct State {
     std::vector<Buf> sscale;       // pending real scale factor of a site tensor (one device double; null = 1): the tensor the
                                    // reference holds is site[v] * (*sscale[v]).  Normalisation after a gate only records the factor;
                                    // every consumer on the hot path is scale-invariant, the others call materialize_scale() first
+    // pending one-site gate of a vertex (d x d complex128, column-major [s' + d s]; empty = none): the tensor the reference holds is
+    // (G applied to the site leg of) site[v] * sscale[v].  A UNITARY one-site gate is only recorded: BP messages sum over the site index of
+    // ket and bra, so they do not see it; the next two-site gate on the vertex absorbs it exactly (g . (G1 (x) G2) is the gate simple_update
+    // then applies: same theta); everything that reads the tensor itself materialises it first (materialize_pending).  Host-side metadata,
+    // identical on every rank of a sharded handle.  unit_norm[v]: the last operation on v left ||psi_v|| = 1 (normalize_tensors), so a
+    // deferred unitary gate with normalize_tensors has nothing to normalise
+    std::vector<std::vector<double>> pend1; std::vector<char> unit_norm;
     std::vector<Buf> msg;          // 2*ne, null = unset = identity (tensornetworkstate.jl:72-75)
     std::shared_ptr<Pool> pool;
     hipStream_t stream = nullptr; bool own_stream = false;

@@ -185,6 +185,7 @@ State* state_create(int nv, int ne, const int32_t* es, const int32_t* ed, const 
     if (sd) for (int v = 0; v < nv; ++v) { if (sd[v] < 1 || sd[v] > 16) throw Err(TNQS_ERR_INVALID, "tnqs_create: site dimension out of range"); s->d[v] = sd[v]; }
     s->chi.assign(ne, 1);
     s->site.resize(nv); s->sscale.assign(nv, nullptr); s->msg.assign(2 * (size_t)ne, nullptr);
+    s->pend1.assign(nv, {}); s->unit_norm.assign(nv, 0);
     s->pool = std::make_shared<Pool>(device);
     s->prof = std::make_shared<Prof>();
     s->stream = acquire_stream(device); s->own_stream = true;
@@ -196,6 +197,7 @@ State* state_copy(const State* o) {
     auto s = std::make_unique<State>();
     s->g = o->g; s->dtype = o->dtype; s->real_io = o->real_io; s->device = o->device; s->d = o->d; s->chi = o->chi;
     s->site = o->site; s->sscale = o->sscale; s->msg = o->msg; s->pool = o->pool; s->prof = o->prof;
+    s->pend1 = o->pend1; s->unit_norm = o->unit_norm;
     s->rank = o->rank; s->nranks = o->nranks; s->owner = o->owner; s->ag_fn = o->ag_fn; s->ag_ctx = o->ag_ctx;
     s->exch = o->exch; s->exch_bytes = o->exch_bytes; s->comm = o->comm;
     HIPCHK(hipSetDevice(o->device));
@@ -237,6 +239,7 @@ void state_set_site(State* s, int v, const void* host, int ndim, const int64_t* 
     size_t n = 1; std::vector<long long> stride_caller(ndim);
     for (int k = 0; k < ndim; ++k) { stride_caller[k] = (long long)n; if (dims[k] < 1) throw Err(TNQS_ERR_INVALID, "set_site_tensor: bad dim"); n *= (size_t)dims[k]; }
     HIPCHK(hipSetDevice(s->device));
+    s->pend1[v].clear(); s->unit_norm[v] = 0;                   // a new tensor: nothing pending on it
     if (!s->owns(v)) {          // sharded, not ours: only the bond dimensions are recorded (host may be null)
         s->site[v] = nullptr; s->sscale[v] = nullptr;
         for (int j = 0; j < z; ++j) {
@@ -265,6 +268,7 @@ void state_get_site(State* s, int v, void* host, int ndim, const int32_t* role) 
     const Graph& g = *s->g;
     if (v < 0 || v >= g.nv) throw Err(TNQS_ERR_INVALID, "get_site_tensor: bad vertex");
     if (!s->site[v]) throw Err(TNQS_ERR_INVALID, "get_site_tensor: vertex not owned by this rank");
+    materialize_pending(s, {v});
     SD sd = site_dims(s, v);
     if (ndim != sd.z + 1 || ndim > 8) throw Err(TNQS_ERR_INVALID, "get_site_tensor: ndim mismatch");
     // consistency: the neighbour tensors must agree on bond dims; verify buffer size

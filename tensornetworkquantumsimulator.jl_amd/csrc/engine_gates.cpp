@@ -31,6 +31,26 @@ void materialize_scale_all(State* s) {
     std::vector<int> all(s->site.size()); std::iota(all.begin(), all.end(), 0);
     materialize_scale(s, all);
 }
+template <class T> static void apply_one_site_batch(State* s, const std::vector<Gate1>& gates_in, bool normalize, bool force);
+// apply the pending one-site gates of `verts` (State::pend1) in one streaming pass; they are unitary, so norms, pending scale factors
+// and unit_norm stay as they are
+void materialize_pending(State* s, const std::vector<int>& verts) {
+    std::vector<std::vector<double>> mats; std::vector<Gate1> gs; std::vector<char> norm_was;
+    for (int v : verts) {
+        if (v < 0 || v >= (int)s->pend1.size() || s->pend1[v].empty()) continue;
+        mats.push_back(std::move(s->pend1[v])); s->pend1[v].clear(); norm_was.push_back(s->unit_norm[v]);
+        gs.push_back(Gate1{v, nullptr});
+    }
+    if (gs.empty()) return;
+    for (size_t k = 0; k < gs.size(); ++k) gs[k].mat = mats[k].data();
+    HIPCHK(hipSetDevice(s->device));
+    if (s->dtype == TNQS_C64) apply_one_site_batch<float>(s, gs, false, true); else apply_one_site_batch<double>(s, gs, false, true);
+    for (size_t k = 0; k < gs.size(); ++k) s->unit_norm[gs[k].v] = norm_was[k];
+}
+void materialize_pending_all(State* s) {
+    std::vector<int> all(s->site.size()); std::iota(all.begin(), all.end(), 0);
+    materialize_pending(s, all);
+}
 
 // the new site tensors replace the old ones; with `normalize` their norm (from the producing kernel's partial sums) becomes
 // the pending scale factor 1/||psi|| instead of a scaling pass over the tensor (simple_update.jl:66-72 normalises eagerly;
@@ -56,9 +76,46 @@ template <class T> static void norm_and_replace(State* s, std::vector<int>& vert
     }
 }
 
-template <class T> static void apply_one_site_batch(State* s, const std::vector<Gate1>& gates, bool normalize) {
-    if (gates.empty()) return;
+// d x d complex matrices, column-major [s' + d s] as (re, im) pairs
+static bool is_unitary(const double* m, int d) {
+    for (int a = 0; a < d; ++a) for (int b = 0; b < d; ++b) {
+        double re = 0, im = 0;                                    // (G^dagger G)[a][b] = sum_s conj(G[s][a]) G[s][b]
+        for (int t = 0; t < d; ++t) { const double* x = m + 2 * (t + d * a); const double* y = m + 2 * (t + d * b); re += x[0] * y[0] + x[1] * y[1]; im += x[0] * y[1] - x[1] * y[0]; }
+        if (std::fabs(re - (a == b ? 1.0 : 0.0)) > 1e-13 || std::fabs(im) > 1e-13) return false;
+    }
+    return true;
+}
+static std::vector<double> matmul_dd(const double* a, const double* b, int d) {       // a . b
+    std::vector<double> c(2 * (size_t)d * d, 0.0);
+    for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) {
+        double re = 0, im = 0;
+        for (int t = 0; t < d; ++t) { const double* x = a + 2 * (i + d * t); const double* y = b + 2 * (t + d * j); re += x[0] * y[0] - x[1] * y[1]; im += x[0] * y[1] + x[1] * y[0]; }
+        c[2 * (i + d * j)] = re; c[2 * (i + d * j) + 1] = im;
+    }
+    return c;
+}
+
+template <class T> static void apply_one_site_batch(State* s, const std::vector<Gate1>& gates_in, bool normalize, bool force) {
+    if (gates_in.empty()) return;
     const size_t esz = s->esz();
+    // ---- deferral (State::pend1): a unitary gate on a tensor that needs no normalisation pass is only recorded -- BP does not see it, the
+    // next two-site gate on the vertex absorbs it.  Anything else is applied now, composed with what was pending on the vertex.
+    std::vector<std::vector<double>> composed; composed.reserve(gates_in.size());
+    std::vector<Gate1> gates;
+    const bool may_defer = !force && defer_site1() && s->nranks == 1;      // (sharded handles apply at once: the pending set must be identical on all ranks)
+    for (auto& g1 : gates_in) {
+        const int d = s->d[g1.v];
+        std::vector<double>& pend = s->pend1[g1.v];
+        if (may_defer && is_unitary(g1.mat, d) && (!normalize || s->unit_norm[g1.v])) {
+            pend = pend.empty() ? std::vector<double>(g1.mat, g1.mat + 2 * (size_t)d * d) : matmul_dd(g1.mat, pend.data(), d);
+            s->stats.n_deferred_1site += 1;
+            continue;
+        }
+        if (!pend.empty()) { composed.push_back(matmul_dd(g1.mat, pend.data(), d)); pend.clear(); gates.push_back(Gate1{g1.v, composed.back().data()}); }
+        else gates.push_back(g1);
+        s->unit_norm[g1.v] = normalize ? 1 : 0;
+    }
+    if (gates.empty()) return;
     if (std::is_same<T, float>::value) {
         bool all2 = true; for (auto& g1 : gates) all2 = all2 && s->d[g1.v] == 2;
         if (all2) {         // streaming 2x2 kernel (HBM-bound: read + write each site tensor once)
@@ -124,13 +181,31 @@ template <class T> static void apply_one_site_batch(State* s, const std::vector<
     norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, normalize);
 }
 
-template <class T> static void apply_two_site_batch(State* s, const std::vector<Gate2>& gates, const tnqs_apply_opts& ao, double* errs) {
-    if (gates.empty()) return;
+template <class T> static void apply_two_site_batch(State* s, const std::vector<Gate2>& gates_in, const tnqs_apply_opts& ao, double* errs) {
+    if (gates_in.empty()) return;
     const Graph& g = *s->g;
     const size_t esz = s->esz();
     const bool sharded = s->nranks > 1;
     const double sqrt_cutoff = ao.sqrt_cutoff >= 0 ? ao.sqrt_cutoff : 10.0 * (s->dtype == TNQS_C64 ? 1.1920928955078125e-07 : 2.220446049250313e-16);
-    const int ng = (int)gates.size();
+    const int ng = (int)gates_in.size();
+    // pending one-site gates of the gate vertices are absorbed into the gate matrix: g' = g . (G1 (x) G2) is exactly what simple_update sees
+    // when the one-site gates were applied to the tensors first (State::pend1); cleared once the batch has replaced the tensors
+    std::vector<std::vector<double>> absorbed; absorbed.reserve(gates_in.size());
+    std::vector<Gate2> gates = gates_in;
+    for (auto& g2 : gates) {
+        const std::vector<double>& p1 = s->pend1[g2.v1]; const std::vector<double>& p2 = s->pend1[g2.v2];
+        if (p1.empty() && p2.empty()) continue;
+        const int d1 = s->d[g2.v1], d2 = s->d[g2.v2], dd = d1 * d2;
+        std::vector<double> kron(2 * (size_t)dd * dd, 0.0);                 // (G1 (x) G2)[(t1 t2),(s1 s2)], first vertex most significant
+        for (int t1 = 0; t1 < d1; ++t1) for (int s1 = 0; s1 < d1; ++s1) for (int t2 = 0; t2 < d2; ++t2) for (int s2 = 0; s2 < d2; ++s2) {
+            const double ar = p1.empty() ? (t1 == s1 ? 1.0 : 0.0) : p1[2 * (t1 + d1 * s1)], ai = p1.empty() ? 0.0 : p1[2 * (t1 + d1 * s1) + 1];
+            const double br = p2.empty() ? (t2 == s2 ? 1.0 : 0.0) : p2[2 * (t2 + d2 * s2)], bi = p2.empty() ? 0.0 : p2[2 * (t2 + d2 * s2) + 1];
+            const size_t e = (size_t)(t1 * d2 + t2) + (size_t)dd * (s1 * d2 + s2);
+            kron[2 * e] = ar * br - ai * bi; kron[2 * e + 1] = ar * bi + ai * br;
+        }
+        absorbed.push_back(matmul_dd(g2.mat, kron.data(), dd));
+        g2.mat = absorbed.back().data();
+    }
     HostTimer ht_a(3);                 // TNQS_HOST_TIMING=1: host time of the batch up to the first read-back (3), between the read-backs (4), after them (5)
     if (!ao.normalize_tensors) {       // without the final normalisation the result scales with the inputs: apply pending factors first
         std::vector<int> vs; for (auto& g2 : gates) { vs.push_back(g2.v1); vs.push_back(g2.v2); }
@@ -331,7 +406,9 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         int chi = a.sd.chi[a.bleg];
         w.n1 = a.sd.d * chi; w.n2 = b.sd.d * chi; w.chi = chi;
         int Mr = w.n1 * a.sd.d, Nc = w.n2 * b.sd.d;
-        if (Mr > 256 || Nc > 256) throw Err(TNQS_ERR_UNSUPPORTED, "two-site gate: d^2*chi > 256 is not supported by the Jacobi SVD kernel yet");
+        // theta is at most 512 x 512 (d^2 chi <= 512: chi <= 128 for qubits); up to 256 rows everything has an LDS or MFMA-preprocessed route, beyond
+        // that the factorisations run in the global-memory Jacobi kernel (8 rows per lane)
+        if (Mr > 512 || Nc > 512) throw Err(TNQS_ERR_UNSUPPORTED, "two-site gate: d^2*chi > 512 is not supported by the theta SVD kernels");
         int cap = std::min(Mr, Nc); if (ao.maxdim > 0) cap = std::min(cap, ao.maxdim);
         w.cap = cap; cap_max = std::max(cap_max, cap);
         x2_max = std::max(x2_max, (size_t)w.n2 * b.sd.d * cap * esz);
@@ -792,13 +869,14 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         const DiagItem* d = upload(s, di);
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_diag<T>(s->stream, d, (int)di.size()); }
     }
+    for (auto& g2 : gates) { s->pend1[g2.v1].clear(); s->pend1[g2.v2].clear(); s->unit_norm[g2.v1] = s->unit_norm[g2.v2] = ao.normalize_tensors ? 1 : 0; }
     s->stats.n_two_site += ng;
     soft_sync(s);   // workspace of this batch goes back to the pool at the next stream synchronisation (the BP update's first read-back)
 }
 
 template <class T> static void flush_batch(State* s, std::vector<Gate1>& b1, std::vector<Gate2>& b2, const tnqs_apply_opts& ao, double* errs) {
     if (b1.empty() && b2.empty()) return;
-    apply_one_site_batch<T>(s, b1, ao.normalize_tensors != 0);
+    apply_one_site_batch<T>(s, b1, ao.normalize_tensors != 0, false);
     apply_two_site_batch<T>(s, b2, ao, errs);
     s->stats.n_batches += 1;
     b1.clear(); b2.clear();

@@ -43,6 +43,7 @@ TNQS_SWITCH(use_lowrank, !envflag("TNQS_NO_LOWRANK"))            // theta SVD on
 TNQS_SWITCH(use_small_svd, !envflag("TNQS_NO_SMALLSVD"))         // sites with fewer fibers than columns: Gram + eigen instead of the direct SVD
 TNQS_SWITCH(use_apply64, !envflag("TNQS_NO_APPLY64"))            // chi = 32 gate epilogue on the fiber kernel instead of the plane kernel
 TNQS_SWITCH(eager_scale, envflag("TNQS_EAGER_SCALE"))            // apply 1/||psi|| after every gate instead of deferring it
+TNQS_SWITCH(defer_site1, !envflag("TNQS_NO_DEFER_1SITE"))         // unitary one-site gates are applied in a pass of their own instead of being carried to the next two-site gate
 // chi = 64 kernels (kernels_chi64.hip); TNQS_NO_CHI64=1 switches all of them off
 TNQS_SWITCH(use_rowgemm, !(envflag("TNQS_NO_ROWGEMM") || envflag("TNQS_NO_CHI64")))      // register-direct MFMA fiber GEMM
 TNQS_SWITCH(use_rowgemm32, !(envflag("TNQS_NO_ROWGEMM32") || envflag("TNQS_NO_ROWGEMM")))  // the same kernel for chi = 32 legs and the chi = 32 gate epilogue
@@ -101,6 +102,8 @@ inline void drained(State* s) {
 }
 void materialize_scale(State* s, const std::vector<int>& verts);
 void materialize_scale_all(State* s);
+void materialize_pending(State* s, const std::vector<int>& verts);      // apply the pending one-site gates of these vertices (State::pend1)
+void materialize_pending_all(State* s);
 inline Buf dalloc(State* s, size_t bytes) {
     auto b = std::make_shared<DevBuf>();
     b->pool = s->pool; b->bytes = bytes;

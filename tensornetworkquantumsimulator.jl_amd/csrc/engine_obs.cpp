@@ -9,6 +9,7 @@ namespace tnqs {
 template <class T> static void rdm_batch(State* s, const std::vector<int>& vs, double* out /* per vertex d*d complex128, packed */) {
     const Graph& g = *s->g;
     HIPCHK(hipSetDevice(s->device));
+    materialize_pending(s, vs);
     std::vector<Chain> chains(vs.size());
     for (size_t i = 0; i < vs.size(); ++i) {
         int v = vs[i];
@@ -126,7 +127,7 @@ template <class T> static void rescale_vertices_t(State* s, int n, const int32_t
     if (!cs.empty()) {
         const CScaleItem* d = upload(s, cs);
         launch_cscale<T>(s->stream, d, (int)cs.size());
-        for (size_t i = 0; i < vs.size(); ++i) { s->keepalive.push_back(s->site[vs[i]]); s->site[vs[i]] = outs[i]; }
+        for (size_t i = 0; i < vs.size(); ++i) { s->keepalive.push_back(s->site[vs[i]]); s->site[vs[i]] = outs[i]; s->unit_norm[vs[i]] = 0; }
     }
     sync(s);
 }
@@ -235,6 +236,7 @@ void expect_region(State* s, int nr, const int32_t* rv, const int32_t* parent, c
     const Graph& g = *s->g;
     if (nr < 1 || !rv || !parent || !ops || !out4) throw Err(TNQS_ERR_INVALID, "expect_region: bad arguments");
     int roots = 0;
+    materialize_pending_all(s);
     for (int i = 0; i < nr; ++i) {
         if (rv[i] < 0 || rv[i] >= g.nv) throw Err(TNQS_ERR_INVALID, "expect_region: bad vertex");
         if (parent[i] < 0) ++roots; else if (parent[i] >= nr || g.edge(rv[i], rv[parent[i]]) < 0) throw Err(TNQS_ERR_INVALID, "expect_region: parent is not a neighbour");
@@ -310,7 +312,7 @@ template <class T> static void symmetric_gauge_t(State* s, double regularization
         Buf nb;
         for (int k = 0; k < 2; ++k) if (chains[i].tmp[k] && chains[i].tmp[k]->p == chains[i].result) nb = chains[i].tmp[k];
         if (!nb) throw Err(TNQS_ERR_HIP, "internal: symmetric_gauge chain result");
-        s->keepalive.push_back(s->site[verts[i]]); s->site[verts[i]] = nb;
+        s->keepalive.push_back(s->site[verts[i]]); s->site[verts[i]] = nb; s->unit_norm[verts[i]] = 0;
     }
     // both messages of an edge := diag(S)   (:54-55)
     std::vector<DiagItem> di;

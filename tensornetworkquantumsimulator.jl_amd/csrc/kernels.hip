@@ -315,11 +315,10 @@ template void launch_msg_finalize<double>(hipStream_t, const MsgFinalItem*, int)
 
 // ------------------------------------------------------------------------------------------------------------
 // one-sided (Hestenes) Jacobi: A <- A J_1 J_2 ..., V <- V J_1 J_2 ...  until the columns of A are orthogonal.
-// One workgroup per matrix, one wave per column pair, round-robin pair ordering.  m, n <= 256.
+// One workgroup per matrix, one wave per column pair, round-robin pair ordering.  m <= 64 R (R = 4 or 8: up to 512 rows), any n.
 // ------------------------------------------------------------------------------------------------------------
-template <class T>
+template <class T, int R>          // R rows per lane: m <= 64 R
 __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restrict__ items, int max_sweeps) {
-    constexpr int R = 4;
     __shared__ int s_rot;
     const JacobiItem it = items[blockIdx.x];
     cx<T>* A = reinterpret_cast<cx<T>*>(it.A);
@@ -627,9 +626,8 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
 // V[:,u] = A0^dagger a_u / |a_u|^2   (a_u = column u of U Sigma), for the factorisations run without accumulating V.
 // grid (item, column block of 8): a wave owns one output column u and keeps a_u in registers (lanes = rows, coalesced);
 // every V[col, u] is one coalesced column read of A0 and a wave reduction.
-template <class T>
+template <class T, int R>                  // m <= 64 R rows
 __global__ __launch_bounds__(512) void recover_v_kernel(const RecoverItem* __restrict__ items) {
-    constexpr int R = 4;                     // m <= 256 rows
     const RecoverItem it = items[blockIdx.x];
     const cx<T>* A0 = reinterpret_cast<const cx<T>*>(it.A0);
     const cx<T>* A = reinterpret_cast<const cx<T>*>(it.A);
@@ -677,7 +675,8 @@ __global__ __launch_bounds__(512) void recover_v_kernel(const RecoverItem* __res
 }
 template <class T> void launch_recover_v(hipStream_t s, const RecoverItem* d_items, int nitems, int nmax) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((recover_v_kernel<T>), dim3(nitems, (nmax + 7) / 8), dim3(512), 0, s, d_items); TNQS_CHECK_LAUNCH();
+    // (rows: at most 512 = theta of d^2 chi <= 512; R = 8 costs registers only when it is needed, and the caller cannot know m per item here)
+    hipLaunchKernelGGL((recover_v_kernel<T, 8>), dim3(nitems, (nmax + 7) / 8), dim3(512), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_recover_v<float>(hipStream_t, const RecoverItem*, int, int);
 template void launch_recover_v<double>(hipStream_t, const RecoverItem*, int, int);
@@ -703,7 +702,10 @@ template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, 
         else if (mmax <= 128) launch_jacobi_lds<T, 8>(s, d_items, nitems, max_sweeps, lds_bytes, ncols);
         else launch_jacobi_lds<T, 16>(s, d_items, nitems, max_sweeps, lds_bytes, ncols);
     } else {
-        hipLaunchKernelGGL((jacobi_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items, max_sweeps); TNQS_CHECK_LAUNCH();
+        if (mmax > 512) throw std::runtime_error("launch_jacobi: more than 512 rows");
+        if (mmax <= 256) { hipLaunchKernelGGL((jacobi_kernel<T, 4>), dim3(nitems), dim3(1024), 0, s, d_items, max_sweeps); }
+        else { hipLaunchKernelGGL((jacobi_kernel<T, 8>), dim3(nitems), dim3(1024), 0, s, d_items, max_sweeps); }
+        TNQS_CHECK_LAUNCH();
     }
 }
 template void launch_jacobi<float>(hipStream_t, const JacobiItem*, int, int, size_t, int, int);
@@ -1061,7 +1063,7 @@ __device__ int gate_ill_conditioned(int chol, const cx<double>* L, int n, const 
 
 template <class T>
 __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __restrict__ items) {
-    __shared__ double lam_tmp[256];
+    __shared__ double lam_tmp[512];
     __shared__ int s_r1, s_r2;
     // grid (gate, part): every part repeats the small serial prologue (identical values) and takes a strided share of the element loops --
     // with one workgroup per gate the kernel was pure latency (0.56 ms per colour batch whatever the batch size)
@@ -1366,8 +1368,8 @@ void launch_qr2_compose(hipStream_t s, const Qr2ComposeItem* d_items, int nitems
 
 template <class T>
 __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __restrict__ items) {
-    __shared__ double sig[256];
-    __shared__ int perm[256];
+    __shared__ double sig[512];
+    __shared__ int perm[512];
     __shared__ int s_keep;
     // grid (gate, part) as gate_theta_kernel: the ranking / truncation prologue is repeated per part, only part 0 writes its results
     const GateItem it = items[blockIdx.x];
@@ -1425,7 +1427,7 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
     }
     // per-column factors of R^+ = W diag(lambda^-1/2) (and of the theta scaling), once per workgroup: a square root and a division per
     // INNER iteration were most of this kernel's time
-    __shared__ double fa1[256], fa2[256];
+    __shared__ double fa1[512], fa2[512];
     for (int a = threadIdx.x; a < r1; a += blockDim.x) fa1[a] = (wide ? 1.0 : tsc) / sqrt(it.lam1[a]);      // th holds the scaled U Sigma (tv, the recovered vectors, is scale free)
     for (int c = threadIdx.x; c < r2; c += blockDim.x) fa2[c] = (wide ? tsc : 1.0) / sqrt(it.lam2[c]);
     __syncthreads();

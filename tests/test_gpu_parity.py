@@ -428,6 +428,55 @@ def test_deferred_normalisation_is_invisible_to_callers(dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_deferred_one_site_gates_are_invisible_to_callers(dtype):
+    """a UNITARY one-site gate is only recorded on the handle (State::pend1): BP does not see it and the next two-site gate on the vertex absorbs
+    it into its matrix.  Every accessor must still see simple_update.jl:26-28's result: (1) downloaded tensors, (2) <Z> and the rdm, (3) copies,
+    (4) a second one-site gate on the same vertex composes, (5) a non-unitary one-site gate is applied at once together with what was pending,
+    (6) a two-site gate after pending gates gives the oracle's truncation errors / <Z>, and nothing stays pending on its vertices."""
+    tol = 2e-6 if dtype == np.complex64 else 1e-12
+    g = tn.named_grid((3, 3))
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=2, seed=23)
+    for v in g.vertices:
+        psi.tensors[v] = (psi.tensors[v] / np.linalg.norm(psi.tensors[v])).astype(dtype)
+    bpc = tn.update(tn.BeliefPropagationCache(psi), **tight(dtype))
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **tight(dtype))
+    kw = dict(maxdim=4, cutoff=1e-12, normalize_tensors=False)
+    ones = [("Rx", [v], 0.37) for v in g.vertices] + [("Rz", [v], -0.81) for v in g.vertices[:5]]
+    info = {}
+    out, _ = tn.apply_gates(ones, bpc, apply_kwargs=kw, bp_update_kwargs=tight(dtype), info=info)
+    ob, _ = o.apply_gates(ones, oc, apply_kwargs=kw, bp_update_kwargs=tight(dtype))
+    assert info["n_deferred_1site"] == len(ones)
+    for v in g.vertices:                                      # (2) observables first: the tensors are still un-materialised here
+        assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(ob, Z, v)) < 20 * tol
+    cp = out.copy()                                           # (3)
+    for v in g.vertices:                                      # (1), (4)
+        assert np.max(np.abs(out.tensor(v) - ob.tns.tensors[v])) < 20 * tol
+        assert np.max(np.abs(cp.tensor(v) - ob.tns.tensors[v])) < 20 * tol
+    # (5) non-unitary gate on a vertex that carries a pending unitary one
+    v0 = g.vertices[4]
+    seq = [("Rx", [v0], 0.2), (np.array([[1.0, 0.3], [0.0, 0.5j]], dtype=complex), [v0])]
+    info = {}
+    out2, _ = tn.apply_gates(seq, bpc, apply_kwargs=kw, bp_update_kwargs=tight(dtype), info=info)
+    ob2, _ = o.apply_gates(seq, oc, apply_kwargs=kw, bp_update_kwargs=tight(dtype))
+    assert info["n_deferred_1site"] == 1
+    assert np.max(np.abs(out2.tensor(v0) - ob2.tns.tensors[v0])) < 20 * tol
+    # (6) a layer: one-site gates absorbed by the two-site gates of the first colour that touches each vertex
+    layer = tfim_layer(g, tn.edge_color(g))
+    kwn = dict(maxdim=3, cutoff=1e-12, normalize_tensors=True)
+    b1 = tn.update(tn.BeliefPropagationCache(psi), **tight(dtype))
+    info = {}
+    o1, e1 = tn.apply_gates(layer, b1, apply_kwargs=kwn, bp_update_kwargs=tight(dtype), info=info)
+    o1, e1b = tn.apply_gates(layer, o1, apply_kwargs=kwn, bp_update_kwargs=tight(dtype), info=info)      # second layer: tensors are normalised -> deferral with normalize_tensors
+    assert info["n_deferred_1site"] > 0
+    oo, f1 = o.apply_gates(layer, oc, apply_kwargs=kwn, bp_update_kwargs=tight(dtype))
+    oo, f1b = o.apply_gates(layer, oo, apply_kwargs=kwn, bp_update_kwargs=tight(dtype))
+    assert np.max(np.abs(e1b - np.array(f1b))) < (1e-9 if dtype == np.complex128 else 2e-3 * np.max(f1b) + 3e-7)
+    for v in g.vertices:
+        assert abs(tn.expect(o1, ("Z", [v])) - o.expect_1site(oo, Z, v)) < max(50 * tol, 1e-7)
+        assert abs(np.linalg.norm(o1.tensor(v)) - 1) < 50 * tol
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 @pytest.mark.parametrize("lattice", ["grid3x3", "comb33", "hh11"])
 def test_bp_scalars_and_rescale_match_oracle(dtype, lattice):
     """8f N2: vertex / edge scalars, partition function (abstract...:22-28, 289-304) and rescale! (beliefpropagationcache.jl:82-140)"""
@@ -878,6 +927,39 @@ def test_theta_svd_beyond_the_lds_matches_oracle(chi):
         sd = np.sort(np.abs(np.diag(b2.message((c, nb)))))[::-1]; so = np.sort(np.abs(np.diag(o2.message((c, nb)))))[::-1]
         assert np.max(np.abs(sd / sd[0] - so / so[0])) < 2e-5, gt[0]
         assert abs(ed[0] - eo[0]) < 1e-4 * eo[0] + 1e-9, (gt[0], ed[0], eo[0])
+
+
+@pytest.mark.parametrize("gate", [("Rzz", 0.3), ("Rxxyyzz", 0.7)])
+def test_gate_beyond_the_old_theta_cap_matches_oracle(gate):
+    """d^2 chi = 384 > 256 (a chi = 96 bond): the round-2 engine refused such a gate (the Jacobi kernels held 256 rows); the reference's
+    factorize_svd has no limit (src/Apply/simple_update.jl:53-59).  Two sites of bond dimension 96 between them, each with two further legs of
+    dimension 16 (enough fibers for the Gram route: 256 >= 192 columns): G is 192 x 192 (eigen route in the global-memory kernel), theta
+    384 x 384 (global-memory Jacobi with 8 rows per lane).  Bond dimension, spectrum, truncation error and <Z> against the oracle."""
+    from helpers import oracle_cache_from_device
+    a, b = (1, 1), (2, 1)
+    g = tn.NamedGraph([a, b, (0, 0), (0, 2), (3, 0), (3, 2)], [(a, b), (a, (0, 0)), (a, (0, 2)), (b, (3, 0)), (b, (3, 2))])
+    chis = {frozenset((a, b)): 96}
+    rng = np.random.default_rng(96)
+    tensors = {}
+    for v in g.vertices:
+        shp = (2,) + tuple(chis.get(frozenset((v, w)), 16) for w in g.neighbors(v))
+        t = rng.standard_normal(shp) + 1j * rng.standard_normal(shp)
+        tensors[v] = (t / np.linalg.norm(t)).astype(np.complex64)
+    psi = tn.TensorNetworkState(g, tensors)
+    bpkw = dict(maxiter=2, tolerance=None, edge_sequence=tn.forest_cover_edge_sequence(g))
+    bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
+    bo = oracle_cache_from_device(bd)
+    kw = dict(maxdim=96, cutoff=1e-10, normalize_tensors=True)
+    gt = (gate[0], [a, b], gate[1])
+    b2, ed = tn.apply_gates([gt], bd, apply_kwargs=kw, bp_update_kwargs=bpkw, update_cache=False)
+    o2, eo = o.apply_gates([gt], bo, apply_kwargs=kw, bp_update_kwargs=bpkw, update_cache=False)
+    assert b2.bond_dim(a, b) == o2.tns.bond_dim(a, b) == 96
+    sd = np.sort(np.abs(np.diag(b2.message((a, b)))))[::-1]; so = np.sort(np.abs(np.diag(o2.message((a, b)))))[::-1]
+    print(gate[0], "chi = 96: spectrum", float(np.max(np.abs(sd / sd[0] - so / so[0]))), " truncation error", ed[0], eo[0])
+    assert np.max(np.abs(sd / sd[0] - so / so[0])) < 2e-5
+    assert abs(ed[0] - eo[0]) < 1e-4 * eo[0] + 1e-9
+    for v in (a, b):
+        assert abs(tn.expect(b2, ("Z", [v])) - o.expect_1site(o2, Z, v)) < 1e-5
 
 
 @pytest.mark.parametrize("scale", [1e-4, 1e-9, 1e6])
