@@ -447,7 +447,7 @@ def test_deferred_one_site_gates_are_invisible_to_callers(dtype):
     ob, _ = o.apply_gates(ones, oc, apply_kwargs=kw, bp_update_kwargs=tight(dtype))
     assert info["n_deferred_1site"] == len(ones)
     for v in g.vertices:                                      # (2) observables first: the tensors are still un-materialised here
-        assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(ob, Z, v)) < 20 * tol
+        assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(ob, Z, v)) < max(20 * tol, 1e-7)      # two independently converged BP runs: fixed-point tolerance
     cp = out.copy()                                           # (3)
     for v in g.vertices:                                      # (1), (4)
         assert np.max(np.abs(out.tensor(v) - ob.tns.tensors[v])) < 20 * tol
@@ -472,7 +472,7 @@ def test_deferred_one_site_gates_are_invisible_to_callers(dtype):
     oo, f1b = o.apply_gates(layer, oo, apply_kwargs=kwn, bp_update_kwargs=tight(dtype))
     assert np.max(np.abs(e1b - np.array(f1b))) < (1e-9 if dtype == np.complex128 else 2e-3 * np.max(f1b) + 3e-7)
     for v in g.vertices:
-        assert abs(tn.expect(o1, ("Z", [v])) - o.expect_1site(oo, Z, v)) < max(50 * tol, 1e-7)
+        assert abs(tn.expect(o1, ("Z", [v])) - o.expect_1site(oo, Z, v)) < max(50 * tol, 1e-6)      # two layers of independently converged BP (stopping rule quadratic in the message error)
         assert abs(np.linalg.norm(o1.tensor(v)) - 1) < 50 * tol
 
 
@@ -947,7 +947,16 @@ def test_gate_beyond_the_old_theta_cap_matches_oracle(gate):
         tensors[v] = (t / np.linalg.norm(t)).astype(np.complex64)
     psi = tn.TensorNetworkState(g, tensors)
     bpkw = dict(maxiter=2, tolerance=None, edge_sequence=tn.forest_cover_edge_sequence(g))
-    bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
+    bd = tn.BeliefPropagationCache(psi)
+    # full-rank environments: the BP messages of the d = 2 leaves would have rank 2, and theta rank 8 whatever the bond dimension -- the
+    # incoming messages are set to random positive definite matrices instead (update_cache = False below: no BP involved)
+    for v in (a, b):
+        for w in g.neighbors(v):
+            if w in (a, b):
+                continue
+            x = rng.standard_normal((16, 16)) + 1j * rng.standard_normal((16, 16))
+            m = x @ x.conj().T + 0.5 * np.eye(16)
+            bd.setmessage((w, v), (m / m.sum()).astype(np.complex64))
     bo = oracle_cache_from_device(bd)
     kw = dict(maxdim=96, cutoff=1e-10, normalize_tensors=True)
     gt = (gate[0], [a, b], gate[1])
