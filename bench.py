@@ -181,7 +181,7 @@ def main():
             bpc._declare_dims(v, t)
         else:
             bpc._set_tensor(v, t)
-    sweeps, updates = [], []
+    sweeps, updates, svd_sweeps = [], [], []
     for _ in range(args.warmup):
         info = {}
         bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=apply_kwargs, info=info)
@@ -198,7 +198,7 @@ def main():
     for _ in range(args.steps):
         info = {}
         bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=apply_kwargs, info=info)
-        sweeps.append(info["n_sweeps"]); updates.append(info["n_updates"])
+        sweeps.append(info["n_sweeps"]); updates.append(info["n_updates"]); svd_sweeps.append(info.get("n_svd_sweeps", 0))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -267,6 +267,7 @@ def main():
            "config": {"workload": f"{L}x{L} square-lattice TFIM Trotter layer (Rx + 4 edge colours of Rzz), chi={chi}, ComplexF32, "
                                   f"apply_gates incl. BP updates; BASELINE.json configs[1]",
                       "two_site_gates_per_step": n2, "bp_updates_per_step": updates, "bp_sweeps_per_step": sweeps,
+                      "theta_svd_sweeps_per_gate": round(float(np.mean(svd_sweeps)) / max(1, n2), 2),
                       "apply_kwargs": {"maxdim": chi, "cutoff": 1e-10, "normalize_tensors": True},
                       "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)", "parallelism": f"vertex-shard x{world}",
                       "transport": (None if world == 1 else {"kind": type(bpc._shard).__name__, "nranks": world, "backend": dist.get_backend(),

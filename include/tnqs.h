@@ -56,7 +56,9 @@ typedef struct {
                            * (1e-5 f32 / c64, 1e-8 f64 / c128, none on trees), i.e. what apply_gates / truncate / normalize use when
                            * bp_update_kwargs is omitted.  A NULL opts pointer = default_bp_update_kwargs altogether */
     int normalize;        /* message_update_alg "contract" kwarg `normalize` (default true): m <- m / sum(m) */
-    int n_sequence;       /* 0: library default edge sequence (edge-colour grouped Gauss-Seidel) */
+    int n_sequence;       /* 0: library default edge sequence (linear forests, DESIGN.md 4.3: the order the plane kernels share products on);
+                           * -1: the reference's default, forest_cover_edge_sequence(graph) (beliefpropagationcache.jl:28), built by the library;
+                           * > 0: the explicit sequence below */
     const int32_t* seq_src; /* explicit `edge_sequence` kwarg: directed edges, swept sequentially (Gauss-Seidel) */
     const int32_t* seq_dst;
 } tnqs_bp_opts;
@@ -82,6 +84,7 @@ typedef struct {
     int n_qr2_sites;        /* ComplexF64 sites that went through the second factorisation pass (ill-conditioned psi~) */
     int n_lowrank_svd;      /* two-site gates whose theta SVD ran on the low-rank factor (gate of operator Schmidt rank kappa, kappa chi < d chi) */
     int n_tall_svd;         /* theta SVDs that went through the Cholesky-QR preprocessing (matrix too tall for the LDS-resident Jacobi: 256 x 128 at chi = 64) */
+    int n_svd_sweeps;       /* Jacobi sweeps of the theta SVDs, summed over the two-site gates of the call (diagnostic: sweeps per gate = this / n_two_site) */
     int n_deferred_1site;   /* unitary one-site gates that were only recorded and later absorbed by a two-site gate on the vertex (or applied when the tensor was read) */
 } tnqs_apply_stats;
 

@@ -56,8 +56,10 @@ mutable struct HipBeliefPropagationCache{V} <: TN.AbstractBeliefPropagationCache
     vid::Dict{V, Int32}                  # vertex -> 0-based id (order of vertices(g)) = the ids tnqs_create was given
     siteinds::Any                        # Dictionary{V, Vector{<:Index}} of the state (tensornetworkstate.jl:14)
     linkinds::Dict{Tuple{Int32, Int32}, Index}   # (min id, max id) -> link Index; re-created when a gate changes the bond dimension
-    function HipBeliefPropagationCache{V}(h, g, vid, s, l) where {V}
-        c = new{V}(h, g, vid, s, l)
+    reference_order::Bool                # no edge_sequence given: sweep in forest_cover_edge_sequence(g) (the reference's default, n_sequence = -1)
+                                         # instead of the library's linear-forest order (same fixed point, fewer dependency levels per sweep)
+    function HipBeliefPropagationCache{V}(h, g, vid, s, l, reference_order = false) where {V}
+        c = new{V}(h, g, vid, s, l, reference_order)
         finalizer(x -> ccall((:tnqs_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), c)
         return c
     end
@@ -67,7 +69,7 @@ const DTYPE_CODE = Dict(ComplexF32 => 0, ComplexF64 => 1, Float32 => 2, Float64 
 const DTYPE_OF = (ComplexF32, ComplexF64, Float32, Float64)
 
 # ---- construction: BeliefPropagationCache(psi) -> device (beliefpropagationcache.jl:27-31) ----------------------------------------------
-function HipBeliefPropagationCache(ψ::TN.TensorNetworkState; device::Integer = 0)
+function HipBeliefPropagationCache(ψ::TN.TensorNetworkState; device::Integer = 0, reference_order::Bool = false)
     g = TN.graph(ψ)
     vs = collect(vertices(g))
     V = eltype(vs)
@@ -79,7 +81,7 @@ function HipBeliefPropagationCache(ψ::TN.TensorNetworkState; device::Integer = 
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:tnqs_create, LIB), Cint, (Cint, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Cint, Cint, Ptr{Ptr{Cvoid}}),
                 length(vs), length(es), esrc, edst, sd, DTYPE_CODE[TN.scalartype(ψ)], device, h))
-    c = HipBeliefPropagationCache{V}(h[], g, vid, TN.siteinds(ψ), Dict{Tuple{Int32, Int32}, Index}())
+    c = HipBeliefPropagationCache{V}(h[], g, vid, TN.siteinds(ψ), Dict{Tuple{Int32, Int32}, Index}(), reference_order)
     for v in vs
         upload_site!(c, ψ, v)
     end
@@ -116,7 +118,7 @@ linkkey(c, u, v) = (min(c.vid[u], c.vid[v]), max(c.vid[u], c.vid[v]))
 function Base.copy(c::HipBeliefPropagationCache{V}) where {V}
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:tnqs_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), c.handle, h))
-    return HipBeliefPropagationCache{V}(h[], c.g, c.vid, c.siteinds, copy(c.linkinds))
+    return HipBeliefPropagationCache{V}(h[], c.g, c.vid, c.siteinds, copy(c.linkinds), c.reference_order)
 end
 
 # ---- the abstract cache interface (abstractbeliefpropagationcache.jl:7-37) ------------------------------------------------------------
@@ -215,7 +217,7 @@ function with_bpopts(f, c::HipBeliefPropagationCache, kw)
     tol = get(kw, :tolerance, nothing)
     GC.@preserve ss sd begin
         o = BpOpts(maxiter === nothing ? 0 : maxiter, tol === nothing ? -1.0 : tol, normalize ? 1 : 0,
-                   length(ss), isempty(ss) ? Ptr{Int32}(C_NULL) : pointer(ss), isempty(sd) ? Ptr{Int32}(C_NULL) : pointer(sd))
+                   (seq === nothing && c.reference_order) ? -1 : length(ss), isempty(ss) ? Ptr{Int32}(C_NULL) : pointer(ss), isempty(sd) ? Ptr{Int32}(C_NULL) : pointer(sd))
         return f(o)
     end
 end

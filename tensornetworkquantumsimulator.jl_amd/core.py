@@ -270,6 +270,11 @@ def _bp_opts(g: NamedGraph, kw: Optional[dict], defaults: Optional[dict] = None)
     o.tolerance = -1.0 if tol is None else float(tol)
     o.normalize = 1 if kw.get("normalize", True) else 0
     seq = kw.get("edge_sequence")
+    if isinstance(seq, str):
+        if seq != "forest_cover":
+            raise ValueError('edge_sequence: a list of (src, dst) pairs, or "forest_cover" for the reference\'s default order')
+        o.n_sequence = -1          # forest_cover_edge_sequence(graph), built inside the library (include/tnqs.h)
+        return o, keep
     if seq is not None:
         for (a, b) in seq:
             if a not in g.index or b not in g.index or not g.has_edge(a, b):
@@ -358,7 +363,7 @@ def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_
         warnings.warn(f"BP did not converge in {st.bp_not_converged} of {st.n_bp_updates} cache updates "
                       f"(final average message change: {st.last_bp_diff}).")
     if info is not None:
-        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_tall_svd=st.n_tall_svd, n_deferred_1site=st.n_deferred_1site, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
+        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_tall_svd=st.n_tall_svd, n_deferred_1site=st.n_deferred_1site, n_svd_sweeps=st.n_svd_sweeps, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
                     n_two_site=st.n_two_site, bp_not_converged=st.bp_not_converged)
     return out, errs[:ng]
 

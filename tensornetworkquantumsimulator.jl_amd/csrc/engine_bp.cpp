@@ -61,6 +61,44 @@ static std::vector<int> tree_sequence(const Graph& g) {
     }
     return seq;
 }
+// The reference's default order on ANY graph (beliefpropagationcache.jl:28: NamedGraphs forest_cover_edge_sequence, restated -- it is not under
+// /root/reference; julia/replay_golden.jl checks the restatement against NamedGraphs' own): the edges are covered greedily by spanning forests
+// (breadth-first from the first vertex that still has an uncovered edge, neighbours in ascending vertex id); per tree the edges towards the root in
+// depth-first post-order, then their reverses in reverse order.  Selected with tnqs_bp_opts.n_sequence = -1; the same sequence as the host's
+// graphs.py forest_cover_edge_sequence passed explicitly.
+static std::vector<int> forest_cover_sequence(const Graph& g) {
+    std::vector<char> remaining(g.ne, 1); int left = g.ne;
+    std::vector<int> seq;
+    while (left > 0) {
+        std::vector<char> visited(g.nv, 0), used(g.ne, 0);
+        for (int root = 0; root < g.nv; ++root) {
+            if (visited[root]) continue;
+            bool any = false; for (int e : g.nbr_e[root]) any = any || remaining[e];
+            if (!any) continue;
+            std::vector<std::vector<int>> children(g.nv);
+            std::vector<int> queue{root}; visited[root] = 1;
+            for (size_t qi = 0; qi < queue.size(); ++qi) {
+                const int x = queue[qi];
+                for (size_t j = 0; j < g.nbr[x].size(); ++j) {
+                    const int y = g.nbr[x][j], e = g.nbr_e[x][j];
+                    if (visited[y] || !remaining[e]) continue;
+                    visited[y] = 1; children[x].push_back(y); used[e] = 1; queue.push_back(y);
+                }
+            }
+            std::vector<std::pair<int, int>> post;                      // (child, parent)
+            std::vector<std::pair<int, size_t>> stack{{root, 0}};
+            while (!stack.empty()) {
+                auto& top = stack.back();
+                if (top.second < children[top.first].size()) { const int c = children[top.first][top.second++]; stack.push_back({c, 0}); }
+                else { const int x = top.first; stack.pop_back(); if (!stack.empty()) post.push_back({x, stack.back().first}); }
+            }
+            for (auto& e : post) seq.push_back(g.dedge(e.first, e.second));
+            for (auto it = post.rbegin(); it != post.rend(); ++it) seq.push_back(g.dedge(it->second, it->first));
+        }
+        for (int e = 0; e < g.ne; ++e) if (used[e]) { remaining[e] = 0; --left; }
+    }
+    return seq;
+}
 static std::vector<int> default_sequence(const Graph& g) {
     if (g.is_tree) {
         std::vector<int> seq = tree_sequence(g);
@@ -138,7 +176,8 @@ static BPPlan make_plan(const State* s, const tnqs_bp_opts* o) {
             if (de < 0) throw Err(TNQS_ERR_INVALID, "bp_update: edge_sequence contains a pair of non-adjacent vertices");
             p.seq.push_back(de);
         }
-    } else { if (g.default_seq.empty() && g.ne > 0) g.default_seq = default_sequence(g); p.seq = g.default_seq; }
+    } else if (o && o->n_sequence < 0) p.seq = forest_cover_sequence(g);      // the reference's own default order
+    else { if (g.default_seq.empty() && g.ne > 0) g.default_seq = default_sequence(g); p.seq = g.default_seq; }
     p.pos_of.assign(2 * (size_t)g.ne, -1);
     for (size_t t = 0; t < p.seq.size(); ++t) { if (p.pos_of[p.seq[t]] >= 0) p.in_place = true; p.pos_of[p.seq[t]] = (int)t; }
     if (p.in_place) { for (size_t t = 0; t < p.seq.size(); ++t) { p.levels.push_back({(int)t}); p.level_of.push_back((int)t); } return p; }
@@ -178,7 +217,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
     HIPCHK(hipSetDevice(s->device));
     // the level schedule depends on the graph and the sequence only: the one of the default sequence is kept with the graph
     std::shared_ptr<const BPPlan> plan_p;
-    if (o && o->n_sequence > 0) plan_p = std::make_shared<const BPPlan>(make_plan(s, o));
+    if (o && o->n_sequence != 0) plan_p = std::make_shared<const BPPlan>(make_plan(s, o));
     else {
         if (!g.default_plan) g.default_plan = std::make_shared<const BPPlan>(make_plan(s, o));
         plan_p = std::static_pointer_cast<const BPPlan>(g.default_plan);

@@ -216,9 +216,13 @@ static std::vector<char> widen_real(const State* s, const void* host, size_t n) 
     else { const double* p = static_cast<const double*>(host); double* q = reinterpret_cast<double*>(out.data()); for (size_t i = 0; i < n; ++i) { q[2 * i] = p[i]; q[2 * i + 1] = 0.0; } }
     return out;
 }
+// (a real handle only ever holds zero imaginary parts: real tensors, real gates -- a complex gate promotes it first; anything else is a bug
+// in the library, reported instead of being dropped silently)
 static void narrow_real(const State* s, const std::vector<char>& cplx, void* host, size_t n) {
-    if (s->dtype == TNQS_C64) { const float* q = reinterpret_cast<const float*>(cplx.data()); float* p = static_cast<float*>(host); for (size_t i = 0; i < n; ++i) p[i] = q[2 * i]; }
-    else { const double* q = reinterpret_cast<const double*>(cplx.data()); double* p = static_cast<double*>(host); for (size_t i = 0; i < n; ++i) p[i] = q[2 * i]; }
+    bool bad = false;
+    if (s->dtype == TNQS_C64) { const float* q = reinterpret_cast<const float*>(cplx.data()); float* p = static_cast<float*>(host); for (size_t i = 0; i < n; ++i) { p[i] = q[2 * i]; bad = bad || q[2 * i + 1] != 0.f; } }
+    else { const double* q = reinterpret_cast<const double*>(cplx.data()); double* p = static_cast<double*>(host); for (size_t i = 0; i < n; ++i) { p[i] = q[2 * i]; bad = bad || q[2 * i + 1] != 0.0; } }
+    if (bad) throw Err(TNQS_ERR_NUMERIC, "internal: a real-typed handle holds a non-zero imaginary part");
 }
 
 void state_set_site(State* s, int v, const void* host, int ndim, const int64_t* dims, const int32_t* role) {

@@ -697,7 +697,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             if (h_flags[2 * i + 1]) throw Err(TNQS_ERR_NUMERIC, "simple_update: incoming message has a negative eigenvalue above sqrt_cutoff (DomainError in the reference, src/utils.jl:21)");
         for (int q = 0; q < npg; ++q) {
             int Mr, Nc, ncolJ; theta_dims(hinfo.data() + 8 * q, gitems[q].d1, gitems[q].d2, Mr, Nc, ncolJ);
-            s->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0;
+            s->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0; s->stats.n_svd_sweeps += hinfo[8 * q + 4];
             for (int k = 0; k < 8; ++k) info[8 * pg[q] + k] = hinfo[8 * q + k]; terr[pg[q]] = hterr[q];
         }
     }

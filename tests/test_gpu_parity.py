@@ -427,6 +427,30 @@ def test_deferred_normalisation_is_invisible_to_callers(dtype):
         assert abs(np.linalg.norm(out2.tensor(v)) - np.linalg.norm(oc2.tns.tensors[v])) < 50 * tol
 
 
+@pytest.mark.parametrize("lattice", ["grid3x3", "hh11", "comb33", "ring5"])
+def test_reference_default_sweep_order_inside_the_library(lattice):
+    """edge_sequence = "forest_cover" (tnqs_bp_opts.n_sequence = -1): the reference's default order (beliefpropagationcache.jl:28) built by
+    the library itself.  Bit-identical messages to passing the host's forest_cover_edge_sequence explicitly (same sequence, same level
+    schedule), trajectories against the oracle sweeping in that order, and -- with it -- the reference's DEFAULT `update(bpc)` semantics
+    (maxiter 25 / 1, no tolerance) against the oracle's default."""
+    g = {"grid3x3": lambda: tn.named_grid((3, 3)), "hh11": lambda: tn.heavy_hexagonal_lattice(1, 1), "comb33": lambda: tn.named_comb_tree((3, 3)),
+         "ring5": lambda: tn.NamedGraph(list(range(5)), [(i, (i + 1) % 5) for i in range(5)])}[lattice]()
+    psi = tn.random_tensornetworkstate(np.complex128, g, bond_dimension=3, seed=31)
+    bpc = tn.BeliefPropagationCache(psi)
+    seq = tn.forest_cover_edge_sequence(g)
+    for ns in (1, 3):
+        a = tn.update(bpc, maxiter=ns, tolerance=None, edge_sequence="forest_cover")
+        b = tn.update(bpc, maxiter=ns, tolerance=None, edge_sequence=seq)
+        oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), maxiter=ns, tolerance=None, edge_sequence=seq)
+        for e in seq:
+            assert np.array_equal(a.message(e), b.message(e))
+        compare_messages(a, oc, 1e-10)
+    # the oracle's own default order is the same restatement: default-kwargs update on both sides
+    d = tn.update(bpc, maxiter=(1 if g.is_tree() else 25), tolerance=None, edge_sequence="forest_cover")
+    od = o.update(o.BeliefPropagationCache(to_oracle_state(psi)))
+    compare_messages(d, od, 1e-9)
+
+
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_deferred_one_site_gates_are_invisible_to_callers(dtype):
     """a UNITARY one-site gate is only recorded on the handle (State::pend1): BP does not see it and the next two-site gate on the vertex absorbs
