@@ -177,7 +177,7 @@ template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, 
         for (size_t i = 0; i < nt; ++i) {
             const size_t nn = (size_t)tall[i].n * tall[i].n, mn = (size_t)tall[i].m * tall[i].n;
             oG[i] = off; off += round256(nn * 16); oL[i] = off; off += round256(nn * 16); oW[i] = off; off += round256(nn * 16);
-            oR0[i] = off; off += round256(nn * 8); oRr[i] = off; off += round256(nn * 8); oJ[i] = off; off += round256(nn * 8); oT[i] = off; off += round256(mn * 8);
+            oR0[i] = off; off += round256(nn * 8); oRr[i] = off; off += round256(nn * 8); oJ[i] = off; off += round256(nn * 16); oT[i] = off; off += round256(mn * 8);
         }
         Buf arena = dalloc(s, off); s->keepalive.push_back(arena);
         Buf d_fail = dalloc(s, nt * sizeof(int)); s->keepalive.push_back(d_fail);
@@ -204,18 +204,15 @@ template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, 
         size_t lds = 0; for (auto& j : rj) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, false, esz));
         launch_jacobi<T>(s->stream, dj, (int)nt, 60, lds, nmax);
         launch_tall_w(s->stream, dw, (int)nt, nmax);
-        launch_small_cgemm(s->stream, dg, (int)nt, mmax, nmax);
+        launch_tall_mj(s->stream, dg, (int)nt);                        // A J in f64 (J is complex128): column-relative accuracy, no polishing needed
         launch_copy_items(s->stream, dcp, (int)nt);
-        // polish: J comes out of f32 arithmetic, so a column of A J with a small singular value carries rounding residue ALONG the large left
-        // singular vectors (absolute size eps sigma_max -- large relative to the column itself), which the V recovery that follows
-        // (theta0^dagger (U Sigma) Sigma^-2) would amplify by sigma_max / sigma_j.  One-sided Jacobi on A itself guarantees orthogonality
-        // RELATIVE to the column norms; a few sweeps of the global-memory kernel on the already orthogonalised A J restore exactly that
-        // (they find almost nothing to rotate: 1-2 sweeps instead of the 8-10 of a cold start).
+        // Polishing sweeps on A J itself are only needed where the preprocessing gave nothing to build on: an item whose Cholesky pivot
+        // collapsed in spite of the shift (J := I above) is factorised from scratch here; every other item is skipped on the device
+        // (JacobiItem::only_if).  Round 2 polished every item (2.6 ms per chi = 64 colour batch): its A J was an f32 product with an f32 J,
+        // which leaves eps32 sigma_max of residue in every column -- the f64 product does not.
         std::vector<JacobiItem> pol;
-        for (auto& j : tall) pol.push_back(JacobiItem{j.A, nullptr, j.m, j.n, nullptr});
+        for (size_t i = 0; i < nt; ++i) { JacobiItem j{tall[i].A, nullptr, tall[i].m, tall[i].n, nullptr}; j.only_if = reinterpret_cast<const int*>(d_fail->p) + i; pol.push_back(j); }
         const JacobiItem* dp = upload(s, pol);
-        // (the kernel stops at convergence: 1-2 sweeps here; the cap is the ordinary one, so an item whose preprocessing did not help --
-        // failure flag above, or a J that came out far from unitary -- is still factorised to the same tolerance as everything else)
         launch_jacobi<T>(s->stream, dp, (int)nt, 60, 0, mmax);
         s->stats.n_tall_svd += (int)nt;
     }

@@ -321,6 +321,7 @@ template <class T, int R>          // R rows per lane: m <= 64 R
 __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restrict__ items, int max_sweeps) {
     __shared__ int s_rot;
     const JacobiItem it = items[blockIdx.x];
+    if (it.only_if && *it.only_if == 0) return;          // conditional item (svd_batch: polishing sweeps only where the preprocessing failed)
     cx<T>* A = reinterpret_cast<cx<T>*>(it.A);
     cx<T>* V = reinterpret_cast<cx<T>*>(it.V);
     int m_ = it.m, n_ = it.n;
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
 // for the inverse: when CholItem::Winv is given, (L^-1)^dagger is built in place in global memory by a second phase).
 __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double s_piv; __shared__ double s_dmax;
+    __shared__ double s_dmax;
     const CholItem it = items[blockIdx.x];
     const int n = it.n, tid = threadIdx.x;
     cx<double>* A = reinterpret_cast<cx<double>*>(smem);
@@ -874,30 +875,36 @@ __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __rest
     __syncthreads();
     if (it.shift > 0) { for (int i = tid; i < n; i += 256) A[at(i, i)].re += it.shift * s_dmax; __syncthreads(); }
     const double tiny = it.tau * s_dmax;
+    // right-looking with ONE barrier per column, as chol_kernel: trailing updates from the unscaled column, pivots by the same rule in every
+    // thread, all columns scaled at the end
+    auto pivot_of = [&](int k, bool& bad) { double d = A[at(k, k)].re; bad = !(d > tiny); return bad ? (tiny > 0 ? tiny : 1.0) : d; };
+    const int ti = tid & 63, tj = tid >> 6;
     for (int k = 0; k < n; ++k) {
-        if (tid == 0) {
-            double d = A[at(k, k)].re;
-            if (!(d > tiny)) { *it.fail = 1; d = (tiny > 0 ? tiny : 1.0); }
-            s_piv = sqrt(d);
-        }
-        __syncthreads();
-        const double inv = 1.0 / s_piv;
-        for (int i = k + tid; i < n; i += 256) {
-            if (i == k) A[at(k, k)] = cmake<double>(s_piv, 0.0);
-            else { cx<double> v = A[at(i, k)]; A[at(i, k)] = cmake<double>(v.re * inv, v.im * inv); }
-        }
-        __syncthreads();
-        const int m = n - k - 1;
-        for (int e = tid; e < m * m; e += 256) {
-            int i = k + 1 + e % m, j = k + 1 + e / m;
-            if (i < j) continue;
-            cx<double> li = A[at(i, k)], lj = A[at(j, k)];
-            cx<double> v = A[at(i, j)];
-            v.re -= li.re * lj.re + li.im * lj.im; v.im -= li.im * lj.re - li.re * lj.im;
-            A[at(i, j)] = v;
+        bool bad; const double d = pivot_of(k, bad);
+        if (bad && tid == 0) *it.fail = 1;
+        const double dinv = 1.0 / d;
+        for (int i = k + 1 + ti; i < n; i += 64) {
+            const cx<double> li = A[at(i, k)];
+            const cx<double> ls = cmake<double>(li.re * dinv, li.im * dinv);
+            for (int j = k + 1 + tj; j <= i; j += 4) {
+                const cx<double> lj = A[at(j, k)];
+                cx<double> v = A[at(i, j)];
+                v.re -= ls.re * lj.re + ls.im * lj.im; v.im -= ls.im * lj.re - ls.re * lj.im;
+                A[at(i, j)] = v;
+            }
         }
         __syncthreads();
     }
+    __shared__ double s_pivs[128];
+    for (int k = tid; k < n; k += 256) { bool bad; s_pivs[k] = sqrt(pivot_of(k, bad)); }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e % n, k = e / n;
+        if (i < k) continue;
+        if (i == k) A[at(k, k)] = cmake<double>(s_pivs[k], 0.0);
+        else { const cx<double> v = A[at(i, k)]; const double r = 1.0 / s_pivs[k]; A[at(i, k)] = cmake<double>(v.re * r, v.im * r); }
+    }
+    __syncthreads();
     cx<double>* L = reinterpret_cast<cx<double>*>(it.L);
     for (int e = tid; e < n * n; e += 256) { int i = e % n, j = e / n; L[e] = (i >= j) ? A[at(i, j)] : cmake<double>(0, 0); }
     if (!it.Winv) return;
@@ -932,7 +939,7 @@ __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __rest
 void launch_chol_packed(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {
     if (nitems <= 0) return;
     const size_t lds = (size_t)nmax * (nmax + 1) / 2 * 16;
-    set_max_dynamic_lds((const void*)chol_packed_kernel, (size_t)(160 * 1024 - 256));
+    set_max_dynamic_lds((const void*)chol_packed_kernel, (size_t)(160 * 1024 - 2048));      // (+ ~1 KB of static LDS: pivots)
     hipLaunchKernelGGL(chol_packed_kernel, dim3(nitems), dim3(256), lds, s, d_items); TNQS_CHECK_LAUNCH();
 }
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {

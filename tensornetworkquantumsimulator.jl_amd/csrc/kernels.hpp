@@ -49,6 +49,7 @@ struct JacobiItem {       // one-sided Jacobi on A (m x n, col-major, ld = m); V
     // is what lets a gate batch run from the Gram matrices to the truncated factors without a host round trip in between.
     const int* dyn; int dm, dn;
     int nhint;            // host only: the column count the item is EXPECTED to have when dyn decides it (0: n)
+    const int* only_if;   // global-memory kernel only: skip the item unless *only_if != 0 (null: always run)
 };
 // dimensions of a gate's theta SVD from its info array (gate_theta_kernel): rows, columns of theta, columns the Jacobi runs on
 __host__ __device__ inline void theta_dims(const int* info, int d1, int d2, int& m, int& nfull, int& ncol) {
@@ -174,8 +175,9 @@ void rowgemm_tiles(FiberItem& it);
 void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, int K, double* d_norm_partials);   // all items: the same K and D
 void launch_tall_gram(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);
 void launch_tall_rt(hipStream_t s, const TallSvdItem* d_items, int nitems);
-void launch_tall_w(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);      // R0 slot (out, ComplexF32) = [L slot: R^-1, complex128] x Rrot
+void launch_tall_w(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);      // R0 slot (out, complex128) = [L slot: R^-1, complex128] x Rrot
 void launch_small_cgemm(hipStream_t s, const SmallGemmItem* d_items, int nitems, int mmax, int nmax);
+void launch_tall_mj(hipStream_t s, const SmallGemmItem* d_items, int nitems);      // C (m x n, ComplexF32) = A (m x k, ComplexF32) B (k x n, complex128), f64 matrix cores
 void launch_copy_items(hipStream_t s, const CopyItem* d_items, int nitems);
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax);
 void launch_chol_packed(hipStream_t s, const CholItem* d_items, int nitems, int nmax);      // n <= 128 (packed triangle in LDS); Winv may be null

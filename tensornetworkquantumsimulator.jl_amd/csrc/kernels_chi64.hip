@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void tall_w_kernel(const TallSvdItem* __restri
     __shared__ double Ar[32][33], Ai[32][33], Br[32][33], Bi[32][33];       // A = Rinv[32 I + i][j0 + j], B = Rrot[j0 + j][32 J + c]
     const cd* __restrict__ Rinv = reinterpret_cast<const cd*>(it.L);        // the caller passes R^-1 in the L slot of this launch
     const cf* __restrict__ Rrot = reinterpret_cast<const cf*>(it.Rrot);
-    cf* __restrict__ W = reinterpret_cast<cf*>(it.R0);                     // and the output in the R0 slot
+    cd* __restrict__ W = reinterpret_cast<cd*>(it.R0);                     // and the output in the R0 slot, complex128: J is multiplied into A in f64 (tall_mj_kernel)
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     // a Cholesky pivot of this item collapsed in spite of the shift (flag in the G slot of this launch): R is not a usable preconditioner,
     // so J := I -- A stays as it is and the sweeps on A that follow (svd_batch, full sweep cap) do the whole factorisation themselves
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void tall_w_kernel(const TallSvdItem* __restri
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int i = 32 * I + 2 * tx + p, c = 32 * J + 2 * ty + q;
-                if (i < n && c < n) { cf v; v.re = (i == c) ? 1.f : 0.f; v.im = 0.f; W[i + (size_t)n * c] = v; }
+                if (i < n && c < n) { cd v; v.re = (i == c) ? 1.0 : 0.0; v.im = 0.0; W[i + (size_t)n * c] = v; }
             }
         return;
     }
@@ -304,13 +304,53 @@ __global__ __launch_bounds__(256) void tall_w_kernel(const TallSvdItem* __restri
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int i = 32 * I + 2 * tx + p, c = 32 * J + 2 * ty + q;
-            if (i < n && c < n) { cf v; v.re = (float)cr[p][q]; v.im = (float)ci[p][q]; W[i + (size_t)n * c] = v; }
+            if (i < n && c < n) { cd v; v.re = cr[p][q]; v.im = ci[p][q]; W[i + (size_t)n * c] = v; }
         }
 }
 void launch_tall_w(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax) {
     if (nitems <= 0) return;
     const int nt = (nmax + 31) / 32;
     hipLaunchKernelGGL(tall_w_kernel, dim3(nitems, nt * nt), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+// C (m x n, ComplexF32) = A (m x k, ComplexF32) J (k x n, complex128) accumulated in f64 on v_mfma_f64_16x16x4_f64: one wave per 16 x 16
+// tile, tile rows = columns j of C, lanes = rows i (contiguous in A and C).  A J is the rotated theta factor of the Cholesky-QR route: with J
+// in f64 and the product in f64 every column of A J keeps the accuracy the Jacobi sweeps on R gave it RELATIVE TO ITS OWN NORM
+// (A J = Q (R J): the columns are Q times the sweeps' output), so no polishing sweeps on A J are needed -- the f32 product they followed
+// left a residue of eps32 sigma_max in every column.
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void tall_mj_kernel(const SmallGemmItem* __restrict__ items) {
+    const SmallGemmItem it = items[blockIdx.x];
+    struct alignas(16) cd { double re, im; };
+    const cf* __restrict__ A = reinterpret_cast<const cf*>(it.A);
+    const cd* __restrict__ J = reinterpret_cast<const cd*>(it.B);
+    cf* __restrict__ C = reinterpret_cast<cf*>(it.C);
+    const int m = it.m, n = it.n, k = it.k;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    const int w = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.y * (blockDim.x >> 6);
+    const int tr = (n + 15) >> 4, tc = (m + 15) >> 4;
+    for (int t = w; t < tr * tc; t += nw) {
+        const int j0 = 16 * (t % tr), i0 = 16 * (t / tr);
+        const int jj = j0 + l15, ii = i0 + l15;
+        v4d_t cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < k; k0 += 4) {
+            const int kk = k0 + kq;
+            cd a = {0.0, 0.0}; double br = 0.0, bi = 0.0;
+            if (kk < k) { if (jj < n) a = J[kk + (size_t)k * jj]; if (ii < m) { const cf v = A[ii + (size_t)m * kk]; br = (double)v.re; bi = (double)v.im; } }
+            cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, br, cr, 0, 0, 0);       // C'[j][i] = sum_k J[k, j] A[i, k]
+            cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, bi, cr, 0, 0, 0);
+            ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, bi, ci, 0, 0, 0);
+            ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, br, ci, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + kq + 4 * r, i = i0 + l15;
+            if (i < m && j < n) { cf v; v.re = (float)cr[r]; v.im = (float)ci[r]; C[i + (size_t)m * j] = v; }
+        }
+    }
+}
+void launch_tall_mj(hipStream_t s, const SmallGemmItem* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(tall_mj_kernel, dim3(nitems, 4), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 // C (m x n) = A (m x k) B (k x n), ComplexF32 column-major, one wave per 32 x 32 tile of C, operands straight from L2 (all <= 512 KiB)
 __global__ __launch_bounds__(256) void small_cgemm_kernel(const SmallGemmItem* __restrict__ items) {
