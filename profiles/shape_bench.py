@@ -1,5 +1,6 @@
 """Per-site shapes of the BASELINE configurations that need 8 GPUs at full size, measured on one MI355X on a lattice that fits:
     python profiles/shape_bench.py cubic16     3x3x3 periodic cubic, chi = 16 (configs[3] per-site shape: degree 6, 268 MB tensors)
+    python profiles/shape_bench.py c128        LxL grid (L = 8), chi = 32 (CHI), ComplexF64: the reference's default element type at the bulk shape
     python profiles/shape_bench.py chi64       5x5 grid, chi = 64 (configs[4] per-site shape: degree 4, 268 MB bulk tensors, 256 x 256 theta)
 Prints one JSON line: ms per layer, gates/s, BP sweeps, and per kernel class the HIP-event time, algorithmic TFLOP/s and TB/s (the
 engine accumulates algorithmic flops / minimum bytes per class, include/tnqs.h tnqs_profile_get)."""
@@ -32,6 +33,13 @@ def main():
         for grp in groups:
             layer += [("Rxx", [a, b], -0.08) for (a, b) in grp]
         z = 6
+    elif mode == "c128":
+        L = int(os.environ.get("L", 8)); chi = int(os.environ.get("CHI", 32))
+        g = tn.named_grid((L, L)); groups = tn.edge_color(g, 4)
+        layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+        for grp in groups:
+            layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+        z = 4
     else:
         L = int(os.environ.get("L", 5)); chi = 64
         g = tn.named_grid((L, L)); groups = tn.edge_color(g, 4)
@@ -39,9 +47,10 @@ def main():
         for grp in groups:
             layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
         z = 4
-    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex64, lambda v: "↑", g))
+    dt_ = np.complex128 if mode == "c128" else np.complex64
+    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(dt_, lambda v: "↑", g))
     for v, t in unit_state(g, chi, 1234):
-        bpc._set_tensor(v, t)
+        bpc._set_tensor(v, t.astype(dt_))
     kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
     for _ in range(2):
         bpc, _ = tn.apply_gates(layer, bpc, apply_kwargs=kw)

@@ -47,7 +47,7 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
                 int nslices = it.g.n0 * it.g.n1 * it.g.n2;
                 it.spw = spw; it.slice_begin = wgs; wgs += pair_wgs(nslices, spw);
                 items.push_back(it);
-                c.result = dst->p; nt[se.first]++;
+                c.result = dst->p; nt[se.first]++; c.trail.push_back({x, y});
                 // drop the two consumed steps
                 c.steps.erase(c.steps.begin() + se.second.second); c.steps.erase(c.steps.begin() + se.second.first);
                 bytes += 2.0 * c.sd.n * esz; flops += 2 * 8.0 * c.sd.n * 32;
@@ -62,6 +62,13 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
                 Chain& c = chains[ci];
                 if (c.steps.size() < 2 || c.sd.n < (size_t)(1u << 14)) continue;     // small tensors stay on the single-leg kernel (launch bound)
                 bool found = false;
+                if (c.ordered) {                                                     // the caller's first two legs, when they form a plane
+                    Pair16Item it{};
+                    if (plane_geometry(c.sd.d, c.sd.z, c.sd.chi.data(), c.steps[0].first, c.steps[1].first, 16, it.g)) {
+                        it.Mx = c.steps[0].second; it.My = c.steps[1].second;
+                        it16.push_back(it); sel16.push_back({ci, {0, 1}}); slices16 += (double)it.g.nslices(); found = true;
+                    }
+                }
                 for (int qy = (int)c.steps.size() - 1; qy >= 1 && !found; --qy)
                     for (int qx = qy - 1; qx >= 0 && !found; --qx) {
                         Pair16Item it{};
@@ -80,6 +87,7 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
                 if (!dst) dst = dalloc(s, c.sd.n * esz);
                 it.in = c.result; it.out = dst->p; it.spw = spw; it.wg_begin = wgs16; wgs16 += (it.g.nslices() + spw - 1) / spw;
                 c.result = dst->p; nt[sel16[q].first]++;
+                c.trail.push_back({c.steps[sel16[q].second.first].first, c.steps[sel16[q].second.second].first});
                 c.steps.erase(c.steps.begin() + sel16[q].second.second); c.steps.erase(c.steps.begin() + sel16[q].second.first);
                 by16 += 2.0 * c.sd.n * esz; fl16 += 2 * 8.0 * c.sd.n * 16;
             }
@@ -103,6 +111,7 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
             Chain& c = chains[ci];
             if (c.steps.size() <= o) continue;
             int j = c.steps[o].first;
+            c.trail.push_back({j});
             FiberItem it{};
             Buf& dst = c.tmp[nt[ci] & 1];
             if (!dst) dst = dalloc(s, c.sd.n * esz);

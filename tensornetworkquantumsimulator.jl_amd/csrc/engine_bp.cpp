@@ -212,6 +212,49 @@ static double default_tol(const State* s) { return s->dtype == TNQS_C64 ? 1e-5 :
 // 4 + 4.  Validity is not assumed but checked: an entry is reused only while the very same site / message buffers are current.
 struct SharedT { Buf site, ma, mb, T; int la = -1, lb = -1; };
 
+// ---- partial products kept ACROSS levels (sites the plane kernels of the bulk shape do not cover) -------------------------------------
+// A message leaving a site absorbs the messages on all its other legs; which of them are absorbed in two-leg passes and which one inside
+// the Gram pass is free.  Two facts make most of those passes redundant on lattices whose forests are straight lines: (i) the levels of one
+// axis (a path and the edge that closes it on a periodic lattice) need the SAME product over the other axes' legs -- only messages along
+// the axis change in between; (ii) the products of two axes share the factor over the third axis' legs.  So every product a chain writes
+// (the final one and the one before it: the ping-pong buffers are both intact) is remembered with the exact buffers it was built from,
+// and a later chain continues from the largest remembered product whose (leg, message buffer) pairs are a subset of what it needs.
+// Legs are absorbed most-stable first (the messages that stay unchanged for the most levels to come), so that the early products are the
+// reusable ones and the leg whose message changes next is left for the Gram pass.  Validity is by buffer identity, never assumed: the
+// entries hold references, so an address cannot be recycled while an entry names it.  3 x 3 x 3 periodic cubic lattice, chi = 16: 5
+// two-leg passes per site and sweep instead of 6.8.
+struct ProdEntry { Buf site; std::vector<std::pair<int, Buf>> legs; Buf prod; unsigned long long stamp = 0; };
+struct ProdCache {
+    std::unordered_map<int, std::vector<ProdEntry>> by_site; unsigned long long clock = 0; int per_site = 3; size_t bytes = 0, cap = bp_cache_budget();
+    // the largest entry of site v whose legs all occur in `want` with the same buffer; returns false when there is none
+    bool find(int v, const Buf& site, const std::vector<std::pair<int, Buf>>& want, ProdEntry& out) {
+        auto it = by_site.find(v); if (it == by_site.end()) return false;
+        ProdEntry* best = nullptr;
+        for (auto& e : it->second) {
+            if (e.site != site || (best && e.legs.size() <= best->legs.size())) continue;
+            bool sub = true;
+            for (auto& lm : e.legs) { bool f = false; for (auto& w : want) if (w.first == lm.first && w.second == lm.second) { f = true; break; } if (!f) { sub = false; break; } }
+            if (sub) best = &e;
+        }
+        if (!best) return false;
+        best->stamp = ++clock; out = *best; return true;
+    }
+    void put(int v, const Buf& site, std::vector<std::pair<int, Buf>> legs, const Buf& prod) {
+        if (legs.size() < 2 || !prod) return;
+        std::sort(legs.begin(), legs.end(), [](const std::pair<int, Buf>& a, const std::pair<int, Buf>& b) { return a.first < b.first; });
+        auto& vec = by_site[v];
+        for (auto& e : vec) if (e.site == site && e.legs == legs) { bytes += prod->bytes; bytes -= e.prod->bytes; e.prod = prod; e.stamp = ++clock; return; }
+        if ((int)vec.size() >= per_site) { size_t lru = 0; for (size_t i = 1; i < vec.size(); ++i) if (vec[i].stamp < vec[lru].stamp) lru = i; bytes -= vec[lru].prod->bytes; vec.erase(vec.begin() + lru); }
+        ProdEntry e; e.site = site; e.legs = std::move(legs); e.prod = prod; e.stamp = ++clock; bytes += prod->bytes; vec.push_back(std::move(e));
+        while (bytes > cap) {                      // over the byte bound: the least recently used entry of all sites goes
+            std::vector<ProdEntry>* wv = nullptr; size_t wi = 0;
+            for (auto& kv : by_site) for (size_t i = 0; i < kv.second.size(); ++i) if (!wv || kv.second[i].stamp < (*wv)[wi].stamp) { wv = &kv.second; wi = i; }
+            if (!wv) break;
+            bytes -= (*wv)[wi].prod->bytes; wv->erase(wv->begin() + wi);
+        }
+    }
+};
+
 template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out) {
     const Graph& g = *s->g;
     HIPCHK(hipSetDevice(s->device));
@@ -255,6 +298,29 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
             partner[v][ord[2].second] = ord[3].second; partner[v][ord[3].second] = ord[2].second;
         }
     }
+    ProdCache pcache;
+    const bool cache_on = use_prodcache() && use_prefix() && !plan.in_place;
+    const int nlev = (int)plan.levels.size();
+    // levels until the message entering src through leg j changes again, seen from position t of the sequence (INT_MAX: never)
+    auto horizon = [&](int src, int j, int t) -> int {
+        const int pp = plan.pos_of[g.dedge(g.nbr[src][j], src)];
+        if (pp < 0) return INT_MAX;
+        const int Lc = plan.level_of[t], Lj = plan.level_of[pp];
+        return Lj > Lc ? Lj - Lc : (Lj < Lc ? nlev - Lc + Lj : 0);
+    };
+    typedef std::vector<std::pair<int, Buf>> LegBufs;
+    auto by_stability = [&](LegBufs& w, int src, int t) {
+        std::stable_sort(w.begin(), w.end(), [&](const std::pair<int, Buf>& a, const std::pair<int, Buf>& b) { return horizon(src, a.first, t) > horizon(src, b.first, t); });
+    };
+    // every product a chain wrote that is still intact (its last two passes), with the buffers it was built from
+    auto remember = [&](const Chain& c, const Buf& site, const LegBufs& base, const LegBufs& absorbed) {
+        const int np = (int)c.trail.size();
+        LegBufs acc = base;
+        for (int k = 0; k < np; ++k) {
+            for (int leg : c.trail[k]) for (auto& lm : absorbed) if (lm.first == leg) { acc.push_back(lm); break; }
+            if (k >= np - 2 && c.tmp[k & 1]) pcache.put(c.v, site, acc, c.tmp[k & 1]);
+        }
+    };
     for (int iter = 1; iter <= maxiter; ++iter) {
         std::vector<Buf> fresh(2 * (size_t)g.ne);
         for (auto& lev : plan.levels) {
@@ -270,6 +336,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     used += need; ++end;
                 }
                 std::vector<Chain> chains; std::vector<int> tpos; std::vector<const void*> fmsg;
+                std::unordered_map<size_t, LegBufs> cbase, cabs;           // chain index -> legs of the remembered product it starts from / legs it absorbs
                 std::vector<PairItem> sh_pair; std::vector<PairGramItem> sh_gram; std::vector<int> sh_chain;   // shared-T path
                 std::vector<int> is_shared_chain;
                 std::vector<PairGram2Item> sh_dbl; std::vector<std::pair<int, int>> sh_dbl_chain;              // both messages of a forest in one pass
@@ -294,27 +361,42 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                         int de = plan.seq[lev[q]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
                         if (s->owns(src) && generic_site(src, g.leg(src, dst))) outl[src].push_back(g.leg(src, dst));
                     }
-                    std::vector<Chain> pch; std::vector<int> psrc;
+                    std::vector<Chain> pch; std::vector<int> psrc; std::vector<LegBufs> pbase, pabs;
                     for (size_t q = start; q < end; ++q) {
                         int t = lev[q]; int de = plan.seq[t]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
                         auto ol = outl.find(src);
                         if (ol == outl.end() || ol->second.size() < 2 || prefix.count(src)) continue;
                         Chain cp; cp.v = src; cp.src = s->site[src]->p; cp.sd = site_dims(s, src);
                         Prefix pf; pf.site = s->site[src];
+                        LegBufs want;
                         for (int j = 0; j < cp.sd.z; ++j) {
                             if (std::find(ol->second.begin(), ol->second.end(), j) != ol->second.end()) continue;
                             const Buf& mb = select_in(src, j, t);
                             if (!mb) continue;
-                            cp.steps.push_back({j, mb->p}); pf.legs.push_back({j, mb->p});
+                            want.push_back({j, mb}); pf.legs.push_back({j, mb->p});
                         }
                         if (pf.legs.empty()) continue;
-                        prefix[src] = pf; pch.push_back(std::move(cp)); psrc.push_back(src);
+                        LegBufs base;
+                        if (cache_on) {
+                            by_stability(want, src, t); cp.ordered = true;
+                            ProdEntry hit;
+                            if (pcache.find(src, s->site[src], want, hit)) {
+                                base = hit.legs; cp.src = hit.prod->p; pf.prod = hit.prod;      // (pf.prod: the product itself when nothing is left to absorb)
+                                LegBufs rest; for (auto& w : want) { bool in = false; for (auto& b : base) in = in || b.first == w.first; if (!in) rest.push_back(w); }
+                                want.swap(rest);
+                            }
+                        }
+                        for (auto& w : want) cp.steps.push_back({w.first, w.second->p});
+                        prefix[src] = pf;
+                        if (cp.steps.empty()) continue;                                            // the whole product was remembered
+                        pch.push_back(std::move(cp)); psrc.push_back(src); pbase.push_back(std::move(base)); pabs.push_back(std::move(want));
                     }
                     if (!pch.empty()) {
                         run_chains<T>(s, pch, TNQS_PROF_BP_MODEPROD, TNQS_PROF_BP_PAIR);
                         for (size_t i = 0; i < pch.size(); ++i) {
                             Prefix& pf = prefix[psrc[i]];
                             for (int k = 0; k < 2; ++k) if (pch[i].tmp[k] && pch[i].tmp[k]->p == pch[i].result) pf.prod = pch[i].tmp[k];
+                            if (cache_on) remember(pch[i], pf.site, pbase[i], pabs[i]);
                         }
                     }
                 }
@@ -376,14 +458,29 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                             if (same) { c.y = c.src; c.src = pf->second.prod->p; for (auto& lm : pf->second.legs) done[lm.first] = 1; }
                         }
                     }
+                    LegBufs want, base;
                     for (int j = 0; j < c.sd.z; ++j) {
                         int k = g.nbr[src][j]; if (k == dst || done[j]) continue;
                         int din = g.dedge(k, src); int pp = plan.pos_of[din];
                         const Buf& mb = (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
                         if (!mb) continue;                               // unset message = identity: nothing to absorb
-                        if (j == fr) fm = mb->p;                         // absorbed inside the Gram kernel
-                        else c.steps.push_back({j, mb->p});
+                        want.push_back({j, mb});
                     }
+                    const bool from_prefix = c.y != nullptr;             // continues from this level's shared product: that product is remembered, not what follows
+                    if (cache_on && !from_prefix) {
+                        by_stability(want, src, t); c.ordered = true;
+                        ProdEntry hit;
+                        if (pcache.find(src, s->site[src], want, hit)) {
+                            base = hit.legs; c.y = c.src; c.src = hit.prod->p;
+                            LegBufs rest; for (auto& w : want) { bool in = false; for (auto& b : base) in = in || b.first == w.first; if (!in) rest.push_back(w); }
+                            want.swap(rest);
+                        }
+                    }
+                    for (auto& w : want) {
+                        if (w.first == fr) fm = w.second->p;             // absorbed inside the Gram kernel
+                        else c.steps.push_back({w.first, w.second->p});
+                    }
+                    if (cache_on && !from_prefix) { cbase[chains.size()] = std::move(base); cabs[chains.size()] = std::move(want); }
                     chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(fm);
                 }
                 // ---- 16-dimensional planes: the two messages a site sends in this level, both continuing from the same shared product and
@@ -414,7 +511,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 if (std::is_same<T, float>::value && use_mfma() && use_pair() && use_dbl()) {
                     for (size_t ci = 0; ci < chains.size(); ++ci) {
                         Chain& c = chains[ci];
-                        if (c.y || fmsg[ci] || c.steps.empty() || (c.steps.size() & 1) == 0 || c.sd.n < (size_t)(1u << 14)) continue;
+                        if ((c.y && (!cbase.count(ci) || cbase[ci].empty())) || fmsg[ci] || c.steps.empty() || (c.steps.size() & 1) == 0 || c.sd.n < (size_t)(1u << 14)) continue;
                         bool sh = false; for (int q : is_shared_chain) sh = sh || q == (int)ci;
                         if (sh) continue;
                         const int de = plan.seq[tpos[ci]]; const int e = de / 2; const int dst = (de & 1) ? g.esrc[e] : g.edst[e];
@@ -423,7 +520,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                         if (!plane_geometry(c.sd.d, c.sd.z, c.sd.chi.data(), lx, ly, 16, it.g)) continue;
                         bool all16 = true; for (auto& st : c.steps) all16 = all16 && c.sd.chi[st.first] == 16;
                         if (!all16) continue;
-                        it.Y = c.src; it.Mx = c.steps.back().second; it.My = nullptr; it.X = nullptr;      // X = the chain's result, known after run_chains
+                        it.Y = c.y ? c.y : c.src; it.Mx = c.steps.back().second; it.My = nullptr; it.X = nullptr;      // X = the chain's result, known after run_chains
                         c.steps.pop_back();
                         g16_single.push_back((int)g16.size());
                         g16.push_back(it); g16_chain.push_back({(int)ci, -1});
@@ -441,6 +538,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     launch_mfma_pair(s->stream, d, (int)sh_pair.size(), wgs);
                 }
                 run_chains<T>(s, chains, TNQS_PROF_BP_MODEPROD, TNQS_PROF_BP_PAIR);
+                if (cache_on) for (auto& kv : cabs) if (!chains[kv.first].trail.empty()) remember(chains[kv.first], s->site[chains[kv.first].v], cbase[kv.first], kv.second);
                 std::vector<GramJob> jobs;
                 for (size_t i = 0; i < chains.size(); ++i) {
                     int de = plan.seq[tpos[i]]; int e = de / 2; int dst = (de & 1) ? g.esrc[e] : g.edst[e];

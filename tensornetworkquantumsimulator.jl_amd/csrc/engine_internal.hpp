@@ -37,6 +37,7 @@ TNQS_SWITCH(use_pair, !envflag("TNQS_NO_PAIR"))                  // no plane ker
 TNQS_SWITCH(use_tshare, !envflag("TNQS_NO_TSHARE"))              // degree-4 chi = 32 sites: no pair product shared by the two messages of a forest
 TNQS_SWITCH(use_dbl, !envflag("TNQS_NO_DOUBLE_GRAM"))            // one pair-Gram pass per message instead of both messages of a forest per pass
 TNQS_SWITCH(use_prefix, !envflag("TNQS_NO_PREFIX"))              // BP: no shared partial product for the messages a site sends in one level
+TNQS_SWITCH(use_prodcache, !envflag("TNQS_NO_PRODCACHE"))        // BP: no partial product kept from one level to the next (engine_bp.cpp ProdCache)
 TNQS_SWITCH(use_chol, !envflag("TNQS_NO_CHOL"))                  // R factor from the eigen factorisation of the Gram matrix instead of Cholesky
 TNQS_SWITCH(use_qr2, !envflag("TNQS_NO_QR2"))                    // ComplexF64: no second factorisation pass; TNQS_QR2_ALL=1: on every site
 TNQS_SWITCH(use_lowrank, !envflag("TNQS_NO_LOWRANK"))            // theta SVD on the full theta instead of the low-rank factor
@@ -62,6 +63,8 @@ TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64
 // TNQS_NO_3M=1 (launch_util.hpp): four-multiplication complex product in every MFMA kernel instead of Gauss' three (mfma_common.hpp, CAcc32);
 // kernels_mfma.hip reads TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP (single-message pair-Gram), TNQS_DBG_GRAM_SKIP; kernels.hpp reads TNQS_PAIR_SPW
 // (slices per workgroup pair of the chi = 32 pair product) -- kernel experiments
+// TNQS_BP_CACHE_MB: bound on the partial products kept across BP levels (MiB, default 49152)
+inline size_t bp_cache_budget() { static const size_t v = [] { const char* e = std::getenv("TNQS_BP_CACHE_MB"); return (e ? (size_t)std::atoll(e) : (size_t)49152) << 20; }(); return v; }
 inline size_t bp_ws_budget() { static const size_t v = [] { const char* e = std::getenv("TNQS_BP_WS_MB"); return (e ? (size_t)std::atoll(e) : (size_t)24576) << 20; }(); return v; }
 inline size_t jacobi_lds(size_t bytes) { static const bool g = envflag("TNQS_JACOBI_GLOBAL"); return (g || bytes > 160 * 1024 - 256) ? 0 : bytes; }
 inline int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j : ji) m = std::max(m, std::max(j.m, j.n)); return m; }
@@ -183,6 +186,8 @@ struct Chain {
     const void* y = nullptr;                     // the untouched site tensor when src is a shared partial product of it (BP prefix sharing)
     std::vector<std::pair<int, const void*>> steps;
     const void* result = nullptr; Buf tmp[2];
+    bool ordered = false;                        // steps are in the caller's priority order: the two-leg stages take them from the front
+    std::vector<std::vector<int>> trail;         // legs absorbed by each pass, in order; pass k wrote tmp[k & 1] (the last two are intact afterwards)
 };
 
 

@@ -41,7 +41,7 @@ def test_lowrank_theta_route_matches_the_full_svd():
 
 @pytest.mark.parametrize("switch", ["TNQS_NO_CHOL", "TNQS_NO_SMALLSVD", "TNQS_JACOBI_GLOBAL", "TNQS_NO_PAIR", "TNQS_NO_TSHARE", "TNQS_NO_FUSED_GRAM",
                                     "TNQS_NO_APPLY64", "TNQS_NO_MFMA", "TNQS_EAGER_SCALE", "TNQS_NO_PREFIX", "TNQS_NO_ROWGEMM32", "TNQS_NO_3M",
-                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_DEFER_1SITE"])
+                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE"])
 def test_alternative_routes_match_the_default(switch):
     """every documented switch selects an alternative route of the same algorithm: all-eigen factorisation instead
     of Cholesky, Gram-eigen instead of the small-SVD route, global-memory Jacobi, single-leg mode products, per-message BP products,
@@ -116,6 +116,25 @@ def test_chi16_plane_kernels_match_the_single_leg_route():
         a = np.array(ma[0]) + 1j * np.array(ma[1]); b = np.array(mb[0]) + 1j * np.array(mb[1])
         worst = max(worst, float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
     print("chi = 16 plane kernels vs single-leg route: messages", worst)
+    assert worst < 2e-5
+    assert on["dims"] == off["dims"]
+    ea, eb = np.array(on["errs"]), np.array(off["errs"])
+    assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7)
+    assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-5
+
+
+def test_partial_products_kept_across_levels_change_nothing_but_the_pass_count():
+    """3x3x3 torus, chi = 16: the BP partial products remembered from one level to the next (engine_bp.cpp ProdCache: the levels of one axis
+    share the product over the other axes' legs, two axes share the factor over the third) against every level absorbing from the site
+    tensor again (TNQS_NO_PRODCACHE=1).  The same products of the same buffers in a different order: messages to f32 rounding, same layer;
+    and the remembered route must actually save two-leg passes."""
+    on, off = run_worker({}, "cubic16"), run_worker({"TNQS_NO_PRODCACHE": "1"}, "cubic16")
+    assert 0 < on["pair"] < off["pair"], (on["pair"], off["pair"])
+    worst = 0.0
+    for ma, mb in zip(on["msgs"], off["msgs"]):
+        a = np.array(ma[0]) + 1j * np.array(ma[1]); b = np.array(mb[0]) + 1j * np.array(mb[1])
+        worst = max(worst, float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
+    print("remembered partial products: two-leg launches", on["pair"], "against", off["pair"], " messages", worst)
     assert worst < 2e-5
     assert on["dims"] == off["dims"]
     ea, eb = np.array(on["errs"]), np.array(off["errs"])
