@@ -242,6 +242,7 @@ template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& job
     bool mf128 = std::is_same<T, float>::value && std::is_same<Acc, double>::value && use_mfma() && use_gram128() && KKmax <= 128 && KKmax > 64;
     for (auto& j : jobs) { mf64 = mf64 && (j.X == j.Y); mf128 = mf128 && (j.X == j.Y); }
     if (gauge_fused) { mf64 = true; mf128 = false; }
+    const bool gauge16 = gauge_fused && KKmax == 32;      // 16-dimensional legs: the wave-private kernel (units of one fiber of r, one partial per chunk)
     if (mf || mf64 || mf128) TR = 64;
     const int target = 2048;
     int per_item = std::max(1, target / (int)jobs.size());
@@ -255,20 +256,22 @@ template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& job
             it.K = j.sd.chi[j.leg]; it.PB = (int)j.sd.post(j.leg);
         } else { it.D = j.sd.d; it.PA = (int)(j.sd.n / j.sd.d); it.K = 1; it.PB = 1; }
         tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
+        if (gauge16) { it.nta = gauge_gram32_units(j.sd.z, j.sd.chi.data(), j.leg); it.ntb = 1; }
         int ntiles = it.nta * it.ntb;
         int nch = std::min(per_item, ntiles);
         it.tiles_per_chunk = (ntiles + nch - 1) / nch;
         it.nchunks = (ntiles + it.tiles_per_chunk - 1) / it.tiles_per_chunk;
         // 32 x 32 f32 MFMA kernels: one partial per wave; f64 64 x 64 MFMA kernel: one per tile parity; the chi = 64 kernels: one per chunk
-        j.nchunks = (mf && (fused || KKmax <= 32)) ? 4 * it.nchunks : (mf64 ? 2 * it.nchunks : it.nchunks);
+        j.nchunks = (mf && (fused || KKmax <= 32)) ? 4 * it.nchunks : ((mf64 && !gauge16) ? 2 * it.nchunks : it.nchunks);
         j.partial = dalloc(s, (size_t)j.nchunks * j.KK * j.KK * 2 * sizeof(Acc));
         it.partial = j.partial->p; it.chunk_begin = chunks; chunks += it.nchunks;
         items.push_back(it);
-        bytes += (j.X == j.Y ? 1.0 : 2.0) * j.sd.n * esz; flops += gauge_fused ? 8.0 * j.sd.n * (j.KK + 32.0) : 8.0 * j.sd.n * j.KK * (j.M ? 2.0 : 1.0);
+        bytes += (j.X == j.Y ? 1.0 : 2.0) * j.sd.n * esz; flops += gauge_fused ? 8.0 * j.sd.n * (j.KK + (gauge16 ? 16.0 : 32.0)) : 8.0 * j.sd.n * j.KK * (j.M ? 2.0 : 1.0);
     }
     const GramItem* d = upload(s, items);
     ProfScope ps(s, cls, bytes, flops);
-    if (gauge_fused) launch_mfma_gauge_gram64(s->stream, d, (int)items.size(), chunks);
+    if (gauge16) launch_mfma_gauge_gram32(s->stream, d, (int)items.size(), chunks);
+    else if (gauge_fused) launch_mfma_gauge_gram64(s->stream, d, (int)items.size(), chunks);
     else if (fused) launch_mfma_gram32_fused(s->stream, d, (int)items.size(), chunks);
     else if (mf64) { bool all64 = true; for (auto& j : jobs) all64 = all64 && j.KK == 64; launch_mfma_gram64_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax, all64); }
     else if (mf128) { bool all128 = true; for (auto& j : jobs) all128 = all128 && j.KK == 128; launch_mfma_gram128_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax, all128); }

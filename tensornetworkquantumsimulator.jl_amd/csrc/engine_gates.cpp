@@ -277,6 +277,11 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             gauge_gram64_covers(j.sd.d, j.sd.z, j.sd.chi.data(), j.bleg, c.steps[0].first)) {
             fused_M[q] = c.steps[0].second; c.steps.erase(c.steps.begin());
         }
+        // 16-dimensional legs (degree 6, chi = 16: five gauge legs): the same with mfma_gauge_gram32_kernel -- four legs in two two-leg passes, the fifth inside the Gram
+        else if (fuse_on && std::is_same<T, float>::value && use_mfma() && use_pair() && c.steps.size() >= 1 && c.steps[0].first == (j.bleg == 0 ? 1 : 0) &&
+                 j.sd.n >= (size_t)(1u << 14) && gauge_gram32_covers(j.sd.d, j.sd.z, j.sd.chi.data(), j.bleg, c.steps[0].first)) {
+            fused_M[q] = c.steps[0].second; c.steps.erase(c.steps.begin());
+        }
     }
     run_chains<T>(s, chains, TNQS_PROF_GATE_MODEPROD);
     // ---- 3. G = psi~^dagger psi~ over the outer legs, f64 accumulation (replaces the thin QR, simple_update.jl:45-48) --
@@ -287,11 +292,16 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         jobs.push_back(j);
     }
     {   // the fused and the plain Gram are different kernels: two batches, job order kept
-        std::vector<GramJob> jf, jp; std::vector<size_t> idf, idp;
-        for (size_t q = 0; q < jobs.size(); ++q) { if (jobs[q].M) { jf.push_back(jobs[q]); idf.push_back(q); } else { jp.push_back(jobs[q]); idp.push_back(q); } }
+        std::vector<GramJob> jf, jf16, jp; std::vector<size_t> idf, idf16, idp;
+        for (size_t q = 0; q < jobs.size(); ++q) {
+            if (jobs[q].M && jobs[q].sd.chi[jobs[q].leg] == 16) { jf16.push_back(jobs[q]); idf16.push_back(q); }
+            else if (jobs[q].M) { jf.push_back(jobs[q]); idf.push_back(q); } else { jp.push_back(jobs[q]); idp.push_back(q); }
+        }
         run_grams<T, double>(s, jf, TNQS_PROF_GATE_GRAM);
+        run_grams<T, double>(s, jf16, TNQS_PROF_GATE_GRAM);
         run_grams<T, double>(s, jp, TNQS_PROF_GATE_GRAM);
         for (size_t q = 0; q < jf.size(); ++q) jobs[idf[q]] = jf[q];
+        for (size_t q = 0; q < jf16.size(); ++q) jobs[idf16[q]] = jf16[q];
         for (size_t q = 0; q < jp.size(); ++q) jobs[idp[q]] = jp[q];
     }
     std::vector<Buf> GA(sj.size()), GV(sj.size());

@@ -309,6 +309,9 @@ bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, 
 // the third gauge leg absorbed inside the f64 Gram (kernels_gate.hip): GramItem::M = the 32 x 32 matrix of the fastest outer leg `rleg`; same
 // tiles and partial layout as launch_mfma_gram64_f64 (2 partials per chunk)
 bool gauge_gram64_covers(int d, int z, const int* chi, int bleg, int rleg);
+bool gauge_gram32_covers(int d, int z, const int* chi, int bleg, int rleg);      // the same fusion for 16-dimensional legs (32 columns)
+int gauge_gram32_units(int z, const int* chi, int bleg);                         // units (one fiber of r = 16 rows) of a site
+void launch_mfma_gauge_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
 void launch_mfma_gauge_gram64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
 // the same for 64 < D*K <= 128 (chi = 64 sites; kernels_chi64.hip); writes ONE partial per chunk
 bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax, bool all_kk128 = false);   // all_kk128: every item has D * K = 128

@@ -178,4 +178,170 @@ void launch_mfma_gauge_gram64(hipStream_t s, const GramItem* d_items, int nitems
     hipLaunchKernelGGL(mfma_gauge_gram64_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same fusion for bond dimension 16 (BASELINE configs[3]: degree 6, chi = 16, five gauge legs): the last gauge leg r and the f64 Gram
+// over 32 columns (s, k) in one pass, after two two-leg passes (mfma_pair16_kernel) instead of two two-leg passes + a single-leg pass + a
+// Gram pass.  Here the whole kernel is WAVE PRIVATE: a unit is ONE complete fiber of r = 16 rows x 32 columns (4 KiB); a wave loads it
+// (four 16-byte loads per lane, 256-byte runs), commits it to its own LDS slab, multiplies it with A_r in place
+//      X'[c][r'] = sum_r X[c][r] A[r][r']          (32 x 16) x (16 x 16), v_mfma_f32_16x16x4_f32, Gauss' three products
+// and accumulates the three upper 16 x 16 blocks of G over its own rows on v_mfma_f64_16x16x4_f64 (3M in f64).  No workgroup barrier in
+// the loop; the four waves' accumulators are summed through LDS at the end (one partial per workgroup).  Layout: planes Xr / Xi of a
+// slab, element (column c = s + 2 k, row r) at c * TRP + r, TRP = 20 (16-byte aligned operand rows; the 16 rows a b128 read of a
+// quarter wave touches fall on 16 different 4-bank groups).
+// Unit u of a site (K = 16, PA = product of the legs below the bond, site index excluded):
+//      bond leg >= 1:  r = leg 0, u = a' + (PA / 16) b', element (s, r, k) at 2 (16 a' + 16 PA b') + s + 2 r + 2 PA k
+//      bond leg == 0:  r = leg 1, u = b'',               element (s, r, k) at 512 u + s + 2 k + 32 r      (lanes run along k)
+__global__ __launch_bounds__(256, 3) void mfma_gauge_gram32_kernel(const GramItem* __restrict__ items, int nitems) {
+    constexpr int TRP = 20, PL = 32 * TRP, SLAB = 2 * PL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    float* const Xr = reinterpret_cast<float*>(smem) + w * SLAB; float* const Xi = Xr + PL;
+    int lo = 0, hi = nitems - 1;
+    const int gc = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].chunk_begin <= gc) lo = mid; else hi = mid - 1; }
+    const GramItem it = items[lo];
+    const int lc = gc - it.chunk_begin;
+    const long long PA = it.PA;
+    const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
+    const cf* __restrict__ Mg = reinterpret_cast<const cf*>(it.M);
+    const int nunits = it.nta * it.ntb;
+    const int u_begin = lc * it.tiles_per_chunk, u_end = min(nunits, u_begin + it.tiles_per_chunk);
+    const bool along_k = (PA == 1);                               // bond leg 0: the lanes run along k, the four loads along r
+    const long long st0 = along_k ? 2 : 2, st1 = along_k ? 32 : 2 * PA;      // element strides of (lane & 15) and of (lane >> 4) + 4 i
+    const int na = (int)(PA >> 4);                                // fibers of r per b' (bond leg >= 1)
+    // B operand of the transform: A[r = 4 kq + t][r' = l15], element (r, r') at r + 16 r'; the three combinations of Gauss' product
+    float br[4], bd[4], bs[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const cf a = ldgc(Mg + (4 * kq + t) + 16 * l15); br[t] = a.re; bd[t] = a.im - a.re; bs[t] = a.re + a.im; }
+    v4f pre[4];
+    auto issue = [&](int u) {
+        const long long base = along_k ? 512LL * u : 2LL * (16LL * (u % na) + 16LL * PA * (u / na));
+        const cf* p = Xg + base + st0 * l15 + st1 * kq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[i] = ldg4(p + 4 * st1 * i);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = along_k ? l15 : kq + 4 * i, r = along_k ? kq + 4 * i : l15;
+            const int o = (2 * k) * TRP + r;
+            Xr[o] = pre[i][0]; Xi[o] = pre[i][1]; Xr[o + TRP] = pre[i][2]; Xi[o + TRP] = pre[i][3];
+        }
+    };
+    v4d G00r = {0, 0, 0, 0}, G00i = G00r, G00c = G00r, G01r = G00r, G01i = G00r, G01c = G00r, G11r = G00r, G11i = G00r, G11c = G00r;
+    int u = u_begin + w;
+    if (u < u_end) issue(u);
+    for (; u < u_end; u += 4) {
+        commit();
+        __builtin_amdgcn_wave_barrier();                          // LDS is in order per wave; only the compiler must not reorder
+        if (u + 4 < u_end) issue(u + 4);
+        // ---- X' = X A, in place: two blocks of 16 columns ----------------------------------------------------------------
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int ro = (16 * mb + l15) * TRP + 4 * kq;
+            const v4f ar4 = *reinterpret_cast<const v4f*>(Xr + ro), ai4 = *reinterpret_cast<const v4f*>(Xi + ro);
+            v4f k1 = {0.f, 0.f, 0.f, 0.f}, k2 = k1, k3 = k1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                k1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ar4[t] + ai4[t], br[t], k1, 0, 0, 0);
+                k2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ar4[t], bd[t], k2, 0, 0, 0);
+                k3 = __builtin_amdgcn_mfma_f32_16x16x4f32(ai4[t], bs[t], k3, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                         // C[row = column 4 kq + r of the block][col = r' = l15]
+                const int o = (16 * mb + 4 * kq + r) * TRP + l15;
+                Xr[o] = k1[r] - k3[r]; Xi[o] = k1[r] + k2[r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- G += X'^dagger X' over the 16 rows: blocks (0,0), (0,1), (1,1); lane (l15, kq) supplies rows 4 kq + c ------------------
+        {
+            const int r0 = l15 * TRP + 4 * kq, r1 = (16 + l15) * TRP + 4 * kq;
+            const v4f p0 = *reinterpret_cast<const v4f*>(Xr + r0), p1 = *reinterpret_cast<const v4f*>(Xi + r0);
+            const v4f q0 = *reinterpret_cast<const v4f*>(Xr + r1), q1 = *reinterpret_cast<const v4f*>(Xi + r1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double pr = (double)p0[c], pi = (double)p1[c], qr = (double)q0[c], qi = (double)q1[c];
+                const double ps = pr + pi, qs = qr + qi;
+                G00r = __builtin_amdgcn_mfma_f64_16x16x4f64(ps, pr, G00r, 0, 0, 0);
+                G00i = __builtin_amdgcn_mfma_f64_16x16x4f64(pi, pr - pi, G00i, 0, 0, 0);
+                G00c = __builtin_amdgcn_mfma_f64_16x16x4f64(pr, ps, G00c, 0, 0, 0);
+                G01r = __builtin_amdgcn_mfma_f64_16x16x4f64(ps, qr, G01r, 0, 0, 0);
+                G01i = __builtin_amdgcn_mfma_f64_16x16x4f64(pi, qr - qi, G01i, 0, 0, 0);
+                G01c = __builtin_amdgcn_mfma_f64_16x16x4f64(pr, qs, G01c, 0, 0, 0);
+                G11r = __builtin_amdgcn_mfma_f64_16x16x4f64(qs, qr, G11r, 0, 0, 0);
+                G11i = __builtin_amdgcn_mfma_f64_16x16x4f64(qi, qr - qi, G11i, 0, 0, 0);
+                G11c = __builtin_amdgcn_mfma_f64_16x16x4f64(qr, qs, G11c, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                          // the slab has been consumed: the next commit may overwrite it
+    }
+    // ---- the four waves' accumulators -> one partial: (2, 3) -> LDS, (0, 1) add; 1 -> LDS, 0 adds and writes ---------------------
+    struct alignas(16) cd { double re, im; };
+    cd* const R = reinterpret_cast<cd*>(smem);                   // [2 waves][3 blocks][256]
+    cd v[3][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[0][r].re = G00r[r] - G00i[r]; v[0][r].im = G00r[r] - G00c[r];
+        v[1][r].re = G01r[r] - G01i[r]; v[1][r].im = G01r[r] - G01c[r];
+        v[2][r].re = G11r[r] - G11i[r]; v[2][r].im = G11r[r] - G11c[r];
+    }
+    __syncthreads();                                              // every wave is done with its slab
+    if (w >= 2) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[((w - 2) * 3 + b) * 256 + 64 * r + lane] = v[b][r];
+    }
+    __syncthreads();
+    if (w < 2) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const cd o = R[(w * 3 + b) * 256 + 64 * r + lane]; v[b][r].re += o.re; v[b][r].im += o.im; }
+    }
+    __syncthreads();
+    if (w == 1) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[b * 256 + 64 * r + lane] = v[b][r];
+    }
+    __syncthreads();
+    if (w == 0) {
+        cd* __restrict__ part = reinterpret_cast<cd*>(it.partial) + (size_t)lc * 1024;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int I = b == 2 ? 1 : 0, J = b == 0 ? 0 : 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const cd o = R[b * 256 + 64 * r + lane];
+                cd g; g.re = v[b][r].re + o.re; g.im = v[b][r].im + o.im;
+                const int i = 16 * I + kq + 4 * r, j = 16 * J + l15;
+                part[i + 32 * j] = g;
+                if (I != J) { cd c; c.re = g.re; c.im = -g.im; part[j + 32 * i] = c; }      // G[j][i] = conj(G[i][j])
+            }
+        }
+    }
+}
+
+// the shape the kernel covers: d = 2, a 16-dimensional bond leg b, fastest outer leg r (the lowest leg that is not b) of dimension 16,
+// whole fibers of r contiguous in 256-byte runs (everything below the bond is a multiple of 16 fibers, or the bond is leg 0)
+bool gauge_gram32_covers(int d, int z, const int* chi, int bleg, int rleg) {
+    if (d != 2 || z < 2 || bleg < 0 || bleg >= z || rleg < 0 || rleg >= z || rleg == bleg) return false;
+    if (chi[bleg] != 16 || chi[rleg] != 16 || !mfma_use_3m()) return false;
+    if (rleg != (bleg == 0 ? 1 : 0)) return false;
+    return true;
+}
+int gauge_gram32_units(int z, const int* chi, int bleg) {
+    long long n = 1; for (int i = 0; i < z; ++i) if (i != bleg) n *= chi[i];
+    return (int)(n / 16);
+}
+void launch_mfma_gauge_gram32(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks) {
+    if (total_chunks <= 0) return;
+    const size_t lds = 2 * 3 * 256 * 16;                          // the reduction of the accumulators (24 KiB) > the four slabs (20 KiB)
+    set_max_dynamic_lds((const void*)mfma_gauge_gram32_kernel, lds);
+    hipLaunchKernelGGL(mfma_gauge_gram32_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+}
+
 }  // namespace tnqs

@@ -142,6 +142,18 @@ def test_partial_products_kept_across_levels_change_nothing_but_the_pass_count()
     assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-5
 
 
+def test_chi16_gauge_leg_inside_the_gram_matches_the_separate_pass():
+    """3x3x3 torus, chi = 16: the fifth gauge leg absorbed inside the f64 Gram kernel (mfma_gauge_gram32_kernel, kernels_gate.hip) against
+    a single-leg pass + plain Gram (TNQS_NO_GAUGE_GRAM=1).  The gauged tensor is rounded to f32 at the same place on both routes, so the Gram
+    matrices agree to f64 summation order: same layer to f32 rounding of the downstream factorisations."""
+    on, off = run_worker({}, "cubic16"), run_worker({"TNQS_NO_GAUGE_GRAM": "1"}, "cubic16")
+    assert on["dims"] == off["dims"]
+    ea, eb = np.array(on["errs"]), np.array(off["errs"])
+    print("chi = 16 fused gauge + Gram: max |derr|", float(np.max(np.abs(ea - eb))), " max |dZ|", float(np.max(np.abs(np.array(on["z"]) - np.array(off["z"])))))
+    assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7)
+    assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-5
+
+
 def test_chi64_kernels_match_the_generic_route_on_a_physical_evolution():
     """nine TFIM layers from the product state at maxdim 64 (bonds grow 2 -> 64, theta rank deficient on the way): the chi = 64 kernels
     (kernels_chi64.hip and the Cholesky-QR theta SVD) against the generic route (TNQS_NO_CHI64=1: round-1 kernels, global-memory Jacobi).
