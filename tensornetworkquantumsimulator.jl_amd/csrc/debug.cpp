@@ -195,8 +195,56 @@ void dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X,
 }
 // timing of the chi = 32 plane kernels on `nsites` degree-4 site tensors [2][32]^4 resident in HBM (which: 0 pair product on legs (lx, ly),
 // 1 both-messages pair-Gram); *ms = average launch duration over `reps` launches (HIP events), after one untimed launch
+// which = 2 / 3: the chi = 16 plane kernels (mfma_pair16_kernel / mfma_pair_gram2x16_kernel, both messages) on degree-6 site tensors
+static void dbg_bench_plane16(int which, int nsites, int lx, int ly, int reps, double* ms) {
+    const int chi[6] = {16, 16, 16, 16, 16, 16};
+    PlaneGeom g{};
+    if (!plane_geometry(2, 6, chi, lx, ly, 16, g)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_bench_plane: legs not covered");
+    const size_t n = (size_t)2 << 24;
+    DBuf dA((size_t)nsites * n * 8), dB((size_t)nsites * n * 8), dM(2 * 256 * 8);
+    HIPCHK(hipMemsetD32((hipDeviceptr_t)dA.p, 0x3c23d70a, (size_t)nsites * n * 2));
+    HIPCHK(hipMemsetD32((hipDeviceptr_t)dB.p, 0x3c23d70a, (size_t)nsites * n * 2));
+    HIPCHK(hipMemsetD32((hipDeviceptr_t)dM.p, 0x3c23d70a, 2 * 256 * 2));
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    float t = 0.f;
+    const double tot = (double)nsites * g.nslices();
+    if (which == 2) {
+        std::vector<Pair16Item> items(nsites);
+        int spw = 4; while (spw < 64 && tot / (2 * spw) >= 2048.0) spw *= 2;
+        int wgs = 0;
+        for (int i = 0; i < nsites; ++i) {
+            Pair16Item& it = items[i]; it.g = g; it.in = (char*)dA.p + (size_t)i * n * 8; it.out = (char*)dB.p + (size_t)i * n * 8;
+            it.Mx = dM.p; it.My = (char*)dM.p + 256 * 8; it.wg_begin = wgs; it.spw = spw; wgs += (g.nslices() + spw - 1) / spw;
+        }
+        DBuf dI(items.size() * sizeof(Pair16Item)); dI.up(items.data(), items.size() * sizeof(Pair16Item));
+        launch_mfma_pair16(nullptr, (const Pair16Item*)dI.p, nsites, wgs, pair16_whole_lines(g));
+        HIPCHK(hipEventRecord(e0, nullptr));
+        for (int r = 0; r < reps; ++r) launch_mfma_pair16(nullptr, (const Pair16Item*)dI.p, nsites, wgs, pair16_whole_lines(g));
+        HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1)); HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    } else {
+        std::vector<PairGram2x16Item> items(nsites);
+        int spw = 2; while (spw < 128 && tot / (2 * spw) >= 2048.0) spw *= 2;
+        int wgs = 0; const int nwg = (g.nslices() + spw - 1) / spw;
+        DBuf dP((size_t)2 * nsites * nwg * 256 * 8);
+        for (int i = 0; i < nsites; ++i) {
+            PairGram2x16Item& it = items[i]; it.g = g; it.X = (char*)dA.p + (size_t)i * n * 8; it.Y = (char*)dB.p + (size_t)i * n * 8;
+            it.Mx = dM.p; it.My = (char*)dM.p + 256 * 8; it.wg_begin = wgs; it.spw = spw;
+            it.partial_y = (char*)dP.p + (size_t)(2 * i) * nwg * 256 * 8; it.partial_x = (char*)dP.p + (size_t)(2 * i + 1) * nwg * 256 * 8;
+            wgs += nwg;
+        }
+        DBuf dI(items.size() * sizeof(PairGram2x16Item)); dI.up(items.data(), items.size() * sizeof(PairGram2x16Item));
+        launch_mfma_pair_gram2x16(nullptr, (const PairGram2x16Item*)dI.p, nsites, wgs);
+        HIPCHK(hipEventRecord(e0, nullptr));
+        for (int r = 0; r < reps; ++r) launch_mfma_pair_gram2x16(nullptr, (const PairGram2x16Item*)dI.p, nsites, wgs);
+        HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1)); HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms = (double)t / reps;
+}
 void dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms) {
     need_gpu();
+    if (which >= 2) { dbg_bench_plane16(which, nsites, lx, ly, reps, ms); return; }
     const int chi[4] = {32, 32, 32, 32};
     PairGeom g{};
     if (!pair_geometry(2, 4, chi, lx, ly, g)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_bench_plane: legs not covered");

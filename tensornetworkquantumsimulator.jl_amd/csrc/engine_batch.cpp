@@ -78,22 +78,27 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
                     }
             }
             if (it16.empty()) break;
-            // slices per workgroup: a multiple of 4 (8 waves = 4 slices x 2 halves), at least ~8 workgroups per CU overall
+            // slices per workgroup: a multiple of 4 (4 slices at a time, as 8 waves x half slices or 4 waves x whole slices), at least ~8 workgroups per CU overall
             int spw = 4; while (spw < 64 && slices16 / (2 * spw) >= 2048.0) spw *= 2;
-            int wgs16 = 0;
+            std::vector<Pair16Item> kind[2]; int wgs16[2] = {0, 0};           // [1]: whole 128-byte lines per wave (pair16_whole_lines)
             for (size_t q = 0; q < it16.size(); ++q) {
                 Chain& c = chains[sel16[q].first]; Pair16Item& it = it16[q];
+                const int wl = pair16_whole_lines(it.g) ? 1 : 0;
                 Buf& dst = c.tmp[nt[sel16[q].first] & 1];
                 if (!dst) dst = dalloc(s, c.sd.n * esz);
-                it.in = c.result; it.out = dst->p; it.spw = spw; it.wg_begin = wgs16; wgs16 += (it.g.nslices() + spw - 1) / spw;
+                it.in = c.result; it.out = dst->p; it.spw = spw; it.wg_begin = wgs16[wl]; wgs16[wl] += (it.g.nslices() + spw - 1) / spw;
+                kind[wl].push_back(it);
                 c.result = dst->p; nt[sel16[q].first]++;
                 c.trail.push_back({c.steps[sel16[q].second.first].first, c.steps[sel16[q].second.second].first});
                 c.steps.erase(c.steps.begin() + sel16[q].second.second); c.steps.erase(c.steps.begin() + sel16[q].second.first);
                 by16 += 2.0 * c.sd.n * esz; fl16 += 2 * 8.0 * c.sd.n * 16;
             }
-            const Pair16Item* d = upload(s, it16);
             ProfScope ps(s, cls_pair, by16, fl16);
-            launch_mfma_pair16(s->stream, d, (int)it16.size(), wgs16);
+            for (int wl = 0; wl < 2; ++wl) {
+                if (kind[wl].empty()) continue;
+                const Pair16Item* d = upload(s, kind[wl]);
+                launch_mfma_pair16(s->stream, d, (int)kind[wl].size(), wgs16[wl], wl == 1);
+            }
         }
     }
     size_t maxsteps = 0;

@@ -293,7 +293,10 @@ struct Pair16Item {       // out = in x_x Mx x_y My for two 16-dimensional legs
 //   partial_y[b,b'] = sum (X x_lx Mx)[.. b on ly ..] conj(Y[.. b' on ly ..]),   partial_x[d,d'] = sum (X x_ly My)[.. d on lx ..] conj(Y[.. d' on lx ..])
 // one 16 x 16 partial per workgroup each
 struct PairGram2x16Item { const void* X; const void* Y; const void* Mx; const void* My; void* partial_y; void* partial_x; PlaneGeom g; int wg_begin; int spw; };
-void launch_mfma_pair16(hipStream_t s, const Pair16Item* d_items, int nitems, int total_wgs);
+// two kernels: a wave pair sharing every 128-byte line (planes that contain leg 0: a wave's lanes read 256 contiguous bytes anyway) and one
+// wave owning whole lines (the 16 companions are 16 consecutive elements); a launch holds items of one kind
+bool pair16_whole_lines(const PlaneGeom& g);
+void launch_mfma_pair16(hipStream_t s, const Pair16Item* d_items, int nitems, int total_wgs, bool whole_lines);
 void launch_mfma_pair_gram2x16(hipStream_t s, const PairGram2x16Item* d_items, int nitems, int total_wgs);
 
 // ---- MFMA fast paths (ComplexF32 only; kernels_mfma.hip) -----------------------------------------------------------
