@@ -12,7 +12,7 @@ nsites = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n = 2 * 32 ** 4
 for which, name, flops in ((0, "pair", 2 * 8.0 * n * 32), (1, "pair_gram2", 4 * 8.0 * n * 32)):
-    for lx, ly in ((0, 1), (1, 3), (2, 3)):
+    for lx, ly in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)):
         ms = C.c_double(0)
         rc = lib.tnqs_dbg_bench_plane(which, nsites, lx, ly, reps, C.byref(ms))
         if rc != 0:

@@ -1,5 +1,6 @@
 """Per-site shapes of the BASELINE configurations that need 8 GPUs at full size, measured on one MI355X on a lattice that fits:
     python profiles/shape_bench.py cubic16     3x3x3 periodic cubic, chi = 16 (configs[3] per-site shape: degree 6, 268 MB tensors)
+    python profiles/shape_bench.py heavyhex    heavy-hex (5,5), chi = 16 (configs[2]);   c1: 5x5, chi = 10, ComplexF64 (configs[0]) -- both latency-bound
     python profiles/shape_bench.py c128        LxL grid (L = 8), chi = 32 (CHI), ComplexF64: the reference's default element type at the bulk shape
     python profiles/shape_bench.py chi64       5x5 grid, chi = 64 (configs[4] per-site shape: degree 4, 268 MB bulk tensors, 256 x 256 theta)
 Prints one JSON line: ms per layer, gates/s, BP sweeps, and per kernel class the HIP-event time, algorithmic TFLOP/s and TB/s (the
@@ -33,6 +34,19 @@ def main():
         for grp in groups:
             layer += [("Rxx", [a, b], -0.08) for (a, b) in grp]
         z = 6
+    elif mode == "heavyhex":      # BASELINE configs[2]: heavy-hex (5,5), chi = 16, degrees 2 / 3 (examples/heavyhexIsing_dynamics.jl circuit); latency-bound
+        g = tn.heavy_hexagonal_lattice(5, 5); chi = 16
+        groups = tn.edge_color(g, 3)
+        layer = [("Rx", [v], 0.4) for v in g.vertices]
+        for grp in groups:
+            layer += [("Rzz", [a, b], 0.1) for (a, b) in grp]
+        z = 3
+    elif mode == "c1":            # BASELINE configs[0]: 5x5 TFIM, chi = 10, ComplexF64 (the reference's CPU-runnable case); latency-bound
+        g = tn.named_grid((5, 5)); chi = 10; groups = tn.edge_color(g, 4)
+        layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+        for grp in groups:
+            layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+        z = 4
     elif mode == "c128":
         L = int(os.environ.get("L", 8)); chi = int(os.environ.get("CHI", 32))
         g = tn.named_grid((L, L)); groups = tn.edge_color(g, 4)
@@ -47,7 +61,7 @@ def main():
         for grp in groups:
             layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
         z = 4
-    dt_ = np.complex128 if mode == "c128" else np.complex64
+    dt_ = np.complex128 if mode in ("c128", "c1") else np.complex64
     bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(dt_, lambda v: "↑", g))
     for v, t in unit_state(g, chi, 1234):
         bpc._set_tensor(v, t.astype(dt_))

@@ -798,7 +798,19 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
         for (int i = k + 1 + ti; i < n; i += 64) {
             const cx<double> li = A[i + np * k];
             const cx<double> ls = cmake<double>(li.re * dinv, li.im * dinv);
-            for (int j = k + 1 + tj; j <= i; j += 4) {
+            // (four independent updates at a time, loads first: a load behind a store to the same array waits for it, so the one-at-a-time loop
+            // paid two LDS latencies per element)
+            int j = k + 1 + tj;
+            for (; j + 12 <= i; j += 16) {
+                cx<double> lj[4], v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { lj[u] = A[(j + 4 * u) + np * k]; v[u] = A[i + np * (j + 4 * u)]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v[u].re -= ls.re * lj[u].re + ls.im * lj[u].im; v[u].im -= ls.im * lj[u].re - ls.re * lj[u].im; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) A[i + np * (j + 4 * u)] = v[u];
+            }
+            for (; j <= i; j += 4) {
                 const cx<double> lj = A[j + np * k];
                 cx<double> v = A[i + np * j];
                 v.re -= ls.re * lj.re + ls.im * lj.im; v.im -= ls.im * lj.re - ls.re * lj.im;
@@ -886,7 +898,26 @@ __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __rest
         for (int i = k + 1 + ti; i < n; i += 64) {
             const cx<double> li = A[at(i, k)];
             const cx<double> ls = cmake<double>(li.re * dinv, li.im * dinv);
-            for (int j = k + 1 + tj; j <= i; j += 4) {
+            int j = k + 1 + tj;
+            for (; j + 28 <= i; j += 32) {                      // eight independent updates at a time, loads first (see chol_kernel)
+                cx<double> lj[8], v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { lj[u] = A[at(j + 4 * u, k)]; v[u] = A[at(i, j + 4 * u)]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v[u].re -= ls.re * lj[u].re + ls.im * lj[u].im; v[u].im -= ls.im * lj[u].re - ls.re * lj[u].im; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) A[at(i, j + 4 * u)] = v[u];
+            }
+            for (; j + 12 <= i; j += 16) {
+                cx<double> lj[4], v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { lj[u] = A[at(j + 4 * u, k)]; v[u] = A[at(i, j + 4 * u)]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v[u].re -= ls.re * lj[u].re + ls.im * lj[u].im; v[u].im -= ls.im * lj[u].re - ls.re * lj[u].im; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) A[at(i, j + 4 * u)] = v[u];
+            }
+            for (; j <= i; j += 4) {
                 const cx<double> lj = A[at(j, k)];
                 cx<double> v = A[at(i, j)];
                 v.re -= ls.re * lj.re + ls.im * lj.im; v.im -= ls.im * lj.re - ls.re * lj.im;
@@ -908,32 +939,43 @@ __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __rest
     cx<double>* L = reinterpret_cast<cx<double>*>(it.L);
     for (int e = tid; e < n * n; e += 256) { int i = e % n, j = e / n; L[e] = (i >= j) ? A[at(i, j)] : cmake<double>(0, 0); }
     if (!it.Winv) return;
-    // W = (L^-1)^dagger (upper triangular), W[c + n*i] = conj(Linv[i, c]): column c of L^-1 by forward substitution, one thread per column;
-    // the packed layout has no spare triangle, so the running column lives in W itself (thread c only ever touches row c of W: the
-    // accesses of neighbouring threads are neighbouring addresses)
+    // W = (L^-1)^dagger (upper triangular), W[c + n*i] = conj(Linv[i, c]).  L^-1 is built IN PLACE in the packed triangle, from the last column
+    // to the first: column j of the inverse is  -Linv[j+1:, j+1:] L[j+1:, j] / L[j, j]  -- the trailing block is already inverted, column j still
+    // holds L.  Two threads per row i split the sum over k (one LDS read of Linv[i, k], consecutive in i, and one broadcast read of L[k, j] per
+    // term); two barriers per column.  (Round 2 ran one thread per column of the inverse against global memory: 0.6 of the kernel's 0.78 ms
+    // at n = 128.)  L itself has been written out above.
+    __syncthreads();
     cx<double>* W = reinterpret_cast<cx<double>*>(it.Winv);
-    for (int e = tid; e < n * n; e += 256) { int i = e % n, a = e / n; if (i > a) W[e] = cmake<double>(0, 0); }
-    for (int c = tid; c < n; c += 256) {
-        W[c + (size_t)n * c] = cmake<double>(1.0 / A[at(c, c)].re, 0.0);
-        for (int i = c + 1; i < n; ++i) {
-            // four independent partial sums: the loads of W do not depend on the running sum, so four are in flight at a time
-            double ar[4] = {0, 0, 0, 0}, ai[4] = {0, 0, 0, 0};
-            int j = c;
-            for (; j + 4 <= i; j += 4) {
+    const int row = tid >> 1, half = tid & 1;
+    for (int j = n - 1; j >= 0; --j) {
+        const double dj = 1.0 / A[at(j, j)].re;
+        const int i = j + 1 + row;
+        double ar = 0, ai = 0;
+        if (i < n) {
+            int k = j + 1 + half;
+            for (; k + 6 <= i; k += 8) {                         // four independent terms in flight
+                cx<double> x[4], l[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const cx<double> lj = A[at(i, j + u)]; cx<double> x = W[c + (size_t)n * (j + u)]; x.im = -x.im;      // stored conjugated
-                    ar[u] -= lj.re * x.re - lj.im * x.im; ai[u] -= lj.re * x.im + lj.im * x.re;
-                }
+                for (int u = 0; u < 4; ++u) { x[u] = A[at(i, k + 2 * u)]; l[u] = A[at(k + 2 * u, j)]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { ar -= x[u].re * l[u].re - x[u].im * l[u].im; ai -= x[u].re * l[u].im + x[u].im * l[u].re; }
             }
-            for (; j < i; ++j) {
-                const cx<double> lj = A[at(i, j)]; cx<double> x = W[c + (size_t)n * j]; x.im = -x.im;
-                ar[0] -= lj.re * x.re - lj.im * x.im; ai[0] -= lj.re * x.im + lj.im * x.re;
+            for (; k <= i; k += 2) {
+                const cx<double> x = A[at(i, k)], l = A[at(k, j)];
+                ar -= x.re * l.re - x.im * l.im; ai -= x.re * l.im + x.im * l.re;
             }
-            cx<double> acc = cmake<double>((ar[0] + ar[1]) + (ar[2] + ar[3]), (ai[0] + ai[1]) + (ai[2] + ai[3]));
-            const double inv = 1.0 / A[at(i, i)].re;
-            W[c + (size_t)n * i] = cmake<double>(acc.re * inv, -acc.im * inv);
         }
+        ar += __shfl_xor(ar, 1, 64); ai += __shfl_xor(ai, 1, 64);
+        __syncthreads();                                   // column j has been read by everybody
+        if (i < n && half == 0) A[at(i, j)] = cmake<double>(ar * dj, ai * dj);
+        if (tid == 0) A[at(j, j)] = cmake<double>(dj, 0.0);
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += 256) {
+        const int c = e % n, i = e / n;
+        cx<double> v = cmake<double>(0, 0);
+        if (i >= c) { v = A[at(i, c)]; v.im = -v.im; }
+        W[e] = v;
     }
 }
 void launch_chol_packed(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {
