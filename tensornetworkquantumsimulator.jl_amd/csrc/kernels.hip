@@ -798,18 +798,7 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
         for (int i = k + 1 + ti; i < n; i += 64) {
             const cx<double> li = A[i + np * k];
             const cx<double> ls = cmake<double>(li.re * dinv, li.im * dinv);
-            // (four independent updates at a time, loads first: a load behind a store to the same array waits for it, so the one-at-a-time loop
-            // paid two LDS latencies per element)
             int j = k + 1 + tj;
-            for (; j + 12 <= i; j += 16) {
-                cx<double> lj[4], v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { lj[u] = A[(j + 4 * u) + np * k]; v[u] = A[i + np * (j + 4 * u)]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { v[u].re -= ls.re * lj[u].re + ls.im * lj[u].im; v[u].im -= ls.im * lj[u].re - ls.re * lj[u].im; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) A[i + np * (j + 4 * u)] = v[u];
-            }
             for (; j <= i; j += 4) {
                 const cx<double> lj = A[j + np * k];
                 cx<double> v = A[i + np * j];
@@ -899,24 +888,6 @@ __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __rest
             const cx<double> li = A[at(i, k)];
             const cx<double> ls = cmake<double>(li.re * dinv, li.im * dinv);
             int j = k + 1 + tj;
-            for (; j + 28 <= i; j += 32) {                      // eight independent updates at a time, loads first (see chol_kernel)
-                cx<double> lj[8], v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { lj[u] = A[at(j + 4 * u, k)]; v[u] = A[at(i, j + 4 * u)]; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { v[u].re -= ls.re * lj[u].re + ls.im * lj[u].im; v[u].im -= ls.im * lj[u].re - ls.re * lj[u].im; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) A[at(i, j + 4 * u)] = v[u];
-            }
-            for (; j + 12 <= i; j += 16) {
-                cx<double> lj[4], v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { lj[u] = A[at(j + 4 * u, k)]; v[u] = A[at(i, j + 4 * u)]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { v[u].re -= ls.re * lj[u].re + ls.im * lj[u].im; v[u].im -= ls.im * lj[u].re - ls.re * lj[u].im; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) A[at(i, j + 4 * u)] = v[u];
-            }
             for (; j <= i; j += 4) {
                 const cx<double> lj = A[at(j, k)];
                 cx<double> v = A[at(i, j)];

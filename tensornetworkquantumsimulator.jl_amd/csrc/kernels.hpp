@@ -176,7 +176,6 @@ void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, in
 void launch_tall_gram(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);
 void launch_tall_rt(hipStream_t s, const TallSvdItem* d_items, int nitems);
 void launch_tall_w(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);      // R0 slot (out, complex128) = [L slot: R^-1, complex128] x Rrot
-void launch_small_cgemm(hipStream_t s, const SmallGemmItem* d_items, int nitems, int mmax, int nmax);
 void launch_tall_mj(hipStream_t s, const SmallGemmItem* d_items, int nitems);      // C (m x n, ComplexF32) = A (m x k, ComplexF32) B (k x n, complex128), f64 matrix cores
 void launch_copy_items(hipStream_t s, const CopyItem* d_items, int nitems);
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax);

@@ -192,7 +192,7 @@ bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int 
 //   G = A^dagger A + delta I (f64, n x n)  ->  G = L L^dagger (chol_packed_kernel, shift delta)  ->  R = L^dagger (n x n, f32)
 //   one-sided Jacobi on R in LDS: R J = U_R Sigma_R            (jacobi_lds_kernel<float>)
 //   J = R^-1 (U_R Sigma_R)                                      (tall_w_kernel, f64: the rotations are never accumulated in f32)
-//   A <- A J = U Sigma of A                                    (small_cgemm: the same rotations orthogonalise the columns of A, because
+//   A <- A J = U Sigma of A                                    (tall_mj_kernel: the same rotations orthogonalise the columns of A, because
 //                                                               R^dagger R and A^dagger A have the same eigenvectors; the shift only
 //                                                               bounds the condition number of R, it cancels in R^-1 (R J) = J)
 // The kernels below are the three small pieces around the existing ones.
@@ -352,42 +352,6 @@ void launch_tall_mj(hipStream_t s, const SmallGemmItem* d_items, int nitems) {
     if (nitems <= 0) return;
     hipLaunchKernelGGL(tall_mj_kernel, dim3(nitems, 4), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
-// C (m x n) = A (m x k) B (k x n), ComplexF32 column-major, one wave per 32 x 32 tile of C, operands straight from L2 (all <= 512 KiB)
-__global__ __launch_bounds__(256) void small_cgemm_kernel(const SmallGemmItem* __restrict__ items) {
-    const SmallGemmItem it = items[blockIdx.x];
-    const cf* __restrict__ A = reinterpret_cast<const cf*>(it.A);
-    const cf* __restrict__ B = reinterpret_cast<const cf*>(it.B);
-    cf* __restrict__ C = reinterpret_cast<cf*>(it.C);
-    const int m = it.m, n = it.n, k = it.k;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, ln = lane & 31, h = lane >> 5;
-    const int mt = (m + 31) >> 5, ntl = (n + 31) >> 5;
-    const int tile = blockIdx.y * 4 + w;
-    if (tile >= mt * ntl) return;
-    const int r0 = 32 * (tile % mt), c0 = 32 * (tile / mt);
-    const int row = r0 + ln, col = c0 + ln;
-    const bool okr = row < m, okc = col < n;
-    const cf* pa = A + min(row, m - 1);                       // A[row][kk] at row + m kk
-    const cf* pb = B + (size_t)k * min(col, n - 1);          // B[kk][col] at kk + k col
-    v16f Cr, Ci;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { Cr[r] = 0.f; Ci[r] = 0.f; }
-    for (int k0 = 0; k0 < k; k0 += 2) {
-        const int kk = k0 + h;
-        cf a = {0.f, 0.f}, b = {0.f, 0.f};
-        if (kk < k) { if (okr) a = pa[(size_t)m * kk]; if (okc) b = pb[kk]; }
-        Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.re, b.re, Cr, 0, 0, 0);
-        Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(a.re, b.im, Ci, 0, 0, 0);
-        Cr = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.im, b.im, Cr, 0, 0, 0);
-        Ci = __builtin_amdgcn_mfma_f32_32x32x2f32(a.im, b.re, Ci, 0, 0, 0);
-    }
-    if (okc) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;      // C[row = i][col = ln]
-            if (i < m) { cf v; v.re = Cr[r]; v.im = Ci[r]; C[i + (size_t)m * col] = v; }
-        }
-    }
-}
 __global__ __launch_bounds__(256) void copy_items_kernel(const CopyItem* __restrict__ items) {
     const CopyItem it = items[blockIdx.x];
     const v4f* __restrict__ src = reinterpret_cast<const v4f*>(it.src); v4f* __restrict__ dst = reinterpret_cast<v4f*>(it.dst);
@@ -401,11 +365,6 @@ void launch_tall_gram(hipStream_t s, const TallSvdItem* d_items, int nitems, int
 void launch_tall_rt(hipStream_t s, const TallSvdItem* d_items, int nitems) {
     if (nitems <= 0) return;
     hipLaunchKernelGGL(tall_rt_kernel, dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
-}
-void launch_small_cgemm(hipStream_t s, const SmallGemmItem* d_items, int nitems, int mmax, int nmax) {
-    if (nitems <= 0) return;
-    const int tiles = ((mmax + 31) / 32) * ((nmax + 31) / 32);
-    hipLaunchKernelGGL(small_cgemm_kernel, dim3(nitems, (tiles + 3) / 4), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 void launch_copy_items(hipStream_t s, const CopyItem* d_items, int nitems) {
     if (nitems <= 0) return;
