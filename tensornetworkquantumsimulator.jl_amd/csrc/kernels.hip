@@ -1458,43 +1458,56 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
     cx<T>* X2 = reinterpret_cast<cx<T>*>(it.X2);
     const int n1 = it.n1, n2 = it.n2;
     // X1[(s,b),(s1',u)] = sum_a W1[(s,b),a] / sqrt(l1_a) * (U Sigma)[(a,s1'),pi(u)] / sqrt(sigma_u)
-    for (int e = tid0; e < n1 * d1 * nk; e += tstride) {
-        int kk = e % n1, nn = e / n1;
-        int s1p = nn % d1, u = nn / d1;
-        int pu = perm[u];
-        double su = sig[pu];
-        cx<double> acc = cmake<double>(0, 0);
-        if (su > 0) {
-            for (int a = 0; a < r1; ++a) {
-                cx<double> w = V1[kk + (size_t)n1 * it.idx1[a]];
-                cx<T> l = wide ? tv[(a + r1 * s1p) + (size_t)Mr * pu] : th[(a + r1 * s1p) + (size_t)Mr * pu];
-                const double f = fa1[a];
-                cx<double> lv = cmake<double>(l.re * f, l.im * f);
-                cfma(acc, w, lv);
-            }
-            double f = wide ? sqrt(su) : 1.0 / sqrt(su);        // L = U sqrt(S)
-            acc.re *= f; acc.im *= f;
-        }
-        X1[e] = cmake<T>((T)acc.re, (T)acc.im);
-    }
     // X2[(s,b),(s2',u)] = sum_c W2[(s,b),c] / sqrt(l2_c) * sqrt(sigma_u) conj(Vtheta[(c,s2'),pi(u)])
-    for (int e = tid0; e < n2 * d2 * nk; e += tstride) {
-        int kk = e % n2, nn = e / n2;
-        int s2p = nn % d2, u = nn / d2;
-        int pu = perm[u];
-        double su = sig[pu];
-        cx<double> acc = cmake<double>(0, 0);
-        if (su > 0 || !wide) {
-            for (int c = 0; c < r2; ++c) {
-                cx<double> w = V2[kk + (size_t)n2 * it.idx2[c]];
-                cx<T> v = wide ? th[(c + r2 * s2p) + (size_t)Nc * pu] : tv[(c + r2 * s2p) + (size_t)Nc * pu];
-                const double f = fa2[c];
-                cx<double> vd = cmake<double>(v.re * f, -v.im * f);
-                cfma(acc, w, vd);
+    // Two small complex products (64 x 64 x 64 at chi = 32) on the f64 matrix cores, one wave per 16 x 16 tile (ztile_mm); the tile's lanes
+    // run along (s,b), the contiguous index of X.  (The scalar loops these replace chased idx -> W -> multiply-add through L2 once per term:
+    // 0.23 ms per launch at chi = 32, most of it load latency.)
+    (void)tid0; (void)tstride;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wv = part * (blockDim.x >> 6) + (threadIdx.x >> 6), nwv = gridDim.y * (blockDim.x >> 6);
+    const int N1 = d1 * nk, N2 = d2 * nk;
+    const int t1r = (N1 + 15) >> 4, t1c = (n1 + 15) >> 4, t2r = (N2 + 15) >> 4, t2c = (n2 + 15) >> 4;
+    for (int t = wv; t < t1r * t1c + t2r * t2c; t += nwv) {
+        const bool second = t >= t1r * t1c;
+        const int tt = second ? t - t1r * t1c : t;
+        const int tr = second ? t2r : t1r;
+        const int r0 = 16 * (tt % tr), c0 = 16 * (tt / tr);
+        v4d_t cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+        if (!second) {
+            ztile_mm(r1, r0 + l15, c0 + l15,
+                     [&](int nn, int a2) {
+                         if (nn >= N1 || a2 >= r1) return cmake<double>(0, 0);
+                         const int s1p = nn % d1, u = nn / d1, pu = perm[u];
+                         const double su = sig[pu];
+                         if (!(su > 0)) return cmake<double>(0, 0);
+                         const cx<T> l = wide ? tv[(a2 + r1 * s1p) + (size_t)Mr * pu] : th[(a2 + r1 * s1p) + (size_t)Mr * pu];
+                         const double f = fa1[a2] * (wide ? sqrt(su) : 1.0 / sqrt(su));              // L = U sqrt(S)
+                         return cmake<double>(l.re * f, l.im * f);
+                     },
+                     [&](int a2, int kk) { return (kk < n1 && a2 < r1) ? V1[kk + (size_t)n1 * it.idx1[a2]] : cmake<double>(0, 0); }, cr, ci);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = r0 + kq + 4 * r, kk = c0 + l15;
+                if (nn < N1 && kk < n1) X1[kk + (size_t)n1 * nn] = cmake<T>((T)cr[r], (T)ci[r]);
+            }
+        } else {
+            ztile_mm(r2, r0 + l15, c0 + l15,
+                     [&](int nn, int c2) {
+                         if (nn >= N2 || c2 >= r2) return cmake<double>(0, 0);
+                         const int s2p = nn % d2, u = nn / d2, pu = perm[u];
+                         const double su = sig[pu];
+                         if (wide && !(su > 0)) return cmake<double>(0, 0);
+                         const cx<T> v = wide ? th[(c2 + r2 * s2p) + (size_t)Nc * pu] : tv[(c2 + r2 * s2p) + (size_t)Nc * pu];
+                         const double f = fa2[c2] * (wide ? 1.0 / sqrt(su) : sqrt(su));              // R = sqrt(S) V^dagger
+                         return cmake<double>(v.re * f, -v.im * f);
+                     },
+                     [&](int c2, int kk) { return (kk < n2 && c2 < r2) ? V2[kk + (size_t)n2 * it.idx2[c2]] : cmake<double>(0, 0); }, cr, ci);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = r0 + kq + 4 * r, kk = c0 + l15;
+                if (nn < N2 && kk < n2) X2[kk + (size_t)n2 * nn] = cmake<T>((T)cr[r], (T)ci[r]);
             }
         }
-        double f = wide ? (su > 0 ? 1.0 / sqrt(su) : 0.0) : sqrt(su);    // R = sqrt(S) V^dagger
-        X2[e] = cmake<T>((T)(acc.re * f), (T)(acc.im * f));
     }
 }
 template <class T> void launch_gate_finish(hipStream_t s, const GateItem* d_items, int nitems) {
