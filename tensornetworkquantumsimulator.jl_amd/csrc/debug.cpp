@@ -223,7 +223,7 @@ static void dbg_bench_plane16(int which, int nsites, int lx, int ly, int reps, d
         HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1)); HIPCHK(hipEventElapsedTime(&t, e0, e1));
     } else {
         std::vector<PairGram2x16Item> items(nsites);
-        int spw = 2; while (spw < 128 && tot / (2 * spw) >= 2048.0) spw *= 2;
+        int spw = pair_gram2x16_slices_at_a_time(); while (spw < 128 && tot / (2 * spw) >= 2048.0) spw *= 2;
         int wgs = 0; const int nwg = (g.nslices() + spw - 1) / spw;
         DBuf dP((size_t)2 * nsites * nwg * 256 * 8);
         for (int i = 0; i < nsites; ++i) {

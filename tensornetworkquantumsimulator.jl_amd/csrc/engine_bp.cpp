@@ -571,7 +571,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 for (int q : g16_single) { g16[q].X = chains[g16_chain[q].first].result; is_shared[g16_chain[q].first] = 1; }
                 if (!g16.empty()) {
                     double tot = 0; for (auto& it : g16) tot += it.g.nslices();
-                    int spw = 2; while (spw < 128 && tot / (2 * spw) >= 2048.0) spw *= 2;       // a multiple of 2: 4 waves = 2 slices x 2 halves
+                    int spw = pair_gram2x16_slices_at_a_time(); while (spw < 128 && tot / (2 * spw) >= 2048.0) spw *= 2;       // a multiple of the slices a workgroup walks at a time (waves / 2: half slices)
                     int wgs = 0; double by = 0, fl = 0;
                     for (size_t q = 0; q < g16.size(); ++q) {
                         PairGram2x16Item& it = g16[q]; GramJob& jy = jobs[g16_chain[q].first];

@@ -296,6 +296,7 @@ struct PairGram2x16Item { const void* X; const void* Y; const void* Mx; const vo
 // wave owning whole lines (the 16 companions are 16 consecutive elements); a launch holds items of one kind
 bool pair16_whole_lines(const PlaneGeom& g);
 void launch_mfma_pair16(hipStream_t s, const Pair16Item* d_items, int nitems, int total_wgs, bool whole_lines);
+int pair_gram2x16_slices_at_a_time();
 void launch_mfma_pair_gram2x16(hipStream_t s, const PairGram2x16Item* d_items, int nitems, int total_wgs);
 
 // ---- MFMA fast paths (ComplexF32 only; kernels_mfma.hip) -----------------------------------------------------------

@@ -289,14 +289,19 @@ void launch_mfma_pair16(hipStream_t s, const Pair16Item* d_items, int nitems, in
 // BOTH messages a site sends into a linear forest, from one pass over the shared partial product X and psi = Y (16 x 16 planes):
 //      out_y[b,b'] = sum_{c,jx} ( sum_ix X[c,ix,b] Mx[ix,jx] ) conj Y[c,jx,b']      (kept leg y, leg x absorbed)
 //      out_x[d,d'] = sum_{c,jy} ( sum_iy X[c,d,iy] My[iy,jy] ) conj Y[c,d',jy]      (kept leg x, leg y absorbed)
-// 32 flop/B: co-bound.  A workgroup has 4 waves (one per SIMD); a wave keeps the X and Y planes of its 8 companions resident together
-// (2 x 18 KiB), prefetches the next unit into registers and accumulates both 16 x 16 messages in 16 registers.
+// 32 flop/B: co-bound.  Both 16 x 16 messages are accumulated in registers over the workgroup's slices.
 // ------------------------------------------------------------------------------------------------------------
+// Eight waves per workgroup, two per SIMD.  A wave moves half slices (8 companions, 64-byte runs) through its registers but keeps only FOUR
+// companions' planes resident (18 KiB): commit companions 0..3 (the lanes that hold them) -> matrix work -> commit 4..7 -> prefetch the next
+// half slice -> matrix work.  The matrix phase of one wave runs under the memory phases of the other wave of its SIMD: 1.61 - 1.87 ms per
+// 12 sites against 1.97 - 2.15 with four waves of 8 resident companions (one per SIMD), which was matrix-core bound in practice: 1.78 ms
+// even without its global loads.
 template <bool M3>          // M3: three-multiplication complex products, 48 instead of 64 matrix instructions per companion (both messages)
-__global__ __launch_bounds__(256) void mfma_pair_gram2x16_kernel(const PairGram2x16Item* __restrict__ items, int nitems) {
+__global__ __launch_bounds__(512) void mfma_pair_gram2x16_kernel(const PairGram2x16Item* __restrict__ items, int nitems) {
+    constexpr int NW = 8, NC = 4;                                        // waves per workgroup, companions resident per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, g4 = lane >> 4;
-    v2f* const L = reinterpret_cast<v2f*>(smem) + w * (16 * PS16);       // planes 0..7: X of companions 0..7, planes 8..15: Y
+    v2f* const L = reinterpret_cast<v2f*>(smem) + w * (2 * NC * PS16);   // planes 0..NC-1: X of the resident companions, planes NC..2NC-1: Y
     int lo = 0, hi_ = nitems - 1;
     const int gw = blockIdx.x;
     while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].wg_begin <= gw) lo = mid; else hi_ = mid - 1; }
@@ -322,37 +327,37 @@ __global__ __launch_bounds__(256) void mfma_pair_gram2x16_kernel(const PairGram2
     v4f O1r = {0.f, 0.f, 0.f, 0.f}, O1i = O1r, O2r = O1r, O2i = O1r, O1c = O1r, O2c = O1r;
     const int f = lane & 3, ix0 = lane >> 2, half = w & 1;
     const long long toff = (long long)(4 * half + f) * g.cstr + g.sx * ix0;
-    v2f* const lbase = L + (2 * f) * PS16 + ix0;
+    v2f* const lbase = L + (2 * (f & 1)) * PS16 + ix0;
     v4f px[16], py[16];
     auto issue = [&](int sl) {
         const long long b = plane_slice_base(g, sl) + toff;
 #pragma unroll
         for (int j = 0; j < 16; ++j) { px[j] = ldg4(Xg + b + g.sy * j); py[j] = ldg4(Yg + b + g.sy * j); }
     };
-    auto commit = [&]() {
+    auto commit = [&](int sub) {                        // the lanes whose companion pair belongs to the group `sub` of four
+        if ((f >> 1) != sub) return;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             v2f a = {px[j][0], px[j][1]}, b = {px[j][2], px[j][3]}, c = {py[j][0], py[j][1]}, d = {py[j][2], py[j][3]};
-            lbase[P16 * j] = a; lbase[P16 * j + PS16] = b; lbase[P16 * j + 8 * PS16] = c; lbase[P16 * j + 9 * PS16] = d;
+            lbase[P16 * j] = a; lbase[P16 * j + PS16] = b; lbase[P16 * j + NC * PS16] = c; lbase[P16 * j + (NC + 1) * PS16] = d;
         }
     };
-    // waves (0, 1) and (2, 3) take the two halves of slices s0, s0 + 2, ... / s0 + 1, s0 + 3, ...
+    // waves (2 m, 2 m + 1) take the two halves of slices s0 + m, s0 + m + 4, ...  (m = 0..3)
     // (the loop is instantiated for both / one message: a wave-uniform branch inside it would split the companion loop into basic blocks and
     // keep the scheduler from overlapping one companion's LDS reads with the previous one's matrix instructions)
     auto run = [&](auto both_c) {
     constexpr bool BOTH = decltype(both_c)::value;
     int sl = s_begin + (w >> 1);
     if (sl < s_end) issue(sl);
-    for (; sl < s_end; sl += 2) {
-        commit();
+    for (; sl < s_end; sl += NW / 2) {
+        commit(0);
         __builtin_amdgcn_wave_barrier();
-        if (sl + 2 < s_end) issue(sl + 2);
         // the companion loop, software pipelined: the operands of companion c + 1 are read from LDS before the matrix work of companion c, and the
         // two messages' products advance together (first products of both, then the second ones), so that the LDS latency and the result
         // latency of the first products are covered by the other chain's instructions -- a wave has its SIMD to itself here
         struct Ops { v4f x01, x23, y01, y23; v2f xt[4], yt[4]; };
         auto load_ops = [&](int c, Ops& o) {
-            const v2f* const PX = L + c * PS16; const v2f* const PY = L + (8 + c) * PS16;
+            const v2f* const PX = L + c * PS16; const v2f* const PY = L + (NC + c) * PS16;
             o.x01 = *reinterpret_cast<const v4f*>(PX + c16 * P16 + 4 * g4);                  // B[k = ix = 4 g + t][j = b = iy = c16]
             o.x23 = *reinterpret_cast<const v4f*>(PX + c16 * P16 + 4 * g4 + 2);
             o.y01 = *reinterpret_cast<const v4f*>(PY + c16 * P16 + 4 * g4);                  // B[k = jx = 4 g + r][j = b' = iy = c16]
@@ -423,17 +428,23 @@ __global__ __launch_bounds__(256) void mfma_pair_gram2x16_kernel(const PairGram2
                 }
             }
         };
-        {
+        auto resident = [&]() {
             Ops oa, ob;
             load_ops(0, oa);
 #pragma unroll
-            for (int c = 0; c < 8; c += 2) {
+            for (int c = 0; c < NC; c += 2) {
                 load_ops(c + 1, ob);
                 compute(oa);
-                if (c + 2 < 8) load_ops(c + 2, oa);
+                if (c + 2 < NC) load_ops(c + 2, oa);
                 compute(ob);
             }
-        }
+        };
+        resident();
+        __builtin_amdgcn_wave_barrier();                 // companions 0..3 consumed
+        commit(1);
+        __builtin_amdgcn_wave_barrier();
+        if (sl + 4 < s_end) issue(sl + 4);               // every lane's registers are free now
+        resident();
         __builtin_amdgcn_wave_barrier();                 // the planes have been consumed: the next commit may overwrite them
     }
     };
@@ -443,27 +454,29 @@ __global__ __launch_bounds__(256) void mfma_pair_gram2x16_kernel(const PairGram2
     cf* __restrict__ p2 = reinterpret_cast<cf*>(it.partial_x) + (size_t)lw * 256;
     if (M3) { const v4f a1 = O1r, a2 = O2r; O1r = a1 - O1i; O1i = a1 - O1c; O2r = a2 - O2i; O2i = a2 - O2c; }
     __syncthreads();                                     // every wave is done with its slab
-    v2f* const R = reinterpret_cast<v2f*>(smem);        // [message 2][wave 4][16 x 17]
+    v2f* const R = reinterpret_cast<v2f*>(smem);        // [message 2][wave NW][16 x 17]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = 4 * g4 + r;                        // element (i, j = c16)
         v2f a = {O1r[r], O1i[r]}, b = {O2r[r], O2i[r]};
-        R[(0 * 4 + w) * 272 + c16 * 17 + i] = a; R[(1 * 4 + w) * 272 + c16 * 17 + i] = b;
+        R[(0 * NW + w) * 272 + c16 * 17 + i] = a; R[(1 * NW + w) * 272 + c16 * 17 + i] = b;
     }
     __syncthreads();
-    for (int e = tid; e < 512; e += 256) {
+    for (int e = tid; e < 512; e += 64 * NW) {
         const int msg = e >> 8, q = e & 255, i = q & 15, j = q >> 4;
         float sr = 0.f, si = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) { const v2f v = R[(msg * 4 + ww) * 272 + j * 17 + i]; sr += v[0]; si += v[1]; }
+        for (int ww = 0; ww < NW; ++ww) { const v2f v = R[(msg * NW + ww) * 272 + j * 17 + i]; sr += v[0]; si += v[1]; }
         cf o; o.re = sr; o.im = si; if (msg == 0) p1[q] = o; else if (both) p2[q] = o;
     }
 }
+// slices a workgroup walks at a time (eight waves x half slices): PairGram2x16Item::spw must be a multiple
+int pair_gram2x16_slices_at_a_time() { return 4; }
 void launch_mfma_pair_gram2x16(hipStream_t s, const PairGram2x16Item* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
-    const size_t lds = (size_t)4 * 16 * PS16 * sizeof(v2f);
-    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_pair_gram2x16_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair_gram2x16_kernel<true>, dim3(total_wgs), dim3(256), lds, s, d_items, nitems); }
-    else { set_max_dynamic_lds((const void*)mfma_pair_gram2x16_kernel<false>, lds); hipLaunchKernelGGL(mfma_pair_gram2x16_kernel<false>, dim3(total_wgs), dim3(256), lds, s, d_items, nitems); }
+    const size_t lds = (size_t)8 * 8 * PS16 * sizeof(v2f);
+    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_pair_gram2x16_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair_gram2x16_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    else { set_max_dynamic_lds((const void*)mfma_pair_gram2x16_kernel<false>, lds); hipLaunchKernelGGL(mfma_pair_gram2x16_kernel<false>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
     TNQS_CHECK_LAUNCH();
 }
 
