@@ -764,20 +764,29 @@ void launch_small_svd_finish(hipStream_t s, const SmallSvdItem* d_items, int nit
 // Right-looking, ONE workgroup barrier per column: the trailing update of step k works from the UNSCALED column k,
 //   A[i][j] -= A[i][k] conj(A[j][k]) / A[k][k]     (columns j > k; column k itself is never written again),
 // every thread derives the pivot from A[k][k] by the same rule, and the scaling L[i][k] = A[i][k] / sqrt(A[k][k]) happens for all columns
-// at once at the end.  (The first version scaled the column between two extra barriers per step, paid two integer divisions per updated
-// element and inverted L with one serial thread per column: 214 us per launch on a 64 x 64 matrix, the second largest latency item of a
-// colour batch.)  The inverse triangle is built by FOUR lanes per column (adjacent lanes of one wave: partial sums meet through DPP-free
-// shuffles, no barrier): column c of L^-1 only depends on L and on its own earlier entries.
+// at once at the end.  With Lt = unit lower triangular, Lt[i][k] = A[i][k] / A[k][k], this is G = Lt D Lt^dagger, L = Lt D^1/2.
+// The INVERSE rides along in the same steps (round 3): M = Lt^-1 is what the same row operations make of the identity,
+//   M[i][c] -= Lt[i][k] M[k][c]     (rows i > k, columns c <= k, M[k][k] = 1),
+// kept in the free strict upper triangle (M[i][c] at A[c + np i]); L^-1 = D^-1/2 M.  No separate substitution phase, no extra barrier.
+// Within a step every element update is independent: a thread takes elements e = tid + 256 u of the trailing triangle (row-major
+// triangular numbering, which is NESTED: the first m (m + 1) / 2 numbers are the triangle of size m, so a thread's (row, column) pairs
+// are decoded once for the whole factorisation) and of the (rows > k) x (columns <= k) rectangle, eight at a time with all their LDS
+// loads issued before the first store -- the column step is then one LDS round trip deep instead of one per element.
+// (History: a first version scaled the column between two extra barriers per step and inverted L with one serial thread per column:
+// 214 us per launch on a 64 x 64 matrix; the one-barrier version with a per-thread loop over columns and a 4-lane substitution for the
+// inverse: 122 us = 10 load + 64 column loop (1 us per column, a chain of LDS latencies) + 45 inverse.)
 __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_dmax;
     const CholItem it = items[blockIdx.x];
     const int n = it.n, np = n + 1, tid = threadIdx.x;
-    cx<double>* A = reinterpret_cast<cx<double>*>(smem);          // [col j][row i] at i + np*j, lower triangle becomes L
+    cx<double>* A = reinterpret_cast<cx<double>*>(smem);          // [col j][row i] at i + np*j, lower triangle becomes L (unscaled), strict upper M
     const cx<double>* G = reinterpret_cast<const cx<double>*>(it.G);
-    for (int e = tid; e < n * n; e += 256) {                       // Hermitian part, as the eigen path sees it
-        int i = e % n, j = e / n; cx<double> a = G[i + (size_t)n * j], b = G[j + (size_t)n * i];
-        A[i + np * j] = cmake<double>(0.5 * (a.re + b.re), 0.5 * (a.im - b.im));
+    for (int e = tid; e < n * n; e += 256) {                       // Hermitian part, as the eigen path sees it; zeros above the diagonal
+        int i = e % n, j = e / n;
+        cx<double> v = cmake<double>(0, 0);
+        if (i >= j) { cx<double> a = G[i + (size_t)n * j], b = G[j + (size_t)n * i]; v = cmake<double>(0.5 * (a.re + b.re), 0.5 * (a.im - b.im)); }
+        A[i + np * j] = v;
     }
     __syncthreads();
     if (tid < 64) {                                                // largest diagonal entry (one wave)
@@ -790,69 +799,92 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
     const double tiny = it.tau * s_dmax;
     // the pivot rule: a pivot at or below tiny (or not a number) flags the item and is replaced, so that the factorisation completes
     auto pivot_of = [&](int k, bool& bad) { double d = A[k + np * k].re; bad = !(d > tiny); return bad ? (tiny > 0 ? tiny : 1.0) : d; };
-    const int ti = tid & 63, tj = tid >> 6;
+    // this thread's elements of the trailing triangle: number e = r (r + 1) / 2 + c, 0 <= c <= r  (n <= 96: at most 4560 / 256 -> 18)
+    constexpr int UT = 18;
+    unsigned char tr[UT], tc[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        const int e = tid + 256 * u;
+        int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (r * (r + 1) / 2 > e) --r;
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        tr[u] = (unsigned char)r; tc[u] = (unsigned char)(e - r * (r + 1) / 2);
+    }
+    const bool wantW = it.Winv != nullptr;
     for (int k = 0; k < n; ++k) {
         bool bad; const double d = pivot_of(k, bad);
         if (bad && tid == 0) *it.fail = 1;
         const double dinv = 1.0 / d;
-        for (int i = k + 1 + ti; i < n; i += 64) {
-            const cx<double> li = A[i + np * k];
-            const cx<double> ls = cmake<double>(li.re * dinv, li.im * dinv);
-            int j = k + 1 + tj;
-            for (; j <= i; j += 4) {
-                const cx<double> lj = A[j + np * k];
-                cx<double> v = A[i + np * j];
-                v.re -= ls.re * lj.re + ls.im * lj.im; v.im -= ls.im * lj.re - ls.re * lj.im;
-                A[i + np * j] = v;
+        const int m = n - k - 1, k1 = k + 1;
+        const cx<double>* colk = A + np * k;                       // colk[i] = A[i][k]
+        // ---- trailing triangle: A[i][j] -= (A[i][k] / d) conj(A[j][k]),  i = k1 + r,  j = k1 + c ----------------------------------------
+        const int nt = m * (m + 1) / 2;
+#pragma unroll
+        for (int u0 = 0; u0 < UT; u0 += 6) {
+            if (256 * u0 >= nt) break;                              // (workgroup-uniform)
+            cx<double> li[6], lj[6], v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const bool on = tid + 256 * (u0 + u) < nt;
+                const int i = k1 + tr[u0 + u], j = k1 + tc[u0 + u];
+                if (on) { li[u] = colk[i]; lj[u] = colk[j]; v[u] = A[i + np * j]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const bool on = tid + 256 * (u0 + u) < nt;
+                if (on) {
+                    const double sr = li[u].re * dinv, si = li[u].im * dinv;
+                    v[u].re -= sr * lj[u].re + si * lj[u].im; v[u].im -= si * lj[u].re - sr * lj[u].im;
+                    A[(k1 + tr[u0 + u]) + np * (k1 + tc[u0 + u])] = v[u];
+                }
+            }
+        }
+        // ---- inverse: M[i][c] -= (A[i][k] / d) M[k][c],  i = k1 + ri,  c <= k;  M[i][c] at A[c + np i], M[k][k] = 1 ------------------------
+        if (wantW) {
+            const int nr = m * k1;
+            const float rk1 = 1.0f / (float)k1;
+            for (int q0 = 0; q0 < nr; q0 += 256 * 6) {
+                cx<double> li[6], mk[6], v[6]; int ii[6], cc[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int q = q0 + tid + 256 * u;
+                    int ri = (int)((float)q * rk1); if (ri * k1 > q) --ri; if ((ri + 1) * k1 <= q) ++ri;
+                    ii[u] = k1 + ri; cc[u] = q - ri * k1;
+                    if (q < nr) {
+                        li[u] = colk[ii[u]];
+                        mk[u] = cc[u] == k ? cmake<double>(1.0, 0.0) : A[cc[u] + np * k];
+                        v[u] = A[cc[u] + np * ii[u]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int q = q0 + tid + 256 * u;
+                    if (q < nr) {
+                        const double sr = li[u].re * dinv, si = li[u].im * dinv;
+                        v[u].re -= sr * mk[u].re - si * mk[u].im; v[u].im -= sr * mk[u].im + si * mk[u].re;
+                        A[cc[u] + np * ii[u]] = v[u];
+                    }
+                }
             }
         }
         __syncthreads();
     }
-    // L[i][k] = A[i][k] / sqrt(pivot_k), L[k][k] = sqrt(pivot_k): all columns at once (the pivots are taken before any diagonal entry changes)
+    // L[i][k] = A[i][k] / sqrt(pivot_k), L[k][k] = sqrt(pivot_k);  W = (L^-1)^dagger: W[i + n a] = conj(M[a][i]) / sqrt(pivot_a) above the diagonal
     __shared__ double s_piv[96];
     for (int k = tid; k < n; k += 256) { bool bad; s_piv[k] = sqrt(pivot_of(k, bad)); }
     __syncthreads();
     cx<double>* L = reinterpret_cast<cx<double>*>(it.L);
+    cx<double>* W = reinterpret_cast<cx<double>*>(it.Winv);
     for (int e = tid; e < n * n; e += 256) {
         const int i = e % n, k = e / n;
-        cx<double> l = cmake<double>(0, 0);
-        if (i == k) l = cmake<double>(s_piv[k], 0.0);
-        else if (i > k) { const cx<double> v = A[i + np * k]; const double r = 1.0 / s_piv[k]; l = cmake<double>(v.re * r, v.im * r); }
-        if (i >= k) A[i + np * k] = l;
+        const cx<double> a = A[i + np * k];
+        const double r = 1.0 / s_piv[k];
+        cx<double> l = cmake<double>(0, 0), w = cmake<double>(0, 0);
+        if (i == k) { l = cmake<double>(s_piv[k], 0.0); w = cmake<double>(r, 0.0); }
+        else if (i > k) l = cmake<double>(a.re * r, a.im * r);
+        else w = cmake<double>(a.re * r, -a.im * r);
         L[e] = l;
-    }
-    __syncthreads();
-    cx<double>* W = reinterpret_cast<cx<double>*>(it.Winv);
-    if (!W) return;
-    // column c of L^-1 by forward substitution, four adjacent lanes per column (j-sum split four ways); conj(Linv[i, c]) (i > c) goes to the
-    // free strict upper triangle A[c + np*i]
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int c = c0 + (tid >> 2), part = tid & 3;
-        const bool on = c < n;
-        const double dc = on ? 1.0 / A[c + np * c].re : 0.0;
-        for (int i = c0 + 1; i < n; ++i) {                         // wave-uniform trip count; lanes whose column has not started yet (i <= c) idle
-            double sr = 0, si = 0;
-            if (on && i > c) {
-                for (int j = c + 1 + part; j < i; j += 4) {
-                    cx<double> lj = A[i + np * j], x = A[c + np * j]; x.im = -x.im;      // stored conjugated
-                    sr += lj.re * x.re - lj.im * x.im; si += lj.re * x.im + lj.im * x.re;
-                }
-            }
-            sr += __shfl_xor(sr, 1, 64); si += __shfl_xor(si, 1, 64);
-            sr += __shfl_xor(sr, 2, 64); si += __shfl_xor(si, 2, 64);
-            if (on && i > c && part == 0) {
-                const cx<double> l = A[i + np * c];
-                const double inv = 1.0 / A[i + np * i].re;
-                A[c + np * i] = cmake<double>(-(l.re * dc + sr) * inv, (l.im * dc + si) * inv);
-            }
-            __builtin_amdgcn_wave_barrier();                      // the four lanes of a column read what lane 0 just wrote (same wave: LDS is in order)
-        }
-    }
-    __syncthreads();
-    // W = (L^-1)^dagger (upper triangular): W[i + n*a] = conj(Linv[a, i])
-    for (int e = tid; e < n * n; e += 256) {
-        int i = e % n, a = e / n;
-        W[e] = (i < a) ? A[i + np * a] : (i == a ? cmake<double>(1.0 / A[i + np * i].re, 0.0) : cmake<double>(0, 0));
+        if (W) W[e] = w;
     }
 }
 // Same factorisation with the lower triangle PACKED in LDS (column j holds rows j..n-1): n up to 128 fits (132 KB), which the low-rank theta

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512) void mfma_pair16_kernel(const Pair16Item* __re
 // against 50 ms of memory time on the 3 x 3 x 3 torus), so one wave per SIMD is enough to cover the compute phase with the prefetch.
 // ------------------------------------------------------------------------------------------------------------
 template <bool M3>
-__global__ __launch_bounds__(256) void mfma_pair16w_kernel(const Pair16Item* __restrict__ items, int nitems, int rot_mul) {
+__global__ __launch_bounds__(256) void mfma_pair16w_kernel(const Pair16Item* __restrict__ items, int nitems) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, g4 = lane >> 4;
     v2f* const L = reinterpret_cast<v2f*>(smem) + w * (16 * PS16);
@@ -203,20 +203,12 @@ __global__ __launch_bounds__(256) void mfma_pair16w_kernel(const Pair16Item* __r
                 lbase[P16 * j + 8 * h] = a; lbase[P16 * j + 8 * h + PS16] = b;
             }
     };
-    // the workgroup walks its slices in groups of four, starting at a group that depends on the workgroup id (and wrapping): workgroups
-    // that run at the same time then sit at different offsets inside their 4 - 8 KiB windows instead of all asking the same HBM channels
-    const int nb = (s_end - s_begin + 3) >> 2;
-    const int rot = (rot_mul && nb > 0) ? (int)(((long long)(gw - it.wg_begin) * rot_mul) % nb) : 0;
-    auto slice_of = [&](int b) { int q = b + rot; if (q >= nb) q -= nb; return s_begin + 4 * q + w; };
-    int sl = slice_of(0);
+    int sl = s_begin + w;
     if (sl < s_end) issue(sl);
-    for (int b = 0; b < nb; ++b) {
-        sl = slice_of(b);
-        const int sn = b + 1 < nb ? slice_of(b + 1) : s_end;
-        if (sl >= s_end) { if (sn < s_end) issue(sn); continue; }     // (ragged last group: this wave has no slice in it)
+    for (; sl < s_end; sl += 4) {
         commit();
         __builtin_amdgcn_wave_barrier();                 // LDS is in order per wave; only the compiler must not reorder
-        if (sn < s_end) issue(sn);
+        if (sl + 4 < s_end) issue(sl + 4);
 #pragma unroll 2
         for (int c = 0; c < 16; ++c) {
             v2f* const P = L + c * PS16;
@@ -281,9 +273,8 @@ bool pair16_whole_lines(const PlaneGeom& g) { static const bool off = [] { const
 void launch_mfma_pair16(hipStream_t s, const Pair16Item* d_items, int nitems, int total_wgs, bool whole_lines) {
     if (total_wgs > 0 && whole_lines) {
         const size_t lds = (size_t)4 * 16 * PS16 * sizeof(v2f);
-        static const int rot_mul = [] { const char* e = std::getenv("TNQS_PAIR16_ROT"); return e ? atoi(e) : 0; }();
-        if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_pair16w_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair16w_kernel<true>, dim3(total_wgs), dim3(256), lds, s, d_items, nitems, rot_mul); }
-        else { set_max_dynamic_lds((const void*)mfma_pair16w_kernel<false>, lds); hipLaunchKernelGGL(mfma_pair16w_kernel<false>, dim3(total_wgs), dim3(256), lds, s, d_items, nitems, rot_mul); }
+        if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_pair16w_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair16w_kernel<true>, dim3(total_wgs), dim3(256), lds, s, d_items, nitems); }
+        else { set_max_dynamic_lds((const void*)mfma_pair16w_kernel<false>, lds); hipLaunchKernelGGL(mfma_pair16w_kernel<false>, dim3(total_wgs), dim3(256), lds, s, d_items, nitems); }
         TNQS_CHECK_LAUNCH();
         return;
     }
