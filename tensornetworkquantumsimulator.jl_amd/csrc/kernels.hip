@@ -775,14 +775,15 @@ void launch_small_svd_finish(hipStream_t s, const SmallSvdItem* d_items, int nit
 // (History: a first version scaled the column between two extra barriers per step and inverted L with one serial thread per column:
 // 214 us per launch on a 64 x 64 matrix; the one-barrier version with a per-thread loop over columns and a 4-lane substitution for the
 // inverse: 122 us = 10 load + 64 column loop (1 us per column, a chain of LDS latencies) + 45 inverse.)
-__global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ items) {
+__global__ __launch_bounds__(1024) void chol_kernel(const CholItem* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_dmax;
     const CholItem it = items[blockIdx.x];
+    constexpr int NT = 1024;                                         // sixteen waves: the other waves of a SIMD cover a wave's LDS round trips
     const int n = it.n, np = n + 1, tid = threadIdx.x;
     cx<double>* A = reinterpret_cast<cx<double>*>(smem);          // [col j][row i] at i + np*j, lower triangle becomes L (unscaled), strict upper M
     const cx<double>* G = reinterpret_cast<const cx<double>*>(it.G);
-    for (int e = tid; e < n * n; e += 256) {                       // Hermitian part, as the eigen path sees it; zeros above the diagonal
+    for (int e = tid; e < n * n; e += NT) {                       // Hermitian part, as the eigen path sees it; zeros above the diagonal
         int i = e % n, j = e / n;
         cx<double> v = cmake<double>(0, 0);
         if (i >= j) { cx<double> a = G[i + (size_t)n * j], b = G[j + (size_t)n * i]; v = cmake<double>(0.5 * (a.re + b.re), 0.5 * (a.im - b.im)); }
@@ -799,12 +800,12 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
     const double tiny = it.tau * s_dmax;
     // the pivot rule: a pivot at or below tiny (or not a number) flags the item and is replaced, so that the factorisation completes
     auto pivot_of = [&](int k, bool& bad) { double d = A[k + np * k].re; bad = !(d > tiny); return bad ? (tiny > 0 ? tiny : 1.0) : d; };
-    // this thread's elements of the trailing triangle: number e = r (r + 1) / 2 + c, 0 <= c <= r  (n <= 96: at most 4560 / 256 -> 18)
-    constexpr int UT = 18;
+    // this thread's elements of the trailing triangle: number e = r (r + 1) / 2 + c, 0 <= c <= r  (n <= 96: at most 4560 / 1024 -> 5)
+    constexpr int UT = 6;
     unsigned char tr[UT], tc[UT];
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
-        const int e = tid + 256 * u;
+        const int e = tid + NT * u;
         int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while (r * (r + 1) / 2 > e) --r;
         while ((r + 1) * (r + 2) / 2 <= e) ++r;
@@ -820,19 +821,16 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
         // ---- trailing triangle: A[i][j] -= (A[i][k] / d) conj(A[j][k]),  i = k1 + r,  j = k1 + c ----------------------------------------
         const int nt = m * (m + 1) / 2;
 #pragma unroll
-        for (int u0 = 0; u0 < UT; u0 += 6) {
-            if (256 * u0 >= nt) break;                              // (workgroup-uniform)
-            cx<double> li[6], lj[6], v[6];
+        for (int u0 = 0; u0 < UT; u0 += 3) {
+            if (NT * u0 >= nt) break;                               // (workgroup-uniform)
+            cx<double> li[3], lj[3], v[3];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const bool on = tid + 256 * (u0 + u) < nt;
-                const int i = k1 + tr[u0 + u], j = k1 + tc[u0 + u];
-                if (on) { li[u] = colk[i]; lj[u] = colk[j]; v[u] = A[i + np * j]; }
+            for (int u = 0; u < 3; ++u) {
+                if (u0 + u < UT && tid + NT * (u0 + u) < nt) { const int i = k1 + tr[u0 + u], j = k1 + tc[u0 + u]; li[u] = colk[i]; lj[u] = colk[j]; v[u] = A[i + np * j]; }
             }
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const bool on = tid + 256 * (u0 + u) < nt;
-                if (on) {
+            for (int u = 0; u < 3; ++u) {
+                if (u0 + u < UT && tid + NT * (u0 + u) < nt) {
                     const double sr = li[u].re * dinv, si = li[u].im * dinv;
                     v[u].re -= sr * lj[u].re + si * lj[u].im; v[u].im -= si * lj[u].re - sr * lj[u].im;
                     A[(k1 + tr[u0 + u]) + np * (k1 + tc[u0 + u])] = v[u];
@@ -843,11 +841,11 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
         if (wantW) {
             const int nr = m * k1;
             const float rk1 = 1.0f / (float)k1;
-            for (int q0 = 0; q0 < nr; q0 += 256 * 6) {
-                cx<double> li[6], mk[6], v[6]; int ii[6], cc[6];
+            for (int q0 = 0; q0 < nr; q0 += NT * 2) {
+                cx<double> li[2], mk[2], v[2]; int ii[2], cc[2];
 #pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    const int q = q0 + tid + 256 * u;
+                for (int u = 0; u < 2; ++u) {
+                    const int q = q0 + tid + NT * u;
                     int ri = (int)((float)q * rk1); if (ri * k1 > q) --ri; if ((ri + 1) * k1 <= q) ++ri;
                     ii[u] = k1 + ri; cc[u] = q - ri * k1;
                     if (q < nr) {
@@ -857,8 +855,8 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    const int q = q0 + tid + 256 * u;
+                for (int u = 0; u < 2; ++u) {
+                    const int q = q0 + tid + NT * u;
                     if (q < nr) {
                         const double sr = li[u].re * dinv, si = li[u].im * dinv;
                         v[u].re -= sr * mk[u].re - si * mk[u].im; v[u].im -= sr * mk[u].im + si * mk[u].re;
@@ -871,11 +869,11 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
     }
     // L[i][k] = A[i][k] / sqrt(pivot_k), L[k][k] = sqrt(pivot_k);  W = (L^-1)^dagger: W[i + n a] = conj(M[a][i]) / sqrt(pivot_a) above the diagonal
     __shared__ double s_piv[96];
-    for (int k = tid; k < n; k += 256) { bool bad; s_piv[k] = sqrt(pivot_of(k, bad)); }
+    for (int k = tid; k < n; k += NT) { bool bad; s_piv[k] = sqrt(pivot_of(k, bad)); }
     __syncthreads();
     cx<double>* L = reinterpret_cast<cx<double>*>(it.L);
     cx<double>* W = reinterpret_cast<cx<double>*>(it.Winv);
-    for (int e = tid; e < n * n; e += 256) {
+    for (int e = tid; e < n * n; e += NT) {
         const int i = e % n, k = e / n;
         const cx<double> a = A[i + np * k];
         const double r = 1.0 / s_piv[k];
@@ -890,23 +888,29 @@ __global__ __launch_bounds__(256) void chol_kernel(const CholItem* __restrict__ 
 // Same factorisation with the lower triangle PACKED in LDS (column j holds rows j..n-1): n up to 128 fits (132 KB), which the low-rank theta
 // route needs at chi = 64 (K = kappa chi = 128).  Only L is produced (CholItem::Winv is not written: the packed layout has no spare triangle
 // for the inverse: when CholItem::Winv is given, (L^-1)^dagger is built in place in global memory by a second phase).
-__global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __restrict__ items) {
+__global__ __launch_bounds__(1024) void chol_packed_kernel(const CholItem* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_dmax;
     const CholItem it = items[blockIdx.x];
+    constexpr int NT = 1024;                                         // sixteen waves: a thread's column loop is at most 8 long, and the other waves of its SIMD cover its LDS round trips
     const int n = it.n, tid = threadIdx.x;
     cx<double>* A = reinterpret_cast<cx<double>*>(smem);
     auto at = [n](int i, int j) { return (size_t)j * n - (size_t)j * (j - 1) / 2 + (i - j); };      // i >= j
     const cx<double>* G = reinterpret_cast<const cx<double>*>(it.G);
-    for (int e = tid; e < n * n; e += 256) {
+    for (int e = tid; e < n * n; e += NT) {
         int i = e % n, j = e / n; if (i < j) continue;
         cx<double> a = G[i + (size_t)n * j], b = G[j + (size_t)n * i];
         A[at(i, j)] = cmake<double>(0.5 * (a.re + b.re), 0.5 * (a.im - b.im));
     }
     __syncthreads();
-    if (tid == 0) { double m = 0; for (int i = 0; i < n; ++i) m = fmax(m, A[at(i, i)].re); s_dmax = m; }
+    if (tid < 64) {
+        double m = 0; for (int i = tid; i < n; i += 64) m = fmax(m, A[at(i, i)].re);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+        if (tid == 0) s_dmax = m;
+    }
     __syncthreads();
-    if (it.shift > 0) { for (int i = tid; i < n; i += 256) A[at(i, i)].re += it.shift * s_dmax; __syncthreads(); }
+    if (it.shift > 0) { for (int i = tid; i < n; i += NT) A[at(i, i)].re += it.shift * s_dmax; __syncthreads(); }
     const double tiny = it.tau * s_dmax;
     // right-looking with ONE barrier per column, as chol_kernel: trailing updates from the unscaled column, pivots by the same rule in every
     // thread, all columns scaled at the end
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __rest
             const cx<double> li = A[at(i, k)];
             const cx<double> ls = cmake<double>(li.re * dinv, li.im * dinv);
             int j = k + 1 + tj;
-            for (; j <= i; j += 4) {
+            for (; j <= i; j += NT / 64) {
                 const cx<double> lj = A[at(j, k)];
                 cx<double> v = A[at(i, j)];
                 v.re -= ls.re * lj.re + ls.im * lj.im; v.im -= ls.im * lj.re - ls.re * lj.im;
@@ -930,9 +934,9 @@ __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __rest
         __syncthreads();
     }
     __shared__ double s_pivs[128];
-    for (int k = tid; k < n; k += 256) { bool bad; s_pivs[k] = sqrt(pivot_of(k, bad)); }
+    for (int k = tid; k < n; k += NT) { bool bad; s_pivs[k] = sqrt(pivot_of(k, bad)); }
     __syncthreads();
-    for (int e = tid; e < n * n; e += 256) {
+    for (int e = tid; e < n * n; e += NT) {
         const int i = e % n, k = e / n;
         if (i < k) continue;
         if (i == k) A[at(k, k)] = cmake<double>(s_pivs[k], 0.0);
@@ -940,41 +944,43 @@ __global__ __launch_bounds__(256) void chol_packed_kernel(const CholItem* __rest
     }
     __syncthreads();
     cx<double>* L = reinterpret_cast<cx<double>*>(it.L);
-    for (int e = tid; e < n * n; e += 256) { int i = e % n, j = e / n; L[e] = (i >= j) ? A[at(i, j)] : cmake<double>(0, 0); }
+    for (int e = tid; e < n * n; e += NT) { int i = e % n, j = e / n; L[e] = (i >= j) ? A[at(i, j)] : cmake<double>(0, 0); }
     if (!it.Winv) return;
     // W = (L^-1)^dagger (upper triangular), W[c + n*i] = conj(Linv[i, c]).  L^-1 is built IN PLACE in the packed triangle, from the last column
     // to the first: column j of the inverse is  -Linv[j+1:, j+1:] L[j+1:, j] / L[j, j]  -- the trailing block is already inverted, column j still
-    // holds L.  Two threads per row i split the sum over k (one LDS read of Linv[i, k], consecutive in i, and one broadcast read of L[k, j] per
+    // holds L.  Eight threads per row i split the sum over k (one LDS read of Linv[i, k], consecutive in i, and one broadcast read of L[k, j] per
     // term); two barriers per column.  (Round 2 ran one thread per column of the inverse against global memory: 0.6 of the kernel's 0.78 ms
     // at n = 128.)  L itself has been written out above.
     __syncthreads();
     cx<double>* W = reinterpret_cast<cx<double>*>(it.Winv);
-    const int row = tid >> 1, half = tid & 1;
+    const int row = tid >> 3, half = tid & 7;                     // eight threads per row split the sum over k
     for (int j = n - 1; j >= 0; --j) {
         const double dj = 1.0 / A[at(j, j)].re;
         const int i = j + 1 + row;
         double ar = 0, ai = 0;
         if (i < n) {
             int k = j + 1 + half;
-            for (; k + 6 <= i; k += 8) {                         // four independent terms in flight
+            for (; k + 24 <= i; k += 32) {                       // four independent terms in flight
                 cx<double> x[4], l[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { x[u] = A[at(i, k + 2 * u)]; l[u] = A[at(k + 2 * u, j)]; }
+                for (int u = 0; u < 4; ++u) { x[u] = A[at(i, k + 8 * u)]; l[u] = A[at(k + 8 * u, j)]; }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { ar -= x[u].re * l[u].re - x[u].im * l[u].im; ai -= x[u].re * l[u].im + x[u].im * l[u].re; }
             }
-            for (; k <= i; k += 2) {
+            for (; k <= i; k += 8) {
                 const cx<double> x = A[at(i, k)], l = A[at(k, j)];
                 ar -= x.re * l.re - x.im * l.im; ai -= x.re * l.im + x.im * l.re;
             }
         }
         ar += __shfl_xor(ar, 1, 64); ai += __shfl_xor(ai, 1, 64);
+        ar += __shfl_xor(ar, 2, 64); ai += __shfl_xor(ai, 2, 64);
+        ar += __shfl_xor(ar, 4, 64); ai += __shfl_xor(ai, 4, 64);
         __syncthreads();                                   // column j has been read by everybody
         if (i < n && half == 0) A[at(i, j)] = cmake<double>(ar * dj, ai * dj);
         if (tid == 0) A[at(j, j)] = cmake<double>(dj, 0.0);
         __syncthreads();
     }
-    for (int e = tid; e < n * n; e += 256) {
+    for (int e = tid; e < n * n; e += NT) {
         const int c = e % n, i = e / n;
         cx<double> v = cmake<double>(0, 0);
         if (i >= c) { v = A[at(i, c)]; v.im = -v.im; }
@@ -985,13 +991,13 @@ void launch_chol_packed(hipStream_t s, const CholItem* d_items, int nitems, int 
     if (nitems <= 0) return;
     const size_t lds = (size_t)nmax * (nmax + 1) / 2 * 16;
     set_max_dynamic_lds((const void*)chol_packed_kernel, (size_t)(160 * 1024 - 2048));      // (+ ~1 KB of static LDS: pivots)
-    hipLaunchKernelGGL(chol_packed_kernel, dim3(nitems), dim3(256), lds, s, d_items); TNQS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(chol_packed_kernel, dim3(nitems), dim3(1024), lds, s, d_items); TNQS_CHECK_LAUNCH();
 }
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {
     if (nitems <= 0) return;
     const size_t lds = (size_t)nmax * (nmax + 1) * 16;
     set_max_dynamic_lds((const void*)chol_kernel, (size_t)(160 * 1024 - 1024));       // (the kernel also has ~0.8 KB of static LDS: pivots)
-    hipLaunchKernelGGL(chol_kernel, dim3(nitems), dim3(256), lds, s, d_items); TNQS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(chol_kernel, dim3(nitems), dim3(1024), lds, s, d_items); TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------
