@@ -130,6 +130,11 @@ def test_partial_products_kept_across_levels_change_nothing_but_the_pass_count()
     and the remembered route must actually save two-leg passes."""
     on, off = run_worker({}, "cubic16"), run_worker({"TNQS_NO_PRODCACHE": "1"}, "cubic16")
     assert 0 < on["pair"] < off["pair"], (on["pair"], off["pair"])
+    # a byte bound that holds three products of the 27 x 3 the sweep would keep: entries are evicted all the time (least recently used of all
+    # sites), reuse mostly misses -- and nothing but the pass count may change
+    tight = run_worker({"TNQS_BP_CACHE_MB": "800"}, "cubic16")
+    assert on["pair"] < tight["pair"] <= off["pair"], (on["pair"], tight["pair"], off["pair"])
+    assert tight["dims"] == off["dims"] and np.max(np.abs(np.array(tight["z"]) - np.array(off["z"]))) < 1e-5
     worst = 0.0
     for ma, mb in zip(on["msgs"], off["msgs"]):
         a = np.array(ma[0]) + 1j * np.array(ma[1]); b = np.array(mb[0]) + 1j * np.array(mb[1])
