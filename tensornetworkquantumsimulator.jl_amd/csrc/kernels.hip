@@ -1030,7 +1030,7 @@ template void launch_env_prepare<double>(hipStream_t, const EnvItem*, int);
 
 template <class T>
 __global__ __launch_bounds__(256) void env_finish_kernel(const EnvFinishItem* __restrict__ items) {
-    __shared__ double lam[256];
+    __shared__ double lam[256], sq[256];
     __shared__ int s_full, s_err;
     const EnvFinishItem it = items[blockIdx.x];
     const int n = it.n;
@@ -1042,12 +1042,14 @@ __global__ __launch_bounds__(256) void env_finish_kernel(const EnvFinishItem* __
         double l = 0;       // Rayleigh quotient v_j^dagger H v_j = Re(v_j^dagger a_j)
         for (int i = 0; i < n; ++i) { cx<double> v = V[i + n * j], a = A[i + n * j]; l += v.re * a.re + v.im * a.im; }
         lam[j] = l;
+        // (sq[j]: sqrt(lambda_j) of the eigenvalues that are kept, -1 for the dropped ones -- once per eigenvalue instead of once per term below)
         // the reference casts the eigenvalues back to the message precision BEFORE the cutoff test (safe_eigen, src/utils.jl:100-107, then
         // `abs(x) < cutoff` on the Float32 value, :21-22): an eigenvalue within an f32 ulp of the cutoff must land on the same side here
         const double lt = (double)(T)l;
         const bool zero = (lt == 0) || (fabs(lt) < it.cutoff);
         if (zero) s_full = 0;
         else if (lt < 0) s_err = 1;       // Julia: sqrt(negative) -> DomainError (src/utils.jl:21)
+        sq[j] = (zero || lt < 0) ? -1.0 : sqrt(l);
     }
     __syncthreads();
     cx<T>* ms = reinterpret_cast<cx<T>*>(it.msqrt);
@@ -1056,12 +1058,11 @@ __global__ __launch_bounds__(256) void env_finish_kernel(const EnvFinishItem* __
         int i = e % n, l = e / n;
         cx<double> s1 = cmake<double>(0, 0), s2 = cmake<double>(0, 0);
         for (int j = 0; j < n; ++j) {
-            double lj = lam[j];
-            { const double lt = (double)(T)lj; if ((lt == 0) || (fabs(lt) < it.cutoff) || lt < 0) continue; }
+            const double sj = sq[j];
+            if (sj < 0) continue;
             cx<double> vi = V[i + n * j], vl = V[l + n * j];
             cx<double> o = cmake<double>(vi.re * vl.re + vi.im * vl.im, vi.im * vl.re - vi.re * vl.im);  // vi conj(vl)
-            double sq = sqrt(lj);
-            s1.re += sq * o.re; s1.im += sq * o.im;
+            s1.re += sj * o.re; s1.im += sj * o.im;
             s2.re += o.re; s2.im += o.im;
         }
         ms[e] = cmake<T>((T)s1.re, (T)s1.im);
@@ -1432,7 +1433,7 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
     // grid (gate, part) as gate_theta_kernel: the ranking / truncation prologue is repeated per part, only part 0 writes its results
     const GateItem it = items[blockIdx.x];
     const int part = blockIdx.y, tid0 = part * blockDim.x + threadIdx.x, tstride = gridDim.y * blockDim.x;
-    const int r1 = it.info[0], r2 = it.info[1], d1 = it.d1, d2 = it.d2, chi = it.chi;
+    const int r1 = it.info[0], r2 = it.info[1], d1 = it.d1, d2 = it.d2;
     const int Mr = r1 * d1, Nc = r2 * d2;
     const bool wide = it.info[5] != 0;                                // theta stored as theta^dagger (Nc x Mr)
     const int ncol = wide ? Mr : Nc, ld = wide ? Nc : Mr;
