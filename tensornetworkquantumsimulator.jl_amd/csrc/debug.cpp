@@ -19,7 +19,7 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
     dA.up(A, (size_t)m * n * esz);
     if (dtype == TNQS_C64) launch_identity<float>(nullptr, dV.p, n); else launch_identity<double>(nullptr, dV.p, n);
     // same residency policy as the engine: A+V in LDS, else A in LDS with V recovered, else global memory
-    const size_t lim = 160 * 1024 - 256;
+    const size_t lim = 160 * 1024 - 2048;
     size_t lds_av = jacobi_lds_bytes(m, n, true, esz), lds_a = jacobi_lds_bytes(m, n, false, esz);
     const char* fg = std::getenv("TNQS_DBG_NOV_GLOBAL");      // the engine's combination for matrices beyond the LDS: global-memory kernel, V recovered
     const bool force_global_nov = fg && fg[0] == '1';

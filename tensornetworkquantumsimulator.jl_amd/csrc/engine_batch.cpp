@@ -165,7 +165,7 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
 //   * anything else: the global-memory kernel.
 template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, bool with_v) {
     const size_t esz = s->esz();
-    const size_t cap = 160 * 1024 - 256;
+    const size_t cap = 160 * 1024 - 2048;
     std::vector<JacobiItem> fit, tall, rest;
     static const bool force_global = [] { const char* e = std::getenv("TNQS_JACOBI_GLOBAL"); return e && e[0] == '1'; }();
     for (auto& j : all) {

@@ -67,7 +67,7 @@ TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64
 // TNQS_BP_CACHE_MB: bound on the partial products kept across BP levels (MiB, default 49152)
 inline size_t bp_cache_budget() { static const size_t v = [] { const char* e = std::getenv("TNQS_BP_CACHE_MB"); return (e ? (size_t)std::atoll(e) : (size_t)49152) << 20; }(); return v; }
 inline size_t bp_ws_budget() { static const size_t v = [] { const char* e = std::getenv("TNQS_BP_WS_MB"); return (e ? (size_t)std::atoll(e) : (size_t)24576) << 20; }(); return v; }
-inline size_t jacobi_lds(size_t bytes) { static const bool g = envflag("TNQS_JACOBI_GLOBAL"); return (g || bytes > 160 * 1024 - 256) ? 0 : bytes; }
+inline size_t jacobi_lds(size_t bytes) { static const bool g = envflag("TNQS_JACOBI_GLOBAL"); return (g || bytes > 160 * 1024 - 2048) ? 0 : bytes; }
 inline int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j : ji) m = std::max(m, std::max(j.m, j.n)); return m; }
 
 // optional host-side phase timing (TNQS_HOST_TIMING=1): printed when the process exits

@@ -590,6 +590,27 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     cx<T>* A = reinterpret_cast<cx<T>*>(smem);
     cx<T>* V = A + (size_t)mp * n;
     const bool hasV = Vg != nullptr;
+    // Without V the order of the columns is free (the caller ranks the singular values itself): they enter the sweeps sorted by decreasing
+    // norm (de Rijk), which the cyclic sweeps converge from in fewer passes than from an arbitrary order
+    __shared__ float s_cn[256]; __shared__ unsigned char s_pos[256];
+    const bool sorted = !hasV && n <= 256 && n > 2;
+    if (sorted) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        for (int j = w; j < n; j += nw) {
+            float s2 = 0.f;
+            for (int i = lane; i < m; i += 64) { const cx<T> v = Ag[i + (size_t)m * j]; s2 += (float)v.re * (float)v.re + (float)v.im * (float)v.im; }
+            s2 = wave_sum(s2);
+            if (lane == 0) s_cn[j] = s2 == s2 ? s2 : 0.f;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            int rk = 0; const float cj = s_cn[j];
+            for (int v = 0; v < n; ++v) rk += (s_cn[v] > cj) || (s_cn[v] == cj && v < j);
+            s_pos[j] = (unsigned char)rk;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < m * n; e += blockDim.x) A[(e % m) + mp * (int)s_pos[e / m]] = Ag[e];
+    } else
     for (int e = threadIdx.x; e < m * n; e += blockDim.x) A[(e % m) + mp * (e / m)] = Ag[e];
     if (hasV) for (int e = threadIdx.x; e < n * n; e += blockDim.x) V[(e % n) + np_ * (e / n)] = cmake<T>((e % n) == (e / n) ? (T)1 : (T)0, (T)0);
     __syncthreads();
@@ -688,7 +709,7 @@ template void launch_recover_v<double>(hipStream_t, const RecoverItem*, int, int
 // barriers: 1140 such matrices per colour batch).  The workgroup is sized for the columns the matrices are expected to have (`ncols`;
 // more columns than that still work: the slots loop).
 template <class T, int RQ> static void launch_jacobi_lds(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int ncols) {
-    set_max_dynamic_lds((const void*)jacobi_lds_kernel<T, RQ>, (size_t)(160 * 1024 - 256));
+    set_max_dynamic_lds((const void*)jacobi_lds_kernel<T, RQ>, (size_t)(160 * 1024 - 2048));
     int waves = (ncols + 7) / 8; waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
     hipLaunchKernelGGL((jacobi_lds_kernel<T, RQ>), dim3(nitems), dim3(64 * waves), lds_bytes, s, d_items, max_sweeps); TNQS_CHECK_LAUNCH();
 }
@@ -696,7 +717,7 @@ template <class T, int RQ> static void launch_jacobi_lds(hipStream_t s, const Ja
 template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax, int ncols) {
     if (nitems <= 0) return;
     if (ncols <= 0) ncols = mmax;
-    if (lds_bytes > 0 && lds_bytes <= 160 * 1024 - 256 && mmax <= 256) {
+    if (lds_bytes > 0 && lds_bytes <= 160 * 1024 - 2048 && mmax <= 256) {
         if (mmax <= 32) launch_jacobi_lds<T, 2>(s, d_items, nitems, max_sweeps, lds_bytes, ncols);
         else if (mmax <= 64) launch_jacobi_lds<T, 4>(s, d_items, nitems, max_sweeps, lds_bytes, ncols);
         else if (mmax <= 96) launch_jacobi_lds<T, 6>(s, d_items, nitems, max_sweeps, lds_bytes, ncols);
