@@ -299,6 +299,10 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
         }
     }
     ProdCache pcache;
+    {   // never more than a third of what the device has free right now (the products are an optimisation, the workspace is not)
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) pcache.cap = std::min(pcache.cap, (fr + s->pool->bytes_cached()) / 3);
+    }
     const bool cache_on = use_prodcache() && use_prefix() && !plan.in_place;
     const int nlev = (int)plan.levels.size();
     // levels until the message entering src through leg j changes again, seen from position t of the sequence (INT_MAX: never)
