@@ -19,6 +19,9 @@ int tnqs_dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No,
 int tnqs_dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma);
 /* c64 only: out[i + K*j] = sum ( X x_r M )[i,.] conj(Y[j,.]) with D = 1 and r = the first row leg (chi_r = 32, d = 2) */
 int tnqs_dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out);
+/* the gate path's fused gauge + f64 Gram kernels on one ComplexF32 site tensor [2, chi...] (column-major): out (complex128, KK x KK, KK = 2 chi_b)
+   = G[i + KK j] = sum X'[i, fibers] conj(X'[j, fibers]), X' = X x_r M rounded to f32, r = the lowest leg that is not bleg; chi_b = chi_r = 32 or 16 */
+int tnqs_dbg_gauge_gram(int z, const int* chi, int bleg, const void* X, const void* M, void* out);
 /* c64 only: out[c,jx,mid,jy,hi] = sum in[c,ix,mid,iy,hi] Mx[ix,jx] My[iy,jy]; element at c + C0*(ix + 32*(mid + NMID*(iy + 32*hi))) */
 int tnqs_dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const void* My, void* out);
 /* c64 only, site tensor [d][chi_0]..[chi_{z-1}] column-major: out = in x_lx Mx x_ly My (chi_lx = chi_ly = 32; leg 0 allowed) */

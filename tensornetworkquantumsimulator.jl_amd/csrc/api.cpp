@@ -178,6 +178,7 @@ int tnqs_profile_reset(tnqs_handle h) {
 namespace tnqs { void dbg_default_sequence(const State* s, std::vector<int>& src, std::vector<int>& dst);
                  void dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const void* My, void* out);
                  void dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out);
+                 void dbg_gauge_gram(int z, const int* chi, int bleg, const void* X, const void* M, void* out);
                  void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps);
                  void dbg_chol(int n, const void* G, void* L, void* W, int* fail, double tau);
                  void dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in, const void* Mx, const void* My, void* out);
@@ -206,6 +207,7 @@ int tnqs_dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void
 int tnqs_dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms) { return guard([&] { dbg_bench_plane(which, nsites, lx, ly, reps, ms); }); }
 int tnqs_dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* M, void* out) { return guard([&] { dbg_pair_gram(d, z, chi, lx, ly, X, Y, M, out); }); }
 int tnqs_dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out) { return guard([&] { dbg_gram_fused(PA, K, PB, X, Y, M, out); }); }
+int tnqs_dbg_gauge_gram(int z, const int* chi, int bleg, const void* X, const void* M, void* out) { return guard([&] { dbg_gauge_gram(z, chi, bleg, X, M, out); }); }
 int tnqs_dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void* Y, void* out, int acc64, int use_mfma) {
     return guard([&] { dbg_gram(dtype, D, PA, K, PB, X, Y, out, acc64, use_mfma); });
 }

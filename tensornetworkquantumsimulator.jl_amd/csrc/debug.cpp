@@ -329,4 +329,31 @@ void dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const v
     HIPCHK(hipDeviceSynchronize());
     dO.down(out, (size_t)K * K * 8);
 }
+// the gate path's fused gauge + f64 Gram kernels (kernels_gate.hip) on one site tensor: out[i + KK j] = sum_fibers X'[i, .] conj(X'[j, .]),
+// X' = X x_r M with r the lowest leg that is not the bond leg, (i, j) = (s, k); chi_b = 32 (mfma_gauge_gram64_kernel) or 16 (mfma_gauge_gram32_kernel)
+void dbg_gauge_gram(int z, const int* chi, int bleg, const void* X, const void* M, void* out) {
+    need_gpu();
+    if (z < 2 || z > 8 || bleg < 0 || bleg >= z) throw Err(TNQS_ERR_INVALID, "dbg_gauge_gram: bad shape");
+    const int rleg = bleg == 0 ? 1 : 0, K = chi[bleg], KK = 2 * K;
+    const bool k16 = gauge_gram32_covers(2, z, chi, bleg, rleg), k32 = gauge_gram64_covers(2, z, chi, bleg, rleg);
+    if (!k16 && !k32) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_gauge_gram: shape not covered by the fused kernels");
+    size_t n = 2; for (int i = 0; i < z; ++i) n *= chi[i];
+    long long PA = 1, PB = 1; for (int i = 0; i < bleg; ++i) PA *= chi[i]; for (int i = bleg + 1; i < z; ++i) PB *= chi[i];
+    DBuf dX(n * 8), dM((size_t)chi[rleg] * chi[rleg] * 8), dI(sizeof(GramItem)), dR(sizeof(ReduceItem));
+    dX.up(X, n * 8); dM.up(M, (size_t)chi[rleg] * chi[rleg] * 8);
+    GramItem it{}; it.X = dX.p; it.Y = dX.p; it.M = dM.p; it.D = 2; it.PA = (int)PA; it.K = K; it.PB = (int)PB;
+    tile_params(PA, PB, 64, it.TA, it.TB, it.nta, it.ntb);
+    if (k16) { it.nta = gauge_gram32_units(z, chi, bleg); it.ntb = 1; }
+    const int ntiles = it.nta * it.ntb, nch = std::min(5, ntiles);
+    it.tiles_per_chunk = (ntiles + nch - 1) / nch; it.nchunks = (ntiles + it.tiles_per_chunk - 1) / it.tiles_per_chunk; it.chunk_begin = 0;
+    const int npart = k16 ? it.nchunks : 2 * it.nchunks;
+    DBuf dP((size_t)npart * KK * KK * 16), dO((size_t)KK * KK * 16);
+    HIPCHK(hipMemset(dP.p, 0, (size_t)npart * KK * KK * 16));
+    it.partial = dP.p; dI.up(&it, sizeof(it));
+    if (k16) launch_mfma_gauge_gram32(nullptr, (const GramItem*)dI.p, 1, it.nchunks); else launch_mfma_gauge_gram64(nullptr, (const GramItem*)dI.p, 1, it.nchunks);
+    ReduceItem ri{dP.p, dO.p, KK * KK, npart, 0, 0}; dR.up(&ri, sizeof(ri));
+    launch_reduce<double, double>(nullptr, (const ReduceItem*)dR.p, 1, KK * KK);
+    HIPCHK(hipDeviceSynchronize());
+    dO.down(out, (size_t)KK * KK * 16);
+}
 }  // namespace tnqs

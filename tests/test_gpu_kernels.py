@@ -116,6 +116,31 @@ def test_gram(dtype, acc64, mfma, D, PA, K, PB, same):
     assert np.max(np.abs(out - ref)) < tol * max(1.0, np.sqrt(PA * PB / 64))
 
 
+@pytest.mark.parametrize("chi,bleg", [((16, 16, 16, 16), 0), ((16, 16, 16, 16), 1), ((16, 16, 16, 16), 3), ((16, 16, 16), 2), ((16, 16, 8, 16, 4), 3),
+                                      ((32, 32, 32, 32), 0), ((32, 32, 32, 32), 2), ((32, 32, 32, 32), 3), ((32, 32, 32), 1)])
+def test_gauge_leg_inside_the_f64_gram(chi, bleg):
+    """the gate path's fused kernels (kernels_gate.hip): the last gauge leg r (the lowest leg that is not the bond) absorbed inside the f64
+    Gram over the (s, bond) columns -- mfma_gauge_gram64_kernel (chi = 32) and the wave-private mfma_gauge_gram32_kernel (chi = 16), bond leg 0
+    (lanes along the bond index) and >= 1 -- against numpy in f64: G = X'^dagger X' of X' = X x_r M.  The kernels round X' to f32 and add
+    the squares up in f64, so the difference to the all-f64 reference is the f32 rounding of X' (three-multiplication product: normwise)."""
+    lib.tnqs_dbg_gauge_gram.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(sum(chi) + bleg)
+    z = len(chi); K = chi[bleg]; KK = 2 * K; r = 1 if bleg == 0 else 0
+    n = 2 * int(np.prod(chi))
+    x = rnd(rng, n, np.complex64); m = rnd(rng, chi[r] * chi[r], np.complex64)
+    out = np.zeros(KK * KK, dtype=np.complex128)
+    rc = lib.tnqs_dbg_gauge_gram(z, (C.c_int * z)(*chi), bleg, x.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0, lib.tnqs_last_error()
+    X = x.reshape((2,) + tuple(chi), order="F").astype(np.complex128)              # [s, l0, l1, ...]
+    mm = m.reshape(chi[r], chi[r], order="F").astype(np.complex128)                # M[r, r'] at r + chi r'
+    Xp = np.moveaxis(np.tensordot(X, mm, axes=([1 + r], [0])), -1, 1 + r)          # X x_r M
+    cols = np.moveaxis(Xp, 1 + bleg, 1).reshape(KK, -1, order="F")                 # rows i = s + 2 k
+    ref = (cols @ cols.conj().T).reshape(-1, order="F")                            # out[i + KK j] = sum X'[i, .] conj(X'[j, .])
+    err = np.max(np.abs(out - ref)) / np.max(np.abs(ref))
+    print(f"chi {chi} bond leg {bleg}: fused gauge + Gram against f64 numpy, relative {err:.1e}")
+    assert err < 1e-6            # measured 4e-9 ... 3e-8
+
+
 @pytest.mark.parametrize("PA,K,PB", [(64, 32, 64), (2048, 32, 8), (2, 32, 32 * 33), (64, 17, 40), (2, 9, 64)])
 def test_gram_fused_mode_product(PA, K, PB):
     """fused (X x_r M) + Gram: r = first row leg; rows of a 64-fiber tile are (s:2, i_r:32)"""
