@@ -12,11 +12,19 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+_RUNS = {}
+
+
 def run_worker(env, *args):
-    r = subprocess.run([sys.executable, os.path.join(HERE, "toggle_worker.py"), *args], env=dict(os.environ, PYTHONPATH=os.pathsep.join(sys.path), **env),
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    """one worker process per (switches, mode); the result of a configuration is reused by the tests that compare against it (the default
+    route is the reference of every parametrised case: without the memo it ran once per case)"""
+    key = (tuple(sorted(env.items())), args)
+    if key not in _RUNS:
+        r = subprocess.run([sys.executable, os.path.join(HERE, "toggle_worker.py"), *args], env=dict(os.environ, PYTHONPATH=os.pathsep.join(sys.path), **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        _RUNS[key] = r.stdout.strip().splitlines()[-1]
+    return json.loads(_RUNS[key])
 
 
 def test_lowrank_theta_route_matches_the_full_svd():
