@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
     __shared__ int s_keep;
     // grid (gate, part) as gate_theta_kernel: the ranking / truncation prologue is repeated per part, only part 0 writes its results
     const GateItem it = items[blockIdx.x];
-    const int part = blockIdx.y, tid0 = part * blockDim.x + threadIdx.x, tstride = gridDim.y * blockDim.x;
+    const int part = blockIdx.y;
     const int r1 = it.info[0], r2 = it.info[1], d1 = it.d1, d2 = it.d2;
     const int Mr = r1 * d1, Nc = r2 * d2;
     const bool wide = it.info[5] != 0;                                // theta stored as theta^dagger (Nc x Mr)
@@ -1522,7 +1522,6 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
     // Two small complex products (64 x 64 x 64 at chi = 32) on the f64 matrix cores, one wave per 16 x 16 tile (ztile_mm); the tile's lanes
     // run along (s,b), the contiguous index of X.  (The scalar loops these replace chased idx -> W -> multiply-add through L2 once per term:
     // 0.23 ms per launch at chi = 32, most of it load latency.)
-    (void)tid0; (void)tstride;
     const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
     const int wv = part * (blockDim.x >> 6) + (threadIdx.x >> 6), nwv = gridDim.y * (blockDim.x >> 6);
     const int N1 = d1 * nk, N2 = d2 * nk;

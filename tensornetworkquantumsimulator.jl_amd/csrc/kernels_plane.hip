@@ -2,13 +2,16 @@
 // (periodic cubic lattice, degree 6, chi = 16: site tensors of 2 x 16^6 elements = 268 MB) and of the heavy-hex lattice.
 //
 // At chi = 16 one mode product has an arithmetic intensity of 8 flop/B (ridge of the machine: 19.7), so everything here is about HBM
-// passes: two legs per pass (mfma_pair16_kernel, 16 flop/B) and both messages of a forest from one pass over (T, psi)
-// (mfma_pair_gram2x16_kernel, 32 flop/B).  The kernels are WAVE PRIVATE: a wave owns an LDS slab, moves its own half slice (8 companion
-// elements = 64-byte runs; the other half of every 128-byte line belongs to the neighbouring wave of the same workgroup, which walks
-// the same slices at the same time) and never meets a workgroup barrier inside its loop, so the waves of a CU drift apart and one
-// wave's global / LDS phases hide behind the others' MFMAs -- the structure that reached 80 % of the streaming rate for the single
-// mode product (mfma_fiber_gemm_w_kernel), where the workgroup-synchronous chi = 32 plane kernels stop at 2.9 TB/s.
-//
+// passes: two legs per pass (mfma_pair16_kernel / mfma_pair16w_kernel, 16 flop/B) and both messages of a forest from one pass over
+// (T, psi) (mfma_pair_gram2x16_kernel, 32 flop/B).  The kernels are WAVE PRIVATE: a wave owns an LDS slab, moves the companion planes of
+// its slice itself (register prefetch of the next one) and never meets a workgroup barrier inside its loop, so the waves of a CU drift
+// apart and one wave's global / LDS phases hide behind the others' MFMAs.  What a wave owns differs per kernel, and measurably matters
+// (profiles/plane16_bench.py):
+//   mfma_pair16_kernel        8 waves x half slices (8 companions, the other half of each line belongs to the neighbouring wave): planes that
+//                             contain leg 0, where a wave's 16 lanes read 256 contiguous bytes anyway (5.0 - 5.3 TB/s)
+//   mfma_pair16w_kernel       4 waves x whole slices: all other planes, whose 16 companions are ONE 128-byte line (4.0 - 5.1 TB/s; the
+//                             half-slice kernel ran them at 2.5 - 3.9)
+//   mfma_pair_gram2x16_kernel 8 waves x half slices, four companions resident at a time: two waves per SIMD keep the matrix pipe fed
 // Matrix instruction: v_mfma_f32_16x16x4_f32 (one 16 x 16 plane = one tile).  Lane l = (c = l & 15, g = l >> 4):
 //      A[i = c][k = g]   B[k = g][j = c]   C[row = 4 g + r][col = c],  r = 0..3
 // k only has to be consistent between A and B: k-step t of group g is mapped to index 4 g + t, so a lane reads FOUR CONSECUTIVE complex
