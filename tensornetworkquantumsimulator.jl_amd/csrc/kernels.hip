@@ -317,6 +317,28 @@ template void launch_msg_finalize<double>(hipStream_t, const MsgFinalItem*, int)
 // one-sided (Hestenes) Jacobi: A <- A J_1 J_2 ..., V <- V J_1 J_2 ...  until the columns of A are orthogonal.
 // One workgroup per matrix, one wave per column pair, round-robin pair ordering.  m <= 64 R (R = 4 or 8: up to 512 rows), any n.
 // ------------------------------------------------------------------------------------------------------------
+// Rotation parameters.  f32: the hardware reciprocal (square root).  f64: the compiler's IEEE sqrt and division are ~55 dependent
+// instructions each, and a Jacobi round has three of each on its critical path (most of the 1.2 us per round of the f64 kernels); the
+// hardware seeds (v_rsq_f64 / v_rcp_f64, ~2^-23 relative) with two Newton steps are ~8 instructions and good to a few ulp, which is all
+// a plane rotation needs (c^2 + s^2 = 1 to 1e-15).  Arguments are normal, positive numbers here (see the guards on g2).
+template <class T> __device__ __forceinline__ T fast_rsqrt(T x);
+template <> __device__ __forceinline__ float fast_rsqrt<float>(float x) { return __frsqrt_rn(x); }
+template <> __device__ __forceinline__ double fast_rsqrt<double>(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = x * y; y = y * (1.5 - 0.5 * h * y);
+    h = x * y; y = y * (1.5 - 0.5 * h * y);
+    return y;
+}
+template <class T> __device__ __forceinline__ T fast_rcp(T x);
+template <> __device__ __forceinline__ float fast_rcp<float>(float x) { return __frcp_rn(x); }
+template <> __device__ __forceinline__ double fast_rcp<double>(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y); y = y * (2.0 - x * y);
+    return y;
+}
+template <class T> __device__ __forceinline__ T fast_sqrt(T x);          // x >= 1 at the call sites
+template <> __device__ __forceinline__ float fast_sqrt<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double fast_sqrt<double>(double x) { return x * fast_rsqrt<double>(x); }
 template <class T, int R>          // R rows per lane: m <= 64 R
 __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restrict__ items, int max_sweeps) {
     __shared__ int s_rot;
@@ -366,12 +388,13 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restri
                 }
                 alpha = wave_sum(alpha); beta = wave_sum(beta); gre = wave_sum(gre); gim = wave_sum(gim);
                 const T g2 = gre * gre + gim * gim;
-                if (g2 > 0 && g2 > tol * tol * alpha * beta) {
-                    const T ga = sqrt(g2);
-                    const T pre = gre / ga, pim = -gim / ga;           // e^{-i phi}
-                    const T zeta = (beta - alpha) / (2 * ga);
-                    const T t = (zeta >= 0 ? (T)1 : (T)-1) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-                    const T c = 1 / sqrt(1 + t * t), sn = c * t;
+                if (g2 > (sizeof(T) == 4 ? (T)1e-36 : (T)1e-290) && g2 > tol * tol * alpha * beta) {      // (g2 normal: see fast_rsqrt)
+                    const T iga = fast_rsqrt<T>(g2);
+                    const T pre = gre * iga, pim = -gim * iga;         // e^{-i phi}
+                    const T zeta = (beta - alpha) * (T)0.5 * iga;
+                    const T az = fabs(zeta);
+                    const T t = (zeta >= 0 ? (T)1 : (T)-1) * fast_rcp<T>(az + fast_sqrt<T>(1 + az * az));
+                    const T c = fast_rsqrt<T>(1 + t * t), sn = c * t;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         int i = lane + 64 * r;
@@ -410,10 +433,6 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restri
 // A QUARTER wave (16 lanes) owns one column pair, so a 16-wave workgroup rotates 64 pairs at once (one full round of a
 // 128-column matrix); the dot products reduce inside 16-lane rows.  Columns are padded by 2 elements so the four
 // quarter-waves of a wave hit different LDS banks.
-template <class T> __device__ __forceinline__ T fast_rsqrt(T x) { return 1 / sqrt(x); }
-template <> __device__ __forceinline__ float fast_rsqrt<float>(float x) { return __frsqrt_rn(x); }
-template <class T> __device__ __forceinline__ T fast_rcp(T x) { return 1 / x; }
-template <> __device__ __forceinline__ float fast_rcp<float>(float x) { return __frcp_rn(x); }
 // all-reduce over a 16-lane row with DPP row rotations (VALU, no LDS crossbar): after adding the rotations by 8, 4, 2, 1 every lane
 // holds the row sum (the same summation tree in every lane of the row, so the four quarter-waves' decisions stay uniform per row)
 template <int ROR> __device__ __forceinline__ float dpp_ror_f(float v) {
@@ -476,13 +495,13 @@ __device__ __forceinline__ int jacobi_lds_sweeps(cx<T>* A, cx<T>* V, bool hasV, 
                 alpha = row16_sum(alpha); beta = row16_sum(beta); gre = row16_sum(gre); gim = row16_sum(gim);
                 const T g2 = gre * gre + gim * gim;
                 // f32: g2 must be a NORMAL number -- the fast reciprocal square root returns inf for (flushed) denormals
-                const bool rot = act && g2 > (sizeof(T) == 4 ? (T)1e-36 : (T)0) && g2 > tol * tol * alpha * beta && !(alpha < tiny && beta < tiny);
+                const bool rot = act && g2 > (sizeof(T) == 4 ? (T)1e-36 : (T)1e-290) && g2 > tol * tol * alpha * beta && !(alpha < tiny && beta < tiny);
                 if (rot) {
                     const T iga = fast_rsqrt<T>(g2);
                     const T pre = gre * iga, pim = -gim * iga;
                     const T zeta = (beta - alpha) * (T)0.5 * iga;
                     const T az = fabs(zeta);
-                    const T t = (zeta >= 0 ? (T)1 : (T)-1) * fast_rcp<T>(az + sqrt(1 + az * az));
+                    const T t = (zeta >= 0 ? (T)1 : (T)-1) * fast_rcp<T>(az + fast_sqrt<T>(1 + az * az));
                     const T c = fast_rsqrt<T>(1 + t * t), sn = c * t;
 #pragma unroll
                     for (int r = 0; r < RQ; ++r) {
