@@ -78,10 +78,13 @@ void dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, con
     if (mf) TR = mfma_fiber_tile_rows(D * K, Do * No);
     tile_params(PA, PB, TR, it.TA, it.TB, it.nta, it.ntb);
     it.tile_begin = 0; it.want_norm = 1; it.tpw = mf ? 5 : 1;
+    const bool mf64 = use_mfma && dtype == TNQS_C128 && fiber_gemm_f64_covers(it);       // kernels_f64.hip (general form: D, Do, norm partial)
+    if (mf64) { fiber_gemm_f64_tiles(it); it.tpw = 12; }
     int tiles = (it.nta * it.ntb + it.tpw - 1) / it.tpw;
     DBuf dN((size_t)tiles * 8);
     dI.up(&it, sizeof(it));
-    if (mf) launch_mfma_fiber_gemm(nullptr, (const FiberItem*)dI.p, 1, tiles, D * K, Do * No, (double*)dN.p);
+    if (mf64) launch_mfma_fiber_gemm_f64(nullptr, (const FiberItem*)dI.p, 1, tiles, D * K, Do * No, (double*)dN.p, true);
+    else if (mf) launch_mfma_fiber_gemm(nullptr, (const FiberItem*)dI.p, 1, tiles, D * K, Do * No, (double*)dN.p);
     else if (dtype == TNQS_C64) launch_fiber_gemm<float>(nullptr, (const FiberItem*)dI.p, 1, tiles, TR, D * K, (double*)dN.p);
     else launch_fiber_gemm<double>(nullptr, (const FiberItem*)dI.p, 1, tiles, TR, D * K, (double*)dN.p);
     HIPCHK(hipDeviceSynchronize());
@@ -101,6 +104,8 @@ void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void
     bool mf = use_mfma && dtype == TNQS_C64 && !acc64 && KK <= 32;
     bool mf64 = use_mfma && dtype == TNQS_C64 && acc64 && same && KK <= 64 && KK >= 16;
     if (mf || mf64) TR = 64;
+    const bool mfz = use_mfma && dtype == TNQS_C128 && gram_f64in_covers(D, K);           // kernels_f64.hip
+    if (mfz) TR = 32;
     tile_params(PA, PB, TR, it.TA, it.TB, it.nta, it.ntb);
     int ntiles = it.nta * it.ntb; int nch = std::min(7, ntiles);
     if (const char* e = std::getenv("TNQS_DBG_GRAM_CHUNKS")) nch = std::min(ntiles, std::max(1, std::atoi(e)));
@@ -110,7 +115,8 @@ void dbg_gram(int dtype, int D, int PA, int K, int PB, const void* X, const void
     int npart = mf ? 4 * it.nchunks : (mf64 ? 2 * it.nchunks : it.nchunks);
     DBuf dP((size_t)npart * KK * KK * asz), dO((size_t)KK * KK * asz);
     it.partial = dP.p; dI.up(&it, sizeof(it));
-    if (mf64) launch_mfma_gram64_f64(nullptr, (const GramItem*)dI.p, 1, it.nchunks, KK, KK == 64);
+    if (mfz) launch_mfma_gram_f64in(nullptr, (const GramItem*)dI.p, 1, it.nchunks);
+    else if (mf64) launch_mfma_gram64_f64(nullptr, (const GramItem*)dI.p, 1, it.nchunks, KK, KK == 64);
     else if (mf) launch_mfma_gram32(nullptr, (const GramItem*)dI.p, 1, it.nchunks, KK);
     else if (dtype == TNQS_C64) { if (a64) launch_gram<float, double>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); else launch_gram<float, float>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK); }
     else launch_gram<double, double>(nullptr, (const GramItem*)dI.p, 1, it.nchunks, TR, KK);

@@ -148,6 +148,20 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
             launch_mfma_rowgemm(s->stream, d, (int)ri.size(), wgs, 1, pass ? 32 : 64, nullptr);
         }
         if (items.empty()) continue;
+        // ComplexF64: the f64 matrix cores (kernels_f64.hip) when every product of the pass is one the kernel takes
+        static const bool f64_mfma_off = envflag("TNQS_NO_F64_MFMA");
+        bool f64mf = std::is_same<T, double>::value && use_mfma() && !f64_mfma_off;
+        for (auto& it : items) f64mf = f64mf && fiber_gemm_f64_covers(it);
+        if (f64mf) {
+            double tot = 0; for (auto& it : items) { fiber_gemm_f64_tiles(it); tot += (double)it.nta * it.ntb; }
+            int tpw = (int)std::max(8.0, std::min(64.0, tot / 4096.0)); tpw &= ~3;
+            int wgs = 0;
+            for (auto& it : items) { it.tpw = tpw; it.tile_begin = wgs; wgs += (it.nta * it.ntb + tpw - 1) / tpw; }
+            const FiberItem* d = upload(s, items);
+            ProfScope ps(s, cls, bytes, flops);
+            launch_mfma_fiber_gemm_f64(s->stream, d, (int)items.size(), wgs, (int)KKmax, (int)KKmax, nullptr, false);
+            continue;
+        }
         const FiberItem* d = upload(s, items);
         ProfScope ps(s, cls, bytes, flops);
         if (mf) launch_mfma_fiber_gemm(s->stream, d, (int)items.size(), tiles, (int)KKmax, (int)KKmax, nullptr);
@@ -249,6 +263,11 @@ template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& job
     if (gauge_fused) { mf64 = true; mf128 = false; }
     const bool gauge16 = gauge_fused && KKmax == 32;      // 16-dimensional legs: the wave-private kernel (units of one fiber of r, one partial per chunk)
     if (mf || mf64 || mf128) TR = 64;
+    // ComplexF64 operands: tiles of 32 fibers through LDS, f64 matrix cores (kernels_f64.hip)
+    static const bool f64_mfma_off = envflag("TNQS_NO_F64_MFMA");
+    bool mf64in = std::is_same<T, double>::value && use_mfma() && !f64_mfma_off && jobs[0].M == nullptr;
+    for (auto& j : jobs) mf64in = mf64in && j.M == nullptr && gram_f64in_covers(j.keep_site ? j.sd.d : 1, j.leg >= 0 ? j.sd.chi[j.leg] : 1);
+    if (mf64in) TR = 32;
     const int target = 2048;
     int per_item = std::max(1, target / (int)jobs.size());
     std::vector<GramItem> items; int chunks = 0; double bytes = 0, flops = 0;
@@ -280,6 +299,7 @@ template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& job
     else if (fused) launch_mfma_gram32_fused(s->stream, d, (int)items.size(), chunks);
     else if (mf64) { bool all64 = true; for (auto& j : jobs) all64 = all64 && j.KK == 64; launch_mfma_gram64_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax, all64); }
     else if (mf128) { bool all128 = true; for (auto& j : jobs) all128 = all128 && j.KK == 128; launch_mfma_gram128_f64(s->stream, d, (int)items.size(), chunks, (int)KKmax, all128); }
+    else if (mf64in) launch_mfma_gram_f64in(s->stream, d, (int)items.size(), chunks);
     else if (mf) { if (KKmax <= 32) launch_mfma_gram32(s->stream, d, (int)items.size(), chunks, (int)KKmax); else launch_mfma_gram64(s->stream, d, (int)items.size(), chunks, (int)KKmax); }
     else launch_gram<T, Acc>(s->stream, d, (int)items.size(), chunks, TR, (int)KKmax);
 }

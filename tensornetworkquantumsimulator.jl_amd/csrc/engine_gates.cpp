@@ -780,6 +780,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         int TR = pick_TR(KKmax, esz, 1);
         bool mf = false;
         if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)NNmax); if (t > 0) { TR = t; mf = true; } }
+        static const bool f64_mfma_off = envflag("TNQS_NO_F64_MFMA");
+        const bool f64mf = std::is_same<T, double>::value && use_mfma() && !f64_mfma_off && KKmax >= 4 && KKmax <= 64 && NNmax <= 64;      // kernels_f64.hip
         // plane kernel for the common shape d = 2, chi_b = chi_b' = 32 (pair-kernel geometry, two waves per SIMD)
         std::vector<Apply64Item> a64; std::vector<XbItem> xbi; std::vector<int> a64_verts; std::vector<Buf> a64_outs; std::vector<size_t> a64_ne;
         std::vector<char> via64(own_idx.size(), 0); double a64_slices = 0;
@@ -849,6 +851,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             it.D = j.sd.d; it.PA = (int)(pre / j.sd.d); it.K = chi; it.PB = (int)post; it.Do = j.sd.d; it.No = chin;
             tile_params(it.PA, it.PB, TR, it.TA, it.TB, it.nta, it.ntb);
             it.tpw = mf ? (TR == 32 ? 16 : 4) : 1;
+            if (f64mf) { fiber_gemm_f64_tiles(it); it.tpw = 32; }      // ComplexF64 epilogue on the f64 matrix cores: tiles of 16 fibers, 32 per workgroup
             const int nwg = (it.nta * it.ntb + it.tpw - 1) / it.tpw;
             it.tile_begin = tiles; it.want_norm = ao.normalize_tensors ? 1 : 0;
             verts.push_back(j.v); outs.push_back(out); ne.push_back(nout); tb.push_back(tiles); nt.push_back(nwg);
@@ -859,7 +862,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         const FiberItem* d = upload(s, items);
         if (!items.empty())
         { ProfScope ps(s, TNQS_PROF_GATE_APPLY, bytes, flops);
-          if (mf) launch_mfma_fiber_gemm(s->stream, d, (int)items.size(), tiles, (int)KKmax, (int)NNmax, reinterpret_cast<double*>(np->p));
+          if (f64mf) launch_mfma_fiber_gemm_f64(s->stream, d, (int)items.size(), tiles, (int)KKmax, (int)NNmax, reinterpret_cast<double*>(np->p), true);
+          else if (mf) launch_mfma_fiber_gemm(s->stream, d, (int)items.size(), tiles, (int)KKmax, (int)NNmax, reinterpret_cast<double*>(np->p));
           else launch_fiber_gemm<T>(s->stream, d, (int)items.size(), tiles, TR, (int)KKmax, reinterpret_cast<double*>(np->p)); }
         norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, ao.normalize_tensors != 0);
     }

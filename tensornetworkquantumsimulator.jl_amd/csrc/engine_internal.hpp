@@ -60,6 +60,7 @@ TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64
 // leaving them on the device (one host round trip per batch);  TNQS_ARENA_KB: size of the pinned staging arena (tests of its overflow path);
 // TNQS_JACOBI_GLOBAL=1: every Jacobi factorisation in the global-memory kernel;  TNQS_BP_WS_MB: workspace bound of a BP sub-batch (MiB);
 // TNQS_HOST_TIMING=1: host-side phase timers printed at exit;  TNQS_RCCL_LIB: path of librccl.so (sharding.cpp);
+// TNQS_NO_F64_MFMA=1 (engine_batch.cpp): ComplexF64 mode products on the generic vector kernel instead of the f64 matrix cores (kernels_f64.hip);
 // TNQS_PAIR16_HALF=1 (kernels_plane.hip): every chi = 16 two-leg pass on the kernel in which two waves share each 128-byte line (default: only planes that contain leg 0);
 // TNQS_NO_3M=1 (launch_util.hpp): four-multiplication complex product in every MFMA kernel instead of Gauss' three (mfma_common.hpp, CAcc32);
 // kernels_mfma.hip reads TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP (single-message pair-Gram), TNQS_DBG_GRAM_SKIP; kernels.hpp reads TNQS_PAIR_SPW

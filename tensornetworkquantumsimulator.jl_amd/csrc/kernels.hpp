@@ -311,6 +311,12 @@ void launch_mfma_gram32_fused(hipStream_t s, const GramItem* d_items, int nitems
 bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax, bool all_kk64 = false);   // all_kk64: every item has D * K = 64
 // the third gauge leg absorbed inside the f64 Gram (kernels_gate.hip): GramItem::M = the 32 x 32 matrix of the fastest outer leg `rleg`; same
 // tiles and partial layout as launch_mfma_gram64_f64 (2 partials per chunk)
+// ComplexF64 mode products on the f64 matrix cores (kernels_f64.hip): one wave per tile of 16 fibers, FiberItem::tpw tiles per wave-quartet
+bool fiber_gemm_f64_covers(const FiberItem& it);
+void fiber_gemm_f64_tiles(FiberItem& it);
+void launch_mfma_fiber_gemm_f64(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int Kmax, int Nmax, double* d_norm_partials, bool general);
+bool gram_f64in_covers(int D, int K);          // ComplexF64 Gram over tiles of 32 fibers (one partial per chunk)
+void launch_mfma_gram_f64in(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks);
 bool gauge_gram64_covers(int d, int z, const int* chi, int bleg, int rleg);
 bool gauge_gram32_covers(int d, int z, const int* chi, int bleg, int rleg);      // the same fusion for 16-dimensional legs (32 columns)
 int gauge_gram32_units(int z, const int* chi, int bleg);                         // units (one fiber of r = 16 rows) of a site

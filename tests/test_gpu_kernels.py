@@ -67,7 +67,7 @@ def fiber_ref(x, X, D, PA, K, PB, Do, No):
     return out.transpose(3, 2, 1, 0).reshape(-1)                 # memory order: s' fastest, then a, n, b
 
 
-@pytest.mark.parametrize("dtype,mfma", [(0, 0), (1, 0), (0, 1)])
+@pytest.mark.parametrize("dtype,mfma", [(0, 0), (1, 0), (0, 1), (1, 1)])       # (1, 1): ComplexF64 on the f64 matrix cores (kernels_f64.hip), shapes it covers
 @pytest.mark.parametrize("D,PA,K,PB,Do,No", [(2, 64, 64, 8, 2, 64), (1, 128, 64, 16, 1, 64), (2, 4, 64, 70, 2, 40), (1, 64, 32, 64, 1, 32), (2, 32, 32, 32, 2, 32), (2, 128, 32, 4, 2, 17), (1, 2, 32, 200, 1, 32), (2, 16, 16, 70, 2, 5),
                                              (1, 2, 3, 5, 1, 3), (1, 100, 10, 7, 1, 10), (1, 1, 7, 130, 1, 7), (2, 9, 5, 4, 2, 3),
                                              (2, 1, 1, 1, 2, 1), (2, 300, 1, 1, 2, 1), (1, 64, 32, 33, 1, 32), (2, 16, 16, 16, 2, 16),
@@ -88,14 +88,14 @@ def test_fiber_gemm(dtype, mfma, D, PA, K, PB, Do, No):
     assert abs(n2.value - np.sum(np.abs(ref) ** 2)) < 1e-5 * np.sum(np.abs(ref) ** 2)
 
 
-@pytest.mark.parametrize("dtype,acc64,mfma", [(0, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (0, 1, 1)])
+@pytest.mark.parametrize("dtype,acc64,mfma", [(0, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (0, 1, 1), (1, 1, 1)])       # (1, 1, 1): ComplexF64 operands, f64 matrix cores
 @pytest.mark.parametrize("D,PA,K,PB,same", [(2, 64, 64, 16, 1), (2, 2, 64, 300, 1), (1, 64, 64, 32, 0), (2, 1024, 32, 32, 1), (2, 32, 32, 1000, 1), (2, 1, 32, 1024, 1), (2, 77, 19, 11, 1), (1, 64, 32, 1024, 0), (1, 2048, 32, 32, 0), (1, 2, 32, 700, 1), (1, 70, 17, 9, 0),
                                            (1, 2, 3, 5, 0), (1, 100, 10, 7, 0), (1, 1, 7, 130, 1), (2, 9, 5, 40, 1), (2, 30, 1, 1, 0),
                                            (1, 64, 32, 33, 0), (2, 16, 16, 16, 1), (2, 512, 32, 8, 1), (3, 5, 5, 6, 0)])
 def test_gram(dtype, acc64, mfma, D, PA, K, PB, same):
     if mfma and not acc64 and D * K > 32:
         pytest.skip('f32 MFMA Gram covers D*K <= 32')
-    if mfma and acc64 and not (same and 16 <= D * K <= 64):
+    if mfma and acc64 and dtype == 0 and not (same and 16 <= D * K <= 64):
         pytest.skip('f64 MFMA Gram covers X == Y, 16 <= D*K <= 64')
     rng = np.random.default_rng(D + PA + K + PB)
     dt = CDT[dtype]

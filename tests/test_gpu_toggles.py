@@ -167,6 +167,24 @@ def test_chi16_gauge_leg_inside_the_gram_matches_the_separate_pass():
     assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-5
 
 
+def test_f64_matrix_core_kernels_match_the_vector_kernels():
+    """ComplexF64 state: mode products, Grams and the gate epilogue on the f64 matrix cores (kernels_f64.hip) against the generic vector kernels
+    (TNQS_NO_F64_MFMA=1).  The same f64 arithmetic in a different summation order: layer results to 1e-10, messages elementwise to 1e-11."""
+    on, off = run_worker({}, "c128"), run_worker({"TNQS_NO_F64_MFMA": "1"}, "c128")
+    for name in ("Rzz", "SWAP"):
+        a, b = on[name], off[name]
+        assert a["dims"] == b["dims"], name
+        ea, eb = np.array(a["errs"]), np.array(b["errs"])
+        assert np.all(np.abs(ea - eb) < 1e-9 * np.maximum(ea, eb) + 1e-13), (name, float(np.max(np.abs(ea - eb))))
+        assert np.max(np.abs(np.array(a["z"]) - np.array(b["z"]))) < 1e-10, name
+        worst = 0.0
+        for ma, mb in zip(a["msgs"], b["msgs"]):
+            x = np.array(ma[0]) + 1j * np.array(ma[1]); y = np.array(mb[0]) + 1j * np.array(mb[1])
+            worst = max(worst, float(np.max(np.abs(x - y)) / np.max(np.abs(y))))
+        print(name, "f64 matrix cores against vector kernels: messages", worst, " max |dZ|", float(np.max(np.abs(np.array(a["z"]) - np.array(b["z"])))))
+        assert worst < 1e-11, name
+
+
 def test_chi64_kernels_match_the_generic_route_on_a_physical_evolution():
     """nine TFIM layers from the product state at maxdim 64 (bonds grow 2 -> 64, theta rank deficient on the way): the chi = 64 kernels
     (kernels_chi64.hip and the Cholesky-QR theta SVD) against the generic route (TNQS_NO_CHI64=1: round-1 kernels, global-memory Jacobi).

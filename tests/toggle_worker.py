@@ -69,7 +69,25 @@ def chi32():
                           modeprod_launches=prof["gate_modeprod"]["launches"], gram_launches=prof["gate_gram"]["launches"])))
 
 
+def c128():
+    """ComplexF64 (the reference's default element type): 4x4 lattice, random chi = 8 state, a layer of Rx + Rzz / SWAP and BP sweeps -- the f64
+    matrix-core products, Grams and gate epilogue (kernels_f64.hip) against the generic vector kernels (TNQS_NO_F64_MFMA=1)"""
+    g = tn.named_grid((4, 4))
+    psi = tn.random_tensornetworkstate(np.complex128, g, bond_dimension=8, seed=9)
+    bpc = tn.update(tn.BeliefPropagationCache(psi), maxiter=20, tolerance=None)
+    out = {}
+    for name in ("Rzz", "SWAP"):
+        layer = [("Rx", [v], 0.3) for v in g.vertices] + [((name, [a, b], 0.4) if name == "Rzz" else (name, [a, b])) for grp in tn.edge_color(g, 4) for (a, b) in grp]
+        b2, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=8, cutoff=1e-12, normalize_tensors=True), bp_update_kwargs=dict(maxiter=20, tolerance=None))
+        msgs = [b2.message(e) for (a, b) in g.edges[:8] for e in ((a, b), (b, a))]
+        out[name] = dict(errs=errs.tolist(), z=[float(np.real(x)) for x in tn.expect_all(b2, "Z")], dims=[b2.bond_dim(a, b) for a, b in g.edges],
+                         msgs=[[m.real.tolist(), m.imag.tolist()] for m in msgs])
+    print(json.dumps(out))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "c128":
+        return c128()
     if len(sys.argv) > 1 and sys.argv[1] == "chi32":
         return chi32()
     if len(sys.argv) > 1 and sys.argv[1] == "cubic16":
