@@ -363,7 +363,7 @@ def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_
         warnings.warn(f"BP did not converge in {st.bp_not_converged} of {st.n_bp_updates} cache updates "
                       f"(final average message change: {st.last_bp_diff}).")
     if info is not None:
-        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_tall_svd=st.n_tall_svd, n_deferred_1site=st.n_deferred_1site, n_svd_sweeps=st.n_svd_sweeps, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
+        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_tall_svd=st.n_tall_svd, n_deferred_1site=st.n_deferred_1site, n_forked_batches=st.n_forked_batches, n_svd_sweeps=st.n_svd_sweeps, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
                     n_two_site=st.n_two_site, bp_not_converged=st.bp_not_converged)
     return out, errs[:ng]
 
@@ -371,10 +371,19 @@ def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_
 apply_circuit = apply_gates
 
 
-def truncate(bpc: BeliefPropagationCache, maxdim: int, cutoff: Optional[float] = None, edge_color=True,
-             normalize_tensors: bool = True, bp_update_kwargs: Optional[dict] = None, info: Optional[dict] = None):
+def truncate(bpc, maxdim: int, cutoff: Optional[float] = None, edge_color=True,
+             normalize_tensors: bool = True, bp_update_kwargs: Optional[dict] = None, info: Optional[dict] = None, alg: str = "bp",
+             device: int = 0):
     """truncate(bpc; maxdim, cutoff, edge_color, normalize_tensors) (src/truncate.jl:12-38).  `edge_color` may be
-    True (compute a colouring), False (update after every edge) or an explicit list of edge groups."""
+    True (compute a colouring), False (update after every edge) or an explicit list of edge groups.
+    Given a TensorNetworkState instead of a cache (src/truncate.jl:74-79, alg"bp"): a cache is built and updated with the defaults, truncated,
+    and its network returned."""
+    if alg != "bp":
+        raise ValueError(f'truncate: only alg = "bp" is part of this path (received {alg!r}; boundary MPS truncation is out of scope)')
+    if isinstance(bpc, TensorNetworkState):
+        cache = update(BeliefPropagationCache(bpc, device=device))
+        return network(truncate(cache, maxdim, cutoff=cutoff, edge_color=edge_color, normalize_tensors=normalize_tensors,
+                                bp_update_kwargs=bp_update_kwargs, info=info))
     g = bpc.graph
     if edge_color is True:
         groups = _edge_color(g)

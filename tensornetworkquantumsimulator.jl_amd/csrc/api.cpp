@@ -137,6 +137,9 @@ int tnqs_set_sharding(tnqs_handle h, int rank, int nranks, const int32_t* owner,
             for (int v = 0; v < s->g->nv; ++v) if (owner[v] < 0 || owner[v] >= nranks) throw Err(TNQS_ERR_INVALID, "set_sharding: owner out of range");
             s->owner.assign(owner, owner + s->g->nv);
         } else s->owner.clear();
+        // one-site gates deferred while the handle was unsharded are applied NOW, while every tensor is still here: afterwards an accessor only
+        // touches the vertices its rank owns, and a pending set that differs between ranks would give the two ranks of a gate different thetas
+        materialize_pending_all(s);
         s->comm.reset();       // callback transport from here on: a communicator of an earlier tnqs_set_sharding_rccl must not keep serving exchange()
         s->rank = rank; s->nranks = nranks; s->ag_fn = fn; s->ag_ctx = ctx; s->exch = exch_dev; s->exch_bytes = (size_t)exch_bytes;
         if (nranks > 1) for (int v = 0; v < s->g->nv; ++v) if (!s->owns(v)) { s->site[v] = nullptr; s->sscale[v] = nullptr; }   // only owners hold site tensors

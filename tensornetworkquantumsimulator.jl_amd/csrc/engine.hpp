@@ -11,6 +11,8 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <condition_variable>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -25,7 +27,11 @@ struct Err : std::runtime_error {
 };
 void hipchk(hipError_t e, const char* what);
 
-// ---- caching device allocator (stream-ordered reuse on the handle's single stream) ----------------------------
+// ---- caching device allocator ---------------------------------------------------------------------------------
+// Reuse is stream-ordered: a buffer that goes back to the free list may be handed out again at once, which is safe while all work of a
+// handle is enqueued on ONE stream.  While a gate batch runs as two halves on two streams (engine_gates.cpp, fork / join), releases are
+// DEFERRED instead: nothing freed inside the forked region is handed out before the join has ordered both streams again.  The two halves
+// are driven by two host threads, hence the lock.
 class Pool {
 public:
     explicit Pool(int device) : device_(device) {}
@@ -35,9 +41,12 @@ public:
     size_t bytes_live() const { return live_; }
     size_t bytes_cached() const { return cached_; }
     void trim();
+    void set_defer(bool on);         // off: everything released meanwhile becomes available
 private:
     int device_ [[maybe_unused]];
+    std::mutex mu_;
     std::map<size_t, std::vector<void*>> free_;
+    std::vector<std::pair<void*, size_t>> deferred_; bool defer_ = false;
     size_t live_ = 0, cached_ = 0;
 };
 struct DevBuf {
@@ -59,6 +68,7 @@ struct Graph {
     std::vector<int> ecolor; int ncolors = 0;     // deterministic greedy proper edge colouring
     mutable std::vector<int> default_seq;         // default BP sweep order (engine.cpp default_sequence), built on first use
     mutable std::shared_ptr<const void> default_plan;   // its level schedule (engine.cpp BPPlan), built on first use
+    mutable std::shared_ptr<const void> forest_plan;    // level schedule of the forest-cover order (n_sequence = -1), built on first use
     int edge(int u, int v) const;                 // -1 if absent
     int leg(int v, int w) const;                  // position of neighbour w in nbr[v], -1 if absent
     int dedge(int src, int dst) const;            // directed edge id 2*e + (src == edst[e]), -1 if absent
@@ -109,9 +119,27 @@ struct State {
     // identical on every rank of a sharded handle.  unit_norm[v]: the last operation on v left ||psi_v|| = 1 (normalize_tensors), so a
     // deferred unitary gate with normalize_tensors has nothing to normalise
     std::vector<std::vector<double>> pend1; std::vector<char> unit_norm;
+    // A sharded handle defers only INSIDE one apply_gates call (every rank walks the same gate list, so the pending sets stay identical) and
+    // applies what is left before the call returns: between calls an accessor of one rank only touches the vertices that rank owns
+    bool in_apply = false;
     std::vector<Buf> msg;          // 2*ne, null = unset = identity (tensornetworkstate.jl:72-75)
     std::shared_ptr<Pool> pool;
     hipStream_t stream = nullptr; bool own_stream = false;
+    // second stream of a forked gate batch (engine_gates.cpp apply_two_site_forked) with the two events that order it against `stream`;
+    // created on first use, owned by this State
+    hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
+    // HIGH-PRIORITY streams for the per-gate factorisation chains of the two halves: next to the other half's tensor passes (thousands of
+    // queued workgroups) the one-workgroup-per-gate kernels of a chain would wait for a free CU at every step (measured: chol_kernel 1.4 ms
+    // instead of 0.07, gate_finish 0.9 instead of 0.06); with queue priority their workgroups take the next slot that frees up.
+    // chain_stream != null: this State switches to it for the chain phases of a batch (switch_stream, engine_internal.hpp)
+    hipStream_t hi_stream[2] = {nullptr, nullptr}; hipStream_t chain_stream = nullptr;
+    std::vector<hipEvent_t> ev_ring, ev_ring_b; size_t ev_next = 0;      // events that order a State's streams against each other (ev_ring_b: lent to half B)
+    // set while this State is one half of a forked batch: half A (role 1) records `ev` behind its Gram pass and signals; half B (role 2) lets
+    // its own tensor passes wait for that event, so that B's heavy passes run under A's factorisation chain instead of next to A's heavy passes
+    struct ForkSync { std::mutex m; std::condition_variable cv; bool recorded = false; hipEvent_t ev = nullptr;
+                      void signal() { { std::lock_guard<std::mutex> lk(m); recorded = true; } cv.notify_all(); }
+                      void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return recorded; }); } };
+    ForkSync* fork_sync = nullptr; int fork_role = 0;
     // sharding
     int rank = 0, nranks = 1; std::vector<int> owner; tnqs_allgather_fn ag_fn = nullptr; void* ag_ctx = nullptr;
     void* exch = nullptr; size_t exch_bytes = 0;      // device exchange buffer (nranks equal blocks): the host's (callback mode) or comm->exch_owned
@@ -153,6 +181,7 @@ void rescale_messages(State* s, int n, const int32_t* eu, const int32_t* ev);   
 void rescale_vertices(State* s, int n, const int32_t* verts);
 void symmetric_gauge(State* s, double regularization);
 void prof_collect(State* s);
+void materialize_pending_all(State* s);      // apply every deferred one-site gate (State::pend1)
 // sharding.cpp
 void rccl_unique_id(void* out128);
 void set_sharding_rccl(State* s, int rank, int nranks, const int32_t* owner, const void* unique_id128, int64_t exch_bytes);

@@ -260,8 +260,11 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
     HIPCHK(hipSetDevice(s->device));
     // the level schedule depends on the graph and the sequence only: the one of the default sequence is kept with the graph
     std::shared_ptr<const BPPlan> plan_p;
-    if (o && o->n_sequence != 0) plan_p = std::make_shared<const BPPlan>(make_plan(s, o));
-    else {
+    if (o && o->n_sequence > 0) plan_p = std::make_shared<const BPPlan>(make_plan(s, o));
+    else if (o && o->n_sequence < 0) {       // the reference's default order: also a function of the graph alone
+        if (!g.forest_plan) g.forest_plan = std::make_shared<const BPPlan>(make_plan(s, o));
+        plan_p = std::static_pointer_cast<const BPPlan>(g.forest_plan);
+    } else {
         if (!g.default_plan) g.default_plan = std::make_shared<const BPPlan>(make_plan(s, o));
         plan_p = std::static_pointer_cast<const BPPlan>(g.default_plan);
     }

@@ -22,28 +22,39 @@ static size_t round_size(size_t b) {
     size_t step = p >> 3;
     return (b + step - 1) / step * step;
 }
-Pool::~Pool() { trim(); }
+Pool::~Pool() { set_defer(false); trim(); }
 void Pool::trim() {
+    std::lock_guard<std::mutex> lk(mu_);
     for (auto& kv : free_) for (void* p : kv.second) (void)hipFree(p);
     free_.clear(); cached_ = 0;
 }
 void* Pool::alloc(size_t bytes, size_t* rounded) {
     size_t r = round_size(bytes);
     *rounded = r;
-    auto it = free_.find(r);
-    if (it != free_.end() && !it->second.empty()) {
-        void* p = it->second.back(); it->second.pop_back(); cached_ -= r; live_ += r; return p;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = free_.find(r);
+        if (it != free_.end() && !it->second.empty()) {
+            void* p = it->second.back(); it->second.pop_back(); cached_ -= r; live_ += r; return p;
+        }
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, r);
     if (e != hipSuccess) { trim(); e = hipMalloc(&p, r); }
     hipchk(e, "hipMalloc");
+    std::lock_guard<std::mutex> lk(mu_);
     live_ += r;
     return p;
 }
 void Pool::release(void* p, size_t rounded) {
+    std::lock_guard<std::mutex> lk(mu_);
     live_ -= rounded; cached_ += rounded;
-    free_[rounded].push_back(p);
+    if (defer_) deferred_.push_back({p, rounded}); else free_[rounded].push_back(p);
+}
+void Pool::set_defer(bool on) {
+    std::lock_guard<std::mutex> lk(mu_);
+    defer_ = on;
+    if (!on) { for (auto& d : deferred_) free_[d.second].push_back(d.first); deferred_.clear(); }
 }
 // ---------------------------------------------------------------------------------------------------------------
 // graph
@@ -102,8 +113,9 @@ static std::shared_ptr<Graph> make_graph(int nv, int ne, const int32_t* es, cons
 // recycled through these small free lists instead (a State still owns its stream and arena exclusively while it lives).
 static std::mutex g_recycle_mu;
 static std::vector<HostArena> g_spare_arenas;                              // pinned, device independent
-static std::vector<std::pair<int, hipStream_t>> g_spare_streams;           // (device, idle stream)
-static const size_t kMaxSpares = 8;
+struct SpareStream { int device; int hi; hipStream_t st; };
+static std::vector<SpareStream> g_spare_streams;                           // idle streams (hi = 1: created with the highest priority)
+static const size_t kMaxSpares = 16;
 HostArena acquire_arena() {
     HostArena ar{};
     { std::lock_guard<std::mutex> lk(g_recycle_mu); if (!g_spare_arenas.empty()) { ar = g_spare_arenas.back(); g_spare_arenas.pop_back(); ar.off = 0; } }
@@ -114,29 +126,55 @@ HostArena acquire_arena() {
     }
     return ar;
 }
-static hipStream_t acquire_stream(int device) {
+static hipStream_t acquire_stream(int device, int hi = 0) {
     {
         std::lock_guard<std::mutex> lk(g_recycle_mu);
         for (size_t i = 0; i < g_spare_streams.size(); ++i)
-            if (g_spare_streams[i].first == device) { hipStream_t st = g_spare_streams[i].second; g_spare_streams.erase(g_spare_streams.begin() + i); return st; }
+            if (g_spare_streams[i].device == device && g_spare_streams[i].hi == hi) { hipStream_t st = g_spare_streams[i].st; g_spare_streams.erase(g_spare_streams.begin() + (std::ptrdiff_t)i); return st; }
     }
     hipStream_t st = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (hi) { int least = 0, greatest = 0; HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest)); HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest)); }
+    else HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     return st;
 }
 
 State::~State() {
     if (own_stream && stream) (void)hipStreamSynchronize(stream);           // nothing of this State is in flight past this point
+    if (aux_stream) (void)hipStreamSynchronize(aux_stream);
+    for (auto q : hi_stream) if (q) (void)hipStreamSynchronize(q);
     keepalive.clear(); site.clear(); msg.clear();
     HostArena ar = arena; arena = HostArena{};
-    hipStream_t st = (own_stream && stream) ? stream : nullptr;
+    SpareStream st[4] = {{device, 0, (own_stream && stream) ? stream : nullptr}, {device, 0, aux_stream}, {device, 1, hi_stream[0]}, {device, 1, hi_stream[1]}};
     {
         std::lock_guard<std::mutex> lk(g_recycle_mu);
         if (ar.base && g_spare_arenas.size() < kMaxSpares) { ar.off = 0; g_spare_arenas.push_back(ar); ar.base = nullptr; }
-        if (st && g_spare_streams.size() < kMaxSpares) { g_spare_streams.push_back({device, st}); st = nullptr; }
+        for (auto& q : st) if (q.st && g_spare_streams.size() < kMaxSpares) { g_spare_streams.push_back(q); q.st = nullptr; }
     }
     if (ar.base) (void)hipHostFree(ar.base);
-    if (st) (void)hipStreamDestroy(st);
+    for (auto& q : st) if (q.st) (void)hipStreamDestroy(q.st);
+    for (hipEvent_t e : {ev_fork, ev_join, ev_stagger}) if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_ring) (void)hipEventDestroy(e);
+    for (auto e : ev_ring_b) (void)hipEventDestroy(e);
+}
+hipStream_t aux_stream_of(State* s) {
+    if (!s->aux_stream) {
+        s->aux_stream = acquire_stream(s->device);
+        s->hi_stream[0] = acquire_stream(s->device, 1); s->hi_stream[1] = acquire_stream(s->device, 1);
+        HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_stagger, hipEventDisableTiming));
+    }
+    return s->aux_stream;
+}
+// continue on another stream of this State: everything enqueued so far on the current one comes first
+void switch_stream(State* s, hipStream_t to) {
+    if (!to || to == s->stream) return;
+    if (s->ev_ring.size() < 8) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); s->ev_ring.push_back(e); s->ev_next = s->ev_ring.size() - 1; }
+    hipEvent_t e = s->ev_ring[s->ev_next]; s->ev_next = (s->ev_next + 1) % 8;
+    HIPCHK(hipEventRecord(e, s->stream));
+    HIPCHK(hipStreamWaitEvent(to, e, 0));
+    s->stream = to;
+    if (s->prof) s->prof->chain = false;
 }
 
 void sync(State* s) {

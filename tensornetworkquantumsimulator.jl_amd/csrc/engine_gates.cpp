@@ -1,5 +1,7 @@
 // engine_gates.cpp -- apply_gates (src/Apply/apply_gates.jl:46-143), simple_update as batched launches, truncate (src/truncate.jl).
 #include "engine_internal.hpp"
+#include <exception>
+#include <thread>
 
 namespace tnqs {
 
@@ -77,11 +79,11 @@ template <class T> static void norm_and_replace(State* s, std::vector<int>& vert
 }
 
 // d x d complex matrices, column-major [s' + d s] as (re, im) pairs
-static bool is_unitary(const double* m, int d) {
+static bool is_unitary(const double* m, int d, double tol) {
     for (int a = 0; a < d; ++a) for (int b = 0; b < d; ++b) {
         double re = 0, im = 0;                                    // (G^dagger G)[a][b] = sum_s conj(G[s][a]) G[s][b]
         for (int t = 0; t < d; ++t) { const double* x = m + 2 * (t + d * a); const double* y = m + 2 * (t + d * b); re += x[0] * y[0] + x[1] * y[1]; im += x[0] * y[1] - x[1] * y[0]; }
-        if (std::fabs(re - (a == b ? 1.0 : 0.0)) > 1e-13 || std::fabs(im) > 1e-13) return false;
+        if (std::fabs(re - (a == b ? 1.0 : 0.0)) > tol || std::fabs(im) > tol) return false;
     }
     return true;
 }
@@ -102,11 +104,14 @@ template <class T> static void apply_one_site_batch(State* s, const std::vector<
     // next two-site gate on the vertex absorbs it.  Anything else is applied now, composed with what was pending on the vertex.
     std::vector<std::vector<double>> composed; composed.reserve(gates_in.size());
     std::vector<Gate1> gates;
-    const bool may_defer = !force && defer_site1() && s->nranks == 1;      // (sharded handles apply at once: the pending set must be identical on all ranks)
+    const bool may_defer = !force && defer_site1() && (s->nranks == 1 || s->in_apply);      // (sharded handles: only inside apply_gates, State::in_apply)
+    // unitary to what the state's precision resolves: a gate the caller built in complex64 is unitary to ~1e-7 only, and BP messages of a
+    // ComplexF32 state do not see a deviation of that size either
+    const double utol = s->dtype == TNQS_C64 ? 1e-6 : 1e-13;
     for (auto& g1 : gates_in) {
         const int d = s->d[g1.v];
         std::vector<double>& pend = s->pend1[g1.v];
-        if (may_defer && is_unitary(g1.mat, d) && (!normalize || s->unit_norm[g1.v])) {
+        if (may_defer && is_unitary(g1.mat, d, utol) && (!normalize || s->unit_norm[g1.v])) {
             pend = pend.empty() ? std::vector<double>(g1.mat, g1.mat + 2 * (size_t)d * d) : matmul_dd(g1.mat, pend.data(), d);
             s->stats.n_deferred_1site += 1;
             continue;
@@ -206,6 +211,9 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         absorbed.push_back(matmul_dd(g2.mat, kron.data(), dd));
         g2.mat = absorbed.back().data();
     }
+    // forked batch (apply_two_site_forked): the per-gate chains run on the half's high-priority stream, the tensor passes on its ordinary one
+    hipStream_t const heavy_stream = s->stream; hipStream_t const chain_stream = s->chain_stream;
+    struct RestoreStream { State* s; hipStream_t h; ~RestoreStream() { s->stream = h; } } restore_stream{s, heavy_stream};
     HostTimer ht_a(3);                 // TNQS_HOST_TIMING=1: host time of the batch up to the first read-back (3), between the read-backs (4), after them (5)
     if (!ao.normalize_tensors) {       // without the final normalisation the result scales with the inputs: apply pending factors first
         std::vector<int> vs; for (auto& g2 : gates) { vs.push_back(g2.v1); vs.push_back(g2.v2); }
@@ -235,6 +243,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             }
         }
     }
+    switch_stream(s, chain_stream);
     std::vector<int> h_flags(2 * envs.size() + 2, 0);
     Buf d_flags = dalloc(s, h_flags.size() * sizeof(int));
     Buf env_arena;
@@ -283,6 +292,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             fused_M[q] = c.steps[0].second; c.steps.erase(c.steps.begin());
         }
     }
+    switch_stream(s, heavy_stream);
+    if (s->fork_role == 2) { s->fork_sync->wait(); HIPCHK(hipStreamWaitEvent(s->stream, s->fork_sync->ev, 0)); }      // forked batch, half B: behind A's Gram pass
     run_chains<T>(s, chains, TNQS_PROF_GATE_MODEPROD);
     // ---- 3. G = psi~^dagger psi~ over the outer legs, f64 accumulation (replaces the thin QR, simple_update.jl:45-48) --
     std::vector<GramJob> jobs;
@@ -304,6 +315,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         for (size_t q = 0; q < jf16.size(); ++q) jobs[idf16[q]] = jf16[q];
         for (size_t q = 0; q < jp.size(); ++q) jobs[idp[q]] = jp[q];
     }
+    if (s->fork_role == 1) { HIPCHK(hipEventRecord(s->fork_sync->ev, s->stream)); s->fork_sync->signal(); }      // forked batch, half A: B's tensor passes may start
+    switch_stream(s, chain_stream);
     std::vector<Buf> GA(sj.size()), GV(sj.size());
     auto nof = [&](size_t i) { return sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]; };
     // G slots: in the sharded case every rank needs G1 and G2 of the gates it takes part in -> all-gather all of them (the same layout
@@ -595,8 +608,12 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             one_trip = jacobi_lds(jacobi_lds_bytes(Mr, Nc, false, esz)) > 0 && Mr <= 256;
         }
         const int* st_flags = nullptr; const int* st_chol = nullptr;
+        // the four staged read-backs of a batch (flags, Cholesky flags, info, truncation errors) are consumed together after ONE synchronisation:
+        // room for all of them is made up front, so that none of them can wrap the arena on top of another (round-3 advisor finding)
+        const size_t rb_bytes = round256(2 * envs.size() * sizeof(int)) + round256(sj.size() * sizeof(int)) + round256((size_t)npg * 32) + round256((size_t)npg * 8) + 1024;
         if (one_trip) {
             svd_and_finish(nullptr);
+            reserve_readback(s, rb_bytes);
             st_flags = !envs.empty() ? readback<int>(s, d_flags->p, 2 * envs.size()) : nullptr;
             st_chol = !sj.empty() ? readback<int>(s, d_cholfail->p, sj.size()) : nullptr;
             ht_a.stop();
@@ -606,6 +623,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             if (chol_failures()) { redo_with_eigen(); svd_and_finish(hinfo.data()); read_results(); }
         } else {
             // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
+            reserve_readback(s, rb_bytes);
             const int* st_info = npg ? readback<int>(s, d_info_all->p, (size_t)npg * 8) : nullptr;
             st_flags = !envs.empty() ? readback<int>(s, d_flags->p, 2 * envs.size()) : nullptr;
             st_chol = !sj.empty() ? readback<int>(s, d_cholfail->p, sj.size()) : nullptr;
@@ -761,6 +779,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     // every gate's status is checked before anything of the handle is replaced: a failing batch leaves the state as it was
     for (int gi = 0; gi < ng; ++gi) if (info[8 * gi + 3] != 0) throw Err(TNQS_ERR_NUMERIC, "simple_update: internal bond capacity exceeded");
     // ---- 5. psi' = (psi x_outer P) x_(s,b) X  (simple_update.jl:62-64, net effect of gauge + ungauge) ----------------
+    switch_stream(s, heavy_stream);
     std::vector<Chain> pch(own_idx.size());
     for (size_t q = 0; q < own_idx.size(); ++q) {
         const SiteJob& j = sj[own_idx[q]];
@@ -888,10 +907,94 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     soft_sync(s);   // workspace of this batch goes back to the pool at the next stream synchronisation (the BP update's first read-back)
 }
 
+// ---- a batch as two halves on two streams ---------------------------------------------------------------------------------------
+// Between the Gram pass and the epilogue of a batch lies a chain of one-workgroup-per-gate kernels (Cholesky, theta, its SVD, V recovery,
+// truncation: ~2 ms per batch whatever its size) during which the chip idles.  The gates of a batch are independent of each other, so the
+// batch is cut in two halves that run the SAME code on two streams, driven by two host threads: while one half sits in its chain, the
+// other half's gauge / Gram / epilogue passes have the chip.  Half B works on a clone of the handle (its own stream, staging arena,
+// keep-alive list, profiler; the buffer pool is shared and defers every release until the join, see Pool) and its results are merged
+// back afterwards; the main stream waits for B's stream before anything else is enqueued.  Taken when the heavy passes are long enough
+// to hide a chain (single rank; TNQS_FORK=0 switches it off, TNQS_FORK=1 forks every batch of two or more gates -- the route tests).
+static std::unique_ptr<State> fork_state(State* s) {
+    auto b = std::make_unique<State>();
+    b->g = s->g; b->dtype = s->dtype; b->real_io = s->real_io; b->device = s->device; b->d = s->d; b->chi = s->chi;
+    b->site = s->site; b->sscale = s->sscale; b->msg = s->msg; b->pool = s->pool;
+    b->prof = std::make_shared<Prof>(); b->prof->on = s->prof->on;
+    b->pend1 = s->pend1; b->unit_norm = s->unit_norm; b->in_apply = s->in_apply;
+    b->stream = aux_stream_of(s); b->own_stream = false;
+    return b;
+}
+template <class T> static void apply_two_site_forked(State* s, const std::vector<Gate2>& gates, const tnqs_apply_opts& ao, double* errs) {
+    static const int fork_mode = [] { const char* e = std::getenv("TNQS_FORK"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();      // 0: never, 2: every batch of two or more gates (tests), unset: by size
+    double elems = 0;
+    for (auto& g2 : gates) elems += (double)site_dims(s, g2.v1).n + (double)site_dims(s, g2.v2).n;
+    // Which share f goes to half A.  Model of a batch (ms; measured on the 20x20 chi = 32 layer): gauge + Gram passes h = 9.4e-9 per
+    // element, epilogue e = 3.5e-9 per element, chain c = 2.0 whatever the size.  Unforked: h + c + e.  Forked, with B's passes behind A's Gram:
+    // h f + max(c, h (1 - f)) + max(c, e f) + e (1 - f) -- A's chain under B's gauge + Gram, B's chain under A's epilogue.  Both chains are hidden
+    // when h (1 - f) >= c and e f >= c (f ~ 0.72 at 20x20); small batches gain nothing (the two chains would merely run one after the other).
+    double f = 0.5; bool take = fork_mode == 2 && gates.size() >= 2;
+    if (fork_mode == 1 && gates.size() >= 8 && s->nranks == 1) {
+        const double h = 9.4e-9 * elems, e = 3.5e-9 * elems, c = 2.0;
+        double best = h + c + e; const double unforked = best;
+        for (double t = 0.40; t <= 0.801; t += 0.02) { const double tt = h * t + std::max(c, h * (1 - t)) + std::max(c, e * t) + e * (1 - t); if (tt < best) { best = tt; f = t; } }
+        take = best < 0.88 * unforked;       // (at 0.91 -- a 14 x 14 lattice -- the measured layer was 1 % slower forked than unforked)
+    }
+    if (!take || s->nranks > 1) { apply_two_site_batch<T>(s, gates, ao, errs); return; }
+    // half A: the first gates up to the share f of the elements
+    size_t na = 0; { double acc = 0; while (na + 1 < gates.size() && acc < f * elems) { acc += (double)site_dims(s, gates[na].v1).n + (double)site_dims(s, gates[na].v2).n; ++na; } }
+    na = std::max<size_t>(1, std::min(na, gates.size() - 1));
+    const std::vector<Gate2> ga(gates.begin(), gates.begin() + (std::ptrdiff_t)na), gb(gates.begin() + (std::ptrdiff_t)na, gates.end());
+    std::unique_ptr<State> b = fork_state(s);
+    HIPCHK(hipEventRecord(s->ev_fork, s->stream));
+    HIPCHK(hipStreamWaitEvent(b->stream, s->ev_fork, 0));                 // B starts after everything enqueued so far (the BP update's messages)
+    s->pool->set_defer(true);
+    State::ForkSync fs; fs.ev = s->ev_stagger;
+    s->fork_sync = &fs; s->fork_role = 1; b->fork_sync = &fs; b->fork_role = 2;
+    s->chain_stream = s->hi_stream[0]; b->chain_stream = s->hi_stream[1]; b->ev_ring.swap(s->ev_ring_b); b->ev_next = 0;
+    std::exception_ptr ea, eb;
+    std::thread th([&] {
+        try { HIPCHK(hipSetDevice(b->device)); apply_two_site_batch<T>(b.get(), gb, ao, errs); }
+        catch (...) { eb = std::current_exception(); }
+    });
+    try { apply_two_site_batch<T>(s, ga, ao, errs); } catch (...) { ea = std::current_exception(); }
+    if (!fs.recorded) { (void)hipEventRecord(fs.ev, s->stream); fs.signal(); }      // A failed before its Gram pass: B must not wait for ever
+    th.join();
+    s->fork_sync = nullptr; s->fork_role = 0; s->chain_stream = nullptr; b->ev_ring.swap(s->ev_ring_b);
+    // join: the main stream continues after B's epilogue; only then may anything released meanwhile be handed out again
+    (void)hipEventRecord(s->ev_join, b->stream);
+    (void)hipStreamWaitEvent(s->stream, s->ev_join, 0);
+    if (!ea && !eb) {
+        const Graph& g = *s->g;
+        for (auto& g2 : gb) {
+            for (int v : {g2.v1, g2.v2}) { s->site[v] = b->site[v]; s->sscale[v] = b->sscale[v]; s->pend1[v] = b->pend1[v]; s->unit_norm[v] = b->unit_norm[v]; }
+            const int e = g.edge(g2.v1, g2.v2);
+            s->chi[e] = b->chi[e]; s->msg[2 * e] = b->msg[2 * e]; s->msg[2 * e + 1] = b->msg[2 * e + 1];
+        }
+        s->stats.n_two_site += b->stats.n_two_site; s->stats.n_chol_fallbacks += b->stats.n_chol_fallbacks; s->stats.n_qr2_sites += b->stats.n_qr2_sites;
+        s->stats.n_lowrank_svd += b->stats.n_lowrank_svd; s->stats.n_tall_svd += b->stats.n_tall_svd; s->stats.n_svd_sweeps += b->stats.n_svd_sweeps;
+        s->stats.n_forked_batches += 1;
+    }
+    // B's workspaces and descriptor buffers live until the main stream has drained past the join
+    for (auto& k : b->keepalive) s->keepalive.push_back(k);
+    b->keepalive.clear(); soft_sync(s);
+    {   // B's profiler scopes: events recorded on its stream, collected with the others
+        Prof& P = *s->prof; Prof& Q = *b->prof;
+        for (int c = 0; c < TNQS_PROF_NCLASSES; ++c) { P.cls[c].launches += Q.cls[c].launches; P.cls[c].bytes += Q.cls[c].bytes; P.cls[c].flops += Q.cls[c].flops; P.cls[c].ms += Q.cls[c].ms; }
+        for (auto& pe : Q.pending) P.pending.push_back(pe);
+        Q.pending.clear();
+        for (auto e : Q.ev_free) P.ev_free.push_back(e);
+        Q.ev_free.clear(); P.chain = false;
+    }
+    b.reset();
+    s->pool->set_defer(false);
+    if (ea) std::rethrow_exception(ea);
+    if (eb) std::rethrow_exception(eb);
+}
+
 template <class T> static void flush_batch(State* s, std::vector<Gate1>& b1, std::vector<Gate2>& b2, const tnqs_apply_opts& ao, double* errs) {
     if (b1.empty() && b2.empty()) return;
     apply_one_site_batch<T>(s, b1, ao.normalize_tensors != 0, false);
-    apply_two_site_batch<T>(s, b2, ao, errs);
+    apply_two_site_forked<T>(s, b2, ao, errs);
     s->stats.n_batches += 1;
     b1.clear(); b2.clear();
     soft_sync(s);
@@ -927,6 +1030,7 @@ template <class T> static void apply_gates_t(State* s, int ngates, const int32_t
     }
     std::set<int> affected, batch_verts;
     std::vector<Gate1> b1; std::vector<Gate2> b2;
+    struct InApply { State* s; explicit InApply(State* st) : s(st) { s->in_apply = true; } ~InApply() { s->in_apply = false; } } in_apply_guard(s);
     for (int i = 0; i < ngates; ++i) {
         const int nv = nverts[i]; const int32_t* vs = verts + voff[i];
         bool need = false;
@@ -944,6 +1048,7 @@ template <class T> static void apply_gates_t(State* s, int ngates, const int32_t
     }
     flush_batch<T>(s, b1, b2, ao, errs);
     if (ao.update_cache) bp_update_t<T>(s, bp, nullptr, nullptr);                                   // :93-95
+    if (s->nranks > 1) materialize_pending_all(s);      // sharded: nothing stays pending between calls (State::in_apply)
     sync(s);                                                                                        // the call returns with the stream drained
 }
 
@@ -976,7 +1081,7 @@ template <class T> static void truncate_t(State* s, int maxdim, double cutoff, i
             idmats.push_back(ident(s->d[pr.first] * s->d[pr.second]));
             b2.push_back(Gate2{pr.first, pr.second, idmats.back().data(), 0});
         }
-        apply_two_site_batch<T>(s, b2, ao, nullptr);
+        apply_two_site_forked<T>(s, b2, ao, nullptr);
         if (!b2.empty()) s->stats.n_batches += 1;
         bp_update_t<T>(s, bp, nullptr, nullptr);                               // :28 / :34
     };

@@ -76,11 +76,13 @@ struct HostTimer {
     static double acc[8]; static long cnt[8];
     int k; std::chrono::steady_clock::time_point t0; bool on;
     explicit HostTimer(int kk) : k(kk), t0(std::chrono::steady_clock::now()), on(true) {}
-    void stop() { if (on) { acc[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); cnt[k]++; on = false; } }
+    void stop() { if (on) { static std::mutex mu; std::lock_guard<std::mutex> lk(mu); acc[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); cnt[k]++; on = false; } }
     ~HostTimer() { stop(); }
 };
 
 void sync(State* s);                                   // stream synchronise + release of the batch's descriptor buffers
+hipStream_t aux_stream_of(State* s);                  // second stream of a forked gate batch (+ its events), created / recycled with the State
+void switch_stream(State* s, hipStream_t to);        // continue on another stream of this State, ordered behind the current one (null / same: no-op)
 HostArena acquire_arena();                             // a recycled or freshly pinned 32 MiB arena (engine_core.cpp)
 // Read-back through the pinned staging arena: the copy is enqueued and the staged host pointer returned; it holds the data once the stream
 // has been synchronised (a read-back into pageable memory is staged by the runtime and BLOCKS per call).  The staged bytes stay valid until the
@@ -95,6 +97,13 @@ template <class X> const X* readback(State* s, const void* dsrc, size_t count) {
     char* h = ar.base + ar.off; ar.off += aligned;
     if (bytes) HIPCHK(hipMemcpyAsync(h, dsrc, bytes, hipMemcpyDeviceToHost, s->stream));
     return reinterpret_cast<const X*>(h);
+}
+// room for `bytes` of staged read-backs without a wrap in between (several read-backs that are consumed after one synchronisation)
+inline void reserve_readback(State* s, size_t bytes) {
+    HostArena& ar = s->arena;
+    if (!ar.base) ar = acquire_arena();
+    if (bytes > ar.cap) throw Err(TNQS_ERR_UNSUPPORTED, "read-backs of one batch too large for the staging arena");
+    if (ar.off + bytes > ar.cap) { HIPCHK(hipStreamSynchronize(s->stream)); ar.off = 0; }
 }
 // End of a phase WITHOUT draining the stream: everything in the keep-alive list so far may go once the stream has been synchronised for some
 // other reason (the next read-back), so the host can start preparing the next phase while this one's last kernels still run.

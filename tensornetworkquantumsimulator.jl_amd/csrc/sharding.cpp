@@ -68,6 +68,7 @@ void set_sharding_rccl(State* s, int rank, int nranks, const int32_t* owner, con
     if (nranks > 1 && !owner) throw Err(TNQS_ERR_INVALID, "set_sharding_rccl: vertex_owner is required for nranks > 1");
     if (owner) for (int v = 0; v < s->g->nv; ++v) if (owner[v] < 0 || owner[v] >= nranks) throw Err(TNQS_ERR_INVALID, "set_sharding_rccl: owner out of range");
     hipchk(hipSetDevice(s->device), "hipSetDevice");
+    materialize_pending_all(s);      // deferred one-site gates are applied while every tensor is still here (see tnqs_set_sharding)
     // everything that can fail locally happens BEFORE the collective communicator set-up: a rank that threw after ncclCommInitRank would
     // leave its peers joined to a communicator that is about to be destroyed
     RcclApi& api = rccl();

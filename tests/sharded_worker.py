@@ -87,7 +87,28 @@ def main():
         psi0 = tn.tensornetworkstate(dtype, lambda v: "↑", g)
         nlayers = 8
 
+    if mode == "pendshard":
+        # round-3 advisor finding: one-site gates deferred on an UNSHARDED handle (State::pend1) must be applied when the handle is sharded
+        # afterwards -- otherwise the owner of a vertex applies and clears them in its accessors while the partner rank of a later cross-rank
+        # gate still folds them into the gate matrix.  Evolve unsharded, end on a one-site layer (deferred: the tensors have unit norm after
+        # the two-site gates), shard, read <Z> on the owners (accessor), then two more layers.
+        dtype = np.complex64
+        psi0 = tn.random_tensornetworkstate(dtype, g, bond_dimension=2, seed=11)
+        tail = [("Rx", [v], 0.3 + 0.01 * i) for i, v in enumerate(g.vertices)]
+
+        def pre(shard_it):
+            b = tn.update(tn.BeliefPropagationCache(psi0, device=dev), **bpkw)
+            info = {}
+            b, _ = tn.apply_gates(layer + tail, b, apply_kwargs=kw, bp_update_kwargs=bpkw, info=info)
+            assert info["n_deferred_1site"] >= len(tail), info
+            if shard_it:
+                tn.shard(b, rank, world, exch_bytes=8 << 20, max_chi=64)
+                tn.expect_all(b, "Z")          # an accessor that only touches owned vertices
+            return b
+
     def sharded_factory():
+        if mode == "pendshard":
+            return pre(True)
         b = tn.BeliefPropagationCache(tn.tensornetworkstate(dtype, lambda v: "↑", g), device=dev)
         tn.shard(b, rank, world, exch_bytes=(64 << 20) if big else (8 << 20), max_chi=64)
         for v in g.vertices:
@@ -137,7 +158,7 @@ def main():
         ezg_full, sg = np.zeros(0), np.zeros(0)
     nex = bs._shard.n_exchanges
     if rank == 0:
-        bu, eu = run(lambda: tn.BeliefPropagationCache(psi0, device=dev), layer, kw, bpkw, nlayers)
+        bu, eu = run((lambda: pre(False)) if mode == "pendshard" else (lambda: tn.BeliefPropagationCache(psi0, device=dev)), layer, kw, bpkw, nlayers)
         ezu = tn.expect_all(bu, "Z")
         spu = []
         for (a, b) in g.edges:

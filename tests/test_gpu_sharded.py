@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("dt,nranks", [("c128", 2), ("c64", 2), ("chi32", 2), ("illc128", 2), ("c128", 4), ("illc128", 4),
-                                       ("z6chi16", 2), ("z4chi64", 2)])
+                                       ("z6chi16", 2), ("z4chi64", 2), ("pendshard", 2)])
 def test_sharded_apply_gates_matches_single_rank(tmp_path, dt, nranks):
     """2 and 4 ranks (with 4, ranks own three or four vertices each and sit out whole colour batches -- every collective must still be
     issued by all of them).  A one-off run with 8 ranks of all four cases gave the same deviations."""

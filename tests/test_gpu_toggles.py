@@ -49,7 +49,7 @@ def test_lowrank_theta_route_matches_the_full_svd():
 
 @pytest.mark.parametrize("switch", ["TNQS_NO_CHOL", "TNQS_NO_SMALLSVD", "TNQS_JACOBI_GLOBAL", "TNQS_NO_PAIR", "TNQS_NO_TSHARE", "TNQS_NO_FUSED_GRAM",
                                     "TNQS_NO_APPLY64", "TNQS_NO_MFMA", "TNQS_EAGER_SCALE", "TNQS_NO_PREFIX", "TNQS_NO_ROWGEMM32", "TNQS_NO_3M",
-                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE", "TNQS_PAIR16_HALF"])
+                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE", "TNQS_PAIR16_HALF", "TNQS_FORK"])
 def test_alternative_routes_match_the_default(switch):
     """every documented switch selects an alternative route of the same algorithm: all-eigen factorisation instead
     of Cholesky, Gram-eigen instead of the small-SVD route, global-memory Jacobi, single-leg mode products, per-message BP products,
@@ -79,7 +79,7 @@ def test_staging_arena_overflow_keeps_descriptors_alive():
         assert ref[name]["z"] == alt[name]["z"], name
 
 
-@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_DEFER_1SITE"])
+@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_DEFER_1SITE", "TNQS_FORK"])
 def test_bulk_shape_routes_match(switch):
     """the chi = 32 bulk shape (BASELINE configs[1]): the third gauge leg absorbed inside the f64 Gram kernel (kernels_gate.hip) against the
     separate single-leg pass + plain Gram; ranks of the R factors left on the device against read back; three- against four-multiplication
@@ -91,6 +91,8 @@ def test_bulk_shape_routes_match(switch):
     dz = float(np.max(np.abs(np.array(ref["z"]) - np.array(alt["z"])))); dsp = float(np.max(np.abs(np.array(ref["spectra"]) - np.array(alt["spectra"]))))
     print(switch, "max |dZ|", dz, " spectra", dsp, " max |derr|", float(np.max(np.abs(ea - eb))))
     assert dz < 1e-5 and dsp < 1e-5
+    if switch == "TNQS_FORK":               # TNQS_FORK=1: every batch as two halves on two streams / two host threads (small lattices never fork by size)
+        assert ref["forked"] == 0 and alt["forked"] == 4        # the four colour batches (the fifth batch holds the one-site gates only)
     if switch == "TNQS_NO_GAUGE_GRAM":      # the fused route must actually have been taken: it saves the single-leg launches of the gauge
         assert ref["modeprod_launches"] < alt["modeprod_launches"] and ref["gram_launches"] > alt["gram_launches"]
 

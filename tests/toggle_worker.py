@@ -60,13 +60,14 @@ def chi32():
     bpc = tn.update(bpc, maxiter=3, tolerance=None)
     layer = [("Rx", [v], 0.05) for v in g.vertices] + [("Rzz", [a, b], 0.3) for grp in tn.edge_color(g, 4) for (a, b) in grp]
     tn.profile_enable(bpc, True)
-    b2, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True), bp_update_kwargs=dict(maxiter=3, tolerance=None))
+    info = {}
+    b2, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True), bp_update_kwargs=dict(maxiter=3, tolerance=None), info=info)
     prof = tn.profile_get(b2)
     sp = []
     for (a, b) in g.edges:
         m = b2.message((a, b)).astype(np.complex128); w = np.linalg.eigvalsh((m + m.conj().T) / 2); sp += (w / w.sum()).tolist()
     print(json.dumps(dict(errs=errs.tolist(), z=[float(np.real(x)) for x in tn.expect_all(b2, "Z")], dims=[b2.bond_dim(a, b) for a, b in g.edges], spectra=sp,
-                          modeprod_launches=prof["gate_modeprod"]["launches"], gram_launches=prof["gate_gram"]["launches"])))
+                          modeprod_launches=prof["gate_modeprod"]["launches"], gram_launches=prof["gate_gram"]["launches"], forked=info["n_forked_batches"], batches=info["n_batches"])))
 
 
 def c128():
