@@ -119,8 +119,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--L", type=int, default=20)
-    ap.add_argument("--chi", type=int, default=32)
+    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2",
+                    help="BASELINE.json configuration: c2 = configs[1] (L x L TFIM, chi 32; the headline metric), c4 = configs[3] (L^3 periodic cubic 3-D Ising "
+                         "layer, chi 16; full size L = 10 needs 8 GPUs), c5 = configs[4] (L x L TFIM, chi 64; full size L = 32 needs 8 GPUs)")
+    ap.add_argument("--L", type=int, default=0, help="lattice side (default: the BASELINE size of the configuration: 20 / 10 / 32)")
+    ap.add_argument("--chi", type=int, default=0, help="bond dimension (default: 32 / 16 / 64)")
+    ap.add_argument("--host-init", action="store_true", help="c4 / c5: generate the synthetic state with numpy on the host instead of on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--evolved", type=int, default=0, metavar="N",
                     help="also time the same lattice on a PHYSICALLY evolved state: N layers of the TFIM circuit at dt = 0.1 from the product state "
@@ -146,11 +150,28 @@ def main():
         dist.init_process_group(os.environ.get("TNQS_BENCH_BACKEND", "nccl"))
     import tnqs_amd as tn
 
-    L, chi, d = args.L, args.chi, 2
+    cfg = args.config
+    L = args.L or {"c2": 20, "c4": 10, "c5": 32}[cfg]
+    chi = args.chi or {"c2": 32, "c4": 16, "c5": 64}[cfg]
+    d = 2
     dtype = np.complex64
-    g = tn.named_grid((L, L))
-    groups = tn.edge_color(g, 4)
-    layer = tfim_layer(tn, g, groups)
+    if cfg == "c4":       # examples/3dIsing_dynamics.jl:15-26: Rz(h dt) on every vertex, Rxx(2 J dt) per edge colour, Rz(h dt) again; h = J = -1, dt = 0.04
+        g = tn.named_grid((L, L, L), periodic=True)
+        groups = tn.edge_color(g)
+        layer = [("Rz", [v], -0.04) for v in g.vertices]
+        for grp in groups:
+            layer += [("Rxx", [a, b], -0.08) for (a, b) in grp]
+        layer += [("Rz", [v], -0.04) for v in g.vertices]
+        zdeg = 6
+        workload = (f"{L}x{L}x{L} periodic cubic lattice, 3-D Ising Trotter layer (Rz + {len(groups)} edge colours of Rxx + Rz; examples/3dIsing_dynamics.jl), chi={chi}, "
+                    f"ComplexF32, apply_gates incl. BP updates; BASELINE.json configs[3]" + ("" if L == 10 else f" at L = {L} instead of 10"))
+    else:
+        g = tn.named_grid((L, L))
+        groups = tn.edge_color(g, 4)
+        layer = tfim_layer(tn, g, groups)
+        zdeg = 4
+        workload = (f"{L}x{L} square-lattice TFIM Trotter layer (Rx + 4 edge colours of Rzz), chi={chi}, ComplexF32, apply_gates incl. BP updates; "
+                    + ("BASELINE.json configs[1]" if cfg == "c2" else "BASELINE.json configs[4]" + ("" if L == 32 else f" at L = {L} instead of 32")))
     n2 = g.ne()
     apply_kwargs = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
 
@@ -176,11 +197,24 @@ def main():
                 tdist.shard(bpc, rank, world, transport="callback")
         else:
             tdist.shard(bpc, rank, world)
-    for v, t in random_state_tensors(g, chi, d, 1234, dtype, wanted=(None if world == 1 else bpc.owns)):
-        if isinstance(t, tuple):
-            bpc._declare_dims(v, t)
-        else:
-            bpc._set_tensor(v, t)
+    # memory: a rank holds its own site tensors; a layer needs about three more copies of them at its peak (new tensors of a batch, the gauge
+    # ping-pong buffers / BP partial products, Gram partials) -- refuse before allocating instead of dying in the middle of the upload
+    own_bytes = sum(8 * d * chi ** g.degree(v) for v in g.vertices if (world == 1 or bpc.owns(v)))
+    free_b, total_b = torch.cuda.mem_get_info(local if world > 1 else 0)
+    mem = {"site_tensor_GiB_this_rank": round(own_bytes / 2 ** 30, 2), "estimated_peak_GiB": round(4.0 * own_bytes / 2 ** 30 + 2.0, 2), "free_GiB": round(free_b / 2 ** 30, 1)}
+    if 4.0 * own_bytes + (2 << 30) > free_b:
+        raise SystemExit(f"bench.py: {workload}: rank {rank} of {world} would hold {mem['site_tensor_GiB_this_rank']} GiB of site tensors (estimated peak "
+                         f"{mem['estimated_peak_GiB']} GiB) but the device has {mem['free_GiB']} GiB free -- use more GPUs (--gpus) or a smaller --L")
+    if cfg == "c2" or args.host_init:
+        for v, t in random_state_tensors(g, chi, d, 1234, dtype, wanted=(None if world == 1 else bpc.owns)):
+            if isinstance(t, tuple):
+                bpc._declare_dims(v, t)
+            else:
+                bpc._set_tensor(v, t)
+    else:       # the big configurations: generated on the device, rank by rank (counter-based: the same state whatever the sharding)
+        for v in g.vertices:
+            z = g.degree(v)
+            bpc._set_random(v, [chi] * z, 1234, scale=1.0 / np.sqrt(d * float(chi) ** z))
     sweeps, updates, svd_sweeps = [], [], []
     for _ in range(args.warmup):
         info = {}
@@ -220,6 +254,12 @@ def main():
                  "gate_modeprod": "tnqs::mfma_pair_kernel" + tf, "bp_fused": "tnqs::mfma_gram32_fused_kernel",
                  "bp_gram": "tnqs::mfma_gram32_kernel", "gate_gram": "tnqs::mfma_gram64_f64_kernel<%s, true>" % ("true" if m3 else "false"),
                  "gate_apply": "tnqs::mfma_rowgemm_kernel<2, 2, 2, %s>" % ("true" if m3 else "false"), "bp_pairgram": "tnqs::mfma_pair_gram2_kernel" + tf}
+    if cfg == "c4":
+        KERNEL_OF.update({"bp_pair": "tnqs::mfma_pair16_kernel / tnqs::mfma_pair16w_kernel", "gate_modeprod": "tnqs::mfma_pair16_kernel / tnqs::mfma_pair16w_kernel",
+                          "bp_pairgram": "tnqs::mfma_pair_gram2x16_kernel", "gate_gram": "tnqs::mfma_gauge_gram32_kernel"})
+    elif cfg == "c5":
+        KERNEL_OF.update({"bp_modeprod": "tnqs::mfma_rowgemm_kernel<2, 2, 1>", "gate_modeprod": "tnqs::mfma_rowgemm_kernel<2, 2, 1>", "bp_gram": "tnqs::mfma_gram64_kernel",
+                          "gate_gram": "tnqs::mfma_gram128_f64_kernel", "gate_apply": "tnqs::mfma_rowgemm_kernel<4, 4, 2>"})
     traffic_db, traffic_src = profile_db(os.environ.get("TNQS_BENCH_PMC_PROFILE", "r3_pmc_traffic.json"))
     mfma_db, mfma_src = profile_db(os.environ.get("TNQS_BENCH_MFMA_PROFILE", "r3_mfma_util.json"))
     dom = max(prof, key=lambda k: prof[k]["ms"])
@@ -230,14 +270,15 @@ def main():
         tflops, gbs = p["flops"] / sec / 1e12, p["bytes"] / sec / 1e9
         ai = p["flops"] / p["bytes"]
         kern = KERNEL_OF.get(dom)
-        traffic = traffic_db.get(kern, {}).get("hbm_bytes_per_launch") if (world == 1 and L == 20 and chi == 32) else None
+        headline = world == 1 and cfg == "c2" and L == 20 and chi == 32      # the committed counter passes are of that command
+        traffic = traffic_db.get(kern, {}).get("hbm_bytes_per_launch") if headline else None
         common = {"kernel_class": dom, "kernel": kern, "avg_launch_ms": round(p["ms"] / max(1, p["launches"]), 4), "launches": p["launches"],
                   "arithmetic_intensity_flop_per_B": round(ai, 2), "alg_bytes_per_launch": round(p["bytes"] / max(1, p["launches"])),
                   "alg_TFLOPs": round(tflops, 2), "alg_GBps": round(gbs, 1), "traffic": traffic,
                   # matrix-core utilisation of the same kernel from the committed counter pass (profiles/r2_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES /
                   # (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs)); like `traffic` it is a profile of this command, not re-measured in this run
-                  "mfma_busy": (mfma_db.get(kern, {}).get("mfma_busy") if (world == 1 and L == 20 and chi == 32) else None),
-                  "mfma_executed_TFLOPs": (mfma_db.get(kern, {}).get("mfma_tflops") if (world == 1 and L == 20 and chi == 32) else None),
+                  "mfma_busy": (mfma_db.get(kern, {}).get("mfma_busy") if headline else None),
+                  "mfma_executed_TFLOPs": (mfma_db.get(kern, {}).get("mfma_tflops") if headline else None),
                   # `achieved` counts ALGORITHMIC flops (8 per complex multiply-add).  The plane kernels form the complex product with Gauss' three
                   # real multiplications (csrc/mfma_common.hpp, CAcc32): the matrix cores execute 0.75 x the algorithmic count, so the
                   # algorithmic rate can exceed what `peak` allows a four-multiplication kernel; executed / peak is the matrix-core load
@@ -260,21 +301,33 @@ def main():
     phases = {"ms_per_bp_sweep": round(bp_ms / max(1.0, float(np.mean(sweeps))), 3), "ms_per_colour_batch": round(gate_ms / max(1, len(groups)), 3),
               "bp_ms_per_step": round(bp_ms, 2), "gate_ms_per_step": round(gate_ms, 2)}
 
+    # both flop counts of a step (round-3 verdict): what the engine's algorithm executes (algorithmic flops booked per kernel class: 3u instead of 4u per
+    # message through shared pair products, Gram / Cholesky instead of Householder QR) and SURVEY.md 8(d)'s count of the REFERENCE's contraction order
+    # with the bulk formulas (per gate 2 (2 n d + 3 d^2) chi^(z+1) cMAC, per message (n + 1) d chi^(z+1) cMAC, n = z - 1; an upper bound on open lattices)
+    nz = zdeg - 1
+    ref_flops = 8.0 * (n2 * 2 * (2 * nz * d + 3 * d * d) * float(chi) ** (zdeg + 1) + float(np.mean(sweeps)) * 2 * n2 * (nz + 1) * d * float(chi) ** (zdeg + 1))
+    exe_flops = sum(v["flops"] for v in prof.values()) / nst
+    flop_counts = {"executed_algorithm_TFLOP_per_step": round(exe_flops / 1e12, 3), "executed_algorithm_TFLOPs": round(exe_flops / (ms_per_step * 1e-3) / 1e12, 2),
+                   "reference_order_TFLOP_per_step": round(ref_flops / 1e12, 3), "reference_order_TFLOPs": round(ref_flops / (ms_per_step * 1e-3) / 1e12, 2),
+                   "note": "reference_order = SURVEY.md 8(d) bulk formulas for the reference's contraction sequence; it may exceed the f32 matrix peak because the "
+                           "engine does less work for the same result (shared pair products, Gram + Cholesky instead of QR), not because a kernel skips any"}
     out = {"metric": "two-site gates/sec at fixed chi (LxL TFIM Trotter layer)", "value": round(value, 2),
            "unit": "two-site gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "c64 (ComplexF32; Gram/eigen steps in f64)", "data": "synthetic",
-           "config": {"workload": f"{L}x{L} square-lattice TFIM Trotter layer (Rx + 4 edge colours of Rzz), chi={chi}, ComplexF32, "
-                                  f"apply_gates incl. BP updates; BASELINE.json configs[1]",
+           "config": {"workload": workload, "baseline_config": cfg,
                       "two_site_gates_per_step": n2, "bp_updates_per_step": updates, "bp_sweeps_per_step": sweeps,
                       "theta_svd_sweeps_per_gate": round(float(np.mean(svd_sweeps)) / max(1, n2), 2),
                       "apply_kwargs": {"maxdim": chi, "cutoff": 1e-10, "normalize_tensors": True},
-                      "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)", "parallelism": f"vertex-shard x{world}",
+                      "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)",
+                      "bp_order": "library default: linear forests, one level per forest (tnqs_bp_opts.n_sequence = 0; the reference's forest_cover_edge_sequence is n_sequence = -1; same fixed point)",
+                      "state_init": ("host numpy, per-vertex counter streams" if (cfg == "c2" or args.host_init) else "on device (tnqs_set_site_random, counter-based)"),
+                      "memory": mem, "parallelism": f"vertex-shard x{world}",
                       "transport": (None if world == 1 else {"kind": type(bpc._shard).__name__, "nranks": world, "backend": dist.get_backend(),
                                                              **({"note": transport_note} if transport_note else {}),
                                                              "allgathers_per_step": round(bpc._shard.n_exchanges / max(1, args.steps + args.warmup), 1),
                                                              "MB_gathered_per_step": round(bpc._shard.bytes_exchanged / max(1, args.steps + args.warmup) / 1e6, 2)})},
-           "roofline": roofline, "phases": phases, "kernel_classes": classes}
+           "roofline": roofline, "flop_counts": flop_counts, "phases": phases, "kernel_classes": classes}
     if args.evolved > 0 and world == 1:
         # optional second measurement (not the headline value): a state grown by the circuit itself -- BP needs several sweeps per update there,
         # which the synthetic iid state at dt = 0.01 (one sweep per update) does not show
@@ -291,7 +344,7 @@ def main():
                           "max_bond_dim": int(b2.maxvirtualdim()), "ms_per_step": round(1e3 * el2 / max(1, args.steps), 3),
                           "value": round(n2 * args.steps / el2, 2), "bp_sweeps_per_step": sw2, "bp_updates_not_converged": nc2, "max_truncation_error": float(np.max(_e))}
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and cfg == "c2":      # (the CPU leg restates the 2-D chi = 32 path on a bounded sample; the 8-GPU shapes have none)
             try:
                 out["cpu_baseline"] = cpu_baseline(chi, L)
             except Exception as e:      # the baseline must never take the measured number down with it

@@ -116,6 +116,11 @@ int tnqs_set_stream(tnqs_handle h, void* hip_stream);
  * on an edge whose dimension changes are reset to the identity. */
 int tnqs_set_site_tensor(tnqs_handle h, int v, const void* host, int ndim, const int64_t* dims, const int32_t* leg_role);
 int tnqs_get_site_tensor(tnqs_handle h, int v, void* host, int ndim, const int32_t* leg_role);
+/* Synthetic site tensor generated ON THE DEVICE (the benchmark states of the 8-GPU configurations are ~250 GiB: host random numbers plus PCIe
+ * would take minutes): iid complex-normal entries (real-normal for a real handle), scaled by `scale`, in the canonical layout; bond_dims[j] =
+ * dimension of the leg to the j-th neighbour in ascending vertex order.  Counter-based: entry e of vertex v depends on (seed, v, e) only, so
+ * a sharded and an unsharded run build the same state.  Sharded handles: a vertex owned by another rank only records the dimensions. */
+int tnqs_set_site_random(tnqs_handle h, int v, int n_neighbours, const int64_t* bond_dims, uint64_t seed, double scale);
 int tnqs_site_tensor_size(tnqs_handle h, int v, int64_t* nelem);
 int tnqs_set_message(tnqs_handle h, int src, int dst, const void* host, int chi);
 int tnqs_get_message(tnqs_handle h, int src, int dst, void* host, int chi);
@@ -153,8 +158,10 @@ int tnqs_expect_all(tnqs_handle h, const double* ops, double* out_re_im);
 
 /* ---- multi-site observables (src/expect.jl:59-82) ------------------------------------------
  * The caller passes the region = the vertices of the Steiner tree of the observable's support (expect.jl:68), as a rooted
- * tree: region_parent[i] = index (into region_verts) of the parent of vertex i, -1 for the single root; the induced
- * subgraph of the region must be that tree.  ops = one d x d complex128 column-major matrix op[s',s] per region vertex
+ * tree: region_parent[i] = index (into region_verts) of the parent of vertex i, -1 for the single root.  What is contracted is the
+ * INDUCED region, as in the reference (norm_factors over the Steiner vertices share every internal bond): a bond between two region
+ * vertices that is not a tree edge (a plaquette's closing bond) is summed over as well -- chi^2 tree contractions per such bond, at
+ * most 2^20 terms in all.  ops = one d x d complex128 column-major matrix op[s',s] per region vertex
  * (identity off the support).  out = {Re, Im numerator, Re, Im denominator}; <O> = coeff * numer / denom. */
 int tnqs_expect_region(tnqs_handle h, int n_region, const int32_t* region_verts, const int32_t* region_parent,
                        const double* ops, double* out_numer_denom);

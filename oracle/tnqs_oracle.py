@@ -842,6 +842,70 @@ def expect_1site(bpc: BeliefPropagationCache, op: np.ndarray, v: Vertex) -> comp
     return complex(numer / np.trace(rho))
 
 
+def steiner_vertices(g: Graph, terminals: Sequence[Vertex]) -> List[Vertex]:
+    """vertices(steiner_tree(network(cache), obs_vs)) (expect.jl:67; Graphs.jl steiner_tree, [upstream, recalled]: Kou-Markowsky-Berman with
+    unit weights).  Dijkstra from every terminal (heap keyed by (distance, discovery count); a vertex is relaxed only by a strictly
+    shorter path, so the first parent found stays), minimum spanning tree of the terminals' distance graph, its pairs expanded into
+    paths, a spanning tree of the union, non-terminal leaves pruned.  Returned in vertex order."""
+    import heapq
+    terms = list(dict.fromkeys(terminals))
+    if len(terms) == 1:
+        return terms
+    dist: Dict = {}; parent: Dict = {}
+    for t in terms:
+        d = {t: 0}; pa = {t: None}; heap = [(0, 0, t)]; count = 1; done = set()
+        while heap:
+            du, _, u = heapq.heappop(heap)
+            if u in done:
+                continue
+            done.add(u)
+            for w in g.nbrs[u]:
+                if w not in d or du + 1 < d[w]:
+                    d[w] = du + 1; pa[w] = u
+                    heapq.heappush(heap, (du + 1, count, w)); count += 1
+        dist[t], parent[t] = d, pa
+    if any(t not in dist[terms[0]] for t in terms):
+        raise ValueError("steiner tree: terminals are not connected")
+
+    def spanning(nodes, weighted):
+        root = {v: v for v in nodes}
+
+        def find(x):
+            while root[x] != x:
+                x = root[x]
+            return x
+        keep = []
+        for (_, a, b) in sorted(weighted, key=lambda t: t[0]):
+            ra, rb = find(a), find(b)
+            if ra != rb:
+                root[ra] = rb; keep.append((a, b))
+        return keep
+
+    pairs = [(dist[terms[i]][terms[j]], terms[i], terms[j]) for i in range(len(terms)) for j in range(i + 1, len(terms))]
+    used = set()
+    for (a, b) in spanning(terms, pairs):
+        x = b
+        while x != a:
+            y = parent[a][x]
+            used.add((x, y) if g.pos[x] < g.pos[y] else (y, x)); x = y
+    nodes = sorted({v for e in used for v in e}, key=lambda v: g.pos[v])
+    tree = spanning(nodes, [(1, a, b) for (a, b) in g.edges if (a, b) in used])
+    while True:
+        deg: Dict = {}
+        for (a, b) in tree:
+            deg[a] = deg.get(a, 0) + 1; deg[b] = deg.get(b, 0) + 1
+        leaves = {v for v, k in deg.items() if k == 1 and v not in terms}
+        if not leaves:
+            break
+        tree = [(a, b) for (a, b) in tree if a not in leaves and b not in leaves]
+    return sorted({v for e in tree for v in e}, key=lambda v: g.pos[v])
+
+
+def expect(bpc: BeliefPropagationCache, ops: Dict) -> complex:
+    """expect(alg"bp", cache, (ops, vertices)) (expect.jl:59-82): the region is the vertex set of the Steiner tree of the support"""
+    return expect_region(bpc, ops, steiner_vertices(bpc.g, list(ops.keys())))
+
+
 def expect_region(bpc: BeliefPropagationCache, ops: Dict, region: Sequence[Vertex]) -> complex:
     """expect(alg"bp", cache, obs) for a multi-site observable (expect.jl:59-82): the norm network of `region` (the Steiner tree
     of the observable's support, :68) with the cache's messages on the boundary edges (:69), operators `ops[v]` (op[s', s])

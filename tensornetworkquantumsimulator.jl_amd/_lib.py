@@ -77,6 +77,7 @@ _SIGS = {
     "tnqs_scalartype": ([H, C.POINTER(C.c_int)], C.c_int),
     "tnqs_set_stream": ([H, C.c_void_p], C.c_int),
     "tnqs_set_site_tensor": ([H, C.c_int, C.c_void_p, C.c_int, _I64P, _I32P], C.c_int),
+    "tnqs_set_site_random": ([H, C.c_int, C.c_int, _I64P, C.c_uint64, C.c_double], C.c_int),
     "tnqs_get_site_tensor": ([H, C.c_int, C.c_void_p, C.c_int, _I32P], C.c_int),
     "tnqs_site_tensor_size": ([H, C.c_int, _I64P], C.c_int),
     "tnqs_set_message": ([H, C.c_int, C.c_int, C.c_void_p, C.c_int], C.c_int),

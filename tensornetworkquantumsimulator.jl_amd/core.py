@@ -207,6 +207,13 @@ class BeliefPropagationCache:
     def owns(self, v) -> bool:
         return self._shard is None or self._shard.owner[self.graph.index[v]] == self._shard.rank
 
+    def _set_random(self, v, bond_dims, seed: int, scale: float = 1.0):
+        """synthetic site tensor generated on the device (tnqs_set_site_random): iid normal entries, bond_dims[j] = dimension of the leg to the
+        j-th neighbour in ascending vertex order; on a sharded handle a vertex of another rank only records the dimensions"""
+        dims = np.array(list(bond_dims), dtype=np.int64)
+        L.check(L.lib.tnqs_set_site_random(self._h, self.graph.index[v], len(dims), dims.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           C.c_uint64(seed), C.c_double(scale)))
+
     def _declare_dims(self, v, shape):
         """sharded mode: record the bond dimensions of a vertex owned by another rank (no data is uploaded)"""
         dims = np.array(list(reversed(shape)), dtype=np.int64)

@@ -53,6 +53,9 @@ int tnqs_set_stream(tnqs_handle h, void* stream) {
 int tnqs_set_site_tensor(tnqs_handle h, int v, const void* host, int ndim, const int64_t* dims, const int32_t* role) {
     return guard([&] { if (!dims || !role) throw Err(TNQS_ERR_INVALID, "set_site_tensor: null argument"); state_set_site(S(h), v, host, ndim, dims, role); });
 }
+int tnqs_set_site_random(tnqs_handle h, int v, int n_neighbours, const int64_t* bond_dims, uint64_t seed, double scale) {
+    return guard([&] { if (!bond_dims && n_neighbours > 0) throw Err(TNQS_ERR_INVALID, "set_site_random: null bond_dims"); state_set_site_random(S(h), v, n_neighbours, bond_dims, seed, scale); });
+}
 int tnqs_get_site_tensor(tnqs_handle h, int v, void* host, int ndim, const int32_t* role) {
     return guard([&] { if (!host || !role) throw Err(TNQS_ERR_INVALID, "get_site_tensor: null argument"); state_get_site(S(h), v, host, ndim, role); });
 }

@@ -163,6 +163,7 @@ State* state_create(int nv, int ne, const int32_t* es, const int32_t* ed, const 
 State* state_copy(const State* s);
 void state_set_site(State* s, int v, const void* host, int ndim, const int64_t* dims, const int32_t* role);
 void state_get_site(State* s, int v, void* host, int ndim, const int32_t* role);
+void state_set_site_random(State* s, int v, int nn, const int64_t* bond_dims, uint64_t seed, double scale);
 int64_t state_site_size(const State* s, int v);
 void state_set_message(State* s, int src, int dst, const void* host, int chi);
 void state_get_message(State* s, int src, int dst, void* host, int chi);

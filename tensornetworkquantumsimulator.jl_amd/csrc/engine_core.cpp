@@ -306,6 +306,28 @@ void state_set_site(State* s, int v, const void* host, int ndim, const int64_t* 
     }
 }
 
+void state_set_site_random(State* s, int v, int nn, const int64_t* bond_dims, uint64_t seed, double scale) {
+    const Graph& g = *s->g;
+    if (v < 0 || v >= g.nv) throw Err(TNQS_ERR_INVALID, "set_site_random: bad vertex");
+    const int z = (int)g.nbr[v].size();
+    if (nn != z) throw Err(TNQS_ERR_INVALID, "set_site_random: one bond dimension per neighbour expected");
+    size_t n = (size_t)s->d[v];
+    for (int j = 0; j < z; ++j) { if (bond_dims[j] < 1 || bond_dims[j] > 4096) throw Err(TNQS_ERR_INVALID, "set_site_random: bad bond dimension"); n *= (size_t)bond_dims[j]; }
+    HIPCHK(hipSetDevice(s->device));
+    s->pend1[v].clear(); s->unit_norm[v] = 0;
+    if (s->owns(v)) {
+        Buf out = dalloc(s, n * s->esz());
+        const unsigned long long sd = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)v * 0xC2B2AE3D27D4EB4Full;
+        if (s->dtype == TNQS_C64) launch_random_fill<float>(s->stream, out->p, n, sd, scale, s->real_io); else launch_random_fill<double>(s->stream, out->p, n, sd, scale, s->real_io);
+        HIPCHK(hipStreamSynchronize(s->stream));
+        s->site[v] = out; s->sscale[v] = nullptr;
+    } else { s->site[v] = nullptr; s->sscale[v] = nullptr; }
+    for (int j = 0; j < z; ++j) {
+        const int e = g.nbr_e[v][j], c = (int)bond_dims[j];
+        if (s->chi[e] != c) { s->chi[e] = c; s->msg[2 * e] = nullptr; s->msg[2 * e + 1] = nullptr; }
+    }
+}
+
 void state_get_site(State* s, int v, void* host, int ndim, const int32_t* role) {
     const Graph& g = *s->g;
     if (v < 0 || v >= g.nv) throw Err(TNQS_ERR_INVALID, "get_site_tensor: bad vertex");

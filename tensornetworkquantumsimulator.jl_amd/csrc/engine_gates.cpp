@@ -417,7 +417,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     };
     factor_G(use_chol());
     // ---- 4. theta = gate . (R1 R2), SVD, truncation, X1 / X2  (simple_update.jl:51-59) -----------------------------
-    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S, lowA, lowB, lowG, lowL, lowW; int n1, n2, chi, cap; };
+    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S, lowA, lowB, lowG, lowL, lowW, lowB1, lowG2, lowL2, lowLc; int n1, n2, chi, cap; };
     std::vector<GateWS> ws(ng);
     std::vector<int> pg;                              // gates this rank takes part in
     for (int gi = 0; gi < ng; ++gi) if (part[gi]) pg.push_back(gi);
@@ -443,7 +443,9 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     {
         std::vector<char> raw;
         std::vector<size_t> off(pg.size()), offA(pg.size(), 0), offB(pg.size(), 0); std::vector<int> kappa(pg.size(), 0);
-        const bool lowrank_on = std::is_same<T, float>::value && use_lowrank();
+        // ComplexF64 takes the route as well (round 4): B is orthogonalised by CholeskyQR2 (kernels.hpp LowQr2Item), and the 128 x 64 factor of a
+        // chi = 32 gate fits the LDS-resident Jacobi where the 128 x 128 theta (256 KiB) ran in the global-memory kernel
+        const bool lowrank_on = use_lowrank();
         for (size_t q = 0; q < pg.size(); ++q) {
             int gi = pg[q];
             const int d1 = s->d[gates[gi].v1], d2 = s->d[gates[gi].v2];
@@ -501,9 +503,13 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                     w.lowA = dalloc(s, (size_t)Mr * K * 16); w.lowB = dalloc(s, (size_t)Nc * K * 16);
                     it.kappa = kappa[q]; it.opA = reinterpret_cast<const double*>(d_gm + offA[q]); it.opB = reinterpret_cast<const double*>(d_gm + offB[q]);
                     it.lowA = w.lowA->p; it.lowB = w.lowB->p; lowrank_on_batch = true;
-                    if (K < Nc && K <= 128 && cap <= K && Mr >= Nc) {
+                    const bool lds_fits = std::is_same<T, float>::value || jacobi_lds(jacobi_lds_bytes(Mr, K, false, esz)) > 0;      // ComplexF64: only where it buys the LDS route
+                    if (K < Nc && K <= 128 && cap <= K && Mr >= Nc && lds_fits) {
                         w.lowG = dalloc(s, (size_t)K * K * 16); w.lowL = dalloc(s, (size_t)K * K * 16); w.lowW = dalloc(s, (size_t)K * K * 16);
                         it.lowG = w.lowG->p; it.lowL = w.lowL->p;
+                        if (!std::is_same<T, float>::value) {
+                            w.lowB1 = dalloc(s, (size_t)Nc * K * 16); w.lowG2 = dalloc(s, (size_t)K * K * 16); w.lowL2 = dalloc(s, (size_t)K * K * 16); w.lowLc = dalloc(s, (size_t)K * K * 16);
+                        }
                     }
                 }
             }
@@ -526,6 +532,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     // low-rank route: one failure flag per gate for the Cholesky factorisation of B^dagger B
     Buf d_lowfail = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));
     Buf d_texp = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));
+    Buf d_lowfail2 = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));      // ComplexF64: second CholeskyQR pass of the low-rank route
     for (int q = 0; q < npg; ++q) { gitems[q].lowfail = reinterpret_cast<const int*>(d_lowfail->p) + q; gitems[q].texp = reinterpret_cast<int*>(d_texp->p) + q; }
     const GateItem* d_gitems = upload(s, gitems);
     auto run_theta = [&]() {
@@ -534,17 +541,38 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
         launch_gate_theta<T>(s->stream, d_gitems, npg);
         if (lowrank_on_batch) launch_gate_theta_mm<T>(s->stream, d_gitems, npg);        // theta = A B^T on the f64 matrix cores (gates with operator-sum factors)
-        std::vector<CholItem> lc; int kmax = 1;
+        const bool f64 = !std::is_same<T, float>::value;
+        std::vector<CholItem> lc, lc2; int kmax = 1;
+        std::vector<GateItem> g2, g3; std::vector<LowQr2Item> qi;
+        if (f64) HIPCHK(hipMemsetAsync(d_lowfail2->p, 0, std::max<size_t>(1, (size_t)npg * sizeof(int)), s->stream));
         for (int q = 0; q < npg; ++q) {
             if (!gitems[q].lowG) continue;
-            const int K = gitems[q].kappa * gitems[q].chi;
-            lc.push_back(CholItem{gitems[q].lowG, const_cast<void*>(gitems[q].lowL), K <= 96 ? ws[pg[q]].lowW->p : nullptr, K, reinterpret_cast<int*>(d_lowfail->p) + q, rank_tau(true, K)});
+            const int K = gitems[q].kappa * gitems[q].chi; GateWS& w = ws[pg[q]];
+            int* fail1 = reinterpret_cast<int*>(d_lowfail->p) + q;
+            // ComplexF32: tau at the f32 noise floor.  ComplexF64: 1e-12 on the pivots of pass 1 keeps kappa(B) <= 1e6, where the second pass restores
+            // orthogonality to eps; anything worse falls back to the SVD of the full theta
+            lc.push_back(CholItem{gitems[q].lowG, const_cast<void*>(gitems[q].lowL), (K <= 96 || f64) ? w.lowW->p : nullptr, K, fail1, f64 ? 1e-12 : rank_tau(true, K)});
             kmax = std::max(kmax, K);
+            if (f64) {
+                int* fail2 = reinterpret_cast<int*>(d_lowfail2->p) + q;
+                lc2.push_back(CholItem{w.lowG2->p, w.lowL2->p, nullptr, K, fail2, 1e-3});      // G2 is the identity up to kappa(G1) eps: a pivot below 1e-3 means pass 1 was not good enough
+                GateItem a = gitems[q]; a.lowB = w.lowB1->p; a.lowG = w.lowG2->p; a.lowL = w.lowL2->p; g2.push_back(a);
+                GateItem b = gitems[q]; b.lowL = w.lowLc->p; g3.push_back(b);
+                qi.push_back(LowQr2Item{w.lowB->p, w.lowW->p, w.lowB1->p, gitems[q].lowL, w.lowL2->p, w.lowLc->p, gitems[q].info, gitems[q].d2, fail1, fail2});
+            }
         }
         if (!lc.empty()) {
             const CholItem* dc = upload(s, lc); launch_lowrank_g(s->stream, d_gitems, npg);
-            if (kmax <= 96) launch_chol(s->stream, dc, (int)lc.size(), kmax); else launch_chol_packed(s->stream, dc, (int)lc.size(), kmax);      // only L is used here
-            launch_lowrank_m(s->stream, d_gitems, npg);
+            if (kmax <= 96) launch_chol(s->stream, dc, (int)lc.size(), kmax); else launch_chol_packed(s->stream, dc, (int)lc.size(), kmax);      // ComplexF32: only L is used here
+            if (!f64) launch_lowrank_m<T>(s->stream, d_gitems, npg);
+            else {
+                const LowQr2Item* dq = upload(s, qi); const GateItem* d2 = upload(s, g2); const GateItem* d3 = upload(s, g3); const CholItem* dc2 = upload(s, lc2);
+                launch_lowrank_bw(s->stream, dq, (int)qi.size());                       // B1 = B L1^-dagger
+                launch_lowrank_g(s->stream, d2, (int)g2.size());                        // G2 = B1^dagger B1
+                if (kmax <= 96) launch_chol(s->stream, dc2, (int)lc2.size(), kmax); else launch_chol_packed(s->stream, dc2, (int)lc2.size(), kmax);
+                launch_lowrank_ll(s->stream, dq, (int)qi.size());                       // Lc = L1 L2 (+ pass-2 failure -> the gate's flag)
+                launch_lowrank_m<T>(s->stream, d3, (int)g3.size());                     // theta[:, :K] = A conj(Lc)
+            }
         }
         launch_theta_scale<T>(s->stream, d_gitems, npg);       // theta (or M) and theta0 to O(1), exponent kept per gate for gate_finish
     };
@@ -644,7 +672,11 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                 std::vector<size_t> rs; std::vector<int> rq;
                 for (int q = 0; q < npg; ++q) for (int side = 0; side < 2; ++side) {
                     const size_t i = 2 * (size_t)pg[q] + side;
-                    static const bool all = [] { const char* v = std::getenv("TNQS_QR2_ALL"); return v && v[0] == '1'; }();      // debug: refine every site
+#ifdef TNQS_EXPERIMENTS
+                    static const bool all = [] { const char* v = std::getenv("TNQS_QR2_ALL"); return v && v[0] == '1'; }();      // refine every site
+#else
+                    const bool all = false;
+#endif
                     if ((all || ((hinfo[8 * q + 6] >> side) & 1)) && !small_shape(i)) { rs.push_back(i); rq.push_back(q); }
                 }
                 if (sharded || !rs.empty()) {
@@ -829,7 +861,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             norm_and_replace<T>(s, a64_verts, a64_outs, a64_ne, np64, tb64, nt64, ao.normalize_tensors != 0);
         }
         {   // chi = 64 sites: K = (s, b) = 128 -> N = (s', b') <= 128 on the register-direct MFMA kernel
-            std::vector<FiberItem> rg; std::vector<int> rverts, rtb, rnt; std::vector<Buf> routs; std::vector<size_t> rne; double rt = 0, rby = 0, rfl = 0;
+            std::vector<FiberItem> rg; std::vector<int> rverts, rtb, rnt; std::vector<Buf> routs; std::vector<size_t> rne; double rby = 0, rfl = 0;
             if (std::is_same<T, float>::value && use_mfma() && use_rowgemm())
                 for (size_t q = 0; q < own_idx.size(); ++q) {
                     if (via64[q]) continue;
@@ -841,7 +873,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                     Buf out = dalloc(s, nout * esz);
                     it.in = pch[q].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
                     rowgemm_tiles(it); it.want_norm = ao.normalize_tensors ? 1 : 0;
-                    rg.push_back(it); rverts.push_back(j.v); routs.push_back(out); rne.push_back(nout); rt += (double)it.nta * it.ntb;
+                    rg.push_back(it); rverts.push_back(j.v); routs.push_back(out); rne.push_back(nout);
                     rby += (double)(j.sd.n + nout) * esz; rfl += 8.0 * j.sd.n * j.sd.d * chin; via64[q] = 1;
                 }
             bool booked = false;

@@ -61,10 +61,11 @@ TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64
 // TNQS_JACOBI_GLOBAL=1: every Jacobi factorisation in the global-memory kernel;  TNQS_BP_WS_MB: workspace bound of a BP sub-batch (MiB);
 // TNQS_HOST_TIMING=1: host-side phase timers printed at exit;  TNQS_RCCL_LIB: path of librccl.so (sharding.cpp);
 // TNQS_NO_F64_MFMA=1 (engine_batch.cpp): ComplexF64 mode products on the generic vector kernel instead of the f64 matrix cores (kernels_f64.hip);
-// TNQS_PAIR16_HALF=1 (kernels_plane.hip): every chi = 16 two-leg pass on the kernel in which two waves share each 128-byte line (default: only planes that contain leg 0);
 // TNQS_NO_3M=1 (launch_util.hpp): four-multiplication complex product in every MFMA kernel instead of Gauss' three (mfma_common.hpp, CAcc32);
-// kernels_mfma.hip reads TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP (single-message pair-Gram), TNQS_DBG_GRAM_SKIP; kernels.hpp reads TNQS_PAIR_SPW
-// (slices per workgroup pair of the chi = 32 pair product) -- kernel experiments
+// TNQS_FORK=0 / 1 (engine_gates.cpp): never / always run a gate batch as two halves on two streams (default: by size);
+// Kernel experiments are NOT in the shipped library: TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP, TNQS_DBG_GRAM_SKIP, TNQS_PAIR_SPW, TNQS_PAIR16_HALF
+// and TNQS_QR2_ALL only exist in a build with -DTNQS_EXPERIMENTS (csrc/build.sh EXPERIMENTS=1); the kernel-level entry points of
+// include/tnqs_debug.h (debug.cpp) read TNQS_DBG_* themselves and are not part of the hot path.
 // TNQS_BP_CACHE_MB: bound on the partial products kept across BP levels (MiB, default 49152)
 inline size_t bp_cache_budget() { static const size_t v = [] { const char* e = std::getenv("TNQS_BP_CACHE_MB"); return (e ? (size_t)std::atoll(e) : (size_t)49152) << 20; }(); return v; }
 inline size_t bp_ws_budget() { static const size_t v = [] { const char* e = std::getenv("TNQS_BP_WS_MB"); return (e ? (size_t)std::atoll(e) : (size_t)24576) << 20; }(); return v; }
@@ -151,8 +152,7 @@ struct ProfScope {
         if (!P.on) return;
         P.cls[c].bytes += bytes; P.cls[c].flops += flops; P.cls[c].launches += 1;
         auto get = [&]() { hipEvent_t e; if (!P.ev_free.empty()) { e = P.ev_free.back(); P.ev_free.pop_back(); } else HIPCHK(hipEventCreate(&e)); return e; };
-        static const bool nochain = envflag("TNQS_PROF_NOCHAIN");                       // A/B: every scope records its own start event
-        if (P.chain && P.last_b && P.last_stream == s->stream && !nochain) { a = P.last_b; own_a = false; }
+        if (P.chain && P.last_b && P.last_stream == s->stream) { a = P.last_b; own_a = false; }
         else { a = get(); own_a = true; HIPCHK(hipEventRecord(a, s->stream)); }
         b = get();
     }

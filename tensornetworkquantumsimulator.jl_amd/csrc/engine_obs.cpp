@@ -142,8 +142,12 @@ void rescale(State* s) { rescale_messages(s, 0, nullptr, nullptr); rescale_verti
 // vertices with the cache's messages on the boundary edges and operators inserted, numerator (ops) over denominator (identities).
 // The region is contracted leaves-to-root with the message kernels: m_{u->parent} = sum (O_u psi_u) conj(psi_u) prod(incoming).
 // ---------------------------------------------------------------------------------------------------------------
+// Bonds BETWEEN region vertices that are not tree edges (the induced region has a loop: a plaquette, say) are part of the norm network too
+// (norm_factors over steiner_vs, src/expect.jl:72: every internal bond is shared).  Such a bond is cut: with its ket index fixed to i and its
+// bra index to j the region is the tree again, and the value is the sum over all (i, j).  Fixing the indices costs no new kernel: at both
+// ends the bond absorbs the "message" e_i e_j^T (a chi x chi matrix with a single one at [ket i][bra j]) -- `cut_sel[edge]` below.
 template <class T> static void region_contract(State* s, int nr, const int32_t* rv, const int32_t* parent, const double* ops /* may be null */,
-                                               double* out_re_im) {
+                                               double* out_re_im, const std::unordered_map<int, Buf>& cut_sel) {
     const Graph& g = *s->g;
     const size_t esz = s->esz();
     std::vector<int> pos(g.nv, -1);
@@ -197,8 +201,8 @@ template <class T> static void region_contract(State* s, int nr, const int32_t* 
                 int k = g.nbr[u][j]; if (k == par) continue;
                 const void* mp = nullptr;
                 if (pos[k] >= 0) {
-                    if (parent[pos[k]] < 0 || rv[parent[pos[k]]] != u) throw Err(TNQS_ERR_INVALID, "expect_region: the region's induced subgraph is not the given tree");
-                    mp = up[pos[k]]->p;
+                    if (parent[pos[k]] >= 0 && rv[parent[pos[k]]] == u) mp = up[pos[k]]->p;      // a child: its message
+                    else mp = cut_sel.at(g.edge(u, k))->p;                                      // a cut bond: this term's index selector
                 } else { int de = g.dedge(k, u); if (s->msg[de]) mp = s->msg[de]->p; }
                 if (mp) c.steps.push_back({j, mp});
             }
@@ -212,9 +216,6 @@ template <class T> static void region_contract(State* s, int nr, const int32_t* 
             const ReduceItem* dr = upload(s, ri);
             if (par >= 0) launch_reduce<T, T>(s->stream, dr, 1, n2); else launch_reduce<double, double>(s->stream, dr, 1, n2);
         } else {
-            // the tree-shape check of the owner is repeated here so that every rank fails (or not) together
-            for (size_t j = 0; j < g.nbr[u].size(); ++j) { int k = g.nbr[u][j]; if (k == par) continue;
-                if (pos[k] >= 0 && (parent[pos[k]] < 0 || rv[parent[pos[k]]] != u)) throw Err(TNQS_ERR_INVALID, "expect_region: the region's induced subgraph is not the given tree"); }
         }
         if (sharded) {
             exchange(s, stride);
@@ -243,8 +244,41 @@ void expect_region(State* s, int nr, const int32_t* rv, const int32_t* parent, c
     }
     if (roots != 1) throw Err(TNQS_ERR_INVALID, "expect_region: exactly one root expected");
     HIPCHK(hipSetDevice(s->device));
-    if (s->dtype == TNQS_C64) { region_contract<float>(s, nr, rv, parent, ops, out4); region_contract<float>(s, nr, rv, parent, nullptr, out4 + 2); }
-    else { region_contract<double>(s, nr, rv, parent, ops, out4); region_contract<double>(s, nr, rv, parent, nullptr, out4 + 2); }
+    // cut bonds: edges between two region vertices of which neither is the other's parent
+    std::vector<int> pos(g.nv, -1); for (int i = 0; i < nr; ++i) { if (pos[rv[i]] >= 0) throw Err(TNQS_ERR_INVALID, "expect_region: repeated vertex"); pos[rv[i]] = i; }
+    std::vector<int> cuts; double combos = 1;
+    for (int e = 0; e < g.ne; ++e) {
+        const int a = pos[g.esrc[e]], b = pos[g.edst[e]];
+        if (a < 0 || b < 0 || parent[a] == b || parent[b] == a) continue;
+        cuts.push_back(e); combos *= (double)s->chi[e] * s->chi[e];
+    }
+    if (combos > 1048576.0) throw Err(TNQS_ERR_UNSUPPORTED, "expect_region: the region's loops need more than 2^20 terms (product of chi^2 over the bonds that close a loop)");
+    std::unordered_map<int, Buf> sel;
+    const size_t esz = s->esz();
+    for (int e : cuts) { sel[e] = dalloc(s, (size_t)s->chi[e] * s->chi[e] * esz); }
+    std::vector<int> ij(2 * cuts.size(), 0);          // odometer over (i, j) of every cut bond
+    double acc[4] = {0, 0, 0, 0};
+    const double one_d[2] = {1.0, 0.0}; const float one_f[2] = {1.f, 0.f};
+    for (;;) {
+        for (size_t c = 0; c < cuts.size(); ++c) {
+            const int e = cuts[c], n = s->chi[e];
+            HIPCHK(hipMemsetAsync(sel[e]->p, 0, (size_t)n * n * esz, s->stream));
+            HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(sel[e]->p) + ((size_t)ij[2 * c] + (size_t)n * ij[2 * c + 1]) * esz,
+                                  s->dtype == TNQS_C64 ? (const void*)one_f : (const void*)one_d, esz, hipMemcpyHostToDevice, s->stream));
+        }
+        double term[4];
+        if (s->dtype == TNQS_C64) { region_contract<float>(s, nr, rv, parent, ops, term, sel); region_contract<float>(s, nr, rv, parent, nullptr, term + 2, sel); }
+        else { region_contract<double>(s, nr, rv, parent, ops, term, sel); region_contract<double>(s, nr, rv, parent, nullptr, term + 2, sel); }
+        for (int k = 0; k < 4; ++k) acc[k] += term[k];
+        size_t c = 0;
+        for (; c < cuts.size(); ++c) {
+            const int n = s->chi[cuts[c]];
+            if (++ij[2 * c] < n) break; ij[2 * c] = 0;
+            if (++ij[2 * c + 1] < n) break; ij[2 * c + 1] = 0;
+        }
+        if (c == cuts.size()) break;
+    }
+    for (int k = 0; k < 4; ++k) out4[k] = acc[k];
 }
 
 // ---------------------------------------------------------------------------------------------------------------

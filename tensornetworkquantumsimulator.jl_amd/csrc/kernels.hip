@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
     for (int e = tid0; e < nI * nI; e += tstride) tv[e] = cmake<T>((e % nI) == (e / nI) ? (T)1 : (T)0, (T)0);
     // low-rank route (GateItem): A[(a,s1'),(k,b)] = sum_s1 a_k[s1',s1] R1[a,(s1,b)],  B[(c,s2'),(k,b)] = sum_s2 b_k[s2',s2] R2[c,(s2,b)],  G = B^dagger B
     const int K = it.kappa * chi;
-    const bool low = sizeof(T) == 4 && it.kappa > 0 && it.lowG && !wide && K < Nc && it.chi_cap <= K;
+    const bool low = it.kappa > 0 && it.lowG && !wide && K < Nc && it.chi_cap <= K;      // (the host only hands out lowG where the route may be taken)
     if (threadIdx.x == 0 && part == 0) { it.info[5] = wide ? 1 : 0; it.info[7] = low ? K : 0; }       // info[7]: lowrank_g / chol / lowrank_m follow
     if (via_factors) {
         cx<double>* LA = reinterpret_cast<cx<double>*>(it.lowA);
@@ -1395,9 +1395,64 @@ template <class T> void launch_theta_scale(hipStream_t s, const GateItem* d_item
 }
 template void launch_theta_scale<float>(hipStream_t, const GateItem*, int);
 template void launch_theta_scale<double>(hipStream_t, const GateItem*, int);
-void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems) {
+template <class T> void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((lowrank_m_kernel<float>), dim3(nitems, 4), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((lowrank_m_kernel<T>), dim3(nitems, 4), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+template void launch_lowrank_m<float>(hipStream_t, const GateItem*, int);
+template void launch_lowrank_m<double>(hipStream_t, const GateItem*, int);
+// CholeskyQR2 of B (LowQr2Item, kernels.hpp): B1 = B W1, W1 = L1^-dagger upper triangular
+__global__ __launch_bounds__(1024) void lowrank_bw_kernel(const LowQr2Item* __restrict__ items) {
+    const LowQr2Item it = items[blockIdx.x];
+    const int K = it.info[7];
+    if (K <= 0 || *it.fail1) return;
+    const int Nc = it.info[1] * it.d2;
+    const cx<double>* B = reinterpret_cast<const cx<double>*>(it.B);
+    const cx<double>* W = reinterpret_cast<const cx<double>*>(it.W1);
+    cx<double>* B1 = reinterpret_cast<cx<double>*>(it.B1);
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    const int w = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.y * (blockDim.x >> 6);
+    const int tr = (K + 15) >> 4, tc = (Nc + 15) >> 4;
+    for (int t = w; t < tr * tc; t += nw) {                                             // tile rows = column j of B1, lanes = row i (contiguous)
+        const int j0 = 16 * (t % tr), i0 = 16 * (t / tr);
+        v4d_t cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+        ztile_mm(K, j0 + l15, i0 + l15,                                                 // B1[i][j] = sum_{l <= j} B[i, l] W[l, j]
+                 [&](int j, int l) { return (j < K && l < K && l <= j) ? W[l + (size_t)K * j] : cmake<double>(0, 0); },
+                 [&](int l, int i) { return (i < Nc && l < K) ? B[i + (size_t)Nc * l] : cmake<double>(0, 0); }, cr, ci);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int j = j0 + kq + 4 * r, i = i0 + l15; if (i < Nc && j < K) B1[i + (size_t)Nc * j] = cmake<double>(cr[r], ci[r]); }
+    }
+}
+void launch_lowrank_bw(hipStream_t s, const LowQr2Item* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(lowrank_bw_kernel, dim3(nitems, 4), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
+}
+// Lc = L1 L2 (both lower triangular), and the second pass's failure folded into the gate's flag
+__global__ __launch_bounds__(1024) void lowrank_ll_kernel(const LowQr2Item* __restrict__ items) {
+    const LowQr2Item it = items[blockIdx.x];
+    const int K = it.info[7];
+    if (K <= 0 || *it.fail1) return;
+    if (*it.fail2) { if (threadIdx.x == 0) *it.fail1 = 1; return; }
+    const cx<double>* L1 = reinterpret_cast<const cx<double>*>(it.L1);
+    const cx<double>* L2 = reinterpret_cast<const cx<double>*>(it.L2);
+    cx<double>* Lc = reinterpret_cast<cx<double>*>(it.Lc);
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nt = (K + 15) >> 4;
+    for (int t = w; t < nt * nt; t += nw) {                                             // tile rows = column j, lanes = row i
+        const int j0 = 16 * (t % nt), i0 = 16 * (t / nt);
+        v4d_t cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+        if (i0 + 15 >= j0)
+        ztile_mm(K, j0 + l15, i0 + l15,                                                 // Lc[i][j] = sum_{j <= l <= i} L1[i, l] L2[l, j]
+                 [&](int j, int l) { return (j < K && l < K && l >= j) ? L2[l + (size_t)K * j] : cmake<double>(0, 0); },
+                 [&](int l, int i) { return (i < K && l < K && l <= i) ? L1[i + (size_t)K * l] : cmake<double>(0, 0); }, cr, ci);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int j = j0 + kq + 4 * r, i = i0 + l15; if (i < K && j < K) Lc[i + (size_t)K * j] = (i >= j) ? cmake<double>(cr[r], ci[r]) : cmake<double>(0, 0); }
+    }
+}
+void launch_lowrank_ll(hipStream_t s, const LowQr2Item* d_items, int nitems) {
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(lowrank_ll_kernel, dim3(nitems), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
@@ -1860,6 +1915,25 @@ template <class T> __global__ void identity_kernel(cx<T>* out, int n) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * n; e += gridDim.x * blockDim.x)
         out[e] = cmake<T>((e % n) == (e / n) ? (T)1 : (T)0, (T)0);
 }
+// iid standard-normal (re, im) pairs from a counter-based generator: entry e <- splitmix64(seed + e) -> two uniforms -> Box-Muller
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31);
+}
+template <class T> __global__ __launch_bounds__(256) void random_fill_kernel(cx<T>* out, size_t n, unsigned long long seed, double scale, int real_only) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long r = splitmix64(seed + 0xD1B54A32D192ED03ull * (unsigned long long)e);
+        const double u1 = ((double)(r >> 32) + 1.0) * (1.0 / 4294967296.0), u2 = (double)(r & 0xffffffffull) * (1.0 / 4294967296.0);
+        const double rad = sqrt(-2.0 * log(u1)) * scale; double sn, cs; sincospi(2.0 * u2, &sn, &cs);
+        out[e] = cmake<T>((T)(rad * cs), real_only ? (T)0 : (T)(rad * sn));
+    }
+}
+template <class T> void launch_random_fill(hipStream_t s, void* out, size_t n, unsigned long long seed, double scale, bool real_only) {
+    if (!n) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 65536);
+    hipLaunchKernelGGL((random_fill_kernel<T>), dim3(blocks), dim3(256), 0, s, reinterpret_cast<cx<T>*>(out), n, seed, scale, real_only ? 1 : 0); TNQS_CHECK_LAUNCH();
+}
+template void launch_random_fill<float>(hipStream_t, void*, size_t, unsigned long long, double, bool);
+template void launch_random_fill<double>(hipStream_t, void*, size_t, unsigned long long, double, bool);
 template <class T> void launch_identity(hipStream_t s, void* out, int n) {
     hipLaunchKernelGGL((identity_kernel<T>), dim3((n * n + 255) / 256), dim3(256), 0, s, reinterpret_cast<cx<T>*>(out), n); TNQS_CHECK_LAUNCH();
 }

@@ -100,7 +100,14 @@ struct GateItem {         // everything the per-gate small-algebra kernels need 
 };
 template <class T> void launch_theta_scale(hipStream_t s, const GateItem* d_items, int nitems);
 void launch_lowrank_g(hipStream_t s, const GateItem* d_items, int nitems);
-void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems);
+template <class T> void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems);
+// ComplexF64 low-rank route: B (Nc x K) is orthogonalised by CholeskyQR2 -- a single Gram / Cholesky pass squares the condition number, which
+// f32 data do not notice and f64 data do.  Pass 1: G1 = B^dagger B = L1 L1^dagger, B1 = B W1 with W1 = L1^-dagger; pass 2: G2 = B1^dagger B1 =
+// L2 L2^dagger; then B = Q (L1 L2)^dagger with Q orthonormal to eps and theta = A B^T = (A conj(L1 L2)) Q^T.  bw: B1 = B W1;  ll: Lc = L1 L2 and the
+// failure flag of pass 2 folded into the gate's (a failed pass sends the gate back to the SVD of the full theta).
+struct LowQr2Item { const void* B; const void* W1; void* B1; const void* L1; const void* L2; void* Lc; const int* info; int d2; int* fail1; const int* fail2; };
+void launch_lowrank_bw(hipStream_t s, const LowQr2Item* d_items, int nitems);
+void launch_lowrank_ll(hipStream_t s, const LowQr2Item* d_items, int nitems);
 // Second factorisation pass of an ill-conditioned ComplexF64 site (CholeskyQR2).  With the first-pass factor R1 (interface of
 // GateItem: R1[a,(s,b)] = sqrt(l_a) conj(GV[(s,b), idx_a]), R1^+[:,a] = GW[:, idx_a] / sqrt(l_a), r kept columns):
 //   Qr2RinvItem:    X1 = R1^+ as an explicit n x n matrix (columns >= r zero), so that Q1 = psi~ x_(s,b) X1 can be formed;
@@ -192,6 +199,7 @@ template <class T> void launch_scale(hipStream_t s, const ScaleItem* d_items, in
 void launch_norm_factor(hipStream_t s, const NormFactorItem* d_items, int nitems);
 template <class T> void launch_permute(hipStream_t s, const PermItem& item);
 template <class T> void launch_identity(hipStream_t s, void* out, int n);
+template <class T> void launch_random_fill(hipStream_t s, void* out, size_t n, unsigned long long seed, double scale, bool real_only);   // iid normal entries, counter-based
 void launch_sum_doubles(hipStream_t s, const double* in, int n, double* out);
 // one-site gates on d = 2, ComplexF32: streaming 2x2 apply, norm partials [item][nbx]
 void launch_site1_c64(hipStream_t s, const Site1Item* d_items, int nitems, int nbx, double* d_norm_partials);
@@ -330,8 +338,10 @@ void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int to
 inline int pair_wgs(int nslices, int spw) { const int np = (nslices + spw - 1) / spw; return 16 * ((np + 7) / 8); }
 // slices per workgroup for a batch of `total_slices`: the largest power of two <= 16 that still gives >= 1024 workgroups
 inline int pair_spw(double total_slices) {
-    static const int forced = [] { const char* e = std::getenv("TNQS_PAIR_SPW"); return e ? std::atoi(e) : 0; }();      // kernel experiments
+#ifdef TNQS_EXPERIMENTS
+    static const int forced = [] { const char* e = std::getenv("TNQS_PAIR_SPW"); return e ? std::atoi(e) : 0; }();
     if (forced > 0) return forced;
+#endif
     int spw = 16; while (spw > 1 && 2.0 * total_slices / spw < 1024.0) spw >>= 1; return spw;
 }
 // gate epilogue psi' = psi x_(s,b) X for d = 2, chi_b = chi_b' = 32 (K = N = 64) in the pair-kernel shape: plane (b, y) per companion,

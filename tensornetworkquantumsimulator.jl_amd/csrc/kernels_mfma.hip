@@ -373,7 +373,15 @@ template <int KB, int NB, int TR> static size_t fiber_lds() {
     return (size_t)(2 * TR * (CP + 1) + 2 * NNP * (KKP + 1)) * sizeof(float);
 }
 static int g_wave_private = -1;
-static bool wave_private() { if (g_wave_private < 0) { const char* e = getenv("TNQS_MFMA_WG_TILES"); g_wave_private = (e && e[0] == '1') ? 0 : 1; } return g_wave_private == 1; }
+static bool wave_private() {
+    if (g_wave_private < 0) {
+        g_wave_private = 1;
+#ifdef TNQS_EXPERIMENTS
+        const char* e = getenv("TNQS_MFMA_WG_TILES"); if (e && e[0] == '1') g_wave_private = 0;
+#endif
+    }
+    return g_wave_private == 1;
+}
 int mfma_fiber_tile_rows(int KK, int NN) {
     if (wave_private()) return (KK <= 64 && NN <= 64) ? 32 : 0;
     if (KK <= 32 && NN <= 32) return 128;
@@ -896,7 +904,13 @@ void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitem
     if (total_wgs <= 0) return;
     const size_t lds = (size_t)16 * (32 * 33 + 1) * 2 * sizeof(float);
     set_max_dynamic_lds((const void*)mfma_pair_gram_kernel, lds);
-    static int xcd = -1; if (xcd < 0) { const char* e = std::getenv("TNQS_XCD_REMAP"); xcd = e ? std::atoi(e) : 0; }
+    static int xcd = -1;
+    if (xcd < 0) {
+        xcd = 0;
+#ifdef TNQS_EXPERIMENTS
+        if (const char* e = std::getenv("TNQS_XCD_REMAP")) xcd = std::atoi(e);
+#endif
+    }
     hipLaunchKernelGGL(mfma_pair_gram_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems, xcd); TNQS_CHECK_LAUNCH();
 }
 
@@ -1481,7 +1495,13 @@ bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, 
     if (KKmax > 64) return false;
     if (total_chunks <= 0) return true;
     const size_t lds = (size_t)4 * 64 * 68 * sizeof(float);
-    static int skip = -1; if (skip < 0) { const char* e = std::getenv("TNQS_DBG_GRAM_SKIP"); skip = e ? std::atoi(e) : 0; }
+    static int skip = -1;
+    if (skip < 0) {
+        skip = 0;
+#ifdef TNQS_EXPERIMENTS
+        if (const char* e = std::getenv("TNQS_DBG_GRAM_SKIP")) skip = std::atoi(e);
+#endif
+    }
 #define TNQS_G64(M3, SH) { set_max_dynamic_lds((const void*)mfma_gram64_f64_kernel<M3, SH>, lds); hipLaunchKernelGGL((mfma_gram64_f64_kernel<M3, SH>), dim3(total_chunks), dim3(256), lds, s, d_items, nitems, skip); }
     if (mfma_use_3m()) { if (all_kk64) TNQS_G64(true, true) else TNQS_G64(true, false) }
     else { if (all_kk64) TNQS_G64(false, true) else TNQS_G64(false, false) }

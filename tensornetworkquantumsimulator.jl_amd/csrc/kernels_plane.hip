@@ -272,7 +272,13 @@ __global__ __launch_bounds__(256) void mfma_pair16w_kernel(const Pair16Item* __r
     }
 }
 // whole_lines: every item has its 16 companions in one 128-byte line (PlaneGeom::cstr == 2) and TNQS_PAIR16_HALF is not set: see pair16_whole_lines()
-bool pair16_whole_lines(const PlaneGeom& g) { static const bool off = [] { const char* e = std::getenv("TNQS_PAIR16_HALF"); return e && e[0] == '1'; }(); return !off && g.cstr == 2; }
+bool pair16_whole_lines(const PlaneGeom& g) {
+#ifdef TNQS_EXPERIMENTS
+    static const bool off = [] { const char* e = std::getenv("TNQS_PAIR16_HALF"); return e && e[0] == '1'; }();
+    if (off) return false;
+#endif
+    return g.cstr == 2;
+}
 void launch_mfma_pair16(hipStream_t s, const Pair16Item* d_items, int nitems, int total_wgs, bool whole_lines) {
     if (total_wgs > 0 && whole_lines) {
         const size_t lds = (size_t)4 * 16 * PS16 * sizeof(v2f);

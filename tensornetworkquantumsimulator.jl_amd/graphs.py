@@ -280,53 +280,87 @@ def forest_cover_edge_sequence(g: NamedGraph) -> List[Tuple[Vertex, Vertex]]:
     return seq
 
 
-def steiner_region(g: "NamedGraph", verts) -> Tuple[List[Vertex], List[int]]:
-    """Vertices of the Steiner tree of `verts` (src/expect.jl:68 uses Graphs.steiner_tree) as (region, parent) with
-    parent[i] = index of the parent of region[i], -1 for the root region[0] = verts[0].  The tree is grown by attaching each
-    further vertex through its shortest path to the tree; the construction only accepts UNIQUE shortest paths and a region whose
-    induced subgraph is that tree, so that the result does not depend on tie-breaking inside a Steiner-tree heuristic
-    (neighbouring vertices, vertices on a line, any vertices of a tree graph); otherwise a ValueError explains why."""
-    verts = list(verts)
-    if len(set(verts)) != len(verts):
-        raise ValueError("steiner_region: repeated vertex")
-    tree = [verts[0]]
-    tset = {verts[0]}
-    for v in verts[1:]:
-        if v in tset:
-            continue
-        # BFS from v, counting shortest paths
-        dist, cnt, prev = {v: 0}, {v: 1}, {v: None}
-        frontier, hit = [v], []
-        while frontier and not hit:
+def steiner_tree_edges(g: "NamedGraph", verts) -> List[Tuple[Vertex, Vertex]]:
+    """Edges of the Steiner tree of the terminals `verts`, as Graphs.steiner_tree builds it (src/expect.jl:67 -> NamedGraphs.steiner_tree ->
+    Graphs.jl; [upstream, recalled] -- Kou / Markowsky / Berman): (1) shortest paths from every terminal (unit weights: breadth-first, first in first out, neighbours in
+    ascending vertex position; a vertex keeps the FIRST parent that reaches it); (2) minimum spanning tree of the complete graph on the terminals weighted
+    by those distances (Kruskal over the pairs (i, j), i < j, in lexicographic order, stable in the weight); (3) every tree pair replaced by its
+    shortest path; (4) a minimum spanning tree of the union of those paths (Kruskal over its edges in graph edge order); (5) leaves that are not
+    terminals removed until none is left.  Where several shortest paths tie, the choice in (1) decides -- deterministic here, and the same rule
+    as the breadth-first search of Graphs.jl, but not pinned against it."""
+    terms = list(dict.fromkeys(verts))
+    if len(terms) < 2:
+        return []
+    par, dist = {}, {}
+    for t in terms:
+        d, p, frontier = {t: 0}, {t: None}, [t]
+        while frontier:
             nxt = []
             for a in frontier:
                 for b in g.neighbors(a):
-                    if b not in dist:
-                        dist[b], cnt[b], prev[b] = dist[a] + 1, cnt[a], a
+                    if b not in d:
+                        d[b], p[b] = d[a] + 1, a
                         nxt.append(b)
-                    elif dist[b] == dist[a] + 1:
-                        cnt[b] += cnt[a]
-            hit = [b for b in nxt if b in tset]
             frontier = nxt
-        if not hit:
-            raise ValueError("steiner_region: the observable's vertices are not connected")
-        if len(hit) > 1 or cnt[hit[0]] != 1:
-            raise ValueError("steiner_region: the Steiner tree of these vertices is not unique (several shortest paths); "
-                             "only observables with an unambiguous region are supported on the HIP path")
-        a = prev[hit[0]]
-        while a is not None:
-            tree.append(a); tset.add(a)
-            a = prev[a]
-    n_int = sum(1 for (a, b) in g.edges if a in tset and b in tset)
-    if n_int != len(tree) - 1:
-        raise ValueError("steiner_region: the region's induced subgraph contains a loop")
-    # root at verts[0]
+        par[t], dist[t] = p, d
+    for t in terms[1:]:
+        if t not in dist[terms[0]]:
+            raise ValueError("steiner_tree: the observable's vertices are not connected")
+
+    def kruskal(nodes, wedges):
+        comp = {v: v for v in nodes}
+
+        def find(x):
+            while comp[x] != x:
+                comp[x] = comp[comp[x]]
+                x = comp[x]
+            return x
+        out = []
+        for (w, a, b) in sorted(wedges, key=lambda e: e[0]):      # stable: ties keep the enumeration order
+            ra, rb = find(a), find(b)
+            if ra != rb:
+                comp[ra] = rb
+                out.append((a, b))
+        return out
+
+    closure = [(dist[a][b], a, b) for i, a in enumerate(terms) for b in terms[i + 1:]]
+    union = set()
+    for (a, b) in kruskal(terms, closure):
+        x = b
+        while par[a][x] is not None:                               # walk b -> a along a's breadth-first parents
+            union.add(frozenset((x, par[a][x])))
+            x = par[a][x]
+    uverts = sorted({v for e in union for v in e}, key=g.index.__getitem__)
+    tree = kruskal(uverts, [(1, a, b) for (a, b) in g.edges if frozenset((a, b)) in union])
+    tset = set(terms)
+    while True:
+        deg = {}
+        for (a, b) in tree:
+            deg[a] = deg.get(a, 0) + 1
+            deg[b] = deg.get(b, 0) + 1
+        drop = {v for v, k in deg.items() if k == 1 and v not in tset}
+        if not drop:
+            return tree
+        tree = [(a, b) for (a, b) in tree if a not in drop and b not in drop]
+
+
+def steiner_region(g: "NamedGraph", verts) -> Tuple[List[Vertex], List[int]]:
+    """Vertices of the Steiner tree of `verts` (src/expect.jl:67) as (region, parent): region[0] = verts[0] is the root and parent[i] the index of
+    the tree parent of region[i] (-1 for the root).  The library contracts the INDUCED region, like the reference's `norm_factors` over
+    `steiner_vs` (src/expect.jl:72): bonds between region vertices that are not tree edges are summed over as well (tnqs_expect_region)."""
+    verts = list(verts)
+    if len(set(verts)) != len(verts):
+        raise ValueError("steiner_region: repeated vertex")
+    adj: Dict[Vertex, List[Vertex]] = {}
+    for (a, b) in steiner_tree_edges(g, verts):
+        adj.setdefault(a, []).append(b)
+        adj.setdefault(b, []).append(a)
     region, parent, seen = [verts[0]], [-1], {verts[0]: 0}
     q = 0
     while q < len(region):
         a = region[q]
-        for b in g.neighbors(a):
-            if b in tset and b not in seen:
+        for b in sorted(adj.get(a, []), key=g.index.__getitem__):
+            if b not in seen:
                 seen[b] = len(region); region.append(b); parent.append(q)
         q += 1
     return region, parent

@@ -74,7 +74,7 @@ def tfim_case(name, g, groups, dtype, maxdim, cutoff, nlayers, rx, rz, rzz, norm
     print("wrote", name, {k: v.shape for k, v in arrays.items() if not k.startswith("spectra")})
 
 
-def bp_case(name, g, chi, dtype, seed):
+def bp_case(name, g, chi, dtype, seed, regions=None):
     psi = o.random_state(dtype, g, chi, seed=seed)
     seq = o.forest_cover_edge_sequence(g)
     arrays = {"psi_" + str(i): psi.tensors[v] for i, v in enumerate(g.vertices)}
@@ -90,6 +90,17 @@ def bp_case(name, g, chi, dtype, seed):
         arrays["expZ_exact"] = ex
     meta = dict(name=name, vertices=[list(map(float, v)) for v in g.vertices], edges=[[list(map(float, a)), list(map(float, b))] for (a, b) in g.edges],
                 seq=[[list(map(float, a)), list(map(float, b))] for (a, b) in seq], chi=chi, dtype=np.dtype(dtype).name, seed=seed)
+    if regions:
+        # multi-site observables at the 60-sweep fixed point (expect.jl:59-82): the Steiner tree of the support (recalled rule, graphs.py /
+        # o.steiner_vertices) and the dense contraction of the induced region; (ops, vertices) pairs of Pauli letters
+        mats = {"Z": Z, "X": np.array([[0, 1], [1, 0.0]], dtype=complex)}
+        vals, rmeta = [], []
+        for ops, vs in regions:
+            st = o.steiner_vertices(g, vs)
+            vals.append(o.expect_region(bpc, {v: mats[c] for v, c in zip(vs, ops)}, st))
+            rmeta.append(dict(ops=ops, vertices=[list(map(float, v)) for v in vs], steiner=[list(map(float, v)) for v in st]))
+        arrays["region_vals"] = np.array(vals)
+        meta["regions"] = rmeta
     np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=json.dumps(meta), **arrays)
     print("wrote", name)
 
@@ -137,4 +148,10 @@ if __name__ == "__main__":
     bp_case("bp_comb33_chi2_c128", o.comb_tree((3, 3)), 2, np.complex128, 7)
     bp_case("bp_grid3x3_chi3_c128", g33, 3, np.complex128, 5)
     bp_case("bp_grid3x3_chi3_c64", g33, 3, np.complex64, 5)
+    # round 4: an evolution small enough to commit (the chi = 32 version runs device-vs-oracle in tests/test_gpu_fullsize.py): 4x4, ComplexF32, twelve
+    # TFIM layers at dt = 0.1, maxdim 8 -- truncation live from the fourth layer on; and multi-site observables on regions with a tie / a loop
+    g44 = o.named_grid((4, 4))
+    tfim_case("tfim4x4_c64_maxdim8_12layers", g44, o.edge_color(g44), np.complex64, 8, 1e-10, 12, 0.5, None, 0.2, True, sweeps=4)
+    bp_case("bp_grid4x4_chi4_c128_regions", g44, 4, np.complex128, 29,
+            regions=[("ZZ", [(1, 1), (2, 2)]), ("ZX", [(2, 2), (3, 3)]), ("ZZZZ", [(2, 2), (2, 3), (3, 3), (3, 2)]), ("ZXZ", [(1, 1), (1, 2), (2, 2)]), ("ZX", [(1, 2), (3, 3)])])
     unit_vectors()

@@ -136,7 +136,7 @@ def main():
     vs = list(g.vertices)
     # regions with a unique Steiner tree: neighbours, and vertices on one lattice line (also across the rank boundary)
     line = [v for v in vs if v[0] == vs[0][0]] if extra else []
-    regions = [[vs[0], vs[1]], [line[0], line[-1]], [line[0], line[1], line[-1]]] if extra else []
+    regions = [[vs[0], vs[1]], [line[0], line[-1]], [line[0], line[1], line[-1]], [(1, 1), (2, 2)], [(2, 1), (2, 2), (3, 2), (3, 1)]] if extra else []      # + a diagonal pair (tie) and a plaquette (loop) across the rank boundary
     def multi(b):
         out = []
         for r in regions:

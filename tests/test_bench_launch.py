@@ -53,3 +53,28 @@ def test_single_gpu_line_carries_roofline_and_no_transport():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["config"]["transport"] is None and "kernel_classes" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,L", [("c4", "3"), ("c5", "4")])
+def test_big_configurations_run_sharded_over_gloo(cfg, L):
+    """bench.py --config c4 / c5 (BASELINE configs[3] / [4]: the 8-GPU shapes) on lattices that fit one GPU, two ranks sharing the device over
+    gloo: the state is generated on the device rank by rank (tnqs_set_site_random), the line names the BASELINE entry and carries the memory
+    estimate, both flop counts and the sweep order."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--config", cfg, "--L", L, "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=clean_env(TNQS_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = out["config"]
+    assert out["n_gpus"] == 2 and c["baseline_config"] == cfg and ("configs[3]" if cfg == "c4" else "configs[4]") in c["workload"]
+    assert c["state_init"].startswith("on device") and c["memory"]["site_tensor_GiB_this_rank"] > 0 and "bp_order" in c
+    assert out["flop_counts"]["executed_algorithm_TFLOP_per_step"] > 0 and out["flop_counts"]["reference_order_TFLOP_per_step"] > 0
+    assert out["value"] > 0 and out["roofline"] is not None
+
+
+def test_memory_estimate_refuses_what_cannot_fit():
+    """--config c4 at full size on ONE rank is 250 GiB of site tensors: refused before anything is allocated (on a CPU box the script stops earlier,
+    at the missing device -- either way no JSON line and a non-zero exit)"""
+    r = subprocess.run([sys.executable, BENCH, "--config", "c4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=clean_env(),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout

@@ -9,7 +9,7 @@ from golden_util import load, layer_from_meta, TFIM_CASES, BP_CASES
 Z = np.diag([1.0, -1.0]).astype(complex)
 
 
-@pytest.mark.parametrize("name", ["tfim3x3_c128_maxdim2", "tfim3x3_c64_maxdim3", "heavyhex11_c128_maxdim4"])
+@pytest.mark.parametrize("name", ["tfim3x3_c128_maxdim2", "tfim3x3_c64_maxdim3", "heavyhex11_c128_maxdim4", "tfim4x4_c64_maxdim8_12layers"])
 def test_oracle_reproduces_tfim_fixture(name):
     meta, z = load(name)
     g = o.Graph(meta["vertices"], meta["edges"])
@@ -37,6 +37,12 @@ def test_oracle_reproduces_bp_fixture(name):
         bpc = o.update(o.BeliefPropagationCache(psi), maxiter=ns, tolerance=None, edge_sequence=meta["seq"])
         got = np.concatenate([bpc.message(e).reshape(-1) for e in meta["seq"]])
         assert np.max(np.abs(got - z[f"msgs_{ns}"])) < tol
+    if "regions" in meta:
+        X = np.array([[0, 1], [1, 0.0]], dtype=complex)
+        bpc = o.update(o.BeliefPropagationCache(psi), maxiter=60, tolerance=None, edge_sequence=meta["seq"])
+        for r, ref in zip(meta["regions"], z["region_vals"]):
+            assert o.steiner_vertices(g, r["vertices"]) == r["steiner"]
+            assert abs(o.expect(bpc, {v: {"Z": Z, "X": X}[c] for v, c in zip(r["vertices"], r["ops"])}) - ref) < 1e-12
 
 
 def test_unit_vectors():

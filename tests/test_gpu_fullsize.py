@@ -158,25 +158,6 @@ def test_chi64_site_path_runs():
     assert np.max(np.abs(tn.expect_all(t, "Z") - ez)) < 2e-3
 
 
-def test_cubic_degree6_chi16_layer_runs():
-    """BASELINE configs[3] per-site shape: periodic cubic, degree 6, chi = 16 (256 MiB site tensors) on a 3x3x3 torus"""
-    g = tn.named_grid((3, 3, 3), periodic=True)
-    chi = 16
-    groups = tn.edge_color(g)
-    layer = [("Rz", [v], -0.04) for v in g.vertices]
-    for grp in groups:
-        layer += [("Rxx", [a, b], -0.08) for (a, b) in grp]
-    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex64, lambda v: "↑", g))
-    for v, t in random_unit_state(g, chi, np.complex64, seed=6).items():
-        bpc._set_tensor(v, t)
-    info = {}
-    bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True), info=info)
-    assert info["n_updates"] == len(groups) + 1 and info["n_two_site"] == 81
-    assert bpc.maxvirtualdim() <= chi and np.all((errs >= 0) & (errs <= 1))
-    ez = tn.expect_all(bpc, "Z")
-    assert np.all(np.abs(ez.real) <= 1 + 1e-4) and np.all(np.abs(ez.imag) < 1e-4)
-
-
 def test_c2_physical_evolution_from_product_state():
     """the benchmark lattice on PHYSICAL states: 20x20 TFIM (J = 1, hx = 2.5, dt = 0.1) from all-up, maxdim 32, cutoff 1e-10 -- bond
     dimensions grow 2 -> 32 over 11 layers, so every route is exercised at scale (small-SVD corners, per-site Cholesky fallbacks, the
@@ -285,60 +266,59 @@ def test_c3_layers_match_oracle():
         bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw)
         bo, eo = o.apply_gates(layer, bo, apply_kwargs=kw, bp_update_kwargs=bpkw)
         assert [bd.bond_dim(a, b) for (a, b) in g.edges] == [bo.tns.bond_dim(a, b) for (a, b) in g.edges], it
-        assert c64_errs_close(ed, eo, rel=5e-3, floor=1e-6), (it, float(np.max(np.abs(ed - np.array(eo)))))
+        assert c64_errs_close(ed, eo), (it, float(np.max(np.abs(ed - np.array(eo)))))
         zd = tn.expect_all(bd, "Z").real
         zo = np.array([o.expect_1site(bo, zop, v).real for v in g.vertices])
         print(f"C3 layer {it}: max|dZ| {np.max(np.abs(zd - zo)):.1e}  max|derr| {np.max(np.abs(ed - np.array(eo))):.1e}  max err {max(eo):.1e}  chi {bd.maxvirtualdim()}")
         assert np.max(np.abs(zd - zo)) < 1e-5, (it, float(np.max(np.abs(zd - zo))))      # north star: expectation values within 1e-5
 
 
-def test_c2_shape_layer_matches_oracle():
-    """BASELINE configs[1] at the size the oracle can follow: 4x4 grid, chi = 32, ComplexF32, small-norm random tensors as in bench.py, ONE
-    full TFIM layer with the benchmark's gates and apply_kwargs (Rx on every site, Rzz per edge colour, the BP updates in between; explicit
-    common sweep order, two sweeps per update).  The four bulk sites run the whole MFMA path -- pair products, double pair-Gram, f64 Gram,
-    Cholesky, low-rank theta SVD, apply64, deferred normalisation.  Truncation errors (relative), bond dimensions, <Z> and message spectra;
-    measured: <Z> to 1.8e-6, truncation errors to 4e-6 relative (1e-4 in size), message spectra to 1.4e-7."""
+def test_c2_evolution_drift_over_ten_layers():
+    """north star: "expectation values within 1e-5 of reference" is a statement about an EVOLUTION.  BASELINE configs[1] at the size the oracle can
+    follow: 4x4 grid, ComplexF32, ten TFIM layers at dt = 0.3 (at dt = 0.1 the bonds only reach 23 in ten layers) from the product state with maxdim = 32 (the bonds saturate at 32 in the fifth layer,
+    truncation is live from then on), a common explicit sweep order and two sweeps per update; device against the oracle iterating its OWN state
+    (oracle/cpu_layer.py: the oracle's arithmetic on a thread pool).  After EVERY layer: bond dimensions, truncation errors at the helper defaults
+    (2e-3 relative, floor 3e-7) and <Z> on every site to 1e-5; after the last one the message spectra as well.  The four bulk sites run the whole MFMA
+    path from the fifth layer on -- pair products, double pair-Gram, fused gauge + f64 Gram, Cholesky, low-rank theta SVD, row-GEMM epilogue, deferred
+    normalisation.  The measured drift per layer is printed.  (Replaces the one-layer test on a random state of rounds 2-3.)"""
     import tnqs_oracle as o
+    import cpu_layer
     from helpers import to_oracle_state, c64_errs_close
     g = tn.named_grid((4, 4))
-    chi = 32
-    psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=chi, seed=12)
-    for v in g.vertices:
-        t = psi.tensors[v]; psi.tensors[v] = (t / np.linalg.norm(t) / np.sqrt(t.size)).astype(np.complex64)
+    chi, nlayers, dt = 32, 10, 0.3
     groups = tn.edge_color(g, 4)
-    layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+    seq = []
     for grp in groups:
-        layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
-    bpkw = dict(edge_sequence=tn.forest_cover_edge_sequence(g), maxiter=2, tolerance=None)
+        seq += list(grp) + [(b, a) for (a, b) in grp]
+    one_site = [("Rx", [v], 2 * 2.5 * dt) for v in g.vertices]
+    colour_groups = [[("Rzz", [a, b], 2 * 1.0 * dt) for (a, b) in grp] for grp in groups]
+    layer = one_site + [gt for grp in colour_groups for gt in grp]
     kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
-    bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
-    bo = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)
-    info = {}
-    bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw, info=info)
-    bo, eo = o.apply_gates(layer, bo, apply_kwargs=kw, bp_update_kwargs=bpkw)
-    assert info["n_updates"] == 5 and info["n_lowrank_svd"] > 0
-    assert [bd.bond_dim(a, b) for (a, b) in g.edges] == [bo.tns.bond_dim(a, b) for (a, b) in g.edges]
-    assert c64_errs_close(ed, eo, rel=5e-3, floor=1e-6), float(np.max(np.abs(ed - np.array(eo))))
+    psi = tn.tensornetworkstate(np.complex64, lambda v: "↑", g)
+    bd = tn.update(tn.BeliefPropagationCache(psi), edge_sequence=seq, maxiter=2, tolerance=None)
     zop = np.diag([1.0, -1.0]).astype(complex)
-    zd = tn.expect_all(bd, "Z").real
-    zo = np.array([o.expect_1site(bo, zop, v).real for v in g.vertices])
-    worst = 0.0
-    for (a, b) in g.edges:
-        for e in ((a, b), (b, a)):
-            md, mo = bd.message(e).astype(np.complex128), np.asarray(bo.message(e), dtype=np.complex128)
-            wd, wo = np.linalg.eigvalsh((md + md.conj().T) / 2), np.linalg.eigvalsh((mo + mo.conj().T) / 2)
-            worst = max(worst, float(np.max(np.abs(wd / wd.sum() - wo / wo.sum()))))
-    print(f"C2 shape, one layer: max|dZ| {np.max(np.abs(zd - zo)):.1e}  max|derr| {np.max(np.abs(ed - np.array(eo))):.1e} (max err {max(eo):.1e})  message spectra {worst:.1e}")
-    assert np.max(np.abs(zd - zo)) < 1e-5 and worst < 1e-5      # north star: expectation values within 1e-5 (same bound on the message spectra)
+    drift = []; lowrank = 0
+    with cpu_layer.parallel_oracle() as pool:
+        bo = cpu_layer.update(o.BeliefPropagationCache(to_oracle_state(psi), edge_sequence=seq), pool, maxiter=2, tolerance=None)
+        for it in range(nlayers):
+            info = {}
+            bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=dict(edge_sequence=seq, maxiter=2, tolerance=None), info=info)
+            bo, eo, _ = cpu_layer.apply_layer(bo, one_site, colour_groups, pool, kw, dict(maxiter=2, tolerance=None))
+            assert info["n_updates"] == 5; lowrank += info["n_lowrank_svd"]
+            ed2 = ed[len(one_site):]
+            assert [bd.bond_dim(a, b) for (a, b) in g.edges] == [bo.tns.bond_dim(a, b) for (a, b) in g.edges], it
+            zd = tn.expect_all(bd, "Z").real
+            zo = np.array([o.expect_1site(bo, zop, v).real for v in g.vertices])
+            dz = float(np.max(np.abs(zd - zo))); drift.append(dz)
+            print(f"C2 evolution layer {it + 1}: chi {bd.maxvirtualdim()}  max|dZ| {dz:.1e}  max truncation error {float(np.max(eo)):.1e}  "
+                  f"max |derr| {float(np.max(np.abs(ed2 - eo))):.1e}", flush=True)
+            assert c64_errs_close(ed2, eo), (it, float(np.max(np.abs(ed2 - eo))))
+            assert dz < 1e-5, (it, dz)
+    assert bd.maxvirtualdim() == chi and float(np.max(eo)) > 1e-7 and lowrank > 0      # the bonds did saturate, the last layers did truncate, the low-rank SVD route ran
+    compare_with_oracle_after_layer(g, bd, bo, ed2, eo, f"C2 evolution, after layer {nlayers}")
+    print("C2 evolution: max|dZ| per layer", " ".join(f"{x:.1e}" for x in drift))
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# BASELINE configs[3] / [4] per-site shapes with the ORACLE computing its own BP messages (no device message is copied into it).
-# The 3x3x3 torus of configs[3] has 27 degree-6 sites: one oracle sweep over it (162 messages of 26 GFLOP each through numpy) takes
-# about ten minutes, so the degree-6 shape is exercised on the smallest loopy graph that has two ADJACENT degree-6 sites -- a gate
-# between them is the bulk gate of the cubic lattice (both tensors 2 x 16^6 = 268 MB, five gauge legs each), every message the
-# hubs send is a bulk cubic message (five absorbed legs), and the spokes close 4-cycles through both hubs so BP is not exact.
-# ---------------------------------------------------------------------------------------------------------------
 def double_wheel():
     """vertices 0 (hub A), 1..5 (spokes of A), 6 (hub B), 7..11 (spokes of B); edges A-B, A-a_i, B-b_i, a_i-b_i: degrees 6, 6, 2 x 10"""
     edges = [(0, 6)] + [(0, 1 + i) for i in range(5)] + [(6, 7 + i) for i in range(5)] + [(1 + i, 7 + i) for i in range(5)]
@@ -356,7 +336,7 @@ def compare_with_oracle_after_layer(g, bd, bo, ed, eo, label):
     import tnqs_oracle as o
     from helpers import c64_errs_close
     assert [bd.bond_dim(a, b) for (a, b) in g.edges] == [bo.tns.bond_dim(a, b) for (a, b) in g.edges]
-    assert c64_errs_close(ed, eo, rel=5e-3, floor=1e-6), float(np.max(np.abs(ed - np.array(eo))))
+    assert c64_errs_close(ed, eo), float(np.max(np.abs(ed - np.array(eo))))
     zop = np.diag([1.0, -1.0]).astype(complex)
     zd = tn.expect_all(bd, "Z").real
     zo = np.array([o.expect_1site(bo, zop, v).real for v in g.vertices])
@@ -380,42 +360,11 @@ def messages_elementwise(bd, bo, g, tol):
     return worst
 
 
-def test_c4_shape_bp_and_layer_match_oracle():
-    """BASELINE configs[3] per-site shape (degree 6, chi = 16, ComplexF32) end to end against the oracle, the oracle iterating its OWN
-    messages: (i) two BP sweeps in a common explicit order from unset messages -- every message elementwise (same site tensors on both
-    sides, so the gauge is the same); (ii) one full layer of the 3-D Ising circuit (examples/3dIsing_dynamics.jl:15-26: Rz, Rxx per
-    colour, Rz) with a BP update per colour group: bond dimensions, truncation errors, <Z>, message spectra."""
-    import tnqs_oracle as o
-    from helpers import to_oracle_state
-    g = double_wheel()
-    assert sorted(g.degree(v) for v in g.vertices)[-2:] == [6, 6]
-    chi = 16
-    psi = small_norm_state(g, chi, seed=31)
-    seq = tn.forest_cover_edge_sequence(g)
-    bd = tn.update(tn.BeliefPropagationCache(psi), edge_sequence=seq, maxiter=2, tolerance=None)
-    bo = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), edge_sequence=seq, maxiter=2, tolerance=None)
-    w = messages_elementwise(bd, bo, g, 5e-5)
-    print(f"C4 shape, two BP sweeps: messages elementwise to {w:.1e}")
-    groups = tn.edge_color(g)
-    J, h, dt = -1.0, -1.0, 0.04
-    layer = [("Rz", [v], h * dt) for v in g.vertices]
-    for grp in groups:
-        layer += [("Rxx", [a, b], 2 * J * dt) for (a, b) in grp]
-    layer += [("Rz", [v], h * dt) for v in g.vertices]
-    kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
-    bpkw = dict(edge_sequence=seq, maxiter=1, tolerance=None)
-    info = {}
-    bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw, info=info)
-    bo, eo = o.apply_gates(layer, bo, apply_kwargs=kw, bp_update_kwargs=bpkw)
-    assert info["n_updates"] == len(groups) + 1 and info["n_two_site"] == g.ne()
-    compare_with_oracle_after_layer(g, bd, bo, ed, eo, "C4 shape, one layer")
-
-
 def test_c4_periodic_cubic_layer_matches_oracle():
     """BASELINE configs[3] on its own lattice type: the 3x3x3 PERIODIC cubic lattice at chi = 16, ComplexF32 (27 degree-6 sites of 268 MB, 81
     edges, 7 colours) -- the oracle iterating its OWN messages, no stand-in graph.  The oracle's arithmetic runs through oracle/cpu_layer.py
     (the same functions, the messages of a dependency level and the gates of a colour group on a thread pool), which makes a sweep a matter
-    of a minute on the GPU box's host.  (i) two BP sweeps in a common explicit order from unset messages: every message elementwise;
+    of a minute on the GPU box's host.  (i) one BP sweep in a common explicit order from unset messages: every message elementwise;
     (ii) one layer of the 3-D Ising circuit (examples/3dIsing_dynamics.jl:15-26: Rz on every vertex, Rxx per colour) with one BP sweep per
     update: bond dimensions, truncation errors, <Z>, message spectra."""
     import tnqs_oracle as o
@@ -429,7 +378,7 @@ def test_c4_periodic_cubic_layer_matches_oracle():
     seq = []
     for grp in groups:
         seq += list(grp) + [(b, a) for (a, b) in grp]
-    bd = tn.update(tn.BeliefPropagationCache(psi), edge_sequence=seq, maxiter=2, tolerance=None)
+    bd = tn.update(tn.BeliefPropagationCache(psi), edge_sequence=seq, maxiter=1, tolerance=None)
     J, h, dt = -1.0, -1.0, 0.04
     one_site = [("Rz", [v], h * dt) for v in g.vertices]
     colour_groups = [[("Rxx", [a, b], 2 * J * dt) for (a, b) in grp] for grp in groups]
@@ -437,9 +386,9 @@ def test_c4_periodic_cubic_layer_matches_oracle():
     kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
     with cpu_layer.parallel_oracle() as pool:
         bo = o.BeliefPropagationCache(to_oracle_state(psi), edge_sequence=seq)
-        bo = cpu_layer.update(bo, pool, maxiter=2, tolerance=None)
+        bo = cpu_layer.update(bo, pool, maxiter=1, tolerance=None)
         w = messages_elementwise(bd, bo, g, 5e-5)
-        print(f"C4 lattice (3x3x3 periodic), two BP sweeps: messages elementwise to {w:.1e}")
+        print(f"C4 lattice (3x3x3 periodic), one BP sweep: messages elementwise to {w:.1e}")
         info = {}
         bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=dict(edge_sequence=seq, maxiter=1, tolerance=None), info=info)
         bo, eo, _ = cpu_layer.apply_layer(bo, one_site, colour_groups, pool, kw, dict(maxiter=1, tolerance=None))

@@ -73,5 +73,9 @@ def test_bp_update_matches_golden(name):
         assert np.max(np.abs(got - ref)) < tol * np.max(np.abs(ref)), ns
     out = tn.update(bpc, maxiter=60, tolerance=None, edge_sequence=meta["seq"])
     assert np.max(np.abs(tn.expect_all(out, "Z") - z["expZ"])) < 100 * tol
+    for r, ref in zip(meta.get("regions", []), z["region_vals"] if "region_vals" in z.files else []):      # multi-site observables (ties, loops)
+        region, _ = tn.steiner_region(g, r["vertices"])
+        assert sorted(region, key=g.index.__getitem__) == r["steiner"]
+        assert abs(tn.expect(out, (r["ops"], r["vertices"])) - ref) < 100 * tol * max(1.0, abs(ref)), r
     if "expZ_exact" in z.files:                                  # BP is exact on trees (test/test_expect.jl:26-28)
         assert np.max(np.abs(tn.expect_all(out, "Z") - z["expZ_exact"])) < 100 * tol

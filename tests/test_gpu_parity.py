@@ -355,7 +355,7 @@ def test_identity_gate_leaves_the_bond_contracted_pair_unchanged(dtype, tol, lat
         assert out.bond_dim(a, b) == min(chi, 2 * min(chi ** (g.degree(a) - 1), chi ** (g.degree(b) - 1)))
 
 
-@pytest.mark.parametrize("seq_name", ["default", "forest", "colour", "reversed"])
+@pytest.mark.parametrize("seq_name", ["default", "reversed"])      # (rounds 2-3 also ran "forest" and "colour": 8.6 s each, same kernels; the default order and an adversarial one stay)
 def test_bp_update_chi32_bulk_sites_matches_oracle(seq_name):
     """chi = 32 on a 4x4 grid: the degree-4 sites run the shared pair-product path (two pair products per sweep reused
     by two messages each, validity tracked per message buffer) -- trajectories must still be the Gauss-Seidel ones of
@@ -582,11 +582,33 @@ def test_multi_site_expect_matches_oracle(dtype):
     oc = oracle_cache_from_device(bpc)
     vs = [(2, 1), (2, 2), (2, 3)]
     assert abs(tn.expect(bpc, (["Z", "X", "Z"], vs)) - o.expect_region(oc, {vs[0]: Z, vs[1]: X, vs[2]: Z}, vs)) < tol
-    # an ambiguous Steiner tree (two shortest paths around a plaquette) is refused, not guessed
-    with pytest.raises(tn.TnqsError):
-        tn.expect(bpc, ("ZZ", [(1, 1), (2, 2)]))
     with pytest.raises(tn.TnqsError):
         tn.expect(bpc, ("ZZZ", [(1, 1), (2, 2)]))
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_general_multi_site_expect_matches_oracle(dtype):
+    """any connected support (round-3 verdict, item 4; expect.jl:59-82): a diagonal pair (two shortest paths tie: the Steiner tree is picked by
+    the deterministic rule of graphs.py, the oracle picks it by its own statement of the same rule), a 2 x 2 plaquette (the induced region has a
+    loop: the closing bond is summed over inside the library), a three-site L, and a 2 x 3 block (two loops) on the 4 x 4 grid at chi = 4 --
+    against the oracle's dense contraction of the induced region."""
+    tol = 1e-5 if dtype == np.complex64 else 1e-9
+    X = np.array([[0, 1], [1, 0.0]])
+    g = tn.named_grid((4, 4))
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=4, seed=29)
+    kw = dict(maxiter=12, tolerance=None, edge_sequence=tn.forest_cover_edge_sequence(g))
+    bpc = tn.update(tn.BeliefPropagationCache(psi), **kw)
+    oc = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **kw)
+    cases = [("ZZ", [(1, 1), (2, 2)]), ("ZX", [(2, 2), (3, 3)]), ("ZZZZ", [(2, 2), (2, 3), (3, 3), (3, 2)]), ("ZXZ", [(1, 1), (1, 2), (2, 2)]),
+             ("ZX", [(1, 2), (3, 3)]), ("XZZX", [(1, 1), (2, 3), (1, 3), (2, 1)])]
+    mats = {"Z": Z, "X": X}
+    for ops, vs in cases:
+        got = tn.expect(bpc, (ops, vs))
+        ref = o.expect(oc, {v: mats[c] for v, c in zip(vs, ops)})
+        region, parent = tn.steiner_region(g, vs)
+        assert sorted(region, key=g.index.__getitem__) == o.steiner_vertices(oc.g, vs)
+        print(ops, vs, "region", len(region), "device", got, "oracle", ref)
+        assert abs(got - ref) < tol * max(1.0, abs(ref)), (ops, vs, got, ref)
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])

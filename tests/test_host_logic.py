@@ -126,3 +126,30 @@ def test_upstream_only_registry_entries_resolve_but_do_not_guess_a_matrix():
         tn.register_gate("Rz+", lambda t: np.eye(2))
     with pytest.raises(ValueError, match="upstream"):
         tn.gate_matrix("Rz+", 0.3)
+
+
+def test_steiner_tree_of_an_observable_support():
+    """steiner_region (graphs.py; src/expect.jl:67 -> Graphs.steiner_tree): terminals are in the tree, the tree is connected and minimal where the
+    answer is unambiguous, ties are resolved deterministically, and the oracle's own statement of the rule picks the same vertices."""
+    import tnqs_oracle as o
+    g = tn.named_grid((4, 4)); og = o.named_grid((4, 4))
+    region, parent = tn.steiner_region(g, [(1, 1), (1, 4)])
+    assert region == [(1, 1), (1, 2), (1, 3), (1, 4)] and parent == [-1, 0, 1, 2]
+    region, parent = tn.steiner_region(g, [(1, 1), (2, 2)])                       # two shortest paths: one of them, always the same
+    assert len(region) == 3 and region[0] == (1, 1) and region[-1] == (2, 2) and region == tn.steiner_region(g, [(1, 1), (2, 2)])[0]
+    region, parent = tn.steiner_region(g, [(2, 2), (2, 3), (3, 3), (3, 2)])       # a plaquette: its four vertices, three tree edges
+    assert sorted(region) == [(2, 2), (2, 3), (3, 2), (3, 3)] and sorted(parent)[0] == -1 and sum(1 for q in parent if q >= 0) == 3
+    import random
+    rnd = random.Random(5)
+    for hg, ho in ((g, og), (tn.heavy_hexagonal_lattice(2, 2), o.heavy_hexagonal_lattice(2, 2)), (tn.named_grid((3, 3, 2)), o.named_grid((3, 3, 2)))):
+        for _ in range(60):
+            vs = rnd.sample(list(hg.vertices), rnd.choice([2, 3, 4]))
+            region, parent = tn.steiner_region(hg, vs)
+            assert set(vs) <= set(region) and region[0] == vs[0]
+            for i, q in enumerate(parent):
+                assert (q == -1) == (i == 0) and (q < 0 or hg.has_edge(region[i], region[q]))
+            leaves = set(region) - {region[q] for q in parent if q >= 0}
+            assert leaves <= set(vs) or len(region) == 1                               # no dangling non-terminal
+            assert sorted(region, key=hg.index.__getitem__) == o.steiner_vertices(ho, vs)
+    with pytest.raises(ValueError):
+        tn.steiner_region(tn.NamedGraph([1, 2, 3], [(1, 2)]), [1, 3])
