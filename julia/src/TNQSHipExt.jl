@@ -338,7 +338,8 @@ function TN.expect(c::HipBeliefPropagationCache, obs::Tuple; alg = "bp", kwargs.
                                        c.handle, c.vid[vs[1]], m, out))
         return coeff * complex(out[1], out[2])
     end
-    # several sites: the region = vertices of the Steiner tree of the support (expect.jl:67), handed over as a rooted tree (BFS parents)
+    # several sites: the region = vertices of the Steiner tree of the support (expect.jl:67), handed over as a rooted spanning tree (BFS parents) of
+    # the INDUCED region; the library sums over region bonds that are not tree edges (a plaquette's closing bond), like norm_factors does (expect.jl:72)
     region = collect(vertices(NamedGraphs.steiner_tree(c.g, vs)))
     order = [first(vs)]
     par = Dict(first(vs) => Int32(-1))

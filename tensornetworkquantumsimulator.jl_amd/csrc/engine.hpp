@@ -149,6 +149,7 @@ struct State {
     std::vector<Buf> keepalive;    // descriptor buffers and workspaces kept until the next host sync
     size_t keep_mark = 0;          // keepalive[0, keep_mark) belongs to phases that have ended: released at the next stream synchronisation (soft_sync)
     HostArena arena;               // this handle's pinned staging arena (taken from / returned to a small free list, engine_core.cpp)
+    std::vector<HostArena> retired_arenas;      // arenas of forked halves: pending copies / kernels may still read them; recycled when this handle's stream has drained
     tnqs_apply_stats stats{};
 
     size_t esz() const { return dtype == TNQS_C64 ? 8 : 16; }

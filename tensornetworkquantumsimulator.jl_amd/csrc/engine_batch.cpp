@@ -191,7 +191,7 @@ template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, 
     }
     if (!fit.empty()) {
         size_t lds = 0; for (auto& j : fit) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, with_v, esz));
-        const JacobiItem* d = upload(s, fit);
+        const JacobiItem* d = upload_small(s, fit);
         int ncols = 1; for (auto& j : fit) ncols = std::max(ncols, j.nhint > 0 ? j.nhint : j.n);
         launch_jacobi<T>(s->stream, d, (int)fit.size(), 60, lds, mmax_of(fit), ncols);
     }

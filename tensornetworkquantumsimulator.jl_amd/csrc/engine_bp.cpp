@@ -670,7 +670,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     }
                 }
                 {
-                    const MsgFinalItem* d = upload(s, fin);
+                    const MsgFinalItem* d = upload_small(s, fin);
                     ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
                     launch_msg_finalize<T>(s->stream, d, (int)fin.size());
                 }

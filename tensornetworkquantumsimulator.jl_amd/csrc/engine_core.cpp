@@ -126,6 +126,11 @@ HostArena acquire_arena() {
     }
     return ar;
 }
+void recycle_arena(HostArena ar) {
+    if (!ar.base) return;
+    { std::lock_guard<std::mutex> lk(g_recycle_mu); if (g_spare_arenas.size() < kMaxSpares) { ar.off = 0; g_spare_arenas.push_back(ar); ar.base = nullptr; } }
+    if (ar.base) (void)hipHostFree(ar.base);
+}
 static hipStream_t acquire_stream(int device, int hi = 0) {
     {
         std::lock_guard<std::mutex> lk(g_recycle_mu);
@@ -143,6 +148,8 @@ State::~State() {
     if (aux_stream) (void)hipStreamSynchronize(aux_stream);
     for (auto q : hi_stream) if (q) (void)hipStreamSynchronize(q);
     keepalive.clear(); site.clear(); msg.clear();
+    for (auto& r : retired_arenas) recycle_arena(r);
+    retired_arenas.clear();
     HostArena ar = arena; arena = HostArena{};
     SpareStream st[4] = {{device, 0, (own_stream && stream) ? stream : nullptr}, {device, 0, aux_stream}, {device, 1, hi_stream[0]}, {device, 1, hi_stream[1]}};
     {
@@ -181,6 +188,8 @@ void sync(State* s) {
     HIPCHK(hipStreamSynchronize(s->stream));
     s->keepalive.clear(); s->keep_mark = 0;
     s->arena.off = 0;
+    for (auto& ar : s->retired_arenas) recycle_arena(ar);
+    s->retired_arenas.clear();
     if (s->prof) s->prof->chain = false;
 }
 

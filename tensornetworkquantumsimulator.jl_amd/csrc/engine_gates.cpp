@@ -69,7 +69,7 @@ template <class T> static void norm_and_replace(State* s, std::vector<int>& vert
             it.factor = reinterpret_cast<double*>(reinterpret_cast<char*>(fac->p) + 256 * i);
             nf.push_back(it);
         }
-        const NormFactorItem* d = upload(s, nf);
+        const NormFactorItem* d = upload_small(s, nf);
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_norm_factor(s->stream, d, (int)nf.size()); }
         for (size_t i = 0; i < verts.size(); ++i) { s->site[verts[i]] = outs[i]; s->sscale[verts[i]] = sub_buffer(fac, 256 * i, 8); }
         if (eager_scale()) materialize_scale_t<T>(s, verts);
@@ -262,7 +262,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             fi.push_back(EnvFinishItem{r.H, r.V, r.msq, r.prj, r.n, sqrt_cutoff, reinterpret_cast<int*>(d_flags->p) + 2 * i});
         }
         if (!envs.empty()) {
-            const EnvItem* de = upload(s, ei); const JacobiItem* dj = upload(s, ji); const EnvFinishItem* df = upload(s, fi);
+            const EnvItem* de = upload_small(s, ei); const JacobiItem* dj = upload_small(s, ji); const EnvFinishItem* df = upload_small(s, fi);
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, de, (int)ei.size()); }
             size_t lds = 0; for (auto& r : envs) lds = std::max(lds, jacobi_lds_bytes(r.n, r.n, true, 16));
             { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60, jacobi_lds(lds), mmax_of(ji)); }
@@ -295,12 +295,43 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     switch_stream(s, heavy_stream);
     if (s->fork_role == 2) { s->fork_sync->wait(); HIPCHK(hipStreamWaitEvent(s->stream, s->fork_sync->ev, 0)); }      // forked batch, half B: behind A's Gram pass
     run_chains<T>(s, chains, TNQS_PROF_GATE_MODEPROD);
+    std::vector<Buf> GA(sj.size()), GV(sj.size()), GW(sj.size()); std::vector<char> is_chol(sj.size(), 0), is_small(sj.size(), 0), small_done(sj.size(), 0);
+    auto nof = [&](size_t i) { return sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]; };
+    auto small_shape = [&](size_t i) { const int n = nof(i); return sj[i].sd.n / (size_t)n < (size_t)n && n <= 256 && use_small_svd(); };
+    // ---- 2b. sites with fewer fibers than columns (corners, low bond dimensions) are factorised without a Gram matrix, by a one-sided Jacobi of
+    // the small matricised psi~ (f64): three dependent launches (0.2 ms on a 7 x 7 lattice) that only need the gauged tensor.  They start NOW on a
+    // side stream, under the Gram pass, instead of in front of the Cholesky kernels afterwards (single rank, unforked batches) --------------------
+    hipEvent_t ev_small = nullptr;
+    if (!sharded && !chain_stream) {
+        std::vector<SmallSvdItem> si; std::vector<JacobiItem> sji;
+        for (size_t q = 0; q < own_idx.size(); ++q) {
+            const size_t i = own_idx[q];
+            if (!small_shape(i) || fused_M[q]) continue;
+            const int n = nof(i); const size_t Nout = sj[i].sd.n / (size_t)n;
+            GA[i] = dalloc(s, (size_t)n * n * 16); GV[i] = dalloc(s, (size_t)n * n * 16); GW[i] = GV[i]; is_small[i] = 1; small_done[i] = 1;
+            Buf M = dalloc(s, (size_t)n * Nout * 16); s->keepalive.push_back(M);
+            const SD& sd = sj[i].sd; const int b = sj[i].bleg;
+            si.push_back(SmallSvdItem{chains[q].result, M->p, GA[i]->p, GV[i]->p, sd.d, (int)(sd.pre(b) / sd.d), sd.chi[b], (int)sd.post(b)});
+            sji.push_back(JacobiItem{M->p, nullptr, n, (int)Nout, nullptr});
+        }
+        if (!si.empty()) {
+            const SmallSvdItem* ds = upload_small(s, si); const JacobiItem* dj = upload_small(s, sji);
+            hipStream_t side = aux_stream_of(s);
+            HIPCHK(hipEventRecord(s->ev_fork, s->stream)); HIPCHK(hipStreamWaitEvent(side, s->ev_fork, 0));
+            launch_small_svd_prepare<T>(side, ds, (int)si.size());
+            size_t lds = 0; for (auto& j : sji) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, false, 16));
+            launch_jacobi<double>(side, dj, (int)sji.size(), 60, jacobi_lds(lds), mmax_of(sji));
+            launch_small_svd_finish(side, ds, (int)si.size());
+            HIPCHK(hipEventRecord(s->ev_join, side)); ev_small = s->ev_join;
+        }
+    }
     // ---- 3. G = psi~^dagger psi~ over the outer legs, f64 accumulation (replaces the thin QR, simple_update.jl:45-48) --
-    std::vector<GramJob> jobs;
+    std::vector<GramJob> jobs; std::vector<int> job_of(own_idx.size(), -1);
     for (size_t q = 0; q < own_idx.size(); ++q) {
         const SiteJob& sjq = sj[own_idx[q]];
+        if (small_done[own_idx[q]]) continue;              // factorised without a Gram matrix (2b)
         GramJob j{}; j.X = chains[q].result; j.Y = chains[q].result; j.sd = sjq.sd; j.leg = sjq.bleg; j.keep_site = true; j.M = fused_M[q];
-        jobs.push_back(j);
+        job_of[q] = (int)jobs.size(); jobs.push_back(j);
     }
     {   // the fused and the plain Gram are different kernels: two batches, job order kept
         std::vector<GramJob> jf, jf16, jp; std::vector<size_t> idf, idf16, idp;
@@ -317,8 +348,6 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     }
     if (s->fork_role == 1) { HIPCHK(hipEventRecord(s->fork_sync->ev, s->stream)); s->fork_sync->signal(); }      // forked batch, half A: B's tensor passes may start
     switch_stream(s, chain_stream);
-    std::vector<Buf> GA(sj.size()), GV(sj.size());
-    auto nof = [&](size_t i) { return sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]; };
     // G slots: in the sharded case every rank needs G1 and G2 of the gates it takes part in -> all-gather all of them (the same layout
     // serves the Gram matrices of the second factorisation pass further down)
     std::vector<size_t> slot(sj.size(), 0); size_t stride = 0;
@@ -331,10 +360,12 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         }
         std::vector<ReduceItem> ri; int elems = 0;
         for (size_t q = 0; q < own_idx.size(); ++q) {
-            size_t i = own_idx[q]; int n = jobs[q].KK; size_t nn = (size_t)n * n;
+            if (job_of[q] < 0) continue;
+            const GramJob& jb = jobs[job_of[q]];
+            size_t i = own_idx[q]; int n = jb.KK; size_t nn = (size_t)n * n;
             GA[i] = dalloc(s, nn * 16);
             void* dst = sharded ? (void*)(reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride + slot[i]) : GA[i]->p;
-            ri.push_back(ReduceItem{jobs[q].partial->p, dst, (int)nn, jobs[q].nchunks, 1, elems}); elems += (int)nn;
+            ri.push_back(ReduceItem{jb.partial->p, dst, (int)nn, jb.nchunks, 1, elems}); elems += (int)nn;
         }
         const ReduceItem* dr = upload(s, ri);
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, dr, (int)ri.size(), elems); }
@@ -354,14 +385,12 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     // R factor of psi~ = Q R from G = R^dagger R: Cholesky (R = L^dagger) where G has full rank by construction (at least as
     // many fibers as columns); the f64 Jacobi eigen factorisation R = Lambda^1/2 W^dagger otherwise, and for the whole batch when
     // a Cholesky pivot collapses (numerically rank-deficient G; the eigen path drops the null space, rank_tau in kernels.hpp)
-    std::vector<Buf> GW(sj.size()); std::vector<char> is_chol(sj.size(), 0), is_small(sj.size(), 0);
     // ComplexF64, single rank: ill-conditioned sites get a second factorisation pass below, which sorts out what is signal and what is
     // noise among the smallest directions -- so the first pass keeps everything above the f64 noise floor instead of rank_tau
     const bool qr2 = !std::is_same<T, float>::value && use_qr2();
     auto tau_of = [&](int n) { return qr2 ? 1e-15 : rank_tau(std::is_same<T, float>::value, n); };
     // sites with fewer fibers than columns are factorised by their owner without a Gram matrix (small-SVD route) and never refined; the
     // criterion must not depend on ownership, every rank taking part in a gate has to reach the same decision
-    auto small_shape = [&](size_t i) { const int n = nof(i); return sj[i].sd.n / (size_t)n < (size_t)n && n <= 256 && use_small_svd(); };
     std::vector<const void*> gauged_of(sj.size(), nullptr);      // psi~ of the owned sites
     for (size_t q = 0; q < own_idx.size(); ++q) gauged_of[own_idx[q]] = chains[q].result;
     Buf d_cholfail = dalloc(s, std::max<size_t>(1, sj.size()) * sizeof(int));      // one flag per site: only the sites whose pivot collapsed are redone
@@ -370,7 +399,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         std::vector<JacobiItem> ji, sji; std::vector<EnvItem> idn; std::vector<CholItem> ci; std::vector<SmallSvdItem> si; int cmax = 1;
         if (!fallback) HIPCHK(hipMemsetAsync(d_cholfail->p, 0, std::max<size_t>(1, sj.size()) * sizeof(int), s->stream));
         for (size_t i = 0; i < sj.size(); ++i) {
-            if (!part[i / 2]) continue;
+            if (!part[i / 2] || small_done[i]) continue;
             if (fallback && !(is_chol[i] && h_cholfail[i])) continue;      // fallback pass: only the Cholesky sites whose pivot collapsed (the eigen sites are factorised, GA rotated in place)
             int n = nof(i);
             if (!GV[i]) GV[i] = dalloc(s, (size_t)n * n * 16);
@@ -396,7 +425,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             }
         }
         if (!si.empty()) {
-            const SmallSvdItem* ds = upload(s, si); const JacobiItem* dj = upload(s, sji);
+            const SmallSvdItem* ds = upload_small(s, si); const JacobiItem* dj = upload_small(s, sji);
             ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0);
             launch_small_svd_prepare<T>(s->stream, ds, (int)si.size());
             size_t lds = 0; for (auto& j : sji) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, false, 16));
@@ -404,13 +433,13 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             launch_small_svd_finish(s->stream, ds, (int)si.size());
         }
         if (!ci.empty()) {      // n <= 96: square LDS array; 96 < n <= 128 (chi = 64 sites): packed triangle
-            const CholItem* dc = upload(s, ci); ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0);
+            const CholItem* dc = upload_small(s, ci); ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0);
             if (cmax <= 96) launch_chol(s->stream, dc, (int)ci.size(), cmax); else launch_chol_packed(s->stream, dc, (int)ci.size(), cmax);
         }
         if (!ji.empty()) {
-            const EnvItem* di = upload(s, idn);
+            const EnvItem* di = upload_small(s, idn);
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, di, (int)idn.size()); }
-            const JacobiItem* dj = upload(s, ji);
+            const JacobiItem* dj = upload_small(s, ji);
             size_t lds = 0; for (auto& j : ji) lds = std::max(lds, jacobi_lds_bytes(j.n, j.n, true, 16));
             { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); launch_jacobi<double>(s->stream, dj, (int)ji.size(), 60, jacobi_lds(lds), mmax_of(ji)); }
         }
@@ -534,7 +563,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     Buf d_texp = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));
     Buf d_lowfail2 = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));      // ComplexF64: second CholeskyQR pass of the low-rank route
     for (int q = 0; q < npg; ++q) { gitems[q].lowfail = reinterpret_cast<const int*>(d_lowfail->p) + q; gitems[q].texp = reinterpret_cast<int*>(d_texp->p) + q; }
-    const GateItem* d_gitems = upload(s, gitems);
+    const GateItem* d_gitems = upload(s, gitems);       // (read again after the host synchronisations of the batch: a device copy, not upload_small)
     auto run_theta = [&]() {
         HIPCHK(hipMemsetAsync(d_info_all->p, 0, std::max<size_t>(1, (size_t)npg * 32), s->stream));
         HIPCHK(hipMemsetAsync(d_lowfail->p, 0, std::max<size_t>(1, (size_t)npg * sizeof(int)), s->stream));
@@ -562,11 +591,11 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             }
         }
         if (!lc.empty()) {
-            const CholItem* dc = upload(s, lc); launch_lowrank_g(s->stream, d_gitems, npg);
+            const CholItem* dc = upload_small(s, lc); launch_lowrank_g(s->stream, d_gitems, npg);
             if (kmax <= 96) launch_chol(s->stream, dc, (int)lc.size(), kmax); else launch_chol_packed(s->stream, dc, (int)lc.size(), kmax);      // ComplexF32: only L is used here
             if (!f64) launch_lowrank_m<T>(s->stream, d_gitems, npg);
             else {
-                const LowQr2Item* dq = upload(s, qi); const GateItem* d2 = upload(s, g2); const GateItem* d3 = upload(s, g3); const CholItem* dc2 = upload(s, lc2);
+                const LowQr2Item* dq = upload_small(s, qi); const GateItem* d2 = upload_small(s, g2); const GateItem* d3 = upload_small(s, g3); const CholItem* dc2 = upload_small(s, lc2);
                 launch_lowrank_bw(s->stream, dq, (int)qi.size());                       // B1 = B L1^-dagger
                 launch_lowrank_g(s->stream, d2, (int)g2.size());                        // G2 = B1^dagger B1
                 if (kmax <= 96) launch_chol(s->stream, dc2, (int)lc2.size(), kmax); else launch_chol_packed(s->stream, dc2, (int)lc2.size(), kmax);
@@ -576,6 +605,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         }
         launch_theta_scale<T>(s->stream, d_gitems, npg);       // theta (or M) and theta0 to O(1), exponent kept per gate for gate_finish
     };
+    if (ev_small) HIPCHK(hipStreamWaitEvent(s->stream, ev_small, 0));      // the early small-SVD factors (2b) are inputs of gate_theta
     run_theta();
     std::vector<int> info(8 * (size_t)ng, 0); std::vector<double> terr(ng, 0.0);
     {
@@ -605,7 +635,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); svd_batch<T>(s, ji, false); }
             std::vector<RecoverItem> rv;
             for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ncfull[q], ji[q].n, ji[q].dyn, ji[q].dm, ji[q].dn});
-            const RecoverItem* dr = upload(s, rv);
+            const RecoverItem* dr = upload_small(s, rv);
             { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); { int nmax = 1; for (int nc : ncfull) nmax = std::max(nmax, nc); if (std::is_same<T, float>::value && use_mfma()) launch_recover_v_mfma(s->stream, dr, npg, nmax); else launch_recover_v<T>(s->stream, dr, npg, nmax); } }
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
         };
@@ -931,7 +961,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             }
             if (errs) errs[gates[gi].index] = terr[gi];
         }
-        const DiagItem* d = upload(s, di);
+        const DiagItem* d = upload_small(s, di);
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_diag<T>(s->stream, d, (int)di.size()); }
     }
     for (auto& g2 : gates) { s->pend1[g2.v1].clear(); s->pend1[g2.v2].clear(); s->unit_norm[g2.v1] = s->unit_norm[g2.v2] = ao.normalize_tensors ? 1 : 0; }
@@ -1009,6 +1039,7 @@ template <class T> static void apply_two_site_forked(State* s, const std::vector
     // B's workspaces and descriptor buffers live until the main stream has drained past the join
     for (auto& k : b->keepalive) s->keepalive.push_back(k);
     b->keepalive.clear(); soft_sync(s);
+    if (b->arena.base) { s->retired_arenas.push_back(b->arena); b->arena = HostArena{}; }      // B's pending copies / kernels still read its staging arena
     {   // B's profiler scopes: events recorded on its stream, collected with the others
         Prof& P = *s->prof; Prof& Q = *b->prof;
         for (int c = 0; c < TNQS_PROF_NCLASSES; ++c) { P.cls[c].launches += Q.cls[c].launches; P.cls[c].bytes += Q.cls[c].bytes; P.cls[c].flops += Q.cls[c].flops; P.cls[c].ms += Q.cls[c].ms; }

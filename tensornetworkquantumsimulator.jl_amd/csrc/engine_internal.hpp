@@ -84,6 +84,7 @@ struct HostTimer {
 void sync(State* s);                                   // stream synchronise + release of the batch's descriptor buffers
 hipStream_t aux_stream_of(State* s);                  // second stream of a forked gate batch (+ its events), created / recycled with the State
 void switch_stream(State* s, hipStream_t to);        // continue on another stream of this State, ordered behind the current one (null / same: no-op)
+void recycle_arena(HostArena ar);                     // back to the free list (nothing on the device may still read it)
 HostArena acquire_arena();                             // a recycled or freshly pinned 32 MiB arena (engine_core.cpp)
 // Read-back through the pinned staging arena: the copy is enqueued and the staged host pointer returned; it holds the data once the stream
 // has been synchronised (a read-back into pageable memory is staged by the runtime and BLOCKS per call).  The staged bytes stay valid until the
@@ -113,6 +114,8 @@ inline void soft_sync(State* s) { s->keep_mark = s->keepalive.size(); }
 inline void drained(State* s) {
     s->prof->chain = false;                    // the host waited: the next profiled scope records its own start event
     s->arena.off = 0;                          // every staged upload has been copied; staged read-backs are consumed by the caller before its next upload
+    for (auto& ar : s->retired_arenas) recycle_arena(ar);
+    s->retired_arenas.clear();
     if (s->keep_mark) { s->keepalive.erase(s->keepalive.begin(), s->keepalive.begin() + (std::ptrdiff_t)std::min(s->keep_mark, s->keepalive.size())); s->keep_mark = 0; }
 }
 void materialize_scale(State* s, const std::vector<int>& verts);
@@ -143,6 +146,27 @@ template <class Item> const Item* upload(State* s, const std::vector<Item>& v) {
     HIPCHK(hipMemcpyAsync(b->p, h, bytes, hipMemcpyHostToDevice, s->stream));
     s->keepalive.push_back(b);
     return reinterpret_cast<const Item*>(b->p);
+}
+
+// The same for the descriptor arrays of the ONE-WORKGROUP-PER-ITEM kernels (items[blockIdx.x]: env / Cholesky / theta / Jacobi / finish / diag ...):
+// no copy at all -- the kernel reads its item straight from the pinned arena (hipHostMalloc memory is mapped into the device's address space under the
+// same pointer).  A dependent chain of 20-60 us kernels paid ~5 us of stream time and ~8 us of host time per descriptor copy (two dozen per gate
+// batch); a workgroup's single ~100-byte read over the host link costs it 1-2 us.  NOT for kernels that binary-search their item list per workgroup
+// (the tensor passes, reduce) or re-read the data in inner loops (gate matrices).  The bytes stay valid until the arena is reset, which only
+// happens after the stream has been synchronised (drained / sync / wrap below) -- by then every kernel that reads them has run.  Hence: only for
+// arrays whose kernels are ALL launched before the next host synchronisation of the phase (the GateItem array of a batch is read again after the
+// read-back of the ranks in the two-trip flow: it keeps its device copy).
+template <class Item> const Item* upload_small(State* s, const std::vector<Item>& v) {
+    if (v.empty()) return nullptr;
+    const size_t bytes = v.size() * sizeof(Item);
+    HostArena& ar = s->arena;
+    if (!ar.base) ar = acquire_arena();
+    const size_t aligned = (bytes + 255) & ~size_t(255);
+    if (aligned > ar.cap) throw Err(TNQS_ERR_UNSUPPORTED, "descriptor batch too large");
+    if (ar.off + aligned > ar.cap) { HIPCHK(hipStreamSynchronize(s->stream)); ar.off = 0; s->prof->chain = false; }
+    char* h = ar.base + ar.off; ar.off += aligned;
+    std::memcpy(h, v.data(), bytes);
+    return reinterpret_cast<const Item*>(h);
 }
 
 struct ProfScope {
