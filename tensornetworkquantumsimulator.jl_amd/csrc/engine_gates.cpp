@@ -213,7 +213,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     }
     // forked batch (apply_two_site_forked): the per-gate chains run on the half's high-priority stream, the tensor passes on its ordinary one
     hipStream_t const heavy_stream = s->stream; hipStream_t const chain_stream = s->chain_stream;
-    struct RestoreStream { State* s; hipStream_t h; ~RestoreStream() { s->stream = h; } } restore_stream{s, heavy_stream};
+    struct RestoreStream { State* s; hipStream_t h; ~RestoreStream() { s->stream = h; g_corun_geometry = false; } } restore_stream{s, heavy_stream};
+    g_corun_geometry = s->fork_role != 0;       // chain kernels of a forked half run next to the other half's tensor passes (kernels.hpp)
     HostTimer ht_a(3);                 // TNQS_HOST_TIMING=1: host time of the batch up to the first read-back (3), between the read-backs (4), after them (5)
     if (!ao.normalize_tensors) {       // without the final normalisation the result scales with the inputs: apply pending factors first
         std::vector<int> vs; for (auto& g2 : gates) { vs.push_back(g2.v1); vs.push_back(g2.v2); }

@@ -671,7 +671,7 @@ __device__ __forceinline__ long long pair_slice_base(const PairGeom& g, int sl) 
 }
 template <bool M3>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mfma_pair_kernel(const PairItem* __restrict__ items, int nitems) {
-    constexpr int PS = 32 * 33 + 1;            // plane stride in complex elements, pitch 33 (rows and columns both conflict-free)
+    constexpr int PS = 32 * 33 + 4;            // plane stride in complex elements, pitch 33 (rows and columns both conflict-free)
     constexpr int BUF = 8 * PS;
     #define TNQS_PIN() __builtin_amdgcn_sched_barrier(0x2 | 0x4)      // VALU / SALU may cross; LDS, global and matrix instructions keep their order
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
-    const size_t lds = (size_t)16 * (32 * 33 + 1) * 2 * sizeof(float);
+    const size_t lds = (size_t)16 * (32 * 33 + 4) * 2 * sizeof(float);
     if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_pair_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
     else { set_max_dynamic_lds((const void*)mfma_pair_kernel<false>, lds); hipLaunchKernelGGL(mfma_pair_kernel<false>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
     TNQS_CHECK_LAUNCH();
@@ -936,7 +936,7 @@ void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitem
 // ------------------------------------------------------------------------------------------------------------
 template <bool M3>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mfma_pair_gram2_kernel(const PairGram2Item* __restrict__ items, int nitems) {
-    constexpr int PS = 32 * 33 + 1;            // plane stride in complex elements
+    constexpr int PS = 32 * 33 + 8;            // plane stride in complex elements
     constexpr int BUF = 8 * PS;                // one phase: X planes of companions 0..3, then their Y planes
     // scheduling barrier: VALU / SALU may cross, LDS, global-memory and matrix instructions keep their program order
     #define TNQS_PIN() __builtin_amdgcn_sched_barrier(0x2 | 0x4)
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 int pair_gram2_group() { return 32; }
 void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
-    const size_t lds = (size_t)16 * (32 * 33 + 1) * 2 * sizeof(float);
+    const size_t lds = (size_t)16 * (32 * 33 + 8) * 2 * sizeof(float);
     if (mfma_use_3m()) {
         set_max_dynamic_lds((const void*)mfma_pair_gram2_kernel<true>, lds);
         hipLaunchKernelGGL(mfma_pair_gram2_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
