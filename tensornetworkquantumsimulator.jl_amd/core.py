@@ -333,6 +333,47 @@ def _apply_opts(kw: Optional[dict], update_cache: bool) -> L.ApplyOpts:
     return a
 
 
+def _gate_spec_of(name: str):
+    """the registry entry a gate name resolves to right now (None: a Pauli string or an unknown name)"""
+    from .gates import _resolve
+    return _resolve(name)
+
+
+_MARSHALLED: list = []      # (graph, ids of the gate tuples, gate tuples, arrays): the last few circuits, most recent first
+
+
+def _marshal_circuit(circuit: Sequence, g: NamedGraph):
+    """circuit tuples -> the flat arrays of tnqs_apply_gates (vertex counts, vertex ids, complex128 matrices).  A Trotter loop applies the same
+    layer object over and over (examples/2dIsing_dynamics.jl:56-57); resolving 1160 gate tuples costs 2.5 ms of Python per 20x20 layer and 0.75 ms of
+    a 5 ms heavy-hex layer, so the arrays of the last few circuits are kept -- keyed by the IDENTITY of every gate tuple (tuples are immutable: the same
+    objects in the same order on the same graph are the same circuit), which costs ~30 ns per gate to check."""
+    ids = tuple(map(id, circuit))
+    for k, (g0, ids0, _gates, specs, arrs) in enumerate(_MARSHALLED):
+        if g0 is g and ids0 == ids and all(_gate_spec_of(nm) is sp for nm, sp in specs):      # (the registry still maps every name to the same definition)
+            if k:
+                _MARSHALLED.insert(0, _MARSHALLED.pop(k))
+            return arrs
+    nverts, verts, mats = [], [], []
+    index = g.index
+    for gate in circuit:
+        m, vs = resolve_gate_flat(gate, g)
+        nverts.append(len(vs))
+        for v in vs:
+            verts.append(index[v])
+        mats.append(m)
+    ng = len(nverts)
+    nv_a, nv_p = L.i32(nverts if ng else [0])
+    vs_a, vs_p = L.i32(verts if verts else [0])
+    mat_a = np.ascontiguousarray(np.concatenate(mats) if mats else np.zeros(1, dtype=np.complex128))
+    arrs = (ng, nv_a, nv_p, vs_a, vs_p, mat_a)
+    # not cached: a gate given as a list (it could be edited in place) or as a matrix (an array is mutable)
+    if all(isinstance(gt, tuple) and isinstance(gt[0], str) for gt in circuit):
+        names = {gt[0] for gt in circuit}
+        _MARSHALLED.insert(0, (g, ids, tuple(circuit), [(nm, _gate_spec_of(nm)) for nm in names], arrs))   # the tuple keeps the gate objects (and their ids) alive
+        del _MARSHALLED[4:]
+    return arrs
+
+
 def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_update_kwargs: Optional[dict] = None,
                 update_cache: bool = True, verbose: bool = False, info: Optional[dict] = None):
     """apply_gates(circuit, psi; apply_kwargs, bp_update_kwargs, update_cache) -> (psi', truncation_errors).
@@ -347,18 +388,7 @@ def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_
     if not isinstance(psi, BeliefPropagationCache):
         raise TypeError("apply_gates: expected a TensorNetworkState or a BeliefPropagationCache")
     g = psi.graph
-    nverts, verts, mats = [], [], []
-    index = g.index
-    for gate in circuit:
-        m, vs = resolve_gate_flat(gate, g)
-        nverts.append(len(vs))
-        for v in vs:
-            verts.append(index[v])
-        mats.append(m)
-    ng = len(nverts)
-    nv_a, nv_p = L.i32(nverts if ng else [0])
-    vs_a, vs_p = L.i32(verts if verts else [0])
-    mat_a = np.ascontiguousarray(np.concatenate(mats) if mats else np.zeros(1, dtype=np.complex128))
+    ng, nv_a, nv_p, vs_a, vs_p, mat_a = _marshal_circuit(circuit, g)
     errs = np.zeros(max(ng, 1), dtype=np.float64)
     ao = _apply_opts(apply_kwargs, update_cache)
     bo, keep = _bp_opts(g, bp_update_kwargs, psi.default_bp_update_kwargs())

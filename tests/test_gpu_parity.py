@@ -1135,3 +1135,27 @@ def test_real_network_real_gates_then_promotion_by_a_complex_gate(real, cplx):
     assert np.max(np.abs(ed2 - eo2)) < max(tol, 1e-6) * 10
     for v in g.vertices:
         assert abs(tn.expect(bd2, ("Z", [v])) - o.expect_1site(bo2, Z, v)) < tol
+
+
+def test_marshalled_circuits_are_reused_only_while_they_mean_the_same():
+    """core._marshal_circuit keeps the flat arrays of the last few circuits, keyed by the identity of the gate tuples: the same layer object applied twice
+    takes the cached arrays, an equal but rebuilt layer gives the same result, and re-registering a custom gate under the same name invalidates the entry."""
+    g = tn.named_grid((3, 3))
+    psi = tn.random_tensornetworkstate(np.complex128, g, bond_dimension=2, seed=5)
+    bpc = tn.update(tn.BeliefPropagationCache(psi), maxiter=20, tolerance=None)
+    tn.register_gate("MyPhase", lambda t: np.diag([1.0, np.exp(1j * t)]), nparams=1)
+    try:
+        mk = lambda: [("MyPhase", [v], 0.3) for v in g.vertices] + [("Rzz", [a, b], 0.2) for grp in tn.edge_color(g, 4) for (a, b) in grp]
+        layer = mk()
+        kw = dict(maxdim=4, cutoff=1e-12, normalize_tensors=True); bk = dict(maxiter=20, tolerance=None)
+        b1, e1 = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=bk)
+        b2, e2 = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=bk)          # cached arrays
+        b3, e3 = tn.apply_gates(mk(), bpc, apply_kwargs=kw, bp_update_kwargs=bk)           # rebuilt list: marshalled afresh
+        z1, z2, z3 = tn.expect_all(b1, "Z"), tn.expect_all(b2, "Z"), tn.expect_all(b3, "Z")
+        assert np.array_equal(z1, z2) and np.array_equal(e1, e2) and np.array_equal(z1, z3)
+        tn.unregister_gate("MyPhase")
+        tn.register_gate("MyPhase", lambda t: np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]]), nparams=1)      # same name, another gate
+        b4, _ = tn.apply_gates(layer, bpc, apply_kwargs=kw, bp_update_kwargs=bk)
+        assert np.max(np.abs(tn.expect_all(b4, "Z") - z1)) > 1e-3
+    finally:
+        tn.unregister_gate("MyPhase")
