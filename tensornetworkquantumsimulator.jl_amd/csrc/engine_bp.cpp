@@ -246,11 +246,17 @@ struct ProdCache {
         for (auto& e : vec) if (e.site == site && e.legs == legs) { bytes += prod->bytes; bytes -= e.prod->bytes; e.prod = prod; e.stamp = ++clock; return; }
         if ((int)vec.size() >= per_site) { size_t lru = 0; for (size_t i = 1; i < vec.size(); ++i) if (vec[i].stamp < vec[lru].stamp) lru = i; bytes -= vec[lru].prod->bytes; vec.erase(vec.begin() + lru); }
         ProdEntry e; e.site = site; e.legs = std::move(legs); e.prod = prod; e.stamp = ++clock; bytes += prod->bytes; vec.push_back(std::move(e));
-        while (bytes > cap) {                      // over the byte bound: the least recently used entry of all sites goes
-            std::vector<ProdEntry>* wv = nullptr; size_t wi = 0;
-            for (auto& kv : by_site) for (size_t i = 0; i < kv.second.size(); ++i) if (!wv || kv.second[i].stamp < (*wv)[wi].stamp) { wv = &kv.second; wi = i; }
-            if (!wv) break;
-            bytes -= (*wv)[wi].prod->bytes; wv->erase(wv->begin() + wi);
+        if (bytes > cap) {                         // over the byte bound: the least recently used entries of all sites go, in ONE pass -- down to 7/8 of the
+            // bound, so that a long level under memory pressure does not rescan every entry for every product it stores (round-3 advisor finding)
+            std::vector<std::pair<unsigned long long, int>> order;          // (stamp, site)
+            for (auto& kv : by_site) for (auto& en : kv.second) order.push_back({en.stamp, kv.first});
+            std::sort(order.begin(), order.end());
+            const size_t target = cap - cap / 8;
+            for (auto& o : order) {
+                if (bytes <= target) break;
+                auto& vv = by_site[o.second];
+                for (size_t i = 0; i < vv.size(); ++i) if (vv[i].stamp == o.first) { bytes -= vv[i].prod->bytes; vv.erase(vv.begin() + (std::ptrdiff_t)i); break; }
+            }
         }
     }
 };

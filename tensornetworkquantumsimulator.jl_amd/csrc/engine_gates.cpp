@@ -789,6 +789,10 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         for (int q = 0; q < npg; ++q) {
             int Mr, Nc, ncolJ; theta_dims(hinfo.data() + 8 * q, gitems[q].d1, gitems[q].d2, Mr, Nc, ncolJ);
             s->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0; s->stats.n_svd_sweeps += hinfo[8 * q + 4];
+            {   // qualified for the low-rank route by its ranks, but gate_theta's offer was withdrawn on the device (lowrank_m: a refused pivot)
+                const int K = gitems[q].kappa * gitems[q].chi, r1d = hinfo[8 * q] * gitems[q].d1, r2d = hinfo[8 * q + 1] * gitems[q].d2;
+                if (gitems[q].lowG && ncolJ == Nc && r1d >= r2d && K < r2d && gitems[q].chi_cap <= K) s->stats.n_lowrank_fallbacks += 1;
+            }
             for (int k = 0; k < 8; ++k) info[8 * pg[q] + k] = hinfo[8 * q + k]; terr[pg[q]] = hterr[q];
         }
     }
@@ -1034,7 +1038,7 @@ template <class T> static void apply_two_site_forked(State* s, const std::vector
             s->chi[e] = b->chi[e]; s->msg[2 * e] = b->msg[2 * e]; s->msg[2 * e + 1] = b->msg[2 * e + 1];
         }
         s->stats.n_two_site += b->stats.n_two_site; s->stats.n_chol_fallbacks += b->stats.n_chol_fallbacks; s->stats.n_qr2_sites += b->stats.n_qr2_sites;
-        s->stats.n_lowrank_svd += b->stats.n_lowrank_svd; s->stats.n_tall_svd += b->stats.n_tall_svd; s->stats.n_svd_sweeps += b->stats.n_svd_sweeps;
+        s->stats.n_lowrank_svd += b->stats.n_lowrank_svd; s->stats.n_lowrank_fallbacks += b->stats.n_lowrank_fallbacks; s->stats.n_tall_svd += b->stats.n_tall_svd; s->stats.n_svd_sweeps += b->stats.n_svd_sweeps;
         s->stats.n_forked_batches += 1;
     }
     // B's workspaces and descriptor buffers live until the main stream has drained past the join

@@ -206,3 +206,27 @@ def test_chi64_kernels_match_the_generic_route_on_a_physical_evolution():
     assert np.all(np.abs(ea - eb) < 5e-3 * np.maximum(ea, eb) + 5e-7)
     assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-4
     assert abs(on["norm"] - 1) < 1e-4 and np.all(ea >= 0) and np.all(ea <= 1)
+
+
+def test_partial_product_cache_under_a_small_budget():
+    """TNQS_BP_CACHE_MB=700 holds two or three of the 268 MB products of the 3x3x3 torus: entries are evicted all the time (in bulk, least recently
+    used first).  Validity is by buffer identity, so an evicted product is simply recomputed: same layer as with the default budget, more two-leg passes."""
+    on, small = run_worker({}, "cubic16"), run_worker({"TNQS_BP_CACHE_MB": "700"}, "cubic16")
+    assert small["pair"] > on["pair"], (small["pair"], on["pair"])
+    assert on["dims"] == small["dims"]
+    ea, eb = np.array(on["errs"]), np.array(small["errs"])
+    assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7)
+    assert np.max(np.abs(np.array(on["z"]) - np.array(small["z"]))) < 1e-5
+
+
+def test_c128_lowrank_theta_route_matches_the_full_svd():
+    """ComplexF64 (round 4): theta SVD on the low-rank factor with B orthogonalised by CholeskyQR2 against the SVD of the full theta
+    (TNQS_NO_LOWRANK=1): same bond dimensions, truncation errors and <Z> to 1e-9; taken for the kappa = 2 gate (Rzz) in the bulk, never for SWAP
+    (kappa = 4: K = 4 chi is not below theta's column count), and no gate fell back on this well-conditioned state."""
+    on, off = run_worker({}, "c128"), run_worker({"TNQS_NO_LOWRANK": "1"}, "c128")
+    assert on["Rzz"]["lowrank"] > 0 and on["Rzz"]["fallbacks"] == 0 and on["SWAP"]["lowrank"] == 0 and off["Rzz"]["lowrank"] == 0
+    for name in ("Rzz", "SWAP"):
+        a, b = on[name], off[name]
+        assert a["dims"] == b["dims"]
+        assert np.max(np.abs(np.array(a["errs"]) - np.array(b["errs"]))) < 1e-9
+        assert np.max(np.abs(np.array(a["z"]) - np.array(b["z"]))) < 1e-9       # (messages are not compared elementwise: the two routes fix the phases of the singular vectors differently)

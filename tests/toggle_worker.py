@@ -79,10 +79,11 @@ def c128():
     out = {}
     for name in ("Rzz", "SWAP"):
         layer = [("Rx", [v], 0.3) for v in g.vertices] + [((name, [a, b], 0.4) if name == "Rzz" else (name, [a, b])) for grp in tn.edge_color(g, 4) for (a, b) in grp]
-        b2, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=8, cutoff=1e-12, normalize_tensors=True), bp_update_kwargs=dict(maxiter=20, tolerance=None))
+        info = {}
+        b2, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=8, cutoff=1e-12, normalize_tensors=True), bp_update_kwargs=dict(maxiter=20, tolerance=None), info=info)
         msgs = [b2.message(e) for (a, b) in g.edges[:8] for e in ((a, b), (b, a))]
         out[name] = dict(errs=errs.tolist(), z=[float(np.real(x)) for x in tn.expect_all(b2, "Z")], dims=[b2.bond_dim(a, b) for a, b in g.edges],
-                         msgs=[[m.real.tolist(), m.imag.tolist()] for m in msgs])
+                         msgs=[[m.real.tolist(), m.imag.tolist()] for m in msgs], lowrank=info["n_lowrank_svd"], fallbacks=info["n_lowrank_fallbacks"], n2=info["n_two_site"])
     print(json.dumps(out))
 
 
