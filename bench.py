@@ -260,8 +260,8 @@ def main():
     elif cfg == "c5":
         KERNEL_OF.update({"bp_modeprod": "tnqs::mfma_rowgemm_kernel<2, 2, 1>", "gate_modeprod": "tnqs::mfma_rowgemm_kernel<2, 2, 1>", "bp_gram": "tnqs::mfma_gram64_kernel",
                           "gate_gram": "tnqs::mfma_gram128_f64_kernel", "gate_apply": "tnqs::mfma_rowgemm_kernel<4, 4, 2>"})
-    traffic_db, traffic_src = profile_db(os.environ.get("TNQS_BENCH_PMC_PROFILE", "r3_pmc_traffic.json"))
-    mfma_db, mfma_src = profile_db(os.environ.get("TNQS_BENCH_MFMA_PROFILE", "r3_mfma_util.json"))
+    traffic_db, traffic_src = profile_db(os.environ.get("TNQS_BENCH_PMC_PROFILE", "r4_pmc_traffic.json"))
+    mfma_db, mfma_src = profile_db(os.environ.get("TNQS_BENCH_MFMA_PROFILE", "r4_mfma_util.json"))
     dom = max(prof, key=lambda k: prof[k]["ms"])
     p = prof[dom]
     roofline = None

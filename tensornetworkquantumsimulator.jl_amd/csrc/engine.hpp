@@ -125,6 +125,7 @@ struct State {
     std::vector<Buf> msg;          // 2*ne, null = unset = identity (tensornetworkstate.jl:72-75)
     std::shared_ptr<Pool> pool;
     hipStream_t stream = nullptr; bool own_stream = false;
+    hipStream_t base_stream = nullptr;      // forked half: its ordinary stream (`stream` alternates between this one and chain_stream)
     // second stream of a forked gate batch (engine_gates.cpp apply_two_site_forked) with the two events that order it against `stream`;
     // created on first use, owned by this State
     hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;

@@ -988,7 +988,7 @@ static std::unique_ptr<State> fork_state(State* s) {
     b->site = s->site; b->sscale = s->sscale; b->msg = s->msg; b->pool = s->pool;
     b->prof = std::make_shared<Prof>(); b->prof->on = s->prof->on;
     b->pend1 = s->pend1; b->unit_norm = s->unit_norm; b->in_apply = s->in_apply;
-    b->stream = aux_stream_of(s); b->own_stream = false;
+    b->stream = aux_stream_of(s); b->own_stream = false; b->base_stream = b->stream;
     return b;
 }
 template <class T> static void apply_two_site_forked(State* s, const std::vector<Gate2>& gates, const tnqs_apply_opts& ao, double* errs) {
@@ -1017,7 +1017,7 @@ template <class T> static void apply_two_site_forked(State* s, const std::vector
     s->pool->set_defer(true);
     State::ForkSync fs; fs.ev = s->ev_stagger;
     s->fork_sync = &fs; s->fork_role = 1; b->fork_sync = &fs; b->fork_role = 2;
-    s->chain_stream = s->hi_stream[0]; b->chain_stream = s->hi_stream[1]; b->ev_ring.swap(s->ev_ring_b); b->ev_next = 0;
+    s->base_stream = s->stream; s->chain_stream = s->hi_stream[0]; b->chain_stream = s->hi_stream[1]; b->ev_ring.swap(s->ev_ring_b); b->ev_next = 0;
     std::exception_ptr ea, eb;
     std::thread th([&] {
         try { HIPCHK(hipSetDevice(b->device)); apply_two_site_batch<T>(b.get(), gb, ao, errs); }
@@ -1026,7 +1026,7 @@ template <class T> static void apply_two_site_forked(State* s, const std::vector
     try { apply_two_site_batch<T>(s, ga, ao, errs); } catch (...) { ea = std::current_exception(); }
     if (!fs.recorded) { (void)hipEventRecord(fs.ev, s->stream); fs.signal(); }      // A failed before its Gram pass: B must not wait for ever
     th.join();
-    s->fork_sync = nullptr; s->fork_role = 0; s->chain_stream = nullptr; b->ev_ring.swap(s->ev_ring_b);
+    s->fork_sync = nullptr; s->fork_role = 0; s->chain_stream = nullptr; s->base_stream = nullptr; b->ev_ring.swap(s->ev_ring_b);
     // join: the main stream continues after B's epilogue; only then may anything released meanwhile be handed out again
     (void)hipEventRecord(s->ev_join, b->stream);
     (void)hipStreamWaitEvent(s->stream, s->ev_join, 0);

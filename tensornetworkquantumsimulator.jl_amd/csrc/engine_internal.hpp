@@ -86,6 +86,12 @@ hipStream_t aux_stream_of(State* s);                  // second stream of a fork
 void switch_stream(State* s, hipStream_t to);        // continue on another stream of this State, ordered behind the current one (null / same: no-op)
 void recycle_arena(HostArena ar);                     // back to the free list (nothing on the device may still read it)
 HostArena acquire_arena();                             // a recycled or freshly pinned 32 MiB arena (engine_core.cpp)
+// The staging arena is about to be reused from its start: everything that may still read it must have run -- on the current stream and on the other
+// streams this State enqueues on (the side stream of the early small-SVD launches, the two streams of a forked half)
+inline void drain_for_arena_reuse(State* s) {
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (hipStream_t q : {s->base_stream, s->chain_stream, s->aux_stream}) if (q && q != s->stream) HIPCHK(hipStreamSynchronize(q));
+}
 // Read-back through the pinned staging arena: the copy is enqueued and the staged host pointer returned; it holds the data once the stream
 // has been synchronised (a read-back into pageable memory is staged by the runtime and BLOCKS per call).  The staged bytes stay valid until the
 // next upload() / readback() after a sync(s) reuses the arena.
@@ -95,7 +101,7 @@ template <class X> const X* readback(State* s, const void* dsrc, size_t count) {
     if (!ar.base) ar = acquire_arena();
     const size_t aligned = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
     if (aligned > ar.cap) throw Err(TNQS_ERR_UNSUPPORTED, "read-back too large for the staging arena");
-    if (ar.off + aligned > ar.cap) { HIPCHK(hipStreamSynchronize(s->stream)); ar.off = 0; }     // pending uploads have been copied: the host side is free
+    if (ar.off + aligned > ar.cap) { drain_for_arena_reuse(s); ar.off = 0; }     // pending uploads have been copied: the host side is free
     char* h = ar.base + ar.off; ar.off += aligned;
     if (bytes) HIPCHK(hipMemcpyAsync(h, dsrc, bytes, hipMemcpyDeviceToHost, s->stream));
     return reinterpret_cast<const X*>(h);
@@ -105,7 +111,7 @@ inline void reserve_readback(State* s, size_t bytes) {
     HostArena& ar = s->arena;
     if (!ar.base) ar = acquire_arena();
     if (bytes > ar.cap) throw Err(TNQS_ERR_UNSUPPORTED, "read-backs of one batch too large for the staging arena");
-    if (ar.off + bytes > ar.cap) { HIPCHK(hipStreamSynchronize(s->stream)); ar.off = 0; }
+    if (ar.off + bytes > ar.cap) { drain_for_arena_reuse(s); ar.off = 0; }
 }
 // End of a phase WITHOUT draining the stream: everything in the keep-alive list so far may go once the stream has been synchronised for some
 // other reason (the next read-back), so the host can start preparing the next phase while this one's last kernels still run.
@@ -139,7 +145,7 @@ template <class Item> const Item* upload(State* s, const std::vector<Item>& v) {
     // arena full: wait for the copies that still read it and start over.  ONLY the host staging is recycled here -- the device buffers of
     // earlier uploads (descriptor arrays whose kernels are not launched yet) stay in the keep-alive list: a sync(s) at this point would hand
     // them back to the pool in the middle of a phase and the next dalloc of the same size class could alias them
-    if (ar.off + aligned > ar.cap) { HIPCHK(hipStreamSynchronize(s->stream)); ar.off = 0; s->prof->chain = false; }
+    if (ar.off + aligned > ar.cap) { drain_for_arena_reuse(s); ar.off = 0; s->prof->chain = false; }
     char* h = ar.base + ar.off; ar.off += aligned;
     std::memcpy(h, v.data(), bytes);
     Buf b = dalloc(s, bytes);
@@ -163,7 +169,7 @@ template <class Item> const Item* upload_small(State* s, const std::vector<Item>
     if (!ar.base) ar = acquire_arena();
     const size_t aligned = (bytes + 255) & ~size_t(255);
     if (aligned > ar.cap) throw Err(TNQS_ERR_UNSUPPORTED, "descriptor batch too large");
-    if (ar.off + aligned > ar.cap) { HIPCHK(hipStreamSynchronize(s->stream)); ar.off = 0; s->prof->chain = false; }
+    if (ar.off + aligned > ar.cap) { drain_for_arena_reuse(s); ar.off = 0; s->prof->chain = false; }
     char* h = ar.base + ar.off; ar.off += aligned;
     std::memcpy(h, v.data(), bytes);
     return reinterpret_cast<const Item*>(h);
