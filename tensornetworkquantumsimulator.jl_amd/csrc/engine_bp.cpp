@@ -543,6 +543,23 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 std::vector<char> is_shared(chains.size(), 0);
                 for (int ci : is_shared_chain) is_shared[ci] = 1;
                 HostTimer ht_launch(1);
+                // Two independent launch chains make up a level: the bulk sites' plane kernels (pair product -> both-messages pair-Gram) and the other
+                // sites' single-leg products -> Grams (boundary sites of a lattice: 24 of the 49 sites of a 7 x 7 one, small launches of 10-50 us each).
+                // They meet in msg_finalize.  The second chain goes to the side stream, under the plane kernels (single rank, unforked; the chi = 16
+                // pair-Gram items that continue from a chain's result keep everything on one stream); nothing released inside the region is handed out
+                // again before the join (Pool::set_defer).
+                static const bool bp_split_on = !envflag("TNQS_NO_BP_SPLIT");
+                hipStream_t const main_stream = s->stream;
+                bool has_other = false; for (size_t ci = 0; ci < chains.size(); ++ci) has_other = has_other || !is_shared[ci];
+                const bool split_level = s->nranks == 1 && !s->chain_stream && !s->fork_role && (!sh_pair.empty() || !sh_dbl.empty()) && has_other && g16.empty() && bp_split_on;
+                hipStream_t side_stream = nullptr;
+                if (split_level) {
+                    side_stream = aux_stream_of(s);
+                    HIPCHK(hipEventRecord(s->ev_fork, main_stream)); HIPCHK(hipStreamWaitEvent(side_stream, s->ev_fork, 0));
+                    s->pool->set_defer(true);
+                }
+                struct SplitGuard { State* s; hipStream_t m; bool on; ~SplitGuard() { s->stream = m; if (on) s->pool->set_defer(false); } } split_guard{s, main_stream, split_level};
+                auto on_side = [&](bool side) { if (split_level) { s->stream = side ? side_stream : main_stream; s->prof->chain = false; } };
                 if (!sh_pair.empty()) {
                     const int spw = pair_spw(sh_pair_slices); int wgs = 0;
                     for (auto& it : sh_pair) { it.spw = spw; it.slice_begin = wgs; wgs += pair_wgs(it.g.n0 * it.g.n1 * it.g.n2, spw); }
@@ -550,7 +567,9 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     ProfScope ps(s, TNQS_PROF_BP_PAIR, 2.0 * sh_pair_slices * 16384.0 * esz, 2 * 8.0 * sh_pair_slices * 16384.0 * 32);
                     launch_mfma_pair(s->stream, d, (int)sh_pair.size(), wgs);
                 }
+                on_side(true);
                 run_chains<T>(s, chains, TNQS_PROF_BP_MODEPROD, TNQS_PROF_BP_PAIR);
+                on_side(false);
                 if (cache_on) for (auto& kv : cabs) if (!chains[kv.first].trail.empty()) remember(chains[kv.first], s->site[chains[kv.first].v], cbase[kv.first], kv.second);
                 std::vector<GramJob> jobs;
                 for (size_t i = 0; i < chains.size(); ++i) {
@@ -622,8 +641,11 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 {   // the fused and the plain Gram are different kernels: run them as two batches, keep the job order
                     std::vector<GramJob> jf, jp; std::vector<size_t> idf, idp;
                     for (size_t i = 0; i < jobs.size(); ++i) { if (is_shared[i]) continue; if (jobs[i].M) { jf.push_back(jobs[i]); idf.push_back(i); } else { jp.push_back(jobs[i]); idp.push_back(i); } }
+                    on_side(true);
                     run_grams<T, T>(s, jf, TNQS_PROF_BP_FUSED);
                     run_grams<T, T>(s, jp, TNQS_PROF_BP_GRAM);
+                    if (split_level) { HIPCHK(hipEventRecord(s->ev_join, side_stream)); HIPCHK(hipStreamWaitEvent(main_stream, s->ev_join, 0)); }
+                    on_side(false);
                     for (size_t q = 0; q < jf.size(); ++q) jobs[idf[q]] = jf[q];
                     for (size_t q = 0; q < jp.size(); ++q) jobs[idp[q]] = jp[q];
                 }

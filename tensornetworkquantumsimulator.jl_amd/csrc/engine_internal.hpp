@@ -62,6 +62,7 @@ TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64
 // TNQS_HOST_TIMING=1: host-side phase timers printed at exit;  TNQS_RCCL_LIB: path of librccl.so (sharding.cpp);
 // TNQS_NO_F64_MFMA=1 (engine_batch.cpp): ComplexF64 mode products on the generic vector kernel instead of the f64 matrix cores (kernels_f64.hip);
 // TNQS_NO_3M=1 (launch_util.hpp): four-multiplication complex product in every MFMA kernel instead of Gauss' three (mfma_common.hpp, CAcc32);
+// TNQS_NO_BP_SPLIT=1 (engine_bp.cpp): the boundary sites' products and Grams of a BP level on the same stream as the bulk sites' plane kernels instead of next to them;
 // TNQS_FORK=0 / 1 (engine_gates.cpp): never / always run a gate batch as two halves on two streams (default: by size);
 // Kernel experiments are NOT in the shipped library: TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP, TNQS_DBG_GRAM_SKIP, TNQS_PAIR_SPW, TNQS_PAIR16_HALF
 // and TNQS_QR2_ALL only exist in a build with -DTNQS_EXPERIMENTS (csrc/build.sh EXPERIMENTS=1); the kernel-level entry points of

@@ -79,7 +79,7 @@ def test_staging_arena_overflow_keeps_descriptors_alive():
         assert ref[name]["z"] == alt[name]["z"], name
 
 
-@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_DEFER_1SITE", "TNQS_FORK"])
+@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_DEFER_1SITE", "TNQS_FORK", "TNQS_NO_BP_SPLIT"])
 def test_bulk_shape_routes_match(switch):
     """the chi = 32 bulk shape (BASELINE configs[1]): the third gauge leg absorbed inside the f64 Gram kernel (kernels_gate.hip) against the
     separate single-leg pass + plain Gram; ranks of the R factors left on the device against read back; three- against four-multiplication
