@@ -554,6 +554,43 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         }
     }
     const int npg = (int)pg.size();
+    // ---- epilogue plan (step 5) for the register-direct MFMA kernel: items, output buffers, uploaded descriptors.  Built twice at most: speculatively
+    // BEFORE the read-back of the batch -- assuming every new bond dimension equals its cap and no projector pass is needed, which is the steady state of a
+    // saturated evolution -- so that after the synchronisation the epilogue is launched at once instead of after 0.25 ms of host preparation with an idle
+    // chip (20x20: 380 items and output buffers); and again after the read-back when the assumption did not hold --------------------------------------
+    struct RgGroup { int kk = 0; std::vector<FiberItem> sub; std::vector<int> sv, stb, snt; std::vector<Buf> so; std::vector<size_t> sn; int wgs = 0; Buf npr; const FiberItem* d = nullptr; };
+    struct RgPlan { bool valid = false; std::vector<RgGroup> groups; std::vector<char> via; double rby = 0, rfl = 0; };
+    auto plan_rowgemm = [&](auto chi_of, auto in_of, std::vector<char>* skip) {
+        RgPlan P; P.via.assign(own_idx.size(), 0);
+        std::vector<FiberItem> rg; std::vector<int> rverts; std::vector<Buf> routs; std::vector<size_t> rne;
+        if (std::is_same<T, float>::value && use_mfma() && use_rowgemm())
+            for (size_t q = 0; q < own_idx.size(); ++q) {
+                if (skip && (*skip)[q]) continue;
+                size_t i = own_idx[q]; int gi = (int)i / 2; int chin = chi_of(gi); const SiteJob& j = sj[i];
+                FiberItem it{};
+                it.D = j.sd.d; it.PA = (int)(j.sd.pre(j.bleg) / j.sd.d); it.K = j.sd.chi[j.bleg]; it.PB = (int)j.sd.post(j.bleg); it.Do = j.sd.d; it.No = chin;
+                if (!rowgemm_covers(it) || it.D != 2 || !(it.K == 64 || use_rowgemm32())) continue;
+                const size_t nout = j.sd.n / it.K * chin;
+                Buf out = dalloc(s, nout * esz);
+                it.in = in_of(q); it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
+                rowgemm_tiles(it); it.want_norm = ao.normalize_tensors ? 1 : 0;
+                rg.push_back(it); rverts.push_back(j.v); routs.push_back(out); rne.push_back(nout);
+                P.rby += (double)(j.sd.n + nout) * esz; P.rfl += 8.0 * j.sd.n * j.sd.d * chin; P.via[q] = 1; if (skip) (*skip)[q] = 1;
+            }
+        for (int kk : {64, 32}) {
+            RgGroup G; G.kk = kk; double st = 0;
+            for (size_t q = 0; q < rg.size(); ++q) if (rg[q].K == kk) { G.sub.push_back(rg[q]); G.sv.push_back(rverts[q]); G.so.push_back(routs[q]); G.sn.push_back(rne[q]); st += (double)rg[q].nta * rg[q].ntb; }
+            if (G.sub.empty()) continue;
+            int tpw = (int)std::max(4.0, std::min(32.0, st / 2048.0)); tpw &= ~3;
+            for (auto& it : G.sub) { const int nwg = (it.nta * it.ntb + tpw - 1) / tpw; it.tpw = tpw; it.tile_begin = G.wgs; G.stb.push_back(G.wgs); G.snt.push_back(nwg); G.wgs += nwg; }
+            G.npr = dalloc(s, (size_t)G.wgs * sizeof(double));
+            G.d = upload(s, G.sub);
+            P.groups.push_back(std::move(G));
+        }
+        P.valid = true;
+        return P;
+    };
+    RgPlan spec_plan;
     // per-gate (r1, r2, chi', status, sweeps, wide, -, -) and truncation error live in two contiguous arrays: one D2H each
     Buf d_info_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 32));
     Buf d_terr_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 8));
@@ -672,6 +709,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         const size_t rb_bytes = round256(2 * envs.size() * sizeof(int)) + round256(sj.size() * sizeof(int)) + round256((size_t)npg * 32) + round256((size_t)npg * 8) + 1024;
         if (one_trip) {
             svd_and_finish(nullptr);
+            if (!sharded && ao.maxdim > 0) spec_plan = plan_rowgemm([&](int gi) { return ws[gi].cap; }, [&](size_t q) { return (const void*)s->site[sj[own_idx[q]].v]->p; }, nullptr);
             reserve_readback(s, rb_bytes);
             st_flags = !envs.empty() ? readback<int>(s, d_flags->p, 2 * envs.size()) : nullptr;
             st_chol = !sj.empty() ? readback<int>(s, d_cholfail->p, sj.size()) : nullptr;
@@ -895,33 +933,20 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
               launch_mfma_apply64(s->stream, da, (int)a64.size(), wgs); }
             norm_and_replace<T>(s, a64_verts, a64_outs, a64_ne, np64, tb64, nt64, ao.normalize_tensors != 0);
         }
-        {   // chi = 64 sites: K = (s, b) = 128 -> N = (s', b') <= 128 on the register-direct MFMA kernel
-            std::vector<FiberItem> rg; std::vector<int> rverts, rtb, rnt; std::vector<Buf> routs; std::vector<size_t> rne; double rby = 0, rfl = 0;
-            if (std::is_same<T, float>::value && use_mfma() && use_rowgemm())
-                for (size_t q = 0; q < own_idx.size(); ++q) {
-                    if (via64[q]) continue;
-                    size_t i = own_idx[q]; int gi = (int)i / 2; int chin = info[8 * gi + 2]; const SiteJob& j = sj[i];
-                    FiberItem it{};
-                    it.D = j.sd.d; it.PA = (int)(j.sd.pre(j.bleg) / j.sd.d); it.K = j.sd.chi[j.bleg]; it.PB = (int)j.sd.post(j.bleg); it.Do = j.sd.d; it.No = chin;
-                    if (!rowgemm_covers(it) || it.D != 2 || !(it.K == 64 || use_rowgemm32())) continue;
-                    const size_t nout = j.sd.n / it.K * chin;
-                    Buf out = dalloc(s, nout * esz);
-                    it.in = pch[q].result; it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
-                    rowgemm_tiles(it); it.want_norm = ao.normalize_tensors ? 1 : 0;
-                    rg.push_back(it); rverts.push_back(j.v); routs.push_back(out); rne.push_back(nout);
-                    rby += (double)(j.sd.n + nout) * esz; rfl += 8.0 * j.sd.n * j.sd.d * chin; via64[q] = 1;
-                }
+        {   // chi = 64 sites (K = (s, b) = 128 -> N = (s', b') <= 128) and chi = 32 sites on the register-direct MFMA kernel: the speculative plan built
+            // before the read-back when it came true, a fresh one otherwise
+            bool spec_ok = spec_plan.valid && a64.empty();
+            for (size_t q = 0; q < own_idx.size() && spec_ok; ++q) { const int gi = (int)own_idx[q] / 2; spec_ok = info[8 * gi + 2] == ws[gi].cap && pch[q].steps.empty() && pch[q].result == s->site[sj[own_idx[q]].v]->p; }
+            RgPlan fresh_plan;
+            if (!spec_ok) {
+                spec_plan = RgPlan{};              // (its output buffers go back to the pool)
+                fresh_plan = plan_rowgemm([&](int gi) { return info[8 * gi + 2]; }, [&](size_t q) { return pch[q].result; }, &via64);
+            } else for (size_t q = 0; q < own_idx.size(); ++q) via64[q] = via64[q] || spec_plan.via[q];
+            RgPlan& P = spec_ok ? spec_plan : fresh_plan;
             bool booked = false;
-            for (int kk : {64, 32}) {          // one launch per contracted dimension
-                std::vector<FiberItem> sub; std::vector<int> sv, stb, snt; std::vector<Buf> so; std::vector<size_t> sn; double st = 0;
-                for (size_t q = 0; q < rg.size(); ++q) if (rg[q].K == kk) { sub.push_back(rg[q]); sv.push_back(rverts[q]); so.push_back(routs[q]); sn.push_back(rne[q]); st += (double)rg[q].nta * rg[q].ntb; }
-                if (sub.empty()) continue;
-                int tpw = (int)std::max(4.0, std::min(32.0, st / 2048.0)); tpw &= ~3; int wgs = 0;
-                for (auto& it : sub) { const int nwg = (it.nta * it.ntb + tpw - 1) / tpw; it.tpw = tpw; it.tile_begin = wgs; stb.push_back(wgs); snt.push_back(nwg); wgs += nwg; }
-                Buf npr = dalloc(s, (size_t)wgs * sizeof(double));
-                const FiberItem* d = upload(s, sub);
-                { ProfScope ps(s, TNQS_PROF_GATE_APPLY, booked ? 0.0 : rby, booked ? 0.0 : rfl); booked = true; launch_mfma_rowgemm(s->stream, d, (int)sub.size(), wgs, 2, kk, reinterpret_cast<double*>(npr->p)); }
-                norm_and_replace<T>(s, sv, so, sn, npr, stb, snt, ao.normalize_tensors != 0);
+            for (auto& G : P.groups) {          // one launch per contracted dimension
+                { ProfScope ps(s, TNQS_PROF_GATE_APPLY, booked ? 0.0 : P.rby, booked ? 0.0 : P.rfl); booked = true; launch_mfma_rowgemm(s->stream, G.d, (int)G.sub.size(), G.wgs, 2, G.kk, reinterpret_cast<double*>(G.npr->p)); }
+                norm_and_replace<T>(s, G.sv, G.so, G.sn, G.npr, G.stb, G.snt, ao.normalize_tensors != 0);
             }
         }
         for (size_t q = 0; q < own_idx.size(); ++q) {
@@ -994,7 +1019,7 @@ static std::unique_ptr<State> fork_state(State* s) {
 template <class T> static void apply_two_site_forked(State* s, const std::vector<Gate2>& gates, const tnqs_apply_opts& ao, double* errs) {
     static const int fork_mode = [] { const char* e = std::getenv("TNQS_FORK"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();      // 0: never, 2: every batch of two or more gates (tests), unset: by size
     double elems = 0;
-    for (auto& g2 : gates) elems += (double)site_dims(s, g2.v1).n + (double)site_dims(s, g2.v2).n;
+    if (fork_mode == 1 && gates.size() >= 8 && s->nranks == 1) for (auto& g2 : gates) elems += (double)site_nelem(s, g2.v1) + (double)site_nelem(s, g2.v2);
     // Which share f goes to half A.  Model of a batch (ms; measured on the 20x20 chi = 32 layer): gauge + Gram passes h = 9.4e-9 per
     // element, epilogue e = 3.5e-9 per element, chain c = 2.0 whatever the size.  Unforked: h + c + e.  Forked, with B's passes behind A's Gram:
     // h f + max(c, h (1 - f)) + max(c, e f) + e (1 - f) -- A's chain under B's gauge + Gram, B's chain under A's epilogue.  Both chains are hidden
@@ -1008,7 +1033,8 @@ template <class T> static void apply_two_site_forked(State* s, const std::vector
     }
     if (!take || s->nranks > 1) { apply_two_site_batch<T>(s, gates, ao, errs); return; }
     // half A: the first gates up to the share f of the elements
-    size_t na = 0; { double acc = 0; while (na + 1 < gates.size() && acc < f * elems) { acc += (double)site_dims(s, gates[na].v1).n + (double)site_dims(s, gates[na].v2).n; ++na; } }
+    if (fork_mode == 2) for (auto& g2 : gates) elems += (double)site_nelem(s, g2.v1) + (double)site_nelem(s, g2.v2);
+    size_t na = 0; { double acc = 0; while (na + 1 < gates.size() && acc < f * elems) { acc += (double)site_nelem(s, gates[na].v1) + (double)site_nelem(s, gates[na].v2); ++na; } }
     na = std::max<size_t>(1, std::min(na, gates.size() - 1));
     const std::vector<Gate2> ga(gates.begin(), gates.begin() + (std::ptrdiff_t)na), gb(gates.begin() + (std::ptrdiff_t)na, gates.end());
     std::unique_ptr<State> b = fork_state(s);
@@ -1096,7 +1122,10 @@ template <class T> static void apply_gates_t(State* s, int ngates, const int32_t
         for (size_t k = 1; k < moff[ngates] && !cplx; k += 2) cplx = mats[k] != 0.0;
         if (cplx) s->real_io = false;
     }
-    std::set<int> affected, batch_verts;
+    // vertex flags instead of std::set: this walk sits between the end of a BP update and the first kernel of the next batch (chip idle)
+    struct VSet { std::vector<char> f; std::vector<int> l; explicit VSet(int n) : f(n, 0) {} bool count(int v) const { return f[v] != 0; }
+                  void insert(int v) { if (!f[v]) { f[v] = 1; l.push_back(v); } } void clear() { for (int v : l) f[v] = 0; l.clear(); } };
+    VSet affected(g.nv), batch_verts(g.nv);
     std::vector<Gate1> b1; std::vector<Gate2> b2;
     struct InApply { State* s; explicit InApply(State* st) : s(st) { s->in_apply = true; } ~InApply() { s->in_apply = false; } } in_apply_guard(s);
     for (int i = 0; i < ngates; ++i) {

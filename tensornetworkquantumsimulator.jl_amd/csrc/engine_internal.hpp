@@ -208,6 +208,8 @@ inline SD site_dims(const State* s, int v) {
     return r;
 }
 
+// number of elements of a site tensor (no allocation: site_dims builds a vector)
+inline size_t site_nelem(const State* s, int v) { size_t n = (size_t)s->d[v]; for (int e : s->g->nbr_e[v]) n *= (size_t)s->chi[e]; return n; }
 inline size_t round256(size_t b) { return (b + 255) & ~size_t(255); }
 void exchange(State* s, size_t bytes_per_rank);                       // sharding.cpp
 void check_exchange(const State* s, size_t bytes_per_rank);           // call BEFORE enqueuing anything that writes into s->exch
