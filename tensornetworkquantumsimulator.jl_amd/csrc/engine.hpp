@@ -152,6 +152,10 @@ struct State {
     HostArena arena;               // this handle's pinned staging arena (taken from / returned to a small free list, engine_core.cpp)
     std::vector<HostArena> retired_arenas;      // arenas of forked halves: pending copies / kernels may still read them; recycled when this handle's stream has drained
     tnqs_apply_stats stats{};
+    // A BP update inside apply_gates whose convergence verdict has not been read yet (engine_bp.cpp, "optimistic" mode): the first sweep is enqueued
+    // together with the copy of its summed message change into `host` (a pinned slot behind the staging arena), the messages are committed, and the
+    // host goes on PREPARING the next gate batch while the sweep runs; resolve_bp() -- called before that batch enqueues anything -- waits and decides.
+    struct BpPending { bool active = false; const double* host = nullptr; double tol = 0; size_t nseq = 0; int iters_done = 0, maxiter = 0; } bp_pending;
 
     size_t esz() const { return dtype == TNQS_C64 ? 8 : 16; }
     int scalartype() const { return real_io ? (dtype == TNQS_C64 ? TNQS_F32 : TNQS_F64) : dtype; }

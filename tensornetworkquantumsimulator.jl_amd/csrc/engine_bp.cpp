@@ -261,9 +261,25 @@ struct ProdCache {
     }
 };
 
-template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out) {
+bool resolve_bp(State* s) {
+    State::BpPending& p = s->bp_pending;
+    if (!p.active) return true;
+    HIPCHK(hipStreamSynchronize(s->stream));          // NOT drained(): the caller has staged descriptors in the arena for what it is about to launch
+    s->prof->chain = false;
+    const double avg = *p.host / (double)p.nseq;
+    s->stats.last_bp_diff = avg;
+    if (avg <= p.tol) { p.active = false; return true; }
+    if (p.iters_done >= p.maxiter) { p.active = false; s->stats.bp_not_converged += 1; return true; }      // the reference stops here too (and warns)
+    return false;
+}
+
+template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out, bool optimistic, int iters_before) {
     const Graph& g = *s->g;
     HIPCHK(hipSetDevice(s->device));
+    if (s->bp_pending.active && !resolve_bp(s)) {      // an optimistic update nobody has consumed yet: finish it first
+        const int done = s->bp_pending.iters_done; s->bp_pending.active = false;
+        bp_update_t<T>(s, o, nullptr, nullptr, false, done);
+    }
     // the level schedule depends on the graph and the sequence only: the one of the default sequence is kept with the graph
     std::shared_ptr<const BPPlan> plan_p;
     if (o && o->n_sequence > 0) plan_p = std::make_shared<const BPPlan>(make_plan(s, o));
@@ -334,7 +350,9 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
             if (k >= np - 2 && c.tmp[k & 1]) pcache.put(c.v, site, acc, c.tmp[k & 1]);
         }
     };
-    for (int iter = 1; iter <= maxiter; ++iter) {
+    static const bool optimistic_on = !envflag("TNQS_NO_OPTIMISTIC_BP");
+    const bool go_optimistic = optimistic && optimistic_on && compute_error && s->nranks == 1 && iters_before == 0 && s->arena.base;
+    for (int iter = 1 + iters_before; iter <= maxiter; ++iter) {
         std::vector<Buf> fresh(2 * (size_t)g.ne);
         for (auto& lev : plan.levels) {
             // sub-batches bounded by workspace bytes
@@ -712,6 +730,16 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
         s->stats.n_bp_sweeps += 1;
         if (compute_error) {
             launch_sum_doubles(s->stream, reinterpret_cast<const double*>(d_diffs->p), (int)nseq, reinterpret_cast<double*>(d_sum->p));
+            if (go_optimistic) {
+                // the verdict travels to the pinned slot behind the arena; the messages are committed and the caller prepares its next phase meanwhile
+                double* slot = reinterpret_cast<double*>(s->arena.base + s->arena.cap);
+                HIPCHK(hipMemcpyAsync(slot, d_sum->p, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+                s->keepalive.push_back(d_diffs); s->keepalive.push_back(d_sum);
+                s->bp_pending = State::BpPending{true, slot, tol, nseq, iter, maxiter};
+                s->msg = cur; s->stats.n_bp_updates += 1;
+                soft_sync(s);
+                return;
+            }
             const double* st_tot = readback<double>(s, d_sum->p, 1);
             sync(s);
             const double tot = *st_tot;                                  // (the arena's memory is untouched until the next upload)
@@ -721,7 +749,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
     }
     sync(s);
     s->msg = cur;
-    s->stats.n_bp_updates += 1;
+    if (iters_before == 0) s->stats.n_bp_updates += 1;
     if (compute_error && !converged) s->stats.bp_not_converged += 1;
     s->stats.last_bp_diff = avg;
     if (niter_out) *niter_out = niter;
@@ -732,7 +760,7 @@ void bp_update(State* s, const tnqs_bp_opts* o, int* niter, double* diff) {
     if (s->dtype == TNQS_C64) bp_update_t<float>(s, o, niter, diff); else bp_update_t<double>(s, o, niter, diff);
 }
 
-template void bp_update_t<float>(State*, const tnqs_bp_opts*, int*, double*);
-template void bp_update_t<double>(State*, const tnqs_bp_opts*, int*, double*);
+template void bp_update_t<float>(State*, const tnqs_bp_opts*, int*, double*, bool, int);
+template void bp_update_t<double>(State*, const tnqs_bp_opts*, int*, double*, bool, int);
 
 }  // namespace tnqs

@@ -122,7 +122,7 @@ HostArena acquire_arena() {
     if (!ar.base) {
         // TNQS_ARENA_KB: a small arena makes every phase overflow it (tests/test_gpu_toggles.py drives the overflow path that way)
         static const size_t cap = [] { const char* e = std::getenv("TNQS_ARENA_KB"); return e ? std::max<size_t>(16, (size_t)std::atoll(e)) << 10 : size_t(32) << 20; }();
-        ar.cap = cap; HIPCHK(hipHostMalloc((void**)&ar.base, ar.cap, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&ar.base, cap, hipHostMallocDefault)); ar.cap = cap - 256;       // (the last 256 bytes: State::bp_pending's slot, never recycled by the arena)
     }
     return ar;
 }

@@ -99,6 +99,7 @@ static std::vector<double> matmul_dd(const double* a, const double* b, int d) { 
 
 template <class T> static void apply_one_site_batch(State* s, const std::vector<Gate1>& gates_in, bool normalize, bool force) {
     if (gates_in.empty()) return;
+    if (s->bp_pending.active && !resolve_bp(s)) throw BpNotConverged{};       // (an optimistic BP update: its verdict before anything is applied)
     const size_t esz = s->esz();
     // ---- deferral (State::pend1): a unitary gate on a tensor that needs no normalisation pass is only recorded -- BP does not see it, the
     // next two-site gate on the vertex absorbs it.  Anything else is applied now, composed with what was pending on the vertex.
@@ -216,6 +217,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     struct RestoreStream { State* s; hipStream_t h; ~RestoreStream() { s->stream = h; g_corun_geometry = false; } } restore_stream{s, heavy_stream};
     g_corun_geometry = s->fork_role != 0;       // chain kernels of a forked half run next to the other half's tensor passes (kernels.hpp)
     HostTimer ht_a(3);                 // TNQS_HOST_TIMING=1: host time of the batch up to the first read-back (3), between the read-backs (4), after them (5)
+    if (!ao.normalize_tensors && s->bp_pending.active && !resolve_bp(s)) throw BpNotConverged{};      // (materialize_scale below launches)
     if (!ao.normalize_tensors) {       // without the final normalisation the result scales with the inputs: apply pending factors first
         std::vector<int> vs; for (auto& g2 : gates) { vs.push_back(g2.v1); vs.push_back(g2.v2); }
         materialize_scale(s, vs);
@@ -262,6 +264,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             ji.push_back(JacobiItem{r.H, r.V, r.n, r.n, nullptr});
             fi.push_back(EnvFinishItem{r.H, r.V, r.msq, r.prj, r.n, sqrt_cutoff, reinterpret_cast<int*>(d_flags->p) + 2 * i});
         }
+        // everything up to here was host preparation: the verdict of an optimistic BP update is awaited only now, in front of the first launch
+        if (s->bp_pending.active && !resolve_bp(s)) throw BpNotConverged{};
         if (!envs.empty()) {
             const EnvItem* de = upload_small(s, ei); const JacobiItem* dj = upload_small(s, ji); const EnvFinishItem* df = upload_small(s, fi);
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, de, (int)ei.size()); }
@@ -1012,7 +1016,7 @@ static std::unique_ptr<State> fork_state(State* s) {
     b->g = s->g; b->dtype = s->dtype; b->real_io = s->real_io; b->device = s->device; b->d = s->d; b->chi = s->chi;
     b->site = s->site; b->sscale = s->sscale; b->msg = s->msg; b->pool = s->pool;
     b->prof = std::make_shared<Prof>(); b->prof->on = s->prof->on;
-    b->pend1 = s->pend1; b->unit_norm = s->unit_norm; b->in_apply = s->in_apply;
+    b->pend1 = s->pend1; b->unit_norm = s->unit_norm; b->in_apply = s->in_apply; b->bp_pending = s->bp_pending;
     b->stream = aux_stream_of(s); b->own_stream = false; b->base_stream = b->stream;
     return b;
 }
@@ -1127,23 +1131,35 @@ template <class T> static void apply_gates_t(State* s, int ngates, const int32_t
                   void insert(int v) { if (!f[v]) { f[v] = 1; l.push_back(v); } } void clear() { for (int v : l) f[v] = 0; l.clear(); } };
     VSet affected(g.nv), batch_verts(g.nv);
     std::vector<Gate1> b1; std::vector<Gate2> b2;
+    // A mid-circuit BP update returns with its verdict pending (engine_bp.cpp); the batch that follows prepares itself on the host while the sweep runs and
+    // asks for the verdict before its first launch.  Negative (rare: one sweep reaches the tolerance on the states of an evolution): nothing has been
+    // enqueued or mutated -- the update is continued, blocking, and the batch starts over
+    auto flush = [&]() {
+        for (;;) {
+            try { flush_batch<T>(s, b1, b2, ao, errs); return; }
+            catch (const BpNotConverged&) {
+                const int done = s->bp_pending.iters_done; s->bp_pending.active = false;
+                bp_update_t<T>(s, bp, nullptr, nullptr, false, done);
+            }
+        }
+    };
     struct InApply { State* s; explicit InApply(State* st) : s(st) { s->in_apply = true; } ~InApply() { s->in_apply = false; } } in_apply_guard(s);
     for (int i = 0; i < ngates; ++i) {
         const int nv = nverts[i]; const int32_t* vs = verts + voff[i];
         bool need = false;
         if (nv >= 2) for (int k = 0; k < nv; ++k) need = need || affected.count(vs[k]);            // apply_gates.jl:68
         if (ao.update_cache && need) {
-            flush_batch<T>(s, b1, b2, ao, errs); batch_verts.clear();
-            bp_update_t<T>(s, bp, nullptr, nullptr);                                               // :76
+            flush(); batch_verts.clear();
+            bp_update_t<T>(s, bp, nullptr, nullptr, /*optimistic=*/true);                          // :76
             affected.clear();                                                                      // :78
         }
         bool overlap = false;
         for (int k = 0; k < nv; ++k) overlap = overlap || batch_verts.count(vs[k]);
-        if (overlap) { flush_batch<T>(s, b1, b2, ao, errs); batch_verts.clear(); }
+        if (overlap) { flush(); batch_verts.clear(); }
         if (nv == 1) b1.push_back(Gate1{vs[0], mats + moff[i]}); else b2.push_back(Gate2{vs[0], vs[1], mats + moff[i], i});
         for (int k = 0; k < nv; ++k) { batch_verts.insert(vs[k]); affected.insert(vs[k]); }         // :88-90
     }
-    flush_batch<T>(s, b1, b2, ao, errs);
+    flush();
     if (ao.update_cache) bp_update_t<T>(s, bp, nullptr, nullptr);                                   // :93-95
     if (s->nranks > 1) materialize_pending_all(s);      // sharded: nothing stays pending between calls (State::in_apply)
     sync(s);                                                                                        // the call returns with the stream drained

@@ -62,6 +62,7 @@ TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64
 // TNQS_HOST_TIMING=1: host-side phase timers printed at exit;  TNQS_RCCL_LIB: path of librccl.so (sharding.cpp);
 // TNQS_NO_F64_MFMA=1 (engine_batch.cpp): ComplexF64 mode products on the generic vector kernel instead of the f64 matrix cores (kernels_f64.hip);
 // TNQS_NO_3M=1 (launch_util.hpp): four-multiplication complex product in every MFMA kernel instead of Gauss' three (mfma_common.hpp, CAcc32);
+// TNQS_NO_OPTIMISTIC_BP=1 (engine_bp.cpp): every BP update inside apply_gates waits for its convergence verdict before the next batch is prepared;
 // TNQS_NO_BP_SPLIT=1 (engine_bp.cpp): the boundary sites' products and Grams of a BP level on the same stream as the bulk sites' plane kernels instead of next to them;
 // TNQS_FORK=0 / 1 (engine_gates.cpp): never / always run a gate batch as two halves on two streams (default: by size);
 // Kernel experiments are NOT in the shipped library: TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP, TNQS_DBG_GRAM_SKIP, TNQS_PAIR_SPW, TNQS_PAIR16_HALF
@@ -244,6 +245,10 @@ struct GramJob {      // out[i,j] = sum X[i,.] conj(Y[j,.]) over everything but 
 template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls, int cls_pair = -1);
 template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& jobs, int cls);
 template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, bool with_v);
-template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out);
+// optimistic: (apply_gates, single rank, a tolerance given) return after ENQUEUING the first sweep, verdict pending (State::bp_pending);
+// iters_before: sweeps this update has already run (the continuation after a pending verdict turned out negative)
+template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out, bool optimistic = false, int iters_before = 0);
+struct BpNotConverged {};                 // thrown by the first consumer of an optimistic update whose sweep did not reach the tolerance: nothing has been enqueued or mutated yet
+bool resolve_bp(State* s);                // waits for a pending verdict; true: converged (or nothing pending, or the sweep budget is used up)
 
 }  // namespace tnqs

@@ -49,7 +49,7 @@ def test_lowrank_theta_route_matches_the_full_svd():
 
 @pytest.mark.parametrize("switch", ["TNQS_NO_CHOL", "TNQS_NO_SMALLSVD", "TNQS_JACOBI_GLOBAL", "TNQS_NO_PAIR", "TNQS_NO_TSHARE", "TNQS_NO_FUSED_GRAM",
                                     "TNQS_NO_APPLY64", "TNQS_NO_MFMA", "TNQS_EAGER_SCALE", "TNQS_NO_PREFIX", "TNQS_NO_ROWGEMM32", "TNQS_NO_3M",
-                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE", "TNQS_FORK"])
+                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE", "TNQS_FORK", "TNQS_NO_OPTIMISTIC_BP"])
 def test_alternative_routes_match_the_default(switch):
     """every documented switch selects an alternative route of the same algorithm: all-eigen factorisation instead
     of Cholesky, Gram-eigen instead of the small-SVD route, global-memory Jacobi, single-leg mode products, per-message BP products,
@@ -79,7 +79,7 @@ def test_staging_arena_overflow_keeps_descriptors_alive():
         assert ref[name]["z"] == alt[name]["z"], name
 
 
-@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_DEFER_1SITE", "TNQS_FORK", "TNQS_NO_BP_SPLIT"])
+@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_DEFER_1SITE", "TNQS_FORK", "TNQS_NO_BP_SPLIT", "TNQS_NO_OPTIMISTIC_BP"])
 def test_bulk_shape_routes_match(switch):
     """the chi = 32 bulk shape (BASELINE configs[1]): the third gauge leg absorbed inside the f64 Gram kernel (kernels_gate.hip) against the
     separate single-leg pass + plain Gram; ranks of the R factors left on the device against read back; three- against four-multiplication
@@ -230,3 +230,15 @@ def test_c128_lowrank_theta_route_matches_the_full_svd():
         assert a["dims"] == b["dims"]
         assert np.max(np.abs(np.array(a["errs"]) - np.array(b["errs"]))) < 1e-9
         assert np.max(np.abs(np.array(a["z"]) - np.array(b["z"]))) < 1e-9       # (messages are not compared elementwise: the two routes fix the phases of the singular vectors differently)
+
+
+def test_optimistic_bp_update_starts_over_when_its_sweep_did_not_converge():
+    """Inside apply_gates a BP update returns after enqueuing its first sweep; the batch that follows prepares itself meanwhile and reads the verdict before its
+    first launch.  Here every update needs several sweeps (tight tolerance, strong gates): the verdict is negative each time, the update is
+    continued and the batch starts over -- same sweep counts and bit-identical results as with blocking updates (TNQS_NO_OPTIMISTIC_BP=1)."""
+    on, off = run_worker({}, "tolsweeps"), run_worker({"TNQS_NO_OPTIMISTIC_BP": "1"}, "tolsweeps")
+    for k in ("complex64", "complex128"):
+        a, b = on[k], off[k]
+        assert a["sweeps"] == b["sweeps"] and a["updates"] == b["updates"] == 5 and a["sweeps"] > 2 * a["updates"], (a["sweeps"], b["sweeps"])
+        assert a["not_converged"] == b["not_converged"]
+        assert a["dims"] == b["dims"] and a["errs"] == b["errs"] and a["z"] == b["z"]

@@ -87,7 +87,25 @@ def c128():
     print(json.dumps(out))
 
 
+def tolsweeps():
+    """BP updates that need SEVERAL sweeps to reach their tolerance inside apply_gates: the optimistic update (verdict read by the next batch, which starts over
+    after the remaining sweeps when it is negative) against the blocking one"""
+    g = tn.named_grid((4, 4))
+    out = {}
+    for dt, tol in ((np.complex64, 1e-7), (np.complex128, 1e-12)):
+        psi = tn.random_tensornetworkstate(dt, g, bond_dimension=4, seed=21)
+        bpc = tn.update(tn.BeliefPropagationCache(psi), maxiter=40, tolerance=tol)
+        layer = [("Rx", [v], 0.7) for v in g.vertices] + [("Rzz", [a, b], 0.9) for grp in tn.edge_color(g, 4) for (a, b) in grp] + [("Ry", [v], 0.3) for v in g.vertices]
+        info = {}
+        b2, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=4, cutoff=1e-10, normalize_tensors=True), bp_update_kwargs=dict(maxiter=40, tolerance=tol), info=info)
+        out[np.dtype(dt).name] = dict(errs=errs.tolist(), z=[float(np.real(x)) for x in tn.expect_all(b2, "Z")], dims=[b2.bond_dim(a, b) for a, b in g.edges],
+                                      sweeps=info["n_sweeps"], updates=info["n_updates"], not_converged=info["bp_not_converged"])
+    print(json.dumps(out))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "tolsweeps":
+        return tolsweeps()
     if len(sys.argv) > 1 and sys.argv[1] == "c128":
         return c128()
     if len(sys.argv) > 1 and sys.argv[1] == "chi32":
