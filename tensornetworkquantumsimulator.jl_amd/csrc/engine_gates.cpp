@@ -1044,6 +1044,16 @@ template <class T> static void apply_two_site_forked(State* s, const std::vector
     std::unique_ptr<State> b = fork_state(s);
     HIPCHK(hipEventRecord(s->ev_fork, s->stream));
     HIPCHK(hipStreamWaitEvent(b->stream, s->ev_fork, 0));                 // B starts after everything enqueued so far (the BP update's messages)
+    // a failing batch leaves the state as it was (apply_two_site_batch checks every gate before it replaces anything): half A works on the handle
+    // itself, so what it is about to replace is remembered and put back should half B fail after A has succeeded
+    struct Saved { int v; Buf site, sscale; std::vector<double> pend1; char unit_norm; };
+    struct SavedEdge { int e, chi; Buf m0, m1; };
+    std::vector<Saved> saved_v; std::vector<SavedEdge> saved_e;
+    for (auto& g2 : ga) {
+        for (int v : {g2.v1, g2.v2}) saved_v.push_back(Saved{v, s->site[v], s->sscale[v], s->pend1[v], s->unit_norm[v]});
+        const int e = s->g->edge(g2.v1, g2.v2); saved_e.push_back(SavedEdge{e, s->chi[e], s->msg[2 * e], s->msg[2 * e + 1]});
+    }
+    const tnqs_apply_stats stats_before = s->stats;
     s->pool->set_defer(true);
     State::ForkSync fs; fs.ev = s->ev_stagger;
     s->fork_sync = &fs; s->fork_role = 1; b->fork_sync = &fs; b->fork_role = 2;
@@ -1070,6 +1080,11 @@ template <class T> static void apply_two_site_forked(State* s, const std::vector
         s->stats.n_two_site += b->stats.n_two_site; s->stats.n_chol_fallbacks += b->stats.n_chol_fallbacks; s->stats.n_qr2_sites += b->stats.n_qr2_sites;
         s->stats.n_lowrank_svd += b->stats.n_lowrank_svd; s->stats.n_lowrank_fallbacks += b->stats.n_lowrank_fallbacks; s->stats.n_tall_svd += b->stats.n_tall_svd; s->stats.n_svd_sweeps += b->stats.n_svd_sweeps;
         s->stats.n_forked_batches += 1;
+    }
+    if (eb && !ea) {      // A replaced its tensors, B failed: back to the state before the batch
+        for (auto& sv : saved_v) { s->site[sv.v] = sv.site; s->sscale[sv.v] = sv.sscale; s->pend1[sv.v] = sv.pend1; s->unit_norm[sv.v] = sv.unit_norm; }
+        for (auto& se : saved_e) { s->chi[se.e] = se.chi; s->msg[2 * se.e] = se.m0; s->msg[2 * se.e + 1] = se.m1; }
+        s->stats = stats_before;
     }
     // B's workspaces and descriptor buffers live until the main stream has drained past the join
     for (auto& k : b->keepalive) s->keepalive.push_back(k);

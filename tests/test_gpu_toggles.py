@@ -242,3 +242,33 @@ def test_optimistic_bp_update_starts_over_when_its_sweep_did_not_converge():
         assert a["sweeps"] == b["sweeps"] and a["updates"] == b["updates"] == 5 and a["sweeps"] > 2 * a["updates"], (a["sweeps"], b["sweeps"])
         assert a["not_converged"] == b["not_converged"]
         assert a["dims"] == b["dims"] and a["errs"] == b["errs"] and a["z"] == b["z"]
+
+
+def test_a_failing_forked_batch_leaves_the_state_as_it_was():
+    """TNQS_FORK=1, the C ABI called IN PLACE on a handle: a message with a negative eigenvalue next to a gate of the SECOND half of the batch makes half B fail
+    (DomainError in the reference, src/utils.jl:21) after half A has replaced its tensors -- the library puts them back: every site tensor, message and bond
+    dimension is what it was before the call."""
+    code = (
+        "import sys, ctypes as C; sys.path[:0] = %r\n"
+        "import numpy as np, tnqs_amd as tn\n"
+        "from tnqs_amd import core, _lib as L\n"
+        "g = tn.named_grid((4, 4))\n"
+        "bpc = tn.update(tn.BeliefPropagationCache(tn.random_tensornetworkstate(np.complex64, g, bond_dimension=4, seed=3)), maxiter=10, tolerance=None)\n"
+        "grp = tn.edge_color(g, 4)[0]\n"
+        "layer = [('Rzz', [a, b], 0.3) for (a, b) in grp]\n"
+        "a, b = grp[-1]                                   # a gate of the second half\n"
+        "w = [x for x in g.neighbors(a) if x != b][0]\n"
+        "bad = np.diag([1.0, 0.5, 0.2, -0.3]).astype(np.complex64)\n"
+        "bpc.setmessage((w, a), bad)\n"
+        "before = {v: bpc.tensor(v) for v in g.vertices}; mb = {e: bpc.message(e) for e in g.edges}\n"
+        "ng, nv_a, nv_p, vs_a, vs_p, mat_a = core._marshal_circuit(layer, g)\n"
+        "ao = core._apply_opts(dict(maxdim=4, cutoff=1e-10, normalize_tensors=True), False)\n"
+        "bo, keep = core._bp_opts(g, dict(maxiter=1, tolerance=None))\n"
+        "errs = np.zeros(ng); st = L.ApplyStats()\n"
+        "rc = L.lib.tnqs_apply_gates(bpc._h, ng, nv_p, vs_p, mat_a.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ao), C.byref(bo), errs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st))\n"
+        "assert rc != 0, rc\n"
+        "for v in g.vertices: assert np.array_equal(bpc.tensor(v), before[v]), v\n"
+        "for e in g.edges: assert np.array_equal(bpc.message(e), mb[e]) and bpc.bond_dim(*e) == 4, e\n"
+        "print('ok')\n") % (sys.path,)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TNQS_FORK="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1500:] + r.stderr[-3000:]
