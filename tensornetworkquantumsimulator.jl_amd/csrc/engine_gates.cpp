@@ -1023,13 +1023,15 @@ static std::unique_ptr<State> fork_state(State* s) {
 template <class T> static void apply_two_site_forked(State* s, const std::vector<Gate2>& gates, const tnqs_apply_opts& ao, double* errs) {
     static const int fork_mode = [] { const char* e = std::getenv("TNQS_FORK"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();      // 0: never, 2: every batch of two or more gates (tests), unset: by size
     double elems = 0;
-    if (fork_mode == 1 && gates.size() >= 8 && s->nranks == 1) for (auto& g2 : gates) elems += (double)site_nelem(s, g2.v1) + (double)site_nelem(s, g2.v2);
+    // (>= 64 gates: with a dozen gates of 268 MB tensors per batch -- the 3x3x3 cubic lattice -- the halves' tensor passes lose more to their smaller
+    //  launches than the chains cost: 319.5 ms forked against 311.3 unforked per layer)
+    if (fork_mode == 1 && gates.size() >= 64 && s->nranks == 1) for (auto& g2 : gates) elems += (double)site_nelem(s, g2.v1) + (double)site_nelem(s, g2.v2);
     // Which share f goes to half A.  Model of a batch (ms; measured on the 20x20 chi = 32 layer): gauge + Gram passes h = 9.4e-9 per
     // element, epilogue e = 3.5e-9 per element, chain c = 2.0 whatever the size.  Unforked: h + c + e.  Forked, with B's passes behind A's Gram:
     // h f + max(c, h (1 - f)) + max(c, e f) + e (1 - f) -- A's chain under B's gauge + Gram, B's chain under A's epilogue.  Both chains are hidden
     // when h (1 - f) >= c and e f >= c (f ~ 0.72 at 20x20); small batches gain nothing (the two chains would merely run one after the other).
     double f = 0.5; bool take = fork_mode == 2 && gates.size() >= 2;
-    if (fork_mode == 1 && gates.size() >= 8 && s->nranks == 1) {
+    if (fork_mode == 1 && gates.size() >= 64 && s->nranks == 1) {
         const double h = 9.4e-9 * elems, e = 3.5e-9 * elems, c = 2.0;
         double best = h + c + e; const double unforked = best;
         for (double t = 0.40; t <= 0.801; t += 0.02) { const double tt = h * t + std::max(c, h * (1 - t)) + std::max(c, e * t) + e * (1 - t); if (tt < best) { best = tt; f = t; } }
