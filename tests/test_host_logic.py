@@ -153,3 +153,30 @@ def test_steiner_tree_of_an_observable_support():
             assert sorted(region, key=hg.index.__getitem__) == o.steiner_vertices(ho, vs)
     with pytest.raises(ValueError):
         tn.steiner_region(tn.NamedGraph([1, 2, 3], [(1, 2)]), [1, 3])
+
+
+def test_marshalled_circuit_cache_keys_on_gate_identity_and_registry():
+    """core._marshal_circuit: the flat arrays of a circuit are reused for the SAME gate tuples on the same graph only, and not after the registry entry of
+    one of its names changed; lists and explicit matrices are never cached."""
+    from tnqs_amd import core
+    g = tn.named_grid((2, 2))
+    layer = [("Rx", [v], 0.3) for v in g.vertices] + [("Rzz", [a, b], 0.2) for (a, b) in g.edges]
+    a1 = core._marshal_circuit(layer, g); a2 = core._marshal_circuit(layer, g)
+    assert a1[5] is a2[5] and a1[0] == len(layer)                                   # same arrays
+    a3 = core._marshal_circuit(list(layer), g)                                      # another list of the same tuples: same circuit
+    assert a3[5] is a1[5]
+    rebuilt = [("Rx", [v], 0.3) for v in g.vertices] + [("Rzz", [a, b], 0.2) for (a, b) in g.edges]
+    a4 = core._marshal_circuit(rebuilt, g)
+    assert a4[5] is not a1[5] and np.array_equal(a4[5], a1[5])
+    assert core._marshal_circuit(layer, tn.named_grid((2, 2)))[5] is not a1[5]       # another graph object
+    tn.register_gate("MyG", lambda: np.eye(2))
+    try:
+        c = [("MyG", [g.vertices[0]])]
+        m1 = core._marshal_circuit(c, g)[5]
+        tn.unregister_gate("MyG"); tn.register_gate("MyG", lambda: np.diag([1.0, -1.0]))
+        m2 = core._marshal_circuit(c, g)[5]
+        assert not np.array_equal(m1, m2)
+    finally:
+        tn.unregister_gate("MyG")
+    mat = np.eye(2, dtype=complex)
+    assert core._marshal_circuit([(mat, [g.vertices[0]])], g)[5] is not core._marshal_circuit([(mat, [g.vertices[0]])], g)[5]
