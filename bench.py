@@ -171,7 +171,8 @@ def main():
         layer = tfim_layer(tn, g, groups)
         zdeg = 4
         workload = (f"{L}x{L} square-lattice TFIM Trotter layer (Rx + 4 edge colours of Rzz), chi={chi}, ComplexF32, apply_gates incl. BP updates; "
-                    + ("BASELINE.json configs[1]" if cfg == "c2" else "BASELINE.json configs[4]" + ("" if L == 32 else f" at L = {L} instead of 32")))
+                    + (("BASELINE.json configs[1]" + ("" if (L == 20 and chi == 32) else f" at L = {L}, chi = {chi} instead of 20, 32")) if cfg == "c2"
+                       else "BASELINE.json configs[4]" + ("" if L == 32 else f" at L = {L} instead of 32")))
     n2 = g.ne()
     apply_kwargs = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
 
