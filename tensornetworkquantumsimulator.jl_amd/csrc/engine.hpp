@@ -155,7 +155,8 @@ struct State {
     // A BP update inside apply_gates whose convergence verdict has not been read yet (engine_bp.cpp, "optimistic" mode): the first sweep is enqueued
     // together with the copy of its summed message change into `host` (a pinned slot behind the staging arena), the messages are committed, and the
     // host goes on PREPARING the next gate batch while the sweep runs; resolve_bp() -- called before that batch enqueues anything -- waits and decides.
-    struct BpPending { bool active = false; const double* host = nullptr; double tol = 0; size_t nseq = 0; int iters_done = 0, maxiter = 0; } bp_pending;
+    struct BpPending { bool active = false; const double* host = nullptr; double tol = 0; size_t nseq = 0; int iters_done = 0, maxiter = 0; hipEvent_t ev = nullptr; } bp_pending;
+    hipEvent_t ev_bp = nullptr;        // recorded behind the copy of the verdict: resolve_bp waits for THIS, not for what was enqueued after it
 
     size_t esz() const { return dtype == TNQS_C64 ? 8 : 16; }
     int scalartype() const { return real_io ? (dtype == TNQS_C64 ? TNQS_F32 : TNQS_F64) : dtype; }

@@ -264,8 +264,9 @@ struct ProdCache {
 bool resolve_bp(State* s) {
     State::BpPending& p = s->bp_pending;
     if (!p.active) return true;
-    HIPCHK(hipStreamSynchronize(s->stream));          // NOT drained(): the caller has staged descriptors in the arena for what it is about to launch
-    s->prof->chain = false;
+    // the event behind the verdict's copy, not the stream: the caller may already have enqueued work behind it (the next batch's environment chain runs
+    // while the host reads the verdict and enqueues the tensor passes); and NOT drained(): the caller has staged descriptors in the arena
+    HIPCHK(hipEventSynchronize(p.ev));
     const double avg = *p.host / (double)p.nseq;
     s->stats.last_bp_diff = avg;
     if (avg <= p.tol) { p.active = false; return true; }
@@ -734,8 +735,10 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 // the verdict travels to the pinned slot behind the arena; the messages are committed and the caller prepares its next phase meanwhile
                 double* slot = reinterpret_cast<double*>(s->arena.base + s->arena.cap);
                 HIPCHK(hipMemcpyAsync(slot, d_sum->p, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+                if (!s->ev_bp) HIPCHK(hipEventCreateWithFlags(&s->ev_bp, hipEventDisableTiming));
+                HIPCHK(hipEventRecord(s->ev_bp, s->stream));
                 s->keepalive.push_back(d_diffs); s->keepalive.push_back(d_sum);
-                s->bp_pending = State::BpPending{true, slot, tol, nseq, iter, maxiter};
+                s->bp_pending = State::BpPending{true, slot, tol, nseq, iter, maxiter, s->ev_bp};
                 s->msg = cur; s->stats.n_bp_updates += 1;
                 soft_sync(s);
                 return;

@@ -159,7 +159,7 @@ State::~State() {
     }
     if (ar.base) (void)hipHostFree(ar.base);
     for (auto& q : st) if (q.st) (void)hipStreamDestroy(q.st);
-    for (hipEvent_t e : {ev_fork, ev_join, ev_stagger}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev_fork, ev_join, ev_stagger, ev_bp}) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_ring) (void)hipEventDestroy(e);
     for (auto e : ev_ring_b) (void)hipEventDestroy(e);
 }

@@ -264,8 +264,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             ji.push_back(JacobiItem{r.H, r.V, r.n, r.n, nullptr});
             fi.push_back(EnvFinishItem{r.H, r.V, r.msq, r.prj, r.n, sqrt_cutoff, reinterpret_cast<int*>(d_flags->p) + 2 * i});
         }
-        // everything up to here was host preparation: the verdict of an optimistic BP update is awaited only now, in front of the first launch
-        if (s->bp_pending.active && !resolve_bp(s)) throw BpNotConverged{};
+        // everything up to here was host preparation.  The environment chain (small kernels that only READ the messages and write fresh buffers) is
+        // enqueued behind the pending BP sweep right away; the verdict is awaited after that, in front of the tensor passes
         if (!envs.empty()) {
             const EnvItem* de = upload_small(s, ei); const JacobiItem* dj = upload_small(s, ji); const EnvFinishItem* df = upload_small(s, fi);
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_prepare<T>(s->stream, de, (int)ei.size()); }
@@ -297,6 +297,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             fused_M[q] = c.steps[0].second; c.steps.erase(c.steps.begin());
         }
     }
+    if (s->bp_pending.active && !resolve_bp(s)) throw BpNotConverged{};      // (nothing of the state has been touched; the environment kernels' outputs are dropped)
     switch_stream(s, heavy_stream);
     if (s->fork_role == 2) { s->fork_sync->wait(); HIPCHK(hipStreamWaitEvent(s->stream, s->fork_sync->ev, 0)); }      // forked batch, half B: behind A's Gram pass
     run_chains<T>(s, chains, TNQS_PROF_GATE_MODEPROD);
