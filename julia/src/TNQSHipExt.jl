@@ -22,7 +22,7 @@ using Graphs: Graphs
 using Dictionaries: Dictionaries, Dictionary
 import Adapt
 
-export HipBeliefPropagationCache, HipStorage, shard!
+export HipBeliefPropagationCache, HipStorage, shard!, set_site_random!
 
 const LIB = get(ENV, "TNQS_HIP_LIB", "libtnqs_hip.so")
 
@@ -113,6 +113,16 @@ function upload_site!(c::HipBeliefPropagationCache, ψ, v)
 end
 
 linkkey(c, u, v) = (min(c.vid[u], c.vid[v]), max(c.vid[u], c.vid[v]))
+
+# Synthetic site tensor generated on the device (tnqs_set_site_random; benchmarks of states too large to build on the host): iid normal entries scaled by
+# `scale`, `bond_dims[j]` = dimension of the leg to the j-th neighbour of `v` in ascending vertex id; entry e of vertex v depends on (seed, v, e) only.
+# The cache's link indices of `v` are re-created lazily like after a gate (a bond whose dimension changed gets a new Index when it is next asked for).
+function set_site_random!(c::HipBeliefPropagationCache, v, bond_dims::Vector{<:Integer}; seed::Integer = 1234, scale::Real = 1.0)
+    dims = Int64.(bond_dims)
+    GC.@preserve dims check(ccall((:tnqs_set_site_random, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Int64}, UInt64, Cdouble),
+                                  c.handle, c.vid[v], length(dims), dims, UInt64(seed), Float64(scale)))
+    return c
+end
 
 # Base.copy (beliefpropagationcache.jl:35-37): O(V + E) on the device (buffers are shared and never mutated in place)
 function Base.copy(c::HipBeliefPropagationCache{V}) where {V}
