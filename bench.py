@@ -177,6 +177,7 @@ def main():
     apply_kwargs = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
 
     # ---- state: bond dimension 1 handle, then upload the synthetic chi-saturated tensors ---------------------
+    free_at_start = torch.cuda.mem_get_info(local if world > 1 else 0)[0]
     psi0 = tn.tensornetworkstate(dtype, lambda v: "↑", g)
     bpc = tn.BeliefPropagationCache(psi0, device=local if world > 1 else 0)
     transport_note = None
@@ -187,7 +188,7 @@ def main():
             # them fall back to the callback transport (the same all-gathers through torch.distributed) and the JSON line says so
             ok, why = 1, ""
             try:
-                tdist.shard(bpc, rank, world, transport="rccl")
+                tdist.shard(bpc, rank, world, transport="rccl", balance_chi=chi)
             except Exception as e:                                   # noqa: BLE001 -- any failure means "no in-library RCCL on this node"
                 ok, why = 0, f"{type(e).__name__}: {e}"
             flag = torch.tensor([ok], device=f"cuda:{local}", dtype=torch.int32)
@@ -195,9 +196,9 @@ def main():
             if int(flag.item()) == 0:
                 transport_note = "callback (in-library RCCL set-up failed on at least one rank" + (f": {why}" if why else "") + ")"
                 bpc = tn.BeliefPropagationCache(psi0, device=local)
-                tdist.shard(bpc, rank, world, transport="callback")
+                tdist.shard(bpc, rank, world, transport="callback", balance_chi=chi)
         else:
-            tdist.shard(bpc, rank, world)
+            tdist.shard(bpc, rank, world, balance_chi=chi)
     # memory: a rank holds its own site tensors; a layer needs about three more copies of them at its peak (new tensors of a batch, the gauge
     # ping-pong buffers / BP partial products, Gram partials) -- refuse before allocating instead of dying in the middle of the upload
     own_bytes = sum(8 * d * chi ** g.degree(v) for v in g.vertices if (world == 1 or bpc.owns(v)))
@@ -241,6 +242,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     prof = tn.profile_get(bpc)
+    # the library's pool keeps what it has allocated: device memory taken since the start of the run = the high-water mark of the layer
+    mem["measured_peak_GiB"] = round((free_at_start - torch.cuda.mem_get_info(local if world > 1 else 0)[0]) / 2 ** 30, 2)
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
     value = n2 * args.steps / elapsed
 
@@ -325,6 +328,8 @@ def main():
                       "state_init": ("host numpy, per-vertex counter streams" if (cfg == "c2" or args.host_init) else "on device (tnqs_set_site_random, counter-based)"),
                       "memory": mem, "parallelism": f"vertex-shard x{world}",
                       "transport": (None if world == 1 else {"kind": type(bpc._shard).__name__, "nranks": world, "backend": dist.get_backend(),
+                                                             "partition": {"rule": "contiguous vertex blocks, heaviest block minimised (weight = site-tensor elements at chi)",
+                                                                           **tdist.partition_summary(g, bpc._shard.owner, chi)},
                                                              **({"note": transport_note} if transport_note else {}),
                                                              "allgathers_per_step": round(bpc._shard.n_exchanges / max(1, args.steps + args.warmup), 1),
                                                              "MB_gathered_per_step": round(bpc._shard.bytes_exchanged / max(1, args.steps + args.warmup) / 1e6, 2)})},

@@ -87,7 +87,6 @@ typedef struct {
     int n_svd_sweeps;       /* Jacobi sweeps of the theta SVDs, summed over the two-site gates of the call (diagnostic: sweeps per gate = this / n_two_site) */
     int n_deferred_1site;   /* unitary one-site gates that were only recorded and later absorbed by a two-site gate on the vertex (or applied when the tensor was read) */
     int n_lowrank_fallbacks; /* gates that qualified for the low-rank theta SVD but whose Cholesky / CholeskyQR2 of B refused a pivot: they took the SVD of the full theta */
-    int n_forked_batches;   /* gate batches that ran as two halves on two streams (one half's per-gate factorisation chain under the other half's tensor passes) */
 } tnqs_apply_stats;
 
 /* ---- library ---------------------------------------------------------------------------------------- */

@@ -9,7 +9,7 @@ CMD=${2:-"python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline"}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export TNQS_BENCH_NOPROF=1 TNQS_FORK=0
+export TNQS_BENCH_NOPROF=1
 pass() { name=$1; shift; rm -rf $OUT/pmc_$name; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$name -- $CMD > $OUT/pmc_$name.log 2>&1 || echo "pass $name failed (see $OUT/pmc_$name.log)"; }
 pass a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE
 pass b SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE

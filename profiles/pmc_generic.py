@@ -61,7 +61,7 @@ def main():
             if m.get("SQ_ACTIVE_INST_VALU") is not None and gui: der["valu_active_per_simd_cycle"] = round(m["SQ_ACTIVE_INST_VALU"] / (gui * 256 * 4), 4)
             if m.get("TCP_PENDING_STALL_CYCLES") is not None and gui: der["tcp_pending_stall_frac"] = round(m["TCP_PENDING_STALL_CYCLES"] / (gui * 256), 4)
             if m.get("TCC_HIT") is not None and (m.get("TCC_HIT", 0) + m.get("TCC_MISS", 0)) > 0: der["l2_hit_rate"] = round(m["TCC_HIT"] / (m["TCC_HIT"] + m["TCC_MISS"]), 4)
-    json.dump({"build_id": build_id(), "command": os.environ.get("PROFILE_CMD", "bench.py --steps 1 --warmup 1 --no-cpu-baseline (TNQS_FORK=0)"), "kernels": res}, open(out, "w"), indent=1)
+    json.dump({"build_id": build_id(), "command": os.environ.get("PROFILE_CMD", "bench.py --steps 1 --warmup 1 --no-cpu-baseline"), "kernels": res}, open(out, "w"), indent=1)
     for k, v in res.items():
         print(k[:60], v.get("avg_ms_by_pass"), v.get("derived"))
 

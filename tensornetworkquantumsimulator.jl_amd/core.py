@@ -400,7 +400,7 @@ def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_
         warnings.warn(f"BP did not converge in {st.bp_not_converged} of {st.n_bp_updates} cache updates "
                       f"(final average message change: {st.last_bp_diff}).")
     if info is not None:
-        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_tall_svd=st.n_tall_svd, n_deferred_1site=st.n_deferred_1site, n_forked_batches=st.n_forked_batches, n_lowrank_fallbacks=st.n_lowrank_fallbacks, n_svd_sweeps=st.n_svd_sweeps, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
+        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_tall_svd=st.n_tall_svd, n_deferred_1site=st.n_deferred_1site, n_lowrank_fallbacks=st.n_lowrank_fallbacks, n_svd_sweeps=st.n_svd_sweeps, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
                     n_two_site=st.n_two_site, bp_not_converged=st.bp_not_converged)
     return out, errs[:ng]
 

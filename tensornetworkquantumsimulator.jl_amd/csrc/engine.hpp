@@ -11,7 +11,6 @@
 #include <cstdint>
 #include <map>
 #include <memory>
-#include <condition_variable>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -29,9 +28,8 @@ void hipchk(hipError_t e, const char* what);
 
 // ---- caching device allocator ---------------------------------------------------------------------------------
 // Reuse is stream-ordered: a buffer that goes back to the free list may be handed out again at once, which is safe while all work of a
-// handle is enqueued on ONE stream.  While a gate batch runs as two halves on two streams (engine_gates.cpp, fork / join), releases are
-// DEFERRED instead: nothing freed inside the forked region is handed out before the join has ordered both streams again.  The two halves
-// are driven by two host threads, hence the lock.
+// handle is enqueued on ONE stream.  While the boundary sites of a BP level run on the side stream (engine_bp.cpp, fork / join), releases are
+// DEFERRED instead: nothing freed inside that region is handed out before the join has ordered both streams again.
 class Pool {
 public:
     explicit Pool(int device) : device_(device) {}
@@ -125,22 +123,9 @@ struct State {
     std::vector<Buf> msg;          // 2*ne, null = unset = identity (tensornetworkstate.jl:72-75)
     std::shared_ptr<Pool> pool;
     hipStream_t stream = nullptr; bool own_stream = false;
-    hipStream_t base_stream = nullptr;      // forked half: its ordinary stream (`stream` alternates between this one and chain_stream)
-    // second stream of a forked gate batch (engine_gates.cpp apply_two_site_forked) with the two events that order it against `stream`;
-    // created on first use, owned by this State
-    hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stagger = nullptr;
-    // HIGH-PRIORITY streams for the per-gate factorisation chains of the two halves: next to the other half's tensor passes (thousands of
-    // queued workgroups) the one-workgroup-per-gate kernels of a chain would wait for a free CU at every step (measured: chol_kernel 1.4 ms
-    // instead of 0.07, gate_finish 0.9 instead of 0.06); with queue priority their workgroups take the next slot that frees up.
-    // chain_stream != null: this State switches to it for the chain phases of a batch (switch_stream, engine_internal.hpp)
-    hipStream_t hi_stream[2] = {nullptr, nullptr}; hipStream_t chain_stream = nullptr;
-    std::vector<hipEvent_t> ev_ring, ev_ring_b; size_t ev_next = 0;      // events that order a State's streams against each other (ev_ring_b: lent to half B)
-    // set while this State is one half of a forked batch: half A (role 1) records `ev` behind its Gram pass and signals; half B (role 2) lets
-    // its own tensor passes wait for that event, so that B's heavy passes run under A's factorisation chain instead of next to A's heavy passes
-    struct ForkSync { std::mutex m; std::condition_variable cv; bool recorded = false; hipEvent_t ev = nullptr;
-                      void signal() { { std::lock_guard<std::mutex> lk(m); recorded = true; } cv.notify_all(); }
-                      void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return recorded; }); } };
-    ForkSync* fork_sync = nullptr; int fork_role = 0;
+    // side stream (+ the two events that order it against `stream`): the early small-SVD launches of a gate batch (engine_gates.cpp 2b) and the
+    // boundary sites of a BP level (engine_bp.cpp) run on it next to the tensor passes of the main stream; created on first use, owned by this State
+    hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // sharding
     int rank = 0, nranks = 1; std::vector<int> owner; tnqs_allgather_fn ag_fn = nullptr; void* ag_ctx = nullptr;
     void* exch = nullptr; size_t exch_bytes = 0;      // device exchange buffer (nranks equal blocks): the host's (callback mode) or comm->exch_owned
@@ -150,7 +135,6 @@ struct State {
     std::vector<Buf> keepalive;    // descriptor buffers and workspaces kept until the next host sync
     size_t keep_mark = 0;          // keepalive[0, keep_mark) belongs to phases that have ended: released at the next stream synchronisation (soft_sync)
     HostArena arena;               // this handle's pinned staging arena (taken from / returned to a small free list, engine_core.cpp)
-    std::vector<HostArena> retired_arenas;      // arenas of forked halves: pending copies / kernels may still read them; recycled when this handle's stream has drained
     tnqs_apply_stats stats{};
     // A BP update inside apply_gates whose convergence verdict has not been read yet (engine_bp.cpp, "optimistic" mode): the first sweep is enqueued
     // together with the copy of its summed message change into `host` (a pinned slot behind the staging arena), the messages are committed, and the

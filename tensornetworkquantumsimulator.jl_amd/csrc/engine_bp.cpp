@@ -570,7 +570,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 static const bool bp_split_on = !envflag("TNQS_NO_BP_SPLIT");
                 hipStream_t const main_stream = s->stream;
                 bool has_other = false; for (size_t ci = 0; ci < chains.size(); ++ci) has_other = has_other || !is_shared[ci];
-                const bool split_level = s->nranks == 1 && !s->chain_stream && !s->fork_role && (!sh_pair.empty() || !sh_dbl.empty()) && has_other && g16.empty() && bp_split_on;
+                const bool split_level = s->nranks == 1 && (!sh_pair.empty() || !sh_dbl.empty()) && has_other && g16.empty() && bp_split_on;
                 hipStream_t side_stream = nullptr;
                 if (split_level) {
                     side_stream = aux_stream_of(s);

@@ -146,12 +146,9 @@ static hipStream_t acquire_stream(int device, int hi = 0) {
 State::~State() {
     if (own_stream && stream) (void)hipStreamSynchronize(stream);           // nothing of this State is in flight past this point
     if (aux_stream) (void)hipStreamSynchronize(aux_stream);
-    for (auto q : hi_stream) if (q) (void)hipStreamSynchronize(q);
     keepalive.clear(); site.clear(); msg.clear();
-    for (auto& r : retired_arenas) recycle_arena(r);
-    retired_arenas.clear();
     HostArena ar = arena; arena = HostArena{};
-    SpareStream st[4] = {{device, 0, (own_stream && stream) ? stream : nullptr}, {device, 0, aux_stream}, {device, 1, hi_stream[0]}, {device, 1, hi_stream[1]}};
+    SpareStream st[2] = {{device, 0, (own_stream && stream) ? stream : nullptr}, {device, 0, aux_stream}};
     {
         std::lock_guard<std::mutex> lk(g_recycle_mu);
         if (ar.base && g_spare_arenas.size() < kMaxSpares) { ar.off = 0; g_spare_arenas.push_back(ar); ar.base = nullptr; }
@@ -159,37 +156,20 @@ State::~State() {
     }
     if (ar.base) (void)hipHostFree(ar.base);
     for (auto& q : st) if (q.st) (void)hipStreamDestroy(q.st);
-    for (hipEvent_t e : {ev_fork, ev_join, ev_stagger, ev_bp}) if (e) (void)hipEventDestroy(e);
-    for (auto e : ev_ring) (void)hipEventDestroy(e);
-    for (auto e : ev_ring_b) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev_fork, ev_join, ev_bp}) if (e) (void)hipEventDestroy(e);
 }
 hipStream_t aux_stream_of(State* s) {
     if (!s->aux_stream) {
         s->aux_stream = acquire_stream(s->device);
-        s->hi_stream[0] = acquire_stream(s->device, 1); s->hi_stream[1] = acquire_stream(s->device, 1);
         HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&s->ev_stagger, hipEventDisableTiming));
     }
     return s->aux_stream;
 }
-// continue on another stream of this State: everything enqueued so far on the current one comes first
-void switch_stream(State* s, hipStream_t to) {
-    if (!to || to == s->stream) return;
-    if (s->ev_ring.size() < 8) { hipEvent_t e = nullptr; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); s->ev_ring.push_back(e); s->ev_next = s->ev_ring.size() - 1; }
-    hipEvent_t e = s->ev_ring[s->ev_next]; s->ev_next = (s->ev_next + 1) % 8;
-    HIPCHK(hipEventRecord(e, s->stream));
-    HIPCHK(hipStreamWaitEvent(to, e, 0));
-    s->stream = to;
-    if (s->prof) s->prof->chain = false;
-}
-
 void sync(State* s) {
     HIPCHK(hipStreamSynchronize(s->stream));
     s->keepalive.clear(); s->keep_mark = 0;
     s->arena.off = 0;
-    for (auto& ar : s->retired_arenas) recycle_arena(ar);
-    s->retired_arenas.clear();
     if (s->prof) s->prof->chain = false;
 }
 

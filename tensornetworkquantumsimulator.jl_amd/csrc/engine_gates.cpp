@@ -1,7 +1,5 @@
 // engine_gates.cpp -- apply_gates (src/Apply/apply_gates.jl:46-143), simple_update as batched launches, truncate (src/truncate.jl).
 #include "engine_internal.hpp"
-#include <exception>
-#include <thread>
 
 namespace tnqs {
 
@@ -212,10 +210,6 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         absorbed.push_back(matmul_dd(g2.mat, kron.data(), dd));
         g2.mat = absorbed.back().data();
     }
-    // forked batch (apply_two_site_forked): the per-gate chains run on the half's high-priority stream, the tensor passes on its ordinary one
-    hipStream_t const heavy_stream = s->stream; hipStream_t const chain_stream = s->chain_stream;
-    struct RestoreStream { State* s; hipStream_t h; ~RestoreStream() { s->stream = h; g_corun_geometry = false; } } restore_stream{s, heavy_stream};
-    g_corun_geometry = s->fork_role != 0;       // chain kernels of a forked half run next to the other half's tensor passes (kernels.hpp)
     HostTimer ht_a(3);                 // TNQS_HOST_TIMING=1: host time of the batch up to the first read-back (3), between the read-backs (4), after them (5)
     if (!ao.normalize_tensors && s->bp_pending.active && !resolve_bp(s)) throw BpNotConverged{};      // (materialize_scale below launches)
     if (!ao.normalize_tensors) {       // without the final normalisation the result scales with the inputs: apply pending factors first
@@ -246,7 +240,6 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             }
         }
     }
-    switch_stream(s, chain_stream);
     std::vector<int> h_flags(2 * envs.size() + 2, 0);
     Buf d_flags = dalloc(s, h_flags.size() * sizeof(int));
     Buf env_arena;
@@ -298,17 +291,18 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         }
     }
     if (s->bp_pending.active && !resolve_bp(s)) throw BpNotConverged{};      // (nothing of the state has been touched; the environment kernels' outputs are dropped)
-    switch_stream(s, heavy_stream);
-    if (s->fork_role == 2) { s->fork_sync->wait(); HIPCHK(hipStreamWaitEvent(s->stream, s->fork_sync->ev, 0)); }      // forked batch, half B: behind A's Gram pass
     run_chains<T>(s, chains, TNQS_PROF_GATE_MODEPROD);
     std::vector<Buf> GA(sj.size()), GV(sj.size()), GW(sj.size()); std::vector<char> is_chol(sj.size(), 0), is_small(sj.size(), 0), small_done(sj.size(), 0);
     auto nof = [&](size_t i) { return sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]; };
     auto small_shape = [&](size_t i) { const int n = nof(i); return sj[i].sd.n / (size_t)n < (size_t)n && n <= 256 && use_small_svd(); };
     // ---- 2b. sites with fewer fibers than columns (corners, low bond dimensions) are factorised without a Gram matrix, by a one-sided Jacobi of
     // the small matricised psi~ (f64): three dependent launches (0.2 ms on a 7 x 7 lattice) that only need the gauged tensor.  They start NOW on a
-    // side stream, under the Gram pass, instead of in front of the Cholesky kernels afterwards (single rank, unforked batches) --------------------
+    // side stream, under the Gram pass, instead of in front of the Cholesky kernels afterwards (single rank) -------------------------------------
     hipEvent_t ev_small = nullptr;
-    if (!sharded && !chain_stream) {
+    // (whatever happens before the regular wait below -- an exception in the Gram / reduce / Cholesky steps -- the main stream is ordered behind the side
+    //  stream before this frame releases M / GA / GV to the stream-ordered pool: round-4 advisor finding)
+    struct SmallJoin { State* s; hipEvent_t& ev; ~SmallJoin() { if (ev) (void)hipStreamWaitEvent(s->stream, ev, 0); } } small_join{s, ev_small};
+    if (!sharded) {
         std::vector<SmallSvdItem> si; std::vector<JacobiItem> sji;
         for (size_t q = 0; q < own_idx.size(); ++q) {
             const size_t i = own_idx[q];
@@ -352,8 +346,6 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         for (size_t q = 0; q < jf16.size(); ++q) jobs[idf16[q]] = jf16[q];
         for (size_t q = 0; q < jp.size(); ++q) jobs[idp[q]] = jp[q];
     }
-    if (s->fork_role == 1) { HIPCHK(hipEventRecord(s->fork_sync->ev, s->stream)); s->fork_sync->signal(); }      // forked batch, half A: B's tensor passes may start
-    switch_stream(s, chain_stream);
     // G slots: in the sharded case every rank needs G1 and G2 of the gates it takes part in -> all-gather all of them (the same layout
     // serves the Gram matrices of the second factorisation pass further down)
     std::vector<size_t> slot(sj.size(), 0); size_t stride = 0;
@@ -648,7 +640,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         }
         launch_theta_scale<T>(s->stream, d_gitems, npg);       // theta (or M) and theta0 to O(1), exponent kept per gate for gate_finish
     };
-    if (ev_small) HIPCHK(hipStreamWaitEvent(s->stream, ev_small, 0));      // the early small-SVD factors (2b) are inputs of gate_theta
+    if (ev_small) { HIPCHK(hipStreamWaitEvent(s->stream, ev_small, 0)); ev_small = nullptr; }      // the early small-SVD factors (2b) are inputs of gate_theta
     run_theta();
     std::vector<int> info(8 * (size_t)ng, 0); std::vector<double> terr(ng, 0.0);
     {
@@ -889,7 +881,6 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     // every gate's status is checked before anything of the handle is replaced: a failing batch leaves the state as it was
     for (int gi = 0; gi < ng; ++gi) if (info[8 * gi + 3] != 0) throw Err(TNQS_ERR_NUMERIC, "simple_update: internal bond capacity exceeded");
     // ---- 5. psi' = (psi x_outer P) x_(s,b) X  (simple_update.jl:62-64, net effect of gauge + ungauge) ----------------
-    switch_stream(s, heavy_stream);
     std::vector<Chain> pch(own_idx.size());
     for (size_t q = 0; q < own_idx.size(); ++q) {
         const SiteJob& j = sj[own_idx[q]];
@@ -1004,113 +995,10 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     soft_sync(s);   // workspace of this batch goes back to the pool at the next stream synchronisation (the BP update's first read-back)
 }
 
-// ---- a batch as two halves on two streams ---------------------------------------------------------------------------------------
-// Between the Gram pass and the epilogue of a batch lies a chain of one-workgroup-per-gate kernels (Cholesky, theta, its SVD, V recovery,
-// truncation: ~2 ms per batch whatever its size) during which the chip idles.  The gates of a batch are independent of each other, so the
-// batch is cut in two halves that run the SAME code on two streams, driven by two host threads: while one half sits in its chain, the
-// other half's gauge / Gram / epilogue passes have the chip.  Half B works on a clone of the handle (its own stream, staging arena,
-// keep-alive list, profiler; the buffer pool is shared and defers every release until the join, see Pool) and its results are merged
-// back afterwards; the main stream waits for B's stream before anything else is enqueued.  Taken when the heavy passes are long enough
-// to hide a chain (single rank; TNQS_FORK=0 switches it off, TNQS_FORK=1 forks every batch of two or more gates -- the route tests).
-static std::unique_ptr<State> fork_state(State* s) {
-    auto b = std::make_unique<State>();
-    b->g = s->g; b->dtype = s->dtype; b->real_io = s->real_io; b->device = s->device; b->d = s->d; b->chi = s->chi;
-    b->site = s->site; b->sscale = s->sscale; b->msg = s->msg; b->pool = s->pool;
-    b->prof = std::make_shared<Prof>(); b->prof->on = s->prof->on;
-    b->pend1 = s->pend1; b->unit_norm = s->unit_norm; b->in_apply = s->in_apply; b->bp_pending = s->bp_pending;
-    b->stream = aux_stream_of(s); b->own_stream = false; b->base_stream = b->stream;
-    return b;
-}
-template <class T> static void apply_two_site_forked(State* s, const std::vector<Gate2>& gates, const tnqs_apply_opts& ao, double* errs) {
-    static const int fork_mode = [] { const char* e = std::getenv("TNQS_FORK"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();      // 0: never, 2: every batch of two or more gates (tests), unset: by size
-    double elems = 0;
-    // (>= 64 gates: with a dozen gates of 268 MB tensors per batch -- the 3x3x3 cubic lattice -- the halves' tensor passes lose more to their smaller
-    //  launches than the chains cost: 319.5 ms forked against 311.3 unforked per layer)
-    if (fork_mode == 1 && gates.size() >= 64 && s->nranks == 1) for (auto& g2 : gates) elems += (double)site_nelem(s, g2.v1) + (double)site_nelem(s, g2.v2);
-    // Which share f goes to half A.  Model of a batch (ms; measured on the 20x20 chi = 32 layer): gauge + Gram passes h = 9.4e-9 per
-    // element, epilogue e = 3.5e-9 per element, chain c = 2.0 whatever the size.  Unforked: h + c + e.  Forked, with B's passes behind A's Gram:
-    // h f + max(c, h (1 - f)) + max(c, e f) + e (1 - f) -- A's chain under B's gauge + Gram, B's chain under A's epilogue.  Both chains are hidden
-    // when h (1 - f) >= c and e f >= c (f ~ 0.72 at 20x20); small batches gain nothing (the two chains would merely run one after the other).
-    double f = 0.5; bool take = fork_mode == 2 && gates.size() >= 2;
-    if (fork_mode == 1 && gates.size() >= 64 && s->nranks == 1) {
-        const double h = 9.4e-9 * elems, e = 3.5e-9 * elems, c = 2.0;
-        double best = h + c + e; const double unforked = best;
-        for (double t = 0.40; t <= 0.801; t += 0.02) { const double tt = h * t + std::max(c, h * (1 - t)) + std::max(c, e * t) + e * (1 - t); if (tt < best) { best = tt; f = t; } }
-        take = best < 0.88 * unforked;       // (at 0.91 -- a 14 x 14 lattice -- the measured layer was 1 % slower forked than unforked)
-    }
-    if (!take || s->nranks > 1) { apply_two_site_batch<T>(s, gates, ao, errs); return; }
-    // half A: the first gates up to the share f of the elements
-    if (fork_mode == 2) for (auto& g2 : gates) elems += (double)site_nelem(s, g2.v1) + (double)site_nelem(s, g2.v2);
-    size_t na = 0; { double acc = 0; while (na + 1 < gates.size() && acc < f * elems) { acc += (double)site_nelem(s, gates[na].v1) + (double)site_nelem(s, gates[na].v2); ++na; } }
-    na = std::max<size_t>(1, std::min(na, gates.size() - 1));
-    const std::vector<Gate2> ga(gates.begin(), gates.begin() + (std::ptrdiff_t)na), gb(gates.begin() + (std::ptrdiff_t)na, gates.end());
-    std::unique_ptr<State> b = fork_state(s);
-    HIPCHK(hipEventRecord(s->ev_fork, s->stream));
-    HIPCHK(hipStreamWaitEvent(b->stream, s->ev_fork, 0));                 // B starts after everything enqueued so far (the BP update's messages)
-    // a failing batch leaves the state as it was (apply_two_site_batch checks every gate before it replaces anything): half A works on the handle
-    // itself, so what it is about to replace is remembered and put back should half B fail after A has succeeded
-    struct Saved { int v; Buf site, sscale; std::vector<double> pend1; char unit_norm; };
-    struct SavedEdge { int e, chi; Buf m0, m1; };
-    std::vector<Saved> saved_v; std::vector<SavedEdge> saved_e;
-    for (auto& g2 : ga) {
-        for (int v : {g2.v1, g2.v2}) saved_v.push_back(Saved{v, s->site[v], s->sscale[v], s->pend1[v], s->unit_norm[v]});
-        const int e = s->g->edge(g2.v1, g2.v2); saved_e.push_back(SavedEdge{e, s->chi[e], s->msg[2 * e], s->msg[2 * e + 1]});
-    }
-    const tnqs_apply_stats stats_before = s->stats;
-    s->pool->set_defer(true);
-    State::ForkSync fs; fs.ev = s->ev_stagger;
-    s->fork_sync = &fs; s->fork_role = 1; b->fork_sync = &fs; b->fork_role = 2;
-    s->base_stream = s->stream; s->chain_stream = s->hi_stream[0]; b->chain_stream = s->hi_stream[1]; b->ev_ring.swap(s->ev_ring_b); b->ev_next = 0;
-    std::exception_ptr ea, eb;
-    std::thread th([&] {
-        try { HIPCHK(hipSetDevice(b->device)); apply_two_site_batch<T>(b.get(), gb, ao, errs); }
-        catch (...) { eb = std::current_exception(); }
-    });
-    try { apply_two_site_batch<T>(s, ga, ao, errs); } catch (...) { ea = std::current_exception(); }
-    if (!fs.recorded) { (void)hipEventRecord(fs.ev, s->stream); fs.signal(); }      // A failed before its Gram pass: B must not wait for ever
-    th.join();
-    s->fork_sync = nullptr; s->fork_role = 0; s->chain_stream = nullptr; s->base_stream = nullptr; b->ev_ring.swap(s->ev_ring_b);
-    // join: the main stream continues after B's epilogue; only then may anything released meanwhile be handed out again
-    (void)hipEventRecord(s->ev_join, b->stream);
-    (void)hipStreamWaitEvent(s->stream, s->ev_join, 0);
-    if (!ea && !eb) {
-        const Graph& g = *s->g;
-        for (auto& g2 : gb) {
-            for (int v : {g2.v1, g2.v2}) { s->site[v] = b->site[v]; s->sscale[v] = b->sscale[v]; s->pend1[v] = b->pend1[v]; s->unit_norm[v] = b->unit_norm[v]; }
-            const int e = g.edge(g2.v1, g2.v2);
-            s->chi[e] = b->chi[e]; s->msg[2 * e] = b->msg[2 * e]; s->msg[2 * e + 1] = b->msg[2 * e + 1];
-        }
-        s->stats.n_two_site += b->stats.n_two_site; s->stats.n_chol_fallbacks += b->stats.n_chol_fallbacks; s->stats.n_qr2_sites += b->stats.n_qr2_sites;
-        s->stats.n_lowrank_svd += b->stats.n_lowrank_svd; s->stats.n_lowrank_fallbacks += b->stats.n_lowrank_fallbacks; s->stats.n_tall_svd += b->stats.n_tall_svd; s->stats.n_svd_sweeps += b->stats.n_svd_sweeps;
-        s->stats.n_forked_batches += 1;
-    }
-    if (eb && !ea) {      // A replaced its tensors, B failed: back to the state before the batch
-        for (auto& sv : saved_v) { s->site[sv.v] = sv.site; s->sscale[sv.v] = sv.sscale; s->pend1[sv.v] = sv.pend1; s->unit_norm[sv.v] = sv.unit_norm; }
-        for (auto& se : saved_e) { s->chi[se.e] = se.chi; s->msg[2 * se.e] = se.m0; s->msg[2 * se.e + 1] = se.m1; }
-        s->stats = stats_before;
-    }
-    // B's workspaces and descriptor buffers live until the main stream has drained past the join
-    for (auto& k : b->keepalive) s->keepalive.push_back(k);
-    b->keepalive.clear(); soft_sync(s);
-    if (b->arena.base) { s->retired_arenas.push_back(b->arena); b->arena = HostArena{}; }      // B's pending copies / kernels still read its staging arena
-    {   // B's profiler scopes: events recorded on its stream, collected with the others
-        Prof& P = *s->prof; Prof& Q = *b->prof;
-        for (int c = 0; c < TNQS_PROF_NCLASSES; ++c) { P.cls[c].launches += Q.cls[c].launches; P.cls[c].bytes += Q.cls[c].bytes; P.cls[c].flops += Q.cls[c].flops; P.cls[c].ms += Q.cls[c].ms; }
-        for (auto& pe : Q.pending) P.pending.push_back(pe);
-        Q.pending.clear();
-        for (auto e : Q.ev_free) P.ev_free.push_back(e);
-        Q.ev_free.clear(); P.chain = false;
-    }
-    b.reset();
-    s->pool->set_defer(false);
-    if (ea) std::rethrow_exception(ea);
-    if (eb) std::rethrow_exception(eb);
-}
-
 template <class T> static void flush_batch(State* s, std::vector<Gate1>& b1, std::vector<Gate2>& b2, const tnqs_apply_opts& ao, double* errs) {
     if (b1.empty() && b2.empty()) return;
     apply_one_site_batch<T>(s, b1, ao.normalize_tensors != 0, false);
-    apply_two_site_forked<T>(s, b2, ao, errs);
+    apply_two_site_batch<T>(s, b2, ao, errs);
     s->stats.n_batches += 1;
     b1.clear(); b2.clear();
     soft_sync(s);
@@ -1212,7 +1100,7 @@ template <class T> static void truncate_t(State* s, int maxdim, double cutoff, i
             idmats.push_back(ident(s->d[pr.first] * s->d[pr.second]));
             b2.push_back(Gate2{pr.first, pr.second, idmats.back().data(), 0});
         }
-        apply_two_site_forked<T>(s, b2, ao, nullptr);
+        apply_two_site_batch<T>(s, b2, ao, nullptr);
         if (!b2.empty()) s->stats.n_batches += 1;
         bp_update_t<T>(s, bp, nullptr, nullptr);                               // :28 / :34
     };

@@ -64,7 +64,6 @@ TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64
 // TNQS_NO_3M=1 (launch_util.hpp): four-multiplication complex product in every MFMA kernel instead of Gauss' three (mfma_common.hpp, CAcc32);
 // TNQS_NO_OPTIMISTIC_BP=1 (engine_bp.cpp): every BP update inside apply_gates waits for its convergence verdict before the next batch is prepared;
 // TNQS_NO_BP_SPLIT=1 (engine_bp.cpp): the boundary sites' products and Grams of a BP level on the same stream as the bulk sites' plane kernels instead of next to them;
-// TNQS_FORK=0 / 1 (engine_gates.cpp): never / always run a gate batch as two halves on two streams (default: by size);
 // Kernel experiments are NOT in the shipped library: TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP, TNQS_DBG_GRAM_SKIP, TNQS_PAIR_SPW, TNQS_PAIR16_HALF
 // and TNQS_QR2_ALL only exist in a build with -DTNQS_EXPERIMENTS (csrc/build.sh EXPERIMENTS=1); the kernel-level entry points of
 // include/tnqs_debug.h (debug.cpp) read TNQS_DBG_* themselves and are not part of the hot path.
@@ -84,15 +83,14 @@ struct HostTimer {
 };
 
 void sync(State* s);                                   // stream synchronise + release of the batch's descriptor buffers
-hipStream_t aux_stream_of(State* s);                  // second stream of a forked gate batch (+ its events), created / recycled with the State
-void switch_stream(State* s, hipStream_t to);        // continue on another stream of this State, ordered behind the current one (null / same: no-op)
+hipStream_t aux_stream_of(State* s);                  // the State's side stream (+ its events), created on first use / recycled with the State
 void recycle_arena(HostArena ar);                     // back to the free list (nothing on the device may still read it)
 HostArena acquire_arena();                             // a recycled or freshly pinned 32 MiB arena (engine_core.cpp)
 // The staging arena is about to be reused from its start: everything that may still read it must have run -- on the current stream and on the other
-// streams this State enqueues on (the side stream of the early small-SVD launches, the two streams of a forked half)
+// stream this State enqueues on (the side stream of the early small-SVD launches and of the BP levels' boundary sites)
 inline void drain_for_arena_reuse(State* s) {
     HIPCHK(hipStreamSynchronize(s->stream));
-    for (hipStream_t q : {s->base_stream, s->chain_stream, s->aux_stream}) if (q && q != s->stream) HIPCHK(hipStreamSynchronize(q));
+    if (s->aux_stream && s->aux_stream != s->stream) HIPCHK(hipStreamSynchronize(s->aux_stream));
 }
 // Read-back through the pinned staging arena: the copy is enqueued and the staged host pointer returned; it holds the data once the stream
 // has been synchronised (a read-back into pageable memory is staged by the runtime and BLOCKS per call).  The staged bytes stay valid until the
@@ -122,8 +120,6 @@ inline void soft_sync(State* s) { s->keep_mark = s->keepalive.size(); }
 inline void drained(State* s) {
     s->prof->chain = false;                    // the host waited: the next profiled scope records its own start event
     s->arena.off = 0;                          // every staged upload has been copied; staged read-backs are consumed by the caller before its next upload
-    for (auto& ar : s->retired_arenas) recycle_arena(ar);
-    s->retired_arenas.clear();
     if (s->keep_mark) { s->keepalive.erase(s->keepalive.begin(), s->keepalive.begin() + (std::ptrdiff_t)std::min(s->keep_mark, s->keepalive.size())); s->keep_mark = 0; }
 }
 void materialize_scale(State* s, const std::vector<int>& verts);

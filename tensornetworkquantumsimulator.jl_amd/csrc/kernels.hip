@@ -21,7 +21,6 @@
 #include "launch_util.hpp"
 
 namespace tnqs {
-thread_local bool g_corun_geometry = false;       // kernels.hpp
 
 template <class T> struct alignas(2 * sizeof(T)) cx { T re, im; };
 
@@ -827,7 +826,7 @@ __global__ __launch_bounds__(NT) void chol_kernel(const CholItem* __restrict__ i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_dmax;
     const CholItem it = items[blockIdx.x];
-    // (NT = 1024, sixteen waves: the other waves of a SIMD cover a wave's LDS round trips; NT = 256: g_corun_geometry)
+    // (NT = 1024, sixteen waves: the other waves of a SIMD cover a wave's LDS round trips)
     const int n = it.n, np = n + 1, tid = threadIdx.x;
     cx<double>* A = reinterpret_cast<cx<double>*>(smem);          // [col j][row i] at i + np*j, lower triangle becomes L (unscaled), strict upper M
     const cx<double>* G = reinterpret_cast<const cx<double>*>(it.G);
@@ -1043,11 +1042,6 @@ void launch_chol_packed(hipStream_t s, const CholItem* d_items, int nitems, int 
 void launch_chol(hipStream_t s, const CholItem* d_items, int nitems, int nmax) {
     if (nitems <= 0) return;
     const size_t lds = (size_t)nmax * (nmax + 1) * 16;
-    if (g_corun_geometry) {
-        set_max_dynamic_lds((const void*)chol_kernel<256, 21>, (size_t)(160 * 1024 - 1024));
-        hipLaunchKernelGGL((chol_kernel<256, 21>), dim3(nitems), dim3(256), lds, s, d_items); TNQS_CHECK_LAUNCH();
-        return;
-    }
     set_max_dynamic_lds((const void*)chol_kernel<1024, 6>, (size_t)(160 * 1024 - 1024));       // (the kernel also has ~0.8 KB of static LDS: pivots)
     hipLaunchKernelGGL((chol_kernel<1024, 6>), dim3(nitems), dim3(1024), lds, s, d_items); TNQS_CHECK_LAUNCH();
 }
@@ -1314,8 +1308,7 @@ __global__ __launch_bounds__(1024) void gate_theta_mm_kernel(const GateItem* __r
 }
 template <class T> void launch_gate_theta_mm(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    if (g_corun_geometry) hipLaunchKernelGGL((gate_theta_mm_kernel<T>), dim3(nitems, 8), dim3(256), 0, s, d_items);
-    else hipLaunchKernelGGL((gate_theta_mm_kernel<T>), dim3(nitems, 2), dim3(1024), 0, s, d_items);
+    hipLaunchKernelGGL((gate_theta_mm_kernel<T>), dim3(nitems, 2), dim3(1024), 0, s, d_items);
     TNQS_CHECK_LAUNCH();
 }
 template void launch_gate_theta_mm<float>(hipStream_t, const GateItem*, int);
@@ -1347,8 +1340,7 @@ __global__ __launch_bounds__(1024) void lowrank_g_kernel(const GateItem* __restr
 }
 void launch_lowrank_g(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    if (g_corun_geometry) hipLaunchKernelGGL(lowrank_g_kernel, dim3(nitems, 16), dim3(256), 0, s, d_items);
-    else hipLaunchKernelGGL(lowrank_g_kernel, dim3(nitems, 4), dim3(1024), 0, s, d_items);
+    hipLaunchKernelGGL(lowrank_g_kernel, dim3(nitems, 4), dim3(1024), 0, s, d_items);
     TNQS_CHECK_LAUNCH();
 }
 // theta[:, 0..K) := M = A conj(L) where G = L L^dagger (chol_kernel); on a collapsed pivot the full theta (already in place) stays.
@@ -1407,14 +1399,13 @@ __global__ __launch_bounds__(1024) void theta_scale_kernel(const GateItem* __res
 }
 template <class T> void launch_theta_scale(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((theta_scale_kernel<T>), dim3(nitems), dim3(g_corun_geometry ? 256 : 1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((theta_scale_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_theta_scale<float>(hipStream_t, const GateItem*, int);
 template void launch_theta_scale<double>(hipStream_t, const GateItem*, int);
 template <class T> void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    if (g_corun_geometry) hipLaunchKernelGGL((lowrank_m_kernel<T>), dim3(nitems, 16), dim3(256), 0, s, d_items);
-    else hipLaunchKernelGGL((lowrank_m_kernel<T>), dim3(nitems, 4), dim3(1024), 0, s, d_items);
+    hipLaunchKernelGGL((lowrank_m_kernel<T>), dim3(nitems, 4), dim3(1024), 0, s, d_items);
     TNQS_CHECK_LAUNCH();
 }
 template void launch_lowrank_m<float>(hipStream_t, const GateItem*, int);
@@ -1474,8 +1465,7 @@ void launch_lowrank_ll(hipStream_t s, const LowQr2Item* d_items, int nitems) {
 }
 template <class T> void launch_gate_theta(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    if (g_corun_geometry) hipLaunchKernelGGL((gate_theta_kernel<T>), dim3(nitems, 32), dim3(256), 0, s, d_items);
-    else hipLaunchKernelGGL((gate_theta_kernel<T>), dim3(nitems, 8), dim3(1024), 0, s, d_items);
+    hipLaunchKernelGGL((gate_theta_kernel<T>), dim3(nitems, 8), dim3(1024), 0, s, d_items);
     TNQS_CHECK_LAUNCH();
 }
 template void launch_gate_theta<float>(hipStream_t, const GateItem*, int);
@@ -1665,8 +1655,7 @@ __global__ __launch_bounds__(1024) void gate_finish_kernel(const GateItem* __res
 }
 template <class T> void launch_gate_finish(hipStream_t s, const GateItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    if (g_corun_geometry) hipLaunchKernelGGL((gate_finish_kernel<T>), dim3(nitems, 16), dim3(256), 0, s, d_items);
-    else hipLaunchKernelGGL((gate_finish_kernel<T>), dim3(nitems, 4), dim3(1024), 0, s, d_items);
+    hipLaunchKernelGGL((gate_finish_kernel<T>), dim3(nitems, 4), dim3(1024), 0, s, d_items);
     TNQS_CHECK_LAUNCH();
 }
 template void launch_gate_finish<float>(hipStream_t, const GateItem*, int);

@@ -98,12 +98,6 @@ struct GateItem {         // everything the per-gate small-algebra kernels need 
     // SVD pipeline squares and multiplies these entries; gate_finish puts the factor back into the singular values
     int* texp;
 };
-// Launch geometry of the per-gate chain kernels.  Alone on the chip they run 1024-thread workgroups (sixteen waves cover each other's LDS round
-// trips).  While the OTHER half of a forked batch (engine_gates.cpp) streams a tensor pass whose waves hold a SIMD's whole register file, a
-// 1024-thread workgroup only finds a CU when that pass drains (measured: chol_kernel 1.6 ms instead of 0.07, gate_finish 0.9 instead of 0.06); a
-// 256-thread workgroup (one wave per SIMD, <= 64 VGPRs) fits next to a single retiring tensor-pass workgroup.  The engine sets this thread-local
-// flag around the chain phase of a forked half: the launchers then use 256-thread workgroups and four times as many parts per gate.
-extern thread_local bool g_corun_geometry;
 template <class T> void launch_theta_scale(hipStream_t s, const GateItem* d_items, int nitems);
 void launch_lowrank_g(hipStream_t s, const GateItem* d_items, int nitems);
 template <class T> void launch_lowrank_m(hipStream_t s, const GateItem* d_items, int nitems);

@@ -49,7 +49,7 @@ def test_lowrank_theta_route_matches_the_full_svd():
 
 @pytest.mark.parametrize("switch", ["TNQS_NO_CHOL", "TNQS_NO_SMALLSVD", "TNQS_JACOBI_GLOBAL", "TNQS_NO_PAIR", "TNQS_NO_TSHARE", "TNQS_NO_FUSED_GRAM",
                                     "TNQS_NO_APPLY64", "TNQS_NO_MFMA", "TNQS_EAGER_SCALE", "TNQS_NO_PREFIX", "TNQS_NO_ROWGEMM32", "TNQS_NO_3M",
-                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE", "TNQS_FORK", "TNQS_NO_OPTIMISTIC_BP"])
+                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE", "TNQS_NO_OPTIMISTIC_BP"])
 def test_alternative_routes_match_the_default(switch):
     """every documented switch selects an alternative route of the same algorithm: all-eigen factorisation instead
     of Cholesky, Gram-eigen instead of the small-SVD route, global-memory Jacobi, single-leg mode products, per-message BP products,
@@ -79,7 +79,7 @@ def test_staging_arena_overflow_keeps_descriptors_alive():
         assert ref[name]["z"] == alt[name]["z"], name
 
 
-@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_DEFER_1SITE", "TNQS_FORK", "TNQS_NO_BP_SPLIT", "TNQS_NO_OPTIMISTIC_BP"])
+@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_DEFER_1SITE", "TNQS_NO_BP_SPLIT", "TNQS_NO_OPTIMISTIC_BP"])
 def test_bulk_shape_routes_match(switch):
     """the chi = 32 bulk shape (BASELINE configs[1]): the third gauge leg absorbed inside the f64 Gram kernel (kernels_gate.hip) against the
     separate single-leg pass + plain Gram; ranks of the R factors left on the device against read back; three- against four-multiplication
@@ -91,8 +91,6 @@ def test_bulk_shape_routes_match(switch):
     dz = float(np.max(np.abs(np.array(ref["z"]) - np.array(alt["z"])))); dsp = float(np.max(np.abs(np.array(ref["spectra"]) - np.array(alt["spectra"]))))
     print(switch, "max |dZ|", dz, " spectra", dsp, " max |derr|", float(np.max(np.abs(ea - eb))))
     assert dz < 1e-5 and dsp < 1e-5
-    if switch == "TNQS_FORK":               # TNQS_FORK=1: every batch as two halves on two streams / two host threads (small lattices never fork by size)
-        assert ref["forked"] == 0 and alt["forked"] == 4        # the four colour batches (the fifth batch holds the one-site gates only)
     if switch == "TNQS_NO_GAUGE_GRAM":      # the fused route must actually have been taken: it saves the single-leg launches of the gauge
         assert ref["modeprod_launches"] < alt["modeprod_launches"] and ref["gram_launches"] > alt["gram_launches"]
 
@@ -244,10 +242,10 @@ def test_optimistic_bp_update_starts_over_when_its_sweep_did_not_converge():
         assert a["dims"] == b["dims"] and a["errs"] == b["errs"] and a["z"] == b["z"]
 
 
-def test_a_failing_forked_batch_leaves_the_state_as_it_was():
-    """TNQS_FORK=1, the C ABI called IN PLACE on a handle: a message with a negative eigenvalue next to a gate of the SECOND half of the batch makes half B fail
-    (DomainError in the reference, src/utils.jl:21) after half A has replaced its tensors -- the library puts them back: every site tensor, message and bond
-    dimension is what it was before the call."""
+def test_a_failing_batch_leaves_the_state_as_it_was():
+    """the C ABI called IN PLACE on a handle: a message with a negative eigenvalue next to one gate of a batch makes the batch fail (DomainError in the
+    reference, src/utils.jl:21) -- every gate's status is checked before anything of the handle is replaced: every site tensor, message and bond dimension
+    is what it was before the call."""
     code = (
         "import sys, ctypes as C; sys.path[:0] = %r\n"
         "import numpy as np, tnqs_amd as tn\n"
@@ -256,7 +254,7 @@ def test_a_failing_forked_batch_leaves_the_state_as_it_was():
         "bpc = tn.update(tn.BeliefPropagationCache(tn.random_tensornetworkstate(np.complex64, g, bond_dimension=4, seed=3)), maxiter=10, tolerance=None)\n"
         "grp = tn.edge_color(g, 4)[0]\n"
         "layer = [('Rzz', [a, b], 0.3) for (a, b) in grp]\n"
-        "a, b = grp[-1]                                   # a gate of the second half\n"
+        "a, b = grp[-1]\n"
         "w = [x for x in g.neighbors(a) if x != b][0]\n"
         "bad = np.diag([1.0, 0.5, 0.2, -0.3]).astype(np.complex64)\n"
         "bpc.setmessage((w, a), bad)\n"
@@ -270,5 +268,5 @@ def test_a_failing_forked_batch_leaves_the_state_as_it_was():
         "for v in g.vertices: assert np.array_equal(bpc.tensor(v), before[v]), v\n"
         "for e in g.edges: assert np.array_equal(bpc.message(e), mb[e]) and bpc.bond_dim(*e) == 4, e\n"
         "print('ok')\n") % (sys.path,)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TNQS_FORK="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1500:] + r.stderr[-3000:]

@@ -25,6 +25,34 @@ def test_partition_vertices():
     assert tn.dist.exchange_bytes_needed(32, 2, 760, 400, 8) < 200 << 20
 
 
+def test_partition_by_work_balances_the_bulk_sites():
+    """strong scaling is decided by the heaviest rank: a boundary site of the open 20 x 20 lattice costs 1/32 (degree 3) or 1/1024 (corner) of a bulk
+    site at chi = 32, so equal vertex counts leave the end ranks with 27 and the middle ranks with 45 bulk sites at 8 ranks.  The weighted
+    partition is contiguous, uses every rank, and is optimal: its heaviest block is within one bulk site of total / ranks (brute force on a small case)."""
+    g = tn.named_grid((20, 20))
+    w = tn.dist.site_weights(g, 32)
+    for world in (2, 4, 8):
+        own = tn.partition_vertices(g.nv(), world, w)
+        assert len(own) == g.nv() and own == sorted(own) and sorted(set(own)) == list(range(world))
+        summ = tn.dist.partition_summary(g, own, 32)
+        assert max(summ["bulk_sites"]) - min(summ["bulk_sites"]) <= 1, summ
+        assert max(summ["load_in_bulk_sites"]) <= 324.0 / world + 1.7, summ
+    assert tn.dist.partition_summary(g, tn.partition_vertices(g.nv(), 8), 32)["bulk_sites"] == [27, 45, 45, 45, 45, 45, 45, 27]
+    # optimality against brute force: 9 weights, 3 blocks
+    import itertools
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        ww = rng.integers(1, 50, size=9).astype(float)
+        own = tn.partition_vertices(9, 3, ww)
+        mine = max(ww[np.array(own) == r].sum() for r in range(3))
+        best = min(max(ww[:a].sum(), ww[a:b].sum(), ww[b:].sum()) for a, b in itertools.combinations(range(1, 9), 2))
+        assert mine == best
+    # more ranks than vertices: one vertex each, the surplus ranks own nothing
+    assert tn.partition_vertices(3, 5, [1.0, 1.0, 1.0]) == [0, 1, 2]
+    with pytest.raises(ValueError):
+        tn.partition_vertices(4, 2, [1.0, -1.0, 1.0, 1.0])
+
+
 def test_two_rank_protocol_matches_serial_oracle(tmp_path):
     out = str(tmp_path / "sim.pkl")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")

@@ -67,7 +67,7 @@ def chi32():
     for (a, b) in g.edges:
         m = b2.message((a, b)).astype(np.complex128); w = np.linalg.eigvalsh((m + m.conj().T) / 2); sp += (w / w.sum()).tolist()
     print(json.dumps(dict(errs=errs.tolist(), z=[float(np.real(x)) for x in tn.expect_all(b2, "Z")], dims=[b2.bond_dim(a, b) for a, b in g.edges], spectra=sp,
-                          modeprod_launches=prof["gate_modeprod"]["launches"], gram_launches=prof["gate_gram"]["launches"], forked=info["n_forked_batches"], batches=info["n_batches"])))
+                          modeprod_launches=prof["gate_modeprod"]["launches"], gram_launches=prof["gate_gram"]["launches"], batches=info["n_batches"])))
 
 
 def c128():
