@@ -27,9 +27,9 @@ import numpy as np
 
 def tfim_layer(tn, g, groups, J=1.0, hx=2.5, dt=0.01):
     """README.md:42-48 circuit: Rx(2 hx dt) on every vertex, Rzz(2 J dt) per edge colour"""
-    layer = [("Rx", [v], 2 * hx * dt) for v in g.vertices]
+    layer = [("Rx", (v,), 2 * hx * dt) for v in g.vertices]      # (vertex TUPLES: the host keeps the marshalled arrays of an immutable circuit)
     for grp in groups:
-        layer += [("Rzz", [a, b], 2 * J * dt) for (a, b) in grp]
+        layer += [("Rzz", (a, b), 2 * J * dt) for (a, b) in grp]
     return layer
 
 
@@ -158,10 +158,10 @@ def main():
     if cfg == "c4":       # examples/3dIsing_dynamics.jl:15-26: Rz(h dt) on every vertex, Rxx(2 J dt) per edge colour, Rz(h dt) again; h = J = -1, dt = 0.04
         g = tn.named_grid((L, L, L), periodic=True)
         groups = tn.edge_color(g)
-        layer = [("Rz", [v], -0.04) for v in g.vertices]
+        layer = [("Rz", (v,), -0.04) for v in g.vertices]
         for grp in groups:
-            layer += [("Rxx", [a, b], -0.08) for (a, b) in grp]
-        layer += [("Rz", [v], -0.04) for v in g.vertices]
+            layer += [("Rxx", (a, b), -0.08) for (a, b) in grp]
+        layer += [("Rz", (v,), -0.04) for v in g.vertices]
         zdeg = 6
         workload = (f"{L}x{L}x{L} periodic cubic lattice, 3-D Ising Trotter layer (Rz + {len(groups)} edge colours of Rxx + Rz; examples/3dIsing_dynamics.jl), chi={chi}, "
                     f"ComplexF32, apply_gates incl. BP updates; BASELINE.json configs[3]" + ("" if L == 10 else f" at L = {L} instead of 10"))
@@ -199,12 +199,13 @@ def main():
                 tdist.shard(bpc, rank, world, transport="callback", balance_chi=chi)
         else:
             tdist.shard(bpc, rank, world, balance_chi=chi)
-    # memory: a rank holds its own site tensors; a layer needs about three more copies of them at its peak (new tensors of a batch, the gauge
-    # ping-pong buffers / BP partial products, Gram partials) -- refuse before allocating instead of dying in the middle of the upload
+    # memory: a rank holds its own site tensors; a layer needs about four more copies of them at its peak (new tensors of a batch, the gauge
+    # ping-pong buffers, BP partial products kept across levels, Gram partials; measured 4.4 - 5.1 x the site tensors, profiles/r5_bench_c4_L5.json,
+    # r5_bench_c5_L11.json) -- refuse before allocating instead of dying in the middle of the upload
     own_bytes = sum(8 * d * chi ** g.degree(v) for v in g.vertices if (world == 1 or bpc.owns(v)))
     free_b, total_b = torch.cuda.mem_get_info(local if world > 1 else 0)
-    mem = {"site_tensor_GiB_this_rank": round(own_bytes / 2 ** 30, 2), "estimated_peak_GiB": round(4.0 * own_bytes / 2 ** 30 + 2.0, 2), "free_GiB": round(free_b / 2 ** 30, 1)}
-    if 4.0 * own_bytes + (2 << 30) > free_b:
+    mem = {"site_tensor_GiB_this_rank": round(own_bytes / 2 ** 30, 2), "estimated_peak_GiB": round(5.0 * own_bytes / 2 ** 30 + 0.5, 2), "free_GiB": round(free_b / 2 ** 30, 1)}
+    if 5.0 * own_bytes + (1 << 29) > free_b:
         raise SystemExit(f"bench.py: {workload}: rank {rank} of {world} would hold {mem['site_tensor_GiB_this_rank']} GiB of site tensors (estimated peak "
                          f"{mem['estimated_peak_GiB']} GiB) but the device has {mem['free_GiB']} GiB free -- use more GPUs (--gpus) or a smaller --L")
     if cfg == "c2" or args.host_init:
@@ -217,7 +218,7 @@ def main():
         for v in g.vertices:
             z = g.degree(v)
             bpc._set_random(v, [chi] * z, 1234, scale=1.0 / np.sqrt(d * float(chi) ** z))
-    sweeps, updates, svd_sweeps = [], [], []
+    sweeps, updates, svd_sweeps, svd_max, reused, evicted = [], [], [], [], [], []
     for _ in range(args.warmup):
         info = {}
         bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=apply_kwargs, info=info)
@@ -234,7 +235,7 @@ def main():
     for _ in range(args.steps):
         info = {}
         bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=apply_kwargs, info=info)
-        sweeps.append(info["n_sweeps"]); updates.append(info["n_updates"]); svd_sweeps.append(info.get("n_svd_sweeps", 0))
+        sweeps.append(info["n_sweeps"]); updates.append(info["n_updates"]); svd_sweeps.append(info.get("n_svd_sweeps", 0)); svd_max.append(info.get("n_svd_sweeps_max", 0)); reused.append(info.get("n_bp_products_reused", 0)); evicted.append(info.get("n_bp_products_evicted", 0))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -321,7 +322,8 @@ def main():
            "dtype": "c64 (ComplexF32; Gram/eigen steps in f64)", "data": "synthetic",
            "config": {"workload": workload, "baseline_config": cfg,
                       "two_site_gates_per_step": n2, "bp_updates_per_step": updates, "bp_sweeps_per_step": sweeps,
-                      "theta_svd_sweeps_per_gate": round(float(np.mean(svd_sweeps)) / max(1, n2), 2),
+                      "theta_svd_sweeps_per_gate": round(float(np.mean(svd_sweeps)) / max(1, n2), 2), "theta_svd_sweeps_slowest_gate": int(max(svd_max) if svd_max else 0),
+                      "bp_partial_products": {"reused_per_step": reused, "evicted_per_step": evicted},
                       "apply_kwargs": {"maxdim": chi, "cutoff": 1e-10, "normalize_tensors": True},
                       "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)",
                       "bp_order": "library default: linear forests, one level per forest (tnqs_bp_opts.n_sequence = 0; the reference's forest_cover_edge_sequence is n_sequence = -1; same fixed point)",

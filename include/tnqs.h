@@ -85,7 +85,10 @@ typedef struct {
     int n_lowrank_svd;      /* two-site gates whose theta SVD ran on the low-rank factor (gate of operator Schmidt rank kappa, kappa chi < d chi) */
     int n_tall_svd;         /* theta SVDs that went through the Cholesky-QR preprocessing (matrix too tall for the LDS-resident Jacobi: 256 x 128 at chi = 64) */
     int n_svd_sweeps;       /* Jacobi sweeps of the theta SVDs, summed over the two-site gates of the call (diagnostic: sweeps per gate = this / n_two_site) */
+    int n_svd_sweeps_max;   /* ... and the largest count of any single gate: a colour batch's SVD launch lasts as long as its slowest gate */
     int n_deferred_1site;   /* unitary one-site gates that were only recorded and later absorbed by a two-site gate on the vertex (or applied when the tensor was read) */
+    int n_bp_products_reused;  /* BP: partial products (site tensor x messages of some legs) taken from an earlier level instead of recomputed */
+    int n_bp_products_evicted; /* ... dropped again by the per-site bound (3) or the byte bound (TNQS_BP_CACHE_MB) before anything could reuse them or after */
     int n_lowrank_fallbacks; /* gates that qualified for the low-rank theta SVD but whose Cholesky / CholeskyQR2 of B refused a pivot: they took the SVD of the full theta */
 } tnqs_apply_stats;
 

@@ -30,36 +30,36 @@ def main():
     if mode == "cubic16":
         g = tn.named_grid((3, 3, 3), periodic=True); chi = 16
         groups = tn.edge_color(g)
-        layer = [("Rz", [v], -0.04) for v in g.vertices]
+        layer = [("Rz", (v,), -0.04) for v in g.vertices]
         for grp in groups:
-            layer += [("Rxx", [a, b], -0.08) for (a, b) in grp]
+            layer += [("Rxx", (a, b), -0.08) for (a, b) in grp]
         z = 6
     elif mode == "heavyhex":      # BASELINE configs[2]: heavy-hex (5,5), chi = 16, degrees 2 / 3 (examples/heavyhexIsing_dynamics.jl circuit); latency-bound
         g = tn.heavy_hexagonal_lattice(5, 5); chi = 16
         groups = tn.edge_color(g, 3)
-        layer = [("Rx", [v], 0.4) for v in g.vertices]
+        layer = [("Rx", (v,), 0.4) for v in g.vertices]
         for grp in groups:
-            layer += [("Rzz", [a, b], 0.1) for (a, b) in grp]
+            layer += [("Rzz", (a, b), 0.1) for (a, b) in grp]
         z = 3
     elif mode == "c1":            # BASELINE configs[0]: 5x5 TFIM, chi = 10, ComplexF64 (the reference's CPU-runnable case); latency-bound
         g = tn.named_grid((5, 5)); chi = 10; groups = tn.edge_color(g, 4)
-        layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+        layer = [("Rx", (v,), 2 * 2.5 * 0.01) for v in g.vertices]
         for grp in groups:
-            layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+            layer += [("Rzz", (a, b), 2 * 1.0 * 0.01) for (a, b) in grp]
         z = 4
     elif mode == "c128":
         L = int(os.environ.get("L", 8)); chi = int(os.environ.get("CHI", 32))
         g = tn.named_grid((L, L)); groups = tn.edge_color(g, 4)
-        layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+        layer = [("Rx", (v,), 2 * 2.5 * 0.01) for v in g.vertices]
         for grp in groups:
-            layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+            layer += [("Rzz", (a, b), 2 * 1.0 * 0.01) for (a, b) in grp]
         z = 4
     else:
         L = int(os.environ.get("L", 5)); chi = 64
         g = tn.named_grid((L, L)); groups = tn.edge_color(g, 4)
-        layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+        layer = [("Rx", (v,), 2 * 2.5 * 0.01) for v in g.vertices]
         for grp in groups:
-            layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+            layer += [("Rzz", (a, b), 2 * 1.0 * 0.01) for (a, b) in grp]
         z = 4
     dt_ = np.complex128 if mode in ("c128", "c1") else np.complex64
     bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(dt_, lambda v: "↑", g))

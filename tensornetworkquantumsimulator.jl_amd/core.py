@@ -366,8 +366,17 @@ def _marshal_circuit(circuit: Sequence, g: NamedGraph):
     vs_a, vs_p = L.i32(verts if verts else [0])
     mat_a = np.ascontiguousarray(np.concatenate(mats) if mats else np.zeros(1, dtype=np.complex128))
     arrs = (ng, nv_a, nv_p, vs_a, vs_p, mat_a)
-    # not cached: a gate given as a list (it could be edited in place) or as a matrix (an array is mutable)
-    if all(isinstance(gt, tuple) and isinstance(gt[0], str) for gt in circuit):
+    # cached only when NOTHING of a gate can be edited in place behind the identity key (round-4 advisor finding: ("Rzz", [a, b], theta) is a tuple, but
+    # its vertex list is mutable, and so is an array parameter): the gate is a tuple, its name a string, its vertices a tuple (or one hashable vertex that
+    # is not a list), its parameters plain numbers.  Anything else is resolved again on every call.
+    def _frozen(gt):
+        if not (isinstance(gt, tuple) and len(gt) >= 2 and isinstance(gt[0], str)):
+            return False
+        vs = gt[1]
+        if isinstance(vs, list) or isinstance(vs, np.ndarray) or (isinstance(vs, tuple) and any(isinstance(x, (list, np.ndarray)) for x in vs)):
+            return False
+        return all(isinstance(x, (int, float, complex, np.integer, np.floating, np.complexfloating)) and not isinstance(x, bool) or isinstance(x, bool) for x in gt[2:])
+    if all(_frozen(gt) for gt in circuit):
         names = {gt[0] for gt in circuit}
         _MARSHALLED.insert(0, (g, ids, tuple(circuit), [(nm, _gate_spec_of(nm)) for nm in names], arrs))   # the tuple keeps the gate objects (and their ids) alive
         del _MARSHALLED[4:]
@@ -400,7 +409,7 @@ def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_
         warnings.warn(f"BP did not converge in {st.bp_not_converged} of {st.n_bp_updates} cache updates "
                       f"(final average message change: {st.last_bp_diff}).")
     if info is not None:
-        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_tall_svd=st.n_tall_svd, n_deferred_1site=st.n_deferred_1site, n_lowrank_fallbacks=st.n_lowrank_fallbacks, n_svd_sweeps=st.n_svd_sweeps, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
+        info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_tall_svd=st.n_tall_svd, n_deferred_1site=st.n_deferred_1site, n_lowrank_fallbacks=st.n_lowrank_fallbacks, n_bp_products_reused=st.n_bp_products_reused, n_bp_products_evicted=st.n_bp_products_evicted, n_svd_sweeps=st.n_svd_sweeps, n_svd_sweeps_max=st.n_svd_sweeps_max, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
                     n_two_site=st.n_two_site, bp_not_converged=st.bp_not_converged)
     return out, errs[:ng]
 

@@ -42,6 +42,71 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
     if (sweeps) dS.down(sweeps, 4);
 }
 
+// theta_svd_pre_kernel on one ComplexF32 factor A (m x n) of theta = A Q^T, Q (nq x n, complex128, orthonormal columns): A := U Sigma, V (nq x n) := conj(Q) U_L.
+// reps > 0: additionally time `reps` launches on `copies` device-resident copies of A (one workgroup each) with HIP events -> *ms = average per launch
+void dbg_theta_svd_pre(int m, int n, int nq, void* A, const void* Q, void* V, int* sweeps, int copies, int reps, double* ms, double* phase_us) {
+    need_gpu();
+    if (!theta_svd_pre_covers(m, n) || nq < n || nq > m) throw Err(TNQS_ERR_INVALID, "dbg_theta_svd_pre: 2 <= n <= 64, n <= nq <= m <= 128");
+    if (copies < 1) copies = 1;
+    const size_t ab = (size_t)m * n * 8, vb = (size_t)nq * n * 8;
+    DBuf dA(ab * copies), dA0(ab), dQ((size_t)nq * n * 16), dV(vb * copies), dS(4 * (size_t)copies), dInfo(32), dI(sizeof(JacobiItem) * (size_t)copies), dT(64);
+    dA0.up(A, ab); dQ.up(Q, (size_t)nq * n * 16);
+    const int info[8] = {m, nq, 0, 0, 0, 0, 0, n};      // theta_dims with d1 = d2 = 1: m rows, nq columns of theta, n columns of the factor
+    dInfo.up(info, 32);
+    std::vector<JacobiItem> its(copies);
+    for (int c = 0; c < copies; ++c) {
+        JacobiItem it{}; it.A = (char*)dA.p + ab * c; it.V = (c == 0 && phase_us) ? dT.p : nullptr; it.m = m; it.n = nq; it.sweeps_out = (int*)dS.p + c; it.dyn = (const int*)dInfo.p; it.dm = 1; it.dn = 1; it.nhint = (std::getenv("TNQS_DBG_PRE_QUARTER") ? -7 : (std::getenv("TNQS_DBG_PRE_DUMP_L") ? -8 : n));
+        it.QB = dQ.p; it.Vout = (char*)dV.p + vb * c; it.pre = 1; its[c] = it;
+    }
+    dI.up(its.data(), sizeof(JacobiItem) * (size_t)copies);
+    auto reset = [&]() { for (int c = 0; c < copies; ++c) HIPCHK(hipMemcpyAsync((char*)dA.p + ab * c, dA0.p, ab, hipMemcpyDeviceToDevice, nullptr)); };
+    reset();
+    launch_theta_svd_pre(nullptr, (const JacobiItem*)dI.p, copies, 60, m, n);
+    HIPCHK(hipDeviceSynchronize());
+    dA.down(A, ab); dV.down(V, vb);
+    if (sweeps) dS.down(sweeps, 4);
+    if (phase_us) {      // constant-rate clock (100 MHz) at the seven phase boundaries of workgroup 0 -> six durations in us
+        unsigned long long t[8]; dT.down(t, 64);
+        for (int k = 0; k < 6; ++k) phase_us[k] = (double)(t[k + 1] - t[k]) * 0.01;
+    }
+    if (reps > 0 && ms) {
+        hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        double tot = 0;
+        for (int r = 0; r < reps; ++r) {
+            reset();
+            HIPCHK(hipEventRecord(e0, nullptr));
+            launch_theta_svd_pre(nullptr, (const JacobiItem*)dI.p, copies, 60, m, n);
+            HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1));
+            float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1)); tot += t;
+        }
+        *ms = tot / reps;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+}
+// the plain LDS-resident Jacobi on the same factor, timed the same way (what the preconditioned kernel replaces)
+void dbg_time_jacobi_f32(int m, int n, const void* A, int copies, int reps, double* ms, int* sweeps) {
+    need_gpu();
+    if (copies < 1) copies = 1;
+    const size_t ab = (size_t)m * n * 8;
+    DBuf dA(ab * copies), dA0(ab), dS(4 * (size_t)copies), dI(sizeof(JacobiItem) * (size_t)copies);
+    dA0.up(A, ab);
+    std::vector<JacobiItem> its(copies);
+    for (int c = 0; c < copies; ++c) { JacobiItem it{}; it.A = (char*)dA.p + ab * c; it.m = m; it.n = n; it.sweeps_out = (int*)dS.p + c; its[c] = it; }
+    dI.up(its.data(), sizeof(JacobiItem) * (size_t)copies);
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    double tot = 0;
+    for (int r = 0; r < reps + 1; ++r) {
+        for (int c = 0; c < copies; ++c) HIPCHK(hipMemcpyAsync((char*)dA.p + ab * c, dA0.p, ab, hipMemcpyDeviceToDevice, nullptr));
+        HIPCHK(hipEventRecord(e0, nullptr));
+        launch_jacobi<float>(nullptr, (const JacobiItem*)dI.p, copies, 60, jacobi_lds_bytes(m, n, false, 8), std::max(m, n), n);
+        HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1)); if (r > 0) tot += t;
+    }
+    if (ms) *ms = tot / std::max(1, reps);
+    if (sweeps) dS.down(sweeps, 4);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+}
+
 // Cholesky kernels on one Hermitian n x n complex128 matrix: L (lower), W = (L^-1)^dagger, *fail; n <= 96: chol_kernel, else packed
 void dbg_chol(int n, const void* G, void* Lout, void* Wout, int* fail, double tau) {
     need_gpu();

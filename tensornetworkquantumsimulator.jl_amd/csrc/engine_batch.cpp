@@ -180,14 +180,22 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
 template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, bool with_v) {
     const size_t esz = s->esz();
     const size_t cap = 160 * 1024 - 2048;
-    std::vector<JacobiItem> fit, tall, rest;
+    std::vector<JacobiItem> fit, tall, rest, pre;
     static const bool force_global = [] { const char* e = std::getenv("TNQS_JACOBI_GLOBAL"); return e && e[0] == '1'; }();
     for (auto& j : all) {
         if (j.n < 1 || j.m < 1) continue;
+        // a low-rank theta the caller offers to the preconditioned kernel (JacobiItem::pre): that kernel takes it when the dimensions found on the device
+        // fit; the item stays in the lists below as well, whose kernels skip it in that case
+        if (j.pre) pre.push_back(j);
         if (!force_global && jacobi_lds_bytes(j.m, j.n, with_v, esz) <= cap && std::max(j.m, j.n) <= 256) fit.push_back(j);
         else if (!force_global && std::is_same<T, float>::value && !with_v && !j.V && use_mfma() && use_tall_svd() && j.m >= j.n && j.n <= 128 && j.n >= 2 &&
                  jacobi_lds_bytes(j.n, j.n, false, esz) <= cap) tall.push_back(j);
         else rest.push_back(j);
+    }
+    if (!pre.empty()) {
+        const JacobiItem* d = upload_small(s, pre);
+        int mm = 1, nn = 1; for (auto& j : pre) { mm = std::max(mm, std::min(j.m, 128)); nn = std::max(nn, std::min(j.nhint > 0 ? j.nhint : j.n, 64)); }
+        launch_theta_svd_pre(s->stream, d, (int)pre.size(), 60, mm, nn);
     }
     if (!fit.empty()) {
         size_t lds = 0; for (auto& j : fit) lds = std::max(lds, jacobi_lds_bytes(j.m, j.n, with_v, esz));
@@ -268,7 +276,9 @@ template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& job
     bool mf64in = std::is_same<T, double>::value && use_mfma() && !f64_mfma_off && jobs[0].M == nullptr;
     for (auto& j : jobs) mf64in = mf64in && j.M == nullptr && gram_f64in_covers(j.keep_site ? j.sd.d : 1, j.leg >= 0 ? j.sd.chi[j.leg] : 1);
     if (mf64in) TR = 32;
-    const int target = 2048;
+    // workgroups per launch.  The f64 Grams of the gate path write one 64 KiB partial per (site, chunk, tile parity) which reduce_kernel reads back: 2048 chunks were
+    // 268 MB and 85-90 us per colour batch WHATEVER its size; 1024 (four workgroups per CU) halves that and costs the Gram pass nothing measurable
+    const int target = (std::is_same<T, float>::value && std::is_same<Acc, double>::value) ? 1024 : 2048;
     int per_item = std::max(1, target / (int)jobs.size());
     std::vector<GramItem> items; int chunks = 0; double bytes = 0, flops = 0;
     for (auto& j : jobs) {

@@ -226,6 +226,7 @@ struct SharedT { Buf site, ma, mb, T; int la = -1, lb = -1; };
 struct ProdEntry { Buf site; std::vector<std::pair<int, Buf>> legs; Buf prod; unsigned long long stamp = 0; };
 struct ProdCache {
     std::unordered_map<int, std::vector<ProdEntry>> by_site; unsigned long long clock = 0; int per_site = 3; size_t bytes = 0, cap = bp_cache_budget();
+    int n_hits = 0, n_evicted = 0;          // diagnostics (tnqs_apply_stats): lookups that found a product; entries dropped by the per-site or the byte bound
     // the largest entry of site v whose legs all occur in `want` with the same buffer; returns false when there is none
     bool find(int v, const Buf& site, const std::vector<std::pair<int, Buf>>& want, ProdEntry& out) {
         auto it = by_site.find(v); if (it == by_site.end()) return false;
@@ -237,14 +238,14 @@ struct ProdCache {
             if (sub) best = &e;
         }
         if (!best) return false;
-        best->stamp = ++clock; out = *best; return true;
+        best->stamp = ++clock; out = *best; ++n_hits; return true;
     }
     void put(int v, const Buf& site, std::vector<std::pair<int, Buf>> legs, const Buf& prod) {
         if (legs.size() < 2 || !prod) return;
         std::sort(legs.begin(), legs.end(), [](const std::pair<int, Buf>& a, const std::pair<int, Buf>& b) { return a.first < b.first; });
         auto& vec = by_site[v];
         for (auto& e : vec) if (e.site == site && e.legs == legs) { bytes += prod->bytes; bytes -= e.prod->bytes; e.prod = prod; e.stamp = ++clock; return; }
-        if ((int)vec.size() >= per_site) { size_t lru = 0; for (size_t i = 1; i < vec.size(); ++i) if (vec[i].stamp < vec[lru].stamp) lru = i; bytes -= vec[lru].prod->bytes; vec.erase(vec.begin() + lru); }
+        if ((int)vec.size() >= per_site) { size_t lru = 0; for (size_t i = 1; i < vec.size(); ++i) if (vec[i].stamp < vec[lru].stamp) lru = i; bytes -= vec[lru].prod->bytes; vec.erase(vec.begin() + lru); ++n_evicted; }
         ProdEntry e; e.site = site; e.legs = std::move(legs); e.prod = prod; e.stamp = ++clock; bytes += prod->bytes; vec.push_back(std::move(e));
         if (bytes > cap) {                         // over the byte bound: the least recently used entries of all sites go, in ONE pass -- down to 7/8 of the
             // bound, so that a long level under memory pressure does not rescan every entry for every product it stores (round-3 advisor finding)
@@ -255,7 +256,7 @@ struct ProdCache {
             for (auto& o : order) {
                 if (bytes <= target) break;
                 auto& vv = by_site[o.second];
-                for (size_t i = 0; i < vv.size(); ++i) if (vv[i].stamp == o.first) { bytes -= vv[i].prod->bytes; vv.erase(vv.begin() + (std::ptrdiff_t)i); break; }
+                for (size_t i = 0; i < vv.size(); ++i) if (vv[i].stamp == o.first) { bytes -= vv[i].prod->bytes; vv.erase(vv.begin() + (std::ptrdiff_t)i); ++n_evicted; break; }
             }
         }
     }
@@ -325,6 +326,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
         }
     }
     ProdCache pcache;
+    struct CacheStats { State* s; ProdCache& c; ~CacheStats() { s->stats.n_bp_products_reused += c.n_hits; s->stats.n_bp_products_evicted += c.n_evicted; } } cache_stats{s, pcache};
     {   // never more than a third of what the device has free right now (the products are an optimisation, the workspace is not)
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) pcache.cap = std::min(pcache.cap, (fr + s->pool->bytes_cached()) / 3);
@@ -352,7 +354,8 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
         }
     };
     static const bool optimistic_on = !envflag("TNQS_NO_OPTIMISTIC_BP");
-    const bool go_optimistic = optimistic && optimistic_on && compute_error && s->nranks == 1 && iters_before == 0 && s->arena.base;
+    // (sharded handles too, round 5: messages are replicated and every rank normalises / diffs all of them, so the verdict is the same on every rank)
+    const bool go_optimistic = optimistic && optimistic_on && compute_error && iters_before == 0 && s->arena.base;
     for (int iter = 1 + iters_before; iter <= maxiter; ++iter) {
         std::vector<Buf> fresh(2 * (size_t)g.ne);
         for (auto& lev : plan.levels) {
@@ -570,7 +573,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 static const bool bp_split_on = !envflag("TNQS_NO_BP_SPLIT");
                 hipStream_t const main_stream = s->stream;
                 bool has_other = false; for (size_t ci = 0; ci < chains.size(); ++ci) has_other = has_other || !is_shared[ci];
-                const bool split_level = s->nranks == 1 && (!sh_pair.empty() || !sh_dbl.empty()) && has_other && g16.empty() && bp_split_on;
+                const bool split_level = (!sh_pair.empty() || !sh_dbl.empty()) && has_other && g16.empty() && bp_split_on;
                 hipStream_t side_stream = nullptr;
                 if (split_level) {
                     side_stream = aux_stream_of(s);

@@ -241,7 +241,14 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         }
     }
     std::vector<int> h_flags(2 * envs.size() + 2, 0);
-    Buf d_flags = dalloc(s, h_flags.size() * sizeof(int));
+    // Everything of a batch the host zeroes and reads back lives in ONE buffer -- [info | low-rank failure flags (two passes) | truncation errors | Cholesky failure
+    // flags | message-eigenvalue flags]: one memset where there were four, one device-to-host copy where there were four (5 us of stream time each in a chain
+    // of 20-60 us kernels)
+    int npg0 = 0; for (int gi = 0; gi < ng; ++gi) npg0 += part[gi] ? 1 : 0;
+    const size_t rb_info = 0, rb_low = rb_info + round256((size_t)npg0 * 32), rb_low2 = rb_low + round256((size_t)npg0 * 4), rb_terr = rb_low2 + round256((size_t)npg0 * 4),
+                 rb_chol = rb_terr + round256((size_t)npg0 * 8), rb_env = rb_chol + round256(sj.size() * sizeof(int)), rb_total = rb_env + round256(h_flags.size() * sizeof(int));
+    Buf d_rb = dalloc(s, rb_total);
+    Buf d_flags = sub_buffer(d_rb, rb_env, h_flags.size() * sizeof(int));
     Buf env_arena;
     {
         std::vector<EnvItem> ei; std::vector<JacobiItem> ji; std::vector<EnvFinishItem> fi;
@@ -346,15 +353,22 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         for (size_t q = 0; q < jf16.size(); ++q) jobs[idf16[q]] = jf16[q];
         for (size_t q = 0; q < jp.size(); ++q) jobs[idp[q]] = jp[q];
     }
-    // G slots: in the sharded case every rank needs G1 and G2 of the gates it takes part in -> all-gather all of them (the same layout
-    // serves the Gram matrices of the second factorisation pass further down)
+    // G slots: in the sharded case both ranks of a gate that STRADDLES two ranks need G1 and G2 -> all-gather those (a gate whose two sites live on
+    // one rank is that rank's business alone: round 4 gathered the Gram matrices of every site, 25 MB per colour batch of the 20 x 20 lattice, of which
+    // a contiguous partition needs 20 gates' worth per cut).  The same layout serves the Gram matrices of the second factorisation pass further down.
+    // Every rank derives the same slots from the gate list and the owner map, so the collective is entered by all ranks or by none.
     std::vector<size_t> slot(sj.size(), 0); size_t stride = 0;
+    std::vector<char> cross(sj.size(), 0);        // the site's gate partner lives on another rank
     {
         std::vector<size_t> rank_bytes(s->nranks, 0);
         if (sharded) {
-            for (size_t i = 0; i < sj.size(); ++i) { int r = s->owner[sj[i].v]; slot[i] = rank_bytes[r]; rank_bytes[r] += round256((size_t)nof(i) * nof(i) * 16); }
+            for (size_t i = 0; i < sj.size(); ++i) {
+                if (s->owner[sj[i].v] == s->owner[sj[i].other]) continue;
+                cross[i] = 1;
+                int r = s->owner[sj[i].v]; slot[i] = rank_bytes[r]; rank_bytes[r] += round256((size_t)nof(i) * nof(i) * 16);
+            }
             for (size_t b : rank_bytes) stride = std::max(stride, b);
-            check_exchange(s, stride);
+            if (stride) check_exchange(s, stride);
         }
         std::vector<ReduceItem> ri; int elems = 0;
         for (size_t q = 0; q < own_idx.size(); ++q) {
@@ -362,19 +376,19 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             const GramJob& jb = jobs[job_of[q]];
             size_t i = own_idx[q]; int n = jb.KK; size_t nn = (size_t)n * n;
             GA[i] = dalloc(s, nn * 16);
-            void* dst = sharded ? (void*)(reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride + slot[i]) : GA[i]->p;
+            void* dst = cross[i] ? (void*)(reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride + slot[i]) : GA[i]->p;
             ri.push_back(ReduceItem{jb.partial->p, dst, (int)nn, jb.nchunks, 1, elems}); elems += (int)nn;
         }
         const ReduceItem* dr = upload(s, ri);
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, dr, (int)ri.size(), elems); }
-        if (sharded) {
+        if (sharded && stride) {
             exchange(s, stride);
             // one private copy of the gathered block (the exchange buffer is reused by the record exchange of this batch); the G of
             // every site this rank needs is a view into it
             Buf G_keep = dalloc(s, std::max<size_t>(256, stride * (size_t)s->nranks));
             HIPCHK(hipMemcpyAsync(G_keep->p, s->exch, stride * (size_t)s->nranks, hipMemcpyDeviceToDevice, s->stream));
             for (size_t i = 0; i < sj.size(); ++i) {
-                if (!part[i / 2]) continue;
+                if (!part[i / 2] || !cross[i]) continue;
                 size_t nn = (size_t)nof(i) * nof(i);
                 GA[i] = sub_buffer(G_keep, (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16);
             }
@@ -391,7 +405,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     // criterion must not depend on ownership, every rank taking part in a gate has to reach the same decision
     std::vector<const void*> gauged_of(sj.size(), nullptr);      // psi~ of the owned sites
     for (size_t q = 0; q < own_idx.size(); ++q) gauged_of[own_idx[q]] = chains[q].result;
-    Buf d_cholfail = dalloc(s, std::max<size_t>(1, sj.size()) * sizeof(int));      // one flag per site: only the sites whose pivot collapsed are redone
+    Buf d_cholfail = sub_buffer(d_rb, rb_chol, std::max<size_t>(1, sj.size()) * sizeof(int));      // one flag per site: only the sites whose pivot collapsed are redone
     std::vector<int> h_cholfail(sj.size(), 0);
     auto factor_G = [&](bool allow_chol, bool fallback = false) {
         std::vector<JacobiItem> ji, sji; std::vector<EnvItem> idn; std::vector<CholItem> ci; std::vector<SmallSvdItem> si; int cmax = 1;
@@ -444,7 +458,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     };
     factor_G(use_chol());
     // ---- 4. theta = gate . (R1 R2), SVD, truncation, X1 / X2  (simple_update.jl:51-59) -----------------------------
-    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S, lowA, lowB, lowG, lowL, lowW, lowB1, lowG2, lowL2, lowLc; int n1, n2, chi, cap; };
+    struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S, lowA, lowB, lowG, lowL, lowW, lowQ, lowB1, lowG2, lowL2, lowLc; int n1, n2, chi, cap; };
     std::vector<GateWS> ws(ng);
     std::vector<int> pg;                              // gates this rank takes part in
     for (int gi = 0; gi < ng; ++gi) if (part[gi]) pg.push_back(gi);
@@ -522,7 +536,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             it.GW1 = GW[2 * gi]->p; it.GW2 = GW[2 * gi + 1]->p; it.chol1 = is_chol[2 * gi]; it.chol2 = is_chol[2 * gi + 1];
             it.n1 = w.n1; it.n2 = w.n2; it.d1 = a.sd.d; it.d2 = b.sd.d; it.chi = w.chi;
             it.gate = reinterpret_cast<const double*>(d_gm + off[q]);
-            it.kappa = 0; it.opA = it.opB = nullptr; it.lowA = it.lowB = it.lowG = nullptr; it.lowL = nullptr; it.lowfail = nullptr;
+            it.kappa = 0; it.opA = it.opB = nullptr; it.lowA = it.lowB = it.lowG = nullptr; it.lowL = nullptr; it.lowfail = nullptr; it.lowW = nullptr; it.lowQ = nullptr;
             {   // the operator-sum factors A ((r1 d1) x K), B ((r2 d2) x K), K = kappa chi: theta = A B^T is formed from them (gate_theta_mm_kernel);
                 // the low-rank route of the theta SVD (lowG / lowL) only where it can apply -- K below the theta columns and chol_kernel's size
                 const int K = kappa[q] * w.chi;
@@ -534,6 +548,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                     if (K < Nc && K <= 128 && cap <= K && Mr >= Nc && lds_fits) {
                         w.lowG = dalloc(s, (size_t)K * K * 16); w.lowL = dalloc(s, (size_t)K * K * 16); w.lowW = dalloc(s, (size_t)K * K * 16);
                         it.lowG = w.lowG->p; it.lowL = w.lowL->p;
+                        // ComplexF32, factor of at most 128 x 64: the preconditioned SVD kernel builds V from Q = B L^-dagger (lowrank_m_kernel writes it)
+                        if (std::is_same<T, float>::value && use_precond_svd() && theta_svd_pre_covers(Mr, K) && K <= 96) { w.lowQ = dalloc(s, (size_t)Nc * K * 16); it.lowW = w.lowW->p; it.lowQ = w.lowQ->p; }
                         if (!std::is_same<T, float>::value) {
                             w.lowB1 = dalloc(s, (size_t)Nc * K * 16); w.lowG2 = dalloc(s, (size_t)K * K * 16); w.lowL2 = dalloc(s, (size_t)K * K * 16); w.lowLc = dalloc(s, (size_t)K * K * 16);
                         }
@@ -589,26 +605,23 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     };
     RgPlan spec_plan;
     // per-gate (r1, r2, chi', status, sweeps, wide, -, -) and truncation error live in two contiguous arrays: one D2H each
-    Buf d_info_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 32));
-    Buf d_terr_all = dalloc(s, std::max<size_t>(1, (size_t)npg * 8));
-    HIPCHK(hipMemsetAsync(d_info_all->p, 0, std::max<size_t>(1, (size_t)npg * 32), s->stream));
+    Buf d_info_all = sub_buffer(d_rb, rb_info, std::max<size_t>(1, (size_t)npg * 32));      // (zeroed by run_theta)
+    Buf d_terr_all = sub_buffer(d_rb, rb_terr, std::max<size_t>(1, (size_t)npg * 8));
     for (int q = 0; q < npg; ++q) { gitems[q].info = reinterpret_cast<int*>(d_info_all->p) + 8 * q; gitems[q].truncerr = reinterpret_cast<double*>(d_terr_all->p) + q; }
     // low-rank route: one failure flag per gate for the Cholesky factorisation of B^dagger B
-    Buf d_lowfail = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));
+    Buf d_lowfail = sub_buffer(d_rb, rb_low, std::max<size_t>(1, (size_t)npg * sizeof(int)));
     Buf d_texp = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));
-    Buf d_lowfail2 = dalloc(s, std::max<size_t>(1, (size_t)npg * sizeof(int)));      // ComplexF64: second CholeskyQR pass of the low-rank route
+    Buf d_lowfail2 = sub_buffer(d_rb, rb_low2, std::max<size_t>(1, (size_t)npg * sizeof(int)));      // ComplexF64: second CholeskyQR pass of the low-rank route
     for (int q = 0; q < npg; ++q) { gitems[q].lowfail = reinterpret_cast<const int*>(d_lowfail->p) + q; gitems[q].texp = reinterpret_cast<int*>(d_texp->p) + q; }
     const GateItem* d_gitems = upload(s, gitems);       // (read again after the host synchronisations of the batch: a device copy, not upload_small)
     auto run_theta = [&]() {
-        HIPCHK(hipMemsetAsync(d_info_all->p, 0, std::max<size_t>(1, (size_t)npg * 32), s->stream));
-        HIPCHK(hipMemsetAsync(d_lowfail->p, 0, std::max<size_t>(1, (size_t)npg * sizeof(int)), s->stream));
+        HIPCHK(hipMemsetAsync(d_rb->p, 0, rb_terr, s->stream));       // info and both low-rank failure flag arrays (contiguous)
         ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
         launch_gate_theta<T>(s->stream, d_gitems, npg);
         if (lowrank_on_batch) launch_gate_theta_mm<T>(s->stream, d_gitems, npg);        // theta = A B^T on the f64 matrix cores (gates with operator-sum factors)
         const bool f64 = !std::is_same<T, float>::value;
         std::vector<CholItem> lc, lc2; int kmax = 1;
         std::vector<GateItem> g2, g3; std::vector<LowQr2Item> qi;
-        if (f64) HIPCHK(hipMemsetAsync(d_lowfail2->p, 0, std::max<size_t>(1, (size_t)npg * sizeof(int)), s->stream));
         for (int q = 0; q < npg; ++q) {
             if (!gitems[q].lowG) continue;
             const int K = gitems[q].kappa * gitems[q].chi; GateWS& w = ws[pg[q]];
@@ -662,6 +675,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                     const int Mr = std::max(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2), Nc = std::min(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2);
                     j = JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, gitems[q].info + 4, gitems[q].info, gitems[q].d1, gitems[q].d2,
                                    gitems[q].lowG ? gitems[q].kappa * gitems[q].chi : 0};      // low-rank route expected: K columns
+                    if (gitems[q].lowQ) { j.QB = gitems[q].lowQ; j.Vout = ws[gi].thetaV->p; j.pre = 1; }      // offered to theta_svd_pre_kernel (decides on the device)
                     ncfull.push_back(Nc);
                 }
                 j.V = nullptr;          // V is never accumulated from the rotations (theta0_used): recovered below
@@ -669,16 +683,22 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             }
             { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); svd_batch<T>(s, ji, false); }
             std::vector<RecoverItem> rv;
-            for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ncfull[q], ji[q].n, ji[q].dyn, ji[q].dm, ji[q].dn});
+            for (int q = 0; q < npg; ++q) rv.push_back(RecoverItem{ws[pg[q]].theta0->p, ws[pg[q]].theta->p, ws[pg[q]].thetaV->p, ji[q].m, ncfull[q], ji[q].n, ji[q].dyn, ji[q].dm, ji[q].dn, ji[q].pre});
             const RecoverItem* dr = upload_small(s, rv);
             { ProfScope ps(s, TNQS_PROF_JACOBI, 0, 0); { int nmax = 1; for (int nc : ncfull) nmax = std::max(nmax, nc); if (std::is_same<T, float>::value && use_mfma()) launch_recover_v_mfma(s->stream, dr, npg, nmax); else launch_recover_v<T>(s->stream, dr, npg, nmax); } }
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_gate_finish<T>(s->stream, d_gitems, npg); }
         };
-        auto read_results = [&]() {          // (r1, r2, chi', status, ...) and the truncation errors of every gate: one synchronisation
-            const int* st_info2 = npg ? readback<int>(s, d_info_all->p, (size_t)npg * 8) : nullptr;
-            const double* st_terr = npg ? readback<double>(s, d_terr_all->p, (size_t)npg) : nullptr;
+        const char* st_all = nullptr;        // the staged copy of d_rb
+        auto read_results = [&]() {          // (r1, r2, chi', status, ...), the truncation errors of every gate and every flag of the batch: one copy, one synchronisation
+            st_all = readback<char>(s, d_rb->p, rb_total);
             HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
-            if (npg) { std::copy(st_info2, st_info2 + (size_t)npg * 8, hinfo.begin()); std::copy(st_terr, st_terr + npg, hterr.begin()); }
+            if (npg) { const int* a = reinterpret_cast<const int*>(st_all + rb_info); const double* b = reinterpret_cast<const double*>(st_all + rb_terr);
+                       std::copy(a, a + (size_t)npg * 8, hinfo.begin()); std::copy(b, b + npg, hterr.begin()); }
+        };
+        auto take_flags = [&]() {
+            const int* f = reinterpret_cast<const int*>(st_all + rb_env); const int* c = reinterpret_cast<const int*>(st_all + rb_chol);
+            if (!envs.empty()) std::copy(f, f + 2 * envs.size(), h_flags.begin());
+            if (!sj.empty()) std::copy(c, c + sj.size(), h_cholfail.begin());
         };
         auto chol_failures = [&]() { int c = 0; for (size_t i = 0; i < sj.size(); ++i) c += (part[i / 2] && is_chol[i] && h_cholfail[i]) ? 1 : 0; return c; };
         auto redo_with_eigen = [&]() {      // numerically rank-deficient Gram matrix somewhere in the batch: those sites take the eigen path
@@ -700,32 +720,21 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             const int Mr = std::max(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2), Nc = std::min(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2);
             one_trip = jacobi_lds(jacobi_lds_bytes(Mr, Nc, false, esz)) > 0 && Mr <= 256;
         }
-        const int* st_flags = nullptr; const int* st_chol = nullptr;
         // the four staged read-backs of a batch (flags, Cholesky flags, info, truncation errors) are consumed together after ONE synchronisation:
         // room for all of them is made up front, so that none of them can wrap the arena on top of another (round-3 advisor finding)
-        const size_t rb_bytes = round256(2 * envs.size() * sizeof(int)) + round256(sj.size() * sizeof(int)) + round256((size_t)npg * 32) + round256((size_t)npg * 8) + 1024;
+        const size_t rb_bytes = rb_total + 1024;
         if (one_trip) {
             svd_and_finish(nullptr);
             if (!sharded && ao.maxdim > 0) spec_plan = plan_rowgemm([&](int gi) { return ws[gi].cap; }, [&](size_t q) { return (const void*)s->site[sj[own_idx[q]].v]->p; }, nullptr);
             reserve_readback(s, rb_bytes);
-            st_flags = !envs.empty() ? readback<int>(s, d_flags->p, 2 * envs.size()) : nullptr;
-            st_chol = !sj.empty() ? readback<int>(s, d_cholfail->p, sj.size()) : nullptr;
             ht_a.stop();
-            read_results();
-            if (st_flags) std::copy(st_flags, st_flags + 2 * envs.size(), h_flags.begin());
-            if (st_chol) std::copy(st_chol, st_chol + sj.size(), h_cholfail.begin());
+            read_results(); take_flags();
             if (chol_failures()) { redo_with_eigen(); svd_and_finish(hinfo.data()); read_results(); }
         } else {
             // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
             reserve_readback(s, rb_bytes);
-            const int* st_info = npg ? readback<int>(s, d_info_all->p, (size_t)npg * 8) : nullptr;
-            st_flags = !envs.empty() ? readback<int>(s, d_flags->p, 2 * envs.size()) : nullptr;
-            st_chol = !sj.empty() ? readback<int>(s, d_cholfail->p, sj.size()) : nullptr;
             ht_a.stop();
-            HIPCHK(hipStreamSynchronize(s->stream)); drained(s);
-            if (st_info) std::copy(st_info, st_info + (size_t)npg * 8, hinfo.begin());
-            if (st_flags) std::copy(st_flags, st_flags + 2 * envs.size(), h_flags.begin());
-            if (st_chol) std::copy(st_chol, st_chol + sj.size(), h_cholfail.begin());
+            read_results(); take_flags();
             if (chol_failures()) redo_with_eigen();
             if (qr2) {
                 // ---- second factorisation pass (CholeskyQR2) of the sites gate_theta flagged as ill-conditioned: a Gram matrix resolves the
@@ -774,17 +783,17 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                         for (size_t t = 0; t < own_k.size(); ++t) {
                             const size_t k = own_k[t], i = rs[k]; const int nn = gj[t].KK * gj[t].KK;
                             void* dst;
-                            if (sharded) dst = reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride + slot[i];
+                            if (cross[i]) dst = reinterpret_cast<char*>(s->exch) + (size_t)s->rank * stride + slot[i];
                             else { G2[k] = dalloc(s, (size_t)nn * 16); dst = G2[k]->p; }
                             rd.push_back(ReduceItem{gj[t].partial->p, dst, nn, gj[t].nchunks, 1, elems}); elems += nn;
                         }
                         const ReduceItem* d2 = upload(s, rd); ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_reduce<double, double>(s->stream, d2, (int)rd.size(), elems);
                     }
-                    if (sharded) {
+                    if (sharded && stride) {
                         exchange(s, stride);
                         Buf G2_keep = dalloc(s, std::max<size_t>(256, stride * (size_t)s->nranks));
                         HIPCHK(hipMemcpyAsync(G2_keep->p, s->exch, stride * (size_t)s->nranks, hipMemcpyDeviceToDevice, s->stream));
-                        for (size_t k = 0; k < m; ++k) { const size_t i = rs[k]; const size_t nn = (size_t)nof(i) * nof(i); G2[k] = sub_buffer(G2_keep, (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16); }
+                        for (size_t k = 0; k < m; ++k) { const size_t i = rs[k]; if (!cross[i]) continue; const size_t nn = (size_t)nof(i) * nof(i); G2[k] = sub_buffer(G2_keep, (size_t)s->owner[sj[i].v] * stride + slot[i], nn * 16); }
                     }
                     if (m) {
                         std::vector<EnvItem> idn; std::vector<JacobiItem> ji; size_t lds = 0;
@@ -823,7 +832,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             if (h_flags[2 * i + 1]) throw Err(TNQS_ERR_NUMERIC, "simple_update: incoming message has a negative eigenvalue above sqrt_cutoff (DomainError in the reference, src/utils.jl:21)");
         for (int q = 0; q < npg; ++q) {
             int Mr, Nc, ncolJ; theta_dims(hinfo.data() + 8 * q, gitems[q].d1, gitems[q].d2, Mr, Nc, ncolJ);
-            s->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0; s->stats.n_svd_sweeps += hinfo[8 * q + 4];
+            s->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0; s->stats.n_svd_sweeps += hinfo[8 * q + 4]; s->stats.n_svd_sweeps_max = std::max(s->stats.n_svd_sweeps_max, hinfo[8 * q + 4]);
             {   // qualified for the low-rank route by its ranks, but gate_theta's offer was withdrawn on the device (lowrank_m: a refused pivot)
                 const int K = gitems[q].kappa * gitems[q].chi, r1d = hinfo[8 * q] * gitems[q].d1, r2d = hinfo[8 * q + 1] * gitems[q].d2;
                 if (gitems[q].lowG && ncolJ == Nc && r1d >= r2d && K < r2d && gitems[q].chi_cap <= K) s->stats.n_lowrank_fallbacks += 1;
@@ -835,9 +844,12 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     std::vector<const double*> Sptr(ng, nullptr);
     Buf S_keep;
     if (sharded) {
-        const size_t slot_bytes = round256(32 + (size_t)cap_max * 8 + x2_max);
+        // every rank needs (chi', status, truncerr, S) of every gate (bond dimensions and messages are replicated); X2 only travels for a gate that straddles two ranks
         std::vector<size_t> slot(ng, 0); std::vector<size_t> rank_bytes(s->nranks, 0);
-        for (int gi = 0; gi < ng; ++gi) { int r = s->owner[gates[gi].v1]; slot[gi] = rank_bytes[r]; rank_bytes[r] += slot_bytes; }
+        for (int gi = 0; gi < ng; ++gi) {
+            int r = s->owner[gates[gi].v1]; slot[gi] = rank_bytes[r];
+            rank_bytes[r] += round256(32 + (size_t)cap_max * 8 + (s->owner[gates[gi].v1] != s->owner[gates[gi].v2] ? x2_max : 0));
+        }
         size_t stride = 0; for (size_t b : rank_bytes) stride = std::max(stride, b);
         check_exchange(s, stride);
         char* base = reinterpret_cast<char*>(s->exch);
@@ -847,8 +859,9 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             for (int gi = 0; gi < ng; ++gi) {
                 if (s->owner[gates[gi].v1] != s->rank) continue;
                 const SiteJob& b = sj[2 * gi + 1]; const int q = qof[gi];
+                const bool straddles = s->owner[gates[gi].v1] != s->owner[gates[gi].v2];
                 rp.push_back(RecordPackItem{base + (size_t)s->rank * stride + slot[gi], gitems[q].info, gitems[q].truncerr, reinterpret_cast<const double*>(ws[gi].S->p),
-                                            ws[gi].cap, ws[gi].X2->p, (long long)((size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz / 8), (long long)(32 + (size_t)cap_max * 8)});
+                                            ws[gi].cap, ws[gi].X2->p, straddles ? (long long)((size_t)ws[gi].n2 * b.sd.d * ws[gi].cap * esz / 8) : 0LL, (long long)(32 + (size_t)cap_max * 8)});
             }
             if (!rp.empty()) { const RecordPackItem* d = upload(s, rp); launch_record_pack(s->stream, d, (int)rp.size()); }
         }

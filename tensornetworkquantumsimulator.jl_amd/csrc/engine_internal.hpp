@@ -41,6 +41,7 @@ TNQS_SWITCH(use_prodcache, !envflag("TNQS_NO_PRODCACHE"))        // BP: no parti
 TNQS_SWITCH(use_chol, !envflag("TNQS_NO_CHOL"))                  // R factor from the eigen factorisation of the Gram matrix instead of Cholesky
 TNQS_SWITCH(use_qr2, !envflag("TNQS_NO_QR2"))                    // ComplexF64: no second factorisation pass; TNQS_QR2_ALL=1: on every site
 TNQS_SWITCH(use_lowrank, !envflag("TNQS_NO_LOWRANK"))            // theta SVD on the full theta instead of the low-rank factor
+TNQS_SWITCH(use_precond_svd, !envflag("TNQS_NO_PRECOND_SVD"))    // low-rank theta SVD: Gram + Cholesky + Jacobi on the triangular factor in one kernel (kernels.hip theta_svd_pre_kernel) instead of the plain Jacobi on the factor
 TNQS_SWITCH(use_small_svd, !envflag("TNQS_NO_SMALLSVD"))         // sites with fewer fibers than columns: Gram + eigen instead of the direct SVD
 TNQS_SWITCH(use_apply64, !envflag("TNQS_NO_APPLY64"))            // chi = 32 gate epilogue on the fiber kernel instead of the plane kernel
 TNQS_SWITCH(eager_scale, envflag("TNQS_EAGER_SCALE"))            // apply 1/||psi|| after every gate instead of deferring it

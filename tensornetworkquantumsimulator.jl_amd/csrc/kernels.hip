@@ -344,6 +344,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restri
     __shared__ int s_rot;
     const JacobiItem it = items[blockIdx.x];
     if (it.only_if && *it.only_if == 0) return;          // conditional item (svd_batch: polishing sweeps only where the preprocessing failed)
+    if (it.pre && theta_pre_takes(it.dyn, it.dm, it.dn)) return;      // taken by theta_svd_pre_kernel
     cx<T>* A = reinterpret_cast<cx<T>*>(it.A);
     cx<T>* V = reinterpret_cast<cx<T>*>(it.V);
     int m_ = it.m, n_ = it.n;
@@ -606,6 +607,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_rot;
     const JacobiItem it = items[blockIdx.x];
+    if (it.pre && theta_pre_takes(it.dyn, it.dm, it.dn)) return;      // taken by theta_svd_pre_kernel
     cx<T>* Ag = reinterpret_cast<cx<T>*>(it.A);
     cx<T>* Vg = reinterpret_cast<cx<T>*>(it.V);
     int m_ = it.m, n_ = it.n;
@@ -670,12 +672,379 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     if (threadIdx.x == 0 && it.sweeps_out) *it.sweeps_out = sweep;
 }
 
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+template <class FA, class FB> __device__ __forceinline__ void ztile_mm(int K, int i, int j, FA fa, FB fb, v4d_t& cr, v4d_t& ci) {
+    const int kq = (threadIdx.x & 63) >> 4;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const cx<double> a = fa(i, k0 + kq), b = fb(k0 + kq, j);
+        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, cr, 0, 0, 0);
+        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b.im, cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.im, ci, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.re, ci, 0, 0, 0);
+    }
+}
+
+// the same tile product for FULL tiles with complex f32 operands in LDS (no guards, loads hoisted by unrolling): this lane supplies A[row l15][k] = ap[k * as]
+// (conjugated when CA) and B[k][column l15] = bp[k * bs]; K a multiple of 4
+template <bool CA> __device__ __forceinline__ void tile_mm_f32(const cx<float>* ap, int as, const cx<float>* bp, int bs, int K, v4d_t& cr, v4d_t& ci) {
+    const int kq = (threadIdx.x & 63) >> 4;
+    ap += kq * as; bp += kq * bs;
+#pragma unroll 4
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const cx<float> a = ap[k0 * as], b = bp[k0 * bs];
+        const double ar = a.re, ai = CA ? -(double)a.im : (double)a.im, br = b.re, bi = b.im;
+        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cr, 0, 0, 0);
+        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, ci, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
+    }
+}
+// Sweeps of the preconditioned route on the n x n triangular factor (n <= 64 rows): an EIGHTH of a wave (8 lanes, up to 8 rows per lane) owns one column
+// pair, so the 32 pairs of a 64-column round fit FOUR waves -- one per SIMD.  A round of the quarter-wave layout above costs ~150 instructions per wave whatever
+// the row count (index arithmetic, four reductions, the rotation parameters), and with two waves per SIMD the round is bound by instruction issue; halving the
+// waves per SIMD halves that.  The 8-lane sums are three DPP steps (xor 1, xor 2 inside a quad, then the mirrored half row).  Waves beyond the fourth only
+// take part in the barriers.  Same cyclic order, threshold and `tiny` rule as jacobi_lds_sweeps.
+__device__ __forceinline__ float half8_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));     // row_half_mirror
+    return v;
+}
+template <bool FULL>          // FULL: n == 64 (every lane owns 8 real rows, every eighth-wave of the first four waves a real pair)
+__device__ __forceinline__ int jacobi_x8_sweeps(cx<float>* A, int n, int mp, int max_sweeps, float tiny, int* s_rot) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int grp = lane >> 3, l8 = lane & 7;
+    const int ne = n + (n & 1);
+    const int nwork = nw < 4 ? nw : 4;                 // waves that rotate
+    const int nslots = 8 * nwork;
+    const float tol = eps_of<float>() * 2.0f;
+    v2f_t* Av = reinterpret_cast<v2f_t*>(A);
+    int sweep = 0;
+    for (; sweep < max_sweeps && n > 1; ++sweep) {
+        if (threadIdx.x == 0) *s_rot = 0;
+        __syncthreads();
+        for (int round = 0; round < ne - 1; ++round) {
+            if (w < nwork)
+            for (int base = 8 * w; base < ne / 2; base += nslots) {
+                const int pi = base + grp;
+                int p = 0, q = 0; bool act = FULL || pi < ne / 2;
+                if (act) {
+                    if (pi == 0) { p = ne - 1; q = round; }
+                    else { p = round + pi; if (p >= ne - 1) p -= ne - 1; q = round - pi; if (q < 0) q += ne - 1; }
+                    if (p > q) { int t = p; p = q; q = t; }
+                    if (!FULL) act = q < n;
+                }
+                v2f_t* cp = Av + l8 + mp * p; v2f_t* cq = Av + l8 + mp * q;
+                v2f_t ap[8], aq[8];
+                v2f_t sa = {0.f, 0.f}, sb = {0.f, 0.f}, g1 = {0.f, 0.f}, g2v = {0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const bool ok = FULL || (act && l8 + 8 * r < n);
+                    ap[r] = ok ? cp[8 * r] : v2f_t{0.f, 0.f}; aq[r] = ok ? cq[8 * r] : v2f_t{0.f, 0.f};
+                    sa += ap[r] * ap[r]; sb += aq[r] * aq[r];
+                    g1 += ap[r] * aq[r];
+                    g2v += ap[r] * __builtin_shufflevector(aq[r], aq[r], 1, 0);
+                }
+                const float alpha = half8_sum(sa.x + sa.y), beta = half8_sum(sb.x + sb.y), gre = half8_sum(g1.x + g1.y), gim = half8_sum(g2v.x - g2v.y);
+                const float g2 = gre * gre + gim * gim;
+                const bool rot = act && g2 > 1e-36f && g2 > tol * tol * alpha * beta && !(alpha < tiny && beta < tiny);
+                if (rot) {
+                    // two levels of transcendental operations: 1/|g| and 1/r = 1/sqrt(tau^2 + |g|^2) together, then c = sqrt(x) and 1/c = rsqrt(x), x = (1 + |tau|/r)/2;
+                    // s = |g| / (2 r c) with the sign of tau  (the same rotation as t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), c = 1/sqrt(1 + t^2), s = c t)
+                    // (the hardware reciprocal square root is good to 1 ulp but biased: hundreds of rotations whose c^2 + s^2 and |phase| sit a few 1e-8 on
+                    //  the same side of 1 shifted every singular value by 3e-6 relative; one Newton step each makes them unbiased to rounding)
+                    auto rsq = [](float v) { const float y = fast_rsqrt<float>(v); return y * fmaf(-0.5f * v * y, y, 1.5f); };
+                    const float iga = rsq(g2);
+                    const float tau = 0.5f * (beta - alpha);
+                    const float ir = rsq(fmaf(tau, tau, g2));
+                    const float x = 0.5f + 0.5f * fabsf(tau) * ir;
+                    const float ic = rsq(x), c = x * ic;
+                    const float sn = (tau >= 0 ? 0.5f : -0.5f) * (g2 * iga) * ir * ic;
+                    const float pre = gre * iga, pim = -gim * iga;
+                    const v2f_t e1 = {pre, pim}, e2 = {-pim, pre}, cc = {c, c}, ss = {sn, sn};
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        if (FULL || l8 + 8 * r < n) {
+                            const v2f_t qv = __builtin_shufflevector(aq[r], aq[r], 0, 0) * e1 + __builtin_shufflevector(aq[r], aq[r], 1, 1) * e2;
+                            cp[8 * r] = cc * ap[r] - ss * qv;
+                            cq[8 * r] = ss * ap[r] + cc * qv;
+                        }
+                    }
+                    if (l8 == 0) *s_rot = 1;
+                }
+            }
+            __syncthreads();
+        }
+        const int rotd = *s_rot;
+        __syncthreads();
+        if (!rotd) { ++sweep; break; }
+    }
+    return sweep;
+}
+// ------------------------------------------------------------------------------------------------------------
+// Preconditioned theta SVD (round 5): ComplexF32, V not wanted, tall or square A (m >= n), n <= 64, m <= 128 -- the 128 x 64 low-rank factor
+// of a chi = 32 gate and every smaller theta.  ONE workgroup per gate, everything in LDS:
+//   1. A -> LDS, columns sorted by decreasing norm (de Rijk), scaled to ||A||_F = O(1) by a power of two;
+//   2. G = A^dagger A in f64 (f32 products are exact in f64: G is the exact Gram matrix of the rounded A);
+//   3. G = L L^dagger, right-looking Cholesky with one barrier per column (a collapsed pivot -- A rank deficient, the normal case early in
+//      an evolution -- is replaced by 1e-13 of the largest one: directions below 3e-7 sigma_max are f32 noise of A anyway);
+//   4. one-sided Jacobi on the COLUMNS OF L (n x n, f32): L J = U_L Sigma.  L = R^dagger of the QR factorisation of A: orthogonalising the rows
+//      of R instead of the columns of A is the Drmac-Veselic preconditioning -- the sorted triangular factor is graded, L^dagger L is much
+//      closer to diagonal than A^dagger A: 4-5 sweeps instead of 8 on the thetas of the benchmark (scratch numpy model: oracle thetas of a 4 x 4
+//      chi = 32 lattice, 7-9 -> 3-5; evolved chi = 16 states, 7-8 -> 5-7), and each sweep rotates n rows instead of m;
+//   5. A^dagger A = L L^dagger = U_L Sigma^2 U_L^dagger: the normalised columns of L J ARE the right singular vectors of A, so
+//      U Sigma = A U_L -- an (m x n)(n x n) product accumulated in f64 -- goes back to global memory where the rotated A used to go.
+// No inverse of R, no accumulated rotations.  What the kernel replaces took 0.46-0.81 ms per colour batch (8.1 sweeps x 63 rounds on 128 rows).
+// ------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void theta_svd_pre_kernel(const JacobiItem* __restrict__ items, int max_sweeps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_rot;
+    __shared__ double s_red[17];
+    __shared__ double s_cn[64]; __shared__ double s_piv[64]; __shared__ unsigned char s_pos[64]; __shared__ unsigned char s_perm[64];
+    __shared__ double s_dmax; __shared__ double s_sig[64];
+    // it.V is never an output here (V is not accumulated); the kernel tests pass a buffer of 8 x 64-bit slots that receives the constant-rate clock at the
+    // phase boundaries (engine: null)
+#define PRE_STAMP(k) do { if (tstamp && threadIdx.x == 0) tstamp[k] = wall_clock64(); } while (0)
+    const JacobiItem it = items[blockIdx.x];
+    unsigned long long* tstamp = reinterpret_cast<unsigned long long*>(it.V);
+    cx<float>* Ag = reinterpret_cast<cx<float>*>(it.A);
+    int m_ = it.m, n_ = it.n;
+    if (it.dyn) { int nf; theta_dims(it.dyn, it.dm, it.dn, m_, nf, n_); }
+    const int m = m_, n = n_, tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, nw = NT >> 6;
+    PRE_STAMP(0);
+    // pre != 0 (engine): the item is taken only when the low-rank route survived on the device and its factor fits (theta_pre_takes); the plain Jacobi
+    // kernel launched next to this one makes the complementary decision.  pre == 0 (kernel tests): the dimensions given decide
+    if (it.pre ? !theta_pre_takes(it.dyn, it.dm, it.dn) : (n < 2 || m < n || n > 64 || m > 128)) return;
+    const int mp = m + 2, gp = n + 1, xp = n + 2;
+    cx<float>* Mf = reinterpret_cast<cx<float>*>(smem);                                   // sorted A, column a at mp * a
+    const size_t m_bytes = (((size_t)mp * n * sizeof(cx<float>)) + 15) & ~(size_t)15;
+    cx<double>* Gd = reinterpret_cast<cx<double>*>(smem + m_bytes);                      // G / L (lower triangle), element (i, j) at i + gp * j
+    cx<float>* X = reinterpret_cast<cx<float>*>(smem + m_bytes);                         // later: L in f32, column k at xp * k (over the start of Gd)
+    // ---- 1. column norms (first pass over A: 64 KiB, L2 resident afterwards), de Rijk order, SORTED load (column a of the LDS copy = column s_perm[a] of A);
+    // the power-of-two scaling is applied to G (exactly) instead of to the entries ------------------------------------------------------------------
+    for (int j = w; j < n; j += nw) {
+        double s2 = 0;
+        for (int i = lane; i < m; i += 64) { const cx<float> v = Ag[i + (size_t)m * j]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
+        s2 = wave_sum(s2);
+        if (lane == 0) s_cn[j] = s2 == s2 ? s2 : 0.0;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += NT) {
+        int rk = 0; const double cj = s_cn[j];
+        for (int v = 0; v < n; ++v) rk += (s_cn[v] > cj) || (s_cn[v] == cj && v < j);
+        s_pos[j] = (unsigned char)rk; s_perm[rk] = (unsigned char)j;
+    }
+    double fro = 0; for (int j = tid; j < n; j += NT) fro += s_cn[j];
+    fro = block_sum(fro, s_red);                                                         // (also orders s_pos before the load below)
+    int kexp = 0;
+    if (fro > 0 && fro < 1e300) { kexp = -(ilogb(fro) / 2); kexp = kexp > 120 ? 120 : (kexp < -120 ? -120 : kexp); }
+    const double sc2 = ldexp(1.0, 2 * kexp), sc_out = ldexp(1.0, -kexp);                 // G is formed at ||A||_F = O(1): L, the sweeps and s_sig live at that scale
+    fro = ldexp(fro, 2 * kexp);
+    for (int e = tid; e < m * n; e += NT) Mf[(e % m) + mp * (int)s_pos[e / m]] = Ag[e];
+    __syncthreads();
+    PRE_STAMP(1);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const bool full16 = !(m & 15) && !(n & 15);          // every 16 x 16 tile is full: the unguarded tile products
+    // ---- 2. G = A^dagger A (sorted order), lower triangle, f64 matrix cores: one wave per 16 x 16 tile, operands converted from the f32 columns in LDS ------
+    {
+        const int nt = (n + 15) >> 4, ntile = nt * (nt + 1) / 2;
+        for (int t = w; t < ntile; t += nw) {
+            int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while (ti * (ti + 1) / 2 > t) --ti;
+            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+            const int tj = t - ti * (ti + 1) / 2;                                       // ti >= tj
+            const int ia = 16 * ti + l15, ja = 16 * tj + l15;
+            const cx<float>* ci_ = Mf + mp * (ia < n ? ia : 0); const cx<float>* cj_ = Mf + mp * (ja < n ? ja : 0);
+            v4d_t cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+            if (full16) tile_mm_f32<true>(ci_, 1, cj_, 1, m, cr, ci);                    // G[i][j] = sum_r conj(A[r][i]) A[r][j]
+            else ztile_mm(m, ia, ja,
+                     [&](int i, int r) { cx<double> v = cmake<double>(0, 0); if (i < n && r < m) { const cx<float> a = ci_[r]; v = cmake<double>(a.re, -a.im); } return v; },
+                     [&](int r, int j) { cx<double> v = cmake<double>(0, 0); if (j < n && r < m) { const cx<float> a = cj_[r]; v = cmake<double>(a.re, a.im); } return v; }, cr, ci);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + kq + 4 * r, j = 16 * tj + l15;
+                if (i < n && j < n && i >= j) Gd[i + gp * j] = cmake<double>(cr[r] * sc2, i == j ? 0.0 : ci[r] * sc2);
+            }
+        }
+    }
+    __syncthreads();
+    PRE_STAMP(2);
+    // ---- 3. Cholesky, right-looking from the unscaled column, one barrier per column (see chol_kernel) -------------------------------------
+    if (tid < 64) {
+        double mx = 0; for (int i = tid; i < n; i += 64) mx = fmax(mx, Gd[i + gp * i].re);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+        if (tid == 0) s_dmax = mx;
+    }
+    __syncthreads();
+    const double ptiny = 1e-13 * s_dmax;
+    auto pivot_of = [&](int k) { const double d = Gd[k + gp * k].re; return (d > ptiny) ? d : (ptiny > 0 ? ptiny : 1.0); };
+    {
+        constexpr int UT = (64 * 63 / 2 + NT - 1) / NT;           // trailing-triangle elements a thread owns at most (nested triangular numbering)
+        unsigned char tr[UT], tc[UT];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const int e = tid + NT * u;
+            int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while (r * (r + 1) / 2 > e) --r;
+            while ((r + 1) * (r + 2) / 2 <= e) ++r;
+            tr[u] = (unsigned char)r; tc[u] = (unsigned char)(e - r * (r + 1) / 2);
+        }
+        for (int k = 0; k < n - 1; ++k) {
+            // a collapsed pivot (A rank deficient: the Schur complement left is rounding noise) ends the column: no trailing update from it, its entries below
+            // the diagonal are dropped in step 4.  (Continuing with the clamped pivot divides noise by 1e-13: measured on a rank-20 factor, the entries of the
+            // 44 noise columns grew to 1e22.)  Every thread reads the same diagonal entry, so the decision is uniform and the barrier count stays the same.
+            if (!(Gd[k + gp * k].re > ptiny)) { __syncthreads(); continue; }
+            const double dinv = 1.0 / pivot_of(k);
+            const int mm = n - k - 1, k1 = k + 1, nt = mm * (mm + 1) / 2;
+            const cx<double>* colk = Gd + gp * k;
+            cx<double> li[UT], lj[UT], v[UT];
+#pragma unroll
+            for (int u = 0; u < UT; ++u) if (tid + NT * u < nt) { const int i = k1 + tr[u], j = k1 + tc[u]; li[u] = colk[i]; lj[u] = colk[j]; v[u] = Gd[i + gp * j]; }
+#pragma unroll
+            for (int u = 0; u < UT; ++u) if (tid + NT * u < nt) {
+                const double sr = li[u].re * dinv, si = li[u].im * dinv;
+                v[u].re -= sr * lj[u].re + si * lj[u].im; v[u].im -= si * lj[u].re - sr * lj[u].im;
+                Gd[(k1 + tr[u]) + gp * (k1 + tc[u])] = v[u];
+            }
+            __syncthreads();
+        }
+    }
+    for (int k = tid; k < n; k += NT) s_piv[k] = 1.0 / sqrt(pivot_of(k));
+    __syncthreads();
+    // ---- 4. X = L in f32 (over the start of the f64 array: everything is read before anything is written) --------------------------------
+    {
+        constexpr int UX = (64 * 64 + NT - 1) / NT;
+        cx<float> xv[UX];
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+            const int e = tid + NT * u; const int i = e % n, k = e / n;
+            xv[u] = cmake<float>(0.f, 0.f);
+            if (e < n * n && i >= k) {
+                const cx<double> a = Gd[i + gp * k]; const double r = s_piv[k];
+                const bool dead = !(Gd[k + gp * k].re > ptiny);                      // collapsed pivot: the column is (0, ..., sqrt(ptiny), 0, ..., 0)
+                xv[u] = (i == k) ? cmake<float>((float)(pivot_of(k) * r), 0.f) : (dead ? cmake<float>(0.f, 0.f) : cmake<float>((float)(a.re * r), (float)(a.im * r)));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UX; ++u) { const int e = tid + NT * u; if (e < n * n) X[(e % n) + xp * (e / n)] = xv[u]; }
+    }
+    __syncthreads();
+    PRE_STAMP(3);
+    if (it.nhint == -8) {          // (kernel tests only: hand back the triangular factor the sweeps would start from -- f32, n x n, column-major, sorted order -- and stop)
+        cx<float>* out = reinterpret_cast<cx<float>*>(it.Vout);
+        for (int e = tid; e < n * n; e += NT) out[e] = X[(e % n) + xp * (e / n)];
+        return;
+    }
+    // ---- 5. sweeps on the columns of L (n rows) ---------------------------------------------------------------------------------------
+    const float tiny = (float)((double)n * (double)eps_of<float>() * (double)eps_of<float>() * fro);
+    int sweep;
+    if (it.nhint == -7) {          // (kernel tests only: the quarter-wave sweeps of jacobi_lds_kernel on the same factor)
+        if (n == 64) sweep = jacobi_lds_sweeps_f32_full<4>(X, n, n, xp, max_sweeps, tiny, &s_rot);
+        else sweep = jacobi_lds_sweeps<float, 4, false>(X, (cx<float>*)nullptr, false, n, n, xp, 0, max_sweeps, tiny, &s_rot);
+    }
+    else if (n == 64) sweep = jacobi_x8_sweeps<true>(X, n, xp, max_sweeps, tiny, &s_rot);
+    else sweep = jacobi_x8_sweeps<false>(X, n, xp, max_sweeps, tiny, &s_rot);
+    __syncthreads();
+    PRE_STAMP(4);
+    // ---- 6. U_L = normalised columns; U Sigma = A U_L in f64, written over A ------------------------------------------------------------
+    for (int j = w; j < n; j += nw) {
+        double s2 = 0;
+        for (int i = lane; i < n; i += 64) { const cx<float> v = X[i + xp * j]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
+        s2 = wave_sum(s2);
+        if (lane == 0) { s_cn[j] = s2 > 0 ? 1.0 / sqrt(s2) : 0.0; s_sig[j] = sqrt(s2); }      // sigma_j of the sweeps: relative accuracy (what the truncation is decided on)
+    }
+    __syncthreads();
+    {
+        // U Sigma = A U_L on the f64 matrix cores, computed TRANSPOSED (tile rows = column j of the result, lanes = row i: stores run along i).  A wave keeps its
+        // (at most four) tiles in registers until the column norms are complete: the columns leave with the norm the sweeps found for them (s_sig) -- A u_j
+        // carries an error of eps sigma_max in norm and direction like any product in working precision, the singular VALUE does not have to
+        double* s_on = s_piv;                                        // column norms^2 of A X_final
+        for (int j = tid; j < n; j += NT) s_on[j] = 0.0;
+        __syncthreads();
+        const int tr = (n + 15) >> 4, tc = (m + 15) >> 4;            // tr * tc <= 4 * 8 = 32 tiles, at most four per wave
+        v4d_t acr[4], aci[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = w + nw * q;
+            acr[q] = v4d_t{0, 0, 0, 0}; aci[q] = v4d_t{0, 0, 0, 0};
+            if (t < tr * tc) {
+                const int j0 = 16 * (t % tr), i0 = 16 * (t / tr);
+                if (full16) tile_mm_f32<false>(X + xp * (j0 + l15), 1, Mf + (i0 + l15), mp, n, acr[q], aci[q]);      // out[i][j] = sum_k A[i][k] X[k][j] (sorted columns)
+                else ztile_mm(n, j0 + l15, i0 + l15,
+                         [&](int j, int k) { cx<double> v = cmake<double>(0, 0); if (j < n && k < n) { const cx<float> a = X[k + xp * j]; v = cmake<double>(a.re, a.im); } return v; },
+                         [&](int k, int i) { cx<double> v = cmake<double>(0, 0); if (i < m && k < n) { const cx<float> a = Mf[i + mp * k]; v = cmake<double>(a.re, a.im); } return v; },
+                         acr[q], aci[q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double p2 = acr[q][r] * acr[q][r] + aci[q][r] * aci[q][r];            // row j = j0 + kq + 4 r of the tile, column i = i0 + l15
+                    if (i0 + l15 >= m) p2 = 0;
+                    p2 = row16_sum(p2);
+                    if (l15 == 0 && j0 + kq + 4 * r < n) atomicAdd(&s_on[j0 + kq + 4 * r], p2);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = w + nw * q;
+            if (t < tr * tc) {
+                const int j0 = 16 * (t % tr), i0 = 16 * (t / tr);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + kq + 4 * r, i = i0 + l15;
+                    if (j < n && i < m) {
+                        const double f = s_on[j] > 0 ? s_sig[j] / sqrt(s_on[j]) * sc_out : 0.0;
+                        Ag[i + (size_t)m * j] = cmake<float>((float)(acr[q][r] * f), (float)(aci[q][r] * f));
+                    }
+                }
+            }
+        }
+    }
+    PRE_STAMP(5);
+    // ---- 7. right singular vectors of theta = A Q^T:  V = conj(Q) U_L  (Q = B L^-dagger, (r2 d2) x n, f64; written by lowrank_m_kernel).  U_L is orthonormal
+    // to f32 rounding whatever the spectrum, so V needs no division by Sigma^2 -- the recovery from the unrotated theta this replaces amplified the error of a
+    // column of U Sigma by (sigma_max / sigma_j)^2 and therefore needed U Sigma orthogonal relative to each column's own norm ------------------------------
+    if (it.QB && it.Vout && it.dyn) {
+        int mq, nq, kq_; theta_dims(it.dyn, it.dm, it.dn, mq, nq, kq_);      // nq = r2 d2: rows of Q and of V
+        (void)mq; (void)kq_;
+        const cx<double>* Q = reinterpret_cast<const cx<double>*>(it.QB);
+        cx<float>* Vg = reinterpret_cast<cx<float>*>(it.Vout);
+        const int tr = (n + 15) >> 4, tc = (nq + 15) >> 4;
+        for (int t = w; t < tr * tc; t += nw) {
+            const int j0 = 16 * (t % tr), i0 = 16 * (t / tr);
+            v4d_t cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+            ztile_mm(n, j0 + l15, i0 + l15,                                              // V[i][j] = sum_k conj(Q[i][perm k]) X[k][j] / |x_j|
+                     [&](int j, int k) { cx<double> v = cmake<double>(0, 0); if (j < n && k < n) { const cx<float> a = X[k + xp * j]; v = cmake<double>(a.re, a.im); } return v; },
+                     [&](int k, int i) { cx<double> v = cmake<double>(0, 0); if (i < nq && k < n) { v = Q[i + (size_t)nq * (int)s_perm[k]]; v.im = -v.im; } return v; }, cr, ci);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + kq + 4 * r, i = i0 + l15;
+                if (j < n && i < nq) { const double f = s_cn[j]; Vg[i + (size_t)nq * j] = cmake<float>((float)(cr[r] * f), (float)(ci[r] * f)); }
+            }
+        }
+    }
+    PRE_STAMP(6);
+#undef PRE_STAMP
+    if (tid == 0 && it.sweeps_out) *it.sweeps_out = sweep;
+}
+void launch_theta_svd_pre(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, int mmax, int nmax) {
+    if (nitems <= 0) return;
+    const size_t lds = theta_svd_pre_lds_bytes(mmax, nmax);
+    set_max_dynamic_lds((const void*)theta_svd_pre_kernel<512>, (size_t)(160 * 1024 - 4096));
+    hipLaunchKernelGGL((theta_svd_pre_kernel<512>), dim3(nitems), dim3(512), lds, s, d_items, max_sweeps); TNQS_CHECK_LAUNCH();
+}
+
 // V[:,u] = A0^dagger a_u / |a_u|^2   (a_u = column u of U Sigma), for the factorisations run without accumulating V.
 // grid (item, column block of 8): a wave owns one output column u and keeps a_u in registers (lanes = rows, coalesced);
 // every V[col, u] is one coalesced column read of A0 and a wave reduction.
 template <class T, int R>                  // m <= 64 R rows
 __global__ __launch_bounds__(512) void recover_v_kernel(const RecoverItem* __restrict__ items) {
     const RecoverItem it = items[blockIdx.x];
+    if (it.pre && theta_pre_takes(it.dyn, it.dm, it.dn)) return;      // V already written by theta_svd_pre_kernel
     const cx<T>* A0 = reinterpret_cast<const cx<T>*>(it.A0);
     const cx<T>* A = reinterpret_cast<const cx<T>*>(it.A);
     cx<T>* V = reinterpret_cast<cx<T>*>(it.V);
@@ -1259,17 +1628,6 @@ __global__ __launch_bounds__(1024) void gate_theta_kernel(const GateItem* __rest
 // Operand layout of the instruction: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], C[row = (lane >> 4) + 4 r][col = lane & 15].
 // fa(i, k) / fb(k, j) return the operand (zero outside the matrix); four real products per complex step (these kernels are latency, not
 // throughput: the gain over the scalar loops is that a tile takes 2 loads per 4 x 256 multiply-adds instead of 2 per multiply-add)
-typedef double v4d_t __attribute__((ext_vector_type(4)));
-template <class FA, class FB> __device__ __forceinline__ void ztile_mm(int K, int i, int j, FA fa, FB fb, v4d_t& cr, v4d_t& ci) {
-    const int kq = (threadIdx.x & 63) >> 4;
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        const cx<double> a = fa(i, k0 + kq), b = fb(k0 + kq, j);
-        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.re, cr, 0, 0, 0);
-        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, b.im, cr, 0, 0, 0);
-        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, b.im, ci, 0, 0, 0);
-        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, b.re, ci, 0, 0, 0);
-    }
-}
 // theta = A B^T from the operator-sum factors gate_theta_kernel wrote (lowA: Mr x K, lowB: Nc x K, complex128), to theta and theta0 in
 // the state's precision; a wide theta is stored as its adjoint.  The tile orientation is chosen so that the lanes run along the
 // contiguous index of the destination.
@@ -1368,6 +1726,26 @@ __global__ __launch_bounds__(1024) void lowrank_m_kernel(const GateItem* __restr
         for (int r = 0; r < 4; ++r) {
             const int j = j0 + kq + 4 * r, i = i0 + l15;
             if (i < Mr && j < K) th[i + (size_t)Mr * j] = cmake<T>((T)cr[r], (T)ci[r]);
+        }
+    }
+    // Q = B L^-dagger = B W (Nc x K, orthonormal columns; W upper triangular): theta = M Q^T, so the right singular vectors of theta are
+    // conj(Q) times those of M -- what theta_svd_pre_kernel builds V from (no recovery from theta0)
+    if (!it.lowQ || !it.lowW) return;
+    const int Nc = it.info[1] * it.d2;
+    const cx<double>* LB = reinterpret_cast<const cx<double>*>(it.lowB);
+    const cx<double>* W = reinterpret_cast<const cx<double>*>(it.lowW);
+    cx<double>* Q = reinterpret_cast<cx<double>*>(it.lowQ);
+    const int qc = (Nc + 15) >> 4;
+    for (int t = w; t < tr * qc; t += nw) {
+        const int j0 = 16 * (t % tr), i0 = 16 * (t / tr);
+        v4d_t cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+        ztile_mm(K, j0 + l15, i0 + l15,                                              // Q[i][j] = sum_{l <= j} B[i, l] W[l, j]   (tile rows = j, lanes = i)
+                 [&](int j, int l) { return (j < K && l < K && l <= j) ? W[l + (size_t)K * j] : cmake<double>(0, 0); },
+                 [&](int l, int i) { return (i < Nc && l < K) ? LB[i + (size_t)Nc * l] : cmake<double>(0, 0); }, cr, ci);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + kq + 4 * r, i = i0 + l15;
+            if (i < Nc && j < K) Q[i + (size_t)Nc * j] = cmake<double>(cr[r], ci[r]);
         }
     }
 }

@@ -50,7 +50,20 @@ struct JacobiItem {       // one-sided Jacobi on A (m x n, col-major, ld = m); V
     const int* dyn; int dm, dn;
     int nhint;            // host only: the column count the item is EXPECTED to have when dyn decides it (0: n)
     const int* only_if;   // global-memory kernel only: skip the item unless *only_if != 0 (null: always run)
+    // Preconditioned route of a low-rank theta (theta_svd_pre_kernel): QB = the orthonormal factor Q of theta = M Q^T ((r2 d2) x K, complex128), Vout = where the
+    // right singular vectors of theta go ((r2 d2) x K, data precision).  pre != 0: the item has ALSO been handed to that kernel, which takes it when the
+    // dimensions found on the device fit (theta_pre_takes); the plain Jacobi kernel and the V recovery then skip it
+    const void* QB; void* Vout; int pre;
 };
+// device-side decision shared by theta_svd_pre_kernel, jacobi_lds_kernel / jacobi_kernel and the V-recovery kernels: the low-rank route survived on the device
+// (info[7] = K > 0) and the factor fits the kernel
+__host__ __device__ inline bool theta_pre_takes(const int* info, int d1, int d2) {
+    if (!info || info[7] <= 0) return false;
+    int Mr = info[0] * d1, Nc = info[1] * d2;
+    if (Mr < Nc) return false;
+    const int K = info[7];
+    return K >= 2 && K <= 64 && Mr >= K && Mr <= 128;
+}
 // dimensions of a gate's theta SVD from its info array (gate_theta_kernel): rows, columns of theta, columns the Jacobi runs on
 __host__ __device__ inline void theta_dims(const int* info, int d1, int d2, int& m, int& nfull, int& ncol) {
     int Mr = info[0] * d1, Nc = info[1] * d2;
@@ -97,6 +110,8 @@ struct GateItem {         // everything the per-gate small-algebra kernels need 
     // theta (or its low-rank factor) and theta0 are scaled by 2^(*texp) so that their largest entry is O(1) (theta_scale_kernel): the f32
     // SVD pipeline squares and multiplies these entries; gate_finish puts the factor back into the singular values
     int* texp;
+    // low-rank route, preconditioned theta SVD (round 5): W = L^-dagger of the Cholesky factor of B^dagger B, and Q = B W (written by lowrank_m_kernel)
+    const void* lowW; void* lowQ;
 };
 template <class T> void launch_theta_scale(hipStream_t s, const GateItem* d_items, int nitems);
 void launch_lowrank_g(hipStream_t s, const GateItem* d_items, int nitems);
@@ -154,10 +169,15 @@ template <class T, class Acc> void launch_gram(hipStream_t s, const GramItem* d_
                                                int TR, int KKmax);
 template <class Acc, class Out> void launch_reduce(hipStream_t s, const ReduceItem* d_items, int nitems, int total_elems);
 template <class T> void launch_msg_finalize(hipStream_t s, const MsgFinalItem* d_items, int nitems);
-struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; int nu; const int* dyn; int dm, dn; };   // dyn: as in JacobiItem   // V (n x nu) = A0^dagger (U Sigma) Sigma^-2; A0: m x n, U Sigma: m x nu
+struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; int nu; const int* dyn; int dm, dn; int pre; /* != 0: skip when theta_pre_takes */ };   // dyn: as in JacobiItem   // V (n x nu) = A0^dagger (U Sigma) Sigma^-2; A0: m x n, U Sigma: m x nu
 // LDS bytes the LDS-resident Jacobi needs for an m x n matrix (columns padded by 2 elements)
 inline size_t jacobi_lds_bytes(int m, int n, bool withV, size_t esz) { return ((size_t)(m + 2) * n + (withV ? (size_t)(n + 2) * n : 0)) * esz; }
 template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax, int ncols = 0);   // ncols: expected columns (sizes the workgroup of the LDS kernel)
+// Preconditioned theta SVD in one kernel (kernels.hip theta_svd_pre_kernel): ComplexF32, no V, m >= n, n <= 64, m <= 128 (upper bounds when JacobiItem::dyn
+// decides the dimensions on the device).  LDS: the sorted A (f32) + the n x n Gram / Cholesky array (f64)
+inline bool theta_svd_pre_covers(int m, int n) { return n >= 2 && n <= 64 && m >= n && m <= 128; }
+inline size_t theta_svd_pre_lds_bytes(int m, int n) { return ((((size_t)(m + 2) * n * 8) + 15) & ~(size_t)15) + (size_t)(n + 1) * n * 16; }
+void launch_theta_svd_pre(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, int mmax, int nmax);
 // sites with fewer fibers than columns (N < n = d*chi): the R factor comes from a one-sided Jacobi SVD of the n x N matrix
 // M[(s,b), outer] = conj(psi~[outer,(s,b)]) (f64) instead of the eigen factorisation of the rank-deficient n x n Gram matrix
 struct SmallSvdItem { const void* src; void* M; void* GA; void* GV; int d, low, chi_b, hi; };   // low = pre(b)/d, hi = post(b); n = d*chi_b, N = low*hi

@@ -17,8 +17,8 @@ def partition_vertices(nv: int, world: int, weights: Optional[Sequence[float]] =
     """contiguous blocks of vertex positions: owner[v] = rank.  Any partition is valid (messages are replicated, every per-vertex
     unit of work belongs to exactly one rank); what a partition decides is the time of the slowest rank.
     weights = None: blocks of equal vertex COUNT.
-    weights given (one per vertex; `site_weights` below: the elements of the site tensor at the evolution's bond dimension, which is what
-    every tensor pass of a BP level or gate batch costs): the contiguous partition that minimises the heaviest block -- on an open 20 x 20
+    weights given (one per vertex; `site_weights` below: the elements of the site tensor at the evolution's bond dimension -- what every tensor
+    pass of a BP level or gate batch costs -- with a floor for the latency-bound share every site pays): the contiguous partition that minimises the heaviest block -- on an open 20 x 20
     lattice at chi = 32 a boundary site costs 1/32 (degree 3) or 1/1024 (corner) of a bulk site, and equal counts would give the end
     ranks 27 and the middle ranks 45 bulk sites at 8 ranks instead of 40 / 41 each.  Ties: the lexicographically smallest cut positions
     among the optimal ones, so every rank computes the same partition from the same inputs."""
@@ -59,9 +59,15 @@ def partition_vertices(nv: int, world: int, weights: Optional[Sequence[float]] =
     return owner
 
 
-def site_weights(graph, chi: int, d: int = 2) -> List[float]:
-    """work of a vertex in a tensor pass: the elements of its site tensor with every bond at dimension chi, d * chi^degree"""
-    return [float(d) * float(chi) ** graph.degree(v) for v in graph.vertices]
+def site_weights(graph, chi: int, d: int = 2, floor: float = 0.3) -> List[float]:
+    """cost model of a vertex, in units of the elements of the largest site tensor (d * chi^max degree): its tensor passes cost its own elements,
+    d * chi^degree; on top of that every site pays the latency-bound part of the path (its share of the per-gate factorisation chain, the small-tensor
+    BP kernels, descriptor traffic), which does not shrink with the tensor -- measured on the sharded 20 x 20 chi = 32 layer (profiles/shard_proxy.py,
+    round 5): a rank with 40 bulk + 25 boundary sites took 26.3 ms against 22.5 ms for 40 bulk + 4 boundary sites, i.e. ~0.18 ms per boundary site next
+    to 0.39 ms per bulk site, although a degree-3 site holds 1/32 of a bulk site's elements.  `floor` is that latency share (0 = elements only)."""
+    zmax = max(graph.degree(v) for v in graph.vertices)
+    bulk = float(d) * float(chi) ** zmax
+    return [max(float(d) * float(chi) ** graph.degree(v) / bulk, float(floor)) for v in graph.vertices]
 
 
 def partition_summary(graph, owner: Sequence[int], chi: int, d: int = 2) -> dict:
@@ -69,11 +75,10 @@ def partition_summary(graph, owner: Sequence[int], chi: int, d: int = 2) -> dict
     world = max(owner) + 1
     zmax = max(graph.degree(v) for v in graph.vertices)
     wts = site_weights(graph, chi, d)
-    bulk_w = float(d) * float(chi) ** zmax
     cnt, bulk, load = [0] * world, [0] * world, [0.0] * world
     for i, v in enumerate(graph.vertices):
         r = owner[i]
-        cnt[r] += 1; bulk[r] += 1 if graph.degree(v) == zmax else 0; load[r] += wts[i] / bulk_w
+        cnt[r] += 1; bulk[r] += 1 if graph.degree(v) == zmax else 0; load[r] += wts[i]
     return {"vertices": cnt, "bulk_sites": bulk, "load_in_bulk_sites": [round(x, 2) for x in load]}
 
 
@@ -101,6 +106,10 @@ class Sharding:
         self.backend = dist.get_backend(group)
         self.n_exchanges = 0
         self.bytes_exchanged = 0
+        # hooks around the host part of a gloo exchange (profiles/shard_proxy.py: ranks that share ONE GPU take turns on it -- a rank gives the device up
+        # while it waits for its peers in the collective and takes it back before the gathered block is copied to the device)
+        self.on_release = None
+        self.on_acquire = None
 
         def _cb(ctx, base, bytes_per_rank, nranks):
             try:
@@ -116,7 +125,11 @@ class Sharding:
                 else:                                   # gloo: stage through the host (tests; ranks may share a GPU)
                     host = mine.cpu()
                     outs = [self.torch.empty_like(host) for _ in range(nranks)]
+                    if self.on_release is not None:
+                        self.on_release()
                     self.dist.all_gather(outs, host, group=self.group)
+                    if self.on_acquire is not None:
+                        self.on_acquire()
                     flat.copy_(self.torch.cat(outs).to(flat.device))
                     self.torch.cuda.synchronize()
                 self.n_exchanges += 1

@@ -115,3 +115,20 @@ def c64_errs_close(errs, oerrs, rel=2e-3, floor=3e-7):
     with a floor at the f32 rounding level of the normalised spectrum"""
     e, f = np.asarray(errs, dtype=float), np.asarray(oerrs, dtype=float)
     return bool(np.all(np.abs(e - f) < rel * np.maximum(np.abs(e), np.abs(f)) + floor))
+
+
+def bond_dims_agree(dims_dev, dims_or, errs_dev, errs_or, gate_of_edge, cutoff):
+    """bond dimensions of a ComplexF32 run against the oracle's.  A relative cutoff of 1e-12 on sigma^2 asks whether a singular value of 1e-6 sigma_max is
+    kept -- f32 arithmetic resolves singular values to ~1e-7 sigma_max (LAPACK's backward error as much as the device's), so two correct implementations
+    disagree on a value that sits AT the cutoff.  Equal everywhere, except that a bond may differ by one where the two truncation errors differ by less than the
+    cutoff itself -- i.e. where the singular value in question carries a weight within rounding of the threshold.  Returns (ok, list of such bonds)."""
+    noise = []
+    for k, (a, b) in enumerate(zip(dims_dev, dims_or)):
+        if a == b:
+            continue
+        g = gate_of_edge[k]
+        if abs(a - b) > 1 or g is None or not abs(float(errs_dev[g]) - float(errs_or[g])) <= cutoff:
+            return False, [k]
+        noise.append(k)
+    return True, noise
+

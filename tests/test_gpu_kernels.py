@@ -1,6 +1,7 @@
 """Kernel-level GPU tests through include/tnqs_debug.h: each HIP kernel against a float64 numpy evaluation of the
 same contraction (transposition-detecting random inputs, odd dimensions, ragged tiles)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -350,3 +351,91 @@ def test_cholesky_kernels(n, cond):
         g2 = np.asfortranarray((q * lam2) @ q.conj().T)
         rc = lib.tnqs_dbg_chol(n, g2.ctypes.data_as(C.c_void_p), L.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p), C.byref(fail), C.c_double(1e-12))
         assert rc == 0 and (fail.value == 1 or cond > 1e9) and np.all(np.isfinite(L))
+
+
+# ---- preconditioned theta SVD kernel (round 5) ----------------------------------------------------------------------------------------
+def theta_svd_pre(a, q, copies=1, reps=0):
+    m, n = a.shape; nq = q.shape[0]
+    A = np.asfortranarray(a.astype(np.complex64)); Q = np.asfortranarray(q.astype(np.complex128))
+    V = np.zeros((nq, n), dtype=np.complex64, order="F")
+    sw = C.c_int(); ms = C.c_double(0.0); ph = (C.c_double * 6)()
+    rc = lib.tnqs_dbg_theta_svd_pre(m, n, nq, A.ctypes.data_as(C.c_void_p), Q.ctypes.data_as(C.c_void_p), V.ctypes.data_as(C.c_void_p), C.byref(sw), copies, reps, C.byref(ms), ph)
+    assert rc == 0, lib.tnqs_last_error()
+    theta_svd_pre.phases_us = [round(x, 1) for x in ph]          # load, Gram, Cholesky + conversion, sweeps, U Sigma, V (workgroup 0)
+    return A, V, sw.value, ms.value
+
+
+def low_rank_factors(r1, r2, gate):
+    """the engine's low-rank route in numpy (f64): operator-sum factors of the gate by elimination with complete pivoting, theta = A B^T, B = Q L^dagger
+    (Cholesky QR), M = A conj(L) -- returns (M, Q, theta)"""
+    d1 = d2 = 2
+    g4 = gate.reshape(d1, d2, d1, d2)
+    O = np.transpose(g4, (0, 2, 1, 3)).reshape(d1 * d1, d2 * d2).astype(np.complex128).copy()
+    fa, fb, amax = [], [], np.abs(O).max()
+    for _ in range(min(O.shape)):
+        i, j = np.unravel_index(np.argmax(np.abs(O)), O.shape)
+        if not np.abs(O[i, j]) > 1e-13 * amax:
+            break
+        col, row = O[:, j].copy(), O[i, :] / O[i, j]
+        O -= np.outer(col, row); fa.append(col.reshape(d1, d1)); fb.append(row.reshape(d2, d2))
+    R1, R2 = r1.astype(np.complex128), r2.astype(np.complex128)
+    A = np.concatenate([np.einsum("xs,rsb->rxb", a, R1).reshape(R1.shape[0] * d1, -1) for a in fa], axis=1)
+    B = np.concatenate([np.einsum("ys,rsb->ryb", b, R2).reshape(R2.shape[0] * d2, -1) for b in fb], axis=1)
+    L = np.linalg.cholesky(B.conj().T @ B)
+    Q = B @ np.linalg.inv(L).conj().T
+    return A @ np.conj(L), Q, A @ B.T
+
+
+def check_theta_svd_pre(M, Q, theta, sv_tol=4e-6):
+    A, V, sw, _ = theta_svd_pre(M, Q)
+    A = A.astype(np.complex128); V = V.astype(np.complex128)
+    M32 = M.astype(np.complex64).astype(np.complex128)
+    s_ref = np.linalg.svd(M32, compute_uv=False)
+    nrm = np.linalg.norm(A, axis=0)
+    assert 0 < sw < 30
+    assert np.max(np.abs(np.sort(nrm)[::-1] - s_ref)) < sv_tol * s_ref[0], (np.sort(nrm)[::-1][:4], s_ref[:4])
+    rec = A @ V.conj().T                                                     # (U Sigma) V^dagger = theta = M Q^T
+    assert np.max(np.abs(rec - M32 @ Q.T)) < 2e-6 * s_ref[0] * np.sqrt(M.shape[1])
+    if theta is not None:
+        assert np.max(np.abs(rec - theta)) < 3e-6 * s_ref[0] * np.sqrt(M.shape[1])
+    big = nrm > 1e-5 * s_ref[0]                                             # V: orthonormal to f32 rounding whatever the singular value (no division by Sigma^2)
+    Vb = V[:, big]
+    assert np.max(np.abs(Vb.conj().T @ Vb - np.eye(Vb.shape[1]))) < 3e-6
+    U = A[:, big] / nrm[big]                                                # U Sigma = M U_L: absolute accuracy eps * sigma_max per column (like LAPACK's)
+    assert np.max(np.abs((U.conj().T @ U - np.eye(U.shape[1])) * np.minimum.outer(nrm[big], nrm[big]))) < 3e-6 * s_ref[0]
+    return sw
+
+
+@pytest.mark.parametrize("shape,rank", [((128, 64, 128), 64), ((128, 64, 128), 20), ((128, 40, 100), 40), ((64, 64, 64), 64), ((100, 33, 80), 33), ((72, 8, 40), 8),
+                                        ((40, 40, 40), 3), ((128, 64, 64), 64), ((6, 2, 4), 2)])
+@pytest.mark.parametrize("scale", [1e-9, 1.0, 1e6])
+def test_theta_svd_pre_kernel(shape, rank, scale):
+    """synthetic factors with spectra spread over 3.5 decades, full rank and rank deficient, badly scaled: singular values against LAPACK, the reconstruction
+    theta = (U Sigma) V^dagger, V orthonormal, U Sigma orthogonal to eps sigma_max"""
+    m, n, nq = shape
+    rng = np.random.default_rng(m + 7 * rank + n)
+    dec = np.exp(-np.arange(rank) * (8.0 / max(rank, 1)))
+    q1, _ = np.linalg.qr(rnd(rng, (m, rank), np.complex128)); q2, _ = np.linalg.qr(rnd(rng, (n, rank), np.complex128))
+    M = (q1 * dec) @ q2.conj().T * scale
+    Q, _ = np.linalg.qr(rnd(rng, (nq, n), np.complex128))
+    check_theta_svd_pre(M, Q, None)
+
+
+def test_theta_svd_pre_kernel_on_harvested_factors():
+    """R factors of two-site gates harvested from oracle runs (tests/golden/make_theta_factors.py: a random chi = 32 state after three TFIM layers, a chi = 16
+    state evolved from the product state): the engine's low-rank factor M and Q built in numpy, then the kernel against LAPACK.  Sweeps: the numpy model of
+    the kernel (scratch notes in DESIGN.md 4.26) needs 3-7 where the plain Jacobi on M needs 7-9"""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "theta_factors.npz"))
+    keys = sorted({k.rsplit("_", 1)[0] for k in z.files})
+    sweeps = {}
+    for k in keys:
+        r1, r2, gate = z[k + "_r1"], z[k + "_r2"], z[k + "_gate"]
+        if r1.shape[0] * 2 < r2.shape[0] * 2:           # theta wider than tall: the engine stores its adjoint and runs no low-rank route
+            continue
+        M, Q, theta = low_rank_factors(r1, r2, gate)
+        if not (M.shape[1] <= 64 and M.shape[0] <= 128):
+            continue
+        sweeps[k] = check_theta_svd_pre(M, Q, theta)
+    print("sweeps of the preconditioned kernel:", sweeps)
+    assert len(sweeps) >= 6 and max(sweeps.values()) <= 8
+

@@ -160,14 +160,23 @@ def test_marshalled_circuit_cache_keys_on_gate_identity_and_registry():
     one of its names changed; lists and explicit matrices are never cached."""
     from tnqs_amd import core
     g = tn.named_grid((2, 2))
-    layer = [("Rx", [v], 0.3) for v in g.vertices] + [("Rzz", [a, b], 0.2) for (a, b) in g.edges]
+    layer = [("Rx", (v,), 0.3) for v in g.vertices] + [("Rzz", (a, b), 0.2) for (a, b) in g.edges]      # vertex TUPLES: nothing of a gate can be edited in place
     a1 = core._marshal_circuit(layer, g); a2 = core._marshal_circuit(layer, g)
     assert a1[5] is a2[5] and a1[0] == len(layer)                                   # same arrays
     a3 = core._marshal_circuit(list(layer), g)                                      # another list of the same tuples: same circuit
     assert a3[5] is a1[5]
-    rebuilt = [("Rx", [v], 0.3) for v in g.vertices] + [("Rzz", [a, b], 0.2) for (a, b) in g.edges]
+    rebuilt = [("Rx", (v,), 0.3) for v in g.vertices] + [("Rzz", (a, b), 0.2) for (a, b) in g.edges]
     a4 = core._marshal_circuit(rebuilt, g)
     assert a4[5] is not a1[5] and np.array_equal(a4[5], a1[5])
+    # a vertex LIST or an array parameter can be mutated behind the identity key (round-4 advisor finding): such circuits are resolved on every call
+    mutable = [("Rx", [v], 0.3) for v in g.vertices] + [("Rzz", [a, b], 0.2) for (a, b) in g.edges]
+    b1 = core._marshal_circuit(mutable, g); b2 = core._marshal_circuit(mutable, g)
+    assert b1[5] is not b2[5] and np.array_equal(b1[5], a1[5]) and np.array_equal(b1[3], a1[3])
+    mutable[-1][1][0], mutable[-1][1][1] = mutable[-1][1][1], mutable[-1][1][0]      # swap the two vertices of the last gate in place
+    b3 = core._marshal_circuit(mutable, g)
+    assert not np.array_equal(b3[3], b1[3])                                          # the edit is seen
+    arr_param = [("Rx", (g.vertices[0],), np.array(0.3))]
+    assert core._marshal_circuit(arr_param, g)[5] is not core._marshal_circuit(arr_param, g)[5]
     assert core._marshal_circuit(layer, tn.named_grid((2, 2)))[5] is not a1[5]       # another graph object
     tn.register_gate("MyG", lambda: np.eye(2))
     try:

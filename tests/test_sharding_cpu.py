@@ -35,8 +35,13 @@ def test_partition_by_work_balances_the_bulk_sites():
         own = tn.partition_vertices(g.nv(), world, w)
         assert len(own) == g.nv() and own == sorted(own) and sorted(set(own)) == list(range(world))
         summ = tn.dist.partition_summary(g, own, 32)
-        assert max(summ["bulk_sites"]) - min(summ["bulk_sites"]) <= 1, summ
-        assert max(summ["load_in_bulk_sites"]) <= 324.0 / world + 1.7, summ
+        total = sum(w)
+        assert max(summ["load_in_bulk_sites"]) <= total / world + 1.0, summ        # optimal to within one site
+        # the end ranks own the top and bottom rows (boundary sites pay the latency floor of the cost model): fewer bulk sites there, never more
+        assert summ["bulk_sites"][0] <= min(summ["bulk_sites"][1:-1] or summ["bulk_sites"]) and summ["bulk_sites"][-1] <= min(summ["bulk_sites"][1:-1] or summ["bulk_sites"])
+        own0 = tn.partition_vertices(g.nv(), world, tn.dist.site_weights(g, 32, floor=0.0))      # elements only: bulk counts within one of each other
+        s0 = tn.dist.partition_summary(g, own0, 32)
+        assert max(s0["bulk_sites"]) - min(s0["bulk_sites"]) <= 1, s0
     assert tn.dist.partition_summary(g, tn.partition_vertices(g.nv(), 8), 32)["bulk_sites"] == [27, 45, 45, 45, 45, 45, 45, 27]
     # optimality against brute force: 9 weights, 3 blocks
     import itertools
