@@ -126,6 +126,10 @@ def main():
     ap.add_argument("--chi", type=int, default=0, help="bond dimension (default: 32 / 16 / 64)")
     ap.add_argument("--host-init", action="store_true", help="c4 / c5: generate the synthetic state with numpy on the host instead of on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bp-order", choices=["library", "reference"], default="library",
+                    help="sweep order of the BP updates: the library default (linear forests, the order the plane kernels share products on) or the reference's "
+                         "default forest_cover_edge_sequence (tnqs_bp_opts.n_sequence = -1).  Same fixed point; at the default tolerance both stop after one "
+                         "sweep per update on different trajectories")
     ap.add_argument("--evolved", type=int, default=0, metavar="N",
                     help="also time the same lattice on a PHYSICALLY evolved state: N layers of the TFIM circuit at dt = 0.1 from the product state "
                          "(bonds saturate at chi), then --steps timed layers of that circuit; reported as the extra object \"evolved\"")
@@ -175,6 +179,9 @@ def main():
                        else "BASELINE.json configs[4]" + ("" if L == 32 else f" at L = {L} instead of 32")))
     n2 = g.ne()
     apply_kwargs = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+    # None = reference-default bp_update_kwargs with the library's sweep order; "reference": the same defaults (maxiter 25, tolerance 1e-5 for ComplexF32) with
+    # the reference's own order
+    bp_kwargs = None if args.bp_order == "library" else dict(maxiter=25, tolerance=1e-5, edge_sequence="forest_cover")
 
     # ---- state: bond dimension 1 handle, then upload the synthetic chi-saturated tensors ---------------------
     free_at_start = torch.cuda.mem_get_info(local if world > 1 else 0)[0]
@@ -221,7 +228,7 @@ def main():
     sweeps, updates, svd_sweeps, svd_max, reused, evicted = [], [], [], [], [], []
     for _ in range(args.warmup):
         info = {}
-        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=apply_kwargs, info=info)
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=apply_kwargs, bp_update_kwargs=bp_kwargs, info=info)
     tn.profile_enable(bpc, os.environ.get("TNQS_BENCH_NOPROF") != "1")      # (experiment: what the per-class HIP events cost)
     tn.profile_reset(bpc)
 
@@ -234,7 +241,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         info = {}
-        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=apply_kwargs, info=info)
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=apply_kwargs, bp_update_kwargs=bp_kwargs, info=info)
         sweeps.append(info["n_sweeps"]); updates.append(info["n_updates"]); svd_sweeps.append(info.get("n_svd_sweeps", 0)); svd_max.append(info.get("n_svd_sweeps_max", 0)); reused.append(info.get("n_bp_products_reused", 0)); evicted.append(info.get("n_bp_products_evicted", 0))
     barrier()
     elapsed = time.perf_counter() - t0
@@ -326,7 +333,9 @@ def main():
                       "bp_partial_products": {"reused_per_step": reused, "evicted_per_step": evicted},
                       "apply_kwargs": {"maxdim": chi, "cutoff": 1e-10, "normalize_tensors": True},
                       "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)",
-                      "bp_order": "library default: linear forests, one level per forest (tnqs_bp_opts.n_sequence = 0; the reference's forest_cover_edge_sequence is n_sequence = -1; same fixed point)",
+                      "bp_order": ("library default: linear forests, one level per forest (tnqs_bp_opts.n_sequence = 0; the reference's forest_cover_edge_sequence is n_sequence = -1, "
+                                   "bench.py --bp-order reference; same fixed point)" if args.bp_order == "library" else
+                                   "the reference's default, forest_cover_edge_sequence(graph) (tnqs_bp_opts.n_sequence = -1)"),
                       "state_init": ("host numpy, per-vertex counter streams" if (cfg == "c2" or args.host_init) else "on device (tnqs_set_site_random, counter-based)"),
                       "memory": mem, "parallelism": f"vertex-shard x{world}",
                       "transport": (None if world == 1 else {"kind": type(bpc._shard).__name__, "nranks": world, "backend": dist.get_backend(),

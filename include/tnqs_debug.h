@@ -12,7 +12,8 @@ int tnqs_dbg_jacobi(int dtype, int m, int n, void* A_inout, void* V_out, int* sw
 /* preconditioned theta SVD kernel (kernels.hip theta_svd_pre_kernel) on one ComplexF32 factor A (m x n, 2 <= n <= 64, n <= nq <= m <= 128) of theta = A Q^T with Q
  * (nq x n complex128, orthonormal columns): on return A = U Sigma (columns, any order), V (nq x n ComplexF32) = right singular vectors of theta in the same column
  * order.  reps > 0: also the average duration (ms, HIP events) of a launch over `copies` device-resident copies */
-int tnqs_dbg_theta_svd_pre(int m, int n, int nq, void* A_inout, const void* Q, void* V_out, int* sweeps_out, int copies, int reps, double* ms_out, double* phase_us_out /* 6 doubles or NULL: load, Gram, Cholesky + conversion, sweeps, U Sigma, V */);
+int tnqs_dbg_theta_svd_pre(int m, int n, int nq, void* A_inout, const void* Q, void* V_out, int* sweeps_out, int copies, int reps, double* ms_out, double* phase_us_out /* 6 doubles or NULL: load, Gram, Cholesky + conversion, sweeps, U Sigma, V */,
+                           int cap /* > 0: only the cap largest singular triplets are formed, the other columns of A leave as sigma_j e_0; Q == NULL: A is theta itself, V (n x n) = its right singular vectors */);
 /* timing of the plain LDS-resident ComplexF32 Jacobi (no V) on `copies` copies of A (m x n): average launch duration and the sweeps it took */
 int tnqs_dbg_time_jacobi_f32(int m, int n, const void* A, int copies, int reps, double* ms_out, int* sweeps_out);
 /* Cholesky of a Hermitian positive definite n x n complex128 matrix (n <= 128): L lower with G = L L^dagger, W = (L^-1)^dagger; *fail = 1 when a

@@ -58,7 +58,7 @@ mutable struct HipBeliefPropagationCache{V} <: TN.AbstractBeliefPropagationCache
     linkinds::Dict{Tuple{Int32, Int32}, Index}   # (min id, max id) -> link Index; re-created when a gate changes the bond dimension
     reference_order::Bool                # no edge_sequence given: sweep in forest_cover_edge_sequence(g) (the reference's default, n_sequence = -1)
                                          # instead of the library's linear-forest order (same fixed point, fewer dependency levels per sweep)
-    function HipBeliefPropagationCache{V}(h, g, vid, s, l, reference_order = false) where {V}
+    function HipBeliefPropagationCache{V}(h, g, vid, s, l, reference_order = true) where {V}
         c = new{V}(h, g, vid, s, l, reference_order)
         finalizer(x -> ccall((:tnqs_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), c)
         return c
@@ -69,7 +69,7 @@ const DTYPE_CODE = Dict(ComplexF32 => 0, ComplexF64 => 1, Float32 => 2, Float64 
 const DTYPE_OF = (ComplexF32, ComplexF64, Float32, Float64)
 
 # ---- construction: BeliefPropagationCache(psi) -> device (beliefpropagationcache.jl:27-31) ----------------------------------------------
-function HipBeliefPropagationCache(ψ::TN.TensorNetworkState; device::Integer = 0, reference_order::Bool = false)
+function HipBeliefPropagationCache(ψ::TN.TensorNetworkState; device::Integer = 0, reference_order::Bool = true)
     g = TN.graph(ψ)
     vs = collect(vertices(g))
     V = eltype(vs)

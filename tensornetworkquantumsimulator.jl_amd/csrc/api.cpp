@@ -187,7 +187,7 @@ namespace tnqs { void dbg_default_sequence(const State* s, std::vector<int>& src
                  void dbg_gauge_gram(int z, const int* chi, int bleg, const void* X, const void* M, void* out);
                  void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps);
                  void dbg_chol(int n, const void* G, void* L, void* W, int* fail, double tau);
-                 void dbg_theta_svd_pre(int m, int n, int nq, void* A, const void* Q, void* V, int* sweeps, int copies, int reps, double* ms, double* phase_us);
+                 void dbg_theta_svd_pre(int m, int n, int nq, void* A, const void* Q, void* V, int* sweeps, int copies, int reps, double* ms, double* phase_us, int cap);
                  void dbg_time_jacobi_f32(int m, int n, const void* A, int copies, int reps, double* ms, int* sweeps);
                  void dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in, const void* Mx, const void* My, void* out);
                  void dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2);
@@ -202,7 +202,7 @@ int tnqs_dbg_default_sequence(tnqs_handle h, int* src, int* dst, int cap, int* n
                        for (int i = 0; i < (int)a.size() && i < cap; ++i) { src[i] = a[i]; dst[i] = b[i]; } });
 }
 int tnqs_dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) { return guard([&] { dbg_jacobi(dtype, m, n, A, V, sweeps); }); }
-int tnqs_dbg_theta_svd_pre(int m, int n, int nq, void* A, const void* Q, void* V, int* sweeps, int copies, int reps, double* ms, double* phase_us) { return guard([&] { dbg_theta_svd_pre(m, n, nq, A, Q, V, sweeps, copies, reps, ms, phase_us); }); }
+int tnqs_dbg_theta_svd_pre(int m, int n, int nq, void* A, const void* Q, void* V, int* sweeps, int copies, int reps, double* ms, double* phase_us, int cap) { return guard([&] { dbg_theta_svd_pre(m, n, nq, A, Q, V, sweeps, copies, reps, ms, phase_us, cap); }); }
 int tnqs_dbg_time_jacobi_f32(int m, int n, const void* A, int copies, int reps, double* ms, int* sweeps) { return guard([&] { dbg_time_jacobi_f32(m, n, A, copies, reps, ms, sweeps); }); }
 int tnqs_dbg_chol(int n, const void* G, void* L, void* W, int* fail, double tau) { return guard([&] { dbg_chol(n, G, L, W, fail, tau); }); }
 int tnqs_dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No, const void* in, const void* X, void* out, double* norm2, int use_mfma) {

@@ -44,19 +44,20 @@ void dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) {
 
 // theta_svd_pre_kernel on one ComplexF32 factor A (m x n) of theta = A Q^T, Q (nq x n, complex128, orthonormal columns): A := U Sigma, V (nq x n) := conj(Q) U_L.
 // reps > 0: additionally time `reps` launches on `copies` device-resident copies of A (one workgroup each) with HIP events -> *ms = average per launch
-void dbg_theta_svd_pre(int m, int n, int nq, void* A, const void* Q, void* V, int* sweeps, int copies, int reps, double* ms, double* phase_us) {
+void dbg_theta_svd_pre(int m, int n, int nq, void* A, const void* Q, void* V, int* sweeps, int copies, int reps, double* ms, double* phase_us, int cap) {
     need_gpu();
+    if (!Q) nq = n;                                 // no Q: theta itself is factorised, V is n x n
     if (!theta_svd_pre_covers(m, n) || nq < n || nq > m) throw Err(TNQS_ERR_INVALID, "dbg_theta_svd_pre: 2 <= n <= 64, n <= nq <= m <= 128");
     if (copies < 1) copies = 1;
     const size_t ab = (size_t)m * n * 8, vb = (size_t)nq * n * 8;
     DBuf dA(ab * copies), dA0(ab), dQ((size_t)nq * n * 16), dV(vb * copies), dS(4 * (size_t)copies), dInfo(32), dI(sizeof(JacobiItem) * (size_t)copies), dT(64);
-    dA0.up(A, ab); dQ.up(Q, (size_t)nq * n * 16);
-    const int info[8] = {m, nq, 0, 0, 0, 0, 0, n};      // theta_dims with d1 = d2 = 1: m rows, nq columns of theta, n columns of the factor
+    dA0.up(A, ab); if (Q) dQ.up(Q, (size_t)nq * n * 16);
+    const int info[8] = {m, nq, 0, 0, 0, 0, 0, Q ? n : 0};      // theta_dims with d1 = d2 = 1: m rows, nq columns of theta, n columns of the factor (0: theta itself)
     dInfo.up(info, 32);
     std::vector<JacobiItem> its(copies);
     for (int c = 0; c < copies; ++c) {
-        JacobiItem it{}; it.A = (char*)dA.p + ab * c; it.V = (c == 0 && phase_us) ? dT.p : nullptr; it.m = m; it.n = nq; it.sweeps_out = (int*)dS.p + c; it.dyn = (const int*)dInfo.p; it.dm = 1; it.dn = 1; it.nhint = (std::getenv("TNQS_DBG_PRE_QUARTER") ? -7 : (std::getenv("TNQS_DBG_PRE_DUMP_L") ? -8 : n));
-        it.QB = dQ.p; it.Vout = (char*)dV.p + vb * c; it.pre = 1; its[c] = it;
+        JacobiItem it{}; it.A = (char*)dA.p + ab * c; it.V = (c == 0 && phase_us) ? dT.p : nullptr; it.m = m; it.n = nq; it.sweeps_out = (int*)dS.p + c; it.dyn = (const int*)dInfo.p; it.dm = 1; it.dn = 1; it.nhint = n;
+        it.QB = Q ? dQ.p : nullptr; it.Vout = (char*)dV.p + vb * c; it.pre = 0 /* the dimensions given decide, whatever the size */; it.cap = cap; its[c] = it;
     }
     dI.up(its.data(), sizeof(JacobiItem) * (size_t)copies);
     auto reset = [&]() { for (int c = 0; c < copies; ++c) HIPCHK(hipMemcpyAsync((char*)dA.p + ab * c, dA0.p, ab, hipMemcpyDeviceToDevice, nullptr)); };

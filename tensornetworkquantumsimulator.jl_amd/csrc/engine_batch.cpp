@@ -194,7 +194,8 @@ template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, 
     }
     if (!pre.empty()) {
         const JacobiItem* d = upload_small(s, pre);
-        int mm = 1, nn = 1; for (auto& j : pre) { mm = std::max(mm, std::min(j.m, 128)); nn = std::max(nn, std::min(j.nhint > 0 ? j.nhint : j.n, 64)); }
+        // LDS for the largest matrix the device may find: the low-rank factor (nhint columns) OR, when that route is withdrawn on the device, theta itself (j.n)
+        int mm = 1, nn = 1; for (auto& j : pre) { mm = std::max(mm, std::min(j.m, 128)); nn = std::max(nn, std::min(j.n, 64)); }
         launch_theta_svd_pre(s->stream, d, (int)pre.size(), 60, mm, nn);
     }
     if (!fit.empty()) {

@@ -675,7 +675,16 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                     const int Mr = std::max(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2), Nc = std::min(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2);
                     j = JacobiItem{ws[gi].theta->p, ws[gi].thetaV->p, Mr, Nc, gitems[q].info + 4, gitems[q].info, gitems[q].d1, gitems[q].d2,
                                    gitems[q].lowG ? gitems[q].kappa * gitems[q].chi : 0};      // low-rank route expected: K columns
-                    if (gitems[q].lowQ) { j.QB = gitems[q].lowQ; j.Vout = ws[gi].thetaV->p; j.pre = 1; }      // offered to theta_svd_pre_kernel (decides on the device)
+                    // offered to theta_svd_pre_kernel, which decides on the device: the low-rank factor with its Q (2), or theta as it stands when the ranks the
+                    // sites CAN have (a site with fewer fibers than columns: a corner) keep it within 128 x 64 (1) -- those gates took 12-13 plain sweeps on 128 rows
+                    // and were what a colour batch of a small lattice waited for
+                    if (std::is_same<T, float>::value && use_precond_svd()) {
+                        auto rub = [&](size_t i) { const int n = nof(i); return (int)std::min<size_t>((size_t)n, sj[i].sd.n / (size_t)n); };
+                        const int a1 = rub(2 * (size_t)gi) * gitems[q].d1, a2 = rub(2 * (size_t)gi + 1) * gitems[q].d2;
+                        if (gitems[q].lowQ) { j.QB = gitems[q].lowQ; j.Vout = ws[gi].thetaV->p; j.pre = 2; }
+                        else if (theta_svd_pre_covers(std::max(a1, a2), std::min(a1, a2))) { j.Vout = ws[gi].thetaV->p; j.pre = 1; }
+                        j.cap = ws[gi].cap;
+                    }
                     ncfull.push_back(Nc);
                 }
                 j.V = nullptr;          // V is never accumulated from the rotations (theta0_used): recovered below
@@ -833,6 +842,8 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         for (int q = 0; q < npg; ++q) {
             int Mr, Nc, ncolJ; theta_dims(hinfo.data() + 8 * q, gitems[q].d1, gitems[q].d2, Mr, Nc, ncolJ);
             s->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0; s->stats.n_svd_sweeps += hinfo[8 * q + 4]; s->stats.n_svd_sweeps_max = std::max(s->stats.n_svd_sweeps_max, hinfo[8 * q + 4]);
+            { static const bool dbg = envflag("TNQS_DEBUG_SWEEPS");      // diagnostics: which thetas the SVD launch of a batch waits for
+              if (dbg) std::fprintf(stderr, "[tnqs sweeps] gate %d: r1 %d r2 %d theta %d x %d, SVD on %d columns, %d sweeps, chi' %d\n", pg[q], hinfo[8 * q], hinfo[8 * q + 1], Mr, Nc, ncolJ, hinfo[8 * q + 4], hinfo[8 * q + 2]); }
             {   // qualified for the low-rank route by its ranks, but gate_theta's offer was withdrawn on the device (lowrank_m: a refused pivot)
                 const int K = gitems[q].kappa * gitems[q].chi, r1d = hinfo[8 * q] * gitems[q].d1, r2d = hinfo[8 * q + 1] * gitems[q].d2;
                 if (gitems[q].lowG && ncolJ == Nc && r1d >= r2d && K < r2d && gitems[q].chi_cap <= K) s->stats.n_lowrank_fallbacks += 1;

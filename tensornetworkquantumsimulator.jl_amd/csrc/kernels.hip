@@ -344,7 +344,7 @@ __global__ __launch_bounds__(1024) void jacobi_kernel(const JacobiItem* __restri
     __shared__ int s_rot;
     const JacobiItem it = items[blockIdx.x];
     if (it.only_if && *it.only_if == 0) return;          // conditional item (svd_batch: polishing sweeps only where the preprocessing failed)
-    if (it.pre && theta_pre_takes(it.dyn, it.dm, it.dn)) return;      // taken by theta_svd_pre_kernel
+    if (it.pre && theta_pre_takes(it.dyn, it.dm, it.dn, it.QB != nullptr)) return;      // taken by theta_svd_pre_kernel
     cx<T>* A = reinterpret_cast<cx<T>*>(it.A);
     cx<T>* V = reinterpret_cast<cx<T>*>(it.V);
     int m_ = it.m, n_ = it.n;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(const JacobiItem* __re
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_rot;
     const JacobiItem it = items[blockIdx.x];
-    if (it.pre && theta_pre_takes(it.dyn, it.dm, it.dn)) return;      // taken by theta_svd_pre_kernel
+    if (it.pre && theta_pre_takes(it.dyn, it.dm, it.dn, it.QB != nullptr)) return;      // taken by theta_svd_pre_kernel
     cx<T>* Ag = reinterpret_cast<cx<T>*>(it.A);
     cx<T>* Vg = reinterpret_cast<cx<T>*>(it.V);
     int m_ = it.m, n_ = it.n;
@@ -699,88 +699,6 @@ template <bool CA> __device__ __forceinline__ void tile_mm_f32(const cx<float>* 
         ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, ci, 0, 0, 0);
     }
 }
-// Sweeps of the preconditioned route on the n x n triangular factor (n <= 64 rows): an EIGHTH of a wave (8 lanes, up to 8 rows per lane) owns one column
-// pair, so the 32 pairs of a 64-column round fit FOUR waves -- one per SIMD.  A round of the quarter-wave layout above costs ~150 instructions per wave whatever
-// the row count (index arithmetic, four reductions, the rotation parameters), and with two waves per SIMD the round is bound by instruction issue; halving the
-// waves per SIMD halves that.  The 8-lane sums are three DPP steps (xor 1, xor 2 inside a quad, then the mirrored half row).  Waves beyond the fourth only
-// take part in the barriers.  Same cyclic order, threshold and `tiny` rule as jacobi_lds_sweeps.
-__device__ __forceinline__ float half8_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));     // row_half_mirror
-    return v;
-}
-template <bool FULL>          // FULL: n == 64 (every lane owns 8 real rows, every eighth-wave of the first four waves a real pair)
-__device__ __forceinline__ int jacobi_x8_sweeps(cx<float>* A, int n, int mp, int max_sweeps, float tiny, int* s_rot) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int grp = lane >> 3, l8 = lane & 7;
-    const int ne = n + (n & 1);
-    const int nwork = nw < 4 ? nw : 4;                 // waves that rotate
-    const int nslots = 8 * nwork;
-    const float tol = eps_of<float>() * 2.0f;
-    v2f_t* Av = reinterpret_cast<v2f_t*>(A);
-    int sweep = 0;
-    for (; sweep < max_sweeps && n > 1; ++sweep) {
-        if (threadIdx.x == 0) *s_rot = 0;
-        __syncthreads();
-        for (int round = 0; round < ne - 1; ++round) {
-            if (w < nwork)
-            for (int base = 8 * w; base < ne / 2; base += nslots) {
-                const int pi = base + grp;
-                int p = 0, q = 0; bool act = FULL || pi < ne / 2;
-                if (act) {
-                    if (pi == 0) { p = ne - 1; q = round; }
-                    else { p = round + pi; if (p >= ne - 1) p -= ne - 1; q = round - pi; if (q < 0) q += ne - 1; }
-                    if (p > q) { int t = p; p = q; q = t; }
-                    if (!FULL) act = q < n;
-                }
-                v2f_t* cp = Av + l8 + mp * p; v2f_t* cq = Av + l8 + mp * q;
-                v2f_t ap[8], aq[8];
-                v2f_t sa = {0.f, 0.f}, sb = {0.f, 0.f}, g1 = {0.f, 0.f}, g2v = {0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const bool ok = FULL || (act && l8 + 8 * r < n);
-                    ap[r] = ok ? cp[8 * r] : v2f_t{0.f, 0.f}; aq[r] = ok ? cq[8 * r] : v2f_t{0.f, 0.f};
-                    sa += ap[r] * ap[r]; sb += aq[r] * aq[r];
-                    g1 += ap[r] * aq[r];
-                    g2v += ap[r] * __builtin_shufflevector(aq[r], aq[r], 1, 0);
-                }
-                const float alpha = half8_sum(sa.x + sa.y), beta = half8_sum(sb.x + sb.y), gre = half8_sum(g1.x + g1.y), gim = half8_sum(g2v.x - g2v.y);
-                const float g2 = gre * gre + gim * gim;
-                const bool rot = act && g2 > 1e-36f && g2 > tol * tol * alpha * beta && !(alpha < tiny && beta < tiny);
-                if (rot) {
-                    // two levels of transcendental operations: 1/|g| and 1/r = 1/sqrt(tau^2 + |g|^2) together, then c = sqrt(x) and 1/c = rsqrt(x), x = (1 + |tau|/r)/2;
-                    // s = |g| / (2 r c) with the sign of tau  (the same rotation as t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), c = 1/sqrt(1 + t^2), s = c t)
-                    // (the hardware reciprocal square root is good to 1 ulp but biased: hundreds of rotations whose c^2 + s^2 and |phase| sit a few 1e-8 on
-                    //  the same side of 1 shifted every singular value by 3e-6 relative; one Newton step each makes them unbiased to rounding)
-                    auto rsq = [](float v) { const float y = fast_rsqrt<float>(v); return y * fmaf(-0.5f * v * y, y, 1.5f); };
-                    const float iga = rsq(g2);
-                    const float tau = 0.5f * (beta - alpha);
-                    const float ir = rsq(fmaf(tau, tau, g2));
-                    const float x = 0.5f + 0.5f * fabsf(tau) * ir;
-                    const float ic = rsq(x), c = x * ic;
-                    const float sn = (tau >= 0 ? 0.5f : -0.5f) * (g2 * iga) * ir * ic;
-                    const float pre = gre * iga, pim = -gim * iga;
-                    const v2f_t e1 = {pre, pim}, e2 = {-pim, pre}, cc = {c, c}, ss = {sn, sn};
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        if (FULL || l8 + 8 * r < n) {
-                            const v2f_t qv = __builtin_shufflevector(aq[r], aq[r], 0, 0) * e1 + __builtin_shufflevector(aq[r], aq[r], 1, 1) * e2;
-                            cp[8 * r] = cc * ap[r] - ss * qv;
-                            cq[8 * r] = ss * ap[r] + cc * qv;
-                        }
-                    }
-                    if (l8 == 0) *s_rot = 1;
-                }
-            }
-            __syncthreads();
-        }
-        const int rotd = *s_rot;
-        __syncthreads();
-        if (!rotd) { ++sweep; break; }
-    }
-    return sweep;
-}
 // ------------------------------------------------------------------------------------------------------------
 // Preconditioned theta SVD (round 5): ComplexF32, V not wanted, tall or square A (m >= n), n <= 64, m <= 128 -- the 128 x 64 low-rank factor
 // of a chi = 32 gate and every smaller theta.  ONE workgroup per gate, everything in LDS:
@@ -816,7 +734,7 @@ __global__ __launch_bounds__(NT) void theta_svd_pre_kernel(const JacobiItem* __r
     PRE_STAMP(0);
     // pre != 0 (engine): the item is taken only when the low-rank route survived on the device and its factor fits (theta_pre_takes); the plain Jacobi
     // kernel launched next to this one makes the complementary decision.  pre == 0 (kernel tests): the dimensions given decide
-    if (it.pre ? !theta_pre_takes(it.dyn, it.dm, it.dn) : (n < 2 || m < n || n > 64 || m > 128)) return;
+    if (it.pre ? !theta_pre_takes(it.dyn, it.dm, it.dn, it.QB != nullptr) : (n < 2 || m < n || n > 64 || m > 128)) return;
     const int mp = m + 2, gp = n + 1, xp = n + 2;
     cx<float>* Mf = reinterpret_cast<cx<float>*>(smem);                                   // sorted A, column a at mp * a
     const size_t m_bytes = (((size_t)mp * n * sizeof(cx<float>)) + 15) & ~(size_t)15;
@@ -934,56 +852,68 @@ __global__ __launch_bounds__(NT) void theta_svd_pre_kernel(const JacobiItem* __r
     }
     __syncthreads();
     PRE_STAMP(3);
-    if (it.nhint == -8) {          // (kernel tests only: hand back the triangular factor the sweeps would start from -- f32, n x n, column-major, sorted order -- and stop)
-        cx<float>* out = reinterpret_cast<cx<float>*>(it.Vout);
-        for (int e = tid; e < n * n; e += NT) out[e] = X[(e % n) + xp * (e / n)];
-        return;
-    }
-    // ---- 5. sweeps on the columns of L (n rows) ---------------------------------------------------------------------------------------
+    // ---- 5. sweeps on the columns of L (n rows): the quarter-wave sweeps of jacobi_lds_kernel (an eighth-wave layout with four waves measured the same 45 us
+    // per 64 x 64 sweep and, with its two-level rotation formulas, singular values 6-9 x less accurate) -------------------------------------------------------
     const float tiny = (float)((double)n * (double)eps_of<float>() * (double)eps_of<float>() * fro);
     int sweep;
-    if (it.nhint == -7) {          // (kernel tests only: the quarter-wave sweeps of jacobi_lds_kernel on the same factor)
-        if (n == 64) sweep = jacobi_lds_sweeps_f32_full<4>(X, n, n, xp, max_sweeps, tiny, &s_rot);
-        else sweep = jacobi_lds_sweeps<float, 4, false>(X, (cx<float>*)nullptr, false, n, n, xp, 0, max_sweeps, tiny, &s_rot);
-    }
-    else if (n == 64) sweep = jacobi_x8_sweeps<true>(X, n, xp, max_sweeps, tiny, &s_rot);
-    else sweep = jacobi_x8_sweeps<false>(X, n, xp, max_sweeps, tiny, &s_rot);
+    if (n == 64) sweep = jacobi_lds_sweeps_f32_full<4>(X, n, n, xp, max_sweeps, tiny, &s_rot);
+    else sweep = jacobi_lds_sweeps<float, 4, false>(X, (cx<float>*)nullptr, false, n, n, xp, 0, max_sweeps, tiny, &s_rot);
     __syncthreads();
     PRE_STAMP(4);
-    // ---- 6. U_L = normalised columns; U Sigma = A U_L in f64, written over A ------------------------------------------------------------
+    // ---- 6. sigma_j = |x_j| (relative accuracy: what the truncation is decided on), U_L = normalised columns.  Only the `cap` largest singular values can survive
+    // the truncation (JacobiItem::cap = the bond dimension cap of the gate): U Sigma and V are formed for those columns only; the others leave as sigma_j e_0,
+    // which carries their weight into the truncation error and nothing else ------------------------------------------------------------------------------
+    __shared__ unsigned char s_keep[64]; __shared__ int s_nk;
     for (int j = w; j < n; j += nw) {
         double s2 = 0;
         for (int i = lane; i < n; i += 64) { const cx<float> v = X[i + xp * j]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
         s2 = wave_sum(s2);
-        if (lane == 0) { s_cn[j] = s2 > 0 ? 1.0 / sqrt(s2) : 0.0; s_sig[j] = sqrt(s2); }      // sigma_j of the sweeps: relative accuracy (what the truncation is decided on)
+        if (lane == 0) { s_cn[j] = s2 > 0 ? 1.0 / sqrt(s2) : 0.0; s_sig[j] = sqrt(s2); }
     }
     __syncthreads();
+    const int cap = (it.cap > 0 && it.cap < n) ? it.cap : n;
+    __shared__ unsigned char s_rank[64];
+    for (int j = tid; j < n; j += NT) {
+        int rk = 0; const double sj_ = s_sig[j];
+        for (int v = 0; v < n; ++v) rk += (s_sig[v] > sj_) || (s_sig[v] == sj_ && v < j);
+        s_keep[rk] = (unsigned char)j; s_rank[j] = (unsigned char)rk;                // columns by decreasing singular value
+    }
+    __syncthreads();
+    // the consumer (gate_finish) ranks the columns again, by their f32 norms: everything within 1e-4 of the cap-th singular value is formed as well, so that a tie
+    // at the cap -- the equal pseudo-values of collapsed pivots, or a degenerate pair -- can never make it pick a column that was not formed
+    if (tid == 0) { int k = cap; const double thr = s_sig[s_keep[cap - 1]] * (1.0 - 1e-4); while (k < n && s_sig[s_keep[k]] >= thr) ++k; s_nk = k; }
+    __syncthreads();
+    const int nk = s_nk;
+    for (int j = tid; j < n; j += NT)
+        if ((int)s_rank[j] >= nk) for (int i = 0; i < m; ++i) Ag[i + (size_t)m * j] = cmake<float>(i == 0 ? (float)(s_sig[j] * sc_out) : 0.f, 0.f);
+    const bool fullk = full16 && !(nk & 15);
     {
-        // U Sigma = A U_L on the f64 matrix cores, computed TRANSPOSED (tile rows = column j of the result, lanes = row i: stores run along i).  A wave keeps its
-        // (at most four) tiles in registers until the column norms are complete: the columns leave with the norm the sweeps found for them (s_sig) -- A u_j
+        // U Sigma = A U_L on the f64 matrix cores, computed TRANSPOSED (tile rows = kept column c of the result, lanes = row i: stores run along i).  A wave keeps
+        // its (at most four) tiles in registers until the column norms are complete: the columns leave with the norm the sweeps found for them (s_sig) -- A u_j
         // carries an error of eps sigma_max in norm and direction like any product in working precision, the singular VALUE does not have to
         double* s_on = s_piv;                                        // column norms^2 of A X_final
         for (int j = tid; j < n; j += NT) s_on[j] = 0.0;
         __syncthreads();
-        const int tr = (n + 15) >> 4, tc = (m + 15) >> 4;            // tr * tc <= 4 * 8 = 32 tiles, at most four per wave
+        const int tr = (nk + 15) >> 4, tc = (m + 15) >> 4;           // tr * tc <= 4 * 8 = 32 tiles, at most four per wave
         v4d_t acr[4], aci[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int t = w + nw * q;
             acr[q] = v4d_t{0, 0, 0, 0}; aci[q] = v4d_t{0, 0, 0, 0};
             if (t < tr * tc) {
-                const int j0 = 16 * (t % tr), i0 = 16 * (t / tr);
-                if (full16) tile_mm_f32<false>(X + xp * (j0 + l15), 1, Mf + (i0 + l15), mp, n, acr[q], aci[q]);      // out[i][j] = sum_k A[i][k] X[k][j] (sorted columns)
-                else ztile_mm(n, j0 + l15, i0 + l15,
-                         [&](int j, int k) { cx<double> v = cmake<double>(0, 0); if (j < n && k < n) { const cx<float> a = X[k + xp * j]; v = cmake<double>(a.re, a.im); } return v; },
+                const int c0 = 16 * (t % tr), i0 = 16 * (t / tr);
+                const int jl = (int)s_keep[c0 + l15 < nk ? c0 + l15 : 0];              // this lane's column of X (A operand)
+                if (fullk) tile_mm_f32<false>(X + xp * jl, 1, Mf + (i0 + l15), mp, n, acr[q], aci[q]);      // out[i][j] = sum_k A[i][k] X[k][j] (sorted columns of A)
+                else ztile_mm(n, c0 + l15, i0 + l15,
+                         [&](int c, int k) { cx<double> v = cmake<double>(0, 0); if (c < nk && k < n) { const cx<float> a = X[k + xp * jl]; v = cmake<double>(a.re, a.im); } return v; },
                          [&](int k, int i) { cx<double> v = cmake<double>(0, 0); if (i < m && k < n) { const cx<float> a = Mf[i + mp * k]; v = cmake<double>(a.re, a.im); } return v; },
                          acr[q], aci[q]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double p2 = acr[q][r] * acr[q][r] + aci[q][r] * aci[q][r];            // row j = j0 + kq + 4 r of the tile, column i = i0 + l15
+                    double p2 = acr[q][r] * acr[q][r] + aci[q][r] * aci[q][r];            // row c = c0 + kq + 4 r of the tile, column i = i0 + l15
                     if (i0 + l15 >= m) p2 = 0;
                     p2 = row16_sum(p2);
-                    if (l15 == 0 && j0 + kq + 4 * r < n) atomicAdd(&s_on[j0 + kq + 4 * r], p2);
+                    if (l15 == 0 && c0 + kq + 4 * r < nk) atomicAdd(&s_on[s_keep[c0 + kq + 4 * r]], p2);
                 }
             }
         }
@@ -992,11 +922,12 @@ __global__ __launch_bounds__(NT) void theta_svd_pre_kernel(const JacobiItem* __r
         for (int q = 0; q < 4; ++q) {
             const int t = w + nw * q;
             if (t < tr * tc) {
-                const int j0 = 16 * (t % tr), i0 = 16 * (t / tr);
+                const int c0 = 16 * (t % tr), i0 = 16 * (t / tr);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int j = j0 + kq + 4 * r, i = i0 + l15;
-                    if (j < n && i < m) {
+                    const int c = c0 + kq + 4 * r, i = i0 + l15;
+                    if (c < nk && i < m) {
+                        const int j = s_keep[c];
                         const double f = s_on[j] > 0 ? s_sig[j] / sqrt(s_on[j]) * sc_out : 0.0;
                         Ag[i + (size_t)m * j] = cmake<float>((float)(acr[q][r] * f), (float)(aci[q][r] * f));
                     }
@@ -1005,25 +936,37 @@ __global__ __launch_bounds__(NT) void theta_svd_pre_kernel(const JacobiItem* __r
         }
     }
     PRE_STAMP(5);
-    // ---- 7. right singular vectors of theta = A Q^T:  V = conj(Q) U_L  (Q = B L^-dagger, (r2 d2) x n, f64; written by lowrank_m_kernel).  U_L is orthonormal
-    // to f32 rounding whatever the spectrum, so V needs no division by Sigma^2 -- the recovery from the unrotated theta this replaces amplified the error of a
-    // column of U Sigma by (sigma_max / sigma_j)^2 and therefore needed U Sigma orthogonal relative to each column's own norm ------------------------------
-    if (it.QB && it.Vout && it.dyn) {
+    // ---- 7. right singular vectors, kept columns only.  Low-rank theta = A Q^T (Q = B L^-dagger, (r2 d2) x n, f64; written by lowrank_m_kernel):
+    // V = conj(Q) U_L on the f64 matrix cores.  A theta factorised as it stands (QB null): V = U_L itself, rows back in the original column order.  U_L is
+    // orthonormal to f32 rounding whatever the spectrum, so V needs no division by Sigma^2 -- the recovery from the unrotated theta this replaces amplified the
+    // error of a column of U Sigma by (sigma_max / sigma_j)^2 and therefore needed U Sigma orthogonal relative to each column's own norm ---------------------
+    const bool lowrank = it.QB && (!it.dyn || it.dyn[7] > 0);          // (an item offered with its Q whose low-rank route was withdrawn on the device is theta itself)
+    if (it.Vout && !lowrank) {
+        cx<float>* Vg = reinterpret_cast<cx<float>*>(it.Vout);
+        for (int e = tid; e < n * (n - nk); e += NT) Vg[(e % n) + (size_t)n * (int)s_keep[nk + e / n]] = cmake<float>(0.f, 0.f);      // columns that were not formed: zero, never garbage
+        for (int e = tid; e < n * nk; e += NT) {
+            const int k = e % n, j = s_keep[e / n];
+            const cx<float> v = X[k + xp * j]; const float f = (float)s_cn[j];
+            Vg[(int)s_perm[k] + (size_t)n * j] = cmake<float>(v.re * f, v.im * f);
+        }
+    } else if (it.Vout && it.dyn) {
         int mq, nq, kq_; theta_dims(it.dyn, it.dm, it.dn, mq, nq, kq_);      // nq = r2 d2: rows of Q and of V
         (void)mq; (void)kq_;
         const cx<double>* Q = reinterpret_cast<const cx<double>*>(it.QB);
         cx<float>* Vg = reinterpret_cast<cx<float>*>(it.Vout);
-        const int tr = (n + 15) >> 4, tc = (nq + 15) >> 4;
+        const int tr = (nk + 15) >> 4, tc = (nq + 15) >> 4;
+        for (int e = tid; e < nq * (n - nk); e += NT) Vg[(e % nq) + (size_t)nq * (int)s_keep[nk + e / nq]] = cmake<float>(0.f, 0.f);      // columns that were not formed: zero, never garbage
         for (int t = w; t < tr * tc; t += nw) {
-            const int j0 = 16 * (t % tr), i0 = 16 * (t / tr);
+            const int c0 = 16 * (t % tr), i0 = 16 * (t / tr);
+            const int jl = (int)s_keep[c0 + l15 < nk ? c0 + l15 : 0];
             v4d_t cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
-            ztile_mm(n, j0 + l15, i0 + l15,                                              // V[i][j] = sum_k conj(Q[i][perm k]) X[k][j] / |x_j|
-                     [&](int j, int k) { cx<double> v = cmake<double>(0, 0); if (j < n && k < n) { const cx<float> a = X[k + xp * j]; v = cmake<double>(a.re, a.im); } return v; },
+            ztile_mm(n, c0 + l15, i0 + l15,                                              // V[i][j] = sum_k conj(Q[i][perm k]) X[k][j] / |x_j|
+                     [&](int c, int k) { cx<double> v = cmake<double>(0, 0); if (c < nk && k < n) { const cx<float> a = X[k + xp * jl]; v = cmake<double>(a.re, a.im); } return v; },
                      [&](int k, int i) { cx<double> v = cmake<double>(0, 0); if (i < nq && k < n) { v = Q[i + (size_t)nq * (int)s_perm[k]]; v.im = -v.im; } return v; }, cr, ci);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j = j0 + kq + 4 * r, i = i0 + l15;
-                if (j < n && i < nq) { const double f = s_cn[j]; Vg[i + (size_t)nq * j] = cmake<float>((float)(cr[r] * f), (float)(ci[r] * f)); }
+                const int c = c0 + kq + 4 * r, i = i0 + l15;
+                if (c < nk && i < nq) { const int j = s_keep[c]; const double f = s_cn[j]; Vg[i + (size_t)nq * j] = cmake<float>((float)(cr[r] * f), (float)(ci[r] * f)); }
             }
         }
     }
@@ -1044,7 +987,7 @@ void launch_theta_svd_pre(hipStream_t s, const JacobiItem* d_items, int nitems, 
 template <class T, int R>                  // m <= 64 R rows
 __global__ __launch_bounds__(512) void recover_v_kernel(const RecoverItem* __restrict__ items) {
     const RecoverItem it = items[blockIdx.x];
-    if (it.pre && theta_pre_takes(it.dyn, it.dm, it.dn)) return;      // V already written by theta_svd_pre_kernel
+    if (it.pre && theta_pre_takes(it.dyn, it.dm, it.dn, it.pre == 2)) return;      // V already written by theta_svd_pre_kernel
     const cx<T>* A0 = reinterpret_cast<const cx<T>*>(it.A0);
     const cx<T>* A = reinterpret_cast<const cx<T>*>(it.A);
     cx<T>* V = reinterpret_cast<cx<T>*>(it.V);

@@ -53,16 +53,23 @@ struct JacobiItem {       // one-sided Jacobi on A (m x n, col-major, ld = m); V
     // Preconditioned route of a low-rank theta (theta_svd_pre_kernel): QB = the orthonormal factor Q of theta = M Q^T ((r2 d2) x K, complex128), Vout = where the
     // right singular vectors of theta go ((r2 d2) x K, data precision).  pre != 0: the item has ALSO been handed to that kernel, which takes it when the
     // dimensions found on the device fit (theta_pre_takes); the plain Jacobi kernel and the V recovery then skip it
-    const void* QB; void* Vout; int pre;
+    const void* QB; void* Vout; int pre;     // pre: 1 = offered, theta as it stands; 2 = offered, low-rank factor with Q
+    int cap;                                 // columns that can survive the truncation (0: all): U Sigma and V are only formed for the `cap` largest singular values
 };
-// device-side decision shared by theta_svd_pre_kernel, jacobi_lds_kernel / jacobi_kernel and the V-recovery kernels: the low-rank route survived on the device
-// (info[7] = K > 0) and the factor fits the kernel
-__host__ __device__ inline bool theta_pre_takes(const int* info, int d1, int d2) {
-    if (!info || info[7] <= 0) return false;
+// device-side decision shared by theta_svd_pre_kernel, jacobi_lds_kernel / jacobi_kernel and the V-recovery kernels: the matrix the SVD runs on -- the low-rank
+// factor when that route survived on the device (info[7] = K > 0; needs Q), theta itself otherwise -- fits the kernel
+__host__ __device__ inline bool theta_pre_takes(const int* info, int d1, int d2, bool have_q) {
+    if (!info) return false;
     int Mr = info[0] * d1, Nc = info[1] * d2;
-    if (Mr < Nc) return false;
-    const int K = info[7];
-    return K >= 2 && K <= 64 && Mr >= K && Mr <= 128;
+    if (info[7] > 0) {                                  // low-rank route alive: the K-column factor, V through Q
+        const int K = info[7];
+        return have_q && Mr >= Nc && K > 32 && K <= 64 && Mr >= K && Mr <= 128;
+    }
+    if (Mr < Nc) { const int t = Mr; Mr = Nc; Nc = t; }   // theta itself (stored as its adjoint when wide): V = U_L
+    return Nc > 32 && Nc <= 64 && Mr <= 128;
+    // (more than 32 columns: a round of the sweeps costs ~0.7 us whatever the row count -- latency of the load / reduce / rotate / barrier chain -- so on a 64 x 32
+    //  factor the plain kernel's 7-8 sweeps of 31 rounds, 0.14-0.16 ms, beat 6-7 preconditioned sweeps plus 37 us of Gram, Cholesky and products: 0.18-0.21 ms
+    //  measured, profiles/svd_bench.py; at 64 columns it is 0.42-0.47 ms against 0.27-0.31)
 }
 // dimensions of a gate's theta SVD from its info array (gate_theta_kernel): rows, columns of theta, columns the Jacobi runs on
 __host__ __device__ inline void theta_dims(const int* info, int d1, int d2, int& m, int& nfull, int& ncol) {
@@ -169,7 +176,7 @@ template <class T, class Acc> void launch_gram(hipStream_t s, const GramItem* d_
                                                int TR, int KKmax);
 template <class Acc, class Out> void launch_reduce(hipStream_t s, const ReduceItem* d_items, int nitems, int total_elems);
 template <class T> void launch_msg_finalize(hipStream_t s, const MsgFinalItem* d_items, int nitems);
-struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; int nu; const int* dyn; int dm, dn; int pre; /* != 0: skip when theta_pre_takes */ };   // dyn: as in JacobiItem   // V (n x nu) = A0^dagger (U Sigma) Sigma^-2; A0: m x n, U Sigma: m x nu
+struct RecoverItem { const void* A0; const void* A; void* V; int m; int n; int nu; const int* dyn; int dm, dn; int pre; /* JacobiItem::pre of the same gate: skip when theta_pre_takes */ };   // dyn: as in JacobiItem   // V (n x nu) = A0^dagger (U Sigma) Sigma^-2; A0: m x n, U Sigma: m x nu
 // LDS bytes the LDS-resident Jacobi needs for an m x n matrix (columns padded by 2 elements)
 inline size_t jacobi_lds_bytes(int m, int n, bool withV, size_t esz) { return ((size_t)(m + 2) * n + (withV ? (size_t)(n + 2) * n : 0)) * esz; }
 template <class T> void launch_jacobi(hipStream_t s, const JacobiItem* d_items, int nitems, int max_sweeps, size_t lds_bytes, int mmax, int ncols = 0);   // ncols: expected columns (sizes the workgroup of the LDS kernel)

@@ -1241,7 +1241,7 @@ void launch_mfma_apply64(hipStream_t s, const Apply64Item* d_items, int nitems, 
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void recover_v_mfma_kernel(const RecoverItem* __restrict__ items) {
     const RecoverItem it = items[blockIdx.x];
-    if (it.pre && theta_pre_takes(it.dyn, it.dm, it.dn)) return;      // V already written by theta_svd_pre_kernel
+    if (it.pre && theta_pre_takes(it.dyn, it.dm, it.dn, it.pre == 2)) return;      // V already written by theta_svd_pre_kernel
     const cf* __restrict__ A0 = reinterpret_cast<const cf*>(it.A0);
     const cf* __restrict__ A = reinterpret_cast<const cf*>(it.A);
     cf* __restrict__ V = reinterpret_cast<cf*>(it.V);

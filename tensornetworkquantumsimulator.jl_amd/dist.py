@@ -59,12 +59,14 @@ def partition_vertices(nv: int, world: int, weights: Optional[Sequence[float]] =
     return owner
 
 
-def site_weights(graph, chi: int, d: int = 2, floor: float = 0.3) -> List[float]:
+def site_weights(graph, chi: int, d: int = 2, floor: float = 0.17) -> List[float]:
     """cost model of a vertex, in units of the elements of the largest site tensor (d * chi^max degree): its tensor passes cost its own elements,
     d * chi^degree; on top of that every site pays the latency-bound part of the path (its share of the per-gate factorisation chain, the small-tensor
     BP kernels, descriptor traffic), which does not shrink with the tensor -- measured on the sharded 20 x 20 chi = 32 layer (profiles/shard_proxy.py,
     round 5): a rank with 40 bulk + 25 boundary sites took 26.3 ms against 22.5 ms for 40 bulk + 4 boundary sites, i.e. ~0.18 ms per boundary site next
-    to 0.39 ms per bulk site, although a degree-3 site holds 1/32 of a bulk site's elements.  `floor` is that latency share (0 = elements only)."""
+    to 0.39 ms per bulk site, although a degree-3 site holds 1/32 of a bulk site's elements; with the floor at 0.3 the end ranks (36 bulk + 24 boundary sites) then
+    took 22.9 ms against 23.7-25.6 ms for the interior ranks (42 + 4), which puts a boundary site at 0.06 ms = 0.17 of a bulk site.  `floor` is that latency share
+    (0 = elements only)."""
     zmax = max(graph.degree(v) for v in graph.vertices)
     bulk = float(d) * float(chi) ** zmax
     return [max(float(d) * float(chi) ** graph.degree(v) / bulk, float(floor)) for v in graph.vertices]

@@ -405,29 +405,46 @@ def test_c4_periodic_cubic_layer_matches_oracle():
         bo, eo, _ = cpu_layer.apply_layer(bo, one_site, colour_groups, pool, kw, dict(maxiter=1, tolerance=None))
     assert info["n_updates"] == len(groups) + 1 and info["n_two_site"] == sum(len(grp) for grp in groups)
     compare_with_oracle_after_layer(g, bd, bo, ed[len(one_site):], eo, "C4 lattice (3x3x3 periodic), four colour groups of a layer")
+    # The 6e-6 the comparison above measures is the ORACLE's f32 accumulation noise (numpy sums 1.7e7 terms in f32), not the device's: the same circuit on
+    # the device in ComplexF64 is the yardstick -- device f32 against device f64 to 1e-6 (measured 1.2e-7, profiles/c4_f32_noise.py), i.e. the 1e-5 bound
+    # against the oracle is not what protects the device here, this is (round-4 verdict)
+    zd32 = tn.expect_all(bd, "Z").real
+    del bd
+    p64 = tn.TensorNetworkState(g, {v: psi.tensors[v].astype(np.complex128) for v in g.vertices})
+    b64 = tn.update(tn.BeliefPropagationCache(p64), edge_sequence=seq, maxiter=1, tolerance=None)
+    b64, _e64 = tn.apply_gates(layer, b64, apply_kwargs=kw, bp_update_kwargs=dict(edge_sequence=seq, maxiter=1, tolerance=None))
+    d3264 = float(np.max(np.abs(zd32 - tn.expect_all(b64, "Z").real)))
+    print(f"C4 lattice: max|<Z> device f32 - device f64| {d3264:.1e}")
+    assert d3264 < 1e-6
 
 
 def test_c5_shape_bp_and_layer_match_oracle():
-    """BASELINE configs[4] per-site shape (degree 4, chi = 64, ComplexF32; 268 MB bulk tensor, 256 x 256 theta) on a 3x3 grid, the oracle
-    iterating its own messages: two BP sweeps elementwise, then one full TFIM layer (Rx, Rzz per colour, two sweeps per update)."""
+    """BASELINE configs[4] per-site shape (degree 4, chi = 64, ComplexF32; 268 MB bulk tensor, 256 x 256 theta) on a 4x4 grid -- FOUR bulk sites, so that
+    bulk-bulk gates (two 256 x 128 theta factors per gate, both sites on the chi = 64 kernels) and bulk-bulk messages exist; round 4 ran a 3x3 grid with a single
+    bulk site.  The oracle iterates its own messages (oracle/cpu_layer.py: the oracle's arithmetic on a thread pool): two BP sweeps elementwise, then one full TFIM
+    layer (Rx, Rzz per colour, two sweeps per update): bond dimensions, truncation errors, <Z> and message spectra to 1e-5."""
     import tnqs_oracle as o
+    import cpu_layer
     from helpers import to_oracle_state
-    g = tn.named_grid((3, 3))
+    g = tn.named_grid((4, 4))
+    assert sum(1 for v in g.vertices if g.degree(v) == 4) == 4
     chi = 64
     psi = small_norm_state(g, chi, seed=32)
     seq = tn.forest_cover_edge_sequence(g)
     bpkw = dict(edge_sequence=seq, maxiter=2, tolerance=None)
     bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
-    bo = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)
-    w = messages_elementwise(bd, bo, g, 5e-5)
-    print(f"C5 shape, two BP sweeps: messages elementwise to {w:.1e}")
     groups = tn.edge_color(g, 4)
-    layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
-    for grp in groups:
-        layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+    one_site = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+    colour_groups = [[("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp] for grp in groups]
+    layer = one_site + [gt for grp in colour_groups for gt in grp]
     kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
-    info = {}
-    bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw, info=info)
-    bo, eo = o.apply_gates(layer, bo, apply_kwargs=kw, bp_update_kwargs=bpkw)
-    assert info["n_updates"] == 5 and info["n_two_site"] == 12
-    compare_with_oracle_after_layer(g, bd, bo, ed, eo, "C5 shape, one layer")
+    with cpu_layer.parallel_oracle() as pool:
+        bo = o.BeliefPropagationCache(to_oracle_state(psi), edge_sequence=seq)
+        bo = cpu_layer.update(bo, pool, maxiter=2, tolerance=None)
+        w = messages_elementwise(bd, bo, g, 5e-5)
+        print(f"C5 shape (4x4, four bulk sites), two BP sweeps: messages elementwise to {w:.1e}")
+        info = {}
+        bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw, info=info)
+        bo, eo, _ = cpu_layer.apply_layer(bo, one_site, colour_groups, pool, kw, dict(maxiter=2, tolerance=None))
+    assert info["n_updates"] == 5 and info["n_two_site"] == 24
+    compare_with_oracle_after_layer(g, bd, bo, ed[len(one_site):], eo, "C5 shape (4x4), one layer")

@@ -41,7 +41,7 @@ def test_apply_gates_matches_golden(name):
         assert info["n_updates"] == len(meta["groups"]) + 1
         assert np.array_equal(np.array([bpc.bond_dim(a, b) for (a, b) in g.edges]), z["bond_dims"][l]), l
         assert (np.max(np.abs(errs - z["errs"][l])) < 1e-9) if c128 else c64_errs_close(errs, z["errs"][l]), l
-        scale = (l + 1) * (1e-8 if c128 else 1e-5)
+        scale = (l + 1) * 1e-8 if c128 else 1e-5          # ComplexF32: a FLAT 1e-5 on every layer (the north star's bound; the device measures 1-7e-6 over ten layers)
         ez = tn.expect_all(bpc, "Z")
         assert np.max(np.abs(ez - z["expZ"][l])) < scale, (l, np.max(np.abs(ez - z["expZ"][l])))
         sp = []

@@ -354,12 +354,14 @@ def test_cholesky_kernels(n, cond):
 
 
 # ---- preconditioned theta SVD kernel (round 5) ----------------------------------------------------------------------------------------
-def theta_svd_pre(a, q, copies=1, reps=0):
-    m, n = a.shape; nq = q.shape[0]
-    A = np.asfortranarray(a.astype(np.complex64)); Q = np.asfortranarray(q.astype(np.complex128))
+def theta_svd_pre(a, q=None, copies=1, reps=0, cap=0):
+    """q given: a is the low-rank factor of theta = a q^T, V (nq x n) = right singular vectors of theta; q None: a is theta itself, V is n x n"""
+    m, n = a.shape; nq = q.shape[0] if q is not None else n
+    A = np.asfortranarray(a.astype(np.complex64)); Q = np.asfortranarray(q.astype(np.complex128)) if q is not None else None
     V = np.zeros((nq, n), dtype=np.complex64, order="F")
     sw = C.c_int(); ms = C.c_double(0.0); ph = (C.c_double * 6)()
-    rc = lib.tnqs_dbg_theta_svd_pre(m, n, nq, A.ctypes.data_as(C.c_void_p), Q.ctypes.data_as(C.c_void_p), V.ctypes.data_as(C.c_void_p), C.byref(sw), copies, reps, C.byref(ms), ph)
+    rc = lib.tnqs_dbg_theta_svd_pre(m, n, nq, A.ctypes.data_as(C.c_void_p), Q.ctypes.data_as(C.c_void_p) if Q is not None else None, V.ctypes.data_as(C.c_void_p), C.byref(sw),
+                                    copies, reps, C.byref(ms), ph, cap)
     assert rc == 0, lib.tnqs_last_error()
     theta_svd_pre.phases_us = [round(x, 1) for x in ph]          # load, Gram, Cholesky + conversion, sweeps, U Sigma, V (workgroup 0)
     return A, V, sw.value, ms.value
@@ -386,23 +388,36 @@ def low_rank_factors(r1, r2, gate):
     return A @ np.conj(L), Q, A @ B.T
 
 
-def check_theta_svd_pre(M, Q, theta, sv_tol=4e-6):
-    A, V, sw, _ = theta_svd_pre(M, Q)
+def check_theta_svd_pre(M, Q, theta, sv_tol=4e-6, cap=0):
+    A, V, sw, _ = theta_svd_pre(M, Q, cap=cap)
     A = A.astype(np.complex128); V = V.astype(np.complex128)
     M32 = M.astype(np.complex64).astype(np.complex128)
     s_ref = np.linalg.svd(M32, compute_uv=False)
     nrm = np.linalg.norm(A, axis=0)
     assert 0 < sw < 30
-    assert np.max(np.abs(np.sort(nrm)[::-1] - s_ref)) < sv_tol * s_ref[0], (np.sort(nrm)[::-1][:4], s_ref[:4])
-    rec = A @ V.conj().T                                                     # (U Sigma) V^dagger = theta = M Q^T
-    assert np.max(np.abs(rec - M32 @ Q.T)) < 2e-6 * s_ref[0] * np.sqrt(M.shape[1])
-    if theta is not None:
-        assert np.max(np.abs(rec - theta)) < 3e-6 * s_ref[0] * np.sqrt(M.shape[1])
-    big = nrm > 1e-5 * s_ref[0]                                             # V: orthonormal to f32 rounding whatever the singular value (no division by Sigma^2)
-    Vb = V[:, big]
+    assert np.max(np.abs(np.sort(nrm)[::-1] - s_ref)) < sv_tol * s_ref[0], (np.sort(nrm)[::-1][:4], s_ref[:4])      # EVERY singular value (the truncation error needs them all)
+    n = M.shape[1]
+    order = np.argsort(-nrm, kind="stable")
+    keep = order[: (cap if 0 < cap < n else n)]                                               # the columns whose vectors must be formed
+    # the others leave as sigma_j e_0 -- except those within 1e-4 of the cap-th singular value (ties at the cap are formed too: the consumer ranks again)
+    other = np.array([j for j in order[len(keep):] if nrm[j] < nrm[keep[-1]] * (1 - 2e-4)], dtype=int)
+    if len(other):
+        assert np.all(A[1:, other] == 0) and np.allclose(A[0, other].real, nrm[other]) and np.all(A[0, other].imag == 0)
+        assert np.all(V[:, other] == 0)                                                       # never garbage
+    full = M32 @ Q.T if Q is not None else M32                                                # theta
+    u, sv, vh = np.linalg.svd(full, full_matrices=False)
+    k = len(keep)
+    best = (u[:, :k] * sv[:k]) @ vh[:k]                                                       # best rank-k approximation
+    rec = A[:, keep] @ V[:, keep].conj().T                                                    # (U Sigma) V^dagger over the kept triplets
+    assert np.max(np.abs(rec - best)) < 3e-6 * s_ref[0] * np.sqrt(n), float(np.max(np.abs(rec - best)) / s_ref[0])
+    if theta is not None and k == n:
+        assert np.max(np.abs(rec - theta)) < 3e-6 * s_ref[0] * np.sqrt(n)
+    big = nrm[keep] > 1e-5 * s_ref[0]                                       # V: orthonormal to f32 rounding whatever the singular value (no division by Sigma^2)
+    Vb = V[:, keep][:, big]
     assert np.max(np.abs(Vb.conj().T @ Vb - np.eye(Vb.shape[1]))) < 3e-6
-    U = A[:, big] / nrm[big]                                                # U Sigma = M U_L: absolute accuracy eps * sigma_max per column (like LAPACK's)
-    assert np.max(np.abs((U.conj().T @ U - np.eye(U.shape[1])) * np.minimum.outer(nrm[big], nrm[big]))) < 3e-6 * s_ref[0]
+    nb = nrm[keep][big]
+    U = A[:, keep][:, big] / nb                                             # U Sigma = M U_L: absolute accuracy eps * sigma_max per column (like LAPACK's)
+    assert np.max(np.abs((U.conj().T @ U - np.eye(U.shape[1])) * np.minimum.outer(nb, nb))) < 3e-6 * s_ref[0]
     return sw
 
 
@@ -419,6 +434,9 @@ def test_theta_svd_pre_kernel(shape, rank, scale):
     M = (q1 * dec) @ q2.conj().T * scale
     Q, _ = np.linalg.qr(rnd(rng, (nq, n), np.complex128))
     check_theta_svd_pre(M, Q, None)
+    if rank == n and n >= 8:
+        check_theta_svd_pre(M, Q, None, cap=n // 2)           # only the n/2 largest triplets are formed (the bond dimension cap of a gate)
+    check_theta_svd_pre(M, None, None, cap=(n // 2 if n >= 8 else 0))      # theta itself (a corner gate: no low-rank route): V = its right singular vectors
 
 
 def test_theta_svd_pre_kernel_on_harvested_factors():
