@@ -164,7 +164,7 @@ int tnqs_expect_all(tnqs_handle h, const double* ops, double* out_re_im);
  * tree: region_parent[i] = index (into region_verts) of the parent of vertex i, -1 for the single root.  What is contracted is the
  * INDUCED region, as in the reference (norm_factors over the Steiner vertices share every internal bond): a bond between two region
  * vertices that is not a tree edge (a plaquette's closing bond) is summed over as well -- chi^2 tree contractions per such bond, at
- * most 2^20 terms in all.  ops = one d x d complex128 column-major matrix op[s',s] per region vertex
+ * most 2^16 terms in all (TNQS_ERR_UNSUPPORTED beyond: one closing bond up to chi = 256, two up to chi = 16).  ops = one d x d complex128 column-major matrix op[s',s] per region vertex
  * (identity off the support).  out = {Re, Im numerator, Re, Im denominator}; <O> = coeff * numer / denom. */
 int tnqs_expect_region(tnqs_handle h, int n_region, const int32_t* region_verts, const int32_t* region_parent,
                        const double* ops, double* out_numer_denom);

@@ -375,6 +375,15 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 std::vector<PairItem> sh_pair; std::vector<PairGramItem> sh_gram; std::vector<int> sh_chain;   // shared-T path
                 std::vector<int> is_shared_chain;
                 std::vector<PairGram2Item> sh_dbl; std::vector<std::pair<int, int>> sh_dbl_chain;              // both messages of a forest in one pass
+                // small sites (<= 8192 elements, ComplexF32): the whole message in ONE kernel with the tensor resident in LDS (kernels.hip bp_small_site_kernel);
+                // TNQS_NO_SMALL_SITE_BP=1: the generic chain + Gram route
+                std::vector<SmallMsgItem> small_items; std::vector<int> small_chain; int small_max = 0;
+                static const bool small_on = !envflag("TNQS_NO_SMALL_SITE_BP");
+                auto small_site = [&](int src) {
+                    if (!small_on || !std::is_same<T, float>::value) return false;
+                    const SD sd = site_dims(s, src);
+                    return sd.n >= 64 && bp_small_site_covers(sd.d, sd.z, sd.chi.data(), sd.n);
+                };
                 struct Pend { int idx, jo, r; };                                                                // first message of a (site, T) seen in this level
                 std::unordered_map<long long, Pend> pend;
                 double sh_pair_slices = 0, sh_gram_slices = 0, sh_dbl_slices = 0;
@@ -391,7 +400,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 };
                 if (use_prefix() && !plan.in_place) {
                     std::unordered_map<int, std::vector<int>> outl;            // source site -> legs going out in this sub-batch
-                    auto generic_site = [&](int src, int jo) { return tshare.empty() || site_dims(s, src).z != 4 || partner[src][jo] < 0; };
+                    auto generic_site = [&](int src, int jo) { return (tshare.empty() || site_dims(s, src).z != 4 || partner[src][jo] < 0) && !small_site(src); };
                     for (size_t q = start; q < end; ++q) {
                         int de = plan.seq[lev[q]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
                         if (s->owns(src) && generic_site(src, g.leg(src, dst))) outl[src].push_back(g.leg(src, dst));
@@ -501,6 +510,15 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                         if (!mb) continue;                               // unset message = identity: nothing to absorb
                         want.push_back({j, mb});
                     }
+                    if (small_site(src)) {
+                        SmallMsgItem si{}; si.psi = c.src; si.d = c.sd.d; si.z = c.sd.z; si.jo = jo;
+                        for (int j = 0; j < c.sd.z; ++j) { si.chi[j] = c.sd.chi[j]; si.M[j] = nullptr; }
+                        for (auto& w : want) si.M[w.first] = w.second->p;
+                        small_items.push_back(si); small_chain.push_back((int)chains.size()); small_max = std::max(small_max, (int)c.sd.n);
+                        is_shared_chain.push_back((int)chains.size());
+                        chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(nullptr);
+                        continue;
+                    }
                     const bool from_prefix = c.y != nullptr;             // continues from this level's shared product: that product is remembered, not what follows
                     if (cache_on && !from_prefix) {
                         by_stability(want, src, t); c.ordered = true;
@@ -572,7 +590,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 // again before the join (Pool::set_defer).
                 static const bool bp_split_on = !envflag("TNQS_NO_BP_SPLIT");
                 hipStream_t const main_stream = s->stream;
-                bool has_other = false; for (size_t ci = 0; ci < chains.size(); ++ci) has_other = has_other || !is_shared[ci];
+                bool has_other = !small_items.empty(); for (size_t ci = 0; ci < chains.size(); ++ci) has_other = has_other || !is_shared[ci];
                 const bool split_level = (!sh_pair.empty() || !sh_dbl.empty()) && has_other && g16.empty() && bp_split_on;
                 hipStream_t side_stream = nullptr;
                 if (split_level) {
@@ -599,6 +617,19 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     GramJob j{}; j.X = chains[i].result; j.Y = chains[i].y ? chains[i].y : chains[i].src; j.sd = chains[i].sd; j.leg = g.leg(chains[i].v, dst); j.keep_site = false;
                     j.M = fmsg[i];
                     jobs.push_back(j);
+                }
+                if (!small_items.empty()) {
+                    for (size_t q = 0; q < small_items.size(); ++q) {
+                        GramJob& j = jobs[small_chain[q]];
+                        const int co = small_items[q].chi[small_items[q].jo];
+                        j.nchunks = 1; j.KK = co; j.partial = dalloc(s, (size_t)co * co * esz);
+                        small_items[q].out = j.partial->p;
+                    }
+                    on_side(true);          // (with a split level: next to the bulk sites' plane kernels, like the other boundary-site work; the descriptor copy
+                                            //  travels on the same stream as the kernel that reads it)
+                    const SmallMsgItem* d = upload(s, small_items);
+                    { ProfScope ps(s, TNQS_PROF_BP_FUSED, 0, 0); launch_bp_small_site(s->stream, d, (int)small_items.size(), small_max); }
+                    on_side(false);
                 }
                 if (!sh_dbl.empty()) {
                     // full slices per workgroup pair: the largest power of two that still gives >= 4 workgroups per CU; an item gets groups

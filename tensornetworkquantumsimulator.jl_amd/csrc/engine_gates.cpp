@@ -1074,6 +1074,14 @@ template <class T> static void apply_gates_t(State* s, int ngates, const int32_t
         }
     };
     struct InApply { State* s; explicit InApply(State* st) : s(st) { s->in_apply = true; } ~InApply() { s->in_apply = false; } } in_apply_guard(s);
+    // An optimistic BP update commits its messages with the verdict pending.  Whatever ends this call -- also an error of the batch that follows (a numeric
+    // failure, a negative message eigenvalue) -- the verdict is consumed before the handle is handed back: every other accessor reads messages and
+    // statistics of a FINISHED update (round-4 advisor finding).  The continuation may itself fail: then the first error wins.
+    struct PendingGuard { State* s; const tnqs_bp_opts* bp; ~PendingGuard() {
+        if (!s->bp_pending.active) return;
+        try { if (!resolve_bp(s)) { const int done = s->bp_pending.iters_done; s->bp_pending.active = false; bp_update_t<T>(s, bp, nullptr, nullptr, false, done); } }
+        catch (...) { s->bp_pending.active = false; }
+    } } pending_guard{s, bp};
     for (int i = 0; i < ngates; ++i) {
         const int nv = nverts[i]; const int32_t* vs = verts + voff[i];
         bool need = false;

@@ -64,6 +64,7 @@ TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64
 // TNQS_NO_F64_MFMA=1 (engine_batch.cpp): ComplexF64 mode products on the generic vector kernel instead of the f64 matrix cores (kernels_f64.hip);
 // TNQS_NO_3M=1 (launch_util.hpp): four-multiplication complex product in every MFMA kernel instead of Gauss' three (mfma_common.hpp, CAcc32);
 // TNQS_NO_OPTIMISTIC_BP=1 (engine_bp.cpp): every BP update inside apply_gates waits for its convergence verdict before the next batch is prepared;
+// TNQS_NO_SMALL_SITE_BP=1 (engine_bp.cpp): sites of at most 8192 elements take the generic chain + Gram route instead of the one-kernel LDS-resident message (kernels.hip bp_small_site_kernel);
 // TNQS_NO_BP_SPLIT=1 (engine_bp.cpp): the boundary sites' products and Grams of a BP level on the same stream as the bulk sites' plane kernels instead of next to them;
 // Kernel experiments are NOT in the shipped library: TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP, TNQS_DBG_GRAM_SKIP, TNQS_PAIR_SPW, TNQS_PAIR16_HALF
 // and TNQS_QR2_ALL only exist in a build with -DTNQS_EXPERIMENTS (csrc/build.sh EXPERIMENTS=1); the kernel-level entry points of

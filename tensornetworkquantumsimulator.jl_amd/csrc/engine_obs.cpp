@@ -252,7 +252,9 @@ void expect_region(State* s, int nr, const int32_t* rv, const int32_t* parent, c
         if (a < 0 || b < 0 || parent[a] == b || parent[b] == a) continue;
         cuts.push_back(e); combos *= (double)s->chi[e] * s->chi[e];
     }
-    if (combos > 1048576.0) throw Err(TNQS_ERR_UNSUPPORTED, "expect_region: the region's loops need more than 2^20 terms (product of chi^2 over the bonds that close a loop)");
+    // every term is two region contractions with a read-back each: 2^16 terms are tens of seconds of blocked time, 2^20 (two cut bonds at chi = 32) would be hours
+    // without progress or a way to interrupt (round-4 advisor finding)
+    if (combos > 65536.0) throw Err(TNQS_ERR_UNSUPPORTED, "expect_region: the region's loops need more than 2^16 terms (product of chi^2 over the bonds that close a loop)");
     std::unordered_map<int, Buf> sel;
     const size_t esz = s->esz();
     for (int e : cuts) { sel[e] = dalloc(s, (size_t)s->chi[e] * s->chi[e] * esz); }

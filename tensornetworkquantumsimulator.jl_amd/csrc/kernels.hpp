@@ -42,6 +42,15 @@ struct MsgFinalItem {     // BP epilogue: reduce partials, m /= sum(m), message_
     int normalize;
 };
 
+// BP message of a small site (bp_small_site_kernel): psi in the canonical layout [d][chi_0]..[chi_{z-1}] (<= 8192 elements, every chi <= 32, z <= 8), the message
+// entering through leg k (null: unset = identity; M[jo] is ignored), out = the raw chi_jo x chi_jo message [ket + chi bra]
+struct SmallMsgItem { const void* psi; void* out; const void* M[8]; int chi[8]; int d, z, jo; };
+inline bool bp_small_site_covers(int d, int z, const int* chi, size_t nelem) {
+    if (z < 1 || z > 8 || nelem > 8192 || d < 1) return false;
+    for (int k = 0; k < z; ++k) if (chi[k] > 32) return false;
+    return true;
+}
+void launch_bp_small_site(hipStream_t s, const SmallMsgItem* d_items, int nitems, int max_elems);
 struct JacobiItem {       // one-sided Jacobi on A (m x n, col-major, ld = m); V (n x n) accumulates the rotations (null: not wanted)
     void* A; void* V; int m; int n; int* sweeps_out;
     // dyn != null: the dimensions are decided ON THE DEVICE by an earlier kernel of the same stream (the theta of a gate: ranks of the two
