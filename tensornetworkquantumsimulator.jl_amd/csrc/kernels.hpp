@@ -370,6 +370,7 @@ void launch_mfma_gauge_gram64(hipStream_t s, const GramItem* d_items, int nitems
 bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax, bool all_kk128 = false);   // all_kk128: every item has D * K = 128
 // fused pair of mode products on two slow 32-dim legs (16 companions = 128-byte runs per workgroup)
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs);
+void launch_x3_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs);                  // kernels_x3.hip: the same pass on the bf16 matrix cores
 // workgroups of one PairItem: ceil(nslices / spw) slice ranges in groups of 8, two workgroups (one per 8-companion half) per range
 inline int pair_wgs(int nslices, int spw) { const int np = (nslices + spw - 1) / spw; return 16 * ((np + 7) / 8); }
 // slices per workgroup for a batch of `total_slices`: the largest power of two <= 16 that still gives >= 1024 workgroups
@@ -391,6 +392,7 @@ void launch_mfma_apply64(hipStream_t s, const Apply64Item* d_items, int nitems, 
 //   partial_x[d,d'] = sum (X x_ly My)[.. d on lx ..] conj(Y[.. d' on lx ..])      (message leaving through lx: ly absorbed with My)
 struct PairGram2Item { const void* X; const void* Y; const void* Mx; const void* My; void* partial_y; void* partial_x; PairGeom g; int wg_begin; int spw; };
 void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs);
+void launch_x3_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs);      // kernels_x3.hip: the same pass on the bf16 matrix cores
 int pair_gram2_group();      // workgroups of one group of 8 slice ranges: 32 (a workgroup walks one quarter of each slice)
 // last absorption + Gram on two arbitrary 32-dim legs (absorbed leg x, kept leg y), reading a (cached) pair product X and psi = Y
 void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitems, int total_wgs);

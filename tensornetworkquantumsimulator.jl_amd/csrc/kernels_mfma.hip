@@ -782,6 +782,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
+    if (mfma_use_x3()) { launch_x3_pair(s, d_items, nitems, total_wgs); return; }
     const size_t lds = (size_t)16 * (32 * 33 + 4) * 2 * sizeof(float);
     if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_pair_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
     else { set_max_dynamic_lds((const void*)mfma_pair_kernel<false>, lds); hipLaunchKernelGGL(mfma_pair_kernel<false>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
@@ -1068,9 +1069,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     #undef TNQS_PIN
 }
-int pair_gram2_group() { return 32; }
+int x3_pair_gram2_group();
+int pair_gram2_group() { return mfma_use_x3() ? x3_pair_gram2_group() : 32; }
 void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
+    if (mfma_use_x3()) { launch_x3_pair_gram2(s, d_items, nitems, total_wgs); return; }
     const size_t lds = (size_t)16 * (32 * 33 + 8) * 2 * sizeof(float);
     if (mfma_use_3m()) {
         set_max_dynamic_lds((const void*)mfma_pair_gram2_kernel<true>, lds);

@@ -1,0 +1,395 @@
+// kernels_x3.hip -- the chi = 32 plane kernels of the BP level with the f32 products carried by the bf16 matrix cores (round 5).
+//
+// v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate (64 cycles per SIMD for 4096 multiply-adds); v_mfma_f32_32x32x16_bf16 multiplies
+// 32768 bf16 pairs in 32 cycles -- sixteen times the rate, products exact (8 x 8 significand bits), accumulation in f32 exactly as the f32
+// instruction accumulates.  An f32 number IS the sum of three bf16 numbers:
+//      x = h + m + l,   h = x truncated to its leading 8 significand bits,  m = (x - h) truncated likewise,  l = x - h - m   (all exact: 8 + 8 + 8 = 24 bits)
+// so an f32 product is the sum of nine exact bf16 products; the three smallest ones (m l, l m, l l: <= 2^-24 |x y|, the size of ONE f32 rounding
+// of the product) are dropped, the other six are accumulated in f32:
+//      x y  =  h h' + (h m' + m h') + (m m' + h l' + l h')  +  O(2^-24 |x y|)
+// i.e. an f32 multiply-add chain with the product rounded to 24 bits before it is added -- the error model of an UNFUSED f32 multiply-add, normwise
+// the same class as the three-multiplication f32 product this replaces (mfma_common.hpp).  Six bf16 instructions of 32 cycles replace sixteen f32
+// instructions of 64 (k = 16 against k = 2): 5.3 x the matrix rate per real product; with the textbook four real products per complex one (no operand
+// sums to split) 4 x 6 x 32 = 768 cycles per 16 complex k against 3 x 8 x 64 = 1536 of the 3M f32 route.  The splitting costs 5.5 vector
+// instructions per f32 value (and, subtract, and, subtract, 1.5 byte-permutes to pack pairs), on the VALU next to the matrix pipe.
+// The kernels keep the data movement of the f32 kernels they replace (kernels_mfma.hip); with the matrix time halved they are bound by HBM.
+// TNQS_NO_BF16X3=1 selects the f32 kernels.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#define TNQS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP kernel launch failed (") + __func__ + "): " + hipGetErrorString(e_)); } while (0)
+#include "kernels.hpp"
+#include "mfma_common.hpp"
+#include "launch_util.hpp"
+
+namespace tnqs {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+// eight k-slots of one real MFMA operand as three bf16 pieces; slots (2 i, 2 i + 1) share register i
+struct P3 { u4 h, m, l; };
+
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                                   // (upper half of x1, upper half of x0)
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u); // <= 8 significant bits left: exact
+}
+template <int MODE = 0>
+__device__ __forceinline__ P3 split8(const float (&x)[8]) {
+    P3 p;
+    if (MODE == 1 || MODE >= 3) {        // timing experiment: no splitting
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { p.h[i] = __float_as_uint(x[2 * i]); p.m[i] = __float_as_uint(x[2 * i + 1]); p.l[i] = __float_as_uint(x[i]); }
+        return p;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { unsigned h, m, l; split_pair(x[2 * i], x[2 * i + 1], h, m, l); p.h[i] = h; p.m[i] = m; p.l[i] = l; }
+    return p;
+}
+__device__ __forceinline__ P3 neg(const P3& a) {
+    P3 p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { p.h[i] = a.h[i] ^ 0x80008000u; p.m[i] = a.m[i] ^ 0x80008000u; p.l[i] = a.l[i] ^ 0x80008000u; }
+    return p;
+}
+#define TNQS_BF(A, B, ACC) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, A), __builtin_bit_cast(bf8, B), ACC, 0, 0, 0)
+// two independent accumulators side by side (no instruction depends on the one in front of it):  p += a b,  q += c d,  six products each, small terms first
+template <bool FIRST, int MODE = 0>
+__device__ __forceinline__ void mac6x2(v16f& p, const P3& a, const P3& b, v16f& q, const P3& c, const P3& d) {
+    const v16f z = (v16f)(0.f);
+    if (MODE == 2) {        // timing experiment: no matrix instructions, the pieces stay alive
+        if (FIRST) { p = z; q = z; }
+        p[0] += __uint_as_float(a.h[0] ^ a.m[1] ^ a.l[2] ^ b.h[3] ^ b.m[0] ^ b.l[1]);
+        q[0] += __uint_as_float(c.h[0] ^ c.m[1] ^ c.l[2] ^ d.h[3] ^ d.m[0] ^ d.l[1]);
+        return;
+    }
+    p = TNQS_BF(a.l, b.h, FIRST ? z : p); q = TNQS_BF(c.l, d.h, FIRST ? z : q);
+    p = TNQS_BF(a.h, b.l, p);             q = TNQS_BF(c.h, d.l, q);
+    p = TNQS_BF(a.m, b.m, p);             q = TNQS_BF(c.m, d.m, q);
+    p = TNQS_BF(a.m, b.h, p);             q = TNQS_BF(c.m, d.h, q);
+    p = TNQS_BF(a.h, b.m, p);             q = TNQS_BF(c.h, d.m, q);
+    p = TNQS_BF(a.h, b.h, p);             q = TNQS_BF(c.h, d.h, q);
+}
+
+__device__ __forceinline__ long long x3_slice_base(const PairGeom& g, int sl) {
+    int a0 = sl % g.n0; int r1 = sl / g.n0; int a1 = r1 % g.n1; int a2 = r1 / g.n1;
+    return (long long)a0 * g.t0 + (long long)a1 * g.t1 + (long long)a2 * g.t2;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// BOTH messages a degree-4 site sends into a linear forest (the pass of mfma_pair_gram2_kernel, kernels_mfma.hip: same items, same partials):
+//      step 1  C[j'][kept] = sum_k M[k][j'] X[k][kept]      step 2  O[kept][kept'] += sum_j' C[j'][kept] conj Y[j'][kept']
+// HALF slices: a workgroup takes 8 of a slice's 16 companions per phase (workgroups lw and lw + 8 of a group of 16 sit on the same XCD and take the two
+// 64-byte halves of every line at the same time) -- the f32 kernel walks quarters (32-byte pieces), and with the matrix time halved it is the number of
+// memory requests in flight, not the matrix pipe, that bounds the pass (measured: 3.1 TB/s with quarters and the matrix instructions removed).  The 16 planes
+// of a phase (8 X + 8 Y, 137 KiB) fill the LDS ONCE; the next phase's planes wait in registers (16 x 16 bytes per thread, issued at the start of the phase:
+// a whole phase to arrive) and are committed between two barriers.  Wave w: message m = w >> 2, companions (w & 3) and (w & 3) + 4, one after the other.
+// One v_mfma_f32_32x32x16_bf16 covers sixteen k: lane (ln, h) supplies eight of them,
+//      step 1:  k  = 16 n + 8 h + e                       (n = 0, 1: the instruction, e = 0..7 the slot): eight CONSECUTIVE plane elements
+//      step 2:  j' = 4 h + 8 (2 n + (e >> 2)) + (e & 3)   = the rows of C this lane's accumulator registers 8 n + e hold -- C never leaves the registers
+// M lives in registers as split A operands (48 registers); X, Y and C are split on the fly.  Planes in LDS with an EVEN pitch (34) so that a lane's
+// eight consecutive elements are four aligned 16-byte reads (message 0; message 1 reads the same planes transposed, 8-byte reads along the lanes).
+// ------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void x3_pair_gram2_kernel(const PairGram2Item* __restrict__ items, int nitems) {
+    constexpr int P = 34;                      // row pitch in complex elements
+    constexpr int PS = 32 * P + 2;             // plane stride: X planes of companions 0..7, then their Y planes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2f* L = reinterpret_cast<v2f*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
+    int lo = 0, hi_ = nitems - 1;
+    const int gw = blockIdx.x;
+    while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].wg_begin <= gw) lo = mid; else hi_ = mid - 1; }
+    const PairGram2Item it = items[lo];
+    const PairGeom g = it.g;
+    const int nslices = g.n0 * g.n1 * g.n2;
+    const int lw = gw - it.wg_begin;                        // wg_begin is a multiple of 16
+    const int half = (lw >> 3) & 1, pw = ((lw >> 4) << 3) | (lw & 7);
+    const int s_begin = pw * it.spw, s_end = min(nslices, s_begin + it.spw);
+    const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
+    const cf* __restrict__ Yg = reinterpret_cast<const cf*>(it.Y);
+    const int comp = w & 3, msg = w >> 2;
+    // A operands of step 1: A[i = j' = ln][k] = M[k + 32 ln], k = 16 n + 8 h + e
+    P3 Mr[2], Mi[2];
+    {
+        const cf* __restrict__ M = reinterpret_cast<const cf*>(msg ? it.My : it.Mx) + 32 * ln + 8 * h;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float xr[8], xi[8];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) { const v4f v = ldg4(M + 16 * n + e); xr[e] = v[0]; xi[e] = v[1]; xr[e + 1] = v[2]; xi[e + 1] = v[3]; }
+            Mr[n] = split8<MODE>(xr); Mi[n] = split8<MODE>(xi);
+        }
+    }
+    // mover: thread -> (companion pair f4 = 0..3 of the half, first segment sg0 = 0..127); segment j: ix = sg0 & 31, iy = (sg0 >> 5) + 4 j
+    const int f4 = tid & 3, sg0 = tid >> 2;
+    const int ix0 = sg0 & 31, iy0 = sg0 >> 5;
+    const long long toff = (long long)(4 * half + f4) * g.cstr + g.sx * ix0 + g.sy * iy0, tstr = 4 * g.sy;
+    v2f* const lbase = L + (2 * f4) * PS + iy0 * P + ix0;                // element (ix, iy) at [iy][ix]
+    v4f px[8], py[8];
+    auto commit = [&]() {
+        if (MODE >= 3) return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v2f* p0 = lbase + 4 * P * j;                                 // iy advances by 4 per j
+            v2f a; a[0] = px[j][0]; a[1] = px[j][1]; v2f b; b[0] = px[j][2]; b[1] = px[j][3];
+            p0[0] = a; p0[PS] = b;
+            v2f c; c[0] = py[j][0]; c[1] = py[j][1]; v2f d; d[0] = py[j][2]; d[1] = py[j][3];
+            p0[8 * PS] = c; p0[9 * PS] = d;
+        }
+    };
+    v16f Or, Oi;                               // O_re = sum Cr Yr + Ci Yi;  O_im = sum Ci Yr + (-Cr) Yi
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { Or[r] = 0.f; Oi[r] = 0.f; }
+    if (s_begin < s_end) {
+        const long long b = x3_slice_base(g, s_begin) + toff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { px[j] = ldg4(Xg + b + tstr * j); py[j] = ldg4(Yg + b + tstr * j); }
+        commit();
+    }
+    lds_barrier();
+    auto run = [&](auto msg_c) {
+    constexpr int MSG = decltype(msg_c)::value;
+    // eight plane elements (index i0 .. i0 + 3 and i1 .. i1 + 3 along the contracted direction) of the kept index ln: message 0 reads rows, message 1 columns
+    auto read8 = [&](const v2f* PL, int i0, int i1, float (&re)[8], float (&im)[8]) {
+        if (MODE == 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { re[e] = __int_as_float(i0 + e + ln); im[e] = __int_as_float(i1 + e); }
+            return;
+        }
+        if (MSG == 0) {
+            const v4f* a = reinterpret_cast<const v4f*>(PL + ln * P + i0); const v4f* b = reinterpret_cast<const v4f*>(PL + ln * P + i1);
+            const v4f a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+            re[0] = a0[0]; im[0] = a0[1]; re[1] = a0[2]; im[1] = a0[3]; re[2] = a1[0]; im[2] = a1[1]; re[3] = a1[2]; im[3] = a1[3];
+            re[4] = b0[0]; im[4] = b0[1]; re[5] = b0[2]; im[5] = b0[3]; re[6] = b1[0]; im[6] = b1[1]; re[7] = b1[2]; im[7] = b1[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const v2f u = PL[(i0 + e) * P + ln], v = PL[(i1 + e) * P + ln]; re[e] = u[0]; im[e] = u[1]; re[4 + e] = v[0]; im[4 + e] = v[1]; }
+        }
+    };
+    for (int sl = s_begin; sl < s_end; ++sl) {
+        const bool more = sl + 1 < s_end;
+        const long long nb = x3_slice_base(g, more ? sl + 1 : sl) + toff;          // (the last phase re-reads its own slice: no branch in the stream)
+        float ar[8], ai[8], br[8], bi[8];
+        read8(L + comp * PS, 8 * h, 8 * h + 4, ar, ai);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const v2f* PX = L + (comp + 4 * t) * PS; const v2f* PY = PX + 8 * PS;
+            // ---- step 1: C[j'][kept] = sum_k M[k][j'] X[k][kept] -------------------------------------------------------------------------
+            v16f Cr, Ci;
+            read8(PX, 16 + 8 * h, 16 + 8 * h + 4, br, bi);
+            if (t == 0 && MODE < 3) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { px[j] = ldg4(Xg + nb + tstr * j); py[j] = ldg4(Yg + nb + tstr * j); }
+            }
+            {
+                const P3 xr = split8<MODE>(ar), xi = split8<MODE>(ai);
+                mac6x2<true, MODE>(Cr, Mr[0], xr, Ci, Mr[0], xi);
+                mac6x2<false, MODE>(Cr, Mi[0], neg(xi), Ci, Mi[0], xr);
+            }
+            read8(PY, 4 * h, 4 * h + 8, ar, ai);                                         // first operands of step 2
+            if (t == 0 && MODE < 3) {
+#pragma unroll
+                for (int j = 2; j < 4; ++j) { px[j] = ldg4(Xg + nb + tstr * j); py[j] = ldg4(Yg + nb + tstr * j); }
+            }
+            {
+                const P3 xr = split8<MODE>(br), xi = split8<MODE>(bi);
+                mac6x2<false, MODE>(Cr, Mr[1], xr, Ci, Mr[1], xi);
+                mac6x2<false, MODE>(Cr, Mi[1], neg(xi), Ci, Mi[1], xr);
+            }
+            // ---- step 2: O[kept][kept'] += sum_j' C[j'][kept] conj Y[j'][kept'] ----------------------------------------------------------
+            read8(PY, 16 + 4 * h, 16 + 4 * h + 8, br, bi);
+            if (t == 0 && MODE < 3) {
+#pragma unroll
+                for (int j = 4; j < 6; ++j) { px[j] = ldg4(Xg + nb + tstr * j); py[j] = ldg4(Yg + nb + tstr * j); }
+            }
+            {
+                float cr[8], ci[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { cr[e] = Cr[e]; ci[e] = Ci[e]; }
+                const P3 pcr = split8<MODE>(cr), pci = split8<MODE>(ci), yr = split8<MODE>(ar), yi = split8<MODE>(ai);
+                mac6x2<false, MODE>(Or, pcr, yr, Oi, pci, yr);
+                mac6x2<false, MODE>(Or, pci, yi, Oi, neg(pcr), yi);
+            }
+            if (t == 0 && MODE < 3) {
+#pragma unroll
+                for (int j = 6; j < 8; ++j) { px[j] = ldg4(Xg + nb + tstr * j); py[j] = ldg4(Yg + nb + tstr * j); }
+            }
+            if (t == 0) read8(L + (comp + 4) * PS, 8 * h, 8 * h + 4, ar, ai);            // first operands of the second companion
+            {
+                float cr[8], ci[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { cr[e] = Cr[8 + e]; ci[e] = Ci[8 + e]; }
+                const P3 pcr = split8<MODE>(cr), pci = split8<MODE>(ci), yr = split8<MODE>(br), yi = split8<MODE>(bi);
+                mac6x2<false, MODE>(Or, pcr, yr, Oi, pci, yr);
+                mac6x2<false, MODE>(Or, pci, yi, Oi, neg(pcr), yi);
+            }
+        }
+        lds_barrier();                                                  // every wave has read its planes
+        if (more) commit();
+        lds_barrier();
+    }
+    };
+    if (msg == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+    // one partial per workgroup and message: the four waves of a message are summed through the (now free) planes
+    cf* __restrict__ p1 = reinterpret_cast<cf*>(it.partial_y) + (size_t)lw * 1024;
+    cf* __restrict__ p2 = reinterpret_cast<cf*>(it.partial_x) + (size_t)lw * 1024;
+    v2f* const R = L;                                           // 8 blocks of 32 x 33
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        v2f v; v[0] = Or[r]; v[1] = Oi[r];
+        R[w * (32 * 33) + ln * 33 + i] = v;                     // element (i, j = ln)
+    }
+    lds_barrier();
+    for (int e = tid; e < 2048; e += 512) {
+        const int mm = e >> 10, ee = e & 1023, i = ee & 31, j = ee >> 5;
+        float sr = 0.f, si = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { const v2f v = R[(4 * mm + ww) * (32 * 33) + j * 33 + i]; sr += v[0]; si += v[1]; }
+        cf o; o.re = sr; o.im = si; stgc((mm ? p2 : p1) + ee, o);
+    }
+}
+int x3_pair_gram2_group() { return 16; }
+void launch_x3_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs) {
+    if (total_wgs <= 0) return;
+    const size_t lds = (size_t)16 * (32 * 34 + 2) * 2 * sizeof(float);
+    static const int mode = [] { const char* e = std::getenv("TNQS_X3_MODE"); return e ? std::atoi(e) : 0; }();
+    if (mode == 1) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<1>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<1>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    else if (mode == 2) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<2>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<2>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    else if (mode == 3) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<3>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<3>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    else if (mode == 4) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<4>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<4>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    else { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<0>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<0>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    TNQS_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pair of mode products on two 32-dimensional legs in one pass (mfma_pair_kernel, kernels_mfma.hip: same items, same workgroup -> half-slice map, same
+// movers and double buffering, one barrier per phase):
+//   step 1  Y[iy][jx] = sum_ix S[ix][iy] Mx[ix][jx]      A = S^T from LDS: lane (ln = iy, h) reads ix = 16 n + 8 h + e, eight consecutive elements of row iy
+//   step 2  S'[jx][jy] = sum_iy Y[iy][jx] My[iy][jy]      A = Y's accumulator registers 8 n + e (iy = 4 h + 8 (2 n + (e >> 2)) + (e & 3)), split on the fly
+// Both matrices live in registers as split B operands (96 registers).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void x3_pair_kernel(const PairItem* __restrict__ items, int nitems) {
+    constexpr int P = 34;
+    constexpr int PS = 32 * P + 2;             // plane stride in complex elements
+    constexpr int BUF = 8 * PS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2f* L = reinterpret_cast<v2f*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
+    int lo = 0, hi_ = nitems - 1;
+    const int gw = blockIdx.x;
+    while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].slice_begin <= gw) lo = mid; else hi_ = mid - 1; }
+    const PairItem it = items[lo];
+    const PairGeom g = it.g;
+    const int nslices = g.n0 * g.n1 * g.n2;
+    const int lw = gw - it.slice_begin;                     // slice_begin is a multiple of 16
+    const int half = (lw >> 3) & 1, pw = ((lw >> 4) << 3) | (lw & 7);
+    const int s_begin = pw * it.spw, s_end = min(nslices, s_begin + it.spw);
+    const cf* __restrict__ in = reinterpret_cast<const cf*>(it.in);
+    cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
+    // B operands: Mx[k = ix][j = ln] at ix + 32 ln, ix = 16 n + 8 h + e;  My[k = iy][j = ln], iy = 4 h + 16 n + 8 (e >> 2) + (e & 3)
+    P3 Mxr[2], Mxi[2], Myr[2], Myi[2];
+    {
+        const cf* __restrict__ Mx = reinterpret_cast<const cf*>(it.Mx) + 32 * ln; const cf* __restrict__ My = reinterpret_cast<const cf*>(it.My) + 32 * ln;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float xr[8], xi[8];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) { const v4f v = ldg4(Mx + 16 * n + 8 * h + e); xr[e] = v[0]; xi[e] = v[1]; xr[e + 1] = v[2]; xi[e + 1] = v[3]; }
+            Mxr[n] = split8(xr); Mxi[n] = split8(xi);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) { const v4f v = ldg4(My + 4 * h + 16 * n + 8 * (e >> 2) + (e & 3)); xr[e] = v[0]; xi[e] = v[1]; xr[e + 1] = v[2]; xi[e + 1] = v[3]; }
+            Myr[n] = split8(xr); Myi[n] = split8(xi);
+        }
+    }
+    // mover: thread -> (companion pair f4 = 0..3 of the half, first segment sg0 = 0..127); segment j: ix = sg0 & 31, iy = (sg0 >> 5) + 4 j
+    const int f4 = tid & 3, sg0 = tid >> 2;
+    const int ix0 = sg0 & 31, iy0 = sg0 >> 5;
+    const long long toff = (long long)(4 * half + f4) * g.cstr + g.sx * ix0 + g.sy * iy0, tstr = 4 * g.sy;
+    v2f* const lbase = L + (2 * f4) * PS + iy0 * P + ix0;            // element (ix, iy) of a plane at [iy][ix]; iy advances by 4 per j
+    v4f pre[8];
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v2f* p0 = lbase + buf * BUF + 4 * P * j;
+            v2f a; a[0] = pre[j][0]; a[1] = pre[j][1]; v2f b; b[0] = pre[j][2]; b[1] = pre[j][3];
+            p0[0] = a; p0[PS] = b;
+        }
+    };
+    auto store1 = [&](int buf, long long ob, int j) {            // one 16-byte piece of a finished phase: LDS -> global
+        const v2f* p0 = lbase + buf * BUF + 4 * P * j;
+        const v2f a = p0[0], c = p0[PS];
+        v4f v; v[0] = a[0]; v[1] = a[1]; v[2] = c[0]; v[3] = c[1];
+        stg4(out + ob + tstr * j, v);
+    };
+    if (s_begin < s_end) {
+        const long long b = x3_slice_base(g, s_begin) + toff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pre[j] = ldg4(in + b + tstr * j);
+        commit(0);
+    }
+    lds_barrier();
+    for (int sl = s_begin; sl < s_end; ++sl) {
+        const int buf = (sl - s_begin) & 1;
+        const bool more = sl + 1 < s_end, prev = sl > s_begin;
+        const long long nb = x3_slice_base(g, more ? sl + 1 : sl) + toff;      // (the last phase re-reads its own slice: no branch in the stream)
+        const long long ob = x3_slice_base(g, prev ? sl - 1 : sl) + toff;
+        v2f* Pw = L + buf * BUF + w * PS;
+        // ---- step 1 ---------------------------------------------------------------------------------------------------------------
+        v16f Yr, Yi;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float ar[8], ai[8];
+            const v4f* a = reinterpret_cast<const v4f*>(Pw + ln * P + 16 * n + 8 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const v4f v = a[q]; ar[2 * q] = v[0]; ai[2 * q] = v[1]; ar[2 * q + 1] = v[2]; ai[2 * q + 1] = v[3]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pre[4 * n + j] = ldg4(in + nb + tstr * (4 * n + j));
+            const P3 sr = split8(ar), si = split8(ai), nsi = neg(si);
+            if (n == 0) mac6x2<true>(Yr, sr, Mxr[n], Yi, sr, Mxi[n]); else mac6x2<false>(Yr, sr, Mxr[n], Yi, sr, Mxi[n]);
+            mac6x2<false>(Yr, nsi, Mxi[n], Yi, si, Mxr[n]);
+        }
+        // ---- step 2 (and the previous phase's plane on its way out) -----------------------------------------------------------------
+        v16f Sr, Si;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float yr[8], yi[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { yr[e] = Yr[8 * n + e]; yi[e] = Yi[8 * n + e]; }
+            const P3 pr = split8(yr), pi = split8(yi), npi = neg(pi);
+            if (prev) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) store1(buf ^ 1, ob, 4 * n + j);
+            }
+            if (n == 0) mac6x2<true>(Sr, pr, Myr[n], Si, pr, Myi[n]); else mac6x2<false>(Sr, pr, Myr[n], Si, pr, Myi[n]);
+            mac6x2<false>(Sr, npi, Myi[n], Si, pi, Myr[n]);
+        }
+        // S'[jx = (r & 3) + 8 (r >> 2) + 4 h][jy = ln] -> LDS [jy][jx] (the plane is private to this wave; its reads are complete)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) { const int jx = (r & 3) + 8 * (r >> 2) + 4 * h; v4f v; v[0] = Sr[r]; v[1] = Si[r]; v[2] = Sr[r + 1]; v[3] = Si[r + 1]; *reinterpret_cast<v4f*>(Pw + ln * P + jx) = v; }
+        if (more) commit(buf ^ 1);                // over the locations this thread stored from above
+        lds_barrier();
+    }
+    if (s_begin < s_end) {                         // the last phase's plane
+        const int buf = (s_end - 1 - s_begin) & 1;
+        const long long ob = x3_slice_base(g, s_end - 1) + toff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) store1(buf, ob, j);
+    }
+}
+void launch_x3_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs) {
+    if (total_wgs <= 0) return;
+    const size_t lds = (size_t)16 * (32 * 34 + 2) * 2 * sizeof(float);
+    set_max_dynamic_lds((const void*)x3_pair_kernel, lds);
+    hipLaunchKernelGGL(x3_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
+    TNQS_CHECK_LAUNCH();
+}
+
+}  // namespace tnqs
