@@ -43,7 +43,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsi
 template <int MODE = 0>
 __device__ __forceinline__ P3 split8(const float (&x)[8]) {
     P3 p;
-    if (MODE == 1 || MODE >= 3) {        // timing experiment: no splitting
+    if (MODE == 1 || MODE == 3 || MODE == 4) {        // timing experiment: no splitting
 #pragma unroll
         for (int i = 0; i < 4; ++i) { p.h[i] = __float_as_uint(x[2 * i]); p.m[i] = __float_as_uint(x[2 * i + 1]); p.l[i] = __float_as_uint(x[i]); }
         return p;
@@ -100,6 +100,9 @@ template <int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void x3_pair_gram2_kernel(const PairGram2Item* __restrict__ items, int nitems) {
     constexpr int P = 34;                      // row pitch in complex elements
     constexpr int PS = 32 * P + 2;             // plane stride: X planes of companions 0..7, then their Y planes
+    // scheduling barrier: VALU / SALU may cross; LDS, global-memory and matrix instructions keep their program order (left to itself the compiler sinks the
+    // global loads to the end of the phase, directly in front of the commit that waits for them, and the LDS reads directly in front of their first use)
+    #define TNQS_PIN() __builtin_amdgcn_sched_barrier(0x2 | 0x4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v2f* L = reinterpret_cast<v2f*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     v2f* const lbase = L + (2 * f4) * PS + iy0 * P + ix0;                // element (ix, iy) at [iy][ix]
     v4f px[8], py[8];
     auto commit = [&]() {
-        if (MODE >= 3) return;
+        if (MODE == 3 || MODE == 4) return;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             v2f* p0 = lbase + 4 * P * j;                                 // iy advances by 4 per j
@@ -178,26 +181,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const long long nb = x3_slice_base(g, more ? sl + 1 : sl) + toff;          // (the last phase re-reads its own slice: no branch in the stream)
         float ar[8], ai[8], br[8], bi[8];
         read8(L + comp * PS, 8 * h, 8 * h + 4, ar, ai);
+        if (MODE == 5) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { px[j] = ldg4(Xg + nb + tstr * j); py[j] = ldg4(Yg + nb + tstr * j); }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const v2f* PX = L + (comp + 4 * t) * PS; const v2f* PY = PX + 8 * PS;
             // ---- step 1: C[j'][kept] = sum_k M[k][j'] X[k][kept] -------------------------------------------------------------------------
             v16f Cr, Ci;
             read8(PX, 16 + 8 * h, 16 + 8 * h + 4, br, bi);
-            if (t == 0 && MODE < 3) {
+            if (t == 0 && (MODE < 3)) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) { px[j] = ldg4(Xg + nb + tstr * j); py[j] = ldg4(Yg + nb + tstr * j); }
             }
+            TNQS_PIN();
             {
                 const P3 xr = split8<MODE>(ar), xi = split8<MODE>(ai);
                 mac6x2<true, MODE>(Cr, Mr[0], xr, Ci, Mr[0], xi);
                 mac6x2<false, MODE>(Cr, Mi[0], neg(xi), Ci, Mi[0], xr);
             }
             read8(PY, 4 * h, 4 * h + 8, ar, ai);                                         // first operands of step 2
-            if (t == 0 && MODE < 3) {
+            if (t == 0 && (MODE < 3)) {
 #pragma unroll
                 for (int j = 2; j < 4; ++j) { px[j] = ldg4(Xg + nb + tstr * j); py[j] = ldg4(Yg + nb + tstr * j); }
             }
+            TNQS_PIN();
             {
                 const P3 xr = split8<MODE>(br), xi = split8<MODE>(bi);
                 mac6x2<false, MODE>(Cr, Mr[1], xr, Ci, Mr[1], xi);
@@ -205,10 +214,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             // ---- step 2: O[kept][kept'] += sum_j' C[j'][kept] conj Y[j'][kept'] ----------------------------------------------------------
             read8(PY, 16 + 4 * h, 16 + 4 * h + 8, br, bi);
-            if (t == 0 && MODE < 3) {
+            if (t == 0 && (MODE < 3)) {
 #pragma unroll
                 for (int j = 4; j < 6; ++j) { px[j] = ldg4(Xg + nb + tstr * j); py[j] = ldg4(Yg + nb + tstr * j); }
             }
+            TNQS_PIN();
             {
                 float cr[8], ci[8];
 #pragma unroll
@@ -217,11 +227,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 mac6x2<false, MODE>(Or, pcr, yr, Oi, pci, yr);
                 mac6x2<false, MODE>(Or, pci, yi, Oi, neg(pcr), yi);
             }
-            if (t == 0 && MODE < 3) {
+            if (t == 0 && (MODE < 3)) {
 #pragma unroll
                 for (int j = 6; j < 8; ++j) { px[j] = ldg4(Xg + nb + tstr * j); py[j] = ldg4(Yg + nb + tstr * j); }
             }
             if (t == 0) read8(L + (comp + 4) * PS, 8 * h, 8 * h + 4, ar, ai);            // first operands of the second companion
+            TNQS_PIN();
             {
                 float cr[8], ci[8];
 #pragma unroll
@@ -231,6 +242,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 mac6x2<false, MODE>(Or, pci, yi, Oi, neg(pcr), yi);
             }
         }
+        TNQS_PIN();
         lds_barrier();                                                  // every wave has read its planes
         if (more) commit();
         lds_barrier();
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         cf o; o.re = sr; o.im = si; stgc((mm ? p2 : p1) + ee, o);
     }
 }
+#undef TNQS_PIN
 int x3_pair_gram2_group() { return 16; }
 void launch_x3_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
@@ -264,6 +277,7 @@ void launch_x3_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitem
     if (mode == 1) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<1>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<1>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
     else if (mode == 2) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<2>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<2>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
     else if (mode == 3) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<3>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<3>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    else if (mode == 5) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<5>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<5>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
     else if (mode == 4) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<4>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<4>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
     else { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<0>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<0>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
     TNQS_CHECK_LAUNCH();
