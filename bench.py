@@ -111,6 +111,7 @@ def profile_db(name):
 
 
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix (= vector) peak
+PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -266,14 +267,20 @@ def main():
                  "gate_modeprod": "tnqs::mfma_pair_kernel" + tf, "bp_fused": "tnqs::mfma_gram32_fused_kernel",
                  "bp_gram": "tnqs::mfma_gram32_kernel", "gate_gram": "tnqs::mfma_gram64_f64_kernel<%s, true>" % ("true" if m3 else "false"),
                  "gate_apply": "tnqs::mfma_rowgemm_kernel<2, 2, 2, %s>" % ("true" if m3 else "false"), "bp_pairgram": "tnqs::mfma_pair_gram2_kernel" + tf}
+    # round 5: the chi = 32 plane kernels carry their f32 products on the bf16 matrix cores (csrc/kernels_x3.hip: every f32 operand is the exact sum of three
+    # bf16 pieces, six of the nine piece products are kept -- the dropped ones are below one f32 rounding of the product -- and accumulated in f32)
+    x3 = os.environ.get("TNQS_NO_BF16X3") != "1"
+    X3_CLASSES = ("bp_pair", "bp_pairgram", "gate_modeprod") if x3 else ()
+    if x3:
+        KERNEL_OF.update({"bp_pair": "tnqs::x3_pair_kernel", "gate_modeprod": "tnqs::x3_pair_kernel", "bp_pairgram": "tnqs::x3_pair_gram2_kernel<0>"})
     if cfg == "c4":
         KERNEL_OF.update({"bp_pair": "tnqs::mfma_pair16_kernel / tnqs::mfma_pair16w_kernel", "gate_modeprod": "tnqs::mfma_pair16_kernel / tnqs::mfma_pair16w_kernel",
                           "bp_pairgram": "tnqs::mfma_pair_gram2x16_kernel", "gate_gram": "tnqs::mfma_gauge_gram32_kernel"})
     elif cfg == "c5":
         KERNEL_OF.update({"bp_modeprod": "tnqs::mfma_rowgemm_kernel<2, 2, 1>", "gate_modeprod": "tnqs::mfma_rowgemm_kernel<2, 2, 1>", "bp_gram": "tnqs::mfma_gram64_kernel",
                           "gate_gram": "tnqs::mfma_gram128_f64_kernel", "gate_apply": "tnqs::mfma_rowgemm_kernel<4, 4, 2>"})
-    traffic_db, traffic_src = profile_db(os.environ.get("TNQS_BENCH_PMC_PROFILE", "r4_pmc_traffic.json"))
-    mfma_db, mfma_src = profile_db(os.environ.get("TNQS_BENCH_MFMA_PROFILE", "r4_mfma_util.json"))
+    traffic_db, traffic_src = profile_db(os.environ.get("TNQS_BENCH_PMC_PROFILE", "r5_pmc_traffic.json"))
+    mfma_db, mfma_src = profile_db(os.environ.get("TNQS_BENCH_MFMA_PROFILE", "r5_mfma_util.json"))
     dom = max(prof, key=lambda k: prof[k]["ms"])
     p = prof[dom]
     roofline = None
@@ -298,7 +305,18 @@ def main():
                   "executed_over_peak": round((0.75 if m3 else 1.0) * tflops / PEAK_F32_TFLOPS, 4),
                   # `traffic`, `mfma_busy`, `mfma_executed_TFLOPs` are NOT measured in this run: they are read from the committed counter passes
                   "from_profile": {"traffic": traffic_src, "mfma": mfma_src}}
-        if ai < PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+        if dom in X3_CLASSES and cfg == "c2":
+            # bf16 x 3 kernels: four real products per complex one (no Gauss trick: its operand sums would have to be split too), six bf16 instructions per
+            # real product -> the matrix cores execute 6 x the algorithmic count in bf16; what bounds an f32 product on this pipe is 2500 / 6 = 417 TFLOP/s
+            exe = 6.0 * tflops
+            common.update({"complex_product": "4M, every real product = six exact bf16 products (csrc/kernels_x3.hip)", "executed_over_peak": round(exe / PEAK_BF16_TFLOPS, 4),
+                           "executed_bf16_TFLOPs": round(exe, 1), "f32_equivalent_peak_TFLOPs": round(PEAK_BF16_TFLOPS / 6.0, 1)})
+            if ai < (PEAK_BF16_TFLOPS / 6.0) * 1e12 / (PEAK_HBM_GBS * 1e9):
+                roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), **common}
+            else:
+                roofline = {"bound": "mfma", "achieved": round(exe, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(exe / PEAK_BF16_TFLOPS, 4),
+                            "hbm_frac": round(gbs / PEAK_HBM_GBS, 4), **common}
+        elif ai < PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
             roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), **common}
         else:
             roofline = {"bound": "mfma", "achieved": round(tflops, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_F32_TFLOPS, 4), **common}
@@ -326,7 +344,8 @@ def main():
     out = {"metric": "two-site gates/sec at fixed chi (LxL TFIM Trotter layer)", "value": round(value, 2),
            "unit": "two-site gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "c64 (ComplexF32; Gram/eigen steps in f64)", "data": "synthetic",
+           "dtype": ("c64 (ComplexF32; Gram/eigen steps in f64; the chi = 32 plane products as exact bf16 x 3 splits with f32 accumulation, TNQS_NO_BF16X3=1 for f32 matrix instructions)"
+                     if x3 and cfg == "c2" else "c64 (ComplexF32; Gram/eigen steps in f64)"), "data": "synthetic",
            "config": {"workload": workload, "baseline_config": cfg,
                       "two_site_gates_per_step": n2, "bp_updates_per_step": updates, "bp_sweeps_per_step": sweeps,
                       "theta_svd_sweeps_per_gate": round(float(np.mean(svd_sweeps)) / max(1, n2), 2), "theta_svd_sweeps_slowest_gate": int(max(svd_max) if svd_max else 0),

@@ -9,7 +9,7 @@ Per kernel, over its full-batch launches (GRBM_GUI_ACTIVE above 50 % of the kern
                    reports is the SUM over the XCDs' GRBMs (checked on mfma_pair_gram2_kernel: 111.9 M "active" for a 6.32 ms launch = 8 x 13.99 M
                    cycles at 2.21 GHz).  1.0 = every matrix core issuing back to back for the whole kernel.  Cross-check: BUSY_CYCLES equals
                    8 cycles x MOPS exactly for the f32 32x32x2 kernels, i.e. the 64-cycle issue of an instruction that is 8 MOPS
-  mfma_flops     = 512 * (SQ_INSTS_VALU_MFMA_MOPS_F32 + SQ_INSTS_VALU_MFMA_MOPS_F64) per launch (one MOP = 512 flop), to be compared with the
+  mfma_flops     = 512 * (SQ_INSTS_VALU_MFMA_MOPS_F32 + _F64 + _BF16) per launch (one MOP = 512 flop; round 5: the bf16 x 3 kernels count under _BF16), to be compared with the
                    algorithmic flops the engine accounts for the kernel's class (bench.py "kernel_classes")
   mfma_tflops    = mfma_flops / kernel duration from the kernel trace of the same pass
 The raw counter means are kept next to the derived values."""
@@ -52,15 +52,16 @@ def main():
         big = [i for i, a in act.items() if a > 0.5 * max(act.values())]
         mean = lambda name: sum(disp[i].get(name, 0.0) for i in big) / len(big)
         gui, busy = mean("GRBM_GUI_ACTIVE"), mean("SQ_VALU_MFMA_BUSY_CYCLES")
-        mops = mean("SQ_INSTS_VALU_MFMA_MOPS_F32") + mean("SQ_INSTS_VALU_MFMA_MOPS_F64")
+        mops = mean("SQ_INSTS_VALU_MFMA_MOPS_F32") + mean("SQ_INSTS_VALU_MFMA_MOPS_F64") + mean("SQ_INSTS_VALU_MFMA_MOPS_BF16")
         ns = [dur[k][i] for i in big if i in dur.get(k, {})]
         t = sum(ns) / len(ns) * 1e-9 if ns else None
         res[k] = {"launches_full_batch": len(big), "mfma_busy": round(busy / (gui / NXCD * NCU * NSIMD), 4) if gui > 0 else None,
                   "mfma_flops_per_launch": 512.0 * mops, "mfma_tflops": round(512.0 * mops / t / 1e12, 2) if t else None,
                   "avg_ms": round(t * 1e3, 4) if t else None,
+                  "clock_GHz": round(gui / NXCD / (t * 1e9), 3) if t else None,       # GRBM_GUI_ACTIVE of one XCD / duration: the clock the kernel ran at
                   "raw_means": {c: mean(c) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32",
-                                                     "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")}}
-    doc = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 "
+                                                     "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")}}
+    doc = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_BF16 "
                       "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- " + os.environ.get("PROFILE_CMD", "<command not recorded>") + " (one pass; profiles/collect_mfma.sh)",
            "build_id": build_id(),
            "formulas": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 * 4); mfma_flops = 512 * MOPS; full-batch launches only",

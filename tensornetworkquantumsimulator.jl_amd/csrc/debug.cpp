@@ -2,6 +2,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "engine.hpp"
 #include "kernels.hpp"
 
@@ -265,6 +266,20 @@ void dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X,
     dO.down(out_y, 1024 * 8);
     HIPCHK(hipMemcpy(out_x, (char*)dO.p + 1024 * 8, 1024 * 8, hipMemcpyDeviceToHost));
 }
+// pseudo-random f32 fill in (-0.01, 0.01) for the timing entry points: constant data flatters the matrix kernels (fewer bits toggle, the chip clocks higher:
+// the both-messages pair-Gram measured 1.0 ms per 100 sites on constant data and 1.29 in the benchmark)
+static void fill_random(void* d, size_t nfloats, unsigned seed) {
+    const size_t blk = (size_t)1 << 22;                   // 4 Mi floats generated on the host, tiled over the buffer with a shifting offset
+    std::vector<float> h(blk + 4096);
+    unsigned x = seed * 2654435761u + 12345u;
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; v = ((int)(x >> 8) - (1 << 23)) * (0.01f / (1 << 23)); }
+    size_t off = 0; unsigned k = 0;
+    while (off < nfloats) {
+        const size_t m = std::min(blk, nfloats - off);
+        HIPCHK(hipMemcpy((char*)d + off * 4, h.data() + (k * 257u) % 4096u, m * 4, hipMemcpyHostToDevice));
+        off += m; ++k;
+    }
+}
 // timing of the chi = 32 plane kernels on `nsites` degree-4 site tensors [2][32]^4 resident in HBM (which: 0 pair product on legs (lx, ly),
 // 1 both-messages pair-Gram); *ms = average launch duration over `reps` launches (HIP events), after one untimed launch
 // which = 2 / 3: the chi = 16 plane kernels (mfma_pair16_kernel / mfma_pair_gram2x16_kernel, both messages) on degree-6 site tensors
@@ -274,9 +289,7 @@ static void dbg_bench_plane16(int which, int nsites, int lx, int ly, int reps, d
     if (!plane_geometry(2, 6, chi, lx, ly, 16, g)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_bench_plane: legs not covered");
     const size_t n = (size_t)2 << 24;
     DBuf dA((size_t)nsites * n * 8), dB((size_t)nsites * n * 8), dM(2 * 256 * 8);
-    HIPCHK(hipMemsetD32((hipDeviceptr_t)dA.p, 0x3c23d70a, (size_t)nsites * n * 2));
-    HIPCHK(hipMemsetD32((hipDeviceptr_t)dB.p, 0x3c23d70a, (size_t)nsites * n * 2));
-    HIPCHK(hipMemsetD32((hipDeviceptr_t)dM.p, 0x3c23d70a, 2 * 256 * 2));
+    fill_random(dA.p, (size_t)nsites * n * 2, 1); fill_random(dB.p, (size_t)nsites * n * 2, 2); fill_random(dM.p, 2 * 256 * 2, 3);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     float t = 0.f;
     const double tot = (double)nsites * g.nslices();
@@ -322,9 +335,7 @@ void dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms
     if (!pair_geometry(2, 4, chi, lx, ly, g)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_bench_plane: legs not covered");
     const size_t n = (size_t)2 * 32 * 32 * 32 * 32, nslices = (size_t)g.n0 * g.n1 * g.n2;
     DBuf dA((size_t)nsites * n * 8), dB((size_t)nsites * n * 8), dM(2 * 1024 * 8);
-    HIPCHK(hipMemsetD32((hipDeviceptr_t)dA.p, 0x3c23d70a, (size_t)nsites * n * 2));       // 0.01f everywhere: the timing does not depend on the data
-    HIPCHK(hipMemsetD32((hipDeviceptr_t)dB.p, 0x3c23d70a, (size_t)nsites * n * 2));
-    HIPCHK(hipMemsetD32((hipDeviceptr_t)dM.p, 0x3c23d70a, 2 * 1024 * 2));
+    fill_random(dA.p, (size_t)nsites * n * 2, 1); fill_random(dB.p, (size_t)nsites * n * 2, 2); fill_random(dM.p, 2 * 1024 * 2, 3);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     float t = 0.f;
     if (which == 0) {

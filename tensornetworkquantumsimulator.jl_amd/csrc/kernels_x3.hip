@@ -273,13 +273,16 @@ int x3_pair_gram2_group() { return 16; }
 void launch_x3_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
     const size_t lds = (size_t)16 * (32 * 34 + 2) * 2 * sizeof(float);
+#ifdef TNQS_EXPERIMENTS
+    // timing experiments (never in the shipped build): 1 no splitting, 2 no matrix instructions, 3 no global loads / commits, 4 no LDS reads either, 5 all loads at the phase start
     static const int mode = [] { const char* e = std::getenv("TNQS_X3_MODE"); return e ? std::atoi(e) : 0; }();
-    if (mode == 1) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<1>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<1>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
-    else if (mode == 2) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<2>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<2>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
-    else if (mode == 3) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<3>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<3>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
-    else if (mode == 5) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<5>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<5>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
-    else if (mode == 4) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<4>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<4>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
-    else { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<0>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<0>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    #define TNQS_X3_LAUNCH(M) { set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<M>, lds); hipLaunchKernelGGL(x3_pair_gram2_kernel<M>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    if (mode == 1) TNQS_X3_LAUNCH(1) else if (mode == 2) TNQS_X3_LAUNCH(2) else if (mode == 3) TNQS_X3_LAUNCH(3) else if (mode == 4) TNQS_X3_LAUNCH(4) else if (mode == 5) TNQS_X3_LAUNCH(5) else TNQS_X3_LAUNCH(0)
+    #undef TNQS_X3_LAUNCH
+#else
+    set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<0>, lds);
+    hipLaunchKernelGGL(x3_pair_gram2_kernel<0>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
+#endif
     TNQS_CHECK_LAUNCH();
 }
 
@@ -309,7 +312,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const cf* __restrict__ in = reinterpret_cast<const cf*>(it.in);
     cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
     // B operands: Mx[k = ix][j = ln] at ix + 32 ln, ix = 16 n + 8 h + e;  My[k = iy][j = ln], iy = 4 h + 16 n + 8 (e >> 2) + (e & 3)
-    P3 Mxr[2], Mxi[2], Myr[2], Myi[2];
+    // (My's pieces wait in LDS behind the planes, 12 KiB: 96 registers of matrices next to two staging sets do not fit)
+    P3 Mxr[2], Mxi[2];
+    u4* const MyL = reinterpret_cast<u4*>(L + 16 * PS) + lane;             // [(n, re / im, piece)][lane]
     {
         const cf* __restrict__ Mx = reinterpret_cast<const cf*>(it.Mx) + 32 * ln; const cf* __restrict__ My = reinterpret_cast<const cf*>(it.My) + 32 * ln;
 #pragma unroll
@@ -320,7 +325,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             Mxr[n] = split8(xr); Mxi[n] = split8(xi);
 #pragma unroll
             for (int e = 0; e < 8; e += 2) { const v4f v = ldg4(My + 4 * h + 16 * n + 8 * (e >> 2) + (e & 3)); xr[e] = v[0]; xi[e] = v[1]; xr[e + 1] = v[2]; xi[e + 1] = v[3]; }
-            Myr[n] = split8(xr); Myi[n] = split8(xi);
+            const P3 yr_ = split8(xr), yi_ = split8(xi);
+            if (w == 0) { MyL[(6 * n + 0) * 64] = yr_.h; MyL[(6 * n + 1) * 64] = yr_.m; MyL[(6 * n + 2) * 64] = yr_.l; MyL[(6 * n + 3) * 64] = yi_.h; MyL[(6 * n + 4) * 64] = yi_.m; MyL[(6 * n + 5) * 64] = yi_.l; }
         }
     }
     // mover: thread -> (companion pair f4 = 0..3 of the half, first segment sg0 = 0..127); segment j: ix = sg0 & 31, iy = (sg0 >> 5) + 4 j
@@ -328,8 +334,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ix0 = sg0 & 31, iy0 = sg0 >> 5;
     const long long toff = (long long)(4 * half + f4) * g.cstr + g.sx * ix0 + g.sy * iy0, tstr = 4 * g.sy;
     v2f* const lbase = L + (2 * f4) * PS + iy0 * P + ix0;            // element (ix, iy) of a plane at [iy][ix]; iy advances by 4 per j
-    v4f pre[8];
-    auto commit = [&](int buf) {
+    // two staging register sets: the loads of phase p + 2 are issued at the start of phase p and committed at the end of phase p + 1 (a phase is ~2 us of
+    // matrix work, less than the memory latency under load: with one set the commit waited for loads issued half a phase earlier)
+    v4f preA[8], preB[8];
+    #define TNQS_PIN() __builtin_amdgcn_sched_barrier(0x2 | 0x4)      // VALU / SALU may cross; LDS, global and matrix instructions keep their order
+    auto commit = [&](int buf, const v4f (&pre)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             v2f* p0 = lbase + buf * BUF + 4 * P * j;
@@ -346,14 +355,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (s_begin < s_end) {
         const long long b = x3_slice_base(g, s_begin) + toff;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pre[j] = ldg4(in + b + tstr * j);
-        commit(0);
+        for (int j = 0; j < 8; ++j) preB[j] = ldg4(in + b + tstr * j);
+        const long long b1 = x3_slice_base(g, s_begin + 1 < s_end ? s_begin + 1 : s_begin) + toff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) preA[j] = ldg4(in + b1 + tstr * j);
+        commit(0, preB);
     }
     lds_barrier();
-    for (int sl = s_begin; sl < s_end; ++sl) {
-        const int buf = (sl - s_begin) & 1;
+    // one phase: slice sl from LDS buffer `buf`; cur = the staged slice sl + 1 (committed at the end), nxt = receives slice sl + 2
+    auto phase = [&](int sl, int buf, const v4f (&cur)[8], v4f (&nxt)[8]) {
         const bool more = sl + 1 < s_end, prev = sl > s_begin;
-        const long long nb = x3_slice_base(g, more ? sl + 1 : sl) + toff;      // (the last phase re-reads its own slice: no branch in the stream)
+        const long long nb = x3_slice_base(g, sl + 2 < s_end ? sl + 2 : sl) + toff;      // (past the end: a slice of its own is re-read, no branch in the stream)
         const long long ob = x3_slice_base(g, prev ? sl - 1 : sl) + toff;
         v2f* Pw = L + buf * BUF + w * PS;
         // ---- step 1 ---------------------------------------------------------------------------------------------------------------
@@ -365,7 +377,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int q = 0; q < 4; ++q) { const v4f v = a[q]; ar[2 * q] = v[0]; ai[2 * q] = v[1]; ar[2 * q + 1] = v[2]; ai[2 * q + 1] = v[3]; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pre[4 * n + j] = ldg4(in + nb + tstr * (4 * n + j));
+            for (int j = 0; j < 4; ++j) nxt[4 * n + j] = ldg4(in + nb + tstr * (4 * n + j));
+            TNQS_PIN();
             const P3 sr = split8(ar), si = split8(ai), nsi = neg(si);
             if (n == 0) mac6x2<true>(Yr, sr, Mxr[n], Yi, sr, Mxi[n]); else mac6x2<false>(Yr, sr, Mxr[n], Yi, sr, Mxi[n]);
             mac6x2<false>(Yr, nsi, Mxi[n], Yi, si, Mxr[n]);
@@ -382,14 +395,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int j = 0; j < 4; ++j) store1(buf ^ 1, ob, 4 * n + j);
             }
-            if (n == 0) mac6x2<true>(Sr, pr, Myr[n], Si, pr, Myi[n]); else mac6x2<false>(Sr, pr, Myr[n], Si, pr, Myi[n]);
-            mac6x2<false>(Sr, npi, Myi[n], Si, pi, Myr[n]);
+            P3 myr, myi;
+            myr.h = MyL[(6 * n + 0) * 64]; myr.m = MyL[(6 * n + 1) * 64]; myr.l = MyL[(6 * n + 2) * 64]; myi.h = MyL[(6 * n + 3) * 64]; myi.m = MyL[(6 * n + 4) * 64]; myi.l = MyL[(6 * n + 5) * 64];
+            TNQS_PIN();
+            if (n == 0) mac6x2<true>(Sr, pr, myr, Si, pr, myi); else mac6x2<false>(Sr, pr, myr, Si, pr, myi);
+            mac6x2<false>(Sr, npi, myi, Si, pi, myr);
         }
+        TNQS_PIN();
         // S'[jx = (r & 3) + 8 (r >> 2) + 4 h][jy = ln] -> LDS [jy][jx] (the plane is private to this wave; its reads are complete)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) { const int jx = (r & 3) + 8 * (r >> 2) + 4 * h; v4f v; v[0] = Sr[r]; v[1] = Si[r]; v[2] = Sr[r + 1]; v[3] = Si[r + 1]; *reinterpret_cast<v4f*>(Pw + ln * P + jx) = v; }
-        if (more) commit(buf ^ 1);                // over the locations this thread stored from above
+        if (more) commit(buf ^ 1, cur);           // over the locations this thread stored from above
         lds_barrier();
+    };
+    for (int sl = s_begin; sl < s_end; sl += 2) {
+        phase(sl, 0, preA, preB);
+        if (sl + 1 < s_end) phase(sl + 1, 1, preB, preA);
     }
     if (s_begin < s_end) {                         // the last phase's plane
         const int buf = (s_end - 1 - s_begin) & 1;
@@ -397,10 +418,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < 8; ++j) store1(buf, ob, j);
     }
+    #undef TNQS_PIN
 }
 void launch_x3_pair(hipStream_t s, const PairItem* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
-    const size_t lds = (size_t)16 * (32 * 34 + 2) * 2 * sizeof(float);
+    const size_t lds = (size_t)16 * (32 * 34 + 2) * 2 * sizeof(float) + 12 * 64 * 16;
     set_max_dynamic_lds((const void*)x3_pair_kernel, lds);
     hipLaunchKernelGGL(x3_pair_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
     TNQS_CHECK_LAUNCH();

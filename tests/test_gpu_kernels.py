@@ -276,6 +276,37 @@ def test_double_pair_gram(chi, lx, ly):
         assert np.max(np.abs(got.reshape(32, 32).T - ref)) < 3e-5 * np.max(np.abs(ref)) * scale
 
 
+@pytest.mark.parametrize("lx,ly", [(1, 2), (0, 3), (2, 0)])
+@pytest.mark.parametrize("scale", [1e-12, 1e-3, 1e6])
+def test_bf16x3_plane_kernels_are_f32_accurate(lx, ly, scale):
+    """round 5: the chi = 32 plane kernels multiply on the bf16 matrix cores -- every f32 operand split EXACTLY into three bf16 pieces, six of the nine piece
+    products kept (the dropped ones are below one f32 rounding of the product), f32 accumulation (csrc/kernels_x3.hip).  That is f32 arithmetic, not bf16
+    arithmetic: against an f64 reference the error has to be what the f32 matrix instructions give (measured on the same inputs, profiles/x3_error.py:
+    3.0-5.6e-7 of the largest entry for the split route, 2.6-6.2e-7 for v_mfma_f32_32x32x2_f32; a bf16-rounded operand alone would give 4e-3), at any
+    scale of the data (bf16 has the exponent range of f32: no scaling anywhere).  Bound: 1e-6 of the largest entry, thirty times tighter than the generic
+    kernel tests above."""
+    rng = np.random.default_rng(11 * lx + ly)
+    chi = (32, 32, 32, 32); z = 4
+    cchi = (C.c_int * z)(*chi)
+    fx, tx = _site(rng, 2, chi); fy, ty = _site(rng, 2, chi)
+    fx *= np.float32(scale); tx = tx * float(np.float32(scale)); fy *= np.float32(scale); ty = ty * float(np.float32(scale))
+    mx = rnd(rng, 1024, np.complex64); my = rnd(rng, 1024, np.complex64)
+    Mx = mx.reshape(32, 32).T.astype(np.complex128); My = my.reshape(32, 32).T.astype(np.complex128)
+    out = np.zeros_like(fx)
+    assert lib.tnqs_dbg_pair_legs(2, z, cchi, lx, ly, fx.ctypes.data_as(C.c_void_p), mx.ctypes.data_as(C.c_void_p), my.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+    ref = np.moveaxis(np.tensordot(tx, Mx, axes=([1 + lx], [0])), -1, 1 + lx)
+    ref = np.moveaxis(np.tensordot(ref, My, axes=([1 + ly], [0])), -1, 1 + ly)
+    assert np.max(np.abs(out.reshape((2,) + chi, order="F") - ref)) < 1e-6 * np.max(np.abs(ref))
+    oy = np.zeros(1024, dtype=np.complex64); ox = np.zeros(1024, dtype=np.complex64)
+    assert lib.tnqs_dbg_pair_gram2(2, z, cchi, lx, ly, fx.ctypes.data_as(C.c_void_p), fy.ctypes.data_as(C.c_void_p), mx.ctypes.data_as(C.c_void_p),
+                                   my.ctypes.data_as(C.c_void_p), oy.ctypes.data_as(C.c_void_p), ox.ctypes.data_as(C.c_void_p)) == 0
+    for (absorbed, kept, M, got) in ((lx, ly, Mx, oy), (ly, lx, My, ox)):
+        xm = np.moveaxis(np.tensordot(tx, M, axes=([1 + absorbed], [0])), -1, 1 + absorbed)
+        axes = [a for a in range(z + 1) if a != 1 + kept]
+        ref = np.tensordot(xm, ty.conj(), axes=(axes, axes))
+        assert np.max(np.abs(got.reshape(32, 32).T - ref)) < 2e-6 * np.max(np.abs(ref))
+
+
 @pytest.mark.parametrize("shape,rank", [((64, 64), 64), ((128, 128), 64), ((144, 144), 72), ((200, 120), 120)])
 @pytest.mark.parametrize("scale", [1e-18, 1e-10, 1e-5, 1.0, 1e12])
 def test_jacobi_svd_is_scale_invariant(shape, rank, scale):

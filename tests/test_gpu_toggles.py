@@ -49,7 +49,7 @@ def test_lowrank_theta_route_matches_the_full_svd():
 
 @pytest.mark.parametrize("switch", ["TNQS_NO_CHOL", "TNQS_NO_SMALLSVD", "TNQS_JACOBI_GLOBAL", "TNQS_NO_PAIR", "TNQS_NO_TSHARE", "TNQS_NO_FUSED_GRAM",
                                     "TNQS_NO_APPLY64", "TNQS_NO_MFMA", "TNQS_EAGER_SCALE", "TNQS_NO_PREFIX", "TNQS_NO_ROWGEMM32", "TNQS_NO_3M",
-                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE", "TNQS_NO_OPTIMISTIC_BP", "TNQS_NO_PRECOND_SVD", "TNQS_NO_SMALL_SITE_BP"])
+                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE", "TNQS_NO_OPTIMISTIC_BP", "TNQS_NO_PRECOND_SVD", "TNQS_NO_SMALL_SITE_BP", "TNQS_NO_BF16X3"])
 def test_alternative_routes_match_the_default(switch):
     """every documented switch selects an alternative route of the same algorithm: all-eigen factorisation instead
     of Cholesky, Gram-eigen instead of the small-SVD route, global-memory Jacobi, single-leg mode products, per-message BP products,
@@ -79,7 +79,7 @@ def test_staging_arena_overflow_keeps_descriptors_alive():
         assert ref[name]["z"] == alt[name]["z"], name
 
 
-@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_DEFER_1SITE", "TNQS_NO_BP_SPLIT", "TNQS_NO_OPTIMISTIC_BP", "TNQS_NO_PRECOND_SVD"])
+@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_DEFER_1SITE", "TNQS_NO_BP_SPLIT", "TNQS_NO_OPTIMISTIC_BP", "TNQS_NO_PRECOND_SVD", "TNQS_NO_BF16X3"])
 def test_bulk_shape_routes_match(switch):
     """the chi = 32 bulk shape (BASELINE configs[1]): the third gauge leg absorbed inside the f64 Gram kernel (kernels_gate.hip) against the
     separate single-leg pass + plain Gram; ranks of the R factors left on the device against read back; three- against four-multiplication
