@@ -1,4 +1,5 @@
 // debug.cpp -- kernel-level test entry points (include/tnqs_debug.h): host arrays in, host arrays out.
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <vector>
@@ -329,7 +330,7 @@ static void dbg_bench_plane16(int which, int nsites, int lx, int ly, int reps, d
 }
 void dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms) {
     need_gpu();
-    if (which >= 2) { dbg_bench_plane16(which, nsites, lx, ly, reps, ms); return; }
+    if (which == 2 || which == 3) { dbg_bench_plane16(which, nsites, lx, ly, reps, ms); return; }
     const int chi[4] = {32, 32, 32, 32};
     PairGeom g{};
     if (!pair_geometry(2, 4, chi, lx, ly, g)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_bench_plane: legs not covered");
@@ -338,7 +339,43 @@ void dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms
     fill_random(dA.p, (size_t)nsites * n * 2, 1); fill_random(dB.p, (size_t)nsites * n * 2, 2); fill_random(dM.p, 2 * 1024 * 2, 3);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     float t = 0.f;
-    if (which == 0) {
+    if (which == 4) {
+        // one BP level of a degree-4 site: T = psi x_lx Mx x_ly My (pair product), then both messages through the other two legs from (T, psi).  The sites are
+        // processed in groups of TNQS_DBG_GROUP (0: all at once, as the engine does): with a few sites per group T (16 MiB per site) is still in the 256 MiB
+        // Infinity Cache when the pair-Gram reads it, and psi is read from memory once instead of twice
+        const char* e = std::getenv("TNQS_DBG_GROUP"); int G = e ? std::atoi(e) : 0; if (G <= 0 || G > nsites) G = nsites;
+        int ox = -1, oy = -1; for (int q = 0; q < 4; ++q) if (q != lx && q != ly) { if (ox < 0) ox = q; else oy = q; }
+        PairGeom g2{}; if (!pair_geometry(2, 4, chi, ox, oy, g2)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_bench_plane: other legs not covered");
+        const size_t ns2 = (size_t)g2.n0 * g2.n1 * g2.n2;
+        const int ngroups = (nsites + G - 1) / G;
+        int spw_p = pair_spw((double)G * nslices);
+        int spw_g = 16; while (spw_g > 1 && (long)G * pair_gram2_group() * (((ns2 + spw_g - 1) / spw_g + 7) / 8) < 1024) spw_g >>= 1;
+        const int npairs = (int)((ns2 + spw_g - 1) / spw_g), nwg_g = pair_gram2_group() * ((npairs + 7) / 8);
+        DBuf dT((size_t)G * n * 8), dP((size_t)2 * nsites * nwg_g * 1024 * 8);
+        std::vector<PairItem> pit(nsites); std::vector<PairGram2Item> git(nsites);
+        std::vector<int> pw(ngroups, 0), gwg(ngroups, 0);
+        for (int i = 0; i < nsites; ++i) {
+            const int gr = i / G, k = i % G;
+            PairItem& a = pit[i]; a.g = g; a.in = (char*)dA.p + (size_t)i * n * 8; a.out = (char*)dT.p + (size_t)k * n * 8; a.Mx = dM.p; a.My = (char*)dM.p + 1024 * 8;
+            a.slice_begin = pw[gr]; a.spw = spw_p; pw[gr] += pair_wgs((int)nslices, spw_p);
+            PairGram2Item& b = git[i]; b.g = g2; b.X = a.out; b.Y = a.in; b.Mx = dM.p; b.My = (char*)dM.p + 1024 * 8; b.wg_begin = gwg[gr]; b.spw = spw_g; gwg[gr] += nwg_g;
+            b.partial_y = (char*)dP.p + (size_t)(2 * i) * nwg_g * 1024 * 8; b.partial_x = (char*)dP.p + (size_t)(2 * i + 1) * nwg_g * 1024 * 8;
+        }
+        DBuf dPI(pit.size() * sizeof(PairItem)), dGI(git.size() * sizeof(PairGram2Item));
+        dPI.up(pit.data(), pit.size() * sizeof(PairItem)); dGI.up(git.data(), git.size() * sizeof(PairGram2Item));
+        auto level = [&]() {
+            for (int gr = 0; gr < ngroups; ++gr) {
+                const int cnt = std::min(G, nsites - gr * G);
+                launch_mfma_pair(nullptr, (const PairItem*)dPI.p + (size_t)gr * G, cnt, pw[gr]);
+                launch_mfma_pair_gram2(nullptr, (const PairGram2Item*)dGI.p + (size_t)gr * G, cnt, gwg[gr]);
+            }
+        };
+        level();
+        HIPCHK(hipEventRecord(e0, nullptr));
+        for (int r = 0; r < reps; ++r) level();
+        HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1)); HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        std::fprintf(stderr, "level bench: group %d, pair spw %d, gram spw %d\n", G, spw_p, spw_g);
+    } else if (which == 0) {
         std::vector<PairItem> items(nsites);
         const int spw = pair_spw((double)nsites * nslices); int wgs = 0;
         for (int i = 0; i < nsites; ++i) {

@@ -69,8 +69,11 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
                         it16.push_back(it); sel16.push_back({ci, {0, 1}}); slices16 += (double)it.g.nslices(); found = true;
                     }
                 }
-                for (int qy = (int)c.steps.size() - 1; qy >= 1 && !found; --qy)
-                    for (int qx = qy - 1; qx >= 0 && !found; --qx) {
+                // the LOWEST remaining leg with the HIGHEST one (round 5): a plane that contains leg 0 streams at 4.4 - 4.55 TB/s, every other one at 3.7 - 3.9 and
+                // (3,5) at 3.0 (profiles/plane16_bench.py, 12 sites, random data) -- "the two highest legs first" gave the y-lines of the cubic lattice (cross legs
+                // 0, 2, 3, 5) the passes (3,5) + (0,2) = 3.57 ms per 12 sites, this rule (0,5) + (2,3) = 3.16; x-lines 3.17 -> 3.14, z-lines 3.33 -> 3.38
+                for (int qx = 0; qx + 1 < (int)c.steps.size() && !found; ++qx)
+                    for (int qy = (int)c.steps.size() - 1; qy > qx && !found; --qy) {
                         Pair16Item it{};
                         if (!plane_geometry(c.sd.d, c.sd.z, c.sd.chi.data(), c.steps[qx].first, c.steps[qy].first, 16, it.g)) continue;
                         it.Mx = c.steps[qx].second; it.My = c.steps[qy].second;
