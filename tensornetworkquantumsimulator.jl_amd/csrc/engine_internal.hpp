@@ -62,6 +62,8 @@ TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64
 // TNQS_JACOBI_GLOBAL=1: every Jacobi factorisation in the global-memory kernel;  TNQS_BP_WS_MB: workspace bound of a BP sub-batch (MiB);
 // TNQS_HOST_TIMING=1: host-side phase timers printed at exit;  TNQS_RCCL_LIB: path of librccl.so (sharding.cpp);
 // TNQS_NO_F64_MFMA=1 (engine_batch.cpp): ComplexF64 mode products on the generic vector kernel instead of the f64 matrix cores (kernels_f64.hip);
+// TNQS_NO_BF16X3=1 (launch_util.hpp): the chi = 32 plane kernels (pair product, both-messages pair-Gram) on v_mfma_f32_32x32x2_f32 instead of the bf16 matrix cores with exact three-way
+//                   operand splits (kernels_x3.hip);
 // TNQS_NO_3M=1 (launch_util.hpp): four-multiplication complex product in every MFMA kernel instead of Gauss' three (mfma_common.hpp, CAcc32);
 // TNQS_NO_OPTIMISTIC_BP=1 (engine_bp.cpp): every BP update inside apply_gates waits for its convergence verdict before the next batch is prepared;
 // TNQS_NO_SMALL_SITE_BP=1 (engine_bp.cpp): sites of at most 8192 elements take the generic chain + Gram route instead of the one-kernel LDS-resident message (kernels.hip bp_small_site_kernel);
