@@ -228,7 +228,10 @@ int tnqs_rccl_preflight(void);
 
 /* ---- profiling: HIP-event timing of the kernel classes on the handle's stream ---------------------------- */
 enum { TNQS_PROF_BP_MODEPROD = 0, TNQS_PROF_BP_GRAM = 1, TNQS_PROF_GATE_MODEPROD = 2, TNQS_PROF_GATE_GRAM = 3,
-       TNQS_PROF_GATE_APPLY = 4, TNQS_PROF_JACOBI = 5, TNQS_PROF_SMALL = 6, TNQS_PROF_BP_FUSED = 7, TNQS_PROF_BP_PAIR = 8, TNQS_PROF_BP_PAIRGRAM = 9, TNQS_PROF_NCLASSES = 10 };
+       TNQS_PROF_GATE_APPLY = 4, TNQS_PROF_JACOBI = 5, TNQS_PROF_SMALL = 6, TNQS_PROF_BP_FUSED = 7, TNQS_PROF_BP_PAIR = 8, TNQS_PROF_BP_PAIRGRAM = 9,
+       /* whole phases, first to last kernel on the handle's stream (side streams join it before a phase ends): the CRITICAL-PATH time of the BP updates (launches =
+        * sweeps) and of the batches of two-site gates (launches = batches) -- the kernel classes above overlap each other where a phase runs on two streams */
+       TNQS_PROF_PHASE_BP_UPDATE = 10, TNQS_PROF_PHASE_GATE_BATCH = 11, TNQS_PROF_NCLASSES = 12 };
 int tnqs_profile_enable(tnqs_handle h, int on);
 /* launches, total ms, algorithmic bytes (min traffic: operands read once + result written once) and flops */
 int tnqs_profile_get(tnqs_handle h, int cls, int64_t* launches, double* total_ms, double* alg_bytes, double* alg_flops);

@@ -622,7 +622,9 @@ def profile_enable(bpc: BeliefPropagationCache, on: bool = True):
     L.check(L.lib.tnqs_profile_enable(bpc._h, 1 if on else 0))
 
 
-PROF_CLASSES = ("bp_modeprod", "bp_gram", "gate_modeprod", "gate_gram", "gate_apply", "jacobi", "small", "bp_fused", "bp_pair", "bp_pairgram")
+PROF_CLASSES = ("bp_modeprod", "bp_gram", "gate_modeprod", "gate_gram", "gate_apply", "jacobi", "small", "bp_fused", "bp_pair", "bp_pairgram",
+                # whole phases on the handle's stream (critical path; the kernel classes above overlap where a phase uses two streams): launches = sweeps / batches
+                "phase_bp_update", "phase_gate_batch")
 
 
 def profile_get(bpc: BeliefPropagationCache) -> dict:

@@ -302,6 +302,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
     const size_t esz = s->esz();
     const size_t nseq = plan.seq.size();
     if (nseq == 0) { if (niter_out) *niter_out = 0; if (diff_out) *diff_out = 0; return; }
+    PhaseScope phase_scope(s, TNQS_PROF_PHASE_BP_UPDATE); phase_scope.count = 0;       // launches = sweeps enqueued
     Buf d_diffs = dalloc(s, nseq * sizeof(double));
     Buf d_sum = dalloc(s, sizeof(double));
     std::vector<Buf> cur = s->msg;
@@ -357,6 +358,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
     // (sharded handles too, round 5: messages are replicated and every rank normalises / diffs all of them, so the verdict is the same on every rank)
     const bool go_optimistic = optimistic && optimistic_on && compute_error && iters_before == 0 && s->arena.base;
     for (int iter = 1 + iters_before; iter <= maxiter; ++iter) {
+        phase_scope.count += 1;
         std::vector<Buf> fresh(2 * (size_t)g.ne);
         for (auto& lev : plan.levels) {
             // sub-batches bounded by workspace bytes

@@ -210,6 +210,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         absorbed.push_back(matmul_dd(g2.mat, kron.data(), dd));
         g2.mat = absorbed.back().data();
     }
+    PhaseScope phase_scope(s, TNQS_PROF_PHASE_GATE_BATCH);
     HostTimer ht_a(3);                 // TNQS_HOST_TIMING=1: host time of the batch up to the first read-back (3), between the read-backs (4), after them (5)
     if (!ao.normalize_tensors && s->bp_pending.active && !resolve_bp(s)) throw BpNotConverged{};      // (materialize_scale below launches)
     if (!ao.normalize_tensors) {       // without the final normalisation the result scales with the inputs: apply pending factors first

@@ -197,6 +197,25 @@ struct ProfScope {
     }
 };
 
+// a whole phase on the handle's stream (TNQS_PROF_PHASE_*): own events, outside the chaining of the kernel-class scopes; `count` is added to the class's launches
+struct PhaseScope {
+    State* s; int cls; hipEvent_t a = nullptr, b = nullptr; long count = 1;
+    PhaseScope(State* st, int c) : s(st), cls(c) {
+        Prof& P = *s->prof;
+        if (!P.on) return;
+        auto get = [&]() { hipEvent_t e; if (!P.ev_free.empty()) { e = P.ev_free.back(); P.ev_free.pop_back(); } else HIPCHK(hipEventCreate(&e)); return e; };
+        a = get(); b = get();
+        HIPCHK(hipEventRecord(a, s->stream));
+    }
+    ~PhaseScope() {
+        if (!a) return;
+        Prof& P = *s->prof;
+        (void)hipEventRecord(b, s->stream);
+        P.cls[cls].launches += count;
+        P.pending.push_back({cls, a, b, true});
+    }
+};
+
 struct SD {       // dims of a site tensor in canonical layout
     int z = 0, d = 1; std::vector<int> chi; size_t n = 1;
     size_t pre(int j) const { size_t p = d; for (int i = 0; i < j; ++i) p *= chi[i]; return p; }
