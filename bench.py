@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--chi", type=int, default=0, help="bond dimension (default: 32 / 16 / 64)")
     ap.add_argument("--host-init", action="store_true", help="c4 / c5: generate the synthetic state with numpy on the host instead of on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ab", action="store_true", help="skip the second, untimed-by-the-driver leg: the same command with TNQS_NO_BF16X3=1 (the f32 matrix instructions) in a child process")
     ap.add_argument("--bp-order", choices=["library", "reference"], default="library",
                     help="sweep order of the BP updates: the library default (linear forests, the order the plane kernels share products on) or the reference's "
                          "default forest_cover_edge_sequence (tnqs_bp_opts.n_sequence = -1).  Same fixed point; at the default tolerance both stop after one "
@@ -387,6 +388,20 @@ def main():
         out["evolved"] = {"state": f"{args.evolved} TFIM layers at dt = 0.1 (J = 1, hx = 2.5) from the product state, maxdim {chi}",
                           "max_bond_dim": int(b2.maxvirtualdim()), "ms_per_step": round(1e3 * el2 / max(1, args.steps), 3),
                           "value": round(n2 * args.steps / el2, 2), "bp_sweeps_per_step": sw2, "bp_updates_not_converged": nc2, "max_truncation_error": float(np.max(_e))}
+    if rank == 0 and world == 1 and cfg == "c2" and x3 and not args.no_ab and not args.no_cpu_baseline:
+        # A/B in the same run on the same box (not part of `value`): the chi = 32 plane kernels on v_mfma_f32_32x32x2_f32 instead of the bf16 matrix cores.  The
+        # switches are read once per process, hence a child; it must never take the measured number down with it
+        try:
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--L", str(L), "--chi", str(chi), "--no-cpu-baseline", "--no-ab"]
+            r = subprocess.run(cmd, env=dict(os.environ, TNQS_NO_BF16X3="1"), capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            d2 = json.loads(line)
+            out["ab_f32_matrix_instructions"] = {"env": "TNQS_NO_BF16X3=1", "ms_per_step": d2["ms_per_step"], "value": d2["value"],
+                                                 "kernel_classes_ms": {k: v["ms"] for k, v in d2["kernel_classes"].items() if k in ("bp_pair", "bp_pairgram", "gate_modeprod")},
+                                                 "this_run_kernel_classes_ms": {k: v["ms"] for k, v in classes.items() if k in ("bp_pair", "bp_pairgram", "gate_modeprod")}}
+        except Exception as e:
+            out["ab_f32_matrix_instructions"] = {"value": None, "error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and cfg == "c2":      # (the CPU leg restates the 2-D chi = 32 path on a bounded sample; the 8-GPU shapes have none)
             try:
