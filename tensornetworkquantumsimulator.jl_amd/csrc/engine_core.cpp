@@ -3,8 +3,8 @@
 
 namespace tnqs {
 
-double HostTimer::acc[8] = {0}; long HostTimer::cnt[8] = {0};
-static struct HostTimerReport { ~HostTimerReport() { if (envflag("TNQS_HOST_TIMING")) for (int k = 0; k < 8; ++k) if (HostTimer::cnt[k])
+double HostTimer::acc[16] = {0}; long HostTimer::cnt[16] = {0};
+static struct HostTimerReport { ~HostTimerReport() { if (envflag("TNQS_HOST_TIMING")) for (int k = 0; k < 16; ++k) if (HostTimer::cnt[k])
     std::fprintf(stderr, "[tnqs host timing] phase %d: %.2f ms total, %ld calls, %.1f us each\n", k, HostTimer::acc[k], HostTimer::cnt[k], 1e3 * HostTimer::acc[k] / HostTimer::cnt[k]); } } g_host_timer_report;
 
 void hipchk(hipError_t e, const char* what) {

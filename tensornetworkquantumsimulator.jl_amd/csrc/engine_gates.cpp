@@ -220,6 +220,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     struct SiteJob { int v, other, bleg; bool owned; SD sd; std::vector<int> env_idx; std::vector<int> env_leg; };
     std::vector<SiteJob> sj(2 * (size_t)ng);
     std::vector<char> part(ng, 0);                  // this rank runs the small algebra of the gate
+    HostTimer ht_s1(8);
     // ---- 1. environments: sqrt(M) and projector for every incoming message of an owned site (utils.jl:18-27) ------
     struct EnvRec { int de; int n; void *H, *V, *msq, *prj; };      // views into one arena (env_arena): thousands of 16 KiB pool allocations per batch
                                                                     // were a third of the host time between a BP update and the first kernel of a batch
@@ -275,6 +276,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_env_finish<T>(s->stream, df, (int)fi.size()); }
         }
     }
+    ht_s1.stop(); HostTimer ht_s2(9);
     // ---- 2. gauge: psi~ = psi x_outer M^{1/2}  (simple_update.jl:43-44), owned sites only -----------------------------
     std::vector<int> own_idx;                        // indices into sj of the owned sites
     for (size_t i = 0; i < sj.size(); ++i) if (sj[i].owned) own_idx.push_back((int)i);
@@ -333,6 +335,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             HIPCHK(hipEventRecord(s->ev_join, side)); ev_small = s->ev_join;
         }
     }
+    ht_s2.stop(); HostTimer ht_s3(10);
     // ---- 3. G = psi~^dagger psi~ over the outer legs, f64 accumulation (replaces the thin QR, simple_update.jl:45-48) --
     std::vector<GramJob> jobs; std::vector<int> job_of(own_idx.size(), -1);
     for (size_t q = 0; q < own_idx.size(); ++q) {
@@ -458,6 +461,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         }
     };
     factor_G(use_chol());
+    ht_s3.stop(); HostTimer ht_s4(11);
     // ---- 4. theta = gate . (R1 R2), SVD, truncation, X1 / X2  (simple_update.jl:51-59) -----------------------------
     struct GateWS { Buf lam1, lam2, idx1, idx2, theta, thetaV, theta0, X1, X2, S, lowA, lowB, lowG, lowL, lowW, lowQ, lowB1, lowG2, lowL2, lowLc; int n1, n2, chi, cap; };
     std::vector<GateWS> ws(ng);
@@ -737,13 +741,13 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             svd_and_finish(nullptr);
             if (!sharded && ao.maxdim > 0) spec_plan = plan_rowgemm([&](int gi) { return ws[gi].cap; }, [&](size_t q) { return (const void*)s->site[sj[own_idx[q]].v]->p; }, nullptr);
             reserve_readback(s, rb_bytes);
-            ht_a.stop();
+            ht_a.stop(); ht_s4.stop();
             read_results(); take_flags();
             if (chol_failures()) { redo_with_eigen(); svd_and_finish(hinfo.data()); read_results(); }
         } else {
             // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
             reserve_readback(s, rb_bytes);
-            ht_a.stop();
+            ht_a.stop(); ht_s4.stop();
             read_results(); take_flags();
             if (chol_failures()) redo_with_eigen();
             if (qr2) {

@@ -79,7 +79,7 @@ inline int mmax_of(const std::vector<JacobiItem>& ji) { int m = 1; for (auto& j 
 
 // optional host-side phase timing (TNQS_HOST_TIMING=1): printed when the process exits
 struct HostTimer {
-    static double acc[8]; static long cnt[8];
+    static double acc[16]; static long cnt[16];
     int k; std::chrono::steady_clock::time_point t0; bool on;
     explicit HostTimer(int kk) : k(kk), t0(std::chrono::steady_clock::now()), on(true) {}
     void stop() { if (on) { static std::mutex mu; std::lock_guard<std::mutex> lk(mu); acc[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); cnt[k]++; on = false; } }

@@ -320,7 +320,8 @@ template void launch_msg_finalize<double>(hipStream_t, const MsgFinalItem*, int)
 // streamed such a tensor through one fiber-GEMM launch per leg plus a Gram launch, each with its descriptor copy: 16 launch groups of ~90 us per heavy-hex layer at
 // 0.09 TB/s (updated_message, abstractbeliefpropagationcache.jl:162-190)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bp_small_site_kernel(const SmallMsgItem* __restrict__ items) {
+template <int NT>
+__global__ __launch_bounds__(NT) void bp_small_site_kernel(const SmallMsgItem* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SmallMsgItem it = items[blockIdx.x];
     const int tid = threadIdx.x;
@@ -329,21 +330,21 @@ __global__ __launch_bounds__(256) void bp_small_site_kernel(const SmallMsgItem* 
     cx<float>* nxt = cur + E;
     cx<float>* Ms = nxt + E;                                          // one message matrix, TRANSPOSED: Ms[qo + c q] = M[q + c qo] (<= 32 x 32)
     const cx<float>* psi = reinterpret_cast<const cx<float>*>(it.psi);
-    for (int e = tid; e < E; e += 256) cur[e] = psi[e];
+    for (int e = tid; e < E; e += NT) cur[e] = psi[e];
     __syncthreads();
     int P = it.d;                                                     // stride of leg k
     for (int k = 0; k < it.z; ++k) {
         const int c = it.chi[k];
         if (k != it.jo && it.M[k]) {
             const cx<float>* Mg = reinterpret_cast<const cx<float>*>(it.M[k]);
-            for (int e = tid; e < c * c; e += 256) Ms[(e / c) + c * (e % c)] = Mg[e];
+            for (int e = tid; e < c * c; e += NT) Ms[(e / c) + c * (e % c)] = Mg[e];
             __syncthreads();
             // one OUTPUT element per thread and step: out[pre, qo, post] = sum_q cur[pre, q, post] M[q, qo].  Consecutive threads take consecutive output
             // elements: the stores are contiguous, the lanes of a wave read few distinct fibers (broadcasts) and consecutive entries of the transposed matrix
-            // (pre, qo, post) of e = tid + 256 t by carries instead of divisions: an integer division is ~40 instructions, more than the 16-term sum it would index
+            // (pre, qo, post) of e = tid + NT t by carries instead of divisions: an integer division is ~40 instructions, more than the 16-term sum it would index
             int pre = tid % P, qo = (tid / P) % c, post = tid / (P * c);
-            const int dpre = 256 % P, dq = (256 / P) % c, dpost = 256 / (P * c);
-            for (int e = tid; e < E; e += 256, pre += dpre, qo += dq, post += dpost) {
+            const int dpre = NT % P, dq = (NT / P) % c, dpost = NT / (P * c);
+            for (int e = tid; e < E; e += NT, pre += dpre, qo += dq, post += dpost) {
                 if (pre >= P) { pre -= P; ++qo; }
                 if (qo >= c) { qo -= c; ++post; }
                 const cx<float>* src = cur + pre + (size_t)P * c * post;
@@ -364,19 +365,19 @@ __global__ __launch_bounds__(256) void bp_small_site_kernel(const SmallMsgItem* 
         P *= c;
     }
     // psi again, into the free copy; then out[i + co j] = sum_rest cur[rest, i] conj(psi[rest, j]) over everything but the outgoing leg
-    for (int e = tid; e < E; e += 256) nxt[e] = psi[e];
+    for (int e = tid; e < E; e += NT) nxt[e] = psi[e];
     __syncthreads();
     int Po = it.d; for (int k = 0; k < it.jo; ++k) Po *= it.chi[k];
     const int co = it.chi[it.jo], nrest = E / co;
     cx<float>* out = reinterpret_cast<cx<float>*>(it.out);
     // thread = (output element o, slice of the rest index): co^2 outputs x nsl slices fill the workgroup; partial sums meet in LDS (behind the message matrix)
     const int no = co * co;
-    int nsl = 256 / no; if (nsl < 1) nsl = 1; if (nsl > 16) nsl = 16;
-    float* red = reinterpret_cast<float*>(Ms);                        // 2 * 256 floats <= 2 KiB (the matrix slot holds 8 KiB)
-    for (int o0 = 0; o0 < no; o0 += 256 / nsl) {
+    int nsl = NT / no; if (nsl < 1) nsl = 1; if (nsl > 16) nsl = 16;
+    float* red = reinterpret_cast<float*>(Ms);                        // 2 * NT floats <= 8 KiB (the matrix slot holds 8 KiB)
+    for (int o0 = 0; o0 < no; o0 += NT / nsl) {
         const int o = o0 + tid / nsl, sl = tid % nsl;
         float ar = 0.f, ai = 0.f;
-        if (o < no && tid < (256 / nsl) * nsl) {
+        if (o < no && tid < (NT / nsl) * nsl) {
             const int i = o % co, j = o / co;
             int pre = sl % Po, post = sl / Po; const int dpre = nsl % Po, dpost = nsl / Po;
             for (int r = sl; r < nrest; r += nsl, pre += dpre, post += dpost) {
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) void bp_small_site_kernel(const SmallMsgItem* 
         __syncthreads();
         red[2 * tid] = ar; red[2 * tid + 1] = ai;
         __syncthreads();
-        if (sl == 0 && o < no && tid < (256 / nsl) * nsl) {
+        if (sl == 0 && o < no && tid < (NT / nsl) * nsl) {
             float sr = 0.f, si = 0.f;
             for (int u = 0; u < nsl; ++u) { sr += red[2 * (tid + u)]; si += red[2 * (tid + u) + 1]; }
             out[o] = cmake<float>(sr, si);
@@ -399,8 +400,10 @@ __global__ __launch_bounds__(256) void bp_small_site_kernel(const SmallMsgItem* 
 void launch_bp_small_site(hipStream_t s, const SmallMsgItem* d_items, int nitems, int max_elems) {
     if (nitems <= 0) return;
     const size_t lds = (size_t)max_elems * 16 + 32 * 32 * 8;
-    set_max_dynamic_lds((const void*)bp_small_site_kernel, (size_t)(160 * 1024 - 1024));
-    hipLaunchKernelGGL(bp_small_site_kernel, dim3(nitems), dim3(256), lds, s, d_items); TNQS_CHECK_LAUNCH();
+    // 1024 threads: the LDS footprint allows one workgroup per CU, and with 256 threads (one wave per SIMD) every LDS read of the dependent sums was exposed --
+    // 107 us per message of a heavy-hex degree-3 site whatever the number of messages in the launch
+    set_max_dynamic_lds((const void*)bp_small_site_kernel<1024>, (size_t)(160 * 1024 - 1024));
+    hipLaunchKernelGGL(bp_small_site_kernel<1024>, dim3(nitems), dim3(1024), lds, s, d_items); TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------
