@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libtnqs_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result ${EXTRA_FLAGS:-}"
 [ "${EXPERIMENTS:-0}" = "1" ] && FLAGS="$FLAGS -DTNQS_EXPERIMENTS"      # kernel-experiment switches (engine_internal.hpp); never in the shipped build
 mkdir -p build
 pids=()

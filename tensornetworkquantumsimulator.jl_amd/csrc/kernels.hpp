@@ -67,18 +67,23 @@ struct JacobiItem {       // one-sided Jacobi on A (m x n, col-major, ld = m); V
 };
 // device-side decision shared by theta_svd_pre_kernel, jacobi_lds_kernel / jacobi_kernel and the V-recovery kernels: the matrix the SVD runs on -- the low-rank
 // factor when that route survived on the device (info[7] = K > 0; needs Q), theta itself otherwise -- fits the kernel
+#ifndef TNQS_PRE_MIN_COLS
+#define TNQS_PRE_MIN_COLS 16      // the preconditioned kernel takes factors of MORE than this many columns (csrc/build.sh EXTRA_FLAGS=-DTNQS_PRE_MIN_COLS=32: the round-5 start)
+#endif
 __host__ __device__ inline bool theta_pre_takes(const int* info, int d1, int d2, bool have_q) {
     if (!info) return false;
     int Mr = info[0] * d1, Nc = info[1] * d2;
     if (info[7] > 0) {                                  // low-rank route alive: the K-column factor, V through Q
         const int K = info[7];
-        return have_q && Mr >= Nc && K > 32 && K <= 64 && Mr >= K && Mr <= 128;
+        return have_q && Mr >= Nc && K > TNQS_PRE_MIN_COLS && K <= 64 && Mr >= K && Mr <= 128;
     }
     if (Mr < Nc) { const int t = Mr; Mr = Nc; Nc = t; }   // theta itself (stored as its adjoint when wide): V = U_L
-    return Nc > 32 && Nc <= 64 && Mr <= 128;
-    // (more than 32 columns: a round of the sweeps costs ~0.7 us whatever the row count -- latency of the load / reduce / rotate / barrier chain -- so on a 64 x 32
-    //  factor the plain kernel's 7-8 sweeps of 31 rounds, 0.14-0.16 ms, beat 6-7 preconditioned sweeps plus 37 us of Gram, Cholesky and products: 0.18-0.21 ms
-    //  measured, profiles/svd_bench.py; at 64 columns it is 0.42-0.47 ms against 0.27-0.31)
+    return Nc > TNQS_PRE_MIN_COLS && Nc <= 64 && Mr <= 128;
+    // (a round of the sweeps costs ~0.7 us whatever the row count -- latency of the load / reduce / rotate / barrier chain.  On ISOLATED 64 x 32 factors of the
+    //  benchmark state the plain kernel's 7-8 sweeps of 31 rounds, 0.14-0.16 ms, beat 6-7 preconditioned sweeps plus 37 us of Gram, Cholesky and products (0.18-0.21 ms,
+    //  profiles/svd_bench.py), which is why the limit was 32 columns at first; inside the heavy-hex layer (64 x 32 factors of every gate, 0.2-0.3 ms per batch in the
+    //  plain kernel) the preconditioned kernel wins: Jacobi class 1.17 -> 0.96 ms per layer, layer 3.8 -> 3.6 ms, and the 7 x 7 lattice 15.9 -> 15.8.  At 64 columns:
+    //  0.42-0.47 ms against 0.27-0.31)
 }
 // dimensions of a gate's theta SVD from its info array (gate_theta_kernel): rows, columns of theta, columns the Jacobi runs on
 __host__ __device__ inline void theta_dims(const int* info, int d1, int d2, int& m, int& nfull, int& ncol) {
