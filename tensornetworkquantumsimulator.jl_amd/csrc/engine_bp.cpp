@@ -452,6 +452,21 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     if (!s->owns(src)) continue;
                     Chain c; c.v = src; c.src = s->site[src]->p; c.sd = site_dims(s, src);
                     const int jo = g.leg(src, dst);
+                    if (small_on && std::is_same<T, float>::value && c.sd.n >= 64 && bp_small_site_covers(c.sd.d, c.sd.z, c.sd.chi.data(), c.sd.n)) {
+                        // small site: one kernel for the whole message (no shared products, no remembered ones: nothing of the generic bookkeeping below applies)
+                        SmallMsgItem si{}; si.psi = c.src; si.d = c.sd.d; si.z = c.sd.z; si.jo = jo;
+                        for (int j = 0; j < c.sd.z; ++j) {
+                            si.chi[j] = c.sd.chi[j]; si.M[j] = nullptr;
+                            const int k = g.nbr[src][j]; if (k == dst) continue;
+                            const int din = g.dedge(k, src); const int pp = plan.pos_of[din];
+                            const Buf& mb = (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
+                            if (mb) si.M[j] = mb->p;                 // unset message = identity: nothing to absorb
+                        }
+                        small_items.push_back(si); small_chain.push_back((int)chains.size()); small_max = std::max(small_max, (int)c.sd.n);
+                        is_shared_chain.push_back((int)chains.size());
+                        chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(nullptr);
+                        continue;
+                    }
                     if (!tshare.empty() && c.sd.z == 4 && partner[src][jo] >= 0) {
                         const int r = partner[src][jo];
                         int pa = -1, pb = -1;
@@ -511,15 +526,6 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                         const Buf& mb = (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
                         if (!mb) continue;                               // unset message = identity: nothing to absorb
                         want.push_back({j, mb});
-                    }
-                    if (small_site(src)) {
-                        SmallMsgItem si{}; si.psi = c.src; si.d = c.sd.d; si.z = c.sd.z; si.jo = jo;
-                        for (int j = 0; j < c.sd.z; ++j) { si.chi[j] = c.sd.chi[j]; si.M[j] = nullptr; }
-                        for (auto& w : want) si.M[w.first] = w.second->p;
-                        small_items.push_back(si); small_chain.push_back((int)chains.size()); small_max = std::max(small_max, (int)c.sd.n);
-                        is_shared_chain.push_back((int)chains.size());
-                        chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(nullptr);
-                        continue;
                     }
                     const bool from_prefix = c.y != nullptr;             // continues from this level's shared product: that product is remembered, not what follows
                     if (cache_on && !from_prefix) {
@@ -621,10 +627,13 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     jobs.push_back(j);
                 }
                 if (!small_items.empty()) {
+                    size_t slab_bytes = 0;                   // one allocation for the raw messages of the level (views into it: a pool round trip per message otherwise)
+                    for (size_t q = 0; q < small_items.size(); ++q) { const int co = small_items[q].chi[small_items[q].jo]; slab_bytes += round256((size_t)co * co * esz); }
+                    Buf slab = dalloc(s, slab_bytes); size_t off = 0;
                     for (size_t q = 0; q < small_items.size(); ++q) {
                         GramJob& j = jobs[small_chain[q]];
                         const int co = small_items[q].chi[small_items[q].jo];
-                        j.nchunks = 1; j.KK = co; j.partial = dalloc(s, (size_t)co * co * esz);
+                        j.nchunks = 1; j.KK = co; j.partial = sub_buffer(slab, off, (size_t)co * co * esz); off += round256((size_t)co * co * esz);
                         small_items[q].out = j.partial->p;
                     }
                     on_side(true);          // (with a split level: next to the bulk sites' plane kernels, like the other boundary-site work; the descriptor copy

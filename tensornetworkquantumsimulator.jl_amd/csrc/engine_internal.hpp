@@ -216,8 +216,22 @@ struct PhaseScope {
     }
 };
 
+// bond dimensions of a site's legs without a heap allocation for degrees up to 8 (site_dims is called several times per message and per gate on the host:
+// on the latency-bound lattices the allocations were a measurable share of the BP preparation)
+struct ChiVec {
+    int inl[8]; int n = 0; std::vector<int> big;          // big: only when the degree exceeds 8
+    void push_back(int c) { if (n < 8 && big.empty()) inl[n++] = c; else { if (big.empty()) big.assign(inl, inl + n); big.push_back(c); ++n; } }
+    int* data() { return big.empty() ? inl : big.data(); }
+    const int* data() const { return big.empty() ? inl : big.data(); }
+    int& operator[](size_t i) { return data()[i]; }
+    const int& operator[](size_t i) const { return data()[i]; }
+    size_t size() const { return (size_t)n; }
+    bool empty() const { return n == 0; }
+    const int* begin() const { return data(); }
+    const int* end() const { return data() + n; }
+};
 struct SD {       // dims of a site tensor in canonical layout
-    int z = 0, d = 1; std::vector<int> chi; size_t n = 1;
+    int z = 0, d = 1; ChiVec chi; size_t n = 1;
     size_t pre(int j) const { size_t p = d; for (int i = 0; i < j; ++i) p *= chi[i]; return p; }
     size_t post(int j) const { size_t p = 1; for (int i = j + 1; i < z; ++i) p *= chi[i]; return p; }
 };
