@@ -527,16 +527,25 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             offB[q] = raw.size(); raw.insert(raw.end(), reinterpret_cast<const char*>(fb.data()), reinterpret_cast<const char*>(fb.data()) + fb.size() * 16);
         }
         const char* d_gm = pg.empty() ? nullptr : upload(s, raw);
+        // the per-gate workspaces (sixteen small buffers per gate, all of them dead at the end of the batch) are views into a few 4 MiB slabs: ~1100 pool round
+        // trips per heavy-hex batch, 0.13 ms of host time in front of gate_theta, were what the chip waited for after the Cholesky kernels
+        struct BatchArena { State* s; Buf cur; size_t off = 0, cap = 0;
+            Buf get(size_t bytes) {
+                const size_t b = round256(std::max<size_t>(bytes, 1));
+                if (b > ((size_t)1 << 20)) return dalloc(s, bytes);
+                if (!cur || off + b > cap) { cap = (size_t)4 << 20; cur = dalloc(s, cap); off = 0; }
+                Buf v = sub_buffer(cur, off, bytes); off += b; return v;
+            } } arena{s};
         for (size_t q = 0; q < pg.size(); ++q) {
             int gi = pg[q];
             GateWS& w = ws[gi]; GateItem& it = gitems[q];
             const SiteJob& a = sj[2 * gi]; const SiteJob& b = sj[2 * gi + 1];
             int Mr = w.n1 * a.sd.d, Nc = w.n2 * b.sd.d, cap = w.cap;
-            w.lam1 = dalloc(s, w.n1 * 8); w.lam2 = dalloc(s, w.n2 * 8); w.idx1 = dalloc(s, w.n1 * 4); w.idx2 = dalloc(s, w.n2 * 4);
-            w.theta = dalloc(s, (size_t)Mr * Nc * esz); w.thetaV = dalloc(s, (size_t)std::max(Mr, Nc) * std::max(Mr, Nc) * esz);
-            if (theta0_used) w.theta0 = dalloc(s, (size_t)Mr * Nc * esz);
-            w.X1 = dalloc(s, (size_t)w.n1 * a.sd.d * cap * esz); w.X2 = dalloc(s, (size_t)w.n2 * b.sd.d * cap * esz);
-            w.S = dalloc(s, cap * 8);
+            w.lam1 = arena.get(w.n1 * 8); w.lam2 = arena.get(w.n2 * 8); w.idx1 = arena.get(w.n1 * 4); w.idx2 = arena.get(w.n2 * 4);
+            w.theta = arena.get((size_t)Mr * Nc * esz); w.thetaV = arena.get((size_t)std::max(Mr, Nc) * std::max(Mr, Nc) * esz);
+            if (theta0_used) w.theta0 = arena.get((size_t)Mr * Nc * esz);
+            w.X1 = arena.get((size_t)w.n1 * a.sd.d * cap * esz); w.X2 = arena.get((size_t)w.n2 * b.sd.d * cap * esz);
+            w.S = arena.get(cap * 8);
             it.GA1 = GA[2 * gi]->p; it.GV1 = GV[2 * gi]->p; it.GA2 = GA[2 * gi + 1]->p; it.GV2 = GV[2 * gi + 1]->p;
             it.GW1 = GW[2 * gi]->p; it.GW2 = GW[2 * gi + 1]->p; it.chol1 = is_chol[2 * gi]; it.chol2 = is_chol[2 * gi + 1];
             it.n1 = w.n1; it.n2 = w.n2; it.d1 = a.sd.d; it.d2 = b.sd.d; it.chi = w.chi;
@@ -546,17 +555,17 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                 // the low-rank route of the theta SVD (lowG / lowL) only where it can apply -- K below the theta columns and chol_kernel's size
                 const int K = kappa[q] * w.chi;
                 if (lowrank_on && kappa[q] > 0) {
-                    w.lowA = dalloc(s, (size_t)Mr * K * 16); w.lowB = dalloc(s, (size_t)Nc * K * 16);
+                    w.lowA = arena.get((size_t)Mr * K * 16); w.lowB = arena.get((size_t)Nc * K * 16);
                     it.kappa = kappa[q]; it.opA = reinterpret_cast<const double*>(d_gm + offA[q]); it.opB = reinterpret_cast<const double*>(d_gm + offB[q]);
                     it.lowA = w.lowA->p; it.lowB = w.lowB->p; lowrank_on_batch = true;
                     const bool lds_fits = std::is_same<T, float>::value || jacobi_lds(jacobi_lds_bytes(Mr, K, false, esz)) > 0;      // ComplexF64: only where it buys the LDS route
                     if (K < Nc && K <= 128 && cap <= K && Mr >= Nc && lds_fits) {
-                        w.lowG = dalloc(s, (size_t)K * K * 16); w.lowL = dalloc(s, (size_t)K * K * 16); w.lowW = dalloc(s, (size_t)K * K * 16);
+                        w.lowG = arena.get((size_t)K * K * 16); w.lowL = arena.get((size_t)K * K * 16); w.lowW = arena.get((size_t)K * K * 16);
                         it.lowG = w.lowG->p; it.lowL = w.lowL->p;
                         // ComplexF32, factor of at most 128 x 64: the preconditioned SVD kernel builds V from Q = B L^-dagger (lowrank_m_kernel writes it)
-                        if (std::is_same<T, float>::value && use_precond_svd() && theta_svd_pre_covers(Mr, K) && K <= 96) { w.lowQ = dalloc(s, (size_t)Nc * K * 16); it.lowW = w.lowW->p; it.lowQ = w.lowQ->p; }
+                        if (std::is_same<T, float>::value && use_precond_svd() && theta_svd_pre_covers(Mr, K) && K <= 96) { w.lowQ = arena.get((size_t)Nc * K * 16); it.lowW = w.lowW->p; it.lowQ = w.lowQ->p; }
                         if (!std::is_same<T, float>::value) {
-                            w.lowB1 = dalloc(s, (size_t)Nc * K * 16); w.lowG2 = dalloc(s, (size_t)K * K * 16); w.lowL2 = dalloc(s, (size_t)K * K * 16); w.lowLc = dalloc(s, (size_t)K * K * 16);
+                            w.lowB1 = arena.get((size_t)Nc * K * 16); w.lowG2 = arena.get((size_t)K * K * 16); w.lowL2 = arena.get((size_t)K * K * 16); w.lowLc = arena.get((size_t)K * K * 16);
                         }
                     }
                 }
