@@ -18,14 +18,14 @@ from buildid import build_id  # noqa: E402
 
 
 def load(d):
-    f = glob.glob(d + "/*/*counter_collection.csv")
+    f = sorted(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime, reverse=True)      # (the newest run: a merged scratch directory keeps older ones)
     if not f:
         return {}, {}
     rows = defaultdict(lambda: defaultdict(dict)); dur = defaultdict(dict)
     for r in csv.DictReader(open(f[0])):
         name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
         rows[name][r["Dispatch_Id"]][r["Counter_Name"]] = rows[name][r["Dispatch_Id"]].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    for kt in glob.glob(d + "/*/*kernel_trace.csv"):
+    for kt in [f[0].replace("counter_collection", "kernel_trace")]:
         for r in csv.DictReader(open(kt)):
             name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
             dur[name][r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
@@ -37,7 +37,7 @@ def main():
     for d in sys.argv[2:]:
         rows, dur = load(d)
         for k, disp in rows.items():
-            if not any(t in k for t in ("mfma_", "rowgemm", "jacobi_lds", "chol_kernel")):
+            if not any(t in k for t in ("mfma_", "x3_", "rowgemm", "jacobi_lds", "chol_kernel", "theta_svd_pre")):
                 continue
             ds = {i: dur.get(k, {}).get(i, 0.0) for i in disp}
             if not ds or max(ds.values()) <= 0:
