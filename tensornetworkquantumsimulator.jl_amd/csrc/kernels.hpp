@@ -221,6 +221,7 @@ struct CopyItem { const void* src; void* dst; size_t n16; };                    
 bool rowgemm_covers(const FiberItem& it);
 void rowgemm_tiles(FiberItem& it);
 void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, int K, double* d_norm_partials);   // all items: the same K and D
+void launch_x3_rowgemm64(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, double* d_norm_partials);              // kernels_x3.hip: D K = 64 on the bf16 matrix cores
 void launch_tall_gram(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);
 void launch_tall_rt(hipStream_t s, const TallSvdItem* d_items, int nitems);
 void launch_tall_w(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);      // R0 slot (out, complex128) = [L slot: R^-1, complex128] x Rrot

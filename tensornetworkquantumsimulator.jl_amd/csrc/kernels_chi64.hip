@@ -528,6 +528,7 @@ template <int KB, int NB, int D> static void launch_rowgemm_t(hipStream_t s, con
 // all items of one launch must share K and D (the caller groups them)
 void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, int K, double* d_norm_partials) {
     if (total_wgs <= 0) return;
+    if (D * K == 64 && mfma_use_x3()) { launch_x3_rowgemm64(s, d_items, nitems, total_wgs, D, d_norm_partials); return; }      // <2, 2, 1> and <2, 2, 2> on the bf16 matrix cores
     if (K == 64 && D == 1) launch_rowgemm_t<2, 2, 1>(s, d_items, nitems, total_wgs, d_norm_partials);
     else if (K == 64 && D == 2) launch_rowgemm_t<4, 4, 2>(s, d_items, nitems, total_wgs, d_norm_partials);
     else if (K == 32 && D == 1) launch_rowgemm_t<1, 1, 1>(s, d_items, nitems, total_wgs, d_norm_partials);

@@ -428,4 +428,138 @@ void launch_x3_pair(hipStream_t s, const PairItem* d_items, int nitems, int tota
     TNQS_CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// register-direct fiber GEMM with KK = D K = 64 contracted and up to 64 output columns (mfma_rowgemm_kernel<2, 2, D>, kernels_chi64.hip: same items, same
+// tiles, same stores): the chi = 64 mode product (D = 1) and the chi = 32 gate epilogue with the site index folded in (D = 2).
+//   out[(s', n), row] = sum_kk in[kk, row] X[kk, (s', n)],   kk = (s, k);   computed transposed, C'[nn][row] = sum_kk X^T[nn][kk] in[row][kk]
+// B' operand = the tensor, straight from global memory into the registers that are split for the matrix cores: lane (ln = row, h) supplies the eight
+// k-slots kk = 16 n + 8 h + e of instruction n (D = 2: four 16-byte loads -- both site components of four k -- D = 1: eight 8-byte loads); A' operand =
+// X^T, split ONCE per workgroup into LDS in operand order (48 KiB: [n][nb][re / im][piece][lane] x 16 bytes, one conflict-free 16-byte read per piece).
+// Two half tiles of operand registers as in the f32 kernel: a half is refilled with the next tile's data as soon as its instructions are issued.
+// ------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void x3_rowgemm64_kernel(const FiberItem* __restrict__ items, int nitems, double* __restrict__ norm_partials) {
+    constexpr int KK = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u4* const Xl = reinterpret_cast<u4*>(smem);              // [(n, nb)][re h m l, im h m l][lane]
+    __shared__ double sh_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
+    int lo = 0, hi = nitems - 1;
+    const int gw = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].tile_begin <= gw) lo = mid; else hi = mid - 1; }
+    const FiberItem it = items[lo];
+    const int K = it.K, No = it.No, NN = it.Do * No;
+    const long long PA = it.PA;
+    const int ntiles = it.nta * it.ntb;
+    const int t_begin = (gw - it.tile_begin) * it.tpw, t_end = min(ntiles, t_begin + it.tpw);
+    const cf* __restrict__ in = reinterpret_cast<const cf*>(it.in);
+    const cf* __restrict__ X = reinterpret_cast<const cf*>(it.X);
+    cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
+    for (int e = tid; e < 4 * 2 * 64; e += 256) {            // (n, nb, lane): eight consecutive kk of column nn
+        const int l = e & 63, nb = (e >> 6) & 1, n = e >> 7;
+        const int nn = 32 * nb + (l & 31), kk0 = 16 * n + 8 * (l >> 5);
+        float xr[8], xi[8];
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (nn < NN) v = ldg4(X + kk0 + q + (size_t)KK * nn);
+            xr[q] = v[0]; xi[q] = v[1]; xr[q + 1] = v[2]; xi[q + 1] = v[3];
+        }
+        const P3 pr = split8(xr), pi = split8(xi);
+        u4* d = Xl + (size_t)((2 * n + nb) * 6) * 64 + l;
+        d[0] = pr.h; d[64] = pr.m; d[128] = pr.l; d[192] = pi.h; d[256] = pi.m; d[320] = pi.l;
+    }
+    __syncthreads();                                           // the only workgroup barrier
+    float hb[2][32];                                           // two half tiles: instructions n = 2 hf, 2 hf + 1 -> (re, im) of eight slots each
+    const bool rows_b = PA < 32;
+    const int RB = rows_b ? 32 / (int)PA : 1;
+    const long long kst = (long long)D * PA;                                                   // stride of the contracted index (elements)
+    const long long lane_in = rows_b ? (long long)D * (ln % (int)PA) + kst * K * (ln / (int)PA) : (long long)D * ln;
+    const long long lane_out = rows_b ? (long long)D * (ln % (int)PA) + kst * No * (ln / (int)PA) : (long long)D * ln;
+    auto base_in = [&](int t) { return rows_b ? kst * K * RB * t : (long long)D * 32 * (t % it.nta) + kst * K * (t / it.nta); };
+    auto base_out = [&](int t) { return rows_b ? kst * No * RB * t : (long long)D * 32 * (t % it.nta) + kst * No * (t / it.nta); };
+    // one 32-bit per-lane byte offset for every load of the kernel (row and lane half), everything else of an address is wave-uniform: the loads take the
+    // scalar-base form instead of one 64-bit address register pair each (sixteen of them live per half tile spilled the D = 1 variant at two workgroups per CU)
+    const unsigned voff = (unsigned)((lane_in + kst * (D == 1 ? 8 : 4) * h) * (long long)sizeof(cf));
+    auto issue_half = [&](int t, int hf) {
+        const cf* pu = in + base_in(t);
+#pragma unroll
+        for (int nn2 = 0; nn2 < 2; ++nn2) {
+            const int n = 2 * hf + nn2;
+            if (D == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const v2f v = ldg2(reinterpret_cast<const char*>(pu + kst * (16 * n + e)) + voff); hb[hf][16 * nn2 + e] = v[0]; hb[hf][16 * nn2 + 8 + e] = v[1]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const v4f v = ldg4(reinterpret_cast<const char*>(pu + kst * (8 * n + j)) + voff);
+                                              hb[hf][16 * nn2 + 2 * j] = v[0]; hb[hf][16 * nn2 + 8 + 2 * j] = v[1]; hb[hf][16 * nn2 + 2 * j + 1] = v[2]; hb[hf][16 * nn2 + 8 + 2 * j + 1] = v[3]; }
+            }
+        }
+    };
+    double nrm = 0;
+    int t = t_begin + w;
+    if (t < t_end) { issue_half(t, 0); issue_half(t, 1); }
+    for (; t < t_end; t += 4) {
+        v16f Cr[2], Ci[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int nn2 = 0; nn2 < 2; ++nn2) {
+                const int n = 2 * hf + nn2;
+                float br[8], bi[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { br[e] = hb[hf][16 * nn2 + e]; bi[e] = hb[hf][16 * nn2 + 8 + e]; }
+                const P3 pbr = split8(br), pbi = split8(bi), nbi = neg(pbi);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const u4* a = Xl + (size_t)((2 * n + nb) * 6) * 64 + lane;
+                    P3 xr, xi; xr.h = a[0]; xr.m = a[64]; xr.l = a[128]; xi.h = a[192]; xi.m = a[256]; xi.l = a[320];
+                    if (n == 0) mac6x2<true>(Cr[nb], xr, pbr, Ci[nb], xr, pbi); else mac6x2<false>(Cr[nb], xr, pbr, Ci[nb], xr, pbi);
+                    mac6x2<false>(Cr[nb], xi, nbi, Ci[nb], xi, pbr);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                                   // the refill must not be hoisted above the instructions that read the half
+            if (t + 4 < t_end) issue_half(t + 4, hf);
+        }
+        float nf = 0.f;
+        cf* p = out + base_out(t) + lane_out;
+        if (D == 1) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (n < No) { cf v; v.re = Cr[nb][r]; v.im = Ci[nb][r]; stgc(p + PA * n, v); nf += v.re * v.re + v.im * v.im; }
+                }
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int nn = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h;  // even: s' = 0 of n = nn / 2; register r + 1 is s' = 1
+                    const int n = nn >> 1;
+                    if (n < No) {
+                        v4f v = {Cr[nb][r], Ci[nb][r], Cr[nb][r + 1], Ci[nb][r + 1]};
+                        stg4(p + 2 * PA * n, v);
+                        nf += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                    }
+                }
+        }
+        nrm += (double)nf;
+    }
+    if (it.want_norm) {
+        nrm = wave_sum_d(nrm);
+        if (lane == 0) sh_red[w] = nrm;
+        __syncthreads();
+        if (tid == 0) norm_partials[gw] = sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3];
+    }
+}
+void launch_x3_rowgemm64(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, double* d_norm_partials) {
+    if (total_wgs <= 0) return;
+    const size_t lds = (size_t)4 * 2 * 6 * 64 * 16;
+    if (D == 1) { set_max_dynamic_lds((const void*)x3_rowgemm64_kernel<1>, lds); hipLaunchKernelGGL(x3_rowgemm64_kernel<1>, dim3(total_wgs), dim3(256), lds, s, d_items, nitems, d_norm_partials); }
+    else { set_max_dynamic_lds((const void*)x3_rowgemm64_kernel<2>, lds); hipLaunchKernelGGL(x3_rowgemm64_kernel<2>, dim3(total_wgs), dim3(256), lds, s, d_items, nitems, d_norm_partials); }
+    TNQS_CHECK_LAUNCH();
+}
+
 }  // namespace tnqs
