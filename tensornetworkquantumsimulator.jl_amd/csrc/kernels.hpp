@@ -221,6 +221,7 @@ struct CopyItem { const void* src; void* dst; size_t n16; };                    
 bool rowgemm_covers(const FiberItem& it);
 void rowgemm_tiles(FiberItem& it);
 void launch_mfma_rowgemm(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, int K, double* d_norm_partials);   // all items: the same K and D
+bool launch_x3_gram64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax);                               // kernels_x3.hip: mfma_gram64_kernel on the bf16 matrix cores
 void launch_x3_rowgemm64(hipStream_t s, const FiberItem* d_items, int nitems, int total_wgs, int D, double* d_norm_partials);              // kernels_x3.hip: D K = 64 on the bf16 matrix cores
 void launch_tall_gram(hipStream_t s, const TallSvdItem* d_items, int nitems, int nmax);
 void launch_tall_rt(hipStream_t s, const TallSvdItem* d_items, int nitems);

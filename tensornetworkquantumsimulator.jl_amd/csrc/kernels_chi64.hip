@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void mfma_gram64_kernel(const GramItem* __r
 bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
     if (KKmax > 64) return false;
     if (total_chunks <= 0) return true;
+    if (mfma_use_x3()) return launch_x3_gram64(s, d_items, nitems, total_chunks, KKmax);
     const size_t lds = (size_t)4 * 64 * 68 * sizeof(float);
     if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_gram64_kernel<true>, lds); hipLaunchKernelGGL(mfma_gram64_kernel<true>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }
     else { set_max_dynamic_lds((const void*)mfma_gram64_kernel<false>, lds); hipLaunchKernelGGL(mfma_gram64_kernel<false>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }

@@ -562,4 +562,174 @@ void launch_x3_rowgemm64(hipStream_t s, const FiberItem* d_items, int nitems, in
     TNQS_CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Gram with f32 accumulation, KK = D K <= 64 (mfma_gram64_kernel, kernels_chi64.hip: same items, tiles, loads, LDS image and partials): the BP message Gram
+// at chi = 64 and at chi = 32 with the site index kept.  The sixteen tile rows a wave takes per half are exactly one v_mfma_f32_32x32x16_bf16 (lane half h:
+// eight CONSECUTIVE rows of its column, already contiguous in the [kk][row] image): 96 bf16 instructions per tile and wave where the f32 kernel issued 96 of
+// twice the length, and 552 vector instructions of splitting.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void x3_gram64_kernel(const GramItem* __restrict__ items, int nitems) {
+    constexpr int TR = 64, TRP = TR + 4, NU = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const Xr = reinterpret_cast<float*>(smem);
+    float* const Xi = Xr + 64 * TRP;
+    float* const Yr = Xi + 64 * TRP;
+    float* const Yi = Yr + 64 * TRP;
+    const int tid = threadIdx.x;
+    int lo = 0, hi = nitems - 1;
+    const int gc = blockIdx.x;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (items[mid].chunk_begin <= gc) lo = mid; else hi = mid - 1; }
+    const GramItem it = items[lo];
+    const int lc = gc - it.chunk_begin;
+    const int D = it.D, K = it.K, TA = it.TA, TB = it.TB, KK = D * K;
+    const long long PA = it.PA;
+    const bool same = (it.X == it.Y);
+    const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
+    const cf* __restrict__ Yg = reinterpret_cast<const cf*>(it.Y);
+    const int ntiles = it.nta * it.ntb;
+    const int t_begin = lc * it.tiles_per_chunk;
+    const int t_end = min(ntiles, t_begin + it.tiles_per_chunk);
+    const int lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
+    // wave w: output rows block a = w & 1 (i in [32 a, 32 a + 32)) x all 64 columns, tile rows 32 (w >> 1) .. + 32 -- 64 accumulator
+    // registers per wave instead of 128, so that TWO workgroups fit a CU (one's barriers and LDS commits hide behind the other's MFMAs)
+    const int a = w & 1, rh = w >> 1;
+    v16f Cr[2], Ci[2];                                           // out = X conj(Y):  re = Xr Yr + Xi Yi,  im = Xi Yr + Xr (-Yi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { Cr[0][r] = 0.f; Cr[1][r] = 0.f; Ci[0][r] = 0.f; Ci[1][r] = 0.f; }
+    for (int e = tid; e < 64 * TRP; e += 256) { Xr[e] = 0.f; Xi[e] = 0.f; Yr[e] = 0.f; Yi[e] = 0.f; }
+    const TileMap m = make_map(tid, D, TA, TB, PA, K);
+    const long long kstride = (long long)D * PA;
+    const bool fast = m.U <= 256 && (K + m.KP - 1) / m.KP <= NU;
+    v4f px[NU], py[NU];
+    auto tile_origin = [&](int t, int& a0, int& b0, int& na, int& nb) {
+        int ta = t % it.nta, tb = t / it.nta;
+        a0 = ta * TA; b0 = tb * TB; na = min(TA, it.PA - a0); nb = min(TB, it.PB - b0);
+    };
+    // full tiles of the usual shape (every thread owns NU two-element units): straight-line loads.  The guarded path below compiles
+    // into one branch per load with an s_waitcnt vmcnt(0) in front of the next one, i.e. the NU loads of a tile are SERIALISED (seen in the
+    // ISA; a 64-row tile then costs NU memory latencies, ~10 us instead of the 3.4 us of its matrix work)
+    const bool straight = fast && m.active && m.vec == 2 && K == m.KP * NU;
+    auto issue_loads = [&](int t) {
+        int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
+        const long long org = (long long)D * (a0 + PA * (long long)K * b0);
+        if (straight && na == TA && nb == TB) {
+            const cf* px0 = Xg + org + m.off + kstride * m.kp; const cf* py0 = Yg + org + m.off + kstride * m.kp;
+            const long long st = kstride * m.KP;
+            if (same) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) { px[j] = ldg4(px0 + st * j); py[j] = px[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) { px[j] = ldg4(px0 + st * j); py[j] = ldg4(py0 + st * j); }
+            }
+            return;
+        }
+        const bool v0 = m.active && m.al < na && m.bl < nb, v1 = v0 && m.al1 < na;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = m.kp + m.KP * j;
+            v4f vx, vy; vx[0] = vx[1] = vx[2] = vx[3] = 0.f; vy = vx;
+            if (k < K && v0) {
+                const long long o = org + m.off + kstride * k;
+                if (m.vec == 2 && v1) { vx = ldg4(Xg + o); vy = same ? vx : ldg4(Yg + o); }
+                else { cf x = ldgc(Xg + o); vx[0] = x.re; vx[1] = x.im; if (same) vy = vx; else { cf y = ldgc(Yg + o); vy[0] = y.re; vy[1] = y.im; } }
+            }
+            px[j] = vx; py[j] = vy;
+        }
+    };
+    auto commit_loads = [&]() {                  // invalid cells were loaded as zeros, so edge tiles need no extra clearing
+        if (!m.active) return;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            int k = m.kp + m.KP * j;
+            if (k < K) {
+                int o0 = (m.c0 + D * k) * TRP + m.row0;
+                Xr[o0] = px[j][0]; Xi[o0] = px[j][1]; Yr[o0] = py[j][0]; Yi[o0] = py[j][1];
+                if (m.vec == 2) { int o1 = (m.c1 + D * k) * TRP + m.row1; Xr[o1] = px[j][2]; Xi[o1] = px[j][3]; Yr[o1] = py[j][2]; Yi[o1] = py[j][3]; }
+            }
+        }
+    };
+    if (fast && t_begin < t_end) issue_loads(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        lds_barrier();
+        if (fast) commit_loads();
+        else {
+            int a0, b0, na, nb; tile_origin(t, a0, b0, na, nb);
+            const int ntile_el = D * TA * K * TB;
+            for (int e = tid; e < ntile_el; e += 256) {
+                int s = e % D; int r1 = e / D; int al = r1 % TA; int r2 = r1 / TA; int k = r2 % K; int bl = r2 / K;
+                cf vx, vy; vx.re = vx.im = vy.re = vy.im = 0.f;
+                if (al < na && bl < nb) {
+                    long long off = s + D * ((long long)(a0 + al) + PA * ((long long)k + (long long)K * (b0 + bl)));
+                    vx = Xg[off]; vy = same ? vx : Yg[off];
+                }
+                int o = (s + D * k) * TRP + (al + TA * bl);
+                Xr[o] = vx.re; Xi[o] = vx.im; Yr[o] = vy.re; Yi[o] = vy.im;
+            }
+        }
+        lds_barrier();
+        if (fast && t + 1 < t_end) issue_loads(t + 1);
+        // rows 32 rh .. 32 rh + 31 in two halves of 16 (lane half h takes 8 of them): bounds the operand registers
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int r0 = 32 * rh + 16 * hf + 8 * h;
+            float xr[8], xi[8], yr[2][8], yi[2][8];
+            {
+                const int ro = (32 * a + ln) * TRP + r0;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    v4f t0 = *reinterpret_cast<const v4f*>(Xr + ro + 4 * q), t1 = *reinterpret_cast<const v4f*>(Xi + ro + 4 * q);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { xr[4 * q + c] = t0[c]; xi[4 * q + c] = t1[c]; }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ro = (32 * b + ln) * TRP + r0;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    v4f t2 = *reinterpret_cast<const v4f*>(Yr + ro + 4 * q), t3 = *reinterpret_cast<const v4f*>(Yi + ro + 4 * q);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { yr[b][4 * q + c] = t2[c]; yi[b][4 * q + c] = t3[c]; }
+                }
+            }
+            // one matrix instruction covers the sixteen rows of this half (lane half h: eight of them): operands split on the fly
+            const P3 pxr = split8(xr), pxi = split8(xi);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const P3 pyr = split8(yr[b]), pyi = split8(yi[b]);
+                mac6x2<false>(Cr[b], pxr, pyr, Ci[b], pxi, pyr);
+                mac6x2<false>(Cr[b], pxi, pyi, Ci[b], pxr, neg(pyi));
+            }
+        }
+    }
+    // one partial per chunk: the two row halves (waves w, w + 2) are summed through the free tile buffers
+    lds_barrier();
+    v2f* const R = reinterpret_cast<v2f*>(smem);                // [rh][j][i], pitch 65: 2 * 64 * 65 * 8 B = 66.5 KB
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, j = 32 * b + ln;
+            v2f v = {Cr[b][r], Ci[b][r]};
+            R[(rh * 64 + j) * 65 + i] = v;
+        }
+    lds_barrier();
+    cf* __restrict__ part = reinterpret_cast<cf*>(it.partial) + (size_t)lc * KK * KK;
+    for (int e = tid; e < KK * KK; e += 256) {
+        const int i = e % KK, j = e / KK;
+        const v2f u = R[j * 65 + i], v = R[(64 + j) * 65 + i];
+        cf o; o.re = u[0] + v[0]; o.im = u[1] + v[1]; part[e] = o;
+    }
+}
+bool launch_x3_gram64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks, int KKmax) {
+    if (KKmax > 64) return false;
+    if (total_chunks <= 0) return true;
+    const size_t lds = (size_t)4 * 64 * 68 * sizeof(float);
+    set_max_dynamic_lds((const void*)x3_gram64_kernel, lds);
+    hipLaunchKernelGGL(x3_gram64_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems);
+    TNQS_CHECK_LAUNCH();
+    return true;
+}
+
 }  // namespace tnqs
