@@ -257,17 +257,38 @@ template void launch_reduce<double, float>(hipStream_t, const ReduceItem*, int, 
 // ------------------------------------------------------------------------------------------------------------
 // BP message epilogue: reduce partials, normalise by the sum of all elements, message_diff
 // ------------------------------------------------------------------------------------------------------------
+// several block-wide sums with ONE pair of barriers (blockDim.x <= 1024); results valid in every thread
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double* sh /* >= 17 N doubles */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) sh[N * w + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < N) { double t = 0; for (int i = 0; i < nw; ++i) t += sh[N * i + threadIdx.x]; sh[16 * N + threadIdx.x] = t; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = sh[16 * N + k];
+}
+// 1024 threads per message (round 5): with 256 a chi = 32 message was four elements per thread x 16 partials in dependent groups of eight loads, then six
+// block-wide sums of three barriers each -- 50 us per launch on the critical path of every BP level, whatever the lattice size; now one element per thread and
+// two reductions (element sum; the four sums of message_diff together)
 template <class T>
-__global__ __launch_bounds__(256) void msg_finalize_kernel(const MsgFinalItem* __restrict__ items) {
-    __shared__ double sh[17];
+__global__ __launch_bounds__(1024) void msg_finalize_kernel(const MsgFinalItem* __restrict__ items) {
+    __shared__ double sh[17 * 4];
     const MsgFinalItem it = items[blockIdx.x];
     const int n2 = it.chi * it.chi;
+    const int NT = blockDim.x;
     const cx<T>* p = reinterpret_cast<const cx<T>*>(it.partial);
     cx<T>* out = reinterpret_cast<cx<T>*>(it.new_msg);
     const cx<T>* old = reinterpret_cast<const cx<T>*>(it.old_msg);
     // pass 1: reduce chunks (fixed order) into new_msg, accumulate the element sum
-    double sre = 0, sim = 0;
-    for (int e = threadIdx.x; e < n2; e += 256) {
+    double s2[2] = {0, 0};
+    for (int e = threadIdx.x; e < n2; e += NT) {
         // eight independent partial sums (fixed order): the loads of a thread do not depend on each other, so eight are in flight at a
         // time instead of one -- a message with thousands of partials took a millisecond here
         T pr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -280,35 +301,36 @@ __global__ __launch_bounds__(256) void msg_finalize_kernel(const MsgFinalItem* _
         const T re = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
         const T im = ((pi[0] + pi[1]) + (pi[2] + pi[3])) + ((pi[4] + pi[5]) + (pi[6] + pi[7]));
         out[e] = cmake<T>(re, im);
-        sre += re; sim += im;
+        s2[0] += re; s2[1] += im;
     }
-    sre = block_sum(sre, sh); sim = block_sum(sim, sh);
+    block_sum_n<2>(s2, sh);
+    const double sre = s2[0], sim = s2[1];
     // m / sum(m)   (abstractbeliefpropagationcache.jl:182-187; skipped when the sum is exactly zero)
     double ire = 1, iim = 0;
     if (it.normalize && (sre != 0 || sim != 0)) { double d = sre * sre + sim * sim; ire = sre / d; iim = -sim / d; }
-    double dre = 0, dim_ = 0, na = 0, nb = 0;
-    for (int e = threadIdx.x; e < n2; e += 256) {
-        cx<T> v = out[e];
+    double d4[4] = {0, 0, 0, 0};       // Re, Im of dot(new, old), |new|^2, |old|^2
+    for (int e = threadIdx.x; e < n2; e += NT) {
+        cx<T> v = out[e];              // (written by this thread above)
         double re = v.re * ire - v.im * iim, im = v.re * iim + v.im * ire;
         cx<T> w = cmake<T>((T)re, (T)im);
         out[e] = w;
         double ore, oim;
         if (old) { ore = old[e].re; oim = old[e].im; } else { ore = (e % it.chi == e / it.chi) ? 1.0 : 0.0; oim = 0; }
         // dot(a, b) = sum conj(a) b with a = new, b = old  (beliefpropagationcache.jl:17-21)
-        dre += (double)w.re * ore + (double)w.im * oim;
-        dim_ += (double)w.re * oim - (double)w.im * ore;
-        na += (double)w.re * w.re + (double)w.im * w.im;
-        nb += ore * ore + oim * oim;
+        d4[0] += (double)w.re * ore + (double)w.im * oim;
+        d4[1] += (double)w.re * oim - (double)w.im * ore;
+        d4[2] += (double)w.re * w.re + (double)w.im * w.im;
+        d4[3] += ore * ore + oim * oim;
     }
-    dre = block_sum(dre, sh); dim_ = block_sum(dim_, sh); na = block_sum(na, sh); nb = block_sum(nb, sh);
+    block_sum_n<4>(d4, sh);
     if (threadIdx.x == 0 && it.diff_out) {
-        double f = (dre * dre + dim_ * dim_) / (na * nb);
+        double f = (d4[0] * d4[0] + d4[1] * d4[1]) / (d4[2] * d4[3]);
         *it.diff_out = 1.0 - f;
     }
 }
 template <class T> void launch_msg_finalize(hipStream_t s, const MsgFinalItem* d_items, int nitems) {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL((msg_finalize_kernel<T>), dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((msg_finalize_kernel<T>), dim3(nitems), dim3(1024), 0, s, d_items); TNQS_CHECK_LAUNCH();
 }
 template void launch_msg_finalize<float>(hipStream_t, const MsgFinalItem*, int);
 template void launch_msg_finalize<double>(hipStream_t, const MsgFinalItem*, int);
