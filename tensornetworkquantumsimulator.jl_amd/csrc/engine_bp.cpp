@@ -638,7 +638,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     }
                     on_side(true);          // (with a split level: next to the bulk sites' plane kernels, like the other boundary-site work; the descriptor copy
                                             //  travels on the same stream as the kernel that reads it)
-                    const SmallMsgItem* d = upload(s, small_items);
+                    const SmallMsgItem* d = upload_small(s, small_items);          // (one workgroup per item reads its own descriptor: straight from the pinned arena)
                     { ProfScope ps(s, TNQS_PROF_BP_FUSED, 0, 0); launch_bp_small_site(s->stream, d, (int)small_items.size(), small_max); }
                     on_side(false);
                 }

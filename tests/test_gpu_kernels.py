@@ -72,7 +72,9 @@ def fiber_ref(x, X, D, PA, K, PB, Do, No):
 @pytest.mark.parametrize("D,PA,K,PB,Do,No", [(2, 64, 64, 8, 2, 64), (1, 128, 64, 16, 1, 64), (2, 4, 64, 70, 2, 40), (1, 64, 32, 64, 1, 32), (2, 32, 32, 32, 2, 32), (2, 128, 32, 4, 2, 17), (1, 2, 32, 200, 1, 32), (2, 16, 16, 70, 2, 5),
                                              (1, 2, 3, 5, 1, 3), (1, 100, 10, 7, 1, 10), (1, 1, 7, 130, 1, 7), (2, 9, 5, 4, 2, 3),
                                              (2, 1, 1, 1, 2, 1), (2, 300, 1, 1, 2, 1), (1, 64, 32, 33, 1, 32), (2, 16, 16, 16, 2, 16),
-                                             (3, 5, 4, 6, 3, 2), (2, 70, 8, 3, 2, 11)])
+                                             (3, 5, 4, 6, 3, 2), (2, 70, 8, 3, 2, 11),
+                                             # D K = 64 with fewer than 32 fibers below the leg (rows of a tile = several b-indices): the register-direct kernels' second addressing mode
+                                             (2, 1, 32, 64, 2, 32), (2, 8, 32, 16, 2, 32), (1, 16, 64, 8, 1, 64), (1, 4, 64, 32, 1, 40), (2, 2, 32, 48, 2, 9)])
 def test_fiber_gemm(dtype, mfma, D, PA, K, PB, Do, No):
     rng = np.random.default_rng(D + PA + K + PB)
     dt = CDT[dtype]
