@@ -10,7 +10,7 @@ pids=()
 for f in kernels.hip kernels_mfma.hip kernels_x3.hip kernels_plane.hip kernels_chi64.hip kernels_gate.hip kernels_f64.hip engine_core.cpp engine_batch.cpp engine_bp.cpp engine_gates.cpp engine_obs.cpp sharding.cpp api.cpp debug.cpp; do
   [ -f "$f" ] || continue
   o=build/${f%.*}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ kernels.hpp -nt "$o" ] || [ engine.hpp -nt "$o" ] || [ engine_internal.hpp -nt "$o" ] || [ launch_util.hpp -nt "$o" ] || [ mfma_common.hpp -nt "$o" ] || [ ../../include/tnqs.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ kernels.hpp -nt "$o" ] || [ engine.hpp -nt "$o" ] || [ engine_internal.hpp -nt "$o" ] || [ launch_util.hpp -nt "$o" ] || [ mfma_common.hpp -nt "$o" ] || [ x3_common.hpp -nt "$o" ] || [ ../../include/tnqs.h -nt "$o" ]; then
     if [[ "$f" == *.hip ]]; then hipcc $FLAGS -c "$f" -o "$o" & else hipcc $FLAGS -x hip -c "$f" -o "$o" & fi
     pids+=($!)
   fi

@@ -15,6 +15,7 @@
 #include "kernels.hpp"
 #include "mfma_common.hpp"
 #include "launch_util.hpp"
+#include "x3_common.hpp"
 
 namespace tnqs {
 
@@ -30,6 +31,10 @@ namespace tnqs {
 //              the waves exactly as in mfma_gram64_f64_kernel<true, true> (same partial layout: 2 per chunk, one per tile parity).
 // Pipeline: iteration t commits and transforms tile t + 1 in the other buffer, issues the loads of tile t + 2, then multiplies tile t;
 // ONE workgroup barrier per tile.
+// X3 (round 5, default): the transform on the bf16 matrix cores -- the tile rows split exactly into three bf16 pieces on the fly, the matrix A split once per
+// workgroup into LDS in operand order (12 KiB in place of the 8 KiB f32 copy: 80 KiB per workgroup, two of them fill the 160 KiB of a CU exactly), four real
+// products x six piece products: 48 instructions of 32 cycles instead of 48 of 64 (kernels_x3.hip; TNQS_NO_BF16X3=1: the f32 instructions)
+template <bool X3>
 __global__ __launch_bounds__(256, 2) void mfma_gauge_gram64_kernel(const GramItem* __restrict__ items, int nitems) {
     constexpr int TRP = 68, PLANE = 64 * TRP, NU = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -50,7 +55,20 @@ __global__ __launch_bounds__(256, 2) void mfma_gauge_gram64_kernel(const GramIte
     const int t_begin = lc * it.tiles_per_chunk;
     const int t_end = min(ntiles, t_begin + it.tiles_per_chunk);
     // the matrix of the absorbed leg, transposed for the B operand: column-major A[r + 32 r'] -> Mr[r * 32 + r']
-    for (int e = tid; e < 1024; e += 256) { const cf v = ldgc(Mg + e); const int r = e & 31, rp = e >> 5; Mr[r * 32 + rp] = v.re; Mi[r * 32 + rp] = v.im; }
+    u4* const Mp = reinterpret_cast<u4*>(Mr);                    // X3: [n][re h m l, im h m l][lane] x 16 bytes: B[k = r = 16 n + 8 (lane >> 5) + e][j = r' = lane & 31]
+    if (X3) {
+        if (tid < 128) {
+            const int l = tid & 63, n = tid >> 6, rp = l & 31, r0 = 16 * n + 8 * (l >> 5);
+            float xr[8], xi[8];
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) { const v4f v = ldg4(Mg + r0 + q + 32 * rp); xr[q] = v[0]; xi[q] = v[1]; xr[q + 1] = v[2]; xi[q + 1] = v[3]; }
+            const P3 pr = split8(xr), pi = split8(xi);
+            u4* d = Mp + (size_t)(6 * n) * 64 + l;
+            d[0] = pr.h; d[64] = pr.m; d[128] = pr.l; d[192] = pi.h; d[256] = pi.m; d[320] = pi.l;
+        }
+    } else {
+        for (int e = tid; e < 1024; e += 256) { const cf v = ldgc(Mg + e); const int r = e & 31, rp = e >> 5; Mr[r * 32 + rp] = v.re; Mi[r * 32 + rp] = v.im; }
+    }
     // thread -> fiber of the tile and its element offset (D = 2, K = 32):  2 (al + PA 32 bl)
     const int al = lane % TA, bl = lane / TA;
     const long long off = 2LL * (al + PA * 32LL * bl) + 2LL * PA * (8 * w);     // + kstride * first bond index of this wave
@@ -75,6 +93,33 @@ __global__ __launch_bounds__(256, 2) void mfma_gauge_gram64_kernel(const GramIte
     const int abase = (16 * w + (gi & 15)) * TRP + 32 * (gi >> 4) + 16 * gh;
     auto transform = [&](int buf) {
         float* Xr = Xbuf + buf * (2 * PLANE); float* Xi = Xr + PLANE;
+        if (X3) {
+            // A operand: row i = gi, slots k = r = 16 n + 8 gh + e: eight consecutive floats of the row per instruction n
+            const int ab3 = (16 * w + (gi & 15)) * TRP + 32 * (gi >> 4) + 8 * gh;
+            v16f Re, Im;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float ar[8], ai[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const v4f a = *reinterpret_cast<const v4f*>(Xr + ab3 + 16 * n + 4 * q), b = *reinterpret_cast<const v4f*>(Xi + ab3 + 16 * n + 4 * q);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { ar[4 * q + c] = a[c]; ai[4 * q + c] = b[c]; }
+                }
+                const P3 pxr = split8(ar), pxi = split8(ai);
+                const u4* m = Mp + (size_t)(6 * n) * 64 + lane;
+                P3 br, bi; br.h = m[0]; br.m = m[64]; br.l = m[128]; bi.h = m[192]; bi.m = m[256]; bi.l = m[320];
+                if (n == 0) mac6x2<true>(Re, pxr, br, Im, pxr, bi); else mac6x2<false>(Re, pxr, br, Im, pxr, bi);
+                mac6x2<false>(Re, neg(pxi), bi, Im, pxi, br);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * gh;            // GEMM row (q, j) of this accumulator register; column r' = gi
+                const int o = (16 * w + (row & 15)) * TRP + 32 * (row >> 4) + gi;
+                Xr[o] = Re[r]; Xi[o] = Im[r];
+            }
+            return;
+        }
         v16f k1, k2, k3;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { k1[r] = 0.f; k2[r] = 0.f; k3[r] = 0.f; }
@@ -173,9 +218,15 @@ bool gauge_gram64_covers(int d, int z, const int* chi, int bleg, int rleg) {
 }
 void launch_mfma_gauge_gram64(hipStream_t s, const GramItem* d_items, int nitems, int total_chunks) {
     if (total_chunks <= 0) return;
+    if (mfma_use_x3()) {
+        const size_t lds = (size_t)(4 * 64 * 68) * sizeof(float) + 12 * 64 * 16;
+        set_max_dynamic_lds((const void*)mfma_gauge_gram64_kernel<true>, lds);
+        hipLaunchKernelGGL(mfma_gauge_gram64_kernel<true>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+        return;
+    }
     const size_t lds = (size_t)(4 * 64 * 68 + 2048) * sizeof(float);
-    set_max_dynamic_lds((const void*)mfma_gauge_gram64_kernel, lds);
-    hipLaunchKernelGGL(mfma_gauge_gram64_kernel, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
+    set_max_dynamic_lds((const void*)mfma_gauge_gram64_kernel<false>, lds);
+    hipLaunchKernelGGL(mfma_gauge_gram64_kernel<false>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
 }
 
 // ------------------------------------------------------------------------------------------------------------
