@@ -278,6 +278,31 @@ def test_double_pair_gram(chi, lx, ly):
         assert np.max(np.abs(got.reshape(32, 32).T - ref)) < 3e-5 * np.max(np.abs(ref)) * scale
 
 
+@pytest.mark.parametrize("D,PA,K,PB", [(2, 64, 32, 64), (1, 128, 64, 32), (2, 1, 32, 2048)])
+def test_bf16x3_fiber_gemm_and_gram_are_f32_accurate(D, PA, K, PB):
+    """the other kernels of the bf16 x 3 route (csrc/kernels_x3.hip: x3_rowgemm64_kernel -- chi = 32 epilogue with the site index folded in, chi = 64 mode
+    product -- and x3_gram64_kernel) against f64 references, held to f32-class bounds: 1e-6 of the largest entry for the 64-term products, 3e-6 for the Gram's
+    sums of PA PB terms (the generic tests above allow EPS D K = 4e-5 resp. 3e-5)"""
+    rng = np.random.default_rng(D + PA + K + PB)
+    x = rnd(rng, D * PA * K * PB, np.complex64)
+    X = rnd(rng, D * K * D * K, np.complex64)
+    out = np.zeros(D * PA * K * PB, dtype=np.complex64)
+    n2 = C.c_double()
+    assert lib.tnqs_dbg_fiber_gemm(0, D, PA, K, PB, D, K, x.ctypes.data_as(C.c_void_p), X.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(n2), 1) == 0
+    ref = fiber_ref(x, X, D, PA, K, PB, D, K)
+    assert np.max(np.abs(out - ref)) < 1e-6 * np.max(np.abs(ref))
+    if D * K == 64 and PA * PB >= 64:
+        y = rnd(rng, D * PA * K * PB, np.complex64)
+        KK = D * K
+        g = np.zeros(KK * KK, dtype=np.complex64)
+        assert lib.tnqs_dbg_gram(0, D, PA, K, PB, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), 0, 1) == 0
+        tx = x.reshape(PB, K, PA, D).transpose(3, 1, 2, 0).reshape(D, K, -1).astype(np.complex128)
+        ty = y.reshape(PB, K, PA, D).transpose(3, 1, 2, 0).reshape(D, K, -1).astype(np.complex128)
+        mx = tx.transpose(1, 0, 2).reshape(KK, -1); my = ty.transpose(1, 0, 2).reshape(KK, -1)
+        gref = (mx @ my.conj().T).T.reshape(-1)
+        assert np.max(np.abs(g - gref)) < 3e-6 * np.max(np.abs(gref))
+
+
 @pytest.mark.parametrize("lx,ly", [(1, 2), (0, 3), (2, 0)])
 @pytest.mark.parametrize("scale", [1e-12, 1e-3, 1e6])
 def test_bf16x3_plane_kernels_are_f32_accurate(lx, ly, scale):
