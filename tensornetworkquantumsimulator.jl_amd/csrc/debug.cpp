@@ -6,6 +6,7 @@
 #include <algorithm>
 #include "engine.hpp"
 #include "kernels.hpp"
+#include "launch_util.hpp"
 
 namespace tnqs {
 #define HIPCHK(x) hipchk((x), #x)
@@ -234,12 +235,19 @@ void dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, 
     size_t n = d; for (int i = 0; i < z; ++i) n *= chi[i];
     int nslices = it.g.n0 * it.g.n1 * it.g.n2;
     it.spw = 3; it.wg_begin = 0;
-    int nwg = (nslices + it.spw - 1) / it.spw, npart = nwg;
-    DBuf dX(n * 8), dY(n * 8), dM(32 * 32 * 8), dI(sizeof(PairGramItem)), dR(sizeof(ReduceItem)), dP((size_t)npart * 1024 * 8), dO(1024 * 8);
+    const bool x3 = mfma_use_x3();       // the engine's route: the bf16 kernel in its one-message form (half-slice workgroups in groups of 16)
+    int nwg = x3 ? 16 * (((nslices + it.spw - 1) / it.spw + 7) / 8) : (nslices + it.spw - 1) / it.spw, npart = nwg;
+    DBuf dX(n * 8), dY(n * 8), dM(32 * 32 * 8), dI(sizeof(PairGram2Item)), dR(sizeof(ReduceItem)), dP((size_t)npart * 1024 * 8), dO(1024 * 8);
     dX.up(X, n * 8); dY.up(Y, n * 8); dM.up(M, 32 * 32 * 8);
     it.X = dX.p; it.Y = dY.p; it.M = dM.p; it.partial = dP.p;
-    dI.up(&it, sizeof(it));
-    launch_mfma_pair_gram(nullptr, (const PairGramItem*)dI.p, 1, nwg);
+    if (x3) {
+        PairGram2Item one{}; one.X = it.X; one.Y = it.Y; one.Mx = it.M; one.My = nullptr; one.partial_y = it.partial; one.partial_x = nullptr; one.g = it.g; one.wg_begin = 0; one.spw = it.spw;
+        dI.up(&one, sizeof(one));
+        launch_x3_pair_gram1(nullptr, (const PairGram2Item*)dI.p, 1, nwg);
+    } else {
+        dI.up(&it, sizeof(it));
+        launch_mfma_pair_gram(nullptr, (const PairGramItem*)dI.p, 1, nwg);
+    }
     ReduceItem ri{dP.p, dO.p, 1024, npart, 0, 0}; dR.up(&ri, sizeof(ri));
     launch_reduce<float, float>(nullptr, (const ReduceItem*)dR.p, 1, 1024);
     HIPCHK(hipDeviceSynchronize());

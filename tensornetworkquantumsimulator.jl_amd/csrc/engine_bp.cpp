@@ -1,5 +1,6 @@
 // engine_bp.cpp -- BP update (abstractbeliefpropagationcache.jl:223-259): default sweep order, level schedule, message launches.
 #include "engine_internal.hpp"
+#include "launch_util.hpp"
 
 namespace tnqs {
 
@@ -689,7 +690,23 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     for (size_t q = 0; q < sh_gram.size(); ++q) if (sh_gram[q].X) { keep.push_back(sh_gram[q]); keepc.push_back(sh_chain[q]); }
                     sh_gram.swap(keep); sh_chain.swap(keepc);
                 }
-                if (!sh_gram.empty()) {
+                if (!sh_gram.empty() && mfma_use_x3()) {
+                    // the bf16 kernel in its one-message form (round 5): half-slice workgroups in groups of 16, one partial per workgroup.  These launches are what a
+                    // sweep in the reference's forest-cover order consists of (a handful of messages per dependency level)
+                    double tot = 0; for (auto& it : sh_gram) tot += (double)(it.g.n0 * it.g.n1 * it.g.n2);
+                    int spw = 16; while (spw > 1 && 2.0 * tot / spw < 1024.0) spw >>= 1;
+                    std::vector<PairGram2Item> one(sh_gram.size()); int wgs = 0;
+                    for (size_t q = 0; q < sh_gram.size(); ++q) {
+                        const PairGramItem& a = sh_gram[q]; PairGram2Item& it = one[q]; GramJob& j = jobs[sh_chain[q]];
+                        const int np = (a.g.n0 * a.g.n1 * a.g.n2 + spw - 1) / spw, nwg = 16 * ((np + 7) / 8);
+                        it.X = a.X; it.Y = a.Y; it.Mx = a.M; it.My = nullptr; it.g = a.g; it.spw = spw; it.wg_begin = wgs; wgs += nwg;
+                        j.nchunks = nwg; j.KK = 32; j.partial = dalloc(s, (size_t)j.nchunks * 1024 * esz);
+                        it.partial_y = j.partial->p; it.partial_x = nullptr;
+                    }
+                    const PairGram2Item* d = upload(s, one);
+                    ProfScope ps(s, TNQS_PROF_BP_PAIRGRAM, 2.0 * sh_gram_slices * 16384.0 * esz, 2 * 8.0 * sh_gram_slices * 16384.0 * 32);
+                    launch_x3_pair_gram1(s->stream, d, (int)one.size(), wgs);
+                } else if (!sh_gram.empty()) {
                     int spw = (int)std::max(4.0, std::min(16.0, sh_gram_slices / 2048.0)); int wgs = 0;
                     for (size_t q = 0; q < sh_gram.size(); ++q) {
                         PairGramItem& it = sh_gram[q]; GramJob& j = jobs[sh_chain[q]];

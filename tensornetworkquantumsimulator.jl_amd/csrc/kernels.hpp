@@ -400,6 +400,7 @@ void launch_mfma_apply64(hipStream_t s, const Apply64Item* d_items, int nitems, 
 struct PairGram2Item { const void* X; const void* Y; const void* Mx; const void* My; void* partial_y; void* partial_x; PairGeom g; int wg_begin; int spw; };
 void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs);
 void launch_x3_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs);      // kernels_x3.hip: the same pass on the bf16 matrix cores
+void launch_x3_pair_gram1(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs);     // kernels_x3.hip: ONE message per item (My = partial_x = null)
 int pair_gram2_group();      // workgroups of one group of 8 slice ranges: 32 (a workgroup walks one quarter of each slice)
 // last absorption + Gram on two arbitrary 32-dim legs (absorbed leg x, kept leg y), reading a (cached) pair product X and psi = Y
 void launch_mfma_pair_gram(hipStream_t s, const PairGramItem* d_items, int nitems, int total_wgs);

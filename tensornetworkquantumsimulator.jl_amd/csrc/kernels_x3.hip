@@ -46,7 +46,8 @@ __device__ __forceinline__ long long x3_slice_base(const PairGeom& g, int sl) {
 // M lives in registers as split A operands (48 registers); X, Y and C are split on the fly.  Planes in LDS with an EVEN pitch (34) so that a lane's
 // eight consecutive elements are four aligned 16-byte reads (message 0; message 1 reads the same planes transposed, 8-byte reads along the lanes).
 // ------------------------------------------------------------------------------------------------------------
-template <int MODE>
+// SINGLE: one message per item (partial_y only; My, partial_x unused) -- the eight waves take the eight companions of a phase, one each
+template <int MODE, bool SINGLE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void x3_pair_gram2_kernel(const PairGram2Item* __restrict__ items, int nitems) {
     constexpr int P = 34;                      // row pitch in complex elements
     constexpr int PS = 32 * P + 2;             // plane stride: X planes of companions 0..7, then their Y planes
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int s_begin = pw * it.spw, s_end = min(nslices, s_begin + it.spw);
     const cf* __restrict__ Xg = reinterpret_cast<const cf*>(it.X);
     const cf* __restrict__ Yg = reinterpret_cast<const cf*>(it.Y);
-    const int comp = w & 3, msg = w >> 2;
+    const int comp = SINGLE ? w : (w & 3), msg = SINGLE ? 0 : (w >> 2);
     // A operands of step 1: A[i = j' = ln][k] = M[k + 32 ln], k = 16 n + 8 h + e
     P3 Mr[2], Mi[2];
     {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int j = 0; j < 8; ++j) { px[j] = ldg4(Xg + nb + tstr * j); py[j] = ldg4(Yg + nb + tstr * j); }
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < (SINGLE ? 1 : 2); ++t) {
             const v2f* PX = L + (comp + 4 * t) * PS; const v2f* PY = PX + 8 * PS;
             // ---- step 1: C[j'][kept] = sum_k M[k][j'] X[k][kept] -------------------------------------------------------------------------
             v16f Cr, Ci;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int j = 6; j < 8; ++j) { px[j] = ldg4(Xg + nb + tstr * j); py[j] = ldg4(Yg + nb + tstr * j); }
             }
-            if (t == 0) read8(L + (comp + 4) * PS, 8 * h, 8 * h + 4, ar, ai);            // first operands of the second companion
+            if (t == 0 && !SINGLE) read8(L + (comp + 4) * PS, 8 * h, 8 * h + 4, ar, ai);            // first operands of the second companion
             TNQS_PIN();
             {
                 float cr[8], ci[8];
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         lds_barrier();
     }
     };
-    if (msg == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+    if (SINGLE || msg == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
     // one partial per workgroup and message: the four waves of a message are summed through the (now free) planes
     cf* __restrict__ p1 = reinterpret_cast<cf*>(it.partial_y) + (size_t)lw * 1024;
     cf* __restrict__ p2 = reinterpret_cast<cf*>(it.partial_x) + (size_t)lw * 1024;
@@ -210,6 +211,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         R[w * (32 * 33) + ln * 33 + i] = v;                     // element (i, j = ln)
     }
     lds_barrier();
+    if (SINGLE) {
+        for (int e = tid; e < 1024; e += 512) {
+            const int i = e & 31, j = e >> 5;
+            float sr = 0.f, si = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) { const v2f v = R[ww * (32 * 33) + j * 33 + i]; sr += v[0]; si += v[1]; }
+            cf o; o.re = sr; o.im = si; stgc(p1 + e, o);
+        }
+        return;
+    }
     for (int e = tid; e < 2048; e += 512) {
         const int mm = e >> 10, ee = e & 1023, i = ee & 31, j = ee >> 5;
         float sr = 0.f, si = 0.f;
@@ -220,6 +231,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 #undef TNQS_PIN
 int x3_pair_gram2_group() { return 16; }
+// one message per item (the entries of a level that have no partner message: PairGram2Item with My = partial_x = null)
+void launch_x3_pair_gram1(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs) {
+    if (total_wgs <= 0) return;
+    const size_t lds = (size_t)16 * (32 * 34 + 2) * 2 * sizeof(float);
+    set_max_dynamic_lds((const void*)x3_pair_gram2_kernel<0, true>, lds);
+    hipLaunchKernelGGL((x3_pair_gram2_kernel<0, true>), dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
+    TNQS_CHECK_LAUNCH();
+}
 void launch_x3_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
     const size_t lds = (size_t)16 * (32 * 34 + 2) * 2 * sizeof(float);
