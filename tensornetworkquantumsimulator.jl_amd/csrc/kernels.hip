@@ -293,6 +293,15 @@ __global__ __launch_bounds__(1024) void msg_finalize_kernel(const MsgFinalItem* 
         // time instead of one -- a message with thousands of partials took a millisecond here
         T pr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int c = 0;
+        // (32 loads in flight, added in the same order as the groups of eight below: a level of the forest-cover order has a few messages of a few hundred
+        //  partials each -- many short workgroups per site -- and their 32 dependent rounds of eight loads were 25 us of a 60 us level)
+        for (; c + 32 <= it.nchunks; c += 32) {
+            cx<T> v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = p[(size_t)(c + u) * n2 + e];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) { pr[u & 7] += v[u].re; pi[u & 7] += v[u].im; }
+        }
         for (; c + 8 <= it.nchunks; c += 8) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) { cx<T> v = p[(size_t)(c + u) * n2 + e]; pr[u] += v.re; pi[u] += v.im; }
