@@ -9,4 +9,4 @@ python $R/profiles/timeline.py $(ls $O/hh/*/*kernel_trace.csv | head -1) 4 > $O/
 NREP=2 rocprofv3 --kernel-trace --output-format csv -d $O/c1 -- python $R/profiles/shape_bench.py c1 > $O/c1.log 2>&1
 python $R/profiles/timeline.py $(ls $O/c1/*/*kernel_trace.csv | head -1) 4 > $O/c1_timeline.txt
 rm -rf $O/l7 $O/hh $O/c1
-tail -3 $O/*.log
+tail -n 3 $O/hh.log
