@@ -1,17 +1,14 @@
-O=gpurun_out/r5at; mkdir -p $O
-bash profiles/collect.sh r5 > $O/collect.log 2>&1; tail -2 $O/collect.log
-bash profiles/collect_mfma.sh r5 > $O/collect_mfma.log 2>&1; head -4 $O/collect_mfma.log
-bash profiles/collect_stalls.sh r5 > $O/collect_stalls.log 2>&1; tail -3 $O/collect_stalls.log
-python bench.py --steps 20 --warmup 3 > $O/bench_c2.json 2>> $O/err.txt
+O=gpurun_out/r5mix; mkdir -p $O
+TNQS_X3_MIX=1 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "double_pair or bf16x3 or pair_gram" 2>&1 | tail -8 > $O/kernels.log
+for m in 0 1; do
+  TNQS_X3_MIX=$m python profiles/plane_bench.py 100 5 > $O/plane_$m.txt 2>&1
+  TNQS_X3_MIX=$m python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ab > $O/b_$m.json 2>> $O/err.txt
+done
+TNQS_X3_MIX=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ab > $O/b_1b.json 2>> $O/err.txt
+TNQS_X3_MIX=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ab > $O/b_0b.json 2>> $O/err.txt
+cat $O/kernels.log; tail -n 4 $O/plane_0.txt $O/plane_1.txt
 python - <<PY
 import json
-d=json.load(open("$O/bench_c2.json")); print("c2", d["ms_per_step"], d["value"], d["roofline"]["frac"], d["roofline"]["traffic"], d["roofline"]["mfma_busy"], d["roofline"]["from_profile"], d.get("ab_f32_matrix_instructions"))
-PY
-for m in heavyhex c1 chi64 cubic16; do NREP=5 python profiles/shape_bench.py $m > $O/shape_$m.json 2>> $O/err.txt; done
-python bench.py --L 7 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_L7.json 2>> $O/err.txt
-python - <<PY
-import json
-for m in ("heavyhex","c1","chi64","cubic16"):
-    d=json.load(open("$O/shape_%s.json"%m)); print(m, d["ms_per_layer"])
-d=json.load(open("$O/bench_L7.json")); print("L7", d["ms_per_step"])
+for f in ("b_0","b_1","b_0b","b_1b"):
+    d=json.load(open("$O/%s.json"%f)); print(f, d["ms_per_step"], d["phases"]["bp_ms_per_step"], d["phases"]["gate_ms_per_step"], d["kernel_classes"].get("pair_gram"))
 PY
