@@ -1,13 +1,10 @@
-O=gpurun_out/r5av; mkdir -p $O
-python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "fiber_gemm" --tb=short 2>&1 | tail -4
-python -m pytest tests/test_gpu_fullsize.py -q -m gpu -k "chi64 or c5" --tb=short 2>&1 | tail -3
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c2.json 2>> $O/err.txt
-NREP=5 python profiles/shape_bench.py chi64 > $O/shape_chi64.json 2>> $O/err.txt
-NREP=5 TNQS_NO_BF16X3=1 python profiles/shape_bench.py chi64 > $O/shape_chi64_f32.json 2>> $O/err.txt
+O=gpurun_out/r5cyc2; mkdir -p $O
+python -m pytest tests/test_gpu_parity.py -q -m gpu -k "periodic_lattices" 2>&1 | tail -15 > $O/parity.log
+python -m pytest tests/test_gpu_sharded.py tests/test_gpu_toggles.py -q -m gpu -x 2>&1 | tail -8 > $O/sh.log
+python bench.py --config c4 --L 5 --steps 2 --warmup 1 --no-cpu-baseline --no-ab > $O/c4_L5.json 2>> $O/err.txt
+cat $O/parity.log $O/sh.log
 python - <<PY
 import json
-d=json.load(open("$O/bench_c2.json")); print("c2", d["ms_per_step"], {k:v["ms"] for k,v in d["kernel_classes"].items() if k.startswith("gate")})
-for f in ("shape_chi64","shape_chi64_f32"):
-    d=json.load(open("$O/%s.json"%f)); print(f, d["ms_per_layer"], {k:(v["ms"],v.get("tflops")) for k,v in d["classes"].items() if not k.startswith("phase")})
+for f in ("c4_L5",):
+    d=json.load(open("$O/%s.json"%f)); print(f, d["ms_per_step"], d["phases"]["bp_ms_per_step"], d["phases"]["gate_ms_per_step"], {k:(round(v["ms"]/d["steps"],1),v["launches"]) for k,v in d["kernel_classes"].items() if k.startswith("bp_")}, d["config"]["bp_partial_products"], d["config"]["memory"])
 PY
-tail -3 $O/err.txt

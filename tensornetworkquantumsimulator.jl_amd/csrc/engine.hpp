@@ -65,6 +65,7 @@ struct Graph {
     bool is_tree = false;
     std::vector<int> ecolor; int ncolors = 0;     // deterministic greedy proper edge colouring
     mutable std::vector<int> default_seq;         // default BP sweep order (engine.cpp default_sequence), built on first use
+    mutable std::vector<int> default_set_starts;  // positions of default_seq where a set that may close cycles begins (empty: linear forests): a set's levels follow the previous set's
     mutable std::shared_ptr<const void> default_plan;   // its level schedule (engine.cpp BPPlan), built on first use
     mutable std::shared_ptr<const void> forest_plan;    // level schedule of the forest-cover order (n_sequence = -1), built on first use
     int edge(int u, int v) const;                 // -1 if absent

@@ -100,19 +100,67 @@ static std::vector<int> forest_cover_sequence(const Graph& g) {
     }
     return seq;
 }
-static std::vector<int> default_sequence(const Graph& g) {
-    if (g.is_tree) {
-        std::vector<int> seq = tree_sequence(g);
-        if ((int)seq.size() != 2 * g.ne) throw Err(TNQS_ERR_HIP, "internal: tree sequence does not cover every message");
-        return seq;
+// dependency level of every position of a sequence: one more than the highest level among the EARLIER positions whose message enters the source
+// (a later position is read in its old value); a level's messages are independent of each other
+// `starts` (optional, ascending positions): the levels of the positions from a start on lie above everything before it (later is always allowed: which
+// value a message reads is decided by the positions, not by the levels) -- a site then never meets messages of two sets in one level
+static std::vector<int> sequence_levels(const Graph& g, const std::vector<int>& seq, const std::vector<int>& pos_of, const std::vector<int>* starts = nullptr) {
+    std::vector<int> level(seq.size(), 0);
+    int floor_lv = 0, top = -1; size_t ks = 0;
+    for (size_t t = 0; t < seq.size(); ++t) {
+        if (starts) while (ks < starts->size() && (*starts)[ks] == (int)t) { floor_lv = top + 1; ++ks; }
+        int de = seq[t]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
+        int lv = 0;
+        for (size_t j = 0; j < g.nbr[src].size(); ++j) {
+            int k = g.nbr[src][j]; if (k == dst) continue;
+            int pp = pos_of[g.dedge(k, src)];
+            if (pp >= 0 && pp < (int)t) lv = std::max(lv, level[pp] + 1);
+        }
+        lv = std::max(lv, floor_lv);
+        level[t] = lv; top = std::max(top, lv);
     }
-    std::vector<int> forest(g.ne, -1);
-    int nf = 0;
-    // 1. unions of two colour classes that contain no cycle are linear forests (straight lines on lattices): pair the colours up
+    return level;
+}
+// The messages of edge sets of maximum degree 2 (`part[e]` = set of edge e), set after set.  Along a path v0..vk the hops v_i -> v_{i+1} are listed
+// last hop first and the hops v_{i+1} -> v_i first hop first: every message is computed from the OLD values of its own set, the whole path is one
+// level and an inner site sends both its messages in it.  Round a cycle v0..v_{n-1} the same holds for all hops but the two that leave v0, which
+// come last (one of the messages a cycle carries must see a new value in any sequential order): v1..v_{n-1} send both their messages in one level,
+// v0 both of its own in the next -- n two-message passes per cycle, where a path plus its closing edge in another forest takes n + 2 passes.
+static std::vector<int> path_cycle_sequence(const Graph& g, const std::vector<int>& part, int np, std::vector<int>& starts) {
+    std::vector<int> seq; starts.clear();
+    for (int f = 0; f < np; ++f) {
+        starts.push_back((int)seq.size());
+        std::vector<std::vector<int>> adj(g.nv);
+        for (int e = 0; e < g.ne; ++e) if (part[e] == f) { adj[g.esrc[e]].push_back(g.edst[e]); adj[g.edst[e]].push_back(g.esrc[e]); }
+        std::vector<char> seen(g.nv, 0);
+        for (int v = 0; v < g.nv; ++v) {
+            if (adj[v].size() != 1 || seen[v]) continue;                   // start at a path end
+            std::vector<int> path{v}; seen[v] = 1; int prev = -1, cur = v;
+            for (;;) { int nxt = -1; for (int w : adj[cur]) if (w != prev) nxt = w; if (nxt < 0) break; prev = cur; cur = nxt; path.push_back(cur); seen[cur] = 1; }
+            const int k = (int)path.size() - 1;
+            for (int i = k - 1; i >= 0; --i) seq.push_back(g.dedge(path[i], path[i + 1]));
+            for (int i = 0; i < k; ++i) seq.push_back(g.dedge(path[i + 1], path[i]));
+        }
+        for (int v = 0; v < g.nv; ++v) {
+            if (adj[v].size() != 2 || seen[v]) continue;                   // what is left has no end: cycles
+            std::vector<int> cyc{v}; seen[v] = 1; int prev = -1, cur = v;
+            for (;;) { int nxt = (adj[cur][0] != prev) ? adj[cur][0] : adj[cur][1]; if (nxt == v) break; prev = cur; cur = nxt; cyc.push_back(cur); seen[cur] = 1; }
+            const int n = (int)cyc.size();
+            for (int i = n - 1; i >= 1; --i) seq.push_back(g.dedge(cyc[i], cyc[(i + 1) % n]));
+            for (int i = 0; i + 1 < n; ++i) seq.push_back(g.dedge(cyc[i + 1], cyc[i]));
+            seq.push_back(g.dedge(cyc[0], cyc[1])); seq.push_back(g.dedge(cyc[0], cyc[n - 1]));
+        }
+    }
+    return seq;
+}
+// edge sets of maximum degree 2; with_cycles = false: linear forests (no cycle closes inside a set)
+static void degree2_sets(const Graph& g, bool with_cycles, std::vector<int>& part, int& np) {
+    part.assign(g.ne, -1); np = 0;
+    // 1. unions of two colour classes (straight lines on lattices): pair the colours up; a union is a set of paths and even cycles
     std::vector<std::vector<char>> ok(g.ncolors, std::vector<char>(g.ncolors, 0));
     for (int a = 0; a < g.ncolors; ++a) for (int b = a + 1; b < g.ncolors; ++b) {
-        DSU d(g.nv); bool acyclic = true;
-        for (int e = 0; e < g.ne && acyclic; ++e) if (g.ecolor[e] == a || g.ecolor[e] == b) acyclic = d.join(g.esrc[e], g.edst[e]);
+        bool acyclic = true;
+        if (!with_cycles) { DSU d(g.nv); for (int e = 0; e < g.ne && acyclic; ++e) if (g.ecolor[e] == a || g.ecolor[e] == b) acyclic = d.join(g.esrc[e], g.edst[e]); }
         ok[a][b] = ok[b][a] = acyclic ? 1 : 0;
     }
     std::vector<int> mate(g.ncolors, -1), best;
@@ -124,47 +172,61 @@ static std::vector<int> default_sequence(const Graph& g) {
         for (int b = c + 1; b < g.ncolors; ++b) if (mate[b] < 0 && ok[c][b]) { mate[c] = b; mate[b] = c; rec(c + 1, pairs + 1); mate[c] = mate[b] = -1; }
     };
     if (g.ncolors <= 10) rec(0, 0);
-    // 2. greedy linear forests: an edge joins the first forest where both ends still have degree < 2 and no cycle closes
-    std::vector<int> gforest(g.ne, -1); int gnf = 0;
+    // 2. greedy: an edge joins the first set where both ends still have degree < 2 (and, for forests, no cycle closes)
+    std::vector<int> gpart(g.ne, -1); int gnp = 0;
     {
         std::vector<std::vector<int>> deg; std::vector<DSU> comp;
         for (int e = 0; e < g.ne; ++e) {
             int a = g.esrc[e], b = g.edst[e], f = 0;
             for (;; ++f) {
-                if (f == gnf) { deg.emplace_back(g.nv, 0); comp.emplace_back(g.nv); ++gnf; }
-                if (deg[f][a] < 2 && deg[f][b] < 2 && comp[f].f(a) != comp[f].f(b)) break;
+                if (f == gnp) { deg.emplace_back(g.nv, 0); comp.emplace_back(g.nv); ++gnp; }
+                if (deg[f][a] < 2 && deg[f][b] < 2 && (with_cycles || comp[f].f(a) != comp[f].f(b))) break;
             }
-            comp[f].join(a, b); ++deg[f][a]; ++deg[f][b]; gforest[e] = f;
+            comp[f].join(a, b); ++deg[f][a]; ++deg[f][b]; gpart[e] = f;
         }
     }
-    // the decomposition with fewer forests (= fewer levels per sweep) wins; ties go to the colour pairs (straight lines on lattices)
-    if (best_pairs > 0 && g.ncolors - best_pairs <= gnf) {
+    // the decomposition with fewer sets wins; ties go to the colour pairs
+    if (best_pairs > 0 && g.ncolors - best_pairs <= gnp) {
         std::vector<int> fof(g.ncolors, -1);
-        for (int c = 0; c < g.ncolors; ++c) if (fof[c] < 0) { fof[c] = nf; if (best[c] != c && best[c] >= 0) fof[best[c]] = nf; ++nf; }
-        for (int e = 0; e < g.ne; ++e) forest[e] = fof[g.ecolor[e]];
-    } else { forest = gforest; nf = gnf; }
-    std::vector<int> seq;
-    for (int f = 0; f < nf; ++f) {
-        std::vector<std::vector<int>> adj(g.nv);
-        for (int e = 0; e < g.ne; ++e) if (forest[e] == f) { adj[g.esrc[e]].push_back(g.edst[e]); adj[g.edst[e]].push_back(g.esrc[e]); }
-        std::vector<char> seen(g.nv, 0);
-        for (int v = 0; v < g.nv; ++v) {
-            if (adj[v].size() != 1 || seen[v]) continue;                   // start at a path end
-            std::vector<int> path{v}; seen[v] = 1; int prev = -1, cur = v;
-            for (;;) { int nxt = -1; for (int w : adj[cur]) if (w != prev) nxt = w; if (nxt < 0) break; prev = cur; cur = nxt; path.push_back(cur); seen[cur] = 1; }
-            const int k = (int)path.size() - 1;
-            for (int i = k - 1; i >= 0; --i) seq.push_back(g.dedge(path[i], path[i + 1]));
-            for (int i = 0; i < k; ++i) seq.push_back(g.dedge(path[i + 1], path[i]));
-        }
+        for (int c = 0; c < g.ncolors; ++c) if (fof[c] < 0) { fof[c] = np; if (best[c] != c && best[c] >= 0) fof[best[c]] = np; ++np; }
+        for (int e = 0; e < g.ne; ++e) part[e] = fof[g.ecolor[e]];
+    } else { part = gpart; np = gnp; }
+}
+static std::vector<int> default_sequence(const Graph& g, std::vector<int>& set_starts) {
+    set_starts.clear();
+    if (g.is_tree) {
+        std::vector<int> seq = tree_sequence(g);
+        if ((int)seq.size() != 2 * g.ne) throw Err(TNQS_ERR_HIP, "internal: tree sequence does not cover every message");
+        return seq;
     }
-    if ((int)seq.size() != 2 * g.ne) throw Err(TNQS_ERR_HIP, "internal: default sequence does not cover every message");
-    return seq;
+    // linear forests (a forest is one level), or -- where it saves at least a twentieth of the (site, level) passes over the site tensors, i.e. on periodic
+    // lattices -- sets that may close cycles (two levels per set, see path_cycle_sequence).  A pass is what a sweep costs on big tensors; the levels are
+    // what it costs on small ones, and there the forests have fewer
+    std::vector<int> best_seq; long best_passes = -1;
+    static const int nvariants = envflag("TNQS_NO_CYCLE_SETS") ? 1 : 2;
+    for (int with_cycles = 0; with_cycles < nvariants; ++with_cycles) {
+        std::vector<int> part; int np = 0;
+        degree2_sets(g, with_cycles != 0, part, np);
+        std::vector<int> starts;
+        std::vector<int> seq = path_cycle_sequence(g, part, np, starts);
+        if ((int)seq.size() != 2 * g.ne) throw Err(TNQS_ERR_HIP, "internal: default sequence does not cover every message");
+        std::vector<int> pos_of(2 * (size_t)g.ne, -1);
+        for (size_t t = 0; t < seq.size(); ++t) pos_of[seq[t]] = (int)t;
+        if (!with_cycles) starts.clear();                                 // forests: plain dependency levels, as ever
+        const std::vector<int> level = sequence_levels(g, seq, pos_of, starts.empty() ? nullptr : &starts);
+        std::vector<std::pair<int, int>> sl;
+        for (size_t t = 0; t < seq.size(); ++t) { int de = seq[t]; int e = de / 2; sl.push_back({(de & 1) ? g.edst[e] : g.esrc[e], level[t]}); }
+        std::sort(sl.begin(), sl.end()); sl.erase(std::unique(sl.begin(), sl.end()), sl.end());
+        const long passes = (long)sl.size();
+        if (best_passes < 0 || passes * 20 <= best_passes * 19) { best_seq = std::move(seq); best_passes = passes; set_starts = starts; }
+    }
+    return best_seq;
 }
 
 // the default order as (src, dst) vertex pairs, for tests that replay it on the oracle (include/tnqs_debug.h)
 void dbg_default_sequence(const State* s, std::vector<int>& src, std::vector<int>& dst) {
     const Graph& g = *s->g;
-    if (g.default_seq.empty() && g.ne > 0) g.default_seq = default_sequence(g);
+    if (g.default_seq.empty() && g.ne > 0) g.default_seq = default_sequence(g, g.default_set_starts);
     for (int de : g.default_seq) { const int e = de / 2; src.push_back((de & 1) ? g.edst[e] : g.esrc[e]); dst.push_back((de & 1) ? g.esrc[e] : g.edst[e]); }
 }
 
@@ -178,21 +240,13 @@ static BPPlan make_plan(const State* s, const tnqs_bp_opts* o) {
             p.seq.push_back(de);
         }
     } else if (o && o->n_sequence < 0) p.seq = forest_cover_sequence(g);      // the reference's own default order
-    else { if (g.default_seq.empty() && g.ne > 0) g.default_seq = default_sequence(g); p.seq = g.default_seq; }
+    else { if (g.default_seq.empty() && g.ne > 0) g.default_seq = default_sequence(g, g.default_set_starts); p.seq = g.default_seq; }
     p.pos_of.assign(2 * (size_t)g.ne, -1);
     for (size_t t = 0; t < p.seq.size(); ++t) { if (p.pos_of[p.seq[t]] >= 0) p.in_place = true; p.pos_of[p.seq[t]] = (int)t; }
     if (p.in_place) { for (size_t t = 0; t < p.seq.size(); ++t) { p.levels.push_back({(int)t}); p.level_of.push_back((int)t); } return p; }
-    std::vector<int> level(p.seq.size(), 0); int nlev = 0;
-    for (size_t t = 0; t < p.seq.size(); ++t) {
-        int de = p.seq[t]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
-        int lv = 0;
-        for (size_t j = 0; j < g.nbr[src].size(); ++j) {
-            int k = g.nbr[src][j]; if (k == dst) continue;
-            int din = g.dedge(k, src); int pp = p.pos_of[din];
-            if (pp >= 0 && pp < (int)t) lv = std::max(lv, level[pp] + 1);
-        }
-        level[t] = lv; nlev = std::max(nlev, lv + 1);
-    }
+    const bool is_default = !(o && o->n_sequence != 0);
+    std::vector<int> level = sequence_levels(g, p.seq, p.pos_of, is_default && !g.default_set_starts.empty() ? &g.default_set_starts : nullptr); int nlev = 0;
+    for (int lv : level) nlev = std::max(nlev, lv + 1);
     p.levels.resize(nlev);
     for (size_t t = 0; t < p.seq.size(); ++t) p.levels[level[t]].push_back((int)t);
     // the messages of a level are independent of each other: list them by source vertex, so that a workspace-bounded sub-batch (bp_update_t)
@@ -224,10 +278,15 @@ struct SharedT { Buf site, ma, mb, T; int la = -1, lb = -1; };
 // reusable ones and the leg whose message changes next is left for the Gram pass.  Validity is by buffer identity, never assumed: the
 // entries hold references, so an address cannot be recycled while an entry names it.  3 x 3 x 3 periodic cubic lattice, chi = 16: 5
 // two-leg passes per site and sweep instead of 6.8.
-struct ProdEntry { Buf site; std::vector<std::pair<int, Buf>> legs; Buf prod; unsigned long long stamp = 0; };
+struct ProdEntry { Buf site; std::vector<std::pair<int, Buf>> legs; Buf prod; long long next_use = 0; };
+// Which entries stay is decided by the level schedule, which is known in advance (round 5; least-recently-used before): `next_use` = the level, counted
+// through the sweeps, at which the site next sends a message that can continue from the entry while every message it was built from is still current
+// (bp_update_t: next_use_of).  A product without such a level is not stored at all, an entry that has served its last use is dropped when it is found,
+// and what has to go -- more than `per_site` entries of a site, more bytes than `cap` -- is the entry whose next use is farthest away.
 struct ProdCache {
-    std::unordered_map<int, std::vector<ProdEntry>> by_site; unsigned long long clock = 0; int per_site = 3; size_t bytes = 0, cap = bp_cache_budget();
+    std::unordered_map<int, std::vector<ProdEntry>> by_site; int per_site = 3; size_t bytes = 0, cap = bp_cache_budget();
     int n_hits = 0, n_evicted = 0;          // diagnostics (tnqs_apply_stats): lookups that found a product; entries dropped by the per-site or the byte bound
+    std::function<long long(int, const std::vector<std::pair<int, Buf>>&)> next_use_of;       // -1: never
     // the largest entry of site v whose legs all occur in `want` with the same buffer; returns false when there is none
     bool find(int v, const Buf& site, const std::vector<std::pair<int, Buf>>& want, ProdEntry& out) {
         auto it = by_site.find(v); if (it == by_site.end()) return false;
@@ -239,25 +298,35 @@ struct ProdCache {
             if (sub) best = &e;
         }
         if (!best) return false;
-        best->stamp = ++clock; out = *best; ++n_hits; return true;
+        out = *best; ++n_hits;
+        const long long nu = next_use_of ? next_use_of(v, best->legs) : 0;
+        if (nu < 0) { bytes -= best->prod->bytes; it->second.erase(it->second.begin() + (best - it->second.data())); }      // its last use: the caller holds the buffer
+        else best->next_use = nu;
+        return true;
     }
     void put(int v, const Buf& site, std::vector<std::pair<int, Buf>> legs, const Buf& prod) {
         if (legs.size() < 2 || !prod) return;
         std::sort(legs.begin(), legs.end(), [](const std::pair<int, Buf>& a, const std::pair<int, Buf>& b) { return a.first < b.first; });
+        const long long nu = next_use_of ? next_use_of(v, legs) : 0;
+        if (nu < 0) return;
         auto& vec = by_site[v];
-        for (auto& e : vec) if (e.site == site && e.legs == legs) { bytes += prod->bytes; bytes -= e.prod->bytes; e.prod = prod; e.stamp = ++clock; return; }
-        if ((int)vec.size() >= per_site) { size_t lru = 0; for (size_t i = 1; i < vec.size(); ++i) if (vec[i].stamp < vec[lru].stamp) lru = i; bytes -= vec[lru].prod->bytes; vec.erase(vec.begin() + lru); ++n_evicted; }
-        ProdEntry e; e.site = site; e.legs = std::move(legs); e.prod = prod; e.stamp = ++clock; bytes += prod->bytes; vec.push_back(std::move(e));
-        if (bytes > cap) {                         // over the byte bound: the least recently used entries of all sites go, in ONE pass -- down to 7/8 of the
-            // bound, so that a long level under memory pressure does not rescan every entry for every product it stores (round-3 advisor finding)
-            std::vector<std::pair<unsigned long long, int>> order;          // (stamp, site)
-            for (auto& kv : by_site) for (auto& en : kv.second) order.push_back({en.stamp, kv.first});
-            std::sort(order.begin(), order.end());
+        for (auto& e : vec) if (e.site == site && e.legs == legs) { bytes += prod->bytes; bytes -= e.prod->bytes; e.prod = prod; e.next_use = nu; return; }
+        if ((int)vec.size() >= per_site) {
+            size_t far = 0; for (size_t i = 1; i < vec.size(); ++i) if (vec[i].next_use > vec[far].next_use) far = i;
+            if (vec[far].next_use <= nu) return;                                       // everything kept is needed sooner than the new product
+            bytes -= vec[far].prod->bytes; vec.erase(vec.begin() + (std::ptrdiff_t)far); ++n_evicted;
+        }
+        ProdEntry e; e.site = site; e.legs = std::move(legs); e.prod = prod; e.next_use = nu; bytes += prod->bytes; vec.push_back(std::move(e));
+        if (bytes > cap) {                         // over the byte bound: the entries needed last go, in ONE pass -- down to 7/8 of the bound, so that a long
+            // level under memory pressure does not rescan every entry for every product it stores (round-3 advisor finding)
+            std::vector<std::pair<long long, int>> order;          // (next use, site)
+            for (auto& kv : by_site) for (auto& en : kv.second) order.push_back({en.next_use, kv.first});
+            std::sort(order.begin(), order.end(), [](const std::pair<long long, int>& a, const std::pair<long long, int>& b) { return a.first > b.first; });
             const size_t target = cap - cap / 8;
             for (auto& o : order) {
                 if (bytes <= target) break;
                 auto& vv = by_site[o.second];
-                for (size_t i = 0; i < vv.size(); ++i) if (vv[i].stamp == o.first) { bytes -= vv[i].prod->bytes; vv.erase(vv.begin() + (std::ptrdiff_t)i); ++n_evicted; break; }
+                for (size_t i = 0; i < vv.size(); ++i) if (vv[i].next_use == o.first) { bytes -= vv[i].prod->bytes; vv.erase(vv.begin() + (std::ptrdiff_t)i); ++n_evicted; break; }
             }
         }
     }
@@ -343,6 +412,33 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
         return Lj > Lc ? Lj - Lc : (Lj < Lc ? nlev - Lc + Lj : 0);
     };
     typedef std::vector<std::pair<int, Buf>> LegBufs;
+    // the level (counted through the sweeps of this call) at which site v next sends a message that can continue from a product over `legs`: a message through
+    // a leg outside `legs`, in a level where v sends nothing through a leg of `legs`, no later than the first level that recomputes a message entering through
+    // `legs` (a message recomputed in the very level of the use is still read in its old value there).  -1: no such level
+    int cur_level = 0, cur_iter = 1;
+    std::vector<std::vector<int>> out_level(g.nv), in_level(g.nv);           // per site and leg: level of the outgoing / incoming message (-1: not in the sequence)
+    for (int v = 0; v < g.nv; ++v) for (size_t j = 0; j < g.nbr[v].size(); ++j) {
+        const int po = plan.pos_of[g.dedge(v, g.nbr[v][j])], pi = plan.pos_of[g.dedge(g.nbr[v][j], v)];
+        out_level[v].push_back(po >= 0 ? plan.level_of[po] : -1); in_level[v].push_back(pi >= 0 ? plan.level_of[pi] : -1);
+    }
+    pcache.next_use_of = [&](int v, const LegBufs& legs) -> long long {
+        if (plan.in_place) return 0;
+        const int Lc = cur_level, z = (int)g.nbr[v].size();
+        auto has = [&](int j) { for (auto& lm : legs) if (lm.first == j) return true; return false; };
+        int life = INT_MAX;
+        for (auto& lm : legs) { const int L = in_level[v][lm.first]; if (L < 0) continue; life = std::min(life, L > Lc ? L - Lc : (L < Lc ? nlev - Lc + L : 0)); }
+        int best = INT_MAX;
+        for (int j = 0; j < z; ++j) {
+            const int L = out_level[v][j]; if (L < 0 || has(j)) continue;
+            const int d = L > Lc ? L - Lc : nlev - Lc + L;
+            if (d > life || d >= best) continue;
+            bool clash = false; for (int j2 = 0; j2 < z; ++j2) if (out_level[v][j2] == L && has(j2)) clash = true;
+            if (!clash) best = d;
+        }
+        if (best == INT_MAX) return -1;
+        if (Lc + best >= nlev && cur_iter >= maxiter) return -1;              // the use lies in a sweep that will not happen
+        return (long long)(cur_iter - 1) * nlev + Lc + best;
+    };
     auto by_stability = [&](LegBufs& w, int src, int t) {
         std::stable_sort(w.begin(), w.end(), [&](const std::pair<int, Buf>& a, const std::pair<int, Buf>& b) { return horizon(src, a.first, t) > horizon(src, b.first, t); });
     };
@@ -361,7 +457,9 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
     for (int iter = 1 + iters_before; iter <= maxiter; ++iter) {
         phase_scope.count += 1;
         std::vector<Buf> fresh(2 * (size_t)g.ne);
+        cur_iter = iter; cur_level = -1;
         for (auto& lev : plan.levels) {
+            ++cur_level;
             // sub-batches bounded by workspace bytes
             size_t start = 0;
             while (start < lev.size()) {

@@ -384,6 +384,45 @@ def test_bp_update_chi32_bulk_sites_matches_oracle(seq_name):
         assert abs(tn.expect(out2, ("Z", [v])) - o.expect_1site(oc2, Z, v)) < 2e-5
 
 
+def sequence_levels(g, seq):
+    """dependency levels of a sequential sweep order (a message waits for the EARLIER messages that enter its source; engine_bp.cpp sequence_levels)"""
+    pos = {m: t for t, m in enumerate(seq)}
+    level = []
+    for t, (s, d) in enumerate(seq):
+        deps = [pos[(k, s)] for k in g.neighbors(s) if k != d and (k, s) in pos and pos[(k, s)] < t]
+        level.append(1 + max((level[p] for p in deps), default=-1))
+    return level
+
+
+@pytest.mark.parametrize("lattice", ["torus4x4_chi32", "cubic3_chi4", "ring5_chi6"])
+def test_default_order_on_periodic_lattices_matches_oracle(lattice):
+    """Periodic lattices: the library's default order takes edge sets that close cycles (round a cycle every site but one sends both its
+    messages in one level, the last site both of its own in the next; engine_bp.cpp path_cycle_sequence) where that saves passes over the site
+    tensors.  It is still an ordinary sequential order: the oracle replaying it (abstractbeliefpropagationcache.jl:204-218) must reproduce the
+    trajectory sweep by sweep, on the plane route (chi = 32 torus, every site of degree 4) and on the generic one."""
+    g, chi = {"torus4x4_chi32": (tn.named_grid((4, 4), periodic=True), 32), "cubic3_chi4": (tn.named_grid((3, 3, 3), periodic=True), 4),
+              "ring5_chi6": (tn.named_grid((5,), periodic=True), 6)}[lattice]
+    psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=chi, seed=77)
+    for v in g.vertices:
+        psi.tensors[v] = (psi.tensors[v] / np.linalg.norm(psi.tensors[v])).astype(np.complex64)
+    bpc = tn.BeliefPropagationCache(psi)
+    seq = device_default_sequence(bpc)
+    assert sorted(seq) == sorted([(a, b) for (a, b) in g.edges] + [(b, a) for (a, b) in g.edges])
+    # the structure the order is chosen for: (site, level) passes -- with the sets kept apart as the engine does, a site of these lattices sends
+    # its messages two at a time: degree / 2 passes per site and sweep
+    lev = sequence_levels(g, seq)
+    passes = {(s, l) for (s, _d), l in zip(seq, lev)}
+    assert len(passes) <= g.nv() * (max(g.degree(v) for v in g.vertices) // 2), (lattice, len(passes))
+    kw = dict(maxiter=1, tolerance=None)
+    out, oc = bpc, o.BeliefPropagationCache(to_oracle_state(psi))
+    for _sweep in range(3):
+        out = tn.update(out, **kw)
+        oc = o.update(oc, **dict(kw, edge_sequence=seq))
+        compare_messages(out, oc, 5e-5)
+    for v in list(g.vertices)[:3]:
+        assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oc, Z, v)) < 2e-5
+
+
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_deferred_normalisation_is_invisible_to_callers(dtype):
     """normalize_tensors = true only records 1/||psi_v|| on the device (no scaling pass); every accessor that depends on
