@@ -56,7 +56,7 @@ typedef struct {
                            * (1e-5 f32 / c64, 1e-8 f64 / c128, none on trees), i.e. what apply_gates / truncate / normalize use when
                            * bp_update_kwargs is omitted.  A NULL opts pointer = default_bp_update_kwargs altogether */
     int normalize;        /* message_update_alg "contract" kwarg `normalize` (default true): m <- m / sum(m) */
-    int n_sequence;       /* 0: library default edge sequence (linear forests, DESIGN.md 4.3: the order the plane kernels share products on);
+    int n_sequence;       /* 0: library default edge sequence (linear forests -- on periodic lattices edge sets that close cycles --, DESIGN.md 4.3: the order the plane kernels share products on);
                            * -1: the reference's default, forest_cover_edge_sequence(graph) (beliefpropagationcache.jl:28), built by the library;
                            * > 0: the explicit sequence below */
     const int32_t* seq_src; /* explicit `edge_sequence` kwarg: directed edges, swept sequentially (Gauss-Seidel) */

@@ -1,5 +1,13 @@
-python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "fiber_gemm" --tb=short 2>&1 | tail -4
-python -m pytest tests/test_gpu_fullsize.py -q -m gpu -k "c3 or heavy" --tb=short 2>&1 | tail -2
-NREP=10 python profiles/shape_bench.py heavyhex | python -c "
-import sys, json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('heavyhex', d['ms_per_layer'], d['classes'].get('phase_bp_update'), d['classes'].get('phase_gate_batch'))"
+O=gpurun_out/r5small2; mkdir -p $O
+python -m pytest tests/test_gpu_parity.py -q -m gpu -k "small_sites_with_16 or heavy_hex or periodic_lattices or hh11 or random_graphs" 2>&1 | tail -15 > $O/parity.log
+python -m pytest tests/test_gpu_fullsize.py -q -m gpu -k "c3" 2>&1 | tail -8 > $O/full.log
+for m in 0 1; do
+  TNQS_NO_SMALL_SITE_FINALIZE=$m NREP=5 python profiles/shape_bench.py heavyhex > $O/hh_$m.json 2>> $O/err.txt
+  TNQS_NO_SMALL_SITE_FINALIZE=$m NREP=5 python profiles/shape_bench.py heavyhex > $O/hh_${m}b.json 2>> $O/err.txt
+done
+cat $O/parity.log $O/full.log
+python - <<PY
+import json
+for f in ("hh_0","hh_0b","hh_1","hh_1b"):
+    d=json.loads(open("$O/%s.json"%f).read().strip().splitlines()[-1]); print(f, d["ms_per_layer"], {k:(v["ms"],v["launches"]) for k,v in d["classes"].items() if k in ("bp_fused","jacobi","small","phase_bp_update","phase_gate_batch")})
+PY

@@ -1,10 +1,8 @@
-O=gpurun_out/r5ba; mkdir -p $O
-python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "gauge_leg" --tb=short 2>&1 | tail -3
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_toggles.py -q -m gpu -x --tb=short 2>&1 | tail -2
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c2.json 2>> $O/err.txt
-TNQS_NO_BF16X3=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c2_f32.json 2>> $O/err.txt
-python - <<PY
-import json
-for f in ("bench_c2","bench_c2_f32"):
-    d=json.load(open("$O/%s.json"%f)); print(f, d["ms_per_step"], {k:v["ms"] for k,v in d["kernel_classes"].items() if k.startswith("gate")})
-PY
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5trace2; mkdir -p $O
+NREP=2 rocprofv3 --kernel-trace --output-format csv -d $O/hh -- python $R/profiles/shape_bench.py heavyhex > $O/hh.log 2>&1
+python $R/profiles/timeline.py $(ls $O/hh/*/*kernel_trace.csv | head -1) 4 > $O/hh_timeline.txt
+TNQS_NO_SMALL_SITE_FINALIZE=1 NREP=2 rocprofv3 --kernel-trace --output-format csv -d $O/hh1 -- python $R/profiles/shape_bench.py heavyhex > $O/hh1.log 2>&1
+python $R/profiles/timeline.py $(ls $O/hh1/*/*kernel_trace.csv | head -1) 4 > $O/hh1_timeline.txt
+rm -rf $O/hh $O/hh1
+tail -n 2 $O/hh.log

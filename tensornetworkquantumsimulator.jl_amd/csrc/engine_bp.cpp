@@ -31,6 +31,7 @@ struct BPPlan {
 // u -> w depends on the message entering u through its other path edge, which therefore must come LATER in the sequence).  Level
 // scheduling then puts a whole forest into one level: 2 levels per sweep on a square lattice (rows, columns), and both outgoing
 // messages of a site inside a forest share one pair product.  It is an ordinary sequential Gauss-Seidel order.
+// On periodic lattices the paths close: there the edge sets may contain cycles (path_cycle_sequence, default_sequence below) -- still a sequential order.
 struct DSU { std::vector<int> p; explicit DSU(int n) : p(n) { std::iota(p.begin(), p.end(), 0); } int f(int x) { while (p[x] != x) x = p[x] = p[p[x]]; return x; }
              bool join(int a, int b) { a = f(a); b = f(b); if (a == b) return false; p[a] = b; return true; } };
 // Forests: the reference's own default order (NamedGraphs forest_cover_edge_sequence: per component, post-order DFS edges towards the
@@ -495,6 +496,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 // Gauss-Seidel rule may give two messages of a site different versions of an incoming message), never assumed.
                 struct Prefix { Buf site; std::vector<std::pair<int, const void*>> legs; Buf prod; };
                 std::unordered_map<int, Prefix> prefix;
+                std::vector<Buf> hits_alive;          // remembered products this sub-batch continues from: the cache may drop its entry (last use, or the byte bound) before the launches
                 auto select_in = [&](int src, int j, int t) -> const Buf& {
                     int din = g.dedge(g.nbr[src][j], src); int pp = plan.pos_of[din];
                     return (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
@@ -526,7 +528,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                             by_stability(want, src, t); cp.ordered = true;
                             ProdEntry hit;
                             if (pcache.find(src, s->site[src], want, hit)) {
-                                base = hit.legs; cp.src = hit.prod->p; pf.prod = hit.prod;      // (pf.prod: the product itself when nothing is left to absorb)
+                                base = hit.legs; cp.src = hit.prod->p; pf.prod = hit.prod; hits_alive.push_back(hit.prod);      // (pf.prod: the product itself when nothing is left to absorb)
                                 LegBufs rest; for (auto& w : want) { bool in = false; for (auto& b : base) in = in || b.first == w.first; if (!in) rest.push_back(w); }
                                 want.swap(rest);
                             }
@@ -561,6 +563,9 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                             const Buf& mb = (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
                             if (mb) si.M[j] = mb->p;                 // unset message = identity: nothing to absorb
                         }
+                        static const bool small_mfma_on = !envflag("TNQS_NO_SMALL_SITE_MFMA");
+                        si.mfma = small_mfma_on && (c.sd.n % 256) == 0;
+                        for (int j = 0; j < c.sd.z; ++j) if (c.sd.chi[j] != 16) si.mfma = 0;
                         small_items.push_back(si); small_chain.push_back((int)chains.size()); small_max = std::max(small_max, (int)c.sd.n);
                         is_shared_chain.push_back((int)chains.size());
                         chains.push_back(std::move(c)); tpos.push_back(t); fmsg.push_back(nullptr);
@@ -631,7 +636,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                         by_stability(want, src, t); c.ordered = true;
                         ProdEntry hit;
                         if (pcache.find(src, s->site[src], want, hit)) {
-                            base = hit.legs; c.y = c.src; c.src = hit.prod->p;
+                            base = hit.legs; c.y = c.src; c.src = hit.prod->p; hits_alive.push_back(hit.prod);
                             LegBufs rest; for (auto& w : want) { bool in = false; for (auto& b : base) in = in || b.first == w.first; if (!in) rest.push_back(w); }
                             want.swap(rest);
                         }
@@ -735,6 +740,24 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                         j.nchunks = 1; j.KK = co; j.partial = sub_buffer(slab, off, (size_t)co * co * esz); off += round256((size_t)co * co * esz);
                         small_items[q].out = j.partial->p;
                     }
+                    // matrix-core form on an unsharded handle: the kernel holds the whole message and finishes it (normalisation, message_diff) -- one launch less on
+                    // the critical path of the level
+                    static const bool small_fuse_on = !envflag("TNQS_NO_SMALL_SITE_FINALIZE");
+                    if (small_fuse_on && s->nranks <= 1 && !plan.in_place) {
+                        size_t nb_bytes = 0;
+                        for (size_t q = 0; q < small_items.size(); ++q) if (small_items[q].mfma) nb_bytes += round256((size_t)256 * esz);
+                        if (nb_bytes) {
+                            Buf nslab = dalloc(s, nb_bytes); size_t noff = 0;
+                            for (size_t q = 0; q < small_items.size(); ++q) {
+                                SmallMsgItem& si = small_items[q]; if (!si.mfma) continue;
+                                GramJob& j = jobs[small_chain[q]];
+                                const int t = tpos[small_chain[q]]; const int de = plan.seq[t];
+                                j.final_msg = sub_buffer(nslab, noff, (size_t)256 * esz); noff += round256((size_t)256 * esz);
+                                si.new_msg = j.final_msg->p; si.old_msg = cur[de] ? cur[de]->p : nullptr;
+                                si.diff_out = reinterpret_cast<double*>(d_diffs->p) + t; si.normalize = normalize;
+                            }
+                        }
+                    }
                     on_side(true);          // (with a split level: next to the bulk sites' plane kernels, like the other boundary-site work; the descriptor copy
                                             //  travels on the same stream as the kernel that reads it)
                     const SmallMsgItem* d = upload_small(s, small_items);          // (one workgroup per item reads its own descriptor: straight from the pinned arena)
@@ -834,6 +857,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 if (s->nranks <= 1) {
                     for (size_t i = 0; i < jobs.size(); ++i) {
                         int t = tpos[i]; int de = plan.seq[t]; int c = s->chi[de / 2];
+                        if (jobs[i].final_msg) { fresh[de] = jobs[i].final_msg; continue; }
                         Buf nb = dalloc(s, (size_t)c * c * esz);
                         MsgFinalItem f{}; f.partial = jobs[i].partial->p; f.nchunks = jobs[i].nchunks; f.chi = c;
                         const Buf& oldb = plan.in_place && fresh[de] ? fresh[de] : cur[de];
@@ -876,7 +900,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                         fresh[de] = nb;
                     }
                 }
-                {
+                if (!fin.empty()) {
                     const MsgFinalItem* d = upload_small(s, fin);
                     ProfScope ps(s, TNQS_PROF_SMALL, 0, 0);
                     launch_msg_finalize<T>(s->stream, d, (int)fin.size());

@@ -273,6 +273,7 @@ struct GramJob {      // out[i,j] = sum X[i,.] conj(Y[j,.]) over everything but 
     const void* X; const void* Y; SD sd; int leg;  /* -1: keep the site index only */ bool keep_site;
     Buf partial; int nchunks = 0; int KK = 0;
     const void* M = nullptr;       // fused path: message absorbed on the first row leg inside the Gram kernel
+    Buf final_msg;                 // set: the kernel that computed the message normalised and diffed it too (bp_small_site_kernel, matrix-core form): no msg_finalize item
 };
 
 template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls, int cls_pair = -1);

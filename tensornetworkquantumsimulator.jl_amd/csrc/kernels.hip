@@ -351,6 +351,122 @@ template void launch_msg_finalize<double>(hipStream_t, const MsgFinalItem*, int)
 // streamed such a tensor through one fiber-GEMM launch per leg plus a Gram launch, each with its descriptor copy: 16 launch groups of ~90 us per heavy-hex layer at
 // 0.09 TB/s (updated_message, abstractbeliefpropagationcache.jl:162-190)
 // ------------------------------------------------------------------------------------------------------------
+// The same message with EVERY leg 16-dimensional (heavy-hex at chi = 16: the shape the kernel exists for) on v_mfma_f32_16x16x4_f32 -- the scalar form below reads
+// two LDS operands per multiply-add and is bound by the LDS bandwidth of its CU (55 us per degree-3 message); here an operand is read once per 16 multiply-adds.
+// Lane l = (c = l & 15, g = l >> 4) supplies A[i = c][k = g] and B[k = g][j = c] and receives C[row = 4 g + r][col = c]; instruction t of a product takes
+// contraction index 4 g + t (kernels_plane.hip).  Four real products per complex one.
+//   absorb leg k (stride P):  out[fiber, qo] = sum_q cur[fiber, q] M[q, qo], computed transposed: A = M^T from registers, B = 16 fibers x 16 q from LDS,
+//                             C[qo][fiber] stored along the fibers (contiguous); a wave takes tiles of 16 fibers
+//   Gram over all but leg jo: out[i, j] = sum_rest cur[rest, i] conj psi[rest, j]: A, B = 4 rest values x 16 from the two LDS copies per instruction; the waves split
+//                             the rest index and their 16 x 16 partial sums meet in LDS
+typedef float v4f_ss __attribute__((ext_vector_type(4)));
+template <int NT>
+__device__ __forceinline__ void bp_small_site_mfma16(const SmallMsgItem& it, int E, char* smem, size_t smem_bytes) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = NT >> 6, c = lane & 15, g = lane >> 4;
+    cx<float>* cur = reinterpret_cast<cx<float>*>(smem);
+    cx<float>* nxt = cur + E;
+    // psi: 16-byte loads, all in flight at once, kept in registers for the second copy (E <= 8192: at most four per thread); the message matrices of all legs
+    // are fetched behind them (A[i = qo = c][k = q = 4 g + t] = M[q, qo]: four consecutive numbers per lane) -- one exposed memory latency per message
+    typedef float v4f_ld __attribute__((ext_vector_type(4)));
+    const v4f_ld* p4 = reinterpret_cast<const v4f_ld*>(it.psi);
+    const int n4 = E >> 1;
+    v4f_ld keep[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (tid + NT * u < n4) keep[u] = p4[tid + NT * u];
+    float mr[8][4], mi[8][4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < it.z && k != it.jo && it.M[k]) {
+            const cx<float>* Mg = reinterpret_cast<const cx<float>*>(it.M[k]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const cx<float> v = Mg[(4 * g + t) + 16 * c]; mr[k][t] = v.re; mi[k][t] = v.im; }
+        }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (tid + NT * u < n4) reinterpret_cast<v4f_ld*>(cur)[tid + NT * u] = keep[u];
+    __syncthreads();
+    const int ntile = E >> 8;                                         // tiles of 16 fibers of 16
+    int P = it.d;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k >= it.z) break;
+        if (k != it.jo && it.M[k]) {
+            for (int T = w; T < ntile; T += nw) {
+                const int F = 16 * T + c, pre = F % P, post = F / P;
+                const size_t base = pre + (size_t)P * 16 * post;
+                v4f_ss Cr = {0.f, 0.f, 0.f, 0.f}, Ci = Cr;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const cx<float> x = cur[base + (size_t)P * (4 * g + t)];                                               // B[k = q][j = fiber c]
+                    Cr = __builtin_amdgcn_mfma_f32_16x16x4f32(mr[k][t], x.re, Cr, 0, 0, 0);
+                    Cr = __builtin_amdgcn_mfma_f32_16x16x4f32(-mi[k][t], x.im, Cr, 0, 0, 0);
+                    Ci = __builtin_amdgcn_mfma_f32_16x16x4f32(mr[k][t], x.im, Ci, 0, 0, 0);
+                    Ci = __builtin_amdgcn_mfma_f32_16x16x4f32(mi[k][t], x.re, Ci, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nxt[base + (size_t)P * (4 * g + r)] = cmake<float>(Cr[r], Ci[r]);              // C[row = qo = 4 g + r][col = fiber c]
+            }
+            __syncthreads();
+            cx<float>* t_ = cur; cur = nxt; nxt = t_;
+        }
+        P *= 16;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (tid + NT * u < n4) reinterpret_cast<v4f_ld*>(nxt)[tid + NT * u] = keep[u];
+    __syncthreads();
+    int Po = it.d; for (int k = 0; k < it.jo; ++k) Po *= 16;
+    const int nstep = E >> 6;                                         // instructions' worth of the rest index: 4 rest values each
+    int na = nw < nstep ? nw : nstep;                                 // waves that take part; their 2 KiB partials must fit the kernel's LDS
+    if ((size_t)na * 2048 > smem_bytes) na = (int)(smem_bytes / 2048);
+    v4f_ss Or = {0.f, 0.f, 0.f, 0.f}, Oi = Or;
+    if (w < na)
+        for (int st = w; st < nstep; st += na) {
+            const int R = 4 * st + g, pre = R % Po, post = R / Po;
+            const size_t base = pre + (size_t)Po * 16 * post + (size_t)Po * c;
+            const cx<float> a = cur[base], b = nxt[base];             // A[i = c][k = rest], B[k = rest][j = c]
+            Or = __builtin_amdgcn_mfma_f32_16x16x4f32(a.re, b.re, Or, 0, 0, 0);
+            Or = __builtin_amdgcn_mfma_f32_16x16x4f32(a.im, b.im, Or, 0, 0, 0);
+            Oi = __builtin_amdgcn_mfma_f32_16x16x4f32(a.im, b.re, Oi, 0, 0, 0);
+            Oi = __builtin_amdgcn_mfma_f32_16x16x4f32(-a.re, b.im, Oi, 0, 0, 0);
+        }
+    __syncthreads();                                                  // both copies have been consumed: the partial sums go over them
+    cx<float>* part = reinterpret_cast<cx<float>*>(smem);
+    if (w < na) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[256 * w + (4 * g + r) + 16 * c] = cmake<float>(Or[r], Oi[r]);                     // out[i + 16 j], i = 4 g + r, j = c
+    }
+    __syncthreads();
+    static_assert(NT >= 256, "one thread per element of the 16 x 16 message");
+    cx<float> val = cmake<float>(0.f, 0.f);
+    if (tid < 256) {
+        float sr = 0.f, si = 0.f;
+        for (int u = 0; u < na; ++u) { const cx<float> v = part[256 * u + tid]; sr += v.re; si += v.im; }
+        val = cmake<float>(sr, si);
+    }
+    if (!it.new_msg) { if (tid < 256) reinterpret_cast<cx<float>*>(it.out)[tid] = val; return; }
+    // ---- the epilogue of msg_finalize_kernel on the message this workgroup holds: m / sum(m) (abstractbeliefpropagationcache.jl:182-187; skipped when the sum is
+    // exactly zero), message_diff against the previous message (beliefpropagationcache.jl:17-21) -------------------------------------------------------------
+    __shared__ double sh[17 * 4];
+    double s2[2] = {(double)val.re, (double)val.im};
+    block_sum_n<2>(s2, sh);
+    const double sre = s2[0], sim = s2[1];
+    double ire = 1, iim = 0;
+    if (it.normalize && (sre != 0 || sim != 0)) { const double d = sre * sre + sim * sim; ire = sre / d; iim = -sim / d; }
+    double d4[4] = {0, 0, 0, 0};       // Re, Im of dot(new, old), |new|^2, |old|^2
+    if (tid < 256) {
+        const double re = val.re * ire - val.im * iim, im = val.re * iim + val.im * ire;
+        const cx<float> wv = cmake<float>((float)re, (float)im);
+        reinterpret_cast<cx<float>*>(it.new_msg)[tid] = wv;
+        const cx<float>* old = reinterpret_cast<const cx<float>*>(it.old_msg);
+        double ore, oim;
+        if (old) { ore = old[tid].re; oim = old[tid].im; } else { ore = ((tid & 15) == (tid >> 4)) ? 1.0 : 0.0; oim = 0; }
+        d4[0] = (double)wv.re * ore + (double)wv.im * oim;
+        d4[1] = (double)wv.re * oim - (double)wv.im * ore;
+        d4[2] = (double)wv.re * wv.re + (double)wv.im * wv.im;
+        d4[3] = ore * ore + oim * oim;
+    }
+    block_sum_n<4>(d4, sh);
+    if (tid == 0 && it.diff_out) *it.diff_out = 1.0 - (d4[0] * d4[0] + d4[1] * d4[1]) / (d4[2] * d4[3]);
+}
 template <int NT>
 __global__ __launch_bounds__(NT) void bp_small_site_kernel(const SmallMsgItem* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -361,6 +477,7 @@ __global__ __launch_bounds__(NT) void bp_small_site_kernel(const SmallMsgItem* _
     cx<float>* nxt = cur + E;
     cx<float>* Ms = nxt + E;                                          // one message matrix, TRANSPOSED: Ms[qo + c q] = M[q + c qo] (<= 32 x 32)
     const cx<float>* psi = reinterpret_cast<const cx<float>*>(it.psi);
+    if (it.mfma) { bp_small_site_mfma16<NT>(it, E, smem, (size_t)E * 16 + 32 * 32 * 8); return; }
     for (int e = tid; e < E; e += NT) cur[e] = psi[e];
     __syncthreads();
     int P = it.d;                                                     // stride of leg k
@@ -981,6 +1098,7 @@ __global__ __launch_bounds__(NT) void theta_svd_pre_kernel(const JacobiItem* __r
     const float tiny = (float)((double)n * (double)eps_of<float>() * (double)eps_of<float>() * fro);
     int sweep;
     if (n == 64) sweep = jacobi_lds_sweeps_f32_full<4>(X, n, n, xp, max_sweeps, tiny, &s_rot);
+    else if (n == 32) sweep = jacobi_lds_sweeps_f32_full<2>(X, n, n, xp, max_sweeps, tiny, &s_rot);      // chi = 16 gates: 16 full pairs on four waves, no guards
     else sweep = jacobi_lds_sweeps<float, 4, false>(X, (cx<float>*)nullptr, false, n, n, xp, 0, max_sweeps, tiny, &s_rot);
     __syncthreads();
     PRE_STAMP(4);

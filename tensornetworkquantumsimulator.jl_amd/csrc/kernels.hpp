@@ -44,7 +44,10 @@ struct MsgFinalItem {     // BP epilogue: reduce partials, m /= sum(m), message_
 
 // BP message of a small site (bp_small_site_kernel): psi in the canonical layout [d][chi_0]..[chi_{z-1}] (<= 8192 elements, every chi <= 32, z <= 8), the message
 // entering through leg k (null: unset = identity; M[jo] is ignored), out = the raw chi_jo x chi_jo message [ket + chi bra]
-struct SmallMsgItem { const void* psi; void* out; const void* M[8]; int chi[8]; int d, z, jo; };
+struct SmallMsgItem { const void* psi; void* out; const void* M[8]; int chi[8]; int d, z, jo; int mfma;      // mfma: every leg 16-dimensional and the host allows the matrix-core form
+    // new_msg != null (matrix-core form only): the kernel is the message's epilogue as well -- m /= sum(m), message_diff against old_msg (null: identity), as
+    // msg_finalize_kernel does from the raw message; `out` is not written then
+    const void* old_msg; void* new_msg; double* diff_out; int normalize; };
 inline bool bp_small_site_covers(int d, int z, const int* chi, size_t nelem) {
     if (z < 1 || z > 8 || nelem > 8192 || d < 1) return false;
     for (int k = 0; k < z; ++k) if (chi[k] > 32) return false;

@@ -384,6 +384,27 @@ def test_bp_update_chi32_bulk_sites_matches_oracle(seq_name):
         assert abs(tn.expect(out2, ("Z", [v])) - o.expect_1site(oc2, Z, v)) < 2e-5
 
 
+@pytest.mark.parametrize("lattice", ["hh11", "hh22", "ring6"])
+def test_small_sites_with_16_dimensional_legs_match_oracle(lattice):
+    """heavy-hex sites at chi = 16 (BASELINE configs[2] per-site shape: 2 x 16^3 = 64 KiB, 2 x 16^2 at the degree-2 sites): the whole message of such a site is ONE
+    kernel with the tensor in LDS, on the f32 matrix cores when every leg is 16-dimensional (kernels.hip bp_small_site_mfma16).  Messages elementwise against the
+    oracle over three sweeps, default order replayed (updated_message, abstractbeliefpropagationcache.jl:162-190)."""
+    g = {"hh11": lambda: tn.heavy_hexagonal_lattice(1, 1), "hh22": lambda: tn.heavy_hexagonal_lattice(2, 2), "ring6": lambda: tn.named_grid((6,), periodic=True)}[lattice]()
+    psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=16, seed=5)
+    for v in g.vertices:
+        psi.tensors[v] = (psi.tensors[v] / np.linalg.norm(psi.tensors[v])).astype(np.complex64)
+    bpc = tn.BeliefPropagationCache(psi)
+    seq = device_default_sequence(bpc)
+    kw = dict(maxiter=1, tolerance=None)
+    out, oc = bpc, o.BeliefPropagationCache(to_oracle_state(psi))
+    for _sweep in range(3):
+        out = tn.update(out, **kw)
+        oc = o.update(oc, **dict(kw, edge_sequence=seq))
+        compare_messages(out, oc, 5e-5)
+    for v in list(g.vertices)[:4]:
+        assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oc, Z, v)) < 2e-5
+
+
 def sequence_levels(g, seq):
     """dependency levels of a sequential sweep order (a message waits for the EARLIER messages that enter its source; engine_bp.cpp sequence_levels)"""
     pos = {m: t for t, m in enumerate(seq)}

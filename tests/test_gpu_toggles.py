@@ -131,6 +131,28 @@ def test_chi16_plane_kernels_match_the_single_leg_route():
     assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-5
 
 
+@pytest.mark.parametrize("switch", ["TNQS_NO_SMALL_SITE_MFMA", "TNQS_NO_SMALL_SITE_FINALIZE", "TNQS_NO_SMALL_SITE_BP"])
+def test_small_site_message_kernel_forms_match(switch):
+    """heavy-hex at chi = 16: the whole message of a small site in one LDS-resident kernel (kernels.hip bp_small_site_kernel) -- on the f32 matrix cores when every
+    leg is 16-dimensional, with the normalisation and message_diff of msg_finalize_kernel inside -- against its scalar form, against the separate epilogue launch and
+    against the generic chain + Gram route.  Messages after three sweeps elementwise (same site tensors, same order), then one layer."""
+    on, off = run_worker({}, "hh16"), run_worker({switch: "1"}, "hh16")
+    if switch == "TNQS_NO_SMALL_SITE_FINALIZE":
+        assert on["small"] < off["small"], (on["small"], off["small"])          # the epilogue launches are gone
+    if switch == "TNQS_NO_SMALL_SITE_BP":
+        assert on["modeprod"] < off["modeprod"], (on["modeprod"], off["modeprod"])
+    worst = 0.0
+    for ma, mb in zip(on["msgs"], off["msgs"]):
+        a = np.array(ma[0]) + 1j * np.array(ma[1]); b = np.array(mb[0]) + 1j * np.array(mb[1])
+        worst = max(worst, float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
+    print(switch, "small-site messages", worst)
+    assert worst < 2e-5
+    assert on["dims"] == off["dims"]
+    ea, eb = np.array(on["errs"]), np.array(off["errs"])
+    assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7)
+    assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-5
+
+
 def test_partial_products_kept_across_levels_change_nothing_but_the_pass_count():
     """3x3x3 torus, chi = 16: the BP partial products remembered from one level to the next (engine_bp.cpp ProdCache: the levels of one axis
     share the product over the other axes' legs, two axes share the factor over the third) against every level absorbing from the site

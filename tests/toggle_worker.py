@@ -103,7 +103,30 @@ def tolsweeps():
     print(json.dumps(out))
 
 
+def hh16():
+    """heavy-hex (2,2) at chi = 16 (BASELINE configs[2] per-site shape: degree-3 sites of 2 x 16^3, degree-2 sites of 2 x 16^2): three BP sweeps in the default
+    order and one Rx + Rzz layer -- the one-kernel small-site message (scalar form, matrix-core form, with and without its fused epilogue) against the generic route"""
+    g = tn.heavy_hexagonal_lattice(2, 2)
+    chi = 16
+    bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(np.complex64, lambda v: "↑", g))
+    rng = np.random.default_rng(11)
+    for v in g.vertices:
+        shp = (2,) + (chi,) * g.degree(v); n = int(np.prod(shp))
+        bpc._set_tensor(v, rng.standard_normal(2 * n, dtype=np.float32).view(np.complex64).reshape(shp) / np.float32(np.sqrt(n)))
+    tn.profile_enable(bpc, True)
+    bpc = tn.update(bpc, maxiter=3, tolerance=None)
+    prof = tn.profile_get(bpc)
+    msgs = [bpc.message(e) for (a, b) in g.edges for e in ((a, b), (b, a))]
+    layer = [("Rx", [v], 0.4) for v in g.vertices] + [("Rzz", [a, b], 0.3) for grp in tn.edge_color(g, 3) for (a, b) in grp]
+    b2, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True), bp_update_kwargs=dict(maxiter=3, tolerance=None))
+    out = dict(msgs=[[m.real.tolist(), m.imag.tolist()] for m in msgs], errs=errs.tolist(), z=[float(np.real(x)) for x in tn.expect_all(b2, "Z")],
+               dims=[b2.bond_dim(a, b) for a, b in g.edges], fused=prof["bp_fused"]["launches"], small=prof["small"]["launches"], modeprod=prof["bp_modeprod"]["launches"])
+    print(json.dumps(out))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "hh16":
+        return hh16()
     if len(sys.argv) > 1 and sys.argv[1] == "tolsweeps":
         return tolsweeps()
     if len(sys.argv) > 1 and sys.argv[1] == "c128":
