@@ -361,7 +361,7 @@ def main():
                       "bp_partial_products": {"reused_per_step": reused, "evicted_per_step": evicted},
                       "apply_kwargs": {"maxdim": chi, "cutoff": 1e-10, "normalize_tensors": True},
                       "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-5)",
-                      "bp_order": ("library default: linear forests, one level per forest (tnqs_bp_opts.n_sequence = 0; the reference's forest_cover_edge_sequence is n_sequence = -1, "
+                      "bp_order": ("library default: linear forests, one level per forest -- on periodic lattices edge sets that close cycles, two levels per set -- (tnqs_bp_opts.n_sequence = 0; the reference's forest_cover_edge_sequence is n_sequence = -1, "
                                    "bench.py --bp-order reference; same fixed point)" if args.bp_order == "library" else
                                    "the reference's default, forest_cover_edge_sequence(graph) (tnqs_bp_opts.n_sequence = -1)"),
                       "state_init": ("host numpy, per-vertex counter streams" if (cfg == "c2" or args.host_init) else "on device (tnqs_set_site_random, counter-based)"),
