@@ -95,6 +95,18 @@ def spawn_ranks(n):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def profile_entry(db, kern):
+    """the entry of a kernel in a counter-pass summary: rocprofv3 prints every template argument (`x3_pair_gram2_kernel<0, false>`), KERNEL_OF names the kernel as
+    the sources call it (`x3_pair_gram2_kernel<0>`, defaults omitted)"""
+    if not kern or not db:
+        return {}
+    if kern in db:
+        return db[kern]
+    stem = kern[:-1] if kern.endswith(">") else kern
+    hits = [k for k in db if k.startswith(stem + ",") or k.startswith(stem + ">") or k == stem]
+    return db[hits[0]] if len(hits) == 1 else {}
+
+
 def profile_db(name):
     """counters of a committed profile of THIS command (profiles/<name>) with their provenance: the build id stored in the file against the
     build id of the tree this script runs from (profiles/buildid.py) -- the JSON line says when the two differ instead of quoting counters
@@ -293,14 +305,14 @@ def main():
         ai = p["flops"] / p["bytes"]
         kern = KERNEL_OF.get(dom)
         headline = world == 1 and cfg == "c2" and L == 20 and chi == 32      # the committed counter passes are of that command
-        traffic = traffic_db.get(kern, {}).get("hbm_bytes_per_launch") if headline else None
+        traffic = profile_entry(traffic_db, kern).get("hbm_bytes_per_launch") if headline else None
         common = {"kernel_class": dom, "kernel": kern, "avg_launch_ms": round(p["ms"] / max(1, p["launches"]), 4), "launches": p["launches"],
                   "arithmetic_intensity_flop_per_B": round(ai, 2), "alg_bytes_per_launch": round(p["bytes"] / max(1, p["launches"])),
                   "alg_TFLOPs": round(tflops, 2), "alg_GBps": round(gbs, 1), "traffic": traffic,
                   # matrix-core utilisation of the same kernel from the committed counter pass (profiles/r2_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES /
                   # (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs)); like `traffic` it is a profile of this command, not re-measured in this run
-                  "mfma_busy": (mfma_db.get(kern, {}).get("mfma_busy") if headline else None),
-                  "mfma_executed_TFLOPs": (mfma_db.get(kern, {}).get("mfma_tflops") if headline else None),
+                  "mfma_busy": (profile_entry(mfma_db, kern).get("mfma_busy") if headline else None),
+                  "mfma_executed_TFLOPs": (profile_entry(mfma_db, kern).get("mfma_tflops") if headline else None),
                   # `achieved` counts ALGORITHMIC flops (8 per complex multiply-add).  The plane kernels form the complex product with Gauss' three
                   # real multiplications (csrc/mfma_common.hpp, CAcc32): the matrix cores execute 0.75 x the algorithmic count, so the
                   # algorithmic rate can exceed what `peak` allows a four-multiplication kernel; executed / peak is the matrix-core load
