@@ -44,6 +44,10 @@ int tnqs_dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double
 int tnqs_dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2);
 /* the BP sweep order bp_update uses when no edge_sequence is given, as (src[i] -> dst[i]) vertex indices; *n_out = its length (2 ne) */
 int tnqs_dbg_default_sequence(tnqs_handle h, int* src, int* dst, int cap, int* n_out);
+/* the same order from the graph alone (nv vertices, ne undirected edges esrc[e] - edst[e]) together with the dependency level bp_update runs every message in
+ * (messages of one level are launched together; which value a message reads is decided by the positions).  HOST ONLY: no device is touched, so the scheduling
+ * logic of the BP update -- linear forests, edge sets that close cycles on periodic lattices -- is testable without a GPU (tests/test_bp_schedule.py) */
+int tnqs_dbg_default_sequence_graph(int nv, int ne, const int32_t* esrc, const int32_t* edst, int* src, int* dst, int* level, int cap, int* n_out);
 #ifdef __cplusplus
 }
 #endif

@@ -182,6 +182,8 @@ int tnqs_profile_reset(tnqs_handle h) {
 #include "../../include/tnqs_debug.h"
 #include "kernels.hpp"
 namespace tnqs { void dbg_default_sequence(const State* s, std::vector<int>& src, std::vector<int>& dst);
+                 std::shared_ptr<Graph> dbg_make_graph(int nv, int ne, const int32_t* es, const int32_t* ed);
+                 void dbg_default_sequence_graph(const Graph& g, std::vector<int>& src, std::vector<int>& dst, std::vector<int>& level);
                  void dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const void* My, void* out);
                  void dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out);
                  void dbg_gauge_gram(int z, const int* chi, int bleg, const void* X, const void* M, void* out);
@@ -200,6 +202,11 @@ extern "C" {
 int tnqs_dbg_default_sequence(tnqs_handle h, int* src, int* dst, int cap, int* n_out) {
     return guard([&] { std::vector<int> a, b; dbg_default_sequence(S(h), a, b); *n_out = (int)a.size();
                        for (int i = 0; i < (int)a.size() && i < cap; ++i) { src[i] = a[i]; dst[i] = b[i]; } });
+}
+int tnqs_dbg_default_sequence_graph(int nv, int ne, const int32_t* esrc, const int32_t* edst, int* src, int* dst, int* level, int cap, int* n_out) {
+    return guard([&] { if (nv < 0 || ne < 0 || (ne > 0 && (!esrc || !edst)) || !n_out) throw Err(TNQS_ERR_INVALID, "tnqs_dbg_default_sequence_graph: bad arguments");
+                       auto g = dbg_make_graph(nv, ne, esrc, edst); std::vector<int> a, b, l; dbg_default_sequence_graph(*g, a, b, l); *n_out = (int)a.size();
+                       for (int i = 0; i < (int)a.size() && i < cap; ++i) { if (src) src[i] = a[i]; if (dst) dst[i] = b[i]; if (level) level[i] = l[i]; } });
 }
 int tnqs_dbg_jacobi(int dtype, int m, int n, void* A, void* V, int* sweeps) { return guard([&] { dbg_jacobi(dtype, m, n, A, V, sweeps); }); }
 int tnqs_dbg_theta_svd_pre(int m, int n, int nq, void* A, const void* Q, void* V, int* sweeps, int copies, int reps, double* ms, double* phase_us, int cap) { return guard([&] { dbg_theta_svd_pre(m, n, nq, A, Q, V, sweeps, copies, reps, ms, phase_us, cap); }); }

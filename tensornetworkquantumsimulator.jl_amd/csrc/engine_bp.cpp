@@ -231,6 +231,15 @@ void dbg_default_sequence(const State* s, std::vector<int>& src, std::vector<int
     for (int de : g.default_seq) { const int e = de / 2; src.push_back((de & 1) ? g.edst[e] : g.esrc[e]); dst.push_back((de & 1) ? g.esrc[e] : g.edst[e]); }
 }
 
+// the same from the graph alone, with the dependency levels bp_update schedules the order in (host only, no device: tests/test_bp_schedule.py)
+void dbg_default_sequence_graph(const Graph& g, std::vector<int>& src, std::vector<int>& dst, std::vector<int>& level) {
+    if (g.default_seq.empty() && g.ne > 0) g.default_seq = default_sequence(g, g.default_set_starts);
+    std::vector<int> pos_of(2 * (size_t)g.ne, -1);
+    for (size_t t = 0; t < g.default_seq.size(); ++t) pos_of[g.default_seq[t]] = (int)t;
+    level = sequence_levels(g, g.default_seq, pos_of, g.default_set_starts.empty() ? nullptr : &g.default_set_starts);
+    for (int de : g.default_seq) { const int e = de / 2; src.push_back((de & 1) ? g.edst[e] : g.esrc[e]); dst.push_back((de & 1) ? g.esrc[e] : g.edst[e]); }
+}
+
 static BPPlan make_plan(const State* s, const tnqs_bp_opts* o) {
     const Graph& g = *s->g;
     BPPlan p;

@@ -105,6 +105,9 @@ static std::shared_ptr<Graph> make_graph(int nv, int ne, const int32_t* es, cons
     return g;
 }
 
+// (host only: the graph of a handle without the handle -- include/tnqs_debug.h tnqs_dbg_default_sequence_graph)
+std::shared_ptr<Graph> dbg_make_graph(int nv, int ne, const int32_t* es, const int32_t* ed) { return make_graph(nv, ne, es, ed); }
+
 // ---------------------------------------------------------------------------------------------------------------
 // state plumbing
 // ---------------------------------------------------------------------------------------------------------------
