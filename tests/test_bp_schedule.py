@@ -34,6 +34,8 @@ LATTICES = {
     "cubic3p": lambda: tn.named_grid((3, 3, 3), periodic=True),
     "cubic5p": lambda: tn.named_grid((5, 5, 5), periodic=True),
     "cubic4": lambda: tn.named_grid((4, 4, 4)),
+    "cubic10p": lambda: tn.named_grid((10, 10, 10), periodic=True),      # BASELINE configs[3] at full size (1000 sites, 3000 edges)
+    "grid32x32": lambda: tn.named_grid((32, 32)),                        # BASELINE configs[4]
     "ring7": lambda: tn.named_grid((7,), periodic=True),
     "comb": lambda: tn.named_comb_tree((4, 3)),
 }
@@ -56,7 +58,8 @@ def test_default_order_is_a_sequential_order_with_a_valid_level_schedule(name):
     ("grid5x5", 2, None), ("grid20x20", 2, None),          # rows and columns: two levels per sweep
     ("heavyhex5x5", 2, None),
     ("torus4x4", 4, 2 * 16), ("torus8x8", 4, 2 * 64),      # two sets of cycles: every site sends two messages per set in ONE level
-    ("cubic3p", 6, 3 * 27), ("cubic5p", 6, 3 * 125),       # three sets, two levels each (all sites of a ring but one, then that one)
+    ("cubic3p", 6, 3 * 27), ("cubic5p", 6, 3 * 125), ("cubic10p", 6, 3 * 1000),       # three sets, two levels each (all sites of a ring but one, then that one)
+    ("grid32x32", 2, None),
     ("ring7", 2, 7)])
 def test_two_messages_per_site_and_level_on_lattices(name, levels, passes):
     g = LATTICES[name]()
