@@ -339,6 +339,20 @@ def _gate_spec_of(name: str):
     return _resolve(name)
 
 
+def _frozen_probe(gt):
+    """None: not cacheable; (): nothing mutable; tuple(vs): the snapshot of a vertex list"""
+    if not (isinstance(gt, tuple) and len(gt) >= 2 and isinstance(gt[0], str)):
+        return None
+    if not all(isinstance(x, (int, float, complex, np.integer, np.floating, np.complexfloating, bool)) for x in gt[2:]):
+        return None
+    vs = gt[1]
+    if isinstance(vs, np.ndarray):
+        return None
+    if isinstance(vs, (list, tuple)) and any(isinstance(x, (list, np.ndarray, dict, set)) for x in vs):
+        return None
+    return tuple(vs) if isinstance(vs, list) else ()
+
+
 _MARSHALLED: list = []      # (graph, ids of the gate tuples, gate tuples, arrays): the last few circuits, most recent first
 
 
@@ -348,8 +362,9 @@ def _marshal_circuit(circuit: Sequence, g: NamedGraph):
     a 5 ms heavy-hex layer, so the arrays of the last few circuits are kept -- keyed by the IDENTITY of every gate tuple (tuples are immutable: the same
     objects in the same order on the same graph are the same circuit), which costs ~30 ns per gate to check."""
     ids = tuple(map(id, circuit))
-    for k, (g0, ids0, _gates, specs, arrs) in enumerate(_MARSHALLED):
-        if g0 is g and ids0 == ids and all(_gate_spec_of(nm) is sp for nm, sp in specs):      # (the registry still maps every name to the same definition)
+    for k, (g0, ids0, _gates, specs, snaps, arrs) in enumerate(_MARSHALLED):
+        if (g0 is g and ids0 == ids and all(_gate_spec_of(nm) is sp for nm, sp in specs)      # (the registry still maps every name to the same definition)
+                and (snaps is None or all(sn is None or (type(gt[1]) is list and tuple(gt[1]) == sn) for gt, sn in zip(circuit, snaps)))):
             if k:
                 _MARSHALLED.insert(0, _MARSHALLED.pop(k))
             return arrs
@@ -366,19 +381,18 @@ def _marshal_circuit(circuit: Sequence, g: NamedGraph):
     vs_a, vs_p = L.i32(verts if verts else [0])
     mat_a = np.ascontiguousarray(np.concatenate(mats) if mats else np.zeros(1, dtype=np.complex128))
     arrs = (ng, nv_a, nv_p, vs_a, vs_p, mat_a)
-    # cached only when NOTHING of a gate can be edited in place behind the identity key (round-4 advisor finding: ("Rzz", [a, b], theta) is a tuple, but
-    # its vertex list is mutable, and so is an array parameter): the gate is a tuple, its name a string, its vertices a tuple (or one hashable vertex that
-    # is not a list), its parameters plain numbers.  Anything else is resolved again on every call.
-    def _frozen(gt):
-        if not (isinstance(gt, tuple) and len(gt) >= 2 and isinstance(gt[0], str)):
-            return False
-        vs = gt[1]
-        if isinstance(vs, list) or isinstance(vs, np.ndarray) or (isinstance(vs, tuple) and any(isinstance(x, (list, np.ndarray)) for x in vs)):
-            return False
-        return all(isinstance(x, (int, float, complex, np.integer, np.floating, np.complexfloating)) and not isinstance(x, bool) or isinstance(x, bool) for x in gt[2:])
-    if all(_frozen(gt) for gt in circuit):
+    # cached only when nothing of a gate can be edited in place behind the identity key without being noticed (round-4 advisor finding): the gate is a
+    # tuple, its name a string, its parameters plain numbers, its vertices a tuple / one hashable vertex -- or a LIST of hashable vertices, the form the
+    # reference's API, the README and most callers use (("Rzz", [a, b], theta)): a list can be edited in place, so a frozen snapshot of it is kept next to
+    # the identity key and compared on every lookup (~100 ns per gate; round-5 advisor finding: only tuple-form circuits were cached).  Anything else --
+    # array parameters, nested lists -- is resolved again on every call.
+    fz = [_frozen_probe(gt) for gt in circuit]
+    if all(f is not None for f in fz):
         names = {gt[0] for gt in circuit}
-        _MARSHALLED.insert(0, (g, ids, tuple(circuit), [(nm, _gate_spec_of(nm)) for nm in names], arrs))   # the tuple keeps the gate objects (and their ids) alive
+        snaps = [f if f != () or isinstance(gt[1], list) else None for gt, f in zip(circuit, fz)]
+        if all(sn is None for sn in snaps):
+            snaps = None
+        _MARSHALLED.insert(0, (g, ids, tuple(circuit), [(nm, _gate_spec_of(nm)) for nm in names], snaps, arrs))   # the tuple keeps the gate objects (and their ids) alive
         del _MARSHALLED[4:]
     return arrs
 

@@ -961,7 +961,7 @@ __global__ __launch_bounds__(NT) void theta_svd_pre_kernel(const JacobiItem* __r
     __shared__ int s_rot;
     __shared__ double s_red[17];
     __shared__ double s_cn[64]; __shared__ double s_piv[64]; __shared__ unsigned char s_pos[64]; __shared__ unsigned char s_perm[64];
-    __shared__ double s_dmax; __shared__ double s_sig[64];
+    __shared__ double s_dmax; __shared__ double s_sig[64]; __shared__ int s_bad;
     // it.V is never an output here (V is not accumulated); the kernel tests pass a buffer of 8 x 64-bit slots that receives the constant-rate clock at the
     // phase boundaries (engine: null)
 #define PRE_STAMP(k) do { if (tstamp && threadIdx.x == 0) tstamp[k] = wall_clock64(); } while (0)
@@ -977,6 +977,8 @@ __global__ __launch_bounds__(NT) void theta_svd_pre_kernel(const JacobiItem* __r
     // kernel launched next to this one makes the complementary decision.  pre == 0 (kernel tests): the dimensions given decide
     if (it.pre ? !theta_pre_takes(it.dyn, it.dm, it.dn, it.QB != nullptr) : (n < 2 || m < n || n > 64 || m > 128)) return;
     const int mp = m + 2, gp = n + 1, xp = n + 2;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
     cx<float>* Mf = reinterpret_cast<cx<float>*>(smem);                                   // sorted A, column a at mp * a
     const size_t m_bytes = (((size_t)mp * n * sizeof(cx<float>)) + 15) & ~(size_t)15;
     cx<double>* Gd = reinterpret_cast<cx<double>*>(smem + m_bytes);                      // G / L (lower triangle), element (i, j) at i + gp * j
@@ -987,7 +989,7 @@ __global__ __launch_bounds__(NT) void theta_svd_pre_kernel(const JacobiItem* __r
         double s2 = 0;
         for (int i = lane; i < m; i += 64) { const cx<float> v = Ag[i + (size_t)m * j]; s2 += (double)v.re * v.re + (double)v.im * v.im; }
         s2 = wave_sum(s2);
-        if (lane == 0) s_cn[j] = s2 == s2 ? s2 : 0.0;
+        if (lane == 0) { s_cn[j] = s2 == s2 ? s2 : 0.0; if (!(s2 == s2) || s2 > 1e300) s_bad = 1; }
     }
     __syncthreads();
     for (int j = tid; j < n; j += NT) {
@@ -997,6 +999,21 @@ __global__ __launch_bounds__(NT) void theta_svd_pre_kernel(const JacobiItem* __r
     }
     double fro = 0; for (int j = tid; j < n; j += NT) fro += s_cn[j];
     fro = block_sum(fro, s_red);                                                         // (also orders s_pos before the load below)
+    // Degenerate input (round-5 advisor finding).  theta identically ZERO: its SVD is U Sigma = 0 -- A stays as it is, V = 0; before this guard the largest
+    // Cholesky pivot was 0, every pivot was replaced by 1, L became the identity and the unformed columns left as sigma_j e_0 with sigma = 1: weight in S and in
+    // the truncation error that the matrix does not have.  A NaN / infinite entry: the column norm was mapped to 0 and the column treated as rank deficient
+    // instead of flagged -- now A stays as it is (the NaNs reach gate_finish, which reports TNQS_ERR_NUMERIC like the plain Jacobi route) and V is NaN too
+    if (s_bad || !(fro > 0)) {
+        if (it.Vout) {
+            cx<float>* Vg = reinterpret_cast<cx<float>*>(it.Vout);
+            int rows = n;
+            if (it.QB && it.dyn && it.dyn[7] > 0) { int mq, nq, kq_; theta_dims(it.dyn, it.dm, it.dn, mq, nq, kq_); rows = nq; (void)mq; (void)kq_; }
+            const float fill = s_bad ? __builtin_nanf("") : 0.f;
+            for (int e = tid; e < rows * n; e += NT) Vg[e] = cmake<float>(fill, fill);
+        }
+        if (tid == 0 && it.sweeps_out) *it.sweeps_out = 0;
+        return;
+    }
     int kexp = 0;
     if (fro > 0 && fro < 1e300) { kexp = -(ilogb(fro) / 2); kexp = kexp > 120 ? 120 : (kexp < -120 ? -120 : kexp); }
     const double sc2 = ldexp(1.0, 2 * kexp), sc_out = ldexp(1.0, -kexp);                 // G is formed at ||A||_F = O(1): L, the sweeps and s_sig live at that scale

@@ -157,7 +157,7 @@ def test_steiner_tree_of_an_observable_support():
 
 def test_marshalled_circuit_cache_keys_on_gate_identity_and_registry():
     """core._marshal_circuit: the flat arrays of a circuit are reused for the SAME gate tuples on the same graph only, and not after the registry entry of
-    one of its names changed; lists and explicit matrices are never cached."""
+    one of its names changed; flat vertex lists are cached with a snapshot, array parameters and explicit matrices never."""
     from tnqs_amd import core
     g = tn.named_grid((2, 2))
     layer = [("Rx", (v,), 0.3) for v in g.vertices] + [("Rzz", (a, b), 0.2) for (a, b) in g.edges]      # vertex TUPLES: nothing of a gate can be edited in place
@@ -168,13 +168,20 @@ def test_marshalled_circuit_cache_keys_on_gate_identity_and_registry():
     rebuilt = [("Rx", (v,), 0.3) for v in g.vertices] + [("Rzz", (a, b), 0.2) for (a, b) in g.edges]
     a4 = core._marshal_circuit(rebuilt, g)
     assert a4[5] is not a1[5] and np.array_equal(a4[5], a1[5])
-    # a vertex LIST or an array parameter can be mutated behind the identity key (round-4 advisor finding): such circuits are resolved on every call
+    # a vertex LIST -- the reference's own calling form, ("Rzz", [a, b], theta) -- can be mutated behind the identity key (round-4 advisor finding): it is cached
+    # WITH a frozen snapshot of the list that every lookup compares (round-5 advisor finding: only tuple-form circuits were cached), so an in-place edit is seen
     mutable = [("Rx", [v], 0.3) for v in g.vertices] + [("Rzz", [a, b], 0.2) for (a, b) in g.edges]
     b1 = core._marshal_circuit(mutable, g); b2 = core._marshal_circuit(mutable, g)
-    assert b1[5] is not b2[5] and np.array_equal(b1[5], a1[5]) and np.array_equal(b1[3], a1[3])
+    assert b1[5] is b2[5] and np.array_equal(b1[5], a1[5]) and np.array_equal(b1[3], a1[3])
     mutable[-1][1][0], mutable[-1][1][1] = mutable[-1][1][1], mutable[-1][1][0]      # swap the two vertices of the last gate in place
     b3 = core._marshal_circuit(mutable, g)
-    assert not np.array_equal(b3[3], b1[3])                                          # the edit is seen
+    assert b3[5] is not b1[5] and not np.array_equal(b3[3], b1[3])                    # the edit is seen: resolved again
+    mutable[-1][1][0], mutable[-1][1][1] = mutable[-1][1][1], mutable[-1][1][0]      # ... and back: the ORIGINAL entry's snapshot matches again
+    assert np.array_equal(core._marshal_circuit(mutable, g)[3], b1[3])
+    mutable[0][1].append(g.vertices[1])                                              # a list that grew in place (now an invalid one-site gate on two vertices)
+    assert core._marshal_circuit(mutable, g)[0] == len(mutable) and core._marshal_circuit(mutable, g)[3].size == b1[3].size + 1
+    nested = [("Rzz", [[g.edges[0][0]], g.edges[0][1]], 0.2)]                         # anything stranger than a flat list is never cached (and rejected downstream)
+    assert core._frozen_probe(nested[0]) is None
     arr_param = [("Rx", (g.vertices[0],), np.array(0.3))]
     assert core._marshal_circuit(arr_param, g)[5] is not core._marshal_circuit(arr_param, g)[5]
     assert core._marshal_circuit(layer, tn.named_grid((2, 2)))[5] is not a1[5]       # another graph object
