@@ -122,6 +122,90 @@ def profile_db(name):
         return {}, None
 
 
+def c1_circuit(mod):
+    """BASELINE configs[0] = examples/2dIsing_dynamics.jl with the README quick-start numbers (README.md:36-53): 5 x 5 open grid, J = 1, hx = 2.5, dt = 0.01,
+    Rx on every vertex then Rzz by edge colour; `mod` is the device package or the oracle (same constructors)"""
+    g = mod.named_grid((5, 5))
+    groups = mod.edge_color(g, 4)
+    layer = [("Rx", [v], 2 * 2.5 * 0.01) for v in g.vertices]
+    for grp in groups:
+        layer += [("Rzz", [a, b], 2 * 1.0 * 0.01) for (a, b) in grp]
+    return g, groups, layer
+
+
+def main_c1(args, tn, torch):
+    """BASELINE configs[0], the configuration the reference itself runs on a CPU: 5 x 5 TFIM, 50 Trotter layers from the product state, maxdim 10, ComplexF64,
+    reference-default BP kwargs.  A step = one layer (what examples/2dIsing_dynamics.jl:56-57 times); the timed region is the whole 50-layer run on a fresh state
+    (bonds grow 1 -> 10 on the way), after --warmup layers on a scratch copy that only load the kernels.  The CPU leg runs the SAME 50 layers through the parity
+    oracle (oracle/tnqs_oracle.py: the reference's algorithm gate by gate, message by message -- numpy / LAPACK, one thread, like the reference's sequential
+    Julia loop) on this box's host; 3 MB of state is far too small for a thread pool to pay (oracle/cpu_layer.py is the many-core organisation, for c2)."""
+    chi, dtype = 10, np.complex128
+    g, groups, layer = c1_circuit(tn)
+    kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
+    scratch = tn.update(tn.BeliefPropagationCache(tn.tensornetworkstate(dtype, lambda v: "↑", g)))
+    for _ in range(max(1, args.warmup)):
+        scratch, _e = tn.apply_gates(layer, scratch, apply_kwargs=kw)
+    del scratch
+    bpc = tn.update(tn.BeliefPropagationCache(tn.tensornetworkstate(dtype, lambda v: "↑", g)))
+    tn.profile_enable(bpc, os.environ.get("TNQS_BENCH_NOPROF") != "1"); tn.profile_reset(bpc)
+    torch.cuda.synchronize()
+    per_layer, sweeps, chis = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter(); info = {}
+        bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=kw, info=info)
+        per_layer.append(1e3 * (time.perf_counter() - t1)); sweeps.append(info["n_sweeps"]); chis.append(int(bpc.maxvirtualdim()))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof_all = tn.profile_get(bpc)
+    z_dev = tn.expect_all(bpc, "Z").real
+    n2 = g.ne()
+    sat = [t for t, c in zip(per_layer, chis) if c >= chi]
+    out = {"metric": "two-site gates/sec at fixed chi (LxL TFIM Trotter layer)", "value": round(n2 * args.steps / elapsed, 2), "unit": "two-site gates/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "c128 (ComplexF64)", "data": "synthetic (the example's own product state; no random numbers)",
+           "config": {"workload": f"5x5 square-lattice TFIM, {args.steps} Trotter layers from the product state, chi=10, ComplexF64, apply_gates incl. BP updates; BASELINE.json configs[0]"
+                                  + ("" if args.steps == 50 else f" with {args.steps} instead of 50 layers"),
+                      "baseline_config": "c1", "two_site_gates_per_step": n2, "apply_kwargs": {"maxdim": chi, "cutoff": 1e-10, "normalize_tensors": True},
+                      "bp_update_kwargs": "reference defaults (maxiter 25, tol 1e-8)", "bp_sweeps_per_step": sweeps, "max_bond_dim_per_step": chis,
+                      "ms_per_layer": {"first": round(per_layer[0], 3), "last": round(per_layer[-1], 3), "mean_at_saturated_bonds": (round(float(np.mean(sat)), 3) if sat else None),
+                                       "layers_at_saturated_bonds": len(sat)}},
+           "roofline": {"bound": "latency", "note": "a 3 MB problem: no kernel of this run moves enough bytes or flops for either roof to mean anything (the largest tensor pass is 320 KB); what is "
+                                                    "measured is the dependent chain of ~330 launches per layer, see kernel_classes and DESIGN.md section 7",
+                        "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None},
+           "kernel_classes": {k: {"ms": round(v["ms"], 2), "launches": v["launches"]} for k, v in prof_all.items() if v["launches"]}}
+    if not args.no_cpu_baseline:
+        try:
+            import tnqs_oracle as o
+            og, olayer = o.named_grid((5, 5)), layer          # the same gate list (same vertex labels, same colour order) on both sides
+            ob = o.update(o.BeliefPropagationCache(o.product_state(dtype, lambda v: "↑", og)))
+            t0 = time.perf_counter(); osw = []
+            for _ in range(args.steps):
+                inf = {}
+                ob, _e = o.apply_gates(olayer, ob, apply_kwargs=kw, info=inf); osw.append(int(np.sum(inf.get("sweeps", [0]))))
+            cpu_s = time.perf_counter() - t0
+            zop = np.diag([1.0, -1.0]).astype(complex)
+            z_cpu = np.array([o.expect_1site(ob, zop, v).real for v in og.vertices])
+            host = "unknown CPU"
+            try:
+                with open("/proc/cpuinfo") as f:
+                    models = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
+                if models:
+                    host = f"{models[0]} ({len(models)} hardware threads)"
+            except OSError:
+                pass
+            out["cpu_baseline"] = {"value": round(n2 * args.steps / cpu_s, 2), "unit": "two-site gates/s", "cores": 1, "kind": "port", "host": host,
+                                   "ms_per_step": round(1e3 * cpu_s / args.steps, 3), "bp_sweeps_per_step": osw,
+                                   "sample": f"the same {args.steps} layers of the same circuit from the same product state: the WHOLE workload, {cpu_s:.1f} s of CPU time, parity oracle "
+                                             "(oracle/tnqs_oracle.py, numpy / LAPACK, sequential like the reference's loop, its own default edge sequence); it is NOT the Julia package",
+                                   "device_over_cpu": round(cpu_s / elapsed, 2),
+                                   "max_abs_dZ_device_vs_cpu_after_the_run": float(np.max(np.abs(z_dev - z_cpu))),
+                                   "note": "the two sides sweep BP in different orders to the same tolerance (1e-8): <Z> agrees to that order, not to rounding"}
+        except Exception as e:      # the baseline must never take the measured number down with it
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(out))
+
+
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix (= vector) peak
 PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0
@@ -130,15 +214,17 @@ PEAK_HBM_GBS = 8000.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 3; --config c1: 50, the layers of configs[0])")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2",
+    ap.add_argument("--config", choices=["c1", "c2", "c4", "c5"], default="c2",
                     help="BASELINE.json configuration: c2 = configs[1] (L x L TFIM, chi 32; the headline metric), c4 = configs[3] (L^3 periodic cubic 3-D Ising "
-                         "layer, chi 16; full size L = 10 needs 8 GPUs), c5 = configs[4] (L x L TFIM, chi 64; full size L = 32 needs 8 GPUs)")
+                         "layer, chi 16; full size L = 10 needs 8 GPUs), c5 = configs[4] (L x L TFIM, chi 64; full size L = 32 needs 8 GPUs), c1 = configs[0] (5 x 5 TFIM, "
+                         "chi 10, ComplexF64, 50 layers from the product state: the reference's own CPU-runnable case, timed on the device AND on the host's CPU oracle)")
     ap.add_argument("--L", type=int, default=0, help="lattice side (default: the BASELINE size of the configuration: 20 / 10 / 32)")
     ap.add_argument("--chi", type=int, default=0, help="bond dimension (default: 32 / 16 / 64)")
     ap.add_argument("--host-init", action="store_true", help="c4 / c5: generate the synthetic state with numpy on the host instead of on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-order", action="store_true", help="skip the third leg: the same command with --bp-order reference (the reference's own default sweep order, what a Julia caller of the shim gets) in a child process")
     ap.add_argument("--no-ab", action="store_true", help="skip the second, untimed-by-the-driver leg: the same command with TNQS_NO_BF16X3=1 (the f32 matrix instructions) in a child process")
     ap.add_argument("--bp-order", choices=["library", "reference"], default="library",
                     help="sweep order of the BP updates: the library default (linear forests, the order the plane kernels share products on) or the reference's "
@@ -148,6 +234,8 @@ def main():
                     help="also time the same lattice on a PHYSICALLY evolved state: N layers of the TFIM circuit at dt = 0.1 from the product state "
                          "(bonds saturate at chi), then --steps timed layers of that circuit; reported as the extra object \"evolved\"")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 50 if args.config == "c1" else 3
 
     import torch
     import torch.distributed as dist
@@ -168,6 +256,10 @@ def main():
         dist.init_process_group(os.environ.get("TNQS_BENCH_BACKEND", "nccl"))
     import tnqs_amd as tn
 
+    if args.config == "c1":
+        if world > 1:
+            raise SystemExit("bench.py: --config c1 is a 3 MB problem: one GPU")
+        return main_c1(args, tn, torch)
     cfg = args.config
     L = args.L or {"c2": 20, "c4": 10, "c5": 32}[cfg]
     chi = args.chi or {"c2": 32, "c4": 16, "c5": 64}[cfg]
@@ -414,6 +506,22 @@ def main():
                                                  "this_run_kernel_classes_ms": {k: v["ms"] for k, v in classes.items() if k in ("bp_pair", "bp_pairgram", "gate_modeprod")}}
         except Exception as e:
             out["ab_f32_matrix_instructions"] = {"value": None, "error": repr(e)}
+    if rank == 0 and world == 1 and cfg == "c2" and args.bp_order == "library" and not args.no_ref_order and not args.no_cpu_baseline:
+        # the reference's own default sweep order (beliefpropagationcache.jl:28,41 forest_cover_edge_sequence; what the Julia shim passes by default) in the same run
+        # on the same box, not part of `value` (round-5 verdict: the headline times the library's order; at the default tolerance both stop after one sweep per update
+        # on different trajectories of the same fixed-point iteration)
+        try:
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--L", str(L), "--chi", str(chi), "--bp-order", "reference",
+                   "--no-cpu-baseline", "--no-ab", "--no-ref-order"]
+            r = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=600)
+            d3 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out["reference_order"] = {"flag": "--bp-order reference (tnqs_bp_opts.n_sequence = -1)", "ms_per_step": d3["ms_per_step"], "value": d3["value"],
+                                      "bp_sweeps_per_step": d3["config"]["bp_sweeps_per_step"], "bp_updates_per_step": d3["config"]["bp_updates_per_step"],
+                                      "phases": {k: d3["phases"][k] for k in ("ms_per_bp_sweep", "ms_per_colour_batch", "bp_ms_per_step", "gate_ms_per_step")},
+                                      "kernel_launch_classes": {k: v["launches"] for k, v in d3["kernel_classes"].items()}}
+        except Exception as e:
+            out["reference_order"] = {"value": None, "error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and cfg == "c2":      # (the CPU leg restates the 2-D chi = 32 path on a bounded sample; the 8-GPU shapes have none)
             try:

@@ -90,6 +90,8 @@ typedef struct {
     int n_bp_products_reused;  /* BP: partial products (site tensor x messages of some legs) taken from an earlier level instead of recomputed */
     int n_bp_products_evicted; /* ... dropped again by the per-site bound (3) or the byte bound (TNQS_BP_CACHE_MB) before anything could reuse them or after */
     int n_lowrank_fallbacks; /* gates that qualified for the low-rank theta SVD but whose Cholesky / CholeskyQR2 of B refused a pivot: they took the SVD of the full theta */
+    int n_spec_batches;     /* (library version 101) gate batches enqueued without their host round trip: every bond already at its cap, outcome verified afterwards */
+    int n_spec_redone;      /* ... steps (gate batches, BP updates) whose deferred verification failed: state put back, step run again the careful way */
 } tnqs_apply_stats;
 
 /* ---- library ---------------------------------------------------------------------------------------- */

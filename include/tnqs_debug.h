@@ -41,7 +41,6 @@ int tnqs_dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void
  * which = 0 pair product on legs (lx, ly), 1 both-messages pair-Gram */
 int tnqs_dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms);
 /* c64 only, d = 2, chi_b = 32: out[s',b',rest] = sum in[s,b,rest] X[(s + 2 b) + 64 (s' + 2 b')]; *norm2 = |out|^2 */
-int tnqs_dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2);
 /* the BP sweep order bp_update uses when no edge_sequence is given, as (src[i] -> dst[i]) vertex indices; *n_out = its length (2 ne) */
 int tnqs_dbg_default_sequence(tnqs_handle h, int* src, int* dst, int cap, int* n_out);
 /* the same order from the graph alone (nv vertices, ne undirected edges esrc[e] - edst[e]) together with the dependency level bp_update runs every message in

@@ -1,0 +1,108 @@
+#!/usr/bin/env python
+"""Socket power and shader clock WHILE the chi = 32 plane kernels run (round-5 verdict item 4: "power-bound" was an inference from GRBM_GUI_ACTIVE / duration;
+no power telemetry had been recorded).
+    python profiles/power_trace.py [nsites] [seconds per kernel]
+A sampler thread reads the amdgpu hwmon files of the device at ~50 Hz (power1_average in microwatts -- what `rocm-smi --showpower` prints --, freq1_input = sclk,
+power1_cap) while the main thread launches one kernel back to back through include/tnqs_debug.h (tnqs_dbg_bench_plane; device-resident random site tensors, leg pair
+(1,2)):   the both-messages pair-Gram and the pair product on the bf16 matrix cores (the default route), the same two on the f32 matrix instructions
+(TNQS_NO_BF16X3=1, in a child process: the switch is read once per process), and an idle stretch.  Prints one JSON line: per kernel the ms per launch and the
+mean / max power, mean clock, the cap."""
+import ctypes as C
+import glob
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+here = os.path.dirname(os.path.abspath(__file__))
+
+
+def hwmon_dir():
+    for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        if os.path.exists(os.path.join(d, "power1_average")) or os.path.exists(os.path.join(d, "power1_input")):
+            return d
+    return None
+
+
+def read_int(path):
+    try:
+        with open(path) as f:
+            return int(f.read().strip())
+    except Exception:
+        return None
+
+
+class Sampler(threading.Thread):
+    def __init__(self, d):
+        super().__init__(daemon=True)
+        self.d, self.stop_flag, self.samples = d, False, []
+        self.pfile = os.path.join(d, "power1_average") if os.path.exists(os.path.join(d, "power1_average")) else os.path.join(d, "power1_input")
+
+    def run(self):
+        while not self.stop_flag:
+            self.samples.append((time.perf_counter(), read_int(self.pfile), read_int(os.path.join(self.d, "freq1_input"))))
+            time.sleep(0.02)
+
+
+def smi_power():
+    """fallback when no hwmon file is readable: one rocm-smi call (slow: ~10 Hz at best)"""
+    try:
+        out = subprocess.run(["rocm-smi", "--showpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+        doc = json.loads(out)
+        for card in doc.values():
+            for k, v in card.items():
+                if "ower" in k:
+                    return float(v)
+    except Exception:
+        pass
+    return None
+
+
+def run_kernels(nsites, seconds):
+    lib = C.CDLL(os.path.join(here, "..", "tensornetworkquantumsimulator.jl_amd", "libtnqs_hip.so"))
+    lib.tnqs_dbg_bench_plane.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    d = hwmon_dir()
+    res = {"hwmon": d, "power_cap_W": (read_int(os.path.join(d, "power1_cap")) or 0) / 1e6 if d else None, "route": "f32" if os.environ.get("TNQS_NO_BF16X3") == "1" else "bf16x3"}
+    for which, name in ((1, "pair_gram2"), (0, "pair")):
+        ms = C.c_double(0)
+        lib.tnqs_dbg_bench_plane(which, nsites, 1, 2, 3, C.byref(ms))          # warm-up, one launch time
+        reps = max(5, int(seconds * 1e3 / max(ms.value, 1e-3)))
+        sm = Sampler(d) if d else None
+        if sm:
+            sm.start()
+        t0 = time.perf_counter()
+        rc = lib.tnqs_dbg_bench_plane(which, nsites, 1, 2, reps, C.byref(ms))
+        t1 = time.perf_counter()
+        if sm:
+            sm.stop_flag = True; sm.join()
+        entry = {"rc": rc, "ms_per_launch": round(ms.value, 4), "launches": reps, "seconds": round(t1 - t0, 2)}
+        if sm:
+            mid = [(p, f) for (t, p, f) in sm.samples if p is not None and t0 + 0.3 * (t1 - t0) <= t <= t1 - 0.05 * (t1 - t0)]      # (skip the ramp: the first 30 %)
+            if mid:
+                pw = [p / 1e6 for p, _ in mid]; fq = [f / 1e6 for _, f in mid if f]
+                entry.update({"samples": len(mid), "power_W_mean": round(sum(pw) / len(pw), 1), "power_W_max": round(max(pw), 1),
+                              "sclk_MHz_mean": round(sum(fq) / len(fq), 0) if fq else None, "sclk_MHz_min": round(min(fq), 0) if fq else None})
+        else:
+            entry["power_W_rocm_smi_after"] = smi_power()
+        res[name] = entry
+    if d:
+        sm = Sampler(d); sm.start(); time.sleep(1.5); sm.stop_flag = True; sm.join()
+        pw = [p / 1e6 for (_, p, _f) in sm.samples if p is not None]
+        res["idle"] = {"power_W_mean": round(sum(pw) / len(pw), 1) if pw else None}
+    return res
+
+
+if __name__ == "__main__":
+    nsites = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
+    if os.environ.get("TNQS_POWER_CHILD") == "1":
+        print(json.dumps(run_kernels(nsites, seconds)))
+        sys.exit(0)
+    out = {"nsites": nsites, "seconds_per_kernel": seconds, "runs": []}
+    for env in ({}, {"TNQS_NO_BF16X3": "1"}):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), str(nsites), str(seconds)], env=dict(os.environ, TNQS_POWER_CHILD="1", **env), capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        out["runs"].append(json.loads(line[-1]) if line else {"error": r.stderr[-500:]})
+    print(json.dumps(out))

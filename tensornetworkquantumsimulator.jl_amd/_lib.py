@@ -57,7 +57,7 @@ class ApplyOpts(C.Structure):
 class ApplyStats(C.Structure):
     _fields_ = [("n_bp_updates", C.c_int), ("n_bp_sweeps", C.c_int), ("n_batches", C.c_int), ("n_two_site", C.c_int),
                 ("bp_not_converged", C.c_int), ("last_bp_diff", C.c_double),
-                ("n_chol_fallbacks", C.c_int), ("n_qr2_sites", C.c_int), ("n_lowrank_svd", C.c_int), ("n_tall_svd", C.c_int), ("n_svd_sweeps", C.c_int), ("n_svd_sweeps_max", C.c_int), ("n_deferred_1site", C.c_int), ("n_bp_products_reused", C.c_int), ("n_bp_products_evicted", C.c_int), ("n_lowrank_fallbacks", C.c_int)]
+                ("n_chol_fallbacks", C.c_int), ("n_qr2_sites", C.c_int), ("n_lowrank_svd", C.c_int), ("n_tall_svd", C.c_int), ("n_svd_sweeps", C.c_int), ("n_svd_sweeps_max", C.c_int), ("n_deferred_1site", C.c_int), ("n_bp_products_reused", C.c_int), ("n_bp_products_evicted", C.c_int), ("n_lowrank_fallbacks", C.c_int), ("n_spec_batches", C.c_int), ("n_spec_redone", C.c_int)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)

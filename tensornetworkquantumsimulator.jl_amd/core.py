@@ -424,7 +424,7 @@ def apply_gates(circuit: Sequence, psi, apply_kwargs: Optional[dict] = None, bp_
                       f"(final average message change: {st.last_bp_diff}).")
     if info is not None:
         info.update(n_chol_fallbacks=st.n_chol_fallbacks, n_qr2_sites=st.n_qr2_sites, n_lowrank_svd=st.n_lowrank_svd, n_tall_svd=st.n_tall_svd, n_deferred_1site=st.n_deferred_1site, n_lowrank_fallbacks=st.n_lowrank_fallbacks, n_bp_products_reused=st.n_bp_products_reused, n_bp_products_evicted=st.n_bp_products_evicted, n_svd_sweeps=st.n_svd_sweeps, n_svd_sweeps_max=st.n_svd_sweeps_max, n_updates=st.n_bp_updates, n_sweeps=st.n_bp_sweeps, n_batches=st.n_batches,
-                    n_two_site=st.n_two_site, bp_not_converged=st.bp_not_converged)
+                    n_two_site=st.n_two_site, bp_not_converged=st.bp_not_converged, n_spec_batches=st.n_spec_batches, n_spec_redone=st.n_spec_redone)
     return out, errs[:ng]
 
 

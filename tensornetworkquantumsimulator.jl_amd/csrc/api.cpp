@@ -21,7 +21,7 @@ static State* S(tnqs_handle h) { if (!h || !h->s) throw Err(TNQS_ERR_INVALID, "n
 
 extern "C" {
 
-int tnqs_version(void) { return 100; }
+int tnqs_version(void) { return 101; }
 const char* tnqs_last_error(void) { return g_err.c_str(); }
 int tnqs_device_count(int* count) {
     return guard([&] { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) n = 0; if (count) *count = n; });
@@ -192,7 +192,6 @@ namespace tnqs { void dbg_default_sequence(const State* s, std::vector<int>& src
                  void dbg_theta_svd_pre(int m, int n, int nq, void* A, const void* Q, void* V, int* sweeps, int copies, int reps, double* ms, double* phase_us, int cap);
                  void dbg_time_jacobi_f32(int m, int n, const void* A, int copies, int reps, double* ms, int* sweeps);
                  void dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in, const void* Mx, const void* My, void* out);
-                 void dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2);
                  void dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* Mx, const void* My, void* out_y, void* out_x);
                  void dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms);
                  void dbg_pair_gram(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* M, void* out);
@@ -217,7 +216,6 @@ int tnqs_dbg_fiber_gemm(int dtype, int D, int PA, int K, int PB, int Do, int No,
 }
 int tnqs_dbg_pair(int C0, int NMID, int NHI, const void* in, const void* Mx, const void* My, void* out) { return guard([&] { dbg_pair(C0, NMID, NHI, in, Mx, My, out); }); }
 int tnqs_dbg_pair_legs(int d, int z, const int* chi, int lx, int ly, const void* in, const void* Mx, const void* My, void* out) { return guard([&] { dbg_pair_legs(d, z, chi, lx, ly, in, Mx, My, out); }); }
-int tnqs_dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2) { return guard([&] { dbg_apply64(z, chi, b, in, X, out, norm2); }); }
 int tnqs_dbg_pair_gram2(int d, int z, const int* chi, int lx, int ly, const void* X, const void* Y, const void* Mx, const void* My, void* out_y, void* out_x) {
     return guard([&] { dbg_pair_gram2(d, z, chi, lx, ly, X, Y, Mx, My, out_y, out_x); });
 }

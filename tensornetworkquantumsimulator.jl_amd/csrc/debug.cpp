@@ -416,28 +416,6 @@ void dbg_bench_plane(int which, int nsites, int lx, int ly, int reps, double* ms
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *ms = (double)t / reps;
 }
-void dbg_apply64(int z, const int* chi, int b, const void* in, const void* X, void* out, double* norm2) {
-    need_gpu();
-    Apply64Item it{};
-    if (!apply64_geometry(2, z, chi, b, it.g)) throw Err(TNQS_ERR_UNSUPPORTED, "dbg_apply64: shape not covered");
-    size_t n = 2; for (int i = 0; i < z; ++i) n *= chi[i];
-    int nslices = it.g.n0 * it.g.n1 * it.g.n2;
-    it.spw = 3; it.wg_begin = 0;
-    int nwg = (nslices + it.spw - 1) / it.spw;
-    DBuf dIn(n * 8), dOut(n * 8), dX(64 * 64 * 8), dXb(2048 * 16), dI(sizeof(Apply64Item)), dXi(sizeof(XbItem)), dN(nwg * 8);
-    dIn.up(in, n * 8); dX.up(X, 64 * 64 * 8);
-    HIPCHK(hipMemset(dOut.p, 0xff, n * 8));
-    XbItem xi{dX.p, dXb.p}; dXi.up(&xi, sizeof(xi));
-    launch_make_xb(nullptr, (const XbItem*)dXi.p, 1);
-    it.in = dIn.p; it.out = dOut.p; it.Xb = dXb.p; it.norm_partial = (double*)dN.p;
-    dI.up(&it, sizeof(it));
-    launch_mfma_apply64(nullptr, (const Apply64Item*)dI.p, 1, nwg);
-    HIPCHK(hipDeviceSynchronize());
-    dOut.down(out, n * 8);
-    std::vector<double> hn(nwg); dN.down(hn.data(), nwg * 8);
-    double t = 0; for (double v : hn) t += v;
-    if (norm2) *norm2 = t;
-}
 void dbg_gram_fused(int PA, int K, int PB, const void* X, const void* Y, const void* M, void* out) {
     need_gpu();
     size_t nin = (size_t)PA * K * PB;

@@ -9,6 +9,8 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <cstdint>
+#include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -68,6 +70,7 @@ struct Graph {
     mutable std::vector<int> default_set_starts;  // positions of default_seq where a set that may close cycles begins (empty: linear forests): a set's levels follow the previous set's
     mutable std::shared_ptr<const void> default_plan;   // its level schedule (engine.cpp BPPlan), built on first use
     mutable std::shared_ptr<const void> forest_plan;    // level schedule of the forest-cover order (n_sequence = -1), built on first use
+    mutable int spec_penalty = 0;                       // apply_gates: steps to run one step deep after a failed deferred verification (engine_gates.cpp); shared by the copies of a handle
     int edge(int u, int v) const;                 // -1 if absent
     int leg(int v, int w) const;                  // position of neighbour w in nbr[v], -1 if absent
     int dedge(int src, int dst) const;            // directed edge id 2*e + (src == edst[e]), -1 if absent
@@ -94,7 +97,31 @@ struct RcclComm {
 
 struct HostArena {   // pinned staging for descriptor uploads, reset at host sync points
     char* base = nullptr; size_t cap = 0, off = 0;
+    // pinned ring behind the arena proper: the staged read-backs of pending checks (State::checks) -- they outlive the arena's own resets
+    char* ring = nullptr; size_t ring_cap = 0, ring_off = 0;
+    hipEvent_t cev[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; unsigned cevn = 0;
 };
+
+// ---- deferred verification (round 6) ---------------------------------------------------------------------------------------------------
+// apply_gates runs ahead of the device: a gate batch whose outcome is predictable (every bond already at its cap: the new bond dimension is the cap, no
+// factorisation falls back) and a BP update that is expected to converge in its first sweep are ENQUEUED on those assumptions -- no host round trip in the
+// dependent launch chains -- and leave a Check behind: the staged copy of what decides the assumption, an event behind that copy, and the decision.  Site tensors
+// and messages are never mutated in place, so the state before any step is a vector of references (Snapshot); a check that fails (rare: a cutoff that bites at a
+// saturated bond, a collapsed pivot, a sweep that misses the tolerance) puts the snapshot back, drains the stream and runs the step again the careful way.
+// Checks are settled in order; every host synchronisation point of the path settles what is pending, and apply_gates settles everything before it returns.
+struct State;
+struct Snapshot {
+    std::vector<int> chi; std::vector<Buf> site, sscale, msg; std::vector<std::vector<double>> pend1; std::vector<char> unit_norm;
+    tnqs_apply_stats stats{}; bool real_io = false;
+};
+struct Check {
+    int kind = 0;                          // 0: gate batch enqueued on assumptions; 1: BP update whose verdict is pending
+    int step = 0;                          // step of the apply_gates schedule it belongs to
+    int iters_done = 0;                    // BP: sweeps enqueued so far
+    hipEvent_t ev = nullptr;               // recorded behind the staged copy (HostArena::cev, not owned)
+    std::function<bool(State*)> eval;      // true: the assumption held (results and statistics booked); false: roll back
+};
+struct SpecFailed { int kind, step, iters_done; };       // thrown by settle() for the first check that does not hold
 
 struct State {
     std::shared_ptr<Graph> g;
@@ -137,16 +164,17 @@ struct State {
     size_t keep_mark = 0;          // keepalive[0, keep_mark) belongs to phases that have ended: released at the next stream synchronisation (soft_sync)
     HostArena arena;               // this handle's pinned staging arena (taken from / returned to a small free list, engine_core.cpp)
     tnqs_apply_stats stats{};
-    // A BP update inside apply_gates whose convergence verdict has not been read yet (engine_bp.cpp, "optimistic" mode): the first sweep is enqueued
-    // together with the copy of its summed message change into `host` (a pinned slot behind the staging arena), the messages are committed, and the
-    // host goes on PREPARING the next gate batch while the sweep runs; resolve_bp() -- called before that batch enqueues anything -- waits and decides.
-    struct BpPending { bool active = false; const double* host = nullptr; double tol = 0; size_t nseq = 0; int iters_done = 0, maxiter = 0; hipEvent_t ev = nullptr; } bp_pending;
-    hipEvent_t ev_bp = nullptr;        // recorded behind the copy of the verdict: resolve_bp waits for THIS, not for what was enqueued after it
+    std::deque<Check> checks;          // pending, oldest first (see Check above)
+    int cur_step = -1;                 // apply_gates: the schedule step being executed (labels the checks it leaves behind)
 
     size_t esz() const { return dtype == TNQS_C64 ? 8 : 16; }
     int scalartype() const { return real_io ? (dtype == TNQS_C64 ? TNQS_F32 : TNQS_F64) : dtype; }
     size_t io_esz() const { return real_io ? esz() / 2 : esz(); }
     bool owns(int v) const { return nranks == 1 || owner[v] == rank; }
+    // the sharded code path: more than one rank -- or ONE rank made to take it (TNQS_FORCE_EXCHANGE=1 when tnqs_set_sharding_rccl is called): every exchange point packs
+    // its block, runs the communicator's all-gather on the handle's stream and reads the gathered block back, which is all a single GPU can exercise of the RCCL transport
+    bool force_exchange = false;
+    bool sharded() const { return nranks > 1 || force_exchange; }
     ~State();
 };
 

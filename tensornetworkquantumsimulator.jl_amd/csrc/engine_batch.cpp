@@ -125,7 +125,7 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
             if (!dst) dst = dalloc(s, c.sd.n * esz);
             it.in = c.result; it.out = dst->p; it.X = c.steps[o].second;
             it.D = 1; it.PA = (int)c.sd.pre(j); it.K = c.sd.chi[j]; it.PB = (int)c.sd.post(j); it.Do = 1; it.No = it.K;
-            if (std::is_same<T, float>::value && use_mfma() && use_rowgemm() && rowgemm_covers(it) && (it.K == 64 || use_rowgemm32())) {
+            if (std::is_same<T, float>::value && use_mfma() && rowgemm_covers(it) && (it.K != 64 || use_chi64())) {
                 rowgemm_tiles(it); it.want_norm = 0;
                 (it.K == 64 ? rg_items : rg32_items).push_back(it); (it.K == 64 ? rg_tiles : rg32_tiles) += (double)it.nta * it.ntb;
                 c.result = dst->p; nt[ci]++;
@@ -152,8 +152,7 @@ template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls
         }
         if (items.empty()) continue;
         // ComplexF64: the f64 matrix cores (kernels_f64.hip) when every product of the pass is one the kernel takes
-        static const bool f64_mfma_off = envflag("TNQS_NO_F64_MFMA");
-        bool f64mf = std::is_same<T, double>::value && use_mfma() && !f64_mfma_off;
+        bool f64mf = std::is_same<T, double>::value && use_mfma();
         for (auto& it : items) f64mf = f64mf && fiber_gemm_f64_covers(it);
         if (f64mf) {
             double tot = 0; for (auto& it : items) { fiber_gemm_f64_tiles(it); tot += (double)it.nta * it.ntb; }
@@ -191,7 +190,7 @@ template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, 
         // fit; the item stays in the lists below as well, whose kernels skip it in that case
         if (j.pre) pre.push_back(j);
         if (!force_global && jacobi_lds_bytes(j.m, j.n, with_v, esz) <= cap && std::max(j.m, j.n) <= 256) fit.push_back(j);
-        else if (!force_global && std::is_same<T, float>::value && !with_v && !j.V && use_mfma() && use_tall_svd() && j.m >= j.n && j.n <= 128 && j.n >= 2 &&
+        else if (!force_global && std::is_same<T, float>::value && !with_v && !j.V && use_mfma() && use_chi64() && j.m >= j.n && j.n <= 128 && j.n >= 2 &&
                  jacobi_lds_bytes(j.n, j.n, false, esz) <= cap) tall.push_back(j);
         else rest.push_back(j);
     }
@@ -268,16 +267,15 @@ template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& job
     // absorbs the last gauge leg (mfma_gauge_gram64_kernel) -- a batch is one or the other
     const bool gauge_fused = jobs[0].M != nullptr && std::is_same<T, float>::value && std::is_same<Acc, double>::value;
     const bool fused = jobs[0].M != nullptr && !gauge_fused;
-    const bool mf = fused || (std::is_same<T, float>::value && std::is_same<Acc, float>::value && use_mfma() && KKmax <= (use_gram64() ? 64 : 32) && KKmax >= 8);
+    const bool mf = fused || (std::is_same<T, float>::value && std::is_same<Acc, float>::value && use_mfma() && KKmax <= (use_chi64() ? 64 : 32) && KKmax >= 8);
     bool mf64 = std::is_same<T, float>::value && std::is_same<Acc, double>::value && use_mfma() && KKmax <= 64 && KKmax >= 16;
-    bool mf128 = std::is_same<T, float>::value && std::is_same<Acc, double>::value && use_mfma() && use_gram128() && KKmax <= 128 && KKmax > 64;
+    bool mf128 = std::is_same<T, float>::value && std::is_same<Acc, double>::value && use_mfma() && use_chi64() && KKmax <= 128 && KKmax > 64;
     for (auto& j : jobs) { mf64 = mf64 && (j.X == j.Y); mf128 = mf128 && (j.X == j.Y); }
     if (gauge_fused) { mf64 = true; mf128 = false; }
     const bool gauge16 = gauge_fused && KKmax == 32;      // 16-dimensional legs: the wave-private kernel (units of one fiber of r, one partial per chunk)
     if (mf || mf64 || mf128) TR = 64;
     // ComplexF64 operands: tiles of 32 fibers through LDS, f64 matrix cores (kernels_f64.hip)
-    static const bool f64_mfma_off = envflag("TNQS_NO_F64_MFMA");
-    bool mf64in = std::is_same<T, double>::value && use_mfma() && !f64_mfma_off && jobs[0].M == nullptr;
+    bool mf64in = std::is_same<T, double>::value && use_mfma() && jobs[0].M == nullptr;
     for (auto& j : jobs) mf64in = mf64in && j.M == nullptr && gram_f64in_covers(j.keep_site ? j.sd.d : 1, j.leg >= 0 ? j.sd.chi[j.leg] : 1);
     if (mf64in) TR = 32;
     // workgroups per launch.  The f64 Grams of the gate path write one 64 KiB partial per (site, chunk, tile parity) which reduce_kernel reads back: 2048 chunks were

@@ -8,7 +8,6 @@ namespace tnqs {
 // kept leg <= 32, tiles of 64 fibers = (s, i_r) aligned)
 static int fused_leg(const State* s, const SD& sd, int jo) {
     if (s->dtype != TNQS_C64 || !use_mfma() || sd.d != 2 || sd.z < 2) return -1;
-    const char* e = std::getenv("TNQS_NO_FUSED_GRAM"); if (e && e[0] == '1') return -1;
     int r = (jo == 0) ? 1 : 0;
     if (sd.chi[r] != 32 || sd.chi[jo] > 32 || sd.chi[jo] < 8) return -1;
     return r;
@@ -204,7 +203,7 @@ static std::vector<int> default_sequence(const Graph& g, std::vector<int>& set_s
     // lattices -- sets that may close cycles (two levels per set, see path_cycle_sequence).  A pass is what a sweep costs on big tensors; the levels are
     // what it costs on small ones, and there the forests have fewer
     std::vector<int> best_seq; long best_passes = -1;
-    static const int nvariants = envflag("TNQS_NO_CYCLE_SETS") ? 1 : 2;
+    const int nvariants = 2;
     for (int with_cycles = 0; with_cycles < nvariants; ++with_cycles) {
         std::vector<int> part; int np = 0;
         degree2_sets(g, with_cycles != 0, part, np);
@@ -342,26 +341,9 @@ struct ProdCache {
     }
 };
 
-bool resolve_bp(State* s) {
-    State::BpPending& p = s->bp_pending;
-    if (!p.active) return true;
-    // the event behind the verdict's copy, not the stream: the caller may already have enqueued work behind it (the next batch's environment chain runs
-    // while the host reads the verdict and enqueues the tensor passes); and NOT drained(): the caller has staged descriptors in the arena
-    HIPCHK(hipEventSynchronize(p.ev));
-    const double avg = *p.host / (double)p.nseq;
-    s->stats.last_bp_diff = avg;
-    if (avg <= p.tol) { p.active = false; return true; }
-    if (p.iters_done >= p.maxiter) { p.active = false; s->stats.bp_not_converged += 1; return true; }      // the reference stops here too (and warns)
-    return false;
-}
-
 template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out, bool optimistic, int iters_before) {
     const Graph& g = *s->g;
     HIPCHK(hipSetDevice(s->device));
-    if (s->bp_pending.active && !resolve_bp(s)) {      // an optimistic update nobody has consumed yet: finish it first
-        const int done = s->bp_pending.iters_done; s->bp_pending.active = false;
-        bp_update_t<T>(s, o, nullptr, nullptr, false, done);
-    }
     // the level schedule depends on the graph and the sequence only: the one of the default sequence is kept with the graph
     std::shared_ptr<const BPPlan> plan_p;
     if (o && o->n_sequence > 0) plan_p = std::make_shared<const BPPlan>(make_plan(s, o));
@@ -390,7 +372,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
     // shared pair products (see SharedT): partner[v][j] = the leg paired with j, -1 when the site is not covered
     std::vector<std::array<int, 4>> partner(g.nv, std::array<int, 4>{{-1, -1, -1, -1}});
     std::vector<std::array<SharedT, 2>> tshare;
-    if (std::is_same<T, float>::value && use_mfma() && use_pair() && use_tshare()) {
+    if (std::is_same<T, float>::value && use_mfma() && use_pair()) {
         tshare.resize(g.nv);
         for (int v = 0; v < g.nv; ++v) {
             if (!s->owns(v) || g.nbr[v].size() != 4 || s->d[v] != 2) continue;
@@ -412,7 +394,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) pcache.cap = std::min(pcache.cap, (fr + s->pool->bytes_cached()) / 3);
     }
-    const bool cache_on = use_prodcache() && use_prefix() && !plan.in_place;
+    const bool cache_on = use_prodcache() && !plan.in_place;
     const int nlev = (int)plan.levels.size();
     // levels until the message entering src through leg j changes again, seen from position t of the sequence (INT_MAX: never)
     auto horizon = [&](int src, int j, int t) -> int {
@@ -461,9 +443,9 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
             if (k >= np - 2 && c.tmp[k & 1]) pcache.put(c.v, site, acc, c.tmp[k & 1]);
         }
     };
-    static const bool optimistic_on = !envflag("TNQS_NO_OPTIMISTIC_BP");
+    static const bool optimistic_on = !envflag("TNQS_NO_SPECULATION");
     // (sharded handles too, round 5: messages are replicated and every rank normalises / diffs all of them, so the verdict is the same on every rank)
-    const bool go_optimistic = optimistic && optimistic_on && compute_error && iters_before == 0 && s->arena.base;
+    const bool go_optimistic = optimistic && optimistic_on && compute_error && iters_before == 0;
     for (int iter = 1 + iters_before; iter <= maxiter; ++iter) {
         phase_scope.count += 1;
         std::vector<Buf> fresh(2 * (size_t)g.ne);
@@ -510,7 +492,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     int din = g.dedge(g.nbr[src][j], src); int pp = plan.pos_of[din];
                     return (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
                 };
-                if (use_prefix() && !plan.in_place) {
+                if (!plan.in_place) {
                     std::unordered_map<int, std::vector<int>> outl;            // source site -> legs going out in this sub-batch
                     auto generic_site = [&](int src, int jo) { return (tshare.empty() || site_dims(s, src).z != 4 || partner[src][jo] < 0) && !small_site(src); };
                     for (size_t q = start; q < end; ++q) {
@@ -572,8 +554,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                             const Buf& mb = (plan.in_place || (pp >= 0 && pp < t)) ? (fresh[din] ? fresh[din] : cur[din]) : cur[din];
                             if (mb) si.M[j] = mb->p;                 // unset message = identity: nothing to absorb
                         }
-                        static const bool small_mfma_on = !envflag("TNQS_NO_SMALL_SITE_MFMA");
-                        si.mfma = small_mfma_on && (c.sd.n % 256) == 0;
+                        si.mfma = (c.sd.n % 256) == 0;
                         for (int j = 0; j < c.sd.z; ++j) if (c.sd.chi[j] != 16) si.mfma = 0;
                         small_items.push_back(si); small_chain.push_back((int)chains.size()); small_max = std::max(small_max, (int)c.sd.n);
                         is_shared_chain.push_back((int)chains.size());
@@ -601,7 +582,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                             }
                             gi.X = sh.T->p; gi.Y = c.src; gi.M = mr->p;
                             const long long key = ((long long)src << 1) | (std::min(pa, pb) < std::min(r, jo) ? 0 : 1);
-                            auto pit = use_dbl() ? pend.find(key) : pend.end();
+                            auto pit = pend.find(key);
                             if (pit != pend.end() && pit->second.jo == r && pit->second.r == jo && sh_gram[pit->second.idx].X == gi.X) {
                                 // the partner message of the same forest is in this level too: one pass computes both
                                 PairGramItem& first = sh_gram[pit->second.idx];       // plane (lx = r_first = jo, ly = jo_first = r)
@@ -612,7 +593,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                                 sh_gram_slices -= (double)c.sd.n / 16384.0;
                                 pend.erase(pit);
                             } else {
-                                if (use_dbl()) pend[key] = Pend{(int)sh_gram.size(), jo, r};
+                                pend[key] = Pend{(int)sh_gram.size(), jo, r};
                                 sh_gram.push_back(gi); sh_gram_slices += (double)c.sd.n / 16384.0;
                                 sh_chain.push_back((int)chains.size());
                             }
@@ -660,7 +641,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 // ---- 16-dimensional planes: the two messages a site sends in this level, both continuing from the same shared product and
                 // each absorbing exactly the other's outgoing leg, come from ONE pass over (T, psi) (mfma_pair_gram2x16_kernel) ------------
                 std::vector<PairGram2x16Item> g16; std::vector<std::pair<int, int>> g16_chain;       // (chain of the message through ly, through lx)
-                if (std::is_same<T, float>::value && use_mfma() && use_pair() && use_dbl()) {
+                if (std::is_same<T, float>::value && use_mfma() && use_pair()) {
                     std::unordered_map<int, std::vector<int>> by_src;
                     for (size_t ci = 0; ci < chains.size(); ++ci)
                         if (chains[ci].y && chains[ci].steps.size() == 1 && !fmsg[ci] && chains[ci].sd.n >= (size_t)(1u << 14)) by_src[chains[ci].v].push_back((int)ci);
@@ -682,7 +663,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 // a site that sends ONE message in this level (no shared product): its last absorption is fused with the Gram too -- the chain
                 // stops one leg early and the same kernel computes (T x_lx M) conj(psi) for that single message (My = null)
                 std::vector<int> g16_single;                          // index into g16 of the single items (their chain runs first, X is set after it)
-                if (std::is_same<T, float>::value && use_mfma() && use_pair() && use_dbl()) {
+                if (std::is_same<T, float>::value && use_mfma() && use_pair()) {
                     for (size_t ci = 0; ci < chains.size(); ++ci) {
                         Chain& c = chains[ci];
                         if ((c.y && (!cbase.count(ci) || cbase[ci].empty())) || fmsg[ci] || c.steps.empty() || (c.steps.size() & 1) == 0 || c.sd.n < (size_t)(1u << 14)) continue;
@@ -706,13 +687,12 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 HostTimer ht_launch(1);
                 // Two independent launch chains make up a level: the bulk sites' plane kernels (pair product -> both-messages pair-Gram) and the other
                 // sites' single-leg products -> Grams (boundary sites of a lattice: 24 of the 49 sites of a 7 x 7 one, small launches of 10-50 us each).
-                // They meet in msg_finalize.  The second chain goes to the side stream, under the plane kernels (single rank, unforked; the chi = 16
+                // They meet in msg_finalize.  The second chain goes to the side stream, under the plane kernels (the chi = 16
                 // pair-Gram items that continue from a chain's result keep everything on one stream); nothing released inside the region is handed out
                 // again before the join (Pool::set_defer).
-                static const bool bp_split_on = !envflag("TNQS_NO_BP_SPLIT");
                 hipStream_t const main_stream = s->stream;
                 bool has_other = !small_items.empty(); for (size_t ci = 0; ci < chains.size(); ++ci) has_other = has_other || !is_shared[ci];
-                const bool split_level = (!sh_pair.empty() || !sh_dbl.empty()) && has_other && g16.empty() && bp_split_on;
+                const bool split_level = (!sh_pair.empty() || !sh_dbl.empty()) && has_other && g16.empty();
                 hipStream_t side_stream = nullptr;
                 if (split_level) {
                     side_stream = aux_stream_of(s);
@@ -751,8 +731,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     }
                     // matrix-core form on an unsharded handle: the kernel holds the whole message and finishes it (normalisation, message_diff) -- one launch less on
                     // the critical path of the level
-                    static const bool small_fuse_on = !envflag("TNQS_NO_SMALL_SITE_FINALIZE");
-                    if (small_fuse_on && s->nranks <= 1 && !plan.in_place) {
+                    if (!s->sharded() && !plan.in_place) {
                         size_t nb_bytes = 0;
                         for (size_t q = 0; q < small_items.size(); ++q) if (small_items[q].mfma) nb_bytes += round256((size_t)256 * esz);
                         if (nb_bytes) {
@@ -863,7 +842,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 ht_launch.stop();
                 HostTimer ht_fin(2);
                 std::vector<MsgFinalItem> fin;
-                if (s->nranks <= 1) {
+                if (!s->sharded()) {
                     for (size_t i = 0; i < jobs.size(); ++i) {
                         int t = tpos[i]; int de = plan.seq[t]; int c = s->chi[de / 2];
                         if (jobs[i].final_msg) { fresh[de] = jobs[i].final_msg; continue; }
@@ -925,13 +904,21 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
         if (compute_error) {
             launch_sum_doubles(s->stream, reinterpret_cast<const double*>(d_diffs->p), (int)nseq, reinterpret_cast<double*>(d_sum->p));
             if (go_optimistic) {
-                // the verdict travels to the pinned slot behind the arena; the messages are committed and the caller prepares its next phase meanwhile
-                double* slot = reinterpret_cast<double*>(s->arena.base + s->arena.cap);
+                // the verdict travels to a pinned slot and stays a Check (engine.hpp): the messages are committed and the caller goes on enqueuing meanwhile
+                double* slot = reinterpret_cast<double*>(ring_alloc(s, sizeof(double)));       // (may settle older checks -- and throw -- first: nothing is committed yet)
                 HIPCHK(hipMemcpyAsync(slot, d_sum->p, sizeof(double), hipMemcpyDeviceToHost, s->stream));
-                if (!s->ev_bp) HIPCHK(hipEventCreateWithFlags(&s->ev_bp, hipEventDisableTiming));
-                HIPCHK(hipEventRecord(s->ev_bp, s->stream));
+                Check c; c.kind = 1; c.step = s->cur_step; c.iters_done = iter; c.ev = check_event(s);
+                HIPCHK(hipEventRecord(c.ev, s->stream));
+                const size_t nseq_ = nseq; const int maxiter_ = maxiter;
+                c.eval = [slot, tol, nseq_, iter, maxiter_](State* st) {
+                    const double a = *slot / (double)nseq_;
+                    st->stats.last_bp_diff = a;
+                    if (a <= tol) return true;
+                    if (iter >= maxiter_) { st->stats.bp_not_converged += 1; return true; }      // the reference stops here too (and warns)
+                    return false;
+                };
                 s->keepalive.push_back(d_diffs); s->keepalive.push_back(d_sum);
-                s->bp_pending = State::BpPending{true, slot, tol, nseq, iter, maxiter, s->ev_bp};
+                s->checks.push_back(std::move(c));
                 s->msg = cur; s->stats.n_bp_updates += 1;
                 soft_sync(s);
                 return;
@@ -939,11 +926,13 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
             const double* st_tot = readback<double>(s, d_sum->p, 1);
             sync(s);
             const double tot = *st_tot;                                  // (the arena's memory is untouched until the next upload)
+            settle(s, true);                                             // (the stream is drained: whatever was pending has fired; a failed check unwinds this update, s->msg is untouched)
             avg = tot / (double)nseq;
             if (avg <= tol) { converged = true; niter = iter; break; }
         }
     }
     sync(s);
+    settle(s, true);
     s->msg = cur;
     if (iters_before == 0) s->stats.n_bp_updates += 1;
     if (compute_error && !converged) s->stats.bp_not_converged += 1;

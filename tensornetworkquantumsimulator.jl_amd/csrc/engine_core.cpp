@@ -121,18 +121,24 @@ static std::vector<SpareStream> g_spare_streams;                           // id
 static const size_t kMaxSpares = 16;
 HostArena acquire_arena() {
     HostArena ar{};
-    { std::lock_guard<std::mutex> lk(g_recycle_mu); if (!g_spare_arenas.empty()) { ar = g_spare_arenas.back(); g_spare_arenas.pop_back(); ar.off = 0; } }
+    { std::lock_guard<std::mutex> lk(g_recycle_mu); if (!g_spare_arenas.empty()) { ar = g_spare_arenas.back(); g_spare_arenas.pop_back(); ar.off = 0; ar.ring_off = 0; } }
     if (!ar.base) {
         // TNQS_ARENA_KB: a small arena makes every phase overflow it (tests/test_gpu_toggles.py drives the overflow path that way)
         static const size_t cap = [] { const char* e = std::getenv("TNQS_ARENA_KB"); return e ? std::max<size_t>(16, (size_t)std::atoll(e)) << 10 : size_t(32) << 20; }();
-        HIPCHK(hipHostMalloc((void**)&ar.base, cap, hipHostMallocDefault)); ar.cap = cap - 256;       // (the last 256 bytes: State::bp_pending's slot, never recycled by the arena)
+        const size_t ring = size_t(2) << 20;
+        HIPCHK(hipHostMalloc((void**)&ar.base, cap + ring, hipHostMallocDefault)); ar.cap = cap - 256;
+        ar.ring = ar.base + cap; ar.ring_cap = ring; ar.ring_off = 0;                               // (behind the arena proper: staged read-backs of pending checks)
     }
     return ar;
 }
+static void arena_free(HostArena& ar) {
+    for (hipEvent_t& e : ar.cev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (ar.base) { (void)hipHostFree(ar.base); ar.base = nullptr; }
+}
 void recycle_arena(HostArena ar) {
     if (!ar.base) return;
-    { std::lock_guard<std::mutex> lk(g_recycle_mu); if (g_spare_arenas.size() < kMaxSpares) { ar.off = 0; g_spare_arenas.push_back(ar); ar.base = nullptr; } }
-    if (ar.base) (void)hipHostFree(ar.base);
+    { std::lock_guard<std::mutex> lk(g_recycle_mu); if (g_spare_arenas.size() < kMaxSpares) { ar.off = 0; ar.ring_off = 0; g_spare_arenas.push_back(ar); ar.base = nullptr; } }
+    if (ar.base) arena_free(ar);
 }
 static hipStream_t acquire_stream(int device, int hi = 0) {
     {
@@ -157,9 +163,9 @@ State::~State() {
         if (ar.base && g_spare_arenas.size() < kMaxSpares) { ar.off = 0; g_spare_arenas.push_back(ar); ar.base = nullptr; }
         for (auto& q : st) if (q.st && g_spare_streams.size() < kMaxSpares) { g_spare_streams.push_back(q); q.st = nullptr; }
     }
-    if (ar.base) (void)hipHostFree(ar.base);
+    if (ar.base) arena_free(ar);
     for (auto& q : st) if (q.st) (void)hipStreamDestroy(q.st);
-    for (hipEvent_t e : {ev_fork, ev_join, ev_bp}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev_fork, ev_join}) if (e) (void)hipEventDestroy(e);
 }
 hipStream_t aux_stream_of(State* s) {
     if (!s->aux_stream) {
@@ -229,7 +235,7 @@ State* state_copy(const State* o) {
     s->site = o->site; s->sscale = o->sscale; s->msg = o->msg; s->pool = o->pool; s->prof = o->prof;
     s->pend1 = o->pend1; s->unit_norm = o->unit_norm;
     s->rank = o->rank; s->nranks = o->nranks; s->owner = o->owner; s->ag_fn = o->ag_fn; s->ag_ctx = o->ag_ctx;
-    s->exch = o->exch; s->exch_bytes = o->exch_bytes; s->comm = o->comm;
+    s->exch = o->exch; s->exch_bytes = o->exch_bytes; s->comm = o->comm; s->force_exchange = o->force_exchange;
     HIPCHK(hipSetDevice(o->device));
     if (o->own_stream) { HIPCHK(hipStreamSynchronize(o->stream)); s->stream = acquire_stream(o->device); s->own_stream = true; }
     else { s->stream = o->stream; s->own_stream = false; }

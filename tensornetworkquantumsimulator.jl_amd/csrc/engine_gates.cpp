@@ -70,7 +70,6 @@ template <class T> static void norm_and_replace(State* s, std::vector<int>& vert
         const NormFactorItem* d = upload_small(s, nf);
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_norm_factor(s->stream, d, (int)nf.size()); }
         for (size_t i = 0; i < verts.size(); ++i) { s->site[verts[i]] = outs[i]; s->sscale[verts[i]] = sub_buffer(fac, 256 * i, 8); }
-        if (eager_scale()) materialize_scale_t<T>(s, verts);
     } else {
         for (size_t i = 0; i < verts.size(); ++i) s->site[verts[i]] = outs[i];       // a pending factor of the input carries over (linear map)
     }
@@ -97,13 +96,12 @@ static std::vector<double> matmul_dd(const double* a, const double* b, int d) { 
 
 template <class T> static void apply_one_site_batch(State* s, const std::vector<Gate1>& gates_in, bool normalize, bool force) {
     if (gates_in.empty()) return;
-    if (s->bp_pending.active && !resolve_bp(s)) throw BpNotConverged{};       // (an optimistic BP update: its verdict before anything is applied)
     const size_t esz = s->esz();
     // ---- deferral (State::pend1): a unitary gate on a tensor that needs no normalisation pass is only recorded -- BP does not see it, the
     // next two-site gate on the vertex absorbs it.  Anything else is applied now, composed with what was pending on the vertex.
     std::vector<std::vector<double>> composed; composed.reserve(gates_in.size());
     std::vector<Gate1> gates;
-    const bool may_defer = !force && defer_site1() && (s->nranks == 1 || s->in_apply);      // (sharded handles: only inside apply_gates, State::in_apply)
+    const bool may_defer = !force && defer_site1() && (!s->sharded() || s->in_apply);      // (sharded handles: only inside apply_gates, State::in_apply)
     // unitary to what the state's precision resolves: a gate the caller built in complex64 is unitary to ~1e-7 only, and BP messages of a
     // ComplexF32 state do not see a deviation of that size either
     const double utol = s->dtype == TNQS_C64 ? 1e-6 : 1e-13;
@@ -185,11 +183,22 @@ template <class T> static void apply_one_site_batch(State* s, const std::vector<
     norm_and_replace<T>(s, verts, outs, ne, np, tb, nt, normalize);
 }
 
-template <class T> static void apply_two_site_batch(State* s, const std::vector<Gate2>& gates_in, const tnqs_apply_opts& ao, double* errs) {
+// allow_spec: the batch may be enqueued WITHOUT its host round trip when its outcome is predictable (see `spec` below); it then leaves a Check behind (engine.hpp)
+template <class T> static void apply_two_site_batch(State* s, const std::vector<Gate2>& gates_in, const tnqs_apply_opts& ao, double* errs, bool allow_spec = false) {
     if (gates_in.empty()) return;
     const Graph& g = *s->g;
     const size_t esz = s->esz();
-    const bool sharded = s->nranks > 1;
+    const bool sharded = s->sharded();
+    // ---- run on assumptions?  Every bond of the batch already sits at its cap (a saturated evolution: the new bond dimension is the cap again unless the cutoff
+    // bites), the whole chain can be sized from upper bounds (ComplexF32, every theta within the LDS-resident kernels), single rank.  Then the read-back of the
+    // batch -- ranks, new bond dimensions, statuses, truncation errors, every fallback flag -- is only STAGED, the epilogue is launched for bond dimension = cap,
+    // and the verification happens when the staged copy has arrived (settle).  Anything the assumptions do not cover fails the check and the batch is redone.
+    bool spec = allow_spec && !sharded && ao.maxdim > 0;
+    for (size_t k = 0; k < gates_in.size() && spec; ++k) {
+        const int v1 = gates_in[k].v1, v2 = gates_in[k].v2; const int chi = s->chi[g.edge(v1, v2)];
+        const int Mr = std::max(s->d[v1], s->d[v2]) * std::max(s->d[v1], s->d[v2]) * chi, Nc = std::min(s->d[v1], s->d[v2]) * std::min(s->d[v1], s->d[v2]) * chi;
+        spec = chi == ao.maxdim && Nc >= chi && Mr <= 256 && jacobi_lds(jacobi_lds_bytes(Mr, Nc, false, esz)) > 0;
+    }
     const double sqrt_cutoff = ao.sqrt_cutoff >= 0 ? ao.sqrt_cutoff : 10.0 * (s->dtype == TNQS_C64 ? 1.1920928955078125e-07 : 2.220446049250313e-16);
     const int ng = (int)gates_in.size();
     // pending one-site gates of the gate vertices are absorbed into the gate matrix: g' = g . (G1 (x) G2) is exactly what simple_update sees
@@ -212,7 +221,6 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     }
     PhaseScope phase_scope(s, TNQS_PROF_PHASE_GATE_BATCH);
     HostTimer ht_a(3);                 // TNQS_HOST_TIMING=1: host time of the batch up to the first read-back (3), between the read-backs (4), after them (5)
-    if (!ao.normalize_tensors && s->bp_pending.active && !resolve_bp(s)) throw BpNotConverged{};      // (materialize_scale below launches)
     if (!ao.normalize_tensors) {       // without the final normalisation the result scales with the inputs: apply pending factors first
         std::vector<int> vs; for (auto& g2 : gates) { vs.push_back(g2.v1); vs.push_back(g2.v2); }
         materialize_scale(s, vs);
@@ -284,7 +292,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     // bulk shape (d = 2, chi = 32, three gauged legs): the LAST gauge leg -- the fastest outer leg, which the two-leg kernel leaves over -- is
     // absorbed inside the Gram kernel instead of in a pass of its own (kernels_gate.hip); fused_M[q] = its matrix
     std::vector<const void*> fused_M(own_idx.size(), nullptr);
-    static const bool fuse_on = !envflag("TNQS_NO_GAUGE_GRAM");
+    const bool fuse_on = true;
     for (size_t q = 0; q < own_idx.size(); ++q) {
         const SiteJob& j = sj[own_idx[q]];
         Chain& c = chains[q]; c.v = j.v; c.src = s->site[j.v]->p; c.sd = j.sd;
@@ -300,7 +308,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             fused_M[q] = c.steps[0].second; c.steps.erase(c.steps.begin());
         }
     }
-    if (s->bp_pending.active && !resolve_bp(s)) throw BpNotConverged{};      // (nothing of the state has been touched; the environment kernels' outputs are dropped)
+    if (!spec) settle(s, true);      // the careful route waits for what is pending (the BP update's verdict) in front of its tensor passes: a failure costs the environment chain only
     run_chains<T>(s, chains, TNQS_PROF_GATE_MODEPROD);
     std::vector<Buf> GA(sj.size()), GV(sj.size()), GW(sj.size()); std::vector<char> is_chol(sj.size(), 0), is_small(sj.size(), 0), small_done(sj.size(), 0);
     auto nof = [&](size_t i) { return sj[i].sd.d * sj[i].sd.chi[sj[i].bleg]; };
@@ -420,7 +428,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
             int n = nof(i);
             if (!GV[i]) GV[i] = dalloc(s, (size_t)n * n * 16);
             const size_t Nout = sj[i].sd.n / (size_t)n;
-            const bool ch = allow_chol && n <= (use_chol128() ? 128 : 96) && Nout >= (size_t)n;
+            const bool ch = allow_chol && n <= (use_chi64() ? 128 : 96) && Nout >= (size_t)n;
             is_chol[i] = ch ? 1 : 0;
             if (!ch && sj[i].owned && Nout < (size_t)n && n <= 256 && use_small_svd()) {
                 // fewer fibers than columns: R = Sigma U^dagger straight from the SVD of the n x N matricised psi~ (no rank-deficient G)
@@ -590,13 +598,13 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     auto plan_rowgemm = [&](auto chi_of, auto in_of, std::vector<char>* skip) {
         RgPlan P; P.via.assign(own_idx.size(), 0);
         std::vector<FiberItem> rg; std::vector<int> rverts; std::vector<Buf> routs; std::vector<size_t> rne;
-        if (std::is_same<T, float>::value && use_mfma() && use_rowgemm())
+        if (std::is_same<T, float>::value && use_mfma())
             for (size_t q = 0; q < own_idx.size(); ++q) {
                 if (skip && (*skip)[q]) continue;
                 size_t i = own_idx[q]; int gi = (int)i / 2; int chin = chi_of(gi); const SiteJob& j = sj[i];
                 FiberItem it{};
                 it.D = j.sd.d; it.PA = (int)(j.sd.pre(j.bleg) / j.sd.d); it.K = j.sd.chi[j.bleg]; it.PB = (int)j.sd.post(j.bleg); it.Do = j.sd.d; it.No = chin;
-                if (!rowgemm_covers(it) || it.D != 2 || !(it.K == 64 || use_rowgemm32())) continue;
+                if (!rowgemm_covers(it) || it.D != 2 || (it.K == 64 && !use_chi64())) continue;
                 const size_t nout = j.sd.n / it.K * chin;
                 Buf out = dalloc(s, nout * esz);
                 it.in = in_of(q); it.out = out->p; it.X = (i & 1) ? ws[gi].X2->p : ws[gi].X1->p;
@@ -736,8 +744,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         // ONE host round trip per batch where the whole chain can be sized from upper bounds: ComplexF32 (no second factorisation pass), every
         // theta small enough for the LDS-resident Jacobi at its largest possible size.  The ranks of the R factors stay on the device; the
         // Cholesky failure flags and the message-eigenvalue flags are read together with the results, and a failure (rare) redoes the chain
-        static const bool two_trips = envflag("TNQS_TWO_ROUNDTRIPS");          // A/B: the round-2 flow (ranks read back before the SVD)
-        bool one_trip = !qr2 && !two_trips && npg > 0;
+        bool one_trip = (!qr2 || spec) && npg > 0;      // (ComplexF64 on assumptions: no site flagged for the second factorisation pass -- part of the check)
         for (int q = 0; q < npg && one_trip; ++q) {
             const int gi = pg[q];
             const int Mr = std::max(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2), Nc = std::min(ws[gi].n1 * gitems[q].d1, ws[gi].n2 * gitems[q].d2);
@@ -746,18 +753,56 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         // the four staged read-backs of a batch (flags, Cholesky flags, info, truncation errors) are consumed together after ONE synchronisation:
         // room for all of them is made up front, so that none of them can wrap the arena on top of another (round-3 advisor finding)
         const size_t rb_bytes = rb_total + 1024;
+        char* spec_stage = (spec && one_trip) ? ring_alloc(s, rb_total) : nullptr;      // (may settle -- and throw -- first: nothing of the state has been touched)
+        spec = spec && one_trip && spec_stage;
         if (one_trip) {
             svd_and_finish(nullptr);
             if (!sharded && ao.maxdim > 0) spec_plan = plan_rowgemm([&](int gi) { return ws[gi].cap; }, [&](size_t q) { return (const void*)s->site[sj[own_idx[q]].v]->p; }, nullptr);
-            reserve_readback(s, rb_bytes);
             ht_a.stop(); ht_s4.stop();
+            if (spec) {
+                // no host round trip: the results travel to the check's staging and are verified when they have arrived; the rest of the batch runs on what they are
+                // expected to be -- every factor of full rank, every new bond dimension at its cap, no fallback taken
+                HIPCHK(hipMemcpyAsync(spec_stage, d_rb->p, rb_total, hipMemcpyDeviceToHost, s->stream));
+                Check c; c.kind = 0; c.step = s->cur_step; c.ev = check_event(s);
+                HIPCHK(hipEventRecord(c.ev, s->stream));
+                struct PerGate { int index, cap, d1, d2, K, chi_cap; bool low; };
+                std::vector<PerGate> pgv(npg);
+                for (int q = 0; q < npg; ++q) pgv[q] = PerGate{gates[pg[q]].index, ws[pg[q]].cap, gitems[q].d1, gitems[q].d2, gitems[q].kappa * gitems[q].chi, gitems[q].chi_cap, gitems[q].lowG != nullptr};
+                std::vector<char> chol_site(sj.size(), 0);
+                for (size_t i = 0; i < sj.size(); ++i) chol_site[i] = (part[i / 2] && is_chol[i]) ? 1 : 0;
+                const size_t nenv = envs.size();
+                const char* st = spec_stage;
+                c.eval = [st, rb_info, rb_terr, rb_chol, rb_env, pgv, chol_site, nenv, errs, qr2](State* z) {
+                    const int* hi = reinterpret_cast<const int*>(st + rb_info); const double* ht = reinterpret_cast<const double*>(st + rb_terr);
+                    const int* fl = reinterpret_cast<const int*>(st + rb_env); const int* cf = reinterpret_cast<const int*>(st + rb_chol);
+                    for (size_t q = 0; q < pgv.size(); ++q) if (hi[8 * q + 2] != pgv[q].cap || hi[8 * q + 3] != 0 || (qr2 && hi[8 * q + 6] != 0)) return false;      // a bond below its cap, a failed gate, an ill-conditioned ComplexF64 site (second factorisation pass)
+                    for (size_t i = 0; i < nenv; ++i) if (!fl[2 * i] || fl[2 * i + 1]) return false;                                  // a rank-deficient message (projector pass), or a negative eigenvalue
+                    for (size_t i = 0; i < chol_site.size(); ++i) if (chol_site[i] && cf[i]) return false;                           // a collapsed Cholesky pivot
+                    for (size_t q = 0; q < pgv.size(); ++q) {       // the assumptions held: book what the careful route books after its read-back
+                        int Mr, Nc, ncolJ; theta_dims(hi + 8 * q, pgv[q].d1, pgv[q].d2, Mr, Nc, ncolJ);
+                        z->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0; z->stats.n_svd_sweeps += hi[8 * q + 4]; z->stats.n_svd_sweeps_max = std::max(z->stats.n_svd_sweeps_max, hi[8 * q + 4]);
+                        const int r1d = hi[8 * q] * pgv[q].d1, r2d = hi[8 * q + 1] * pgv[q].d2;
+                        if (pgv[q].low && ncolJ == Nc && r1d >= r2d && pgv[q].K < r2d && pgv[q].chi_cap <= pgv[q].K) z->stats.n_lowrank_fallbacks += 1;
+                        if (errs) errs[pgv[q].index] = ht[q];
+                    }
+                    return true;
+                };
+                s->checks.push_back(std::move(c));
+                for (int q = 0; q < npg; ++q) { for (int k = 0; k < 8; ++k) hinfo[8 * q + k] = 0; hinfo[8 * q + 2] = ws[pg[q]].cap; hterr[q] = 0.0; }
+                for (size_t i = 0; i < envs.size(); ++i) { h_flags[2 * i] = 1; h_flags[2 * i + 1] = 0; }
+                s->stats.n_spec_batches += 1;
+            } else {
+            reserve_readback(s, rb_bytes);
             read_results(); take_flags();
+            settle(s, true);              // (the stream is drained: what was pending has fired; a failed check unwinds this batch before it has replaced anything)
             if (chol_failures()) { redo_with_eigen(); svd_and_finish(hinfo.data()); read_results(); }
+            }
         } else {
             // theta dims depend on the ranks found on the device: read them back (also where message-eigenvalue errors surface)
             reserve_readback(s, rb_bytes);
             ht_a.stop(); ht_s4.stop();
             read_results(); take_flags();
+            settle(s, true);
             if (chol_failures()) redo_with_eigen();
             if (qr2) {
                 // ---- second factorisation pass (CholeskyQR2) of the sites gate_theta flagged as ill-conditioned: a Gram matrix resolves the
@@ -854,6 +899,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         for (size_t i = 0; i < envs.size(); ++i)
             if (h_flags[2 * i + 1]) throw Err(TNQS_ERR_NUMERIC, "simple_update: incoming message has a negative eigenvalue above sqrt_cutoff (DomainError in the reference, src/utils.jl:21)");
         for (int q = 0; q < npg; ++q) {
+            if (spec) { for (int k = 0; k < 8; ++k) info[8 * pg[q] + k] = hinfo[8 * q + k]; terr[pg[q]] = 0.0; continue; }      // (booked by the check)
             int Mr, Nc, ncolJ; theta_dims(hinfo.data() + 8 * q, gitems[q].d1, gitems[q].d2, Mr, Nc, ncolJ);
             s->stats.n_lowrank_svd += (ncolJ < Nc) ? 1 : 0; s->stats.n_svd_sweeps += hinfo[8 * q + 4]; s->stats.n_svd_sweeps_max = std::max(s->stats.n_svd_sweeps_max, hinfo[8 * q + 4]);
             { static const bool dbg = envflag("TNQS_DEBUG_SWEEPS");      // diagnostics: which thetas the SVD launch of a batch waits for
@@ -938,38 +984,11 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
         int TR = pick_TR(KKmax, esz, 1);
         bool mf = false;
         if (std::is_same<T, float>::value && use_mfma() && KKmax >= 8) { int t = mfma_fiber_tile_rows((int)KKmax, (int)NNmax); if (t > 0) { TR = t; mf = true; } }
-        static const bool f64_mfma_off = envflag("TNQS_NO_F64_MFMA");
-        const bool f64mf = std::is_same<T, double>::value && use_mfma() && !f64_mfma_off && KKmax >= 4 && KKmax <= 64 && NNmax <= 64;      // kernels_f64.hip
-        // plane kernel for the common shape d = 2, chi_b = chi_b' = 32 (pair-kernel geometry, two waves per SIMD)
-        std::vector<Apply64Item> a64; std::vector<XbItem> xbi; std::vector<int> a64_verts; std::vector<Buf> a64_outs; std::vector<size_t> a64_ne;
-        std::vector<char> via64(own_idx.size(), 0); double a64_slices = 0;
-        if (std::is_same<T, float>::value && use_mfma() && use_apply64() && !use_rowgemm32()) {
-            for (size_t q = 0; q < own_idx.size(); ++q) {
-                size_t i = own_idx[q]; int gi = (int)i / 2; const SiteJob& j = sj[i];
-                Apply64Item it{};
-                if (info[8 * gi + 2] != 32 || j.sd.chi[j.bleg] != 32 || !apply64_geometry(j.sd.d, j.sd.z, j.sd.chi.data(), j.bleg, it.g)) continue;
-                Buf out = dalloc(s, j.sd.n * esz); Buf xb = dalloc(s, 2048 * 16); s->keepalive.push_back(xb);
-                it.in = pch[q].result; it.out = out->p; it.Xb = xb->p;
-                xbi.push_back(XbItem{(i & 1) ? ws[gi].X2->p : ws[gi].X1->p, xb->p});
-                a64.push_back(it); a64_verts.push_back(j.v); a64_outs.push_back(out); a64_ne.push_back(j.sd.n);
-                a64_slices += (double)j.sd.n / 16384.0; via64[q] = 1;
-            }
-        }
-        if (!a64.empty()) {
-            const int spw = (int)std::max(1.0, std::min(8.0, a64_slices / 2048.0));
-            std::vector<int> tb64, nt64; int wgs = 0;
-            for (auto& it : a64) { int nwg = (it.g.n0 * it.g.n1 * it.g.n2 + spw - 1) / spw; it.spw = spw; it.wg_begin = wgs; tb64.push_back(wgs); nt64.push_back(nwg); wgs += nwg; }
-            Buf np64 = dalloc(s, (size_t)wgs * sizeof(double));
-            for (size_t k = 0; k < a64.size(); ++k) a64[k].norm_partial = ao.normalize_tensors ? reinterpret_cast<double*>(np64->p) + tb64[k] : nullptr;
-            const XbItem* dx = upload(s, xbi); const Apply64Item* da = upload(s, a64);
-            { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_make_xb(s->stream, dx, (int)xbi.size()); }
-            { ProfScope ps(s, TNQS_PROF_GATE_APPLY, 2.0 * a64_slices * 16384.0 * esz, 8.0 * a64_slices * 16384.0 * 64);
-              launch_mfma_apply64(s->stream, da, (int)a64.size(), wgs); }
-            norm_and_replace<T>(s, a64_verts, a64_outs, a64_ne, np64, tb64, nt64, ao.normalize_tensors != 0);
-        }
+        const bool f64mf = std::is_same<T, double>::value && use_mfma() && KKmax >= 4 && KKmax <= 64 && NNmax <= 64;      // kernels_f64.hip
+        std::vector<char> via64(own_idx.size(), 0);      // sites served by the register-direct matrix-core kernel
         {   // chi = 64 sites (K = (s, b) = 128 -> N = (s', b') <= 128) and chi = 32 sites on the register-direct MFMA kernel: the speculative plan built
             // before the read-back when it came true, a fresh one otherwise
-            bool spec_ok = spec_plan.valid && a64.empty();
+            bool spec_ok = spec_plan.valid;
             for (size_t q = 0; q < own_idx.size() && spec_ok; ++q) { const int gi = (int)own_idx[q] / 2; spec_ok = info[8 * gi + 2] == ws[gi].cap && pch[q].steps.empty() && pch[q].result == s->site[sj[own_idx[q]].v]->p; }
             RgPlan fresh_plan;
             if (!spec_ok) {
@@ -1023,7 +1042,7 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
                 di.push_back(DiagItem{m->p, Sptr[gi], chin});
                 s->msg[2 * e + dir] = m;
             }
-            if (errs) errs[gates[gi].index] = terr[gi];
+            if (errs && !spec) errs[gates[gi].index] = terr[gi];      // (spec: written by the check, from the staged truncation errors)
         }
         const DiagItem* d = upload_small(s, di);
         { ProfScope ps(s, TNQS_PROF_SMALL, 0, 0); launch_diag<T>(s->stream, d, (int)di.size()); }
@@ -1033,14 +1052,15 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     soft_sync(s);   // workspace of this batch goes back to the pool at the next stream synchronisation (the BP update's first read-back)
 }
 
-template <class T> static void flush_batch(State* s, std::vector<Gate1>& b1, std::vector<Gate2>& b2, const tnqs_apply_opts& ao, double* errs) {
-    if (b1.empty() && b2.empty()) return;
-    apply_one_site_batch<T>(s, b1, ao.normalize_tensors != 0, false);
-    apply_two_site_batch<T>(s, b2, ao, errs);
-    s->stats.n_batches += 1;
-    b1.clear(); b2.clear();
-    soft_sync(s);
-}
+// ---------------------------------------------------------------------------------------------------------------
+// apply_gates (src/Apply/apply_gates.jl:46-98)
+// ---------------------------------------------------------------------------------------------------------------
+// The walk over the gate list -- which gates form a batch, where a BP update is due -- depends on the gate list alone (apply_gates.jl:64-90: vertex sets), not on
+// any number computed on the way.  So the SCHEDULE is built first: steps = maximal runs of pairwise-disjoint gates ("batch") and the cache updates between them
+// ("bp"), in the reference's order.  It is then executed AHEAD of the device (engine.hpp: Check): a batch whose outcome is predictable and an update expected to
+// converge in one sweep are enqueued without waiting for their results, the state in front of every step is remembered as a vector of references, and a step
+// whose deferred verification fails is run again the careful way from that state.  Results are those of the sequential walk either way.
+struct Step { bool is_bp = false; std::vector<Gate1> b1; std::vector<Gate2> b2; };
 
 template <class T> static void apply_gates_t(State* s, int ngates, const int32_t* nverts, const int32_t* verts, const double* mats,
                                              const tnqs_apply_opts* opts, const tnqs_bp_opts* bp, double* errs) {
@@ -1070,50 +1090,98 @@ template <class T> static void apply_gates_t(State* s, int ngates, const int32_t
         for (size_t k = 1; k < moff[ngates] && !cplx; k += 2) cplx = mats[k] != 0.0;
         if (cplx) s->real_io = false;
     }
-    // vertex flags instead of std::set: this walk sits between the end of a BP update and the first kernel of the next batch (chip idle)
+    // ---- the schedule (vertex flags instead of std::set: this walk sits in front of the first kernel of a call) ----------------------------------------
     struct VSet { std::vector<char> f; std::vector<int> l; explicit VSet(int n) : f(n, 0) {} bool count(int v) const { return f[v] != 0; }
                   void insert(int v) { if (!f[v]) { f[v] = 1; l.push_back(v); } } void clear() { for (int v : l) f[v] = 0; l.clear(); } };
-    VSet affected(g.nv), batch_verts(g.nv);
-    std::vector<Gate1> b1; std::vector<Gate2> b2;
-    // A mid-circuit BP update returns with its verdict pending (engine_bp.cpp); the batch that follows prepares itself on the host while the sweep runs and
-    // asks for the verdict before its first launch.  Negative (rare: one sweep reaches the tolerance on the states of an evolution): nothing has been
-    // enqueued or mutated -- the update is continued, blocking, and the batch starts over
-    auto flush = [&]() {
-        for (;;) {
-            try { flush_batch<T>(s, b1, b2, ao, errs); return; }
-            catch (const BpNotConverged&) {
-                const int done = s->bp_pending.iters_done; s->bp_pending.active = false;
-                bp_update_t<T>(s, bp, nullptr, nullptr, false, done);
+    std::vector<Step> steps;
+    {
+        VSet affected(g.nv), batch_verts(g.nv);
+        Step cur;
+        auto flush = [&]() { if (!cur.b1.empty() || !cur.b2.empty()) { steps.push_back(std::move(cur)); cur = Step{}; } };
+        for (int i = 0; i < ngates; ++i) {
+            const int nv = nverts[i]; const int32_t* vs = verts + voff[i];
+            bool need = false;
+            if (nv >= 2) for (int k = 0; k < nv; ++k) need = need || affected.count(vs[k]);            // apply_gates.jl:68
+            if (ao.update_cache && need) {
+                flush(); batch_verts.clear();
+                Step u; u.is_bp = true; steps.push_back(std::move(u));                                 // :76
+                affected.clear();                                                                      // :78
             }
+            bool overlap = false;
+            for (int k = 0; k < nv; ++k) overlap = overlap || batch_verts.count(vs[k]);
+            if (overlap) { flush(); batch_verts.clear(); }
+            if (nv == 1) cur.b1.push_back(Gate1{vs[0], mats + moff[i]}); else cur.b2.push_back(Gate2{vs[0], vs[1], mats + moff[i], i});
+            for (int k = 0; k < nv; ++k) { batch_verts.insert(vs[k]); affected.insert(vs[k]); }         // :88-90
         }
-    };
-    struct InApply { State* s; explicit InApply(State* st) : s(st) { s->in_apply = true; } ~InApply() { s->in_apply = false; } } in_apply_guard(s);
-    // An optimistic BP update commits its messages with the verdict pending.  Whatever ends this call -- also an error of the batch that follows (a numeric
-    // failure, a negative message eigenvalue) -- the verdict is consumed before the handle is handed back: every other accessor reads messages and
-    // statistics of a FINISHED update (round-4 advisor finding).  The continuation may itself fail: then the first error wins.
-    struct PendingGuard { State* s; const tnqs_bp_opts* bp; ~PendingGuard() {
-        if (!s->bp_pending.active) return;
-        try { if (!resolve_bp(s)) { const int done = s->bp_pending.iters_done; s->bp_pending.active = false; bp_update_t<T>(s, bp, nullptr, nullptr, false, done); } }
-        catch (...) { s->bp_pending.active = false; }
-    } } pending_guard{s, bp};
-    for (int i = 0; i < ngates; ++i) {
-        const int nv = nverts[i]; const int32_t* vs = verts + voff[i];
-        bool need = false;
-        if (nv >= 2) for (int k = 0; k < nv; ++k) need = need || affected.count(vs[k]);            // apply_gates.jl:68
-        if (ao.update_cache && need) {
-            flush(); batch_verts.clear();
-            bp_update_t<T>(s, bp, nullptr, nullptr, /*optimistic=*/true);                          // :76
-            affected.clear();                                                                      // :78
-        }
-        bool overlap = false;
-        for (int k = 0; k < nv; ++k) overlap = overlap || batch_verts.count(vs[k]);
-        if (overlap) { flush(); batch_verts.clear(); }
-        if (nv == 1) b1.push_back(Gate1{vs[0], mats + moff[i]}); else b2.push_back(Gate2{vs[0], vs[1], mats + moff[i], i});
-        for (int k = 0; k < nv; ++k) { batch_verts.insert(vs[k]); affected.insert(vs[k]); }         // :88-90
+        flush();
+        if (ao.update_cache) { Step u; u.is_bp = true; steps.push_back(std::move(u)); }                 // :93-95
     }
-    flush();
-    if (ao.update_cache) bp_update_t<T>(s, bp, nullptr, nullptr);                                   // :93-95
-    if (s->nranks > 1) materialize_pending_all(s);      // sharded: nothing stays pending between calls (State::in_apply)
+    struct InApply { State* s; explicit InApply(State* st) : s(st) { s->in_apply = true; } ~InApply() { s->in_apply = false; s->cur_step = -1; } } in_apply_guard(s);
+    // ---- how far ahead?  Running ahead keeps the state in front of every unverified step alive (the site tensors a batch replaced): up to a layer's worth of
+    // extra copies.  Handles with more than 2 GiB of site tensors stay one step deep -- the round-5 flow: a batch reads its results back, an update
+    // leaves its verdict pending until the next batch has prepared itself --, and so does a handle on which a verification failed a moment ago
+    // (Graph::spec_penalty, shared by the copies of a handle: an evolution whose updates need several sweeps would throw away a batch per update otherwise).
+    size_t own_bytes = 0; for (auto& b : s->site) if (b) own_bytes += b->bytes;
+    size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = 0;
+    static const bool spec_off = envflag("TNQS_NO_SPECULATION");
+    (void)fr; (void)tot;
+    // (measured, round 6: heavy-hex 3.0 -> 2.6 ms per layer, 7 x 7 unchanged -- its launch chain is 97 % busy either way --, 20 x 20 112.6 against 111.5 ms and 37 against
+    //  22 GiB at the peak: where the tensor passes fill the device there is no idle time to win, only memory to lose.  Hence the bound: 2 GiB of site tensors)
+    const bool deep = !spec_off && !s->sharded() && own_bytes <= (size_t(2) << 30);
+    const size_t nst = steps.size();
+    std::vector<std::unique_ptr<Snapshot>> snaps(nst + 1);
+    size_t k = 0; bool careful = false;
+    auto drop_old_snaps = [&]() { const size_t keep_from = s->checks.empty() ? k : (size_t)std::max(0, s->checks.front().step); for (size_t q = 0; q < keep_from && q < snaps.size(); ++q) snaps[q].reset(); };
+    // after SpecFailed: nothing enqueued behind the failed step may leave a trace -- drain, drop the younger checks, put the state back
+    auto recover = [&](const SpecFailed& f) {
+        HIPCHK(hipStreamSynchronize(s->stream)); if (s->aux_stream) HIPCHK(hipStreamSynchronize(s->aux_stream));
+        drained(s); drop_checks(s);
+        const tnqs_apply_stats st_now = s->stats;
+        g.spec_penalty = 12;
+        if (f.kind == 0) {                          // a gate batch: back to the state in front of it, run it the careful way
+            restore_snapshot(s, *snaps[f.step]);
+            k = (size_t)f.step; careful = true;
+        } else {                                    // a BP update whose first sweep missed the tolerance: the state right behind that sweep, then the remaining sweeps
+            if ((size_t)f.step + 1 < snaps.size() && snaps[f.step + 1]) restore_snapshot(s, *snaps[f.step + 1]);
+            s->cur_step = f.step;
+            bp_update_t<T>(s, bp, nullptr, nullptr, false, f.iters_done);
+            k = (size_t)f.step + 1; careful = false;
+        }
+        s->stats.n_spec_redone = st_now.n_spec_redone + 1;
+        for (size_t q = k + 1; q < snaps.size(); ++q) snaps[q].reset();
+    };
+    try {
+        while (k < nst || !s->checks.empty()) {
+            try {
+                if (k >= nst) { settle(s, true); break; }
+                Step& st = steps[k];
+                s->cur_step = (int)k;
+                const bool ahead = deep && g.spec_penalty == 0 && !careful;
+                if (deep || !s->checks.empty()) snaps[k] = std::make_unique<Snapshot>(take_snapshot(s));
+                if (st.is_bp) {
+                    bp_update_t<T>(s, bp, nullptr, nullptr, /*optimistic=*/true);
+                } else {
+                    apply_one_site_batch<T>(s, st.b1, ao.normalize_tensors != 0, false);
+                    apply_two_site_batch<T>(s, st.b2, ao, errs, /*allow_spec=*/ahead);
+                    s->stats.n_batches += 1;
+                    soft_sync(s);
+                }
+                careful = false; ++k;
+                if (g.spec_penalty > 0 && s->checks.empty()) g.spec_penalty -= 1;
+                if (!ahead && s->checks.size() > 1) settle(s, true);        // one step deep: at most the verdict of the update just enqueued stays pending
+                else if (s->checks.size() >= 12) settle(s, true);
+                else settle(s, false);
+                drop_old_snaps();
+            } catch (const SpecFailed& f) { recover(f); }
+        }
+    } catch (...) {
+        // an error of a step: what is still unverified is settled -- or rolled back to the last verified state -- before the handle is handed back; the first error wins
+        try { settle(s, true); }
+        catch (const SpecFailed& f) { (void)hipStreamSynchronize(s->stream); drop_checks(s); if (f.step >= 0 && (size_t)f.step < snaps.size() && snaps[f.step + (f.kind ? 1 : 0)]) restore_snapshot(s, *snaps[f.step + (f.kind ? 1 : 0)]); }
+        catch (...) { drop_checks(s); }
+        throw;
+    }
+    if (s->sharded()) materialize_pending_all(s);      // sharded: nothing stays pending between calls (State::in_apply)
     sync(s);                                                                                        // the call returns with the stream drained
 }
 

@@ -28,48 +28,30 @@ namespace tnqs {
 
 #define HIPCHK(x) hipchk((x), #x)
 
-// ---- environment switches (all default off; read once per process).  They select alternative routes of the SAME algorithm for A/B
-// measurements and for the route-equivalence tests (tests/test_gpu_toggles.py); nothing else steers the hot path. -----------------------
+// ---- environment switches (all default off; read once per process).  ONE alternative route per kernel family (round 6: the table had grown to ~45 switches,
+// most of them A/B levers of decisions that are long made -- each one a route that had to stay correct): they serve the route-equivalence tests
+// (tests/test_gpu_toggles.py) and the A/B legs of bench.py; nothing else steers the hot path. ------------------------------------------------------------
 inline bool envflag(const char* name) { const char* e = std::getenv(name); return e && e[0] == '1'; }
 #define TNQS_SWITCH(fn, expr) inline bool fn() { static const bool v = (expr); return v; }
-TNQS_SWITCH(use_mfma, !envflag("TNQS_NO_MFMA"))                  // no matrix-core kernel at all: the generic tiled kernels (kernels.hip)
-TNQS_SWITCH(use_pair, !envflag("TNQS_NO_PAIR"))                  // no plane kernels (two legs per pass, pair-Gram, chi = 16 / 32): single-leg products
-TNQS_SWITCH(use_tshare, !envflag("TNQS_NO_TSHARE"))              // degree-4 chi = 32 sites: no pair product shared by the two messages of a forest
-TNQS_SWITCH(use_dbl, !envflag("TNQS_NO_DOUBLE_GRAM"))            // one pair-Gram pass per message instead of both messages of a forest per pass
-TNQS_SWITCH(use_prefix, !envflag("TNQS_NO_PREFIX"))              // BP: no shared partial product for the messages a site sends in one level
+TNQS_SWITCH(use_mfma, !envflag("TNQS_NO_MFMA"))                  // no matrix-core kernel at all: the generic tiled kernels (kernels.hip), any dims / element type
+TNQS_SWITCH(use_pair, !envflag("TNQS_NO_PAIR"))                  // no plane kernels (two legs per pass, pair-Gram, chi = 16 / 32): single-leg matrix-core products
 TNQS_SWITCH(use_prodcache, !envflag("TNQS_NO_PRODCACHE"))        // BP: no partial product kept from one level to the next (engine_bp.cpp ProdCache)
-TNQS_SWITCH(use_chol, !envflag("TNQS_NO_CHOL"))                  // R factor from the eigen factorisation of the Gram matrix instead of Cholesky
-TNQS_SWITCH(use_qr2, !envflag("TNQS_NO_QR2"))                    // ComplexF64: no second factorisation pass; TNQS_QR2_ALL=1: on every site
-TNQS_SWITCH(use_lowrank, !envflag("TNQS_NO_LOWRANK"))            // theta SVD on the full theta instead of the low-rank factor
-TNQS_SWITCH(use_precond_svd, !envflag("TNQS_NO_PRECOND_SVD"))    // low-rank theta SVD: Gram + Cholesky + Jacobi on the triangular factor in one kernel (kernels.hip theta_svd_pre_kernel) instead of the plain Jacobi on the factor
+TNQS_SWITCH(use_chol, !envflag("TNQS_NO_CHOL"))                  // R factor from the eigen factorisation of the Gram matrix instead of Cholesky (the route a collapsed pivot falls back to)
+TNQS_SWITCH(use_qr2, !envflag("TNQS_NO_QR2"))                    // ComplexF64: no second factorisation pass
+TNQS_SWITCH(use_lowrank, !envflag("TNQS_NO_LOWRANK"))            // theta SVD on the full theta instead of the low-rank factor (the route a refused pivot falls back to)
+TNQS_SWITCH(use_precond_svd, !envflag("TNQS_NO_PRECOND_SVD"))    // low-rank theta SVD on the plain LDS Jacobi instead of the preconditioned one-kernel route (kernels.hip theta_svd_pre_kernel)
 TNQS_SWITCH(use_small_svd, !envflag("TNQS_NO_SMALLSVD"))         // sites with fewer fibers than columns: Gram + eigen instead of the direct SVD
-TNQS_SWITCH(use_apply64, !envflag("TNQS_NO_APPLY64"))            // chi = 32 gate epilogue on the fiber kernel instead of the plane kernel
-TNQS_SWITCH(eager_scale, envflag("TNQS_EAGER_SCALE"))            // apply 1/||psi|| after every gate instead of deferring it
-TNQS_SWITCH(defer_site1, !envflag("TNQS_NO_DEFER_1SITE"))         // unitary one-site gates are applied in a pass of their own instead of being carried to the next two-site gate
-// chi = 64 kernels (kernels_chi64.hip); TNQS_NO_CHI64=1 switches all of them off
-TNQS_SWITCH(use_rowgemm, !(envflag("TNQS_NO_ROWGEMM") || envflag("TNQS_NO_CHI64")))      // register-direct MFMA fiber GEMM
-TNQS_SWITCH(use_rowgemm32, !(envflag("TNQS_NO_ROWGEMM32") || envflag("TNQS_NO_ROWGEMM")))  // the same kernel for chi = 32 legs and the chi = 32 gate epilogue
-                                                                                           // (measured 89 vs 68 TFLOP/s against mfma_apply64_kernel, which
-                                                                                           // TNQS_NO_ROWGEMM32=1 brings back)
-TNQS_SWITCH(use_gram64, !(envflag("TNQS_NO_GRAM64") || envflag("TNQS_NO_CHI64")))        // 64 x 64 f32 MFMA Gram
-TNQS_SWITCH(use_gram128, !(envflag("TNQS_NO_GRAM128") || envflag("TNQS_NO_CHI64")))      // 128 x 128 f64 MFMA Gram
-TNQS_SWITCH(use_chol128, !(envflag("TNQS_NO_CHOL128") || envflag("TNQS_NO_CHI64")))      // Cholesky for 96 < n <= 128 (packed triangle)
-TNQS_SWITCH(use_tall_svd, !(envflag("TNQS_NO_TALLSVD") || envflag("TNQS_NO_CHI64")))     // Cholesky-QR preprocessed theta SVD
+TNQS_SWITCH(defer_site1, !envflag("TNQS_NO_DEFER_1SITE"))        // unitary one-site gates are applied in a pass of their own instead of being carried to the next two-site gate
+TNQS_SWITCH(use_chi64, !envflag("TNQS_NO_CHI64"))                // the chi = 64 kernel family (kernels_chi64.hip: register-direct fiber GEMM, 64 x 64 / 128 x 128 Grams, packed Cholesky, Cholesky-QR theta SVD)
 #undef TNQS_SWITCH
-// TNQS_NO_GAUGE_GRAM=1 (engine_gates.cpp): bulk chi = 32 sites absorb their third gauge leg in a pass of its own instead of inside the f64 Gram kernel (kernels_gate.hip);
-// TNQS_TWO_ROUNDTRIPS=1 (engine_gates.cpp): a ComplexF32 gate batch reads the ranks of the R factors back before the theta SVD (round-2 flow) instead of
-// leaving them on the device (one host round trip per batch);  TNQS_ARENA_KB: size of the pinned staging arena (tests of its overflow path);
-// TNQS_JACOBI_GLOBAL=1: every Jacobi factorisation in the global-memory kernel;  TNQS_BP_WS_MB: workspace bound of a BP sub-batch (MiB);
-// TNQS_HOST_TIMING=1: host-side phase timers printed at exit;  TNQS_RCCL_LIB: path of librccl.so (sharding.cpp);
-// TNQS_NO_F64_MFMA=1 (engine_batch.cpp): ComplexF64 mode products on the generic vector kernel instead of the f64 matrix cores (kernels_f64.hip);
-// TNQS_NO_BF16X3=1 (launch_util.hpp): the chi = 32 plane kernels (pair product, both-messages pair-Gram) on v_mfma_f32_32x32x2_f32 instead of the bf16 matrix cores with exact three-way
-//                   operand splits (kernels_x3.hip);
-// TNQS_NO_3M=1 (launch_util.hpp): four-multiplication complex product in every MFMA kernel instead of Gauss' three (mfma_common.hpp, CAcc32);
-// TNQS_NO_OPTIMISTIC_BP=1 (engine_bp.cpp): every BP update inside apply_gates waits for its convergence verdict before the next batch is prepared;
-// TNQS_NO_SMALL_SITE_BP=1 (engine_bp.cpp): sites of at most 8192 elements take the generic chain + Gram route instead of the one-kernel LDS-resident message (kernels.hip bp_small_site_kernel);
-// TNQS_NO_BP_SPLIT=1 (engine_bp.cpp): the boundary sites' products and Grams of a BP level on the same stream as the bulk sites' plane kernels instead of next to them;
-// Kernel experiments are NOT in the shipped library: TNQS_MFMA_WG_TILES, TNQS_XCD_REMAP, TNQS_DBG_GRAM_SKIP, TNQS_PAIR_SPW, TNQS_PAIR16_HALF
-// and TNQS_QR2_ALL only exist in a build with -DTNQS_EXPERIMENTS (csrc/build.sh EXPERIMENTS=1); the kernel-level entry points of
+// TNQS_NO_BF16X3=1 (launch_util.hpp): the chi = 32 / 64 plane kernels on v_mfma_f32_32x32x2_f32 instead of the bf16 matrix cores with exact three-way operand splits
+//                   (kernels_x3.hip; bench.py's A/B leg);
+// TNQS_NO_SPECULATION=1 (engine_gates.cpp): apply_gates never runs ahead of the device -- every batch reads its results back, every BP update waits for its verdict;
+// TNQS_NO_SMALL_SITE_BP=1 (engine_bp.cpp): sites of at most 8192 elements take the generic chain + Gram route instead of the one-kernel LDS-resident message;
+// TNQS_JACOBI_GLOBAL=1: every Jacobi factorisation in the global-memory kernel (the route matrices beyond the LDS take);
+// tunables: TNQS_ARENA_KB (pinned staging arena; tests of its overflow path), TNQS_BP_WS_MB (workspace bound of a BP sub-batch), TNQS_BP_CACHE_MB, TNQS_RCCL_LIB (sharding.cpp),
+//           TNQS_FORCE_EXCHANGE (a one-rank RCCL handle takes the sharded path); diagnostics: TNQS_HOST_TIMING, TNQS_DEBUG_SWEEPS.
+// Kernel experiments are NOT in the shipped library: they only exist in a build with -DTNQS_EXPERIMENTS (csrc/build.sh EXPERIMENTS=1); the kernel-level entry points of
 // include/tnqs_debug.h (debug.cpp) read TNQS_DBG_* themselves and are not part of the hot path.
 // TNQS_BP_CACHE_MB: bound on the partial products kept across BP levels (MiB, default 49152)
 inline size_t bp_cache_budget() { static const size_t v = [] { const char* e = std::getenv("TNQS_BP_CACHE_MB"); return (e ? (size_t)std::atoll(e) : (size_t)49152) << 20; }(); return v; }
@@ -279,10 +261,50 @@ struct GramJob {      // out[i,j] = sum X[i,.] conj(Y[j,.]) over everything but 
 template <class T> void run_chains(State* s, std::vector<Chain>& chains, int cls, int cls_pair = -1);
 template <class T, class Acc> void run_grams(State* s, std::vector<GramJob>& jobs, int cls);
 template <class T> void svd_batch(State* s, const std::vector<JacobiItem>& all, bool with_v);
-// optimistic: (apply_gates, single rank, a tolerance given) return after ENQUEUING the first sweep, verdict pending (State::bp_pending);
-// iters_before: sweeps this update has already run (the continuation after a pending verdict turned out negative)
+// optimistic: (apply_gates, a tolerance given) return after ENQUEUING the first sweep with its verdict left as a Check (engine.hpp); iters_before: sweeps this
+// update has already run (the continuation after a verdict turned out negative)
 template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_out, double* diff_out, bool optimistic = false, int iters_before = 0);
-struct BpNotConverged {};                 // thrown by the first consumer of an optimistic update whose sweep did not reach the tolerance: nothing has been enqueued or mutated yet
-bool resolve_bp(State* s);                // waits for a pending verdict; true: converged (or nothing pending, or the sweep budget is used up)
+
+// ---- deferred verification (engine.hpp: Check, Snapshot) ---------------------------------------------------------------------------------
+// Evaluate the pending checks, oldest first.  block: wait for each; otherwise stop at the first whose event has not fired.  The first check that does not
+// hold is removed and thrown as SpecFailed -- the caller (apply_gates_t) drains the stream, drops the younger checks and puts the snapshot back.  Call it only
+// where nothing of the State has been replaced since the last consistent point, or where a snapshot covers what has.
+inline void settle(State* s, bool block) {
+    while (!s->checks.empty()) {
+        Check& c = s->checks.front();
+        if (block) HIPCHK(hipEventSynchronize(c.ev));
+        else { const hipError_t q = hipEventQuery(c.ev); if (q == hipErrorNotReady) return; HIPCHK(q); }
+        const bool ok = c.eval(s);
+        const SpecFailed f{c.kind, c.step, c.iters_done};
+        s->checks.pop_front();
+        if (s->checks.empty()) s->arena.ring_off = 0;
+        if (!ok) throw f;
+    }
+}
+// `bytes` of pinned staging for a check's read-back (valid until the check is settled); makes room by settling what is pending when the ring is full
+inline char* ring_alloc(State* s, size_t bytes) {
+    HostArena& ar = s->arena;
+    if (!ar.base) ar = acquire_arena();
+    const size_t b = round256(std::max<size_t>(bytes, 1));
+    if (b > ar.ring_cap) return nullptr;                                   // (the caller takes the careful route)
+    if (ar.ring_off + b > ar.ring_cap) { settle(s, true); ar.ring_off = 0; }
+    char* p = ar.ring + ar.ring_off; ar.ring_off += b; return p;
+}
+// the event a new check records behind its staged copy (a ring of 16: apply_gates never leaves more than 12 checks pending)
+inline hipEvent_t check_event(State* s) {
+    HostArena& ar = s->arena;
+    if (!ar.base) ar = acquire_arena();
+    hipEvent_t& e = ar.cev[ar.cevn++ & 15];
+    if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return e;
+}
+inline Snapshot take_snapshot(const State* s) {
+    Snapshot n; n.chi = s->chi; n.site = s->site; n.sscale = s->sscale; n.msg = s->msg; n.pend1 = s->pend1; n.unit_norm = s->unit_norm; n.stats = s->stats; n.real_io = s->real_io; return n;
+}
+inline void restore_snapshot(State* s, const Snapshot& n) {
+    s->chi = n.chi; s->site = n.site; s->sscale = n.sscale; s->msg = n.msg; s->pend1 = n.pend1; s->unit_norm = n.unit_norm; s->stats = n.stats; s->real_io = n.real_io;
+}
+// drop every pending check unevaluated (the stream has been drained, a snapshot is about to be put back)
+inline void drop_checks(State* s) { s->checks.clear(); s->arena.ring_off = 0; }
 
 }  // namespace tnqs

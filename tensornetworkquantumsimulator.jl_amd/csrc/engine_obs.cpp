@@ -158,7 +158,7 @@ template <class T> static void region_contract(State* s, int nr, const int32_t* 
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return depth[a] > depth[b]; });
     std::vector<Buf> up(nr);                       // message from region vertex i to its parent
-    const bool sharded = s->nranks > 1;
+    const bool sharded = s->sharded();
     // sharded handles: the owner of a region vertex contracts it; its message to the parent (chi x chi) -- or, at the root, the d x d
     // result -- reaches every rank through one exchange per region vertex (all ranks walk the region in the same order)
     for (int oi = 0; oi < nr; ++oi) {

@@ -285,12 +285,6 @@ inline bool pair_geometry(int d, int z, const int* chi, int lx, int ly, PairGeom
     }
     return true;
 }
-// plane geometry (bond leg b, any other 32-dim leg y) for the gate epilogue kernel; needs d = 2 and chi_b = 32
-inline bool apply64_geometry(int d, int z, const int* chi, int b, PairGeom& g) {
-    if (d != 2 || b < 0 || b >= z || chi[b] != 32) return false;
-    for (int y = 0; y < z; ++y) if (y != b && pair_geometry(d, z, chi, b, y, g)) return true;
-    return false;
-}
 struct PairItem {         // out = in x_x Mx x_y My for two 32-dimensional legs
     const void* in; void* out; const void* Mx; const void* My;
     PairGeom g;
@@ -391,12 +385,6 @@ inline int pair_spw(double total_slices) {
 #endif
     int spw = 16; while (spw > 1 && 2.0 * total_slices / spw < 1024.0) spw >>= 1; return spw;
 }
-// gate epilogue psi' = psi x_(s,b) X for d = 2, chi_b = chi_b' = 32 (K = N = 64) in the pair-kernel shape: plane (b, y) per companion,
-// the two site components of a companion are the planes of one wave.  Xb = X rearranged into MFMA B-operand order (make_xb).
-struct Apply64Item { const void* in; void* out; const void* Xb; PairGeom g; int wg_begin; int spw; double* norm_partial; };
-struct XbItem { const void* X; void* Xb; };       // X[(s + 2 b) + 64 (s' + 2 b')] complex64 -> 2048 float4
-void launch_make_xb(hipStream_t s, const XbItem* d_items, int nitems);
-void launch_mfma_apply64(hipStream_t s, const Apply64Item* d_items, int nitems, int total_wgs);
 // both messages a site sends into one linear forest in ONE pass over (X, Y): legs (lx, ly) span the plane;
 //   partial_y[b,b'] = sum (X x_lx Mx)[.. b on ly ..] conj(Y[.. b' on ly ..])      (message leaving through ly: lx absorbed with Mx)
 //   partial_x[d,d'] = sum (X x_ly My)[.. d on lx ..] conj(Y[.. d' on lx ..])      (message leaving through lx: ly absorbed with My)

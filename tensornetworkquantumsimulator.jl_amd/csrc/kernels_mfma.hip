@@ -1086,159 +1086,6 @@ void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nit
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// gate epilogue for d = 2, chi = chi' = 32:   out[s', b', rest] = sum_{s, b} in[s, b, rest] X[(s,b), (s',b')]
-// Pair-kernel shape: a workgroup stages 16 companions x the 32 x 32 plane (b, y) of the bond leg and one other leg; the
-// companions are 8 (s = 0, 1) pairs, and wave w owns both planes of pair w:  C_{s'}[y][b'] = sum_s sum_b in_s[b][y] X_{s s'}[b][b'].
-// The four 32 x 32 blocks of X stream from L1/L2 in B-operand order (Xb), double-buffered against the MFMAs.
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void make_xb_kernel(const XbItem* __restrict__ items) {
-    const XbItem it = items[blockIdx.x];
-    const cf* __restrict__ X = reinterpret_cast<const cf*>(it.X);
-    v4f* __restrict__ Xb = reinterpret_cast<v4f*>(it.Xb);
-    for (int e = threadIdx.x; e < 2048; e += 256) {
-        int lane = e & 63, j = (e >> 6) & 7, ssp = e >> 9; int s = ssp >> 1, sp = ssp & 1;
-        int ln = lane & 31, h = lane >> 5;
-        cf a = X[(s + 2 * (2 * j + 16 * h)) + 64 * (sp + 2 * ln)], b = X[(s + 2 * (2 * j + 1 + 16 * h)) + 64 * (sp + 2 * ln)];
-        v4f v; v[0] = a.re; v[1] = a.im; v[2] = b.re; v[3] = b.im;
-        Xb[e] = v;
-    }
-}
-void launch_make_xb(hipStream_t s, const XbItem* d_items, int nitems) {
-    if (nitems <= 0) return;
-    hipLaunchKernelGGL(make_xb_kernel, dim3(nitems), dim3(256), 0, s, d_items); TNQS_CHECK_LAUNCH();
-}
-__global__ __launch_bounds__(512) void mfma_apply64_kernel(const Apply64Item* __restrict__ items, int nitems) {
-    // LDS (exactly 160 KiB, no static LDS in this kernel): 16 planes x (re, im) x 32 x 32 floats with an XOR swizzle instead of a
-    // padded pitch -- element (ix, iy) of plane p at iy*32 + ((ix ^ iy ^ sw(p)) & 31), sw(p) = ((p >> 1) & 3) << 3 -- followed by the
-    // four 32 x 32 blocks of X in B-operand order (32 KiB).  Every access pattern below is at most 2-way (= 64 lanes / 32 banks).
-    constexpr int PR = 32 * 32;                 // floats of one re (or im) plane
-    constexpr int PS = 2 * PR;                  // plane stride
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* L = reinterpret_cast<float*>(smem);
-    v4f* Xl = reinterpret_cast<v4f*>(L + 16 * PS);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
-    int lo = 0, hi_ = nitems - 1;
-    const int gw = blockIdx.x;
-    while (lo < hi_) { int mid = (lo + hi_ + 1) >> 1; if (items[mid].wg_begin <= gw) lo = mid; else hi_ = mid - 1; }
-    const Apply64Item it = items[lo];
-    const PairGeom g = it.g;
-    const int nslices = g.n0 * g.n1 * g.n2;
-    const int lw = gw - it.wg_begin;
-    const int s_begin = lw * it.spw, s_end = min(nslices, s_begin + it.spw);
-    const cf* __restrict__ in = reinterpret_cast<const cf*>(it.in);
-    cf* __restrict__ out = reinterpret_cast<cf*>(it.out);
-    {
-        const v4f* __restrict__ Xb = reinterpret_cast<const v4f*>(it.Xb);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Xl[tid + 512 * j] = ldg4(Xb + tid + 512 * j);
-    }
-    const int f = tid & 7, sg0 = tid >> 3;
-    const long long sx = g.sx, sy = g.sy, fo = (long long)f * g.cstr;
-    // segment j of this thread: ix = sg0 & 31 (fixed), iy = (sg0 >> 5) + 2 j  ->  one base address and a constant stride
-    const int ix0 = sg0 & 31, iy0 = sg0 >> 5;
-    const long long toff = fo + sx * ix0 + sy * iy0, tstr = 2 * sy;
-    const int swf = (f & 3) << 3;               // planes 2f and 2f+1 share the swizzle constant
-    float* const lplane = L + (2 * f) * PS;     // plane 2f = site component 0, 2f+1 = component 1
-    v4f pre[16];
-    auto issue = [&](int sl) {
-        const cf* p = in + pair_slice_base(g, sl) + toff;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) pre[j] = ldg4(p + tstr * j);
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int iy = iy0 + 2 * j;
-            float* p0 = lplane + iy * 32 + ((ix0 ^ iy ^ swf) & 31);
-            p0[0] = pre[j][0]; p0[PR] = pre[j][1];
-            p0[PS] = pre[j][2]; p0[PS + PR] = pre[j][3];
-        }
-    };
-    const int sww = (w & 3) << 3;               // swizzle constant of this wave's planes 2w, 2w+1
-    double nrm = 0;
-    if (s_begin < s_end) issue(s_begin);
-    for (int sl = s_begin; sl < s_end; ++sl) {
-        lds_barrier();
-        commit();
-        lds_barrier();
-        if (sl + 1 < s_end) issue(sl + 1);
-        float* P0 = L + (2 * w) * PS; float* P1 = P0 + PS;
-        float nrm_f = 0.f;                                          // 64 squares per slice in f32, slices accumulate in f64
-        v16f Cr[2], Ci[2];                                          // C_{s'}[row = y = kappa(r,h)][col = b' = ln]
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { Cr[sp][r] = 0.f; Ci[sp][r] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const float* Ps = s ? P1 : P0;
-            float ar[16], ai[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { int o = ln * 32 + (((q + 16 * h) ^ ln ^ sww) & 31); ar[q] = Ps[o]; ai[q] = Ps[PR + o]; }     // A[i = y = ln][k = b]
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                __builtin_amdgcn_sched_barrier(0);                 // one X block in registers at a time (VGPR budget)
-                v4f bb[8];                                         // block (s, s') of X, index 2 s + s'
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bb[j] = Xl[((2 * s + sp) * 8 + j) * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int q = 2 * j + t;
-                        const float br = bb[j][2 * t], bi = bb[j][2 * t + 1];
-                        Cr[sp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], br, Cr[sp], 0, 0, 0);
-                        Ci[sp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q], bi, Ci[sp], 0, 0, 0);
-                        Ci[sp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[q], br, Ci[sp], 0, 0, 0);
-                        const float nbi = -bi;                     // bi is dead from here on: the negation reuses its register
-                        Cr[sp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[q], nbi, Cr[sp], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                           // both planes have been consumed: overwrite them with the result
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            float* Po = sp ? P1 : P0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int y = (r & 3) + 8 * (r >> 2) + 4 * h;
-                int o = y * 32 + ((ln ^ y ^ sww) & 31);
-                Po[o] = Cr[sp][r]; Po[PR + o] = Ci[sp][r];
-                nrm_f += Cr[sp][r] * Cr[sp][r] + Ci[sp][r] * Ci[sp][r];
-            }
-        }
-        nrm += (double)nrm_f;
-        lds_barrier();
-        {
-            cf* p = out + pair_slice_base(g, sl) + toff;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int iy = iy0 + 2 * j;
-                const float* p0 = lplane + iy * 32 + ((ix0 ^ iy ^ swf) & 31);
-                v4f v; v[0] = p0[0]; v[1] = p0[PR]; v[2] = p0[PS]; v[3] = p0[PS + PR];
-                stg4(p + tstr * j, v);
-            }
-        }
-    }
-    if (it.norm_partial) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) nrm += __shfl_xor(nrm, o, 64);
-        lds_barrier();                                              // the planes are free: reuse the first bytes for the 8 wave sums
-        double* sh_n = reinterpret_cast<double*>(L);
-        if (lane == 0) sh_n[w] = nrm;
-        lds_barrier();
-        if (tid == 0) { double t = 0; for (int i = 0; i < 8; ++i) t += sh_n[i]; it.norm_partial[lw] = t; }
-    }
-}
-void launch_mfma_apply64(hipStream_t s, const Apply64Item* d_items, int nitems, int total_wgs) {
-    if (total_wgs <= 0) return;
-    const size_t lds = (size_t)16 * (2 * 32 * 32) * sizeof(float) + 2048 * 16;        // 160 KiB: the whole LDS of a CU
-    set_max_dynamic_lds((const void*)mfma_apply64_kernel, lds);
-    hipLaunchKernelGGL(mfma_apply64_kernel, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); TNQS_CHECK_LAUNCH();
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // right singular vectors of the theta SVD, recovered: V = theta0^dagger (U Sigma) Sigma^-2  -- an n x n x m complex GEMM
 // per gate (m, n <= 256).  A wave owns one 32 x 32 tile of V; operands are read straight from L2 (both matrices are <= 512 KiB).
 // ------------------------------------------------------------------------------------------------------------

@@ -22,8 +22,8 @@ inline void set_max_dynamic_lds(const void* func, size_t bytes) {
     done[key] = bytes;
 }
 
-// Gauss' three-multiplication complex product in the plane kernels (mfma_common.hpp, CAcc32); TNQS_NO_3M=1 restores the four-MFMA product.
-inline bool mfma_use_3m() { static const bool v = [] { const char* e = std::getenv("TNQS_NO_3M"); return !(e && e[0] == '1'); }(); return v; }
+// Gauss' three-multiplication complex product in the f32 plane kernels (mfma_common.hpp, CAcc32).
+inline constexpr bool mfma_use_3m() { return true; }      // (the four-multiplication instantiations are kept for the shapes whose registers do not hold three accumulators)
 
 // f32 products of the chi = 32 plane kernels on the bf16 matrix cores (three-way exact split, six products: kernels_x3.hip); TNQS_NO_BF16X3=1 keeps them on
 // v_mfma_f32_32x32x2_f32.

@@ -81,6 +81,8 @@ void set_sharding_rccl(State* s, int rank, int nranks, const int32_t* owner, con
     s->comm = c;
     s->rank = rank; s->nranks = nranks; s->ag_fn = nullptr; s->ag_ctx = nullptr; s->exch = c->exch_owned; s->exch_bytes = (size_t)exch_bytes;
     s->owner.swap(owner_copy);
+    if (s->owner.empty()) s->owner.assign(s->g->nv, 0);
+    s->force_exchange = nranks == 1 && envflag("TNQS_FORCE_EXCHANGE");      // (State::sharded)
     if (nranks > 1) for (int v = 0; v < s->g->nv; ++v) if (!s->owns(v)) { s->site[v] = nullptr; s->sscale[v] = nullptr; }
 }
 
@@ -119,13 +121,13 @@ void rccl_selftest(int device, int64_t bytes) {
 
 // all-gather of equal-sized per-rank blocks laid out back to back in the host-provided exchange buffer
 void check_exchange(const State* s, size_t bytes_per_rank) {
-    if (s->nranks <= 1) return;
+    if (!s->sharded()) return;
     if (bytes_per_rank * (size_t)s->nranks > s->exch_bytes)
         throw Err(TNQS_ERR_COMM, "exchange buffer too small for this batch: " + std::to_string(bytes_per_rank * (size_t)s->nranks) + " bytes needed, " +
                                      std::to_string(s->exch_bytes) + " available (raise the buffer size passed to tnqs_set_sharding)");
 }
 void exchange(State* s, size_t bytes_per_rank) {
-    if (s->nranks <= 1) return;
+    if (!s->sharded()) return;
     check_exchange(s, bytes_per_rank);
     if (s->comm) { rccl_allgather(s, bytes_per_rank); return; }       // RCCL: enqueued on the handle's stream, nothing to wait for here
     if (!s->ag_fn) throw Err(TNQS_ERR_COMM, "sharded handle without a transport (tnqs_set_sharding_rccl or tnqs_set_sharding)");

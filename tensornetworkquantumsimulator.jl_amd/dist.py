@@ -120,6 +120,42 @@ def exchange_bytes_needed(max_chi: int, d: int, n_edges: int, n_vertices: int, e
     return int(max(grams, msgs, recs)) + (1 << 20)
 
 
+def exchange_plan(graph, owner: Sequence[int], chi: int, colour_groups, bp_levels, d: int = 2, esz: int = 8, bp_updates_per_layer: Optional[int] = None,
+                  sweeps_per_update: int = 1) -> dict:
+    """what the library's exchange points of ONE colour-batched layer need, restated on the host from the engine's slot rules (csrc/engine_bp.cpp: one all-gather per
+    BP level, every message a 256-byte-rounded slot in its OWNER's block; csrc/engine_gates.cpp: per colour batch the f64 Gram matrices of the sites whose gate
+    STRADDLES two ranks, then one record (chi', status, truncation error, S -- and X2 for a straddling gate) per gate in the block of its first vertex's owner).
+    An exchange moves `stride x nranks` bytes into every rank, stride = the largest block of any rank: the exchange buffer must hold the largest such product.
+    bp_levels: the dependency levels of one sweep as lists of (src, dst) vertex pairs (tests: tnqs_dbg_default_sequence_graph).
+    Returns {"max_exchange_bytes", "bytes_gathered_per_layer", "exchanges_per_layer", "by_kind"}."""
+    idx = graph.index
+    world = max(owner) + 1
+    r256 = lambda b: (int(b) + 255) & ~255
+    n = d * chi
+    kinds = {"bp_level": [], "gate_gram": [], "gate_record": []}
+    for lev in bp_levels:
+        blocks = [0] * world
+        for (a, _b) in lev:
+            blocks[owner[idx[a]]] += r256(chi * chi * esz)
+        kinds["bp_level"].append(max(blocks) * world)
+    x2 = n * d * chi * esz
+    for grp in colour_groups:
+        gb, rb = [0] * world, [0] * world
+        for (a, b) in grp:
+            ra, rbk = owner[idx[a]], owner[idx[b]]
+            if ra != rbk:
+                gb[ra] += r256(n * n * 16); gb[rbk] += r256(n * n * 16)
+            rb[ra] += r256(32 + chi * 8 + (x2 if ra != rbk else 0))
+        if max(gb):
+            kinds["gate_gram"].append(max(gb) * world)
+        kinds["gate_record"].append(max(rb) * world)
+    nup = len(colour_groups) + 1 if bp_updates_per_layer is None else bp_updates_per_layer
+    per_layer = nup * sweeps_per_update * sum(kinds["bp_level"]) + sum(kinds["gate_gram"]) + sum(kinds["gate_record"])
+    nex = nup * sweeps_per_update * len(kinds["bp_level"]) + len(kinds["gate_gram"]) + len(kinds["gate_record"])
+    return {"max_exchange_bytes": max(max(v) if v else 0 for v in kinds.values()), "bytes_gathered_per_layer": per_layer, "exchanges_per_layer": nex,
+            "by_kind": {k: {"count": len(v), "max": max(v) if v else 0, "sum": sum(v)} for k, v in kinds.items()}}
+
+
 class Sharding:
     """keeps the exchange tensor and the ctypes callback alive for as long as any handle copy uses them"""
 

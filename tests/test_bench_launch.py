@@ -72,6 +72,36 @@ def test_big_configurations_run_sharded_over_gloo(cfg, L):
     assert out["value"] > 0 and out["roofline"] is not None
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,L,chi", [("c2", "8", "8"), ("c4", "4", "4")])
+def test_eight_ranks_over_gloo(cfg, L, chi):
+    """round-5 verdict item 7: the driver's 8-GPU command shape, `python bench.py --gpus 8`, run for real -- eight ranks sharing this box's one GPU over gloo (callback
+    transport; with eight GPUs the same command runs one rank per GPU on the library's RCCL transport): launch, work-balanced partition, every exchange of a
+    layer, the max-over-ranks timing and the JSON line.  The bytes the library counted per step must be what dist.exchange_plan predicts from the slot rules --
+    the restatement the CPU suite sizes the exchange buffer of the full-size configurations with (tests/test_sharding_cpu.py)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--config", cfg, "--L", L, "--chi", chi, "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=clean_env(TNQS_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    tr = out["config"]["transport"]
+    assert out["n_gpus"] == 8 and tr["nranks"] == 8 and len(tr["partition"]["vertices"]) == 8 and min(tr["partition"]["vertices"]) > 0
+    assert out["value"] > 0 and out["config"]["bp_sweeps_per_step"][0] >= out["config"]["bp_updates_per_step"][0]
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tnqs_amd as tn
+    from test_sharding_cpu import _default_levels
+    Li, ci = int(L), int(chi)
+    g = tn.named_grid((Li, Li, Li), periodic=True) if cfg == "c4" else tn.named_grid((Li, Li))
+    groups = tn.edge_color(g) if cfg == "c4" else tn.edge_color(g, 4)
+    owner = tn.partition_vertices(g.nv(), 8, tn.dist.site_weights(g, ci))
+    nup, nsw = out["config"]["bp_updates_per_step"][0], out["config"]["bp_sweeps_per_step"][0]
+    plan = tn.dist.exchange_plan(g, owner, ci, groups, _default_levels(g), bp_updates_per_layer=1, sweeps_per_update=nsw)       # (sweeps of all updates of the step)
+    print(cfg, "library:", tr["allgathers_per_step"], "all-gathers,", tr["MB_gathered_per_step"], "MB per step; plan:", plan["exchanges_per_layer"], plan["bytes_gathered_per_layer"] / 1e6, "updates", nup, "sweeps", nsw)
+    # both counters average the timed step and the warm-up step, which may have swept more often: the plan of the TIMED step is a lower bound within a sweep's worth
+    per_sweep = sum(1 for _ in _default_levels(g))
+    assert abs(tr["allgathers_per_step"] - plan["exchanges_per_layer"]) <= 8 * per_sweep
+    assert abs(tr["MB_gathered_per_step"] - plan["bytes_gathered_per_layer"] / 1e6) <= 0.25 * plan["bytes_gathered_per_layer"] / 1e6
+
+
 def test_memory_estimate_refuses_what_cannot_fit():
     """--config c4 at full size on ONE rank is 250 GiB of site tensors: refused before anything is allocated (on a CPU box the script stops earlier,
     at the missing device -- either way no JSON line and a non-zero exit)"""

@@ -262,14 +262,22 @@ def test_c3_layers_match_oracle():
     bd = tn.update(tn.BeliefPropagationCache(psi), **bpkw)
     bo = o.update(o.BeliefPropagationCache(to_oracle_state(psi)), **bpkw)
     zop = np.diag([1.0, -1.0]).astype(complex)
+    noisy_bonds = set()
     for it in range(5):
         bd, ed = tn.apply_gates(layer, bd, apply_kwargs=kw, bp_update_kwargs=bpkw)
         bo, eo = o.apply_gates(layer, bo, apply_kwargs=kw, bp_update_kwargs=bpkw)
         # (cutoff 1e-12 keeps singular values down to 1e-6 sigma_max, which f32 resolves to ~10 %: a bond may differ by ONE where the weight in question sits
-        #  within rounding of the cutoff -- helpers.bond_dims_agree; the run stops comparing at such a bond, tensors of different shapes have no common elements)
+        #  within rounding of the cutoff -- helpers.bond_dims_agree; the shape-independent quantities are compared to the end)
         gate_of_edge = [next((k for k, gt in enumerate(layer) if len(gt[1]) == 2 and set(gt[1]) == {a, b}), None) for (a, b) in g.edges]
-        ok, at_cutoff = bond_dims_agree([bd.bond_dim(a, b) for (a, b) in g.edges], [bo.tns.bond_dim(a, b) for (a, b) in g.edges], ed, eo, gate_of_edge, 1e-12)
-        assert ok, (it, at_cutoff)
+        dd, do = [bd.bond_dim(a, b) for (a, b) in g.edges], [bo.tns.bond_dim(a, b) for (a, b) in g.edges]
+        if not noisy_bonds:
+            ok, at_cutoff = bond_dims_agree(dd, do, ed, eo, gate_of_edge, 1e-12)
+            assert ok, (it, at_cutoff)
+        else:       # a bond differed by one at the cutoff in an earlier layer: from then on the two runs carry tensors of different shapes there.  Everything that does
+            # not depend on the shape is still compared (round-5 advisor finding: the run used to stop here) -- the extra singular value weighs 1e-12
+            at_cutoff = [k for k, (a, b) in enumerate(zip(dd, do)) if a != b]
+            assert all(abs(dd[k] - do[k]) <= 1 for k in at_cutoff), (it, [(dd[k], do[k]) for k in at_cutoff])
+        noisy_bonds |= set(at_cutoff)
         assert c64_errs_close(ed, eo), (it, float(np.max(np.abs(ed - np.array(eo)))))
         zd = tn.expect_all(bd, "Z").real
         zo = np.array([o.expect_1site(bo, zop, v).real for v in g.vertices])
@@ -278,7 +286,6 @@ def test_c3_layers_match_oracle():
         if at_cutoff:
             print(f"C3 layer {it}: bonds {at_cutoff} differ by one at the cutoff (f32 noise of a singular value of 1e-6 sigma_max)")
             assert it >= 3          # the first layers (chi <= 8) hold no singular value near the cutoff
-            break
 
 
 def test_c2_evolution_drift_over_ten_layers():

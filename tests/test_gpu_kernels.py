@@ -236,27 +236,6 @@ def test_pair_gram_on_arbitrary_legs(chi, lx, ly):
     assert np.max(np.abs(got - ref)) < 3e-5 * np.max(np.abs(ref)) * max(1.0, np.sqrt(tx.size / 65536))
 
 
-@pytest.mark.parametrize("chi,b", [((32, 32, 32), 0), ((32, 32, 32), 1), ((32, 32, 32), 2), ((32, 32, 8, 4), 0), ((32, 8, 32, 32), 3), ((32, 8, 32, 32), 0),
-                                   ((32, 32, 32, 32), 0), ((32, 32, 32, 32), 1), ((32, 32, 32, 32), 2), ((32, 32, 32, 32), 3), ((8, 32, 32), 1), ((8, 32, 32), 2)])
-def test_gate_epilogue_plane_kernel(chi, b):
-    """psi' = psi x_(s,b) X with d = 2, chi_b = chi_b' = 32 (K = N = 64) in the pair-kernel shape, with the |psi'|^2 partials"""
-    rng = np.random.default_rng(sum(chi) + b)
-    z = len(chi)
-    flat, t = _site(rng, 2, chi)
-    x = rnd(rng, 64 * 64, np.complex64)
-    out = np.zeros_like(flat); nrm = C.c_double()
-    cchi = (C.c_int * z)(*chi)
-    rc = lib.tnqs_dbg_apply64(z, cchi, b, flat.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(nrm))
-    assert rc == 0
-    X = x.reshape(32, 2, 32, 2).astype(np.complex128)                   # [b', s', b, s]  (X[(s + 2 b) + 64 (s' + 2 b')])
-    tt = np.moveaxis(t, 1 + b, 1)                                        # [s, b, rest...]
-    ref = np.einsum("sb...,qpbs->pq...", tt, X)                          # [s', b', rest...]
-    ref = np.moveaxis(ref, 1, 1 + b)
-    got = out.reshape((2,) + tuple(chi), order="F")
-    assert np.max(np.abs(got - ref)) < 3e-5 * np.max(np.abs(ref))
-    assert abs(nrm.value - np.sum(np.abs(ref) ** 2)) < 1e-5 * np.sum(np.abs(ref) ** 2)
-
-
 @pytest.mark.parametrize("chi,lx,ly", PAIR_SHAPES)
 def test_double_pair_gram(chi, lx, ly):
     """both messages of a plane from one pass over (X, Y): the second one reads the same LDS planes transposed"""

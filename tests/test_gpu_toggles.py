@@ -47,13 +47,13 @@ def test_lowrank_theta_route_matches_the_full_svd():
     assert on["uncapped"]["lowrank"] == 0 and on["uncapped"]["dim"] == off["uncapped"]["dim"] and on["uncapped"]["dim"] > 16
 
 
-@pytest.mark.parametrize("switch", ["TNQS_NO_CHOL", "TNQS_NO_SMALLSVD", "TNQS_JACOBI_GLOBAL", "TNQS_NO_PAIR", "TNQS_NO_TSHARE", "TNQS_NO_FUSED_GRAM",
-                                    "TNQS_NO_APPLY64", "TNQS_NO_MFMA", "TNQS_EAGER_SCALE", "TNQS_NO_PREFIX", "TNQS_NO_ROWGEMM32", "TNQS_NO_3M",
-                                    "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE", "TNQS_NO_OPTIMISTIC_BP", "TNQS_NO_PRECOND_SVD", "TNQS_NO_SMALL_SITE_BP", "TNQS_NO_BF16X3"])
+@pytest.mark.parametrize("switch", ["TNQS_NO_CHOL", "TNQS_NO_SMALLSVD", "TNQS_JACOBI_GLOBAL", "TNQS_NO_PAIR", "TNQS_NO_MFMA", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE",
+                                    "TNQS_NO_SPECULATION", "TNQS_NO_PRECOND_SVD", "TNQS_NO_SMALL_SITE_BP", "TNQS_NO_BF16X3"])
 def test_alternative_routes_match_the_default(switch):
-    """every documented switch selects an alternative route of the same algorithm: all-eigen factorisation instead
-    of Cholesky, Gram-eigen instead of the small-SVD route, global-memory Jacobi, single-leg mode products, per-message BP products,
-    unfused Grams, generic apply, no MFMA kernels at all, eager normalisation, no shared partial products in BP.  Same bond dimensions; truncation errors and <Z> to f32
+    """every switch the library still has (csrc/engine_internal.hpp: one alternative route per kernel family -- round 6 deleted the A/B levers of decisions long
+    made) selects another route of the same algorithm: all-eigen factorisation instead of Cholesky, Gram-eigen instead of the small-SVD route, global-memory
+    Jacobi, single-leg mode products, no matrix-core kernels at all, one-site gates applied at once, no remembered BP products, no run-ahead, plain Jacobi,
+    no small-site kernel, f32 matrix instructions.  Same bond dimensions; truncation errors and <Z> to f32
     rounding of the whole layer (bounds 2e-3 relative / 1e-5; the switch must at least run -- an intermediate version of the per-site Cholesky
     fallback crashed under TNQS_NO_CHOL without any test noticing)."""
     ref, alt = run_worker({}), run_worker({switch: "1"})
@@ -79,11 +79,11 @@ def test_staging_arena_overflow_keeps_descriptors_alive():
         assert ref[name]["z"] == alt[name]["z"], name
 
 
-@pytest.mark.parametrize("switch", ["TNQS_NO_GAUGE_GRAM", "TNQS_TWO_ROUNDTRIPS", "TNQS_NO_3M", "TNQS_NO_DEFER_1SITE", "TNQS_NO_BP_SPLIT", "TNQS_NO_OPTIMISTIC_BP", "TNQS_NO_PRECOND_SVD", "TNQS_NO_BF16X3"])
+@pytest.mark.parametrize("switch", ["TNQS_NO_DEFER_1SITE", "TNQS_NO_SPECULATION", "TNQS_NO_PRECOND_SVD", "TNQS_NO_BF16X3", "TNQS_NO_PAIR"])
 def test_bulk_shape_routes_match(switch):
-    """the chi = 32 bulk shape (BASELINE configs[1]): the third gauge leg absorbed inside the f64 Gram kernel (kernels_gate.hip) against the
-    separate single-leg pass + plain Gram; ranks of the R factors left on the device against read back; three- against four-multiplication
-    products.  Same bond dimensions, truncation errors (relative), <Z> and message spectra to 1e-5."""
+    """the chi = 32 bulk shape (BASELINE configs[1]) on the alternative routes that touch it: one-site gates applied at once, no run-ahead (every batch reads its
+    results back, every update waits for its verdict), plain Jacobi for the theta SVD, f32 matrix instructions, single-leg products instead of the plane kernels.
+    Same bond dimensions, truncation errors (relative), <Z> and message spectra to 1e-5."""
     ref, alt = run_worker({}, "chi32"), run_worker({switch: "1"}, "chi32")
     assert ref["dims"] == alt["dims"]
     ea, eb = np.array(ref["errs"]), np.array(alt["errs"])
@@ -91,8 +91,8 @@ def test_bulk_shape_routes_match(switch):
     dz = float(np.max(np.abs(np.array(ref["z"]) - np.array(alt["z"])))); dsp = float(np.max(np.abs(np.array(ref["spectra"]) - np.array(alt["spectra"]))))
     print(switch, "max |dZ|", dz, " spectra", dsp, " max |derr|", float(np.max(np.abs(ea - eb))))
     assert dz < 1e-5 and dsp < 1e-5
-    if switch == "TNQS_NO_GAUGE_GRAM":      # the fused route must actually have been taken: it saves the single-leg launches of the gauge
-        assert ref["modeprod_launches"] < alt["modeprod_launches"] and ref["gram_launches"] > alt["gram_launches"]
+    if switch == "TNQS_NO_PAIR":            # the plane route must actually have been taken by the default: it saves single-leg launches
+        assert ref["modeprod_launches"] < alt["modeprod_launches"]
 
 
 def test_torch_can_be_imported_after_the_library():
@@ -131,16 +131,14 @@ def test_chi16_plane_kernels_match_the_single_leg_route():
     assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-5
 
 
-@pytest.mark.parametrize("switch", ["TNQS_NO_SMALL_SITE_MFMA", "TNQS_NO_SMALL_SITE_FINALIZE", "TNQS_NO_SMALL_SITE_BP"])
-def test_small_site_message_kernel_forms_match(switch):
+def test_small_site_message_kernel_matches_the_generic_route():
     """heavy-hex at chi = 16: the whole message of a small site in one LDS-resident kernel (kernels.hip bp_small_site_kernel) -- on the f32 matrix cores when every
-    leg is 16-dimensional, with the normalisation and message_diff of msg_finalize_kernel inside -- against its scalar form, against the separate epilogue launch and
-    against the generic chain + Gram route.  Messages after three sweeps elementwise (same site tensors, same order), then one layer."""
+    leg is 16-dimensional, with the normalisation and message_diff of msg_finalize_kernel inside -- against the generic chain + Gram route.  Messages after three
+    sweeps elementwise (same site tensors, same order), then one layer."""
+    switch = "TNQS_NO_SMALL_SITE_BP"
     on, off = run_worker({}, "hh16"), run_worker({switch: "1"}, "hh16")
-    if switch == "TNQS_NO_SMALL_SITE_FINALIZE":
-        assert on["small"] < off["small"], (on["small"], off["small"])          # the epilogue launches are gone
-    if switch == "TNQS_NO_SMALL_SITE_BP":
-        assert on["modeprod"] < off["modeprod"], (on["modeprod"], off["modeprod"])
+    assert on["modeprod"] < off["modeprod"], (on["modeprod"], off["modeprod"])
+    assert on["small"] < off["small"], (on["small"], off["small"])          # (the epilogue launches are gone too)
     worst = 0.0
     for ma, mb in zip(on["msgs"], off["msgs"]):
         a = np.array(ma[0]) + 1j * np.array(ma[1]); b = np.array(mb[0]) + 1j * np.array(mb[1])
@@ -177,22 +175,10 @@ def test_partial_products_kept_across_levels_change_nothing_but_the_pass_count()
     assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-5
 
 
-def test_chi16_gauge_leg_inside_the_gram_matches_the_separate_pass():
-    """3x3x3 torus, chi = 16: the fifth gauge leg absorbed inside the f64 Gram kernel (mfma_gauge_gram32_kernel, kernels_gate.hip) against
-    a single-leg pass + plain Gram (TNQS_NO_GAUGE_GRAM=1).  The gauged tensor is rounded to f32 at the same place on both routes, so the Gram
-    matrices agree to f64 summation order: same layer to f32 rounding of the downstream factorisations."""
-    on, off = run_worker({}, "cubic16"), run_worker({"TNQS_NO_GAUGE_GRAM": "1"}, "cubic16")
-    assert on["dims"] == off["dims"]
-    ea, eb = np.array(on["errs"]), np.array(off["errs"])
-    print("chi = 16 fused gauge + Gram: max |derr|", float(np.max(np.abs(ea - eb))), " max |dZ|", float(np.max(np.abs(np.array(on["z"]) - np.array(off["z"])))))
-    assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7)
-    assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-5
-
-
 def test_f64_matrix_core_kernels_match_the_vector_kernels():
     """ComplexF64 state: mode products, Grams and the gate epilogue on the f64 matrix cores (kernels_f64.hip) against the generic vector kernels
-    (TNQS_NO_F64_MFMA=1).  The same f64 arithmetic in a different summation order: bond dimensions, truncation errors, <Z> and message spectra to 1e-10."""
-    on, off = run_worker({}, "c128"), run_worker({"TNQS_NO_F64_MFMA": "1"}, "c128")
+    (TNQS_NO_MFMA=1).  The same f64 arithmetic in a different summation order: bond dimensions, truncation errors, <Z> and message spectra to 1e-10."""
+    on, off = run_worker({}, "c128"), run_worker({"TNQS_NO_MFMA": "1"}, "c128")
     for name in ("Rzz", "SWAP"):
         a, b = on[name], off[name]
         assert a["dims"] == b["dims"], name
@@ -255,13 +241,28 @@ def test_c128_lowrank_theta_route_matches_the_full_svd():
 def test_optimistic_bp_update_starts_over_when_its_sweep_did_not_converge():
     """Inside apply_gates a BP update returns after enqueuing its first sweep; the batch that follows prepares itself meanwhile and reads the verdict before its
     first launch.  Here every update needs several sweeps (tight tolerance, strong gates): the verdict is negative each time, the update is
-    continued and the batch starts over -- same sweep counts and bit-identical results as with blocking updates (TNQS_NO_OPTIMISTIC_BP=1)."""
-    on, off = run_worker({}, "tolsweeps"), run_worker({"TNQS_NO_OPTIMISTIC_BP": "1"}, "tolsweeps")
+    continued and the batch starts over -- same sweep counts and bit-identical results as with blocking updates (TNQS_NO_SPECULATION=1)."""
+    on, off = run_worker({}, "tolsweeps"), run_worker({"TNQS_NO_SPECULATION": "1"}, "tolsweeps")
     for k in ("complex64", "complex128"):
         a, b = on[k], off[k]
         assert a["sweeps"] == b["sweeps"] and a["updates"] == b["updates"] == 5 and a["sweeps"] > 2 * a["updates"], (a["sweeps"], b["sweeps"])
         assert a["not_converged"] == b["not_converged"]
         assert a["dims"] == b["dims"] and a["errs"] == b["errs"] and a["z"] == b["z"]
+
+
+def test_failed_deferred_verification_reruns_the_step_with_identical_results():
+    """round 6: apply_gates runs ahead of the device (engine.hpp Check) -- gate batches whose bonds sit at their cap are enqueued without their host round trip,
+    BP updates leave their verdict pending.  Here the assumptions FAIL on purpose (a cutoff that bites at saturated bonds; updates that need several sweeps): every
+    failed check puts the snapshot of the state back, drains the stream and runs the step again the careful way.  Bit-identical bond dimensions, truncation
+    errors, sweep counts and <Z> to a run that never ran ahead; and the run-ahead route must actually have been taken and have failed."""
+    on, off = run_worker({}, "specfail"), run_worker({"TNQS_NO_SPECULATION": "1"}, "specfail")
+    for k in ("complex64", "complex128"):
+        a, b = on[k], off[k]
+        assert b["spec"] == 0 and b["redone"] == 0
+        assert a["spec"] > 0 and a["redone"] > 0, (k, a["spec"], a["redone"])
+        assert a["dims"] == b["dims"] and a["sweeps"] == b["sweeps"], k
+        assert a["errs"] == b["errs"] and a["z"] == b["z"], k
+        assert min(min(d) for d in a["dims"][:2]) < 8                      # the cutoff did bite
 
 
 def test_a_failing_batch_leaves_the_state_as_it_was():
