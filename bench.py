@@ -386,8 +386,8 @@ def main():
     elif cfg == "c5":
         KERNEL_OF.update({"bp_modeprod": "tnqs::mfma_rowgemm_kernel<2, 2, 1>", "gate_modeprod": "tnqs::mfma_rowgemm_kernel<2, 2, 1>", "bp_gram": "tnqs::mfma_gram64_kernel",
                           "gate_gram": "tnqs::mfma_gram128_f64_kernel", "gate_apply": "tnqs::mfma_rowgemm_kernel<4, 4, 2>"})
-    traffic_db, traffic_src = profile_db(os.environ.get("TNQS_BENCH_PMC_PROFILE", "r5_pmc_traffic.json"))
-    mfma_db, mfma_src = profile_db(os.environ.get("TNQS_BENCH_MFMA_PROFILE", "r5_mfma_util.json"))
+    traffic_db, traffic_src = profile_db(os.environ.get("TNQS_BENCH_PMC_PROFILE", "r6_pmc_traffic.json"))
+    mfma_db, mfma_src = profile_db(os.environ.get("TNQS_BENCH_MFMA_PROFILE", "r6_mfma_util.json"))
     dom = max(prof, key=lambda k: prof[k]["ms"] if prof[k]["bytes"] > 0 else -1.0)      # (the tensor-pass class with the most time: the per-gate factorisation classes book no bytes)
     p = prof[dom]
     roofline = None

@@ -193,7 +193,9 @@ template <class T> static void apply_two_site_batch(State* s, const std::vector<
     // bites), the whole chain can be sized from upper bounds (ComplexF32, every theta within the LDS-resident kernels), single rank.  Then the read-back of the
     // batch -- ranks, new bond dimensions, statuses, truncation errors, every fallback flag -- is only STAGED, the epilogue is launched for bond dimension = cap,
     // and the verification happens when the staged copy has arrived (settle).  Anything the assumptions do not cover fails the check and the batch is redone.
-    bool spec = allow_spec && !sharded && ao.maxdim > 0;
+    // (ComplexF64 with the second factorisation pass: an evolution flags ill-conditioned sites in almost every batch -- 40 per layer of a 4 x 4 lattice --, which is a
+    //  read-back the careful route needs anyway: nothing to run ahead on)
+    bool spec = allow_spec && !sharded && ao.maxdim > 0 && (std::is_same<T, float>::value || !use_qr2());
     for (size_t k = 0; k < gates_in.size() && spec; ++k) {
         const int v1 = gates_in[k].v1, v2 = gates_in[k].v2; const int chi = s->chi[g.edge(v1, v2)];
         const int Mr = std::max(s->d[v1], s->d[v2]) * std::max(s->d[v1], s->d[v2]) * chi, Nc = std::min(s->d[v1], s->d[v2]) * std::min(s->d[v1], s->d[v2]) * chi;

@@ -259,10 +259,11 @@ def test_failed_deferred_verification_reruns_the_step_with_identical_results():
     for k in ("complex64", "complex128"):
         a, b = on[k], off[k]
         assert b["spec"] == 0 and b["redone"] == 0
-        assert a["spec"] > 0 and a["redone"] > 0, (k, a["spec"], a["redone"])
+        assert a["redone"] > 0 and (a["spec"] > 0 or k == "complex128"), (k, a["spec"], a["redone"])      # (ComplexF64 batches never run ahead: the second factorisation pass needs its read-back; their BP updates do)
         assert a["dims"] == b["dims"] and a["sweeps"] == b["sweeps"], k
         assert a["errs"] == b["errs"] and a["z"] == b["z"], k
-        assert min(min(d) for d in a["dims"][:2]) < 8                      # the cutoff did bite
+        assert max(a["dims"][3]) == 8 and min(min(d) for d in a["dims"][4:6]) < 8      # saturated after four layers; then the cutoff did bite
+        print(k, "batches enqueued on assumptions:", a["spec"], " steps redone:", a["redone"], " bond dimensions after the cutoff layers:", sorted(set(a["dims"][5])))
 
 
 def test_a_failing_batch_leaves_the_state_as_it_was():

@@ -125,23 +125,22 @@ def hh16():
 
 
 def specfail():
-    """deferred verification that FAILS (engine.hpp Check): every bond sits at its cap, so apply_gates enqueues the batches without their host round trip, assuming
-    the new bond dimension is the cap again -- but the cutoff (1e-3 here) bites and most bonds come out smaller; then BP updates that need several sweeps.  Each
-    failed check puts the snapshot back and reruns the step the careful way: results must be those of a run that never ran ahead (TNQS_NO_SPECULATION=1)."""
+    """deferred verification that FAILS (engine.hpp Check).  A TFIM evolution from the product state: the bonds grow to the cap (8) within four layers and carry a
+    decaying spectrum.  From then on every bond sits at its cap, so apply_gates enqueues the batches without their host round trip, assuming the new bond dimension is
+    the cap again -- but with cutoff = 1e-4 the tail of the spectrum is cut and bonds come out smaller; and with a tight tolerance the BP updates need several
+    sweeps.  Each failed check puts the snapshot back and reruns the step the careful way: results must be those of a run that never ran ahead (TNQS_NO_SPECULATION=1)."""
     out = {}
     for dt in (np.complex64, np.complex128):
         g = tn.named_grid((4, 4))
-        psi = tn.random_tensornetworkstate(dt, g, bond_dimension=8, seed=11)
-        bpc = tn.update(tn.BeliefPropagationCache(psi), maxiter=40, tolerance=None)
+        bpc = tn.BeliefPropagationCache(tn.tensornetworkstate(dt, lambda v: "↑", g))
         layer = [("Rx", [v], 0.3) for v in g.vertices] + [("Rzz", [a, b], 0.4) for grp in tn.edge_color(g, 4) for (a, b) in grp]
         res = dict(errs=[], dims=[], z=[], spec=0, redone=0, sweeps=0)
-        for cutoff, bpkw in ((1e-3, dict(maxiter=25, tolerance=1e-4)), (1e-10, dict(maxiter=25, tolerance=1e-9)), (1e-10, dict(maxiter=25, tolerance=1e-4))):
-            for _ in range(2):
-                info = {}
-                bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=8, cutoff=cutoff, normalize_tensors=True), bp_update_kwargs=bpkw, info=info)
-                res["errs"] += errs.tolist(); res["dims"].append([bpc.bond_dim(a, b) for a, b in g.edges])
-                res["spec"] += info["n_spec_batches"]; res["redone"] += info["n_spec_redone"]; res["sweeps"] += info["n_sweeps"]
-            # back to saturated bonds for the next round: the truncated bonds regrow under the next layers (maxdim 8)
+        rounds = [(1e-12, dict(maxiter=25, tolerance=1e-6))] * 4 + [(1e-4, dict(maxiter=25, tolerance=1e-6))] * 2 + [(1e-12, dict(maxiter=25, tolerance=1e-9))] * 2 + [(1e-12, dict(maxiter=25, tolerance=1e-3))] * 4
+        for cutoff, bpkw in rounds:
+            info = {}
+            bpc, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=8, cutoff=cutoff, normalize_tensors=True), bp_update_kwargs=bpkw, info=info)
+            res["errs"] += errs.tolist(); res["dims"].append([bpc.bond_dim(a, b) for a, b in g.edges])
+            res["spec"] += info["n_spec_batches"]; res["redone"] += info["n_spec_redone"]; res["sweeps"] += info["n_sweeps"]
         res["z"] = [float(np.real(tn.expect(bpc, ("Z", [v])))) for v in g.vertices]
         out[np.dtype(dt).name] = res
     print(json.dumps(out))
