@@ -49,31 +49,36 @@ def random_state_tensors(g, chi, d, seed, dtype, wanted=None):
 
 
 def cpu_baseline(chi, L, seed=1234):
-    """CPU restatement of the reference path, organised for a many-core host (oracle/cpu_layer.py: the oracle's arithmetic -- GEMM-shaped
-    mode products, LAPACK QR / SVD, f64 eigen -- with the messages of a BP dependency level and the gates of a colour group running
-    concurrently, one BLAS thread each) on a bounded sample of the benchmark workload: ONE TFIM layer of the benchmark's own L x L OPEN
-    lattice at the same chi / dtype, reference-default BP kwargs, on ALL cores of the host: numpy's OpenBLAS admits 64 concurrent callers
-    per process, so a 2 x 64-core box runs two pinned processes of 64 threads, each one layer of its own copy of the lattice, and the
-    aggregate rate is reported.  Next to it: the host BLAS rates measured in the same processes (it is NOT the Julia package)."""
+    """COMPILED CPU restatement of the reference path (oracle/cpu_port.cpp, round 6: C++ / OpenMP over scipy's OpenBLAS -- mode products as GEMMs on views, thin
+    Householder QR in row blocks, cgesdd, f64 Hermitian eigen; pinned against the numpy oracle in tests/test_cpu_port.py) on a bounded sample of the benchmark
+    workload: ONE TFIM layer of the benchmark's own L x L OPEN lattice at the same chi / dtype, reference-default BP kwargs, on every core this container may use
+    (cpu_port.cpu_budget: the GPU boxes run under a cgroup quota of 16 CPUs of the 2 x 64-core host) -- the messages of a BP dependency level and the gates of a colour
+    group on an OpenMP team, one BLAS thread per call.  Next to it: the host's BLAS rates on a square GEMM and on the workload's mode-product shape, same thread count
+    (it is NOT the Julia package)."""
+    import cpu_port
     import cpu_layer
-    m = cpu_layer.measure_host(chi=chi, L=L, periodic=False, seed=seed)
+    from concurrent.futures import ThreadPoolExecutor
+    m = cpu_port.measure_host(chi=chi, L=L, periodic=False, seed=seed)
+    with ThreadPoolExecutor(max_workers=m["threads_per_process"]) as pool:
+        rates = cpu_layer._gemm_rates(chi, m["threads_per_process"], pool)
     host = "unknown CPU"
     try:
         with open("/proc/cpuinfo") as f:
             models = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
         if models:
-            host = f"{models[0]} ({len(models)} hardware threads)"
+            host = f"{models[0]} ({len(models)} hardware threads" + (f", cgroup quota {m['cpu_quota']:g} CPUs)" if m.get("cpu_quota") else ")")
     except OSError:
         pass
-    return {"value": m["gates_per_s"], "unit": "two-site gates/s", "cores": int(m["threads"]), "kind": "port", "host": host,
+    return {"value": m["gates_per_s"], "unit": "two-site gates/s", "cores": int(m["threads"]), "kind": "port", "compiled": True, "host": host,
             "processes": m["processes"], "threads_per_process": m["threads_per_process"], "per_process_gates_per_s": m["per_process_gates_per_s"],
-            "algorithmic_gflops": m["algorithmic_gflops"], "host_square_cgemm_gflops_per_process": m["square_cgemm_gflops"],
-            "host_mode_product_shape_gflops_per_process": m["mode_product_shape_gflops"],
-            "frac_of_host_square_cgemm": m["frac_of_square_cgemm"], "frac_of_host_mode_product_shape": m["frac_of_mode_product_shape"],
-            "bp_sweeps": m["bp_sweeps"],
+            "algorithmic_gflops": m["algorithmic_gflops"], "host_square_cgemm_gflops_per_process": rates["square_cgemm_gflops"],
+            "host_mode_product_shape_gflops_per_process": rates["mode_product_shape_gflops"],
+            "frac_of_host_square_cgemm": round(m["algorithmic_gflops"] / (m["processes"] * rates["square_cgemm_gflops"]), 3),
+            "frac_of_host_mode_product_shape": round(m["algorithmic_gflops"] / (m["processes"] * rates["mode_product_shape_gflops"]), 3),
+            "bp_sweeps": m["bp_sweeps"], "thread_seconds_per_layer": m.get("thread_seconds_per_layer"), "wall_seconds_per_layer": m.get("wall_seconds_per_layer"),
             "sample": f"1 TFIM layer ({m['n_two_site']} two-site gates, {len(m['bp_sweeps'])} BP updates, sweeps {m['bp_sweeps']}) of the {L}x{L} open "
                       f"lattice ({m['sites']} sites) per process, {m['processes']} process(es) x {m['threads_per_process']} threads at the same time, chi={chi}, "
-                      f"complex64, threaded numpy/LAPACK port of the reference path (oracle/cpu_layer.py); {m['seconds_per_layer']:.1f} s per layer"}
+                      f"complex64, compiled C++ / OpenMP / OpenBLAS restatement of the reference path (oracle/cpu_port.cpp); {m['seconds_per_layer']:.1f} s per layer"}
 
 
 def spawn_ranks(n):
@@ -191,7 +196,7 @@ def main_c1(args, tn, torch):
                 with open("/proc/cpuinfo") as f:
                     models = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
                 if models:
-                    host = f"{models[0]} ({len(models)} hardware threads)"
+                    host = f"{models[0]} ({len(models)} hardware threads" + (f", cgroup quota {m['cpu_quota']:g} CPUs)" if m.get("cpu_quota") else ")")
             except OSError:
                 pass
             out["cpu_baseline"] = {"value": round(n2 * args.steps / cpu_s, 2), "unit": "two-site gates/s", "cores": 1, "kind": "port", "host": host,

@@ -320,7 +320,8 @@ def measure_host(chi: int = 32, L: int = 20, periodic: bool = False, nproc: Opti
         cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:
         cpus = list(range(os.cpu_count() or 1))
-    ncores = max(1, len(cpus) // 2) if len(cpus) >= 4 else len(cpus)          # SMT-2: physical cores = half the hardware threads
+    from cpu_port import cpu_budget
+    ncores, _ = cpu_budget()                                                     # physical cores, capped by the cgroup's CPU quota
     nproc = nproc or max(1, min(4, ncores // 64))
     per = max(1, min(64, ncores // nproc))
     procs = []

@@ -182,8 +182,7 @@ bool launch_mfma_gram64(hipStream_t s, const GramItem* d_items, int nitems, int 
     if (total_chunks <= 0) return true;
     if (mfma_use_x3()) return launch_x3_gram64(s, d_items, nitems, total_chunks, KKmax);
     const size_t lds = (size_t)4 * 64 * 68 * sizeof(float);
-    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_gram64_kernel<true>, lds); hipLaunchKernelGGL(mfma_gram64_kernel<true>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }
-    else { set_max_dynamic_lds((const void*)mfma_gram64_kernel<false>, lds); hipLaunchKernelGGL(mfma_gram64_kernel<false>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }
+    set_max_dynamic_lds((const void*)mfma_gram64_kernel<true>, lds); hipLaunchKernelGGL(mfma_gram64_kernel<true>, dim3(total_chunks), dim3(256), lds, s, d_items, nitems);
     TNQS_CHECK_LAUNCH();
     return true;
 }
@@ -517,7 +516,7 @@ template <int KB, int NB, int D> static void launch_rowgemm_t(hipStream_t s, con
     const size_t lds = (size_t)(16 * KB) * NB * 64 * sizeof(v2f);
     // three-multiplication product except for K = N = 128: its 16 blocks x 3 accumulators do not fit next to the operand registers (21 spills)
     constexpr bool fits3 = KB * NB <= 4;
-    if (fits3 && mfma_use_3m()) {
+    if (fits3) {
         set_max_dynamic_lds((const void*)mfma_rowgemm_kernel<KB, NB, D, fits3>, lds);
         hipLaunchKernelGGL((mfma_rowgemm_kernel<KB, NB, D, fits3>), dim3(total_wgs), dim3(256), lds, s, d_items, nitems, d_norm_partials);
     } else {
@@ -725,8 +724,7 @@ bool launch_mfma_gram128_f64(hipStream_t s, const GramItem* d_items, int nitems,
     if (total_chunks <= 0) return true;
     const size_t lds = (size_t)4 * 128 * 68 * sizeof(float);
 #define TNQS_G128(M3, SH) { set_max_dynamic_lds((const void*)mfma_gram128_f64_kernel<M3, SH>, lds); hipLaunchKernelGGL((mfma_gram128_f64_kernel<M3, SH>), dim3(total_chunks), dim3(256), lds, s, d_items, nitems); }
-    if (mfma_use_3m()) { if (all_kk128) TNQS_G128(true, true) else TNQS_G128(true, false) }
-    else { if (all_kk128) TNQS_G128(false, true) else TNQS_G128(false, false) }
+    if (all_kk128) TNQS_G128(true, true) else TNQS_G128(true, false)
 #undef TNQS_G128
     TNQS_CHECK_LAUNCH();
     return true;

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void mfma_gauge_gram64_kernel(const GramIte
 // tiles of 64 fibers = (all 32 values of r) x (2 values of the next outer index)
 bool gauge_gram64_covers(int d, int z, const int* chi, int bleg, int rleg) {
     if (d != 2 || z < 3 || bleg < 0 || bleg >= z || rleg < 0 || rleg >= z || rleg == bleg) return false;
-    if (chi[bleg] != 32 || chi[rleg] != 32 || !mfma_use_3m()) return false;
+    if (chi[bleg] != 32 || chi[rleg] != 32) return false;
     if (rleg != (bleg == 0 ? 1 : 0)) return false;
     long long pre = 1; for (int i = 0; i < bleg; ++i) pre *= chi[i];          // PA (site index excluded)
     long long post = 1; for (int i = bleg + 1; i < z; ++i) post *= chi[i];     // PB
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, 3) void mfma_gauge_gram32_kernel(const GramIte
 // whole fibers of r contiguous in 256-byte runs (everything below the bond is a multiple of 16 fibers, or the bond is leg 0)
 bool gauge_gram32_covers(int d, int z, const int* chi, int bleg, int rleg) {
     if (d != 2 || z < 2 || bleg < 0 || bleg >= z || rleg < 0 || rleg >= z || rleg == bleg) return false;
-    if (chi[bleg] != 16 || chi[rleg] != 16 || !mfma_use_3m()) return false;
+    if (chi[bleg] != 16 || chi[rleg] != 16) return false;
     if (rleg != (bleg == 0 ? 1 : 0)) return false;
     return true;
 }

@@ -784,8 +784,7 @@ void launch_mfma_pair(hipStream_t s, const PairItem* d_items, int nitems, int to
     if (total_wgs <= 0) return;
     if (mfma_use_x3()) { launch_x3_pair(s, d_items, nitems, total_wgs); return; }
     const size_t lds = (size_t)16 * (32 * 33 + 4) * 2 * sizeof(float);
-    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_pair_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
-    else { set_max_dynamic_lds((const void*)mfma_pair_kernel<false>, lds); hipLaunchKernelGGL(mfma_pair_kernel<false>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    set_max_dynamic_lds((const void*)mfma_pair_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
     TNQS_CHECK_LAUNCH();
 }
 
@@ -1075,13 +1074,8 @@ void launch_mfma_pair_gram2(hipStream_t s, const PairGram2Item* d_items, int nit
     if (total_wgs <= 0) return;
     if (mfma_use_x3()) { launch_x3_pair_gram2(s, d_items, nitems, total_wgs); return; }
     const size_t lds = (size_t)16 * (32 * 33 + 8) * 2 * sizeof(float);
-    if (mfma_use_3m()) {
-        set_max_dynamic_lds((const void*)mfma_pair_gram2_kernel<true>, lds);
-        hipLaunchKernelGGL(mfma_pair_gram2_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
-    } else {
-        set_max_dynamic_lds((const void*)mfma_pair_gram2_kernel<false>, lds);
-        hipLaunchKernelGGL(mfma_pair_gram2_kernel<false>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
-    }
+    set_max_dynamic_lds((const void*)mfma_pair_gram2_kernel<true>, lds);
+    hipLaunchKernelGGL(mfma_pair_gram2_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
     TNQS_CHECK_LAUNCH();
 }
 
@@ -1354,8 +1348,7 @@ bool launch_mfma_gram64_f64(hipStream_t s, const GramItem* d_items, int nitems, 
 #endif
     }
 #define TNQS_G64(M3, SH) { set_max_dynamic_lds((const void*)mfma_gram64_f64_kernel<M3, SH>, lds); hipLaunchKernelGGL((mfma_gram64_f64_kernel<M3, SH>), dim3(total_chunks), dim3(256), lds, s, d_items, nitems, skip); }
-    if (mfma_use_3m()) { if (all_kk64) TNQS_G64(true, true) else TNQS_G64(true, false) }
-    else { if (all_kk64) TNQS_G64(false, true) else TNQS_G64(false, false) }
+    if (all_kk64) TNQS_G64(true, true) else TNQS_G64(true, false)
 #undef TNQS_G64
     TNQS_CHECK_LAUNCH();
     return true;

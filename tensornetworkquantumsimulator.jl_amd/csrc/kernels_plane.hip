@@ -282,15 +282,13 @@ bool pair16_whole_lines(const PlaneGeom& g) {
 void launch_mfma_pair16(hipStream_t s, const Pair16Item* d_items, int nitems, int total_wgs, bool whole_lines) {
     if (total_wgs > 0 && whole_lines) {
         const size_t lds = (size_t)4 * 16 * PS16 * sizeof(v2f);
-        if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_pair16w_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair16w_kernel<true>, dim3(total_wgs), dim3(256), lds, s, d_items, nitems); }
-        else { set_max_dynamic_lds((const void*)mfma_pair16w_kernel<false>, lds); hipLaunchKernelGGL(mfma_pair16w_kernel<false>, dim3(total_wgs), dim3(256), lds, s, d_items, nitems); }
+        set_max_dynamic_lds((const void*)mfma_pair16w_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair16w_kernel<true>, dim3(total_wgs), dim3(256), lds, s, d_items, nitems);
         TNQS_CHECK_LAUNCH();
         return;
     }
     if (total_wgs <= 0) return;
     const size_t lds = (size_t)8 * 8 * PS16 * sizeof(v2f);
-    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_pair16_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair16_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
-    else { set_max_dynamic_lds((const void*)mfma_pair16_kernel<false>, lds); hipLaunchKernelGGL(mfma_pair16_kernel<false>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    set_max_dynamic_lds((const void*)mfma_pair16_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair16_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
     TNQS_CHECK_LAUNCH();
 }
 
@@ -484,8 +482,7 @@ int pair_gram2x16_slices_at_a_time() { return 4; }
 void launch_mfma_pair_gram2x16(hipStream_t s, const PairGram2x16Item* d_items, int nitems, int total_wgs) {
     if (total_wgs <= 0) return;
     const size_t lds = (size_t)8 * 8 * PS16 * sizeof(v2f);
-    if (mfma_use_3m()) { set_max_dynamic_lds((const void*)mfma_pair_gram2x16_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair_gram2x16_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
-    else { set_max_dynamic_lds((const void*)mfma_pair_gram2x16_kernel<false>, lds); hipLaunchKernelGGL(mfma_pair_gram2x16_kernel<false>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems); }
+    set_max_dynamic_lds((const void*)mfma_pair_gram2x16_kernel<true>, lds); hipLaunchKernelGGL(mfma_pair_gram2x16_kernel<true>, dim3(total_wgs), dim3(512), lds, s, d_items, nitems);
     TNQS_CHECK_LAUNCH();
 }
 

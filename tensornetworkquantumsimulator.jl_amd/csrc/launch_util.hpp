@@ -22,8 +22,7 @@ inline void set_max_dynamic_lds(const void* func, size_t bytes) {
     done[key] = bytes;
 }
 
-// Gauss' three-multiplication complex product in the f32 plane kernels (mfma_common.hpp, CAcc32).
-inline constexpr bool mfma_use_3m() { return true; }      // (the four-multiplication instantiations are kept for the shapes whose registers do not hold three accumulators)
+// (The f32 plane kernels form complex products with Gauss' three multiplications, mfma_common.hpp CAcc32; the K = N = 128 epilogue keeps four: its registers do not hold three accumulators per block.)
 
 // f32 products of the chi = 32 plane kernels on the bf16 matrix cores (three-way exact split, six products: kernels_x3.hip); TNQS_NO_BF16X3=1 keeps them on
 // v_mfma_f32_32x32x2_f32.
