@@ -143,7 +143,7 @@ def main_c1(args, tn, torch):
     reference-default BP kwargs.  A step = one layer (what examples/2dIsing_dynamics.jl:56-57 times); the timed region is the whole 50-layer run on a fresh state
     (bonds grow 1 -> 10 on the way), after --warmup layers on a scratch copy that only load the kernels.  The CPU leg runs the SAME 50 layers through the parity
     oracle (oracle/tnqs_oracle.py: the reference's algorithm gate by gate, message by message -- numpy / LAPACK, one thread, like the reference's sequential
-    Julia loop) on this box's host; 3 MB of state is far too small for a thread pool to pay (oracle/cpu_layer.py is the many-core organisation, for c2)."""
+    Julia loop) on this box's host; 3 MB of state is far too small for a thread pool to pay (oracle/cpu_port.cpp is the many-core organisation, for c2)."""
     chi, dtype = 10, np.complex128
     g, groups, layer = c1_circuit(tn)
     kw = dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True)
@@ -196,7 +196,7 @@ def main_c1(args, tn, torch):
                 with open("/proc/cpuinfo") as f:
                     models = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
                 if models:
-                    host = f"{models[0]} ({len(models)} hardware threads" + (f", cgroup quota {m['cpu_quota']:g} CPUs)" if m.get("cpu_quota") else ")")
+                    host = f"{models[0]} ({len(models)} hardware threads)"
             except OSError:
                 pass
             out["cpu_baseline"] = {"value": round(n2 * args.steps / cpu_s, 2), "unit": "two-site gates/s", "cores": 1, "kind": "port", "host": host,
