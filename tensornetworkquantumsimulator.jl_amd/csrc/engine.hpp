@@ -174,6 +174,7 @@ struct State {
     // the sharded code path: more than one rank -- or ONE rank made to take it (TNQS_FORCE_EXCHANGE=1 when tnqs_set_sharding_rccl is called): every exchange point packs
     // its block, runs the communicator's all-gather on the handle's stream and reads the gathered block back, which is all a single GPU can exercise of the RCCL transport
     bool force_exchange = false;
+    bool msg_hermitian = true;                       // no message handed in through set_message was non-Hermitian (engine_bp.cpp: products absorbed on the bra side)
     bool sharded() const { return nranks > 1 || force_exchange; }
     ~State();
 };

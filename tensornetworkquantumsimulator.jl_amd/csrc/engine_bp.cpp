@@ -395,6 +395,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) pcache.cap = std::min(pcache.cap, (fr + s->pool->bytes_cached()) / 3);
     }
     const bool cache_on = use_prodcache() && !plan.in_place;
+    const bool bra_on = use_bra_products() && s->msg_hermitian && !plan.in_place;
     const int nlev = (int)plan.levels.size();
     // levels until the message entering src through leg j changes again, seen from position t of the sequence (INT_MAX: never)
     auto horizon = [&](int src, int j, int t) -> int {
@@ -485,7 +486,7 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                 // outgoing message continues from T.  With the default linear-forest order a site sends two messages per level, so a degree-6
                 // site does 4 + 2 x 1 absorption passes per level instead of 2 x 5.  Reuse is decided by buffer identity per message (the
                 // Gauss-Seidel rule may give two messages of a site different versions of an incoming message), never assumed.
-                struct Prefix { Buf site; std::vector<std::pair<int, const void*>> legs; Buf prod; };
+                struct Prefix { Buf site; std::vector<std::pair<int, const void*>> legs; Buf prod, bra; bool has_bra = false; };      // legs: of both products
                 std::unordered_map<int, Prefix> prefix;
                 std::vector<Buf> hits_alive;          // remembered products this sub-batch continues from: the cache may drop its entry (last use, or the byte bound) before the launches
                 auto select_in = [&](int src, int j, int t) -> const Buf& {
@@ -499,41 +500,57 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                         int de = plan.seq[lev[q]]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e]; int dst = (de & 1) ? g.esrc[e] : g.edst[e];
                         if (s->owns(src) && generic_site(src, g.leg(src, dst))) outl[src].push_back(g.leg(src, dst));
                     }
-                    std::vector<Chain> pch; std::vector<int> psrc; std::vector<LegBufs> pbase, pabs;
+                    std::vector<Chain> pch; std::vector<int> psrc, pside; std::vector<LegBufs> pbase, pabs;
+                    // one product of the level: the legs `w` of site src absorbed into psi (continuing from a remembered product when there is one); side 1 = the bra product
+                    auto start_product = [&](int src, LegBufs w, int side) {
+                        Prefix& pf = prefix[src];
+                        Chain cp; cp.v = src; cp.src = s->site[src]->p; cp.sd = site_dims(s, src);
+                        LegBufs base;
+                        if (cache_on) {
+                            cp.ordered = true;
+                            ProdEntry hit;
+                            if (pcache.find(src, s->site[src], w, hit)) {
+                                base = hit.legs; cp.src = hit.prod->p; (side ? pf.bra : pf.prod) = hit.prod; hits_alive.push_back(hit.prod);      // (the product itself when nothing is left to absorb)
+                                LegBufs rest; for (auto& x : w) { bool in = false; for (auto& b : base) in = in || b.first == x.first; if (!in) rest.push_back(x); }
+                                w.swap(rest);
+                            }
+                        }
+                        for (auto& x : w) cp.steps.push_back({x.first, x.second->p});
+                        if (cp.steps.empty()) return;                                              // the whole product was remembered
+                        pch.push_back(std::move(cp)); psrc.push_back(src); pside.push_back(side); pbase.push_back(std::move(base)); pabs.push_back(std::move(w));
+                    };
                     for (size_t q = start; q < end; ++q) {
                         int t = lev[q]; int de = plan.seq[t]; int e = de / 2; int src = (de & 1) ? g.edst[e] : g.esrc[e];
                         auto ol = outl.find(src);
                         if (ol == outl.end() || ol->second.size() < 2 || prefix.count(src)) continue;
-                        Chain cp; cp.v = src; cp.src = s->site[src]->p; cp.sd = site_dims(s, src);
+                        const SD sd = site_dims(s, src);
                         Prefix pf; pf.site = s->site[src];
                         LegBufs want;
-                        for (int j = 0; j < cp.sd.z; ++j) {
+                        for (int j = 0; j < sd.z; ++j) {
                             if (std::find(ol->second.begin(), ol->second.end(), j) != ol->second.end()) continue;
                             const Buf& mb = select_in(src, j, t);
                             if (!mb) continue;
-                            want.push_back({j, mb}); pf.legs.push_back({j, mb->p});
+                            want.push_back({j, mb});
                         }
-                        if (pf.legs.empty()) continue;
-                        LegBufs base;
-                        if (cache_on) {
-                            by_stability(want, src, t); cp.ordered = true;
-                            ProdEntry hit;
-                            if (pcache.find(src, s->site[src], want, hit)) {
-                                base = hit.legs; cp.src = hit.prod->p; pf.prod = hit.prod; hits_alive.push_back(hit.prod);      // (pf.prod: the product itself when nothing is left to absorb)
-                                LegBufs rest; for (auto& w : want) { bool in = false; for (auto& b : base) in = in || b.first == w.first; if (!in) rest.push_back(w); }
-                                want.swap(rest);
-                            }
-                        }
-                        for (auto& w : want) cp.steps.push_back({w.first, w.second->p});
+                        if (want.empty()) continue;
+                        if (cache_on || bra_on) by_stability(want, src, t);
+                        // ---- half of the messages on the BRA side (round 6).  m_out = sum (psi x_K m_k x_B m_b) conj(psi) with the messages of the legs B moved over:
+                        // sum_b' m[b][b'] conj(psi[b']) = conj(sum_b' psi[b'] m[b'][b]) for a Hermitian m, i.e. conj(psi x_B m_b) -- the SAME two-leg product a ket
+                        // side would use.  So the Gram pass takes X = psi x_K m_k and Y = psi x_B m_b, both one pass away from psi, instead of X = a product over
+                        // K and B (two passes deep) and Y = psi; and the halves are split by how long their messages stay unchanged (an axis of a lattice each), so
+                        // that the product over an axis is built once per sweep and serves first as the ket, then as the bra factor of the other axes' levels: a
+                        // degree-6 site does 3 two-leg passes per sweep instead of 5.  Messages are Hermitian to rounding by construction (State::msg_hermitian).
+                        const size_t nket = (bra_on && want.size() >= 4) ? (want.size() + 1) / 2 : want.size();
+                        for (size_t i = 0; i < want.size(); ++i) pf.legs.push_back({want[i].first, want[i].second->p});
                         prefix[src] = pf;
-                        if (cp.steps.empty()) continue;                                            // the whole product was remembered
-                        pch.push_back(std::move(cp)); psrc.push_back(src); pbase.push_back(std::move(base)); pabs.push_back(std::move(want));
+                        start_product(src, LegBufs(want.begin(), want.begin() + (std::ptrdiff_t)nket), 0);
+                        if (nket < want.size()) { prefix[src].has_bra = true; start_product(src, LegBufs(want.begin() + (std::ptrdiff_t)nket, want.end()), 1); }
                     }
                     if (!pch.empty()) {
                         run_chains<T>(s, pch, TNQS_PROF_BP_MODEPROD, TNQS_PROF_BP_PAIR);
                         for (size_t i = 0; i < pch.size(); ++i) {
                             Prefix& pf = prefix[psrc[i]];
-                            for (int k = 0; k < 2; ++k) if (pch[i].tmp[k] && pch[i].tmp[k]->p == pch[i].result) pf.prod = pch[i].tmp[k];
+                            for (int k = 0; k < 2; ++k) if (pch[i].tmp[k] && pch[i].tmp[k]->p == pch[i].result) (pside[i] ? pf.bra : pf.prod) = pch[i].tmp[k];
                             if (cache_on) remember(pch[i], pf.site, pbase[i], pabs[i]);
                         }
                     }
@@ -607,10 +624,10 @@ template <class T> void bp_update_t(State* s, const tnqs_bp_opts* o, int* niter_
                     std::vector<char> done(c.sd.z, 0);                   // legs already absorbed in the shared partial product
                     {
                         auto pf = prefix.find(src);
-                        if (pf != prefix.end() && pf->second.prod && pf->second.site == s->site[src]) {
+                        if (pf != prefix.end() && pf->second.prod && (!pf->second.has_bra || pf->second.bra) && pf->second.site == s->site[src]) {
                             bool same = true;
                             for (auto& lm : pf->second.legs) { if (lm.first == jo) { same = false; break; } const Buf& mb = select_in(src, lm.first, t); if (!mb || mb->p != lm.second) { same = false; break; } }
-                            if (same) { c.y = c.src; c.src = pf->second.prod->p; for (auto& lm : pf->second.legs) done[lm.first] = 1; }
+                            if (same) { c.y = pf->second.has_bra ? pf->second.bra->p : c.src; c.src = pf->second.prod->p; for (auto& lm : pf->second.legs) done[lm.first] = 1; }
                         }
                     }
                     LegBufs want, base;

@@ -235,7 +235,7 @@ State* state_copy(const State* o) {
     s->site = o->site; s->sscale = o->sscale; s->msg = o->msg; s->pool = o->pool; s->prof = o->prof;
     s->pend1 = o->pend1; s->unit_norm = o->unit_norm;
     s->rank = o->rank; s->nranks = o->nranks; s->owner = o->owner; s->ag_fn = o->ag_fn; s->ag_ctx = o->ag_ctx;
-    s->exch = o->exch; s->exch_bytes = o->exch_bytes; s->comm = o->comm; s->force_exchange = o->force_exchange;
+    s->exch = o->exch; s->exch_bytes = o->exch_bytes; s->comm = o->comm; s->force_exchange = o->force_exchange; s->msg_hermitian = o->msg_hermitian;
     HIPCHK(hipSetDevice(o->device));
     if (o->own_stream) { HIPCHK(hipStreamSynchronize(o->stream)); s->stream = acquire_stream(o->device); s->own_stream = true; }
     else { s->stream = o->stream; s->own_stream = false; }
@@ -363,6 +363,19 @@ void state_set_message(State* s, int src, int dst, const void* host, int chi) {
     HIPCHK(hipSetDevice(s->device));
     Buf b = dalloc(s, (size_t)chi * chi * s->esz());
     std::vector<char> widened; if (s->real_io) { widened = widen_real(s, host, (size_t)chi * chi); host = widened.data(); }
+    {   // BP may absorb a message on the bra side as its own conjugate transpose (engine_bp.cpp): true of every message the path itself produces (identity, diag(S),
+        // updates from Hermitian messages), to rounding; a caller's message that is not Hermitian switches that route off for this handle
+        auto herm = [&](auto* m, double tol) {
+            double big = 0, dev = 0;
+            for (int i = 0; i < chi; ++i) for (int j = 0; j <= i; ++j) {
+                const double ar = m[2 * ((size_t)i * chi + j)], ai = m[2 * ((size_t)i * chi + j) + 1], br = m[2 * ((size_t)j * chi + i)], bi = m[2 * ((size_t)j * chi + i) + 1];
+                big = std::max(big, std::max(std::fabs(ar) + std::fabs(ai), std::fabs(br) + std::fabs(bi))); dev = std::max(dev, std::fabs(ar - br) + std::fabs(ai + bi));
+            }
+            return dev <= tol * big;
+        };
+        const bool ok = s->dtype == TNQS_C64 ? herm(reinterpret_cast<const float*>(host), 1e-5) : herm(reinterpret_cast<const double*>(host), 1e-12);
+        if (!ok) s->msg_hermitian = false;
+    }
     HIPCHK(hipMemcpyAsync(b->p, host, (size_t)chi * chi * s->esz(), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->msg[de] = b;

@@ -35,6 +35,7 @@ inline bool envflag(const char* name) { const char* e = std::getenv(name); retur
 #define TNQS_SWITCH(fn, expr) inline bool fn() { static const bool v = (expr); return v; }
 TNQS_SWITCH(use_mfma, !envflag("TNQS_NO_MFMA"))                  // no matrix-core kernel at all: the generic tiled kernels (kernels.hip), any dims / element type
 TNQS_SWITCH(use_pair, !envflag("TNQS_NO_PAIR"))                  // no plane kernels (two legs per pass, pair-Gram, chi = 16 / 32): single-leg matrix-core products
+TNQS_SWITCH(use_bra_products, !envflag("TNQS_NO_BRA_PRODUCTS"))  // BP: every message absorbed on the ket side (engine_bp.cpp: sites of degree >= 6 absorb half of them on the bra side)
 TNQS_SWITCH(use_prodcache, !envflag("TNQS_NO_PRODCACHE"))        // BP: no partial product kept from one level to the next (engine_bp.cpp ProdCache)
 TNQS_SWITCH(use_chol, !envflag("TNQS_NO_CHOL"))                  // R factor from the eigen factorisation of the Gram matrix instead of Cholesky (the route a collapsed pivot falls back to)
 TNQS_SWITCH(use_qr2, !envflag("TNQS_NO_QR2"))                    // ComplexF64: no second factorisation pass

@@ -444,6 +444,36 @@ def test_default_order_on_periodic_lattices_matches_oracle(lattice):
         assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oc, Z, v)) < 2e-5
 
 
+@pytest.mark.parametrize("hermitian", [True, False])
+def test_degree6_sweeps_from_caller_supplied_messages_match_oracle(hermitian):
+    """3x3x3 torus (degree 6): BP sweeps started from messages the CALLER sets.  Hermitian ones (what the path itself produces) may be absorbed on the bra side
+    (engine_bp.cpp: half of a level's messages, as the conjugate of the ket-side product); a message that is NOT Hermitian may not -- the reference absorbs every
+    message on the ket side (abstractbeliefpropagationcache.jl:162-190) and the two only coincide for m = m^dagger.  set_message notices and the handle takes the
+    ket-only route: both cases must follow the oracle's trajectory."""
+    g, chi = tn.named_grid((3, 3, 3), periodic=True), 4
+    psi = tn.random_tensornetworkstate(np.complex64, g, bond_dimension=chi, seed=79)
+    for v in g.vertices:
+        psi.tensors[v] = (psi.tensors[v] / np.linalg.norm(psi.tensors[v])).astype(np.complex64)
+    bpc = tn.BeliefPropagationCache(psi)
+    seq = device_default_sequence(bpc)
+    oc = o.BeliefPropagationCache(to_oracle_state(psi))
+    rng = np.random.default_rng(5)
+    for (a, b) in g.edges:
+        for e in ((a, b), (b, a)):
+            x = (rng.standard_normal((chi, chi)) + 1j * rng.standard_normal((chi, chi))) / np.sqrt(2 * chi)
+            m = x @ x.conj().T + 0.5 * np.eye(chi)                       # Hermitian, positive
+            if not hermitian:
+                m = m + 0.3 * (rng.standard_normal((chi, chi)) + 1j * rng.standard_normal((chi, chi))) / np.sqrt(2 * chi)
+            m = m.astype(np.complex64)
+            bpc.setmessage(e, m); oc.messages[e] = m.copy()
+    kw = dict(maxiter=1, tolerance=None)
+    out = bpc
+    for _sweep in range(2):
+        out = tn.update(out, **kw)
+        oc = o.update(oc, **dict(kw, edge_sequence=seq))
+        compare_messages(out, oc, 5e-5)
+
+
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_deferred_normalisation_is_invisible_to_callers(dtype):
     """normalize_tensors = true only records 1/||psi_v|| on the device (no scaling pass); every accessor that depends on

@@ -47,7 +47,7 @@ def test_lowrank_theta_route_matches_the_full_svd():
     assert on["uncapped"]["lowrank"] == 0 and on["uncapped"]["dim"] == off["uncapped"]["dim"] and on["uncapped"]["dim"] > 16
 
 
-@pytest.mark.parametrize("switch", ["TNQS_NO_CHOL", "TNQS_NO_SMALLSVD", "TNQS_JACOBI_GLOBAL", "TNQS_NO_PAIR", "TNQS_NO_MFMA", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE",
+@pytest.mark.parametrize("switch", ["TNQS_NO_CHOL", "TNQS_NO_SMALLSVD", "TNQS_JACOBI_GLOBAL", "TNQS_NO_PAIR", "TNQS_NO_MFMA", "TNQS_NO_DEFER_1SITE", "TNQS_NO_PRODCACHE", "TNQS_NO_BRA_PRODUCTS",
                                     "TNQS_NO_SPECULATION", "TNQS_NO_PRECOND_SVD", "TNQS_NO_SMALL_SITE_BP", "TNQS_NO_BF16X3"])
 def test_alternative_routes_match_the_default(switch):
     """every switch the library still has (csrc/engine_internal.hpp: one alternative route per kernel family -- round 6 deleted the A/B levers of decisions long
@@ -157,17 +157,36 @@ def test_partial_products_kept_across_levels_change_nothing_but_the_pass_count()
     tensor again (TNQS_NO_PRODCACHE=1).  The same products of the same buffers in a different order: messages to f32 rounding, same layer;
     and the remembered route must actually save two-leg passes."""
     on, off = run_worker({}, "cubic16"), run_worker({"TNQS_NO_PRODCACHE": "1"}, "cubic16")
-    assert 0 < on["pair"] < off["pair"], (on["pair"], off["pair"])
+    assert 0 < on["pair_passes"] < off["pair_passes"] - 0.5, (on["pair_passes"], off["pair_passes"])       # (two-leg passes per site: the launches of a level are batched either way)
     # a byte bound that holds three products of the 27 x 3 the sweep would keep: entries are evicted all the time (least recently used of all
     # sites), reuse mostly misses -- and nothing but the pass count may change
     tight = run_worker({"TNQS_BP_CACHE_MB": "800"}, "cubic16")
-    assert on["pair"] < tight["pair"] <= off["pair"], (on["pair"], tight["pair"], off["pair"])
+    assert on["pair_passes"] < tight["pair_passes"] <= off["pair_passes"] + 1e-9, (on["pair_passes"], tight["pair_passes"], off["pair_passes"])
     assert tight["dims"] == off["dims"] and np.max(np.abs(np.array(tight["z"]) - np.array(off["z"]))) < 1e-5
     worst = 0.0
     for ma, mb in zip(on["msgs"], off["msgs"]):
         a = np.array(ma[0]) + 1j * np.array(ma[1]); b = np.array(mb[0]) + 1j * np.array(mb[1])
         worst = max(worst, float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
-    print("remembered partial products: two-leg launches", on["pair"], "against", off["pair"], " messages", worst)
+    print("remembered partial products: two-leg passes per site", on["pair_passes"], "against", off["pair_passes"], " messages", worst)
+    assert worst < 2e-5
+    assert on["dims"] == off["dims"]
+    ea, eb = np.array(on["errs"]), np.array(off["errs"])
+    assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7)
+    assert np.max(np.abs(np.array(on["z"]) - np.array(off["z"]))) < 1e-5
+
+
+def test_bra_side_products_change_nothing_but_the_pass_count():
+    """3x3x3 torus, chi = 16: a degree-6 site absorbs half of the messages of a level on the bra side (engine_bp.cpp: for a Hermitian message that is the
+    conjugate of the same two-leg product, so the product over an axis is built once per sweep and serves as ket and as bra factor) against every message on the
+    ket side (TNQS_NO_BRA_PRODUCTS=1).  Messages are Hermitian to f32 rounding, so the two routes agree to that; the bra route must save two-leg passes."""
+    on, off = run_worker({}, "cubic16"), run_worker({"TNQS_NO_BRA_PRODUCTS": "1"}, "cubic16")
+    assert 0 < on["pair_passes"] < off["pair_passes"] - 0.5, (on["pair_passes"], off["pair_passes"])
+    assert on["pairgram"] == off["pairgram"]
+    worst = 0.0
+    for ma, mb in zip(on["msgs"], off["msgs"]):
+        a = np.array(ma[0]) + 1j * np.array(ma[1]); b = np.array(mb[0]) + 1j * np.array(mb[1])
+        worst = max(worst, float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
+    print("bra-side products: two-leg passes per site over two sweeps", on["pair_passes"], "against", off["pair_passes"], " messages", worst)
     assert worst < 2e-5
     assert on["dims"] == off["dims"]
     ea, eb = np.array(on["errs"]), np.array(off["errs"])

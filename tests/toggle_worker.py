@@ -26,7 +26,8 @@ def cubic16():
     layer = [("Rz", [v], -0.04) for v in g.vertices] + [("Rxx", [a, b], -0.08) for grp in tn.edge_color(g) for (a, b) in grp]
     b2, errs = tn.apply_gates(layer, bpc, apply_kwargs=dict(maxdim=chi, cutoff=1e-10, normalize_tensors=True), bp_update_kwargs=dict(maxiter=2, tolerance=None))
     out = dict(msgs=[[m.real.tolist(), m.imag.tolist()] for m in msgs], errs=errs.tolist(), z=[float(np.real(x)) for x in tn.expect_all(b2, "Z")],
-               dims=[b2.bond_dim(a, b) for a, b in g.edges], pairgram=prof["bp_pairgram"]["launches"], pair=prof["bp_pair"]["launches"])
+               dims=[b2.bond_dim(a, b) for a, b in g.edges], pairgram=prof["bp_pairgram"]["launches"], pair=prof["bp_pair"]["launches"],
+               pair_passes=prof["bp_pair"]["flops"] / (27 * 2 * 8.0 * 2 * chi ** 6 * chi))       # two-leg passes per site over the two sweeps (a pass = two mode products of 8 E chi flop)
     print(json.dumps(out))
 
 
