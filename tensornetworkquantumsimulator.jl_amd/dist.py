@@ -121,12 +121,12 @@ def exchange_bytes_needed(max_chi: int, d: int, n_edges: int, n_vertices: int, e
 
 
 def exchange_plan(graph, owner: Sequence[int], chi: int, colour_groups, bp_levels, d: int = 2, esz: int = 8, bp_updates_per_layer: Optional[int] = None,
-                  sweeps_per_update: int = 1) -> dict:
+                  sweeps_per_update: int = 1, bp_ws_bytes: int = 24576 << 20) -> dict:
     """what the library's exchange points of ONE colour-batched layer need, restated on the host from the engine's slot rules (csrc/engine_bp.cpp: one all-gather per
     BP level, every message a 256-byte-rounded slot in its OWNER's block; csrc/engine_gates.cpp: per colour batch the f64 Gram matrices of the sites whose gate
     STRADDLES two ranks, then one record (chi', status, truncation error, S -- and X2 for a straddling gate) per gate in the block of its first vertex's owner).
     An exchange moves `stride x nranks` bytes into every rank, stride = the largest block of any rank: the exchange buffer must hold the largest such product.
-    bp_levels: the dependency levels of one sweep as lists of (src, dst) vertex pairs (tests: tnqs_dbg_default_sequence_graph).
+    bp_levels: the dependency levels of one sweep as lists of (src, dst) vertex pairs in sequence order (tests: tnqs_dbg_default_sequence_graph).
     Returns {"max_exchange_bytes", "bytes_gathered_per_layer", "exchanges_per_layer", "by_kind"}."""
     idx = graph.index
     world = max(owner) + 1
@@ -134,10 +134,18 @@ def exchange_plan(graph, owner: Sequence[int], chi: int, colour_groups, bp_level
     n = d * chi
     kinds = {"bp_level": [], "gate_gram": [], "gate_record": []}
     for lev in bp_levels:
-        blocks = [0] * world
-        for (a, _b) in lev:
-            blocks[owner[idx[a]]] += r256(chi * chi * esz)
-        kinds["bp_level"].append(max(blocks) * world)
+        # a level is cut into sub-batches by workspace bytes (engine_bp.cpp: 2 x the source site's tensor per message, whoever owns it, against TNQS_BP_WS_MB = 24 GiB
+        # by default -- a 20 x 20 level of 760 messages x 32 MiB is cut in two), and every sub-batch is an exchange of its own
+        start = 0
+        while start < len(lev):
+            blocks, used, end = [0] * world, 0, start
+            while end < len(lev):
+                need = 2 * d * chi ** graph.degree(lev[end][0]) * esz
+                if end > start and used + need > bp_ws_bytes:
+                    break
+                used += need; blocks[owner[idx[lev[end][0]]]] += r256(chi * chi * esz); end += 1
+            kinds["bp_level"].append(max(blocks) * world)
+            start = end
     x2 = n * d * chi * esz
     for grp in colour_groups:
         gb, rb = [0] * world, [0] * world

@@ -237,7 +237,7 @@ def test_partial_product_cache_under_a_small_budget():
     """TNQS_BP_CACHE_MB=700 holds two or three of the 268 MB products of the 3x3x3 torus: entries are evicted all the time (in bulk, least recently
     used first).  Validity is by buffer identity, so an evicted product is simply recomputed: same layer as with the default budget, more two-leg passes."""
     on, small = run_worker({}, "cubic16"), run_worker({"TNQS_BP_CACHE_MB": "700"}, "cubic16")
-    assert small["pair"] > on["pair"], (small["pair"], on["pair"])
+    assert small["pair_passes"] > on["pair_passes"] + 0.2, (small["pair_passes"], on["pair_passes"])       # (two-leg passes per site: the launches of a level are batched either way)
     assert on["dims"] == small["dims"]
     ea, eb = np.array(on["errs"]), np.array(small["errs"])
     assert np.all(np.abs(ea - eb) < 2e-3 * np.maximum(ea, eb) + 2e-7)

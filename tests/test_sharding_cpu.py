@@ -126,5 +126,6 @@ def test_exchange_buffer_holds_every_exchange_of_the_8_gpu_configurations(name, 
     assert plan["max_exchange_bytes"] <= default_buf, (name, plan, default_buf)
     assert plan["max_exchange_bytes"] <= 0.6 * default_buf                                  # (and with room to spare: bond dimensions below the cap only shrink the blocks)
     if name.startswith("c2"):
-        # (the restatement is compared with the library's own counters, exactly, in tests/test_bench_launch.py::test_eight_ranks_over_gloo; the proxy figure is from another build)
+        # (the restatement is compared with the library's own counters, exactly, in tests/test_bench_launch.py::test_eight_ranks_over_gloo; the proxy balances its ranks
+        #  with its own load model -- 63 / 45 / 45 / 46 / 47 / 46 / 45 / 63 vertices -- so its blocks differ from this owner map's by a few per cent: 119.4 against 125.4 MB)
         assert plan["exchanges_per_layer"] == 18 and abs(plan["bytes_gathered_per_layer"] / 1e6 - 125.39) < 0.07 * 125.39, plan
