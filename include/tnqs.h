@@ -127,6 +127,9 @@ int tnqs_get_site_tensor(tnqs_handle h, int v, void* host, int ndim, const int32
  * a sharded and an unsharded run build the same state.  Sharded handles: a vertex owned by another rank only records the dimensions. */
 int tnqs_set_site_random(tnqs_handle h, int v, int n_neighbours, const int64_t* bond_dims, uint64_t seed, double scale);
 int tnqs_site_tensor_size(tnqs_handle h, int v, int64_t* nelem);
+/* chi x chi message src -> dst, axes (ket, bra), column major.  Every message the path itself produces is Hermitian to rounding, and tnqs_update absorbs some of them on
+ * the bra side as their own conjugate transpose (csrc/engine_bp.cpp); a message handed in here that is NOT Hermitian (1e-5 / 1e-12 of its largest entry) makes the
+ * handle (and its copies) absorb everything on the ket side, as abstractbeliefpropagationcache.jl:162-190 does. */
 int tnqs_set_message(tnqs_handle h, int src, int dst, const void* host, int chi);
 int tnqs_get_message(tnqs_handle h, int src, int dst, void* host, int chi);
 int tnqs_bond_dim(tnqs_handle h, int u, int v, int* chi);           /* dim(virtualinds) */
