@@ -6,7 +6,9 @@
 // pipe EXACT: with one power-of-two scale per column, x -> q = rint(x 2^(30 - E_c)) is a 32-bit integer, q = sum_i d_i 256^i with four signed digits d_i in
 // [-128, 127], and  sum_rows q q' = sum_ij 256^(i+j) sum_rows d_i d'_j  -- every digit product is exact in the i32 accumulator (2^14 per product, < 2^31 over 16384 rows
 // x 4 pairs).  The pairs with i + j <= 1 weigh < 2^-34 of the result and are dropped (13 of 16 products, five accumulators by i + j).  What is computed is the EXACT
-// Gram matrix of the tensor rounded to 2^(E_c - 30) per element, E_c >= log2 max |column c|: a perturbation below f32 rounding of the column's largest element.
+// Gram matrix of the tensor rounded to 2^(E_c - 30) per element, E_c >= log2 max |column c|: a perturbation below f32 rounding of the column's largest element --
+// and ONLY of entries within 2^6 of it: the rounding is absolute, f32's is relative to each entry, so columns whose entries span many decades (the tensors of a truncated
+// evolution do) are represented 2^(range - 6) times more coarsely than the f32 data they come from.  DESIGN.md 8.3 says why this stays an experiment.
 // The digits cost 5 + 2 vector instructions per value:  t = q + 0x00808080;  w = t ^ 0x00808080  -- the four bytes of w ARE the signed digits (adding 128 per lower
 // byte and flipping its top bit back is the balanced-digit conversion) -- then a 4 x 4 byte transpose (v_perm_b32) packs four rows per digit plane.
 //
