@@ -57,3 +57,23 @@ def test_compiled_port_is_not_imported_by_the_product():
     import subprocess
     code = "import sys; sys.path.insert(0, %r); import tnqs_amd; assert 'cpu_port' not in sys.modules and 'tnqs_oracle' not in sys.modules" % ROOT
     assert subprocess.run([sys.executable, "-c", code], capture_output=True).returncode == 0
+
+
+def test_cpu_budget_reads_the_cgroup_quota(tmp_path, monkeypatch):
+    """the GPU boxes show 256 hardware threads and run under cpu.max = 16 CPUs: the team is sized to the quota, not to what /proc/cpuinfo lists"""
+    import builtins
+    real_open = builtins.open
+
+    def fake(text):
+        f = tmp_path / "cpu.max"; f.write_text(text)
+
+        def _open(path, *a, **k):
+            return real_open(str(f), *a, **k) if path == "/sys/fs/cgroup/cpu.max" else real_open(path, *a, **k)
+        return _open
+    monkeypatch.setattr(cpu_port.os, "sched_getaffinity", lambda _pid: set(range(256)), raising=False)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert cpu_port.cpu_budget() == (16, 16.0)
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert cpu_port.cpu_budget() == (128, None)                     # no quota: the physical cores (SMT-2)
+    monkeypatch.setattr(builtins, "open", fake("50000 100000\n"))
+    assert cpu_port.cpu_budget()[0] == 1                            # half a CPU still runs one thread

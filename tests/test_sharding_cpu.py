@@ -129,3 +129,21 @@ def test_exchange_buffer_holds_every_exchange_of_the_8_gpu_configurations(name, 
         # (the restatement is compared with the library's own counters, exactly, in tests/test_bench_launch.py::test_eight_ranks_over_gloo; the proxy balances its ranks
         #  with its own load model -- 63 / 45 / 45 / 46 / 47 / 46 / 45 / 63 vertices -- so its blocks differ from this owner map's by a few per cent: 119.4 against 125.4 MB)
         assert plan["exchanges_per_layer"] == 18 and abs(plan["bytes_gathered_per_layer"] / 1e6 - 125.39) < 0.07 * 125.39, plan
+
+
+def test_exchange_plan_cuts_a_level_where_the_engine_does():
+    """a BP level is cut into sub-batches by workspace bytes (engine_bp.cpp: 2 x the source site's tensor per message against TNQS_BP_WS_MB), each an exchange of its own:
+    a tighter bound means more exchanges, never fewer bytes (the largest block of every piece is what travels), and no bound at all means one exchange per level."""
+    g = tn.named_grid((6, 6))
+    groups = tn.edge_color(g, 4)
+    owner = tn.partition_vertices(g.nv(), 4, tn.dist.site_weights(g, 8))
+    levels = _default_levels(g)
+    whole = tn.dist.exchange_plan(g, owner, 8, groups, levels, bp_ws_bytes=1 << 60)
+    assert whole["by_kind"]["bp_level"]["count"] == len(levels)
+    per_msg = 2 * 2 * 8 ** 4 * 8                                   # a bulk site's message: 2 x (d chi^4) elements x 8 bytes
+    tight = tn.dist.exchange_plan(g, owner, 8, groups, levels, bp_ws_bytes=3 * per_msg)
+    assert tight["by_kind"]["bp_level"]["count"] > whole["by_kind"]["bp_level"]["count"]
+    assert tight["by_kind"]["bp_level"]["sum"] >= whole["by_kind"]["bp_level"]["sum"]
+    assert tight["by_kind"]["gate_record"] == whole["by_kind"]["gate_record"] and tight["by_kind"]["gate_gram"] == whole["by_kind"]["gate_gram"]
+    one = tn.dist.exchange_plan(g, owner, 8, groups, levels, bp_ws_bytes=1)      # every message alone (the first of a piece is always taken)
+    assert one["by_kind"]["bp_level"]["count"] == sum(len(lv) for lv in levels)
