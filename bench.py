@@ -531,8 +531,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline and cfg == "c2":      # (the CPU leg restates the 2-D chi = 32 path on a bounded sample; the 8-GPU shapes have none)
             try:
                 out["cpu_baseline"] = cpu_baseline(chi, L)
-            except Exception as e:      # the baseline must never take the measured number down with it
-                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            except Exception as e:      # the baseline must never take the measured number down with it; no compiler / no OpenBLAS on the host: the threaded numpy port
+                try:
+                    import cpu_layer
+                    m = cpu_layer.measure_host(chi=chi, L=L, periodic=False)
+                    out["cpu_baseline"] = {"value": m["gates_per_s"], "unit": "two-site gates/s", "cores": int(m["threads"]), "kind": "port", "compiled": False,
+                                           "sample": f"1 TFIM layer of the {L}x{L} open lattice per process, {m['processes']} process(es) x {m['threads_per_process']} threads, chi={chi}, complex64, "
+                                                     f"threaded numpy / LAPACK port (oracle/cpu_layer.py); {m['seconds_per_layer']:.1f} s per layer", "compiled_port_error": repr(e)}
+                except Exception as e2:
+                    out["cpu_baseline"] = {"value": None, "error": repr(e), "fallback_error": repr(e2)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
