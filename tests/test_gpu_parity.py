@@ -444,6 +444,32 @@ def test_default_order_on_periodic_lattices_matches_oracle(lattice):
         assert abs(tn.expect(out, ("Z", [v])) - o.expect_1site(oc, Z, v)) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [np.complex128, np.float64, np.float32])
+def test_degree6_bra_side_products_in_the_other_element_types(dtype):
+    """the bra-side route (engine_bp.cpp) on ComplexF64 and real handles: Hermitian = symmetric for a real state.  Caller-supplied positive messages, two sweeps of the
+    library's default order on the 3x3x3 torus against the oracle replaying the same order."""
+    g, chi = tn.named_grid((3, 3, 3), periodic=True), 3
+    psi = tn.random_tensornetworkstate(dtype, g, bond_dimension=chi, seed=83)
+    for v in g.vertices:
+        psi.tensors[v] = (psi.tensors[v] / np.linalg.norm(psi.tensors[v])).astype(dtype)
+    bpc = tn.BeliefPropagationCache(psi)
+    seq = device_default_sequence(bpc)
+    oc = o.BeliefPropagationCache(to_oracle_state(psi))
+    rng = np.random.default_rng(6)
+    cplx = np.issubdtype(np.dtype(dtype), np.complexfloating)
+    for (a, b) in g.edges:
+        for e in ((a, b), (b, a)):
+            x = rng.standard_normal((chi, chi)) + (1j * rng.standard_normal((chi, chi)) if cplx else 0.0)
+            m = (x @ x.conj().T / chi + 0.5 * np.eye(chi)).astype(dtype)
+            bpc.setmessage(e, m); oc.messages[e] = m.copy()
+    kw = dict(maxiter=1, tolerance=None)
+    out = bpc
+    for _sweep in range(2):
+        out = tn.update(out, **kw)
+        oc = o.update(oc, **dict(kw, edge_sequence=seq))
+        compare_messages(out, oc, 5e-5 if np.dtype(dtype) == np.dtype(np.float32) else 1e-10)
+
+
 @pytest.mark.parametrize("hermitian", [True, False])
 def test_degree6_sweeps_from_caller_supplied_messages_match_oracle(hermitian):
     """3x3x3 torus (degree 6): BP sweeps started from messages the CALLER sets.  Hermitian ones (what the path itself produces) may be absorbed on the bra side
